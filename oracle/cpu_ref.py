@@ -1,0 +1,228 @@
+"""CPU restatement of the ClimateGAN generator/discriminator hot path (TEST INFRASTRUCTURE).
+
+Own code, functional style, keyed on the reference's state-dict layout; every function cites the reference
+file:line it follows (paths relative to the reference repo root).  Runs in torch fp32 (default) or fp64 on
+the host.  Used as (a) the parity checker for the HIP path in ``tests/`` and ``__graft_entry__.smoke()``
+and (b) the reported ``cpu_baseline`` in ``bench.py`` -- never on the product path.
+
+Pinned by: tests/test_oracle_golden.py (committed vectors produced by the real reference) and
+tests/test_oracle_vs_reference.py (direct comparison with the imported reference, dev container only).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+def sub(sd: SD, prefix: str) -> SD:
+    """Sub-state-dict with ``prefix`` stripped."""
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+
+
+# --------------------------------------------------------------------------------------------------
+# norms.py
+# --------------------------------------------------------------------------------------------------
+def l2normalize(v: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """climategan/norms.py:80-81"""
+    return v / (v.norm() + eps)
+
+
+def spectral_norm_step(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tensor, power_iterations: int = 1):
+    """One ``SpectralNorm._update_u_v`` (climategan/norms.py:100-112).
+
+    Returns (w, u_new, v_new, sigma).  Runs on EVERY forward in the reference, eval included
+    (norms.py:141-143); callers must write u_new/v_new back into the state.
+    """
+    h = w_bar.shape[0]
+    wm = w_bar.reshape(h, -1)
+    for _ in range(power_iterations):
+        v = l2normalize(torch.mv(wm.t(), u))
+        u = l2normalize(torch.mv(wm, v))
+    sigma = u.dot(wm.mv(v))
+    return w_bar / sigma, u, v, sigma
+
+
+def sn_conv2d(x, sd: SD, prefix: str, stride=1, padding=0, dilation=1, update: bool = True):
+    """``SpectralNorm(nn.Conv2d).forward`` (norms.py:141-143): power-iterate, then convolve with w_bar/sigma.
+
+    Mutates ``sd[prefix.module.weight_u/_v]`` in place when ``update`` (as the reference does).
+    """
+    wb = sd[prefix + ".module.weight_bar"]
+    u = sd[prefix + ".module.weight_u"]
+    v = sd[prefix + ".module.weight_v"]
+    w, u2, v2, _ = spectral_norm_step(wb, u, v)
+    if update:
+        sd[prefix + ".module.weight_u"] = u2
+        sd[prefix + ".module.weight_v"] = v2
+    b = sd.get(prefix + ".module.bias")
+    return F.conv2d(x, w, b, stride=stride, padding=padding, dilation=dilation)
+
+
+def instance_norm(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False): biased var over H*W (norms.py:151)."""
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = x.var(dim=(2, 3), unbiased=False, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def batch_norm_param_free(x: torch.Tensor, running_mean=None, running_var=None, training=True, eps=1e-5):
+    """nn.BatchNorm2d(affine=False) (norms.py:155): batch stats in train, running stats in eval."""
+    if training or running_mean is None:
+        mean = x.mean(dim=(0, 2, 3), keepdim=True)
+        var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    else:
+        mean = running_mean.view(1, -1, 1, 1)
+        var = running_var.view(1, -1, 1, 1)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def nearest_resize(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """F.interpolate(mode='nearest') legacy rule src = floor(dst * in / out) (norms.py:179, painter.py:152)."""
+    n, c, h, w = x.shape
+    oh, ow = size
+    if (oh, ow) == (h, w):
+        return x
+    iy = torch.floor(torch.arange(oh, dtype=torch.float64) * (h / oh)).long().clamp_(max=h - 1)
+    ix = torch.floor(torch.arange(ow, dtype=torch.float64) * (w / ow)).long().clamp_(max=w - 1)
+    return x[:, :, iy][:, :, :, ix]
+
+
+def spade(x: torch.Tensor, segmap: torch.Tensor, sd: SD, prefix: str, norm_type: str = "instance",
+          training: bool = True) -> torch.Tensor:
+    """``SPADE.forward`` (climategan/norms.py:174-186); hidden width 128 (norms.py:163)."""
+    if norm_type == "instance":
+        normalized = instance_norm(x)
+    elif norm_type == "batch":
+        normalized = batch_norm_param_free(
+            x, sd.get(prefix + ".param_free_norm.running_mean"), sd.get(prefix + ".param_free_norm.running_var"),
+            training)
+    else:
+        raise ValueError("%s is not a recognized param-free norm type in SPADE" % norm_type)
+    seg = nearest_resize(segmap, x.shape[2:])
+    w0, b0 = sd[prefix + ".mlp_shared.0.weight"], sd[prefix + ".mlp_shared.0.bias"]
+    pw = w0.shape[-1] // 2
+    actv = F.relu(F.conv2d(seg, w0, b0, padding=pw))
+    gamma = F.conv2d(actv, sd[prefix + ".mlp_gamma.weight"], sd[prefix + ".mlp_gamma.bias"], padding=pw)
+    beta = F.conv2d(actv, sd[prefix + ".mlp_beta.weight"], sd[prefix + ".mlp_beta.bias"], padding=pw)
+    return normalized * (1 + gamma) + beta
+
+
+def _conv_maybe_sn(x, sd: SD, prefix: str, padding: int, update: bool):
+    if prefix + ".module.weight_bar" in sd:
+        return sn_conv2d(x, sd, prefix, padding=padding, update=update)
+    return F.conv2d(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"), padding=padding)
+
+
+def spade_resnet_block(x, seg, sd: SD, prefix: str, norm_type="instance", last_activation=None,
+                       training=True, update=True):
+    """``SPADEResnetBlock.forward`` (climategan/blocks.py:369-395).
+
+    Order of spectral-norm updates follows the reference: shortcut (conv_s) first, then conv_0, conv_1.
+    """
+    learned_shortcut = (prefix + ".conv_s.module.weight_bar" in sd) or (prefix + ".conv_s.weight" in sd)
+    if learned_shortcut:
+        x_s = _conv_maybe_sn(spade(x, seg, sd, prefix + ".norm_s", norm_type, training), sd, prefix + ".conv_s",
+                             0, update)
+    else:
+        x_s = x
+    dx = _conv_maybe_sn(F.leaky_relu(spade(x, seg, sd, prefix + ".norm_0", norm_type, training), 0.2), sd,
+                        prefix + ".conv_0", 1, update)
+    dx = _conv_maybe_sn(F.leaky_relu(spade(dx, seg, sd, prefix + ".norm_1", norm_type, training), 0.2), sd,
+                        prefix + ".conv_1", 1, update)
+    out = x_s + dx
+    if last_activation == "lrelu":
+        return F.leaky_relu(out, 0.2)
+    if last_activation is None:
+        return out
+    raise NotImplementedError("The type of activation is not supported: {}".format(last_activation))
+
+
+# --------------------------------------------------------------------------------------------------
+# painter.py / generator.py (paint)
+# --------------------------------------------------------------------------------------------------
+def painter_blocks(sd: SD) -> List[str]:
+    n_up = len({k.split(".")[1] for k in sd if k.startswith("up_spades.")})
+    return ["head_0", "G_middle_0", "G_middle_1"] + ["up_spades.%d" % i for i in range(n_up)] + ["final_spade"]
+
+
+def painter_forward(sd: SD, cond: torch.Tensor, z_h: int, z_w: int, z: Optional[torch.Tensor] = None,
+                    update: bool = True) -> torch.Tensor:
+    """``PainterSpadeDecoder.forward`` (climategan/painter.py:149-168), use_final_shortcut=False.
+
+    ``sd`` is the painter state dict (keys as in the reference, no ``painter.`` prefix).  Spectral-norm
+    u/v entries are updated in place (one power iteration per wrapped conv, reference norms.py:100-112).
+    """
+    if z is None:
+        z = F.conv2d(nearest_resize(cond, (z_h, z_w)), sd["fc.weight"], sd["fc.bias"], padding=1)
+    up = lambda t: nearest_resize(t, (t.shape[-2] * 2, t.shape[-1] * 2))  # blocks.py:28-43
+    y = spade_resnet_block(z, cond, sd, "head_0", update=update)
+    y = up(y)
+    y = spade_resnet_block(y, cond, sd, "G_middle_0", update=update)
+    y = up(y)
+    y = spade_resnet_block(y, cond, sd, "G_middle_1", update=update)
+    n_up = len({k.split(".")[1] for k in sd if k.startswith("up_spades.")})
+    for i in range(n_up):
+        y = up(y)
+        y = spade_resnet_block(y, cond, sd, "up_spades.%d" % i, update=update)
+    y = spade_resnet_block(y, cond, sd, "final_spade", update=update)
+    y = F.conv2d(F.leaky_relu(y, 0.2), sd["conv_img.weight"], sd["conv_img.bias"], padding=1)
+    return torch.tanh(y)
+
+
+def paint(sd: SD, m: torch.Tensor, x: torch.Tensor, z_h: int, z_w: int, no_paste: bool = False,
+          paste_original_content: bool = True, update: bool = True) -> torch.Tensor:
+    """``OmniGenerator.paint`` (climategan/generator.py:279-297) with ``no_z: true`` (z=None)."""
+    m = m.to(x.dtype)
+    fake = painter_forward(sd, x * (1.0 - m), z_h, z_w, update=update)
+    if paste_original_content and not no_paste:
+        return x * (1.0 - m) + fake * m
+    return fake
+
+
+# --------------------------------------------------------------------------------------------------
+# discriminator.py
+# --------------------------------------------------------------------------------------------------
+def nlayer_discriminator(x, sd: SD, prefix: str, n_layers: int = 4, update=True) -> List[torch.Tensor]:
+    """``NLayerDiscriminator.forward`` (climategan/discriminator.py:172-182) with instance norm,
+    get_intermediate_features=True: returns n_layers+2 tensors."""
+    p = prefix + "." if prefix else ""
+    outs = []
+    # model0: SN conv 4x4 s2 + LeakyReLU (discriminator.py:100-109)
+    y = F.leaky_relu(sn_conv2d(x, sd, p + "model0.0", stride=2, padding=1, update=update), 0.2)
+    outs.append(y)
+    for n in range(1, n_layers):  # discriminator.py:113-134
+        y = sn_conv2d(y, sd, p + "model%d.0" % n, stride=2, padding=1, update=update)
+        y = F.leaky_relu(instance_norm(y), 0.2)
+        outs.append(y)
+    y = sn_conv2d(y, sd, p + "model%d.0" % n_layers, stride=1, padding=1, update=update)  # :138-154
+    y = F.leaky_relu(instance_norm(y), 0.2)
+    outs.append(y)
+    y = sn_conv2d(y, sd, p + "model%d.0" % (n_layers + 1), stride=1, padding=1, update=update)  # :157-163
+    outs.append(y)
+    return outs
+
+
+def multiscale_discriminator(x, sd: SD, num_D: int = 3, n_layers: int = 4, update=True):
+    """``MultiscaleDiscriminator.forward`` (climategan/discriminator.py:227-239)."""
+    result = []
+    for i in range(num_D):
+        result.append(nlayer_discriminator(x, sd, "discriminator_%d" % i, n_layers, update))
+        x = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)  # :223-225
+    return result
+
+
+def fc_discriminator(x, sd: SD, prefix: str = "", update=True):
+    """``get_fc_discriminator(use_norm=True)`` (climategan/discriminator.py:327-349)."""
+    p = prefix + "." if prefix else ""
+    for i, idx in enumerate((0, 2, 4, 6, 8)):
+        key = p + str(idx)
+        if key + ".module.weight_bar" in sd:
+            x = sn_conv2d(x, sd, key, stride=2, padding=1, update=update)
+        else:
+            x = F.conv2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1)
+        if i < 4:
+            x = F.leaky_relu(x, 0.2)
+    return x

@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz by running the REAL reference (dev container only; TEST INFRASTRUCTURE).
+
+    python -m oracle.make_golden            # from the repo root, needs /root/reference
+
+Inputs and weights come from the portable fill (climategan_amd/fill.py) so fixtures only hold the
+reference's OUTPUTS (and post-forward spectral-norm u/v state).  The committed fixtures are data, not
+reference source.  ``golden_cases()`` is shared with the tests so both sides build identical inputs.
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from climategan_amd import fill
+
+GOLDEN_DIR = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+# ------------------------------------------------------------------ case table (shared with tests)
+def golden_cases():
+    return {
+        "spade_c20": dict(kind="spade", C=20, cond_nc=3, H=12, W=16, cond_hw=(48, 64), B=2, seed=11),
+        "spade_c40": dict(kind="spade", C=40, cond_nc=3, H=8, W=8, cond_hw=(64, 64), B=1, seed=12),
+        "resblk_16_8": dict(kind="resblk", fin=16, fout=8, H=10, W=12, cond_hw=(40, 48), B=2, seed=21),
+        "resblk_8_8": dict(kind="resblk", fin=8, fout=8, H=10, W=12, cond_hw=(40, 48), B=2, seed=22),
+        "painter_up4": dict(kind="painter", latent_dim=32, n_up=4, H=64, W=96, B=2, seed=31, full=True),
+        "painter_up7": dict(kind="painter", latent_dim=64, n_up=7, H=256, W=384, B=1, seed=32, full=False),
+        "painter_640": dict(kind="painter", latent_dim=640, n_up=7, H=640, W=640, B=1, seed=33, full=False),
+        "paint_up4": dict(kind="paint", latent_dim=32, n_up=4, H=64, W=96, B=2, seed=34, full=True),
+        "disc_p": dict(kind="disc_p", ndf=8, n_layers=3, num_D=3, H=96, W=128, B=2, seed=41),
+        "disc_fc": dict(kind="disc_fc", num_classes=11, H=64, W=96, B=2, seed=42),
+    }
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def case_inputs(name, case):
+    """Seeded inputs for a case (numpy fp32)."""
+    s = case["seed"]
+    B = case["B"]
+    k = case["kind"]
+    if k == "spade":
+        return dict(x=fill.uniform((B, case["C"], case["H"], case["W"]), s * 100 + 1, -2, 2),
+                    seg=fill.uniform((B, case["cond_nc"]) + tuple(case["cond_hw"]), s * 100 + 2))
+    if k == "resblk":
+        return dict(x=fill.uniform((B, case["fin"], case["H"], case["W"]), s * 100 + 1, -2, 2),
+                    seg=fill.uniform((B, 3) + tuple(case["cond_hw"]), s * 100 + 2))
+    if k == "painter":
+        return dict(cond=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1))
+    if k == "paint":
+        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
+                    m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 2))
+    if k == "disc_p":
+        return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
+    if k == "disc_fc":
+        return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    raise KeyError(k)
+
+
+def summarize(y: np.ndarray) -> dict:
+    """Compact statistics of a [B,C,H,W] output too large to commit in full."""
+    yt = t(y).double()
+    pooled = torch.nn.functional.avg_pool2d(yt, 8).float().numpy()
+    h, w = y.shape[-2:]
+    return dict(
+        mean=yt.mean(dim=(2, 3)).float().numpy(),
+        std=yt.std(dim=(2, 3), unbiased=False).float().numpy(),
+        pooled8=pooled,
+        crop_tl=y[..., :32, :32].copy(),
+        crop_c=y[..., h // 2 - 16:h // 2 + 16, w // 2 - 16:w // 2 + 16].copy(),
+        crop_br=y[..., -32:, -32:].copy(),
+    )
+
+
+# ------------------------------------------------------------------ reference builders
+def _painter_opts(case):
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.gen.p.latent_dim = case["latent_dim"]
+    opts.gen.p.spade_n_up = case["n_up"]
+    return opts
+
+
+def build_reference_module(case):
+    """Instantiate the reference module for a case, loaded with the portable fill.  Returns (module, sd_np)."""
+    from oracle import ref_shim
+
+    k = case["kind"]
+    if k == "spade":
+        mod = ref_shim.ref("norms").SPADE("instance", 3, case["C"], case["cond_nc"])
+    elif k == "resblk":
+        mod = ref_shim.ref("blocks").SPADEResnetBlock(case["fin"], case["fout"], 3, True, "instance", 3)
+    elif k in ("painter", "paint"):
+        mod = ref_shim.ref("painter").PainterSpadeDecoder(_painter_opts(case))
+    elif k == "disc_p":
+        mod = ref_shim.ref("discriminator").define_D(
+            input_nc=4, ndf=case["ndf"], n_layers=case["n_layers"], norm="instance", use_sigmoid=False,
+            get_intermediate_features=True, num_D=case["num_D"])
+    elif k == "disc_fc":
+        mod = ref_shim.ref("discriminator").get_fc_discriminator(num_classes=case["num_classes"], use_norm=True)
+    else:
+        raise KeyError(k)
+    shapes = {key: tuple(v.shape) for key, v in mod.state_dict().items()}
+    sd_np = fill.fill_state_dict(shapes, case["seed"])
+    mod.load_state_dict({key: t(v) for key, v in sd_np.items()})
+    mod.eval()
+    return mod, sd_np
+
+
+def run_reference(name, case):
+    """Run the real reference on the seeded inputs; returns dict of numpy outputs."""
+    from oracle import ref_shim
+
+    mod, _ = build_reference_module(case)
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    out = {}
+    k = case["kind"]
+    with torch.no_grad():
+        if k in ("spade", "resblk"):
+            out["y"] = mod(inp["x"], inp["seg"]).numpy()
+        elif k == "painter":
+            mod.set_latent_shape(tuple(inp["cond"].shape), True)
+            y = mod(None, inp["cond"]).numpy()
+            if case["full"]:
+                out["y"] = y
+            else:
+                out.update({"y_" + a: b for a, b in summarize(y).items()})
+        elif k == "paint":
+            # OmniGenerator.paint (generator.py:279-297) around the reference painter, no_z / paste defaults.
+            gen = ref_shim.ref("generator")
+            G = gen.OmniGenerator.__new__(gen.OmniGenerator)
+            torch.nn.Module.__init__(G)
+            G.opts = _painter_opts(case)
+            G.painter = mod
+            mod.set_latent_shape(tuple(inp["x"].shape), True)
+            out["y"] = G.paint(inp["m"], inp["x"]).numpy()
+        elif k == "disc_p":
+            res = mod(inp["x"])
+            for i, scale in enumerate(res):
+                for j, f in enumerate(scale):
+                    out["d%d_%d" % (i, j)] = f.numpy()
+        elif k == "disc_fc":
+            out["y"] = mod(inp["x"]).numpy()
+    # post-forward spectral-norm state (the reference mutates u/v on every forward, norms.py:100-112)
+    for key, v in mod.state_dict().items():
+        if key.endswith("weight_u"):
+            out["post." + key] = v.numpy().copy()
+    return out
+
+
+def main():
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        sys.exit("make_golden needs /root/reference (dev container only)")
+    GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+    manifest = {}
+    for name, case in golden_cases().items():
+        out = run_reference(name, case)
+        path = GOLDEN_DIR / (name + ".npz")
+        np.savez_compressed(path, **out)
+        manifest[name] = dict(case=case, keys=sorted(out), bytes=path.stat().st_size)
+        print("%-14s %8d B  %s" % (name, path.stat().st_size, ", ".join(sorted(out)[:6])))
+    (GOLDEN_DIR / "manifest.json").write_text(json.dumps(manifest, indent=1, default=list))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+"""Shared helpers for the tests: run the oracle (oracle.cpu_ref) on a golden case."""
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from climategan_amd import fill
+from oracle import cpu_ref
+from oracle.make_golden import case_inputs, golden_cases, summarize
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def module_shapes(case):
+    """State-dict shapes of the reference module for a case, restated (no reference import)."""
+    k = case["kind"]
+    if k == "spade":
+        return spade_shapes("", case["C"], case["cond_nc"])
+    if k == "resblk":
+        return resblk_shapes("", case["fin"], case["fout"], 3)
+    if k in ("painter", "paint"):
+        return painter_shapes(case["latent_dim"], case["n_up"])
+    if k == "disc_p":
+        return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
+    if k == "disc_fc":
+        return disc_fc_shapes(case["num_classes"])
+    raise KeyError(k)
+
+
+def _p(prefix, k):
+    return (prefix + "." + k) if prefix else k
+
+
+def spade_shapes(prefix, C, cond_nc, nhidden=128, ks=3):
+    return {
+        _p(prefix, "mlp_shared.0.weight"): (nhidden, cond_nc, ks, ks),
+        _p(prefix, "mlp_shared.0.bias"): (nhidden,),
+        _p(prefix, "mlp_gamma.weight"): (C, nhidden, ks, ks),
+        _p(prefix, "mlp_gamma.bias"): (C,),
+        _p(prefix, "mlp_beta.weight"): (C, nhidden, ks, ks),
+        _p(prefix, "mlp_beta.bias"): (C,),
+    }
+
+
+def sn_conv_shapes(prefix, cin, cout, k, bias=True):
+    d = {}
+    if bias:
+        d[_p(prefix, "module.bias")] = (cout,)
+    d[_p(prefix, "module.weight_u")] = (cout,)
+    d[_p(prefix, "module.weight_v")] = (cin * k * k,)
+    d[_p(prefix, "module.weight_bar")] = (cout, cin, k, k)
+    return d
+
+
+def resblk_shapes(prefix, fin, fout, cond_nc):
+    fmid = min(fin, fout)
+    d = {}
+    d.update(sn_conv_shapes(_p(prefix, "conv_0"), fin, fmid, 3))
+    d.update(sn_conv_shapes(_p(prefix, "conv_1"), fmid, fout, 3))
+    if fin != fout:
+        d.update(sn_conv_shapes(_p(prefix, "conv_s"), fin, fout, 1, bias=False))
+    d.update(spade_shapes(_p(prefix, "norm_0"), fin, cond_nc))
+    d.update(spade_shapes(_p(prefix, "norm_1"), fmid, cond_nc))
+    if fin != fout:
+        d.update(spade_shapes(_p(prefix, "norm_s"), fin, cond_nc))
+    return d
+
+
+def painter_shapes(latent_dim, n_up):
+    d = {"fc.weight": (latent_dim, 3, 3, 3), "fc.bias": (latent_dim,)}
+    for b in ("head_0", "G_middle_0", "G_middle_1"):
+        d.update(resblk_shapes(b, latent_dim, latent_dim, 3))
+    for i in range(n_up - 2):
+        d.update(resblk_shapes("up_spades.%d" % i, latent_dim // 2 ** i, latent_dim // 2 ** (i + 1), 3))
+    fnc = latent_dim // 2 ** (n_up - 2)
+    d.update(resblk_shapes("final_spade", fnc, fnc, 3))
+    d["conv_img.weight"] = (3, fnc, 3, 3)
+    d["conv_img.bias"] = (3,)
+    return d
+
+
+def disc_p_shapes(input_nc, ndf, n_layers, num_D):
+    d = {}
+    for i in range(num_D):
+        pre = "discriminator_%d" % i
+        d.update(sn_conv_shapes(pre + ".model0.0", input_nc, ndf, 4))
+        nf = 1
+        for n in range(1, n_layers):
+            nfp, nf = nf, min(2 ** n, 8)
+            d.update(sn_conv_shapes(pre + ".model%d.0" % n, ndf * nfp, ndf * nf, 4))
+        nfp, nf = nf, min(2 ** n_layers, 8)
+        d.update(sn_conv_shapes(pre + ".model%d.0" % n_layers, ndf * nfp, ndf * nf, 4))
+        d.update(sn_conv_shapes(pre + ".model%d.0" % (n_layers + 1), ndf * nf, 1, 4))
+    return d
+
+
+def disc_fc_shapes(num_classes, ndf=64):
+    chans = [num_classes, ndf, ndf * 2, ndf * 4, ndf * 8, 1]
+    d = {}
+    for i, idx in enumerate((0, 2, 4, 6, 8)):
+        d.update(sn_conv_shapes(str(idx), chans[i], chans[i + 1], 4))
+    return d
+
+
+def case_state_dict(case, dtype=torch.float32):
+    sd = fill.fill_state_dict(module_shapes(case), case["seed"])
+    return {k: t(v).to(dtype) if v.dtype != np.int64 else t(v) for k, v in sd.items()}
+
+
+def run_oracle(name, case, dtype=torch.float32):
+    """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
+    sd = case_state_dict(case, dtype)
+    inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
+    out = {}
+    k = case["kind"]
+    with torch.no_grad():
+        if k == "spade":
+            out["y"] = cpu_ref.spade(inp["x"], inp["seg"], {"s." + a: b for a, b in sd.items()}, "s").numpy()
+        elif k == "resblk":
+            sd = {"b." + a: b for a, b in sd.items()}
+            out["y"] = cpu_ref.spade_resnet_block(inp["x"], inp["seg"], sd, "b").numpy()
+            sd = {a[2:]: b for a, b in sd.items()}
+        elif k == "painter":
+            H, W = case["H"], case["W"]
+            y = cpu_ref.painter_forward(sd, inp["cond"], H // 2 ** case["n_up"], W // 2 ** case["n_up"]).numpy()
+            if case["full"]:
+                out["y"] = y
+            else:
+                out.update({"y_" + a: b for a, b in summarize(y).items()})
+        elif k == "paint":
+            H, W = case["H"], case["W"]
+            out["y"] = cpu_ref.paint(sd, inp["m"], inp["x"], H // 2 ** case["n_up"], W // 2 ** case["n_up"]).numpy()
+        elif k == "disc_p":
+            res = cpu_ref.multiscale_discriminator(inp["x"], sd, case["num_D"], case["n_layers"])
+            for i, scale in enumerate(res):
+                for j, f in enumerate(scale):
+                    out["d%d_%d" % (i, j)] = f.numpy()
+        elif k == "disc_fc":
+            out["y"] = cpu_ref.fc_discriminator(inp["x"], sd).numpy()
+    for key, v in sd.items():
+        if key.endswith("weight_u"):
+            out["post." + key] = v.numpy().copy()
+    return out
+
+
+def load_golden(name):
+    with np.load(GOLDEN / (name + ".npz")) as z:
+        return {k: z[k] for k in z.files}

@@ -1,0 +1,31 @@
+"""Pin the oracle (oracle.cpu_ref) against the committed golden vectors produced by the REAL reference
+(oracle/make_golden.py).  CPU-only; runs everywhere (the GPU box has no /root/reference)."""
+import numpy as np
+import pytest
+
+from helpers import golden_cases, load_golden, run_oracle
+
+CASES = golden_cases()
+# fp32 CPU conv kernels (oneDNN) may pick different blocking for the functional vs module call: 1e-5 abs.
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n != "painter_640"])
+def test_oracle_matches_golden(name):
+    gold = load_golden(name)
+    got = run_oracle(name, CASES[name])
+    assert sorted(gold) == sorted(got)
+    for k in gold:
+        assert gold[k].shape == got[k].shape, k
+        err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
+        assert err <= TOL, "%s/%s: max abs err %.3g" % (name, k, err)
+
+
+def test_oracle_matches_golden_painter_640():
+    """Full-size default Painter (latent 640, spade_n_up 7, 640x640): statistics/crops/pooled map."""
+    name = "painter_640"
+    gold = load_golden(name)
+    got = run_oracle(name, CASES[name])
+    for k in gold:
+        err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
+        assert err <= 5e-5, "%s/%s: max abs err %.3g" % (name, k, err)
