@@ -1,0 +1,285 @@
+"""bench.py -- throughput of the ClimateGAN hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the single-GPU configuration the metric is quoted on):
+  Painter-only SPADE generator forward, 640x640, batch 8 per GPU, bf16 activations / fp32 accumulate,
+  synthetic mask + context: one step = ``OmniGenerator.paint(m, x)`` (mask the image, run the 9-block SPADE
+  Painter incl. the per-forward spectral-norm power iterations, paste) with inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+N > 1: the path shards by image with no data-path collective (inference): every rank runs the same
+per-GPU batch (weak scaling); timing is barrier + synchronize on both sides, max over ranks.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fused SPADE, MFMA-bound) -- algorithmic FLOPs of the SPADE layers /
+                 their summed duration, timed with events on the launch stream inside the timed region
+  cpu_baseline : the oracle's CPU restatement (oracle.cpu_ref, torch fp32 on the host cores) on a bounded
+                 sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+BATCH_PER_GPU = 8
+H = W = 640
+LATENT = 640
+N_UP = 7
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md chip table
+
+
+def painter_shapes(latent_dim, n_up):
+    """State-dict layout of the reference PainterSpadeDecoder (painter.py:36-113), keys -> shapes."""
+    def spade(prefix, c):
+        return {prefix + ".mlp_shared.0.weight": (128, 3, 3, 3), prefix + ".mlp_shared.0.bias": (128,),
+                prefix + ".mlp_gamma.weight": (c, 128, 3, 3), prefix + ".mlp_gamma.bias": (c,),
+                prefix + ".mlp_beta.weight": (c, 128, 3, 3), prefix + ".mlp_beta.bias": (c,)}
+
+    def sn(prefix, cin, cout, k, bias=True):
+        d = {prefix + ".module.weight_u": (cout,), prefix + ".module.weight_v": (cin * k * k,),
+             prefix + ".module.weight_bar": (cout, cin, k, k)}
+        if bias:
+            d[prefix + ".module.bias"] = (cout,)
+        return d
+
+    def blk(prefix, fin, fout):
+        fmid = min(fin, fout)
+        d = {}
+        d.update(sn(prefix + ".conv_0", fin, fmid, 3))
+        d.update(sn(prefix + ".conv_1", fmid, fout, 3))
+        d.update(spade(prefix + ".norm_0", fin))
+        d.update(spade(prefix + ".norm_1", fmid))
+        if fin != fout:
+            d.update(sn(prefix + ".conv_s", fin, fout, 1, bias=False))
+            d.update(spade(prefix + ".norm_s", fin))
+        return d
+
+    d = {"fc.weight": (latent_dim, 3, 3, 3), "fc.bias": (latent_dim,)}
+    for b in ("head_0", "G_middle_0", "G_middle_1"):
+        d.update(blk(b, latent_dim, latent_dim))
+    for i in range(n_up - 2):
+        d.update(blk("up_spades.%d" % i, latent_dim // 2 ** i, latent_dim // 2 ** (i + 1)))
+    fnc = latent_dim // 2 ** (n_up - 2)
+    d.update(blk("final_spade", fnc, fnc))
+    d["conv_img.weight"] = (3, fnc, 3, 3)
+    d["conv_img.bias"] = (3,)
+    return d
+
+
+def spade_layer_table(latent_dim, n_up, h, w):
+    """(C, H, W) of every SPADE layer of the Painter -> algorithmic FLOPs (2*MAC of its three 3x3 convs:
+    3->128 shared, 128->C gamma, 128->C beta; reference norms.py:163-172), per image."""
+    z_h, z_w = h // 2 ** n_up, w // 2 ** n_up
+    layers = []
+    res = [(z_h, z_w), (2 * z_h, 2 * z_w), (4 * z_h, 4 * z_w)]
+    for r in res:
+        layers += [(latent_dim, r), (latent_dim, r)]
+    hh, ww = res[-1]
+    for i in range(n_up - 2):
+        hh, ww = 2 * hh, 2 * ww
+        fin, fout = latent_dim // 2 ** i, latent_dim // 2 ** (i + 1)
+        layers += [(fin, (hh, ww)), (fin, (hh, ww)), (fout, (hh, ww))]
+    fnc = latent_dim // 2 ** (n_up - 2)
+    layers += [(fnc, (hh, ww)), (fnc, (hh, ww))]
+    flops = 0
+    for c, (a, b) in layers:
+        flops += a * b * 2 * (3 * 9 * 128 + 2 * 128 * 9 * c)
+    return layers, flops
+
+
+def build(device, dtype):
+    from climategan_amd import fill
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+
+    opts = default_opts()
+    opts.tasks = ["p"]
+    opts.gen.p.latent_dim = LATENT
+    opts.gen.p.spade_n_up = N_UP
+    G = create_generator(opts, device=device)
+    sd = {k: torch.from_numpy(v) for k, v in fill.fill_state_dict(painter_shapes(LATENT, N_UP), seed=0).items()}
+    G.painter.load_state_dict(sd)
+    G.set_compute_dtype(dtype)
+    G.painter.set_latent_shape((BATCH_PER_GPU, 3, H, W), True)
+    return G, sd
+
+
+def synthetic_batch(rank, device):
+    from climategan_amd import fill
+
+    x = torch.from_numpy(fill.uniform((BATCH_PER_GPU, 3, H, W), seed=1000 + rank)).to(device)
+    m = torch.from_numpy(fill.rect_mask(BATCH_PER_GPU, H, W, seed=2000 + rank)).to(device)
+    return x, m
+
+
+class SpadeTimer:
+    """Event pairs around every fused-SPADE launch (recorded on the stream the kernel is launched on)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def install(self):
+        from climategan_amd import ops
+
+        orig = ops.spade_fused
+        timer = self
+
+        def timed(*a, **k):
+            if not timer.enabled:
+                return orig(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **k)
+            e1.record()
+            timer.pairs.append((e0, e1))
+            return out
+
+        ops.spade_fused = timed
+        import climategan_amd.norms as norms_mod
+
+        norms_mod.ops.spade_fused = timed
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs)
+
+
+def cpu_baseline(sd):
+    """Oracle (CPU restatement of the reference path, torch fp32) on a bounded sample: bs=1, 640x640."""
+    from climategan_amd import fill
+    from oracle import cpu_ref
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    x = torch.from_numpy(fill.uniform((1, 3, H, W), seed=1))
+    m = torch.from_numpy(fill.rect_mask(1, H, W, seed=2))
+    sdc = {k: v.clone() for k, v in sd.items()}
+    z = H // 2 ** N_UP
+    with torch.no_grad():
+        cpu_ref.paint(sdc, m, x, z, z)  # warm-up
+        runs = 3
+        t0 = time.perf_counter()
+        for _ in range(runs):
+            cpu_ref.paint(sdc, m, x, z, z)
+        dt = time.perf_counter() - t0
+    return {"value": round(runs / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "oracle.cpu_ref.paint (torch fp32 CPU restatement of generator.py:279-297), bs=1 640x640, "
+                      "%d runs after 1 warm-up, %d threads" % (runs, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                 % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    G, sd = build(device, dtype)
+    x, m = synthetic_batch(rank, device)
+    timer = SpadeTimer()
+    timer.install()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            G.paint(m, x)
+        barrier()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = G.paint(m, x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+    assert out.shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(out).all()
+
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+
+    if rank == 0:
+        layers, flops_img = spade_layer_table(LATENT, N_UP, H, W)
+        spade_ms = timer.total_ms()
+        n_launch = len(timer.pairs)
+        flops_step = flops_img * BATCH_PER_GPU
+        achieved = flops_step * args.steps / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0
+        res = {
+            "metric": "640x640 images/sec, Painter (SPADE generator) forward, batch 8 per GPU",
+            "value": round(world * BATCH_PER_GPU * args.steps / elapsed, 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (counter-hash fill: U(-1,1) images, 3-rectangle masks ~35%, untrained weights "
+                    "with torch-default conv init ranges)",
+            "config": {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 "
+                                   "(OmniGenerator.paint incl. mask, spectral-norm power iterations, paste)",
+                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
+                       "latent_dim": LATENT, "spade_n_up": N_UP, "parallelism": "independent replicas, image-sharded"},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "spade_fused_kernel (23 launches/step: all SPADE layers of the Painter)",
+                "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "algorithmic_flops_per_step": flops_step,
+                "launches_per_step": n_launch // max(args.steps, 1),
+                "avg_launch_ms": round(spade_ms / max(n_launch, 1), 4),
+                "share_of_step": round(spade_ms / (elapsed * 1e3), 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""ctypes binding of libcgan_hip.so (the C ABI declared in include/climategan_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C climategan_amd/csrc``.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcgan_hip.so"
+
+CGAN_F16, CGAN_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+PAD_ZERO, PAD_REFLECT = 0, 1
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+        ("c_in", C.c_int32), ("c_out", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilation", C.c_int32),
+        ("pad_mode", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32), ("in_upsample", C.c_int32),
+        ("act", C.c_int32), ("act_slope", C.c_float), ("has_bias", C.c_int32), ("has_residual", C.c_int32),
+        ("residual_upsample", C.c_int32),
+    ]
+
+
+class NormStatsDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("hw", C.c_int32), ("c", C.c_int32), ("eps", C.c_float)]
+
+
+class SpadeDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
+        ("x_upsample", C.c_int32), ("cond_h", C.c_int32), ("cond_w", C.c_int32), ("cond_c", C.c_int32),
+        ("hidden", C.c_int32), ("ksize", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "cgan_version": (C.c_int, []),
+    "cgan_last_error": (C.c_char_p, []),
+    "cgan_conv2d_packed_weight_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "cgan_conv2d_pack_weight": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_conv2d_nhwc_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_instnorm_stats_workspace_bytes": (C.c_size_t, [C.POINTER(NormStatsDesc)]),
+    "cgan_instnorm_stats": (C.c_int, [_P, _P, _P, C.POINTER(NormStatsDesc), _P, C.c_size_t, _P]),
+    "cgan_norm_act_apply": (C.c_int, [_P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P]),
+    "cgan_spade_packed_weight_bytes": (C.c_size_t, [C.POINTER(SpadeDesc)]),
+    "cgan_spade_pack_weights": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
+    "cgan_spade_fused_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
+    "cgan_spectral_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cgan_spectral_norm_power_iter": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    "cgan_nchw_to_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_nhwc_to_nchw": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_resize_nearest_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_avgpool3x3s2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            "climategan_amd: %s not found -- the HIP extension is not built (run __graft_entry__.build() or "
+            "`make -C climategan_amd/csrc`).  There is no CPU/PyTorch fallback on the product path." % LIB_PATH)
+    try:
+        # import torch first so that libamdhip64.so.7 resolves to the runtime torch already loaded
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> missing symbol: let it propagate loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.cgan_version()
+    if v != ABI_VERSION:
+        raise RuntimeError("climategan_amd: libcgan_hip.so ABI version %d != expected %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cgan_last_error()
+        raise RuntimeError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

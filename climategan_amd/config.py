@@ -1,0 +1,59 @@
+"""Minimal attribute-dict for options (the reference passes ``addict.Dict`` objects, utils.py:108-208).
+
+Any object with attribute access works for the modules here (an ``addict.Dict`` from the reference's
+``load_opts`` included); ``Opts`` exists so this package has no dependency on addict.  ``default_opts()``
+restates the subset of ``shared/trainer/defaults.yaml`` that the hot path reads.
+"""
+
+
+class Opts(dict):
+    def __init__(self, *a, **kw):
+        super().__init__()
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    @staticmethod
+    def _wrap(v):
+        if isinstance(v, dict) and not isinstance(v, Opts):
+            return Opts(v)
+        if isinstance(v, (list, tuple)):
+            return type(v)(Opts._wrap(i) for i in v)
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, Opts._wrap(v))
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        try:
+            return self[k]
+        except KeyError:
+            # addict auto-vivifies; the reference relies on it in one place (generator.py:144)
+            v = Opts()
+            super().__setitem__(k, v)
+            return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def default_opts() -> Opts:
+    """Hot-path subset of shared/trainer/defaults.yaml (line numbers of the reference file in comments)."""
+    return Opts({
+        "tasks": ["d", "s", "m", "p"],                                   # :19
+        "gen": {
+            "p": {                                                       # :144-165
+                "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True,
+                "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",
+                "spade_use_spectral_norm": True, "use_final_shortcut": False,
+            },
+        },
+        "dis": {
+            "soft_shift": 0.2, "flip_prob": 0.05,                        # :194-195
+            "p": {"input_nc": 3, "ndf": 64, "n_layers": 4, "norm": "instance", "use_sigmoid": False, "num_D": 3,
+                  "get_intermediate_features": True, "use_local_discriminator": False},   # :213-227
+            "m": {"architecture": "base", "gan_type": "WGAN_norm"},      # :229-235
+            "s": {"gan_type": "WGAN_norm"},                              # :236-240
+        },
+    })

@@ -1,0 +1,106 @@
+// Shared device/host helpers for libcgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "climategan_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// error reporting (host)
+// ------------------------------------------------------------------------------------------------
+void cgan_set_error(const char* fmt, ...);
+
+#define CGAN_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      cgan_set_error(__VA_ARGS__);         \
+      return CGAN_ERR_BAD_ARG;             \
+    }                                      \
+  } while (0)
+
+#define CGAN_CHECK_LAUNCH(name)                                                    \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      cgan_set_error("%s: HIP launch failed: %s", name, hipGetErrorString(e__));   \
+      return CGAN_ERR_HIP;                                                         \
+    }                                                                              \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit element types and MFMA wrappers
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct F16 {
+  using scalar = _Float16;
+  using vec8 = f16x8;
+  static constexpr int id = CGAN_F16;
+};
+struct BF16 {
+  using scalar = __bf16;
+  using vec8 = bf16x8;
+  static constexpr int id = CGAN_BF16;
+};
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(typename T::scalar v) {
+  return (float)v;
+}
+template <typename T>
+__device__ __forceinline__ typename T::scalar from_f32(float v) {
+  return (typename T::scalar)v;
+}
+template <typename T>
+__device__ __forceinline__ uint16_t bits_of(float v) {
+  typename T::scalar s = (typename T::scalar)v;
+  return __builtin_bit_cast(uint16_t, s);
+}
+template <typename T>
+__device__ __forceinline__ float f32_of_bits(uint16_t b) {
+  return (float)__builtin_bit_cast(typename T::scalar, b);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)bits_of<T>(lo) | ((uint32_t)bits_of<T>(hi) << 16);
+}
+template <typename T>
+__device__ __forceinline__ void unpack2(uint32_t p, float& lo, float& hi) {
+  lo = f32_of_bits<T>((uint16_t)(p & 0xffffu));
+  hi = f32_of_bits<T>((uint16_t)(p >> 16));
+}
+template <typename T>
+__device__ __forceinline__ typename T::vec8 as_vec8(u32x4 v) {
+  return __builtin_bit_cast(typename T::vec8, v);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case CGAN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CGAN_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case CGAN_ACT_TANH: return tanhf(v);
+    case CGAN_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+// F.interpolate(mode="nearest") legacy source index: min(floor(dst * scale), in - 1), scale = in / out in f32
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+  int s = (int)floorf((float)dst * scale);
+  return s < in_size - 1 ? s : in_size - 1;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

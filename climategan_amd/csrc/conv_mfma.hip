@@ -1,0 +1,307 @@
+// conv2d NHWC forward as an implicit GEMM on MFMA 16x16x32 (f16 / bf16, fp32 accumulate), gfx950.
+//
+// GEMM view (per launch):   D[cout][pixel] = sum_k  Wp[cout][k] * X[k][pixel]
+//   M = output channels (MFMA A operand = packed weights, rows)          -> 16-row "cout tiles"
+//   N = output pixels n*h_out*w_out flattened (MFMA B operand, columns)  -> 16-pixel "pixel tiles"
+//   K = taps * cin_s, ordered k = tap * cin_s + c (cin_s = storage channels, multiple of 8)
+// Putting channels on M means a lane's 4 accumulator registers are 4 CONSECUTIVE channels of one pixel
+// (D layout: col = lane&15, row = 4*(lane>>4)+r), i.e. one 8-byte NHWC store, and the epilogue (bias,
+// residual, activation) works on contiguous channel vectors.
+//
+// Operand fetch: an 8-element K group (lane>>4 selects it) never straddles a tap because cin_s % 8 == 0,
+// so every B fragment is ONE 16-byte NHWC load of 8 channels of the tap-shifted input pixel (zero / reflect
+// padding and the folded x2 nearest upsample are pure index math).  A fragments are pre-packed in fragment
+// order, so a wave reads 1 KiB contiguous per (cout tile, k-step).
+//
+// This is the general kernel (any kh/kw/stride/dilation/pad mode); operands come through L1/L2.
+#include "cgan_common.h"
+
+namespace {
+
+struct ConvParams {
+  const uint16_t* x;
+  const u32x4* w;
+  const float* bias;
+  const uint16_t* res;
+  uint16_t* y;
+  int n, h_in, w_in, hx, wx, cin_s, cg;
+  int cout, cout_s, ctiles;
+  int kh, kw, stride, pad, dil, pad_mode;
+  int h_out, w_out, npix;
+  int kgroups, ksteps;
+  int in_ups, act, has_res, res_ups;
+  float slope;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  // nn.ReflectionPad2d: -1 -> 1, n -> n-2 (pad < n guaranteed by the host check)
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+template <typename T, int CT, int PT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 15;
+  const int g = lane >> 4;
+
+  // ---- per-lane pixel coordinates for the PT pixel tiles of this wave
+  int pn[PT], py0[PT], px0[PT];
+  bool pvalid[PT];
+  const int ptile0 = (blockIdx.x * 4 + wave) * PT;
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    int pix = (ptile0 + t) * 16 + j;
+    pvalid[t] = pix < p.npix;
+    int pc = pvalid[t] ? pix : 0;
+    int ox = pc % p.w_out;
+    int r = pc / p.w_out;
+    int oy = r % p.h_out;
+    pn[t] = r / p.h_out;
+    py0[t] = oy * p.stride - p.pad;
+    px0[t] = ox * p.stride - p.pad;
+  }
+
+  f32x4 acc[CT][PT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ctile0 = blockIdx.y * CT;
+
+  // running (tap, channel-group) of this lane's K group: kg = ks*4 + g
+  int c8 = g, ky = 0, kx = 0;
+  while (c8 >= p.cg) {
+    c8 -= p.cg;
+    if (++kx == p.kw) { kx = 0; ++ky; }
+  }
+
+  for (int ks = 0; ks < p.ksteps; ++ks) {
+    const bool kvalid = (ks * 4 + g) < p.kgroups;
+    // ---- A fragments (packed weights): [ctile][ks][lane] x 16 B
+    u32x4 a[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      int ct = ctile0 + c;
+      a[c] = (u32x4){0u, 0u, 0u, 0u};
+      if (ct < p.ctiles) a[c] = p.w[((size_t)ct * p.ksteps + ks) * 64 + lane];
+    }
+    // ---- B fragments: 8 channels of the tap-shifted input pixel
+    u32x4 b[PT];
+    const int dy = ky * p.dil, dx = kx * p.dil;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      int iy = py0[t] + dy, ix = px0[t] + dx;
+      bool ok = kvalid && pvalid[t];
+      if (p.pad_mode == CGAN_PAD_REFLECT) {
+        iy = reflect_idx(iy, p.h_in);
+        ix = reflect_idx(ix, p.w_in);
+      } else {
+        ok = ok && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
+      }
+      b[t] = (u32x4){0u, 0u, 0u, 0u};
+      if (ok) {
+        if (p.in_ups) { iy >>= 1; ix >>= 1; }
+        size_t off = (((size_t)pn[t] * p.hx + iy) * p.wx + ix) * p.cin_s + c8 * 8;
+        b[t] = *reinterpret_cast<const u32x4*>(p.x + off);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+        acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(b[t]), acc[c][t]);
+
+    // advance this lane's K group by 4
+    c8 += 4;
+    while (c8 >= p.cg) {
+      c8 -= p.cg;
+      if (++kx == p.kw) { kx = 0; ++ky; }
+    }
+  }
+
+  // ---- epilogue: lane holds channels ct*16 + 4g + {0..3} of pixel (tile, j)
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    int pix = (ptile0 + t) * 16 + j;
+    if (pix >= p.npix) continue;
+    size_t rbase = 0;
+    if (p.has_res) {
+      if (p.res_ups) {
+        int ox = pix % p.w_out;
+        int r = pix / p.w_out;
+        int oy = r % p.h_out;
+        int nn = r / p.h_out;
+        rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+      } else {
+        rbase = (size_t)pix * p.cout_s;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      int ch = (ctile0 + c) * 16 + g * 4;
+      if (ch >= p.cout_s) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r] + (p.bias ? p.bias[ch + r] : 0.f);
+      if (p.has_res) {
+        u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
+        float r0, r1, r2, r3;
+        unpack2<T>(rv[0], r0, r1);
+        unpack2<T>(rv[1], r2, r3);
+        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = act_apply(v[r], p.act, p.slope);
+        if (ch + r >= p.cout) v[r] = 0.f;  // keep pad channels zero
+      }
+      u32x2 o;
+      o[0] = pack2<T>(v[0], v[1]);
+      o[1] = pack2<T>(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(p.y + (size_t)pix * p.cout_s + ch) = o;
+    }
+  }
+}
+
+// ---- weight packing: fp32 OIHW (optionally / sigma) -> 16-bit fragments [ctile][ks][lane][8]
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                        const float* __restrict__ sigma, uint16_t* __restrict__ packed,
+                                        float* __restrict__ bias_out, int cout, int cin, int cin_s, int kh, int kw,
+                                        int ctiles, int ksteps) {
+  const int total = ctiles * ksteps * 64;
+  const float inv = sigma ? 1.f / sigma[0] : 1.f;
+  const int taps = kh * kw;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int lane = idx & 63;
+    int ks = (idx >> 6) % ksteps;
+    int ct = (idx >> 6) / ksteps;
+    int co = ct * 16 + (lane & 15);
+    int k0 = ks * 32 + (lane >> 4) * 8;
+    uint16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int k = k0 + e;
+      int tap = k / cin_s;
+      int c = k - tap * cin_s;
+      float v = 0.f;
+      if (co < cout && tap < taps && c < cin) v = w[((size_t)co * cin + c) * taps + tap] * inv;
+      o[e] = bits_of<T>(v);
+    }
+    u32x4 pk;
+    pk[0] = o[0] | ((uint32_t)o[1] << 16);
+    pk[1] = o[2] | ((uint32_t)o[3] << 16);
+    pk[2] = o[4] | ((uint32_t)o[5] << 16);
+    pk[3] = o[6] | ((uint32_t)o[7] << 16);
+    reinterpret_cast<u32x4*>(packed)[idx] = pk;
+  }
+  if (bias_out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ctiles * 16; i += gridDim.x * blockDim.x)
+      bias_out[i] = (bias && i < cout) ? bias[i] : 0.f;
+  }
+}
+
+int fill_params(ConvParams& p, const CganConvDesc* d) {
+  CGAN_REQUIRE(d != nullptr, "conv2d: null descriptor");
+  CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d: bad dtype %d", d->dtype);
+  CGAN_REQUIRE(d->n > 0 && d->h_in > 0 && d->w_in > 0 && d->c_in > 0 && d->c_out > 0, "conv2d: bad shape");
+  CGAN_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0 && d->pad >= 0, "conv2d: bad kernel params");
+  int eh = (d->h_in + 2 * d->pad - d->dilation * (d->kh - 1) - 1) / d->stride + 1;
+  int ew = (d->w_in + 2 * d->pad - d->dilation * (d->kw - 1) - 1) / d->stride + 1;
+  CGAN_REQUIRE(eh == d->h_out && ew == d->w_out, "conv2d: h_out/w_out (%d,%d) inconsistent, expected (%d,%d)",
+               d->h_out, d->w_out, eh, ew);
+  CGAN_REQUIRE(d->pad_mode == CGAN_PAD_ZERO || d->pad_mode == CGAN_PAD_REFLECT, "conv2d: Unsupported padding type: %d",
+               d->pad_mode);
+  if (d->pad_mode == CGAN_PAD_REFLECT)
+    CGAN_REQUIRE(d->pad < d->h_in && d->pad < d->w_in, "conv2d: reflect padding %d must be < input size", d->pad);
+  if (d->in_upsample) CGAN_REQUIRE((d->h_in % 2) == 0 && (d->w_in % 2) == 0, "conv2d: in_upsample needs even h_in/w_in");
+  if (d->has_residual && d->residual_upsample)
+    CGAN_REQUIRE((d->h_out % 2) == 0 && (d->w_out % 2) == 0, "conv2d: residual_upsample needs even h_out/w_out");
+  CGAN_REQUIRE(d->act >= CGAN_ACT_NONE && d->act <= CGAN_ACT_SIGMOID, "conv2d: Unsupported activation: %d", d->act);
+  p.n = d->n; p.h_in = d->h_in; p.w_in = d->w_in;
+  p.hx = d->in_upsample ? d->h_in / 2 : d->h_in;
+  p.wx = d->in_upsample ? d->w_in / 2 : d->w_in;
+  p.cin_s = cgan_cs(d->c_in); p.cg = p.cin_s / 8;
+  p.cout = d->c_out; p.cout_s = cgan_cs(d->c_out); p.ctiles = ceil_div(p.cout_s, 16);
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dilation; p.pad_mode = d->pad_mode;
+  p.h_out = d->h_out; p.w_out = d->w_out;
+  long npix = (long)d->n * d->h_out * d->w_out;
+  CGAN_REQUIRE(npix < (1L << 31) - 64, "conv2d: too many output pixels");
+  p.npix = (int)npix;
+  p.kgroups = d->kh * d->kw * p.cg; p.ksteps = ceil_div(p.kgroups, 4);
+  p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope;
+  p.has_res = d->has_residual; p.res_ups = d->residual_upsample;
+  return CGAN_OK;
+}
+
+template <typename T, int CT>
+void launch_ct(const ConvParams& p, hipStream_t s) {
+  const int ptiles = ceil_div(p.npix, 16);
+  const int gy = ceil_div(p.ctiles, CT);
+  // enough blocks to fill 256 CUs: shrink the per-wave pixel register tile for small problems
+  if ((long)ceil_div(ptiles, 16) * gy >= 512) {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 4>), dim3(ceil_div(ptiles, 16), gy), dim3(256), 0, s, p);
+  } else if ((long)ceil_div(ptiles, 8) * gy >= 512) {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 2>), dim3(ceil_div(ptiles, 8), gy), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1>), dim3(ceil_div(ptiles, 4), gy), dim3(256), 0, s, p);
+  }
+}
+
+template <typename T>
+void launch(const ConvParams& p, hipStream_t s) {
+  if (p.ctiles >= 4 && p.ctiles % 4 == 0) launch_ct<T, 4>(p, s);
+  else if (p.ctiles % 3 == 0) launch_ct<T, 3>(p, s);
+  else if (p.ctiles % 2 == 0) launch_ct<T, 2>(p, s);
+  else if (p.ctiles == 1) launch_ct<T, 1>(p, s);
+  else if (p.ctiles == 5) launch_ct<T, 3>(p, s);
+  else launch_ct<T, 4>(p, s);
+}
+
+}  // namespace
+
+extern "C" size_t cgan_conv2d_packed_weight_bytes(const CganConvDesc* d) {
+  ConvParams p;
+  if (fill_params(p, d) != CGAN_OK) return 0;
+  return (size_t)p.ctiles * p.ksteps * 64 * 16;
+}
+
+extern "C" int cgan_conv2d_pack_weight(const float* w_oihw, const float* bias, const float* sigma, void* packed,
+                                       float* bias_out, const CganConvDesc* d, void* stream) {
+  ConvParams p;
+  int rc = fill_params(p, d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(w_oihw && packed, "conv2d_pack_weight: null pointer");
+  const int total = p.ctiles * p.ksteps * 64;
+  const int blocks = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == CGAN_F16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<F16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
+                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_s, d->kh, d->kw, p.ctiles, p.ksteps);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
+                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_s, d->kh, d->kw, p.ctiles, p.ksteps);
+  CGAN_CHECK_LAUNCH("conv2d_pack_weight");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const float* bias_padded, const void* residual,
+                                    void* y, const CganConvDesc* d, void* stream) {
+  ConvParams p;
+  int rc = fill_params(p, d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(x && packed_w && y, "conv2d_nhwc_fwd: null pointer");
+  CGAN_REQUIRE(!d->has_bias || bias_padded, "conv2d_nhwc_fwd: has_bias but bias is null");
+  CGAN_REQUIRE(!d->has_residual || residual, "conv2d_nhwc_fwd: has_residual but residual is null");
+  p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
+  p.res = (const uint16_t*)residual; p.y = (uint16_t*)y;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == CGAN_F16) launch<F16>(p, s);
+  else launch<BF16>(p, s);
+  CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd");
+  return CGAN_OK;
+}

@@ -1,0 +1,205 @@
+// Instance-norm statistics over H*W per (n, c) on NHWC 16-bit tensors, and the elementwise normalise+act.
+//
+// HBM-bound: one pass over x.  Thread t of a block owns one 8-channel group (16-byte vector loads, lanes
+// sweep consecutive channel groups then consecutive pixels => fully coalesced rows) and a strided subset
+// of the block's pixel range; per-thread (sum, sumsq) over <= a few hundred pixels are converted to
+// (mean, M2) and merged with Chan's parallel formula across threads (LDS) and across blocks (finalize
+// kernel), so the variance never suffers the E[x^2] - E[x]^2 cancellation over 409 600 pixels.
+#include "cgan_common.h"
+
+namespace {
+
+constexpr int STATS_THREADS = 256;
+constexpr int STATS_PIX_PER_BLOCK = 2048;  // pixels per block (per channel-group block)
+
+struct MeanM2 {
+  float n, mean, m2;
+};
+__device__ __forceinline__ MeanM2 chan_merge(MeanM2 a, MeanM2 b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  float n = a.n + b.n;
+  float d = b.mean - a.mean;
+  MeanM2 r;
+  r.n = n;
+  r.mean = a.mean + d * (b.n / n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / n);
+  return r;
+}
+
+// partial: [n][chunks][cs][2] (mean, m2); counts are implied by the chunk extents
+template <typename T>
+__global__ __launch_bounds__(STATS_THREADS) void instnorm_partial_kernel(const uint16_t* __restrict__ x,
+                                                                        float* __restrict__ partial, int hw, int cs,
+                                                                        int chunks) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [PL][cgb*8][2]
+  const int cg_total = cs / 8;
+  const int cgb = cg_total < STATS_THREADS ? cg_total : STATS_THREADS;  // channel groups handled per block
+  const int PL = STATS_THREADS / cgb;                                   // pixel lanes
+  const int n = blockIdx.z;
+  const int cg0 = blockIdx.y * cgb;
+  const int chunk = blockIdx.x;
+  const int p0 = chunk * STATS_PIX_PER_BLOCK;
+  const int p1 = min(hw, p0 + STATS_PIX_PER_BLOCK);
+  const int t = threadIdx.x;
+  const int cgl = t % cgb, pl = t / cgb;
+  const int cg = cg0 + cgl;
+  const bool active = (pl < PL) && (cg < cg_total);
+
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  float cnt = 0.f;
+  if (active) {
+    const uint16_t* base = x + (size_t)n * hw * cs + cg * 8;
+    for (int p = p0 + pl; p < p1; p += PL) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(base + (size_t)p * cs);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a, b;
+        unpack2<T>(v[e], a, b);
+        s[2 * e] += a; q[2 * e] += a * a;
+        s[2 * e + 1] += b; q[2 * e + 1] += b * b;
+      }
+      cnt += 1.f;
+    }
+  }
+  // per-thread (mean, m2) -> LDS; thread-local counts differ by at most one, carried in a parallel array
+  float* smean = sm;                       // [PL][cgb*8]
+  float* sm2 = sm + PL * cgb * 8;          // [PL][cgb*8]
+  float* scnt = sm + 2 * PL * cgb * 8;     // [PL]
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float mean = cnt > 0.f ? s[e] / cnt : 0.f;
+      float m2 = cnt > 0.f ? fmaxf(q[e] - s[e] * mean, 0.f) : 0.f;
+      smean[(pl * cgb + cgl) * 8 + e] = mean;
+      sm2[(pl * cgb + cgl) * 8 + e] = m2;
+    }
+    if (cgl == 0) scnt[pl] = cnt;
+  }
+  __syncthreads();
+  // one thread per channel merges the PL pixel lanes
+  for (int c = t; c < cgb * 8; c += STATS_THREADS) {
+    if (cg0 * 8 + c >= cs) continue;
+    MeanM2 acc = {0.f, 0.f, 0.f};
+    for (int l = 0; l < PL; ++l) {
+      MeanM2 b = {scnt[l], smean[l * cgb * 8 + c], sm2[l * cgb * 8 + c]};
+      acc = chan_merge(acc, b);
+    }
+    float* o = partial + (((size_t)n * chunks + chunk) * cs + cg0 * 8 + c) * 2;
+    o[0] = acc.mean;
+    o[1] = acc.m2;
+  }
+}
+
+__global__ void instnorm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean,
+                                         float* __restrict__ rstd, int n_total, int hw, int cs, int chunks, float eps) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total * cs) return;
+  int n = idx / cs, c = idx - n * cs;
+  MeanM2 acc = {0.f, 0.f, 0.f};
+  for (int k = 0; k < chunks; ++k) {
+    int p0 = k * STATS_PIX_PER_BLOCK;
+    int cnt = min(hw, p0 + STATS_PIX_PER_BLOCK) - p0;
+    const float* o = partial + (((size_t)n * chunks + k) * cs + c) * 2;
+    MeanM2 b = {(float)cnt, o[0], o[1]};
+    acc = chan_merge(acc, b);
+  }
+  mean[idx] = acc.mean;
+  rstd[idx] = rsqrtf(acc.m2 / (float)hw + eps);
+}
+
+template <typename T>
+__global__ void norm_act_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
+                                      const float* __restrict__ rstd, uint16_t* __restrict__ y, int hw, int cs, int c,
+                                      long total_groups, int act, float slope) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_groups;
+       idx += (long)gridDim.x * blockDim.x) {
+    int cg = (int)(idx % cg_total);
+    long pix = idx / cg_total;
+    int n = (int)(pix / hw);
+    u32x4 v = reinterpret_cast<const u32x4*>(x)[idx];
+    const float* m = mean + (size_t)n * cs + cg * 8;
+    const float* r = rstd + (size_t)n * cs + cg * 8;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a, b;
+      unpack2<T>(v[e], a, b);
+      a = act_apply((a - m[2 * e]) * r[2 * e], act, slope);
+      b = act_apply((b - m[2 * e + 1]) * r[2 * e + 1], act, slope);
+      if (cg * 8 + 2 * e >= c) a = 0.f;
+      if (cg * 8 + 2 * e + 1 >= c) b = 0.f;
+      o[e] = pack2<T>(a, b);
+    }
+    reinterpret_cast<u32x4*>(y)[idx] = o;
+  }
+}
+
+int check(const CganNormStatsDesc* d) {
+  CGAN_REQUIRE(d != nullptr, "instnorm: null descriptor");
+  CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "instnorm: bad dtype %d", d->dtype);
+  CGAN_REQUIRE(d->n > 0 && d->hw > 0 && d->c > 0, "instnorm: bad shape");
+  return CGAN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cgan_instnorm_stats_workspace_bytes(const CganNormStatsDesc* d) {
+  if (check(d) != CGAN_OK) return 0;
+  int chunks = ceil_div(d->hw, STATS_PIX_PER_BLOCK);
+  return (size_t)d->n * chunks * cgan_cs(d->c) * 2 * sizeof(float);
+}
+
+extern "C" int cgan_instnorm_stats(const void* x, float* mean, float* rstd, const CganNormStatsDesc* d, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  int rc = check(d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(x && mean && rstd && workspace, "instnorm_stats: null pointer");
+  size_t need = cgan_instnorm_stats_workspace_bytes(d);
+  if (workspace_bytes < need) {
+    cgan_set_error("instnorm_stats: workspace %zu B < required %zu B", workspace_bytes, need);
+    return CGAN_ERR_WORKSPACE;
+  }
+  const int cs = cgan_cs(d->c);
+  const int cg_total = cs / 8;
+  const int cgb = cg_total < STATS_THREADS ? cg_total : STATS_THREADS;
+  const int PL = STATS_THREADS / cgb;
+  const int chunks = ceil_div(d->hw, STATS_PIX_PER_BLOCK);
+  dim3 grid(chunks, ceil_div(cg_total, cgb), d->n);
+  size_t smem = ((size_t)2 * PL * cgb * 8 + PL) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == CGAN_F16)
+    hipLaunchKernelGGL(instnorm_partial_kernel<F16>, grid, dim3(STATS_THREADS), smem, s, (const uint16_t*)x,
+                       (float*)workspace, d->hw, cs, chunks);
+  else
+    hipLaunchKernelGGL(instnorm_partial_kernel<BF16>, grid, dim3(STATS_THREADS), smem, s, (const uint16_t*)x,
+                       (float*)workspace, d->hw, cs, chunks);
+  CGAN_CHECK_LAUNCH("instnorm_stats(partial)");
+  int total = d->n * cs;
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)workspace,
+                     mean, rstd, d->n, d->hw, cs, chunks, d->eps);
+  CGAN_CHECK_LAUNCH("instnorm_stats(finalize)");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_norm_act_apply(const void* x, const float* mean, const float* rstd, void* y,
+                                   const CganNormStatsDesc* d, int32_t act, float act_slope, void* stream) {
+  int rc = check(d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(x && mean && rstd && y, "norm_act_apply: null pointer");
+  const int cs = cgan_cs(d->c);
+  long groups = (long)d->n * d->hw * (cs / 8);
+  int blocks = (int)((groups + 255) / 256 < 4096 ? (groups + 255) / 256 : 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == CGAN_F16)
+    hipLaunchKernelGGL(norm_act_apply_kernel<F16>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)x, mean, rstd,
+                       (uint16_t*)y, d->hw, cs, d->c, groups, act, act_slope);
+  else
+    hipLaunchKernelGGL(norm_act_apply_kernel<BF16>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)x, mean, rstd,
+                       (uint16_t*)y, d->hw, cs, d->c, groups, act, act_slope);
+  CGAN_CHECK_LAUNCH("norm_act_apply");
+  return CGAN_OK;
+}

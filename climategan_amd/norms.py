@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference's ``climategan/norms.py`` for the hot path: SPADE and SpectralNorm.
+
+Same class names, constructor arguments, parameter names and state-dict keys as the reference, so reference
+checkpoints load unchanged; the arithmetic runs in libcgan_hip.so (HIP, gfx950) through ``ops``.
+AdaptiveInstanceNorm2d / LayerNorm of the reference are dead options in the default configs (SURVEY.md
+section 2a) and are not provided.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+DEFAULT_COMPUTE_DTYPE = torch.float16
+
+
+def _grad_guard(module: nn.Module):
+    """The backward kernels are not part of this build: refuse to run under autograd instead of silently
+    returning tensors without a graph."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            "climategan_amd: only the forward (inference) path is implemented in HIP so far; call under "
+            "torch.no_grad() (the reference's infer_all does, trainer.py:217) or set requires_grad=False")
+
+
+class _PackCache:
+    """Re-pack fp32 parameters into MFMA fragment order only when they change."""
+
+    def __init__(self):
+        self.key = None
+        self.value = None
+
+    def get(self, params, dtype, build):
+        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in params if p is not None) + (dtype,)
+        if key != self.key:
+            self.value = build()
+            self.key = key
+        return self.value
+
+
+class SpectralNorm(nn.Module):
+    """Spectral-norm wrapper (reference climategan/norms.py:84-143).
+
+    State: ``module.weight_u [Cout]``, ``module.weight_v [Cin*k*k]``, ``module.weight_bar [Cout,Cin,k,k]``
+    (+ ``module.bias``), all nn.Parameters with u/v ``requires_grad=False`` exactly as the reference
+    (norms.py:129-139).  One power iteration runs on EVERY forward, eval included (norms.py:141-143), and
+    mutates u/v in place; the convolution then uses ``w_bar / sigma``.
+    """
+
+    def __init__(self, module, name="weight", power_iterations=1):
+        super().__init__()
+        if power_iterations != 1:
+            raise NotImplementedError("SpectralNorm: only power_iterations=1 (the reference's only use)")
+        self.module = module
+        self.name = name
+        self.power_iterations = power_iterations
+        if not hasattr(module, name + "_bar"):
+            w = getattr(module, name)
+            rows = w.shape[0]
+            cols = w.numel() // rows
+            u = torch.randn(rows)
+            v = torch.randn(cols)
+            u = u / (u.norm() + 1e-12)
+            v = v / (v.norm() + 1e-12)
+            del module._parameters[name]
+            module.register_parameter(name + "_u", nn.Parameter(u, requires_grad=False))
+            module.register_parameter(name + "_v", nn.Parameter(v, requires_grad=False))
+            module.register_parameter(name + "_bar", nn.Parameter(w.data))
+
+    def packed(self, dtype) -> ops.PackedConv:
+        """Power-iterate (updates u, v) and return w_bar / sigma packed for the MFMA conv kernel."""
+        m = self.module
+        w_bar = getattr(m, self.name + "_bar")
+        u = getattr(m, self.name + "_u")
+        v = getattr(m, self.name + "_v")
+        sigma = ops.spectral_norm_power_iter(w_bar.data, u.data, v.data)
+        return ops.pack_conv_weight(w_bar.data, m.bias.data if m.bias is not None else None, dtype, sigma)
+
+    def forward(self, x, **conv_kwargs):
+        _grad_guard(self)
+        m = self.module
+        pw = self.packed(x.t.dtype)
+        return ops.conv2d(x, pw, stride=m.stride[0], pad=m.padding[0], dilation=m.dilation[0], **conv_kwargs)
+
+
+class PlainConv(nn.Module):
+    """Helper (not in the reference): runs an ``nn.Conv2d``'s parameters through the HIP conv kernel."""
+
+    def __init__(self, conv: nn.Conv2d):
+        super().__init__()
+        self.conv = conv
+        self._cache = _PackCache()
+
+    def packed(self, dtype):
+        c = self.conv
+        return self._cache.get((c.weight, c.bias), dtype,
+                               lambda: ops.pack_conv_weight(c.weight.data, c.bias.data if c.bias is not None else None,
+                                                            dtype))
+
+
+def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.NHWC:
+    """Run a plain ``nn.Conv2d`` (weights cached in packed form) or a ``SpectralNorm`` wrapper on NHWC input."""
+    if isinstance(conv, SpectralNorm):
+        return conv(x, **kw)
+    _grad_guard(conv)
+    pw = cache.get((conv.weight, conv.bias), x.t.dtype,
+                   lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None,
+                                                x.t.dtype))
+    return ops.conv2d(x, pw, stride=conv.stride[0], pad=conv.padding[0], dilation=conv.dilation[0], **kw)
+
+
+class SPADE(nn.Module):
+    """SPADE de-normalisation (reference climategan/norms.py:146-186), fused into one HIP kernel.
+
+    Parameters/keys: ``mlp_shared.0.{weight,bias}``, ``mlp_gamma.{weight,bias}``, ``mlp_beta.{weight,bias}``.
+    ``forward_nhwc`` takes the precomputed instance-norm statistics of x (shared between norm_0 and norm_s of
+    a SPADEResnetBlock, which normalise the same tensor) and optionally applies the block's LeakyReLU.
+    """
+
+    def __init__(self, param_free_norm_type, kernel_size, norm_nc, cond_nc):
+        super().__init__()
+        if param_free_norm_type == "instance":
+            self.param_free_norm = nn.InstanceNorm2d(norm_nc, affine=False)
+        elif param_free_norm_type == "batch":
+            self.param_free_norm = nn.BatchNorm2d(norm_nc, affine=False)
+        else:
+            raise ValueError("%s is not a recognized param-free norm type in SPADE" % param_free_norm_type)
+        self.param_free_norm_type = param_free_norm_type
+        nhidden = 128  # hard-coded in the reference (norms.py:163)
+        pw = kernel_size // 2
+        self.mlp_shared = nn.Sequential(nn.Conv2d(cond_nc, nhidden, kernel_size=kernel_size, padding=pw), nn.ReLU())
+        self.mlp_gamma = nn.Conv2d(nhidden, norm_nc, kernel_size=kernel_size, padding=pw)
+        self.mlp_beta = nn.Conv2d(nhidden, norm_nc, kernel_size=kernel_size, padding=pw)
+        self.kernel_size = kernel_size
+        self._cache = _PackCache()
+
+    def packed(self, dtype) -> ops.PackedSpade:
+        ps = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
+              self.mlp_beta.weight, self.mlp_beta.bias)
+        return self._cache.get(ps, dtype, lambda: ops.pack_spade_weights(*[p.data for p in ps], dtype))
+
+    def forward_nhwc(self, x: ops.NHWC, cond: ops.NHWC, stats=None, act=ops.ACT_NONE, x_upsample=False) -> ops.NHWC:
+        _grad_guard(self)
+        if self.param_free_norm_type != "instance":
+            raise NotImplementedError("SPADE: param-free norm '%s' has no HIP kernel yet (instance only)"
+                                      % self.param_free_norm_type)
+        if self.kernel_size != 3:
+            raise NotImplementedError("SPADE: only kernel_size 3 is supported")
+        if stats is None:
+            stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
+        return ops.spade_fused(x, stats[0], stats[1], cond, self.packed(x.t.dtype), act=act, x_upsample=x_upsample)
+
+    def forward(self, x, segmap, compute_dtype=None):
+        """Reference signature: NCHW tensors in, NCHW fp32 out."""
+        dt = compute_dtype or DEFAULT_COMPUTE_DTYPE
+        xs = ops.nchw_to_nhwc(x, dt)
+        cond = ops.nchw_to_nhwc(segmap, dt, cs=ops.cs4(segmap.shape[1]))
+        return ops.nhwc_to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)

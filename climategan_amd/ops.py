@@ -1,0 +1,267 @@
+"""Thin Python wrappers over the C ABI (include/climategan_hip.h): tensors in, raw device pointers out.
+
+PyTorch is used only as the device-memory container / stream provider (tensor.data_ptr(),
+torch.cuda.current_stream()).  Every op here runs a hand-written HIP kernel from libcgan_hip.so; there is no
+torch fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CGAN_BF16, CGAN_F16, PAD_REFLECT,  # noqa: F401
+                   PAD_ZERO, ConvDesc, NormStatsDesc, SpadeDesc)
+
+_DT = {torch.float16: CGAN_F16, torch.bfloat16: CGAN_BF16}
+
+
+def cs8(c: int) -> int:
+    return (c + 7) & ~7
+
+
+def cs4(c: int) -> int:
+    return (c + 3) & ~3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("climategan_amd ops need device tensors (got a %s tensor); there is no CPU path"
+                               % t.device)
+
+
+@dataclass
+class NHWC:
+    """Channel-padded NHWC 16-bit activation: ``t`` is [N,H,W,Cs] (Cs = storage channels), ``c`` logical."""
+    t: torch.Tensor
+    c: int
+
+    @property
+    def n(self): return self.t.shape[0]
+    @property
+    def h(self): return self.t.shape[1]
+    @property
+    def w(self): return self.t.shape[2]
+    @property
+    def cs(self): return self.t.shape[3]
+    @property
+    def dtype_id(self): return _DT[self.t.dtype]
+
+
+# ------------------------------------------------------------------------------------------------ layout
+def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cs: Optional[int] = None,
+                 mask: Optional[torch.Tensor] = None) -> NHWC:
+    """fp32 NCHW -> 16-bit NHWC (optionally times (1 - mask): cond = x * (1 - m), reference generator.py:294)."""
+    _need_cuda(x, mask)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    cs = cs or cs8(c)
+    if mask is not None:
+        mask = mask.contiguous().float()
+        assert mask.shape == (n, 1, h, w), mask.shape
+    y = torch.empty((n, h, w, cs), dtype=dtype, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_nchw_to_nhwc(_ptr(x), _ptr(mask), _ptr(y), _DT[dtype], n, c, h, w, cs, _stream()),
+               "cgan_nchw_to_nhwc")
+    return NHWC(y, c)
+
+
+def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optional[torch.Tensor] = None):
+    """16-bit NHWC -> fp32 NCHW; with paste: out = paste_x * (1 - m) + y * m (reference generator.py:295-296)."""
+    _need_cuda(y.t, paste_x, paste_m)
+    n, h, w, cs = y.t.shape
+    out = torch.empty((n, y.c, h, w), dtype=torch.float32, device=y.t.device)
+    if paste_x is not None:
+        paste_x = paste_x.contiguous().float()
+        paste_m = paste_m.contiguous().float()
+        assert paste_x.shape == out.shape and paste_m.shape == (n, 1, h, w)
+    lib = _lib.load()
+    _lib.check(lib.cgan_nhwc_to_nchw(_ptr(y.t), _ptr(paste_x), _ptr(paste_m), _ptr(out), y.dtype_id, n, y.c, h, w, cs,
+                                     _stream()), "cgan_nhwc_to_nchw")
+    return out
+
+
+def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None) -> NHWC:
+    _need_cuda(x.t)
+    oh, ow = size
+    cs_out = cs_out or x.cs
+    y = torch.empty((x.n, oh, ow, cs_out), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_resize_nearest_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, x.cs, oh, ow, cs_out,
+                                            _stream()), "cgan_resize_nearest_nhwc")
+    return NHWC(y, x.c)
+
+
+def avgpool3x3s2(x: NHWC) -> NHWC:
+    _need_cuda(x.t)
+    oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
+    y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_avgpool3x3s2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
+               "cgan_avgpool3x3s2_nhwc")
+    return NHWC(y, x.c)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+@dataclass
+class PackedConv:
+    w: torch.Tensor      # opaque packed weights (uint8)
+    bias: torch.Tensor   # fp32 [round_up(c_out,16)]
+    c_in: int
+    c_out: int
+    kh: int
+    kw: int
+    has_bias: bool
+    dtype: torch.dtype
+
+
+def _conv_desc(dtype_id, n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dil, pad_mode, in_upsample=False,
+               act=ACT_NONE, slope=0.2, has_bias=True, has_res=False, res_ups=False) -> ConvDesc:
+    h_out = (h_in + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    w_out = (w_in + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    return ConvDesc(dtype_id, n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dil, pad_mode, h_out, w_out,
+                    int(in_upsample), act, slope, int(has_bias), int(has_res), int(res_ups))
+
+
+def pack_conv_weight(w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
+                     sigma: Optional[torch.Tensor] = None) -> PackedConv:
+    """fp32 OIHW (+ optional device scalar sigma: packed = w / sigma) -> MFMA fragment order."""
+    _need_cuda(w, bias, sigma)
+    w = w.detach().contiguous().float()
+    c_out, c_in, kh, kw = w.shape
+    d = _conv_desc(_DT[dtype], 1, max(kh, 1), max(kw, 1), c_in, c_out, kh, kw, 1, 0, 1, PAD_ZERO)
+    lib = _lib.load()
+    nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
+    if nbytes == 0:
+        _lib.check(-1, "cgan_conv2d_packed_weight_bytes")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    bias_out = torch.empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=w.device)
+    b = bias.detach().contiguous().float() if bias is not None else None
+    _lib.check(lib.cgan_conv2d_pack_weight(_ptr(w), _ptr(b), _ptr(sigma), _ptr(packed), _ptr(bias_out), C.byref(d),
+                                           _stream()), "cgan_conv2d_pack_weight")
+    return PackedConv(packed, bias_out, c_in, c_out, kh, kw, bias is not None, dtype)
+
+
+def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2,
+           residual: Optional[NHWC] = None, in_upsample=False, residual_upsample=False) -> NHWC:
+    """y = act(conv(x) + bias + residual) on NHWC tensors; x may be read through a folded x2 nearest upsample."""
+    _need_cuda(x.t)
+    if x.c != pw.c_in:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.c, pw.c_in))
+    if x.t.dtype != pw.dtype:
+        raise RuntimeError("conv2d: activation dtype %s != packed weight dtype %s" % (x.t.dtype, pw.dtype))
+    h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
+    d = _conv_desc(x.dtype_id, x.n, h_in, w_in, pw.c_in, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode,
+                   in_upsample, act, slope, pw.has_bias, residual is not None, residual_upsample)
+    if residual is not None:
+        rh, rw = (residual.h * 2, residual.w * 2) if residual_upsample else (residual.h, residual.w)
+        if (rh, rw) != (d.h_out, d.w_out) or residual.c != pw.c_out or residual.n != x.n:
+            raise RuntimeError("conv2d: residual shape mismatch")
+    y = torch.empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_conv2d_nhwc_fwd(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias), _ptr(residual.t if residual else None),
+                                        _ptr(y), C.byref(d), _stream()), "cgan_conv2d_nhwc_fwd")
+    return NHWC(y, pw.c_out)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def instnorm_stats(x: NHWC, eps: float = 1e-5):
+    """Per-(n,c) mean and 1/sqrt(var+eps) (biased var over H*W) -> two fp32 [N, Cs] tensors."""
+    _need_cuda(x.t)
+    d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, eps)
+    lib = _lib.load()
+    ws_bytes = lib.cgan_instnorm_stats_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.t.device)
+    mean = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+    rstd = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+    _lib.check(lib.cgan_instnorm_stats(_ptr(x.t), _ptr(mean), _ptr(rstd), C.byref(d), _ptr(ws), ws_bytes, _stream()),
+               "cgan_instnorm_stats")
+    return mean, rstd
+
+
+def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2) -> NHWC:
+    _need_cuda(x.t, mean, rstd)
+    d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, 0.0)
+    y = torch.empty_like(x.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_norm_act_apply(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(y), C.byref(d), act, slope, _stream()),
+               "cgan_norm_act_apply")
+    return NHWC(y, x.c)
+
+
+@dataclass
+class PackedSpade:
+    buf: torch.Tensor
+    c: int
+    cond_c: int
+    dtype: torch.dtype
+
+
+def _spade_desc(dtype_id, n, h, w, c, x_ups, cond_h, cond_w, cond_c, act, slope=0.2):
+    return SpadeDesc(dtype_id, n, h, w, c, int(x_ups), cond_h, cond_w, cond_c, 128, 3, act, slope)
+
+
+def pack_spade_weights(w_shared, b_shared, w_gamma, b_gamma, w_beta, b_beta, dtype: torch.dtype) -> PackedSpade:
+    _need_cuda(w_shared, w_gamma, w_beta)
+    c, hidden = w_gamma.shape[0], w_gamma.shape[1]
+    cond_c = w_shared.shape[1]
+    if hidden != 128 or w_shared.shape[0] != 128 or tuple(w_gamma.shape[2:]) != (3, 3):
+        raise ValueError("SPADE: only hidden=128, kernel_size=3 is supported")
+    d = _spade_desc(_DT[dtype], 1, 16, 16, c, False, 16, 16, cond_c, ACT_NONE)
+    lib = _lib.load()
+    nbytes = lib.cgan_spade_packed_weight_bytes(C.byref(d))
+    if nbytes == 0:
+        _lib.check(-1, "cgan_spade_packed_weight_bytes")
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w_gamma.device)
+    ts = [t.detach().contiguous().float() for t in (w_shared, b_shared, w_gamma, b_gamma, w_beta, b_beta)]
+    _lib.check(lib.cgan_spade_pack_weights(*[_ptr(t) for t in ts], _ptr(buf), C.byref(d), _stream()),
+               "cgan_spade_pack_weights")
+    return PackedSpade(buf, c, cond_c, dtype)
+
+
+def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, slope=0.2, x_upsample=False) -> NHWC:
+    """Fused SPADE: act((x-mean)*rstd*(1+gamma(cond))+beta(cond)); x optionally read through x2 nearest."""
+    _need_cuda(x.t, cond.t, mean, rstd)
+    if x.c != pk.c or cond.c != pk.cond_c:
+        raise RuntimeError("spade_fused: channel mismatch (x %d vs %d, cond %d vs %d)" % (x.c, pk.c, cond.c, pk.cond_c))
+    if cond.cs != cs4(cond.c):
+        raise RuntimeError("spade_fused: cond must be stored with round_up(cond_c,4) channels")
+    if x.t.dtype != pk.dtype or cond.t.dtype != pk.dtype:
+        raise RuntimeError("spade_fused: dtype mismatch")
+    h, w = (x.h * 2, x.w * 2) if x_upsample else (x.h, x.w)
+    d = _spade_desc(x.dtype_id, x.n, h, w, x.c, x_upsample, cond.h, cond.w, cond.c, act, slope)
+    y = torch.empty((x.n, h, w, x.cs), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_spade_fused_fwd(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(cond.t), _ptr(pk.buf), _ptr(y),
+                                        C.byref(d), _stream()), "cgan_spade_fused_fwd")
+    return NHWC(y, x.c)
+
+
+# ------------------------------------------------------------------------------------------------ spectral norm
+def spectral_norm_power_iter(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """One power iteration (reference norms.py:100-112); u, v updated IN PLACE; returns device scalar sigma."""
+    _need_cuda(w_bar, u, v)
+    if w_bar.dtype != torch.float32 or u.dtype != torch.float32 or v.dtype != torch.float32:
+        raise RuntimeError("spectral_norm_power_iter: fp32 parameters expected")
+    if not (w_bar.is_contiguous() and u.is_contiguous() and v.is_contiguous()):
+        raise RuntimeError("spectral_norm_power_iter: contiguous parameters expected")
+    rows = w_bar.shape[0]
+    cols = w_bar.numel() // rows
+    assert u.numel() == rows and v.numel() == cols
+    lib = _lib.load()
+    ws_bytes = lib.cgan_spectral_norm_workspace_bytes(rows, cols)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=w_bar.device)
+    sigma = torch.empty(1, dtype=torch.float32, device=w_bar.device)
+    _lib.check(lib.cgan_spectral_norm_power_iter(_ptr(w_bar), _ptr(u), _ptr(v), _ptr(sigma), rows, cols, _ptr(ws),
+                                                 ws_bytes, _stream()), "cgan_spectral_norm_power_iter")
+    return sigma

@@ -1,0 +1,168 @@
+/* climategan_hip.h -- C ABI of libcgan_hip.so: the MI355X (gfx950) implementation of the ClimateGAN
+ * generator/discriminator hot path.
+ *
+ * The reference (cc-ai/climategan) is pure Python on torch.nn: it has no FFI layer.  The drop-in boundary is
+ * therefore the Python module API (climategan/generator.py, discriminator.py, blocks.py, norms.py,
+ * painter.py); the modules in climategan_amd/ mirror that API and call THIS library through ctypes with raw
+ * device pointers (tensor.data_ptr()).  Each entry point below names the reference code it replaces
+ * (file:line, relative to the reference repo root).  See INTEGRATION.md for the binding a maintainer adds.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller; the library never allocates or frees device
+ *     memory and keeps no reference after return.  Work is enqueued asynchronously on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).
+ *   - Activations are NHWC, 16-bit (dtype CGAN_F16 or CGAN_BF16), channel-padded: a tensor with C logical
+ *     channels is stored with cgan_cs(C) = round_up(C, 8) channels per pixel and the pad channels are ZERO
+ *     (every kernel here preserves that invariant).  Accumulation is fp32.
+ *   - Weights arrive as fp32 in the reference's state-dict layout (OIHW) and are re-laid-out ("packed")
+ *     into MFMA fragment order by the *_pack_* entry points; packed buffers are opaque.
+ *   - Return value: 0 on success, negative cgan_status_t on failure; cgan_last_error() returns a
+ *     thread-local message.  No exception or exit() crosses this boundary (the Python wrappers raise
+ *     RuntimeError, mirroring the reference's ValueError/NotImplementedError for unsupported options,
+ *     climategan/blocks.py:95-96,113-114, climategan/norms.py:156-160).
+ */
+#ifndef CLIMATEGAN_HIP_H
+#define CLIMATEGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGAN_ABI_VERSION 1
+
+typedef enum {
+  CGAN_OK = 0,
+  CGAN_ERR_BAD_ARG = -1,      /* null pointer, bad shape, unsupported option */
+  CGAN_ERR_UNSUPPORTED = -2,  /* valid request this build has no kernel for */
+  CGAN_ERR_WORKSPACE = -3,    /* workspace too small */
+  CGAN_ERR_HIP = -4           /* HIP runtime error (launch failure ...) */
+} cgan_status_t;
+
+typedef enum { CGAN_F16 = 0, CGAN_BF16 = 1 } cgan_dtype_t;
+typedef enum { CGAN_ACT_NONE = 0, CGAN_ACT_RELU = 1, CGAN_ACT_LRELU = 2, CGAN_ACT_TANH = 3, CGAN_ACT_SIGMOID = 4 } cgan_act_t;
+typedef enum { CGAN_PAD_ZERO = 0, CGAN_PAD_REFLECT = 1 } cgan_pad_t;
+
+/* storage channels of a C-channel NHWC tensor */
+static inline int cgan_cs(int c) { return (c + 7) & ~7; }
+
+int cgan_version(void);
+const char* cgan_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv2d (NHWC, implicit GEMM on MFMA 16x16x32)
+ * Replaces nn.Conv2d as used by: SPADEResnetBlock conv_0/conv_1/conv_s (climategan/blocks.py:350-353,
+ * 372-375,387-392), PainterSpadeDecoder.fc / conv_img (climategan/painter.py:50,111,152,166),
+ * Conv2dBlock (climategan/blocks.py:117-139), NLayerDiscriminator / get_fc_discriminator convs
+ * (climategan/discriminator.py:100-163,327-349).
+ * y = act( conv(x, w) + bias + residual )
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;             /* cgan_dtype_t */
+  int32_t n, h_in, w_in;     /* LOGICAL input extent (after the optional x2 nearest upsample) */
+  int32_t c_in, c_out;       /* logical channels */
+  int32_t kh, kw, stride, pad, dilation;
+  int32_t pad_mode;          /* cgan_pad_t: zero (nn.ZeroPad2d / padding=) or reflect (nn.ReflectionPad2d) */
+  int32_t h_out, w_out;      /* must equal floor((h_in + 2 pad - dil (k-1) - 1)/stride) + 1 */
+  int32_t in_upsample;       /* 1: x is stored at (h_in/2, w_in/2) and read through nearest x2
+                                (InterpolateNearest2d folded into the consumer, climategan/blocks.py:28-43) */
+  int32_t act;               /* cgan_act_t applied last */
+  float act_slope;           /* LeakyReLU slope (0.2 everywhere in the reference) */
+  int32_t has_bias;
+  int32_t has_residual;      /* add an NHWC tensor with c_out channels at (h_out, w_out) before act */
+  int32_t residual_upsample; /* 1: residual stored at (h_out/2, w_out/2), read through nearest x2 */
+} CganConvDesc;
+
+size_t cgan_conv2d_packed_weight_bytes(const CganConvDesc* d);
+/* w_oihw: fp32 [c_out][c_in][kh][kw].  sigma: optional device scalar; packed = w / *sigma (spectral norm's
+ * w_bar / sigma, climategan/norms.py:112).  bias_out: fp32 [round_up(c_out,16)] zero-padded copy of bias
+ * (bias may be NULL -> zeros). */
+int cgan_conv2d_pack_weight(const float* w_oihw, const float* bias, const float* sigma, void* packed,
+                            float* bias_out, const CganConvDesc* d, void* stream);
+int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const float* bias_padded, const void* residual,
+                         void* y, const CganConvDesc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Instance-norm statistics (biased variance over H*W per (n, c)), nn.InstanceNorm2d(affine=False,
+ * track_running_stats=False): climategan/norms.py:151, climategan/discriminator.py:70-73.
+ * mean, rstd: fp32 [n][cgan_cs(c)], rstd = 1/sqrt(var + eps).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;
+  int32_t n, hw, c;
+  float eps;
+} CganNormStatsDesc;
+size_t cgan_instnorm_stats_workspace_bytes(const CganNormStatsDesc* d);
+int cgan_instnorm_stats(const void* x, float* mean, float* rstd, const CganNormStatsDesc* d, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* y = act((x - mean) * rstd) elementwise (instance norm + LeakyReLU of the PatchGAN,
+ * climategan/discriminator.py:113-154) */
+int cgan_norm_act_apply(const void* x, const float* mean, const float* rstd, void* y, const CganNormStatsDesc* d,
+                        int32_t act, float act_slope, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused SPADE (climategan/norms.py:146-186):
+ *   seg  = nearest_resize(cond, (h, w))                                   norms.py:179
+ *   actv = ReLU(conv3x3(seg; w_shared, b_shared))        [hidden 128]     norms.py:163-168,180
+ *   y    = act( (x - mean) * rstd * (1 + conv3x3(actv; w_gamma)) + conv3x3(actv; w_beta) )   norms.py:181-184
+ * The 128-channel hidden map lives only in LDS.  act = LeakyReLU(0.2) folds SPADEResnetBlock.activation
+ * (climategan/blocks.py:372-373,394-395); act = NONE is the shortcut path (blocks.py:387-392).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;
+  int32_t n, h, w, c;         /* x / y logical shape [n][h][w][c] */
+  int32_t x_upsample;         /* 1: x stored at (h/2, w/2), read through nearest x2 */
+  int32_t cond_h, cond_w, cond_c; /* cond NHWC [n][cond_h][cond_w][cgan_cond_cs(cond_c)] */
+  int32_t hidden;             /* must be 128 (hard-coded in the reference, norms.py:163) */
+  int32_t ksize;              /* must be 3 */
+  int32_t act;                /* CGAN_ACT_NONE or CGAN_ACT_LRELU */
+  float act_slope;
+} CganSpadeDesc;
+/* storage channels of the conditioning tensor: round_up(cond_c, 4) */
+static inline int cgan_cond_cs(int c) { return (c + 3) & ~3; }
+size_t cgan_spade_packed_weight_bytes(const CganSpadeDesc* d);
+/* fp32 OIHW weights as in the state dict: mlp_shared.0.{weight[hidden][cond_c][3][3],bias},
+ * mlp_gamma.{weight[c][hidden][3][3],bias}, mlp_beta.{...} */
+int cgan_spade_pack_weights(const float* w_shared, const float* b_shared, const float* w_gamma, const float* b_gamma,
+                            const float* w_beta, const float* b_beta, void* packed, const CganSpadeDesc* d,
+                            void* stream);
+int cgan_spade_fused_fwd(const void* x, const float* mean, const float* rstd, const void* cond, const void* packed,
+                         void* y, const CganSpadeDesc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectral norm power iteration (climategan/norms.py:100-112), run on every forward:
+ *   v <- l2n(W^T u); u <- l2n(W v); sigma <- u . (W v)        W = w_bar viewed [rows][cols]
+ * u, v are updated IN PLACE (they are nn.Parameters of the wrapped conv in the reference).
+ * workspace: fp32, cgan_spectral_norm_workspace_bytes(rows, cols).
+ * ------------------------------------------------------------------------------------------------ */
+size_t cgan_spectral_norm_workspace_bytes(int32_t rows, int32_t cols);
+int cgan_spectral_norm_power_iter(const float* w_bar, float* u, float* v, float* sigma, int32_t rows, int32_t cols,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge / glue kernels
+ * ------------------------------------------------------------------------------------------------ */
+/* fp32 NCHW [n][c][h][w] -> 16-bit NHWC [n][h][w][cs] (cs >= c, multiple of 4; pad channels zeroed).
+ * If mask != NULL (fp32 [n][1][h][w]) the values are multiplied by (1 - mask): cond = x * (1 - m),
+ * climategan/generator.py:294. */
+int cgan_nchw_to_nhwc(const float* x, const float* mask, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h,
+                      int32_t w, int32_t cs, void* stream);
+/* 16-bit NHWC [n][h][w][cs] -> fp32 NCHW [n][c][h][w].  If paste_x/paste_m != NULL:
+ * out = paste_x * (1 - m) + y * m   (climategan/generator.py:295-296) */
+int cgan_nhwc_to_nchw(const void* y, const float* paste_x, const float* paste_m, float* out, int32_t dtype,
+                      int32_t n, int32_t c, int32_t h, int32_t w, int32_t cs, void* stream);
+/* nearest resize NHWC -> NHWC, legacy rule src = min(floor(dst * in/out), in-1) (F.interpolate
+ * mode="nearest": climategan/painter.py:152, climategan/norms.py:179). cs_in/cs_out storage channels
+ * (cs_out >= c; extra channels zeroed). */
+int cgan_resize_nearest_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                             int32_t cs_in, int32_t h_out, int32_t w_out, int32_t cs_out, void* stream);
+/* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) on NHWC (climategan/discriminator.py:223-225) */
+int cgan_avgpool3x3s2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIMATEGAN_HIP_H */

@@ -1,0 +1,214 @@
+"""GPU parity tests of the individual HIP ops (through the C ABI) against the CPU oracle.
+
+Inputs and weights are first rounded to the 16-bit compute type so that the comparison isolates the
+kernel (accumulation order + output rounding): tolerance 1e-3 * max|ref| for fp16 (2^-11 output rounding),
+8e-3 for bf16 (2^-8 output rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from climategan_amd import fill
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def q(a, dt):
+    """round an fp32 numpy array to the 16-bit type, back to fp32 torch (CPU)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dt).float()
+
+
+def to_nhwc(x_cpu, dt, cs=None):
+    from climategan_amd import ops
+    return ops.nchw_to_nhwc(x_cpu.cuda(), dt, cs=cs)
+
+
+def back(y):
+    from climategan_amd import ops
+    return ops.nhwc_to_nchw(y).cpu()
+
+
+def assert_close(got, ref, dt, what=""):
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= TOL[dt] * scale + 1e-6, "%s: max err %.3g vs scale %.3g (rel %.3g)" % (what, err, scale, err / scale)
+
+
+def test_library_loads_on_gpu():
+    from climategan_amd import _lib
+    assert _lib.load().cgan_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,h,w", [(3, 5, 7), (20, 9, 16), (40, 4, 4)])
+def test_layout_roundtrip(dt, c, h, w):
+    x = q(fill.uniform((2, c, h, w), 3), dt)
+    y = back(to_nhwc(x, dt))
+    assert torch.equal(y, x)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, pad_mode, H, W
+    (8, 16, 3, 1, 1, 1, "zero", 12, 16),
+    (20, 20, 3, 1, 1, 1, "zero", 17, 19),      # channels not multiple of 8, ragged spatial
+    (40, 20, 1, 1, 0, 1, "zero", 16, 16),      # conv_s
+    (3, 32, 3, 1, 1, 1, "zero", 5, 5),         # fc
+    (20, 3, 3, 1, 1, 1, "zero", 16, 24),       # conv_img
+    (4, 16, 4, 2, 1, 1, "zero", 32, 40),       # PatchGAN first conv
+    (16, 32, 4, 1, 1, 1, "zero", 9, 11),       # PatchGAN stride-1 4x4
+    (32, 32, 3, 1, 2, 2, "zero", 14, 14),      # dilated (ResNet layer3)
+    (16, 16, 3, 1, 1, 1, "reflect", 10, 13),   # reflect pad (mask decoder)
+    (64, 128, 3, 1, 1, 1, "zero", 8, 8),       # multi cout tiles, K = 576
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(dt, case):
+    from climategan_amd import ops
+    cin, cout, k, stride, pad, dil, pmode, H, W = case
+    B = 2
+    x = q(fill.uniform((B, cin, H, W), 100 + cin), dt)
+    w = q(fill.uniform((cout, cin, k, k), 200 + cout, -0.2, 0.2), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 300 + cout))
+    xin = F.pad(x, (pad,) * 4, mode="reflect") if pmode == "reflect" else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=0 if pmode == "reflect" else pad, dilation=dil)
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    y = ops.conv2d(to_nhwc(x, dt), pw, stride=stride, pad=pad, dilation=dil,
+                   pad_mode=ops.PAD_REFLECT if pmode == "reflect" else ops.PAD_ZERO)
+    assert y.t.shape == (B, ref.shape[2], ref.shape[3], ops.cs8(cout))
+    assert_close(back(y), ref, dt, "conv %s" % (case,))
+    # pad channels stay zero
+    if ops.cs8(cout) != cout:
+        assert y.t[..., cout:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv2d_epilogue_residual_upsample_act(dt):
+    from climategan_amd import ops
+    B, cin, cout, H, W = 2, 24, 24, 6, 10
+    x = q(fill.uniform((B, cin, H, W), 1), dt)          # stored pre-upsample
+    res = q(fill.uniform((B, cout, H, W), 2), dt)       # stored pre-upsample
+    w = q(fill.uniform((cout, cin, 3, 3), 3, -0.2, 0.2), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 4))
+    xu = cpu_ref.nearest_resize(x, (2 * H, 2 * W))
+    ru = cpu_ref.nearest_resize(res, (2 * H, 2 * W))
+    ref = F.leaky_relu(F.conv2d(xu, w, b, padding=1) + ru, 0.2)
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    y = ops.conv2d(to_nhwc(x, dt), pw, pad=1, act=ops.ACT_LRELU, residual=to_nhwc(res, dt), in_upsample=True,
+                   residual_upsample=True)
+    assert_close(back(y), ref, dt, "conv+res+ups+lrelu")
+    ref_t = torch.tanh(F.conv2d(x, w, b, padding=1))
+    y = ops.conv2d(to_nhwc(x, dt), pw, pad=1, act=ops.ACT_TANH)
+    assert_close(back(y), ref_t, dt, "conv+tanh")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,h,w", [(20, 33, 47), (640, 5, 5), (40, 96, 128)])
+def test_instnorm_stats(dt, c, h, w):
+    from climategan_amd import ops
+    x = q(fill.uniform((2, c, h, w), 7, -1, 3), dt)
+    mean, rstd = ops.instnorm_stats(to_nhwc(x, dt))
+    xd = x.double()
+    rm = xd.mean(dim=(2, 3))
+    rr = 1.0 / torch.sqrt(xd.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert (mean.cpu()[:, :c].double() - rm).abs().max() < 1e-5 * 3
+    assert ((rstd.cpu()[:, :c].double() - rr).abs() / rr).max() < 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_instnorm_stats_large_offset(dt):
+    """mean >> std: the Chan-merged (mean, M2) reduction must not lose the variance."""
+    from climategan_amd import ops
+    x = q(10.0 + 0.05 * fill.uniform((1, 8, 128, 160), 9), dt)
+    mean, rstd = ops.instnorm_stats(to_nhwc(x, dt))
+    xd = x.double()
+    rr = 1.0 / torch.sqrt(xd.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert ((rstd.cpu().double() - rr).abs() / rr).max() < 2e-3
+
+
+SPADE_CASES = [
+    # C, H, W, cond_hw, x_upsample, act
+    (20, 12, 16, (48, 64), False, "none"),
+    (40, 16, 16, (64, 64), False, "lrelu"),
+    (24, 20, 20, (40, 40), False, "lrelu"),     # 20x20: ragged 16-px tiles
+    (16, 10, 12, (40, 48), True, "lrelu"),      # x stored at 5x6, read through the folded upsample
+    (640, 5, 5, (640, 640), False, "lrelu"),    # head_0 shape: channel split across workgroups
+    (20, 40, 48, (40, 48), False, "none"),      # cond already at x resolution
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", SPADE_CASES)
+def test_spade_fused(dt, case):
+    from climategan_amd import ops
+    from helpers import spade_shapes
+    C, H, W, chw, ups, act = case
+    B = 2
+    sd_np = fill.fill_state_dict(spade_shapes("s", C, 3), seed=C + H)
+    sd = {k: q(v, dt) if "weight" in k else torch.from_numpy(v) for k, v in sd_np.items()}
+    xs = q(fill.uniform((B, C, H // 2, W // 2) if ups else (B, C, H, W), 55, -2, 2), dt)
+    seg = q(fill.uniform((B, 3) + chw, 56), dt)
+    x_full = cpu_ref.nearest_resize(xs, (H, W)) if ups else xs
+    # oracle with the hidden map rounded to the compute type, as the kernel stores it in LDS
+    normalized = cpu_ref.instance_norm(x_full)
+    s = cpu_ref.nearest_resize(seg, (H, W))
+    actv = F.relu(F.conv2d(s, sd["s.mlp_shared.0.weight"], sd["s.mlp_shared.0.bias"], padding=1)).to(dt).float()
+    gamma = F.conv2d(actv, sd["s.mlp_gamma.weight"], sd["s.mlp_gamma.bias"], padding=1)
+    beta = F.conv2d(actv, sd["s.mlp_beta.weight"], sd["s.mlp_beta.bias"], padding=1)
+    ref = normalized * (1 + gamma) + beta
+    if act == "lrelu":
+        ref = F.leaky_relu(ref, 0.2)
+    g = {k: v.cuda() for k, v in sd.items()}
+    pk = ops.pack_spade_weights(g["s.mlp_shared.0.weight"], g["s.mlp_shared.0.bias"], g["s.mlp_gamma.weight"],
+                                g["s.mlp_gamma.bias"], g["s.mlp_beta.weight"], g["s.mlp_beta.bias"], dt)
+    xn = to_nhwc(xs, dt)
+    mean, rstd = ops.instnorm_stats(xn)
+    y = ops.spade_fused(xn, mean, rstd, to_nhwc(seg, dt, cs=4), pk, act=ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE,
+                        x_upsample=ups)
+    assert y.t.shape == (B, H, W, ops.cs8(C))
+    assert_close(back(y), ref, dt, "spade %s" % (case,))
+    if ops.cs8(C) != C:
+        assert y.t[..., C:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("rows,cols", [(20, 360), (640, 5760), (1, 8192), (64, 64)])
+def test_spectral_norm(rows, cols):
+    from climategan_amd import ops
+    w = torch.from_numpy(fill.uniform((rows, cols), 1, -0.1, 0.1))
+    u = cpu_ref.l2normalize(torch.from_numpy(fill.uniform((rows,), 2)))
+    v = cpu_ref.l2normalize(torch.from_numpy(fill.uniform((cols,), 3)))
+    _, u_ref, v_ref, s_ref = cpu_ref.spectral_norm_step(w.double(), u.double(), v.double())
+    ug, vg = u.cuda().clone(), v.cuda().clone()
+    sigma = ops.spectral_norm_power_iter(w.cuda(), ug, vg)
+    assert (ug.cpu().double() - u_ref).abs().max() < 1e-5
+    assert (vg.cpu().double() - v_ref).abs().max() < 1e-5
+    assert abs(sigma.item() - s_ref.item()) < 1e-5 * max(1.0, abs(s_ref.item()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_resize_and_avgpool(dt):
+    from climategan_amd import ops
+    x = q(fill.uniform((2, 4, 17, 23), 5), dt)
+    xn = to_nhwc(x, dt)
+    y = back(ops.avgpool3x3s2(xn))
+    ref = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+    assert_close(y, ref, dt, "avgpool")
+    x3 = q(fill.uniform((2, 3, 64, 128), 6), dt)
+    y = back(ops.resize_nearest(to_nhwc(x3, dt, cs=4), (2, 4), cs_out=8))
+    assert torch.equal(y, cpu_ref.nearest_resize(x3, (2, 4)))
+
+
+def test_errors_are_loud():
+    from climategan_amd import ops
+    x = to_nhwc(q(fill.uniform((1, 8, 4, 4), 1), torch.float16), torch.float16)
+    w = torch.zeros(8, 16, 3, 3, device="cuda")
+    pw = ops.pack_conv_weight(w, None, torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, pw, pad=1)  # channel mismatch
+    with pytest.raises(RuntimeError):
+        ops.nchw_to_nhwc(torch.zeros(1, 3, 4, 4), torch.float16)  # CPU tensor: no CPU path

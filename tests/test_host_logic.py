@@ -1,0 +1,97 @@
+"""CPU-side tests: the C-ABI library builds/loads and exports every declared symbol; host-side module
+mirrors keep the reference's state-dict layout and option handling.  No GPU compute here."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from climategan_amd import _lib
+
+    if not _lib.LIB_PATH.exists():
+        import __graft_entry__ as g
+
+        g.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from climategan_amd import _lib
+
+    header = (ROOT / "include" / "climategan_hip.h").read_text()
+    declared = set(re.findall(r"\b(cgan_[a-z0-9_]+)\s*\(", header)) - {"cgan_cs", "cgan_cond_cs"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.cgan_version() == 1
+
+
+def test_host_side_validation_without_gpu(lib):
+    """Descriptor validation runs on the host before any launch: bad arguments return an error code + message."""
+    from climategan_amd._lib import ConvDesc, SpadeDesc
+
+    d = ConvDesc(0, 1, 8, 8, 8, 8, 3, 3, 1, 1, 1, 0, 9, 9, 0, 0, 0.2, 1, 0, 0)  # wrong h_out
+    assert lib.cgan_conv2d_packed_weight_bytes(ctypes.byref(d)) == 0
+    assert b"inconsistent" in lib.cgan_last_error()
+    d = ConvDesc(0, 1, 8, 8, 20, 20, 3, 3, 1, 1, 1, 0, 8, 8, 0, 0, 0.2, 1, 0, 0)
+    # 20 -> 24 storage channels, K = 9*24 = 216 -> 7 k-steps; 24 rows -> 2 cout tiles
+    assert lib.cgan_conv2d_packed_weight_bytes(ctypes.byref(d)) == 2 * 7 * 64 * 16
+    s = SpadeDesc(0, 1, 16, 16, 40, 0, 64, 64, 3, 64, 3, 0, 0.2)  # hidden != 128
+    assert lib.cgan_spade_packed_weight_bytes(ctypes.byref(s)) == 0
+    assert b"hidden must be 128" in lib.cgan_last_error()
+    assert lib.cgan_spectral_norm_workspace_bytes(640, 5760) == (20 * 5760 + 5760 + 640 + 4) * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    from climategan_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.nchw_to_nhwc(torch.zeros(1, 3, 8, 8), torch.float16)
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "climategan_amd").rglob("*.py"):
+        src = f.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_painter_state_dict_layout():
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+    from helpers import painter_shapes
+
+    opts = default_opts()
+    opts.tasks = ["p"]
+    G = create_generator(opts)
+    sd = G.painter.state_dict()
+    assert len(sd) == 229  # SURVEY 8b [probe]
+    assert {k: tuple(v.shape) for k, v in sd.items()} == painter_shapes(640, 7)
+    uv = [k for k, p in G.painter.named_parameters() if k.endswith(("weight_u", "weight_v"))]
+    assert len(uv) == 46 and all(not dict(G.painter.named_parameters())[k].requires_grad for k in uv)
+    assert sum(p.numel() for p in G.painter.parameters()) == 42341735
+    G.painter.set_latent_shape((8, 3, 640, 640), True)
+    assert (G.painter.z_h, G.painter.z_w) == (5, 5)
+    G.painter.set_latent_shape(7, False)
+    assert (G.painter.z_h, G.painter.z_w) == (7, 7)
+
+
+def test_unsupported_options_raise():
+    from climategan_amd.blocks import SPADEResnetBlock
+    from climategan_amd.config import default_opts
+    from climategan_amd.norms import SPADE
+    from climategan_amd.painter import PainterSpadeDecoder
+
+    with pytest.raises(ValueError, match="not a recognized param-free norm"):
+        SPADE("layer", 3, 8, 3)
+    opts = default_opts()
+    opts.gen.p.use_final_shortcut = True
+    with pytest.raises(NotImplementedError):
+        PainterSpadeDecoder(opts)
+    assert SPADEResnetBlock(8, 4, 3, True, "instance", 3).learned_shortcut
