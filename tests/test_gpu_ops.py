@@ -142,6 +142,24 @@ SPADE_CASES = [
 ]
 
 
+def _set_variant(v):
+    import ctypes
+    from climategan_amd import _lib
+    _lib.load().cgan_debug_set_spade_variant(ctypes.c_int(v))
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", [(40, 36, 52, (72, 104), False, "lrelu"), (88, 18, 16, (36, 32), True, "none")])
+def test_spade_fused_tile_variants(variant, case):
+    """Every channel-tiles-per-workgroup instantiation (NCT = 1..5) on multi-tile, ragged images, including
+    a channel count (C=88 -> 11 channel tiles) that leaves a partial last chunk."""
+    _set_variant(variant)
+    try:
+        test_spade_fused(torch.float16, case)
+    finally:
+        _set_variant(0)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", SPADE_CASES)
 def test_spade_fused(dt, case):
