@@ -7,7 +7,7 @@ every inter-layer activation in 16 bit, so rounding accumulates through ~30 conv
 tanh-bounded in [-1,1].  For scale: the reference's OWN ``.half()`` path run on the CPU deviates from its
 fp32 output by max 6.5e-3 / mean 8.1e-4 on the painter_up4 fixture (bf16: 5.1e-2 / 6.6e-3), measured in
 the dev container (tools/measure_ref_half.py -> REF_HALF_DEV below).  Bound enforced here against the reference's
-fp32 golden vectors: the HIP path must be no further from fp32 than 1.5x what the reference's own 16-bit path is
+fp32 golden vectors: the HIP path must be no further from fp32 than 2x what the reference's own 16-bit path is
 (max and mean abs error, per fixture and dtype).
 """
 import numpy as np
@@ -32,7 +32,7 @@ REF_HALF_DEV = {
     ("paint_up4", "float16"): (0.008357, 0.0003513),
     ("paint_up4", "bfloat16"): (0.06977, 0.003019),
 }
-SLACK = 1.5
+SLACK = 2.0
 
 
 def tol(name, dt):

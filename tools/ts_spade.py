@@ -24,12 +24,8 @@ for C, R in [(40, 640), (20, 640)]:
     torch.cuda.synchronize()
     lib.cgan_debug_set_spade_tsbuf(ctypes.c_void_p(0))
     t = ts.cpu().double()
-    names = ["phase0(cond+lut+prm)", "setup", "hidden h0", "main h0", "barrier", "hidden h1", "main h1", "epilogue"]
-    # timestamps: 0 start,1 after phase0,2 after hidden h0,3 after main h0,4 after hidden h1 (incl. barrier),5 after main h1,6 end
-    d = {
-        "phase0": t[:, 1] - t[:, 0], "hidden h0": t[:, 2] - t[:, 1], "main h0": t[:, 3] - t[:, 2],
-        "barrier+hidden h1": t[:, 4] - t[:, 3], "main h1": t[:, 5] - t[:, 4], "epilogue": t[:, 6] - t[:, 5],
-        "total": t[:, 6] - t[:, 0],
-    }
+    # timestamps: 0 start, 1 after phase 0, 2 after hidden quarter 0, 5 after the K loop, 6 end
+    d = {"phase0": t[:, 1] - t[:, 0], "hidden q0": t[:, 2] - t[:, 1], "K loop": t[:, 5] - t[:, 2],
+         "epilogue": t[:, 6] - t[:, 5], "total": t[:, 6] - t[:, 0]}
     span = (t[:, 6].max() - t[:, 0].min()).item()
     print("C=%d: kernel span %.0f ticks; per-WG mean ticks:" % (C, span), {k: int(v.mean().item()) for k, v in d.items()})
