@@ -160,22 +160,72 @@ def cpu_baseline(sd):
     from climategan_amd import fill
     from oracle import cpu_ref
 
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
     x = torch.from_numpy(fill.uniform((1, 3, H, W), seed=1))
     m = torch.from_numpy(fill.rect_mask(1, H, W, seed=2))
     sdc = {k: v.clone() for k, v in sd.items()}
     z = H // 2 ** N_UP
-    with torch.no_grad():
-        cpu_ref.paint(sdc, m, x, z, z)  # warm-up
-        runs = 3
-        t0 = time.perf_counter()
-        for _ in range(runs):
-            cpu_ref.paint(sdc, m, x, z, z)
-        dt = time.perf_counter() - t0
-    return {"value": round(runs / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+    ncpu = os.cpu_count() or 1
+    best = None
+    # torch's intra-op threading stops scaling on this workload well before a 2-socket host's thread count
+    # (256 threads: 77 s/image; 8 threads: 1.6 s/image on the same box), so report the best of a short sweep
+    for threads in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            cpu_ref.paint(sdc, m, x, z, z)  # warm-up
+            runs = 2
+            t0 = time.perf_counter()
+            for _ in range(runs):
+                cpu_ref.paint(sdc, m, x, z, z)
+            dt = (time.perf_counter() - t0) / runs
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    dt, threads = best
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "oracle.cpu_ref.paint (torch fp32 CPU restatement of generator.py:279-297), bs=1 640x640, "
-                      "%d runs after 1 warm-up, %d threads" % (runs, threads)}
+                      "best of {8,16,32} torch threads (2 runs after 1 warm-up each) on a %d-thread host" % ncpu}
+
+
+def timed_steps(step, steps, warmup, barrier):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier() on both sides."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(elapsed, dist, device):
+    """Whole-job time = the slowest rank's (the only collective on this path)."""
+    if dist is None:
+        return elapsed
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return el.item()
+
+
+def result_line(world, steps, warmup, elapsed, dtype_name):
+    return {
+        "metric": "640x640 images/sec, Painter (SPADE generator) forward, batch 8 per GPU",
+        "value": round(world * BATCH_PER_GPU * steps / elapsed, 3),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype_name,
+        "data": "synthetic (counter-hash fill: U(-1,1) images, 3-rectangle masks ~35%, untrained weights "
+                "with torch-default conv init ranges)",
+        "config": {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 "
+                               "(OmniGenerator.paint incl. mask, spectral-norm power iterations, paste)",
+                   "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
+                   "latent_dim": LATENT, "spade_n_up": N_UP, "parallelism": "independent replicas, image-sharded"},
+    }
 
 
 def main():
@@ -215,23 +265,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = {}
+
+    def step():
+        out["y"] = G.paint(m, x)
+
+    def timed_step():
+        timer.enabled = True
+        step()
+
     with torch.no_grad():
         for _ in range(args.warmup):
-            G.paint(m, x)
-        barrier()
-        timer.enabled = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = G.paint(m, x)
-        barrier()
-        elapsed = time.perf_counter() - t0
+            step()
+        elapsed = timed_steps(timed_step, args.steps, 0, barrier)
         timer.enabled = False
-    assert out.shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(out).all()
-
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = el.item()
+    y = out["y"]
+    assert y.shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(y).all()
+    elapsed = max_over_ranks(elapsed, dist, device)
 
     if rank == 0:
         layers, flops_img = spade_layer_table(LATENT, N_UP, H, W)
@@ -239,24 +289,8 @@ def main():
         n_launch = len(timer.pairs)
         flops_step = flops_img * BATCH_PER_GPU
         achieved = flops_step * args.steps / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0
-        res = {
-            "metric": "640x640 images/sec, Painter (SPADE generator) forward, batch 8 per GPU",
-            "value": round(world * BATCH_PER_GPU * args.steps / elapsed, 3),
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic (counter-hash fill: U(-1,1) images, 3-rectangle masks ~35%, untrained weights "
-                    "with torch-default conv init ranges)",
-            "config": {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 "
-                                   "(OmniGenerator.paint incl. mask, spectral-norm power iterations, paste)",
-                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
-                       "latent_dim": LATENT, "spade_n_up": N_UP, "parallelism": "independent replicas, image-sharded"},
+        res = result_line(world, args.steps, args.warmup, elapsed, args.dtype)
+        res.update({
             "roofline": {
                 "bound": "mfma",
                 "kernel": "spade_fused_kernel (23 launches/step: all SPADE layers of the Painter)",
@@ -270,7 +304,7 @@ def main():
                 "avg_launch_ms": round(spade_ms / max(n_launch, 1), 4),
                 "share_of_step": round(spade_ms / (elapsed * 1e3), 3),
             },
-        }
+        })
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
         else:
