@@ -40,6 +40,17 @@ class SpadeDesc(C.Structure):
     ]
 
 
+class SnItem(C.Structure):
+    _fields_ = [("w_bar", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
+                ("workspace", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("w_oihw", C.c_void_p), ("bias", C.c_void_p), ("sigma", C.c_void_p), ("packed", C.c_void_p),
+                ("bias_out", C.c_void_p), ("c_out", C.c_int32), ("c_in", C.c_int32), ("kh", C.c_int32),
+                ("kw", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -48,6 +59,7 @@ _SIGNATURES = {
     "cgan_conv2d_packed_weight_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "cgan_conv2d_pack_weight": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_conv2d_pack_weight_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_instnorm_stats_workspace_bytes": (C.c_size_t, [C.POINTER(NormStatsDesc)]),
     "cgan_instnorm_stats": (C.c_int, [_P, _P, _P, C.POINTER(NormStatsDesc), _P, C.c_size_t, _P]),
     "cgan_norm_act_apply": (C.c_int, [_P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P]),
@@ -56,6 +68,7 @@ _SIGNATURES = {
     "cgan_spade_fused_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
     "cgan_spectral_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cgan_spectral_norm_power_iter": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    "cgan_spectral_norm_power_iter_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_nchw_to_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_nhwc_to_nchw": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_resize_nearest_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -205,6 +205,44 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
   }
 }
 
+// batched: blockIdx.y = layer
+template <typename T>
+__global__ void pack_conv_weight_batched_kernel(const CganPackItem* __restrict__ items) {
+  const CganPackItem it = items[blockIdx.y];
+  const int cin_s = (it.c_in + 7) & ~7;
+  const int cout_s = (it.c_out + 7) & ~7;
+  const int ctiles = (cout_s + 15) / 16;
+  const int taps = it.kh * it.kw;
+  const int ksteps = (taps * (cin_s / 8) + 3) / 4;
+  const int total = ctiles * ksteps * 64;
+  const float inv = it.sigma ? 1.f / it.sigma[0] : 1.f;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int lane = idx & 63;
+    int ks = (idx >> 6) % ksteps;
+    int ct = (idx >> 6) / ksteps;
+    int co = ct * 16 + (lane & 15);
+    int k0 = ks * 32 + (lane >> 4) * 8;
+    uint16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int k = k0 + e;
+      int tap = k / cin_s;
+      int c = k - tap * cin_s;
+      float v = 0.f;
+      if (co < it.c_out && tap < taps && c < it.c_in) v = it.w_oihw[((size_t)co * it.c_in + c) * taps + tap] * inv;
+      o[e] = bits_of<T>(v);
+    }
+    u32x4 pk;
+    pk[0] = o[0] | ((uint32_t)o[1] << 16);
+    pk[1] = o[2] | ((uint32_t)o[3] << 16);
+    pk[2] = o[4] | ((uint32_t)o[5] << 16);
+    pk[3] = o[6] | ((uint32_t)o[7] << 16);
+    reinterpret_cast<u32x4*>(it.packed)[idx] = pk;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ctiles * 16; i += gridDim.x * blockDim.x)
+    it.bias_out[i] = (it.bias && i < it.c_out) ? it.bias[i] : 0.f;
+}
+
 int fill_params(ConvParams& p, const CganConvDesc* d) {
   CGAN_REQUIRE(d != nullptr, "conv2d: null descriptor");
   CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d: bad dtype %d", d->dtype);
@@ -286,6 +324,20 @@ extern "C" int cgan_conv2d_pack_weight(const float* w_oihw, const float* bias, c
     hipLaunchKernelGGL(pack_conv_weight_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
                        (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_s, d->kh, d->kw, p.ctiles, p.ksteps);
   CGAN_CHECK_LAUNCH("conv2d_pack_weight");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t count, int32_t dtype,
+                                               int32_t max_fragments, void* stream) {
+  CGAN_REQUIRE(items_device && count > 0 && max_fragments > 0, "conv2d_pack_weight_batched: bad arguments");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "conv2d_pack_weight_batched: bad dtype %d", dtype);
+  const int blocks = ceil_div(max_fragments, 256) < 512 ? ceil_div(max_fragments, 256) : 512;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(pack_conv_weight_batched_kernel<F16>, dim3(blocks, count), dim3(256), 0, s, items_device);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_batched_kernel<BF16>, dim3(blocks, count), dim3(256), 0, s, items_device);
+  CGAN_CHECK_LAUNCH("conv2d_pack_weight_batched");
   return CGAN_OK;
 }
 

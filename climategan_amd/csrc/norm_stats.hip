@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int STATS_THREADS = 256;
-constexpr int STATS_PIX_PER_BLOCK = 2048;  // pixels per block (per channel-group block)
+constexpr int STATS_PIX_PER_BLOCK = 8192;  // pixels per block (per channel-group block)
 
 struct MeanM2 {
   float n, mean, m2;

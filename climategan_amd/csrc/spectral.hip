@@ -82,7 +82,89 @@ __global__ __launch_bounds__(1024) void sn_finalize_kernel(const float* __restri
   if (threadIdx.x == 0) sigma[0] = ns2 * inv_u;
 }
 
+// ---- batched variants: blockIdx.z = layer, table of CganSnItem in device memory.  Same arithmetic, same
+// summation order as the single-layer kernels (results are bit-identical), 4 launches for ALL layers.
+__global__ __launch_bounds__(256) void sn_wt_u_batched(const CganSnItem* __restrict__ items) {
+  const CganSnItem it = items[blockIdx.z];
+  int k = blockIdx.x * 256 + threadIdx.x;
+  int r0 = blockIdx.y * SN_ROWS_PER_CHUNK;
+  if (r0 >= it.rows || k >= it.cols) return;
+  int r1 = min(it.rows, r0 + SN_ROWS_PER_CHUNK);
+  float acc = 0.f;
+  for (int o = r0; o < r1; ++o) acc += it.w_bar[(size_t)o * it.cols + k] * it.u[o];
+  it.workspace[(size_t)blockIdx.y * it.cols + k] = acc;
+}
+
+__global__ __launch_bounds__(1024) void sn_reduce_t_batched(const CganSnItem* __restrict__ items) {
+  __shared__ float sm[16];
+  const CganSnItem it = items[blockIdx.x];
+  const int rchunks = (it.rows + SN_ROWS_PER_CHUNK - 1) / SN_ROWS_PER_CHUNK;
+  float* t = it.workspace + (size_t)rchunks * it.cols;
+  float* scal = t + it.cols + it.rows;
+  float sq = 0.f;
+  for (int k = threadIdx.x; k < it.cols; k += blockDim.x) {
+    float acc = 0.f;
+    for (int rc = 0; rc < rchunks; ++rc) acc += it.workspace[(size_t)rc * it.cols + k];
+    t[k] = acc;
+    sq += acc * acc;
+  }
+  float tot = block_sum(sq, sm);
+  if (threadIdx.x == 0) scal[0] = tot;
+}
+
+__global__ __launch_bounds__(256) void sn_w_t_batched(const CganSnItem* __restrict__ items) {
+  const CganSnItem it = items[blockIdx.y];
+  int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (o >= it.rows) return;
+  const int rchunks = (it.rows + SN_ROWS_PER_CHUNK - 1) / SN_ROWS_PER_CHUNK;
+  const float* t = it.workspace + (size_t)rchunks * it.cols;
+  float* r = it.workspace + (size_t)rchunks * it.cols + it.cols;
+  const float* wr = it.w_bar + (size_t)o * it.cols;
+  float acc = 0.f;
+  for (int k = lane; k < it.cols; k += 64) acc += wr[k] * t[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) r[o] = acc;
+}
+
+__global__ __launch_bounds__(1024) void sn_finalize_batched(const CganSnItem* __restrict__ items) {
+  __shared__ float sm[16];
+  const CganSnItem it = items[blockIdx.x];
+  const int rchunks = (it.rows + SN_ROWS_PER_CHUNK - 1) / SN_ROWS_PER_CHUNK;
+  const float* t = it.workspace + (size_t)rchunks * it.cols;
+  const float* r = t + it.cols;
+  const float* scal = r + it.rows;
+  const float inv_v = 1.f / (sqrtf(scal[0]) + SN_EPS);
+  for (int k = threadIdx.x; k < it.cols; k += blockDim.x) it.v[k] = t[k] * inv_v;
+  float sq = 0.f;
+  for (int o = threadIdx.x; o < it.rows; o += blockDim.x) {
+    float s = r[o] * inv_v;
+    sq += s * s;
+  }
+  float ns2 = block_sum(sq, sm);
+  float inv_u = 1.f / (sqrtf(ns2) + SN_EPS);
+  for (int o = threadIdx.x; o < it.rows; o += blockDim.x) it.u[o] = r[o] * inv_v * inv_u;
+  if (threadIdx.x == 0) it.sigma[0] = ns2 * inv_u;
+}
+
 }  // namespace
+
+extern "C" int cgan_spectral_norm_power_iter_batched(const CganSnItem* items_device, int32_t count, int32_t max_rows,
+                                                     int32_t max_cols, void* stream) {
+  CGAN_REQUIRE(items_device && count > 0 && max_rows > 0 && max_cols > 0, "spectral_norm_batched: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int rchunks = ceil_div(max_rows, SN_ROWS_PER_CHUNK);
+  hipLaunchKernelGGL(sn_wt_u_batched, dim3(ceil_div(max_cols, 256), rchunks, count), dim3(256), 0, s, items_device);
+  CGAN_CHECK_LAUNCH("spectral_norm_batched(W^T u)");
+  hipLaunchKernelGGL(sn_reduce_t_batched, dim3(count), dim3(1024), 0, s, items_device);
+  CGAN_CHECK_LAUNCH("spectral_norm_batched(reduce t)");
+  hipLaunchKernelGGL(sn_w_t_batched, dim3(ceil_div(max_rows, 4), count), dim3(256), 0, s, items_device);
+  CGAN_CHECK_LAUNCH("spectral_norm_batched(W t)");
+  hipLaunchKernelGGL(sn_finalize_batched, dim3(count), dim3(1024), 0, s, items_device);
+  CGAN_CHECK_LAUNCH("spectral_norm_batched(finalize)");
+  return CGAN_OK;
+}
 
 extern "C" size_t cgan_spectral_norm_workspace_bytes(int32_t rows, int32_t cols) {
   if (rows <= 0 || cols <= 0) return 0;

@@ -68,8 +68,18 @@ class SpectralNorm(nn.Module):
             module.register_parameter(name + "_v", nn.Parameter(v, requires_grad=False))
             module.register_parameter(name + "_bar", nn.Parameter(w.data))
 
+    _prepacked = None  # set for ONE use by spectral_norm_step_all() (batched power iteration + pack)
+
+    def sn_params(self):
+        m = self.module
+        return (getattr(m, self.name + "_bar").data, getattr(m, self.name + "_u").data,
+                getattr(m, self.name + "_v").data, m.bias.data if m.bias is not None else None)
+
     def packed(self, dtype) -> ops.PackedConv:
         """Power-iterate (updates u, v) and return w_bar / sigma packed for the MFMA conv kernel."""
+        pre, self._prepacked = self._prepacked, None
+        if pre is not None and pre.dtype == dtype:
+            return pre
         m = self.module
         w_bar = getattr(m, self.name + "_bar")
         u = getattr(m, self.name + "_u")
@@ -157,3 +167,20 @@ class SPADE(nn.Module):
         xs = ops.nchw_to_nhwc(x, dt)
         cond = ops.nchw_to_nhwc(segmap, dt, cs=ops.cs4(segmap.shape[1]))
         return ops.nhwc_to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
+
+
+def spectral_norm_step_all(root: nn.Module, dtype) -> None:
+    """Run this forward's power iteration + ``w_bar / sigma`` re-pack for EVERY SpectralNorm under ``root`` in
+    five launches (ops.SpectralNormGroup).  Each wrapper then consumes its pre-packed weight exactly once in
+    ``packed()``; a wrapper called again within the same forward falls back to its own per-layer iteration, so
+    the reference's "one power iteration per call" semantics (norms.py:141-143) hold."""
+    sns = [m for m in root.modules() if isinstance(m, SpectralNorm)]
+    if not sns:
+        return
+    params = [m.sn_params() for m in sns]
+    grp = getattr(root, "_sn_group", None)
+    if grp is None or not grp.matches(params, dtype):
+        grp = ops.SpectralNormGroup(params, dtype)
+        object.__setattr__(root, "_sn_group", grp)
+    for m, pk in zip(sns, grp.step()):
+        m._prepacked = pk

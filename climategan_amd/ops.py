@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CGAN_BF16, CGAN_F16, PAD_REFLECT,  # noqa: F401
-                   PAD_ZERO, ConvDesc, NormStatsDesc, SpadeDesc)
+                   PAD_ZERO, ConvDesc, NormStatsDesc, PackItem, SnItem, SpadeDesc)
 
 _DT = {torch.float16: CGAN_F16, torch.bfloat16: CGAN_BF16}
 
@@ -265,3 +265,74 @@ def spectral_norm_power_iter(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tens
     _lib.check(lib.cgan_spectral_norm_power_iter(_ptr(w_bar), _ptr(u), _ptr(v), _ptr(sigma), rows, cols, _ptr(ws),
                                                  ws_bytes, _stream()), "cgan_spectral_norm_power_iter")
     return sigma
+
+
+class SpectralNormGroup:
+    """All spectral-norm convs of a network, power-iterated and re-packed together: 4 + 1 launches per forward
+    instead of 5 per layer.  Semantics are those of the per-layer path (reference norms.py:100-112,141-143: one
+    power iteration per wrapped conv per forward, u/v updated in place, conv weight = w_bar / sigma); the
+    arithmetic is bit-identical to ``spectral_norm_power_iter`` + ``pack_conv_weight``.
+
+    ``params``: list of (w_bar, u, v, bias-or-None) fp32 device tensors.  Device-side tables, the workspace and
+    the packed-weight buffers are allocated once and reused; they are rebuilt if a parameter moves.
+    """
+
+    def __init__(self, params, dtype: torch.dtype):
+        self.dtype = dtype
+        self.key = self._key(params, dtype)
+        lib = _lib.load()
+        dev = params[0][0].device
+        n = len(params)
+        self.n = n
+        self.sigma = torch.empty(n, dtype=torch.float32, device=dev)
+        ws_sizes = []
+        self.packed = []
+        self.max_rows = self.max_cols = self.max_frag = 0
+        for (w_bar, u, v, bias) in params:
+            _need_cuda(w_bar, u, v, bias)
+            for t in (w_bar, u, v, bias):
+                if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                    raise RuntimeError("SpectralNormGroup: contiguous fp32 parameters expected")
+            rows = w_bar.shape[0]
+            cols = w_bar.numel() // rows
+            self.max_rows, self.max_cols = max(self.max_rows, rows), max(self.max_cols, cols)
+            ws_sizes.append(lib.cgan_spectral_norm_workspace_bytes(rows, cols))
+            c_out, c_in, kh, kw = w_bar.shape
+            d = _conv_desc(_DT[dtype], 1, kh, kw, c_in, c_out, kh, kw, 1, 0, 1, PAD_ZERO)
+            nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
+            self.max_frag = max(self.max_frag, nbytes // 16)
+            pw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            bo = torch.empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=dev)
+            self.packed.append(PackedConv(pw, bo, c_in, c_out, kh, kw, bias is not None, dtype))
+        offs = [0]
+        for sz in ws_sizes:
+            offs.append(offs[-1] + (sz + 255) // 256 * 256)
+        self.ws = torch.empty(offs[-1], dtype=torch.uint8, device=dev)
+        sn_items = (SnItem * n)()
+        pk_items = (PackItem * n)()
+        for i, (w_bar, u, v, bias) in enumerate(params):
+            rows = w_bar.shape[0]
+            sig = self.sigma.data_ptr() + 4 * i
+            sn_items[i] = SnItem(w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), sig, self.ws.data_ptr() + offs[i], rows,
+                                 w_bar.numel() // rows)
+            c_out, c_in, kh, kw = w_bar.shape
+            pk_items[i] = PackItem(w_bar.data_ptr(), bias.data_ptr() if bias is not None else 0, sig,
+                                   self.packed[i].w.data_ptr(), self.packed[i].bias.data_ptr(), c_out, c_in, kh, kw)
+        self.sn_table = torch.frombuffer(bytearray(bytes(sn_items)), dtype=torch.uint8).to(dev)
+        self.pk_table = torch.frombuffer(bytearray(bytes(pk_items)), dtype=torch.uint8).to(dev)
+
+    @staticmethod
+    def _key(params, dtype):
+        return tuple((t.data_ptr() if t is not None else 0) for ps in params for t in ps) + (dtype,)
+
+    def matches(self, params, dtype):
+        return self.key == self._key(params, dtype)
+
+    def step(self):
+        """One power iteration of every layer (u, v updated in place) + re-pack of every w_bar / sigma."""
+        lib = _lib.load()
+        _lib.check(lib.cgan_spectral_norm_power_iter_batched(_ptr(self.sn_table), self.n, self.max_rows, self.max_cols,
+                                                             _stream()), "cgan_spectral_norm_power_iter_batched")
+        _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(self.pk_table), self.n, _DT[self.dtype], self.max_frag,
+                                                       _stream()), "cgan_conv2d_pack_weight_batched")
+        return self.packed

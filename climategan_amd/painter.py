@@ -9,7 +9,8 @@ import torch.nn as nn
 
 from . import ops
 from .blocks import InterpolateNearest2d, SPADEResnetBlock
-from .norms import DEFAULT_COMPUTE_DTYPE, SpectralNorm, _grad_guard, _PackCache, conv_forward
+from .norms import (DEFAULT_COMPUTE_DTYPE, SpectralNorm, _grad_guard, _PackCache, conv_forward,  # noqa: F401
+                    spectral_norm_step_all)
 
 
 def create_painter(opts, no_init=False, verbose=0):
@@ -69,6 +70,7 @@ class PainterSpadeDecoder(nn.Module):
     def forward_nhwc(self, z, cond: ops.NHWC) -> ops.NHWC:
         """cond: NHWC (3 channels stored as 4).  Returns tanh(conv_img(...)) as NHWC (3 channels stored as 8)."""
         _grad_guard(self)
+        spectral_norm_step_all(self, cond.t.dtype)   # all 23 power iterations + w_bar/sigma packs, batched
         if z is None:
             assert self.z_h is not None and self.z_w is not None
             zin = ops.resize_nearest(cond, (self.z_h, self.z_w), cs_out=8)       # painter.py:152

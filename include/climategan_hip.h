@@ -83,6 +83,19 @@ int cgan_conv2d_pack_weight(const float* w_oihw, const float* bias, const float*
                             float* bias_out, const CganConvDesc* d, void* stream);
 int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const float* bias_padded, const void* residual,
                          void* y, const CganConvDesc* d, void* stream);
+/* Batched weight packing: one launch for `count` layers (e.g. the 23 spectral-norm convs of the Painter, whose
+ * w_bar / sigma changes every forward).  `items_device` is a DEVICE array of CganPackItem; `max_fragments` =
+ * max over layers of cgan_conv2d_packed_weight_bytes / 16. */
+typedef struct {
+  const float* w_oihw;   /* fp32 [c_out][c_in][kh][kw] */
+  const float* bias;     /* fp32 [c_out] or NULL */
+  const float* sigma;    /* device scalar or NULL */
+  void* packed;          /* cgan_conv2d_packed_weight_bytes */
+  float* bias_out;       /* fp32 [round_up(round_up(c_out,8),16)] */
+  int32_t c_out, c_in, kh, kw;
+} CganPackItem;
+int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t count, int32_t dtype,
+                                    int32_t max_fragments, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Instance-norm statistics (biased variance over H*W per (n, c)), nn.InstanceNorm2d(affine=False,
@@ -140,6 +153,19 @@ int cgan_spade_fused_fwd(const void* x, const float* mean, const float* rstd, co
 size_t cgan_spectral_norm_workspace_bytes(int32_t rows, int32_t cols);
 int cgan_spectral_norm_power_iter(const float* w_bar, float* u, float* v, float* sigma, int32_t rows, int32_t cols,
                                   void* workspace, size_t workspace_bytes, void* stream);
+/* Batched: the power iteration of `count` layers in 4 launches (the reference runs one per wrapped conv per forward:
+ * 23 in the Painter, norms.py:141-143).  `items_device` is a DEVICE array; each item's workspace holds
+ * cgan_spectral_norm_workspace_bytes(rows, cols).  Bit-identical to the single-layer entry point. */
+typedef struct {
+  const float* w_bar;
+  float* u;
+  float* v;
+  float* sigma;
+  float* workspace;
+  int32_t rows, cols;
+} CganSnItem;
+int cgan_spectral_norm_power_iter_batched(const CganSnItem* items_device, int32_t count, int32_t max_rows,
+                                          int32_t max_cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Edge / glue kernels

@@ -230,3 +230,26 @@ def test_errors_are_loud():
         ops.conv2d(x, pw, pad=1)  # channel mismatch
     with pytest.raises(RuntimeError):
         ops.nchw_to_nhwc(torch.zeros(1, 3, 4, 4), torch.float16)  # CPU tensor: no CPU path
+
+
+def test_spectral_norm_group_equals_per_layer():
+    """Batched power iteration + batched pack (5 launches for all layers) is bit-identical to the per-layer path."""
+    from climategan_amd import ops
+    shapes = [(20, 40, 3, 3), (640, 64, 3, 3), (24, 40, 1, 1), (1, 32, 4, 4)]
+    params_a, params_b = [], []
+    for i, shp in enumerate(shapes):
+        w = torch.from_numpy(fill.uniform(shp, 10 + i, -0.1, 0.1)).cuda()
+        u = cpu_ref.l2normalize(torch.from_numpy(fill.uniform((shp[0],), 20 + i))).cuda()
+        v = cpu_ref.l2normalize(torch.from_numpy(fill.uniform((shp[1] * shp[2] * shp[3],), 30 + i))).cuda()
+        b = torch.from_numpy(fill.uniform((shp[0],), 40 + i)).cuda() if i != 2 else None
+        params_a.append((w, u.clone(), v.clone(), b))
+        params_b.append((w, u.clone(), v.clone(), b))
+    grp = ops.SpectralNormGroup(params_a, torch.float16)
+    for _ in range(2):  # two forwards: state carries over
+        packed = grp.step()
+        for (w, u, v, b), pk in zip(params_b, packed):
+            sigma = ops.spectral_norm_power_iter(w, u, v)
+            ref = ops.pack_conv_weight(w, b, torch.float16, sigma)
+            assert torch.equal(ref.w, pk.w) and torch.equal(ref.bias, pk.bias)
+        for (wa, ua, va, _), (wb, ub, vb, _) in zip(params_a, params_b):
+            assert torch.equal(ua, ub) and torch.equal(va, vb)
