@@ -40,7 +40,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
   return i;
 }
 
-template <typename T, int CT, int PT>
+template <typename T, int CT, int PT, bool PIPE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -79,18 +79,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     if (++kx == p.kw) { kx = 0; ++ky; }
   }
 
-  for (int ks = 0; ks < p.ksteps; ++ks) {
+  // operand fetch of one k-step (A: packed weights [ctile][ks][lane] x 16 B; B: 8 channels of the tap-shifted
+  // input pixel), then advance this lane's K group by 4
+  auto fetch = [&](int ks, u32x4 (&a)[CT], u32x4 (&b)[PT]) {
     const bool kvalid = (ks * 4 + g) < p.kgroups;
-    // ---- A fragments (packed weights): [ctile][ks][lane] x 16 B
-    u32x4 a[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       int ct = ctile0 + c;
       a[c] = (u32x4){0u, 0u, 0u, 0u};
       if (ct < p.ctiles) a[c] = p.w[((size_t)ct * p.ksteps + ks) * 64 + lane];
     }
-    // ---- B fragments: 8 channels of the tap-shifted input pixel
-    u32x4 b[PT];
     const int dy = ky * p.dil, dx = kx * p.dil;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -109,17 +107,39 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         b[t] = *reinterpret_cast<const u32x4*>(p.x + off);
       }
     }
+    c8 += 4;
+    while (c8 >= p.cg) {
+      c8 -= p.cg;
+      if (++kx == p.kw) { kx = 0; ++ky; }
+    }
+  };
+  auto mma = [&](const u32x4 (&a)[CT], const u32x4 (&b)[PT]) {
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int t = 0; t < PT; ++t)
         acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(b[t]), acc[c][t]);
+  };
 
-    // advance this lane's K group by 4
-    c8 += 4;
-    while (c8 >= p.cg) {
-      c8 -= p.cg;
-      if (++kx == p.kw) { kx = 0; ++ky; }
+  if (PIPE) {
+    // software pipeline: the loads of k-step ks+1 are in flight while the MFMAs of k-step ks execute (operands
+    // come from L1/L2: ~500+ cycles, which a small grid cannot hide by occupancy alone; on large grids the extra
+    // registers cost more occupancy than the pipelining buys, so those use the plain loop)
+    u32x4 a0[CT], b0[PT], a1[CT], b1[PT];
+    fetch(0, a0, b0);
+    int ks = 0;
+    for (; ks + 2 <= p.ksteps; ks += 2) {
+      fetch(ks + 1, a1, b1);
+      mma(a0, b0);
+      if (ks + 2 < p.ksteps) fetch(ks + 2, a0, b0);
+      mma(a1, b1);
+    }
+    if (ks < p.ksteps) mma(a0, b0);
+  } else {
+    for (int ks = 0; ks < p.ksteps; ++ks) {
+      u32x4 a[CT], b[PT];
+      fetch(ks, a, b);
+      mma(a, b);
     }
   }
 
@@ -282,22 +302,34 @@ void launch_ct(const ConvParams& p, hipStream_t s) {
   const int gy = ceil_div(p.ctiles, CT);
   // enough blocks to fill 256 CUs: shrink the per-wave pixel register tile for small problems
   if ((long)ceil_div(ptiles, 16) * gy >= 512) {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 4>), dim3(ceil_div(ptiles, 16), gy), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 4, false>), dim3(ceil_div(ptiles, 16), gy), dim3(256), 0, s, p);
   } else if ((long)ceil_div(ptiles, 8) * gy >= 512) {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 2>), dim3(ceil_div(ptiles, 8), gy), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 2, false>), dim3(ceil_div(ptiles, 8), gy), dim3(256), 0, s, p);
+  } else if ((long)ceil_div(ptiles, 4) * gy >= 2048) {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1, false>), dim3(ceil_div(ptiles, 4), gy), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1>), dim3(ceil_div(ptiles, 4), gy), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1, true>), dim3(ceil_div(ptiles, 4), gy), dim3(256), 0, s, p);
   }
 }
 
 template <typename T>
 void launch(const ConvParams& p, hipStream_t s) {
-  if (p.ctiles >= 4 && p.ctiles % 4 == 0) launch_ct<T, 4>(p, s);
-  else if (p.ctiles % 3 == 0) launch_ct<T, 3>(p, s);
-  else if (p.ctiles % 2 == 0) launch_ct<T, 2>(p, s);
-  else if (p.ctiles == 1) launch_ct<T, 1>(p, s);
-  else if (p.ctiles == 5) launch_ct<T, 3>(p, s);
-  else launch_ct<T, 4>(p, s);
+  // channel tiles per workgroup: as many as divide ctiles (more reuse of the gathered B fragments), unless the
+  // grid would then be too small to fill the chip (few pixels, many channels: the 5x5..20x20 Painter layers)
+  const long pblocks = ceil_div(ceil_div(p.npix, 16), 4);
+  int ct = 1;
+  if (p.ctiles >= 4 && p.ctiles % 4 == 0) ct = 4;
+  else if (p.ctiles % 3 == 0) ct = 3;
+  else if (p.ctiles % 2 == 0) ct = 2;
+  else if (p.ctiles == 5) ct = 3;
+  else if (p.ctiles > 1) ct = 4;
+  while (ct > 1 && pblocks * ceil_div(p.ctiles, ct) < 512) --ct;
+  switch (ct) {
+    case 4: launch_ct<T, 4>(p, s); break;
+    case 3: launch_ct<T, 3>(p, s); break;
+    case 2: launch_ct<T, 2>(p, s); break;
+    default: launch_ct<T, 1>(p, s); break;
+  }
 }
 
 }  // namespace

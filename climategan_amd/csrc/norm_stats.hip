@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int STATS_THREADS = 256;
-constexpr int STATS_PIX_PER_BLOCK = 8192;  // pixels per block (per channel-group block)
+constexpr int STATS_MAX_PIX_PER_BLOCK = 2048;  // pixels per block (per channel-group block), upper bound
 
 struct MeanM2 {
   float n, mean, m2;
@@ -20,10 +20,11 @@ __device__ __forceinline__ MeanM2 chan_merge(MeanM2 a, MeanM2 b) {
   if (a.n == 0.f) return b;
   float n = a.n + b.n;
   float d = b.mean - a.mean;
+  float w = b.n * __frcp_rn(n);   // counts are small integers: the 1-ulp reciprocal is ample
   MeanM2 r;
   r.n = n;
-  r.mean = a.mean + d * (b.n / n);
-  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / n);
+  r.mean = a.mean + d * w;
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * w);
   return r;
 }
 
@@ -31,7 +32,7 @@ __device__ __forceinline__ MeanM2 chan_merge(MeanM2 a, MeanM2 b) {
 template <typename T>
 __global__ __launch_bounds__(STATS_THREADS) void instnorm_partial_kernel(const uint16_t* __restrict__ x,
                                                                         float* __restrict__ partial, int hw, int cs,
-                                                                        int chunks) {
+                                                                        int chunks, int ppb) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [PL][cgb*8][2]
   const int cg_total = cs / 8;
   const int cgb = cg_total < STATS_THREADS ? cg_total : STATS_THREADS;  // channel groups handled per block
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(STATS_THREADS) void instnorm_partial_kernel(const u
   const int n = blockIdx.z;
   const int cg0 = blockIdx.y * cgb;
   const int chunk = blockIdx.x;
-  const int p0 = chunk * STATS_PIX_PER_BLOCK;
-  const int p1 = min(hw, p0 + STATS_PIX_PER_BLOCK);
+  const int p0 = chunk * ppb;
+  const int p1 = min(hw, p0 + ppb);
   const int t = threadIdx.x;
   const int cgl = t % cgb, pl = t / cgb;
   const int cg = cg0 + cgl;
@@ -93,21 +94,35 @@ __global__ __launch_bounds__(STATS_THREADS) void instnorm_partial_kernel(const u
   }
 }
 
-__global__ void instnorm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean,
-                                         float* __restrict__ rstd, int n_total, int hw, int cs, int chunks, float eps) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (n, c): lanes stride over the chunk partials, then a 6-step shuffle tree of Chan merges
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ partial,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                int n_total, int hw, int cs, int chunks, int ppb,
+                                                                float eps) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (idx >= n_total * cs) return;
-  int n = idx / cs, c = idx - n * cs;
+  const int n = idx / cs, c = idx - n * cs;
   MeanM2 acc = {0.f, 0.f, 0.f};
-  for (int k = 0; k < chunks; ++k) {
-    int p0 = k * STATS_PIX_PER_BLOCK;
-    int cnt = min(hw, p0 + STATS_PIX_PER_BLOCK) - p0;
+  for (int k = lane; k < chunks; k += 64) {
+    int p0 = k * ppb;
+    int cnt = min(hw, p0 + ppb) - p0;
     const float* o = partial + (((size_t)n * chunks + k) * cs + c) * 2;
     MeanM2 b = {(float)cnt, o[0], o[1]};
     acc = chan_merge(acc, b);
   }
-  mean[idx] = acc.mean;
-  rstd[idx] = rsqrtf(acc.m2 / (float)hw + eps);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    MeanM2 b;
+    b.n = __shfl_down(acc.n, off, 64);
+    b.mean = __shfl_down(acc.mean, off, 64);
+    b.m2 = __shfl_down(acc.m2, off, 64);
+    acc = chan_merge(acc, b);
+  }
+  if (lane == 0) {
+    mean[idx] = acc.mean;
+    rstd[idx] = rsqrtf(acc.m2 / (float)hw + eps);
+  }
 }
 
 template <typename T>
@@ -138,6 +153,16 @@ __global__ void norm_act_apply_kernel(const uint16_t* __restrict__ x, const floa
   }
 }
 
+// pixels per block: as large as possible (fewer partials to merge) while the grid still fills the chip
+int pix_per_block(const CganNormStatsDesc* d) {
+  const int cg_total = cgan_cs(d->c) / 8;
+  const int cgb = cg_total < STATS_THREADS ? cg_total : STATS_THREADS;
+  const long cgblocks = ceil_div(cg_total, cgb);
+  int ppb = STATS_MAX_PIX_PER_BLOCK;
+  while (ppb > 64 && (long)ceil_div(d->hw, ppb) * cgblocks * d->n < 1024) ppb >>= 1;
+  return ppb;
+}
+
 int check(const CganNormStatsDesc* d) {
   CGAN_REQUIRE(d != nullptr, "instnorm: null descriptor");
   CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "instnorm: bad dtype %d", d->dtype);
@@ -149,7 +174,7 @@ int check(const CganNormStatsDesc* d) {
 
 extern "C" size_t cgan_instnorm_stats_workspace_bytes(const CganNormStatsDesc* d) {
   if (check(d) != CGAN_OK) return 0;
-  int chunks = ceil_div(d->hw, STATS_PIX_PER_BLOCK);
+  int chunks = ceil_div(d->hw, 64);  // worst case of pix_per_block()
   return (size_t)d->n * chunks * cgan_cs(d->c) * 2 * sizeof(float);
 }
 
@@ -167,20 +192,21 @@ extern "C" int cgan_instnorm_stats(const void* x, float* mean, float* rstd, cons
   const int cg_total = cs / 8;
   const int cgb = cg_total < STATS_THREADS ? cg_total : STATS_THREADS;
   const int PL = STATS_THREADS / cgb;
-  const int chunks = ceil_div(d->hw, STATS_PIX_PER_BLOCK);
+  const int ppb = pix_per_block(d);
+  const int chunks = ceil_div(d->hw, ppb);
   dim3 grid(chunks, ceil_div(cg_total, cgb), d->n);
   size_t smem = ((size_t)2 * PL * cgb * 8 + PL) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CGAN_F16)
     hipLaunchKernelGGL(instnorm_partial_kernel<F16>, grid, dim3(STATS_THREADS), smem, s, (const uint16_t*)x,
-                       (float*)workspace, d->hw, cs, chunks);
+                       (float*)workspace, d->hw, cs, chunks, ppb);
   else
     hipLaunchKernelGGL(instnorm_partial_kernel<BF16>, grid, dim3(STATS_THREADS), smem, s, (const uint16_t*)x,
-                       (float*)workspace, d->hw, cs, chunks);
+                       (float*)workspace, d->hw, cs, chunks, ppb);
   CGAN_CHECK_LAUNCH("instnorm_stats(partial)");
   int total = d->n * cs;
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)workspace,
-                     mean, rstd, d->n, d->hw, cs, chunks, d->eps);
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, (const float*)workspace,
+                     mean, rstd, d->n, d->hw, cs, chunks, ppb, d->eps);
   CGAN_CHECK_LAUNCH("instnorm_stats(finalize)");
   return CGAN_OK;
 }
