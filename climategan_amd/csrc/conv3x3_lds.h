@@ -1,0 +1,20 @@
+// Interface of the LDS-tiled 3x3 convolution kernel (conv3x3_lds.hip), used by conv_mfma.hip's dispatcher.
+#pragma once
+#include "cgan_common.h"
+
+struct Conv3x3LdsArgs {
+  const uint16_t* x;
+  const u32x4* w;       // packed [ctile][ks = tap * (cin_p/32) + q][lane] (the 3x3 padded K layout)
+  const float* bias;    // padded to ctiles*16, or null
+  const uint16_t* res;  // residual or null
+  uint16_t* y;
+  int n, h, w_;         // output extent (== logical input extent: stride 1, pad 1)
+  int hx, wx;           // stored input extent (h/2, w/2 when in_ups)
+  int cin_s, cin_p, cout, cout_s, ctiles, ksteps;
+  int in_ups, act, has_res, res_ups;
+  float slope;
+};
+
+// true if this conv is a 3x3 / stride 1 / pad 1 (zero) / dilation 1 conv large enough for the tiled kernel
+bool conv3x3_lds_applicable(const CganConvDesc* d);
+int conv3x3_lds_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s);

@@ -1,0 +1,245 @@
+// LDS-tiled 3x3 / stride 1 / pad 1 convolution (NHWC 16-bit, MFMA 16x16x32, fp32 accumulate) for gfx950.
+// Used for the SPADE-ResBlk main convs (reference climategan/blocks.py:350-351,372-375) at 32x32 and above, where
+// the general gather kernel (conv_mfma.hip) re-reads every input pixel 9 times through L1/L2.
+//
+// One workgroup (4 waves, two workgroups per CU) = a 16 x 16 output tile x NCT <= 5 output-channel tiles:
+//   - input channels are consumed in chunks of 32 (one MFMA k-step per tap): the 18 x 18 x 32 halo of the chunk is
+//     brought into LDS by LDS-DMA (global_load_lds_dwordx4; zero padding comes from a zero page, the folded x2
+//     nearest upsample is address math), double-buffered, XOR-swizzled on the SOURCE side so the MFMA B-fragment
+//     reads are spread over the banks while the DMA writes LDS linearly;
+//   - weights stream L2 -> LDS by LDS-DMA, one (chunk, dx) stage = 3 taps x NCT fragments ahead;
+//   - the B fragments of the 6 halo rows a wave needs are read once per (chunk, dx) and reused for the 3 dy taps
+//     ((3*NCT A + 6 B) fragment reads per 12*NCT MFMAs);
+//   - epilogue: bias + residual (optionally through the folded upsample) + activation, staged through LDS so
+//     the tile is written as whole 16-byte channel chunks (contiguous rows).
+// HBM traffic: input once (+ halo) + output once (+ residual): the kernel is HBM-bound at 640x640 / Cout <= 40.
+#include "conv3x3_lds.h"
+
+namespace {
+
+constexpr int TW = 16, TH = 16, WAVES = 4, PT = TH / WAVES;
+constexpr int HPW = TW + 2, HPH = TH + 2, HP = HPH * HPW;   // 18 x 18 halo
+constexpr int XDMA = (HP * 4 + 63) / 64;                    // 21 wave-wide DMAs per input chunk
+constexpr int XBUF_BYTES = XDMA * 1024;                     // 21504 (324 px x 64 B + tail of the last DMA)
+constexpr int MAX_NCT = 5;
+
+// [halo pixel q][4 slots of 16 B]: logical slot s of pixel q lives at slot position s ^ ((q >> 2) & 3)
+__device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 2) & 3)) << 4); }
+
+// 16-byte-aligned zeros in device memory: the source of every out-of-image / pad-channel DMA lane
+__device__ __attribute__((aligned(16))) unsigned int g_zeros[64];
+
+#define STAGE_BARRIER()                                            \
+  do {                                                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                                  \
+    asm volatile("" ::: "memory");                                 \
+  } while (0)
+
+template <typename T, int NCT>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_lds_kernel(Conv3x3LdsArgs p) {
+  const u32x4* zero_page = reinterpret_cast<const u32x4*>(g_zeros);
+  constexpr int STAGE_BYTES = 3 * NCT * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xbuf = smem;                       // 2 * XBUF_BYTES
+  unsigned char* wbuf = xbuf + 2 * XBUF_BYTES;      // 2 * STAGE_BYTES
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int g = lane >> 4;
+
+  const int tiles_x = (p.w_ + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
+  int tile = blockIdx.x;
+  const int txi = tile % tiles_x;
+  tile /= tiles_x;
+  const int tyi = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int ct0 = blockIdx.y * NCT;                 // first output-channel tile of this workgroup
+  const int nq = p.cin_p / 32;                      // input-channel chunks
+  const int nstages = nq * 3;
+
+  // ---- LDS-DMA of input chunk q (18 x 18 halo x 32 channels) into xbuf[q & 1]
+  auto issue_x = [&](int q) {
+    unsigned char* dst = xbuf + (q & 1) * XBUF_BYTES;
+    for (int i = wave; i < XDMA; i += WAVES) {
+      const int idx = i * 64 + lane;                // LDS position: pixel idx/4, slot position idx%4
+      const int pix = idx >> 2, spos = idx & 3;
+      const int slot = spos ^ ((pix >> 2) & 3);     // logical 8-channel group that belongs at this position
+      const int py = pix / HPW, px = pix - py * HPW;
+      const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+      const int ch = q * 32 + slot * 8;
+      const u32x4* src = zero_page;
+      if (pix < HP && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_ && ch < p.cin_s) {
+        const int sy = p.in_ups ? (yy >> 1) : yy, sx = p.in_ups ? (xx >> 1) : xx;
+        src = reinterpret_cast<const u32x4*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cin_s + ch);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+  // ---- LDS-DMA of weight stage s = (chunk q, dx): 3 dy taps x NCT channel tiles -> wbuf[s & 1], slot dy*NCT + c
+  auto issue_w = [&](int s) {
+    const int q = s / 3, dx = s - q * 3;
+    unsigned char* dst = wbuf + (s & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int i0 = 0; i0 < 3 * NCT; i0 += WAVES) {
+      const int i = i0 + wave;
+      if (i < 3 * NCT) {
+        const int dy = i / NCT, c = i - dy * NCT;
+        const int ct = min(ct0 + c, p.ctiles - 1);
+        const u32x4* src = p.w + ((size_t)ct * p.ksteps + (dy * 3 + dx) * nq + q) * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  issue_x(0);
+  issue_w(0);
+
+  f32x4 acc[NCT][PT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---------------- K loop
+  for (int q = 0; q < nq; ++q) {
+    const unsigned char* xb = xbuf + (q & 1) * XBUF_BYTES;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int s = q * 3 + dx;
+      STAGE_BARRIER();                               // chunk q and weight stage s have landed; other buffers free
+      if (dx == 0 && q + 1 < nq) issue_x(q + 1);
+      if (s + 1 < nstages) issue_w(s + 1);
+      u32x4 bfr[PT + 2];
+#pragma unroll
+      for (int r = 0; r < PT + 2; ++r) {
+        const int qq = (wave * PT + r) * HPW + (j + dx);
+        bfr[r] = *reinterpret_cast<const u32x4*>(xb + xq_addr(qq, g));
+      }
+      const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        u32x4 a[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c) * 1024);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+            acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+      }
+    }
+  }
+
+  // ---------------- epilogue: lane holds channels (ct0+c)*16 + 4g + {0..3} of pixel (row wave*PT+t, column j)
+  __syncthreads();                                   // everyone is done with xbuf / wbuf
+  unsigned char* yt = smem;                          // [256 px][NCT * 32 B]
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int row = wave * PT + t;
+    const int yy = ty0 + row, xx = tx0 + j;
+    const bool pin = yy < p.h && xx < p.w_;
+    size_t rbase = 0;
+    if (p.has_res && pin) {
+      if (p.res_ups) rbase = (((size_t)n * (p.h >> 1) + (yy >> 1)) * (p.w_ >> 1) + (xx >> 1)) * p.cout_s;
+      else rbase = (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s;
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int ch = (ct0 + c) * 16 + g * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r];
+      if (ch < p.cout_s) {
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
+        }
+        if (p.has_res && pin) {
+          const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
+          float r0, r1, r2, r3;
+          unpack2<T>(rv[0], r0, r1);
+          unpack2<T>(rv[1], r2, r3);
+          v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = act_apply(v[r], p.act, p.slope);
+          if (ch + r >= p.cout) v[r] = 0.f;          // keep pad channels zero
+        }
+      }
+      u32x2 o;
+      o[0] = pack2<T>(v[0], v[1]);
+      o[1] = pack2<T>(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(yt + ((row * 16 + j) * NCT + c) * 32 + g * 8) = o;
+    }
+  }
+  __syncthreads();
+  // whole 16-byte chunks, lane-linear over [256 px][2*NCT chunks]
+#pragma unroll
+  for (int k = 0; k < 2 * NCT; ++k) {
+    const int id = k * (WAVES * 64) + threadIdx.x;
+    const int pix = id / (2 * NCT), cc = id - pix * (2 * NCT);
+    const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
+    const int ch = ct0 * 16 + cc * 8;
+    if (yy < p.h && xx < p.w_ && ch < p.cout_s)
+      *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s + ch) =
+          *reinterpret_cast<const u32x4*>(yt + id * 16);
+  }
+}
+
+template <typename T, int NCT>
+int launch(const Conv3x3LdsArgs& a, hipStream_t s) {
+  const int tiles = a.n * ((a.h + TH - 1) / TH) * ((a.w_ + TW - 1) / TW);
+  const int chunks = ceil_div(a.ctiles, NCT);
+  size_t smem = (size_t)2 * XBUF_BYTES + 2 * 3 * NCT * 1024;
+  const size_t epi = (size_t)256 * NCT * 32;
+  if (epi > smem) smem = epi;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<T, NCT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      cgan_set_error("conv3x3_lds: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return CGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_lds_kernel<T, NCT>), dim3(tiles, chunks), dim3(WAVES * 64), smem, s, a);
+  return CGAN_OK;
+}
+
+template <typename T>
+int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
+  // channel tiles per workgroup: the divisor of ctiles (<= 5) with the least padding
+  int nct = a.ctiles < MAX_NCT ? a.ctiles : MAX_NCT;
+  if (a.ctiles > MAX_NCT) {
+    int best = MAX_NCT, waste = ceil_div(a.ctiles, MAX_NCT) * MAX_NCT - a.ctiles;
+    for (int k = MAX_NCT - 1; k >= 3; --k) {
+      int w = ceil_div(a.ctiles, k) * k - a.ctiles;
+      if (w < waste) { waste = w; best = k; }
+    }
+    nct = best;
+  }
+  switch (nct) {
+    case 1: return launch<T, 1>(a, s);
+    case 2: return launch<T, 2>(a, s);
+    case 3: return launch<T, 3>(a, s);
+    case 4: return launch<T, 4>(a, s);
+    default: return launch<T, 5>(a, s);
+  }
+}
+
+}  // namespace
+
+bool conv3x3_lds_applicable(const CganConvDesc* d) {
+  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && d->pad == 1 &&
+         d->pad_mode == CGAN_PAD_ZERO && (long)d->h_out * d->w_out >= 1024;
+}
+
+int conv3x3_lds_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s) {
+  return dtype == CGAN_F16 ? launch_nct<F16>(a, s) : launch_nct<BF16>(a, s);
+}

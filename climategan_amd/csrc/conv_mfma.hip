@@ -15,6 +15,7 @@
 //
 // This is the general kernel (any kh/kw/stride/dilation/pad mode); operands come through L1/L2.
 #include "cgan_common.h"
+#include "conv3x3_lds.h"
 
 namespace {
 
@@ -24,7 +25,7 @@ struct ConvParams {
   const float* bias;
   const uint16_t* res;
   uint16_t* y;
-  int n, h_in, w_in, hx, wx, cin_s, cg;
+  int n, h_in, w_in, hx, wx, cin_s, cin_p, cg;   // cin_p: per-tap K extent (cin_s, or padded to 32 for 3x3)
   int cout, cout_s, ctiles;
   int kh, kw, stride, pad, dil, pad_mode;
   int h_out, w_out, npix;
@@ -32,6 +33,13 @@ struct ConvParams {
   int in_ups, act, has_res, res_ups;
   float slope;
 };
+
+// K layout of the packed weights: k = tap * cin_p + c.  3x3 kernels pad the per-tap channel extent to a multiple
+// of 32 (one MFMA k-step never straddles a tap), which is what the LDS-tiled 3x3 kernel (conv3x3_lds.hip) needs;
+// every other kernel size is dense (cin_p = cin_s).
+__host__ __device__ inline int conv_cin_p(int cin_s, int kh, int kw) {
+  return (kh == 3 && kw == 3) ? ((cin_s + 31) & ~31) : cin_s;
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
   // nn.ReflectionPad2d: -1 -> 1, n -> n-2 (pad < n guaranteed by the host check)
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       int iy = py0[t] + dy, ix = px0[t] + dx;
-      bool ok = kvalid && pvalid[t];
+      bool ok = kvalid && pvalid[t] && (c8 * 8 < p.cin_s);
       if (p.pad_mode == CGAN_PAD_REFLECT) {
         iy = reflect_idx(iy, p.h_in);
         ix = reflect_idx(ix, p.w_in);
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 template <typename T>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                         const float* __restrict__ sigma, uint16_t* __restrict__ packed,
-                                        float* __restrict__ bias_out, int cout, int cin, int cin_s, int kh, int kw,
+                                        float* __restrict__ bias_out, int cout, int cin, int cin_p, int kh, int kw,
                                         int ctiles, int ksteps) {
   const int total = ctiles * ksteps * 64;
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
@@ -206,8 +214,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       int k = k0 + e;
-      int tap = k / cin_s;
-      int c = k - tap * cin_s;
+      int tap = k / cin_p;
+      int c = k - tap * cin_p;
       float v = 0.f;
       if (co < cout && tap < taps && c < cin) v = w[((size_t)co * cin + c) * taps + tap] * inv;
       o[e] = bits_of<T>(v);
@@ -229,11 +237,11 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
 template <typename T>
 __global__ void pack_conv_weight_batched_kernel(const CganPackItem* __restrict__ items) {
   const CganPackItem it = items[blockIdx.y];
-  const int cin_s = (it.c_in + 7) & ~7;
+  const int cin_p = conv_cin_p((it.c_in + 7) & ~7, it.kh, it.kw);
   const int cout_s = (it.c_out + 7) & ~7;
   const int ctiles = (cout_s + 15) / 16;
   const int taps = it.kh * it.kw;
-  const int ksteps = (taps * (cin_s / 8) + 3) / 4;
+  const int ksteps = (taps * (cin_p / 8) + 3) / 4;
   const int total = ctiles * ksteps * 64;
   const float inv = it.sigma ? 1.f / it.sigma[0] : 1.f;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -246,8 +254,8 @@ __global__ void pack_conv_weight_batched_kernel(const CganPackItem* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       int k = k0 + e;
-      int tap = k / cin_s;
-      int c = k - tap * cin_s;
+      int tap = k / cin_p;
+      int c = k - tap * cin_p;
       float v = 0.f;
       if (co < it.c_out && tap < taps && c < it.c_in) v = it.w_oihw[((size_t)co * it.c_in + c) * taps + tap] * inv;
       o[e] = bits_of<T>(v);
@@ -283,7 +291,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   p.n = d->n; p.h_in = d->h_in; p.w_in = d->w_in;
   p.hx = d->in_upsample ? d->h_in / 2 : d->h_in;
   p.wx = d->in_upsample ? d->w_in / 2 : d->w_in;
-  p.cin_s = cgan_cs(d->c_in); p.cg = p.cin_s / 8;
+  p.cin_s = cgan_cs(d->c_in); p.cin_p = conv_cin_p(p.cin_s, d->kh, d->kw); p.cg = p.cin_p / 8;
   p.cout = d->c_out; p.cout_s = cgan_cs(d->c_out); p.ctiles = ceil_div(p.cout_s, 16);
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dilation; p.pad_mode = d->pad_mode;
   p.h_out = d->h_out; p.w_out = d->w_out;
@@ -334,6 +342,10 @@ void launch(const ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
+// development knob: 1 = always use the general gather kernel (A/B measurements, parity tests of both kernels)
+int g_conv_force = 0;
+extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; }
+
 extern "C" size_t cgan_conv2d_packed_weight_bytes(const CganConvDesc* d) {
   ConvParams p;
   if (fill_params(p, d) != CGAN_OK) return 0;
@@ -351,10 +363,10 @@ extern "C" int cgan_conv2d_pack_weight(const float* w_oihw, const float* bias, c
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CGAN_F16)
     hipLaunchKernelGGL(pack_conv_weight_kernel<F16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
-                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_s, d->kh, d->kw, p.ctiles, p.ksteps);
+                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_p, d->kh, d->kw, p.ctiles, p.ksteps);
   else
     hipLaunchKernelGGL(pack_conv_weight_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
-                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_s, d->kh, d->kw, p.ctiles, p.ksteps);
+                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_p, d->kh, d->kw, p.ctiles, p.ksteps);
   CGAN_CHECK_LAUNCH("conv2d_pack_weight");
   return CGAN_OK;
 }
@@ -384,6 +396,17 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
   p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
   p.res = (const uint16_t*)residual; p.y = (uint16_t*)y;
   hipStream_t s = (hipStream_t)stream;
+  if (g_conv_force != 1 && conv3x3_lds_applicable(d)) {
+    Conv3x3LdsArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
+    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+    a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+    int rc2 = conv3x3_lds_launch(a, d->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd(3x3 LDS)");
+    return CGAN_OK;
+  }
   if (d->dtype == CGAN_F16) launch<F16>(p, s);
   else launch<BF16>(p, s);
   CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd");

@@ -253,3 +253,54 @@ def test_spectral_norm_group_equals_per_layer():
             assert torch.equal(ref.w, pk.w) and torch.equal(ref.bias, pk.bias)
         for (wa, ua, va, _), (wb, ub, vb, _) in zip(params_a, params_b):
             assert torch.equal(ua, ub) and torch.equal(va, vb)
+
+
+LDS_CONV_CASES = [
+    # cin, cout, H, W, in_upsample, residual ("none" | "same" | "ups"), act
+    (20, 20, 40, 48, False, "same", "lrelu"),     # final_spade conv_1 shape class: 24-channel storage both sides
+    (40, 20, 33, 47, False, "none", "none"),      # ragged tiles, cin 40 -> 2 chunks (second one 8/32 full)
+    (64, 88, 32, 32, False, "none", "none"),      # 6 channel tiles -> 2 workgroup chunks of 3
+    (96, 40, 36, 36, True, "ups", "none"),        # input and residual read through the folded x2 upsample
+    (8, 3, 64, 40, False, "none", "tanh"),        # conv_img shape class
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", LDS_CONV_CASES)
+def test_conv3x3_lds_tiled(dt, case):
+    """The LDS-tiled 3x3 kernel (conv3x3_lds.hip, used from 32x32 up) against the oracle, and bit-for-bit against
+    nothing -- but within tolerance of the general gather kernel forced through the debug knob."""
+    import ctypes
+    from climategan_amd import _lib, ops
+    cin, cout, H, W, ups, resmode, act = case
+    B = 2
+    hs, ws = (H // 2, W // 2) if ups else (H, W)
+    x = q(fill.uniform((B, cin, hs, ws), 500 + cin), dt)
+    w = q(fill.uniform((cout, cin, 3, 3), 600 + cout, -0.2, 0.2), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 700 + cout))
+    xf = cpu_ref.nearest_resize(x, (H, W)) if ups else x
+    ref = F.conv2d(xf, w, b, padding=1)
+    res = None
+    if resmode != "none":
+        rs = (H // 2, W // 2) if resmode == "ups" else (H, W)
+        res = q(fill.uniform((B, cout) + rs, 800 + cout), dt)
+        ref = ref + (cpu_ref.nearest_resize(res, (H, W)) if resmode == "ups" else res)
+    if act == "lrelu":
+        ref = F.leaky_relu(ref, 0.2)
+    elif act == "tanh":
+        ref = torch.tanh(ref)
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    kw = dict(pad=1, act={"none": ops.ACT_NONE, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}[act],
+              residual=to_nhwc(res, dt) if res is not None else None, in_upsample=ups,
+              residual_upsample=(resmode == "ups"))
+    y = ops.conv2d(to_nhwc(x, dt), pw, **kw)
+    assert_close(back(y), ref, dt, "conv3x3 LDS %s" % (case,))
+    if ops.cs8(cout) != cout:
+        assert y.t[..., cout:].abs().max().item() == 0
+    lib = _lib.load()
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(1))
+    try:
+        y2 = ops.conv2d(to_nhwc(x, dt), pw, **kw)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    assert_close(back(y2), ref, dt, "conv3x3 gather %s" % (case,))

@@ -41,8 +41,10 @@ def test_host_side_validation_without_gpu(lib):
     assert lib.cgan_conv2d_packed_weight_bytes(ctypes.byref(d)) == 0
     assert b"inconsistent" in lib.cgan_last_error()
     d = ConvDesc(0, 1, 8, 8, 20, 20, 3, 3, 1, 1, 1, 0, 8, 8, 0, 0, 0.2, 1, 0, 0)
-    # 20 -> 24 storage channels, K = 9*24 = 216 -> 7 k-steps; 24 rows -> 2 cout tiles
-    assert lib.cgan_conv2d_packed_weight_bytes(ctypes.byref(d)) == 2 * 7 * 64 * 16
+    # 20 -> 24 storage channels, padded to 32 per tap for 3x3 kernels: K = 9*32 -> 9 k-steps; 24 rows -> 2 cout tiles
+    assert lib.cgan_conv2d_packed_weight_bytes(ctypes.byref(d)) == 2 * 9 * 64 * 16
+    d1 = ConvDesc(0, 1, 8, 8, 20, 20, 1, 1, 1, 0, 1, 0, 8, 8, 0, 0, 0.2, 1, 0, 0)
+    assert lib.cgan_conv2d_packed_weight_bytes(ctypes.byref(d1)) == 2 * 1 * 64 * 16   # 1x1: dense K = 24 -> 1 k-step
     s = SpadeDesc(0, 1, 16, 16, 40, 0, 64, 64, 3, 64, 3, 0, 0.2)  # hidden != 128
     assert lib.cgan_spade_packed_weight_bytes(ctypes.byref(s)) == 0
     assert b"hidden must be 128" in lib.cgan_last_error()
