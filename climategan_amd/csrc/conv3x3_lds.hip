@@ -36,6 +36,68 @@ __device__ __attribute__((aligned(16))) unsigned int g_zeros[64];
     asm volatile("" ::: "memory");                                 \
   } while (0)
 
+// Epilogue shared by both kernels: bias + residual (optionally through the folded upsample) + activation, staged
+// through LDS so that the tile leaves as whole 16-byte channel chunks.
+template <typename T, int NCT>
+__device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 (&acc)[NCT][PT], unsigned char* smem,
+                                                 int n, int ty0, int tx0, int ct0, int wave, int j, int g) {
+  // ---------------- epilogue: lane holds channels (ct0+c)*16 + 4g + {0..3} of pixel (row wave*PT+t, column j)
+  __syncthreads();                                   // everyone is done with xbuf / wbuf
+  unsigned char* yt = smem;                          // [256 px][NCT * 32 B]
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int row = wave * PT + t;
+    const int yy = ty0 + row, xx = tx0 + j;
+    const bool pin = yy < p.h && xx < p.w_;
+    size_t rbase = 0;
+    if (p.has_res && pin) {
+      if (p.res_ups) rbase = (((size_t)n * (p.h >> 1) + (yy >> 1)) * (p.w_ >> 1) + (xx >> 1)) * p.cout_s;
+      else rbase = (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s;
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int ch = (ct0 + c) * 16 + g * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r];
+      if (ch < p.cout_s) {
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
+        }
+        if (p.has_res && pin) {
+          const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
+          float r0, r1, r2, r3;
+          unpack2<T>(rv[0], r0, r1);
+          unpack2<T>(rv[1], r2, r3);
+          v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = act_apply(v[r], p.act, p.slope);
+          if (ch + r >= p.cout) v[r] = 0.f;          // keep pad channels zero
+        }
+      }
+      u32x2 o;
+      o[0] = pack2<T>(v[0], v[1]);
+      o[1] = pack2<T>(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(yt + ((row * 16 + j) * NCT + c) * 32 + g * 8) = o;
+    }
+  }
+  __syncthreads();
+  // whole 16-byte chunks, lane-linear over [256 px][2*NCT chunks]
+#pragma unroll
+  for (int k = 0; k < 2 * NCT; ++k) {
+    const int id = k * (WAVES * 64) + threadIdx.x;
+    const int pix = id / (2 * NCT), cc = id - pix * (2 * NCT);
+    const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
+    const int ch = ct0 * 16 + cc * 8;
+    if (yy < p.h && xx < p.w_ && ch < p.cout_s)
+      *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s + ch) =
+          *reinterpret_cast<const u32x4*>(yt + id * 16);
+  }
+}
+
 template <typename T, int NCT>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_lds_kernel(Conv3x3LdsArgs p) {
   const u32x4* zero_page = reinterpret_cast<const u32x4*>(g_zeros);
@@ -134,61 +196,88 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_lds_kernel(Conv3x3LdsAr
     }
   }
 
-  // ---------------- epilogue: lane holds channels (ct0+c)*16 + 4g + {0..3} of pixel (row wave*PT+t, column j)
-  __syncthreads();                                   // everyone is done with xbuf / wbuf
-  unsigned char* yt = smem;                          // [256 px][NCT * 32 B]
-#pragma unroll
-  for (int t = 0; t < PT; ++t) {
-    const int row = wave * PT + t;
-    const int yy = ty0 + row, xx = tx0 + j;
-    const bool pin = yy < p.h && xx < p.w_;
-    size_t rbase = 0;
-    if (p.has_res && pin) {
-      if (p.res_ups) rbase = (((size_t)n * (p.h >> 1) + (yy >> 1)) * (p.w_ >> 1) + (xx >> 1)) * p.cout_s;
-      else rbase = (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s;
+  conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);
+}
+
+// Cin <= 32 (one input chunk): a single barrier.  The whole 9-tap weight set (9*NCT fragments) and the input halo
+// are DMA'd up front, no double buffering (39.5 KB of LDS at NCT = 2, <= 128 VGPRs: four workgroups per CU, which
+// is what hides the DMA latency of these short, HBM-bound workgroups: the 640x640 20/40-channel Painter convs).
+template <typename T, int NCT>
+__global__ __launch_bounds__(WAVES * 64, 4) void conv3x3_lds_onechunk_kernel(Conv3x3LdsArgs p) {
+  const u32x4* zero_page = reinterpret_cast<const u32x4*>(g_zeros);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xbuf = smem;                       // XBUF_BYTES
+  unsigned char* wbuf = xbuf + XBUF_BYTES;          // 9 * NCT KiB, slot tap*NCT + c
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int g = lane >> 4;
+  const int tiles_x = (p.w_ + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
+  int tile = blockIdx.x;
+  const int txi = tile % tiles_x;
+  tile /= tiles_x;
+  const int tyi = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int ct0 = blockIdx.y * NCT;
+
+  for (int i = wave; i < XDMA; i += WAVES) {
+    const int idx = i * 64 + lane;
+    const int pix = idx >> 2, spos = idx & 3;
+    const int slot = spos ^ ((pix >> 2) & 3);
+    const int py = pix / HPW, px = pix - py * HPW;
+    const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+    const int ch = slot * 8;
+    const u32x4* src = zero_page;
+    if (pix < HP && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_ && ch < p.cin_s) {
+      const int sy = p.in_ups ? (yy >> 1) : yy, sx = p.in_ups ? (xx >> 1) : xx;
+      src = reinterpret_cast<const u32x4*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cin_s + ch);
     }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(xbuf + i * 1024), 16, 0, 0);
+  }
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-      const int ch = (ct0 + c) * 16 + g * 4;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r];
-      if (ch < p.cout_s) {
-        if (p.bias) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
-        }
-        if (p.has_res && pin) {
-          const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
-          float r0, r1, r2, r3;
-          unpack2<T>(rv[0], r0, r1);
-          unpack2<T>(rv[1], r2, r3);
-          v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = act_apply(v[r], p.act, p.slope);
-          if (ch + r >= p.cout) v[r] = 0.f;          // keep pad channels zero
-        }
-      }
-      u32x2 o;
-      o[0] = pack2<T>(v[0], v[1]);
-      o[1] = pack2<T>(v[2], v[3]);
-      *reinterpret_cast<u32x2*>(yt + ((row * 16 + j) * NCT + c) * 32 + g * 8) = o;
+  for (int i0 = 0; i0 < 9 * NCT; i0 += WAVES) {
+    const int i = i0 + wave;
+    if (i < 9 * NCT) {
+      const int tap = i / NCT, c = i - tap * NCT;
+      const int ct = min(ct0 + c, p.ctiles - 1);
+      const u32x4* src = p.w + ((size_t)ct * p.ksteps + tap) * 64 + lane;   // nq == 1: ks = tap
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(wbuf + i * 1024), 16, 0, 0);
     }
   }
-  __syncthreads();
-  // whole 16-byte chunks, lane-linear over [256 px][2*NCT chunks]
+
+  f32x4 acc[NCT][PT];
 #pragma unroll
-  for (int k = 0; k < 2 * NCT; ++k) {
-    const int id = k * (WAVES * 64) + threadIdx.x;
-    const int pix = id / (2 * NCT), cc = id - pix * (2 * NCT);
-    const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
-    const int ch = ct0 * 16 + cc * 8;
-    if (yy < p.h && xx < p.w_ && ch < p.cout_s)
-      *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s + ch) =
-          *reinterpret_cast<const u32x4*>(yt + id * 16);
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  STAGE_BARRIER();
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    u32x4 bfr[PT + 2];
+#pragma unroll
+    for (int r = 0; r < PT + 2; ++r) {
+      const int qq = (wave * PT + r) * HPW + (j + dx);
+      bfr[r] = *reinterpret_cast<const u32x4*>(xbuf + xq_addr(qq, g));
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      u32x4 a[NCT];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+        a[c] = *reinterpret_cast<const u32x4*>(wbuf + ((dy * 3 + dx) * NCT + c) * 1024 + lane * 16);
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+          acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+    }
   }
+  conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);
 }
 
 template <typename T, int NCT>
@@ -207,6 +296,23 @@ int launch(const Conv3x3LdsArgs& a, hipStream_t s) {
       return CGAN_ERR_HIP;
     }
     attr_set = true;
+  }
+  if (NCT <= 2 && a.cin_p == 32) {
+    size_t smem1 = (size_t)XBUF_BYTES + 9 * NCT * 1024;
+    if (epi > smem1) smem1 = epi;
+    static bool attr1_set = false;
+    if (!attr1_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_onechunk_kernel<T, (NCT <= 2 ? NCT : 1)>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        cgan_set_error("conv3x3_lds: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return CGAN_ERR_HIP;
+      }
+      attr1_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_lds_onechunk_kernel<T, (NCT <= 2 ? NCT : 1)>), dim3(tiles, chunks), dim3(WAVES * 64), smem1,
+                       s, a);
+    return CGAN_OK;
   }
   hipLaunchKernelGGL((conv3x3_lds_kernel<T, NCT>), dim3(tiles, chunks), dim3(WAVES * 64), smem, s, a);
   return CGAN_OK;
