@@ -128,6 +128,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
   const int ty0 = tyi * TH, tx0 = txi * TW;
   const int nt0 = blockIdx.y * NCT;       // first channel tile of this workgroup
   TS(0);
+  if (p.tsbuf && threadIdx.x == 0)
+    p.tsbuf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 
   // ---- LDS-DMA of weight stage s = (quarter q, dx): the three dy taps x NCT channel tiles = 3*NCT fragments of
   // 1 KiB -> buffer s & 1, fragment slot dy*NCT + c.  A channel tile past the end of the tensor is clamped (its
@@ -299,9 +302,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
     }
   };
 
-  // ---------------- hidden map of quarter 0 (not overlapped)
+  // ---------------- hidden map of quarter 0 (not overlapped with MFMA stages: keep all of a wave's tiles in flight)
   if (!(p.dbg & 1)) {
-    for (int ht = wave; ht < NHT; ht += WAVES) hidden_tile(ht, 0, actv);
+    if (C4) {
+      constexpr int TPW = (NHT + WAVES - 1) / WAVES;   // 6 tiles per wave
+      u32x4 gb0[TPW], gb1[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        hid_gather(min(wave + i * WAVES, NHT - 1));
+        gb0[i] = hb0;
+        gb1[i] = hb1;
+      }
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int ht = wave + i * WAVES;
+        hb0 = gb0[i];
+        hb1 = gb1[i];
+        hid_mma();
+        if (ht < NHT) hid_finish(ht, actv);
+      }
+    } else {
+      for (int ht = wave; ht < NHT; ht += WAVES) hidden_tile(ht, 0, actv);
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   TS(2);
@@ -330,6 +352,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
       const int s = q * 3 + dx;
       COUNTED_BARRIER(0);
       if (s + 1 < NSTAGES) issue_stage(s + 1);
+      if (q == 3 && dx == 0) {
+        // the last quarter has no successor: its spare hidden-map buffer (actv[0]) receives the x tile now, as
+        // whole 16-byte channel chunks, lane-linear over [256 pixels][NCT chunks] (id = k*256 + tid -> pixel id / NCT,
+        // chunk id % NCT), so the epilogue finds x in LDS
+#pragma unroll
+        for (int k = 0; k < NCT; ++k) {
+          const int id = k * (WAVES * 64) + threadIdx.x;
+          const int pix = id / NCT, cc = id - pix * NCT;
+          const int yy = min(ty0 + (pix >> 4), p.h - 1), xx = min(tx0 + (pix & 15), p.w - 1);
+          const int sy = p.x_ups ? (yy >> 1) : yy, sx = p.x_ups ? (xx >> 1) : xx;
+          const int nt = min(nt0 + cc, p.nt - 1);
+          const uint16_t* src = p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cs + nt * 8;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)(actv + (k * (WAVES * 64) + wave * 64) * 16), 16, 0, 0);
+        }
+      }
       u32x4 bfr[PT + 2];
 #pragma unroll
       for (int r = 0; r < PT + 2; ++r) {
@@ -376,28 +415,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
 
   // ---------------- epilogue.  The hidden-map region of LDS is free now: use it to turn the lane-linear x chunks
   // into per-lane values and the per-lane results back into lane-linear chunks.
-  // x / y tile traffic is done in whole 16-byte channel chunks, lane-linear over the tile's
-  // [256 pixels][NCT chunks] so that a wave touches contiguous memory:
-  //   id = k*256 + tid -> pixel id / NCT (row-major in the 16x16 tile), channel chunk id % NCT
+  // x already sits in LDS (actv[0], DMA'd during the last quarter; the stage barriers since then made it visible);
+  // every lane reads and rewrites only its own 4-byte slots, so no barrier is needed before the arithmetic
   __builtin_amdgcn_s_setprio(2);
-  u32x4 xv[NCT];
-#pragma unroll
-  for (int k = 0; k < NCT; ++k) {
-    const int id = k * (WAVES * 64) + threadIdx.x;
-    const int pix = id / NCT, cc = id - pix * NCT;
-    const int yy = min(ty0 + (pix >> 4), p.h - 1), xx = min(tx0 + (pix & 15), p.w - 1);
-    const int sy = p.x_ups ? (yy >> 1) : yy, sx = p.x_ups ? (xx >> 1) : xx;
-    const int nt = min(nt0 + cc, p.nt - 1);
-    xv[k] = *reinterpret_cast<const u32x4*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cs + nt * 8);
-  }
-  __syncthreads();   // every wave is done with the hidden map
   unsigned char* xt = actv;   // [256 px][NCT * 16 B]
-#pragma unroll
-  for (int k = 0; k < NCT; ++k) {
-    const int id = k * (WAVES * 64) + threadIdx.x;
-    *reinterpret_cast<u32x4*>(xt + id * 16) = xv[k];
-  }
-  __syncthreads();
 #pragma unroll
   for (int c = 0; c < NCT; ++c) {
     const int ch = (nt0 + c) * 8 + chan_in_tile;

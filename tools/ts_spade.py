@@ -27,5 +27,19 @@ for C, R in [(40, 640), (20, 640)]:
     # timestamps: 0 start, 1 after phase 0, 2 after hidden quarter 0, 5 after the K loop, 6 end
     d = {"phase0": t[:, 1] - t[:, 0], "hidden q0": t[:, 2] - t[:, 1], "K loop": t[:, 5] - t[:, 2],
          "epilogue": t[:, 6] - t[:, 5], "total": t[:, 6] - t[:, 0]}
+    # concurrency: how many workgroups are resident at once (expect 512 = 2 per CU)
+    import numpy as np
+    st = t[:, 0].numpy(); en = t[:, 6].numpy()
+    ids = ts[:, 7].cpu().numpy()
+    cu_key = ((ids >> 32) << 16) | ((ids & 0xffffffff) >> 8 & 0xff)   # (xcc, se/sh/cu)
+    keys = np.unique(cu_key)
+    concs = []
+    for kx in keys:
+        m = cu_key == kx
+        ev = np.concatenate([np.stack([st[m], np.ones(m.sum())], 1), np.stack([en[m], -np.ones(m.sum())], 1)])
+        ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        concs.append(np.cumsum(ev[:, 1]).max())
+    print("C=%d: %d distinct CUs seen; per-CU max concurrent WGs: min %d max %d mean %.2f; WGs per CU mean %.1f" % (
+        C, len(keys), min(concs), max(concs), np.mean(concs), len(st) / len(keys)))
     span = (t[:, 6].max() - t[:, 0].min()).item()
     print("C=%d: kernel span %.0f ticks; per-WG mean ticks:" % (C, span), {k: int(v.mean().item()) for k, v in d.items()})
