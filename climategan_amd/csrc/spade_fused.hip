@@ -28,6 +28,8 @@
 // D's per-lane 4 registers are 4 consecutive channel rows of one pixel (col = lane&15, row = 4*(lane>>4)+r).
 #include "cgan_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TW = 16;       // pixel-tile width == MFMA N
@@ -41,7 +43,7 @@ constexpr int HPH = TH + 2, HPW = TW + 2, HP = HPH * HPW;   // hidden halo (18 x
 constexpr int CTH = TH + 4, CTW = TW + 4;                   // cond halo (20 x 20)
 constexpr int NHT = (HP + 15) / 16;                         // 21 hidden pixel tiles
 constexpr int QC = 32;                                      // hidden channels per quarter
-constexpr int ACTV_Q_BYTES = HP * QC * 2;                   // 20736
+constexpr int ACTV_Q_BYTES = NHT * 16 * QC * 2;             // 21504: 21 full hidden tiles (18*18 = 324 pixels used)
 constexpr int NSTAGES = 12;                                 // 4 quarters x 3 dx (3 dy taps per stage)
 constexpr int NBUF = 2;                                     // weight-stage double buffer
 
@@ -252,16 +254,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
     }
   };
   auto hid_finish = [&](int ht, unsigned char* dst) {
-    const int q = ht * 16 + j;
-    if (q < HP) {
+    const int q = ht * 16 + j;   // buffers hold 21 full tiles: pixels >= 324 are written (zeros) and never read
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        u32x2 o;
-        o[0] = pack2<T>(fmaxf(hacc[c][0], 0.f), fmaxf(hacc[c][1], 0.f));
-        o[1] = pack2<T>(fmaxf(hacc[c][2], 0.f), fmaxf(hacc[c][3], 0.f));
-        // local channel = c*16 + 4g + r  ->  slot c*2 + (g>>1), byte (g&1)*8
-        *reinterpret_cast<u32x2*>(dst + actv_addr(q, c * 2 + (g >> 1)) + (g & 1) * 8) = o;
-      }
+    for (int c = 0; c < 2; ++c) {
+      u32x2 o;
+      o[0] = pack2<T>(fmaxf(hacc[c][0], 0.f), fmaxf(hacc[c][1], 0.f));
+      o[1] = pack2<T>(fmaxf(hacc[c][2], 0.f), fmaxf(hacc[c][3], 0.f));
+      // local channel = c*16 + 4g + r  ->  slot c*2 + (g>>1), byte (g&1)*8
+      *reinterpret_cast<u32x2*>(dst + actv_addr(q, c * 2 + (g >> 1)) + (g & 1) * 8) = o;
     }
   };
   // generic conditioning (cond_c > 4): K lookup table, weights from global memory; not split
@@ -341,12 +341,96 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
 
   // ---------------- K loop: 12 stages = (quarter q, dx), three dy taps (60 MFMAs per wave at NCT = 5) each.
   // Stage s: barrier (weights of stage s landed, hidden map of quarter q visible) -> start the DMA of stage s+1 ->
-  // B fragments of this dx -> per dy: A fragments + MFMAs.  Between the MFMA blocks the wave computes two hidden
-  // tiles of the NEXT quarter (gather / multiply / store separated by MFMA blocks so their latencies are covered).
-  for (int q = 0; q < 4; ++q) {
+  // B fragments of this dx -> three MFMA blocks.  A wave issues about one instruction per 4 cycles and a 16x16x32
+  // MFMA occupies the matrix pipe for 16, so the stage body is ONE basic block in which the A-fragment reads of the
+  // next block and the wave's share of the NEXT quarter's hidden map (two tiles: gather / multiply / store) are
+  // interleaved with the MFMAs at instruction granularity (sched_group_barrier pattern below).
+  auto stage_body = [&](auto hid_tag, int q, int dx, int s) {
+    constexpr bool HID = decltype(hid_tag)::value;
     const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;   // this quarter's hidden map
     unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;   // next quarter's, written during this one
-    const bool hid = q < 3 && !(p.dbg & 1);
+    const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
+    // hidden tiles of this stage (clamped: a duplicate tile stores identical values)
+    const int htA = min(wave + (dx * 2) * WAVES, NHT - 1), htB = min(wave + (dx * 2 + 1) * WAVES, NHT - 1);
+    u32x4 bfr[PT + 2], a[NCT];
+#pragma unroll
+    for (int r = 0; r < PT + 2; ++r) {
+      const int qq = (wave * PT + r) * HPW + (j + dx);
+      bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + c * 1024);
+    if (HID) hid_gather(htA);
+    // three MFMA blocks (dy).  The A fragment of the next block is fetched into the same registers right after the
+    // last MFMA that reads them has been issued: one register set, LDS latency covered by the other channel tiles.
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+        if (dy < 2) a[c] = *reinterpret_cast<const u32x4*>(wb + ((dy + 1) * NCT + c) * 1024);
+      }
+      if (HID) {
+        if (dy == 0) {
+          hid_mma();
+        } else if (dy == 1) {
+          hid_finish(htA, nbuf);
+          hid_gather(htB);
+        } else {
+          hid_mma();
+          hid_finish(htB, nbuf);
+        }
+      }
+    }
+    // issue order: one MFMA, then up to three other instructions (VALU / LDS / SALU), repeated
+#pragma unroll
+    for (int i = 0; i < 3 * NCT * PT + 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x180, 1, 0);   // DS read/write
+    }
+  };
+
+  // plain stage (NCT >= 4): MFMA blocks with the hidden pieces between them, no forced interleave
+  auto stage_plain = [&](int q, int dx, int s) {
+    const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;
+    unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
+    const bool hid = C4 && q < 3 && !(p.dbg & 1);
+    u32x4 bfr[PT + 2];
+#pragma unroll
+    for (int r = 0; r < PT + 2; ++r) {
+      const int qq = (wave * PT + r) * HPW + (j + dx);
+      bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
+    }
+    const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;   // wave-uniform
+    const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
+    if (hid && htA < NHT) hid_gather(htA);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      u32x4 a[NCT];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c) * 1024);
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+          acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+      if (hid) {
+        if (dy == 0) {
+          if (htA < NHT) hid_mma();
+        } else if (dy == 1) {
+          if (htA < NHT) hid_finish(htA, nbuf);
+          if (htB < NHT) hid_gather(htB);
+        } else if (htB < NHT) {
+          hid_mma();
+          hid_finish(htB, nbuf);
+        }
+      }
+    }
+  };
+
+  for (int q = 0; q < 4; ++q) {
     if (C4 && q < 3) load_wsh(q + 1);
     for (int dx = 0; dx < 3; ++dx) {
       const int s = q * 3 + dx;
@@ -369,45 +453,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
               (__attribute__((address_space(3))) void*)(actv + (k * (WAVES * 64) + wave * 64) * 16), 16, 0, 0);
         }
       }
-      u32x4 bfr[PT + 2];
-#pragma unroll
-      for (int r = 0; r < PT + 2; ++r) {
-        const int qq = (wave * PT + r) * HPW + (j + dx);
-        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
+      constexpr bool ILV = NCT <= 3;   // the interleaved body needs ~16 more VGPRs than NCT >= 4 leaves free
+      if (ILV) {
+        if (C4 && q < 3 && !(p.dbg & 1)) stage_body(std::true_type{}, q, dx, s);
+        else stage_body(std::false_type{}, q, dx, s);
+      } else {
+        stage_plain(q, dx, s);
       }
-      const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;   // wave-uniform
-      const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
-      if (C4 && hid && htA < NHT) hid_gather(htA);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        if (!(p.dbg & 2)) {
-          u32x4 a[NCT];
-#pragma unroll
-          for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c) * 1024);
-#pragma unroll
-          for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int t = 0; t < PT; ++t)
-              acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
-        }
-        if (hid) {
-          if (C4) {
-            if (dy == 0) {
-              if (htA < NHT) hid_mma();
-            } else if (dy == 1) {
-              if (htA < NHT) hid_finish(htA, nbuf);
-              if (htB < NHT) hid_gather(htB);
-            } else {
-              if (htB < NHT) {
-                hid_mma();
-                hid_finish(htB, nbuf);
-              }
-            }
-          } else if (dy == 2) {
-            if (htA < NHT) hidden_tile_generic(htA, q + 1, nbuf);
-            if (htB < NHT) hidden_tile_generic(htB, q + 1, nbuf);
-          }
-        }
+      if (!C4 && q < 3) {   // generic conditioning: not interleaved
+        const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;
+        unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
+        if (htA < NHT) hidden_tile_generic(htA, q + 1, nbuf);
+        if (htB < NHT) hidden_tile_generic(htB, q + 1, nbuf);
       }
     }
   }
