@@ -43,6 +43,8 @@ def default_opts() -> Opts:
     return Opts({
         "tasks": ["d", "s", "m", "p"],                                   # :19
         "gen": {
+            "m": {"use_advent": True},                                   # :173
+            "s": {"use_advent": True},                                   # :139
             "p": {                                                       # :144-165
                 "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True,
                 "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",

@@ -97,3 +97,18 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         PainterSpadeDecoder(opts)
     assert SPADEResnetBlock(8, 4, 3, True, "instance", 3).learned_shortcut
+
+
+def test_discriminator_state_dict_layout():
+    from climategan_amd.config import default_opts
+    from climategan_amd.discriminator import create_discriminator
+    from helpers import disc_fc_shapes, disc_p_shapes
+
+    D = create_discriminator(default_opts(), "cpu")
+    sd = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    want = {"p." + k: v for k, v in disc_p_shapes(4, 64, 4, 3).items()}
+    want.update({"m.Advent." + k: v for k, v in disc_fc_shapes(2).items()})
+    want.update({"s.Advent." + k: v for k, v in disc_fc_shapes(11).items()})
+    assert sd == want and len(sd) == 112
+    n = sum(p.numel() for p in D.parameters())
+    assert 26.4e6 < n < 26.6e6   # SURVEY section 6 [probe]: D_p 20.96 M + D_m 2.78 M + D_s 2.79 M
