@@ -51,6 +51,11 @@ class PackItem(C.Structure):
                 ("kw", C.c_int32)]
 
 
+class AdamItem(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("copy", C.c_void_p),
+                ("numel", C.c_int64)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -69,6 +74,8 @@ _SIGNATURES = {
     "cgan_spectral_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cgan_spectral_norm_power_iter": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     "cgan_spectral_norm_power_iter_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_extra_adam_multi_tensor": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                               C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "cgan_nchw_to_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_nhwc_to_nchw": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_resize_nearest_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

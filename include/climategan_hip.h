@@ -168,6 +168,25 @@ int cgan_spectral_norm_power_iter_batched(const CganSnItem* items_device, int32_
                                           int32_t max_cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ExtraAdam (climategan/optim.py:137-291), fused over all parameter tensors.
+ *   mode 0 = Extragradient.extrapolation (optim.py:153-172): Adam moment update, [copy = p if save_copy], p += u
+ *   mode 1 = Extragradient.step          (optim.py:174-197): Adam moment update, p = copy + u
+ * `step` is the Adam step count AFTER this update (state["step"] is incremented by every update(), optim.py:268).
+ * items_device: DEVICE array; all tensors fp32, contiguous.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;      /* exp_avg */
+  float* v;      /* exp_avg_sq */
+  float* copy;   /* parameters saved by the first extrapolation */
+  int64_t numel;
+} CganAdamItem;
+int cgan_extra_adam_multi_tensor(const CganAdamItem* items_device, int32_t count, int64_t max_numel, int32_t mode,
+                                 int32_t save_copy, int32_t step, double lr, double beta1, double beta2, double eps,
+                                 double weight_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Edge / glue kernels
  * ------------------------------------------------------------------------------------------------ */
 /* fp32 NCHW [n][c][h][w] -> 16-bit NHWC [n][h][w][cs] (cs >= c, multiple of 4; pad channels zeroed).

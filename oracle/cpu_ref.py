@@ -226,3 +226,51 @@ def fc_discriminator(x, sd: SD, prefix: str = "", update=True):
         if i < 4:
             x = F.leaky_relu(x, 0.2)
     return x
+
+
+# --------------------------------------------------------------------------------------------------
+# optim.py: ExtraAdam
+# --------------------------------------------------------------------------------------------------
+class ExtraAdamRef:
+    """Functional restatement of ``ExtraAdam`` (climategan/optim.py:200-291) + ``Extragradient.extrapolation/step``
+    (optim.py:153-197) on a list of tensors.  ``grads[i] is None`` skips the parameter like the reference."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = params
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.state = [dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p in params]
+        self.params_copy = []
+
+    def _update(self, i, grad):
+        import math
+
+        if grad is None:
+            return None
+        st = self.state[i]
+        b1, b2 = self.betas
+        st["step"] += 1
+        if self.wd != 0:
+            grad = grad + self.wd * self.params[i]
+        st["exp_avg"] = st["exp_avg"] * b1 + (1 - b1) * grad
+        st["exp_avg_sq"] = st["exp_avg_sq"] * b2 + (1 - b2) * grad * grad
+        denom = st["exp_avg_sq"].sqrt() + self.eps
+        step_size = self.lr * math.sqrt(1 - b2 ** st["step"]) / (1 - b1 ** st["step"])
+        return -step_size * st["exp_avg"] / denom
+
+    def extrapolation(self, grads):
+        is_empty = len(self.params_copy) == 0
+        for i, g in enumerate(grads):
+            u = self._update(i, g)
+            if is_empty:
+                self.params_copy.append(self.params[i].clone())
+            if u is not None:
+                self.params[i] = self.params[i] + u
+
+    def step(self, grads):
+        if len(self.params_copy) == 0:
+            raise RuntimeError("Need to call extrapolation before calling step.")
+        for i, g in enumerate(grads):
+            u = self._update(i, g)
+            if u is not None:
+                self.params[i] = self.params_copy[i] + u
+        self.params_copy = []

@@ -31,6 +31,8 @@ def golden_cases():
         "paint_up4": dict(kind="paint", latent_dim=32, n_up=4, H=64, W=96, B=2, seed=34, full=True),
         "disc_p": dict(kind="disc_p", ndf=8, n_layers=3, num_D=3, H=96, W=128, B=2, seed=41),
         "disc_fc": dict(kind="disc_fc", num_classes=11, H=64, W=96, B=2, seed=42),
+        "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
+                           B=1, seed=51),
     }
 
 
@@ -58,6 +60,13 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    if k == "extra_adam":
+        d = {}
+        for i, shp in enumerate(case["shapes"]):
+            d["p%d" % i] = fill.uniform(shp, s * 100 + i)
+            for st in range(case["steps"]):
+                d["g%d_%d" % (i, st)] = fill.uniform(shp, s * 1000 + 10 * st + i, -0.5, 0.5)
+        return d
     raise KeyError(k)
 
 
@@ -112,10 +121,39 @@ def build_reference_module(case):
     return mod, sd_np
 
 
+def run_reference_extra_adam(name, case):
+    """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
+    from oracle import ref_shim
+
+    optim = ref_shim.ref("optim")
+    inp = case_inputs(name, case)
+    params = [torch.nn.Parameter(t(inp["p%d" % i]).clone()) for i in range(len(case["shapes"]))]
+    opt = optim.ExtraAdam(params, lr=case["lr"], betas=tuple(case["betas"]))
+    out = {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for st in range(case["steps"]):
+            for i, p in enumerate(params):
+                p.grad = t(inp["g%d_%d" % (i, st)]).clone()
+            if st % 2 == 0:
+                opt.extrapolation()
+            else:
+                opt.step()
+            for i, p in enumerate(params):
+                out["p%d_after%d" % (i, st)] = p.data.numpy().copy()
+    for i, p in enumerate(params):
+        out["m%d" % i] = opt.state[p]["exp_avg"].numpy().copy()
+        out["v%d" % i] = opt.state[p]["exp_avg_sq"].numpy().copy()
+    return out
+
+
 def run_reference(name, case):
     """Run the real reference on the seeded inputs; returns dict of numpy outputs."""
     from oracle import ref_shim
 
+    if case["kind"] == "extra_adam":
+        return run_reference_extra_adam(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}

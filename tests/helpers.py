@@ -28,6 +28,8 @@ def module_shapes(case):
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k == "disc_fc":
         return disc_fc_shapes(case["num_classes"])
+    if k == "extra_adam":
+        return {}
     raise KeyError(k)
 
 
@@ -111,8 +113,26 @@ def case_state_dict(case, dtype=torch.float32):
     return {k: t(v).to(dtype) if v.dtype != np.int64 else t(v) for k, v in sd.items()}
 
 
+def run_oracle_extra_adam(name, case):
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+    n = len(case["shapes"])
+    opt = cpu_ref.ExtraAdamRef([inp["p%d" % i].clone() for i in range(n)], lr=case["lr"], betas=tuple(case["betas"]))
+    out = {}
+    for st in range(case["steps"]):
+        grads = [inp["g%d_%d" % (i, st)] for i in range(n)]
+        (opt.extrapolation if st % 2 == 0 else opt.step)(grads)
+        for i in range(n):
+            out["p%d_after%d" % (i, st)] = opt.params[i].numpy().copy()
+    for i in range(n):
+        out["m%d" % i] = opt.state[i]["exp_avg"].numpy().copy()
+        out["v%d" % i] = opt.state[i]["exp_avg_sq"].numpy().copy()
+    return out
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
+    if case["kind"] == "extra_adam":
+        return run_oracle_extra_adam(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}
