@@ -81,6 +81,12 @@ _SIGNATURES = {
     "cgan_resize_nearest_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_avgpool3x3s2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_maxpool3x3s2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_resize_bilinear_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, _P]),
+    "cgan_copy_channels_nhwc": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_eltwise_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    "cgan_fold_bn": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int32, C.c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .norms import DEFAULT_COMPUTE_DTYPE, SPADE, SpectralNorm, _PackCache, conv_forward
+from .norms import (DEFAULT_COMPUTE_DTYPE, SPADE, SpectralNorm, _grad_guard, _PackCache, conv_bn_forward,
+                    conv_forward)
 
 
 class InterpolateNearest2d(nn.Module):
@@ -26,6 +27,162 @@ class InterpolateNearest2d(nn.Module):
         dt = DEFAULT_COMPUTE_DTYPE
         y = ops.resize_nearest(ops.nchw_to_nhwc(x, dt), (x.shape[-2] * self.scale_factor, x.shape[-1] * self.scale_factor))
         return ops.nhwc_to_nchw(y).to(x.dtype)
+
+
+_ACTS = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH, "sigmoid": ops.ACT_SIGMOID,
+         "none": ops.ACT_NONE}
+
+
+class Conv2dBlock(nn.Module):
+    """pad -> conv (optionally spectral-norm wrapped) -> norm -> activation (reference climategan/blocks.py:49-146).
+
+    HIP forward: the explicit pad module becomes the conv kernel's padding mode (zero / reflect); an eval-mode
+    BatchNorm is folded into the weights; bias, activation and an optional residual ride in the conv epilogue."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride=1, padding=0, dilation=1, norm="none",
+                 activation="relu", pad_type="zero", bias=True):
+        super().__init__()
+        self.use_bias = bias
+        if pad_type == "reflect":
+            self.pad = nn.ReflectionPad2d(padding)
+        elif pad_type == "replicate":
+            self.pad = nn.ReplicationPad2d(padding)
+        elif pad_type == "zero":
+            self.pad = nn.ZeroPad2d(padding)
+        else:
+            assert 0, "Unsupported padding type: {}".format(pad_type)
+        self.pad_type, self.padding = pad_type, padding
+        use_spectral_norm = False
+        if norm.startswith("spectral_"):
+            norm = norm.replace("spectral_", "")
+            use_spectral_norm = True
+        if norm == "batch":
+            self.norm = nn.BatchNorm2d(output_dim)
+        elif norm == "instance":
+            self.norm = nn.InstanceNorm2d(output_dim)
+        elif norm in ("layer", "adain"):
+            raise NotImplementedError("Conv2dBlock: norm '%s' is a dead option in the default configs; no HIP path" % norm)
+        elif norm == "spectral" or norm == "none":
+            self.norm = None
+        else:
+            raise ValueError("Unsupported normalization: {}".format(norm))
+        if activation in ("prelu", "selu"):
+            raise NotImplementedError("Conv2dBlock: activation '%s' has no HIP path" % activation)
+        if activation not in _ACTS:
+            raise ValueError("Unsupported activation: {}".format(activation))
+        self.activation_name = activation
+        self.activation = {"relu": nn.ReLU(inplace=False), "lrelu": nn.LeakyReLU(0.2, inplace=False), "tanh": nn.Tanh(),
+                           "sigmoid": nn.Sigmoid(), "none": None}[activation]
+        if norm == "spectral" or use_spectral_norm:
+            self.conv = SpectralNorm(nn.Conv2d(input_dim, output_dim, kernel_size, stride, dilation=dilation,
+                                               bias=self.use_bias))
+        else:
+            self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, dilation=dilation,
+                                  bias=self.use_bias if norm != "batch" else False)
+        self._cache = _PackCache()
+
+    def forward_nhwc(self, x: ops.NHWC, residual=None) -> ops.NHWC:
+        if self.pad_type == "replicate":
+            raise NotImplementedError("Conv2dBlock: replicate padding has no HIP path")
+        pad_mode = ops.PAD_REFLECT if (self.pad_type == "reflect" and self.padding > 0) else ops.PAD_ZERO
+        act = _ACTS[self.activation_name]
+        sn = isinstance(self.conv, SpectralNorm)
+        if isinstance(self.norm, nn.InstanceNorm2d):
+            if residual is not None:
+                raise NotImplementedError("Conv2dBlock: residual + instance norm cannot be fused")
+            y = (self.conv(x, pad=self.padding, pad_mode=pad_mode) if sn else
+                 conv_bn_forward(self.conv, None, self._cache, x, pad_mode=pad_mode, pad=self.padding))
+            mean, rstd = ops.instnorm_stats(y, eps=self.norm.eps)
+            return ops.norm_act_apply(y, mean, rstd, act=act, slope=0.2)
+        if sn:
+            if self.norm is not None:
+                raise NotImplementedError("Conv2dBlock: spectral_batch has no HIP path yet")
+            return self.conv(x, pad=self.padding, pad_mode=pad_mode, act=act, slope=0.2, residual=residual)
+        return conv_bn_forward(self.conv, self.norm, self._cache, x, pad_mode=pad_mode, pad=self.padding, act=act,
+                               slope=0.2, residual=residual)
+
+    def forward(self, x, compute_dtype=None):
+        dt = compute_dtype or DEFAULT_COMPUTE_DTYPE
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x, dt))).to(x.dtype)
+
+
+class ResBlock(nn.Module):
+    """reference climategan/blocks.py:174-201: out = conv_b(conv_a(x)) + x (the add is fused into conv_b)."""
+
+    def __init__(self, dim, norm="in", activation="relu", pad_type="zero"):
+        super().__init__()
+        self.dim, self.norm, self.activation = dim, norm, activation
+        self.model = nn.Sequential(
+            Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation=activation, pad_type=pad_type),
+            Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation="none", pad_type=pad_type))
+
+    def forward_nhwc(self, x):
+        return self.model[1].forward_nhwc(self.model[0].forward_nhwc(x), residual=x)
+
+
+class ResBlocks(nn.Module):
+    """reference climategan/blocks.py:153-171"""
+
+    def __init__(self, num_blocks, dim, norm="in", activation="relu", pad_type="zero"):
+        super().__init__()
+        self.model = nn.Sequential(*[ResBlock(dim, norm=norm, activation=activation, pad_type=pad_type)
+                                     for _ in range(num_blocks)])
+
+    def forward_nhwc(self, x):
+        for b in self.model:
+            x = b.forward_nhwc(x)
+        return x
+
+
+class BaseDecoder(nn.Module):
+    """reference climategan/blocks.py:206-313 (mask decoder base)."""
+
+    def __init__(self, n_upsample=4, n_res=4, input_dim=2048, proj_dim=64, output_dim=3, norm="batch", activ="relu",
+                 pad_type="zero", output_activ="tanh", low_level_feats_dim=-1, use_dada=False):
+        super().__init__()
+        self.low_level_feats_dim = low_level_feats_dim
+        self.use_dada = use_dada
+        if proj_dim != -1:
+            self.proj_conv = Conv2dBlock(input_dim, proj_dim, 1, 1, 0, norm=norm, activation=activ)
+        else:
+            self.proj_conv = None
+            proj_dim = input_dim
+        if low_level_feats_dim > 0:
+            self.low_level_conv = Conv2dBlock(input_dim=low_level_feats_dim, output_dim=proj_dim, kernel_size=3, stride=1,
+                                              padding=1, pad_type=pad_type, norm=norm, activation=activ)
+            self.merge_feats_conv = Conv2dBlock(input_dim=2 * proj_dim, output_dim=proj_dim, kernel_size=1, stride=1,
+                                                padding=0, pad_type=pad_type, norm=norm, activation=activ)
+        else:
+            self.low_level_conv = None
+        model = [ResBlocks(n_res, proj_dim, norm, activ, pad_type=pad_type)]
+        dim = proj_dim
+        for _ in range(n_upsample):
+            model += [InterpolateNearest2d(scale_factor=2),
+                      Conv2dBlock(input_dim=dim, output_dim=dim // 2, kernel_size=3, stride=1, padding=1,
+                                  pad_type=pad_type, norm=norm, activation=activ)]
+            dim //= 2
+        model += [Conv2dBlock(input_dim=dim, output_dim=output_dim, kernel_size=3, stride=1, padding=1,
+                              pad_type=pad_type, norm="none", activation=output_activ)]
+        self.model = nn.Sequential(*model)
+
+    def forward_nhwc(self, z, cond=None, z_depth=None) -> ops.NHWC:
+        low = None
+        if isinstance(z, (list, tuple)):
+            if self.low_level_conv is None:
+                z = z[0]
+            else:
+                z, low = z
+                low = self.low_level_conv.forward_nhwc(low)
+                low = ops.resize_bilinear(low, (z.h, z.w), align_corners=False)     # blocks.py:300-302
+        if z_depth is not None and self.use_dada:
+            z = ops.eltwise_mul(z, z_depth)
+        if self.proj_conv is not None:
+            z = self.proj_conv.forward_nhwc(z)
+        if low is not None:
+            z = self.merge_feats_conv.forward_nhwc(ops.concat_channels([low, z]))
+        for m in self.model:
+            z = m(z) if isinstance(m, InterpolateNearest2d) else m.forward_nhwc(z)
+        return z
 
 
 class SPADEResnetBlock(nn.Module):

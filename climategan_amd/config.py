@@ -42,9 +42,16 @@ def default_opts() -> Opts:
     """Hot-path subset of shared/trainer/defaults.yaml (line numbers of the reference file in comments)."""
     return Opts({
         "tasks": ["d", "s", "m", "p"],                                   # :19
+        "data": {"transforms": [{"name": "resize", "new_size": {"default": 640, "d": 160, "s": 160}}]},   # :61-67
         "gen": {
-            "m": {"use_advent": True},                                   # :173
-            "s": {"use_advent": True},                                   # :139
+            "encoder": {"architecture": "deeplabv3"},                    # :103
+            "deeplabv3": {"backbone": "resnet", "output_stride": 8},     # :115-116
+            "d": {"architecture": "dada", "upsample_featuremaps": True, "output_dim": 1, "norm": "batch"},   # :122-134
+            "s": {"use_advent": True, "use_dada": True, "architecture": "deeplabv3", "output_dim": 11,
+                  "num_classes": 11},                                    # :135-143
+            "m": {"use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
+                  "use_dada": False, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
+                  "activ": "lrelu", "pad_type": "reflect"},              # :166-180 (+ default-gen :89-99)
             "p": {                                                       # :144-165
                 "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True,
                 "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",

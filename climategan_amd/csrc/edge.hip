@@ -122,6 +122,133 @@ __global__ void avgpool3x3s2_kernel(const uint16_t* __restrict__ x, uint16_t* __
   }
 }
 
+// MaxPool2d(3, stride=2, padding=1) (ResNet stem, reference deeplab/resnet101_v3.py:74)
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_in, int w_in,
+                                    int h_out, int w_out, int cs, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int cg = (int)(idx % cg_total);
+    long pix = idx / cg_total;
+    int ox = (int)(pix % w_out);
+    long r = pix / w_out;
+    int oy = (int)(r % h_out);
+    long n = r / h_out;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      int iy = oy * 2 - 1 + dy;
+      if (iy < 0 || iy >= h_in) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        int ix = ox * 2 - 1 + dx;
+        if (ix < 0 || ix >= w_in) continue;
+        u32x4 v = *reinterpret_cast<const u32x4*>(x + ((n * h_in + iy) * (long)w_in + ix) * cs + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          unpack2<T>(v[e], a, b);
+          acc[2 * e] = fmaxf(acc[2 * e], a);
+          acc[2 * e + 1] = fmaxf(acc[2 * e + 1], b);
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(y + pix * cs + cg * 8) = o;
+  }
+}
+
+// F.interpolate(mode="bilinear", align_corners=ac) on NHWC (reference deeplab_v3.py:136-138,262-264,
+// blocks.py:300-302).  Source index as torch's area_pixel_compute_source_index: align_corners -> dst*(in-1)/(out-1);
+// otherwise max((dst+0.5)*in/out - 0.5, 0).
+template <typename T>
+__global__ void resize_bilinear_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_in, int w_in,
+                                       int h_out, int w_out, int cs, float sy, float sx, int align, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int cg = (int)(idx % cg_total);
+    long pix = idx / cg_total;
+    int ox = (int)(pix % w_out);
+    long r = pix / w_out;
+    int oy = (int)(r % h_out);
+    long n = r / h_out;
+    float fy = align ? oy * sy : fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+    float fx = align ? ox * sx : fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < h_in - 1 ? y0 : h_in - 1;
+    x0 = x0 < w_in - 1 ? x0 : w_in - 1;
+    int y1 = y0 < h_in - 1 ? y0 + 1 : y0, x1 = x0 < w_in - 1 ? x0 + 1 : x0;
+    float ly = fy - y0, lx = fx - x0;
+    const uint16_t* base = x + n * (long)h_in * w_in * cs + cg * 8;
+    u32x4 v00 = *reinterpret_cast<const u32x4*>(base + ((long)y0 * w_in + x0) * cs);
+    u32x4 v01 = *reinterpret_cast<const u32x4*>(base + ((long)y0 * w_in + x1) * cs);
+    u32x4 v10 = *reinterpret_cast<const u32x4*>(base + ((long)y1 * w_in + x0) * cs);
+    u32x4 v11 = *reinterpret_cast<const u32x4*>(base + ((long)y1 * w_in + x1) * cs);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a00, b00, a01, b01, a10, b10, a11, b11;
+      unpack2<T>(v00[e], a00, b00); unpack2<T>(v01[e], a01, b01);
+      unpack2<T>(v10[e], a10, b10); unpack2<T>(v11[e], a11, b11);
+      float a = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
+      float b = (1.f - ly) * ((1.f - lx) * b00 + lx * b01) + ly * ((1.f - lx) * b10 + lx * b11);
+      o[e] = pack2<T>(a, b);
+    }
+    *reinterpret_cast<u32x4*>(y + pix * cs + cg * 8) = o;
+  }
+}
+
+// copy the c channels of src [n*hw][cs_src] into channels [c_off, c_off + c) of dst [n*hw][cs_dst]
+// (torch.cat along channels = one call per input; c_off must be a multiple of 8 -- true for every concat of the path)
+__global__ void copy_channels_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cs_src,
+                                     int cs_dst, int c_off, int groups, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int gidx = (int)(idx % groups);
+    long pix = idx / groups;
+    *reinterpret_cast<u32x4*>(dst + pix * cs_dst + c_off + gidx * 8) =
+        *reinterpret_cast<const u32x4*>(src + pix * cs_src + gidx * 8);
+  }
+}
+
+// y = op(a, b): 0 = a * b (DADA feature fusion z * z_depth, reference deeplab_v3.py:253-254, blocks.py:304-305),
+// 1 = sigmoid(a) (generator.py:277)
+template <typename T>
+__global__ void eltwise_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
+                               int op, long total_groups) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_groups; idx += (long)gridDim.x * blockDim.x) {
+    u32x4 va = reinterpret_cast<const u32x4*>(a)[idx];
+    u32x4 vb = op == 0 ? reinterpret_cast<const u32x4*>(b)[idx] : va;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a0, a1, b0, b1;
+      unpack2<T>(va[e], a0, a1);
+      unpack2<T>(vb[e], b0, b1);
+      float r0 = op == 0 ? a0 * b0 : 1.f / (1.f + __expf(-a0));
+      float r1 = op == 0 ? a1 * b1 : 1.f / (1.f + __expf(-a1));
+      o[e] = pack2<T>(r0, r1);
+    }
+    reinterpret_cast<u32x4*>(y)[idx] = o;
+  }
+}
+
+// Fold an eval-mode BatchNorm2d into the preceding convolution:  w' = w * s[o],  b' = (b - mean[o]) * s[o] + beta[o],
+// s[o] = gamma[o] / sqrt(var[o] + eps)     (reference climategan/bn_fusion.py:121-132 states the same algebra)
+__global__ void fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                               float* __restrict__ w_out, float* __restrict__ b_out, int cout, long per_out) {
+  long total = (long)cout * per_out;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int o = (int)(idx / per_out);
+    float s = (gamma ? gamma[o] : 1.f) * rsqrtf(var[o] + eps);
+    w_out[idx] = w[idx] * s;
+    if (idx % per_out == 0) b_out[o] = ((bias ? bias[o] : 0.f) - mean[o]) * s + (beta ? beta[o] : 0.f);
+  }
+}
+
 inline int grid_for(long total, int threads = 256, int cap = 8192) {
   long b = (total + threads - 1) / threads;
   return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -200,5 +327,95 @@ extern "C" int cgan_avgpool3x3s2_nhwc(const void* x, void* y, int32_t dtype, int
     hipLaunchKernelGGL(avgpool3x3s2_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
                        (uint16_t*)y, h_in, w_in, h_out, w_out, cs, total);
   CGAN_CHECK_LAUNCH("avgpool3x3s2");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_maxpool3x3s2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                      int32_t w_in, void* stream) {
+  CGAN_REQUIRE(x && y, "maxpool3x3s2: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "maxpool3x3s2: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0, "maxpool3x3s2: bad shape");
+  int h_out = (h_in + 2 - 3) / 2 + 1, w_out = (w_in + 2 - 3) / 2 + 1;
+  int cs = cgan_cs(c);
+  long total = (long)n * h_out * w_out * (cs / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
+                       (uint16_t*)y, h_in, w_in, h_out, w_out, cs, total);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
+                       (uint16_t*)y, h_in, w_in, h_out, w_out, cs, total);
+  CGAN_CHECK_LAUNCH("maxpool3x3s2");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_resize_bilinear_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                         int32_t w_in, int32_t h_out, int32_t w_out, int32_t align_corners,
+                                         void* stream) {
+  CGAN_REQUIRE(x && y, "resize_bilinear: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "resize_bilinear: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "resize_bilinear: bad shape");
+  int cs = cgan_cs(c);
+  long total = (long)n * h_out * w_out * (cs / 8);
+  float sy, sx;
+  if (align_corners) {
+    sy = h_out > 1 ? (float)(h_in - 1) / (float)(h_out - 1) : 0.f;
+    sx = w_out > 1 ? (float)(w_in - 1) / (float)(w_out - 1) : 0.f;
+  } else {
+    sy = (float)h_in / (float)h_out;
+    sx = (float)w_in / (float)w_out;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(resize_bilinear_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
+                       (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners, total);
+  else
+    hipLaunchKernelGGL(resize_bilinear_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
+                       (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners, total);
+  CGAN_CHECK_LAUNCH("resize_bilinear");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_copy_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src,
+                                       int32_t cs_dst, int32_t c_off, void* stream) {
+  CGAN_REQUIRE(src && dst, "copy_channels: null pointer");
+  CGAN_REQUIRE(npix > 0 && c > 0 && (cs_src % 8) == 0 && (cs_dst % 8) == 0 && (c_off % 8) == 0 && cs_src >= c &&
+                   c_off + cgan_cs(c) <= cs_dst,
+               "copy_channels: bad channel layout");
+  int groups = cgan_cs(c) / 8;
+  long total = npix * groups;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, (uint16_t*)dst, cs_src, cs_dst, c_off, groups, total);
+  CGAN_CHECK_LAUNCH("copy_channels");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_eltwise_nhwc(const void* a, const void* b, void* y, int32_t dtype, int32_t op, int64_t numel,
+                                 void* stream) {
+  CGAN_REQUIRE(a && y && (op == 1 || b), "eltwise: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "eltwise: bad dtype %d", dtype);
+  CGAN_REQUIRE(op == 0 || op == 1, "eltwise: unknown op %d", op);
+  CGAN_REQUIRE(numel > 0 && (numel % 8) == 0, "eltwise: numel must be a positive multiple of 8");
+  long groups = numel / 8;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(eltwise_kernel<F16>, dim3(grid_for(groups)), dim3(256), 0, s, (const uint16_t*)a,
+                       (const uint16_t*)b, (uint16_t*)y, op, groups);
+  else
+    hipLaunchKernelGGL(eltwise_kernel<BF16>, dim3(grid_for(groups)), dim3(256), 0, s, (const uint16_t*)a,
+                       (const uint16_t*)b, (uint16_t*)y, op, groups);
+  CGAN_CHECK_LAUNCH("eltwise");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_fold_bn(const float* w, const float* bias, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, float* w_out, float* b_out, int32_t c_out, int64_t per_out,
+                            void* stream) {
+  CGAN_REQUIRE(w && mean && var && w_out && b_out, "fold_bn: null pointer");
+  CGAN_REQUIRE(c_out > 0 && per_out > 0, "fold_bn: bad shape");
+  long total = (long)c_out * per_out;
+  hipLaunchKernelGGL(fold_bn_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, bias, gamma, beta,
+                     mean, var, eps, w_out, b_out, c_out, (long)per_out);
+  CGAN_CHECK_LAUNCH("fold_bn");
   return CGAN_OK;
 }

@@ -1,0 +1,65 @@
+"""DADA depth decoder -- mirror of the reference's ``climategan/depth.py`` (DADADepthDecoder; the non-default
+BaseDepthDecoder is out of scope)."""
+import torch.nn as nn
+
+from . import ops
+from .blocks import Conv2dBlock, InterpolateNearest2d
+from .norms import _PackCache, conv_bn_forward
+from .utils import find_target_size
+
+
+def create_depth_decoder(opts, no_init=False, verbose=0):
+    """reference depth.py:9-22"""
+    if opts.gen.d.architecture == "base":
+        raise NotImplementedError("BaseDepthDecoder (non-default) has no HIP path")
+    return DADADepthDecoder(opts)
+
+
+class DADADepthDecoder(nn.Module):
+    """reference depth.py:25-158: enc4_1/2/3 (1x1, 3x3 reflect, 1x1; BN + LeakyReLU), optional feature-fusion output
+    ``z_depth = dec4(z4_enc)``, then nearest x2 + 3x3 (128->32) + 1x1 (32->1) and the channel mean."""
+
+    def __init__(self, opts):
+        super().__init__()
+        if opts.gen.encoder.architecture == "deeplabv3" and opts.gen.deeplabv3.backbone == "mobilenet":
+            raise NotImplementedError("DADADepthDecoder: mobilenet backbone has no HIP path")
+        res_dim, mid_dim = 2048, 512
+        self.do_feat_fusion = False
+        if opts.gen.m.use_dada or ("s" in opts.tasks and opts.gen.s.use_dada):
+            self.do_feat_fusion = True
+            self.dec4 = Conv2dBlock(128, res_dim, 1, stride=1, padding=0, bias=True, activation="lrelu", norm="none")
+        self.relu = nn.ReLU(inplace=True)
+        kw = dict(stride=1, bias=False, activation="lrelu", pad_type="reflect", norm="batch")
+        self.enc4_1 = Conv2dBlock(res_dim, mid_dim, 1, padding=0, **kw)
+        self.enc4_2 = Conv2dBlock(mid_dim, mid_dim, 3, padding=1, **kw)
+        self.enc4_3 = Conv2dBlock(mid_dim, 128, 1, padding=0, **kw)
+        self.upsample = None
+        if opts.gen.d.upsample_featuremaps:
+            self.upsample = nn.Sequential(InterpolateNearest2d(), Conv2dBlock(128, 32, 3, padding=1, **kw),
+                                          nn.Conv2d(32, 1, kernel_size=1, stride=1, padding=0))
+        self._target_size = find_target_size(opts, "d")
+        self._cache = _PackCache()
+
+    def set_target_size(self, size):
+        self._target_size = size[:2] if isinstance(size, (list, tuple)) else (size, size)
+
+    def forward_nhwc(self, z):
+        if isinstance(z, (list, tuple)):
+            z = z[0]
+        z4 = self.enc4_3.forward_nhwc(self.enc4_2.forward_nhwc(self.enc4_1.forward_nhwc(z)))
+        z_depth = self.dec4.forward_nhwc(z4) if self.do_feat_fusion else None
+        if self.upsample is None:
+            raise NotImplementedError("DADADepthDecoder: upsample_featuremaps=False (channel mean over 128 maps) "
+                                      "has no HIP path; the default config upsamples")
+        up = ops.resize_nearest(z4, (z4.h * 2, z4.w * 2))
+        up = self.upsample[1].forward_nhwc(up)
+        depth = conv_bn_forward(self.upsample[2], None, self._cache, up)   # 1 channel: the channel mean is the identity
+        ts = self._target_size
+        if ts is not None and depth.w != (ts if isinstance(ts, int) else ts[-1]):
+            raise NotImplementedError("DADADepthDecoder: bicubic re-sampling to a target size different from the "
+                                      "feature size (depth.py:143-153) has no HIP path")
+        return depth, z_depth
+
+    def forward(self, z):
+        d, zd = self.forward_nhwc(z)
+        return ops.nhwc_to_nchw(d), zd

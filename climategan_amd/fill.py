@@ -52,7 +52,7 @@ def rect_mask(batch: int, h: int, w: int, seed: int = 0) -> np.ndarray:
     return m
 
 
-def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
+def fill_state_dict(shapes: dict, seed: int = 0, gain: float = 1.0) -> dict:
     """Fill a {key: shape} dict the way an (untrained) reference module is populated.
 
     * conv weights / ``weight_bar``: U(-1/sqrt(fan_in), 1/sqrt(fan_in))  (torch's default conv init, which is
@@ -63,6 +63,8 @@ def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
     * ``weight_u`` / ``weight_v``: l2-normalised random vectors (reference norms.py:129-133)
     * BatchNorm ``weight``: 1 + 0.1 U(-1,1); ``bias``: 0.1 U(-1,1); ``running_mean``: 0.1 U(-1,1);
       ``running_var``: 1 + 0.2 U(0,1); ``num_batches_tracked``: 0
+    ``gain`` scales the conv-weight bound (the ResNet-101 fixtures use 1.6 so that 33 residual blocks neither
+    vanish nor overflow fp16 with untrained weights).
     """
     out = {}
     fan_in = {}
@@ -74,7 +76,7 @@ def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
         s = key_seed(k, seed)
         base, leaf = k.rsplit(".", 1) if "." in k else ("", k)
         if leaf in ("weight", "weight_bar") and len(shp) == 4:
-            b = 1.0 / np.sqrt(fan_in[base])
+            b = gain / np.sqrt(fan_in[base])
             out[k] = uniform(shp, s, -b, b)
         elif leaf == "bias" and base in fan_in:
             b = 1.0 / np.sqrt(fan_in[base])

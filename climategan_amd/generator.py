@@ -9,6 +9,10 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .deeplab import create_encoder, create_segmentation_decoder
+from .depth import create_depth_decoder
+from .masker import create_mask_decoder
+from .norms import DEFAULT_COMPUTE_DTYPE, _grad_guard, spectral_norm_step_all
 from .painter import create_painter
 
 
@@ -25,10 +29,17 @@ class OmniGenerator(nn.Module):
         self.opts = opts
         self.verbose = verbose
         self.encoder = None
+        self.compute_dtype = DEFAULT_COMPUTE_DTYPE
         if any(t in opts.tasks for t in "msd"):
-            if verbose > 0:
-                print("  - Masker (encoder + d/s/m decoders): HIP path not built yet; skipped")
-        self.decoders = nn.ModuleDict({})
+            self.encoder = create_encoder(opts, no_init, verbose)
+        decoders = {}
+        if "d" in opts.tasks:
+            decoders["d"] = create_depth_decoder(opts, no_init, verbose)
+        if "s" in opts.tasks:
+            decoders["s"] = create_segmentation_decoder(opts, no_init, verbose)
+        if "m" in opts.tasks:
+            decoders["m"] = create_mask_decoder(opts, no_init, verbose)
+        self.decoders = nn.ModuleDict(decoders)
         self.painter = nn.Module()
         if "p" in opts.tasks:
             self.painter = create_painter(opts, no_init, verbose)
@@ -39,16 +50,75 @@ class OmniGenerator(nn.Module):
         for m in self.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = dtype
+        self.compute_dtype = dtype
         return self
 
     def encode(self, x):
-        raise NotImplementedError("OmniGenerator.encode: the Masker's HIP path is not built yet")
+        """reference generator.py:107-118.  x: [B,3,H,W] NCHW; returns (z_high, z_low) as NHWC containers."""
+        assert self.encoder is not None
+        _grad_guard(self.encoder)
+        self.encoder.compute_dtype = self.compute_dtype
+        return self.encoder.forward(x)
+
+    def masker_forward(self, x, sigmoid=True):
+        """Masker inference (reference trainer.py:272-287: z = encode(x); d, z_depth = dec_d(z); s = dec_s(z, z_depth);
+        m = mask(z=z, z_depth=z_depth)).  Returns NCHW fp32 tensors {"d", "s", "m"} (m = sigmoid(logits) by default)."""
+        z = self.encode(x)
+        out = {}
+        z_depth = None
+        if "d" in self.decoders:
+            d, z_depth = self.decoders["d"].forward_nhwc(z)
+            out["d"] = ops.nhwc_to_nchw(d).to(x.dtype)
+        if "s" in self.decoders:
+            out["s"] = ops.nhwc_to_nchw(self.decoders["s"].forward_nhwc(z, z_depth)).to(x.dtype)
+        if "m" in self.decoders:
+            out["m"] = self.mask(z=z, z_depth=z_depth, sigmoid=sigmoid).to(x.dtype)
+        return out
 
     def decode(self, x=None, z=None, return_z=False, return_z_depth=False):
-        raise NotImplementedError("OmniGenerator.decode: the Masker's HIP path is not built yet")
+        """reference generator.py:120-177 (default config: no SPADE conditioning of the mask decoder)."""
+        assert x is not None or z is not None
+        if z is None:
+            z = self.encode(x)
+        out = {}
+        z_depth = None
+        if "d" in self.decoders:
+            d, z_depth = self.decoders["d"].forward_nhwc(z)
+            out["d"] = ops.nhwc_to_nchw(d)
+        if "s" in self.decoders:
+            out["s"] = ops.nhwc_to_nchw(self.decoders["s"].forward_nhwc(z, z_depth))
+        if "m" in self.decoders:
+            out["m"] = self.mask(z=z, z_depth=z_depth)
+        if return_z:
+            out["z"] = z
+        if return_z_depth:
+            out["z_depth"] = z_depth
+        return out
+
+    def depth(self, x=None, z=None, return_z_depth=False):
+        """reference generator.py:330-355"""
+        assert x is not None or z is not None
+        assert "d" in self.decoders
+        if z is None:
+            z = self.encode(x)
+        d, z_depth = self.decoders["d"].forward_nhwc(z)
+        d = ops.nhwc_to_nchw(d)
+        return (d, z_depth) if return_z_depth else d
 
     def mask(self, x=None, z=None, cond=None, z_depth=None, sigmoid=True):
-        raise NotImplementedError("OmniGenerator.mask: the Masker's HIP path is not built yet")
+        """reference generator.py:232-277: logits = decoders["m"](z, cond, z_depth); sigmoid by default."""
+        assert x is not None or z is not None
+        if z is None:
+            z = self.encode(x)
+        dec = self.decoders["m"]
+        _grad_guard(dec)
+        if z_depth is None and self.opts.gen.m.use_dada:
+            _, z_depth = self.decoders["d"].forward_nhwc(z)
+        spectral_norm_step_all(dec, z[0].t.dtype if isinstance(z, (tuple, list)) else z.t.dtype)
+        logits = dec.forward_nhwc(z, cond, z_depth)
+        if sigmoid:
+            logits = ops.sigmoid(logits)
+        return ops.nhwc_to_nchw(logits)
 
     def sample_painter_z(self, batch_size, device, force_half=False):
         """reference generator.py:179-194"""

@@ -91,7 +91,8 @@ class SpectralNorm(nn.Module):
         _grad_guard(self)
         m = self.module
         pw = self.packed(x.t.dtype)
-        return ops.conv2d(x, pw, stride=m.stride[0], pad=m.padding[0], dilation=m.dilation[0], **conv_kwargs)
+        pad = conv_kwargs.pop("pad", m.padding[0])   # Conv2dBlock pads with a separate module (padding=0 on the conv)
+        return ops.conv2d(x, pw, stride=m.stride[0], pad=pad, dilation=m.dilation[0], **conv_kwargs)
 
 
 class PlainConv(nn.Module):
@@ -118,6 +119,32 @@ def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.N
                    lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None,
                                                 x.t.dtype))
     return ops.conv2d(x, pw, stride=conv.stride[0], pad=conv.padding[0], dilation=conv.dilation[0], **kw)
+
+
+def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mode=ops.PAD_ZERO, pad=None, **kw) -> ops.NHWC:
+    """``bn(conv(x))`` with an eval-mode ``nn.BatchNorm2d`` folded into the conv weights (the same algebra as the
+    reference's ``--fuse`` path, bn_fusion.py:121-132); ``bn`` may be None.  Training-mode batch statistics have no
+    HIP kernel yet and raise."""
+    _grad_guard(conv)
+    if bn is not None:
+        if bn.training:
+            raise NotImplementedError("BatchNorm2d in training mode (batch statistics) has no HIP path yet; call .eval()")
+        _grad_guard(bn)
+
+    def build():
+        if bn is None:
+            return ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None, x.t.dtype)
+        w, b = ops.fold_bn(conv.weight.data, conv.bias.data if conv.bias is not None else None,
+                           bn.weight.data if bn.affine else None, bn.bias.data if bn.affine else None,
+                           bn.running_mean, bn.running_var, bn.eps)
+        return ops.pack_conv_weight(w, b, x.t.dtype)
+
+    params = [conv.weight, conv.bias]
+    if bn is not None:
+        params += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    pw = cache.get(params, x.t.dtype, build)
+    return ops.conv2d(x, pw, stride=conv.stride[0], pad=conv.padding[0] if pad is None else pad,
+                      dilation=conv.dilation[0], pad_mode=pad_mode, **kw)
 
 
 class SPADE(nn.Module):

@@ -112,6 +112,83 @@ def avgpool3x3s2(x: NHWC) -> NHWC:
     return NHWC(y, x.c)
 
 
+def maxpool3x3s2(x: NHWC) -> NHWC:
+    _need_cuda(x.t)
+    oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
+    y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_maxpool3x3s2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
+               "cgan_maxpool3x3s2_nhwc")
+    return NHWC(y, x.c)
+
+
+def resize_bilinear(x: NHWC, size: Tuple[int, int], align_corners: bool = False) -> NHWC:
+    _need_cuda(x.t)
+    oh, ow = size
+    if x.cs != cs8(x.c):
+        raise RuntimeError("resize_bilinear: input must be stored with round_up(c, 8) channels")
+    y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_resize_bilinear_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, oh, ow,
+                                             int(bool(align_corners)), _stream()), "cgan_resize_bilinear_nhwc")
+    return NHWC(y, x.c)
+
+
+def concat_channels(xs) -> NHWC:
+    """torch.cat(xs, dim=1) on NHWC tensors; every input but the last must have a multiple-of-8 channel count."""
+    n, h, w = xs[0].n, xs[0].h, xs[0].w
+    c_total = sum(x.c for x in xs)
+    y = torch.zeros((n, h, w, cs8(c_total)), dtype=xs[0].t.dtype, device=xs[0].t.device)
+    lib = _lib.load()
+    off = 0
+    for i, x in enumerate(xs):
+        _need_cuda(x.t)
+        if (x.n, x.h, x.w) != (n, h, w) or x.t.dtype != y.dtype:
+            raise RuntimeError("concat_channels: shape / dtype mismatch")
+        if off % 8 != 0:
+            raise RuntimeError("concat_channels: channel offset %d is not a multiple of 8" % off)
+        _lib.check(lib.cgan_copy_channels_nhwc(_ptr(x.t), _ptr(y), n * h * w, x.c, x.cs, y.shape[3], off, _stream()),
+                   "cgan_copy_channels_nhwc")
+        off += x.c
+    return NHWC(y, c_total)
+
+
+def eltwise_mul(a: NHWC, b: NHWC) -> NHWC:
+    _need_cuda(a.t, b.t)
+    if a.t.shape != b.t.shape or a.c != b.c:
+        raise RuntimeError("eltwise_mul: shape mismatch")
+    y = torch.empty_like(a.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_eltwise_nhwc(_ptr(a.t), _ptr(b.t), _ptr(y), a.dtype_id, 0, a.t.numel(), _stream()),
+               "cgan_eltwise_nhwc")
+    return NHWC(y, a.c)
+
+
+def sigmoid(a: NHWC) -> NHWC:
+    """Elementwise sigmoid (pad channels are re-zeroed by the caller if it matters: sigmoid(0) = 0.5)."""
+    _need_cuda(a.t)
+    y = torch.empty_like(a.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_eltwise_nhwc(_ptr(a.t), _ptr(None), _ptr(y), a.dtype_id, 1, a.t.numel(), _stream()),
+               "cgan_eltwise_nhwc")
+    return NHWC(y, a.c)
+
+
+def fold_bn(w: torch.Tensor, bias, bn_weight, bn_bias, running_mean, running_var, eps: float):
+    """Eval-mode BatchNorm folded into the preceding conv: returns (w', b') fp32 device tensors."""
+    _need_cuda(w, bias, bn_weight, bn_bias, running_mean, running_var)
+    w = w.detach().contiguous().float()
+    c_out = w.shape[0]
+    w_out = torch.empty_like(w)
+    b_out = torch.empty(c_out, dtype=torch.float32, device=w.device)
+    ts = [t.detach().contiguous().float() if t is not None else None
+          for t in (bias, bn_weight, bn_bias, running_mean, running_var)]
+    lib = _lib.load()
+    _lib.check(lib.cgan_fold_bn(_ptr(w), _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]), _ptr(ts[4]), float(eps),
+                                _ptr(w_out), _ptr(b_out), c_out, w.numel() // c_out, _stream()), "cgan_fold_bn")
+    return w_out, b_out
+
+
 # ------------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:

@@ -207,6 +207,25 @@ int cgan_resize_nearest_nhwc(const void* x, void* y, int32_t dtype, int32_t n, i
 int cgan_avgpool3x3s2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
                            void* stream);
 
+/* MaxPool2d(3, stride 2, padding 1) on NHWC (ResNet stem, climategan/deeplab/resnet101_v3.py:74,179) */
+int cgan_maxpool3x3s2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                           void* stream);
+/* F.interpolate(mode="bilinear", align_corners=...) NHWC -> NHWC (climategan/deeplab/deeplab_v3.py:136-138,262-264,
+ * climategan/blocks.py:300-302) */
+int cgan_resize_bilinear_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                              int32_t h_out, int32_t w_out, int32_t align_corners, void* stream);
+/* torch.cat along channels, one call per input: copies the c channels of src (pixel stride cs_src) into channels
+ * [c_off, c_off + c) of dst (pixel stride cs_dst); c_off % 8 == 0 (deeplab_v3.py:107,139; blocks.py:311) */
+int cgan_copy_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t cs_dst,
+                            int32_t c_off, void* stream);
+/* elementwise on NHWC storage: op 0: y = a * b (DADA fusion z * z_depth, deeplab_v3.py:253-254); op 1: y = sigmoid(a)
+ * (climategan/generator.py:277) */
+int cgan_eltwise_nhwc(const void* a, const void* b, void* y, int32_t dtype, int32_t op, int64_t numel, void* stream);
+/* fold an eval-mode BatchNorm2d into the preceding conv (fp32 weights [c_out][per_out]): w' = w s, b' = (b - mean) s + beta,
+ * s = gamma / sqrt(var + eps)  (same algebra as climategan/bn_fusion.py:121-132) */
+int cgan_fold_bn(const float* w, const float* bias, const float* gamma, const float* beta, const float* mean,
+                 const float* var, float eps, float* w_out, float* b_out, int32_t c_out, int64_t per_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,3 +274,133 @@ class ExtraAdamRef:
             if u is not None:
                 self.params[i] = self.params_copy[i] + u
         self.params_copy = []
+
+
+# --------------------------------------------------------------------------------------------------
+# Masker (inference / eval-mode BatchNorm): deeplab/resnet101_v3.py, deeplab/deeplab_v3.py, depth.py, blocks.py
+# --------------------------------------------------------------------------------------------------
+def _bn(x, sd: SD, prefix: str, eps: float = 1e-5):
+    """eval-mode nn.BatchNorm2d"""
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd.get(prefix + ".weight"),
+                        sd.get(prefix + ".bias"), False, 0.0, eps)
+
+
+def bottleneck(x, sd: SD, p: str, stride: int, dilation: int):
+    """``Bottleneck.forward`` (deeplab/resnet101_v3.py:30-50)"""
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1"))
+    out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=dilation, dilation=dilation), sd,
+                     p + ".bn2"))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3")
+    residual = x
+    if p + ".downsample.0.weight" in sd:
+        residual = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1")
+    return F.relu(out + residual)
+
+
+def resnet101(x, sd: SD, prefix: str = "", output_stride: int = 8):
+    """``ResNet.forward`` (deeplab/resnet101_v3.py:176-187), layers [3,4,23,3], MG unit [1,2,4] (:135-174)."""
+    p = prefix + "." if prefix else ""
+    strides, dilations = ([1, 2, 1, 1], [1, 1, 2, 4]) if output_stride == 8 else ([1, 2, 2, 1], [1, 1, 1, 2])
+    x = F.relu(_bn(F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3), sd, p + "bn1"))
+    x = F.max_pool2d(x, 3, stride=2, padding=1)
+    low = None
+    for li, nblocks in enumerate([3, 4, 23, 3]):
+        for b in range(nblocks):
+            if li < 3:
+                dil = dilations[li]
+            else:
+                dil = [1, 2, 4][b] * dilations[3]
+            x = bottleneck(x, sd, "%slayer%d.%d" % (p, li + 1, b), strides[li] if b == 0 else 1, dil)
+        if li == 0:
+            low = x
+    return x, low
+
+
+def _conv_bn(x, sd: SD, p: str, padding=0, dilation=1):
+    """``ConvBNReLU.forward`` = conv + BN, NO ReLU (deeplab/deeplab_v3.py:54-57)"""
+    return _bn(F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=padding, dilation=dilation), sd,
+               p + ".bn")
+
+
+def deeplab_v3_decoder(z, sd: SD, prefix: str, target_size, z_depth=None, use_dada=True):
+    """``DeepLabV3Decoder.forward`` (deeplab_v3.py:244-266) incl. ASPPv3Plus (:95-109) and Decoder (:133-142) with
+    the reference's swapped decoder arguments and the padding=1 1x1 ``conv_out``."""
+    p = prefix + "." if prefix else ""
+    z_high, z_low = z
+    if z_depth is not None and use_dada:
+        z_high = z_high * z_depth
+    a = p + "aspp."
+    feat = torch.cat([_conv_bn(z_high, sd, a + "conv1"), _conv_bn(z_high, sd, a + "conv2", 6, 6),
+                      _conv_bn(z_high, sd, a + "conv3", 12, 12), _conv_bn(z_high, sd, a + "conv4", 18, 18)], 1)
+    aspp = _conv_bn(feat, sd, a + "conv_out", padding=1)           # 1x1 conv with padding 1: (H+2) x (W+2)
+    d = p + "decoder."
+    feat_low, feat_aspp = aspp, z_low                              # decoder(z_high, z_low): arguments swapped
+    h, w = feat_low.shape[2:]
+    fl = _conv_bn(feat_low, sd, d + "conv_low")
+    fa = F.interpolate(feat_aspp, (h, w), mode="bilinear", align_corners=True)
+    f = torch.cat([fl, fa], 1)
+    f = _conv_bn(f, sd, d + "conv_cat.0", 1)
+    f = _conv_bn(f, sd, d + "conv_cat.1", 1)
+    logits = F.conv2d(f, sd[d + "conv_out.weight"])
+    return F.interpolate(logits, size=target_size, mode="bilinear", align_corners=True)
+
+
+def conv2d_block(x, sd: SD, p: str, k: int, padding: int, pad_type: str, norm: str, activ: str, update=True):
+    """``Conv2dBlock.forward`` (blocks.py:138-143) for the configurations on the Masker path."""
+    if padding > 0:
+        x = F.pad(x, (padding,) * 4, mode="reflect" if pad_type == "reflect" else "constant")
+    if p + ".conv.module.weight_bar" in sd:
+        x = sn_conv2d(x, sd, p + ".conv", update=update)
+    else:
+        x = F.conv2d(x, sd[p + ".conv.weight"], sd.get(p + ".conv.bias"))
+    if norm == "batch":
+        x = _bn(x, sd, p + ".norm")
+    if activ == "lrelu":
+        x = F.leaky_relu(x, 0.2)
+    elif activ == "relu":
+        x = F.relu(x)
+    return x
+
+
+def dada_depth_decoder(z, sd: SD, prefix: str):
+    """``DADADepthDecoder.forward`` (depth.py:128-155), feature fusion on, upsample_featuremaps on, no re-sampling."""
+    p = prefix + "." if prefix else ""
+    zz = z[0] if isinstance(z, (tuple, list)) else z
+    e = conv2d_block(zz, sd, p + "enc4_1", 1, 0, "reflect", "batch", "lrelu")
+    e = conv2d_block(e, sd, p + "enc4_2", 3, 1, "reflect", "batch", "lrelu")
+    e = conv2d_block(e, sd, p + "enc4_3", 1, 0, "reflect", "batch", "lrelu")
+    z_depth = conv2d_block(e, sd, p + "dec4", 1, 0, "zero", "none", "lrelu")
+    u = nearest_resize(e, (e.shape[2] * 2, e.shape[3] * 2))
+    u = conv2d_block(u, sd, p + "upsample.1", 3, 1, "reflect", "batch", "lrelu")
+    u = F.conv2d(u, sd[p + "upsample.2.weight"], sd[p + "upsample.2.bias"])
+    return torch.mean(u, dim=1, keepdim=True), z_depth
+
+
+def mask_base_decoder(z, sd: SD, prefix: str, n_res=3, n_upsample=3, update=True):
+    """``BaseDecoder.forward`` (blocks.py:292-313) as configured for the mask (masker.py:25-56): spectral norm,
+    LeakyReLU, reflect padding, low-level features, no DADA fusion."""
+    p = prefix + "." if prefix else ""
+    zz, low = z
+    low = conv2d_block(low, sd, p + "low_level_conv", 3, 1, "reflect", "spectral", "lrelu", update)
+    low = F.interpolate(low, size=zz.shape[-2:], mode="bilinear")
+    zz = conv2d_block(zz, sd, p + "proj_conv", 1, 0, "zero", "spectral", "lrelu", update)
+    zz = conv2d_block(torch.cat([low, zz], 1), sd, p + "merge_feats_conv", 1, 0, "reflect", "spectral", "lrelu", update)
+    for r in range(n_res):
+        q = "%smodel.0.model.%d.model." % (p, r)
+        out = conv2d_block(zz, sd, q + "0", 3, 1, "reflect", "spectral", "lrelu", update)
+        out = conv2d_block(out, sd, q + "1", 3, 1, "reflect", "spectral", "none", update)
+        zz = out + zz
+    for i in range(n_upsample):
+        zz = nearest_resize(zz, (zz.shape[2] * 2, zz.shape[3] * 2))
+        zz = conv2d_block(zz, sd, "%smodel.%d" % (p, 2 + 2 * i), 3, 1, "reflect", "spectral", "lrelu", update)
+    return conv2d_block(zz, sd, "%smodel.%d" % (p, 1 + 2 * n_upsample), 3, 1, "reflect", "none", "none", update)
+
+
+def masker_forward(sd: SD, x: torch.Tensor, s_target, update=True):
+    """Masker inference as in ``Trainer.infer_all`` (trainer.py:272-287) with the default config:
+    z = encode(x); d, z_depth = dec_d(z); s = dec_s(z, z_depth); m = sigmoid(dec_m(z))."""
+    z = resnet101(x, sd, "encoder")
+    d, z_depth = dada_depth_decoder(z, sd, "decoders.d")
+    s = deeplab_v3_decoder(z, sd, "decoders.s", s_target, z_depth, use_dada=True)
+    m = torch.sigmoid(mask_base_decoder(z, sd, "decoders.m", update=update))
+    return {"d": d, "s": s, "m": m, "z_high": z[0], "z_depth": z_depth}

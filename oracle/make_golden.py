@@ -31,6 +31,7 @@ def golden_cases():
         "paint_up4": dict(kind="paint", latent_dim=32, n_up=4, H=64, W=96, B=2, seed=34, full=True),
         "disc_p": dict(kind="disc_p", ndf=8, n_layers=3, num_D=3, H=96, W=128, B=2, seed=41),
         "disc_fc": dict(kind="disc_fc", num_classes=11, H=64, W=96, B=2, seed=42),
+        "masker_small": dict(kind="masker", H=128, W=160, B=1, seed=61, gain=1.6),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -60,6 +61,8 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    if k == "masker":
+        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1))
     if k == "extra_adam":
         d = {}
         for i, shp in enumerate(case["shapes"]):
@@ -121,6 +124,46 @@ def build_reference_module(case):
     return mod, sd_np
 
 
+def masker_generator(case):
+    """The reference OmniGenerator (default config, masker tasks only) loaded with the portable fill, eval mode."""
+    import contextlib
+    import io
+
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.tasks = ["d", "s", "m"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+    shapes = {key: tuple(v.shape) for key, v in G.state_dict().items()}
+    sd_np = fill.fill_state_dict(shapes, case["seed"], gain=case["gain"])
+    G.load_state_dict({key: t(v) for key, v in sd_np.items()})
+    G.eval()
+    return G, shapes
+
+
+def run_reference_masker(name, case):
+    """Trainer.infer_all's masker stage (trainer.py:272-287) on the reference generator."""
+    G, shapes = masker_generator(case)
+    x = t(case_inputs(name, case)["x"])
+    hs, ws = case["H"] // 4, case["W"] // 4
+    G.decoders["d"]._target_size = ws            # int, as find_target_size leaves it: depth.py:143 skips the re-sampling
+    G.decoders["s"].set_target_size((hs, ws))
+    with torch.no_grad():
+        z = G.encode(x)
+        d, z_depth = G.decoders["d"](z)
+        s = G.decoders["s"](z, z_depth)
+        m = G.mask(z=z, z_depth=z_depth)
+    zh = z[0]
+    out = {"d": d.numpy(), "s": s.numpy(), "m": m.numpy(),
+           "z_high_mean": zh.mean(dim=(0, 2, 3)).numpy(), "z_high_std": zh.std(dim=(0, 2, 3)).numpy(),
+           "z_high_crop": zh[:, :64, :8, :8].numpy().copy(), "z_depth_crop": z_depth[:, :64, :8, :8].numpy().copy()}
+    for key, v in G.state_dict().items():
+        if key.endswith("weight_u"):
+            out["post." + key] = v.numpy().copy()
+    return out
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -154,6 +197,8 @@ def run_reference(name, case):
 
     if case["kind"] == "extra_adam":
         return run_reference_extra_adam(name, case)
+    if case["kind"] == "masker":
+        return run_reference_masker(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}
@@ -206,6 +251,9 @@ def main():
         manifest[name] = dict(case=case, keys=sorted(out), bytes=path.stat().st_size)
         print("%-14s %8d B  %s" % (name, path.stat().st_size, ", ".join(sorted(out)[:6])))
     (GOLDEN_DIR / "manifest.json").write_text(json.dumps(manifest, indent=1, default=list))
+    # state-dict layout of the reference's default generator (masker part) -- data for the layout tests
+    _, shapes = masker_generator(golden_cases()["masker_small"])
+    (GOLDEN_DIR / "generator_masker_shapes.json").write_text(json.dumps({k: list(v) for k, v in shapes.items()}))
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ def module_shapes(case):
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k == "disc_fc":
         return disc_fc_shapes(case["num_classes"])
-    if k == "extra_adam":
+    if k in ("extra_adam", "masker"):
         return {}
     raise KeyError(k)
 
@@ -129,10 +129,38 @@ def run_oracle_extra_adam(name, case):
     return out
 
 
+def masker_shapes():
+    import json
+
+    return {k: tuple(v) for k, v in json.loads((GOLDEN / "generator_masker_shapes.json").read_text()).items()}
+
+
+def masker_state_dict(case):
+    sd = fill.fill_state_dict(masker_shapes(), case["seed"], gain=case["gain"])
+    return {k: t(v) for k, v in sd.items()}
+
+
+def run_oracle_masker(name, case):
+    sd = masker_state_dict(case)
+    x = t(case_inputs(name, case)["x"])
+    with torch.no_grad():
+        r = cpu_ref.masker_forward(sd, x, (case["H"] // 4, case["W"] // 4))
+    zh = r["z_high"]
+    out = {"d": r["d"].numpy(), "s": r["s"].numpy(), "m": r["m"].numpy(),
+           "z_high_mean": zh.mean(dim=(0, 2, 3)).numpy(), "z_high_std": zh.std(dim=(0, 2, 3)).numpy(),
+           "z_high_crop": zh[:, :64, :8, :8].numpy().copy(), "z_depth_crop": r["z_depth"][:, :64, :8, :8].numpy().copy()}
+    for key, v in sd.items():
+        if key.endswith("weight_u"):
+            out["post." + key] = v.numpy().copy()
+    return out
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
         return run_oracle_extra_adam(name, case)
+    if case["kind"] == "masker":
+        return run_oracle_masker(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}

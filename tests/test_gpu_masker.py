@@ -1,0 +1,63 @@
+"""GPU parity of the Masker inference path (ResNet-101 encoder, DADA depth, DeepLab-v3+ seg, mask decoder; HIP through
+the module API) against the golden vectors produced by the real reference at 128x160.
+
+Bounds (16-bit activations through ~110 sequential conv layers vs the fp32 reference): relative to each output's
+scale, fp16 max 3e-2 / mean 4e-3.  The binarised flood mask ``m > 0.5`` is compared where the reference's own logit
+is not within the fp16 noise of the threshold (|m - 0.5| > 0.02): there it must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_cases, load_golden, masker_state_dict, t
+from oracle.make_golden import case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def build(case, dt):
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    G = create_generator(opts, device="cuda")
+    G.load_state_dict(masker_state_dict(case), strict=True)
+    G.eval()
+    G.set_compute_dtype(dt)
+    G.decoders["d"]._target_size = case["W"] // 4
+    G.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
+    return G
+
+
+@pytest.mark.parametrize("dt", [torch.float16])
+def test_masker_matches_reference_golden(dt):
+    case = golden_cases()["masker_small"]
+    gold = load_golden("masker_small")
+    G = build(case, dt)
+    x = t(case_inputs("masker_small", case)["x"]).cuda()
+    with torch.no_grad():
+        out = G.masker_forward(x)
+    for k in ("d", "s", "m"):
+        got, ref = out[k].cpu().numpy(), gold[k]
+        assert got.shape == ref.shape, k
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(got - ref)
+        assert err.max() <= 3e-2 * scale, "%s: max err %.3g (scale %.3g)" % (k, err.max(), scale)
+        assert err.mean() <= 4e-3 * scale, "%s: mean err %.3g (scale %.3g)" % (k, err.mean(), scale)
+    m_ref, m_got = gold["m"], out["m"].cpu().numpy()
+    sure = np.abs(m_ref - 0.5) > 0.02
+    assert sure.mean() > 0.5
+    assert np.array_equal((m_got > 0.5)[sure], (m_ref > 0.5)[sure])
+    sd = G.state_dict()
+    for k in gold:
+        if k.startswith("post."):
+            assert np.abs(sd[k[5:]].cpu().numpy() - gold[k]).max() < 2e-5, k
+
+
+def test_training_mode_batchnorm_refused():
+    case = golden_cases()["masker_small"]
+    G = build(case, torch.float16)
+    G.train()
+    x = t(case_inputs("masker_small", case)["x"]).cuda()
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="training mode"):
+        G.encode(x)

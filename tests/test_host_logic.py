@@ -112,3 +112,16 @@ def test_discriminator_state_dict_layout():
     assert sd == want and len(sd) == 112
     n = sum(p.numel() for p in D.parameters())
     assert 26.4e6 < n < 26.6e6   # SURVEY section 6 [probe]: D_p 20.96 M + D_m 2.78 M + D_s 2.79 M
+
+
+def test_generator_masker_state_dict_layout():
+    """encoder / decoders.{d,s,m} keys and shapes equal the reference's default generator (fixture written by
+    oracle/make_golden.py from the real reference); full G = 105.4 M parameters."""
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+    from helpers import masker_shapes
+
+    G = create_generator(default_opts())
+    sd = {k: tuple(v.shape) for k, v in G.state_dict().items() if not k.startswith("painter.")}
+    assert sd == masker_shapes()
+    assert sum(p.numel() for p in G.parameters()) == 105414209
