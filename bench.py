@@ -97,6 +97,18 @@ def spade_layer_table(latent_dim, n_up, h, w):
     return layers, flops
 
 
+def recorded_spade_traffic():
+    """HBM bytes per fused-SPADE launch from the committed PMC summary (tools/summarize_pmc.py); None if absent.
+    The PMC passes cannot run inside the timed bench (rocprofv3 wraps the process), so the number is recorded."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_spade_hbm_pmc.csv")))
+    if not files:
+        return None
+    m = re.search(r"= ([0-9.]+) MB per launch", open(files[-1]).read())
+    return int(float(m.group(1)) * 1e6) if m else None
+
+
 def build(device, dtype):
     from climategan_amd import fill
     from climategan_amd.config import default_opts
@@ -290,6 +302,9 @@ def main():
         flops_step = flops_img * BATCH_PER_GPU
         achieved = flops_step * args.steps / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0
         res = result_line(world, args.steps, args.warmup, elapsed, args.dtype)
+        traffic = recorded_spade_traffic()
+        # minimum HBM bytes of the SPADE launches: x read + 4-channel cond read + output write (16-bit, cs8 padding)
+        alg_bytes = sum(BATCH_PER_GPU * a * b * 2 * (2 * ((c + 7) // 8 * 8) + 4) for c, (a, b) in layers)
         res.update({
             "roofline": {
                 "bound": "mfma",
@@ -298,7 +313,11 @@ def main():
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (mean over the 23 launches), from profiles/*_spade_hbm_pmc.csv: "
+                                "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE "
+                                "doubled per the gfx950 correction",
+                "algorithmic_bytes_per_launch": alg_bytes // max(len(layers), 1),
                 "algorithmic_flops_per_step": flops_step,
                 "launches_per_step": n_launch // max(args.steps, 1),
                 "avg_launch_ms": round(spade_ms / max(n_launch, 1), 4),

@@ -84,9 +84,15 @@ _SIGNATURES = {
     "cgan_maxpool3x3s2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_resize_bilinear_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int32, _P]),
+    "cgan_resize_bicubic_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, _P]),
     "cgan_copy_channels_nhwc": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_eltwise_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
     "cgan_fold_bn": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int32, C.c_int64, _P]),
+    "cgan_normalize_u8_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "cgan_normalize_u8_nhwc": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
+                                         _P]),
+    "cgan_binarize": (C.c_int, [_P, C.c_int32, _P, _P, C.c_float, C.c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -200,6 +200,66 @@ __global__ void resize_bilinear_kernel(const uint16_t* __restrict__ x, uint16_t*
   }
 }
 
+// F.interpolate(mode="bicubic", align_corners=False) (climategan/depth.py:144-149): torch's cubic convolution with
+// A = -0.75, source index (dst + 0.5) * in/out - 0.5 (not clamped), taps clamped to the border.
+__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
+  const float A = -0.75f;
+  float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+template <typename T>
+__global__ void resize_bicubic_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_in, int w_in,
+                                      int h_out, int w_out, int cs, float sy, float sx, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int cg = (int)(idx % cg_total);
+    long pix = idx / cg_total;
+    int ox = (int)(pix % w_out);
+    long r = pix / w_out;
+    int oy = (int)(r % h_out);
+    long n = r / h_out;
+    float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+    float fly = floorf(fy), flx = floorf(fx);
+    int iy = (int)fly, ix = (int)flx;
+    float wy[4], wx[4];
+    cubic_coeffs(fy - fly, wy);
+    cubic_coeffs(fx - flx, wx);
+    const uint16_t* base = x + n * (long)h_in * w_in * cs + cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      int yy = iy - 1 + i;
+      yy = yy < 0 ? 0 : (yy > h_in - 1 ? h_in - 1 : yy);
+      float row[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[e] = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        int xx = ix - 1 + j;
+        xx = xx < 0 ? 0 : (xx > w_in - 1 ? w_in - 1 : xx);
+        u32x4 v = *reinterpret_cast<const u32x4*>(base + ((long)yy * w_in + xx) * cs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          unpack2<T>(v[e], a, b);
+          row[2 * e] += wx[j] * a;
+          row[2 * e + 1] += wx[j] * b;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wy[i] * row[e];
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(y + pix * cs + cg * 8) = o;
+  }
+}
+
 // copy the c channels of src [n*hw][cs_src] into channels [c_off, c_off + c) of dst [n*hw][cs_dst]
 // (torch.cat along channels = one call per input; c_off must be a multiple of 8 -- true for every concat of the path)
 __global__ void copy_channels_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cs_src,
@@ -373,6 +433,25 @@ extern "C" int cgan_resize_bilinear_nhwc(const void* x, void* y, int32_t dtype, 
     hipLaunchKernelGGL(resize_bilinear_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
                        (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners, total);
   CGAN_CHECK_LAUNCH("resize_bilinear");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                        int32_t w_in, int32_t h_out, int32_t w_out, void* stream) {
+  CGAN_REQUIRE(x && y, "resize_bicubic: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "resize_bicubic: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "resize_bicubic: bad shape");
+  int cs = cgan_cs(c);
+  long total = (long)n * h_out * w_out * (cs / 8);
+  float sy = (float)h_in / (float)h_out, sx = (float)w_in / (float)w_out;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(resize_bicubic_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
+                       (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, total);
+  else
+    hipLaunchKernelGGL(resize_bicubic_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
+                       (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, total);
+  CGAN_CHECK_LAUNCH("resize_bicubic");
   return CGAN_OK;
 }
 

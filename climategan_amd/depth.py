@@ -55,9 +55,13 @@ class DADADepthDecoder(nn.Module):
         up = self.upsample[1].forward_nhwc(up)
         depth = conv_bn_forward(self.upsample[2], None, self._cache, up)   # 1 channel: the channel mean is the identity
         ts = self._target_size
-        if ts is not None and depth.w != (ts if isinstance(ts, int) else ts[-1]):
-            raise NotImplementedError("DADADepthDecoder: bicubic re-sampling to a target size different from the "
-                                      "feature size (depth.py:143-153) has no HIP path")
+        if depth.w != ts:                              # depth.py:143 (an int from the ctor; a tuple never compares equal)
+            if not isinstance(ts, int):
+                # the reference passes (ts, ts) to F.interpolate, which rejects a tuple of tuples (depth.py:151-153)
+                raise TypeError("DADADepthDecoder: target size %r is not an int (reference depth.py:151-153 fails "
+                                "the same way after set_target_size)" % (ts,))
+            depth = ops.resize_bicubic(depth, (384, 384))          # MiDaS inference size, depth.py:144-149
+            depth = ops.resize_nearest(depth, (ts, ts))            # depth.py:151-153
         return depth, z_depth
 
     def forward(self, z):

@@ -134,6 +134,17 @@ def resize_bilinear(x: NHWC, size: Tuple[int, int], align_corners: bool = False)
     return NHWC(y, x.c)
 
 
+def resize_bicubic(x: NHWC, size: Tuple[int, int]) -> NHWC:
+    """F.interpolate(mode="bicubic", align_corners=False) (reference depth.py:143-149)."""
+    _need_cuda(x.t)
+    h, w = int(size[0]), int(size[1])
+    y = torch.empty((x.n, h, w, cs8(x.c)), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_resize_bicubic_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, h, w, _stream()),
+               "cgan_resize_bicubic_nhwc")
+    return NHWC(y, x.c)
+
+
 def concat_channels(xs) -> NHWC:
     """torch.cat(xs, dim=1) on NHWC tensors; every input but the last must have a multiple-of-8 channel count."""
     n, h, w = xs[0].n, xs[0].h, xs[0].w
@@ -187,6 +198,40 @@ def fold_bn(w: torch.Tensor, bias, bn_weight, bn_bias, running_mean, running_var
     _lib.check(lib.cgan_fold_bn(_ptr(w), _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]), _ptr(ts[4]), float(eps),
                                 _ptr(w_out), _ptr(b_out), c_out, w.numel() // c_out, _stream()), "cgan_fold_bn")
     return w_out, b_out
+
+
+# ------------------------------------------------------------------------------------------------ output post-ops
+def normalize_to_uint8(x: torch.Tensor) -> torch.Tensor:
+    """Per-image min-max normalise an NCHW fp32/fp16 tensor and convert to uint8 NHWC
+    (reference trainer.py:311-326 + tutils.normalize, tutils.py:567-576)."""
+    _need_cuda(x)
+    if x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError("normalize_to_uint8: fp32 or fp16 input expected, got %s" % x.dtype)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    lib = _lib.load()
+    nbytes = lib.cgan_normalize_u8_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.cgan_normalize_u8_nhwc(_ptr(x), int(x.dtype == torch.float16), _ptr(out), n, c, h, w, _ptr(ws),
+                                          nbytes, _stream()), "cgan_normalize_u8_nhwc")
+    return out
+
+
+def binarize(x: torch.Tensor, threshold: float, want_float: bool = True, want_uint8: bool = False):
+    """``(x > threshold)`` as x.dtype {0,1} and/or uint8 {0,255} (reference trainer.py:1870-1871, 329-332)."""
+    _need_cuda(x)
+    if x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError("binarize: fp32 or fp16 input expected, got %s" % x.dtype)
+    x = x.contiguous()
+    y = torch.empty_like(x) if want_float else None
+    y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_uint8 else None
+    lib = _lib.load()
+    _lib.check(lib.cgan_binarize(_ptr(x), int(x.dtype == torch.float16), _ptr(y), _ptr(y8), float(threshold),
+                                 x.numel(), _stream()), "cgan_binarize")
+    if want_float and want_uint8:
+        return y, y8
+    return y if want_float else y8
 
 
 # ------------------------------------------------------------------------------------------------ conv

@@ -214,6 +214,10 @@ int cgan_maxpool3x3s2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int
  * climategan/blocks.py:300-302) */
 int cgan_resize_bilinear_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
                               int32_t h_out, int32_t w_out, int32_t align_corners, void* stream);
+/* F.interpolate(mode="bicubic", align_corners=False) NHWC -> NHWC (climategan/depth.py:143-149, the MiDaS-size
+ * re-sampling of the depth map when its width differs from the target) */
+int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                             int32_t h_out, int32_t w_out, void* stream);
 /* torch.cat along channels, one call per input: copies the c channels of src (pixel stride cs_src) into channels
  * [c_off, c_off + c) of dst (pixel stride cs_dst); c_off % 8 == 0 (deeplab_v3.py:107,139; blocks.py:311) */
 int cgan_copy_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t cs_dst,
@@ -225,6 +229,20 @@ int cgan_eltwise_nhwc(const void* a, const void* b, void* y, int32_t dtype, int3
  * s = gamma / sqrt(var + eps)  (same algebra as climategan/bn_fusion.py:121-132) */
 int cgan_fold_bn(const float* w, const float* bias, const float* gamma, const float* beta, const float* mean,
                  const float* var, float eps, float* w_out, float* b_out, int32_t c_out, int64_t per_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Output post-ops of the inference harness (Trainer.infer_all, climategan/trainer.py:311-332)
+ * ------------------------------------------------------------------------------------------------ */
+/* tutils.normalize (climategan/tutils.py:567-576) per image over (C,H,W), then `(t * 255).astype(uint8)` (truncation)
+ * and the NCHW -> NHWC permute (trainer.py:314-326): x_nchw [n,c,h,w] fp32 (is_half 0) or fp16 (is_half 1, every
+ * intermediate rounded to fp16 as the reference's half tensors are) -> out_nhwc uint8 [n,h,w,c].
+ * workspace: cgan_normalize_u8_workspace_bytes(n) device bytes. */
+size_t cgan_normalize_u8_workspace_bytes(int32_t n);
+int cgan_normalize_u8_nhwc(const void* x_nchw, int32_t is_half, uint8_t* out_nhwc, int32_t n, int32_t c, int32_t h,
+                           int32_t w, void* workspace, size_t workspace_bytes, void* stream);
+/* `(m > bin_value).to(m.dtype)` (climategan/trainer.py:1870-1871) into y (same dtype as x; may be NULL) and
+ * `((mask > bin_value) * 255).astype(uint8)` (trainer.py:329-332) into y_u8 (may be NULL) */
+int cgan_binarize(const void* x, int32_t is_half, void* y, uint8_t* y_u8, float threshold, int64_t numel, void* stream);
 
 #ifdef __cplusplus
 }

@@ -362,8 +362,10 @@ def conv2d_block(x, sd: SD, p: str, k: int, padding: int, pad_type: str, norm: s
     return x
 
 
-def dada_depth_decoder(z, sd: SD, prefix: str):
-    """``DADADepthDecoder.forward`` (depth.py:128-155), feature fusion on, upsample_featuremaps on, no re-sampling."""
+def dada_depth_decoder(z, sd: SD, prefix: str, target_size: Optional[int] = None):
+    """``DADADepthDecoder.forward`` (depth.py:128-155), feature fusion on, upsample_featuremaps on.  ``target_size``
+    is the int the ctor stores (depth.py:105-107): when the depth map's width differs, it is re-sampled bicubically
+    to 384x384 and then nearest to (target, target) (depth.py:143-153); None = no re-sampling."""
     p = prefix + "." if prefix else ""
     zz = z[0] if isinstance(z, (tuple, list)) else z
     e = conv2d_block(zz, sd, p + "enc4_1", 1, 0, "reflect", "batch", "lrelu")
@@ -373,7 +375,11 @@ def dada_depth_decoder(z, sd: SD, prefix: str):
     u = nearest_resize(e, (e.shape[2] * 2, e.shape[3] * 2))
     u = conv2d_block(u, sd, p + "upsample.1", 3, 1, "reflect", "batch", "lrelu")
     u = F.conv2d(u, sd[p + "upsample.2.weight"], sd[p + "upsample.2.bias"])
-    return torch.mean(u, dim=1, keepdim=True), z_depth
+    depth = torch.mean(u, dim=1, keepdim=True)
+    if target_size is not None and depth.shape[-1] != target_size:
+        depth = F.interpolate(depth, size=(384, 384), mode="bicubic", align_corners=False)
+        depth = F.interpolate(depth, (target_size, target_size), mode="nearest")
+    return depth, z_depth
 
 
 def mask_base_decoder(z, sd: SD, prefix: str, n_res=3, n_upsample=3, update=True):
@@ -396,11 +402,49 @@ def mask_base_decoder(z, sd: SD, prefix: str, n_res=3, n_upsample=3, update=True
     return conv2d_block(zz, sd, "%smodel.%d" % (p, 1 + 2 * n_upsample), 3, 1, "reflect", "none", "none", update)
 
 
-def masker_forward(sd: SD, x: torch.Tensor, s_target, update=True):
+def masker_forward(sd: SD, x: torch.Tensor, s_target, update=True, d_target: Optional[int] = None):
     """Masker inference as in ``Trainer.infer_all`` (trainer.py:272-287) with the default config:
     z = encode(x); d, z_depth = dec_d(z); s = dec_s(z, z_depth); m = sigmoid(dec_m(z))."""
     z = resnet101(x, sd, "encoder")
-    d, z_depth = dada_depth_decoder(z, sd, "decoders.d")
+    d, z_depth = dada_depth_decoder(z, sd, "decoders.d", d_target)
     s = deeplab_v3_decoder(z, sd, "decoders.s", s_target, z_depth, use_dada=True)
     m = torch.sigmoid(mask_base_decoder(z, sd, "decoders.m", update=update))
     return {"d": d, "s": s, "m": m, "z_high": z[0], "z_depth": z_depth}
+
+
+# --------------------------------------------------------------------------------------------------
+# Inference harness: Trainer.infer_all / compute_flood (climategan/trainer.py:217-334, 1844-1877)
+# --------------------------------------------------------------------------------------------------
+def normalize(t: torch.Tensor, mini=0, maxi=1) -> torch.Tensor:
+    """``tutils.normalize`` (tutils.py:567-576): per-image min-max to [mini, maxi]."""
+    if t.dim() == 3:
+        return mini + (maxi - mini) * (t - t.min()) / (t.max() - t.min())
+    b = t.shape[0]
+    t = t - t.reshape(b, -1).min(1)[0].reshape(b, 1, 1, 1)
+    t = t / t.reshape(b, -1).max(1)[0].reshape(b, 1, 1, 1)
+    return mini + (maxi - mini) * t
+
+
+def to_uint8_hwc(t: torch.Tensor):
+    """trainer.py:311-326: normalize -> permute to NHWC -> numpy -> ``(a * 255).astype(uint8)`` (truncation)."""
+    a = normalize(t).permute(0, 2, 3, 1).numpy()
+    return (a * 255).astype("uint8")
+
+
+def compute_flood(sd: SD, x: torch.Tensor, m: torch.Tensor, z_h: int, z_w: int, bin_value: float = -1,
+                  update: bool = True) -> torch.Tensor:
+    """``Trainer.compute_flood`` (trainer.py:1844-1877) with a given mask, non-cloudy: optional binarisation then
+    ``G.paint(m, x)``.  ``sd`` = generator state dict (painter keys prefixed ``painter.``)."""
+    if bin_value >= 0:
+        m = (m > bin_value).to(m.dtype)
+    return paint(sub(sd, "painter"), m, x, z_h, z_w, update=update)
+
+
+def infer_all_flood(sd: SD, x: torch.Tensor, n_up: int, bin_value: float = -1, s_target=(160, 160), d_target=160):
+    """``Trainer.infer_all`` (trainer.py:217-334), flood event only: masker stages in the reference's order, flood,
+    uint8 conversion, and the uint8 mask of ``return_masks``."""
+    z_h, z_w = x.shape[-2] // 2 ** n_up, x.shape[-1] // 2 ** n_up          # painter.set_latent_shape(x.shape, True)
+    mk = masker_forward(sd, x, s_target, d_target=d_target)
+    flood = compute_flood(sd, x, mk["m"], z_h, z_w, bin_value)
+    return {"flood": flood, "flood_u8": to_uint8_hwc(flood), "m": mk["m"], "d": mk["d"], "s": mk["s"],
+            "mask_u8": ((mk["m"] > bin_value) * 255).numpy().astype("uint8")}

@@ -32,6 +32,7 @@ def golden_cases():
         "disc_p": dict(kind="disc_p", ndf=8, n_layers=3, num_D=3, H=96, W=128, B=2, seed=41),
         "disc_fc": dict(kind="disc_fc", num_classes=11, H=64, W=96, B=2, seed=42),
         "masker_small": dict(kind="masker", H=128, W=160, B=1, seed=61, gain=1.6),
+        "infer_small": dict(kind="infer", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -61,7 +62,7 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
-    if k == "masker":
+    if k in ("masker", "infer"):
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1))
     if k == "extra_adam":
         d = {}
@@ -164,6 +165,61 @@ def run_reference_masker(name, case):
     return out
 
 
+def reference_trainer(case):
+    """The reference ``Trainer`` set up for inference (trainer.py:701-760) on CPU with the portable fill.  Patches
+    (SURVEY 8c): ``Timer`` -> null context (it records CUDA events), ``compute_fire`` -> identity (kornia /
+    torchvision arithmetic is not in the tree)."""
+    import contextlib
+    import io
+
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    opts.gen.p.latent_dim = case["latent_dim"]
+    opts.gen.p.spade_n_up = case["n_up"]
+    tr = ref_shim.ref("trainer")
+
+    class NullTimer:
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+
+    tr.Timer = NullTimer
+    T = tr.Trainer(opts, device=torch.device("cpu"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        T.setup(inference=True)
+    shapes = {key: tuple(v.shape) for key, v in T.G.state_dict().items()}
+    sd_np = fill.fill_state_dict(shapes, case["seed"], gain=case["gain"])
+    T.G.load_state_dict({key: t(v) for key, v in sd_np.items()})
+    T.G.eval()
+    T.compute_fire = lambda x, seg_preds=None, **kw: x
+    return T, shapes
+
+
+def run_reference_infer(name, case):
+    """``Trainer.infer_all`` (trainer.py:217-334) end to end; the float event tensors are captured on the way."""
+    T, shapes = reference_trainer(case)
+    x = t(case_inputs(name, case)["x"])
+    cap = {}
+
+    def capture(fn, key):
+        def wrapped(*a, **kw):
+            r = fn(*a, **kw)
+            cap[key] = r.detach().clone()
+            cap[key + "_kw"] = {k2: (v.detach().clone() if torch.is_tensor(v) else v) for k2, v in kw.items()}
+            return r
+        return wrapped
+
+    T.compute_flood = capture(T.compute_flood, "flood")
+    T.compute_smog = capture(T.compute_smog, "smog")
+    res = T.infer_all(x, numpy=True, bin_value=case["bin_value"], return_masks=True)
+    out = {"flood_u8": res["flood"], "smog_u8": res["smog"], "mask_u8": res["mask"],
+           "flood": cap["flood"].numpy(), "smog": cap["smog"].numpy(),
+           "m": cap["flood_kw"]["m"].numpy(), "s": cap["flood_kw"]["s"].numpy(), "d": cap["smog_kw"]["d"].numpy()}
+    return out
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -199,6 +255,8 @@ def run_reference(name, case):
         return run_reference_extra_adam(name, case)
     if case["kind"] == "masker":
         return run_reference_masker(name, case)
+    if case["kind"] == "infer":
+        return run_reference_infer(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}
@@ -243,8 +301,11 @@ def main():
         sys.exit("make_golden needs /root/reference (dev container only)")
     GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
-    manifest = {}
+    only = set(sys.argv[1:])           # optional: regenerate just the named cases
+    manifest = json.loads((GOLDEN_DIR / "manifest.json").read_text()) if only else {}
     for name, case in golden_cases().items():
+        if only and name not in only:
+            continue
         out = run_reference(name, case)
         path = GOLDEN_DIR / (name + ".npz")
         np.savez_compressed(path, **out)

@@ -28,7 +28,7 @@ def module_shapes(case):
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k == "disc_fc":
         return disc_fc_shapes(case["num_classes"])
-    if k in ("extra_adam", "masker"):
+    if k in ("extra_adam", "masker", "infer"):
         return {}
     raise KeyError(k)
 
@@ -155,12 +155,34 @@ def run_oracle_masker(name, case):
     return out
 
 
+def infer_shapes(case):
+    """Full generator (masker + painter) state-dict shapes of an "infer" case."""
+    shapes = dict(masker_shapes())
+    shapes.update({"painter." + k: v for k, v in painter_shapes(case["latent_dim"], case["n_up"]).items()})
+    return shapes
+
+
+def infer_state_dict(case):
+    sd = fill.fill_state_dict(infer_shapes(case), case["seed"], gain=case["gain"])
+    return {k: t(v) for k, v in sd.items()}
+
+
+def run_oracle_infer(name, case):
+    sd = infer_state_dict(case)
+    x = t(case_inputs(name, case)["x"])
+    with torch.no_grad():
+        r = cpu_ref.infer_all_flood(sd, x, case["n_up"], case["bin_value"])
+    return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in r.items()}
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
         return run_oracle_extra_adam(name, case)
     if case["kind"] == "masker":
         return run_oracle_masker(name, case)
+    if case["kind"] == "infer":
+        return run_oracle_infer(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}

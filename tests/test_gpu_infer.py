@@ -1,0 +1,137 @@
+"""GPU parity of the inference harness (Trainer.infer_all, flood event) against the golden captured from the REAL
+reference's ``Trainer.infer_all`` (oracle/make_golden.py: infer_small, 128x160, bs 2, bin_value 0.43), and of the
+output post-op kernels (bit-exact integer work).
+
+The fixture's float mask lies in a narrow band around the threshold (untrained weights), so the end-to-end run is
+compared stage-wise: the HIP float mask against the reference's (fp16 bound of the Masker tests, binarisation exact
+away from the threshold), then ``compute_flood`` fed the reference's own float mask against the reference's flood
+(bound: the paint_up4 16-bit allowance of tests/test_gpu_painter.py), then the uint8 conversion bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_cases, infer_state_dict, load_golden, t
+from oracle import cpu_ref
+from oracle.make_golden import case_inputs
+
+pytestmark = pytest.mark.gpu
+NAME = "infer_small"
+
+
+def build_trainer(case, dt=torch.float16):
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    opts.gen.p.latent_dim = case["latent_dim"]
+    opts.gen.p.spade_n_up = case["n_up"]
+    T = Trainer(opts, device="cuda").setup(inference=True)
+    T.G.load_state_dict(infer_state_dict(case), strict=True)
+    T.G.set_compute_dtype(dt)
+    return T
+
+
+def test_infer_all_flood_matches_reference_golden():
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    T = build_trainer(case)
+    x = t(case_inputs(NAME, case)["x"]).cuda()
+    stores = {k: [] for k in ("all events", "encode", "depth", "segmentation", "mask", "flood", "numpy")}
+    out = T.infer_all(x, numpy=True, stores=stores, bin_value=case["bin_value"], ignore_event={"wildfire", "smog"},
+                      return_masks=True)
+    assert set(out) == {"flood", "mask"}
+    assert out["flood"].shape == gold["flood_u8"].shape and out["flood"].dtype == np.uint8
+    assert out["mask"].shape == gold["mask_u8"].shape and out["mask"].dtype == np.uint8
+    assert all(len(v) == 1 for v in stores.values())
+    # binary mask: exact where the reference's float mask is away from the threshold by more than the fp16 band
+    sure = np.abs(gold["m"] - case["bin_value"]) > 0.01
+    assert sure.mean() > 0.1
+    assert np.array_equal(out["mask"][sure], gold["mask_u8"][sure])
+    assert set(np.unique(out["mask"])) <= {0, 255}
+    # the whole flood image: same picture up to the pixels whose mask bit flipped
+    agree = (out["mask"] == gold["mask_u8"]).mean()
+    assert agree > 0.8, agree
+
+
+def test_float_mask_and_depth_seg_stages():
+    """Stage outputs at the Trainer's default target sizes (depth: bicubic 384 + nearest 160, seg: bilinear 160)."""
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    T = build_trainer(case)
+    x = t(case_inputs(NAME, case)["x"]).cuda()
+    with torch.no_grad():
+        out = T.G.masker_forward(x)
+    for k in ("d", "s", "m"):
+        got, ref = out[k].cpu().numpy(), gold[k]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(got - ref)
+        assert err.max() <= 3e-2 * scale, "%s: max err %.3g (scale %.3g)" % (k, err.max(), scale)
+        assert err.mean() <= 4e-3 * scale, "%s: mean err %.3g (scale %.3g)" % (k, err.mean(), scale)
+
+
+def test_compute_flood_with_reference_mask():
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    T = build_trainer(case)
+    x = t(case_inputs(NAME, case)["x"]).cuda()
+    m = t(gold["m"]).cuda()
+    T.G.painter.set_latent_shape(x.shape, True)
+    with torch.no_grad():
+        flood = T.compute_flood(x, m=m, bin_value=case["bin_value"])
+    err = np.abs(flood.cpu().numpy() - gold["flood"])
+    assert err.max() <= 2 * 0.008357 and err.mean() <= 2 * 0.0003513, (err.max(), err.mean())
+    from climategan_amd import ops
+    d8 = np.abs(ops.normalize_to_uint8(flood).cpu().numpy().astype(np.int32) - gold["flood_u8"].astype(np.int32))
+    assert d8.max() <= 4 and d8.mean() < 0.5, (d8.max(), d8.mean())
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_normalize_to_uint8_bit_exact(half):
+    from climategan_amd import fill, ops
+
+    gold = load_golden(NAME)
+    for x in (t(gold["flood"]), t(fill.uniform((3, 3, 37, 53), 991, -3.0, 5.0)), t(fill.uniform((1, 1, 5, 7), 992))):
+        if half:
+            x = x.half()
+        ref = cpu_ref.to_uint8_hwc(x)                         # torch CPU arithmetic in x's dtype + numpy truncation
+        got = ops.normalize_to_uint8(x.cuda()).cpu().numpy()
+        assert got.dtype == np.uint8 and got.shape == ref.shape
+        assert np.array_equal(got, ref), np.abs(got.astype(int) - ref.astype(int)).max()
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_binarize_bit_exact(half):
+    from climategan_amd import fill, ops
+
+    x = t(fill.uniform((2, 1, 33, 47), 993, 0.0, 1.0))
+    if half:
+        x = x.half()
+    y, y8 = ops.binarize(x.cuda(), 0.43, want_float=True, want_uint8=True)
+    assert y.dtype == x.dtype
+    assert torch.equal(y.cpu(), (x > 0.43).to(x.dtype))
+    assert np.array_equal(y8.cpu().numpy(), ((x > 0.43) * 255).numpy().astype(np.uint8))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_resize_bicubic(dt):
+    from climategan_amd import fill, ops
+
+    x = t(fill.uniform((2, 1, 32, 40), 994)).to(dt).float()
+    ref = torch.nn.functional.interpolate(x, size=(384, 384), mode="bicubic", align_corners=False)
+    got = ops.nhwc_to_nchw(ops.resize_bicubic(ops.nchw_to_nhwc(x.cuda(), dt), (384, 384))).cpu()
+    tol = 1e-3 if dt == torch.float16 else 8e-3
+    assert (got - ref).abs().max() <= tol * max(ref.abs().max().item(), 1.0)
+    x = t(fill.uniform((1, 11, 9, 13), 995)).to(dt).float()
+    ref = torch.nn.functional.interpolate(x, size=(5, 31), mode="bicubic", align_corners=False)
+    got = ops.nhwc_to_nchw(ops.resize_bicubic(ops.nchw_to_nhwc(x.cuda(), dt), (5, 31))).cpu()
+    assert (got - ref).abs().max() <= tol * max(ref.abs().max().item(), 1.0)
+
+
+def test_unbuilt_events_fail_loudly():
+    case = golden_cases()[NAME]
+    T = build_trainer(case)
+    x = t(case_inputs(NAME, case)["x"]).cuda()
+    with pytest.raises(NotImplementedError, match="N1"):
+        T.infer_all(x, bin_value=0.5)

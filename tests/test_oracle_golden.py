@@ -10,7 +10,7 @@ CASES = golden_cases()
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small")])
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small")])
 def test_oracle_matches_golden(name):
     gold = load_golden(name)
     got = run_oracle(name, CASES[name])
@@ -42,3 +42,24 @@ def test_oracle_matches_golden_masker():
         scale = max(np.abs(gold[k]).max(), 1e-6)
         err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
         assert err <= 1e-4 * scale, "%s/%s: max abs err %.3g (scale %.3g)" % (name, k, err, scale)
+
+
+def test_oracle_matches_golden_infer_all():
+    """``Trainer.infer_all`` of the REAL reference (flood event, uint8 conversion, uint8 mask) vs the oracle restatement.
+    Float tensors to 1e-4 of their scale; the uint8 flood may differ by one level where a float sits on a truncation
+    boundary; the binary mask may flip only where the float mask is within 1e-5 of the threshold."""
+    name = "infer_small"
+    case = CASES[name]
+    gold = load_golden(name)
+    got = run_oracle(name, case)
+    for k in ("m", "d", "s", "flood"):
+        scale = max(np.abs(gold[k]).max(), 1e-6)
+        err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
+        assert err <= 1e-4 * scale, "%s/%s: max abs err %.3g (scale %.3g)" % (name, k, err, scale)
+    flips = gold["mask_u8"] != got["mask_u8"]
+    assert (np.abs(gold["m"] - case["bin_value"])[flips] < 1e-5).all()
+    assert flips.mean() < 1e-3
+    if not flips.any():
+        d8 = np.abs(gold["flood_u8"].astype(np.int32) - got["flood_u8"].astype(np.int32))
+        assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (d8.max(), (d8 > 0).mean())
+    assert 0.2 < (gold["mask_u8"] > 0).mean() < 0.5          # the fixture has a real two-valued mask

@@ -73,7 +73,17 @@ def test_state_dict_shapes_match_reference():
     from oracle.make_golden import build_reference_module
 
     for name, case in golden_cases().items():
-        if name == "painter_640" or case["kind"] in ("extra_adam", "masker"):
+        if name == "painter_640" or case["kind"] in ("extra_adam", "masker", "infer"):
             continue
         mod, _ = build_reference_module(case)
         assert {k: tuple(v.shape) for k, v in mod.state_dict().items()} == module_shapes(case), name
+
+
+def test_infer_state_dict_layout_matches_reference_trainer():
+    """The restated full-generator layout (masker + painter) used by the infer fixture == the reference Trainer's G."""
+    from helpers import infer_shapes
+    from oracle.make_golden import reference_trainer
+
+    case = golden_cases()["infer_small"]
+    _, shapes = reference_trainer(case)
+    assert shapes == infer_shapes(case)
