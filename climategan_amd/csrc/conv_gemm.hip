@@ -1,0 +1,288 @@
+// conv2d NHWC forward for WIDE layers (cin % 32 == 0, cout >= 64: the ResNet-101 / ASPP / depth / mask-decoder
+// convolutions of the Masker) as an LDS-tiled implicit GEMM on MFMA 16x16x32, gfx950.
+//
+//   D[cout][pixel] = sum_k Wp[cout][k] * X[k][pixel],   k = tap * cin_s + c   (same operand roles as conv_mfma.hip)
+//
+// Workgroup = 4 waves, block tile = (WAVES_C*WC*16) couts x (WAVES_P*WP*16) pixels (128 x 256 by default), one MFMA
+// k-step (32 channels of one tap) per pipeline stage, 3-stage ring in LDS filled by LDS-DMA
+// (global_load_lds_dwordx4): both operands land in LDS already in MFMA FRAGMENT ORDER (1 KiB per 16x32 tile, lane l at
+// byte 16*l), so every fragment read is a conflict-free linear ds_read_b128 and no register ever stages an operand.
+//   * weights: pre-packed in fragment order -> a wave copies 1 KiB contiguous per (cout tile, k-step);
+//   * pixels : lane (j = l&15, g = l>>4) fetches the 16 B "8 channels c0+8g.. of pixel j" of the tap-shifted input
+//              pixel; zero padding reads a zero page, reflect padding / stride / dilation are index math.
+// Per k-step a wave reads WC + WP fragments for WC*WP MFMAs (12 -> 32: 0.75 of the LDS read bandwidth at full MFMA
+// rate); global->LDS traffic per k-step is 24 KiB per 2.1 MFLOP, so what matters is how much of it hits L2:
+//   * the weights of a layer (<= a few MiB) always do; the block covers ALL couts when cout <= 256 (256 x 128 tile),
+//     so the activations are then fetched from HBM exactly once;
+//   * K order = channel chunk outer, tap inner: the 9 tap-shifted fetches of one 32-channel slice are issued back to
+//     back and overlap almost entirely (L2 hits), instead of streaming the whole input once per tap;
+//   * the grid is linearised so that one XCD (one L2) owns a CONTIGUOUS range of pixel blocks (halo rows of dilated
+//     3x3 windows are shared between neighbouring blocks) and the cout blocks of a pixel block run back to back.
+// Epilogue: accumulators are staged through LDS in fp32 and leave as coalesced 16-byte stores (residual reads
+// likewise), bias / residual / activation applied in fp32 in the same order as the general kernel.
+#include "conv_gemm.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_gemm_zeros[4];
+
+constexpr int NSTAGE = 3;
+
+__device__ __forceinline__ int reflect_i(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+template <typename T, int WAVES_C, int WC, int WP, bool REFLECT>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int npb, int ncb) {
+  constexpr int WAVES_P = 4 / WAVES_C;
+  constexpr int CT_BLK = WAVES_C * WC;
+  constexpr int PT_BLK = WAVES_P * WP;
+  constexpr int STAGE_BYTES = (CT_BLK + PT_BLK) * 1024;
+  constexpr int W_PER_WAVE = CT_BLK / 4;
+  constexpr int P_PER_WAVE = PT_BLK / 4;
+  constexpr int DMA_PER_WAVE = W_PER_WAVE + P_PER_WAVE;
+  static_assert(CT_BLK % 4 == 0 && PT_BLK % 4 == 0, "tiles must split evenly over the 4 waves");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: LDS-DMA bases stay in SGPRs
+  const int j = lane & 15;
+  const int g = lane >> 4;
+  const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+
+  // block -> (pixel block, cout block): ids that differ by 8 share an XCD; each XCD owns a contiguous range of pixel
+  // blocks, cout blocks vary fastest
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cblk = slot % ncb;
+  const int pblk = xcd * ((npb + 7) >> 3) + slot / ncb;
+  if (pblk >= npb) return;
+
+  // ---- per-lane coordinates of the pixel tiles this wave copies (tile i = wave + 4 m of the block)
+  int pbase[P_PER_WAVE], py0[P_PER_WAVE], px0[P_PER_WAVE];
+#pragma unroll
+  for (int m = 0; m < P_PER_WAVE; ++m) {
+    int pix = (pblk * PT_BLK + wave + 4 * m) * 16 + j;
+    bool v = pix < p.npix;
+    int pc = v ? pix : 0;
+    int ox = pc % p.w_out;
+    int r = pc / p.w_out;
+    int oy = r % p.h_out;
+    int nn = r / p.h_out;
+    pbase[m] = nn * p.h_in * p.w_in * p.cin_s + g * 8;
+    py0[m] = v ? oy * p.stride - p.pad : -(1 << 28);   // invalid pixels never pass the range test (zero pad) ...
+    px0[m] = ox * p.stride - p.pad;
+  }
+  const int ccn = p.cin_s >> 5;   // k-steps per tap
+  // byte offset of the zero page relative to x (select between two offsets, not two pointers: one v_cndmask pair)
+  const long zero_off = reinterpret_cast<const unsigned char*>(g_gemm_zeros) - reinterpret_cast<const unsigned char*>(p.x);
+
+  int i_ky = 0, i_kx = 0, i_cc = 0, i_buf = 0;   // (tap, channel chunk, ring slot) of the NEXT stage to issue
+  // one LDS-DMA piece (1 KiB) of the next stage: pieces 0..W_PER_WAVE-1 are weight tiles, the rest pixel tiles
+  auto issue_piece = [&](int piece) {
+    unsigned char* buf = smem + i_buf * STAGE_BYTES;
+    if (piece < W_PER_WAVE) {
+      const int i = wave + 4 * piece;
+      const int ct = min(cblk * CT_BLK + i, p.ctiles - 1);
+      const u32x4* src = p.w + ((size_t)ct * p.ksteps + (i_ky * p.kw + i_kx) * ccn + i_cc) * 64 + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, 0, 0);
+    } else {
+      const int m = piece - W_PER_WAVE;
+      const int i = wave + 4 * m;
+      int iy = py0[m] + i_ky * p.dil, ix = px0[m] + i_kx * p.dil;
+      bool ok;
+      if (REFLECT) {
+        ok = py0[m] > -(1 << 27);
+        iy = reflect_i(ok ? iy : 0, p.h_in);
+        ix = reflect_i(ix, p.w_in);
+      } else {
+        ok = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+      }
+      const long off = ok ? (long)(pbase[m] + (iy * p.w_in + ix) * p.cin_s + i_cc * 32) * 2 : zero_off;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + off;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + (CT_BLK + i) * 1024), 16, 0, 0);
+    }
+  };
+  // advance to the following stage (taps innermost, channel chunks outermost) with selects only: the loop body must
+  // stay one basic block.  The two stages issued past the end wrap to stage 0/1 and are never read.
+  auto issue_advance = [&]() {
+    const int kx1 = i_kx + 1;
+    const bool wx = kx1 == p.kw;
+    i_kx = wx ? 0 : kx1;
+    const int ky1 = i_ky + (wx ? 1 : 0);
+    const bool wy = ky1 == p.kh;
+    i_ky = wy ? 0 : ky1;
+    const int cc1 = i_cc + (wy ? 1 : 0);
+    i_cc = cc1 == ccn ? 0 : cc1;
+    i_buf = (i_buf + 1 == NSTAGE) ? 0 : i_buf + 1;
+  };
+  auto issue = [&]() {
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; ++q) issue_piece(q);
+    issue_advance();
+  };
+
+  f32x4 acc[WC][WP];
+#pragma unroll
+  for (int c = 0; c < WC; ++c)
+#pragma unroll
+    for (int t = 0; t < WP; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // The loop body is branch-free (stages past the end are issued anyway and ignored) so that the LDS-DMA issues can
+  // be spread between the MFMAs: issued back to back right after the barrier they serialise every wave of the CU on
+  // the vector-memory path before any MFMA starts.
+  issue();
+  issue();
+  int r_buf = 0;
+  for (int ks = 0; ks < p.ksteps; ++ks) {
+    // stage ks has landed once at most the DMAs of stage ks+1 are still in flight (in-order completion)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_PER_WAVE) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* buf = smem + r_buf * STAGE_BYTES;
+    u32x4 a[WC], b[WP];
+#pragma unroll
+    for (int c = 0; c < WC; ++c) a[c] = *reinterpret_cast<const u32x4*>(buf + (wc * WC + c) * 1024 + lane * 16);
+#pragma unroll
+    for (int t = 0; t < WP; ++t)
+      b[t] = *reinterpret_cast<const u32x4*>(buf + (CT_BLK + wp * WP + t) * 1024 + lane * 16);
+    // stage ks+2 refills the slot every wave finished reading before this barrier; its DMA pieces are issued one
+    // at a time between groups of MFMAs (hard scheduling fences keep them there)
+    constexpr int NM = WC * WP;
+    constexpr int GAP = NM / (DMA_PER_WAVE + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int c = i / WP, t = i % WP;
+      acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(b[t]), acc[c][t]);
+      if ((i + 1) % GAP == 0 && (i + 1) / GAP <= DMA_PER_WAVE) {
+        issue_piece((i + 1) / GAP - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    issue_advance();
+    r_buf = (r_buf + 1 == NSTAGE) ? 0 : r_buf + 1;
+  }
+
+  // ---- epilogue: lane holds channels ct*16 + 4g + {0..3} of pixel (tile, j).  Staged through LDS (fp32, row =
+  // one pixel x the wave's WC*16 couts, +16 B pad) PP pixel tiles at a time, then written as 16-byte chunks.
+  constexpr int ROWB = WC * 64 + 16;
+  constexpr int PP = (4 * 4 * 16 * ROWB <= NSTAGE * STAGE_BYTES && WP % 4 == 0) ? 4 : 2;   // pixel tiles per pass
+  constexpr int CH = WC * 2;                                  // 8-channel chunks per staged row
+  static_assert(4 * PP * 16 * ROWB <= NSTAGE * STAGE_BYTES, "epilogue staging does not fit");
+  static_assert(WP % PP == 0, "WP must be a multiple of PP");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                               // every wave is done with the operand ring
+  unsigned char* stg = smem + wave * (PP * 16 * ROWB);
+  const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
+#pragma unroll
+  for (int pass = 0; pass < WP / PP; ++pass) {
+#pragma unroll
+    for (int tt = 0; tt < PP; ++tt)
+#pragma unroll
+      for (int c = 0; c < WC; ++c)
+        *reinterpret_cast<f32x4*>(stg + (tt * 16 + j) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int pix_base = (pblk * PT_BLK + wp * WP + pass * PP) * 16;
+#pragma unroll
+    for (int it = 0; it < PP * 16 * CH / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int pl = idx / CH, qc = idx % CH;
+      const int pix = pix_base + pl;
+      const int ch = cout_base + qc * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
+      if (pix >= p.npix || ch >= p.cout_s) continue;
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
+      }
+      if (p.has_res) {
+        size_t rbase;
+        if (p.res_ups) {
+          int ox = pix % p.w_out;
+          int r = pix / p.w_out;
+          int oy = r % p.h_out;
+          int nn = r / p.h_out;
+          rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+        } else {
+          rbase = (size_t)pix * p.cout_s;
+        }
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float r0, r1;
+          unpack2<T>(rv[e], r0, r1);
+          v[2 * e] += r0;
+          v[2 * e + 1] += r1;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        v[r] = act_apply(v[r], p.act, p.slope);
+        if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged rows are consumed before the next pass overwrites
+  }
+}
+
+template <typename T, int WAVES_C, int WC, int WP, bool REFLECT>
+int launch_cfg2(const ConvGemmArgs& a, hipStream_t s) {
+  constexpr int WAVES_P = 4 / WAVES_C;
+  constexpr int CT_BLK = WAVES_C * WC, PT_BLK = WAVES_P * WP;
+  constexpr size_t smem = (size_t)NSTAGE * (CT_BLK + PT_BLK) * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      cgan_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return CGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int npb = ceil_div(ceil_div(a.npix, 16), PT_BLK);
+  const int ncb = ceil_div(a.ctiles, CT_BLK);
+  const int grid = ceil_div(npb, 8) * 8 * ncb;
+  hipLaunchKernelGGL((conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT>), dim3(grid), dim3(256), smem, s, a, npb, ncb);
+  return CGAN_OK;
+}
+
+template <typename T, int WAVES_C, int WC, int WP>
+int launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
+  return a.pad_mode == CGAN_PAD_REFLECT ? launch_cfg2<T, WAVES_C, WC, WP, true>(a, s)
+                                        : launch_cfg2<T, WAVES_C, WC, WP, false>(a, s);
+}
+
+template <typename T>
+int launch(const ConvGemmArgs& a, hipStream_t s) {
+  const int ptiles = ceil_div(a.npix, 16);
+  if (a.ctiles <= 4) return launch_cfg<T, 1, 4, 4>(a, s);                       // 64 couts x 256 pixels
+  // all couts in one block (activations read once) when cout <= 256 and the grid still fills the chip
+  if (a.ctiles > 8 && a.ctiles <= 16 && ceil_div(ptiles, 8) >= 384) return launch_cfg<T, 2, 8, 4>(a, s);
+  // 128 couts x 256 pixels while that still gives every CU a couple of workgroups, else 128 x 128
+  if ((long)ceil_div(ptiles, 16) * ceil_div(a.ctiles, 8) >= 384) return launch_cfg<T, 2, 4, 8>(a, s);
+  return launch_cfg<T, 2, 4, 4>(a, s);
+}
+
+}  // namespace
+
+bool conv_gemm_applicable(const CganConvDesc* d) {
+  const int cin_s = cgan_cs(d->c_in), cout_s = cgan_cs(d->c_out);
+  const long npix = (long)d->n * d->h_out * d->w_out;
+  const long in_elems = (long)d->n * d->h_in * d->w_in * cin_s;
+  return (cin_s % 32) == 0 && cout_s >= 64 && !d->in_upsample && npix >= 2048 && in_elems < (1L << 31) - (1L << 20) &&
+         (long)ceil_div((int)ceil_div((int)npix, 16), 8) * ceil_div(ceil_div(cout_s, 16), 8) >= 128;
+}
+
+int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
+  return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);
+}

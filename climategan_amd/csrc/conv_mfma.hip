@@ -16,6 +16,7 @@
 // This is the general kernel (any kh/kw/stride/dilation/pad mode); operands come through L1/L2.
 #include "cgan_common.h"
 #include "conv3x3_lds.h"
+#include "conv_gemm.h"
 
 namespace {
 
@@ -342,7 +343,8 @@ void launch(const ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
-// development knob: 1 = always use the general gather kernel (A/B measurements, parity tests of both kernels)
+// development knob: 1 = always use the general gather kernel, 2 = never use the wide-layer GEMM kernel
+// (A/B measurements, parity tests of every kernel)
 int g_conv_force = 0;
 extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; }
 
@@ -396,6 +398,21 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
   p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
   p.res = (const uint16_t*)residual; p.y = (uint16_t*)y;
   hipStream_t s = (hipStream_t)stream;
+  // narrow 3x3 / stride-1 layers (< 256 channels in) are faster in the spatially tiled 3x3 kernel (halo reuse in LDS)
+  const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256;
+  if (g_conv_force == 0 && !prefer_3x3 && conv_gemm_applicable(d)) {
+    ConvGemmArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+    a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
+    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+    a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
+    a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
+    a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+    int rc2 = conv_gemm_launch(a, d->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd(GEMM LDS)");
+    return CGAN_OK;
+  }
   if (g_conv_force != 1 && conv3x3_lds_applicable(d)) {
     Conv3x3LdsArgs a;
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;

@@ -304,3 +304,57 @@ def test_conv3x3_lds_tiled(dt, case):
     finally:
         lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
     assert_close(back(y2), ref, dt, "conv3x3 gather %s" % (case,))
+
+
+GEMM_CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, pad_mode, B, H, W, residual, act      (all hit conv_gemm.hip: cin % 32 == 0, cout >= 64)
+    (256, 256, 1, 1, 0, 1, "zero", 2, 80, 80, False, "relu"),       # ResNet 1x1 (128x256 tile config)
+    (256, 1024, 1, 1, 0, 1, "zero", 2, 40, 48, True, "relu"),       # bottleneck expand + residual + ReLU
+    (256, 256, 3, 1, 2, 2, "zero", 2, 40, 40, False, "relu"),       # layer3 dilated 3x3
+    (128, 128, 3, 2, 1, 1, "zero", 2, 81, 95, False, "none"),       # strided 3x3, ragged
+    (256, 512, 1, 2, 0, 1, "zero", 2, 80, 80, False, "none"),       # strided 1x1 downsample
+    (512, 64, 1, 1, 0, 1, "zero", 2, 64, 64, False, "lrelu"),       # 64-cout config (1 x 4 waves)
+    (64, 64, 3, 1, 1, 1, "reflect", 2, 48, 80, False, "lrelu"),     # mask decoder: reflect pad
+    (96, 72, 3, 1, 4, 4, "zero", 3, 37, 53, True, "none"),          # ragged everything: cout 72 (pad tile), npix % 256 != 0
+    (2048, 256, 3, 1, 6, 6, "zero", 1, 48, 48, False, "none"),      # ASPP branch: K = 18432
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", GEMM_CONV_CASES)
+def test_conv_gemm_wide_layers(dt, case):
+    """The LDS-tiled implicit-GEMM kernel for wide layers (conv_gemm.hip) against torch fp32 on 16-bit-rounded
+    operands, and the general gather kernel (forced through the debug knob) on the same case."""
+    import ctypes
+    from climategan_amd import _lib, ops
+    cin, cout, k, stride, pad, dil, pmode, B, H, W, with_res, act = case
+    x = q(fill.uniform((B, cin, H, W), 900 + cin), dt)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = q(fill.uniform((cout, cin, k, k), 1000 + cout, -bound, bound), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 1100 + cout))
+    xin = F.pad(x, (pad,) * 4, mode="reflect") if pmode == "reflect" else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=0 if pmode == "reflect" else pad, dilation=dil)
+    res = None
+    if with_res:
+        res = q(fill.uniform(tuple(ref.shape), 1200 + cout), dt)
+        ref = ref + res
+    ref = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2)}[act](ref)
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    kw = dict(stride=stride, pad=pad, dilation=dil, pad_mode=ops.PAD_REFLECT if pmode == "reflect" else ops.PAD_ZERO,
+              act={"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}[act],
+              residual=to_nhwc(res, dt) if res is not None else None)
+    xg = to_nhwc(x, dt)
+    y = ops.conv2d(xg, pw, **kw)
+    assert y.t.shape == (B, ref.shape[2], ref.shape[3], ops.cs8(cout))
+    assert_close(back(y), ref, dt, "conv GEMM %s" % (case,))
+    if ops.cs8(cout) != cout:
+        assert y.t[..., cout:].abs().max().item() == 0
+    lib = _lib.load()
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(1))
+    try:
+        y2 = ops.conv2d(xg, pw, **kw)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    assert_close(back(y2), ref, dt, "conv gather %s" % (case,))
+    if k == 1:   # same MFMA k-order in both kernels for 1x1 -> they agree to the last bit (k > 1: taps innermost here)
+        assert torch.equal(y.t, y2.t)

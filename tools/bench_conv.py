@@ -1,0 +1,61 @@
+"""Time single convolution shape classes of the Masker through the C ABI.
+usage (GPU box): python tools/bench_conv.py [--force N]   (N: cgan_debug_set_conv_kernel value)"""
+import argparse
+import ctypes
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from climategan_amd import _lib, ops  # noqa: E402
+
+SHAPES = [
+    # name, cin, cout, k, stride, pad, dil, H (input), count-in-resnet
+    ("l3 1x1 1024->256", 1024, 256, 1, 1, 0, 1, 80),
+    ("l3 3x3 d2 256->256", 256, 256, 3, 1, 2, 2, 80),
+    ("l3 1x1 256->1024", 256, 1024, 1, 1, 0, 1, 80),
+    ("l4 3x3 d4 512->512", 512, 512, 3, 1, 4, 4, 80),
+    ("l4 1x1 512->2048", 512, 2048, 1, 1, 0, 1, 80),
+    ("l4 1x1 2048->512", 2048, 512, 1, 1, 0, 1, 80),
+    ("aspp 3x3 d6 2048->256", 2048, 256, 3, 1, 6, 6, 80),
+    ("l1 1x1 64->256", 64, 256, 1, 1, 0, 1, 160),
+    ("l1 3x3 64->64", 64, 64, 3, 1, 1, 1, 160),
+    ("l2 3x3 128->128", 128, 128, 3, 1, 1, 1, 80),
+    ("painter 3x3 160->160 @80", 160, 160, 3, 1, 1, 1, 80),
+    ("painter 3x3 320->320 @40", 320, 320, 3, 1, 1, 1, 40),
+    ("seg 3x3 256->256 @82", 256, 256, 3, 1, 1, 1, 82),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", type=int, default=0)
+    ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--abl", type=int, default=0)
+    ap.add_argument("--dtype", default="fp16")
+    args = ap.parse_args()
+    dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    lib = _lib.load()
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(args.force))
+    for name, cin, cout, k, stride, pad, dil, H in SHAPES:
+        x = ops.NHWC(torch.randn(args.bs, H, H, cin, device="cuda").to(dt), cin)
+        w = torch.randn(cout, cin, k, k, device="cuda") * 0.02
+        pw = ops.pack_conv_weight(w, None, dt)
+        for _ in range(3):
+            y = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_RELU)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 10
+        for _ in range(n):
+            y = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_RELU)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        flops = 2.0 * y.n * y.h * y.w * cout * cin * k * k
+        print("%-24s %8.3f ms  %7.1f TFLOP/s" % (name, ms, flops / ms / 1e9))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""Inference throughput of Trainer.infer_all (flood event only) at BASELINE configs[4]'s shape: 640x640, bs 16, fp16.
+Smog / wildfire are not built, so this is the Masker + Painter + uint8 part of that config.
+
+usage (GPU box): python tools/bench_infer.py [--bs 16] [--steps 10]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+
+from climategan_amd import fill  # noqa: E402
+from climategan_amd.config import default_opts  # noqa: E402
+from climategan_amd.trainer import Trainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="fp16")
+    args = ap.parse_args()
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    T = Trainer(opts, device="cuda").setup(inference=True)
+    shapes = {k: tuple(v.shape) for k, v in T.G.state_dict().items()}
+    sd = fill.fill_state_dict(shapes, seed=0, gain=1.6)
+    T.G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    T.G.set_compute_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
+    x = torch.from_numpy(fill.uniform((args.bs, 3, 640, 640), 5)).cuda()
+    stores = {k: [] for k in ("all events", "encode", "depth", "segmentation", "mask", "flood", "numpy")}
+    for _ in range(args.warmup):
+        T.infer_all(x, numpy=True, bin_value=0.5, half=True, ignore_event={"wildfire", "smog"})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = T.infer_all(x, numpy=True, stores=stores, bin_value=0.5, half=True, ignore_event={"wildfire", "smog"})
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": "Trainer.infer_all flood only, 640x640 bs %d %s (incl. uint8 D2H)" % (args.bs, args.dtype),
+           "images_per_s": round(args.bs * args.steps / dt, 2), "ms_per_batch": round(dt / args.steps * 1e3, 2),
+           "stage_ms": {k: round(1e3 * sum(v) / max(len(v), 1), 2) for k, v in stores.items()},
+           "flood_shape": list(out["flood"].shape)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
