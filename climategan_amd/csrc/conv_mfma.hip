@@ -32,6 +32,7 @@ struct ConvParams {
   int h_out, w_out, npix;
   int kgroups, ksteps;
   int in_ups, act, has_res, res_ups;
+  int in_zs;   // > 1: x is read through zero insertion (stride of the forward conv whose data gradient this is)
   float slope;
 };
 
@@ -110,6 +111,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         ok = ok && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
       }
       b[t] = (u32x4){0u, 0u, 0u, 0u};
+      if (p.in_zs > 1) {   // transposed conv: only every in_zs-th virtual row / column holds data
+        ok = ok && (iy % p.in_zs) == 0 && (ix % p.in_zs) == 0;
+        iy /= p.in_zs;
+        ix /= p.in_zs;
+      }
       if (ok) {
         if (p.in_ups) { iy >>= 1; ix >>= 1; }
         size_t off = (((size_t)pn[t] * p.hx + iy) * p.wx + ix) * p.cin_s + c8 * 8;
@@ -201,7 +207,10 @@ template <typename T>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                         const float* __restrict__ sigma, uint16_t* __restrict__ packed,
                                         float* __restrict__ bias_out, int cout, int cin, int cin_p, int kh, int kw,
-                                        int ctiles, int ksteps) {
+                                        int ctiles, int ksteps, int tr) {
+  // tr = 1: pack the data-gradient operator of the OIHW weight w[cin][cout][kh][kw] of the FORWARD conv (rows =
+  // forward input channels, K channels = forward output channels, taps flipped); cout/cin here are the rows / K
+  // channels of the packed operator in both modes.
   const int total = ctiles * ksteps * 64;
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
   const int taps = kh * kw;
@@ -218,7 +227,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
       int tap = k / cin_p;
       int c = k - tap * cin_p;
       float v = 0.f;
-      if (co < cout && tap < taps && c < cin) v = w[((size_t)co * cin + c) * taps + tap] * inv;
+      if (co < cout && tap < taps && c < cin)
+        v = (tr ? w[((size_t)c * cout + co) * taps + (taps - 1 - tap)] : w[((size_t)co * cin + c) * taps + tap]) * inv;
       o[e] = bits_of<T>(v);
     }
     u32x4 pk;
@@ -300,7 +310,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   CGAN_REQUIRE(npix < (1L << 31) - 64, "conv2d: too many output pixels");
   p.npix = (int)npix;
   p.kgroups = d->kh * d->kw * p.cg; p.ksteps = ceil_div(p.kgroups, 4);
-  p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope;
+  p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1;
   p.has_res = d->has_residual; p.res_ups = d->residual_upsample;
   return CGAN_OK;
 }
@@ -365,10 +375,10 @@ extern "C" int cgan_conv2d_pack_weight(const float* w_oihw, const float* bias, c
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CGAN_F16)
     hipLaunchKernelGGL(pack_conv_weight_kernel<F16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
-                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_p, d->kh, d->kw, p.ctiles, p.ksteps);
+                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_p, d->kh, d->kw, p.ctiles, p.ksteps, 0);
   else
     hipLaunchKernelGGL(pack_conv_weight_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w_oihw, bias, sigma,
-                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_p, d->kh, d->kw, p.ctiles, p.ksteps);
+                       (uint16_t*)packed, bias_out, d->c_out, d->c_in, p.cin_p, d->kh, d->kw, p.ctiles, p.ksteps, 0);
   CGAN_CHECK_LAUNCH("conv2d_pack_weight");
   return CGAN_OK;
 }
@@ -387,6 +397,40 @@ extern "C" int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device,
   return CGAN_OK;
 }
 
+// kernel selection shared by the forward and the stride-1 data-gradient entry points
+static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, const char* what) {
+  // narrow 3x3 / stride-1 layers (< 256 channels in) are faster in the spatially tiled 3x3 kernel (halo reuse in LDS)
+  const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256;
+  if (g_conv_force == 0 && p.in_zs == 1 && !prefer_3x3 && conv_gemm_applicable(d)) {
+    ConvGemmArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+    a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
+    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+    a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
+    a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
+    a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+    int rc2 = conv_gemm_launch(a, d->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH(what);
+    return CGAN_OK;
+  }
+  if (g_conv_force != 1 && p.in_zs == 1 && conv3x3_lds_applicable(d)) {
+    Conv3x3LdsArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
+    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+    a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+    int rc2 = conv3x3_lds_launch(a, d->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH(what);
+    return CGAN_OK;
+  }
+  if (d->dtype == CGAN_F16) launch<F16>(p, s);
+  else launch<BF16>(p, s);
+  CGAN_CHECK_LAUNCH(what);
+  return CGAN_OK;
+}
+
 extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const float* bias_padded, const void* residual,
                                     void* y, const CganConvDesc* d, void* stream) {
   ConvParams p;
@@ -397,35 +441,97 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
   CGAN_REQUIRE(!d->has_residual || residual, "conv2d_nhwc_fwd: has_residual but residual is null");
   p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
   p.res = (const uint16_t*)residual; p.y = (uint16_t*)y;
+  return dispatch_conv(p, d, (hipStream_t)stream, "conv2d_nhwc_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-data: dx = conv_transpose(dy, w) expressed as a stride-1 convolution of dy (read through zero insertion
+// when the forward stride is > 1) with the channel-transposed, tap-flipped weights, pad' = dil (k-1) - pad.
+// ------------------------------------------------------------------------------------------------
+static int dgrad_desc(const CganConvDesc* f, CganConvDesc* t) {
+  CGAN_REQUIRE(f != nullptr, "conv2d bwd_data: null descriptor");
+  CGAN_REQUIRE(f->pad_mode == CGAN_PAD_ZERO, "conv2d bwd_data: only zero padding has a backward path");
+  CGAN_REQUIRE(!f->in_upsample, "conv2d bwd_data: the folded x2 upsample has no backward path yet");
+  CGAN_REQUIRE(f->stride >= 1 && f->dilation >= 1 && f->kh > 0 && f->kw > 0, "conv2d bwd_data: bad kernel params");
+  *t = *f;
+  t->c_in = f->c_out; t->c_out = f->c_in;
+  t->h_in = (f->h_out - 1) * f->stride + 1;      // virtual (zero-inserted) extent of dy
+  t->w_in = (f->w_out - 1) * f->stride + 1;
+  t->stride = 1;
+  t->pad = f->dilation * (f->kh - 1) - f->pad;
+  CGAN_REQUIRE(f->kh == f->kw, "conv2d bwd_data: square kernels only");
+  t->h_out = t->h_in + 2 * t->pad - f->dilation * (f->kh - 1);
+  t->w_out = t->w_in + 2 * t->pad - f->dilation * (f->kw - 1);
+  CGAN_REQUIRE(t->h_out <= f->h_in && t->w_out <= f->w_in && t->h_out > 0 && t->w_out > 0,
+               "conv2d bwd_data: inconsistent forward descriptor");
+  t->in_upsample = 0; t->act = CGAN_ACT_NONE; t->has_bias = 0; t->has_residual = 0; t->residual_upsample = 0;
+  return CGAN_OK;
+}
+
+static int dgrad_params(ConvParams& p, const CganConvDesc* f, CganConvDesc* t) {
+  int rc = dgrad_desc(f, t);
+  if (rc != CGAN_OK) return rc;
+  const int pad_t = t->pad;
+  if (pad_t < 0) t->pad = 0;                       // fill_params wants pad >= 0 (only ASPP's padded 1x1 gets here)
+  if (pad_t < 0) { t->h_out = t->h_in; t->w_out = t->w_in; }
+  rc = fill_params(p, t);
+  if (rc != CGAN_OK) return rc;
+  p.pad = pad_t;
+  // rows / columns of the forward input that no output window reached (floor in the output-size formula) still get
+  // written: every tap lands outside the virtual extent there, so they come out zero
+  p.h_out = f->h_in; p.w_out = f->w_in;
+  p.npix = f->n * f->h_in * f->w_in;
+  p.hx = f->h_out; p.wx = f->w_out;                // stored extent of dy
+  p.in_zs = f->stride;
+  t->h_out = f->h_in; t->w_out = f->w_in;
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_conv2d_dgrad_packed_weight_bytes(const CganConvDesc* fwd) {
+  ConvParams p;
+  CganConvDesc t;
+  if (dgrad_params(p, fwd, &t) != CGAN_OK) return 0;
+  return (size_t)p.ctiles * p.ksteps * 64 * 16;
+}
+
+extern "C" int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* sigma, void* packed,
+                                             const CganConvDesc* fwd, void* stream) {
+  ConvParams p;
+  CganConvDesc t;
+  int rc = dgrad_params(p, fwd, &t);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(w_oihw && packed, "conv2d_pack_weight_dgrad: null pointer");
+  const int total = p.ctiles * p.ksteps * 64;
+  const int blocks = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
   hipStream_t s = (hipStream_t)stream;
-  // narrow 3x3 / stride-1 layers (< 256 channels in) are faster in the spatially tiled 3x3 kernel (halo reuse in LDS)
-  const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256;
-  if (g_conv_force == 0 && !prefer_3x3 && conv_gemm_applicable(d)) {
-    ConvGemmArgs a;
-    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
-    a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
-    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
-    a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
-    a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
-    a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
-    int rc2 = conv_gemm_launch(a, d->dtype, s);
-    if (rc2 != CGAN_OK) return rc2;
-    CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd(GEMM LDS)");
-    return CGAN_OK;
+  // rows = forward c_in, K channels = forward c_out
+  if (fwd->dtype == CGAN_F16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<F16>, dim3(blocks), dim3(256), 0, s, w_oihw, (const float*)nullptr, sigma,
+                       (uint16_t*)packed, (float*)nullptr, t.c_out, t.c_in, p.cin_p, t.kh, t.kw, p.ctiles, p.ksteps, 1);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_kernel<BF16>, dim3(blocks), dim3(256), 0, s, w_oihw, (const float*)nullptr, sigma,
+                       (uint16_t*)packed, (float*)nullptr, t.c_out, t.c_in, p.cin_p, t.kh, t.kw, p.ctiles, p.ksteps, 1);
+  CGAN_CHECK_LAUNCH("conv2d_pack_weight_dgrad");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
+                                         void* stream) {
+  ConvParams p;
+  CganConvDesc t;
+  int rc = dgrad_params(p, fwd, &t);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(dy && packed_w_dgrad && dx, "conv2d_nhwc_bwd_data: null pointer");
+  p.x = (const uint16_t*)dy; p.w = (const u32x4*)packed_w_dgrad; p.bias = nullptr; p.res = nullptr; p.y = (uint16_t*)dx;
+  hipStream_t s = (hipStream_t)stream;
+  const bool plain = fwd->stride == 1 && p.pad >= 0 && t.h_in + 2 * p.pad - t.dilation * (t.kh - 1) == t.h_out &&
+                     t.w_in + 2 * p.pad - t.dilation * (t.kw - 1) == t.w_out;
+  if (plain) {
+    t.pad = p.pad;
+    return dispatch_conv(p, &t, s, "conv2d_nhwc_bwd_data");
   }
-  if (g_conv_force != 1 && conv3x3_lds_applicable(d)) {
-    Conv3x3LdsArgs a;
-    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
-    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
-    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
-    a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
-    int rc2 = conv3x3_lds_launch(a, d->dtype, s);
-    if (rc2 != CGAN_OK) return rc2;
-    CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd(3x3 LDS)");
-    return CGAN_OK;
-  }
-  if (d->dtype == CGAN_F16) launch<F16>(p, s);
+  if (fwd->dtype == CGAN_F16) launch<F16>(p, s);
   else launch<BF16>(p, s);
-  CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd");
+  CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_data");
   return CGAN_OK;
 }

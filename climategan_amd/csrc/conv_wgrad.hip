@@ -1,0 +1,235 @@
+// conv2d backward-weight (NHWC 16-bit activations, fp32 OIHW gradient), MFMA 16x16x32, gfx950.
+//
+//   dW[co][ci][ky][kx] += sum over output pixels  dY[pix][co] * X[pix shifted by tap (ky,kx)][ci]
+//
+// GEMM view per tap: M = co, N = ci, K = output pixels.  Both operands are K-strided in NHWC memory (a lane needs 8
+// PIXELS of one channel), so tiles are staged in LDS row-major [pixel][64 channels] by LDS-DMA (8 pixels x 128 B per
+// 1-KiB piece: whole cache lines) and read with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group
+// reads a [4 pixels][16 channels] block and each lane receives one channel's 4 pixels) -- two of them make one
+// MFMA operand fragment, no shuffles.
+//
+// Workgroup = 4 independent waves: wave w owns pixels [32w, 32w+32) of every 128-pixel chunk (its own DMA, its own
+// double buffer, no barriers in the loop) and accumulates the full 64 co x 64 ci tile of one tap; the four partial
+// tiles are summed through LDS at the end and added to dW with fp32 atomics (grid = pixel splits x taps x channel
+// blocks, so several workgroups contribute to each weight).
+#include "cgan_common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_wgrad_zeros[4];
+
+struct WgradArgs {
+  const uint16_t* x;
+  const uint16_t* dy;
+  float* dw;
+  int n, h_in, w_in, cin, cin_s;
+  int cout, cout_s;
+  int kh, kw, stride, pad, dil;
+  int h_out, w_out, npix;
+  int nchunks, ci_blocks;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SLAB_BYTES = 32 * 128;        // 32 pixels x 64 channels x 2 B
+constexpr int WAVE_LDS = 4 * SLAB_BYTES;    // {dy, x} x double buffer
+
+__device__ __forceinline__ u32x4 tr_frag(const unsigned char* slab, int tile, int lane) {
+  // rows 8g..8g+7 (pixels) of channel tile `tile`: two transposing reads of [4 pixels][16 channels] blocks
+  const int i = lane & 15, g = lane >> 4;
+  const unsigned char* a0 = slab + (8 * g + (i >> 2)) * 128 + tile * 32 + (i & 3) * 8;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 128));
+  u32x4 r;
+  r[0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+  r[1] = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+  r[2] = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+  r[3] = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tap = blockIdx.y;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int cob = blockIdx.z / p.ci_blocks, cib = blockIdx.z - cob * p.ci_blocks;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  unsigned char* wl = smem + wave * WAVE_LDS;
+
+  const int prow = lane >> 3;          // pixel within an 8-pixel DMA piece
+  const int q8 = (lane & 7) * 8;       // first channel of this lane's 16-byte chunk
+  const bool co_ok = co0 + q8 < p.cout_s, ci_ok = ci0 + q8 < p.cin_s;
+  const long zero_dy = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.dy);
+  const long zero_x = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.x);
+
+  // DMA of this wave's 32-pixel slab of chunk c into buffer b: 4 pieces of dy, 4 pieces of (tap-shifted) x
+  auto issue = [&](int c, int b) {
+    unsigned char* dst_dy = wl + b * 2 * SLAB_BYTES;
+    unsigned char* dst_x = dst_dy + SLAB_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pix = c * 128 + wave * 32 + i * 8 + prow;
+      const bool pv = pix < p.npix;
+      const int pc = pv ? pix : 0;
+      const int ox = pc % p.w_out;
+      const int r = pc / p.w_out;
+      const int oy = r % p.h_out;
+      const int nn = r / p.h_out;
+      const long off_dy = (pv && co_ok) ? ((long)pc * p.cout_s + co0 + q8) * 2 : zero_dy;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.dy) + off_dy),
+          (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16, 0, 0);
+      const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
+      const bool xv = pv && ci_ok && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+      const long off_x = xv ? ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + ci0 + q8) * 2 : zero_x;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.x) + off_x),
+          (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int c = blockIdx.x, buf = 0;
+  if (c < p.nchunks) issue(c, 0);
+  for (; c < p.nchunks; c += gridDim.x) {
+    const int cn = c + gridDim.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier fragment reads of the other buffer are done
+    if (cn < p.nchunks) {
+      issue(cn, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned char* sdy = wl + buf * 2 * SLAB_BYTES;
+    const unsigned char* sx = sdy + SLAB_BYTES;
+    u32x4 fa[4], fb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fa[a] = tr_frag(sdy, a, lane);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fb[b] = tr_frag(sx, b, lane);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb[b]), acc[a][b]);
+    buf ^= 1;
+  }
+
+  // ---- sum the four waves' partial tiles through LDS, then fp32 atomics into dW (OIHW)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      *reinterpret_cast<f32x4*>(smem + ((wave * 16 + a * 4 + b) * 64 + lane) * 16) = acc[a][b];
+  __syncthreads();
+  const int taps = p.kh * p.kw;
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int a = wave;   // this wave finalises co tile `wave`
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + ((w * 16 + a * 4 + b) * 64 + lane) * 16);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    const int ci = ci0 + b * 16 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + a * 16 + 4 * g + r;
+      if (co < p.cout && ci < p.cin) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps + tap, s[r]);
+    }
+  }
+}
+
+// per-channel sum over pixels of an NHWC tensor (bias gradient): fp32 atomics into out[c]
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
+                                                          long npix, int cs, int c) {
+  const int groups = cs / 8;
+  const int gi = threadIdx.x % groups;               // channel group of this thread (blockDim % groups == 0 not needed)
+  const int lanes_per_pix = groups;
+  const int ppb = blockDim.x / lanes_per_pix;        // pixels per block iteration
+  const int pl = threadIdx.x / lanes_per_pix;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pl < ppb) {
+    for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + pix * cs + gi * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a, b;
+        unpack2<T>(v[e], a, b);
+        s[2 * e] += a;
+        s[2 * e + 1] += b;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (gi * 8 + e < c) atomicAdd(out + gi * 8 + e, s[e]);
+  }
+}
+
+}  // namespace
+
+extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias,
+                                           const CganConvDesc* d, void* stream) {
+  CGAN_REQUIRE(d != nullptr && x && dy && dw_oihw, "conv2d_nhwc_bwd_weight: null pointer");
+  CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d_nhwc_bwd_weight: bad dtype %d", d->dtype);
+  CGAN_REQUIRE(d->pad_mode == CGAN_PAD_ZERO, "conv2d_nhwc_bwd_weight: only zero padding has a backward path");
+  CGAN_REQUIRE(!d->in_upsample, "conv2d_nhwc_bwd_weight: the folded x2 upsample has no backward path yet");
+  CGAN_REQUIRE(d->n > 0 && d->h_in > 0 && d->w_in > 0 && d->c_in > 0 && d->c_out > 0 && d->kh > 0 && d->kw > 0 &&
+                   d->stride > 0 && d->dilation > 0 && d->pad >= 0,
+               "conv2d_nhwc_bwd_weight: bad shape");
+  const int eh = (d->h_in + 2 * d->pad - d->dilation * (d->kh - 1) - 1) / d->stride + 1;
+  const int ew = (d->w_in + 2 * d->pad - d->dilation * (d->kw - 1) - 1) / d->stride + 1;
+  CGAN_REQUIRE(eh == d->h_out && ew == d->w_out, "conv2d_nhwc_bwd_weight: h_out/w_out inconsistent");
+  WgradArgs a;
+  a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.dw = dw_oihw;
+  a.n = d->n; a.h_in = d->h_in; a.w_in = d->w_in; a.cin = d->c_in; a.cin_s = cgan_cs(d->c_in);
+  a.cout = d->c_out; a.cout_s = cgan_cs(d->c_out);
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dilation;
+  a.h_out = d->h_out; a.w_out = d->w_out;
+  const long npix = (long)d->n * d->h_out * d->w_out;
+  CGAN_REQUIRE(npix < (1L << 31) - 256, "conv2d_nhwc_bwd_weight: too many pixels");
+  a.npix = (int)npix;
+  a.nchunks = ceil_div(a.npix, 128);
+  a.ci_blocks = ceil_div(a.cin_s, 64);
+  const int blocks = ceil_div(a.cout_s, 64) * a.ci_blocks;
+  const int taps = d->kh * d->kw;
+  int splits = ceil_div(2048, taps * blocks);
+  if (splits > a.nchunks) splits = a.nchunks;
+  if (splits < 1) splits = 1;
+  CGAN_REQUIRE(blocks <= 65535 && taps <= 65535, "conv2d_nhwc_bwd_weight: grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t smem = 4 * WAVE_LDS;   // 64 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
+  if (d->dtype == CGAN_F16)
+    hipLaunchKernelGGL(conv_wgrad_kernel<F16>, dim3(splits, taps, blocks), dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(splits, taps, blocks), dim3(256), smem, s, a);
+  CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
+  if (dbias) {
+    const int cs = a.cout_s;
+    const int threads = 256;
+    const int ppb = threads / (cs / 8) > 0 ? threads / (cs / 8) : 1;
+    CGAN_REQUIRE(cs / 8 <= threads, "conv2d_nhwc_bwd_weight: too many channels for the bias reduction");
+    long want = (npix + (long)ppb * 64 - 1) / ((long)ppb * 64);
+    const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    if (d->dtype == CGAN_F16)
+      hipLaunchKernelGGL(channel_sum_kernel<F16>, dim3(grid), dim3(threads), 0, s, (const uint16_t*)dy, dbias, npix, cs,
+                         d->c_out);
+    else
+      hipLaunchKernelGGL(channel_sum_kernel<BF16>, dim3(grid), dim3(threads), 0, s, (const uint16_t*)dy, dbias, npix, cs,
+                         d->c_out);
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(bias)");
+  }
+  return CGAN_OK;
+}

@@ -296,6 +296,47 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
     return NHWC(y, pw.c_out)
 
 
+def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilation=1,
+                    sigma: Optional[torch.Tensor] = None) -> NHWC:
+    """dx of y = conv(x, w / sigma): ``w`` fp32 OIHW, ``x_shape`` = (n, h_in, w_in) of the forward input."""
+    _need_cuda(dy.t, w, sigma)
+    w = w.detach().contiguous().float()
+    c_out, c_in, kh, kw = w.shape
+    n, h_in, w_in = x_shape
+    d = _conv_desc(dy.dtype_id, n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dilation, PAD_ZERO, has_bias=False)
+    if (d.h_out, d.w_out) != (dy.h, dy.w) or dy.c != c_out or dy.n != n:
+        raise RuntimeError("conv2d_bwd_data: dy shape %s does not match the forward conv" % (tuple(dy.t.shape),))
+    lib = _lib.load()
+    nbytes = lib.cgan_conv2d_dgrad_packed_weight_bytes(C.byref(d))
+    if nbytes == 0:
+        _lib.check(-1, "cgan_conv2d_dgrad_packed_weight_bytes")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
+               "cgan_conv2d_pack_weight_dgrad")
+    dx = torch.empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
+    _lib.check(lib.cgan_conv2d_nhwc_bwd_data(_ptr(dy.t), _ptr(packed), _ptr(dx), C.byref(d), _stream()),
+               "cgan_conv2d_nhwc_bwd_data")
+    return NHWC(dx, c_in)
+
+
+def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, want_bias=True,
+                      dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None):
+    """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given."""
+    _need_cuda(x.t, dy.t, dw, dbias)
+    c_out, c_in, kh, kw = w_shape
+    d = _conv_desc(x.dtype_id, x.n, x.h, x.w, c_in, c_out, kh, kw, stride, pad, dilation, PAD_ZERO)
+    if (d.h_out, d.w_out) != (dy.h, dy.w) or dy.c != c_out or x.c != c_in or dy.n != x.n:
+        raise RuntimeError("conv2d_bwd_weight: shapes do not match the forward conv")
+    if dw is None:
+        dw = torch.zeros((c_out, c_in, kh, kw), dtype=torch.float32, device=x.t.device)
+    if want_bias and dbias is None:
+        dbias = torch.zeros((c_out,), dtype=torch.float32, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_conv2d_nhwc_bwd_weight(_ptr(x.t), _ptr(dy.t), _ptr(dw), _ptr(dbias if want_bias else None),
+                                               C.byref(d), _stream()), "cgan_conv2d_nhwc_bwd_weight")
+    return dw, (dbias if want_bias else None)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def instnorm_stats(x: NHWC, eps: float = 1e-5):
     """Per-(n,c) mean and 1/sqrt(var+eps) (biased var over H*W) -> two fp32 [N, Cs] tensors."""

@@ -97,6 +97,21 @@ typedef struct {
 int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t count, int32_t dtype,
                                     int32_t max_fragments, void* stream);
 
+/* Backward of the convolution above (autograd of nn.Conv2d, reached from g_loss.backward() / d_loss.backward(),
+ * climategan/trainer.py:1011,1028).  All take the FORWARD descriptor; act / bias / residual fields are ignored (their
+ * backward is elementwise and lives in the callers); zero padding only, no folded upsample.
+ *  - bwd_data:   dx[n][h_in][w_in][cgan_cs(c_in)] = conv_transpose(dy, w)  (rows / columns no window reached are zero);
+ *                packed_w_dgrad comes from cgan_conv2d_pack_weight_dgrad (channel-transposed, tap-flipped, / *sigma).
+ *  - bwd_weight: dw_oihw[c_out][c_in][kh][kw] += sum_pixels dy * x(shifted)   and   dbias[c_out] += sum_pixels dy
+ *                (fp32, ACCUMULATED with atomics: zero them first; dbias may be NULL). */
+size_t cgan_conv2d_dgrad_packed_weight_bytes(const CganConvDesc* fwd);
+int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* sigma, void* packed, const CganConvDesc* fwd,
+                                  void* stream);
+int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
+                              void* stream);
+int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias, const CganConvDesc* fwd,
+                                void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Instance-norm statistics (biased variance over H*W per (n, c)), nn.InstanceNorm2d(affine=False,
  * track_running_stats=False): climategan/norms.py:151, climategan/discriminator.py:70-73.
