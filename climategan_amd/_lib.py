@@ -93,6 +93,13 @@ _SIGNATURES = {
     "cgan_copy_channels_nhwc": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_eltwise_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
     "cgan_fold_bn": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int32, C.c_int64, _P]),
+    "cgan_act_bwd": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int64, _P]),
+    "cgan_instnorm_act_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(NormStatsDesc)]),
+    "cgan_instnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P, C.c_size_t,
+                                        _P]),
+    "cgan_bce_logits_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
+    "cgan_l1_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),
+    "cgan_spectral_norm_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "cgan_normalize_u8_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_normalize_u8_nhwc": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
                                          _P]),

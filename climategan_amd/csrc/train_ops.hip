@@ -1,0 +1,335 @@
+// Elementwise / reduction kernels of the training path (backward of activations and instance norm, GAN and
+// feature-matching losses with their gradients, spectral-norm weight-gradient transform).  All HBM-bound.
+#include "cgan_common.h"
+
+namespace {
+
+__host__ __device__ inline int grid_for_n(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// d/dz of act, expressed through the OUTPUT of the activation
+__device__ __forceinline__ float act_grad_from_out(float out, int act, float slope) {
+  switch (act) {
+    case CGAN_ACT_RELU: return out > 0.f ? 1.f : 0.f;
+    case CGAN_ACT_LRELU: return out > 0.f ? 1.f : slope;
+    case CGAN_ACT_TANH: return 1.f - out * out;
+    case CGAN_ACT_SIGMOID: return out * (1.f - out);
+    default: return 1.f;
+  }
+}
+
+// dx = dy * act'(.)   (16-bit NHWC storage, 8 elements per thread)
+template <typename T>
+__global__ void act_bwd_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dy,
+                               uint16_t* __restrict__ dx, int act, float slope, long groups) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
+    const u32x4 g = reinterpret_cast<const u32x4*>(dy)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float o0, o1, g0, g1;
+      unpack2<T>(o[e], o0, o1);
+      unpack2<T>(g[e], g0, g1);
+      r[e] = pack2<T>(g0 * act_grad_from_out(o0, act, slope), g1 * act_grad_from_out(o1, act, slope));
+    }
+    reinterpret_cast<u32x4*>(dx)[i] = r;
+  }
+}
+
+// ---- instance norm (+ LeakyReLU) backward -------------------------------------------------------------------
+// out = act(y), y = (x - mean) * rstd.   dz = dy * act'(out), y = act^-1(out)
+// dx = rstd * (dz - mean_hw(dz) - y * mean_hw(dz * y))
+__device__ __forceinline__ void in_bwd_terms(float out, float dy, int act, float slope, float& dz, float& y) {
+  if (act == CGAN_ACT_LRELU) {
+    const bool pos = out > 0.f;
+    dz = pos ? dy : dy * slope;
+    y = pos ? out : out / slope;
+  } else {
+    dz = dy;
+    y = out;
+  }
+}
+
+// sums[n][cs][2] += (sum dz, sum dz*y) over this block's pixel range; grid (chunks, channel-group blocks, n)
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const uint16_t* __restrict__ out,
+                                                            const uint16_t* __restrict__ dy, float* __restrict__ sums,
+                                                            int hw, int cs, int ppb, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL][cgb*8][2]
+  const int cg_total = cs / 8;
+  const int cgb = cg_total < 256 ? cg_total : 256;
+  const int PL = 256 / cgb;
+  const int n = blockIdx.z, cg0 = blockIdx.y * cgb;
+  const int p0 = blockIdx.x * ppb, p1 = min(hw, p0 + ppb);
+  const int t = threadIdx.x, cgl = t % cgb, pl = t / cgb;
+  const int cg = cg0 + cgl;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL && cg < cg_total) {
+    const size_t base = (size_t)n * hw * cs + cg * 8;
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const u32x4 o = *reinterpret_cast<const u32x4*>(out + base + (size_t)p * cs);
+      const u32x4 g = *reinterpret_cast<const u32x4*>(dy + base + (size_t)p * cs);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float o0, o1, g0, g1, dz, y;
+        unpack2<T>(o[e], o0, o1);
+        unpack2<T>(g[e], g0, g1);
+        in_bwd_terms(o0, g0, act, slope, dz, y);
+        s1[2 * e] += dz; s2[2 * e] += dz * y;
+        in_bwd_terms(o1, g1, act, slope, dz, y);
+        s1[2 * e + 1] += dz; s2[2 * e + 1] += dz * y;
+      }
+    }
+  }
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sm[((pl * cgb + cgl) * 8 + e) * 2] = s1[e];
+      sm[((pl * cgb + cgl) * 8 + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < cgb * 8; c += 256) {
+    if (cg0 * 8 + c >= cs) continue;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < PL; ++l) {
+      a += sm[((l * cgb) * 8 + c) * 2];
+      b += sm[((l * cgb) * 8 + c) * 2 + 1];
+    }
+    float* o = sums + ((size_t)n * cs + cg0 * 8 + c) * 2;
+    atomicAdd(o, a);
+    atomicAdd(o + 1, b);
+  }
+}
+
+template <typename T>
+__global__ void in_bwd_apply_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dy,
+                                    const float* __restrict__ rstd, const float* __restrict__ sums,
+                                    uint16_t* __restrict__ dx, int hw, int cs, int c, int act, float slope,
+                                    long groups) {
+  const int cg_total = cs / 8;
+  const float inv_hw = 1.f / (float)hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const long pix = i / cg_total;
+    const int n = (int)(pix / hw);
+    const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
+    const u32x4 g = reinterpret_cast<const u32x4*>(dy)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float o0, o1, g0, g1;
+      unpack2<T>(o[e], o0, o1);
+      unpack2<T>(g[e], g0, g1);
+      float res[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ch = cg * 8 + 2 * e + h;
+        float dz, y;
+        in_bwd_terms(h ? o1 : o0, h ? g1 : g0, act, slope, dz, y);
+        const float* sp = sums + ((size_t)n * cs + ch) * 2;
+        const float v = rstd[(size_t)n * cs + ch] * (dz - sp[0] * inv_hw - y * sp[1] * inv_hw);
+        res[h] = ch < c ? v : 0.f;
+      }
+      r[e] = pack2<T>(res[0], res[1]);
+    }
+    reinterpret_cast<u32x4*>(dx)[i] = r;
+  }
+}
+
+// ---- losses ---------------------------------------------------------------------------------------------------
+// block-level sum -> one atomic per block
+__device__ __forceinline__ void block_atomic_add(float v, float* dst) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
+}
+
+// nn.BCEWithLogitsLoss against a constant target over the c logical channels of an NHWC tensor:
+// loss += weight * sum(max(x,0) - x t + log1p(exp(-|x|)));  dx = weight * (sigmoid(x) - t) (pad channels 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bce_logits_kernel(const uint16_t* __restrict__ x, float target, float weight,
+                                                         float* __restrict__ loss, uint16_t* __restrict__ dx, int cs,
+                                                         int c, long groups) {
+  const int cg_total = cs / 8;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a[2], gr[2];
+      unpack2<T>(v[e], a[0], a[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool live = cg * 8 + 2 * e + h < c;
+        const float xv = a[h];
+        const float l = fmaxf(xv, 0.f) - xv * target + log1pf(__expf(-fabsf(xv)));
+        acc += live ? l : 0.f;
+        const float sg = 1.f / (1.f + __expf(-xv));
+        gr[h] = live ? weight * (sg - target) : 0.f;
+      }
+      r[e] = pack2<T>(gr[0], gr[1]);
+    }
+    if (dx) reinterpret_cast<u32x4*>(dx)[i] = r;
+  }
+  block_atomic_add(acc * weight, loss);
+}
+
+// nn.L1Loss pieces: loss += weight * sum|a - b|;  da = weight * sign(a - b)
+template <typename T>
+__global__ __launch_bounds__(256) void l1_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                 float weight, float* __restrict__ loss, uint16_t* __restrict__ da,
+                                                 long groups) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 va = reinterpret_cast<const u32x4*>(a)[i];
+    const u32x4 vb = reinterpret_cast<const u32x4*>(b)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a0, a1, b0, b1;
+      unpack2<T>(va[e], a0, a1);
+      unpack2<T>(vb[e], b0, b1);
+      const float d0 = a0 - b0, d1 = a1 - b1;
+      acc += fabsf(d0) + fabsf(d1);
+      r[e] = pack2<T>(d0 > 0.f ? weight : (d0 < 0.f ? -weight : 0.f), d1 > 0.f ? weight : (d1 < 0.f ? -weight : 0.f));
+    }
+    if (da) reinterpret_cast<u32x4*>(da)[i] = r;
+  }
+  block_atomic_add(acc * weight, loss);
+}
+
+// ---- spectral norm: gradient w.r.t. w_bar from the gradient w.r.t. w = w_bar / sigma, sigma = u^T w_bar v ------
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ g, const float* __restrict__ w_bar,
+                                                         float* __restrict__ dot, long numel) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x)
+    acc += g[i] * w_bar[i];
+  block_atomic_add(acc, dot);
+}
+__global__ void sn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
+                                    const float* __restrict__ sigma, const float* __restrict__ dot, int cols,
+                                    long numel) {
+  const float inv = 1.f / sigma[0];
+  const float k = dot[0] * inv * inv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    g[i] = g[i] * inv - k * u[r] * v[c];
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, KERNEL, ...)                               \
+  do {                                                               \
+    if ((dtype) == CGAN_F16) hipLaunchKernelGGL(KERNEL<F16>, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<BF16>, __VA_ARGS__);              \
+  } while (0)
+
+extern "C" int cgan_act_bwd(const void* out, const void* dy, void* dx, int32_t dtype, int32_t act, float act_slope,
+                            int64_t numel, void* stream) {
+  CGAN_REQUIRE(out && dy && dx, "act_bwd: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "act_bwd: bad dtype %d", dtype);
+  CGAN_REQUIRE(numel > 0 && (numel % 8) == 0, "act_bwd: numel must be a positive multiple of 8");
+  CGAN_REQUIRE(act >= CGAN_ACT_NONE && act <= CGAN_ACT_SIGMOID, "act_bwd: Unsupported activation: %d", act);
+  const long groups = numel / 8;
+  DISPATCH_T(dtype, act_bwd_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)out,
+             (const uint16_t*)dy, (uint16_t*)dx, act, act_slope, groups);
+  CGAN_CHECK_LAUNCH("act_bwd");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_instnorm_act_bwd_workspace_bytes(const CganNormStatsDesc* d) {
+  if (!d || d->n <= 0 || d->c <= 0) return 0;
+  return (size_t)d->n * cgan_cs(d->c) * 2 * sizeof(float);
+}
+
+extern "C" int cgan_instnorm_act_bwd(const void* out, const void* dy, const float* rstd, void* dx,
+                                     const CganNormStatsDesc* d, int32_t act, float act_slope, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(d && out && dy && rstd && dx && workspace, "instnorm_act_bwd: null pointer");
+  CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "instnorm_act_bwd: bad dtype %d", d->dtype);
+  CGAN_REQUIRE(d->n > 0 && d->hw > 0 && d->c > 0, "instnorm_act_bwd: bad shape");
+  CGAN_REQUIRE(act == CGAN_ACT_NONE || act == CGAN_ACT_LRELU,
+               "instnorm_act_bwd: only invertible activations (none, LeakyReLU) are supported, got %d", act);
+  CGAN_REQUIRE(act != CGAN_ACT_LRELU || act_slope > 0.f, "instnorm_act_bwd: LeakyReLU slope must be > 0");
+  CGAN_REQUIRE(workspace_bytes >= cgan_instnorm_act_bwd_workspace_bytes(d), "instnorm_act_bwd: workspace too small");
+  const int cs = cgan_cs(d->c);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, cgan_instnorm_act_bwd_workspace_bytes(d), s);
+  if (e != hipSuccess) {
+    cgan_set_error("instnorm_act_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CGAN_ERR_HIP;
+  }
+  const int cg_total = cs / 8;
+  const int cgb = cg_total < 256 ? cg_total : 256;
+  const int PL = 256 / cgb;
+  // pixels per block: enough blocks to fill the chip, at least 4 pixels per pixel lane
+  int chunks = ceil_div(2048, d->n * ceil_div(cg_total, cgb));
+  int ppb = ceil_div(d->hw, chunks < 1 ? 1 : chunks);
+  if (ppb < 4 * PL) ppb = 4 * PL;
+  chunks = ceil_div(d->hw, ppb);
+  const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
+  DISPATCH_T(d->dtype, in_bwd_reduce_kernel, dim3(chunks, ceil_div(cg_total, cgb), d->n), dim3(256), smem, s,
+             (const uint16_t*)out, (const uint16_t*)dy, (float*)workspace, d->hw, cs, ppb, act, act_slope);
+  const long groups = (long)d->n * d->hw * cg_total;
+  DISPATCH_T(d->dtype, in_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)out,
+             (const uint16_t*)dy, rstd, (const float*)workspace, (uint16_t*)dx, d->hw, cs, d->c, act, act_slope, groups);
+  CGAN_CHECK_LAUNCH("instnorm_act_bwd");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_bce_logits_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float target, float weight,
+                                    float* loss_accum, void* dx, void* stream) {
+  CGAN_REQUIRE(x && loss_accum, "bce_logits: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "bce_logits: bad dtype %d", dtype);
+  CGAN_REQUIRE(npix > 0 && c > 0, "bce_logits: bad shape");
+  const int cs = cgan_cs(c);
+  const long groups = npix * (cs / 8);
+  DISPATCH_T(dtype, bce_logits_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+             target, weight, loss_accum, (uint16_t*)dx, cs, c, groups);
+  CGAN_CHECK_LAUNCH("bce_logits");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t numel, float weight, float* loss_accum,
+                            void* da, void* stream) {
+  CGAN_REQUIRE(a && b && loss_accum, "l1: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "l1: bad dtype %d", dtype);
+  CGAN_REQUIRE(numel > 0 && (numel % 8) == 0, "l1: numel must be a positive multiple of 8");
+  const long groups = numel / 8;
+  DISPATCH_T(dtype, l1_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+             (const uint16_t*)b, weight, loss_accum, (uint16_t*)da, groups);
+  CGAN_CHECK_LAUNCH("l1");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_spectral_norm_bwd(float* grad_w, const float* w_bar, const float* u, const float* v,
+                                      const float* sigma, int32_t rows, int32_t cols, float* workspace_scalar,
+                                      void* stream) {
+  CGAN_REQUIRE(grad_w && w_bar && u && v && sigma && workspace_scalar, "spectral_norm_bwd: null pointer");
+  CGAN_REQUIRE(rows > 0 && cols > 0, "spectral_norm_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace_scalar, 0, sizeof(float), s);
+  if (e != hipSuccess) {
+    cgan_set_error("spectral_norm_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CGAN_ERR_HIP;
+  }
+  const long numel = (long)rows * cols;
+  int g = grid_for_n(numel);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(g), dim3(256), 0, s, (const float*)grad_w, w_bar, workspace_scalar, numel);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(grid_for_n(numel)), dim3(256), 0, s, grad_w, u, v, sigma,
+                     (const float*)workspace_scalar, cols, numel);
+  CGAN_CHECK_LAUNCH("spectral_norm_bwd");
+  return CGAN_OK;
+}

@@ -362,6 +362,65 @@ def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2) -> NHWC:
     return NHWC(y, x.c)
 
 
+# ------------------------------------------------------------------------------------------------ training path
+def act_bwd(out: NHWC, dy: NHWC, act, slope=0.2) -> NHWC:
+    """dx = dy * act'(.) with the derivative taken from the activation's output."""
+    _need_cuda(out.t, dy.t)
+    dx = torch.empty_like(out.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_act_bwd(_ptr(out.t), _ptr(dy.t), _ptr(dx), out.dtype_id, act, slope, out.t.numel(), _stream()),
+               "cgan_act_bwd")
+    return NHWC(dx, out.c)
+
+
+def instnorm_act_bwd(out: NHWC, dy: NHWC, rstd: torch.Tensor, act=ACT_NONE, slope=0.2) -> NHWC:
+    """Backward of out = act(instance_norm(x)) given out, dy and the forward's rstd (act none or LeakyReLU)."""
+    _need_cuda(out.t, dy.t, rstd)
+    d = NormStatsDesc(out.dtype_id, out.n, out.h * out.w, out.c, 0.0)
+    lib = _lib.load()
+    nbytes = lib.cgan_instnorm_act_bwd_workspace_bytes(C.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=out.t.device)
+    dx = torch.empty_like(out.t)
+    _lib.check(lib.cgan_instnorm_act_bwd(_ptr(out.t), _ptr(dy.t), _ptr(rstd), _ptr(dx), C.byref(d), act, slope,
+                                         _ptr(ws), nbytes, _stream()), "cgan_instnorm_act_bwd")
+    return NHWC(dx, out.c)
+
+
+def bce_logits(x: NHWC, target: float, weight: float, loss_accum: torch.Tensor, want_grad=True):
+    """loss_accum += weight * sum BCEWithLogits(x, target) over x's logical channels; returns d(loss)/dx or None."""
+    _need_cuda(x.t, loss_accum)
+    dx = torch.empty_like(x.t) if want_grad else None
+    lib = _lib.load()
+    _lib.check(lib.cgan_bce_logits_nhwc(_ptr(x.t), x.dtype_id, x.n * x.h * x.w, x.c, float(target), float(weight),
+                                        _ptr(loss_accum), _ptr(dx), _stream()), "cgan_bce_logits_nhwc")
+    return NHWC(dx, x.c) if want_grad else None
+
+
+def l1_loss(a: NHWC, b: NHWC, weight: float, loss_accum: torch.Tensor, want_grad=True):
+    """loss_accum += weight * sum|a - b|; returns d(loss)/da or None."""
+    _need_cuda(a.t, b.t, loss_accum)
+    if a.t.shape != b.t.shape:
+        raise RuntimeError("l1_loss: shape mismatch")
+    da = torch.empty_like(a.t) if want_grad else None
+    lib = _lib.load()
+    _lib.check(lib.cgan_l1_nhwc(_ptr(a.t), _ptr(b.t), a.dtype_id, a.t.numel(), float(weight), _ptr(loss_accum),
+                                _ptr(da), _stream()), "cgan_l1_nhwc")
+    return NHWC(da, a.c) if want_grad else None
+
+
+def spectral_norm_bwd(grad_w: torch.Tensor, w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
+                      sigma: torch.Tensor) -> torch.Tensor:
+    """In place: gradient w.r.t. w = w_bar / sigma  ->  gradient w.r.t. w_bar (u, v constants)."""
+    _need_cuda(grad_w, w_bar, u, v, sigma)
+    rows = w_bar.shape[0]
+    cols = w_bar.numel() // rows
+    scratch = torch.empty(1, dtype=torch.float32, device=grad_w.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_spectral_norm_bwd(_ptr(grad_w), _ptr(w_bar), _ptr(u), _ptr(v), _ptr(sigma), rows, cols,
+                                          _ptr(scratch), _stream()), "cgan_spectral_norm_bwd")
+    return grad_w
+
+
 @dataclass
 class PackedSpade:
     buf: torch.Tensor

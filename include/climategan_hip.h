@@ -246,6 +246,34 @@ int cgan_fold_bn(const float* w, const float* bias, const float* gamma, const fl
                  const float* var, float eps, float* w_out, float* b_out, int32_t c_out, int64_t per_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training path: backward of the elementwise / norm layers, losses with their gradients, spectral-norm gradient.
+ * Loss entry points ACCUMULATE `weight * sum(...)` into a device fp32 scalar (zero it first; weight carries the
+ * 1/N of the mean and any lambda) and write the gradient of that accumulated term.
+ * ------------------------------------------------------------------------------------------------ */
+/* dx = dy * act'(.) with act' expressed through the activation's OUTPUT `out` (nn.LeakyReLU / ReLU / tanh / sigmoid) */
+int cgan_act_bwd(const void* out, const void* dy, void* dx, int32_t dtype, int32_t act, float act_slope,
+                 int64_t numel, void* stream);
+/* backward of out = act(instance_norm(x)) (climategan/discriminator.py:113-154: InstanceNorm2d + LeakyReLU(0.2)):
+ * dx = rstd * (dz - mean_hw(dz) - y * mean_hw(dz * y)), dz = dy * act'(out), y = act^-1(out); act none or LeakyReLU.
+ * workspace: cgan_instnorm_act_bwd_workspace_bytes(d) device bytes. */
+size_t cgan_instnorm_act_bwd_workspace_bytes(const CganNormStatsDesc* d);
+int cgan_instnorm_act_bwd(const void* out, const void* dy, const float* rstd, void* dx, const CganNormStatsDesc* d,
+                          int32_t act, float act_slope, void* workspace, size_t workspace_bytes, void* stream);
+/* nn.BCEWithLogitsLoss(x, target) pieces against a constant target (GANLoss, climategan/losses.py:50-83; ADVENT
+ * D-side BCE, losses.py:461-477) over the c logical channels of x [npix][cgan_cs(c)]:
+ * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */
+int cgan_bce_logits_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float target, float weight,
+                         float* loss_accum, void* dx, void* stream);
+/* nn.L1Loss pieces (FeatMatchLoss, climategan/losses.py:86-103): *loss_accum += weight * sum|a - b|,
+ * da = weight * sign(a - b); da may be NULL. */
+int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t numel, float weight, float* loss_accum, void* da,
+                 void* stream);
+/* spectral norm backward (autograd of climategan/norms.py:107-112, u and v constants): in place
+ * grad_w <- grad_w / sigma - (<grad_w, w_bar> / sigma^2) u v^T; workspace_scalar: one device float. */
+int cgan_spectral_norm_bwd(float* grad_w, const float* w_bar, const float* u, const float* v, const float* sigma,
+                           int32_t rows, int32_t cols, float* workspace_scalar, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Output post-ops of the inference harness (Trainer.infer_all, climategan/trainer.py:311-332)
  * ------------------------------------------------------------------------------------------------ */
 /* tutils.normalize (climategan/tutils.py:567-576) per image over (C,H,W), then `(t * 255).astype(uint8)` (truncation)

@@ -101,3 +101,85 @@ def test_backward_refuses_reflect_and_upsample():
     d = ops._conv_desc(_lib.CGAN_F16, 1, 8, 8, 8, 8, 3, 3, 1, 1, 1, _lib.PAD_REFLECT)
     assert lib.cgan_conv2d_dgrad_packed_weight_bytes(C.byref(d)) == 0
     assert b"zero padding" in lib.cgan_last_error()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,h,w,act", [(64, 20, 24, "lrelu"), (20, 33, 17, "none"), (512, 9, 9, "lrelu")])
+def test_instnorm_act_backward(dt, c, h, w, act):
+    from climategan_amd import ops
+    B = 2
+    x = q(fill.uniform((B, c, h, w), 3100 + c, -2, 2), dt).requires_grad_(True)
+    y = F.instance_norm(x, eps=1e-5)
+    out = F.leaky_relu(y, 0.2) if act == "lrelu" else y
+    dy = q(fill.uniform((B, c, h, w), 3200 + c), dt)
+    out.backward(dy)
+    a = ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE
+    xg = to_nhwc(x.detach(), dt)
+    mean, rstd = ops.instnorm_stats(xg)
+    outg = ops.norm_act_apply(xg, mean, rstd, act=a)
+    dx = ops.instnorm_act_bwd(outg, to_nhwc(dy, dt), rstd, act=a)
+    # the kernel recovers y from the 16-bit output: allow twice the forward-op tolerance
+    assert rel_err(back(dx), x.grad) <= 2 * TOL[dt]
+    if ops.cs8(c) != c:
+        assert dx.t[..., c:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("act", ["relu", "lrelu", "tanh", "sigmoid"])
+def test_act_backward(dt, act):
+    from climategan_amd import ops
+    x = q(fill.uniform((2, 24, 9, 11), 3300, -2, 2), dt).requires_grad_(True)
+    f = {"relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    a = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH, "sigmoid": ops.ACT_SIGMOID}[act]
+    out = f(x)
+    dy = q(fill.uniform((2, 24, 9, 11), 3301), dt)
+    out.backward(dy)
+    outq = q(out.detach().numpy(), dt)
+    dx = ops.act_bwd(to_nhwc(outq, dt), to_nhwc(dy, dt), a)
+    assert rel_err(back(dx), x.grad) <= 4 * TOL[dt]     # derivative evaluated at the 16-bit-rounded output
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("target", [1.0, 0.0, 0.87])
+def test_bce_logits_loss_and_grad(dt, target):
+    from climategan_amd import ops
+    x = q(fill.uniform((2, 1, 19, 23), 3400, -4, 4), dt).requires_grad_(True)
+    loss = F.binary_cross_entropy_with_logits(x, torch.full_like(x, target))
+    (loss * 0.5).backward()
+    acc = torch.zeros(1, device="cuda")
+    n = x.numel()
+    dx = ops.bce_logits(to_nhwc(x.detach(), dt), target, 0.5 / n, acc)
+    assert abs(acc.item() - 0.5 * loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))
+    got = back(dx)
+    assert rel_err(got, x.grad) <= TOL[dt]
+    assert dx.t[..., 1:].abs().max().item() == 0
+    ops.bce_logits(to_nhwc(x.detach(), dt), target, 0.5 / n, acc, want_grad=False)      # accumulates
+    assert abs(acc.item() - loss.item()) <= 2e-5 * max(1.0, abs(loss.item()))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_l1_loss_and_grad(dt):
+    from climategan_amd import ops
+    a = q(fill.uniform((2, 16, 9, 7), 3500), dt).requires_grad_(True)
+    b = q(fill.uniform((2, 16, 9, 7), 3501), dt)
+    b[0, 0, 0, 0] = a.detach()[0, 0, 0, 0]                     # sign(0) = 0
+    loss = F.l1_loss(a, b) * 10.0 / 3
+    loss.backward()
+    acc = torch.zeros(1, device="cuda")
+    da = ops.l1_loss(to_nhwc(a.detach(), dt), to_nhwc(b, dt), 10.0 / 3 / a.numel(), acc)
+    assert abs(acc.item() - loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))
+    assert rel_err(back(da), a.grad) <= TOL[dt]
+
+
+def test_spectral_norm_backward():
+    """Gradient w.r.t. w_bar of L(w_bar / sigma), sigma = u^T w_bar v with u, v constants (norms.py:107-112)."""
+    from climategan_amd import ops
+    rows, cols = 24, 16 * 9
+    w_bar = torch.from_numpy(fill.uniform((rows, cols), 3600)).requires_grad_(True)
+    u = torch.from_numpy(fill.uniform((rows,), 3601))
+    v = torch.from_numpy(fill.uniform((cols,), 3602))
+    g = torch.from_numpy(fill.uniform((rows, cols), 3603))
+    sigma = u.dot(w_bar.mv(v))
+    ((w_bar / sigma) * g).sum().backward()
+    got = ops.spectral_norm_bwd(g.clone().cuda(), w_bar.detach().cuda(), u.cuda(), v.cuda(), sigma.detach().reshape(1).cuda())
+    assert rel_err(got.cpu(), w_bar.grad) <= 1e-5
