@@ -1,0 +1,107 @@
+"""torch.autograd plumbing of the training path: every Function's forward AND backward is a set of HIP kernels behind
+the C ABI (``ops``); torch only records the graph, routes 16-bit NHWC gradient tensors between Functions and
+accumulates the fp32 parameter gradients into ``.grad`` (what ``g_loss.backward()`` / ``d_loss.backward()`` do in the
+reference, trainer.py:1011,1028).
+
+Activations travel as raw 16-bit NHWC tensors ``[N,H,W,Cs]`` (the ``t`` of an ``ops.NHWC``) because autograd tracks
+tensors, with the logical channel count passed alongside.
+"""
+import torch
+
+from . import ops
+
+
+class ConvFn(torch.autograd.Function):
+    """y = act(conv(x, w[/sigma]) + b).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under spectral norm, in
+    which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped back through
+    ``w_bar / sigma``, reference norms.py:107-112)."""
+
+    @staticmethod
+    def forward(ctx, x_t, weight, bias, packed, cfg, sn):
+        x = ops.NHWC(x_t, cfg["c_in"])
+        y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"], act=cfg["act"],
+                       slope=cfg["slope"])
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.sn = None if sn is None else tuple(t.clone() for t in sn)      # (sigma, u, v) as used in this forward
+        ctx.save_for_backward(x_t, weight, y.t if cfg["act"] != ops.ACT_NONE else None)
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        cfg = ctx.cfg
+        x_t, weight, y_t = ctx.saved_tensors
+        c_out = weight.shape[0]
+        dy = ops.NHWC(dy_t.contiguous(), c_out)
+        if y_t is not None:
+            dy = ops.act_bwd(ops.NHWC(y_t, c_out), dy, cfg["act"], cfg["slope"])
+        sigma = ctx.sn[0] if ctx.sn is not None else None
+        dx_t = None
+        if ctx.needs_input_grad[0]:
+            dx_t = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], x_t.shape[1], x_t.shape[2]), stride=cfg["stride"],
+                                       pad=cfg["pad"], dilation=cfg["dilation"], sigma=sigma).t
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"],
+                                           pad=cfg["pad"], dilation=cfg["dilation"], want_bias=ctx.has_bias)
+            if ctx.sn is not None:
+                dw = ops.spectral_norm_bwd(dw, weight.detach(), ctx.sn[1], ctx.sn[2], ctx.sn[0])
+        return dx_t, dw, db, None, None, None
+
+
+class InstNormActFn(torch.autograd.Function):
+    """out = act(instance_norm(x)) (affine-free, biased variance; act none or LeakyReLU)."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, eps, act, slope):
+        x = ops.NHWC(x_t, c)
+        mean, rstd = ops.instnorm_stats(x, eps=eps)
+        out = ops.norm_act_apply(x, mean, rstd, act=act, slope=slope)
+        ctx.c, ctx.act, ctx.slope = c, act, slope
+        ctx.save_for_backward(out.t, rstd)
+        return out.t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        out_t, rstd = ctx.saved_tensors
+        dx = ops.instnorm_act_bwd(ops.NHWC(out_t, ctx.c), ops.NHWC(dy_t.contiguous(), ctx.c), rstd, act=ctx.act,
+                                  slope=ctx.slope)
+        return dx.t, None, None, None, None
+
+
+class BceLogitsFn(torch.autograd.Function):
+    """weight * sum BCEWithLogits(x, target) over the logical channels -> fp32 device scalar."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, target, weight):
+        ctx.c = c
+        acc = torch.zeros(1, dtype=torch.float32, device=x_t.device)
+        dx = ops.bce_logits(ops.NHWC(x_t, c), target, weight, acc, want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(dx.t if dx is not None else None)
+        return acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx_t,) = ctx.saved_tensors
+        if dx_t is None:
+            return None, None, None, None
+        return ops.scale_by_scalar(ops.NHWC(dx_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None
+
+
+class L1Fn(torch.autograd.Function):
+    """weight * sum |a - b| (b is a constant, as FeatMatchLoss detaches the real features, losses.py:99-101)."""
+
+    @staticmethod
+    def forward(ctx, a_t, b_t, c, weight):
+        ctx.c = c
+        acc = torch.zeros(1, dtype=torch.float32, device=a_t.device)
+        da = ops.l1_loss(ops.NHWC(a_t, c), ops.NHWC(b_t, c), weight, acc, want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(da.t if da is not None else None)
+        return acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (da_t,) = ctx.saved_tensors
+        if da_t is None:
+            return None, None, None, None
+        return ops.scale_by_scalar(ops.NHWC(da_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None

@@ -273,21 +273,22 @@ __global__ void copy_channels_kernel(const uint16_t* __restrict__ src, uint16_t*
 }
 
 // y = op(a, b): 0 = a * b (DADA feature fusion z * z_depth, reference deeplab_v3.py:253-254, blocks.py:304-305),
-// 1 = sigmoid(a) (generator.py:277)
+// 1 = sigmoid(a) (generator.py:277); 2 = a * s with s a device fp32 scalar (chain rule through a scalar loss weight)
 template <typename T>
 __global__ void eltwise_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
                                int op, long total_groups) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_groups; idx += (long)gridDim.x * blockDim.x) {
     u32x4 va = reinterpret_cast<const u32x4*>(a)[idx];
     u32x4 vb = op == 0 ? reinterpret_cast<const u32x4*>(b)[idx] : va;
+    const float sc = op == 2 ? reinterpret_cast<const float*>(b)[0] : 1.f;   // op 2: b is a device fp32 scalar
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float a0, a1, b0, b1;
       unpack2<T>(va[e], a0, a1);
       unpack2<T>(vb[e], b0, b1);
-      float r0 = op == 0 ? a0 * b0 : 1.f / (1.f + __expf(-a0));
-      float r1 = op == 0 ? a1 * b1 : 1.f / (1.f + __expf(-a1));
+      float r0 = op == 0 ? a0 * b0 : (op == 2 ? a0 * sc : 1.f / (1.f + __expf(-a0)));
+      float r1 = op == 0 ? a1 * b1 : (op == 2 ? a1 * sc : 1.f / (1.f + __expf(-a1)));
       o[e] = pack2<T>(r0, r1);
     }
     reinterpret_cast<u32x4*>(y)[idx] = o;
@@ -473,7 +474,7 @@ extern "C" int cgan_eltwise_nhwc(const void* a, const void* b, void* y, int32_t 
                                  void* stream) {
   CGAN_REQUIRE(a && y && (op == 1 || b), "eltwise: null pointer");
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "eltwise: bad dtype %d", dtype);
-  CGAN_REQUIRE(op == 0 || op == 1, "eltwise: unknown op %d", op);
+  CGAN_REQUIRE(op >= 0 && op <= 2, "eltwise: unknown op %d", op);
   CGAN_REQUIRE(numel > 0 && (numel % 8) == 0, "eltwise: numel must be a positive multiple of 8");
   long groups = numel / 8;
   hipStream_t s = (hipStream_t)stream;

@@ -5,7 +5,8 @@ Same class names, constructor arguments, child-module names and state-dict keys 
 (``p.discriminator_{i}.model{j}.0.module.{bias,weight_u,weight_v,weight_bar}``, ``{m,s}.Advent.{0,2,4,6,8}.module.*``),
 forward in HIP: NHWC 16-bit activations, 4x4 stride-2 / stride-1 MFMA convs with the LeakyReLU fused into the conv
 epilogue where no norm sits in between, instance-norm statistics + fused normalise/LeakyReLU otherwise, 3x3/s2
-average pool between scales.  Forward only (see norms._grad_guard).
+average pool between scales.  Under autograd the same modules record ``autograd.ConvFn`` / ``InstNormActFn`` nodes whose
+backward is HIP as well (conv data / weight gradients, instance-norm + LeakyReLU backward, spectral-norm gradient).
 """
 import functools
 
@@ -13,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .norms import DEFAULT_COMPUTE_DTYPE, SpectralNorm, _grad_guard, spectral_norm_step_all
+from .norms import DEFAULT_COMPUTE_DTYPE, SpectralNorm, needs_grad, spectral_norm_step_all
 
 
 def create_discriminator(opts, device, no_init=False, verbose=0):
@@ -48,6 +49,16 @@ def _is_instance_norm(norm_layer):
     return f == nn.InstanceNorm2d
 
 
+def _to_nchw(o: ops.NHWC, module, dtype=None):
+    """NCHW fp32 view of a feature map for callers that want the reference's tensors.  The layout kernel has no
+    backward: under autograd ask for ``nhwc=True`` and feed the maps to ``climategan_amd.losses``."""
+    if needs_grad(module, o.t):
+        raise NotImplementedError("climategan_amd discriminators: under autograd call D(x, nhwc=True) and use "
+                                  "climategan_amd.losses (the NHWC -> NCHW layout pass has no backward kernel)")
+    y = ops.nhwc_to_nchw(o)
+    return y if dtype is None else y.to(dtype)
+
+
 class NLayerDiscriminator(nn.Module):
     """PatchGAN (reference discriminator.py:82-182): model0 = SN-conv4x4s2 + LReLU; model1..n-1 = SN-conv4x4s2 +
     norm + LReLU; model_n = SN-conv4x4s1 + norm + LReLU; model_{n+1} = SN-conv4x4s1 -> 1 channel."""
@@ -75,6 +86,7 @@ class NLayerDiscriminator(nn.Module):
                                         bias=use_bias)), norm_layer(ndf * nf_mult), nn.LeakyReLU(0.2, True)]]
         seq += [[SpectralNorm(nn.Conv2d(ndf * nf_mult, 1, kernel_size=kw, stride=1, padding=padw))]]
         for n, mods in enumerate(seq):
+            mods[0].trainable = True
             self.add_module("model" + str(n), nn.Sequential(*mods))
 
     def forward_nhwc(self, x: ops.NHWC):
@@ -88,15 +100,20 @@ class NLayerDiscriminator(nn.Module):
             fuse_act = (len(sub) == 2)  # conv + LeakyReLU with no norm in between
             y = sub[0](y, act=ops.ACT_LRELU if fuse_act else ops.ACT_NONE, slope=0.2)
             if has_norm:
-                mean, rstd = ops.instnorm_stats(y, eps=sub[1].eps)
-                y = ops.norm_act_apply(y, mean, rstd, act=ops.ACT_LRELU, slope=0.2)
+                if needs_grad(self, y.t):
+                    from .autograd import InstNormActFn
+                    y = ops.NHWC(InstNormActFn.apply(y.t, y.c, sub[1].eps, ops.ACT_LRELU, 0.2), y.c)
+                else:
+                    mean, rstd = ops.instnorm_stats(y, eps=sub[1].eps)
+                    y = ops.norm_act_apply(y, mean, rstd, act=ops.ACT_LRELU, slope=0.2)
             outs.append(y)
         return outs
 
-    def forward(self, input):
-        _grad_guard(self)
+    def forward(self, input, nhwc=False):
         x = input if isinstance(input, ops.NHWC) else ops.nchw_to_nhwc(input, DEFAULT_COMPUTE_DTYPE)
-        outs = [ops.nhwc_to_nchw(o) for o in self.forward_nhwc(x)]
+        outs = self.forward_nhwc(x)
+        if not nhwc:
+            outs = [_to_nchw(o, self) for o in outs]
         return outs if self.get_intermediate_features else outs[-1]
 
 
@@ -115,16 +132,28 @@ class MultiscaleDiscriminator(nn.Module):
                 get_intermediate_features=get_intermediate_features))
         self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
 
-    def forward(self, input):
-        _grad_guard(self)
+    def forward(self, input, nhwc=False):
+        """``nhwc=False``: the reference's list[num_D] of list[n_layers+2] NCHW tensors (no-grad callers);
+        ``nhwc=True``: the same structure of ``ops.NHWC`` maps, differentiable (training path)."""
         spectral_norm_step_all(self, self.compute_dtype)      # all 6*num_D power iterations + packs, batched
-        x = ops.nchw_to_nhwc(input, self.compute_dtype)
+        if isinstance(input, ops.NHWC):
+            x = input
+        else:
+            if torch.is_grad_enabled() and input.requires_grad:
+                raise NotImplementedError("MultiscaleDiscriminator: a gradient w.r.t. an NCHW input needs the layout "
+                                          "backward (not built); pass an ops.NHWC input")
+            x = ops.nchw_to_nhwc(input, self.compute_dtype)
         result = []
         for i in range(self.num_D):
             D = getattr(self, "discriminator_%d" % i)
-            outs = [ops.nhwc_to_nchw(o).to(input.dtype) for o in D.forward_nhwc(x)]
+            outs = D.forward_nhwc(x)
+            if not nhwc:
+                outs = [_to_nchw(o, self, input.dtype if torch.is_tensor(input) else None) for o in outs]
             result.append(outs if self.get_intermediate_features else [outs[-1]])
             if i + 1 < self.num_D:
+                if torch.is_grad_enabled() and x.t.requires_grad:
+                    raise NotImplementedError("MultiscaleDiscriminator: average-pool backward is not built yet "
+                                              "(needed only for gradients w.r.t. the input image)")
                 x = ops.avgpool3x3s2(x)
         return result
 
@@ -146,16 +175,20 @@ class FCDiscriminator(nn.Sequential):
         self.compute_dtype = DEFAULT_COMPUTE_DTYPE
         self._caches = {}
 
-    def forward(self, input):
+    def forward(self, input, nhwc=False):
         from .norms import _PackCache, conv_forward
 
-        _grad_guard(self)
         spectral_norm_step_all(self, self.compute_dtype)
-        y = ops.nchw_to_nhwc(input, self.compute_dtype)
+        y = input if isinstance(input, ops.NHWC) else ops.nchw_to_nhwc(input, self.compute_dtype)
         for i, idx in enumerate((0, 2, 4, 6, 8)):
             cache = self._caches.setdefault(idx, _PackCache())
-            y = conv_forward(self[idx], cache, y, act=ops.ACT_LRELU if i < 4 else ops.ACT_NONE, slope=0.2)
-        return ops.nhwc_to_nchw(y).to(input.dtype)
+            if isinstance(self[idx], SpectralNorm):
+                self[idx].trainable = True
+                y = conv_forward(self[idx], cache, y, act=ops.ACT_LRELU if i < 4 else ops.ACT_NONE, slope=0.2)
+            else:
+                y = conv_forward(self[idx], cache, y, act=ops.ACT_LRELU if i < 4 else ops.ACT_NONE, slope=0.2,
+                                 trainable=True)
+        return y if nhwc else _to_nchw(y, self, input.dtype if torch.is_tensor(input) else None)
 
 
 def get_fc_discriminator(num_classes=2, ndf=64, use_norm=False):

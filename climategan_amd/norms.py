@@ -24,6 +24,28 @@ def _grad_guard(module: nn.Module):
             "torch.no_grad() (the reference's infer_all does, trainer.py:217) or set requires_grad=False")
 
 
+def needs_grad(module: nn.Module, *tensors) -> bool:
+    """True when this call must be recorded for autograd (grad mode on and a parameter or an input wants a gradient)."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
+
+
+def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw) -> ops.NHWC:
+    """Differentiable conv (autograd.ConvFn).  Options without a backward kernel raise."""
+    from .autograd import ConvFn
+
+    bad = [k for k in ("residual", "in_upsample", "residual_upsample") if kw.get(k)]
+    if kw.get("pad_mode", ops.PAD_ZERO) != ops.PAD_ZERO:
+        bad.append("pad_mode=reflect")
+    if bad:
+        raise NotImplementedError("climategan_amd: conv options %s have no backward kernel yet (training path)" % bad)
+    cfg = dict(c_in=x.c, stride=stride, pad=pad, dilation=dilation, act=kw.get("act", ops.ACT_NONE),
+               slope=kw.get("slope", 0.2))
+    y_t = ConvFn.apply(x.t, weight, bias, packed, cfg, sn)
+    return ops.NHWC(y_t, weight.shape[0])
+
+
 class _PackCache:
     """Re-pack fp32 parameters into MFMA fragment order only when they change."""
 
@@ -85,13 +107,22 @@ class SpectralNorm(nn.Module):
         u = getattr(m, self.name + "_u")
         v = getattr(m, self.name + "_v")
         sigma = ops.spectral_norm_power_iter(w_bar.data, u.data, v.data)
+        self._sigma = sigma
         return ops.pack_conv_weight(w_bar.data, m.bias.data if m.bias is not None else None, dtype, sigma)
 
+    _sigma = None       # device scalar of the latest power iteration (needed by the backward of w_bar / sigma)
+    trainable = False   # set by modules whose whole forward has backward kernels (the discriminators)
+
     def forward(self, x, **conv_kwargs):
-        _grad_guard(self)
         m = self.module
+        if not self.trainable:
+            _grad_guard(self)
         pw = self.packed(x.t.dtype)
         pad = conv_kwargs.pop("pad", m.padding[0])   # Conv2dBlock pads with a separate module (padding=0 on the conv)
+        if self.trainable and needs_grad(self, x.t):
+            sn = (self._sigma, getattr(m, self.name + "_u").data, getattr(m, self.name + "_v").data)
+            return _conv_train(x, getattr(m, self.name + "_bar"), m.bias, pw, sn, m.stride[0], pad, m.dilation[0],
+                               conv_kwargs)
         return ops.conv2d(x, pw, stride=m.stride[0], pad=pad, dilation=m.dilation[0], **conv_kwargs)
 
 
@@ -114,10 +145,14 @@ def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.N
     """Run a plain ``nn.Conv2d`` (weights cached in packed form) or a ``SpectralNorm`` wrapper on NHWC input."""
     if isinstance(conv, SpectralNorm):
         return conv(x, **kw)
-    _grad_guard(conv)
+    trainable = kw.pop("trainable", False)
+    if not trainable:
+        _grad_guard(conv)
     pw = cache.get((conv.weight, conv.bias), x.t.dtype,
                    lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None,
                                                 x.t.dtype))
+    if trainable and needs_grad(conv, x.t):
+        return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], conv.padding[0], conv.dilation[0], kw)
     return ops.conv2d(x, pw, stride=conv.stride[0], pad=conv.padding[0], dilation=conv.dilation[0], **kw)
 
 
@@ -209,5 +244,6 @@ def spectral_norm_step_all(root: nn.Module, dtype) -> None:
     if grp is None or not grp.matches(params, dtype):
         grp = ops.SpectralNormGroup(params, dtype)
         object.__setattr__(root, "_sn_group", grp)
-    for m, pk in zip(sns, grp.step()):
+    for i, (m, pk) in enumerate(zip(sns, grp.step())):
         m._prepacked = pk
+        m._sigma = grp.sigma[i:i + 1]

@@ -185,6 +185,18 @@ def sigmoid(a: NHWC) -> NHWC:
     return NHWC(y, a.c)
 
 
+def scale_by_scalar(a: NHWC, s: torch.Tensor) -> NHWC:
+    """a * s with s a device fp32 scalar tensor (no host sync)."""
+    _need_cuda(a.t, s)
+    if s.dtype != torch.float32 or s.numel() != 1:
+        raise RuntimeError("scale_by_scalar: one fp32 device scalar expected")
+    y = torch.empty_like(a.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_eltwise_nhwc(_ptr(a.t), _ptr(s), _ptr(y), a.dtype_id, 2, a.t.numel(), _stream()),
+               "cgan_eltwise_nhwc")
+    return NHWC(y, a.c)
+
+
 def fold_bn(w: torch.Tensor, bias, bn_weight, bn_bias, running_mean, running_var, eps: float):
     """Eval-mode BatchNorm folded into the preceding conv: returns (w', b') fp32 device tensors."""
     _need_cuda(w, bias, bn_weight, bn_bias, running_mean, running_var)

@@ -238,7 +238,8 @@ int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, int32_t n, i
 int cgan_copy_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t cs_dst,
                             int32_t c_off, void* stream);
 /* elementwise on NHWC storage: op 0: y = a * b (DADA fusion z * z_depth, deeplab_v3.py:253-254); op 1: y = sigmoid(a)
- * (climategan/generator.py:277) */
+ * (climategan/generator.py:277); op 2: y = a * s, b pointing at ONE device fp32 scalar s (gradient of a loss term
+ * times the upstream scalar gradient, e.g. the lambdas of climategan/trainer.py:1369-1380) */
 int cgan_eltwise_nhwc(const void* a, const void* b, void* y, int32_t dtype, int32_t op, int64_t numel, void* stream);
 /* fold an eval-mode BatchNorm2d into the preceding conv (fp32 weights [c_out][per_out]): w' = w s, b' = (b - mean) s + beta,
  * s = gamma / sqrt(var + eps)  (same algebra as climategan/bn_fusion.py:121-132) */

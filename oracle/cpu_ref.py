@@ -38,10 +38,11 @@ def spectral_norm_step(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tensor, po
     """
     h = w_bar.shape[0]
     wm = w_bar.reshape(h, -1)
+    wd = wm.detach()                       # the reference iterates on ``.data`` (norms.py:103-106): no graph
     for _ in range(power_iterations):
-        v = l2normalize(torch.mv(wm.t(), u))
-        u = l2normalize(torch.mv(wm, v))
-    sigma = u.dot(wm.mv(v))
+        v = l2normalize(torch.mv(wd.t(), u))
+        u = l2normalize(torch.mv(wd, v))
+    sigma = u.dot(wm.mv(v))                # autograd reaches w_bar here and in w_bar / sigma only (norms.py:107-112)
     return w_bar / sigma, u, v, sigma
 
 
@@ -448,3 +449,35 @@ def infer_all_flood(sd: SD, x: torch.Tensor, n_up: int, bin_value: float = -1, s
     flood = compute_flood(sd, x, mk["m"], z_h, z_w, bin_value)
     return {"flood": flood, "flood_u8": to_uint8_hwc(flood), "m": mk["m"], "d": mk["d"], "s": mk["s"],
             "mask_u8": ((mk["m"] > bin_value) * 255).numpy().astype("uint8")}
+
+
+# --------------------------------------------------------------------------------------------------
+# Training: Painter discriminator update (climategan/trainer.py:1073-1107) with GANLoss (losses.py:13-83)
+# --------------------------------------------------------------------------------------------------
+def gan_loss(preds, target_is_real: bool, real_label=1.0, fake_label=0.0) -> torch.Tensor:
+    """``GANLoss.__call__`` with use_lsgan=False, soft_shift=0, flip_prob=0: mean over scales of
+    BCEWithLogits(pred_i[-1], target)."""
+    loss = 0
+    for p in preds:
+        p = p[-1] if isinstance(p, (list, tuple)) else p
+        t = torch.full_like(p, real_label if target_is_real else fake_label)
+        loss = loss + F.binary_cross_entropy_with_logits(p, t)
+    return loss / len(preds)
+
+
+def painter_d_step(sd_d: SD, m: torch.Tensor, x: torch.Tensor, fake: torch.Tensor, num_D: int, n_layers: int):
+    """D-side painter loss and parameter gradients: D(cat_batch[cat_ch(m, x), cat_ch(m, fake)]) -> divide ->
+    GANLoss(fake, False) + GANLoss(real, True); returns (loss, {key: grad}).  ``sd_d`` holds D["p"]'s tensors."""
+    params = {k: v.clone().requires_grad_(k.endswith("weight_bar") or k.endswith("bias")) for k, v in sd_d.items()}
+    real_cat = torch.cat([m, x], dim=1)
+    fake_cat = torch.cat([m, fake], dim=1)
+    out = multiscale_discriminator(torch.cat([real_cat, fake_cat], dim=0), params, num_D, n_layers)
+    real_d = [[t[: t.size(0) // 2] for t in p] for p in out]
+    fake_d = [[t[t.size(0) // 2:] for t in p] for p in out]
+    loss = gan_loss(fake_d, False) + gan_loss(real_d, True)
+    keys = [k for k, v in params.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [params[k] for k in keys])
+    for k in sd_d:                                    # power-iterated u / v back into the caller's state
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            sd_d[k] = params[k].detach()
+    return loss.detach(), dict(zip(keys, grads))

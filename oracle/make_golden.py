@@ -33,6 +33,7 @@ def golden_cases():
         "disc_fc": dict(kind="disc_fc", num_classes=11, H=64, W=96, B=2, seed=42),
         "masker_small": dict(kind="masker", H=128, W=160, B=1, seed=61, gain=1.6),
         "infer_small": dict(kind="infer", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43),
+        "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -62,6 +63,10 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    if k == "dstep_p":
+        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
+                    fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
+                    m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
     if k in ("masker", "infer"):
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1))
     if k == "extra_adam":
@@ -220,6 +225,39 @@ def run_reference_infer(name, case):
     return out
 
 
+def run_reference_dstep(name, case):
+    """The Painter branch of ``Trainer.get_D_loss`` (trainer.py:1073-1107) with the reference's own modules and
+    losses (``GANLoss`` as built by ``get_losses``: BCE form, here soft_shift = flip_prob = 0), then
+    ``d_loss.backward()``: loss value + gradient of every trainable D parameter."""
+    from oracle import ref_shim
+
+    disc = ref_shim.ref("discriminator")
+    losses = ref_shim.ref("losses")
+    tutils = ref_shim.ref("tutils")
+    D = disc.define_D(input_nc=4, ndf=case["ndf"], n_layers=case["n_layers"], norm="instance", use_sigmoid=False,
+                      get_intermediate_features=True, num_D=case["num_D"])
+    shapes = {key: tuple(v.shape) for key, v in D.state_dict().items()}
+    sd_np = fill.fill_state_dict(shapes, case["seed"])
+    D.load_state_dict({key: t(v) for key, v in sd_np.items()})
+    D.train()
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    gan = losses.GANLoss(use_lsgan=False, soft_shift=0.0, flip_prob=0.0)
+    real_cat = torch.cat([inp["m"], inp["x"]], axis=1)
+    fake_cat = torch.cat([inp["m"], inp["fake"]], axis=1)
+    real_fake_d = D(torch.cat([real_cat, fake_cat], dim=0))
+    real_d, fake_d = tutils.divide_pred(real_fake_d)
+    loss = gan(fake_d, False, True)
+    loss += gan(real_d, True, True)
+    loss.backward()
+    out = {"loss": loss.detach().numpy().reshape(1)}
+    for key, p in D.named_parameters():
+        if p.requires_grad:
+            out["grad." + key] = p.grad.numpy().copy()
+        if key.endswith("weight_u"):
+            out["post." + key] = p.data.numpy().copy()
+    return out
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -257,6 +295,8 @@ def run_reference(name, case):
         return run_reference_masker(name, case)
     if case["kind"] == "infer":
         return run_reference_infer(name, case)
+    if case["kind"] == "dstep_p":
+        return run_reference_dstep(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}

@@ -28,6 +28,8 @@ def module_shapes(case):
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k == "disc_fc":
         return disc_fc_shapes(case["num_classes"])
+    if k == "dstep_p":
+        return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k in ("extra_adam", "masker", "infer"):
         return {}
     raise KeyError(k)
@@ -175,6 +177,19 @@ def run_oracle_infer(name, case):
     return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in r.items()}
 
 
+def run_oracle_dstep(name, case):
+    sd = case_state_dict(case)
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+    loss, grads = cpu_ref.painter_d_step(sd, inp["m"], inp["x"], inp["fake"], case["num_D"], case["n_layers"])
+    out = {"loss": loss.numpy().reshape(1)}
+    for k, g in grads.items():
+        out["grad." + k] = g.numpy()
+    for k, v in sd.items():
+        if k.endswith("weight_u"):
+            out["post." + k] = v.numpy().copy()
+    return out
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
@@ -183,6 +198,8 @@ def run_oracle(name, case, dtype=torch.float32):
         return run_oracle_masker(name, case)
     if case["kind"] == "infer":
         return run_oracle_infer(name, case)
+    if case["kind"] == "dstep_p":
+        return run_oracle_dstep(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}

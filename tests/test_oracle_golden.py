@@ -10,7 +10,7 @@ CASES = golden_cases()
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small")])
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p")])
 def test_oracle_matches_golden(name):
     gold = load_golden(name)
     got = run_oracle(name, CASES[name])
@@ -63,3 +63,18 @@ def test_oracle_matches_golden_infer_all():
         d8 = np.abs(gold["flood_u8"].astype(np.int32) - got["flood_u8"].astype(np.int32))
         assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3, (d8.max(), (d8 > 0).mean())
     assert 0.2 < (gold["mask_u8"] > 0).mean() < 0.5          # the fixture has a real two-valued mask
+
+
+def test_oracle_matches_golden_painter_d_step():
+    """Loss and every parameter gradient of the Painter discriminator update (reference modules + GANLoss +
+    ``backward()``) vs the oracle's functional restatement under torch autograd: 1e-4 of each gradient's scale."""
+    name = "dstep_p"
+    gold = load_golden(name)
+    got = run_oracle(name, CASES[name])
+    assert sorted(gold) == sorted(got)
+    for k in gold:
+        scale = max(np.abs(gold[k]).max(), 1e-12)
+        err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
+        # biases in front of an instance norm have an exactly-zero gradient (the norm removes the mean): fp32 noise only
+        assert err <= 1e-4 * scale + 1e-7, "%s/%s: max abs err %.3g (scale %.3g)" % (name, k, err, scale)
+    assert any(k.startswith("grad.") and np.abs(v).max() > 0 for k, v in gold.items())
