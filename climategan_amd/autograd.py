@@ -12,17 +12,21 @@ from . import ops
 
 
 class ConvFn(torch.autograd.Function):
-    """y = act(conv(x, w[/sigma]) + b).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under spectral norm, in
-    which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped back through
-    ``w_bar / sigma``, reference norms.py:107-112)."""
+    """y = act(conv(up?(x), w[/sigma]) + b + up?(res)).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under
+    spectral norm, in which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped
+    back through ``w_bar / sigma``, reference norms.py:107-112).  ``cfg`` keys: c_in, stride, pad, dilation, act, slope,
+    in_upsample, residual_upsample, c_res."""
 
     @staticmethod
-    def forward(ctx, x_t, weight, bias, packed, cfg, sn):
+    def forward(ctx, x_t, weight, bias, res_t, packed, cfg, sn):
         x = ops.NHWC(x_t, cfg["c_in"])
+        res = ops.NHWC(res_t, weight.shape[0]) if res_t is not None else None
         y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"], act=cfg["act"],
-                       slope=cfg["slope"])
+                       slope=cfg["slope"], residual=res, in_upsample=cfg.get("in_upsample", False),
+                       residual_upsample=cfg.get("residual_upsample", False))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.has_res = res_t is not None
         ctx.sn = None if sn is None else tuple(t.clone() for t in sn)      # (sigma, u, v) as used in this forward
         ctx.save_for_backward(x_t, weight, y.t if cfg["act"] != ops.ACT_NONE else None)
         return y.t
@@ -32,21 +36,27 @@ class ConvFn(torch.autograd.Function):
         cfg = ctx.cfg
         x_t, weight, y_t = ctx.saved_tensors
         c_out = weight.shape[0]
+        ups = cfg.get("in_upsample", False)
         dy = ops.NHWC(dy_t.contiguous(), c_out)
         if y_t is not None:
             dy = ops.act_bwd(ops.NHWC(y_t, c_out), dy, cfg["act"], cfg["slope"])
         sigma = ctx.sn[0] if ctx.sn is not None else None
-        dx_t = None
+        dx_t = dres_t = None
         if ctx.needs_input_grad[0]:
-            dx_t = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], x_t.shape[1], x_t.shape[2]), stride=cfg["stride"],
-                                       pad=cfg["pad"], dilation=cfg["dilation"], sigma=sigma).t
+            h_in, w_in = (x_t.shape[1] * 2, x_t.shape[2] * 2) if ups else (x_t.shape[1], x_t.shape[2])
+            dx = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], h_in, w_in), stride=cfg["stride"], pad=cfg["pad"],
+                                     dilation=cfg["dilation"], sigma=sigma)
+            dx_t = (ops.sumpool2x2(dx) if ups else dx).t
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres_t = (ops.sumpool2x2(dy) if cfg.get("residual_upsample", False) else dy).t
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"],
-                                           pad=cfg["pad"], dilation=cfg["dilation"], want_bias=ctx.has_bias)
+                                           pad=cfg["pad"], dilation=cfg["dilation"], want_bias=ctx.has_bias,
+                                           in_upsample=ups)
             if ctx.sn is not None:
                 dw = ops.spectral_norm_bwd(dw, weight.detach(), ctx.sn[1], ctx.sn[2], ctx.sn[0])
-        return dx_t, dw, db, None, None, None
+        return dx_t, dw, db, dres_t, None, None, None
 
 
 class InstNormActFn(torch.autograd.Function):

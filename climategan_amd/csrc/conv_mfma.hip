@@ -451,7 +451,6 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
 static int dgrad_desc(const CganConvDesc* f, CganConvDesc* t) {
   CGAN_REQUIRE(f != nullptr, "conv2d bwd_data: null descriptor");
   CGAN_REQUIRE(f->pad_mode == CGAN_PAD_ZERO, "conv2d bwd_data: only zero padding has a backward path");
-  CGAN_REQUIRE(!f->in_upsample, "conv2d bwd_data: the folded x2 upsample has no backward path yet");
   CGAN_REQUIRE(f->stride >= 1 && f->dilation >= 1 && f->kh > 0 && f->kw > 0, "conv2d bwd_data: bad kernel params");
   *t = *f;
   t->c_in = f->c_out; t->c_out = f->c_in;

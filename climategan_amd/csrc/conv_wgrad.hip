@@ -27,6 +27,7 @@ struct WgradArgs {
   int kh, kw, stride, pad, dil;
   int h_out, w_out, npix;
   int nchunks, ci_blocks;
+  int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
           (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16, 0, 0);
       const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
       const bool xv = pv && ci_ok && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
-      const long off_x = xv ? ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + ci0 + q8) * 2 : zero_x;
+      const long off_x = xv ? (p.x_ups ? ((((long)nn * (p.h_in >> 1) + (iy >> 1)) * (p.w_in >> 1) + (ix >> 1)) * p.cin_s + ci0 + q8) * 2
+                                       : ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + ci0 + q8) * 2)
+                            : zero_x;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.x) + off_x),
           (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16, 0, 0);
@@ -185,7 +188,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   CGAN_REQUIRE(d != nullptr && x && dy && dw_oihw, "conv2d_nhwc_bwd_weight: null pointer");
   CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d_nhwc_bwd_weight: bad dtype %d", d->dtype);
   CGAN_REQUIRE(d->pad_mode == CGAN_PAD_ZERO, "conv2d_nhwc_bwd_weight: only zero padding has a backward path");
-  CGAN_REQUIRE(!d->in_upsample, "conv2d_nhwc_bwd_weight: the folded x2 upsample has no backward path yet");
+  if (d->in_upsample) CGAN_REQUIRE((d->h_in % 2) == 0 && (d->w_in % 2) == 0, "conv2d_nhwc_bwd_weight: in_upsample needs even h_in/w_in");
   CGAN_REQUIRE(d->n > 0 && d->h_in > 0 && d->w_in > 0 && d->c_in > 0 && d->c_out > 0 && d->kh > 0 && d->kw > 0 &&
                    d->stride > 0 && d->dilation > 0 && d->pad >= 0,
                "conv2d_nhwc_bwd_weight: bad shape");
@@ -201,6 +204,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   const long npix = (long)d->n * d->h_out * d->w_out;
   CGAN_REQUIRE(npix < (1L << 31) - 256, "conv2d_nhwc_bwd_weight: too many pixels");
   a.npix = (int)npix;
+  a.x_ups = d->in_upsample;
   a.nchunks = ceil_div(a.npix, 128);
   a.ci_blocks = ceil_div(a.cin_s, 64);
   const int blocks = ceil_div(a.cout_s, 64) * a.ci_blocks;

@@ -260,6 +260,42 @@ __global__ void resize_bicubic_kernel(const uint16_t* __restrict__ x, uint16_t* 
   }
 }
 
+// backward of the nearest x2 upsample (InterpolateNearest2d, blocks.py:28-43): y[n][oy][ox] = sum of the 2x2 block of x
+template <typename T>
+__global__ void sumpool2x2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_out, int w_out, int cs,
+                                  long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int cg = (int)(idx % cg_total);
+    long pix = idx / cg_total;
+    int ox = (int)(pix % w_out);
+    long r = pix / w_out;
+    int oy = (int)(r % h_out);
+    long n = r / h_out;
+    const uint16_t* base = x + ((n * 2 * h_out + 2 * oy) * (long)(2 * w_out) + 2 * ox) * cs + cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(base + ((long)dy * 2 * w_out + dx) * cs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          unpack2<T>(v[e], a, b);
+          acc[2 * e] += a;
+          acc[2 * e + 1] += b;
+        }
+      }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(y + pix * cs + cg * 8) = o;
+  }
+}
+
 // copy the c channels of src [n*hw][cs_src] into channels [c_off, c_off + c) of dst [n*hw][cs_dst]
 // (torch.cat along channels = one call per input; c_off must be a multiple of 8 -- true for every concat of the path)
 __global__ void copy_channels_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cs_src,
@@ -453,6 +489,24 @@ extern "C" int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, i
     hipLaunchKernelGGL(resize_bicubic_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
                        (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, total);
   CGAN_CHECK_LAUNCH("resize_bicubic");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_sumpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_out,
+                                    int32_t w_out, void* stream) {
+  CGAN_REQUIRE(x && y, "sumpool2x2: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "sumpool2x2: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_out > 0 && w_out > 0, "sumpool2x2: bad shape");
+  int cs = cgan_cs(c);
+  long total = (long)n * h_out * w_out * (cs / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(sumpool2x2_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y,
+                       h_out, w_out, cs, total);
+  else
+    hipLaunchKernelGGL(sumpool2x2_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y,
+                       h_out, w_out, cs, total);
+  CGAN_CHECK_LAUNCH("sumpool2x2");
   return CGAN_OK;
 }
 

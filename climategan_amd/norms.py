@@ -35,14 +35,13 @@ def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw
     """Differentiable conv (autograd.ConvFn).  Options without a backward kernel raise."""
     from .autograd import ConvFn
 
-    bad = [k for k in ("residual", "in_upsample", "residual_upsample") if kw.get(k)]
     if kw.get("pad_mode", ops.PAD_ZERO) != ops.PAD_ZERO:
-        bad.append("pad_mode=reflect")
-    if bad:
-        raise NotImplementedError("climategan_amd: conv options %s have no backward kernel yet (training path)" % bad)
+        raise NotImplementedError("climategan_amd: reflect padding has no backward kernel yet (training path)")
+    res = kw.get("residual")
     cfg = dict(c_in=x.c, stride=stride, pad=pad, dilation=dilation, act=kw.get("act", ops.ACT_NONE),
-               slope=kw.get("slope", 0.2))
-    y_t = ConvFn.apply(x.t, weight, bias, packed, cfg, sn)
+               slope=kw.get("slope", 0.2), in_upsample=bool(kw.get("in_upsample", False)),
+               residual_upsample=bool(kw.get("residual_upsample", False)))
+    y_t = ConvFn.apply(x.t, weight, bias, res.t if res is not None else None, packed, cfg, sn)
     return ops.NHWC(y_t, weight.shape[0])
 
 

@@ -331,12 +331,27 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     return NHWC(dx, c_in)
 
 
+def sumpool2x2(x: NHWC) -> NHWC:
+    """Backward of the nearest x2 upsample: sums of 2x2 blocks."""
+    _need_cuda(x.t)
+    if x.h % 2 or x.w % 2 or x.cs != cs8(x.c):
+        raise RuntimeError("sumpool2x2: even extent and round_up(c, 8) storage expected")
+    y = torch.empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_sumpool2x2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h // 2, x.w // 2, _stream()),
+               "cgan_sumpool2x2_nhwc")
+    return NHWC(y, x.c)
+
+
 def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, want_bias=True,
-                      dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None):
-    """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given."""
+                      dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, in_upsample=False):
+    """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given.
+    ``in_upsample``: x is the stored (half-resolution) tensor the forward read through the folded x2 upsample."""
     _need_cuda(x.t, dy.t, dw, dbias)
     c_out, c_in, kh, kw = w_shape
-    d = _conv_desc(x.dtype_id, x.n, x.h, x.w, c_in, c_out, kh, kw, stride, pad, dilation, PAD_ZERO)
+    h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
+    d = _conv_desc(x.dtype_id, x.n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dilation, PAD_ZERO,
+                   in_upsample=in_upsample)
     if (d.h_out, d.w_out) != (dy.h, dy.w) or dy.c != c_out or x.c != c_in or dy.n != x.n:
         raise RuntimeError("conv2d_bwd_weight: shapes do not match the forward conv")
     if dw is None:

@@ -99,7 +99,9 @@ int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t co
 
 /* Backward of the convolution above (autograd of nn.Conv2d, reached from g_loss.backward() / d_loss.backward(),
  * climategan/trainer.py:1011,1028).  All take the FORWARD descriptor; act / bias / residual fields are ignored (their
- * backward is elementwise and lives in the callers); zero padding only, no folded upsample.
+ * backward is elementwise and lives in the callers); zero padding only.  With in_upsample, bwd_weight reads x through
+ * the folded upsample and bwd_data returns the gradient at the LOGICAL (h_in, w_in) extent (follow with
+ * cgan_sumpool2x2_nhwc to get the gradient of the stored tensor).
  *  - bwd_data:   dx[n][h_in][w_in][cgan_cs(c_in)] = conv_transpose(dy, w)  (rows / columns no window reached are zero);
  *                packed_w_dgrad comes from cgan_conv2d_pack_weight_dgrad (channel-transposed, tap-flipped, / *sigma).
  *  - bwd_weight: dw_oihw[c_out][c_in][kh][kw] += sum_pixels dy * x(shifted)   and   dbias[c_out] += sum_pixels dy
@@ -233,6 +235,10 @@ int cgan_resize_bilinear_nhwc(const void* x, void* y, int32_t dtype, int32_t n, 
  * re-sampling of the depth map when its width differs from the target) */
 int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
                              int32_t h_out, int32_t w_out, void* stream);
+/* backward of the nearest x2 upsample (InterpolateNearest2d, climategan/blocks.py:28-43): x [n][2 h_out][2 w_out][cs]
+ * -> y [n][h_out][w_out][cs], each output the sum of its 2x2 block */
+int cgan_sumpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_out, int32_t w_out,
+                         void* stream);
 /* torch.cat along channels, one call per input: copies the c channels of src (pixel stride cs_src) into channels
  * [c_off, c_off + c) of dst (pixel stride cs_dst); c_off % 8 == 0 (deeplab_v3.py:107,139; blocks.py:311) */
 int cgan_copy_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t cs_dst,

@@ -183,3 +183,44 @@ def test_spectral_norm_backward():
     ((w_bar / sigma) * g).sum().backward()
     got = ops.spectral_norm_bwd(g.clone().cuda(), w_bar.detach().cuda(), u.cuda(), v.cuda(), sigma.detach().reshape(1).cuda())
     assert rel_err(got.cpu(), w_bar.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_fn_upsample_residual_autograd(dt):
+    """autograd.ConvFn with the folded x2 upsample on the input and on the residual, LeakyReLU epilogue, spectral-norm
+    sigma: all four gradients (x, residual, w_bar, bias) against torch autograd of the unfused fp32 expression."""
+    from climategan_amd import ops
+    from climategan_amd.autograd import ConvFn
+    from oracle import cpu_ref
+    B, cin, cout, H, W = 2, 24, 16, 6, 10
+    x = q(fill.uniform((B, cin, H, W), 4100), dt).requires_grad_(True)
+    res = q(fill.uniform((B, cout, H, W), 4101), dt).requires_grad_(True)
+    w_bar = torch.from_numpy(fill.uniform((cout, cin, 3, 3), 4102, -0.2, 0.2)).requires_grad_(True)
+    b = torch.from_numpy(fill.uniform((cout,), 4103)).requires_grad_(True)
+    u = torch.from_numpy(fill.uniform((cout,), 4104)); u = u / u.norm()
+    v = torch.from_numpy(fill.uniform((cin * 9,), 4105)); v = v / v.norm()
+    sigma = u.dot(w_bar.reshape(cout, -1).mv(v))
+    w_eff = q((w_bar / sigma).detach().numpy(), dt)                      # what the packed 16-bit weights hold
+    xu = cpu_ref.nearest_resize(x, (2 * H, 2 * W))
+    ru = cpu_ref.nearest_resize(res, (2 * H, 2 * W))
+    # straight-through the 16-bit rounding of w: gradients are taken w.r.t. w_bar through w_bar / sigma
+    w_used = w_bar / sigma + (w_eff - w_bar / sigma).detach()
+    y = F.leaky_relu(F.conv2d(xu, w_used, b, padding=1) + ru, 0.2)
+    dy = q(fill.uniform(tuple(y.shape), 4106), dt)
+    y.backward(dy)
+
+    xg = to_nhwc(x.detach(), dt).t.requires_grad_(True)
+    rg = to_nhwc(res.detach(), dt).t.requires_grad_(True)
+    wg = w_bar.detach().cuda().requires_grad_(True)
+    bg = b.detach().cuda().requires_grad_(True)
+    sig = sigma.detach().reshape(1).cuda()
+    pw = ops.pack_conv_weight(wg.detach(), bg.detach(), dt, sig)
+    cfg = dict(c_in=cin, stride=1, pad=1, dilation=1, act=ops.ACT_LRELU, slope=0.2, in_upsample=True,
+               residual_upsample=True)
+    out = ConvFn.apply(xg, wg, bg, rg, pw, cfg, (sig, u.cuda(), v.cuda()))
+    assert rel_err(back(ops.NHWC(out.detach(), cout)), y.detach()) <= TOL[dt]
+    out.backward(to_nhwc(dy, dt).t)
+    assert rel_err(back(ops.NHWC(xg.grad, cin)), x.grad) <= 2 * TOL[dt]
+    assert rel_err(back(ops.NHWC(rg.grad, cout)), res.grad) <= 2 * TOL[dt]
+    assert rel_err(wg.grad.cpu(), w_bar.grad) <= 5e-3
+    assert rel_err(bg.grad.cpu(), b.grad) <= 5e-3
