@@ -79,6 +79,57 @@ class InstNormActFn(torch.autograd.Function):
         return dx.t, None, None, None, None
 
 
+class SpadeFn(torch.autograd.Function):
+    """y = act(instance_norm(up?(x)) * (1 + gamma(cond)) + beta(cond)) (reference norms.py:174-186 + the block's
+    LeakyReLU).  Forward: the fused HIP kernel (the 128-channel hidden map never leaves LDS).  Backward: the hidden map
+    and gamma are RE-COMPUTED at full resolution (conv kernels), the elementwise stage splits dy into the gradients of
+    gamma / beta / the normalised input, and the conv backward kernels produce the gradients of mlp_gamma, mlp_beta,
+    mlp_shared and (through the ReLU) nothing further: cond is data.  The instance-norm backward then gives dx.
+    The re-materialised maps cost HBM traffic the fused forward avoids (a fused backward is future work)."""
+
+    @staticmethod
+    def forward(ctx, x_t, cond_t, mean, rstd, w_sh, b_sh, w_g, b_g, w_b, b_b, packed, cfg):
+        x = ops.NHWC(x_t, cfg["c"])
+        cond = ops.NHWC(cond_t, cfg["cond_c"])
+        y = ops.spade_fused(x, mean, rstd, cond, packed, act=cfg["act"], slope=cfg["slope"],
+                            x_upsample=cfg["x_upsample"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(x_t, cond_t, mean, rstd, y.t, w_sh, b_sh, w_g, b_g, w_b, b_b)
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        cfg = ctx.cfg
+        x_t, cond_t, mean, rstd, y_t, w_sh, b_sh, w_g, b_g, w_b, b_b = ctx.saved_tensors
+        c, dt = cfg["c"], y_t.dtype
+        x, y = ops.NHWC(x_t, c), ops.NHWC(y_t, c)
+        dy = ops.NHWC(dy_t.contiguous(), c)
+        h, w = y.h, y.w
+        # re-materialise seg -> hidden -> gamma at full resolution
+        seg = ops.resize_nearest(ops.NHWC(cond_t, cfg["cond_c"]), (h, w), cs_out=ops.cs8(cfg["cond_c"]))
+        actv = ops.conv2d(seg, ops.pack_conv_weight(w_sh, b_sh, dt), pad=1, act=ops.ACT_RELU)
+        gamma = ops.conv2d(actv, ops.pack_conv_weight(w_g, b_g, dt), pad=1)
+        dgb, xhat, dxhat = ops.spade_bwd_prepare(dy, y, x, mean, rstd, gamma, act=cfg["act"], slope=cfg["slope"],
+                                                 x_upsample=cfg["x_upsample"])
+        del gamma
+        # mlp_gamma / mlp_beta as ONE conv with 2C outputs: weight and bias gradients, then the hidden map's gradient
+        w_gb = torch.cat([w_g.detach(), w_b.detach()], dim=0)
+        dw_gb, db_gb = ops.conv2d_bwd_weight(actv, dgb, tuple(w_gb.shape), pad=1)
+        d_actv = ops.conv2d_bwd_data(dgb, w_gb, (actv.n, h, w), pad=1)
+        del dgb
+        d_pre = ops.act_bwd(actv, d_actv, ops.ACT_RELU)
+        del d_actv, actv
+        dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
+        del d_pre
+        # instance norm backward on the normalised tensor at full resolution, then back through the folded upsample
+        dx = ops.instnorm_act_bwd(xhat, dxhat, rstd, act=ops.ACT_NONE)
+        if cfg["x_upsample"]:
+            dx = ops.sumpool2x2(dx)
+        dx_t = dx.t if ctx.needs_input_grad[0] else None
+        return (dx_t, None, None, None, dw_sh, db_sh, dw_gb[:c].contiguous(), db_gb[:c].contiguous(),
+                dw_gb[c:].contiguous(), db_gb[c:].contiguous(), None, None)
+
+
 class BceLogitsFn(torch.autograd.Function):
     """weight * sum BCEWithLogits(x, target) over the logical channels -> fp32 device scalar."""
 

@@ -142,6 +142,71 @@ __global__ void in_bwd_apply_kernel(const uint16_t* __restrict__ out, const uint
   }
 }
 
+// ---- SPADE backward, elementwise stage ------------------------------------------------------------------------
+// forward: y = act(xh * (1 + gamma) + beta), xh = (x - mean) * rstd.  Given dy and y:
+//   dz = dy * act'(y);  d_gamma = dz * xh;  d_beta = dz;  d_xh = dz * (1 + gamma)
+// dgb holds [d_gamma (C) | d_beta (C)] as 2C logical channels (storage round_up(2C, 8), pre-zeroed by the host entry).
+template <typename T>
+__global__ void spade_bwd_prepare_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ y,
+                                         const uint16_t* __restrict__ x, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const uint16_t* __restrict__ gamma,
+                                         uint16_t* __restrict__ dgb, uint16_t* __restrict__ xhat,
+                                         uint16_t* __restrict__ dxhat, int h, int w, int c, int cs, int cs2, int x_ups,
+                                         int act, float slope, long groups) {
+  const int cg_total = cs / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const long pix = i / cg_total;
+    const int ox = (int)(pix % w);
+    const long r = pix / w;
+    const int oy = (int)(r % h);
+    const int n = (int)(r / h);
+    const long xoff = x_ups ? (((long)n * (h >> 1) + (oy >> 1)) * (w >> 1) + (ox >> 1)) * cs + cg * 8 : i * 8;
+    const u32x4 vdy = reinterpret_cast<const u32x4*>(dy)[i];
+    const u32x4 vy = reinterpret_cast<const u32x4*>(y)[i];
+    const u32x4 vg = reinterpret_cast<const u32x4*>(gamma)[i];
+    const u32x4 vx = *reinterpret_cast<const u32x4*>(x + xoff);
+    u32x4 oxh, odx, odg;
+    float dbeta[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a[2], b[2], g2[2], xv[2], rxh[2], rdx[2], rdg[2];
+      unpack2<T>(vdy[e], a[0], a[1]);
+      unpack2<T>(vy[e], b[0], b[1]);
+      unpack2<T>(vg[e], g2[0], g2[1]);
+      unpack2<T>(vx[e], xv[0], xv[1]);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int ch = cg * 8 + 2 * e + hh;
+        const bool live = ch < c;
+        const float dz = live ? a[hh] * act_grad_from_out(b[hh], act, slope) : 0.f;
+        const float xh = live ? (xv[hh] - mean[(long)n * cs + ch]) * rstd[(long)n * cs + ch] : 0.f;
+        rxh[hh] = xh;
+        rdx[hh] = dz * (1.f + g2[hh]);
+        rdg[hh] = dz * xh;
+        dbeta[2 * e + hh] = dz;
+      }
+      oxh[e] = pack2<T>(rxh[0], rxh[1]);
+      odx[e] = pack2<T>(rdx[0], rdx[1]);
+      odg[e] = pack2<T>(rdg[0], rdg[1]);
+    }
+    reinterpret_cast<u32x4*>(xhat)[i] = oxh;
+    reinterpret_cast<u32x4*>(dxhat)[i] = odx;
+    uint16_t* row = dgb + pix * cs2;
+    // d_gamma: channels cg*8 .. (8-aligned: one vector unless it would spill into the d_beta range)
+    if (cg * 8 + 8 <= c) {
+      *reinterpret_cast<u32x4*>(row + cg * 8) = odg;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (cg * 8 + e < c) row[cg * 8 + e] = (uint16_t)((odg[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (cg * 8 + e < c) row[c + cg * 8 + e] = bits_of<T>(dbeta[e]);
+  }
+}
+
 // ---- losses ---------------------------------------------------------------------------------------------------
 // block-level sum -> one atomic per block
 __device__ __forceinline__ void block_atomic_add(float v, float* dst) {
@@ -285,6 +350,30 @@ extern "C" int cgan_instnorm_act_bwd(const void* out, const void* dy, const floa
   DISPATCH_T(d->dtype, in_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)out,
              (const uint16_t*)dy, rstd, (const float*)workspace, (uint16_t*)dx, d->hw, cs, d->c, act, act_slope, groups);
   CGAN_CHECK_LAUNCH("instnorm_act_bwd");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                                      const void* gamma, void* dgb, void* xhat, void* dxhat, const CganSpadeDesc* d,
+                                      void* stream) {
+  CGAN_REQUIRE(d && dy && y && x && mean && rstd && gamma && dgb && xhat && dxhat, "spade_bwd_prepare: null pointer");
+  CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "spade_bwd_prepare: bad dtype %d", d->dtype);
+  CGAN_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->c > 0, "spade_bwd_prepare: bad shape");
+  CGAN_REQUIRE(d->act == CGAN_ACT_NONE || d->act == CGAN_ACT_LRELU, "spade_bwd_prepare: Unsupported activation: %d", d->act);
+  if (d->x_upsample) CGAN_REQUIRE((d->h % 2) == 0 && (d->w % 2) == 0, "spade_bwd_prepare: x_upsample needs even h/w");
+  const int cs = cgan_cs(d->c), cs2 = cgan_cs(2 * d->c);
+  const long npix = (long)d->n * d->h * d->w;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dgb, 0, (size_t)npix * cs2 * 2, s);
+  if (e != hipSuccess) {
+    cgan_set_error("spade_bwd_prepare: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CGAN_ERR_HIP;
+  }
+  const long groups = npix * (cs / 8);
+  DISPATCH_T(d->dtype, spade_bwd_prepare_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)dy,
+             (const uint16_t*)y, (const uint16_t*)x, mean, rstd, (const uint16_t*)gamma, (uint16_t*)dgb, (uint16_t*)xhat,
+             (uint16_t*)dxhat, d->h, d->w, d->c, cs, cs2, d->x_upsample, d->act, d->act_slope, groups);
+  CGAN_CHECK_LAUNCH("spade_bwd_prepare");
   return CGAN_OK;
 }
 

@@ -496,6 +496,21 @@ def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, 
     return NHWC(y, x.c)
 
 
+def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=ACT_NONE, slope=0.2, x_upsample=False):
+    """Elementwise stage of the SPADE backward: returns (dgb [2C channels: d_gamma | d_beta], xhat, dxhat)."""
+    _need_cuda(dy.t, y.t, x.t, mean, rstd, gamma.t)
+    c = y.c
+    d = _spade_desc(y.dtype_id, y.n, y.h, y.w, c, x_upsample, y.h, y.w, 3, act, slope)
+    dgb = torch.empty((y.n, y.h, y.w, cs8(2 * c)), dtype=y.t.dtype, device=y.t.device)
+    xhat = torch.empty_like(y.t)
+    dxhat = torch.empty_like(y.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_spade_bwd_prepare(_ptr(dy.t), _ptr(y.t), _ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(gamma.t),
+                                          _ptr(dgb), _ptr(xhat), _ptr(dxhat), C.byref(d), _stream()),
+               "cgan_spade_bwd_prepare")
+    return NHWC(dgb, 2 * c), NHWC(xhat, c), NHWC(dxhat, c)
+
+
 # ------------------------------------------------------------------------------------------------ spectral norm
 def spectral_norm_power_iter(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """One power iteration (reference norms.py:100-112); u, v updated IN PLACE; returns device scalar sigma."""

@@ -266,6 +266,15 @@ int cgan_act_bwd(const void* out, const void* dy, void* dx, int32_t dtype, int32
 size_t cgan_instnorm_act_bwd_workspace_bytes(const CganNormStatsDesc* d);
 int cgan_instnorm_act_bwd(const void* out, const void* dy, const float* rstd, void* dx, const CganNormStatsDesc* d,
                           int32_t act, float act_slope, void* workspace, size_t workspace_bytes, void* stream);
+/* elementwise stage of the SPADE backward (autograd of climategan/norms.py:181-186 and of the block's LeakyReLU):
+ * with dz = dy * act'(y), xh = (x - mean) * rstd (x read through the folded upsample when d->x_upsample):
+ *   dgb   [n][h][w][cgan_cs(2c)] : logical channels [dz * xh (c) | dz (c)]  = gradients of gamma and beta
+ *   xhat  [n][h][w][cgan_cs(c)]  : xh
+ *   dxhat [n][h][w][cgan_cs(c)]  : dz * (1 + gamma)   (gamma = the mlp_gamma conv output, bias included)
+ * The conv gradients (mlp_gamma / mlp_beta / mlp_shared) and the instance-norm backward (cgan_instnorm_act_bwd on
+ * xhat / dxhat) are separate calls. */
+int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                           const void* gamma, void* dgb, void* xhat, void* dxhat, const CganSpadeDesc* d, void* stream);
 /* nn.BCEWithLogitsLoss(x, target) pieces against a constant target (GANLoss, climategan/losses.py:50-83; ADVENT
  * D-side BCE, losses.py:461-477) over the c logical channels of x [npix][cgan_cs(c)]:
  * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */

@@ -224,3 +224,50 @@ def test_conv_fn_upsample_residual_autograd(dt):
     assert rel_err(back(ops.NHWC(rg.grad, cout)), res.grad) <= 2 * TOL[dt]
     assert rel_err(wg.grad.cpu(), w_bar.grad) <= 5e-3
     assert rel_err(bg.grad.cpu(), b.grad) <= 5e-3
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,H,W,ups,act", [(20, 12, 16, False, "lrelu"), (40, 8, 12, True, "none"), (16, 10, 10, True, "lrelu")])
+def test_spade_fn_backward(dt, C, H, W, ups, act):
+    """autograd.SpadeFn (fused forward, re-materialising backward) against torch autograd of the reference expression
+    (norms.py:174-186): gradients of x and of the six mlp parameters."""
+    from climategan_amd import ops
+    from climategan_amd.autograd import SpadeFn
+    from oracle import cpu_ref
+    B = 2
+    hs, ws = (H // 2, W // 2) if ups else (H, W)
+    x = q(fill.uniform((B, C, hs, ws), 5100 + C, -2, 2), dt).requires_grad_(True)
+    cond = q(fill.uniform((B, 3, 2 * H, 2 * W), 5101), dt)
+    shapes = {"mlp_shared.0.weight": (128, 3, 3, 3), "mlp_shared.0.bias": (128,), "mlp_gamma.weight": (C, 128, 3, 3),
+              "mlp_gamma.bias": (C,), "mlp_beta.weight": (C, 128, 3, 3), "mlp_beta.bias": (C,)}
+    sd = {k: q(v, dt).requires_grad_(True) for k, v in fill.fill_state_dict(shapes, 5102).items()}
+    xu = cpu_ref.nearest_resize(x, (H, W)) if ups else x
+    seg = cpu_ref.nearest_resize(cond, (H, W))
+    actv = F.relu(F.conv2d(seg, sd["mlp_shared.0.weight"], sd["mlp_shared.0.bias"], padding=1))
+    gamma = F.conv2d(actv, sd["mlp_gamma.weight"], sd["mlp_gamma.bias"], padding=1)
+    beta = F.conv2d(actv, sd["mlp_beta.weight"], sd["mlp_beta.bias"], padding=1)
+    y = F.instance_norm(xu, eps=1e-5) * (1 + gamma) + beta
+    if act == "lrelu":
+        y = F.leaky_relu(y, 0.2)
+    dy = q(fill.uniform(tuple(y.shape), 5103), dt)
+    y.backward(dy)
+
+    a = ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE
+    xg = to_nhwc(x.detach(), dt)
+    xt = xg.t.requires_grad_(True)
+    condg = ops.nchw_to_nhwc(cond.cuda(), dt, cs=4)
+    ps = {k: v.detach().cuda().requires_grad_(True) for k, v in sd.items()}
+    names = ["mlp_shared.0.weight", "mlp_shared.0.bias", "mlp_gamma.weight", "mlp_gamma.bias", "mlp_beta.weight",
+             "mlp_beta.bias"]
+    pk = ops.pack_spade_weights(*[ps[k].detach() for k in names], dt)
+    mean, rstd = ops.instnorm_stats(xg)
+    cfg = dict(c=C, cond_c=3, act=a, slope=0.2, x_upsample=ups)
+    out = SpadeFn.apply(xt, condg.t, mean, rstd, *[ps[k] for k in names], pk, cfg)
+    assert rel_err(back(ops.NHWC(out.detach(), C)), y.detach()) <= TOL[dt]
+    out.backward(to_nhwc(dy, dt).t)
+    # 16-bit re-materialised hidden map / gamma / gradients: a few 16-bit roundings deep
+    # (bf16: the instance-norm backward subtracts two means from 8-bit-mantissa values: up to 7 % on the 5x5 case)
+    assert rel_err(back(ops.NHWC(xt.grad, C)), x.grad) <= (4e-3 if dt == torch.float16 else 1e-1)
+    for k in names:
+        e = rel_err(ps[k].grad.cpu(), sd[k].grad)
+        assert e <= (5e-3 if dt == torch.float16 else 8e-2), "%s: rel err %.3g" % (k, e)
