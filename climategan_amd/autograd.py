@@ -130,6 +130,50 @@ class SpadeFn(torch.autograd.Function):
                 dw_gb[c:].contiguous(), db_gb[c:].contiguous(), None, None)
 
 
+class PainterHeadsFn(torch.autograd.Function):
+    """(d_in, vgg_in) = heads(paste(x, m, fake)): see ops.painter_heads; gradient flows to ``fake`` only."""
+
+    @staticmethod
+    def forward(ctx, fake_t, x, m, want_d, want_vgg):
+        d_in, v_in = ops.painter_heads(ops.NHWC(fake_t, 3), x, m, fake_t.dtype, want_d, want_vgg)
+        ctx.save_for_backward(m)
+        ctx.want = (want_d, want_vgg)
+        empty = fake_t.new_empty(0)
+        return (d_in.t if want_d else empty), (v_in.t if want_vgg else empty)
+
+    @staticmethod
+    def backward(ctx, dd_t, dv_t):
+        (m,) = ctx.saved_tensors
+        want_d, want_vgg = ctx.want
+        dd = ops.NHWC(dd_t.contiguous(), 4) if want_d and dd_t is not None else None
+        dv = ops.NHWC(dv_t.contiguous(), 3) if want_vgg and dv_t is not None else None
+        return ops.painter_heads_bwd(dd, dv, m).t, None, None, None, None
+
+
+class AvgPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_t, c):
+        ctx.c, ctx.hw = c, (x_t.shape[1], x_t.shape[2])
+        return ops.avgpool3x3s2(ops.NHWC(x_t, c)).t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        return ops.avgpool3x3s2_bwd(ops.NHWC(dy_t.contiguous(), ctx.c), ctx.hw).t, None
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_t, c):
+        ctx.c = c
+        ctx.save_for_backward(x_t)
+        return ops.maxpool2x2(ops.NHWC(x_t, c)).t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        (x_t,) = ctx.saved_tensors
+        return ops.maxpool2x2_bwd(ops.NHWC(x_t, ctx.c), ops.NHWC(dy_t.contiguous(), ctx.c)).t, None
+
+
 class BceLogitsFn(torch.autograd.Function):
     """weight * sum BCEWithLogits(x, target) over the logical channels -> fp32 device scalar."""
 

@@ -230,17 +230,23 @@ class SPADEResnetBlock(nn.Module):
         stats = ops.instnorm_stats(x, eps=self.norm_0.param_free_norm.eps)
         if self.learned_shortcut:
             s = self.norm_s.forward_nhwc(x, cond, stats, act=ops.ACT_NONE, x_upsample=x_upsample)
-            x_s = conv_forward(self.conv_s, self._caches["conv_s"], s)
+            x_s = conv_forward(self.conv_s, self._caches["conv_s"], s, **self._tr(self.conv_s))
             res, res_ups = x_s, False
         else:
             res, res_ups = x, x_upsample
         dx = self.norm_0.forward_nhwc(x, cond, stats, act=ops.ACT_LRELU, x_upsample=x_upsample)
-        dx = conv_forward(self.conv_0, self._caches["conv_0"], dx)
+        dx = conv_forward(self.conv_0, self._caches["conv_0"], dx, **self._tr(self.conv_0))
         dx = self.norm_1.forward_nhwc(dx, cond, None, act=ops.ACT_LRELU)
         act = ops.ACT_LRELU if (self.last_activation == "lrelu" or post_act == "lrelu") else ops.ACT_NONE
         if self.last_activation == "lrelu" and post_act == "lrelu":
             raise NotImplementedError("SPADEResnetBlock: last_activation and post_act cannot both be lrelu")
-        return conv_forward(self.conv_1, self._caches["conv_1"], dx, residual=res, residual_upsample=res_ups, act=act)
+        return conv_forward(self.conv_1, self._caches["conv_1"], dx, residual=res, residual_upsample=res_ups, act=act,
+                            **self._tr(self.conv_1))
+
+    @staticmethod
+    def _tr(conv):
+        """plain (non spectral-norm) convs take the training path through conv_forward's ``trainable`` switch"""
+        return {} if isinstance(conv, SpectralNorm) else {"trainable": True}
 
     def forward(self, x, seg, compute_dtype=None):
         """Reference signature: NCHW tensors in, NCHW out."""

@@ -44,6 +44,7 @@ def default_opts() -> Opts:
         "tasks": ["d", "s", "m", "p"],                                   # :19
         "data": {"transforms": [{"name": "resize", "new_size": {"default": 640, "d": 160, "s": 160}}]},   # :61-67
         "gen": {
+            "opt": {"optimizer": "ExtraAdam", "beta1": 0.9, "lr": {"default": 0.00005}},   # :73-77
             "encoder": {"architecture": "deeplabv3"},                    # :103
             "deeplabv3": {"backbone": "resnet", "output_stride": 8},     # :115-116
             "d": {"architecture": "dada", "upsample_featuremaps": True, "output_dim": 1, "norm": "batch"},   # :122-134
@@ -60,9 +61,12 @@ def default_opts() -> Opts:
         },
         "dis": {
             "soft_shift": 0.2, "flip_prob": 0.05,                        # :194-195
+            "opt": {"optimizer": "ExtraAdam", "beta1": 0.5, "lr": {"default": 0.00002}},   # :196-200
             "p": {"input_nc": 3, "ndf": 64, "n_layers": 4, "norm": "instance", "use_sigmoid": False, "num_D": 3,
                   "get_intermediate_features": True, "use_local_discriminator": False},   # :213-227
             "m": {"architecture": "base", "gan_type": "WGAN_norm"},      # :229-235
             "s": {"gan_type": "WGAN_norm"},                              # :236-240
         },
+        "train": {"lambdas": {"G": {"p": {"context": 0, "dm": 1, "featmatch": 10, "gan": 1, "reconstruction": 0,
+                                          "tv": 0, "vgg": 10}}}},          # :293-300
     })

@@ -152,9 +152,10 @@ class MultiscaleDiscriminator(nn.Module):
             result.append(outs if self.get_intermediate_features else [outs[-1]])
             if i + 1 < self.num_D:
                 if torch.is_grad_enabled() and x.t.requires_grad:
-                    raise NotImplementedError("MultiscaleDiscriminator: average-pool backward is not built yet "
-                                              "(needed only for gradients w.r.t. the input image)")
-                x = ops.avgpool3x3s2(x)
+                    from .autograd import AvgPool3x3s2Fn
+                    x = ops.NHWC(AvgPool3x3s2Fn.apply(x.t, x.c), x.c)
+                else:
+                    x = ops.avgpool3x3s2(x)
         return result
 
 

@@ -130,6 +130,17 @@ class OmniGenerator(nn.Module):
             z = z.half()
         return z
 
+    def paint_nhwc(self, m, x):
+        """Training-path form of ``paint``: returns the Painter's raw output (before the paste) as a differentiable
+        NHWC map; the paste x (1 - m) + fake m and what follows it (discriminator input, VGG input) are produced by
+        ``autograd.PainterHeadsFn`` so that no NCHW fp32 copy of the image is ever materialised."""
+        p = self.painter
+        dt = p.compute_dtype
+        z = self.sample_painter_z(x.shape[0], x.device)
+        cond = ops.nchw_to_nhwc(x, dt, cs=4, mask=m.to(x.dtype))        # x * (1 - m)
+        zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
+        return p.forward_nhwc(zz, cond)
+
     def paint(self, m, x, no_paste=False):
         """reference generator.py:279-297: fake = painter(z, x * (1 - m)); returns x * (1 - m) + fake * m.
 
@@ -141,6 +152,9 @@ class OmniGenerator(nn.Module):
         cond = ops.nchw_to_nhwc(x, dt, cs=4, mask=m)                     # x * (1 - m)
         zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
         fake = p.forward_nhwc(zz, cond)
+        if fake.t.requires_grad:
+            raise NotImplementedError("OmniGenerator.paint: under autograd use paint_nhwc() (the NHWC -> NCHW layout "
+                                      "pass has no backward kernel)")
         if self.opts.gen.p.paste_original_content and not no_paste:
             if tuple(fake.t.shape[1:3]) != tuple(x.shape[-2:]):
                 raise RuntimeError("paint: painter output %s does not match x %s (input must be a multiple of %d)"

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .autograd import BceLogitsFn, L1Fn
+from .autograd import BceLogitsFn, ConvFn, L1Fn, MaxPool2x2Fn
+from .norms import _PackCache
 
 
 def _as_nhwc(t, what):
@@ -75,3 +76,84 @@ class FeatMatchLoss(nn.Module):
                 n = f.n * f.h * f.w * f.c
                 total = total + L1Fn.apply(f.t, r.t.detach(), f.c, 1.0 / (n * num_D))
         return total
+
+
+class Vgg19(nn.Module):
+    """reference losses.py:304-334: torchvision VGG19 ``features[0:30]`` in five slices ending at relu1_1 ... relu5_1,
+    same child names (``slice1.0``, ``slice2.2``, ``slice2.5`` ...) so a torchvision state dict maps onto it.  The
+    pretrained weights (``models.vgg19(pretrained=True)``) are not in the tree and cannot be downloaded here: the layers
+    keep torch's default init until a state dict is loaded (VGG-loss VALUES are therefore unpinned)."""
+
+    CFG = [(0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
+           (16, 256, 256), (19, 256, 512), (21, 512, 512), (23, 512, 512), (25, 512, 512), (28, 512, 512)]
+    POOLS = (4, 9, 18, 27)
+    SLICES = ((0, 2), (2, 7), (7, 12), (12, 21), (21, 30))
+
+    def __init__(self, requires_grad=False):
+        super().__init__()
+        convs = {i: (cin, cout) for i, cin, cout in self.CFG}
+        for k, (a, b) in enumerate(self.SLICES):
+            seq = nn.Sequential()
+            for i in range(a, b):
+                if i in convs:
+                    seq.add_module(str(i), nn.Conv2d(convs[i][0], convs[i][1], 3, padding=1))
+                elif i in self.POOLS:
+                    seq.add_module(str(i), nn.MaxPool2d(2, 2))
+                else:
+                    seq.add_module(str(i), nn.ReLU(inplace=True))
+            setattr(self, "slice%d" % (k + 1), seq)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+        self._caches = {}
+
+    def forward(self, X: ops.NHWC):
+        """X: vgg_preprocess-ed NHWC map (3 channels); returns [relu1_1, relu2_1, relu3_1, relu4_1, relu5_1]."""
+        outs = []
+        y = X
+        for k in range(5):
+            seq = getattr(self, "slice%d" % (k + 1))
+            mods = list(seq.named_children())
+            j = 0
+            while j < len(mods):
+                name, mod = mods[j]
+                if isinstance(mod, nn.Conv2d):                      # conv + the ReLU that follows it, fused
+                    cache = self._caches.setdefault(name, _PackCache())
+                    pw = cache.get((mod.weight, mod.bias), y.t.dtype,
+                                   lambda mod=mod: ops.pack_conv_weight(mod.weight.data, mod.bias.data, y.t.dtype))
+                    if torch.is_grad_enabled() and (y.t.requires_grad or mod.weight.requires_grad):
+                        cfg = dict(c_in=y.c, stride=1, pad=1, dilation=1, act=ops.ACT_RELU, slope=0.0)
+                        y = ops.NHWC(ConvFn.apply(y.t, mod.weight, mod.bias, None, pw, cfg, None), mod.out_channels)
+                    else:
+                        y = ops.conv2d(y, pw, pad=1, act=ops.ACT_RELU)
+                    j += 2
+                else:                                                # max pool
+                    if torch.is_grad_enabled() and y.t.requires_grad:
+                        y = ops.NHWC(MaxPool2x2Fn.apply(y.t, y.c), y.c)
+                    else:
+                        y = ops.maxpool2x2(y)
+                    j += 1
+            outs.append(y)
+        return outs
+
+
+class VGGLoss(nn.Module):
+    """reference losses.py:337-350: sum_i w_i L1(vgg_i(x), vgg_i(y).detach()), w = (1/32, 1/16, 1/8, 1/4, 1)."""
+
+    def __init__(self, device=None):
+        super().__init__()
+        self.vgg = Vgg19().eval()
+        if device is not None:
+            self.vgg = self.vgg.to(device)
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def forward(self, x: ops.NHWC, y: ops.NHWC):
+        x_vgg = self.vgg(_as_nhwc(x, "VGGLoss"))
+        with torch.no_grad():
+            y_vgg = self.vgg(_as_nhwc(y, "VGGLoss"))
+        loss = 0
+        for i in range(len(x_vgg)):
+            f, r = x_vgg[i], y_vgg[i]
+            n = f.n * f.h * f.w * f.c
+            loss = loss + L1Fn.apply(f.t, r.t, f.c, self.weights[i] / n)
+        return loss

@@ -212,7 +212,6 @@ class SPADE(nn.Module):
         return self._cache.get(ps, dtype, lambda: ops.pack_spade_weights(*[p.data for p in ps], dtype))
 
     def forward_nhwc(self, x: ops.NHWC, cond: ops.NHWC, stats=None, act=ops.ACT_NONE, x_upsample=False) -> ops.NHWC:
-        _grad_guard(self)
         if self.param_free_norm_type != "instance":
             raise NotImplementedError("SPADE: param-free norm '%s' has no HIP kernel yet (instance only)"
                                       % self.param_free_norm_type)
@@ -220,6 +219,13 @@ class SPADE(nn.Module):
             raise NotImplementedError("SPADE: only kernel_size 3 is supported")
         if stats is None:
             stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
+        if needs_grad(self, x.t):
+            from .autograd import SpadeFn
+            cfg = dict(c=x.c, cond_c=cond.c, act=act, slope=0.2, x_upsample=bool(x_upsample))
+            y_t = SpadeFn.apply(x.t, cond.t, stats[0], stats[1], self.mlp_shared[0].weight, self.mlp_shared[0].bias,
+                                self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias,
+                                self.packed(x.t.dtype), cfg)
+            return ops.NHWC(y_t, x.c)
         return ops.spade_fused(x, stats[0], stats[1], cond, self.packed(x.t.dtype), act=act, x_upsample=x_upsample)
 
     def forward(self, x, segmap, compute_dtype=None):

@@ -511,6 +511,62 @@ def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=A
     return NHWC(dgb, 2 * c), NHWC(xhat, c), NHWC(dxhat, c)
 
 
+def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype, want_d=True, want_vgg=False):
+    """(d_in, vgg_in) of the pasted image p = x (1 - m) + fake m (or p = x when ``fake`` is None): the discriminator
+    input [m | p] (4 channels) and vgg_preprocess(p * m) (3 channels), NHWC 16-bit; x, m NCHW fp32."""
+    _need_cuda(x, m, fake.t if fake is not None else None)
+    x = x.contiguous().float()
+    m = m.contiguous().float()
+    n, _, h, w = x.shape
+    d_in = torch.empty((n, h, w, 8), dtype=dtype, device=x.device) if want_d else None
+    v_in = torch.empty((n, h, w, 8), dtype=dtype, device=x.device) if want_vgg else None
+    lib = _lib.load()
+    _lib.check(lib.cgan_painter_heads_fwd(_ptr(fake.t if fake is not None else None), _ptr(x), _ptr(m), _ptr(d_in),
+                                          _ptr(v_in), _DT[dtype], n, h, w, _stream()), "cgan_painter_heads_fwd")
+    return (NHWC(d_in, 4) if want_d else None), (NHWC(v_in, 3) if want_vgg else None)
+
+
+def painter_heads_bwd(d_d_in: Optional[NHWC], d_vgg_in: Optional[NHWC], m: torch.Tensor) -> NHWC:
+    ref = d_d_in if d_d_in is not None else d_vgg_in
+    _need_cuda(ref.t, m)
+    m = m.contiguous().float()
+    n, h, w = ref.n, ref.h, ref.w
+    dfake = torch.empty((n, h, w, 8), dtype=ref.t.dtype, device=ref.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_painter_heads_bwd(_ptr(d_d_in.t if d_d_in is not None else None),
+                                          _ptr(d_vgg_in.t if d_vgg_in is not None else None), _ptr(m), _ptr(dfake),
+                                          ref.dtype_id, n, h, w, _stream()), "cgan_painter_heads_bwd")
+    return NHWC(dfake, 3)
+
+
+def avgpool3x3s2_bwd(dy: NHWC, in_hw) -> NHWC:
+    _need_cuda(dy.t)
+    h, w = in_hw
+    dx = torch.empty((dy.n, h, w, dy.cs), dtype=dy.t.dtype, device=dy.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_avgpool3x3s2_bwd_nhwc(_ptr(dy.t), _ptr(dx), dy.dtype_id, dy.n, dy.c, h, w, _stream()),
+               "cgan_avgpool3x3s2_bwd_nhwc")
+    return NHWC(dx, dy.c)
+
+
+def maxpool2x2(x: NHWC) -> NHWC:
+    _need_cuda(x.t)
+    y = torch.empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_maxpool2x2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
+               "cgan_maxpool2x2_nhwc")
+    return NHWC(y, x.c)
+
+
+def maxpool2x2_bwd(x: NHWC, dy: NHWC) -> NHWC:
+    _need_cuda(x.t, dy.t)
+    dx = torch.empty_like(x.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_maxpool2x2_bwd_nhwc(_ptr(x.t), _ptr(dy.t), _ptr(dx), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
+               "cgan_maxpool2x2_bwd_nhwc")
+    return NHWC(dx, x.c)
+
+
 # ------------------------------------------------------------------------------------------------ spectral norm
 def spectral_norm_power_iter(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """One power iteration (reference norms.py:100-112); u, v updated IN PLACE; returns device scalar sigma."""

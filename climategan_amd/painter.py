@@ -51,6 +51,9 @@ class PainterSpadeDecoder(nn.Module):
                                       "defaults.yaml:155) has no HIP path")
         self.conv_img = nn.Conv2d(self.final_nc, 3, 3, padding=1)
         self.upsample = InterpolateNearest2d(scale_factor=2)
+        for m in self.modules():          # every op of this network has a backward kernel: allow autograd
+            if isinstance(m, SpectralNorm):
+                m.trainable = True
         self._fc_cache = _PackCache()
         self._img_cache = _PackCache()
 
@@ -69,12 +72,11 @@ class PainterSpadeDecoder(nn.Module):
 
     def forward_nhwc(self, z, cond: ops.NHWC) -> ops.NHWC:
         """cond: NHWC (3 channels stored as 4).  Returns tanh(conv_img(...)) as NHWC (3 channels stored as 8)."""
-        _grad_guard(self)
         spectral_norm_step_all(self, cond.t.dtype)   # all 23 power iterations + w_bar/sigma packs, batched
         if z is None:
             assert self.z_h is not None and self.z_w is not None
             zin = ops.resize_nearest(cond, (self.z_h, self.z_w), cs_out=8)       # painter.py:152
-            y = conv_forward(self.fc, self._fc_cache, zin)
+            y = conv_forward(self.fc, self._fc_cache, zin, trainable=True)
         else:
             y = z
         y = self.head_0.forward_nhwc(y, cond)
@@ -83,11 +85,15 @@ class PainterSpadeDecoder(nn.Module):
         for up in self.up_spades:
             y = up.forward_nhwc(y, cond, x_upsample=True)
         y = self.final_spade.forward_nhwc(y, cond, post_act="lrelu")             # painter.py:165-166
-        return conv_forward(self.conv_img, self._img_cache, y, act=ops.ACT_TANH)  # painter.py:166-167
+        return conv_forward(self.conv_img, self._img_cache, y, act=ops.ACT_TANH, trainable=True)  # painter.py:166-167
 
     def forward(self, z, cond):
         """Reference signature (painter.py:149): z None or [B,latent,z_h,z_w]; cond [B,3,H,W] NCHW."""
         dt = self.compute_dtype
         c = ops.nchw_to_nhwc(cond, dt, cs=4)
         zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
-        return ops.nhwc_to_nchw(self.forward_nhwc(zz, c)).to(cond.dtype)
+        y = self.forward_nhwc(zz, c)
+        if y.t.requires_grad:
+            raise NotImplementedError("PainterSpadeDecoder.forward: under autograd use forward_nhwc / "
+                                      "OmniGenerator.paint(..., nhwc=True) (the layout pass has no backward kernel)")
+        return ops.nhwc_to_nchw(y).to(cond.dtype)

@@ -4,6 +4,11 @@ conversion of the reference, every arithmetic step a HIP kernel behind the C ABI
 
 Built: the flood event (Masker -> mask -> Painter).  Smog and wildfire (rows N1, ``trainer.py:1821-1842,1879-1939``)
 are not built yet: asking for them raises NotImplementedError instead of silently skipping.
+
+Training half (row H2), Painter tasks only (``opts.tasks == ["p"]``): ``setup(inference=False)`` builds G, D, the
+losses and the two ExtraAdam optimisers; ``update_G`` / ``update_D`` / ``train_step`` reproduce the "rf" branch of
+``get_painter_loss`` (trainer.py:1256-1387) and ``get_D_loss`` (trainer.py:1073-1107) and the extrapolate / step
+schedule (trainer.py:674-694).  Masker domains raise (training-mode BatchNorm and the masker losses are not built).
 """
 import time
 
@@ -52,15 +57,143 @@ class Trainer:
         self.has_painter = "p" in opts.tasks
 
     def setup(self, inference=False):
-        """reference trainer.py:701-760 (inference branch: generator only)."""
-        if not inference:
-            raise NotImplementedError("Trainer.setup(inference=False): the training harness (SURVEY row H2) is not built")
-        self.G = create_generator(self.opts, device=self.device, no_init=True, verbose=self.verbose)
+        """reference trainer.py:701-789."""
+        self.G = create_generator(self.opts, device=self.device, no_init=inference, verbose=self.verbose)
         if self.has_painter:
             self.G.painter.set_latent_shape(find_target_size(self.opts, "x"), True)       # trainer.py:727-728
-        self.G.eval()
+        if inference:
+            self.G.eval()
+            self.is_setup = True
+            return self
+        if list(self.opts.tasks) != ["p"]:
+            raise NotImplementedError("Trainer.setup(inference=False): only the Painter tasks (opts.tasks == ['p']) "
+                                      "have a HIP training path; Masker training (training-mode BatchNorm, masker "
+                                      "losses) is not built")
+        from .discriminator import create_discriminator
+        from .losses import FeatMatchLoss, GANLoss, VGGLoss
+        from .optim import ExtraAdam
+
+        o = self.opts
+        self.D = create_discriminator(o, self.device, verbose=self.verbose)
+        self.G.train()
+        self.D.train()
+        # get_losses (losses.py:369-441): GAN (BCE form, label smoothing / flipping on the D side only), feature
+        # matching, VGG
+        self.losses = {
+            "G": {"p": {"gan": GANLoss(use_lsgan=False, soft_shift=0.0, flip_prob=0.0),
+                        "featmatch": FeatMatchLoss(),
+                        "vgg": VGGLoss(self.device) if o.train.lambdas.G.p.vgg != 0 else None}},
+            "D": {"p": GANLoss(use_lsgan=False, soft_shift=o.dis.soft_shift, flip_prob=o.dis.flip_prob)},
+        }
+        g_params = [p for p in self.G.parameters() if p.requires_grad]
+        d_params = [p for p in self.D.parameters() if p.requires_grad]
+        self.g_opt = ExtraAdam(g_params, lr=o.gen.opt.lr.default, betas=(o.gen.opt.beta1, 0.999))
+        self.d_opt = ExtraAdam(d_params, lr=o.dis.opt.lr.default, betas=(o.dis.opt.beta1, 0.999))
+        self.global_step = 0
+        self.loss_log = {}
         self.is_setup = True
         return self
+
+    # ------------------------------------------------------------------------------------------ training
+    def _painter_terms(self, batch, for_g):
+        """D(cat_batch[real, fake]) on NHWC inputs built by the heads kernel; returns (real_d, fake_d, vgg pair)."""
+        from .autograd import PainterHeadsFn
+        from .tutils import divide_pred
+
+        x, m = batch["data"]["x"], batch["data"]["m"]
+        dt = self.G.painter.compute_dtype
+        want_vgg = for_g and self.losses["G"]["p"]["vgg"] is not None
+        if for_g:
+            fake = self.G.paint_nhwc(m, x)
+        else:
+            with torch.no_grad():                                     # trainer.py:1076-1083
+                fake = self.G.paint_nhwc(m, x)
+        real_in, vgg_real = ops.painter_heads(None, x, m, dt, True, want_vgg)
+        if for_g:
+            fake_in_t, vgg_fake_t = PainterHeadsFn.apply(fake.t, x, m, True, want_vgg)
+        else:
+            fake_in, _ = ops.painter_heads(fake, x, m, dt, True, False)
+            fake_in_t, vgg_fake_t = fake_in.t, None
+        real_fake_cat = ops.NHWC(torch.cat([real_in.t, fake_in_t], dim=0), 4)            # trainer.py:1103,1363
+        real_fake_d = self.D["p"](real_fake_cat, nhwc=True)
+        real_d, fake_d = divide_pred(real_fake_d)
+        vgg = (ops.NHWC(vgg_fake_t, 3), vgg_real) if want_vgg else None
+        return real_d, fake_d, vgg
+
+    def get_painter_loss(self, multi_domain_batch):
+        """reference trainer.py:1256-1387 (single-discriminator branch; TV / context / reconstruction lambdas are 0 in
+        defaults.yaml:293-300 and have no HIP kernel: non-zero values raise)."""
+        lambdas = self.opts.train.lambdas
+        for k in ("tv", "context", "reconstruction"):
+            if lambdas.G.p[k] != 0:
+                raise NotImplementedError("painter loss '%s' has no HIP kernel (lambda must be 0)" % k)
+        real_d, fake_d, vgg = self._painter_terms(multi_domain_batch["rf"], True)
+        step_loss = 0
+        if vgg is not None:
+            loss = self.losses["G"]["p"]["vgg"](vgg[0], vgg[1]) * lambdas.G.p.vgg
+            self.loss_log["G.p.vgg"] = loss.detach()
+            step_loss = step_loss + loss
+        loss = self.losses["G"]["p"]["gan"](fake_d, True, False)        # not scaled by lambdas.G.p.gan (trainer.py:1369-1371)
+        self.loss_log["G.p.gan"] = loss.detach()
+        step_loss = step_loss + loss
+        if self.opts.dis.p.get_intermediate_features and lambdas.G.p.featmatch != 0:
+            loss = self.losses["G"]["p"]["featmatch"](real_d, fake_d) * lambdas.G.p.featmatch
+            self.loss_log["G.p.featmatch"] = loss.detach()
+            step_loss = step_loss + loss
+        return step_loss
+
+    def get_D_loss(self, multi_domain_batch):
+        """reference trainer.py:1034-1160, Painter branch (1073-1107)."""
+        real_d, fake_d, _ = self._painter_terms(multi_domain_batch["rf"], False)
+        loss = self.losses["D"]["p"](fake_d, False, True)
+        loss = loss + self.losses["D"]["p"](real_d, True, True)
+        self.loss_log["D.p.gan"] = loss.detach()
+        return loss
+
+    def _check_batch(self, multi_domain_batch):
+        extra = [d for d in multi_domain_batch if d != "rf"]
+        if extra:
+            raise NotImplementedError("Trainer: masker domains %s have no HIP training path yet" % extra)
+
+    def update_G(self, multi_domain_batch):
+        """reference trainer.py:989-1015 + g_opt_step (674-683): D frozen, backward, extrapolate (even) / step (odd)."""
+        self._check_batch(multi_domain_batch)
+        for p in self.D.parameters():                                   # trainer.py:959-962
+            p.requires_grad_(False)
+        try:
+            self.g_opt.zero_grad(set_to_none=True)
+            g_loss = self.get_painter_loss(multi_domain_batch)
+            g_loss.backward()
+            if self.global_step % 2 == 0:
+                self.g_opt.extrapolation()
+            else:
+                self.g_opt.step()
+        finally:
+            self._restore_d_grad_flags()                                # trainer.py:971-973
+        return g_loss.detach()
+
+    def _restore_d_grad_flags(self):
+        for name, p in self.D.named_parameters():
+            p.requires_grad_(not (name.endswith("weight_u") or name.endswith("weight_v")))
+
+    def update_D(self, multi_domain_batch):
+        """reference trainer.py:1017-1032 + d_opt_step (685-694)."""
+        self._check_batch(multi_domain_batch)
+        self.d_opt.zero_grad(set_to_none=True)
+        d_loss = self.get_D_loss(multi_domain_batch)
+        d_loss.backward()
+        if self.global_step % 2 == 0:
+            self.d_opt.extrapolation()
+        else:
+            self.d_opt.step()
+        return d_loss.detach()
+
+    def train_step(self, multi_domain_batch):
+        """One iteration of run_epoch's loop body (trainer.py:939-976): G update, D update, step counter."""
+        g = self.update_G(multi_domain_batch)
+        d = self.update_D(multi_domain_batch)
+        self.global_step += 1
+        return g, d
 
     # ------------------------------------------------------------------------------------------ events
     def compute_flood(self, x, z=None, z_depth=None, m=None, s=None, cloudy=None, bin_value=-1):

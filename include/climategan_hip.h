@@ -289,6 +289,25 @@ int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t numel, flo
 int cgan_spectral_norm_bwd(float* grad_w, const float* w_bar, const float* u, const float* v, const float* sigma,
                            int32_t rows, int32_t cols, float* workspace_scalar, void* stream);
 
+/* Painter training-step glue (climategan/trainer.py:1256-1387 G side, 1073-1107 D side).
+ * heads_fwd: p = fake ? x (1 - m) + fake m : x  (the paste of generator.py:295-296; fake NHWC 3 channels stored as 8,
+ *   x / m NCHW fp32), then d_in = [m | p] (torch.cat([m, x], axis=1), trainer.py:1101-1102; 4 channels stored as 8)
+ *   and vgg_in = vgg_preprocess(p * m) (tutils.py:416-427: BGR, (t + 1) * 255 * 0.5 - mean; 3 channels stored as 8);
+ *   either output may be NULL.  heads_bwd: d_fake = m * (d_d_in[1..3] + 127.5 m d_vgg_in[BGR -> RGB]). */
+int cgan_painter_heads_fwd(const void* fake_nhwc, const float* x_nchw, const float* m_nchw, void* d_in, void* vgg_in,
+                           int32_t dtype, int32_t n, int32_t h, int32_t w, void* stream);
+int cgan_painter_heads_bwd(const void* d_d_in, const void* d_vgg_in, const float* m_nchw, void* d_fake, int32_t dtype,
+                           int32_t n, int32_t h, int32_t w, void* stream);
+/* backward of cgan_avgpool3x3s2_nhwc: dy [n][h_out][w_out][cs] -> dx [n][h_in][w_in][cs] */
+int cgan_avgpool3x3s2_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                               int32_t w_in, void* stream);
+/* nn.MaxPool2d(2, 2) of the VGG19 feature extractor (climategan/losses.py:304-334) and its backward (dy routed to the
+ * first maximum of each window, torch's tie rule) */
+int cgan_maxpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                         void* stream);
+int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                             int32_t w_in, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Output post-ops of the inference harness (Trainer.infer_all, climategan/trainer.py:311-332)
  * ------------------------------------------------------------------------------------------------ */

@@ -481,3 +481,35 @@ def painter_d_step(sd_d: SD, m: torch.Tensor, x: torch.Tensor, fake: torch.Tenso
         if k.endswith("weight_u") or k.endswith("weight_v"):
             sd_d[k] = params[k].detach()
     return loss.detach(), dict(zip(keys, grads))
+
+
+def feat_match_loss(pred_real, pred_fake) -> torch.Tensor:
+    """``FeatMatchLoss.__call__`` (losses.py:86-103)."""
+    num_D = len(pred_fake)
+    loss = 0.0
+    for i in range(num_D):
+        for j in range(len(pred_fake[i]) - 1):
+            loss = loss + F.l1_loss(pred_fake[i][j], pred_real[i][j].detach()) / num_D
+    return loss
+
+
+def painter_g_step(sd_p: SD, sd_d: SD, m: torch.Tensor, x: torch.Tensor, z_h: int, z_w: int, num_D: int, n_layers: int,
+                   lambda_featmatch: float = 10.0):
+    """G-side painter loss of ``get_painter_loss`` (trainer.py:1256-1387, single-discriminator branch, VGG / TV /
+    context / reconstruction off): fake = paint(m, x); D on cat_batch[cat_ch(m, x), cat_ch(m, fake)];
+    GANLoss(fake_d, True) (unscaled, trainer.py:1369-1371) + lambda * FeatMatch(real_d, fake_d); gradients w.r.t. the
+    Painter's trainable tensors (D frozen).  Returns (loss, {key: grad}, {term: value})."""
+    pp = {k: v.clone().requires_grad_(not (k.endswith("weight_u") or k.endswith("weight_v"))) for k, v in sd_p.items()}
+    dd = {k: v.clone() for k, v in sd_d.items()}
+    fake = paint(pp, m, x, z_h, z_w)
+    real_cat = torch.cat([m, x], dim=1)
+    fake_cat = torch.cat([m, fake], dim=1)
+    out = multiscale_discriminator(torch.cat([real_cat, fake_cat], dim=0), dd, num_D, n_layers)
+    real_d = [[t[: t.size(0) // 2] for t in p] for p in out]
+    fake_d = [[t[t.size(0) // 2:] for t in p] for p in out]
+    gan = gan_loss(fake_d, True)
+    fm = feat_match_loss(real_d, fake_d) * lambda_featmatch
+    loss = gan + fm
+    keys = [k for k, v in pp.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [pp[k] for k in keys])
+    return loss.detach(), dict(zip(keys, grads)), {"gan": gan.detach(), "featmatch": fm.detach()}

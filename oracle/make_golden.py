@@ -34,6 +34,7 @@ def golden_cases():
         "masker_small": dict(kind="masker", H=128, W=160, B=1, seed=61, gain=1.6),
         "infer_small": dict(kind="infer", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
+        "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -63,6 +64,9 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    if k == "gstep_p":
+        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
+                    m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
     if k == "dstep_p":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
@@ -258,6 +262,50 @@ def run_reference_dstep(name, case):
     return out
 
 
+def run_reference_gstep(name, case):
+    """The G side of the Painter step with the reference's own modules: ``OmniGenerator.paint`` around the reference
+    Painter, the reference D, ``GANLoss`` / ``FeatMatchLoss`` as built by ``get_losses``, the single-discriminator
+    branch of ``get_painter_loss`` (trainer.py:1359-1385) with the VGG term off, D frozen, ``backward()``."""
+    from oracle import ref_shim
+
+    gen = ref_shim.ref("generator")
+    disc = ref_shim.ref("discriminator")
+    losses = ref_shim.ref("losses")
+    tutils = ref_shim.ref("tutils")
+    painter, _ = build_reference_module(dict(case, kind="painter"))
+    painter.train()
+    G = gen.OmniGenerator.__new__(gen.OmniGenerator)
+    torch.nn.Module.__init__(G)
+    G.opts = _painter_opts(case)
+    G.painter = painter
+    D = disc.define_D(input_nc=4, ndf=case["ndf"], n_layers=case["n_layers"], norm="instance", use_sigmoid=False,
+                      get_intermediate_features=True, num_D=case["num_D"])
+    dshapes = {key: tuple(v.shape) for key, v in D.state_dict().items()}
+    D.load_state_dict({key: t(v) for key, v in fill.fill_state_dict(dshapes, case["seed"] + 1).items()})
+    D.train()
+    for p in D.parameters():
+        p.requires_grad = False
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    x, m = inp["x"], inp["m"]
+    painter.set_latent_shape(tuple(x.shape), True)
+    gan, fm = losses.GANLoss(use_lsgan=False), losses.FeatMatchLoss()
+    fake_flooded = G.paint(m, x)
+    real_cat = torch.cat([m, x], axis=1)
+    fake_cat = torch.cat([m, fake_flooded], axis=1)
+    real_fake_d = D(torch.cat([real_cat, fake_cat], dim=0))
+    real_d, fake_d = tutils.divide_pred(real_fake_d)
+    l_gan = gan(fake_d, True, False)
+    l_fm = fm(real_d, fake_d) * 10
+    loss = l_gan + l_fm
+    loss.backward()
+    out = {"loss": loss.detach().numpy().reshape(1), "gan": l_gan.detach().numpy().reshape(1),
+           "featmatch": l_fm.detach().numpy().reshape(1), "fake": fake_flooded.detach().numpy()}
+    for key, p in painter.named_parameters():
+        if p.requires_grad:
+            out["grad." + key] = p.grad.numpy().copy()
+    return out
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -297,6 +345,8 @@ def run_reference(name, case):
         return run_reference_infer(name, case)
     if case["kind"] == "dstep_p":
         return run_reference_dstep(name, case)
+    if case["kind"] == "gstep_p":
+        return run_reference_gstep(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}

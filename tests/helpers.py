@@ -28,6 +28,8 @@ def module_shapes(case):
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k == "disc_fc":
         return disc_fc_shapes(case["num_classes"])
+    if k == "gstep_p":
+        return painter_shapes(case["latent_dim"], case["n_up"])
     if k == "dstep_p":
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
     if k in ("extra_adam", "masker", "infer"):
@@ -190,6 +192,27 @@ def run_oracle_dstep(name, case):
     return out
 
 
+def gstep_d_state_dict(case):
+    shapes = disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
+    return {k: t(v) for k, v in fill.fill_state_dict(shapes, case["seed"] + 1).items()}
+
+
+def run_oracle_gstep(name, case):
+    sd_p = case_state_dict(case)
+    sd_d = gstep_d_state_dict(case)
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+    z_h, z_w = case["H"] // 2 ** case["n_up"], case["W"] // 2 ** case["n_up"]
+    with torch.no_grad():
+        fake = cpu_ref.paint({k: v.clone() for k, v in sd_p.items()}, inp["m"], inp["x"], z_h, z_w)
+    loss, grads, terms = cpu_ref.painter_g_step(sd_p, sd_d, inp["m"], inp["x"], z_h, z_w, case["num_D"],
+                                                case["n_layers"])
+    out = {"loss": loss.numpy().reshape(1), "gan": terms["gan"].numpy().reshape(1),
+           "featmatch": terms["featmatch"].numpy().reshape(1), "fake": fake.numpy()}
+    for k, g in grads.items():
+        out["grad." + k] = g.numpy()
+    return out
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
@@ -200,6 +223,8 @@ def run_oracle(name, case, dtype=torch.float32):
         return run_oracle_infer(name, case)
     if case["kind"] == "dstep_p":
         return run_oracle_dstep(name, case)
+    if case["kind"] == "gstep_p":
+        return run_oracle_gstep(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}
