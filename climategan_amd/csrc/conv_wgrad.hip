@@ -26,7 +26,7 @@ struct WgradArgs {
   int cout, cout_s;
   int kh, kw, stride, pad, dil;
   int h_out, w_out, npix;
-  int nchunks, ci_blocks;
+  int nchunks, ci_blocks, splits;
   int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
 };
 
@@ -54,9 +54,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tap = blockIdx.y;
+  // blockIdx.x -> (pixel split, tap): ids that differ by 8 share an XCD (one L2); the taps of one pixel split sit on
+  // the same XCD and walk the same chunks together, so the dy / x slabs are fetched from HBM once, not once per tap
+  const int taps_n = p.kh * p.kw;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tap = slot % taps_n;
+  const int split = (slot / taps_n) * 8 + xcd;
+  if (split >= p.splits) return;
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
-  const int cob = blockIdx.z / p.ci_blocks, cib = blockIdx.z - cob * p.ci_blocks;
+  const int cob = blockIdx.y / p.ci_blocks, cib = blockIdx.y - cob * p.ci_blocks;
   const int co0 = cob * 64, ci0 = cib * 64;
   unsigned char* wl = smem + wave * WAVE_LDS;
 
@@ -100,10 +106,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int c = blockIdx.x, buf = 0;
+  int c = split, buf = 0;
   if (c < p.nchunks) issue(c, 0);
-  for (; c < p.nchunks; c += gridDim.x) {
-    const int cn = c + gridDim.x;
+  for (; c < p.nchunks; c += p.splits) {
+    const int cn = c + p.splits;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier fragment reads of the other buffer are done
     if (cn < p.nchunks) {
       issue(cn, buf ^ 1);
@@ -154,15 +160,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   }
 }
 
-// per-channel sum over pixels of an NHWC tensor (bias gradient): fp32 atomics into out[c]
+// per-channel sum over pixels of an NHWC tensor (bias gradient): per-thread partial sums over a strided pixel subset,
+// reduced across the block's pixel lanes in LDS, then ONE fp32 atomic per channel per block
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
                                                           long npix, int cs, int c) {
+  extern __shared__ __attribute__((aligned(16))) float sm_cs[];   // [ppb][groups * 8]
   const int groups = cs / 8;
-  const int gi = threadIdx.x % groups;               // channel group of this thread (blockDim % groups == 0 not needed)
-  const int lanes_per_pix = groups;
-  const int ppb = blockDim.x / lanes_per_pix;        // pixels per block iteration
-  const int pl = threadIdx.x / lanes_per_pix;
+  const int ppb = blockDim.x / groups;               // pixel lanes per block
+  const int gi = threadIdx.x % groups, pl = threadIdx.x / groups;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (pl < ppb) {
     for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
@@ -176,8 +182,14 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
       }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (gi * 8 + e < c) atomicAdd(out + gi * 8 + e, s[e]);
+    for (int e = 0; e < 8; ++e) sm_cs[(pl * groups + gi) * 8 + e] = s[e];
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < groups * 8; ch += blockDim.x) {
+    if (ch >= c) continue;
+    float acc = 0.f;
+    for (int l = 0; l < ppb; ++l) acc += sm_cs[l * groups * 8 + ch];
+    atomicAdd(out + ch, acc);
   }
 }
 
@@ -212,27 +224,30 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   int splits = ceil_div(2048, taps * blocks);
   if (splits > a.nchunks) splits = a.nchunks;
   if (splits < 1) splits = 1;
-  CGAN_REQUIRE(blocks <= 65535 && taps <= 65535, "conv2d_nhwc_bwd_weight: grid too large");
+  CGAN_REQUIRE(blocks <= 65535, "conv2d_nhwc_bwd_weight: grid too large");
+  a.splits = splits;
+  const int gx = ceil_div(splits, 8) * 8 * taps;
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = 4 * WAVE_LDS;   // 64 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
   if (d->dtype == CGAN_F16)
-    hipLaunchKernelGGL(conv_wgrad_kernel<F16>, dim3(splits, taps, blocks), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<F16>, dim3(gx, blocks), dim3(256), smem, s, a);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(splits, taps, blocks), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(gx, blocks), dim3(256), smem, s, a);
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
   if (dbias) {
     const int cs = a.cout_s;
     const int threads = 256;
     const int ppb = threads / (cs / 8) > 0 ? threads / (cs / 8) : 1;
     CGAN_REQUIRE(cs / 8 <= threads, "conv2d_nhwc_bwd_weight: too many channels for the bias reduction");
-    long want = (npix + (long)ppb * 64 - 1) / ((long)ppb * 64);
-    const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    long want = (npix + (long)ppb * 16 - 1) / ((long)ppb * 16);
+    const int grid = (int)(want < 1 ? 1 : (want > 512 ? 512 : want));
+    const size_t smem_b = (size_t)ppb * (cs / 8) * 8 * sizeof(float);
     if (d->dtype == CGAN_F16)
-      hipLaunchKernelGGL(channel_sum_kernel<F16>, dim3(grid), dim3(threads), 0, s, (const uint16_t*)dy, dbias, npix, cs,
-                         d->c_out);
+      hipLaunchKernelGGL(channel_sum_kernel<F16>, dim3(grid), dim3(threads), smem_b, s, (const uint16_t*)dy, dbias, npix,
+                         cs, d->c_out);
     else
-      hipLaunchKernelGGL(channel_sum_kernel<BF16>, dim3(grid), dim3(threads), 0, s, (const uint16_t*)dy, dbias, npix, cs,
-                         d->c_out);
+      hipLaunchKernelGGL(channel_sum_kernel<BF16>, dim3(grid), dim3(threads), smem_b, s, (const uint16_t*)dy, dbias, npix,
+                         cs, d->c_out);
     CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(bias)");
   }
   return CGAN_OK;
