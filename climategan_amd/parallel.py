@@ -1,0 +1,118 @@
+"""Data-parallel gradient exchange for the training step: one process per GPU, RCCL through
+``torch.distributed`` (backend "nccl" on ROCm), replicas of G and D, **bucketed all-reduce (average) of the gradients,
+launched from post-accumulate-grad hooks while the rest of the backward is still running**.
+
+Stock DistributedDataParallel cannot wrap ``OmniGenerator`` (it has no ``forward``; the trainer calls ``encode`` /
+``paint`` / decoders directly), and this package's gradients come out of custom autograd Functions anyway, so the
+reducer works on the parameter list:
+
+* parameters are grouped into ~25 MB buckets in REVERSE registration order (the order gradients become ready: the
+  Painter's last layers / D's output conv first);
+* a bucket's all-reduce is issued (``async_op=True``, on RCCL's own stream) as soon as its last gradient has been
+  accumulated; xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound: few
+  large messages, not one per tensor (105 M G parameters = 17 buckets);
+* ``finish()`` waits for the outstanding buckets, and copies the averaged values back into ``param.grad``.  ExtraAdam
+  needs it before both ``extrapolation()`` and ``step()`` (reference trainer.py:678-683).
+
+``broadcast_parameters`` makes replicas identical at start (parameters AND buffers, incl. the spectral-norm ``u``/``v``
+vectors, which are parameters with ``requires_grad=False``).
+"""
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """Rank ``src``'s parameters and buffers to every rank (C3)."""
+    if not is_distributed():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = None
+        self.pending = len(params)
+        self.work = None
+
+
+class GradBucketReducer:
+    """Bucketed, overlapped gradient averaging over the default process group."""
+
+    def __init__(self, params, bucket_mb: float = 25.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size() if is_distributed() else 1
+        cap = int(bucket_mb * 2 ** 20)
+        self.buckets: List[_Bucket] = []
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):                        # reverse registration ~ order of gradient readiness
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > cap:
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.reset()
+
+    def reset(self):
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.work = None
+
+    def _launch(self, b: _Bucket):
+        grads = [p.grad for p in b.params]
+        if b.flat is None or b.flat.device != grads[0].device:
+            b.flat = torch.empty(b.numel, dtype=grads[0].dtype, device=grads[0].device)
+        off = 0
+        for g in grads:
+            b.flat[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        if self.world == 1:
+            return
+        b = self._bucket_of[id(p)]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Wait for every bucket (launching the ones whose parameters received no gradient this step as zeros would be
+        wrong: parameters without a gradient are skipped on every rank alike) and write the averages back."""
+        if self.world == 1:
+            self.reset()
+            return
+        for b in self.buckets:
+            if b.pending != 0:
+                if all(p.grad is None for p in b.params):
+                    continue
+                missing = [p for p in b.params if p.grad is None]
+                if missing:
+                    raise RuntimeError("GradBucketReducer: %d parameters of a bucket got no gradient while others did; "
+                                       "replicas would diverge" % len(missing))
+                self._launch(b)
+            b.work.wait()
+            off = 0
+            inv = 1.0 / self.world
+            for p in b.params:
+                n = p.numel()
+                p.grad.copy_(b.flat[off:off + n].reshape(p.grad.shape) * inv)
+                off += n
+        self.reset()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()

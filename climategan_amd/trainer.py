@@ -91,6 +91,15 @@ class Trainer:
         self.d_opt = ExtraAdam(d_params, lr=o.dis.opt.lr.default, betas=(o.dis.opt.beta1, 0.999))
         self.global_step = 0
         self.loss_log = {}
+        # data parallel (one process per GPU, launched by torchrun): identical replicas, bucketed gradient all-reduce
+        # overlapped with the backward
+        from .parallel import GradBucketReducer, broadcast_parameters, is_distributed
+        self.g_reducer = self.d_reducer = None
+        if is_distributed():
+            broadcast_parameters(self.G)
+            broadcast_parameters(self.D)
+            self.g_reducer = GradBucketReducer(g_params)
+            self.d_reducer = GradBucketReducer(d_params)
         self.is_setup = True
         return self
 
@@ -164,6 +173,8 @@ class Trainer:
             self.g_opt.zero_grad(set_to_none=True)
             g_loss = self.get_painter_loss(multi_domain_batch)
             g_loss.backward()
+            if self.g_reducer is not None:
+                self.g_reducer.finish()                                 # before extrapolation AND step (trainer.py:678-683)
             if self.global_step % 2 == 0:
                 self.g_opt.extrapolation()
             else:
@@ -182,6 +193,8 @@ class Trainer:
         self.d_opt.zero_grad(set_to_none=True)
         d_loss = self.get_D_loss(multi_domain_batch)
         d_loss.backward()
+        if self.d_reducer is not None:
+            self.d_reducer.finish()
         if self.global_step % 2 == 0:
             self.d_opt.extrapolation()
         else:

@@ -65,3 +65,70 @@ def test_two_rank_timing_and_aggregation():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config"):
         assert key in d
+
+
+def _reducer_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climategan_amd.parallel import GradBucketReducer, broadcast_parameters
+        torch.manual_seed(100 + rank)                                   # replicas start different ...
+        net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.Tanh(), torch.nn.Linear(33, 5))
+        frozen = torch.nn.Parameter(torch.randn(4), requires_grad=False)  # like spectral norm's u / v
+        net.register_parameter("frozen", frozen)
+        broadcast_parameters(net)                                       # ... and are made identical
+        ref = [p.detach().clone() for p in net.parameters()]
+        red = GradBucketReducer(net.parameters(), bucket_mb=0.001)      # tiny cap -> several buckets
+        nb = len(red.buckets)
+        outs = []
+        for step in range(2):                                           # two steps: buckets re-arm
+            net.zero_grad(set_to_none=True)
+            x = torch.full((3, 7), float(rank + 1 + step))
+            net(x).sum().backward()
+            red.finish()
+            outs.append([p.grad.clone() for p in net.parameters() if p.requires_grad])
+        q.put((rank, nb, [t.numpy() for t in ref], [[g.numpy() for g in o] for o in outs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_averages_over_ranks_gloo():
+    """world_size 2 on gloo: after broadcast both ranks hold rank 0's parameters; after backward + finish() both hold
+    the MEAN of the two ranks' gradients (checked against a single-process evaluation of both inputs)."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 7
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, nb0, ref0, outs0), (_, nb1, ref1, outs1) = res
+    assert nb0 == nb1 and nb0 >= 2
+    for a, b in zip(ref0, ref1):
+        assert np.array_equal(a, b)                                     # broadcast made replicas identical
+    # expected: mean over ranks of the local gradients, from a local re-evaluation with rank 0's parameters
+    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.Tanh(), torch.nn.Linear(33, 5))
+    net.register_parameter("frozen", torch.nn.Parameter(torch.zeros(4), requires_grad=False))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), ref0):
+            p.copy_(torch.from_numpy(v))
+    for step in range(2):
+        exp = None
+        for rank in range(2):
+            net.zero_grad(set_to_none=True)
+            net(torch.full((3, 7), float(rank + 1 + step))).sum().backward()
+            g = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+            exp = g if exp is None else [a + b for a, b in zip(exp, g)]
+        exp = [e / 2 for e in exp]
+        for o in (outs0[step], outs1[step]):
+            for got, e in zip(o, exp):
+                assert np.allclose(got, e.numpy(), rtol=1e-6, atol=1e-7)
