@@ -240,6 +240,38 @@ def result_line(world, steps, warmup, elapsed, dtype_name):
     }
 
 
+def train_block(train_steps, rank, world, device, dtype, dist, barrier, x, m):
+    """Supplementary measurement (not `value`): the Painter G+D training step (BASELINE metric's "G+D step", Painter
+    tasks only -- the Masker has no training path yet): Trainer.train_step = update_G (paint, D, GAN + feature-matching
+    + VGG losses, backward, ExtraAdam) + update_D, data-parallel over the ranks with the bucketed RCCL all-reduce of
+    climategan_amd/parallel.py.  Same barrier / synchronize / max-over-ranks timing as the main line."""
+    from climategan_amd import fill
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    opts = default_opts()
+    opts.tasks = ["p"]
+    opts.gen.p.latent_dim = LATENT
+    opts.gen.p.spade_n_up = N_UP
+    T = Trainer(opts, device=device).setup(inference=False)
+    for mod, seed in ((T.G, 0), (T.D, 1)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=seed).items()})
+    T.G.set_compute_dtype(dtype)
+    T.D.set_compute_dtype(dtype)
+    T.G.painter.set_latent_shape(x.shape, True)
+    batch = {"rf": {"data": {"x": x, "m": m}}}
+    elapsed = timed_steps(lambda: T.train_step(batch), train_steps, 1, barrier)
+    elapsed = max_over_ranks(elapsed, dist, device)
+    losses = {k: round(float(v), 4) for k, v in T.loss_log.items()}
+    return {"workload": "Painter G+D train step (Trainer.train_step: update_G + update_D, ExtraAdam; GAN + "
+                        "feature-matching + VGG(random init) losses), 640x640, batch %d per GPU, data-parallel "
+                        "bucketed gradient all-reduce" % BATCH_PER_GPU,
+            "images_per_s": round(world * BATCH_PER_GPU * train_steps / elapsed, 2),
+            "ms_per_step": round(elapsed / train_steps * 1e3, 1), "steps": train_steps, "warmup": 1,
+            "losses_last_step": losses}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +279,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3,
+                    help="timed steps of the supplementary Painter G+D training-step measurement (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,6 +329,13 @@ def main():
     assert y.shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(y).all()
     elapsed = max_over_ranks(elapsed, dist, device)
 
+    train = None
+    if args.train_steps > 0:
+        try:
+            train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier, x, m)
+        except Exception as e:  # the main line must survive a failure of the supplementary block
+            train = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         layers, flops_img = spade_layer_table(LATENT, N_UP, H, W)
         spade_ms = timer.total_ms()
@@ -324,6 +365,7 @@ def main():
                 "share_of_step": round(spade_ms / (elapsed * 1e3), 3),
             },
         })
+        res["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd)
         else:
