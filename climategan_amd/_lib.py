@@ -111,6 +111,9 @@ _SIGNATURES = {
     "cgan_normalize_u8_nhwc": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
                                          _P]),
     "cgan_binarize": (C.c_int, [_P, C.c_int32, _P, _P, C.c_float, C.c_int64, _P]),
+    "cgan_smog_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "cgan_smog_nchw": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _P, C.c_size_t, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

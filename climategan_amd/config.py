@@ -67,6 +67,10 @@ def default_opts() -> Opts:
             "m": {"architecture": "base", "gan_type": "WGAN_norm"},      # :229-235
             "s": {"gan_type": "WGAN_norm"},                              # :236-240
         },
+        "events": {"smog": {"airlight": 0.76, "beta": 2, "vr": 1, "yellow_color": [224, 192, 29], "alpha": 20},
+                   "fire": {"kernel_size": 281, "kernel_sigma": 140.5, "transparency": 200, "sky_inc_factor": 0.12,
+                            "contrast_factor": 1.5, "brightness_factor": 0.95, "crop_bottom_sky_mask": True}},
+        # shared/trainer/events.yaml:1-14
         "train": {"lambdas": {"G": {"p": {"context": 0, "dm": 1, "featmatch": 10, "gan": 1, "reconstruction": 0,
                                           "tv": 0, "vgg": 10}}}},          # :293-300
     })

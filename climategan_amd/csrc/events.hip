@@ -98,6 +98,91 @@ __global__ void __launch_bounds__(256)
   if (y_u8) y_u8[i] = on ? 255 : 0;
 }
 
+
+// ---- smog event (Trainer.compute_smog, climategan/trainer.py:1879-1939; HazeRD model) ---------------------------
+// per-image min / max of channel 0 of an NHWC 16-bit map
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_c0_kernel(const uint16_t* __restrict__ d, int* ws, long hw, int cs) {
+  const int img = blockIdx.y;
+  const uint16_t* base = d + (long)img * hw * cs;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    float v = f32_of_bits<T>(base[i * cs]);
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  __shared__ float smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mn = fminf(mn, smn[w]);
+      mx = fmaxf(mx, smx[w]);
+    }
+    atomicMin(&ws[2 * img], f2key(mn));
+    atomicMax(&ws[2 * img + 1], f2key(mx));
+  }
+}
+
+struct SmogParams {
+  float airlight, beta, alpha, yellow[3];
+};
+
+// depth -> normalize(.., 0.3, 1) -> 1/. -> normalize(.., 0.1, 1)   (trainer.py:1908-1910), at one low-res pixel.
+// The extrema of the reciprocal map follow from those of the first normalisation (1/. is monotone).
+__device__ __forceinline__ float smog_depth(float d, float dmin, float dmax) {
+  const float t = __fdiv_rn(d - dmin, dmax - dmin);
+  const float d1 = 0.3f + 0.7f * t;
+  const float inv = __fdiv_rn(1.f, d1);
+  const float inv_min = __fdiv_rn(1.f, 0.3f + 0.7f * 1.f);
+  const float inv_max = __fdiv_rn(1.f, 0.3f + 0.7f * 0.f);
+  const float t2 = __fdiv_rn(inv - inv_min, inv_max - inv_min);
+  return 0.1f + 0.9f * t2;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    smog_kernel(const float* __restrict__ x, const uint16_t* __restrict__ d, const int* __restrict__ ws_x,
+                const int* __restrict__ ws_d, float* __restrict__ out, int h, int w, int dh, int dw, int cs,
+                SmogParams prm, float sy, float sx, long total) {
+  const long hw = (long)h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    const int oy = (int)(p / w), ox = (int)(p - (long)oy * w);
+    // bilinear, align_corners=True (trainer.py:1915-1917)
+    const float fy = oy * sy, fx = ox * sx;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < dh - 1 ? y0 : dh - 1;
+    x0 = x0 < dw - 1 ? x0 : dw - 1;
+    const int y1 = y0 < dh - 1 ? y0 + 1 : y0, x1 = x0 < dw - 1 ? x0 + 1 : x0;
+    const float ly = fy - y0, lx = fx - x0;
+    const float dmin = key2f(ws_d[2 * n]), dmax = key2f(ws_d[2 * n + 1]);
+    const uint16_t* db = d + n * (long)dh * dw * cs;
+    const float d00 = smog_depth(f32_of_bits<T>(db[((long)y0 * dw + x0) * cs]), dmin, dmax);
+    const float d01 = smog_depth(f32_of_bits<T>(db[((long)y0 * dw + x1) * cs]), dmin, dmax);
+    const float d10 = smog_depth(f32_of_bits<T>(db[((long)y1 * dw + x0) * cs]), dmin, dmax);
+    const float d11 = smog_depth(f32_of_bits<T>(db[((long)y1 * dw + x1) * cs]), dmin, dmax);
+    const float dd = (1.f - ly) * ((1.f - lx) * d00 + lx * d01) + ly * ((1.f - lx) * d10 + lx * d11);
+    const float tr = expf(-prm.beta * dd);
+    const float xmin = key2f(ws_x[2 * n]), xden = key2f(ws_x[2 * n + 1]) - xmin;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xn = __fdiv_rn(x[(n * 3 + c) * hw + p] - xmin, xden);                     // tutils.normalize
+      const float irr = xn <= 0.04045f ? xn / 12.92f : powf((xn + 0.055f) / 1.055f, 2.4f);  // srgb2lrgb
+      const float sm = tr * irr + (1.f - tr) * prm.airlight;
+      const float srgb = sm <= 0.0031308f ? 12.92f * sm : 1.055f * powf(sm, 1.f / 2.4f) - 0.055f;   // lrgb2srgb
+      out[(n * 3 + c) * hw + p] = srgb * (1.f - prm.alpha) + prm.yellow[c] * prm.alpha;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cgan_normalize_u8_workspace_bytes(int32_t n) { return n > 0 ? (size_t)n * 2 * sizeof(int) : 0; }
@@ -135,5 +220,46 @@ extern "C" int cgan_binarize(const void* x, int32_t is_half, void* y, uint8_t* y
   else
     hipLaunchKernelGGL(binarize_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, x, y, y_u8, threshold, (long)numel);
   CGAN_CHECK_LAUNCH("binarize");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_smog_workspace_bytes(int32_t n) { return n > 0 ? (size_t)n * 4 * sizeof(int) : 0; }
+
+extern "C" int cgan_smog_nchw(const float* x_nchw, const void* depth_nhwc, int32_t dtype, float* out_nchw, int32_t n,
+                              int32_t h, int32_t w, int32_t dh, int32_t dw, float airlight, float beta, float alpha,
+                              const float* yellow_rgb01, void* workspace, size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(x_nchw && depth_nhwc && out_nchw && yellow_rgb01 && workspace, "smog: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "smog: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && h > 0 && w > 0 && dh > 0 && dw > 0, "smog: bad shape");
+  CGAN_REQUIRE(workspace_bytes >= cgan_smog_workspace_bytes(n), "smog: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int* ws_x = (int*)workspace;
+  int* ws_d = ws_x + 2 * n;
+  hipLaunchKernelGGL(minmax_init_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, s, ws_x, 2 * n);
+  const long per_image = 3L * h * w;
+  long want = (per_image + 256 * 16 - 1) / (256 * 16);
+  int bpi = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+  hipLaunchKernelGGL(minmax_kernel<false>, dim3(bpi, n), dim3(256), 0, s, (const void*)x_nchw, ws_x, per_image);
+  const long dhw = (long)dh * dw;
+  want = (dhw + 256 * 4 - 1) / (256 * 4);
+  bpi = (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
+  const int cs = 8;   // one-channel map stored with 8 channels
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(minmax_c0_kernel<F16>, dim3(bpi, n), dim3(256), 0, s, (const uint16_t*)depth_nhwc, ws_d, dhw, cs);
+  else
+    hipLaunchKernelGGL(minmax_c0_kernel<BF16>, dim3(bpi, n), dim3(256), 0, s, (const uint16_t*)depth_nhwc, ws_d, dhw, cs);
+  SmogParams prm;
+  prm.airlight = airlight; prm.beta = beta; prm.alpha = alpha;
+  prm.yellow[0] = yellow_rgb01[0]; prm.yellow[1] = yellow_rgb01[1]; prm.yellow[2] = yellow_rgb01[2];
+  const float sy = h > 1 ? (float)(dh - 1) / (float)(h - 1) : 0.f, sx = w > 1 ? (float)(dw - 1) / (float)(w - 1) : 0.f;
+  const long total = (long)n * h * w;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(smog_kernel<F16>, dim3(grid), dim3(256), 0, s, x_nchw, (const uint16_t*)depth_nhwc, ws_x, ws_d,
+                       out_nchw, h, w, dh, dw, cs, prm, sy, sx, total);
+  else
+    hipLaunchKernelGGL(smog_kernel<BF16>, dim3(grid), dim3(256), 0, s, x_nchw, (const uint16_t*)depth_nhwc, ws_x, ws_d,
+                       out_nchw, h, w, dh, dw, cs, prm, sy, sx, total);
+  CGAN_CHECK_LAUNCH("smog");
   return CGAN_OK;
 }

@@ -246,6 +246,27 @@ def binarize(x: torch.Tensor, threshold: float, want_float: bool = True, want_ui
     return y if want_float else y8
 
 
+def smog(x: torch.Tensor, depth: NHWC, airlight: float, beta: float, alpha: float, yellow_rgb01) -> torch.Tensor:
+    """Smog event (reference trainer.py:1879-1939): x NCHW fp32 in [-1, 1], depth the decoder's 1-channel NHWC map;
+    returns the smogged image, NCHW fp32."""
+    _need_cuda(x, depth.t)
+    if depth.c != 1 or depth.cs != 8:
+        raise RuntimeError("smog: a one-channel depth map stored with 8 channels is expected")
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    if c != 3 or depth.n != n:
+        raise RuntimeError("smog: x must be [n,3,h,w] with the depth map's batch size")
+    lib = _lib.load()
+    nbytes = lib.cgan_smog_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    yel = (C.c_float * 3)(*[float(v) for v in yellow_rgb01])
+    _lib.check(lib.cgan_smog_nchw(_ptr(x), _ptr(depth.t), depth.dtype_id, _ptr(out), n, h, w, depth.h, depth.w,
+                                  float(airlight), float(beta), float(alpha), yel, _ptr(ws), nbytes, _stream()),
+               "cgan_smog_nchw")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:

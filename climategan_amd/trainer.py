@@ -2,8 +2,9 @@
 ``Trainer.setup(inference=True)``, ``infer_all`` and ``compute_flood`` -- the stage order, binarisation and uint8
 conversion of the reference, every arithmetic step a HIP kernel behind the C ABI.
 
-Built: the flood event (Masker -> mask -> Painter).  Smog and wildfire (rows N1, ``trainer.py:1821-1842,1879-1939``)
-are not built yet: asking for them raises NotImplementedError instead of silently skipping.
+Built: the flood event (Masker -> mask -> Painter) and the smog event (depth -> HazeRD transmission model).  Wildfire
+(row N1, ``trainer.py:1821-1842``, fire.py: kornia / torchvision arithmetic that is not in the reference tree) is not
+built: asking for it raises NotImplementedError instead of silently skipping.
 
 Training half (row H2), Painter tasks only (``opts.tasks == ["p"]``): ``setup(inference=False)`` builds G, D, the
 losses and the two ExtraAdam optimisers; ``update_G`` / ``update_D`` / ``train_step`` reproduce the "rf" branch of
@@ -228,7 +229,17 @@ class Trainer:
         raise NotImplementedError("wildfire event (trainer.py:1821-1842, fire.py) has no HIP path yet (SURVEY row N1)")
 
     def compute_smog(self, x, z=None, d=None, s=None, use_sky_seg=False):
-        raise NotImplementedError("smog event (trainer.py:1879-1939) has no HIP path yet (SURVEY row N1)")
+        """reference trainer.py:1879-1939 (``use_sky_seg`` is a no-op there too: the sky mask is never built).
+        ``d``: the depth decoder's NHWC map (``G.decoders["d"].forward_nhwc``) or None."""
+        if d is None:
+            if z is None:
+                z = self.G.encode(x)
+            d, _ = self.G.decoders["d"].forward_nhwc(z)
+        if not isinstance(d, ops.NHWC):
+            raise TypeError("compute_smog: d must be the NHWC depth map of this package's depth decoder")
+        prm = self.opts.events.smog
+        out = ops.smog(x, d, prm.airlight, prm.beta / prm.vr, prm.alpha / 255.0, [v / 255.0 for v in prm.yellow_color])
+        return out.to(x.dtype)
 
     @torch.no_grad()
     def infer_all(self, x, numpy=True, stores={}, bin_value=-1, half=False, xla=False, cloudy=False,

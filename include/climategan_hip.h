@@ -322,6 +322,17 @@ int cgan_normalize_u8_nhwc(const void* x_nchw, int32_t is_half, uint8_t* out_nhw
  * `((mask > bin_value) * 255).astype(uint8)` (trainer.py:329-332) into y_u8 (may be NULL) */
 int cgan_binarize(const void* x, int32_t is_half, void* y, uint8_t* y_u8, float threshold, int64_t numel, void* stream);
 
+/* Smog event (Trainer.compute_smog, climategan/trainer.py:1879-1939, parameters shared/trainer/events.yaml:9-14):
+ * irradiance = srgb2lrgb(normalize(x)) (tutils.py:534-538), depth = normalize(1 / normalize(d, 0.3, 1), 0.1, 1)
+ * bilinearly resized (align_corners=True) to (h, w), transmission = exp(-beta depth),
+ * out = lrgb2srgb(t irradiance + (1 - t) airlight) (1 - alpha) + yellow alpha.
+ * x_nchw fp32 [n][3][h][w]; depth_nhwc: the depth decoder's 16-bit map [n][dh][dw][8] (channel 0); yellow_rgb01:
+ * HOST pointer to 3 floats in [0, 1]; out_nchw fp32 [n][3][h][w]; workspace cgan_smog_workspace_bytes(n). */
+size_t cgan_smog_workspace_bytes(int32_t n);
+int cgan_smog_nchw(const float* x_nchw, const void* depth_nhwc, int32_t dtype, float* out_nchw, int32_t n, int32_t h,
+                   int32_t w, int32_t dh, int32_t dw, float airlight, float beta, float alpha, const float* yellow_rgb01,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -513,3 +513,31 @@ def painter_g_step(sd_p: SD, sd_d: SD, m: torch.Tensor, x: torch.Tensor, z_h: in
     keys = [k for k, v in pp.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [pp[k] for k in keys])
     return loss.detach(), dict(zip(keys, grads)), {"gan": gan.detach(), "featmatch": fm.detach()}
+
+
+# --------------------------------------------------------------------------------------------------
+# Smog event: Trainer.compute_smog (climategan/trainer.py:1879-1939), tutils.srgb2lrgb / lrgb2srgb (:534-565)
+# --------------------------------------------------------------------------------------------------
+def srgb2lrgb(x: torch.Tensor) -> torch.Tensor:
+    x = normalize(x)
+    im = ((x + 0.055) / 1.055) ** 2.4
+    return torch.where(x <= 0.04045, x / 12.92, im)
+
+
+def lrgb2srgb(im: torch.Tensor) -> torch.Tensor:
+    return torch.where(im <= 0.0031308, 12.92 * im, 1.055 * torch.pow(im.clamp_min(0), 1 / 2.4) - 0.055)
+
+
+def compute_smog(x: torch.Tensor, d: torch.Tensor, airlight=0.76, beta=2.0, vr=1.0, yellow_color=(224, 192, 29),
+                 alpha=20.0) -> torch.Tensor:
+    """HazeRD smog model with the parameters of shared/trainer/events.yaml:9-14."""
+    irradiance = srgb2lrgb(x)
+    d = normalize(d, mini=0.3, maxi=1.0)
+    d = 1.0 / d
+    d = normalize(d, mini=0.1, maxi=1)
+    d = F.interpolate(d, size=x.shape[-2:], mode="bilinear", align_corners=True).repeat(1, 3, 1, 1)
+    transmission = torch.exp(d * -(beta / vr))
+    smogged = lrgb2srgb(transmission * irradiance + (1 - transmission) * airlight)
+    a = alpha / 255
+    yellow = (torch.tensor(yellow_color, dtype=x.dtype) / 255).view(1, 3, 1, 1)
+    return smogged * (1 - a) + yellow * a

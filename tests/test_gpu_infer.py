@@ -129,6 +129,37 @@ def test_resize_bicubic(dt):
     assert (got - ref).abs().max() <= tol * max(ref.abs().max().item(), 1.0)
 
 
+def test_smog_event_matches_reference_golden():
+    """compute_smog (HIP) fed the REFERENCE's own depth map (rounded to fp16 NHWC) against the reference's smog tensor
+    captured inside Trainer.infer_all: sRGB <-> linear, the double depth normalisation, bilinear resize, transmission
+    and the yellow blend in fp32 -> 2e-3 absolute on values in [0, 1]; then the uint8 image within one level."""
+    from climategan_amd import ops
+
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    T = build_trainer(case)
+    x = t(case_inputs(NAME, case)["x"]).cuda()
+    d = ops.nchw_to_nhwc(t(gold["d"]).cuda(), torch.float16)
+    smog = T.compute_smog(x, d=d)
+    err = np.abs(smog.cpu().numpy() - gold["smog"])
+    assert err.max() <= 2e-3, err.max()
+    d8 = np.abs(ops.normalize_to_uint8(smog).cpu().numpy().astype(np.int32) - gold["smog_u8"].astype(np.int32))
+    assert d8.max() <= 1, d8.max()
+
+
+def test_infer_all_smog_end_to_end():
+    """infer_all with the HIP depth decoder feeding the smog event: the picture the reference produced, up to the 16-bit
+    depth error (mean absolute difference below 2 grey levels, 99 % of the pixels within 6)."""
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    T = build_trainer(case)
+    x = t(case_inputs(NAME, case)["x"]).cuda()
+    out = T.infer_all(x, numpy=True, bin_value=case["bin_value"], ignore_event={"wildfire"})
+    assert set(out) == {"flood", "smog"}
+    d8 = np.abs(out["smog"].astype(np.int32) - gold["smog_u8"].astype(np.int32))
+    assert d8.mean() < 2.0 and np.percentile(d8, 99) <= 6, (d8.mean(), np.percentile(d8, 99), d8.max())
+
+
 def test_unbuilt_events_fail_loudly():
     case = golden_cases()[NAME]
     T = build_trainer(case)

@@ -105,3 +105,20 @@ def test_oracle_matches_golden_painter_d_step():
         # biases in front of an instance norm have an exactly-zero gradient (the norm removes the mean): fp32 noise only
         assert err <= 1e-4 * scale + 1e-7, "%s/%s: max abs err %.3g (scale %.3g)" % (name, k, err, scale)
     assert any(k.startswith("grad.") and np.abs(v).max() > 0 for k, v in gold.items())
+
+
+def test_oracle_smog_matches_golden():
+    """cpu_ref.compute_smog on the reference's own depth map vs the smog tensor captured inside the reference's
+    Trainer.infer_all (and its uint8 image)."""
+    import torch
+    from helpers import t
+    from oracle import cpu_ref
+    from oracle.make_golden import case_inputs
+
+    name = "infer_small"
+    gold = load_golden(name)
+    x = t(case_inputs(name, CASES[name])["x"])
+    smog = cpu_ref.compute_smog(x, t(gold["d"]))
+    assert np.abs(smog.numpy() - gold["smog"]).max() <= 1e-5
+    d8 = np.abs(cpu_ref.to_uint8_hwc(smog).astype(np.int32) - gold["smog_u8"].astype(np.int32))
+    assert d8.max() <= 1 and (d8 > 0).mean() < 5e-3
