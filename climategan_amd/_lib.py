@@ -114,6 +114,10 @@ _SIGNATURES = {
     "cgan_smog_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_smog_nchw": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _P, C.c_size_t, _P]),
+    "cgan_cloudy_cond_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cgan_cloudy_cond_nhwc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P,
+                                        C.c_size_t, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -183,6 +183,84 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ---- cloudy painting (OmniGenerator.paint_cloudy, generator.py:299-328; tutils.mix_noise / rand_perlin_2d :647-694) --
+// Perlin noise map [h][w] from (res_y+1) x (res_x+1) gradient angles; also tracks the global minimum (ws[0], as a key).
+__global__ void __launch_bounds__(256)
+    perlin_kernel(const float* __restrict__ angles, float* __restrict__ noise, int* __restrict__ ws, int h, int w,
+                  int res_y, int res_x) {
+  const double dy = (double)res_y / (double)h, dx = (double)res_x / (double)w;
+  const int ty = h / res_y, tx = w / res_x;   // pixels per lattice cell (repeat_interleave factors)
+  float mn = __builtin_inff();
+  const long total = (long)h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / w), x = (int)(i - (long)y * w);
+    const float gy = fmodf((float)(y * dy), 1.f), gx = fmodf((float)(x * dx), 1.f);   // torch.arange(...) % 1
+    const int cy = y / ty, cx = x / tx;
+    auto dot = [&](int iy, int ix, float sy, float sx) {
+      const float a = angles[iy * (res_x + 1) + ix];
+      return (gy + sy) * cosf(a) + (gx + sx) * sinf(a);
+    };
+    const float n00 = dot(cy, cx, 0.f, 0.f), n10 = dot(cy + 1, cx, -1.f, 0.f);
+    const float n01 = dot(cy, cx + 1, 0.f, -1.f), n11 = dot(cy + 1, cx + 1, -1.f, -1.f);
+    auto fade = [](float t) { return 6.f * t * t * t * t * t - 15.f * t * t * t * t + 10.f * t * t * t; };
+    const float t0 = fade(gy), t1 = fade(gx);
+    const float a = n00 + t0 * (n10 - n00), b = n01 + t0 * (n11 - n01);           // torch.lerp(s, e, w) = s + w (e - s)
+    const float v = 1.41421356237309515f * (a + t1 * (b - a));
+    noise[i] = v;
+    mn = fminf(mn, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+  if ((threadIdx.x & 63) == 0) atomicMin(&ws[0], f2key(mn));
+}
+
+// cond = noised_x * (1 - m): noised_x = sky ? weight * (noise - min) + (1 - weight) * x : x, sky = argmax_c of the
+// bilinearly up-sampled (align_corners=False) segmentation logits == sky_idx.  cond: NHWC, 3 channels stored as 4.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    cloudy_cond_kernel(const float* __restrict__ x, const float* __restrict__ m, const uint16_t* __restrict__ seg,
+                       const float* __restrict__ noise, const int* __restrict__ ws, uint16_t* __restrict__ cond,
+                       int h, int w, int sh, int sw, int sc, int scs, int sky_idx, float weight, float ry, float rx,
+                       long total) {
+  const long hw = (long)h * w;
+  const float nmin = key2f(ws[0]);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    const int oy = (int)(p / w), ox = (int)(p - (long)oy * w);
+    const float fy = fmaxf((oy + 0.5f) * ry - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * rx - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < sh - 1 ? y0 : sh - 1;
+    x0 = x0 < sw - 1 ? x0 : sw - 1;
+    const int y1 = y0 < sh - 1 ? y0 + 1 : y0, x1 = x0 < sw - 1 ? x0 + 1 : x0;
+    const float ly = fy - y0, lx = fx - x0;
+    const uint16_t* sb = seg + n * (long)sh * sw * scs;
+    const uint16_t* p00 = sb + ((long)y0 * sw + x0) * scs;
+    const uint16_t* p01 = sb + ((long)y0 * sw + x1) * scs;
+    const uint16_t* p10 = sb + ((long)y1 * sw + x0) * scs;
+    const uint16_t* p11 = sb + ((long)y1 * sw + x1) * scs;
+    int best = 0;
+    float bv = -__builtin_inff();
+    for (int c = 0; c < sc; ++c) {
+      const float v = (1.f - ly) * ((1.f - lx) * f32_of_bits<T>(p00[c]) + lx * f32_of_bits<T>(p01[c])) +
+                      ly * ((1.f - lx) * f32_of_bits<T>(p10[c]) + lx * f32_of_bits<T>(p11[c]));
+      if (v > bv) { bv = v; best = c; }   // first maximum, as torch.argmax
+    }
+    const bool sky = best == sky_idx;
+    const float nz = noise[p] - nmin;
+    const float keep = 1.f - m[i];
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xv = x[(n * 3 + c) * hw + p];
+      o[c] = (sky ? weight * nz + (1.f - weight) * xv : xv) * keep;
+    }
+    u32x2 r;
+    r[0] = pack2<T>(o[0], o[1]);
+    r[1] = pack2<T>(o[2], 0.f);
+    reinterpret_cast<u32x2*>(cond)[i] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cgan_normalize_u8_workspace_bytes(int32_t n) { return n > 0 ? (size_t)n * 2 * sizeof(int) : 0; }
@@ -261,5 +339,44 @@ extern "C" int cgan_smog_nchw(const float* x_nchw, const void* depth_nhwc, int32
     hipLaunchKernelGGL(smog_kernel<BF16>, dim3(grid), dim3(256), 0, s, x_nchw, (const uint16_t*)depth_nhwc, ws_x, ws_d,
                        out_nchw, h, w, dh, dw, cs, prm, sy, sx, total);
   CGAN_CHECK_LAUNCH("smog");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_cloudy_cond_workspace_bytes(int32_t h, int32_t w) {
+  return (h > 0 && w > 0) ? (size_t)h * w * sizeof(float) + 16 : 0;
+}
+
+extern "C" int cgan_cloudy_cond_nhwc(const float* x_nchw, const float* m_nchw, const void* seg_nhwc,
+                                     const float* angles, void* cond_nhwc, int32_t dtype, int32_t n, int32_t h,
+                                     int32_t w, int32_t seg_h, int32_t seg_w, int32_t seg_c, int32_t sky_idx,
+                                     int32_t res_y, int32_t res_x, float weight, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  CGAN_REQUIRE(x_nchw && m_nchw && seg_nhwc && angles && cond_nhwc && workspace, "cloudy_cond: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "cloudy_cond: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && h > 0 && w > 0 && seg_h > 0 && seg_w > 0 && seg_c > 0, "cloudy_cond: bad shape");
+  CGAN_REQUIRE(res_y > 0 && res_x > 0 && (h % res_y) == 0 && (w % res_x) == 0,
+               "cloudy_cond: the image extent must be a multiple of the Perlin resolution (%d, %d)", res_y, res_x);
+  CGAN_REQUIRE(sky_idx >= 0 && sky_idx < seg_c, "cloudy_cond: bad sky index");
+  CGAN_REQUIRE(workspace_bytes >= cgan_cloudy_cond_workspace_bytes(h, w), "cloudy_cond: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int* ws = (int*)workspace;                 // [0]: min key (+ padding to 16 B), then the noise map
+  float* noise = (float*)((char*)workspace + 16);
+  hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, ws, 1);
+  const long hw = (long)h * w;
+  hipLaunchKernelGGL(perlin_kernel, dim3((unsigned)((hw + 255) / 256 > 2048 ? 2048 : (hw + 255) / 256)), dim3(256), 0, s,
+                     angles, noise, ws, h, w, res_y, res_x);
+  const long total = (long)n * hw;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  const float ry = (float)seg_h / (float)h, rx = (float)seg_w / (float)w;
+  const int scs = cgan_cs(seg_c);
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(cloudy_cond_kernel<F16>, dim3(grid), dim3(256), 0, s, x_nchw, m_nchw, (const uint16_t*)seg_nhwc,
+                       (const float*)noise, (const int*)ws, (uint16_t*)cond_nhwc, h, w, seg_h, seg_w, seg_c, scs, sky_idx,
+                       weight, ry, rx, total);
+  else
+    hipLaunchKernelGGL(cloudy_cond_kernel<BF16>, dim3(grid), dim3(256), 0, s, x_nchw, m_nchw, (const uint16_t*)seg_nhwc,
+                       (const float*)noise, (const int*)ws, (uint16_t*)cond_nhwc, h, w, seg_h, seg_w, seg_c, scs, sky_idx,
+                       weight, ry, rx, total);
+  CGAN_CHECK_LAUNCH("cloudy_cond");
   return CGAN_OK;
 }

@@ -130,6 +130,28 @@ class OmniGenerator(nn.Module):
             z = z.half()
         return z
 
+    def paint_cloudy(self, m, x, s, sky_idx=9, res=(8, 8), weight=0.8):
+        """reference generator.py:299-328: the Painter is probed with an intermediary image whose sky (class ``sky_idx``
+        of the bilinearly up-sampled segmentation ``s``) is replaced by Perlin clouds; the result is pasted on the
+        ORIGINAL x.  ``s``: the segmentation decoder's NHWC logits (``decoders["s"].forward_nhwc``).  The lattice angles
+        are drawn with ``torch.rand`` on the host like the reference does (tutils.py:660), so a seeded run sees the same
+        clouds."""
+        import math
+
+        if not isinstance(s, ops.NHWC):
+            raise TypeError("paint_cloudy: s must be the NHWC logits of this package's segmentation decoder")
+        p = self.painter
+        dt = p.compute_dtype
+        angles = (2 * math.pi * torch.rand(res[0] + 1, res[1] + 1)).to(x.device)
+        m = m.to(x.dtype)
+        cond = ops.cloudy_cond(x, m, s, angles, sky_idx=sky_idx, weight=weight)       # noised_x * (1 - m)
+        z = self.sample_painter_z(x.shape[0], x.device)
+        zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
+        fake = p.forward_nhwc(zz, cond)                                                # paint(m, noised_x, no_paste=True)
+        if fake.t.requires_grad:
+            raise NotImplementedError("paint_cloudy is an inference path (call under torch.no_grad())")
+        return ops.nhwc_to_nchw(fake, paste_x=x, paste_m=m).to(x.dtype)               # x * (1 - m) + fake * m
+
     def paint_nhwc(self, m, x):
         """Training-path form of ``paint``: returns the Painter's raw output (before the paste) as a differentiable
         NHWC map; the paste x (1 - m) + fake m and what follows it (discriminator input, VGG input) are produced by

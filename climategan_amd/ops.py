@@ -267,6 +267,25 @@ def smog(x: torch.Tensor, depth: NHWC, airlight: float, beta: float, alpha: floa
     return out
 
 
+def cloudy_cond(x: torch.Tensor, m: torch.Tensor, seg: NHWC, angles: torch.Tensor, sky_idx=9, weight=0.8) -> NHWC:
+    """Painter conditioning of paint_cloudy (reference generator.py:319-326): the sky of x replaced by Perlin clouds,
+    times (1 - m); ``angles`` [(ry+1), (rx+1)] fp32 device tensor of lattice gradient angles."""
+    _need_cuda(x, m, seg.t, angles)
+    x = x.contiguous().float()
+    m = m.contiguous().float()
+    angles = angles.contiguous().float()
+    n, _, h, w = x.shape
+    ry, rx = angles.shape[0] - 1, angles.shape[1] - 1
+    lib = _lib.load()
+    nbytes = lib.cgan_cloudy_cond_workspace_bytes(h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    cond = torch.empty((n, h, w, 4), dtype=seg.t.dtype, device=x.device)
+    _lib.check(lib.cgan_cloudy_cond_nhwc(_ptr(x), _ptr(m), _ptr(seg.t), _ptr(angles), _ptr(cond), seg.dtype_id, n, h, w,
+                                         seg.h, seg.w, seg.c, int(sky_idx), ry, rx, float(weight), _ptr(ws), nbytes,
+                                         _stream()), "cgan_cloudy_cond_nhwc")
+    return NHWC(cond, 3)
+
+
 # ------------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:

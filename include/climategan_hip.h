@@ -333,6 +333,18 @@ int cgan_smog_nchw(const float* x_nchw, const void* depth_nhwc, int32_t dtype, f
                    int32_t w, int32_t dh, int32_t dw, float airlight, float beta, float alpha, const float* yellow_rgb01,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Conditioning image of OmniGenerator.paint_cloudy (climategan/generator.py:299-328): sky = argmax_c(bilinear(s -> (h,w),
+ * align_corners=False)) == sky_idx; noised = sky ? weight (perlin - min(perlin)) + (1 - weight) x : x
+ * (tutils.mix_noise / rand_perlin_2d, tutils.py:647-694, one noise map per call); cond = noised (1 - m), NHWC with the 3
+ * channels stored as 4 (what the Painter consumes).  angles: DEVICE fp32 [(res_y+1)][(res_x+1)] = 2 pi U(0,1) drawn
+ * by the caller (the reference draws them with torch.rand); seg_nhwc: the segmentation decoder's 16-bit logits
+ * [n][seg_h][seg_w][cgan_cs(seg_c)]; workspace cgan_cloudy_cond_workspace_bytes(h, w). */
+size_t cgan_cloudy_cond_workspace_bytes(int32_t h, int32_t w);
+int cgan_cloudy_cond_nhwc(const float* x_nchw, const float* m_nchw, const void* seg_nhwc, const float* angles,
+                          void* cond_nhwc, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t seg_h, int32_t seg_w,
+                          int32_t seg_c, int32_t sky_idx, int32_t res_y, int32_t res_x, float weight, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -541,3 +541,43 @@ def compute_smog(x: torch.Tensor, d: torch.Tensor, airlight=0.76, beta=2.0, vr=1
     a = alpha / 255
     yellow = (torch.tensor(yellow_color, dtype=x.dtype) / 255).view(1, 3, 1, 1)
     return smogged * (1 - a) + yellow * a
+
+
+# --------------------------------------------------------------------------------------------------
+# Cloudy painting: OmniGenerator.paint_cloudy (generator.py:299-328), tutils.rand_perlin_2d / mix_noise (:647-694)
+# --------------------------------------------------------------------------------------------------
+def perlin_2d(shape, res, angles: torch.Tensor) -> torch.Tensor:
+    """``rand_perlin_2d`` with the lattice angles given (the reference draws ``2 pi torch.rand(res+1)``)."""
+    import math
+
+    delta = (res[0] / shape[0], res[1] / shape[1])
+    d = (shape[0] // res[0], shape[1] // res[1])
+    grid = torch.stack(torch.meshgrid(torch.arange(0, res[0], delta[0]), torch.arange(0, res[1], delta[1]),
+                                      indexing="ij"), dim=-1) % 1
+    grid = grid[: shape[0], : shape[1]]
+    gradients = torch.stack((torch.cos(angles), torch.sin(angles)), dim=-1)
+
+    def tile(s1, s2):
+        return gradients[s1[0]:s1[1], s2[0]:s2[1]].repeat_interleave(d[0], 0).repeat_interleave(d[1], 1)
+
+    def dot(grad, shift):
+        return (torch.stack((grid[..., 0] + shift[0], grid[..., 1] + shift[1]), dim=-1)
+                * grad[: shape[0], : shape[1]]).sum(dim=-1)
+
+    n00 = dot(tile([0, -1], [0, -1]), [0, 0])
+    n10 = dot(tile([1, None], [0, -1]), [-1, 0])
+    n01 = dot(tile([0, -1], [1, None]), [0, -1])
+    n11 = dot(tile([1, None], [1, None]), [-1, -1])
+    t = 6 * grid ** 5 - 15 * grid ** 4 + 10 * grid ** 3
+    return math.sqrt(2) * torch.lerp(torch.lerp(n00, n10, t[..., 0]), torch.lerp(n01, n11, t[..., 0]), t[..., 1])
+
+
+def paint_cloudy(sd_p: SD, m, x, s, z_h, z_w, angles, sky_idx=9, res=(8, 8), weight=0.8, update=True):
+    """``OmniGenerator.paint_cloudy``: sd_p = painter state dict, s = segmentation logits [B,11,h,w]."""
+    sky = (torch.argmax(F.interpolate(s, x.shape[-2:], mode="bilinear"), dim=1, keepdim=True) == sky_idx).to(x.dtype)
+    noise = perlin_2d(tuple(x.shape[-2:]), res, angles)[None, None]
+    noise = noise - noise.min()
+    mask = sky.repeat(1, 3, 1, 1)
+    noised = mask * (weight * noise + (1 - weight) * x) + (1 - mask) * x
+    fake = paint(sd_p, m, noised, z_h, z_w, no_paste=True, update=update)
+    return x * (1.0 - m) + fake * m

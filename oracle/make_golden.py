@@ -33,6 +33,8 @@ def golden_cases():
         "disc_fc": dict(kind="disc_fc", num_classes=11, H=64, W=96, B=2, seed=42),
         "masker_small": dict(kind="masker", H=128, W=160, B=1, seed=61, gain=1.6),
         "infer_small": dict(kind="infer", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43),
+        "cloudy_small": dict(kind="cloudy", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43,
+                             rng_seed=4321, sky_idx=6),   # class 6 covers 14 % of this untrained net's argmax map
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
@@ -71,7 +73,7 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
                     m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
-    if k in ("masker", "infer"):
+    if k in ("masker", "infer", "cloudy"):
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1))
     if k == "extra_adam":
         d = {}
@@ -229,6 +231,25 @@ def run_reference_infer(name, case):
     return out
 
 
+def run_reference_cloudy(name, case):
+    """``compute_flood(cloudy=True)`` -> ``OmniGenerator.paint_cloudy`` on the reference Trainer's generator, with the
+    global torch RNG seeded right before the call (the Perlin angles are its only random draw)."""
+    T, _ = reference_trainer(case)
+    x = t(case_inputs(name, case)["x"])
+    T.G.painter.set_latent_shape(x.shape, True)
+    with torch.no_grad():
+        z = T.G.encode(x)
+        depth, z_depth = T.G.decoders["d"](z)
+        seg = T.G.decoders["s"](z, z_depth)
+        mask = T.G.mask(z=z, z_depth=z_depth)
+        m_bin = (mask > case["bin_value"]).to(mask.dtype)
+        torch.manual_seed(case["rng_seed"])
+        flood = T.G.paint_cloudy(m_bin, x, seg, sky_idx=case["sky_idx"])      # what compute_flood(cloudy=True) calls
+    sky = torch.argmax(torch.nn.functional.interpolate(seg, x.shape[-2:], mode="bilinear"), 1) == case["sky_idx"]
+    return {"s": seg.numpy(), "m_bin": m_bin.numpy(), "flood": flood.numpy(),
+            "sky_fraction": np.array([sky.float().mean().item()], dtype=np.float32)}
+
+
 def run_reference_dstep(name, case):
     """The Painter branch of ``Trainer.get_D_loss`` (trainer.py:1073-1107) with the reference's own modules and
     losses (``GANLoss`` as built by ``get_losses``: BCE form, here soft_shift = flip_prob = 0), then
@@ -343,6 +364,8 @@ def run_reference(name, case):
         return run_reference_masker(name, case)
     if case["kind"] == "infer":
         return run_reference_infer(name, case)
+    if case["kind"] == "cloudy":
+        return run_reference_cloudy(name, case)
     if case["kind"] == "dstep_p":
         return run_reference_dstep(name, case)
     if case["kind"] == "gstep_p":

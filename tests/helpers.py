@@ -32,7 +32,7 @@ def module_shapes(case):
         return painter_shapes(case["latent_dim"], case["n_up"])
     if k == "dstep_p":
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
-    if k in ("extra_adam", "masker", "infer"):
+    if k in ("extra_adam", "masker", "infer", "cloudy"):
         return {}
     raise KeyError(k)
 
@@ -213,6 +213,21 @@ def run_oracle_gstep(name, case):
     return out
 
 
+def run_oracle_cloudy(name, case):
+    import math
+
+    gold = load_golden(name)
+    sd = infer_state_dict(case)
+    x = t(case_inputs(name, case)["x"])
+    torch.manual_seed(case["rng_seed"])
+    angles = 2 * math.pi * torch.rand(9, 9)
+    z_h, z_w = case["H"] // 2 ** case["n_up"], case["W"] // 2 ** case["n_up"]
+    with torch.no_grad():
+        flood = cpu_ref.paint_cloudy(cpu_ref.sub(sd, "painter"), t(gold["m_bin"]), x, t(gold["s"]), z_h, z_w, angles,
+                                     sky_idx=case["sky_idx"])
+    return {"flood": flood.numpy()}
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
@@ -221,6 +236,8 @@ def run_oracle(name, case, dtype=torch.float32):
         return run_oracle_masker(name, case)
     if case["kind"] == "infer":
         return run_oracle_infer(name, case)
+    if case["kind"] == "cloudy":
+        return run_oracle_cloudy(name, case)
     if case["kind"] == "dstep_p":
         return run_oracle_dstep(name, case)
     if case["kind"] == "gstep_p":
