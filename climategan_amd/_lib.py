@@ -118,6 +118,10 @@ _SIGNATURES = {
     "cgan_cloudy_cond_nhwc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P,
                                         C.c_size_t, _P]),
+    "cgan_bn_eval_stats": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, C.c_int32, C.c_int32, _P]),
+    "cgan_make_m_cond_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "cgan_make_m_cond_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

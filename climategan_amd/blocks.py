@@ -95,8 +95,15 @@ class Conv2dBlock(nn.Module):
             mean, rstd = ops.instnorm_stats(y, eps=self.norm.eps)
             return ops.norm_act_apply(y, mean, rstd, act=act, slope=0.2)
         if sn:
-            if self.norm is not None:
-                raise NotImplementedError("Conv2dBlock: spectral_batch has no HIP path yet")
+            if self.norm is not None:                                   # spectral_batch: SN conv -> BatchNorm -> act
+                if self.norm.training:
+                    raise NotImplementedError("BatchNorm2d in training mode (batch statistics) has no HIP path yet; "
+                                              "call .eval()")
+                if residual is not None:
+                    raise NotImplementedError("Conv2dBlock: residual + spectral_batch cannot be fused")
+                y = self.conv(x, pad=self.padding, pad_mode=pad_mode)
+                mean, rstd = ops.bn_eval_stats(self.norm, y.n)
+                return ops.norm_act_apply(y, mean, rstd, act=act, slope=0.2)
             return self.conv(x, pad=self.padding, pad_mode=pad_mode, act=act, slope=0.2, residual=residual)
         return conv_bn_forward(self.conv, self.norm, self._cache, x, pad_mode=pad_mode, pad=self.padding, act=act,
                                slope=0.2, residual=residual)
@@ -227,7 +234,8 @@ class SPADEResnetBlock(nn.Module):
         if self.last_activation not in (None, "lrelu"):
             raise NotImplementedError(
                 "The type of activation is not supported: {}".format(self.last_activation))
-        stats = ops.instnorm_stats(x, eps=self.norm_0.param_free_norm.eps)
+        # instance-norm statistics are shared by norm_0 and norm_s (same x); a batch param-free norm brings its own
+        stats = None if self.param_free_norm == "batch" else ops.instnorm_stats(x, eps=self.norm_0.param_free_norm.eps)
         if self.learned_shortcut:
             s = self.norm_s.forward_nhwc(x, cond, stats, act=ops.ACT_NONE, x_upsample=x_upsample)
             x_s = conv_forward(self.conv_s, self._caches["conv_s"], s, **self._tr(self.conv_s))

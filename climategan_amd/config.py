@@ -52,7 +52,10 @@ def default_opts() -> Opts:
                   "num_classes": 11},                                    # :135-143
             "m": {"use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
                   "use_dada": False, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
-                  "activ": "lrelu", "pad_type": "reflect"},              # :166-180 (+ default-gen :89-99)
+                  "activ": "lrelu", "pad_type": "reflect", "use_proj": True,
+                  "spade": {"latent_dim": 128, "detach": False, "cond_nc": 15, "spade_use_spectral_norm": True,
+                            "spade_param_free_norm": "batch", "num_layers": 3,
+                            "activations": {"all_lrelu": True}}},       # :166-190 (+ default-gen :89-99)
             "p": {                                                       # :144-165
                 "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True,
                 "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",

@@ -261,6 +261,66 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ---- eval-mode BatchNorm as per-(n, c) "mean / rstd" for the normalise(+act) and fused-SPADE kernels -----------------
+// y = (x - rm) / sqrt(rv + eps) * gamma + beta  ==  (x - mean') * rstd'  with rstd' = gamma / sqrt(rv + eps),
+// mean' = rm - beta / rstd'  (gamma, beta may be NULL: affine=False, the param-free norm of SPADE, norms.py:152-153)
+__global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int n, int c, int cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * cs) return;
+  const int ch = i % cs;
+  float m = 0.f, r = 0.f;
+  if (ch < c) {
+    r = rsqrtf(rv[ch] + eps) * (gamma ? gamma[ch] : 1.f);
+    m = rm[ch] - ((beta && r != 0.f) ? beta[ch] / r : 0.f);
+  }
+  mean[i] = m;
+  rstd[i] = r;
+}
+
+// ---- conditioning of the SPADE mask decoder (OmniGenerator.make_m_cond, generator.py:196-230) ---------------------------
+// cond = cat[normalize(d) (1), softmax(s, dim=1) (sc), bilinear(x -> (h, w), align_corners=True) (3)]  NHWC
+template <typename T>
+__global__ void __launch_bounds__(256)
+    make_m_cond_kernel(const uint16_t* __restrict__ d, const uint16_t* __restrict__ seg, const float* __restrict__ x,
+                       const int* __restrict__ ws_d, uint16_t* __restrict__ cond, int h, int w, int sc, int scs, int xh,
+                       int xw, int with_x, int ccs, float sy, float sx, long total) {
+  const long hw = (long)h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    uint16_t* o = cond + i * ccs;
+    const float dmin = key2f(ws_d[2 * n]), dmax = key2f(ws_d[2 * n + 1]);
+    o[0] = bits_of<T>(__fdiv_rn(f32_of_bits<T>(d[i * 8]) - dmin, dmax - dmin));
+    const uint16_t* sp = seg + i * scs;
+    float mx = -__builtin_inff();
+    for (int c = 0; c < sc; ++c) mx = fmaxf(mx, f32_of_bits<T>(sp[c]));
+    float sum = 0.f;
+    for (int c = 0; c < sc; ++c) sum += __expf(f32_of_bits<T>(sp[c]) - mx);
+    const float inv = 1.f / sum;
+    for (int c = 0; c < sc; ++c) o[1 + c] = bits_of<T>(__expf(f32_of_bits<T>(sp[c]) - mx) * inv);
+    int used = 1 + sc;
+    if (with_x) {
+      const int oy = (int)(p / w), ox = (int)(p - (long)oy * w);
+      const float fy = oy * sy, fx = ox * sx;
+      int y0 = (int)fy, x0 = (int)fx;
+      y0 = y0 < xh - 1 ? y0 : xh - 1;
+      x0 = x0 < xw - 1 ? x0 : xw - 1;
+      const int y1 = y0 < xh - 1 ? y0 + 1 : y0, x1 = x0 < xw - 1 ? x0 + 1 : x0;
+      const float ly = fy - y0, lx = fx - x0;
+      for (int c = 0; c < 3; ++c) {
+        const float* xb = x + (n * 3 + c) * (long)xh * xw;
+        const float v = (1.f - ly) * ((1.f - lx) * xb[(long)y0 * xw + x0] + lx * xb[(long)y0 * xw + x1]) +
+                        ly * ((1.f - lx) * xb[(long)y1 * xw + x0] + lx * xb[(long)y1 * xw + x1]);
+        o[used + c] = bits_of<T>(v);
+      }
+      used += 3;
+    }
+    for (int c = used; c < ccs; ++c) o[c] = 0;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cgan_normalize_u8_workspace_bytes(int32_t n) { return n > 0 ? (size_t)n * 2 * sizeof(int) : 0; }
@@ -378,5 +438,54 @@ extern "C" int cgan_cloudy_cond_nhwc(const float* x_nchw, const float* m_nchw, c
                        (const float*)noise, (const int*)ws, (uint16_t*)cond_nhwc, h, w, seg_h, seg_w, seg_c, scs, sky_idx,
                        weight, ry, rx, total);
   CGAN_CHECK_LAUNCH("cloudy_cond");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* mean, float* rstd, int32_t n, int32_t c,
+                                  void* stream) {
+  CGAN_REQUIRE(running_mean && running_var && mean && rstd, "bn_eval_stats: null pointer");
+  CGAN_REQUIRE(n > 0 && c > 0, "bn_eval_stats: bad shape");
+  const int cs = cgan_cs(c);
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((n * cs + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, mean, rstd, n, c, cs);
+  CGAN_CHECK_LAUNCH("bn_eval_stats");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_make_m_cond_workspace_bytes(int32_t n) { return n > 0 ? (size_t)n * 2 * sizeof(int) : 0; }
+
+extern "C" int cgan_make_m_cond_nhwc(const void* depth_nhwc, const void* seg_nhwc, const float* x_nchw, void* cond_nhwc,
+                                     int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t seg_c, int32_t x_h,
+                                     int32_t x_w, void* workspace, size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(depth_nhwc && seg_nhwc && cond_nhwc && workspace, "make_m_cond: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "make_m_cond: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && h > 0 && w > 0 && seg_c > 0, "make_m_cond: bad shape");
+  CGAN_REQUIRE(!x_nchw || (x_h > 0 && x_w > 0), "make_m_cond: bad x shape");
+  CGAN_REQUIRE(workspace_bytes >= cgan_make_m_cond_workspace_bytes(n), "make_m_cond: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int* ws = (int*)workspace;
+  hipLaunchKernelGGL(minmax_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, n);
+  const long hw = (long)h * w;
+  long want = (hw + 256 * 4 - 1) / (256 * 4);
+  const int bpi = (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
+  const int cond_c = 1 + seg_c + (x_nchw ? 3 : 0);
+  const int ccs = (cond_c + 3) & ~3;
+  const float sy = (x_nchw && h > 1) ? (float)(x_h - 1) / (float)(h - 1) : 0.f;
+  const float sx = (x_nchw && w > 1) ? (float)(x_w - 1) / (float)(w - 1) : 0.f;
+  const long total = (long)n * hw;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (dtype == CGAN_F16) {
+    hipLaunchKernelGGL(minmax_c0_kernel<F16>, dim3(bpi, n), dim3(256), 0, s, (const uint16_t*)depth_nhwc, ws, hw, 8);
+    hipLaunchKernelGGL(make_m_cond_kernel<F16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)depth_nhwc,
+                       (const uint16_t*)seg_nhwc, x_nchw, (const int*)ws, (uint16_t*)cond_nhwc, h, w, seg_c,
+                       cgan_cs(seg_c), x_h, x_w, x_nchw ? 1 : 0, ccs, sy, sx, total);
+  } else {
+    hipLaunchKernelGGL(minmax_c0_kernel<BF16>, dim3(bpi, n), dim3(256), 0, s, (const uint16_t*)depth_nhwc, ws, hw, 8);
+    hipLaunchKernelGGL(make_m_cond_kernel<BF16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)depth_nhwc,
+                       (const uint16_t*)seg_nhwc, x_nchw, (const int*)ws, (uint16_t*)cond_nhwc, h, w, seg_c,
+                       cgan_cs(seg_c), x_h, x_w, x_nchw ? 1 : 0, ccs, sy, sx, total);
+  }
+  CGAN_CHECK_LAUNCH("make_m_cond");
   return CGAN_OK;
 }

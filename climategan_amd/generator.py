@@ -69,10 +69,13 @@ class OmniGenerator(nn.Module):
         if "d" in self.decoders:
             d, z_depth = self.decoders["d"].forward_nhwc(z)
             out["d"] = ops.nhwc_to_nchw(d).to(x.dtype)
+        s_nhwc = None
         if "s" in self.decoders:
-            out["s"] = ops.nhwc_to_nchw(self.decoders["s"].forward_nhwc(z, z_depth)).to(x.dtype)
+            s_nhwc = self.decoders["s"].forward_nhwc(z, z_depth)
+            out["s"] = ops.nhwc_to_nchw(s_nhwc).to(x.dtype)
         if "m" in self.decoders:
-            out["m"] = self.mask(z=z, z_depth=z_depth, sigmoid=sigmoid).to(x.dtype)
+            cond = self.make_m_cond(d, s_nhwc, x) if self.opts.gen.m.use_spade else None     # trainer.py:285-286
+            out["m"] = self.mask(z=z, cond=cond, z_depth=z_depth, sigmoid=sigmoid).to(x.dtype)
         return out
 
     def decode(self, x=None, z=None, return_z=False, return_z_depth=False):
@@ -105,6 +108,17 @@ class OmniGenerator(nn.Module):
         d = ops.nhwc_to_nchw(d)
         return (d, z_depth) if return_z_depth else d
 
+    def make_m_cond(self, d, s, x=None):
+        """reference generator.py:196-230: cat[normalize(d), softmax(s), bilinear(x)] (x when cond_nc == 15).  d, s:
+        the NHWC maps of this package's depth / segmentation decoders; returns the NHWC conditioning map."""
+        if not (isinstance(d, ops.NHWC) and isinstance(s, ops.NHWC)):
+            raise TypeError("make_m_cond: d and s must be the NHWC maps of this package's decoders")
+        if self.opts.gen.m.spade.cond_nc == 15:
+            if x is None:
+                raise ValueError("When using spade for the Masker with 15 channels, x MUST be provided")
+            return ops.make_m_cond(d, s, x)
+        return ops.make_m_cond(d, s, None)
+
     def mask(self, x=None, z=None, cond=None, z_depth=None, sigmoid=True):
         """reference generator.py:232-277: logits = decoders["m"](z, cond, z_depth); sigmoid by default."""
         assert x is not None or z is not None
@@ -112,6 +126,11 @@ class OmniGenerator(nn.Module):
             z = self.encode(x)
         dec = self.decoders["m"]
         _grad_guard(dec)
+        if cond is None and self.opts.gen.m.use_spade:                       # generator.py:257-262
+            assert "s" in self.opts.tasks and "d" in self.opts.tasks
+            d_pred, z_d = self.decoders["d"].forward_nhwc(z)
+            s_pred = self.decoders["s"].forward_nhwc(z, z_d)
+            cond = self.make_m_cond(d_pred, s_pred, x)
         if z_depth is None and self.opts.gen.m.use_dada:
             _, z_depth = self.decoders["d"].forward_nhwc(z)
         spectral_norm_step_all(dec, z[0].t.dtype if isinstance(z, (tuple, list)) else z.t.dtype)

@@ -1,13 +1,15 @@
-"""Mask decoder -- mirror of the reference's ``climategan/masker.py`` (MaskBaseDecoder; MaskSpadeDecoder, the
-non-default SPADE-conditioned variant with batch-norm SPADE, is not built yet)."""
+"""Mask decoders -- mirror of the reference's ``climategan/masker.py``: MaskBaseDecoder (default) and MaskSpadeDecoder
+(``gen.m.use_spade``: the paper's final masker, SPADE blocks conditioned on depth / segmentation / image)."""
+import torch.nn as nn
+
 from . import ops
-from .blocks import BaseDecoder
+from .blocks import BaseDecoder, Conv2dBlock, InterpolateNearest2d, SPADEResnetBlock
 
 
 def create_mask_decoder(opts, no_init=False, verbose=0):
     """reference masker.py:13-22"""
     if opts.gen.m.use_spade:
-        raise NotImplementedError("MaskSpadeDecoder (gen.m.use_spade) has no HIP path yet")
+        return MaskSpadeDecoder(opts)
     return MaskBaseDecoder(opts)
 
 
@@ -25,4 +27,56 @@ class MaskBaseDecoder(BaseDecoder):
                          low_level_feats_dim=low, use_dada=("d" in opts.tasks) and opts.gen.m.use_dada)
 
     def forward(self, z, cond=None, z_depth=None):
+        return ops.nhwc_to_nchw(self.forward_nhwc(z, cond, z_depth))
+
+
+class MaskSpadeDecoder(nn.Module):
+    """reference masker.py:59-231 (resnet deeplabv3 backbone): projection convs (spectral norm + BatchNorm, reflect
+    padding), ``num_layers`` SPADE ResNet blocks with a batch param-free norm, each followed by a x2 nearest upsample
+    (folded into the next consumer), then a spectral-norm 3x3 conv to one channel.  Inference (eval-mode BatchNorm)."""
+
+    def __init__(self, opts):
+        super().__init__()
+        self.opts = opts
+        sp = opts.gen.m.spade
+        self.num_layers = sp.num_layers
+        self.z_nc = sp.latent_dim
+        act = "lrelu" if sp.activations.all_lrelu else None
+        if opts.gen.encoder.architecture != "deeplabv3" or opts.gen.deeplabv3.backbone != "resnet":
+            raise NotImplementedError("MaskSpadeDecoder: only the deeplabv3 / resnet encoder has a HIP path")
+        self.input_dim = [2048, 256]
+        kw = dict(padding=1, activation="lrelu", pad_type="reflect", norm="spectral_batch")
+        if opts.gen.m.use_proj:
+            proj = opts.gen.m.proj_dim
+            self.low_level_conv = Conv2dBlock(self.input_dim[1], proj, 3, **kw)
+            self.high_level_conv = Conv2dBlock(self.input_dim[0], proj, 3, **kw)
+            self.merge_feats_conv = Conv2dBlock(proj * 2, self.z_nc, 3, **kw)
+        else:
+            self.low_level_conv = Conv2dBlock(self.input_dim[1], self.input_dim[0], 3, **kw)
+            self.merge_feats_conv = Conv2dBlock(self.input_dim[0] * 2, self.z_nc, 3, **kw)
+        self.spade_blocks = nn.Sequential(*[
+            SPADEResnetBlock(int(self.z_nc / 2 ** i), int(self.z_nc / 2 ** (i + 1)), sp.cond_nc,
+                             sp.spade_use_spectral_norm, sp.spade_param_free_norm, 3, act)
+            for i in range(self.num_layers)])
+        self.final_nc = int(self.z_nc / 2 ** self.num_layers)
+        self.mask_conv = Conv2dBlock(self.final_nc, 1, 3, padding=1, activation="none", pad_type="reflect",
+                                     norm="spectral")
+        self.upsample = InterpolateNearest2d(scale_factor=2)
+
+    def forward_nhwc(self, z, cond: ops.NHWC, z_depth=None) -> ops.NHWC:
+        if not isinstance(z, (list, tuple)):
+            raise NotImplementedError("MaskSpadeDecoder: the deeplabv2 single-tensor latent has no HIP path")
+        z_h, z_l = z
+        z_l = self.low_level_conv.forward_nhwc(z_l)
+        z_l = ops.resize_bilinear(z_l, (z_h.h, z_h.w), align_corners=False)             # masker.py:217,221
+        if self.opts.gen.m.use_proj:
+            z_h = self.high_level_conv.forward_nhwc(z_h)
+        y = self.merge_feats_conv.forward_nhwc(ops.concat_channels([z_h, z_l]))         # masker.py:222-223
+        for i in range(self.num_layers):
+            y = self.spade_blocks[i].forward_nhwc(y, cond, x_upsample=(i > 0))          # upsample folded: :227-229
+        # the last upsample, read through the conv (reflect padding on the up-sampled extent)
+        c = self.mask_conv
+        return c.conv(y, pad=c.padding, pad_mode=ops.PAD_REFLECT, in_upsample=True)
+
+    def forward(self, z, cond, z_depth=None):
         return ops.nhwc_to_nchw(self.forward_nhwc(z, cond, z_depth))

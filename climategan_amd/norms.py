@@ -212,12 +212,16 @@ class SPADE(nn.Module):
         return self._cache.get(ps, dtype, lambda: ops.pack_spade_weights(*[p.data for p in ps], dtype))
 
     def forward_nhwc(self, x: ops.NHWC, cond: ops.NHWC, stats=None, act=ops.ACT_NONE, x_upsample=False) -> ops.NHWC:
-        if self.param_free_norm_type != "instance":
-            raise NotImplementedError("SPADE: param-free norm '%s' has no HIP kernel yet (instance only)"
-                                      % self.param_free_norm_type)
         if self.kernel_size != 3:
             raise NotImplementedError("SPADE: only kernel_size 3 is supported")
-        if stats is None:
+        if self.param_free_norm_type == "batch":
+            # nn.BatchNorm2d(affine=False) (norms.py:152-153): eval mode normalises with the running statistics
+            if self.param_free_norm.training:
+                raise NotImplementedError("SPADE with a batch param-free norm in training mode (batch statistics) has "
+                                          "no HIP path yet; call .eval()")
+            _grad_guard(self)
+            stats = ops.bn_eval_stats(self.param_free_norm, x.n)
+        elif stats is None:
             stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
         if needs_grad(self, x.t):
             from .autograd import SpadeFn

@@ -286,6 +286,38 @@ def cloudy_cond(x: torch.Tensor, m: torch.Tensor, seg: NHWC, angles: torch.Tenso
     return NHWC(cond, 3)
 
 
+def bn_eval_stats(bn, n: int):
+    """(mean, rstd) fp32 [n, Cs] such that eval-mode ``bn(x) == (x - mean) * rstd`` (affine folded in)."""
+    rm, rv = bn.running_mean, bn.running_var
+    _need_cuda(rm, rv)
+    c = rm.numel()
+    g = bn.weight.detach().float().contiguous() if getattr(bn, "affine", False) and bn.weight is not None else None
+    b = bn.bias.detach().float().contiguous() if getattr(bn, "affine", False) and bn.bias is not None else None
+    mean = torch.empty((n, cs8(c)), dtype=torch.float32, device=rm.device)
+    rstd = torch.empty_like(mean)
+    lib = _lib.load()
+    _lib.check(lib.cgan_bn_eval_stats(_ptr(g), _ptr(b), _ptr(rm.float().contiguous()), _ptr(rv.float().contiguous()),
+                                      float(bn.eps), _ptr(mean), _ptr(rstd), n, c, _stream()), "cgan_bn_eval_stats")
+    return mean, rstd
+
+
+def make_m_cond(d: NHWC, s: NHWC, x: Optional[torch.Tensor]) -> NHWC:
+    """cat[normalize(d), softmax(s), bilinear(x)] (reference generator.py:196-230) as an NHWC conditioning map."""
+    _need_cuda(d.t, s.t, x)
+    if (d.h, d.w, d.n) != (s.h, s.w, s.n) or d.c != 1:
+        raise RuntimeError("make_m_cond: d and s must share batch and spatial size, d with one channel")
+    cond_c = 1 + s.c + (3 if x is not None else 0)
+    xx = x.contiguous().float() if x is not None else None
+    lib = _lib.load()
+    nbytes = lib.cgan_make_m_cond_workspace_bytes(d.n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d.t.device)
+    cond = torch.empty((d.n, d.h, d.w, cs4(cond_c)), dtype=d.t.dtype, device=d.t.device)
+    _lib.check(lib.cgan_make_m_cond_nhwc(_ptr(d.t), _ptr(s.t), _ptr(xx), _ptr(cond), d.dtype_id, d.n, d.h, d.w, s.c,
+                                         xx.shape[-2] if xx is not None else 0, xx.shape[-1] if xx is not None else 0,
+                                         _ptr(ws), nbytes, _stream()), "cgan_make_m_cond_nhwc")
+    return NHWC(cond, cond_c)
+
+
 # ------------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:

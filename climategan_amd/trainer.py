@@ -272,8 +272,8 @@ class Trainer:
             with Timer(store=stores.get("segmentation", [])):
                 seg_nhwc = self.G.decoders["s"].forward_nhwc(z, z_depth)
             with Timer(store=stores.get("mask", [])):
-                # make_m_cond (trainer.py:285) only matters for the SPADE mask decoder, which has no HIP path yet
-                mask = self.G.mask(z=z, cond=None, z_depth=z_depth).to(x.dtype)
+                cond = self.G.make_m_cond(depth_nhwc, seg_nhwc, x) if self.opts.gen.m.use_spade else None   # :285
+                mask = self.G.mask(z=z, cond=cond, z_depth=z_depth).to(x.dtype)
 
             wildfire = smog = flood = None
             if "wildfire" not in ignore_event:

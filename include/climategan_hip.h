@@ -345,6 +345,20 @@ int cgan_cloudy_cond_nhwc(const float* x_nchw, const float* m_nchw, const void* 
                           int32_t seg_c, int32_t sky_idx, int32_t res_y, int32_t res_x, float weight, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Eval-mode nn.BatchNorm2d as the per-(n, c) (mean, rstd) pair cgan_norm_act_apply / cgan_spade_fused_fwd consume:
+ * rstd = gamma / sqrt(running_var + eps), mean = running_mean - beta / rstd; gamma / beta NULL for affine=False (the
+ * "batch" param-free norm of SPADE, climategan/norms.py:152-153; Conv2dBlock's spectral_batch, blocks.py:118-136).
+ * mean, rstd: fp32 [n][cgan_cs(c)]. */
+int cgan_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* mean, float* rstd, int32_t n, int32_t c, void* stream);
+/* OmniGenerator.make_m_cond (climategan/generator.py:196-230): cond = cat[normalize(d), softmax(s, dim=1),
+ * bilinear(x -> (h, w), align_corners=True)] as NHWC with round_up(1 + seg_c + 3, 4) channels; x_nchw NULL drops the
+ * image channels (cond_nc 12).  depth_nhwc [n][h][w][8] (channel 0), seg_nhwc [n][h][w][cgan_cs(seg_c)]. */
+size_t cgan_make_m_cond_workspace_bytes(int32_t n);
+int cgan_make_m_cond_nhwc(const void* depth_nhwc, const void* seg_nhwc, const float* x_nchw, void* cond_nhwc,
+                          int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t seg_c, int32_t x_h, int32_t x_w,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,7 +354,7 @@ def conv2d_block(x, sd: SD, p: str, k: int, padding: int, pad_type: str, norm: s
         x = sn_conv2d(x, sd, p + ".conv", update=update)
     else:
         x = F.conv2d(x, sd[p + ".conv.weight"], sd.get(p + ".conv.bias"))
-    if norm == "batch":
+    if norm in ("batch", "spectral_batch"):
         x = _bn(x, sd, p + ".norm")
     if activ == "lrelu":
         x = F.leaky_relu(x, 0.2)
@@ -581,3 +581,29 @@ def paint_cloudy(sd_p: SD, m, x, s, z_h, z_w, angles, sky_idx=9, res=(8, 8), wei
     noised = mask * (weight * noise + (1 - weight) * x) + (1 - mask) * x
     fake = paint(sd_p, m, noised, z_h, z_w, no_paste=True, update=update)
     return x * (1.0 - m) + fake * m
+
+
+# --------------------------------------------------------------------------------------------------
+# SPADE mask decoder: MaskSpadeDecoder (masker.py:59-231), OmniGenerator.make_m_cond (generator.py:196-230)
+# --------------------------------------------------------------------------------------------------
+def make_m_cond(d, s, x=None):
+    cats = [normalize(d), torch.softmax(s, dim=1)]
+    if x is not None:
+        cats.append(F.interpolate(x, s.shape[-2:], mode="bilinear", align_corners=True))
+    return torch.cat(cats, dim=1)
+
+
+def mask_spade_decoder(z, cond, sd: SD, prefix: str, num_layers=3, update=True):
+    """``MaskSpadeDecoder.forward`` with use_proj (defaults.yaml:174-175), eval-mode BatchNorm everywhere."""
+    p = prefix + "." if prefix else ""
+    z_h, z_l = z
+    z_l = conv2d_block(z_l, sd, p + "low_level_conv", 3, 1, "reflect", "spectral_batch", "lrelu", update)
+    z_l = F.interpolate(z_l, size=z_h.shape[-2:], mode="bilinear")
+    z_h = conv2d_block(z_h, sd, p + "high_level_conv", 3, 1, "reflect", "spectral_batch", "lrelu", update)
+    y = conv2d_block(torch.cat([z_h, z_l], 1), sd, p + "merge_feats_conv", 3, 1, "reflect", "spectral_batch", "lrelu",
+                     update)
+    for i in range(num_layers):
+        y = spade_resnet_block(y, cond, sd, "%sspade_blocks.%d" % (p, i), norm_type="batch", last_activation="lrelu",
+                               training=False, update=update)
+        y = nearest_resize(y, (y.shape[2] * 2, y.shape[3] * 2))
+    return conv2d_block(y, sd, p + "mask_conv", 3, 1, "reflect", "spectral", "none", update)

@@ -35,6 +35,7 @@ def golden_cases():
         "infer_small": dict(kind="infer", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43),
         "cloudy_small": dict(kind="cloudy", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43,
                              rng_seed=4321, sky_idx=6),   # class 6 covers 14 % of this untrained net's argmax map
+        "maskspade_small": dict(kind="maskspade", H=128, W=160, B=2, seed=62, gain=1.6),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
@@ -73,7 +74,7 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
                     m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
-    if k in ("masker", "infer", "cloudy"):
+    if k in ("masker", "infer", "cloudy", "maskspade"):
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1))
     if k == "extra_adam":
         d = {}
@@ -250,6 +251,44 @@ def run_reference_cloudy(name, case):
             "sky_fraction": np.array([sky.float().mean().item()], dtype=np.float32)}
 
 
+def maskspade_generator(case):
+    """The reference OmniGenerator with ``gen.m.use_spade`` (MaskSpadeDecoder; its hard-coded ``.cuda()``,
+    masker.py:196, is neutralised for the construction), masker tasks, eval mode, portable fill."""
+    import contextlib
+    import io
+
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.tasks = ["d", "s", "m"]
+    opts.gen.m.use_spade = True
+    orig = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+    finally:
+        torch.nn.Module.cuda = orig
+    shapes = {key: tuple(v.shape) for key, v in G.state_dict().items()}
+    G.load_state_dict({key: t(v) for key, v in fill.fill_state_dict(shapes, case["seed"], gain=case["gain"]).items()})
+    G.eval()
+    return G, shapes
+
+
+def run_reference_maskspade(name, case):
+    """infer_all's masker stage (trainer.py:272-287) with the SPADE mask decoder: cond = make_m_cond(d, s, x)."""
+    G, shapes = maskspade_generator(case)
+    x = t(case_inputs(name, case)["x"])
+    with torch.no_grad():
+        z = G.encode(x)
+        d, z_depth = G.decoders["d"](z)
+        s = G.decoders["s"](z, z_depth)
+        cond = G.make_m_cond(d, s, x)
+        m = G.mask(z=z, cond=cond, z_depth=z_depth)
+        logits = G.mask(z=z, cond=cond, z_depth=z_depth, sigmoid=False)      # second call: one more power iteration
+    return {"d": d.numpy(), "s": s.numpy(), "cond": cond.numpy(), "m": m.numpy(), "logits2": logits.numpy()}
+
+
 def run_reference_dstep(name, case):
     """The Painter branch of ``Trainer.get_D_loss`` (trainer.py:1073-1107) with the reference's own modules and
     losses (``GANLoss`` as built by ``get_losses``: BCE form, here soft_shift = flip_prob = 0), then
@@ -366,6 +405,8 @@ def run_reference(name, case):
         return run_reference_infer(name, case)
     if case["kind"] == "cloudy":
         return run_reference_cloudy(name, case)
+    if case["kind"] == "maskspade":
+        return run_reference_maskspade(name, case)
     if case["kind"] == "dstep_p":
         return run_reference_dstep(name, case)
     if case["kind"] == "gstep_p":
@@ -428,6 +469,9 @@ def main():
     # state-dict layout of the reference's default generator (masker part) -- data for the layout tests
     _, shapes = masker_generator(golden_cases()["masker_small"])
     (GOLDEN_DIR / "generator_masker_shapes.json").write_text(json.dumps({k: list(v) for k, v in shapes.items()}))
+    _, shapes = maskspade_generator(golden_cases()["maskspade_small"])
+    shapes = {k: v for k, v in shapes.items() if k.startswith("decoders.m.")}
+    (GOLDEN_DIR / "generator_maskspade_shapes.json").write_text(json.dumps({k: list(v) for k, v in shapes.items()}))
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ def module_shapes(case):
         return painter_shapes(case["latent_dim"], case["n_up"])
     if k == "dstep_p":
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
-    if k in ("extra_adam", "masker", "infer", "cloudy"):
+    if k in ("extra_adam", "masker", "infer", "cloudy", "maskspade"):
         return {}
     raise KeyError(k)
 
@@ -228,6 +228,34 @@ def run_oracle_cloudy(name, case):
     return {"flood": flood.numpy()}
 
 
+def maskspade_shapes():
+    """Default generator with gen.m.use_spade: encoder / depth / seg as in the default masker + the SPADE mask decoder."""
+    import json
+
+    shapes = {k: v for k, v in masker_shapes().items() if not k.startswith("decoders.m.")}
+    extra = json.loads((GOLDEN / "generator_maskspade_shapes.json").read_text())
+    shapes.update({k: tuple(v) for k, v in extra.items()})
+    return shapes
+
+
+def maskspade_state_dict(case):
+    sd = fill.fill_state_dict(maskspade_shapes(), case["seed"], gain=case["gain"])
+    return {k: t(v) for k, v in sd.items()}
+
+
+def run_oracle_maskspade(name, case):
+    sd = maskspade_state_dict(case)
+    x = t(case_inputs(name, case)["x"])
+    with torch.no_grad():
+        z = cpu_ref.resnet101(x, sd, "encoder")
+        d, z_depth = cpu_ref.dada_depth_decoder(z, sd, "decoders.d", 160)
+        s = cpu_ref.deeplab_v3_decoder(z, sd, "decoders.s", (160, 160), z_depth, use_dada=True)
+        cond = cpu_ref.make_m_cond(d, s, x)
+        m = torch.sigmoid(cpu_ref.mask_spade_decoder(z, cond, sd, "decoders.m"))
+        logits2 = cpu_ref.mask_spade_decoder(z, cond, sd, "decoders.m")
+    return {"d": d.numpy(), "s": s.numpy(), "cond": cond.numpy(), "m": m.numpy(), "logits2": logits2.numpy()}
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
@@ -238,6 +266,8 @@ def run_oracle(name, case, dtype=torch.float32):
         return run_oracle_infer(name, case)
     if case["kind"] == "cloudy":
         return run_oracle_cloudy(name, case)
+    if case["kind"] == "maskspade":
+        return run_oracle_maskspade(name, case)
     if case["kind"] == "dstep_p":
         return run_oracle_dstep(name, case)
     if case["kind"] == "gstep_p":

@@ -61,3 +61,44 @@ def test_training_mode_batchnorm_refused():
     x = t(case_inputs("masker_small", case)["x"]).cuda()
     with torch.no_grad(), pytest.raises(NotImplementedError, match="training mode"):
         G.encode(x)
+
+
+def test_mask_spade_decoder_matches_reference_golden():
+    """gen.m.use_spade: make_m_cond (normalize(d) | softmax(s) | bilinear x) and MaskSpadeDecoder (spectral_batch
+    projections, three batch-norm SPADE ResNet blocks with folded upsamples, reflect-padded output conv) against the
+    reference generator's outputs; second call checks the per-call spectral-norm power iteration."""
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+    from helpers import maskspade_state_dict
+
+    name = "maskspade_small"
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    opts.gen.m.use_spade = True
+    G = create_generator(opts, device="cuda")
+    G.load_state_dict(maskspade_state_dict(case), strict=True)
+    G.eval()
+    G.set_compute_dtype(torch.float16)
+    x = t(case_inputs(name, case)["x"]).cuda()
+    with torch.no_grad():
+        z = G.encode(x)
+        d, z_depth = G.decoders["d"].forward_nhwc(z)
+        s = G.decoders["s"].forward_nhwc(z, z_depth)
+        cond = G.make_m_cond(d, s, x)
+        m = G.mask(z=z, cond=cond, z_depth=z_depth)
+        logits2 = G.mask(z=z, cond=cond, z_depth=z_depth, sigmoid=False)
+    from climategan_amd import ops
+    got = {"cond": ops.nhwc_to_nchw(cond).cpu().numpy(), "m": m.cpu().numpy(), "logits2": logits2.cpu().numpy()}
+    assert got["cond"].shape == gold["cond"].shape
+    # softmax / image channels are exact up to fp16 rounding of the inputs; normalize(d) divides by (max - min) of a
+    # narrow-range map, which amplifies the 16-bit depth error
+    assert np.abs(got["cond"][:, 1:] - gold["cond"][:, 1:]).max() <= 5e-3
+    assert np.abs(got["cond"][:, :1] - gold["cond"][:, :1]).mean() <= 2e-2
+    for k in ("m", "logits2"):
+        scale = max(np.abs(gold[k]).max(), 1e-6)
+        err = np.abs(got[k] - gold[k])
+        assert err.max() <= 3e-2 * scale and err.mean() <= 4e-3 * scale, (k, err.max(), err.mean(), scale)
+    sure = np.abs(gold["m"] - 0.5) > 0.02
+    assert sure.mean() > 0.3 and np.array_equal((got["m"] > 0.5)[sure], (gold["m"] > 0.5)[sure])

@@ -10,7 +10,7 @@ CASES = golden_cases()
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p", "gstep_p", "cloudy_small")])
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p", "gstep_p", "cloudy_small", "maskspade_small")])
 def test_oracle_matches_golden(name):
     gold = load_golden(name)
     got = run_oracle(name, CASES[name])
@@ -133,3 +133,15 @@ def test_oracle_paint_cloudy_matches_golden():
     assert 0.05 < float(gold["sky_fraction"][0]) < 0.6           # the fixture really replaces part of the image
     err = np.abs(got["flood"] - gold["flood"]).max()
     assert err <= 2e-5, err
+
+
+def test_oracle_matches_golden_mask_spade_decoder():
+    """make_m_cond + MaskSpadeDecoder (batch-norm SPADE, spectral_batch projections) of the reference generator."""
+    name = "maskspade_small"
+    gold = load_golden(name)
+    got = run_oracle(name, CASES[name])
+    assert sorted(gold) == sorted(got)
+    for k in gold:
+        scale = max(np.abs(gold[k]).max(), 1e-6)
+        err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
+        assert err <= 1e-4 * scale, "%s/%s: max abs err %.3g (scale %.3g)" % (name, k, err, scale)
