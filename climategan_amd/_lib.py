@@ -122,6 +122,9 @@ _SIGNATURES = {
     "cgan_make_m_cond_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_make_m_cond_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    "cgan_wildfire_workspace_bytes": (C.c_size_t, [C.c_int32] * 6),
+    "cgan_wildfire_nchw": (C.c_int, [_P, _P, C.c_int32, _P] + [C.c_int32] * 8 + [C.c_float, C.c_float, C.c_int32,
+                                                                               C.c_float, _P, C.c_size_t, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,274 @@
+// Wildfire event (climategan/fire.py:68-126 `add_fire`, parameters shared/trainer/events.yaml:1-8): byte-image work,
+// HBM-bound.  The torchvision / kornia calls of the reference are restated from those libraries' documented formulas
+// (they are not in the reference tree: parity of THIS file is against the oracle's restatement only):
+//   adjust_brightness(u8, f) = uint8(clamp(f * img, 0, 255))
+//   adjust_contrast(u8, f)   = uint8(clamp(f * img + (1 - f) * mean(uint8(0.2989 r + 0.587 g + 0.114 b)), 0, 255))
+//   get_gaussian_kernel2d(k, s) = outer(g, g), g = exp(-(i - k//2)^2 / (2 s^2)) / sum; filter2d(reflect) = correlation
+#include "cgan_common.h"
+
+namespace {
+
+__device__ __forceinline__ int f2key_w(float f) {
+  int b = __float_as_int(f);
+  return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float key2f_w(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+__global__ void wf_init_kernel(int* mm, unsigned int* gray, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    mm[2 * i] = 0x7fffffff;
+    mm[2 * i + 1] = (int)0x80000000;
+    gray[i] = 0u;
+  }
+}
+
+__global__ void __launch_bounds__(256) wf_minmax_kernel(const float* __restrict__ x, int* mm, long per_image) {
+  const int img = blockIdx.y;
+  const float* b = x + (long)img * per_image;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_image; i += (long)gridDim.x * blockDim.x) {
+    mn = fminf(mn, b[i]);
+    mx = fmaxf(mx, b[i]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[2 * img], f2key_w(mn));
+    atomicMax(&mm[2 * img + 1], f2key_w(mx));
+  }
+}
+
+// normalize(x, 0, 255), warm (r += 40, g -= 10, b -= 20), clamp, to uint8; accumulates the per-image sum of the
+// uint8 grey level for adjust_contrast
+__global__ void __launch_bounds__(256)
+    wf_warm_kernel(const float* __restrict__ x, const int* __restrict__ mm, uint8_t* __restrict__ img,
+                   unsigned int* __restrict__ gray, long hw) {
+  const int n = blockIdx.y;
+  const float mn = key2f_w(mm[2 * n]), den = key2f_w(mm[2 * n + 1]) - mn;
+  unsigned int acc = 0;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
+    int c8[3];
+    const float add[3] = {40.f, -10.f, -20.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.f + 255.f * __fdiv_rn(x[((long)n * 3 + c) * hw + p] - mn, den);   // mini + (maxi - mini) * t
+      v = fminf(fmaxf(v + add[c], 0.f), 255.f);
+      c8[c] = (int)v;
+      img[((long)n * 3 + c) * hw + p] = (uint8_t)c8[c];
+    }
+    acc += (unsigned int)(int)(0.2989f * c8[0] + 0.587f * c8[1] + 0.114f * c8[2]);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&gray[n], acc);
+}
+
+// adjust_contrast(1.5) then adjust_brightness(0.73), in place on the uint8 image
+__global__ void __launch_bounds__(256)
+    wf_contrast_kernel(uint8_t* __restrict__ img, const unsigned int* __restrict__ gray, long hw, float contrast,
+                       float brightness) {
+  const int n = blockIdx.y;
+  const float mean = (float)gray[n] / (float)hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * hw; i += (long)gridDim.x * blockDim.x) {
+    uint8_t* p = img + (long)n * 3 * hw + i;
+    float v = fminf(fmaxf(contrast * (float)*p + (1.f - contrast) * mean, 0.f), 255.f);
+    const int c = (int)v;
+    v = fminf(fmaxf(brightness * (float)c, 0.f), 255.f);
+    *p = (uint8_t)(int)v;
+  }
+}
+
+// sky = argmax_c(seg) == sky_idx at the segmentation's resolution, bottom third cleared (fire.py:94-98)
+template <typename T>
+__global__ void wf_sky_kernel(const uint16_t* __restrict__ seg, uint8_t* __restrict__ sky, int sh, int sw, int sc,
+                              int scs, int sky_idx, int crop_row, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int y = (int)((i / sw) % sh);
+    const uint16_t* sp = seg + i * scs;
+    int best = 0;
+    float bv = -__builtin_inff();
+    for (int c = 0; c < sc; ++c) {
+      float v = f32_of_bits<T>(sp[c]);
+      if (v > bv) { bv = v; best = c; }
+    }
+    sky[i] = (best == sky_idx && y < crop_row) ? 1 : 0;
+  }
+}
+
+// nearest up-sampling to (h, w) fused with the horizontal half of increase_sky_mask (fire.py:15-47): out = 1 if any
+// up-sampled mask pixel within |dx| < n_cols on the same row is set
+__global__ void wf_dilate_h_kernel(const uint8_t* __restrict__ sky, uint8_t* __restrict__ out, int h, int w, int sh,
+                                   int sw, int n_cols, float ry, float rx, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long r = i / w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    const int sy = nearest_src(y, ry, sh);
+    const uint8_t* row = sky + (n * sh + sy) * (long)sw;
+    const int x0 = max(x - (n_cols - 1), 0), x1 = min(x + (n_cols - 1), w - 1);
+    uint8_t v = 0;
+    // the up-sampled row is piecewise constant: scan the low-resolution columns the window covers
+    const int s0 = nearest_src(x0, rx, sw), s1 = nearest_src(x1, rx, sw);
+    for (int s = s0; s <= s1 && !v; ++s) v = row[s];
+    out[i] = v;
+  }
+}
+__global__ void wf_dilate_v_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int h, int w, int n_lines,
+                                   long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long r = i / w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    const int y0 = max(y - (n_lines - 1), 0), y1 = min(y + (n_lines - 1), h - 1);
+    uint8_t v = 0;
+    for (int yy = y0; yy <= y1 && !v; ++yy) v = in[(n * h + yy) * (long)w + x];
+    out[i] = v ? 1.f : 0.f;
+  }
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {   // F.pad(mode="reflect")
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+// one pass of the separable Gaussian (taps in `g`, ks of them), along x (axis 0) or y (axis 1), reflect border
+__global__ void wf_blur_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ g, int h,
+                               int w, int ks, int axis, long total) {
+  const int half = ks / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long r = i / w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    const float* base = in + n * (long)h * w;
+    float acc = 0.f;
+    if (axis == 0) {
+      for (int k = 0; k < ks; ++k) acc += g[k] * base[(long)y * w + reflect101(x + k - half, w)];
+    } else {
+      for (int k = 0; k < ks; ++k) acc += g[k] * base[(long)reflect101(y + k - half, h) * w + x];
+    }
+    out[i] = acc;
+  }
+}
+
+// paste_tensor(img, filter, mask, transparency) -> uint8 -> adjust_brightness(0.8) -> float, dummy corner pixels
+__global__ void wf_compose_kernel(const uint8_t* __restrict__ img, const float* __restrict__ mask,
+                                  float* __restrict__ out, int h, int w, float transparency, float fr, float fg,
+                                  float fb, float brightness, long total) {
+  const long hw = (long)h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    const float mk = transparency / 255.f * mask[i];
+    const float fil[3] = {fr, fg, fb};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = mk * fil[c] + (1.f - mk) * (float)img[(n * 3 + c) * hw + p];
+      const int u = (int)v;                                            // .to(torch.uint8) of a value in [0, 255]
+      float o = (float)(int)fminf(fmaxf(brightness * (float)u, 0.f), 255.f);
+      if (p == 0) o = 255.f;                                           // fire.py:121-123
+      if (p == hw - 1) o = 0.f;
+      out[(n * 3 + c) * hw + p] = o;
+    }
+  }
+}
+
+// 1-D Gaussian taps g[i] = exp(-(i - ks/2)^2 / (2 sigma^2)) / sum  (kornia get_gaussian_kernel1d), one block
+__global__ void __launch_bounds__(1024) wf_taps_kernel(float* __restrict__ g, int ks, float sigma) {
+  __shared__ float part[16];
+  __shared__ float total;
+  const int i = threadIdx.x;
+  const float xx = (float)(i - ks / 2);
+  const float e = i < ks ? expf(-(xx * xx) / (2.f * sigma * sigma)) : 0.f;
+  float v = e;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((i & 63) == 0) part[i >> 6] = v;
+  __syncthreads();
+  if (i == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += part[k];
+    total = t;
+  }
+  __syncthreads();
+  if (i < ks) g[i] = e / total;
+}
+
+inline unsigned grid1(long total) { return (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256); }
+
+}  // namespace
+
+extern "C" size_t cgan_wildfire_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t seg_h, int32_t seg_w,
+                                                int32_t kernel_size) {
+  if (n <= 0 || h <= 0 || w <= 0 || seg_h <= 0 || seg_w <= 0 || kernel_size <= 0) return 0;
+  size_t b = 0;
+  b += ((size_t)n * 3 * sizeof(int) + 255) / 256 * 256;                 // min / max keys + grey sums
+  b += ((size_t)kernel_size * sizeof(float) + 255) / 256 * 256;         // 1-D Gaussian taps
+  b += ((size_t)n * 3 * h * w + 255) / 256 * 256;                       // uint8 image
+  b += ((size_t)n * seg_h * seg_w + 255) / 256 * 256;                   // low-resolution sky mask
+  b += ((size_t)n * h * w + 255) / 256 * 256;                           // horizontally dilated mask (uint8)
+  b += 2 * (((size_t)n * h * w * sizeof(float) + 255) / 256 * 256);     // two float masks (blur ping-pong)
+  return b;
+}
+
+extern "C" int cgan_wildfire_nchw(const float* x_nchw, const void* seg_nhwc, int32_t dtype, float* out_nchw, int32_t n,
+                                  int32_t h, int32_t w, int32_t seg_h, int32_t seg_w, int32_t seg_c, int32_t sky_idx,
+                                  int32_t kernel_size, float kernel_sigma, float transparency, int32_t crop_bottom,
+                                  float filter_green, void* workspace, size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(x_nchw && seg_nhwc && out_nchw && workspace, "wildfire: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "wildfire: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && h > 1 && w > 1 && seg_h > 0 && seg_w > 0 && seg_c > 0, "wildfire: bad shape");
+  CGAN_REQUIRE(kernel_size > 0 && kernel_size <= 1023 && (kernel_size % 2) == 1, "wildfire: odd kernel_size <= 1023 expected");
+  CGAN_REQUIRE(kernel_size / 2 < h && kernel_size / 2 < w,
+               "wildfire: reflect border needs kernel_size // 2 (%d) < image extent (%d, %d)", kernel_size / 2, h, w);
+  CGAN_REQUIRE(sky_idx >= 0 && sky_idx < seg_c, "wildfire: bad sky index");
+  CGAN_REQUIRE(workspace_bytes >= cgan_wildfire_workspace_bytes(n, h, w, seg_h, seg_w, kernel_size),
+               "wildfire: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  char* wp = (char*)workspace;
+  auto take = [&](size_t bytes) { char* p = wp; wp += (bytes + 255) / 256 * 256; return p; };
+  int* mm = (int*)take((size_t)n * 3 * sizeof(int));
+  unsigned int* gray = (unsigned int*)(mm + 2 * n);
+  float* taps = (float*)take((size_t)kernel_size * sizeof(float));
+  uint8_t* img = (uint8_t*)take((size_t)n * 3 * h * w);
+  uint8_t* sky = (uint8_t*)take((size_t)n * seg_h * seg_w);
+  uint8_t* dil = (uint8_t*)take((size_t)n * h * w);
+  float* m0 = (float*)take((size_t)n * h * w * sizeof(float));
+  float* m1 = (float*)take((size_t)n * h * w * sizeof(float));
+
+  hipLaunchKernelGGL(wf_taps_kernel, dim3(1), dim3(1024), 0, s, taps, kernel_size, kernel_sigma);
+
+  const long hw = (long)h * w, per_image = 3 * hw;
+  hipLaunchKernelGGL(wf_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mm, gray, n);
+  int bpi = (int)((per_image + 4095) / 4096 > 256 ? 256 : (per_image + 4095) / 4096);
+  hipLaunchKernelGGL(wf_minmax_kernel, dim3(bpi, n), dim3(256), 0, s, x_nchw, mm, per_image);
+  bpi = (int)((hw + 1023) / 1024 > 256 ? 256 : (hw + 1023) / 1024);
+  hipLaunchKernelGGL(wf_warm_kernel, dim3(bpi, n), dim3(256), 0, s, x_nchw, (const int*)mm, img, gray, hw);
+  hipLaunchKernelGGL(wf_contrast_kernel, dim3(bpi, n), dim3(256), 0, s, img, (const unsigned int*)gray, hw, 1.5f, 0.73f);
+  const long stot = (long)n * seg_h * seg_w;
+  const int crop_row = crop_bottom ? 2 * seg_h / 3 : seg_h;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(wf_sky_kernel<F16>, dim3(grid1(stot)), dim3(256), 0, s, (const uint16_t*)seg_nhwc, sky, seg_h,
+                       seg_w, seg_c, cgan_cs(seg_c), sky_idx, crop_row, stot);
+  else
+    hipLaunchKernelGGL(wf_sky_kernel<BF16>, dim3(grid1(stot)), dim3(256), 0, s, (const uint16_t*)seg_nhwc, sky, seg_h,
+                       seg_w, seg_c, cgan_cs(seg_c), sky_idx, crop_row, stot);
+  const long tot = (long)n * hw;
+  const int n_lines = (int)(0.18f * h), n_cols = (int)(0.18f * w);
+  const float ry = (float)seg_h / (float)h, rx = (float)seg_w / (float)w;
+  hipLaunchKernelGGL(wf_dilate_h_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const uint8_t*)sky, dil, h, w, seg_h, seg_w,
+                     n_cols < 1 ? 1 : n_cols, ry, rx, tot);
+  hipLaunchKernelGGL(wf_dilate_v_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const uint8_t*)dil, m0, h, w,
+                     n_lines < 1 ? 1 : n_lines, tot);
+  hipLaunchKernelGGL(wf_blur_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const float*)m0, m1, (const float*)taps, h, w,
+                     kernel_size, 0, tot);
+  hipLaunchKernelGGL(wf_blur_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const float*)m1, m0, (const float*)taps, h, w,
+                     kernel_size, 1, tot);
+  hipLaunchKernelGGL(wf_compose_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const uint8_t*)img, (const float*)m0,
+                     out_nchw, h, w, transparency, 255.f, filter_green, 0.f, 0.8f, tot);
+  CGAN_CHECK_LAUNCH("wildfire");
+  return CGAN_OK;
+}

@@ -318,6 +318,28 @@ def make_m_cond(d: NHWC, s: NHWC, x: Optional[torch.Tensor]) -> NHWC:
     return NHWC(cond, cond_c)
 
 
+def wildfire(x: torch.Tensor, seg: NHWC, filter_green: float, kernel_size=281, kernel_sigma=140.5, transparency=200,
+             crop_bottom=True, sky_idx=9) -> torch.Tensor:
+    """Wildfire event (reference fire.py:68-126): x NCHW fp32 in [-1, 1], seg the segmentation decoder's NHWC logits;
+    returns the float image in [0, 255] (NCHW) that infer_all then normalises to uint8."""
+    _need_cuda(x, seg.t)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    if c != 3 or seg.n != n:
+        raise RuntimeError("wildfire: x must be [n,3,h,w] with the segmentation's batch size")
+    lib = _lib.load()
+    nbytes = lib.cgan_wildfire_workspace_bytes(n, h, w, seg.h, seg.w, int(kernel_size))
+    if nbytes == 0:
+        _lib.check(-1, "cgan_wildfire_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    _lib.check(lib.cgan_wildfire_nchw(_ptr(x), _ptr(seg.t), seg.dtype_id, _ptr(out), n, h, w, seg.h, seg.w, seg.c,
+                                      int(sky_idx), int(kernel_size), float(kernel_sigma), float(transparency),
+                                      int(bool(crop_bottom)), float(filter_green), _ptr(ws), nbytes, _stream()),
+               "cgan_wildfire_nchw")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ conv
 @dataclass
 class PackedConv:

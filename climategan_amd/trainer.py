@@ -2,9 +2,9 @@
 ``Trainer.setup(inference=True)``, ``infer_all`` and ``compute_flood`` -- the stage order, binarisation and uint8
 conversion of the reference, every arithmetic step a HIP kernel behind the C ABI.
 
-Built: the flood event (Masker -> mask -> Painter) and the smog event (depth -> HazeRD transmission model).  Wildfire
-(row N1, ``trainer.py:1821-1842``, fire.py: kornia / torchvision arithmetic that is not in the reference tree) is not
-built: asking for it raises NotImplementedError instead of silently skipping.
+Built: the flood event (Masker -> mask -> Painter, optionally through ``paint_cloudy``), the smog event (depth -> HazeRD
+transmission model) and the wildfire event (``fire.add_fire``; its torchvision / kornia arithmetic is restated from those
+libraries' documentation because they are not in the reference tree, so that event is pinned by the oracle only).
 
 Training half (row H2), Painter tasks only (``opts.tasks == ["p"]``): ``setup(inference=False)`` builds G, D, the
 losses and the two ExtraAdam optimisers; ``update_G`` / ``update_D`` / ``train_step`` reproduce the "rf" branch of
@@ -226,7 +226,21 @@ class Trainer:
         return self.G.paint(m, x)
 
     def compute_fire(self, x, seg_preds=None, z=None, z_depth=None):
-        raise NotImplementedError("wildfire event (trainer.py:1821-1842, fire.py) has no HIP path yet (SURVEY row N1)")
+        """reference trainer.py:1821-1842 -> fire.add_fire (fire.py:68-126).  ``seg_preds``: the segmentation decoder's
+        NHWC logits or None.  The filter's green level is ``random.randint(100, 150)`` like the reference's (fire.py:115)."""
+        import random
+
+        if seg_preds is None:
+            if z is None:
+                z = self.G.encode(x)
+            seg_preds = self.G.decoders["s"].forward_nhwc(z, z_depth)
+        if not isinstance(seg_preds, ops.NHWC):
+            raise TypeError("compute_fire: seg_preds must be the NHWC logits of this package's segmentation decoder")
+        f = self.opts.events.fire
+        out = ops.wildfire(x, seg_preds, float(random.randint(100, 150)), kernel_size=f.get("kernel_size", 301),
+                           kernel_sigma=f.get("kernel_sigma", 150.5), transparency=200,
+                           crop_bottom=bool(f.get("crop_bottom_sky_mask")))
+        return out.to(x.dtype)
 
     def compute_smog(self, x, z=None, d=None, s=None, use_sky_seg=False):
         """reference trainer.py:1879-1939 (``use_sky_seg`` is a no-op there too: the sky mask is never built).

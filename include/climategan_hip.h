@@ -359,6 +359,19 @@ int cgan_make_m_cond_nhwc(const void* depth_nhwc, const void* seg_nhwc, const fl
                           int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t seg_c, int32_t x_h, int32_t x_w,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Wildfire event (climategan/fire.py:68-126 add_fire, parameters shared/trainer/events.yaml:1-8): normalize(x, 0, 255),
+ * warm, uint8, adjust_contrast(1.5), adjust_brightness(0.73); sky = argmax(seg) == sky_idx (bottom third cleared when
+ * crop_bottom), nearest-resized to (h, w), grown by 18 % (increase_sky_mask), blurred by the kernel_size x kernel_size
+ * Gaussian (reflect border); paste of the (255, filter_green, 0) filter with `transparency`/255, adjust_brightness(0.8),
+ * the two dummy corner pixels.  filter_green: the reference's random.randint(100, 150), drawn by the caller.
+ * x_nchw fp32 [n][3][h][w] in [-1, 1]; seg_nhwc 16-bit logits [n][seg_h][seg_w][cgan_cs(seg_c)]; out_nchw fp32 in [0, 255].
+ * The torchvision / kornia arithmetic is restated from those libraries' documentation (not in the reference tree). */
+size_t cgan_wildfire_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t seg_h, int32_t seg_w, int32_t kernel_size);
+int cgan_wildfire_nchw(const float* x_nchw, const void* seg_nhwc, int32_t dtype, float* out_nchw, int32_t n, int32_t h,
+                       int32_t w, int32_t seg_h, int32_t seg_w, int32_t seg_c, int32_t sky_idx, int32_t kernel_size,
+                       float kernel_sigma, float transparency, int32_t crop_bottom, float filter_green, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

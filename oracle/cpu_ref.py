@@ -607,3 +607,61 @@ def mask_spade_decoder(z, cond, sd: SD, prefix: str, num_layers=3, update=True):
                                training=False, update=update)
         y = nearest_resize(y, (y.shape[2] * 2, y.shape[3] * 2))
     return conv2d_block(y, sd, p + "mask_conv", 3, 1, "reflect", "spectral", "none", update)
+
+
+# --------------------------------------------------------------------------------------------------
+# Wildfire event: fire.add_fire (climategan/fire.py:68-126).  PARITY UNPINNED: the torchvision (==0.8.x)
+# adjust_contrast / adjust_brightness and kornia (==0.5.10) get_gaussian_kernel2d / filter2d calls are restated from
+# those libraries' documented formulas -- neither package is available here, so nothing below was checked against them.
+# --------------------------------------------------------------------------------------------------
+def _tv_adjust_brightness_u8(img_u8: torch.Tensor, f: float) -> torch.Tensor:
+    return (f * img_u8.float()).clamp(0, 255).to(torch.uint8)
+
+
+def _tv_adjust_contrast_u8(img_u8: torch.Tensor, f: float) -> torch.Tensor:
+    r, g, b = img_u8[:, 0].float(), img_u8[:, 1].float(), img_u8[:, 2].float()
+    gray = (0.2989 * r + 0.587 * g + 0.114 * b).to(torch.uint8).float()
+    mean = gray.mean(dim=(-2, -1), keepdim=True).unsqueeze(1)
+    return (f * img_u8.float() + (1 - f) * mean).clamp(0, 255).to(torch.uint8)
+
+
+def _kornia_gaussian_1d(ks: int, sigma: float) -> torch.Tensor:
+    x = torch.arange(ks, dtype=torch.float32) - ks // 2
+    g = torch.exp(-x.pow(2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def add_fire(x, seg_preds, filter_green: float, kernel_size=281, kernel_sigma=140.5, crop_bottom=True, sky_idx=9):
+    """``add_fire``: x [B,3,H,W] in [-1,1], seg_preds [B,C,h,w] logits -> float image in [0, 255]."""
+    w_t = normalize(x, 0, 255).clone()
+    w_t[:, 2] -= 20
+    w_t[:, 1] -= 10
+    w_t[:, 0] += 40
+    w_t = w_t.clamp(0, 255).to(torch.uint8)
+    w_t = _tv_adjust_contrast_u8(w_t, 1.5)
+    w_t = _tv_adjust_brightness_u8(w_t, 0.73)
+    sky = (torch.argmax(seg_preds, dim=1) == sky_idx).unsqueeze(1)
+    if crop_bottom:
+        i = 2 * sky.shape[-2] // 3
+        sky = sky.clone()
+        sky[..., i:, :] = 0
+    sky = F.interpolate(sky.float(), (w_t.shape[-2], w_t.shape[-1]))
+    n_lines, n_cols = int(0.18 * sky.shape[-2]), int(0.18 * sky.shape[-1])          # increase_sky_mask(mask, .18, .18)
+    if n_cols > 1:
+        sky = F.max_pool2d(sky, (1, 2 * n_cols - 1), stride=1, padding=(0, n_cols - 1))
+    if n_lines > 1:
+        sky = F.max_pool2d(sky, (2 * n_lines - 1, 1), stride=1, padding=(n_lines - 1, 0))
+    g = _kornia_gaussian_1d(kernel_size, kernel_sigma)
+    half = kernel_size // 2
+    sky = F.conv2d(F.pad(sky, (half, half, 0, 0), mode="reflect"), g.view(1, 1, 1, -1))
+    sky = F.conv2d(F.pad(sky, (0, 0, half, half), mode="reflect"), g.view(1, 1, -1, 1))
+    filt = torch.ones(w_t.shape)
+    filt[:, 0] = 255
+    filt[:, 1] = filter_green
+    filt[:, 2] = 0
+    mk = 200 / 255.0 * sky
+    w_t = mk * filt + (1.0 - mk) * w_t
+    w_t = _tv_adjust_brightness_u8(w_t.to(torch.uint8), 0.8).float()
+    w_t[:, :, 0, 0] = 255.0
+    w_t[:, :, -1, -1] = 0.0
+    return w_t

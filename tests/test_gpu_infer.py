@@ -160,12 +160,42 @@ def test_infer_all_smog_end_to_end():
     assert d8.mean() < 2.0 and np.percentile(d8, 99) <= 6, (d8.mean(), np.percentile(d8, 99), d8.max())
 
 
-def test_unbuilt_events_fail_loudly():
+@pytest.mark.parametrize("sky_idx", [9, 3])
+def test_wildfire_event_matches_oracle(sky_idx):
+    """Wildfire (fire.add_fire) HIP vs the oracle restatement on a 160x192 image (the 281-tap reflect-border Gaussian
+    needs more than 140 pixels per side) with synthetic segmentation logits that contain a sky region.  Byte-image
+    arithmetic: the uint8 stages must agree exactly except where a float lands within rounding of an integer boundary
+    (blurred-mask paste): at most one level, on < 1 % of the values.  PARITY UNPINNED w.r.t. torchvision / kornia."""
+    from climategan_amd import fill, ops
+
+    B, H, W = 2, 160, 192
+    x = t(fill.uniform((B, 3, H, W), 8100))
+    seg = fill.uniform((B, 11, 40, 48), 8101, -1, 1)
+    seg[:, sky_idx, :14, 10:40] += 2.5                                    # a sky band in the upper part
+    seg[:, sky_idx, 30:, :20] += 2.5                                     # and one in the bottom third (cropped away)
+    seg = t(seg).half().float()
+    ref = cpu_ref.add_fire(x, seg, 123.0, sky_idx=sky_idx)
+    got = ops.wildfire(x.cuda(), ops.nchw_to_nhwc(seg.cuda(), torch.float16), 123.0, sky_idx=sky_idx).cpu()
+    assert got.shape == ref.shape
+    d = (got - ref).abs()
+    assert d.max().item() <= 1.0 and (d > 0).float().mean().item() < 1e-2, (d.max().item(), (d > 0).float().mean().item())
+    assert ref[:, 0].max() == 255 and ((ref[:, 0] - ref[:, 2]) > 100).float().mean() > 0.02   # fire really pasted
+
+
+def test_infer_all_three_events():
+    """apply_events' default call: flood + wildfire + smog out of one infer_all (uint8 HWC), masks on request."""
     case = golden_cases()[NAME]
+    # the reflect-border Gaussian of the wildfire needs kernel_size // 2 < image extent: shrink it for the 128x160 fixture
     T = build_trainer(case)
+    T.opts.events.fire.kernel_size, T.opts.events.fire.kernel_sigma = 61, 30.5
     x = t(case_inputs(NAME, case)["x"]).cuda()
-    with pytest.raises(NotImplementedError, match="N1"):
-        T.infer_all(x, bin_value=0.5)
+    out = T.infer_all(x, numpy=True, bin_value=case["bin_value"], return_masks=True)
+    assert set(out) == {"flood", "wildfire", "smog", "mask"}
+    for k in ("flood", "wildfire", "smog"):
+        assert out[k].shape == (case["B"], case["H"], case["W"], 3) and out[k].dtype == np.uint8
+    T.opts.events.fire.kernel_size = 281
+    with pytest.raises(RuntimeError, match="reflect border"):
+        T.infer_all(x, numpy=True, bin_value=case["bin_value"])
 
 
 def test_paint_cloudy_matches_reference_golden():
