@@ -1,5 +1,5 @@
 """Inference throughput of Trainer.infer_all (flood event only) at BASELINE configs[4]'s shape: 640x640, bs 16, fp16.
-Smog / wildfire are not built, so this is the Masker + Painter + uint8 part of that config.
+All three events by default (flood, wildfire, smog); --ignore / --cloudy select variants.
 
 usage (GPU box): python tools/bench_infer.py [--bs 16] [--steps 10]
 """
@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--ignore", nargs="*", default=[], help="events to skip (flood wildfire smog)")
+    ap.add_argument("--cloudy", action="store_true", help="flood through paint_cloudy (apply_events' default)")
     args = ap.parse_args()
     opts = default_opts()
     opts.tasks = ["d", "s", "m", "p"]
@@ -34,19 +36,19 @@ def main():
     T.G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     T.G.set_compute_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
     x = torch.from_numpy(fill.uniform((args.bs, 3, 640, 640), 5)).cuda()
-    stores = {k: [] for k in ("all events", "encode", "depth", "segmentation", "mask", "flood", "numpy")}
+    stores = {k: [] for k in ("all events", "encode", "depth", "segmentation", "mask", "flood", "wildfire", "smog", "numpy")}
     for _ in range(args.warmup):
-        T.infer_all(x, numpy=True, bin_value=0.5, half=True, ignore_event={"wildfire", "smog"})
+        T.infer_all(x, numpy=True, bin_value=0.5, half=True, cloudy=args.cloudy, ignore_event=set(args.ignore))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = T.infer_all(x, numpy=True, stores=stores, bin_value=0.5, half=True, ignore_event={"wildfire", "smog"})
+        out = T.infer_all(x, numpy=True, stores=stores, bin_value=0.5, half=True, cloudy=args.cloudy, ignore_event=set(args.ignore))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = {"workload": "Trainer.infer_all flood only, 640x640 bs %d %s (incl. uint8 D2H)" % (args.bs, args.dtype),
+    res = {"workload": "Trainer.infer_all %s%s, 640x640 bs %d %s (incl. uint8 D2H)" % ("+".join(e for e in ("flood", "wildfire", "smog") if e not in args.ignore), " cloudy" if args.cloudy else "", args.bs, args.dtype),
            "images_per_s": round(args.bs * args.steps / dt, 2), "ms_per_batch": round(dt / args.steps * 1e3, 2),
            "stage_ms": {k: round(1e3 * sum(v) / max(len(v), 1), 2) for k, v in stores.items()},
-           "flood_shape": list(out["flood"].shape)}
+           "outputs": {k: list(v.shape) for k, v in out.items()}}
     print(json.dumps(res))
 
 
