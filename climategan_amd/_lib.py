@@ -107,6 +107,18 @@ _SIGNATURES = {
     "cgan_avgpool3x3s2_bwd_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_maxpool2x2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_maxpool2x2_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_softmax_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    "cgan_softmax_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    "cgan_sigmoid_pair_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    "cgan_sigmoid_pair_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P]),
+    "cgan_softmax_ce_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_float, _P, _P, _P]),
+    "cgan_tv_nhwc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
+    "cgan_entropy_map_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    "cgan_entropy_map_bwd_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    "cgan_minent_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "cgan_bce_logits_map_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),
+    "cgan_ground_intersection_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P]),
+    "cgan_affine_sum_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "cgan_normalize_u8_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_normalize_u8_nhwc": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
                                          _P]),

@@ -210,3 +210,167 @@ class L1Fn(torch.autograd.Function):
         if da_t is None:
             return None, None, None, None
         return ops.scale_by_scalar(ops.NHWC(da_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Masker-side losses and the probability maps they consume
+# ---------------------------------------------------------------------------------------------------------------------
+def _call(name, *args):
+    from . import _lib
+    _lib.check(getattr(_lib.load(), name)(*args), name)
+
+
+def _npix(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+class SoftmaxFn(torch.autograd.Function):
+    """torch.softmax(s, dim=1) on NHWC logits."""
+
+    @staticmethod
+    def forward(ctx, x_t, c):
+        y = torch.empty_like(x_t)
+        _call("cgan_softmax_nhwc", ops._ptr(x_t), ops._ptr(y), ops._DT[x_t.dtype], _npix(x_t), c, ops._stream())
+        ctx.c = c
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        _call("cgan_softmax_bwd_nhwc", ops._ptr(y), ops._ptr(dy.contiguous()), ops._ptr(dx), ops._DT[y.dtype], _npix(y),
+              ctx.c, ops._stream())
+        return dx, None
+
+
+class SigmoidPairFn(torch.autograd.Function):
+    """cat[sigmoid(x), 1 - sigmoid(x)] of 1-channel NHWC logits -> 2-channel NHWC probabilities."""
+
+    @staticmethod
+    def forward(ctx, x_t):
+        y = torch.empty_like(x_t)
+        _call("cgan_sigmoid_pair_nhwc", ops._ptr(x_t), ops._ptr(y), ops._DT[x_t.dtype], _npix(x_t), ops._stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        _call("cgan_sigmoid_pair_bwd_nhwc", ops._ptr(y), ops._ptr(dy.contiguous()), ops._ptr(dx), ops._DT[y.dtype],
+              _npix(y), ops._stream())
+        return dx
+
+
+class SigmoidFn(torch.autograd.Function):
+    """Elementwise sigmoid of an NHWC map (pad channels come out as 0.5; consumers read logical channels only)."""
+
+    @staticmethod
+    def forward(ctx, x_t, c):
+        y = ops.sigmoid(ops.NHWC(x_t, c))
+        ctx.c = c
+        ctx.save_for_backward(y.t)
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(ops.NHWC(y, ctx.c), ops.NHWC(dy.contiguous(), ctx.c), ops.ACT_SIGMOID).t, None
+
+
+class EntropyMapFn(torch.autograd.Function):
+    """prob_2_entropy(p) [* depth] (depth: 1-channel NHWC map, a constant)."""
+
+    @staticmethod
+    def forward(ctx, p_t, c, depth_t):
+        y = torch.empty_like(p_t)
+        _call("cgan_entropy_map_nhwc", ops._ptr(p_t), ops._ptr(depth_t), ops._ptr(y), ops._DT[p_t.dtype], _npix(p_t), c,
+              ops._stream())
+        ctx.c = c
+        ctx.save_for_backward(p_t, depth_t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p_t, depth_t = ctx.saved_tensors
+        dp = torch.empty_like(p_t)
+        _call("cgan_entropy_map_bwd_nhwc", ops._ptr(p_t), ops._ptr(depth_t), ops._ptr(dy.contiguous()), ops._ptr(dp),
+              ops._DT[p_t.dtype], _npix(p_t), ctx.c, ops._stream())
+        return dp, None, None
+
+
+class _ScalarLossFn(torch.autograd.Function):
+    """Shared shape of the value+gradient loss kernels: ``run(acc, dx_or_None)`` fills the device scalar and, when the
+    input wants a gradient, the gradient of the accumulated term; backward scales it by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, run):
+        acc = torch.zeros(1, dtype=torch.float32, device=x_t.device)
+        dx = torch.empty_like(x_t) if ctx.needs_input_grad[0] else None
+        run(acc, dx)
+        ctx.c = c
+        ctx.save_for_backward(dx)
+        return acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        if dx is None:
+            return None, None, None
+        return ops.scale_by_scalar(ops.NHWC(dx, ctx.c), g.reshape(1).float().contiguous()).t, None, None
+
+
+def softmax_ce(logits: ops.NHWC, target: torch.Tensor):
+    """nn.CrossEntropyLoss (mean over pixels); target int64 [n, h, w]."""
+    n = _npix(logits.t)
+    tgt = target.contiguous().long()
+    return _ScalarLossFn.apply(logits.t, logits.c, lambda acc, dx: _call(
+        "cgan_softmax_ce_nhwc", ops._ptr(logits.t), ops._ptr(tgt), logits.dtype_id, n, logits.c, 1.0 / n, ops._ptr(acc),
+        ops._ptr(dx), ops._stream()))
+
+
+def tv_loss(x: ops.NHWC, tvloss_weight=1.0):
+    """TVLoss.forward (losses.py:157-166)."""
+    b, h, w, c = x.n, x.h, x.w, x.c
+    wh = tvloss_weight * 2.0 / (c * (h - 1) * w) / b
+    ww = tvloss_weight * 2.0 / (c * h * (w - 1)) / b
+    return _ScalarLossFn.apply(x.t, c, lambda acc, dx: _call(
+        "cgan_tv_nhwc", ops._ptr(x.t), x.dtype_id, b, h, w, c, wh, ww, ops._ptr(acc), ops._ptr(dx), ops._stream()))
+
+
+def minent_loss(p: ops.NHWC, version=1, lambda_var=0.1):
+    """MinentLoss.__call__ (losses.py:185-196) on a probability map."""
+    n = _npix(p.t)
+    ws = torch.empty(1, dtype=torch.float32, device=p.t.device)
+    return _ScalarLossFn.apply(p.t, p.c, lambda acc, dx: _call(
+        "cgan_minent_nhwc", ops._ptr(p.t), p.dtype_id, n, p.c, int(version), float(lambda_var), 1.0, ops._ptr(acc),
+        ops._ptr(dx), ops._ptr(ws), ops._stream()))
+
+
+def bce_logits_map(x: ops.NHWC, target: torch.Tensor):
+    """nn.BCEWithLogitsLoss(x, target) with a target map [n, 1, h, w] (fp32)."""
+    n = _npix(x.t)
+    tgt = target.contiguous().float()
+    return _ScalarLossFn.apply(x.t, x.c, lambda acc, dx: _call(
+        "cgan_bce_logits_map_nhwc", ops._ptr(x.t), ops._ptr(tgt), x.dtype_id, n, 1.0 / n, ops._ptr(acc), ops._ptr(dx),
+        ops._stream()))
+
+
+def ground_intersection(p: ops.NHWC, ground: torch.Tensor):
+    """GroundIntersectionLoss (piecewise constant: a detached scalar)."""
+    n = _npix(p.t)
+    acc = torch.zeros(1, dtype=torch.float32, device=p.t.device)
+    g = ground.contiguous().float()
+    _call("cgan_ground_intersection_nhwc", ops._ptr(p.t), ops._ptr(g), p.dtype_id, n, 1.0 / n, ops._ptr(acc),
+          ops._stream())
+    return acc[0]
+
+
+def advent_wgan(d_out: ops.NHWC, target: float):
+    """-mean(y * D + (1 - y) * (1 - D)) (losses.py:498-499) for a scalar domain label y."""
+    n = _npix(d_out.t) * d_out.c
+    a, b = -(2.0 * target - 1.0) / n, -(1.0 - target) / n
+    return _ScalarLossFn.apply(d_out.t, d_out.c, lambda acc, dx: _call(
+        "cgan_affine_sum_nhwc", ops._ptr(d_out.t), d_out.dtype_id, _npix(d_out.t), d_out.c, a, b, ops._ptr(acc),
+        ops._ptr(dx), ops._stream()))

@@ -51,7 +51,7 @@ def default_opts() -> Opts:
             "s": {"use_advent": True, "use_dada": True, "architecture": "deeplabv3", "output_dim": 11,
                   "num_classes": 11},                                    # :135-143
             "m": {"use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
-                  "use_dada": False, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
+                  "use_dada": False, "use_minent": True, "use_minent_var": True, "use_ground_intersection": True, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
                   "activ": "lrelu", "pad_type": "reflect", "use_proj": True,
                   "spade": {"latent_dim": 128, "detach": False, "cond_nc": 15, "spade_use_spectral_norm": True,
                             "spade_param_free_norm": "batch", "num_layers": 3,
@@ -74,6 +74,11 @@ def default_opts() -> Opts:
                    "fire": {"kernel_size": 281, "kernel_sigma": 140.5, "transparency": 200, "sky_inc_factor": 0.12,
                             "contrast_factor": 1.5, "brightness_factor": 0.95, "crop_bottom_sky_mask": True}},
         # shared/trainer/events.yaml:1-14
-        "train": {"lambdas": {"G": {"p": {"context": 0, "dm": 1, "featmatch": 10, "gan": 1, "reconstruction": 0,
-                                          "tv": 0, "vgg": 10}}}},          # :293-300
+        "train": {"lambdas": {"advent": {"ent_main": 0.5, "ent_aux": 0.0, "ent_var": 0.1, "adv_main": 1.0,
+                                         "adv_aux": 0.0, "dis_main": 1.0, "dis_aux": 0.0},      # :303-310
+                              "G": {"d": {"main": 1, "gml": 0.5},
+                                    "s": {"crossent": 1, "crossent_pseudo": 0.001, "minent": 0.001, "advent": 0.001},
+                                    "m": {"bce": 1, "tv": 1, "gi": 0.05, "pl4m": 1},               # :280-292
+                                    "p": {"context": 0, "dm": 1, "featmatch": 10, "gan": 1, "reconstruction": 0,
+                                          "tv": 0, "vgg": 10}}}},       # :293-300
     })

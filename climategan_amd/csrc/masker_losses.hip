@@ -1,0 +1,363 @@
+// Masker-side losses (climategan/losses.py:106-196, 444-524) with their gradients, on the NHWC 16-bit maps the
+// decoders produce.  Every entry point ACCUMULATES `weight * sum(...)` into a device fp32 scalar and (optionally)
+// writes the gradient of that term.  HBM-bound elementwise / reduction work.
+#include "cgan_common.h"
+
+namespace {
+
+inline int grid_ml(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+__device__ __forceinline__ void block_add(float v, float* dst) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---- channel softmax (torch.softmax(s, dim=1)) and its backward; sigmoid pair [p, 1 - p] (trainer.py:1533-1534) ----
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                          int c, int cs, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const uint16_t* xp = x + i * cs;
+    float mx = -__builtin_inff();
+    for (int k = 0; k < c; ++k) mx = fmaxf(mx, f32_of_bits<T>(xp[k]));
+    float sum = 0.f;
+    for (int k = 0; k < c; ++k) sum += __expf(f32_of_bits<T>(xp[k]) - mx);
+    const float inv = 1.f / sum;
+    for (int k = 0; k < cs; ++k) y[i * cs + k] = k < c ? bits_of<T>(__expf(f32_of_bits<T>(xp[k]) - mx) * inv) : 0;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const uint16_t* __restrict__ y, const uint16_t* __restrict__ dy,
+                                                          uint16_t* __restrict__ dx, int c, int cs, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float dot = 0.f;
+    for (int k = 0; k < c; ++k) dot += f32_of_bits<T>(y[i * cs + k]) * f32_of_bits<T>(dy[i * cs + k]);
+    for (int k = 0; k < cs; ++k)
+      dx[i * cs + k] = k < c ? bits_of<T>(f32_of_bits<T>(y[i * cs + k]) * (f32_of_bits<T>(dy[i * cs + k]) - dot)) : 0;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_pair_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                               long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float p = 1.f / (1.f + __expf(-f32_of_bits<T>(x[i * 8])));
+    u32x4 o = (u32x4){pack2<T>(p, 1.f - p), 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(y)[i] = o;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_pair_bwd_kernel(const uint16_t* __restrict__ y, const uint16_t* __restrict__ dy,
+                                                               uint16_t* __restrict__ dx, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float p = f32_of_bits<T>(y[i * 8]);
+    const float g = (f32_of_bits<T>(dy[i * 8]) - f32_of_bits<T>(dy[i * 8 + 1])) * p * (1.f - p);
+    u32x4 o = (u32x4){pack2<T>(g, 0.f), 0u, 0u, 0u};
+    reinterpret_cast<u32x4*>(dx)[i] = o;
+  }
+}
+
+// ---- nn.CrossEntropyLoss(logits, target) (losses.py:106-112): mean over pixels of logsumexp(x) - x[target] ----------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const uint16_t* __restrict__ x, const long long* __restrict__ tgt,
+                                                         float weight, float* __restrict__ loss, uint16_t* __restrict__ dx,
+                                                         int c, int cs, long npix) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const uint16_t* xp = x + i * cs;
+    const int t = (int)tgt[i];
+    float mx = -__builtin_inff();
+    for (int k = 0; k < c; ++k) mx = fmaxf(mx, f32_of_bits<T>(xp[k]));
+    float sum = 0.f;
+    for (int k = 0; k < c; ++k) sum += __expf(f32_of_bits<T>(xp[k]) - mx);
+    acc += mx + __logf(sum) - f32_of_bits<T>(xp[t]);
+    if (dx) {
+      const float inv = 1.f / sum;
+      for (int k = 0; k < cs; ++k)
+        dx[i * cs + k] = k < c ? bits_of<T>(weight * (__expf(f32_of_bits<T>(xp[k]) - mx) * inv - (k == t ? 1.f : 0.f))) : 0;
+    }
+  }
+  block_add(acc * weight, loss);
+}
+
+// ---- TVLoss (losses.py:142-169): wh * sum (x[y] - x[y-1])^2 + ww * sum (x[x] - x[x-1])^2 ----------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void tv_kernel(const uint16_t* __restrict__ x, float wh, float ww, float* __restrict__ loss,
+                                                 uint16_t* __restrict__ dx, int h, int w, int c, int cs, long total) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % cs);
+    const long pix = i / cs;
+    if (k >= c) {
+      if (dx) dx[i] = 0;
+      continue;
+    }
+    const int xx = (int)(pix % w), yy = (int)((pix / w) % h);
+    const float v = f32_of_bits<T>(x[i]);
+    float g = 0.f;
+    if (yy > 0) {
+      const float d = v - f32_of_bits<T>(x[i - (long)w * cs]);
+      acc += wh * d * d;
+      g += 2.f * wh * d;
+    }
+    if (yy < h - 1) g -= 2.f * wh * (f32_of_bits<T>(x[i + (long)w * cs]) - v);
+    if (xx > 0) {
+      const float d = v - f32_of_bits<T>(x[i - cs]);
+      acc += ww * d * d;
+      g += 2.f * ww * d;
+    }
+    if (xx < w - 1) g -= 2.f * ww * (f32_of_bits<T>(x[i + cs]) - v);
+    if (dx) dx[i] = bits_of<T>(g);
+  }
+  block_add(acc, loss);
+}
+
+// ---- entropy maps: prob_2_entropy (losses.py:453-458) and MinentLoss (losses.py:172-196) ----------------------------
+__device__ __forceinline__ float ent(float p, float inv_log2c) { return -p * log2f(p + 1e-30f) * inv_log2c; }
+__device__ __forceinline__ float ent_grad(float p, float inv_log2c) {
+  return -(log2f(p + 1e-30f) + p / ((p + 1e-30f) * 0.6931471805599453f)) * inv_log2c;
+}
+
+// y = ent(p) [* depth]  (the DADA weighting of trainer.py:1455-1456); backward dp = dy * ent'(p) [* depth]
+template <typename T>
+__global__ __launch_bounds__(256) void entropy_fwd_kernel(const uint16_t* __restrict__ p, const uint16_t* __restrict__ depth,
+                                                          uint16_t* __restrict__ y, int c, int cs, long total) {
+  const float ilc = 1.f / log2f((float)c);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % cs);
+    const long pix = i / cs;
+    float v = 0.f;
+    if (k < c) {
+      v = ent(f32_of_bits<T>(p[i]), ilc);
+      if (depth) v *= f32_of_bits<T>(depth[pix * 8]);
+    }
+    y[i] = bits_of<T>(v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void entropy_bwd_kernel(const uint16_t* __restrict__ p, const uint16_t* __restrict__ depth,
+                                                          const uint16_t* __restrict__ dy, uint16_t* __restrict__ dp, int c,
+                                                          int cs, long total) {
+  const float ilc = 1.f / log2f((float)c);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % cs);
+    const long pix = i / cs;
+    float v = 0.f;
+    if (k < c) {
+      v = f32_of_bits<T>(dy[i]) * ent_grad(f32_of_bits<T>(p[i]), ilc);
+      if (depth) v *= f32_of_bits<T>(depth[pix * 8]);
+    }
+    dp[i] = bits_of<T>(v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void minent_sum_kernel(const uint16_t* __restrict__ p, float* __restrict__ sum, int c,
+                                                         int cs, long total) {
+  const float ilc = 1.f / log2f((float)c);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    if ((int)(i % cs) < c) acc += ent(f32_of_bits<T>(p[i]), ilc);
+  block_add(acc, sum);
+}
+// version 1: loss = S / nhw.  version 2: mu = S / nhw, loss = sum(e + lam (e - mu)^2) / nhw, whose gradient is
+// e'/nhw * (1 + 2 lam (e - mu) + 2 lam (c - 1) mu)  (the "mean" divides by n h w while the sums run over n c h w).
+template <typename T>
+__global__ __launch_bounds__(256) void minent_kernel(const uint16_t* __restrict__ p, const float* __restrict__ sum, int version,
+                                                     float lam, float weight, float inv_nhw, float* __restrict__ loss,
+                                                     uint16_t* __restrict__ dp, int c, int cs, long total) {
+  const float ilc = 1.f / log2f((float)c);
+  const float mu = sum[0] * inv_nhw;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % cs);
+    float g = 0.f;
+    if (k < c) {
+      const float pv = f32_of_bits<T>(p[i]);
+      const float e = ent(pv, ilc);
+      if (version == 1) {
+        acc += e;
+        g = ent_grad(pv, ilc) * inv_nhw;
+      } else {
+        acc += e + lam * (e - mu) * (e - mu);
+        g = ent_grad(pv, ilc) * inv_nhw * (1.f + 2.f * lam * (e - mu) + 2.f * lam * (float)(c - 1) * mu);
+      }
+    }
+    if (dp) dp[i] = bits_of<T>(weight * g);
+  }
+  block_add(acc * inv_nhw * weight, loss);
+}
+
+// ---- nn.BCEWithLogitsLoss against a target MAP (masker_m_loss, trainer.py:1549-1553): x NHWC 1 channel, t fp32 -------
+template <typename T>
+__global__ __launch_bounds__(256) void bce_map_kernel(const uint16_t* __restrict__ x, const float* __restrict__ t, float weight,
+                                                      float* __restrict__ loss, uint16_t* __restrict__ dx, long npix) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float xv = f32_of_bits<T>(x[i * 8]), tv = t[i];
+    acc += fmaxf(xv, 0.f) - xv * tv + log1pf(__expf(-fabsf(xv)));
+    if (dx) {
+      u32x4 o = (u32x4){pack2<T>(weight * (1.f / (1.f + __expf(-xv)) - tv), 0.f), 0u, 0u, 0u};
+      reinterpret_cast<u32x4*>(dx)[i] = o;
+    }
+  }
+  block_add(acc * weight, loss);
+}
+
+// ---- GroundIntersectionLoss (losses.py:444-450): mean(1.0 * ((g - p) > 0.5)); piecewise constant: no gradient -------
+template <typename T>
+__global__ __launch_bounds__(256) void ground_intersection_kernel(const uint16_t* __restrict__ p, const float* __restrict__ g,
+                                                                  float weight, float* __restrict__ loss, long npix) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x)
+    acc += (g[i] - f32_of_bits<T>(p[i * 8])) > 0.5f ? 1.f : 0.f;
+  block_add(acc * weight, loss);
+}
+
+// ---- sum(a x + b) over the logical channels (the WGAN form of ADVENTAdversarialLoss, losses.py:498-499) ------------
+template <typename T>
+__global__ __launch_bounds__(256) void affine_sum_kernel(const uint16_t* __restrict__ x, float a, float b, float* __restrict__ loss,
+                                                         uint16_t* __restrict__ dx, int c, int cs, long total) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const bool live = (int)(i % cs) < c;
+    if (live) acc += a * f32_of_bits<T>(x[i]) + b;
+    if (dx) dx[i] = live ? bits_of<T>(a) : 0;
+  }
+  block_add(acc, loss);
+}
+
+}  // namespace
+
+#define ML_DISPATCH(dtype, KERNEL, ...)                                     \
+  do {                                                                      \
+    if ((dtype) == CGAN_F16) hipLaunchKernelGGL(KERNEL<F16>, __VA_ARGS__);  \
+    else hipLaunchKernelGGL(KERNEL<BF16>, __VA_ARGS__);                     \
+  } while (0)
+#define ML_CHECK_DT(name) CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, name ": bad dtype %d", dtype)
+
+extern "C" int cgan_softmax_nhwc(const void* x, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream) {
+  CGAN_REQUIRE(x && y && npix > 0 && c > 0, "softmax: bad arguments");
+  ML_CHECK_DT("softmax");
+  ML_DISPATCH(dtype, softmax_fwd_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+              (uint16_t*)y, c, cgan_cs(c), (long)npix);
+  CGAN_CHECK_LAUNCH("softmax");
+  return CGAN_OK;
+}
+extern "C" int cgan_softmax_bwd_nhwc(const void* y, const void* dy, void* dx, int32_t dtype, int64_t npix, int32_t c,
+                                     void* stream) {
+  CGAN_REQUIRE(y && dy && dx && npix > 0 && c > 0, "softmax_bwd: bad arguments");
+  ML_CHECK_DT("softmax_bwd");
+  ML_DISPATCH(dtype, softmax_bwd_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y,
+              (const uint16_t*)dy, (uint16_t*)dx, c, cgan_cs(c), (long)npix);
+  CGAN_CHECK_LAUNCH("softmax_bwd");
+  return CGAN_OK;
+}
+extern "C" int cgan_sigmoid_pair_nhwc(const void* x, void* y, int32_t dtype, int64_t npix, void* stream) {
+  CGAN_REQUIRE(x && y && npix > 0, "sigmoid_pair: bad arguments");
+  ML_CHECK_DT("sigmoid_pair");
+  ML_DISPATCH(dtype, sigmoid_pair_fwd_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+              (uint16_t*)y, (long)npix);
+  CGAN_CHECK_LAUNCH("sigmoid_pair");
+  return CGAN_OK;
+}
+extern "C" int cgan_sigmoid_pair_bwd_nhwc(const void* y, const void* dy, void* dx, int32_t dtype, int64_t npix, void* stream) {
+  CGAN_REQUIRE(y && dy && dx && npix > 0, "sigmoid_pair_bwd: bad arguments");
+  ML_CHECK_DT("sigmoid_pair_bwd");
+  ML_DISPATCH(dtype, sigmoid_pair_bwd_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y,
+              (const uint16_t*)dy, (uint16_t*)dx, (long)npix);
+  CGAN_CHECK_LAUNCH("sigmoid_pair_bwd");
+  return CGAN_OK;
+}
+extern "C" int cgan_softmax_ce_nhwc(const void* logits, const int64_t* target, int32_t dtype, int64_t npix, int32_t c,
+                                    float weight, float* loss_accum, void* dlogits, void* stream) {
+  CGAN_REQUIRE(logits && target && loss_accum && npix > 0 && c > 0, "softmax_ce: bad arguments");
+  ML_CHECK_DT("softmax_ce");
+  ML_DISPATCH(dtype, softmax_ce_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
+              (const long long*)target, weight, loss_accum, (uint16_t*)dlogits, c, cgan_cs(c), (long)npix);
+  CGAN_CHECK_LAUNCH("softmax_ce");
+  return CGAN_OK;
+}
+extern "C" int cgan_tv_nhwc(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, float weight_h,
+                            float weight_w, float* loss_accum, void* dx, void* stream) {
+  CGAN_REQUIRE(x && loss_accum && n > 0 && h > 0 && w > 0 && c > 0, "tv: bad arguments");
+  ML_CHECK_DT("tv");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h * w * cs;
+  ML_DISPATCH(dtype, tv_kernel, dim3(grid_ml(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, weight_h,
+              weight_w, loss_accum, (uint16_t*)dx, h, w, c, cs, total);
+  CGAN_CHECK_LAUNCH("tv");
+  return CGAN_OK;
+}
+extern "C" int cgan_entropy_map_nhwc(const void* p, const void* depth, void* y, int32_t dtype, int64_t npix, int32_t c,
+                                     void* stream) {
+  CGAN_REQUIRE(p && y && npix > 0 && c > 1, "entropy_map: bad arguments");
+  ML_CHECK_DT("entropy_map");
+  const int cs = cgan_cs(c);
+  ML_DISPATCH(dtype, entropy_fwd_kernel, dim3(grid_ml(npix * cs)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)p,
+              (const uint16_t*)depth, (uint16_t*)y, c, cs, (long)npix * cs);
+  CGAN_CHECK_LAUNCH("entropy_map");
+  return CGAN_OK;
+}
+extern "C" int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const void* dy, void* dp, int32_t dtype,
+                                         int64_t npix, int32_t c, void* stream) {
+  CGAN_REQUIRE(p && dy && dp && npix > 0 && c > 1, "entropy_map_bwd: bad arguments");
+  ML_CHECK_DT("entropy_map_bwd");
+  const int cs = cgan_cs(c);
+  ML_DISPATCH(dtype, entropy_bwd_kernel, dim3(grid_ml(npix * cs)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)p,
+              (const uint16_t*)depth, (const uint16_t*)dy, (uint16_t*)dp, c, cs, (long)npix * cs);
+  CGAN_CHECK_LAUNCH("entropy_map_bwd");
+  return CGAN_OK;
+}
+extern "C" int cgan_minent_nhwc(const void* p, int32_t dtype, int64_t npix, int32_t c, int32_t version, float lambda_var,
+                                float weight, float* loss_accum, void* dp, float* workspace_scalar, void* stream) {
+  CGAN_REQUIRE(p && loss_accum && workspace_scalar && npix > 0 && c > 1, "minent: bad arguments");
+  CGAN_REQUIRE(version == 1 || version == 2, "minent: version must be 1 or 2");
+  ML_CHECK_DT("minent");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace_scalar, 0, sizeof(float), s);
+  if (e != hipSuccess) {
+    cgan_set_error("minent: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CGAN_ERR_HIP;
+  }
+  const int cs = cgan_cs(c);
+  const long total = (long)npix * cs;
+  ML_DISPATCH(dtype, minent_sum_kernel, dim3(grid_ml(total)), dim3(256), 0, s, (const uint16_t*)p, workspace_scalar, c, cs,
+              total);
+  ML_DISPATCH(dtype, minent_kernel, dim3(grid_ml(total)), dim3(256), 0, s, (const uint16_t*)p, (const float*)workspace_scalar,
+              version, lambda_var, weight, 1.f / (float)npix, loss_accum, (uint16_t*)dp, c, cs, total);
+  CGAN_CHECK_LAUNCH("minent");
+  return CGAN_OK;
+}
+extern "C" int cgan_bce_logits_map_nhwc(const void* x, const float* target, int32_t dtype, int64_t npix, float weight,
+                                        float* loss_accum, void* dx, void* stream) {
+  CGAN_REQUIRE(x && target && loss_accum && npix > 0, "bce_logits_map: bad arguments");
+  ML_CHECK_DT("bce_logits_map");
+  ML_DISPATCH(dtype, bce_map_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, target,
+              weight, loss_accum, (uint16_t*)dx, (long)npix);
+  CGAN_CHECK_LAUNCH("bce_logits_map");
+  return CGAN_OK;
+}
+extern "C" int cgan_ground_intersection_nhwc(const void* p, const float* ground, int32_t dtype, int64_t npix, float weight,
+                                             float* loss_accum, void* stream) {
+  CGAN_REQUIRE(p && ground && loss_accum && npix > 0, "ground_intersection: bad arguments");
+  ML_CHECK_DT("ground_intersection");
+  ML_DISPATCH(dtype, ground_intersection_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream,
+              (const uint16_t*)p, ground, weight, loss_accum, (long)npix);
+  CGAN_CHECK_LAUNCH("ground_intersection");
+  return CGAN_OK;
+}
+extern "C" int cgan_affine_sum_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float a, float b,
+                                    float* loss_accum, void* dx, void* stream) {
+  CGAN_REQUIRE(x && loss_accum && npix > 0 && c > 0, "affine_sum: bad arguments");
+  ML_CHECK_DT("affine_sum");
+  const int cs = cgan_cs(c);
+  ML_DISPATCH(dtype, affine_sum_kernel, dim3(grid_ml(npix * cs)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, a,
+              b, loss_accum, (uint16_t*)dx, c, cs, (long)npix * cs);
+  CGAN_CHECK_LAUNCH("affine_sum");
+  return CGAN_OK;
+}

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as ag
 from .autograd import BceLogitsFn, ConvFn, L1Fn, MaxPool2x2Fn
 from .norms import _PackCache
 
@@ -157,3 +158,143 @@ class VGGLoss(nn.Module):
             n = f.n * f.h * f.w * f.c
             loss = loss + L1Fn.apply(f.t, r.t, f.c, self.weights[i] / n)
         return loss
+
+
+# ------------------------------------------------------------------------------------------------ masker-side losses
+class CrossEntropy(nn.Module):
+    """reference losses.py:106-112: nn.CrossEntropyLoss(logits, target.long()); logits as an NHWC map."""
+
+    def __call__(self, logits, target):
+        logits = _as_nhwc(logits, "CrossEntropy")
+        return ag.softmax_ce(logits, target.to(logits.t.device))
+
+
+class TVLoss(nn.Module):
+    """reference losses.py:142-169"""
+
+    def __init__(self, tvloss_weight=1):
+        super().__init__()
+        self.tvloss_weight = tvloss_weight
+
+    def forward(self, x):
+        return ag.tv_loss(_as_nhwc(x, "TVLoss"), self.tvloss_weight)
+
+
+class MinentLoss(nn.Module):
+    """reference losses.py:172-196 (version 2 adds the variance of the entropy map)."""
+
+    def __init__(self, version=1, lambda_var=0.1):
+        super().__init__()
+        self.version = version
+        self.lambda_var = lambda_var
+
+    def __call__(self, pred):
+        return ag.minent_loss(_as_nhwc(pred, "MinentLoss"), self.version, self.lambda_var)
+
+
+class GroundIntersectionLoss(nn.Module):
+    """reference losses.py:444-450"""
+
+    def __call__(self, pred, pseudo_ground):
+        pred = _as_nhwc(pred, "GroundIntersectionLoss")
+        return ag.ground_intersection(pred, pseudo_ground.to(pred.t.device))
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """nn.BCEWithLogitsLoss as ``get_losses`` builds it for the mask (losses.py:421): 1-channel NHWC logits vs a target
+    map [n, 1, h, w]."""
+
+    def __call__(self, logits, target):
+        logits = _as_nhwc(logits, "BCEWithLogitsLoss")
+        return ag.bce_logits_map(logits, target.to(logits.t.device))
+
+
+def prob_2_entropy(prob, depth=None):
+    """reference losses.py:453-458 (``depth``: optional 1-channel NHWC map multiplied in, trainer.py:1455-1456)."""
+    prob = _as_nhwc(prob, "prob_2_entropy")
+    y = ag.EntropyMapFn.apply(prob.t, prob.c, depth.t if depth is not None else None)
+    return ops.NHWC(y, prob.c)
+
+
+def softmax(logits):
+    """torch.softmax(s, dim=1) on an NHWC map (trainer.py:1433)."""
+    logits = _as_nhwc(logits, "softmax")
+    return ops.NHWC(ag.SoftmaxFn.apply(logits.t, logits.c), logits.c)
+
+
+def sigmoid(logits):
+    """torch.sigmoid on an NHWC map, differentiable (the mask probability of trainer.py:1533)."""
+    logits = _as_nhwc(logits, "sigmoid")
+    return ops.NHWC(ag.SigmoidFn.apply(logits.t, logits.c), logits.c)
+
+
+def sigmoid_pair(logits):
+    """prob = cat[sigmoid(x), 1 - sigmoid(x)] of the mask logits (trainer.py:1533-1534) as a 2-channel NHWC map."""
+    logits = _as_nhwc(logits, "sigmoid_pair")
+    return ops.NHWC(ag.SigmoidPairFn.apply(logits.t), 2)
+
+
+class CustomBCELoss(nn.Module):
+    """reference losses.py:461-477: BCE-with-logits against a constant domain label."""
+
+    def __call__(self, prediction, target):
+        prediction = _as_nhwc(prediction, "CustomBCELoss")
+        n = prediction.n * prediction.h * prediction.w * prediction.c
+        return BceLogitsFn.apply(prediction.t, prediction.c, float(target), 1.0 / n)
+
+
+class ADVENTAdversarialLoss(nn.Module):
+    """reference losses.py:480-524.  ``gan_type="GAN"`` -> BCE (the D side, losses.py:440); anything else takes the
+    reference's always-true ``elif`` and becomes the WGAN expression -mean(y D + (1 - y)(1 - D))."""
+
+    def __init__(self, opts, gan_type="GAN"):
+        super().__init__()
+        self.opts = opts
+        self.bce = CustomBCELoss() if gan_type == "GAN" else None
+
+    def __call__(self, prediction, target, discriminator, depth_preds=None):
+        d_in = prob_2_entropy(prediction, depth_preds)
+        if self.opts.dis.m.architecture == "OmniDiscriminator":
+            raise NotImplementedError("ADVENT with the OmniDiscriminator architecture has no HIP path (default: base)")
+        d_out = discriminator(d_in, nhwc=True)
+        if self.bce is not None:
+            return self.bce(d_out, target)
+        return ag.advent_wgan(d_out, float(target))
+
+
+class SIGMLoss(nn.Module):
+    """reference losses.py:237-278 (MiDaS scale-invariant loss: medians + 4-scale Sobel).  Not built: needs a device
+    median (selection) kernel; the depth term is inactive for real-domain batches (trainer.py:1389-1407)."""
+
+    def __init__(self, gmweight=0.5, scale=4, device="cuda"):
+        super().__init__()
+        self.gmweight, self.scale = gmweight, scale
+
+    def __call__(self, prediction, target):
+        raise NotImplementedError("SIGMLoss has no HIP kernel yet (device median + multi-scale Sobel)")
+
+
+def get_losses(opts, verbose, device=None):
+    """reference losses.py:353-441: the same nested dictionary (classifier / hinge / DADA-depth options excluded)."""
+    losses = {"G": {"a": {}, "p": {}, "tasks": {}}, "D": {"default": {}, "advent": {}}, "C": {}}
+    if "p" in opts.tasks:
+        losses["G"]["p"]["gan"] = GANLoss(use_lsgan=False, soft_shift=opts.dis.soft_shift, flip_prob=opts.dis.flip_prob)
+        losses["G"]["p"]["vgg"] = VGGLoss(device)
+        losses["G"]["p"]["tv"] = TVLoss()
+        losses["G"]["p"]["featmatch"] = FeatMatchLoss()
+    if "d" in opts.tasks:
+        losses["G"]["tasks"]["d"] = SIGMLoss(opts.train.lambdas.G.d.gml)
+    if "s" in opts.tasks:
+        losses["G"]["tasks"]["s"] = {"crossent": CrossEntropy(), "minent": MinentLoss(),
+                                     "advent": ADVENTAdversarialLoss(opts, gan_type=opts.dis.s.gan_type)}
+    if "m" in opts.tasks:
+        minent = (MinentLoss(version=2, lambda_var=opts.train.lambdas.advent.ent_var) if opts.gen.m.use_minent_var
+                  else MinentLoss())
+        losses["G"]["tasks"]["m"] = {"bce": BCEWithLogitsLoss(), "minent": minent, "tv": TVLoss(),
+                                     "advent": ADVENTAdversarialLoss(opts, gan_type=opts.dis.m.gan_type),
+                                     "gi": GroundIntersectionLoss()}
+    if "p" in opts.tasks:
+        losses["D"]["p"] = losses["G"]["p"]["gan"]          # the SAME object: G-side calls draw smoothing / flips too
+    if "m" in opts.tasks or "s" in opts.tasks:
+        losses["D"]["advent"] = ADVENTAdversarialLoss(opts)
+    return losses

@@ -71,21 +71,18 @@ class Trainer:
                                       "have a HIP training path; Masker training (training-mode BatchNorm, masker "
                                       "losses) is not built")
         from .discriminator import create_discriminator
-        from .losses import FeatMatchLoss, GANLoss, VGGLoss
+        from .losses import get_losses
         from .optim import ExtraAdam
 
         o = self.opts
         self.D = create_discriminator(o, self.device, verbose=self.verbose)
         self.G.train()
         self.D.train()
-        # get_losses (losses.py:369-441): GAN (BCE form, label smoothing / flipping on the D side only), feature
-        # matching, VGG
-        self.losses = {
-            "G": {"p": {"gan": GANLoss(use_lsgan=False, soft_shift=0.0, flip_prob=0.0),
-                        "featmatch": FeatMatchLoss(),
-                        "vgg": VGGLoss(self.device) if o.train.lambdas.G.p.vgg != 0 else None}},
-            "D": {"p": GANLoss(use_lsgan=False, soft_shift=o.dis.soft_shift, flip_prob=o.dis.flip_prob)},
-        }
+        # get_losses (losses.py:353-441).  Note: losses["D"]["p"] IS losses["G"]["p"]["gan"] (one GANLoss object), so
+        # the generator-side call draws label smoothing / flips as well, as in the reference.
+        self.losses = get_losses(o, self.verbose, self.device)
+        if o.train.lambdas.G.p.vgg == 0:
+            self.losses["G"]["p"]["vgg"] = None
         g_params = [p for p in self.G.parameters() if p.requires_grad]
         d_params = [p for p in self.D.parameters() if p.requires_grad]
         self.g_opt = ExtraAdam(g_params, lr=o.gen.opt.lr.default, betas=(o.gen.opt.beta1, 0.999))

@@ -308,6 +308,37 @@ int cgan_maxpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32
 int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
                              int32_t w_in, void* stream);
 
+/* Masker-side losses (climategan/losses.py:106-196, 444-524) on the decoders' NHWC maps; same accumulate-into-a-
+ * device-scalar convention as above (weight carries 1/N and the lambdas).
+ *  softmax / softmax_bwd        torch.softmax(s, dim=1) of the segmentation logits (trainer.py:1433) and its backward
+ *  sigmoid_pair(_bwd)           prob = cat[sigmoid(x), 1 - sigmoid(x)] of the mask logits (trainer.py:1533-1534)
+ *  softmax_ce                   nn.CrossEntropyLoss(logits, target int64) (losses.py:106-112): sum(lse(x) - x[t])
+ *  tv                           TVLoss (losses.py:142-169): weight_h sum (x[y]-x[y-1])^2 + weight_w sum (x[x]-x[x-1])^2
+ *  entropy_map(_bwd)            prob_2_entropy (losses.py:453-458), optionally times a 1-channel depth map (DADA)
+ *  minent                       MinentLoss v1 / v2 (losses.py:172-196) on a probability map; workspace: one float
+ *  bce_logits_map               nn.BCEWithLogitsLoss(x, target map) for the mask (trainer.py:1549-1553)
+ *  ground_intersection          GroundIntersectionLoss (losses.py:444-450): sum 1[(g - p) > 0.5] (no gradient)
+ *  affine_sum                   sum(a x + b): the WGAN form -mean(y D + (1 - y)(1 - D)) of losses.py:498-499 */
+int cgan_softmax_nhwc(const void* x, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream);
+int cgan_softmax_bwd_nhwc(const void* y, const void* dy, void* dx, int32_t dtype, int64_t npix, int32_t c, void* stream);
+int cgan_sigmoid_pair_nhwc(const void* x, void* y, int32_t dtype, int64_t npix, void* stream);
+int cgan_sigmoid_pair_bwd_nhwc(const void* y, const void* dy, void* dx, int32_t dtype, int64_t npix, void* stream);
+int cgan_softmax_ce_nhwc(const void* logits, const int64_t* target, int32_t dtype, int64_t npix, int32_t c, float weight,
+                         float* loss_accum, void* dlogits, void* stream);
+int cgan_tv_nhwc(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, float weight_h, float weight_w,
+                 float* loss_accum, void* dx, void* stream);
+int cgan_entropy_map_nhwc(const void* p, const void* depth, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream);
+int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const void* dy, void* dp, int32_t dtype, int64_t npix,
+                              int32_t c, void* stream);
+int cgan_minent_nhwc(const void* p, int32_t dtype, int64_t npix, int32_t c, int32_t version, float lambda_var,
+                     float weight, float* loss_accum, void* dp, float* workspace_scalar, void* stream);
+int cgan_bce_logits_map_nhwc(const void* x, const float* target, int32_t dtype, int64_t npix, float weight,
+                             float* loss_accum, void* dx, void* stream);
+int cgan_ground_intersection_nhwc(const void* p, const float* ground, int32_t dtype, int64_t npix, float weight,
+                                  float* loss_accum, void* stream);
+int cgan_affine_sum_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float a, float b, float* loss_accum,
+                         void* dx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Output post-ops of the inference harness (Trainer.infer_all, climategan/trainer.py:311-332)
  * ------------------------------------------------------------------------------------------------ */

@@ -36,6 +36,7 @@ def golden_cases():
         "cloudy_small": dict(kind="cloudy", H=128, W=160, B=2, seed=71, gain=1.6, latent_dim=32, n_up=4, bin_value=0.43,
                              rng_seed=4321, sky_idx=6),   # class 6 covers 14 % of this untrained net's argmax map
         "maskspade_small": dict(kind="maskspade", H=128, W=160, B=2, seed=62, gain=1.6),
+        "masker_losses": dict(kind="masker_losses", H=24, W=32, B=2, seed=95),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
@@ -67,6 +68,15 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    if k == "masker_losses":
+        h, w = case["H"], case["W"]
+        return dict(s_logits=fill.uniform((B, 11, h, w), s * 100 + 1, -2, 2),
+                    s_target=(fill.uniform01((B, h, w), s * 100 + 2) * 11).astype(np.int64).clip(0, 10),
+                    m_logits=fill.uniform((B, 1, 2 * h, 2 * w), s * 100 + 3, -3, 3),
+                    m_target=fill.rect_mask(B, 2 * h, 2 * w, s * 100 + 4),
+                    ground=fill.rect_mask(B, 2 * h, 2 * w, s * 100 + 5),
+                    d_pred=fill.uniform((B, 1, h, w), s * 100 + 6, 0.2, 1.0),
+                    d_out=fill.uniform((B, 1, 5, 7), s * 100 + 7, -1, 1))
     if k == "gstep_p":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
@@ -289,6 +299,44 @@ def run_reference_maskspade(name, case):
     return {"d": d.numpy(), "s": s.numpy(), "cond": cond.numpy(), "m": m.numpy(), "logits2": logits.numpy()}
 
 
+def run_reference_masker_losses(name, case):
+    """The masker-side loss classes of the reference (losses.py) on seeded tensors: values and input gradients, composed
+    as masker_s_loss / masker_m_loss compose them (trainer.py:1409-1616)."""
+    from oracle import ref_shim
+
+    L = ref_shim.ref("losses")
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    out = {}
+
+    def record(key, loss, leaf):
+        (g,) = torch.autograd.grad(loss, leaf)
+        out[key] = loss.detach().numpy().reshape(1)
+        out[key + ".grad"] = g.numpy()
+
+    s = inp["s_logits"].clone().requires_grad_(True)
+    record("crossent", L.CrossEntropy()(s, inp["s_target"]), s)
+    s = inp["s_logits"].clone().requires_grad_(True)
+    record("minent_v1", L.MinentLoss()(torch.softmax(s, dim=1)), s)
+    s = inp["s_logits"].clone().requires_grad_(True)
+    ent = L.prob_2_entropy(torch.softmax(s, dim=1)) * inp["d_pred"]
+    out["entropy_dada"] = ent.detach().numpy()
+    record("entropy_dada_sum", (ent * 0.37).sum(), s)
+    m = inp["m_logits"].clone().requires_grad_(True)
+    record("bce", torch.nn.BCEWithLogitsLoss()(m, inp["m_target"]), m)
+    m = inp["m_logits"].clone().requires_grad_(True)
+    record("tv", L.TVLoss()(torch.sigmoid(m)), m)
+    m = inp["m_logits"].clone().requires_grad_(True)
+    p = torch.sigmoid(m)
+    record("minent_v2", L.MinentLoss(version=2, lambda_var=0.1)(torch.cat([p, 1 - p], dim=1)), m)
+    out["gi"] = L.GroundIntersectionLoss()(torch.sigmoid(inp["m_logits"]), inp["ground"]).numpy().reshape(1)
+    d = inp["d_out"].clone().requires_grad_(True)
+    wgan = lambda x, y: -torch.mean(y * x + (1 - y) * (1 - x))      # losses.py:498-499  # noqa: E731
+    record("advent_wgan_0", wgan(d, 0), d)
+    d = inp["d_out"].clone().requires_grad_(True)
+    record("advent_wgan_1", wgan(d, 1), d)
+    return out
+
+
 def run_reference_dstep(name, case):
     """The Painter branch of ``Trainer.get_D_loss`` (trainer.py:1073-1107) with the reference's own modules and
     losses (``GANLoss`` as built by ``get_losses``: BCE form, here soft_shift = flip_prob = 0), then
@@ -407,6 +455,8 @@ def run_reference(name, case):
         return run_reference_cloudy(name, case)
     if case["kind"] == "maskspade":
         return run_reference_maskspade(name, case)
+    if case["kind"] == "masker_losses":
+        return run_reference_masker_losses(name, case)
     if case["kind"] == "dstep_p":
         return run_reference_dstep(name, case)
     if case["kind"] == "gstep_p":

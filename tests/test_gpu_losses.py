@@ -1,0 +1,109 @@
+"""GPU parity of the masker-side losses (HIP value + gradient kernels behind climategan_amd.losses) against values and
+input gradients computed by the REFERENCE's own loss classes (oracle/make_golden.py: masker_losses), composed the way
+masker_s_loss / masker_m_loss compose them (softmax / sigmoid in front, trainer.py:1409-1616).
+
+Inputs are fp32 in the reference and rounded to fp16 NHWC here: loss values within 2e-3 relative, gradients within
+4e-3 of their scale (two to three 16-bit roundings: the probability map and the gradient flowing back through it)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_cases, load_golden, t
+from oracle.make_golden import case_inputs
+
+pytestmark = pytest.mark.gpu
+NAME = "masker_losses"
+
+
+def nhwc(a, requires_grad=False):
+    from climategan_amd import ops
+    x = ops.nchw_to_nhwc(t(a).cuda(), torch.float16)
+    if requires_grad:
+        x.t.requires_grad_(True)
+    return x
+
+
+def grad_nchw(x):
+    from climategan_amd import ops
+    return ops.nhwc_to_nchw(ops.NHWC(x.t.grad, x.c)).cpu().numpy()
+
+
+def check(name, gold, loss, x, vtol=2e-3, gtol=4e-3):
+    ref = float(gold[name][0])
+    assert abs(loss.item() - ref) <= vtol * max(abs(ref), 1e-3), (name, loss.item(), ref)
+    if x is not None:
+        g, gr = grad_nchw(x), gold[name + ".grad"]
+        scale = max(np.abs(gr).max(), 1e-12)
+        err = np.abs(g - gr).max()
+        assert err <= gtol * scale, "%s grad: max err %.3g (scale %.3g)" % (name, err, scale)
+
+
+def test_masker_losses_match_reference():
+    from climategan_amd import losses as L
+
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    inp = case_inputs(NAME, case)
+
+    s = nhwc(inp["s_logits"], True)
+    loss = L.CrossEntropy()(s, t(inp["s_target"]).cuda())
+    loss.backward()
+    check("crossent", gold, loss, s)
+
+    s = nhwc(inp["s_logits"], True)
+    loss = L.MinentLoss()(L.softmax(s))
+    loss.backward()
+    check("minent_v1", gold, loss, s)
+
+    s = nhwc(inp["s_logits"], True)
+    ent = L.prob_2_entropy(L.softmax(s), nhwc(inp["d_pred"]))
+    from climategan_amd import ops
+    got_ent = ops.nhwc_to_nchw(ops.NHWC(ent.t.detach(), ent.c)).cpu().numpy()
+    assert np.abs(got_ent - gold["entropy_dada"]).max() <= 2e-3 * np.abs(gold["entropy_dada"]).max()
+    ent.t.backward(torch.full_like(ent.t, 0.37))       # d/ds of (ent * 0.37).sum()
+    g, gr = grad_nchw(s), gold["entropy_dada_sum.grad"]
+    assert np.abs(g - gr).max() <= 4e-3 * np.abs(gr).max()
+
+    m = nhwc(inp["m_logits"], True)
+    loss = L.BCEWithLogitsLoss()(m, t(inp["m_target"]).cuda())
+    loss.backward()
+    check("bce", gold, loss, m)
+
+    m = nhwc(inp["m_logits"], True)
+    prob = L.sigmoid_pair(m)                            # [p, 1 - p]
+    loss = L.MinentLoss(version=2, lambda_var=0.1)(prob)
+    loss.backward()
+    check("minent_v2", gold, loss, m)
+
+    m = nhwc(inp["m_logits"], True)
+    p1 = L.sigmoid(m)
+    loss = L.TVLoss()(p1)
+    loss.backward()
+    check("tv", gold, loss, m, gtol=8e-3)          # second differences of a 16-bit map
+
+    loss = L.GroundIntersectionLoss()(p1, t(inp["ground"]).cuda())
+    assert abs(loss.item() - float(gold["gi"][0])) <= 2e-3           # a few pixels sit within fp16 rounding of 0.5
+
+    for y in (0, 1):
+        d = nhwc(inp["d_out"], True)
+        from climategan_amd.autograd import advent_wgan
+        loss = advent_wgan(d, float(y))
+        loss.backward()
+        check("advent_wgan_%d" % y, gold, loss, d)
+
+
+def test_tv_loss_gradient_matches_torch():
+    """TVLoss value + gradient on a multi-channel map against torch autograd of the reference formula."""
+    from climategan_amd import fill, losses as L, ops
+    x = t(fill.uniform((2, 3, 17, 23), 9100)).half().float().requires_grad_(True)
+    h_tv = ((x[:, :, 1:, :] - x[:, :, :-1, :]) ** 2).sum()
+    w_tv = ((x[:, :, :, 1:] - x[:, :, :, :-1]) ** 2).sum()
+    ref = 2 * (h_tv / (3 * 16 * 23) + w_tv / (3 * 17 * 22)) / 2
+    ref.backward()
+    xg = ops.nchw_to_nhwc(x.detach().cuda(), torch.float16)
+    xg.t.requires_grad_(True)
+    loss = L.TVLoss()(xg)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-3 * abs(ref.item())
+    g = ops.nhwc_to_nchw(ops.NHWC(xg.t.grad, 3)).cpu()
+    assert (g - x.grad).abs().max() <= 2e-3 * x.grad.abs().max()
