@@ -174,6 +174,48 @@ class MaxPool2x2Fn(torch.autograd.Function):
         return ops.maxpool2x2_bwd(ops.NHWC(x_t, ctx.c), ops.NHWC(dy_t.contiguous(), ctx.c)).t, None
 
 
+class BatchNormActFn(torch.autograd.Function):
+    """out = act(batch_norm(x)) in TRAINING mode (batch statistics over n, h, w; running statistics updated in place,
+    momentum / unbiased variance as nn.BatchNorm2d).  gamma / beta may be None (affine=False)."""
+
+    @staticmethod
+    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope):
+        from . import _lib
+        lib = _lib.load()
+        n, h, w, cs = x_t.shape
+        npix = n * h * w
+        flat = ops.NHWC(x_t.view(1, npix, 1, cs), c)                   # one "image" of n*h*w pixels
+        mean, rstd = ops.instnorm_stats(flat, eps=eps)                  # [1, cs] batch statistics
+        mean_f = torch.empty_like(mean)
+        rstd_f = torch.empty_like(rstd)
+        _lib.check(lib.cgan_bn_train_prepare(
+            ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma), ops._ptr(beta), float(eps), float(momentum), npix,
+            ops._ptr(running_mean), ops._ptr(running_var), ops._ptr(mean_f), ops._ptr(rstd_f), c, ops._stream()),
+            "cgan_bn_train_prepare")
+        out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope).t.view(n, h, w, cs)
+        ctx.cfg = (c, act, slope)
+        ctx.save_for_backward(x_t, out, mean, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        from . import _lib
+        lib = _lib.load()
+        x_t, out, mean, rstd, gamma = ctx.saved_tensors
+        c, act, slope = ctx.cfg
+        n, h, w, cs = x_t.shape
+        nbytes = lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
+        dx = torch.empty_like(x_t)
+        dg = torch.zeros(c, dtype=torch.float32, device=x_t.device) if gamma is not None else None
+        db = torch.zeros(c, dtype=torch.float32, device=x_t.device) if gamma is not None else None
+        _lib.check(lib.cgan_batchnorm_act_bwd(
+            ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t.contiguous()), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
+            ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._DT[x_t.dtype], n * h * w, c, act, slope, ops._ptr(ws), nbytes,
+            ops._stream()), "cgan_batchnorm_act_bwd")
+        return dx, dg, db, None, None, None, None, None, None, None
+
+
 class BceLogitsFn(torch.autograd.Function):
     """weight * sum BCEWithLogits(x, target) over the logical channels -> fp32 device scalar."""
 

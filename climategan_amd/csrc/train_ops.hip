@@ -207,6 +207,137 @@ __global__ void spade_bwd_prepare_kernel(const uint16_t* __restrict__ dy, const 
   }
 }
 
+// ---- training-mode BatchNorm2d (+ activation): statistics over (N, H, W), affine, running-stat update, backward ------
+// The batch statistics come from cgan_instnorm_stats on the tensor viewed as ONE image of n*h*w pixels.
+// bn_train_prepare: (mean, rstd) of the batch -> the (mean', rstd') pair cgan_norm_act_apply consumes
+//   rstd' = gamma * rstd, mean' = mean - beta / rstd'   and   running <- (1 - mom) running + mom * (mean, unbiased var)
+__global__ void bn_train_prepare_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                        float momentum, float count, float* __restrict__ running_mean,
+                                        float* __restrict__ running_var, float* __restrict__ mean_out,
+                                        float* __restrict__ rstd_out, int c, int cs) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= cs) return;
+  float m = 0.f, r = 0.f;
+  if (ch < c) {
+    const float mu = mean[ch], rs = rstd[ch];
+    r = rs * (gamma ? gamma[ch] : 1.f);
+    m = mu - ((beta && r != 0.f) ? beta[ch] / r : 0.f);
+    if (running_mean) {
+      const float var_b = 1.f / (rs * rs) - eps;                               // biased batch variance
+      const float var_u = count > 1.f ? var_b * count / (count - 1.f) : var_b;  // nn.BatchNorm2d tracks the unbiased one
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mu;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * var_u;
+    }
+  }
+  mean_out[ch] = m;
+  rstd_out[ch] = r;
+}
+
+// out = act(gamma xh + beta), xh = (x - mean) rstd.  dz = dy act'(out);  sums[c] = (sum dz, sum dz xh) over n*h*w
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
+                                                            const uint16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ sums,
+                                                            long npix, int cs, int ppb, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL][cgb*8][2]
+  const int cg_total = cs / 8;
+  const int cgb = cg_total < 256 ? cg_total : 256;
+  const int PL = 256 / cgb;
+  const int cg0 = blockIdx.y * cgb;
+  const long p0 = (long)blockIdx.x * ppb, p1 = min(npix, p0 + ppb);
+  const int t = threadIdx.x, cgl = t % cgb, pl = t / cgb;
+  const int cg = cg0 + cgl;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL && cg < cg_total) {
+    for (long p = p0 + pl; p < p1; p += PL) {
+      const size_t off = (size_t)p * cs + cg * 8;
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(x + off);
+      const u32x4 vo = *reinterpret_cast<const u32x4*>(out + off);
+      const u32x4 vg = *reinterpret_cast<const u32x4*>(dy + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xv[2], ov[2], gv[2];
+        unpack2<T>(vx[e], xv[0], xv[1]);
+        unpack2<T>(vo[e], ov[0], ov[1]);
+        unpack2<T>(vg[e], gv[0], gv[1]);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int ch = cg * 8 + 2 * e + hh;
+          const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
+          const float xh = (xv[hh] - mean[ch]) * rstd[ch];
+          s1[2 * e + hh] += dz;
+          s2[2 * e + hh] += dz * xh;
+        }
+      }
+    }
+  }
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sm[((pl * cgb + cgl) * 8 + e) * 2] = s1[e];
+      sm[((pl * cgb + cgl) * 8 + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < cgb * 8; c += 256) {
+    if (cg0 * 8 + c >= cs) continue;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < PL; ++l) {
+      a += sm[((l * cgb) * 8 + c) * 2];
+      b += sm[((l * cgb) * 8 + c) * 2 + 1];
+    }
+    atomicAdd(sums + (size_t)(cg0 * 8 + c) * 2, a);
+    atomicAdd(sums + (size_t)(cg0 * 8 + c) * 2 + 1, b);
+  }
+}
+
+// dx = rstd gamma (dz - mean(dz) - xh mean(dz xh));  dgamma = sum dz xh, dbeta = sum dz (block 0 writes them)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
+                                    const uint16_t* __restrict__ dy, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, uint16_t* __restrict__ dx, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, float inv_count, int cs, int c, int act, float slope,
+                                    long groups) {
+  const int cg_total = cs / 8;
+  if (blockIdx.x == 0) {
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+      if (dgamma) dgamma[ch] += sums[2 * ch + 1];
+      if (dbeta) dbeta[ch] += sums[2 * ch];
+    }
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const u32x4 vx = reinterpret_cast<const u32x4*>(x)[i];
+    const u32x4 vo = reinterpret_cast<const u32x4*>(out)[i];
+    const u32x4 vg = reinterpret_cast<const u32x4*>(dy)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xv[2], ov[2], gv[2], res[2];
+      unpack2<T>(vx[e], xv[0], xv[1]);
+      unpack2<T>(vo[e], ov[0], ov[1]);
+      unpack2<T>(vg[e], gv[0], gv[1]);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int ch = cg * 8 + 2 * e + hh;
+        float v = 0.f;
+        if (ch < c) {
+          const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
+          const float xh = (xv[hh] - mean[ch]) * rstd[ch];
+          v = rstd[ch] * (gamma ? gamma[ch] : 1.f) * (dz - sums[2 * ch] * inv_count - xh * sums[2 * ch + 1] * inv_count);
+        }
+        res[hh] = v;
+      }
+      r[e] = pack2<T>(res[0], res[1]);
+    }
+    reinterpret_cast<u32x4*>(dx)[i] = r;
+  }
+}
+
 // ---- losses ---------------------------------------------------------------------------------------------------
 // block-level sum -> one atomic per block
 __device__ __forceinline__ void block_atomic_add(float v, float* dst) {
@@ -374,6 +505,61 @@ extern "C" int cgan_spade_bwd_prepare(const void* dy, const void* y, const void*
              (const uint16_t*)y, (const uint16_t*)x, mean, rstd, (const uint16_t*)gamma, (uint16_t*)dgb, (uint16_t*)xhat,
              (uint16_t*)dxhat, d->h, d->w, d->c, cs, cs2, d->x_upsample, d->act, d->act_slope, groups);
   CGAN_CHECK_LAUNCH("spade_bwd_prepare");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma,
+                                     const float* beta, float eps, float momentum, int64_t count, float* running_mean,
+                                     float* running_var, float* mean_out, float* rstd_out, int32_t c, void* stream) {
+  CGAN_REQUIRE(batch_mean && batch_rstd && mean_out && rstd_out, "bn_train_prepare: null pointer");
+  CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_prepare: running stats go together");
+  CGAN_REQUIRE(c > 0 && count > 0, "bn_train_prepare: bad shape");
+  const int cs = cgan_cs(c);
+  hipLaunchKernelGGL(bn_train_prepare_kernel, dim3((cs + 255) / 256), dim3(256), 0, (hipStream_t)stream, batch_mean,
+                     batch_rstd, gamma, beta, eps, momentum, (float)count, running_mean, running_var, mean_out, rstd_out, c,
+                     cs);
+  CGAN_CHECK_LAUNCH("bn_train_prepare");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c) {
+  return c > 0 ? (size_t)cgan_cs(c) * 2 * sizeof(float) : 0;
+}
+
+extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
+                                      const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                                      int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(x && out && dy && batch_mean && batch_rstd && dx && workspace, "batchnorm_act_bwd: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "batchnorm_act_bwd: bad dtype %d", dtype);
+  CGAN_REQUIRE(npix > 0 && c > 0, "batchnorm_act_bwd: bad shape");
+  CGAN_REQUIRE(act == CGAN_ACT_NONE || act == CGAN_ACT_RELU || act == CGAN_ACT_LRELU,
+               "batchnorm_act_bwd: Unsupported activation: %d", act);
+  CGAN_REQUIRE(workspace_bytes >= cgan_batchnorm_act_bwd_workspace_bytes(c), "batchnorm_act_bwd: workspace too small");
+  const int cs = cgan_cs(c);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, cgan_batchnorm_act_bwd_workspace_bytes(c), s);
+  if (e != hipSuccess) {
+    cgan_set_error("batchnorm_act_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CGAN_ERR_HIP;
+  }
+  const int cg_total = cs / 8;
+  const int cgb = cg_total < 256 ? cg_total : 256;
+  const int PL = 256 / cgb;
+  long chunks = 2048 / ceil_div(cg_total, cgb);
+  if (chunks < 1) chunks = 1;
+  long ppb = (npix + chunks - 1) / chunks;
+  if (ppb < 4 * PL) ppb = 4 * PL;
+  chunks = (npix + ppb - 1) / ppb;
+  const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
+  DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, ceil_div(cg_total, cgb)), dim3(256), smem, s,
+             (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, (float*)workspace,
+             (long)npix, cs, (int)ppb, act, act_slope);
+  const long groups = (long)npix * cg_total;
+  DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)x,
+             (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, gamma, (const float*)workspace,
+             (uint16_t*)dx, dgamma, dbeta, 1.f / (float)npix, cs, c, act, act_slope, groups);
+  CGAN_CHECK_LAUNCH("batchnorm_act_bwd");
   return CGAN_OK;
 }
 

@@ -275,6 +275,21 @@ int cgan_instnorm_act_bwd(const void* out, const void* dy, const float* rstd, vo
  * xhat / dxhat) are separate calls. */
 int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                            const void* gamma, void* dgb, void* xhat, void* dxhat, const CganSpadeDesc* d, void* stream);
+/* Training-mode nn.BatchNorm2d (+ ReLU / LeakyReLU) (ResNet-101, ASPP, depth decoder: climategan/deeplab/
+ * resnet101_v3.py:30-50, deeplab_v3.py:54-57, depth.py:56-114).  Batch statistics = cgan_instnorm_stats on the tensor
+ * viewed as one image of n*h*w pixels; then
+ *  bn_train_prepare   folds gamma / beta into the (mean', rstd') pair cgan_norm_act_apply consumes and updates the
+ *                     running statistics (momentum, unbiased variance) as nn.BatchNorm2d does; count = n*h*w
+ *  batchnorm_act_bwd  given x (the BN input), out = act(bn(x)) and dy: dx, and dgamma / dbeta ACCUMULATED (fp32);
+ *                     workspace cgan_batchnorm_act_bwd_workspace_bytes(c) */
+int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma, const float* beta,
+                          float eps, float momentum, int64_t count, float* running_mean, float* running_var,
+                          float* mean_out, float* rstd_out, int32_t c, void* stream);
+size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);
+int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
+                           const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                           int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* nn.BCEWithLogitsLoss(x, target) pieces against a constant target (GANLoss, climategan/losses.py:50-83; ADVENT
  * D-side BCE, losses.py:461-477) over the c logical channels of x [npix][cgan_cs(c)]:
  * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */

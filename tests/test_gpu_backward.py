@@ -271,3 +271,41 @@ def test_spade_fn_backward(dt, C, H, W, ups, act):
     for k in names:
         e = rel_err(ps[k].grad.cpu(), sd[k].grad)
         assert e <= (5e-3 if dt == torch.float16 else 8e-2), "%s: rel err %.3g" % (k, e)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,h,w,act,affine", [(64, 20, 24, "relu", True), (256, 9, 11, "none", True), (20, 13, 7, "lrelu", False)])
+def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
+    """autograd.BatchNormActFn (training-mode BatchNorm2d + activation) vs torch: output, running statistics after the
+    update, and the gradients of x, gamma, beta."""
+    from climategan_amd import ops
+    from climategan_amd.autograd import BatchNormActFn
+    B = 3
+    bn = torch.nn.BatchNorm2d(c, affine=affine)
+    if affine:
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(1.0 + 0.3 * fill.uniform((c,), 7100)))
+            bn.bias.copy_(torch.from_numpy(0.2 * fill.uniform((c,), 7101)))
+    bn.running_mean.copy_(torch.from_numpy(0.1 * fill.uniform((c,), 7102)))
+    bn.running_var.copy_(torch.from_numpy(1.0 + 0.2 * fill.uniform01((c,), 7103)))
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train()
+    x = q(fill.uniform((B, c, h, w), 7104 + c, -2, 2), dt).requires_grad_(True)
+    f = {"relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "none": lambda v: v}[act]
+    y = f(bn(x))
+    dy = q(fill.uniform((B, c, h, w), 7105), dt)
+    y.backward(dy)
+
+    a = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act]
+    xt = to_nhwc(x.detach(), dt).t.requires_grad_(True)
+    g = bn.weight.detach().clone().cuda().requires_grad_(True) if affine else None
+    b = bn.bias.detach().clone().cuda().requires_grad_(True) if affine else None
+    rm, rv = rm0.cuda(), rv0.cuda()
+    out = BatchNormActFn.apply(xt, g, b, rm, rv, c, bn.eps, bn.momentum, a, 0.2)
+    assert rel_err(back(ops.NHWC(out.detach(), c)), y.detach()) <= TOL[dt]
+    assert rel_err(rm.cpu(), bn.running_mean) <= 1e-5 and rel_err(rv.cpu(), bn.running_var) <= 1e-5
+    out.backward(to_nhwc(dy, dt).t)
+    assert rel_err(back(ops.NHWC(xt.grad, c)), x.grad) <= (4e-3 if dt == torch.float16 else 4e-2)
+    if affine:
+        assert rel_err(g.grad.cpu(), bn.weight.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
+        assert rel_err(b.grad.cpu(), bn.bias.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
