@@ -91,6 +91,7 @@ _SIGNATURES = {
     "cgan_resize_bicubic_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, _P]),
     "cgan_sumpool2x2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_reflect_pad_bwd_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_copy_channels_nhwc": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_eltwise_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P]),
     "cgan_fold_bn": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int32, C.c_int64, _P]),

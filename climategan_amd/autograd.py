@@ -23,7 +23,7 @@ class ConvFn(torch.autograd.Function):
         res = ops.NHWC(res_t, weight.shape[0]) if res_t is not None else None
         y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"], act=cfg["act"],
                        slope=cfg["slope"], residual=res, in_upsample=cfg.get("in_upsample", False),
-                       residual_upsample=cfg.get("residual_upsample", False))
+                       residual_upsample=cfg.get("residual_upsample", False), pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
@@ -45,7 +45,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             h_in, w_in = (x_t.shape[1] * 2, x_t.shape[2] * 2) if ups else (x_t.shape[1], x_t.shape[2])
             dx = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], h_in, w_in), stride=cfg["stride"], pad=cfg["pad"],
-                                     dilation=cfg["dilation"], sigma=sigma)
+                                     dilation=cfg["dilation"], sigma=sigma, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
             dx_t = (ops.sumpool2x2(dx) if ups else dx).t
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres_t = (ops.sumpool2x2(dy) if cfg.get("residual_upsample", False) else dy).t
@@ -53,7 +53,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"],
                                            pad=cfg["pad"], dilation=cfg["dilation"], want_bias=ctx.has_bias,
-                                           in_upsample=ups)
+                                           in_upsample=ups, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
             if ctx.sn is not None:
                 dw = ops.spectral_norm_bwd(dw, weight.detach(), ctx.sn[1], ctx.sn[2], ctx.sn[0])
         return dx_t, dw, db, dres_t, None, None, None

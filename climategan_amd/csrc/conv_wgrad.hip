@@ -27,6 +27,7 @@ struct WgradArgs {
   int kh, kw, stride, pad, dil;
   int h_out, w_out, npix;
   int nchunks, ci_blocks, splits;
+  int reflect; // 1: nn.ReflectionPad2d(pad) in front of the conv (index math instead of the zero page)
   int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
 };
 
@@ -89,7 +90,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.dy) + off_dy),
           (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16, 0, 0);
-      const int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
+      int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
+      if (p.reflect) {
+        iy = iy < 0 ? -iy : (iy >= p.h_in ? 2 * p.h_in - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= p.w_in ? 2 * p.w_in - 2 - ix : ix);
+      }
       const bool xv = pv && ci_ok && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
       const long off_x = xv ? (p.x_ups ? ((((long)nn * (p.h_in >> 1) + (iy >> 1)) * (p.w_in >> 1) + (ix >> 1)) * p.cin_s + ci0 + q8) * 2
                                        : ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + ci0 + q8) * 2)
@@ -199,7 +204,10 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
                                            const CganConvDesc* d, void* stream) {
   CGAN_REQUIRE(d != nullptr && x && dy && dw_oihw, "conv2d_nhwc_bwd_weight: null pointer");
   CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d_nhwc_bwd_weight: bad dtype %d", d->dtype);
-  CGAN_REQUIRE(d->pad_mode == CGAN_PAD_ZERO, "conv2d_nhwc_bwd_weight: only zero padding has a backward path");
+  CGAN_REQUIRE(d->pad_mode == CGAN_PAD_ZERO || d->pad_mode == CGAN_PAD_REFLECT, "conv2d_nhwc_bwd_weight: bad pad mode");
+  if (d->pad_mode == CGAN_PAD_REFLECT)
+    CGAN_REQUIRE(d->pad < d->h_in && d->pad < d->w_in && !d->in_upsample,
+                 "conv2d_nhwc_bwd_weight: reflect padding must be < input size (and is not combined with in_upsample)");
   if (d->in_upsample) CGAN_REQUIRE((d->h_in % 2) == 0 && (d->w_in % 2) == 0, "conv2d_nhwc_bwd_weight: in_upsample needs even h_in/w_in");
   CGAN_REQUIRE(d->n > 0 && d->h_in > 0 && d->w_in > 0 && d->c_in > 0 && d->c_out > 0 && d->kh > 0 && d->kw > 0 &&
                    d->stride > 0 && d->dilation > 0 && d->pad >= 0,
@@ -217,6 +225,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   CGAN_REQUIRE(npix < (1L << 31) - 256, "conv2d_nhwc_bwd_weight: too many pixels");
   a.npix = (int)npix;
   a.x_ups = d->in_upsample;
+  a.reflect = d->pad_mode == CGAN_PAD_REFLECT;
   a.nchunks = ceil_div(a.npix, 128);
   a.ci_blocks = ceil_div(a.cin_s, 64);
   const int blocks = ceil_div(a.cout_s, 64) * a.ci_blocks;

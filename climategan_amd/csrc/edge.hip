@@ -296,6 +296,47 @@ __global__ void sumpool2x2_kernel(const uint16_t* __restrict__ x, uint16_t* __re
   }
 }
 
+// backward of nn.ReflectionPad2d(p): dx[y][x] = sum of the padded-gradient entries that mirror onto (y, x)
+template <typename T>
+__global__ void reflect_pad_bwd_kernel(const uint16_t* __restrict__ dxp, uint16_t* __restrict__ dx, int h, int w, int pad,
+                                       int cs, long total) {
+  const int cg_total = cs / 8;
+  const int hp = h + 2 * pad, wp = w + 2 * pad;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int x = (int)(pix % w);
+    const long r = pix / w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + pad;
+    if (y >= 1 && y <= pad) ys[ny++] = pad - y;
+    if (y <= h - 2 && y >= h - 1 - pad) ys[ny++] = 2 * (h - 1) - y + pad;
+    xs[nx++] = x + pad;
+    if (x >= 1 && x <= pad) xs[nx++] = pad - x;
+    if (x <= w - 2 && x >= w - 1 - pad) xs[nx++] = 2 * (w - 1) - x + pad;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dxp + ((n * hp + ys[a]) * (long)wp + xs[b]) * cs + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float p0, p1;
+          unpack2<T>(v[e], p0, p1);
+          acc[2 * e] += p0;
+          acc[2 * e + 1] += p1;
+        }
+      }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(dx + pix * cs + cg * 8) = o;
+  }
+}
+
 // copy the c channels of src [n*hw][cs_src] into channels [c_off, c_off + c) of dst [n*hw][cs_dst]
 // (torch.cat along channels = one call per input; c_off must be a multiple of 8 -- true for every concat of the path)
 __global__ void copy_channels_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cs_src,
@@ -507,6 +548,24 @@ extern "C" int cgan_sumpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32
     hipLaunchKernelGGL(sumpool2x2_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y,
                        h_out, w_out, cs, total);
   CGAN_CHECK_LAUNCH("sumpool2x2");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_reflect_pad_bwd_nhwc(const void* dx_padded, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h,
+                                         int32_t w, int32_t pad, void* stream) {
+  CGAN_REQUIRE(dx_padded && dx, "reflect_pad_bwd: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "reflect_pad_bwd: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && pad >= 0 && pad < h && pad < w, "reflect_pad_bwd: bad shape");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h * w * (cs / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)dx_padded,
+                       (uint16_t*)dx, h, w, pad, cs, total);
+  else
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)dx_padded,
+                       (uint16_t*)dx, h, w, pad, cs, total);
+  CGAN_CHECK_LAUNCH("reflect_pad_bwd");
   return CGAN_OK;
 }
 

@@ -35,12 +35,13 @@ def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw
     """Differentiable conv (autograd.ConvFn).  Options without a backward kernel raise."""
     from .autograd import ConvFn
 
-    if kw.get("pad_mode", ops.PAD_ZERO) != ops.PAD_ZERO:
-        raise NotImplementedError("climategan_amd: reflect padding has no backward kernel yet (training path)")
+    pad_mode = kw.get("pad_mode", ops.PAD_ZERO)
+    if pad_mode == ops.PAD_REFLECT and kw.get("in_upsample"):
+        raise NotImplementedError("climategan_amd: reflect padding on a folded upsample has no backward kernel")
     res = kw.get("residual")
     cfg = dict(c_in=x.c, stride=stride, pad=pad, dilation=dilation, act=kw.get("act", ops.ACT_NONE),
                slope=kw.get("slope", 0.2), in_upsample=bool(kw.get("in_upsample", False)),
-               residual_upsample=bool(kw.get("residual_upsample", False)))
+               residual_upsample=bool(kw.get("residual_upsample", False)), pad_mode=pad_mode)
     y_t = ConvFn.apply(x.t, weight, bias, res.t if res is not None else None, packed, cfg, sn)
     return ops.NHWC(y_t, weight.shape[0])
 

@@ -402,9 +402,26 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
     return NHWC(y, pw.c_out)
 
 
+def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
+    """Backward of nn.ReflectionPad2d(pad): folds the gradient of the padded tensor onto the unpadded extent."""
+    _need_cuda(dxp.t)
+    h, w = dxp.h - 2 * pad, dxp.w - 2 * pad
+    dx = torch.empty((dxp.n, h, w, dxp.cs), dtype=dxp.t.dtype, device=dxp.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_reflect_pad_bwd_nhwc(_ptr(dxp.t), _ptr(dx), dxp.dtype_id, dxp.n, dxp.c, h, w, int(pad), _stream()),
+               "cgan_reflect_pad_bwd_nhwc")
+    return NHWC(dx, dxp.c)
+
+
 def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilation=1,
-                    sigma: Optional[torch.Tensor] = None) -> NHWC:
-    """dx of y = conv(x, w / sigma): ``w`` fp32 OIHW, ``x_shape`` = (n, h_in, w_in) of the forward input."""
+                    sigma: Optional[torch.Tensor] = None, pad_mode=PAD_ZERO) -> NHWC:
+    """dx of y = conv(x, w / sigma): ``w`` fp32 OIHW, ``x_shape`` = (n, h_in, w_in) of the forward input.  Reflect
+    padding: data gradient of the pad-0 conv over the padded extent, folded back by the reflection's adjoint."""
+    if pad_mode == PAD_REFLECT and pad > 0:
+        n, h_in, w_in = x_shape
+        dxp = conv2d_bwd_data(dy, w, (n, h_in + 2 * pad, w_in + 2 * pad), stride=stride, pad=0, dilation=dilation,
+                              sigma=sigma)
+        return reflect_pad_bwd(dxp, pad)
     _need_cuda(dy.t, w, sigma)
     w = w.detach().contiguous().float()
     c_out, c_in, kh, kw = w.shape
@@ -438,13 +455,14 @@ def sumpool2x2(x: NHWC) -> NHWC:
 
 
 def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, want_bias=True,
-                      dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, in_upsample=False):
+                      dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, in_upsample=False,
+                      pad_mode=PAD_ZERO):
     """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given.
     ``in_upsample``: x is the stored (half-resolution) tensor the forward read through the folded x2 upsample."""
     _need_cuda(x.t, dy.t, dw, dbias)
     c_out, c_in, kh, kw = w_shape
     h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
-    d = _conv_desc(x.dtype_id, x.n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dilation, PAD_ZERO,
+    d = _conv_desc(x.dtype_id, x.n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dilation, pad_mode,
                    in_upsample=in_upsample)
     if (d.h_out, d.w_out) != (dy.h, dy.w) or dy.c != c_out or x.c != c_in or dy.n != x.n:
         raise RuntimeError("conv2d_bwd_weight: shapes do not match the forward conv")

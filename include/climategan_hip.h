@@ -99,7 +99,9 @@ int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t co
 
 /* Backward of the convolution above (autograd of nn.Conv2d, reached from g_loss.backward() / d_loss.backward(),
  * climategan/trainer.py:1011,1028).  All take the FORWARD descriptor; act / bias / residual fields are ignored (their
- * backward is elementwise and lives in the callers); zero padding only.  With in_upsample, bwd_weight reads x through
+ * backward is elementwise and lives in the callers).  bwd_data takes zero padding only: for a reflect-padded conv call it
+ * with the pad-0 descriptor of the PADDED extent and fold the result with cgan_reflect_pad_bwd_nhwc; bwd_weight accepts
+ * reflect padding directly.  With in_upsample, bwd_weight reads x through
  * the folded upsample and bwd_data returns the gradient at the LOGICAL (h_in, w_in) extent (follow with
  * cgan_sumpool2x2_nhwc to get the gradient of the stored tensor).
  *  - bwd_data:   dx[n][h_in][w_in][cgan_cs(c_in)] = conv_transpose(dy, w)  (rows / columns no window reached are zero);
@@ -239,6 +241,10 @@ int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, int32_t n, i
  * -> y [n][h_out][w_out][cs], each output the sum of its 2x2 block */
 int cgan_sumpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32_t c, int32_t h_out, int32_t w_out,
                          void* stream);
+/* backward of nn.ReflectionPad2d(pad) (Conv2dBlock's reflect padding, climategan/blocks.py:66-72): dx_padded
+ * [n][h+2 pad][w+2 pad][cs] (the data gradient of the pad-0 convolution over the padded extent) -> dx [n][h][w][cs] */
+int cgan_reflect_pad_bwd_nhwc(const void* dx_padded, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                              int32_t pad, void* stream);
 /* torch.cat along channels, one call per input: copies the c channels of src (pixel stride cs_src) into channels
  * [c_off, c_off + c) of dst (pixel stride cs_dst); c_off % 8 == 0 (deeplab_v3.py:107,139; blocks.py:311) */
 int cgan_copy_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t cs_dst,

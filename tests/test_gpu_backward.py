@@ -94,7 +94,7 @@ def test_dgrad_with_sigma():
     assert rel_err(back(dx), x.grad) <= 2e-3     # w / sigma is rounded to fp16 once more than in the reference
 
 
-def test_backward_refuses_reflect_and_upsample():
+def test_dgrad_entry_refuses_reflect_descriptor():
     import ctypes as C
     from climategan_amd import _lib, ops
     lib = _lib.load()
@@ -309,3 +309,24 @@ def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
     if affine:
         assert rel_err(g.grad.cpu(), bn.weight.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
         assert rel_err(b.grad.cpu(), bn.bias.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,pad,H,W", [(64, 64, 3, 1, 20, 24), (16, 32, 3, 1, 9, 13), (8, 8, 7, 3, 12, 10)])
+def test_conv_reflect_pad_backward(dt, cin, cout, k, pad, H, W):
+    """Reflect-padded conv (Conv2dBlock of the mask / depth decoders): data gradient = pad-0 dgrad over the padded extent
+    folded by the reflection's adjoint; weight gradient reads x through the reflection."""
+    from climategan_amd import ops
+    B = 2
+    x = q(fill.uniform((B, cin, H, W), 6100 + cin), dt).requires_grad_(True)
+    w = q(fill.uniform((cout, cin, k, k), 6200 + cout, -0.1, 0.1), dt).requires_grad_(True)
+    b = torch.from_numpy(fill.uniform((cout,), 6300)).requires_grad_(True)
+    y = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), w, b)
+    dy = q(fill.uniform(tuple(y.shape), 6400), dt)
+    y.backward(dy)
+    dyg = to_nhwc(dy, dt)
+    dx = ops.conv2d_bwd_data(dyg, w.detach().cuda(), (B, H, W), pad=pad, pad_mode=ops.PAD_REFLECT)
+    assert dx.t.shape[1:3] == (H, W)
+    assert rel_err(back(dx), x.grad) <= 2 * TOL[dt]
+    dw, db = ops.conv2d_bwd_weight(to_nhwc(x.detach(), dt), dyg, tuple(w.shape), pad=pad, pad_mode=ops.PAD_REFLECT)
+    assert rel_err(dw.cpu(), w.grad) <= 2e-4 and rel_err(db.cpu(), b.grad) <= 2e-4
