@@ -8,21 +8,23 @@
 // One workgroup (4 waves, one per SIMD; two workgroups co-resident per CU) owns a 16 x 16 pixel tile of one
 // image and NCT <= 5 channel tiles (a channel tile = 16 MFMA rows = 8 gamma + 8 beta channels):
 //
-//   prologue  x tile -> registers (lane-linear 16-B chunks), conditioning halo 20 x 20 x cond_c -> LDS, first
-//             weight stages in flight (LDS-DMA)
+//   prologue  conditioning halo 20 x 20 x cond_c -> LDS, first weight stage in flight (LDS-DMA), hidden quarter 0
 //   K loop    the 128 hidden channels are processed in four QUARTERS of 32 (one MFMA k-step per tap), so only
-//             18*18*32 values (20.7 KB) of the hidden map are resident per quarter, double-buffered:
+//             18*18*32 values (21 KB) of the hidden map are resident per quarter, double-buffered:
 //               - gamma||beta implicit GEMM out of LDS, fp32 accumulate: M = NCT*16 rows, N = 256 pixels,
-//                 36 stages = 4 quarters x 3 dx x 3 dy, 1 k-step each.  The activation (B) fragments of the 6 halo
-//                 rows a wave needs are read once per (quarter, dx) and reused for the three dy taps; weight (A)
-//                 fragments stream L2 -> LDS by LDS-DMA through a 4-deep ring with counted vmcnt waits.
-//               - INTERLEAVED with those MFMAs, each wave computes its share of the NEXT quarter's hidden map
-//                 (one 16-pixel hidden tile per stage: cond gather -> 4 small MFMAs -> ReLU -> LDS), so the
-//                 shared 3x3 conv costs no extra wall time after the first quarter.
+//                 12 stages = 4 quarters x 3 dx, the 3 dy taps inside a stage.  The activation (B) fragments of the
+//                 6 halo rows a wave needs are read once per (quarter, dx) and reused for the three dy taps; weight
+//                 (A) fragments stream L2 -> LDS by LDS-DMA, one stage (3*NCT KiB) ahead, double-buffered.
+//               - between the MFMA blocks each wave computes its share of the NEXT quarter's hidden map (cond gather
+//                 -> small MFMAs with the shared-conv weights held in registers, bias through a constant-one column
+//                 -> ReLU -> LDS); for NCT <= 3 that work is interleaved with the MFMAs at instruction granularity
+//                 (sched_group_barrier), for NCT >= 4 it runs between blocks (the interleaved form spills there).
+//               - the x tile is DMA'd into the idle hidden buffer during the last quarter.
 //   epilogue  one v_permlane32_swap pair brings gamma and beta of the same channel into the same lane; x is
 //             normalised, activated and written back through LDS as whole 16-byte channel chunks.
 // The 128-channel hidden map (105 MB/img at 640x640 in 16-bit) never touches HBM; HBM traffic is x (read) +
-// y (write) + the 3-channel cond halo.  LDS fragment reads per MFMA: (15 A + 6 B) / 60 = 0.35.
+// y (write) + the 4-channel cond halo.  LDS fragment reads per MFMA: (3*NCT A + 6 B) / (12*NCT) = 0.35 at NCT 5.
+// Conditioning with more than 4 channels (the SPADE mask decoder's 15) takes a generic, non-interleaved hidden path.
 //
 // MFMA operand roles: A = weights (rows = output channels), B = activations (cols = pixels), so that
 // D's per-lane 4 registers are 4 consecutive channel rows of one pixel (col = lane&15, row = 4*(lane>>4)+r).
