@@ -416,3 +416,129 @@ def advent_wgan(d_out: ops.NHWC, target: float):
     return _ScalarLossFn.apply(d_out.t, d_out.c, lambda acc, dx: _call(
         "cgan_affine_sum_nhwc", ops._ptr(d_out.t), d_out.dtype_id, _npix(d_out.t), d_out.c, a, b, ops._ptr(acc),
         ops._ptr(dx), ops._stream()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Structural ops of the Masker's graph
+# ---------------------------------------------------------------------------------------------------------------------
+class ResizeBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_t, c, size, align_corners):
+        y = ops.resize_bilinear(ops.NHWC(x_t, c), size, align_corners=align_corners)
+        ctx.cfg = (c, x_t.shape[1], x_t.shape[2], int(size[0]), int(size[1]), bool(align_corners))
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        c, h_in, w_in, h_out, w_out, align = ctx.cfg
+        dy = dy.contiguous()
+        n = dy.shape[0]
+        lib = _lib.load()
+        nbytes = lib.cgan_resize_bilinear_bwd_workspace_bytes(n, c, h_in, w_in)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+        dx = torch.empty((n, h_in, w_in, dy.shape[3]), dtype=dy.dtype, device=dy.device)
+        _lib.check(lib.cgan_resize_bilinear_bwd_nhwc(ops._ptr(dy), ops._ptr(dx), ops._DT[dy.dtype], n, c, h_in, w_in,
+                                                     h_out, w_out, int(align), ops._ptr(ws), nbytes, ops._stream()),
+                   "cgan_resize_bilinear_bwd_nhwc")
+        return dx, None, None, None
+
+
+class ResizeNearest2xFn(torch.autograd.Function):
+    """InterpolateNearest2d(scale_factor=2) materialised (the mask decoder's upsamples under autograd)."""
+
+    @staticmethod
+    def forward(ctx, x_t, c):
+        ctx.c = c
+        return ops.resize_nearest(ops.NHWC(x_t, c), (x_t.shape[1] * 2, x_t.shape[2] * 2)).t
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.sumpool2x2(ops.NHWC(dy.contiguous(), ctx.c)).t, None
+
+
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_t, c):
+        ctx.c = c
+        ctx.save_for_backward(x_t)
+        return ops.maxpool3x3s2(ops.NHWC(x_t, c)).t
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        (x_t,) = ctx.saved_tensors
+        dx = torch.empty_like(x_t)
+        _lib.check(_lib.load().cgan_maxpool3x3s2_bwd_nhwc(ops._ptr(x_t), ops._ptr(dy.contiguous()), ops._ptr(dx),
+                                                          ops._DT[x_t.dtype], x_t.shape[0], ctx.c, x_t.shape[1],
+                                                          x_t.shape[2], ops._stream()), "cgan_maxpool3x3s2_bwd_nhwc")
+        return dx, None
+
+
+class AddActFn(torch.autograd.Function):
+    """y = act(a + b); the gradient dy * act'(y) goes to both inputs."""
+
+    @staticmethod
+    def forward(ctx, a_t, b_t, c, act, slope):
+        from . import _lib
+        y = torch.empty_like(a_t)
+        _lib.check(_lib.load().cgan_add_act_nhwc(ops._ptr(a_t), ops._ptr(b_t), ops._ptr(y), ops._DT[a_t.dtype], act,
+                                                 slope, a_t.numel(), ops._stream()), "cgan_add_act_nhwc")
+        ctx.cfg = (c, act, slope)
+        ctx.save_for_backward(y if act != ops.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c, act, slope = ctx.cfg
+        (y,) = ctx.saved_tensors
+        g = dy.contiguous()
+        if y is not None:
+            g = ops.act_bwd(ops.NHWC(y, c), ops.NHWC(g, c), act, slope).t
+        return g, g, None, None, None
+
+
+class MulFn(torch.autograd.Function):
+    """y = a * b elementwise (the DADA fusion z * z_depth, deeplab_v3.py:253-254)."""
+
+    @staticmethod
+    def forward(ctx, a_t, b_t, c):
+        ctx.c = c
+        ctx.save_for_backward(a_t, b_t)
+        return ops.eltwise_mul(ops.NHWC(a_t, c), ops.NHWC(b_t, c)).t
+
+    @staticmethod
+    def backward(ctx, dy):
+        a_t, b_t = ctx.saved_tensors
+        g = ops.NHWC(dy.contiguous(), ctx.c)
+        da = ops.eltwise_mul(g, ops.NHWC(b_t, ctx.c)).t if ctx.needs_input_grad[0] else None
+        db = ops.eltwise_mul(g, ops.NHWC(a_t, ctx.c)).t if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+class ConcatFn(torch.autograd.Function):
+    """torch.cat along channels of NHWC maps (logical channel counts ``cs``; every offset but the last a multiple of 8)."""
+
+    @staticmethod
+    def forward(ctx, cs_list, *ts):
+        ctx.cs_list = list(cs_list)
+        y = ops.concat_channels([ops.NHWC(t, c) for t, c in zip(ts, cs_list)])
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        lib = _lib.load()
+        dy = dy.contiguous()
+        npix = dy.shape[0] * dy.shape[1] * dy.shape[2]
+        grads, off = [], 0
+        for i, c in enumerate(ctx.cs_list):
+            if ctx.needs_input_grad[1 + i]:
+                g = torch.empty(dy.shape[:3] + (ops.cs8(c),), dtype=dy.dtype, device=dy.device)
+                _lib.check(lib.cgan_slice_channels_nhwc(ops._ptr(dy), ops._ptr(g), npix, c, dy.shape[3], off,
+                                                        ops._stream()), "cgan_slice_channels_nhwc")
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += c
+        return (None,) + tuple(grads)

@@ -193,6 +193,142 @@ __global__ void maxpool2x2_bwd_kernel(const uint16_t* __restrict__ x, const uint
   }
 }
 
+
+// ---- backward passes the Masker's graph needs ----------------------------------------------------------------------
+// bilinear resize backward (F.interpolate(mode="bilinear"), both align_corners conventions): scatter with fp32 atomics
+// into an accumulation buffer [n][h_in][w_in][cs] (zeroed by the host entry), converted to 16 bit afterwards
+template <typename T>
+__global__ void bilinear_bwd_scatter_kernel(const uint16_t* __restrict__ dy, float* __restrict__ acc, int h_in, int w_in,
+                                            int h_out, int w_out, int cs, float sy, float sx, int align, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int ox = (int)(pix % w_out);
+    const long r = pix / w_out;
+    const int oy = (int)(r % h_out);
+    const long n = r / h_out;
+    const float fy = align ? oy * sy : fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+    const float fx = align ? ox * sx : fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < h_in - 1 ? y0 : h_in - 1;
+    x0 = x0 < w_in - 1 ? x0 : w_in - 1;
+    const int y1 = y0 < h_in - 1 ? y0 + 1 : y0, x1 = x0 < w_in - 1 ? x0 + 1 : x0;
+    const float ly = fy - y0, lx = fx - x0;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    const u32x4 g = *reinterpret_cast<const u32x4*>(dy + pix * cs + cg * 8);
+    float gv[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unpack2<T>(g[e], gv[2 * e], gv[2 * e + 1]);
+    float* base = acc + n * (long)h_in * w_in * cs + cg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(base + ((long)y0 * w_in + x0) * cs + e, w00 * gv[e]);
+      atomicAdd(base + ((long)y0 * w_in + x1) * cs + e, w01 * gv[e]);
+      atomicAdd(base + ((long)y1 * w_in + x0) * cs + e, w10 * gv[e]);
+      atomicAdd(base + ((long)y1 * w_in + x1) * cs + e, w11 * gv[e]);
+    }
+  }
+}
+template <typename T>
+__global__ void f32_to_16_kernel(const float* __restrict__ a, uint16_t* __restrict__ y, long groups) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v0 = reinterpret_cast<const f32x4*>(a)[2 * i], v1 = reinterpret_cast<const f32x4*>(a)[2 * i + 1];
+    u32x4 o = (u32x4){pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3])};
+    reinterpret_cast<u32x4*>(y)[i] = o;
+  }
+}
+
+// nn.MaxPool2d(3, 2, 1) backward (ResNet stem): every input pixel checks the (<= 4) windows that contain it and takes
+// dy where it is that window's FIRST maximum in row-major order (torch's tie rule)
+template <typename T>
+__global__ void maxpool3x3s2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                        uint16_t* __restrict__ dx, int h_in, int w_in, int h_out, int w_out, int cs,
+                                        long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int ix = (int)(pix % w_in);
+    const long r = pix / w_in;
+    const int iy = (int)(r % h_in);
+    const long n = r / h_in;
+    const uint16_t* xb = x + n * (long)h_in * w_in * cs + cg * 8;
+    float me[8], acc[8];
+    {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * w_in + ix) * cs);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) unpack2<T>(v[e], me[2 * e], me[2 * e + 1]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy >= h_out) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox >= w_out) continue;
+        bool win[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) win[e] = true;
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = 2 * oy - 1 + ky, xx = 2 * ox - 1 + kx;
+            if (yy < 0 || yy >= h_in || xx < 0 || xx >= w_in || (yy == iy && xx == ix)) continue;
+            const bool before = yy < iy || (yy == iy && xx < ix);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((long)yy * w_in + xx) * cs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a, b;
+              unpack2<T>(v[e], a, b);
+              // an earlier element wins ties, a later one only if strictly greater
+              if (before ? a >= me[2 * e] : a > me[2 * e]) win[2 * e] = false;
+              if (before ? b >= me[2 * e + 1] : b > me[2 * e + 1]) win[2 * e + 1] = false;
+            }
+          }
+        const u32x4 g = *reinterpret_cast<const u32x4*>(dy + ((n * h_out + oy) * (long)w_out + ox) * cs + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          unpack2<T>(g[e], a, b);
+          if (win[2 * e]) acc[2 * e] += a;
+          if (win[2 * e + 1]) acc[2 * e + 1] += b;
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(dx + pix * cs + cg * 8) = o;
+  }
+}
+
+// y = act(a + b) (the residual add + ReLU of a ResNet bottleneck in training mode, resnet101_v3.py:46-48)
+template <typename T>
+__global__ void add_act_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
+                               int act, float slope, long groups) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 va = reinterpret_cast<const u32x4*>(a)[i], vb = reinterpret_cast<const u32x4*>(b)[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a0, a1, b0, b1;
+      unpack2<T>(va[e], a0, a1);
+      unpack2<T>(vb[e], b0, b1);
+      o[e] = pack2<T>(act_apply(a0 + b0, act, slope), act_apply(a1 + b1, act, slope));
+    }
+    reinterpret_cast<u32x4*>(y)[i] = o;
+  }
+}
+
+// dst[pix][0..c) = src[pix][c_off_src .. c_off_src + c)   (backward of torch.cat along channels: a channel slice)
+__global__ void slice_channels_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cs_src, int cs_dst,
+                                      int c_off_src, int c, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % cs_dst);
+    const long pix = idx / cs_dst;
+    dst[idx] = k < c ? src[pix * cs_src + c_off_src + k] : 0;
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_PT(dtype, KERNEL, ...)                                     \
@@ -270,5 +406,80 @@ extern "C" int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx,
   DISPATCH_PT(dtype, maxpool2x2_bwd_kernel, dim3(grid_pt(total)), dim3(256), 0, s, (const uint16_t*)x,
               (const uint16_t*)dy, (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, total);
   CGAN_CHECK_LAUNCH("maxpool2x2_bwd");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_resize_bilinear_bwd_workspace_bytes(int32_t n, int32_t c, int32_t h_in, int32_t w_in) {
+  return (n > 0 && c > 0 && h_in > 0 && w_in > 0) ? (size_t)n * h_in * w_in * cgan_cs(c) * sizeof(float) : 0;
+}
+
+extern "C" int cgan_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                             int32_t w_in, int32_t h_out, int32_t w_out, int32_t align_corners,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(dy && dx && workspace, "resize_bilinear_bwd: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "resize_bilinear_bwd: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "resize_bilinear_bwd: bad shape");
+  const size_t need = cgan_resize_bilinear_bwd_workspace_bytes(n, c, h_in, w_in);
+  CGAN_REQUIRE(workspace_bytes >= need, "resize_bilinear_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, need, s);
+  if (e != hipSuccess) {
+    cgan_set_error("resize_bilinear_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CGAN_ERR_HIP;
+  }
+  const int cs = cgan_cs(c);
+  float sy, sx;
+  if (align_corners) {
+    sy = h_out > 1 ? (float)(h_in - 1) / (float)(h_out - 1) : 0.f;
+    sx = w_out > 1 ? (float)(w_in - 1) / (float)(w_out - 1) : 0.f;
+  } else {
+    sy = (float)h_in / (float)h_out;
+    sx = (float)w_in / (float)w_out;
+  }
+  const long total = (long)n * h_out * w_out * (cs / 8);
+  DISPATCH_PT(dtype, bilinear_bwd_scatter_kernel, dim3(grid_pt(total)), dim3(256), 0, s, (const uint16_t*)dy,
+              (float*)workspace, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners, total);
+  const long groups = (long)n * h_in * w_in * (cs / 8);
+  DISPATCH_PT(dtype, f32_to_16_kernel, dim3(grid_pt(groups)), dim3(256), 0, s, (const float*)workspace, (uint16_t*)dx,
+              groups);
+  CGAN_CHECK_LAUNCH("resize_bilinear_bwd");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_maxpool3x3s2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c,
+                                          int32_t h_in, int32_t w_in, void* stream) {
+  CGAN_REQUIRE(x && dy && dx, "maxpool3x3s2_bwd: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "maxpool3x3s2_bwd: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0, "maxpool3x3s2_bwd: bad shape");
+  const int h_out = (h_in + 2 - 3) / 2 + 1, w_out = (w_in + 2 - 3) / 2 + 1, cs = cgan_cs(c);
+  const long total = (long)n * h_in * w_in * (cs / 8);
+  DISPATCH_PT(dtype, maxpool3x3s2_bwd_kernel, dim3(grid_pt(total)), dim3(256), 0, (hipStream_t)stream,
+              (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, total);
+  CGAN_CHECK_LAUNCH("maxpool3x3s2_bwd");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_add_act_nhwc(const void* a, const void* b, void* y, int32_t dtype, int32_t act, float act_slope,
+                                 int64_t numel, void* stream) {
+  CGAN_REQUIRE(a && b && y, "add_act: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "add_act: bad dtype %d", dtype);
+  CGAN_REQUIRE(numel > 0 && (numel % 8) == 0, "add_act: numel must be a positive multiple of 8");
+  CGAN_REQUIRE(act >= CGAN_ACT_NONE && act <= CGAN_ACT_SIGMOID, "add_act: Unsupported activation: %d", act);
+  const long groups = numel / 8;
+  DISPATCH_PT(dtype, add_act_kernel, dim3(grid_pt(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+              (const uint16_t*)b, (uint16_t*)y, act, act_slope, groups);
+  CGAN_CHECK_LAUNCH("add_act");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_slice_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src,
+                                        int32_t c_off_src, void* stream) {
+  CGAN_REQUIRE(src && dst, "slice_channels: null pointer");
+  CGAN_REQUIRE(npix > 0 && c > 0 && c_off_src >= 0 && c_off_src + c <= cs_src, "slice_channels: bad channel range");
+  const int cs_dst = cgan_cs(c);
+  const long total = npix * cs_dst;
+  hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_pt(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, (uint16_t*)dst, cs_src, cs_dst, c_off_src, c, total);
+  CGAN_CHECK_LAUNCH("slice_channels");
   return CGAN_OK;
 }

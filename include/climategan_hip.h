@@ -360,6 +360,23 @@ int cgan_ground_intersection_nhwc(const void* p, const float* ground, int32_t dt
 int cgan_affine_sum_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float a, float b, float* loss_accum,
                          void* dx, void* stream);
 
+/* Backward / training-mode pieces of the Masker's graph:
+ *  resize_bilinear_bwd   adjoint of cgan_resize_bilinear_nhwc (fp32 atomic accumulation, workspace n*h_in*w_in*cs floats)
+ *  maxpool3x3s2_bwd      adjoint of cgan_maxpool3x3s2_nhwc (gradient to the first maximum of each window)
+ *  add_act               y = act(a + b): the residual add + ReLU of a bottleneck when BatchNorm cannot be folded
+ *                        (climategan/deeplab/resnet101_v3.py:46-48); its backward is cgan_act_bwd on y, to both inputs
+ *  slice_channels        dst[.., 0..c) = src[.., c_off_src .. c_off_src + c): adjoint of the channel concatenation */
+size_t cgan_resize_bilinear_bwd_workspace_bytes(int32_t n, int32_t c, int32_t h_in, int32_t w_in);
+int cgan_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                  int32_t w_in, int32_t h_out, int32_t w_out, int32_t align_corners, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+int cgan_maxpool3x3s2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                               int32_t w_in, void* stream);
+int cgan_add_act_nhwc(const void* a, const void* b, void* y, int32_t dtype, int32_t act, float act_slope, int64_t numel,
+                      void* stream);
+int cgan_slice_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t c_off_src,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Output post-ops of the inference harness (Trainer.infer_all, climategan/trainer.py:311-332)
  * ------------------------------------------------------------------------------------------------ */

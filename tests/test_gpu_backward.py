@@ -330,3 +330,38 @@ def test_conv_reflect_pad_backward(dt, cin, cout, k, pad, H, W):
     assert rel_err(back(dx), x.grad) <= 2 * TOL[dt]
     dw, db = ops.conv2d_bwd_weight(to_nhwc(x.detach(), dt), dyg, tuple(w.shape), pad=pad, pad_mode=ops.PAD_REFLECT)
     assert rel_err(dw.cpu(), w.grad) <= 2e-4 and rel_err(db.cpu(), b.grad) <= 2e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_structural_functions_backward(dt):
+    """Bilinear resize (both conventions), 3x3/s2 max pool, nearest x2, add+ReLU, multiply and channel concatenation:
+    the autograd Functions of the Masker's graph against torch autograd."""
+    from climategan_amd import ops
+    from climategan_amd import autograd as ag
+    B = 2
+    tolg = 2 * TOL[dt]
+
+    def run(fn_hip, fn_ref, shapes, seed):
+        xs = [q(fill.uniform(s, seed + i, -2, 2), dt).requires_grad_(True) for i, s in enumerate(shapes)]
+        y = fn_ref(*xs)
+        dy = q(fill.uniform(tuple(y.shape), seed + 50), dt)
+        y.backward(dy)
+        ts = [to_nhwc(x.detach(), dt).t.requires_grad_(True) for x in xs]
+        out = fn_hip(*ts)
+        assert rel_err(back(ops.NHWC(out.detach(), y.shape[1])), y.detach()) <= TOL[dt]
+        out.backward(to_nhwc(dy, dt).t)
+        for x, tt in zip(xs, ts):
+            assert rel_err(back(ops.NHWC(tt.grad, x.shape[1])), x.grad) <= tolg
+
+    for align in (True, False):
+        run(lambda a: ag.ResizeBilinearFn.apply(a, 24, (23, 31), align),
+            lambda a: F.interpolate(a, size=(23, 31), mode="bilinear", align_corners=align), [(B, 24, 10, 14)], 8200)
+        run(lambda a: ag.ResizeBilinearFn.apply(a, 11, (9, 7), align),
+            lambda a: F.interpolate(a, size=(9, 7), mode="bilinear", align_corners=align), [(B, 11, 20, 16)], 8210)
+    run(lambda a: ag.MaxPool3x3s2Fn.apply(a, 16), lambda a: F.max_pool2d(a, 3, 2, 1), [(B, 16, 21, 18)], 8220)
+    run(lambda a: ag.ResizeNearest2xFn.apply(a, 8), lambda a: F.interpolate(a, scale_factor=2), [(B, 8, 6, 5)], 8230)
+    run(lambda a, b: ag.AddActFn.apply(a, b, 16, ops.ACT_RELU, 0.0), lambda a, b: F.relu(a + b),
+        [(B, 16, 7, 9), (B, 16, 7, 9)], 8240)
+    run(lambda a, b: ag.MulFn.apply(a, b, 16), lambda a, b: a * b, [(B, 16, 7, 9), (B, 16, 7, 9)], 8250)
+    run(lambda a, b, c: ag.ConcatFn.apply([16, 24, 5], a, b, c), lambda a, b, c: torch.cat([a, b, c], 1),
+        [(B, 16, 6, 7), (B, 24, 6, 7), (B, 5, 6, 7)], 8260)
