@@ -9,6 +9,7 @@ replicates every pixel 4 times, so mean and biased variance are unchanged).
 import torch
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 from .norms import (DEFAULT_COMPUTE_DTYPE, SPADE, SpectralNorm, _grad_guard, _PackCache, conv_bn_forward,
                     conv_forward)
@@ -23,6 +24,8 @@ class InterpolateNearest2d(nn.Module):
 
     def forward(self, x):
         if isinstance(x, ops.NHWC):
+            if self.scale_factor == 2:
+                return Fn.upsample_nearest2x(x)
             return ops.resize_nearest(x, (x.h * self.scale_factor, x.w * self.scale_factor))
         dt = DEFAULT_COMPUTE_DTYPE
         y = ops.resize_nearest(ops.nchw_to_nhwc(x, dt), (x.shape[-2] * self.scale_factor, x.shape[-1] * self.scale_factor))
@@ -76,6 +79,7 @@ class Conv2dBlock(nn.Module):
         if norm == "spectral" or use_spectral_norm:
             self.conv = SpectralNorm(nn.Conv2d(input_dim, output_dim, kernel_size, stride, dilation=dilation,
                                                bias=self.use_bias))
+            self.conv.trainable = True          # conv (zero / reflect pad), residual and activation all have backward kernels
         else:
             self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, dilation=dilation,
                                   bias=self.use_bias if norm != "batch" else False)
@@ -180,13 +184,13 @@ class BaseDecoder(nn.Module):
             else:
                 z, low = z
                 low = self.low_level_conv.forward_nhwc(low)
-                low = ops.resize_bilinear(low, (z.h, z.w), align_corners=False)     # blocks.py:300-302
+                low = Fn.resize_bilinear(low, (z.h, z.w), align_corners=False)      # blocks.py:300-302
         if z_depth is not None and self.use_dada:
-            z = ops.eltwise_mul(z, z_depth)
+            z = Fn.mul(z, z_depth)
         if self.proj_conv is not None:
             z = self.proj_conv.forward_nhwc(z)
         if low is not None:
-            z = self.merge_feats_conv.forward_nhwc(ops.concat_channels([low, z]))
+            z = self.merge_feats_conv.forward_nhwc(Fn.concat_channels([low, z]))
         for m in self.model:
             z = m(z) if isinstance(m, InterpolateNearest2d) else m.forward_nhwc(z)
         return z

@@ -6,6 +6,7 @@ decoder is called with swapped arguments ``self.decoder(z_high, z_low)`` (deepla
 ``conv_low`` runs on the ASPP output and the encoder's low-level map is the one that gets resized."""
 import torch.nn as nn
 
+from .. import functional as Fn
 from .. import ops
 from ..norms import _PackCache, conv_bn_forward
 
@@ -41,7 +42,7 @@ class ASPPv3Plus(nn.Module):
 
     def forward_nhwc(self, x):
         feats = [c.forward_nhwc(x) for c in (self.conv1, self.conv2, self.conv3, self.conv4)]
-        return self.conv_out.forward_nhwc(ops.concat_channels(feats))
+        return self.conv_out.forward_nhwc(Fn.concat_channels(feats))
 
 
 class Decoder(nn.Module):
@@ -57,8 +58,8 @@ class Decoder(nn.Module):
     def forward_nhwc(self, feat_low, feat_aspp):
         h, w = feat_low.h, feat_low.w
         feat_low = self.conv_low.forward_nhwc(feat_low)
-        feat_aspp_up = ops.resize_bilinear(feat_aspp, (h, w), align_corners=True)
-        feat = ops.concat_channels([feat_low, feat_aspp_up])
+        feat_aspp_up = Fn.resize_bilinear(feat_aspp, (h, w), align_corners=True)
+        feat = Fn.concat_channels([feat_low, feat_aspp_up])
         for c in self.conv_cat:
             feat = c.forward_nhwc(feat)
         return conv_bn_forward(self.conv_out, None, self._cache, feat)
@@ -90,11 +91,11 @@ class DeepLabV3Decoder(nn.Module):
                              "to interpolate logits to the target seg map's size")
         z_high, z_low = z
         if z_depth is not None and self.use_dada:
-            z_high = ops.eltwise_mul(z_high, z_depth)           # deeplab_v3.py:253-254
+            z_high = Fn.mul(z_high, z_depth)           # deeplab_v3.py:253-254
         z_high = self.aspp.forward_nhwc(z_high)
         s = self.decoder.forward_nhwc(z_high, z_low)            # swapped on purpose (deeplab_v3.py:258)
         ts = self._target_size if isinstance(self._target_size, (list, tuple)) else (self._target_size,) * 2
-        return ops.resize_bilinear(s, tuple(ts), align_corners=True)
+        return Fn.resize_bilinear(s, tuple(ts), align_corners=True)
 
     def forward(self, z, z_depth=None):
         return ops.nhwc_to_nchw(self.forward_nhwc(z, z_depth))

@@ -5,6 +5,7 @@ HIP forward: every conv is the MFMA implicit-GEMM kernel with the eval-mode Batc
 ReLU / residual add in its epilogue; 3x3/s2 max-pool kernel; NHWC 16-bit throughout."""
 import torch.nn as nn
 
+from .. import functional as Fn
 from .. import ops
 from ..norms import DEFAULT_COMPUTE_DTYPE, _PackCache, conv_bn_forward
 
@@ -85,7 +86,7 @@ class ResNet(nn.Module):
 
     def forward_nhwc(self, x: ops.NHWC):
         x = conv_bn_forward(self.conv1, self.bn1, self._stem, x, act=ops.ACT_RELU)
-        x = ops.maxpool3x3s2(x)
+        x = Fn.maxpool3x3s2(x)
         for b in self.layer1:
             x = b.forward_nhwc(x)
         low = x

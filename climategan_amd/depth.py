@@ -2,6 +2,7 @@
 BaseDepthDecoder is out of scope)."""
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 from .blocks import Conv2dBlock, InterpolateNearest2d
 from .norms import _PackCache, conv_bn_forward
@@ -51,7 +52,7 @@ class DADADepthDecoder(nn.Module):
         if self.upsample is None:
             raise NotImplementedError("DADADepthDecoder: upsample_featuremaps=False (channel mean over 128 maps) "
                                       "has no HIP path; the default config upsamples")
-        up = ops.resize_nearest(z4, (z4.h * 2, z4.w * 2))
+        up = Fn.upsample_nearest2x(z4)
         up = self.upsample[1].forward_nhwc(up)
         depth = conv_bn_forward(self.upsample[2], None, self._cache, up)   # 1 channel: the channel mean is the identity
         ts = self._target_size

@@ -56,7 +56,6 @@ class OmniGenerator(nn.Module):
     def encode(self, x):
         """reference generator.py:107-118.  x: [B,3,H,W] NCHW; returns (z_high, z_low) as NHWC containers."""
         assert self.encoder is not None
-        _grad_guard(self.encoder)
         self.encoder.compute_dtype = self.compute_dtype
         return self.encoder.forward(x)
 
@@ -125,7 +124,6 @@ class OmniGenerator(nn.Module):
         if z is None:
             z = self.encode(x)
         dec = self.decoders["m"]
-        _grad_guard(dec)
         if cond is None and self.opts.gen.m.use_spade:                       # generator.py:257-262
             assert "s" in self.opts.tasks and "d" in self.opts.tasks
             d_pred, z_d = self.decoders["d"].forward_nhwc(z)
@@ -135,9 +133,19 @@ class OmniGenerator(nn.Module):
             _, z_depth = self.decoders["d"].forward_nhwc(z)
         spectral_norm_step_all(dec, z[0].t.dtype if isinstance(z, (tuple, list)) else z.t.dtype)
         logits = dec.forward_nhwc(z, cond, z_depth)
+        if logits.t.requires_grad:
+            raise NotImplementedError("OmniGenerator.mask: under autograd use mask_nhwc() (the NHWC -> NCHW layout pass "
+                                      "has no backward kernel)")
         if sigmoid:
             logits = ops.sigmoid(logits)
         return ops.nhwc_to_nchw(logits)
+
+    def mask_nhwc(self, z, cond=None, z_depth=None):
+        """Training-path form of ``mask``: the mask decoder's LOGITS as a differentiable NHWC map (the sigmoid / pair /
+        loss kernels of ``climategan_amd.losses`` take it from there)."""
+        dec = self.decoders["m"]
+        spectral_norm_step_all(dec, z[0].t.dtype if isinstance(z, (tuple, list)) else z.t.dtype)
+        return dec.forward_nhwc(z, cond, z_depth)
 
     def sample_painter_z(self, batch_size, device, force_half=False):
         """reference generator.py:179-194"""

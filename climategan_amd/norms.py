@@ -54,7 +54,8 @@ class _PackCache:
         self.value = None
 
     def get(self, params, dtype, build):
-        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in params if p is not None) + (dtype,)
+        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) if torch.is_tensor(p) else p
+                    for p in params if p is not None) + (dtype,)
         if key != self.key:
             self.value = build()
             self.key = key
@@ -157,29 +158,55 @@ def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.N
 
 
 def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mode=ops.PAD_ZERO, pad=None, **kw) -> ops.NHWC:
-    """``bn(conv(x))`` with an eval-mode ``nn.BatchNorm2d`` folded into the conv weights (the same algebra as the
-    reference's ``--fuse`` path, bn_fusion.py:121-132); ``bn`` may be None.  Training-mode batch statistics have no
-    HIP kernel yet and raise."""
-    _grad_guard(conv)
-    if bn is not None:
-        if bn.training:
-            raise NotImplementedError("BatchNorm2d in training mode (batch statistics) has no HIP path yet; call .eval()")
-        _grad_guard(bn)
+    """``act(bn(conv(x)) + residual)``; ``bn`` may be None.
 
-    def build():
-        if bn is None:
-            return ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None, x.t.dtype)
-        w, b = ops.fold_bn(conv.weight.data, conv.bias.data if conv.bias is not None else None,
-                           bn.weight.data if bn.affine else None, bn.bias.data if bn.affine else None,
-                           bn.running_mean, bn.running_var, bn.eps)
-        return ops.pack_conv_weight(w, b, x.t.dtype)
+    * inference (no gradient wanted, BatchNorm in eval mode): the BatchNorm is folded into the conv weights (the same
+      algebra as the reference's ``--fuse`` path, bn_fusion.py:121-132) and everything rides in the conv epilogue;
+    * training (BatchNorm in training mode and / or a gradient wanted): conv (``autograd.ConvFn``) -> batch-statistics
+      BatchNorm + activation (``autograd.BatchNormActFn``, running statistics updated like nn.BatchNorm2d) -> residual
+      add + activation (``autograd.AddActFn``), each with its HIP backward."""
+    train_bn = bn is not None and bn.training
+    grad = needs_grad(conv, x.t) or (bn is not None and needs_grad(bn))
+    p = conv.padding[0] if pad is None else pad
+    if not train_bn and not grad:
+        def build():
+            if bn is None:
+                return ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None, x.t.dtype)
+            w, b = ops.fold_bn(conv.weight.data, conv.bias.data if conv.bias is not None else None,
+                               bn.weight.data if bn.affine else None, bn.bias.data if bn.affine else None,
+                               bn.running_mean, bn.running_var, bn.eps)
+            return ops.pack_conv_weight(w, b, x.t.dtype)
 
-    params = [conv.weight, conv.bias]
-    if bn is not None:
-        params += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    pw = cache.get(params, x.t.dtype, build)
-    return ops.conv2d(x, pw, stride=conv.stride[0], pad=conv.padding[0] if pad is None else pad,
-                      dilation=conv.dilation[0], pad_mode=pad_mode, **kw)
+        params = [conv.weight, conv.bias]
+        if bn is not None:
+            params += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        pw = cache.get(params, x.t.dtype, build)
+        return ops.conv2d(x, pw, stride=conv.stride[0], pad=p, dilation=conv.dilation[0], pad_mode=pad_mode, **kw)
+
+    if bn is not None and not bn.training:
+        raise NotImplementedError("climategan_amd: an eval-mode BatchNorm under autograd has no HIP backward (the "
+                                  "reference trains with BatchNorm in training mode)")
+    from .autograd import BatchNormActFn
+    from . import functional as Fn
+
+    act, slope, residual = kw.pop("act", ops.ACT_NONE), kw.pop("slope", 0.2), kw.pop("residual", None)
+    if kw.get("in_upsample") or kw.get("residual_upsample"):
+        raise NotImplementedError("conv_bn_forward: folded upsamples are not used on the training path")
+    pw = cache.get((conv.weight, conv.bias, "plain"), x.t.dtype,
+                   lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None,
+                                                x.t.dtype))
+    if bn is None:
+        return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0],
+                           dict(act=act, slope=slope, residual=residual, pad_mode=pad_mode))
+    y = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0], dict(pad_mode=pad_mode))
+    bn_act = act if residual is None else ops.ACT_NONE
+    out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.running_mean,
+                                 bn.running_var, y.c, bn.eps, bn.momentum if bn.momentum is not None else 0.1, bn_act,
+                                 slope)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    out = ops.NHWC(out_t, y.c)
+    return out if residual is None else Fn.add_act(out, residual, act, slope)
 
 
 class SPADE(nn.Module):

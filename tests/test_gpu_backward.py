@@ -365,3 +365,22 @@ def test_structural_functions_backward(dt):
     run(lambda a, b: ag.MulFn.apply(a, b, 16), lambda a, b: a * b, [(B, 16, 7, 9), (B, 16, 7, 9)], 8250)
     run(lambda a, b, c: ag.ConcatFn.apply([16, 24, 5], a, b, c), lambda a, b, c: torch.cat([a, b, c], 1),
         [(B, 16, 6, 7), (B, 24, 6, 7), (B, 5, 6, 7)], 8260)
+
+
+def test_conv_backward_padded_1x1_quirk():
+    """ASPPv3Plus.conv_out: a 1x1 conv with padding=1 (output grows by 2): data gradient = the interior
+    of the transposed conv (pad' = -1), weight gradient over the padded extent."""
+    from climategan_amd import ops
+    dt = torch.float16
+    x = q(fill.uniform((2, 64, 10, 12), 9300), dt).requires_grad_(True)
+    w = q(fill.uniform((32, 64, 1, 1), 9301, -0.1, 0.1), dt).requires_grad_(True)
+    b = torch.from_numpy(fill.uniform((32,), 9302)).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    assert y.shape[-2:] == (12, 14)
+    dy = q(fill.uniform(tuple(y.shape), 9303), dt)
+    y.backward(dy)
+    dyg = to_nhwc(dy, dt)
+    dx = ops.conv2d_bwd_data(dyg, w.detach().cuda(), (2, 10, 12), pad=1)
+    assert rel_err(back(dx), x.grad) <= TOL[dt]
+    dw, db = ops.conv2d_bwd_weight(to_nhwc(x.detach(), dt), dyg, tuple(w.shape), pad=1)
+    assert rel_err(dw.cpu(), w.grad) <= 2e-4 and rel_err(db.cpu(), b.grad) <= 2e-4
