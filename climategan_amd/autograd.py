@@ -11,6 +11,18 @@ import torch
 from . import ops
 
 
+# Gradient scale for fp16 activation gradients (what torch.cuda.amp.GradScaler does for the reference's ``train.amp``
+# mode, trainer.py:1011-1013): every loss Function writes its input gradient multiplied by GRAD_SCALE while returning the
+# unscaled loss value; all parameter gradients then come out multiplied by GRAD_SCALE and the trainer divides it out
+# before the optimizer step.  1.0 = off (bf16 has the range and does not need it).
+GRAD_SCALE = 1.0
+
+
+def set_grad_scale(s: float):
+    global GRAD_SCALE
+    GRAD_SCALE = float(s)
+
+
 class ConvFn(torch.autograd.Function):
     """y = act(conv(up?(x), w[/sigma]) + b + up?(res)).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under
     spectral norm, in which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped
@@ -223,9 +235,9 @@ class BceLogitsFn(torch.autograd.Function):
     def forward(ctx, x_t, c, target, weight):
         ctx.c = c
         acc = torch.zeros(1, dtype=torch.float32, device=x_t.device)
-        dx = ops.bce_logits(ops.NHWC(x_t, c), target, weight, acc, want_grad=ctx.needs_input_grad[0])
+        dx = ops.bce_logits(ops.NHWC(x_t, c), target, weight * GRAD_SCALE, acc, want_grad=ctx.needs_input_grad[0])
         ctx.save_for_backward(dx.t if dx is not None else None)
-        return acc[0]
+        return acc[0] / GRAD_SCALE if GRAD_SCALE != 1.0 else acc[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -242,9 +254,9 @@ class L1Fn(torch.autograd.Function):
     def forward(ctx, a_t, b_t, c, weight):
         ctx.c = c
         acc = torch.zeros(1, dtype=torch.float32, device=a_t.device)
-        da = ops.l1_loss(ops.NHWC(a_t, c), ops.NHWC(b_t, c), weight, acc, want_grad=ctx.needs_input_grad[0])
+        da = ops.l1_loss(ops.NHWC(a_t, c), ops.NHWC(b_t, c), weight * GRAD_SCALE, acc, want_grad=ctx.needs_input_grad[0])
         ctx.save_for_backward(da.t if da is not None else None)
-        return acc[0]
+        return acc[0] / GRAD_SCALE if GRAD_SCALE != 1.0 else acc[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -350,10 +362,10 @@ class _ScalarLossFn(torch.autograd.Function):
     def forward(ctx, x_t, c, run):
         acc = torch.zeros(1, dtype=torch.float32, device=x_t.device)
         dx = torch.empty_like(x_t) if ctx.needs_input_grad[0] else None
-        run(acc, dx)
+        run(acc, dx)                      # the closures fold GRAD_SCALE into their weights
         ctx.c = c
         ctx.save_for_backward(dx)
-        return acc[0]
+        return acc[0] / GRAD_SCALE if GRAD_SCALE != 1.0 else acc[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -368,15 +380,15 @@ def softmax_ce(logits: ops.NHWC, target: torch.Tensor):
     n = _npix(logits.t)
     tgt = target.contiguous().long()
     return _ScalarLossFn.apply(logits.t, logits.c, lambda acc, dx: _call(
-        "cgan_softmax_ce_nhwc", ops._ptr(logits.t), ops._ptr(tgt), logits.dtype_id, n, logits.c, 1.0 / n, ops._ptr(acc),
+        "cgan_softmax_ce_nhwc", ops._ptr(logits.t), ops._ptr(tgt), logits.dtype_id, n, logits.c, GRAD_SCALE / n, ops._ptr(acc),
         ops._ptr(dx), ops._stream()))
 
 
 def tv_loss(x: ops.NHWC, tvloss_weight=1.0):
     """TVLoss.forward (losses.py:157-166)."""
     b, h, w, c = x.n, x.h, x.w, x.c
-    wh = tvloss_weight * 2.0 / (c * (h - 1) * w) / b
-    ww = tvloss_weight * 2.0 / (c * h * (w - 1)) / b
+    wh = GRAD_SCALE * tvloss_weight * 2.0 / (c * (h - 1) * w) / b
+    ww = GRAD_SCALE * tvloss_weight * 2.0 / (c * h * (w - 1)) / b
     return _ScalarLossFn.apply(x.t, c, lambda acc, dx: _call(
         "cgan_tv_nhwc", ops._ptr(x.t), x.dtype_id, b, h, w, c, wh, ww, ops._ptr(acc), ops._ptr(dx), ops._stream()))
 
@@ -386,7 +398,7 @@ def minent_loss(p: ops.NHWC, version=1, lambda_var=0.1):
     n = _npix(p.t)
     ws = torch.empty(1, dtype=torch.float32, device=p.t.device)
     return _ScalarLossFn.apply(p.t, p.c, lambda acc, dx: _call(
-        "cgan_minent_nhwc", ops._ptr(p.t), p.dtype_id, n, p.c, int(version), float(lambda_var), 1.0, ops._ptr(acc),
+        "cgan_minent_nhwc", ops._ptr(p.t), p.dtype_id, n, p.c, int(version), float(lambda_var), GRAD_SCALE, ops._ptr(acc),
         ops._ptr(dx), ops._ptr(ws), ops._stream()))
 
 
@@ -395,7 +407,7 @@ def bce_logits_map(x: ops.NHWC, target: torch.Tensor):
     n = _npix(x.t)
     tgt = target.contiguous().float()
     return _ScalarLossFn.apply(x.t, x.c, lambda acc, dx: _call(
-        "cgan_bce_logits_map_nhwc", ops._ptr(x.t), ops._ptr(tgt), x.dtype_id, n, 1.0 / n, ops._ptr(acc), ops._ptr(dx),
+        "cgan_bce_logits_map_nhwc", ops._ptr(x.t), ops._ptr(tgt), x.dtype_id, n, GRAD_SCALE / n, ops._ptr(acc), ops._ptr(dx),
         ops._stream()))
 
 
@@ -412,7 +424,7 @@ def ground_intersection(p: ops.NHWC, ground: torch.Tensor):
 def advent_wgan(d_out: ops.NHWC, target: float):
     """-mean(y * D + (1 - y) * (1 - D)) (losses.py:498-499) for a scalar domain label y."""
     n = _npix(d_out.t) * d_out.c
-    a, b = -(2.0 * target - 1.0) / n, -(1.0 - target) / n
+    a, b = -GRAD_SCALE * (2.0 * target - 1.0) / n, -GRAD_SCALE * (1.0 - target) / n
     return _ScalarLossFn.apply(d_out.t, d_out.c, lambda acc, dx: _call(
         "cgan_affine_sum_nhwc", ops._ptr(d_out.t), d_out.dtype_id, _npix(d_out.t), d_out.c, a, b, ops._ptr(acc),
         ops._ptr(dx), ops._stream()))

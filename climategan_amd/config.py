@@ -48,7 +48,7 @@ def default_opts() -> Opts:
             "encoder": {"architecture": "deeplabv3"},                    # :103
             "deeplabv3": {"backbone": "resnet", "output_stride": 8},     # :115-116
             "d": {"architecture": "dada", "upsample_featuremaps": True, "output_dim": 1, "norm": "batch"},   # :122-134
-            "s": {"use_advent": True, "use_dada": True, "architecture": "deeplabv3", "output_dim": 11,
+            "s": {"use_advent": True, "use_dada": True, "use_minent": True, "architecture": "deeplabv3", "output_dim": 11,
                   "num_classes": 11},                                    # :135-143
             "m": {"use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
                   "use_dada": False, "use_minent": True, "use_minent_var": True, "use_ground_intersection": True, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",

@@ -66,10 +66,9 @@ class Trainer:
             self.G.eval()
             self.is_setup = True
             return self
-        if list(self.opts.tasks) != ["p"]:
-            raise NotImplementedError("Trainer.setup(inference=False): only the Painter tasks (opts.tasks == ['p']) "
-                                      "have a HIP training path; Masker training (training-mode BatchNorm, masker "
-                                      "losses) is not built")
+        if self.opts.gen.m.use_spade and "m" in self.opts.tasks:
+            raise NotImplementedError("Trainer.setup(inference=False): the SPADE mask decoder (batch-norm SPADE) has no "
+                                      "backward kernels; train with gen.m.use_spade = False")
         from .discriminator import create_discriminator
         from .losses import get_losses
         from .optim import ExtraAdam
@@ -78,6 +77,11 @@ class Trainer:
         self.D = create_discriminator(o, self.device, verbose=self.verbose)
         self.G.train()
         self.D.train()
+        # 16-bit activation GRADIENTS: the masker's loss weights (1e-3 / (n h w)) underflow fp16; bf16 has the range
+        self.G.set_compute_dtype(torch.bfloat16)
+        self.D.set_compute_dtype(torch.bfloat16)
+        self.domain_labels = {"s": 0, "r": 1}                          # trainer.py:107
+        self.has_masker = any(t in o.tasks for t in "msd")
         # get_losses (losses.py:353-441).  Note: losses["D"]["p"] IS losses["G"]["p"]["gan"] (one GANLoss object), so
         # the generator-side call draws label smoothing / flips as well, as in the reference.
         self.losses = get_losses(o, self.verbose, self.device)
@@ -157,10 +161,177 @@ class Trainer:
         self.loss_log["D.p.gan"] = loss.detach()
         return loss
 
+    # ------------------------------------------------------------------------------------------ masker losses
+    def masker_d_loss(self, x, z, target, domain, for_="G"):
+        """reference trainer.py:1389-1407.  The reference evaluates the depth loss and then discards it for real-domain
+        batches; here it is only evaluated where it is kept."""
+        prediction, z_depth = self.G.decoders["d"].forward_nhwc(z)
+        weight = self.opts.train.lambdas.G.d.main
+        if weight == 0 or domain == "r":
+            return torch.zeros((), device=self.device), prediction, z_depth
+        return self.losses["G"]["tasks"]["d"](prediction, target) * weight, prediction, z_depth
+
+    def masker_s_loss(self, x, z, depth_preds, z_depth, target, domain, for_="G"):
+        """reference trainer.py:1409-1504"""
+        from . import losses as L
+
+        assert for_ in {"G", "D"} and domain in {"r", "s"}
+        o = self.opts
+        full_loss = 0
+        softmax_preds = None
+        pred = None
+        if for_ == "G" or o.gen.s.use_advent:
+            pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
+        if for_ == "G":
+            if domain == "s":
+                w = o.train.lambdas.G["s"]["crossent"]
+                if w != 0:
+                    loss = self.losses["G"]["tasks"]["s"]["crossent"](pred, target.squeeze(1)) * w
+                    self.loss_log["G.s.crossent." + domain] = loss.detach()
+                    full_loss = full_loss + loss
+            if domain == "r":
+                w = o.train.lambdas.G["s"]["minent"]
+                if o.gen.s.get("use_minent", True) and w != 0:
+                    softmax_preds = L.softmax(pred)
+                    loss = self.losses["G"]["tasks"]["s"]["minent"](softmax_preds) * w
+                    self.loss_log["G.s.minent.r"] = loss.detach()
+                    full_loss = full_loss + loss
+        if o.gen.s.use_advent:
+            dp = None
+            if o.gen.s.use_dada and depth_preds is not None:
+                dp = ops.NHWC(depth_preds.t.detach(), depth_preds.c)
+            if for_ == "D":
+                label, loss_func, w = domain, self.losses["D"]["advent"], o.train.lambdas.advent.adv_main
+                pred = ops.NHWC(pred.t.detach(), pred.c)
+                softmax_preds = None
+            else:
+                label, loss_func, w = "s", self.losses["G"]["tasks"]["s"]["advent"], o.train.lambdas.G["s"]["advent"]
+            if (for_ == "D" or domain == "r") and w != 0:
+                if softmax_preds is None:
+                    softmax_preds = L.softmax(pred)
+                loss = loss_func(softmax_preds, self.domain_labels[label], self.D["s"]["Advent"], dp) * w
+                self.loss_log["%s.s.advent.%s" % (for_, domain)] = loss.detach()
+                full_loss = full_loss + loss
+        return full_loss, pred
+
+    def masker_m_loss(self, x, z, target, domain, for_="G", cond=None, z_depth=None, depth_preds=None):
+        """reference trainer.py:1506-1616"""
+        from . import losses as L
+
+        assert for_ in {"G", "D"} and domain in {"r", "s"}
+        o = self.opts
+        full_loss = 0
+        logits = self.G.mask_nhwc(z, cond=cond, z_depth=z_depth)
+        if for_ == "D":
+            logits = ops.NHWC(logits.t.detach(), logits.c)
+        prob = L.sigmoid_pair(logits)                                   # cat[p, 1 - p]
+        if for_ == "G":
+            pred_prob = L.sigmoid(logits)
+            w = o.train.lambdas.G.m.tv
+            if w != 0:
+                loss = self.losses["G"]["tasks"]["m"]["tv"](pred_prob) * w
+                self.loss_log["G.m.tv." + domain] = loss.detach()
+                full_loss = full_loss + loss
+            w = o.train.lambdas.G.m.bce
+            if domain == "s" and w != 0:
+                loss = self.losses["G"]["tasks"]["m"]["bce"](logits, target) * w
+                self.loss_log["G.m.bce.s"] = loss.detach()
+                full_loss = full_loss + loss
+            if domain == "r":
+                w = o.train.lambdas.G["m"]["gi"]
+                if o.gen.m.use_ground_intersection and w != 0:
+                    loss = self.losses["G"]["tasks"]["m"]["gi"](pred_prob, target) * w
+                    self.loss_log["G.m.gi.r"] = loss.detach()
+                    full_loss = full_loss + loss
+                if o.gen.m.get("use_pl4m", False) and o.train.lambdas.G.m.pl4m != 0:
+                    raise NotImplementedError("pl4m (painter loss for the masker) has no HIP path")
+                w = o.train.lambdas.advent.ent_main
+                if o.gen.m.use_minent and w != 0:
+                    loss = self.losses["G"]["tasks"]["m"]["minent"](prob) * w
+                    self.loss_log["G.m.minent.r"] = loss.detach()
+                    full_loss = full_loss + loss
+        if o.gen.m.use_advent:
+            if o.gen.m.use_dada and depth_preds is not None:
+                raise NotImplementedError("gen.m.use_dada (depth-weighted ADVENT for the mask) has no HIP path")
+            if for_ == "D":
+                label, loss_func = domain, self.losses["D"]["advent"]
+            else:
+                label, loss_func = "s", self.losses["G"]["tasks"]["m"]["advent"]
+            w = o.train.lambdas.advent.adv_main
+            if (for_ == "D" or domain == "r") and w != 0:
+                loss = loss_func(prob, self.domain_labels[label], self.D["m"]["Advent"], None) * w
+                self.loss_log["%s.m.advent.%s" % (for_, domain)] = loss.detach()
+                full_loss = full_loss + loss
+        return full_loss, prob
+
+    def get_masker_loss(self, multi_domain_batch):
+        """reference trainer.py:1184-1254"""
+        m_loss = 0
+        for domain, batch in multi_domain_batch.items():
+            if domain == "rf":
+                continue
+            x = batch["data"]["x"]
+            z = self.G.encode(x)
+            d_pred = s_pred = z_depth = None
+            for task in ["d", "s", "m"]:
+                if task not in batch["data"] or task not in self.opts.tasks:
+                    continue
+                target = batch["data"][task]
+                if task == "d":
+                    loss, d_pred, z_depth = self.masker_d_loss(x, z, target, domain, "G")
+                elif task == "s":
+                    loss, s_pred = self.masker_s_loss(x, z, d_pred, z_depth, target, domain, "G")
+                else:
+                    loss, _ = self.masker_m_loss(x, z, target, domain, "G", cond=None, z_depth=z_depth,
+                                                 depth_preds=d_pred)
+                m_loss = m_loss + loss
+        return m_loss
+
+    def get_masker_d_loss(self, multi_domain_batch):
+        """reference trainer.py:1109-1147 (Masker branch of get_D_loss): the generator side runs without a graph (the
+        reference builds one and detaches the predictions, trainer.py:1113,1464,1578)."""
+        total = 0
+        adv = self.opts.train.lambdas.advent.adv_main
+        for domain, batch in multi_domain_batch.items():
+            if domain == "rf":
+                continue
+            x = batch["data"]["x"]
+            with torch.no_grad():
+                z = self.G.encode(x)
+                d_pred = z_depth = None
+                if "d" in self.opts.tasks and (self.opts.gen.s.use_dada or self.opts.gen.m.use_dada):
+                    d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
+            if "s" in batch["data"] and "s" in self.opts.tasks:
+                with torch.no_grad():
+                    s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
+                loss, _ = self._advent_d_term("s", s_pred, d_pred, domain)
+                total = total + loss * adv
+            if "m" in batch["data"] and "m" in self.opts.tasks:
+                with torch.no_grad():
+                    logits = self.G.mask_nhwc(z, cond=None, z_depth=z_depth)
+                loss, _ = self._advent_d_term("m", logits, None, domain)
+                total = total + loss * adv
+        return total
+
+    def _advent_d_term(self, task, pred, depth_preds, domain):
+        from . import losses as L
+
+        w = self.opts.train.lambdas.advent.adv_main
+        if task == "s":
+            prob = L.softmax(ops.NHWC(pred.t.detach(), pred.c))
+            dp = ops.NHWC(depth_preds.t.detach(), depth_preds.c) if (self.opts.gen.s.use_dada and depth_preds is not None) else None
+        else:
+            prob = L.sigmoid_pair(ops.NHWC(pred.t.detach(), pred.c))
+            dp = None
+        loss = self.losses["D"]["advent"](prob, self.domain_labels[domain], self.D[task]["Advent"], dp) * w
+        self.loss_log["D.%s.advent.%s" % (task, domain)] = loss.detach()
+        return loss, prob
+
     def _check_batch(self, multi_domain_batch):
-        extra = [d for d in multi_domain_batch if d != "rf"]
-        if extra:
-            raise NotImplementedError("Trainer: masker domains %s have no HIP training path yet" % extra)
+        if not self.has_painter and "rf" in multi_domain_batch:
+            raise ValueError("Trainer: an 'rf' batch needs the Painter task")
+        if not self.has_masker and any(d != "rf" for d in multi_domain_batch):
+            raise ValueError("Trainer: masker-domain batches need the masker tasks")
 
     def update_G(self, multi_domain_batch):
         """reference trainer.py:989-1015 + g_opt_step (674-683): D frozen, backward, extrapolate (even) / step (odd)."""
@@ -169,7 +340,11 @@ class Trainer:
             p.requires_grad_(False)
         try:
             self.g_opt.zero_grad(set_to_none=True)
-            g_loss = self.get_painter_loss(multi_domain_batch)
+            g_loss = 0                                                  # get_G_loss, trainer.py:1162-1182
+            if self.has_masker and any(d != "rf" for d in multi_domain_batch):
+                g_loss = g_loss + self.get_masker_loss(multi_domain_batch)
+            if self.has_painter and "rf" in multi_domain_batch:
+                g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
             g_loss.backward()
             if self.g_reducer is not None:
                 self.g_reducer.finish()                                 # before extrapolation AND step (trainer.py:678-683)
@@ -189,7 +364,11 @@ class Trainer:
         """reference trainer.py:1017-1032 + d_opt_step (685-694)."""
         self._check_batch(multi_domain_batch)
         self.d_opt.zero_grad(set_to_none=True)
-        d_loss = self.get_D_loss(multi_domain_batch)
+        d_loss = 0
+        if self.has_painter and "rf" in multi_domain_batch:
+            d_loss = d_loss + self.get_D_loss(multi_domain_batch)
+        if self.has_masker and any(d != "rf" for d in multi_domain_batch):
+            d_loss = d_loss + self.get_masker_d_loss(multi_domain_batch)
         d_loss.backward()
         if self.d_reducer is not None:
             self.d_reducer.finish()

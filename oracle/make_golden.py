@@ -37,6 +37,7 @@ def golden_cases():
                              rng_seed=4321, sky_idx=6),   # class 6 covers 14 % of this untrained net's argmax map
         "maskspade_small": dict(kind="maskspade", H=128, W=160, B=2, seed=62, gain=1.6),
         "masker_losses": dict(kind="masker_losses", H=24, W=32, B=2, seed=95),
+        "mstep": dict(kind="mstep", H=128, W=160, B=2, seed=66, gain=1.6, sub=512),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
@@ -68,6 +69,16 @@ def case_inputs(name, case):
         return dict(x=fill.uniform((B, 4, case["H"], case["W"]), s * 100 + 1))
     if k == "disc_fc":
         return dict(x=fill.uniform01((B, case["num_classes"], case["H"], case["W"]), s * 100 + 1).astype(np.float32))
+    if k == "mstep":
+        H, W = case["H"], case["W"]
+        h, w = H // 4, W // 4
+        d = {}
+        for i, dom in enumerate(("r", "s")):
+            d["x_" + dom] = fill.uniform((B, 3, H, W), s * 100 + 10 * i + 1)
+            d["d_" + dom] = fill.uniform((B, 1, h, w), s * 100 + 10 * i + 2, 0.35, 6.95)
+            d["s_" + dom] = (fill.uniform01((B, 1, h, w), s * 100 + 10 * i + 3) * 11).astype(np.int64).clip(0, 10)
+            d["m_" + dom] = fill.rect_mask(B, H, W, s * 100 + 10 * i + 4)
+        return d
     if k == "masker_losses":
         h, w = case["H"], case["W"]
         return dict(s_logits=fill.uniform((B, 11, h, w), s * 100 + 1, -2, 2),
@@ -337,6 +348,99 @@ def run_reference_masker_losses(name, case):
     return out
 
 
+def grad_subsample(key, g, n):
+    """n entries of a gradient tensor at seeded pseudo-random positions (fixtures cannot hold 105 M-element gradients)."""
+    flat = g.reshape(-1)
+    if flat.numel() <= n:
+        return flat.numpy().copy()
+    idx = (fill.uniform01((n,), fill.key_seed(key, 4242)) * flat.numel()).astype(np.int64).clip(0, flat.numel() - 1)
+    return flat[torch.from_numpy(idx)].numpy().copy()
+
+
+def run_reference_mstep(name, case):
+    """G side of the Masker step: ``get_masker_loss`` (trainer.py:1184-1254) restated on the reference's own modules
+    (generator in train mode: batch-statistics BatchNorm) and loss classes, domains r then s, ADVENT discriminators
+    frozen; the depth term (SIGMLoss) is evaluated and recorded but NOT included in the differentiated loss (the HIP
+    build has no SIGM kernel yet).  Gradients are stored as seeded sub-samples + norms."""
+    import contextlib
+    import io
+
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.tasks = ["d", "s", "m"]
+    L = ref_shim.ref("losses")
+    disc = ref_shim.ref("discriminator")
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+        D = disc.OmniDiscriminator(opts)
+    for mod, seed in ((G, case["seed"]), (D, case["seed"] + 1)):
+        shapes = {key: tuple(v.shape) for key, v in mod.state_dict().items()}
+        mod.load_state_dict({key: t(v) for key, v in fill.fill_state_dict(shapes, seed, gain=case["gain"]).items()})
+    G.train()
+    D.train()
+    for p in D.parameters():
+        p.requires_grad = False
+    hs, ws = case["H"] // 4, case["W"] // 4
+    G.decoders["d"]._target_size = ws
+    G.decoders["s"].set_target_size((hs, ws))
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    lam = opts.train.lambdas
+    crossent, minent1, minent2 = L.CrossEntropy(), L.MinentLoss(), L.MinentLoss(version=2, lambda_var=lam.advent.ent_var)
+    tv, bce, gi = L.TVLoss(), torch.nn.BCEWithLogitsLoss(), L.GroundIntersectionLoss()
+    adv_s = L.ADVENTAdversarialLoss(opts, gan_type=opts.dis.s.gan_type)
+    adv_m = L.ADVENTAdversarialLoss(opts, gan_type=opts.dis.m.gan_type)
+    sigm = L.SIGMLoss(lam.G.d.gml, device="cpu")
+    terms = {}
+    total = 0
+    for dom in ("r", "s"):
+        x = inp["x_" + dom]
+        z = G.encode(x)
+        d_pred, z_depth = G.decoders["d"](z)
+        terms["d." + dom] = (sigm(d_pred, inp["d_" + dom]) * lam.G.d.main).detach()
+        s_pred = G.decoders["s"](z, z_depth)
+        if dom == "s":
+            l = crossent(s_pred, inp["s_" + dom].squeeze(1)) * lam.G.s.crossent
+            terms["s.crossent.s"] = l.detach(); total = total + l
+        else:
+            sm = torch.softmax(s_pred, dim=1)
+            l = minent1(sm) * lam.G.s.minent
+            terms["s.minent.r"] = l.detach(); total = total + l
+            l = adv_s(sm, 0, D["s"]["Advent"], d_pred.detach()) * lam.G.s.advent
+            terms["s.advent.r"] = l.detach(); total = total + l
+        logits = G.decoders["m"](z, cond=None, z_depth=z_depth)
+        p = torch.sigmoid(logits)
+        prob = torch.cat([p, 1 - p], dim=1)
+        l = tv(p) * lam.G.m.tv
+        terms["m.tv." + dom] = l.detach(); total = total + l
+        if dom == "s":
+            l = bce(logits, inp["m_" + dom]) * lam.G.m.bce
+            terms["m.bce.s"] = l.detach(); total = total + l
+        else:
+            l = gi(p, inp["m_" + dom]) * lam.G.m.gi
+            terms["m.gi.r"] = l.detach(); total = total + l
+            l = minent2(prob) * lam.advent.ent_main
+            terms["m.minent.r"] = l.detach(); total = total + l
+            l = adv_m(prob, 0, D["m"]["Advent"], None) * lam.advent.adv_main
+            terms["m.advent.r"] = l.detach(); total = total + l
+    total.backward()
+    out = {"loss": total.detach().numpy().reshape(1)}
+    for k2, v in terms.items():
+        out["term." + k2] = v.numpy().reshape(1)
+    for key, p in G.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            out["gsub." + key] = grad_subsample(key, p.grad, case["sub"])
+            out["gnorm." + key] = np.array([p.grad.norm().item()], dtype=np.float32)
+    sd = G.state_dict()
+    for key in ("encoder.bn1.running_mean", "encoder.layer3.5.bn2.running_var", "decoders.s.aspp.conv2.bn.running_mean",
+                "decoders.d.enc4_2.norm.running_var"):
+        out["post." + key] = sd[key].numpy().copy()
+    for key in sd:
+        if key.endswith("weight_u") and key.startswith("decoders.m."):
+            out["post." + key] = sd[key].numpy().copy()
+    return out
+
+
 def run_reference_dstep(name, case):
     """The Painter branch of ``Trainer.get_D_loss`` (trainer.py:1073-1107) with the reference's own modules and
     losses (``GANLoss`` as built by ``get_losses``: BCE form, here soft_shift = flip_prob = 0), then
@@ -457,6 +561,8 @@ def run_reference(name, case):
         return run_reference_maskspade(name, case)
     if case["kind"] == "masker_losses":
         return run_reference_masker_losses(name, case)
+    if case["kind"] == "mstep":
+        return run_reference_mstep(name, case)
     if case["kind"] == "dstep_p":
         return run_reference_dstep(name, case)
     if case["kind"] == "gstep_p":

@@ -32,7 +32,7 @@ def module_shapes(case):
         return painter_shapes(case["latent_dim"], case["n_up"])
     if k == "dstep_p":
         return disc_p_shapes(4, case["ndf"], case["n_layers"], case["num_D"])
-    if k in ("extra_adam", "masker", "infer", "cloudy", "maskspade", "masker_losses"):
+    if k in ("extra_adam", "masker", "infer", "cloudy", "maskspade", "masker_losses", "mstep"):
         return {}
     raise KeyError(k)
 

@@ -201,3 +201,127 @@ def test_painter_train_steps_run_and_learn():
     assert "G.p.vgg" in T.loss_log and torch.isfinite(T.loss_log["G.p.vgg"])
     flags = {n: p.requires_grad for n, p in T.D.named_parameters()}
     assert all(v == (not (n.endswith("weight_u") or n.endswith("weight_v"))) for n, v in flags.items())
+
+
+# ------------------------------------------------------------------------------------------------ masker G step
+MNAME = "mstep"
+
+
+def build_masker_trainer(case, dt=torch.bfloat16):
+    from climategan_amd import fill
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    opts.train.lambdas.G.d.main = 0            # SIGMLoss has no HIP kernel yet; the golden's gradient excludes it too
+    T = Trainer(opts, device="cuda").setup(inference=False)
+    for mod, seed in ((T.G, case["seed"]), (T.D, case["seed"] + 1)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed, gain=case["gain"]).items()})
+    T.G.set_compute_dtype(dt)
+    T.D.set_compute_dtype(dt)
+    T.G.decoders["d"]._target_size = case["W"] // 4
+    T.G.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
+    return T
+
+
+def masker_batch(case):
+    inp = {k: t(v).cuda() for k, v in case_inputs(MNAME, case).items()}
+    return {dom: {"data": {"x": inp["x_" + dom], "d": inp["d_" + dom], "s": inp["s_" + dom], "m": inp["m_" + dom]}}
+            for dom in ("r", "s")}
+
+
+# Cosine between the REFERENCE's fp32 gradients and the reference's own gradients when every conv / norm / activation
+# output and the gradient flowing back through it is rounded to 16 bit (tools/measure_ref_grad_quant.py, dev container):
+# this untrained ResNet-101 in training mode is chaotic enough that 16-bit storage alone decorrelates the encoder's
+# gradient direction (norms stay within 4 %), for the reference exactly as for this build.
+REF_QUANT_COS = {
+    "float16": {"encoder.conv1.weight": 0.18, "encoder.layer3.16.conv3.weight": 0.30, "encoder.layer4.2.conv2.weight": 0.65,
+                "decoders.m.model.4.conv.module.weight_bar": 0.9999},
+    "bfloat16": {"encoder.conv1.weight": 0.00, "encoder.layer3.16.conv3.weight": 0.02, "encoder.layer4.2.conv2.weight": 0.36,
+                 "decoders.d.enc4_2.conv.weight": 0.19, "decoders.s.aspp.conv1.conv.weight": 0.39,
+                 "decoders.s.decoder.conv_cat.0.conv.weight": 0.84, "decoders.m.model.4.conv.module.weight_bar": 0.9997},
+}
+
+
+def test_masker_g_step_matches_reference():
+    """get_masker_loss + backward on the HIP path (ResNet-101 with batch-statistics BatchNorm, DADA depth, DeepLab-v3+
+    seg, mask decoder, frozen ADVENT discriminators, 9 loss terms over a real and a sim batch) vs the reference's own
+    modules / loss classes / backward (golden ``mstep``; depth term excluded on both sides), in bf16.
+
+    What can be compared: every loss term; the NORM of every parameter gradient (16-bit storage does not move it: the
+    reference's own 16-bit-rounded run keeps norms within 4 %); the gradient DIRECTION where 16-bit storage preserves
+    it in the reference itself (mask decoder >= 0.99, end of the seg decoder >= 0.84, see REF_QUANT_COS): deeper in
+    this untrained network the reference's own direction is lost too (encoder cosine 0.0 - 0.4), so no bound is put
+    there.  Also the running statistics of four BatchNorm layers and the mask decoder's spectral-norm vectors."""
+    from climategan_amd import fill
+
+    case = golden_cases()[MNAME]
+    gold = load_golden(MNAME)
+    T = build_masker_trainer(case)
+    for p in T.D.parameters():
+        p.requires_grad_(False)
+    loss = T.get_masker_loss(masker_batch(case))
+    loss.backward()
+    names = {"term.s.minent.r": "G.s.minent.r", "term.s.advent.r": "G.s.advent.r", "term.m.tv.r": "G.m.tv.r",
+             "term.m.gi.r": "G.m.gi.r", "term.m.minent.r": "G.m.minent.r", "term.m.advent.r": "G.m.advent.r",
+             "term.s.crossent.s": "G.s.crossent.s", "term.m.tv.s": "G.m.tv.s", "term.m.bce.s": "G.m.bce.s"}
+    for gk, hk in names.items():
+        ref, got = float(gold[gk][0]), float(T.loss_log[hk])
+        tol = 0.25 if gk == "term.m.gi.r" else 3e-2          # GI counts pixels across a 0.5 threshold
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-4), (gk, got, ref)
+    assert abs(loss.item() - float(gold["loss"][0])) <= 1e-2 * abs(float(gold["loss"][0]))
+    params = dict(T.G.named_parameters())
+    ratios, cos = {}, {}
+    for gk in gold:
+        if not gk.startswith("gsub."):
+            continue
+        key = gk[5:]
+        g = params[key].grad
+        assert g is not None and torch.isfinite(g).all(), key
+        rn = float(gold["gnorm." + key][0])
+        ref = gold[gk].astype(np.float64)
+        if rn < 1e-7 or np.abs(ref).max() < 1e-9:
+            continue                                              # exactly-zero gradients (biases in front of a norm)
+        flat = g.reshape(-1).float().cpu().numpy()
+        n = case["sub"]
+        if flat.size > n:
+            idx = (fill.uniform01((n,), fill.key_seed(key, 4242)) * flat.size).astype(np.int64).clip(0, flat.size - 1)
+            sub = flat[idx].astype(np.float64)
+        else:
+            sub = flat.astype(np.float64)
+        ratios[key] = float(np.linalg.norm(flat)) / rn
+        cos[key] = (sub * ref).sum() / max(np.sqrt((sub ** 2).sum() * (ref ** 2).sum()), 1e-30)
+    big = {k: v for k, v in ratios.items() if k.endswith("weight") or k.endswith("weight_bar")}
+    assert len(big) > 200
+    r = np.array(list(big.values()))
+    assert 0.95 <= np.median(r) <= 1.08, np.median(r)
+    assert np.mean((r > 0.75) & (r < 1.35)) >= 0.95, sorted(big.items(), key=lambda kv: abs(np.log(kv[1])))[-8:]
+    mdec = [v for k, v in cos.items() if k.startswith("decoders.m.") and k.endswith("weight_bar")]
+    assert len(mdec) >= 10 and np.median(mdec) >= 0.95 and min(mdec) >= 0.85, (np.median(mdec), min(mdec))
+    sdec = [v for k, v in cos.items() if k.startswith("decoders.s.decoder.conv_cat") and k.endswith("conv.weight")]
+    assert min(sdec) >= 0.75, sdec
+    sd = T.G.state_dict()
+    for k in gold:
+        if k.startswith("post."):
+            ref = gold[k]
+            # running statistics after two bf16 forwards (momentum 0.1): the deeper the layer the larger the forward error
+            tol = 2e-5 if k.endswith("weight_u") else 1e-1 * max(np.abs(ref).max(), 1e-3)
+            assert np.abs(sd[k[5:]].float().cpu().numpy() - ref).max() <= tol, k
+
+
+def test_masker_train_step_runs():
+    """update_G + update_D on a two-domain masker batch: finite losses, parameters and running statistics move."""
+    case = golden_cases()[MNAME]
+    T = build_masker_trainer(case)
+    batch = masker_batch(case)
+    w0 = T.G.encoder.layer4[2].conv3.weight.detach().clone()
+    rm0 = T.G.encoder.bn1.running_mean.detach().clone()
+    dw0 = T.D["s"]["Advent"][0].module.weight_bar.detach().clone()
+    for _ in range(2):
+        g, d = T.train_step(batch)
+        assert torch.isfinite(g) and torch.isfinite(d)
+    assert not torch.equal(T.G.encoder.layer4[2].conv3.weight.detach(), w0)
+    assert not torch.equal(T.G.encoder.bn1.running_mean.detach(), rm0)
+    assert not torch.equal(T.D["s"]["Advent"][0].module.weight_bar.detach(), dw0)

@@ -1,0 +1,59 @@
+"""Dev-container measurement (needs /root/reference): how far do the REFERENCE's own masker gradients move when every
+conv / norm / activation output and every gradient flowing back through them is rounded to a 16-bit type (the storage
+precision of this package's training path)?  Prints cosine vs the fp32 gradients for a selection of parameters.
+usage: python tools/measure_ref_grad_quant.py [fp16|bf16]"""
+import contextlib, io, sys
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from oracle import ref_shim
+from oracle.make_golden import golden_cases, case_inputs, t
+from climategan_amd import fill
+
+qdt = torch.bfloat16 if "bf16" in sys.argv else torch.float16
+case = golden_cases()["mstep"]
+opts = ref_shim.default_opts(); opts.tasks = ["d", "s", "m"]
+L = ref_shim.ref("losses")
+
+def build():
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+    shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    G.load_state_dict({k: t(v) for k, v in fill.fill_state_dict(shapes, case["seed"], gain=case["gain"]).items()})
+    G.train()
+    G.decoders["d"]._target_size = case["W"] // 4
+    G.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
+    return G
+
+def run(G):
+    inp = {k: t(v) for k, v in case_inputs("mstep", case).items()}
+    x = inp["x_r"]
+    z = G.encode(x)
+    d, zd = G.decoders["d"](z)
+    s = G.decoders["s"](z, zd)
+    m = G.decoders["m"](z, cond=None, z_depth=zd)
+    p = torch.sigmoid(m)
+    loss = L.MinentLoss()(torch.softmax(s, 1)) * 0.001 + L.TVLoss()(p) + L.MinentLoss(2, 0.1)(torch.cat([p, 1 - p], 1)) * 0.5
+    loss.backward()
+    return {k: v.grad.clone() for k, v in G.named_parameters() if v.grad is not None}
+
+torch.manual_seed(0)
+g32 = run(build())
+G = build()
+rq = lambda v: v.to(qdt).float() if torch.is_tensor(v) and v.is_floating_point() else v
+for mod in G.modules():
+    if isinstance(mod, (torch.nn.ReLU, torch.nn.LeakyReLU)):
+        mod.inplace = False
+    if isinstance(mod, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU, torch.nn.LeakyReLU)):
+        def fwd_hook(m, i, o):
+            o = rq(o).clone()
+            if o.requires_grad:
+                o.register_hook(rq)          # the gradient w.r.t. this (stored) activation is rounded too
+            return o
+        mod.register_forward_hook(fwd_hook)
+gq = run(G)
+for k in ("encoder.conv1.weight", "encoder.layer1.0.conv1.weight", "encoder.layer3.1.conv3.weight", "encoder.layer3.16.conv3.weight",
+          "encoder.layer4.2.conv2.weight", "decoders.d.enc4_2.conv.weight", "decoders.s.aspp.conv1.conv.weight",
+          "decoders.s.decoder.conv_cat.0.conv.weight", "decoders.m.model.4.conv.module.weight_bar", "decoders.m.model.7.conv.weight"):
+    a, b = g32[k].flatten().double(), gq[k].flatten().double()
+    print("%-50s cos %.4f  norm ratio %.3f" % (k, float((a * b).sum() / (a.norm() * b.norm())), float(b.norm() / a.norm())))
