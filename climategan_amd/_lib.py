@@ -129,6 +129,9 @@ _SIGNATURES = {
     "cgan_maxpool3x3s2_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_add_act_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int64, _P]),
     "cgan_slice_channels_nhwc": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_sigm_loss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "cgan_sigm_loss_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float,
+                                      _P, _P, _P, C.c_size_t, _P]),
     "cgan_normalize_u8_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_normalize_u8_nhwc": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
                                          _P]),

@@ -554,3 +554,16 @@ class ConcatFn(torch.autograd.Function):
                 grads.append(None)
             off += c
         return (None,) + tuple(grads)
+
+
+def sigm_loss(pred: ops.NHWC, target: torch.Tensor, gmweight=0.5, scales=4):
+    """SIGMLoss.__call__ (losses.py:248-278) on the depth decoder's NHWC map vs a [b, 1, h, w] target."""
+    from . import _lib
+    lib = _lib.load()
+    tgt = target.contiguous().float()
+    b, h, w = pred.n, pred.h, pred.w
+    nbytes = lib.cgan_sigm_loss_workspace_bytes(b, h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.t.device)
+    return _ScalarLossFn.apply(pred.t, pred.c, lambda acc, dx: _lib.check(lib.cgan_sigm_loss_nhwc(
+        ops._ptr(pred.t), ops._ptr(tgt), pred.dtype_id, b, h, w, float(gmweight), int(scales), GRAD_SCALE, ops._ptr(acc),
+        ops._ptr(dx), ops._ptr(ws), nbytes, ops._stream()), "cgan_sigm_loss_nhwc"))

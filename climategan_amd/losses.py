@@ -263,15 +263,17 @@ class ADVENTAdversarialLoss(nn.Module):
 
 
 class SIGMLoss(nn.Module):
-    """reference losses.py:237-278 (MiDaS scale-invariant loss: medians + 4-scale Sobel).  Not built: needs a device
-    median (selection) kernel; the depth term is inactive for real-domain batches (trainer.py:1389-1407)."""
+    """reference losses.py:237-278: MiDaS scale-and-shift-invariant loss (medians, mean absolute deviations) plus a
+    4-scale Sobel gradient-matching term; the reference's expansion of the filters to B output channels (which counts
+    every response B times) is reproduced."""
 
     def __init__(self, gmweight=0.5, scale=4, device="cuda"):
         super().__init__()
         self.gmweight, self.scale = gmweight, scale
 
     def __call__(self, prediction, target):
-        raise NotImplementedError("SIGMLoss has no HIP kernel yet (device median + multi-scale Sobel)")
+        prediction = _as_nhwc(prediction, "SIGMLoss")
+        return ag.sigm_loss(prediction, target.to(prediction.t.device), self.gmweight, self.scale)
 
 
 def get_losses(opts, verbose, device=None):

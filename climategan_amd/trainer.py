@@ -169,7 +169,9 @@ class Trainer:
         weight = self.opts.train.lambdas.G.d.main
         if weight == 0 or domain == "r":
             return torch.zeros((), device=self.device), prediction, z_depth
-        return self.losses["G"]["tasks"]["d"](prediction, target) * weight, prediction, z_depth
+        loss = self.losses["G"]["tasks"]["d"](prediction, target) * weight
+        self.loss_log["G.d." + domain] = loss.detach()
+        return loss, prediction, z_depth
 
     def masker_s_loss(self, x, z, depth_preds, z_depth, target, domain, for_="G"):
         """reference trainer.py:1409-1504"""

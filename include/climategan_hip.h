@@ -377,6 +377,15 @@ int cgan_add_act_nhwc(const void* a, const void* b, void* y, int32_t dtype, int3
 int cgan_slice_channels_nhwc(const void* src, void* dst, int64_t npix, int32_t c, int32_t cs_src, int32_t c_off_src,
                              void* stream);
 
+/* SIGMLoss (climategan/losses.py:237-278): scale-and-shift-invariant depth loss with a `scales`-level Sobel gradient
+ * matching term, prediction = the depth decoder's 1-channel NHWC map [b][h][w][8], target fp32 [b][1][h][w].
+ * *loss_accum += weight * loss; dpred (may be NULL) = weight * d loss / d prediction.  Medians are exact order statistics
+ * (radix select).  workspace: cgan_sigm_loss_workspace_bytes(b, h, w). */
+size_t cgan_sigm_loss_workspace_bytes(int32_t b, int32_t h, int32_t w);
+int cgan_sigm_loss_nhwc(const void* pred, const float* target, int32_t dtype, int32_t b, int32_t h, int32_t w,
+                        float gmweight, int32_t scales, float weight, float* loss_accum, void* dpred, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Output post-ops of the inference harness (Trainer.infer_all, climategan/trainer.py:311-332)
  * ------------------------------------------------------------------------------------------------ */

@@ -87,7 +87,9 @@ def case_inputs(name, case):
                     m_target=fill.rect_mask(B, 2 * h, 2 * w, s * 100 + 4),
                     ground=fill.rect_mask(B, 2 * h, 2 * w, s * 100 + 5),
                     d_pred=fill.uniform((B, 1, h, w), s * 100 + 6, 0.2, 1.0),
-                    d_out=fill.uniform((B, 1, 5, 7), s * 100 + 7, -1, 1))
+                    d_out=fill.uniform((B, 1, 5, 7), s * 100 + 7, -1, 1),
+                    depth_pred=fill.uniform((B, 1, h, w), s * 100 + 8, -1.0, 2.0),
+                    depth_target=fill.uniform((B, 1, h, w), s * 100 + 9, 0.35, 6.95))
     if k == "gstep_p":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
@@ -345,6 +347,9 @@ def run_reference_masker_losses(name, case):
     record("advent_wgan_0", wgan(d, 0), d)
     d = inp["d_out"].clone().requires_grad_(True)
     record("advent_wgan_1", wgan(d, 1), d)
+    dp = inp["depth_pred"].half().float().clone().requires_grad_(True)     # the values the 16-bit map can hold (ties!)
+    record("sigm", L.SIGMLoss(0.5, device="cpu")(dp, inp["depth_target"]), dp)
+    out["sigm.median_index"] = np.array([int(torch.median(dp.detach().flatten(), 0).indices)], dtype=np.int64)
     return out
 
 
@@ -360,8 +365,7 @@ def grad_subsample(key, g, n):
 def run_reference_mstep(name, case):
     """G side of the Masker step: ``get_masker_loss`` (trainer.py:1184-1254) restated on the reference's own modules
     (generator in train mode: batch-statistics BatchNorm) and loss classes, domains r then s, ADVENT discriminators
-    frozen; the depth term (SIGMLoss) is evaluated and recorded but NOT included in the differentiated loss (the HIP
-    build has no SIGM kernel yet).  Gradients are stored as seeded sub-samples + norms."""
+    frozen.  Gradients are stored as seeded sub-samples + norms."""
     import contextlib
     import io
 
@@ -397,7 +401,10 @@ def run_reference_mstep(name, case):
         x = inp["x_" + dom]
         z = G.encode(x)
         d_pred, z_depth = G.decoders["d"](z)
-        terms["d." + dom] = (sigm(d_pred, inp["d_" + dom]) * lam.G.d.main).detach()
+        l = sigm(d_pred, inp["d_" + dom]) * lam.G.d.main
+        terms["d." + dom] = l.detach()
+        if dom == "s":                                   # real-domain depth loss is computed and discarded (trainer.py:1403-1405)
+            total = total + l
         s_pred = G.decoders["s"](z, z_depth)
         if dom == "s":
             l = crossent(s_pred, inp["s_" + dom].squeeze(1)) * lam.G.s.crossent

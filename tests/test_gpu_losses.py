@@ -107,3 +107,29 @@ def test_tv_loss_gradient_matches_torch():
     assert abs(loss.item() - ref.item()) <= 1e-3 * abs(ref.item())
     g = ops.nhwc_to_nchw(ops.NHWC(xg.t.grad, 3)).cpu()
     assert (g - x.grad).abs().max() <= 2e-3 * x.grad.abs().max()
+
+
+def test_sigm_loss_matches_reference():
+    """SIGMLoss (medians by radix select, mean absolute deviations, 4-scale Sobel term with the reference's B-fold count)
+    value and gradient vs the reference class.  The gradient has one special entry -- the median element, which receives
+    the chain-rule terms through the median -- compared separately because ties (fp16 values) let torch pick another
+    index of the same value."""
+    from climategan_amd import losses as L
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    inp = case_inputs(NAME, case)
+    x = nhwc(inp["depth_pred"], True)
+    loss = L.SIGMLoss(0.5)(x, t(inp["depth_target"]).cuda())
+    loss.backward()
+    ref = float(gold["sigm"][0])
+    assert abs(loss.item() - ref) <= 1e-3 * abs(ref), (loss.item(), ref)
+    g, gr = grad_nchw(x).reshape(-1), gold["sigm.grad"].reshape(-1).copy()
+    pred16 = t(inp["depth_pred"]).half().float().reshape(-1).numpy()
+    med_ref = int(gold["sigm.median_index"][0])
+    ties = np.nonzero(pred16 == pred16[med_ref])[0]                   # the median value's tie set
+    mask = np.ones_like(g, dtype=bool)
+    mask[ties] = False
+    scale = np.abs(gr[mask]).max()
+    assert np.abs(g[mask] - gr[mask]).max() <= 4e-3 * scale
+    # the special entry: same total over the tie set (the extra median term lands on one of its members)
+    assert abs(g[ties].sum() - gr[ties].sum()) <= 2e-2 * max(abs(gr[ties].sum()), scale)

@@ -214,7 +214,6 @@ def build_masker_trainer(case, dt=torch.bfloat16):
 
     opts = default_opts()
     opts.tasks = ["d", "s", "m"]
-    opts.train.lambdas.G.d.main = 0            # SIGMLoss has no HIP kernel yet; the golden's gradient excludes it too
     T = Trainer(opts, device="cuda").setup(inference=False)
     for mod, seed in ((T.G, case["seed"]), (T.D, case["seed"] + 1)):
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
@@ -247,8 +246,8 @@ REF_QUANT_COS = {
 
 def test_masker_g_step_matches_reference():
     """get_masker_loss + backward on the HIP path (ResNet-101 with batch-statistics BatchNorm, DADA depth, DeepLab-v3+
-    seg, mask decoder, frozen ADVENT discriminators, 9 loss terms over a real and a sim batch) vs the reference's own
-    modules / loss classes / backward (golden ``mstep``; depth term excluded on both sides), in bf16.
+    seg, mask decoder, frozen ADVENT discriminators, 10 loss terms over a real and a sim batch) vs the reference's own
+    modules / loss classes / backward (golden ``mstep``), in bf16.
 
     What can be compared: every loss term; the NORM of every parameter gradient (16-bit storage does not move it: the
     reference's own 16-bit-rounded run keeps norms within 4 %); the gradient DIRECTION where 16-bit storage preserves
@@ -266,12 +265,13 @@ def test_masker_g_step_matches_reference():
     loss.backward()
     names = {"term.s.minent.r": "G.s.minent.r", "term.s.advent.r": "G.s.advent.r", "term.m.tv.r": "G.m.tv.r",
              "term.m.gi.r": "G.m.gi.r", "term.m.minent.r": "G.m.minent.r", "term.m.advent.r": "G.m.advent.r",
-             "term.s.crossent.s": "G.s.crossent.s", "term.m.tv.s": "G.m.tv.s", "term.m.bce.s": "G.m.bce.s"}
+             "term.s.crossent.s": "G.s.crossent.s", "term.m.tv.s": "G.m.tv.s", "term.m.bce.s": "G.m.bce.s",
+             "term.d.s": "G.d.s"}
     for gk, hk in names.items():
         ref, got = float(gold[gk][0]), float(T.loss_log[hk])
         tol = 0.25 if gk == "term.m.gi.r" else 3e-2          # GI counts pixels across a 0.5 threshold
         assert abs(got - ref) <= tol * max(abs(ref), 1e-4), (gk, got, ref)
-    assert abs(loss.item() - float(gold["loss"][0])) <= 1e-2 * abs(float(gold["loss"][0]))
+    assert abs(loss.item() - float(gold["loss"][0])) <= 3e-2 * abs(float(gold["loss"][0]))
     params = dict(T.G.named_parameters())
     ratios, cos = {}, {}
     for gk in gold:

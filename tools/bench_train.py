@@ -27,10 +27,11 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-vgg", action="store_true")
+    ap.add_argument("--tasks", default="p", help="'p' (Painter step) or 'dsmp' (joint Masker + Painter step: domains r, s, rf)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     opts = default_opts()
-    opts.tasks = ["p"]
+    opts.tasks = list(args.tasks)
     if args.no_vgg:
         opts.train.lambdas.G.p.vgg = 0
     T = Trainer(opts, device="cuda").setup(inference=False)
@@ -43,6 +44,15 @@ def main():
     m = torch.from_numpy(fill.rect_mask(args.bs, args.size, args.size, 6)).cuda()
     T.G.painter.set_latent_shape(x.shape, True)
     batch = {"rf": {"data": {"x": x, "m": m}}}
+    if "m" in opts.tasks:
+        import numpy as np
+        hs = args.size // 4
+        for i, dom in enumerate(("r", "s")):
+            batch[dom] = {"data": {
+                "x": torch.from_numpy(fill.uniform((args.bs, 3, args.size, args.size), 20 + i)).cuda(),
+                "d": torch.from_numpy(fill.uniform((args.bs, 1, hs, hs), 30 + i, 0.35, 6.95)).cuda(),
+                "s": torch.from_numpy((fill.uniform01((args.bs, 1, hs, hs), 40 + i) * 11).astype(np.int64).clip(0, 10)).cuda(),
+                "m": torch.from_numpy(fill.rect_mask(args.bs, args.size, args.size, 50 + i)).cuda()}}
     for _ in range(args.warmup):
         T.train_step(batch)
     torch.cuda.synchronize()
@@ -61,9 +71,9 @@ def main():
         td += c - b
     dtot = time.perf_counter() - t0
     print(json.dumps({
-        "workload": "Painter train step (update_G + update_D, ExtraAdam), %dx%d bs %d %s, vgg=%s" % (
-            args.size, args.size, args.bs, args.dtype, not args.no_vgg),
-        "images_per_s": round(args.bs * args.steps / dtot, 2), "ms_per_step": round(dtot / args.steps * 1e3, 1),
+        "workload": "%s train step (update_G + update_D, ExtraAdam), %dx%d bs %d per domain %s, vgg=%s" % (
+            "Painter" if args.tasks == "p" else "joint Masker+Painter (domains r, s, rf)", args.size, args.size, args.bs, args.dtype, not args.no_vgg),
+        "images_per_s": round(args.bs * args.steps / dtot, 2), "raw_images_per_s": round(args.bs * len(batch) * args.steps / dtot, 2), "ms_per_step": round(dtot / args.steps * 1e3, 1),
         "update_G_ms": round(tg / args.steps * 1e3, 1), "update_D_ms": round(td / args.steps * 1e3, 1),
         "losses": {k: round(float(v), 4) for k, v in T.loss_log.items()},
         "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
