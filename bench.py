@@ -240,36 +240,57 @@ def result_line(world, steps, warmup, elapsed, dtype_name):
     }
 
 
-def train_block(train_steps, rank, world, device, dtype, dist, barrier, x, m):
-    """Supplementary measurement (not `value`): the Painter G+D training step (BASELINE metric's "G+D step", Painter
-    tasks only -- the Masker has no training path yet): Trainer.train_step = update_G (paint, D, GAN + feature-matching
-    + VGG losses, backward, ExtraAdam) + update_D, data-parallel over the ranks with the bucketed RCCL all-reduce of
-    climategan_amd/parallel.py.  Same barrier / synchronize / max-over-ranks timing as the main line."""
+TRAIN_BS = 4   # per domain per GPU: BASELINE configs[3] is global batch 32 over 8 GPUs
+
+
+def train_block(train_steps, rank, world, device, dtype, dist, barrier):
+    """Supplementary measurement (not `value`): BASELINE's "G+D step" -- the full joint Masker + Painter training
+    iteration of the default config (Trainer.train_step = update_G over the real, sim and flooded domains: ResNet-101
+    encoder with batch-statistics BatchNorm, depth / seg / mask decoders and their 10 loss terms, ADVENT
+    discriminators, Painter with GAN + feature-matching + VGG losses; then update_D; ExtraAdam extrapolate / step),
+    640x640, 4 samples per domain per GPU, bf16, data-parallel over the ranks with the bucketed RCCL all-reduce of
+    climategan_amd/parallel.py.  Same barrier / synchronize / max-over-ranks timing as the main line.  `images_per_s`
+    counts one per-domain sample slot per image; `raw_images_per_s` counts all three domains."""
+    import numpy as np
+
     from climategan_amd import fill
     from climategan_amd.config import default_opts
     from climategan_amd.trainer import Trainer
 
     opts = default_opts()
-    opts.tasks = ["p"]
+    opts.tasks = ["d", "s", "m", "p"]
     opts.gen.p.latent_dim = LATENT
     opts.gen.p.spade_n_up = N_UP
     T = Trainer(opts, device=device).setup(inference=False)
     for mod, seed in ((T.G, 0), (T.D, 1)):
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
-        mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=seed).items()})
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=seed, gain=1.6).items()})
     T.G.set_compute_dtype(dtype)
     T.D.set_compute_dtype(dtype)
-    T.G.painter.set_latent_shape(x.shape, True)
-    batch = {"rf": {"data": {"x": x, "m": m}}}
+    bs, hs = TRAIN_BS, H // 4
+
+    def dev(a):
+        return torch.from_numpy(a).to(device)
+
+    batch = {"rf": {"data": {"x": dev(fill.uniform((bs, 3, H, W), 100 + rank)),
+                             "m": dev(fill.rect_mask(bs, H, W, 200 + rank))}}}
+    for i, dom in enumerate(("r", "s")):
+        sd = 300 + 10 * i + 1000 * rank
+        batch[dom] = {"data": {"x": dev(fill.uniform((bs, 3, H, W), sd)),
+                               "d": dev(fill.uniform((bs, 1, hs, hs), sd + 1, 0.35, 6.95)),
+                               "s": dev((fill.uniform01((bs, 1, hs, hs), sd + 2) * 11).astype(np.int64).clip(0, 10)),
+                               "m": dev(fill.rect_mask(bs, H, W, sd + 3))}}
+    T.G.painter.set_latent_shape((bs, 3, H, W), True)
     elapsed = timed_steps(lambda: T.train_step(batch), train_steps, 1, barrier)
     elapsed = max_over_ranks(elapsed, dist, device)
     losses = {k: round(float(v), 4) for k, v in T.loss_log.items()}
-    return {"workload": "Painter G+D train step (Trainer.train_step: update_G + update_D, ExtraAdam; GAN + "
-                        "feature-matching + VGG(random init) losses), 640x640, batch %d per GPU, data-parallel "
-                        "bucketed gradient all-reduce" % BATCH_PER_GPU,
-            "images_per_s": round(world * BATCH_PER_GPU * train_steps / elapsed, 2),
+    return {"workload": "joint Masker+Painter G+D train step (Trainer.train_step; domains r, s, rf; all default loss "
+                        "terms, VGG with random-init weights), 640x640, %d samples per domain per GPU, data-parallel "
+                        "bucketed gradient all-reduce" % bs,
+            "images_per_s": round(world * bs * train_steps / elapsed, 2),
+            "raw_images_per_s": round(world * bs * 3 * train_steps / elapsed, 2),
             "ms_per_step": round(elapsed / train_steps * 1e3, 1), "steps": train_steps, "warmup": 1,
-            "losses_last_step": losses}
+            "global_batch_per_domain": world * bs, "losses_last_step": losses}
 
 
 def main():
@@ -280,7 +301,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3,
-                    help="timed steps of the supplementary Painter G+D training-step measurement (0 = skip)")
+                    help="timed steps of the supplementary joint G+D training-step measurement (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,7 +353,7 @@ def main():
     train = None
     if args.train_steps > 0:
         try:
-            train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier, x, m)
+            train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier)
         except Exception as e:  # the main line must survive a failure of the supplementary block
             train = {"error": "%s: %s" % (type(e).__name__, e)}
 
