@@ -22,11 +22,13 @@ struct WgradArgs {
   const uint16_t* x;
   const uint16_t* dy;
   float* dw;
+  float* ws;   // non-null: partial tiles go to ws[split][tile][16 fragments][64 lanes] (f32x4) for wgrad_reduce_kernel
   int n, h_in, w_in, cin, cin_s;
   int cout, cout_s;
   int kh, kw, stride, pad, dil;
   int h_out, w_out, npix;
-  int nchunks, ci_blocks, splits;
+  int nchunks, ci_blocks, co_blocks, splits, per_xcd;
+  int dbg;     // debug ablation bits (tools/bench_wgrad.py): 1 = skip the atomics, 2 = skip the MFMAs
   int reflect; // 1: nn.ReflectionPad2d(pad) in front of the conv (index math instead of the zero page)
   int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
 };
@@ -55,15 +57,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // blockIdx.x -> (pixel split, tap): ids that differ by 8 share an XCD (one L2); the taps of one pixel split sit on
-  // the same XCD and walk the same chunks together, so the dy / x slabs are fetched from HBM once, not once per tap
+  // Work items are ordered (pixel split, ci block, tap, co block) with the co block fastest, and each XCD (blockIdx.x
+  // & 7: one L2) takes one CONTIGUOUS range of them, so the co blocks and taps of one (pixel split, ci block) run
+  // together on one XCD and walk the same chunks: their x / dy slabs are L2 hits instead of HBM re-reads.
   const int taps_n = p.kh * p.kw;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tap = slot % taps_n;
-  const int split = (slot / taps_n) * 8 + xcd;
-  if (split >= p.splits) return;
+  int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  const int tiles_n = taps_n * p.ci_blocks * p.co_blocks;
+  if ((int)(blockIdx.x >> 3) >= p.per_xcd || item >= tiles_n * p.splits) return;
+  const int cob = item % p.co_blocks;
+  item /= p.co_blocks;
+  const int tap = item % taps_n;
+  item /= taps_n;
+  const int cib = item % p.ci_blocks;
+  const int split = item / p.ci_blocks;
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
-  const int cob = blockIdx.y / p.ci_blocks, cib = blockIdx.y - cob * p.ci_blocks;
   const int co0 = cob * 64, ci0 = cib * 64;
   unsigned char* wl = smem + wave * WAVE_LDS;
 
@@ -73,20 +80,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const long zero_dy = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.dy);
   const long zero_x = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.x);
 
-  // DMA of this wave's 32-pixel slab of chunk c into buffer b: 4 pieces of dy, 4 pieces of (tap-shifted) x
-  auto issue = [&](int c, int b) {
+  // Pixel coordinates of this lane's 4 DMA pieces for the NEXT chunk to issue.  They are advanced by the (uniform)
+  // chunk stride with carries instead of being re-derived by integer division every chunk: the first version spent
+  // ~12 divisions per lane per chunk, several times the chunk's 16 MFMAs.
+  int c_pix[4], c_ox[4], c_oy[4], c_n[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = split * 128 + wave * 32 + i * 8 + prow;
+    c_pix[i] = pix;
+    c_ox[i] = pix % p.w_out;
+    const int r = pix / p.w_out;
+    c_oy[i] = r % p.h_out;
+    c_n[i] = r / p.h_out;
+  }
+  const int step = p.splits * 128;                                   // pixels between two chunks of this workgroup
+  const int step_x = step % p.w_out, step_r = step / p.w_out;
+  const int step_y = step_r % p.h_out, step_n = step_r / p.h_out;
+
+  // DMA of this wave's 32-pixel slab of the next chunk into buffer b: 4 pieces of dy, 4 pieces of (tap-shifted) x
+  auto issue = [&](int b) {
     unsigned char* dst_dy = wl + b * 2 * SLAB_BYTES;
     unsigned char* dst_x = dst_dy + SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int pix = c * 128 + wave * 32 + i * 8 + prow;
+      const int pix = c_pix[i];
       const bool pv = pix < p.npix;
-      const int pc = pv ? pix : 0;
-      const int ox = pc % p.w_out;
-      const int r = pc / p.w_out;
-      const int oy = r % p.h_out;
-      const int nn = r / p.h_out;
-      const long off_dy = (pv && co_ok) ? ((long)pc * p.cout_s + co0 + q8) * 2 : zero_dy;
+      const int ox = c_ox[i], oy = c_oy[i], nn = c_n[i];
+      const long off_dy = (pv && co_ok) ? ((long)pix * p.cout_s + co0 + q8) * 2 : zero_dy;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.dy) + off_dy),
           (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16, 0, 0);
@@ -102,6 +122,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.x) + off_x),
           (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16, 0, 0);
+      // advance to the following chunk
+      c_pix[i] = pix + step;
+      int nx = ox + step_x, ny = oy + step_y, n2 = nn + step_n;
+      if (nx >= p.w_out) { nx -= p.w_out; ++ny; }
+      if (ny >= p.h_out) { ny -= p.h_out; ++n2; }
+      c_ox[i] = nx; c_oy[i] = ny; c_n[i] = n2;
     }
   };
 
@@ -112,12 +138,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int c = split, buf = 0;
-  if (c < p.nchunks) issue(c, 0);
+  if (c < p.nchunks) issue(0);
   for (; c < p.nchunks; c += p.splits) {
     const int cn = c + p.splits;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier fragment reads of the other buffer are done
     if (cn < p.nchunks) {
-      issue(cn, buf ^ 1);
+      issue(buf ^ 1);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -145,8 +171,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int b = 0; b < 4; ++b)
       *reinterpret_cast<f32x4*>(smem + ((wave * 16 + a * 4 + b) * 64 + lane) * 16) = acc[a][b];
   __syncthreads();
-  const int taps = p.kh * p.kw;
   const int j = lane & 15, g = lane >> 4;
+  f32x4* wst = nullptr;
+  if (p.ws) {
+    const int tile = (tap * p.ci_blocks + cib) * p.co_blocks + cob;
+    wst = reinterpret_cast<f32x4*>(p.ws) + ((size_t)split * tiles_n + tile) * 1024;
+  }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int a = wave;   // this wave finalises co tile `wave`
@@ -156,12 +186,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(smem + ((w * 16 + a * 4 + b) * 64 + lane) * 16);
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
+    if (wst) {
+      wst[(a * 4 + b) * 64 + lane] = s;   // fragment order: 16 B per lane, coalesced
+      continue;
+    }
     const int ci = ci0 + b * 16 + j;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = co0 + a * 16 + 4 * g + r;
-      if (co < p.cout && ci < p.cin) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps + tap, s[r]);
+      if (co < p.cout && ci < p.cin && !(p.dbg & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, s[r]);
     }
+  }
+}
+
+// Second stage of the workspace path: dW += sum over pixel splits of the partial tiles.  One thread per f32x4 of a
+// tile; blockIdx.y strides the splits (G groups) so small-channel layers with hundreds of splits still fill the chip;
+// G > 1 finishes with (at most G-way contended) atomics, G == 1 with a plain read-modify-write.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw,
+                                                           int splits, int taps, int ci_blocks, int co_blocks,
+                                                           int cout, int cin) {
+  const int tiles_n = taps * ci_blocks * co_blocks;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= tiles_n * 1024) return;
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int sp = blockIdx.y; sp < splits; sp += gridDim.y) {
+    const f32x4 v = ws[(size_t)sp * tiles_n * 1024 + e];
+    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+  }
+  int tile = e >> 10;
+  const int frag = (e >> 6) & 15, lane = e & 63;
+  const int cob = tile % co_blocks;
+  tile /= co_blocks;
+  const int cib = tile % ci_blocks, tap = tile / ci_blocks;
+  const int ci = cib * 64 + (frag & 3) * 16 + (lane & 15);
+  if (ci >= cin) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = cob * 64 + (frag >> 2) * 16 + 4 * (lane >> 4) + r;
+    if (co >= cout) continue;
+    float* dst = dw + ((size_t)co * cin + ci) * taps + tap;
+    if (gridDim.y > 1) atomicAdd(dst, s[r]);
+    else *dst += s[r];
   }
 }
 
@@ -198,10 +263,36 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
+int g_wgrad_target = 0, g_wgrad_dbg = 0;
 }  // namespace
 
+extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
+  g_wgrad_target = target_workgroups > 0 ? target_workgroups : 0;
+  g_wgrad_dbg = dbg;
+}
+
+static int wgrad_splits(const CganConvDesc* d) {
+  const long npix = (long)d->n * d->h_out * d->w_out;
+  const int nchunks = (int)((npix + 127) / 128);
+  const int tiles = d->kh * d->kw * ceil_div(cgan_cs(d->c_in), 64) * ceil_div(cgan_cs(d->c_out), 64);
+  // ~4 workgroups per CU for layers with many (tap, channel block) tiles or very long pixel ranges, ~2 otherwise
+  // (measured per layer shape with tools/bench_wgrad.py: the partial-tile workspace traffic grows with the splits)
+  const int target = g_wgrad_target > 0 ? g_wgrad_target : ((tiles >= 512 || tiles <= 16) ? 2048 : 1024);
+  int splits = ceil_div(target, tiles);
+  if (splits > nchunks) splits = nchunks;
+  return splits < 1 ? 1 : splits;
+}
+
+extern "C" size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* d) {
+  if (!d || d->n <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->kh <= 0 || d->kw <= 0)
+    return 0;
+  const size_t tiles = (size_t)d->kh * d->kw * ceil_div(cgan_cs(d->c_in), 64) * ceil_div(cgan_cs(d->c_out), 64);
+  return tiles * (size_t)wgrad_splits(d) * 64 * 64 * sizeof(float);
+}
+
 extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias,
-                                           const CganConvDesc* d, void* stream) {
+                                           const CganConvDesc* d, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
   CGAN_REQUIRE(d != nullptr && x && dy && dw_oihw, "conv2d_nhwc_bwd_weight: null pointer");
   CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d_nhwc_bwd_weight: bad dtype %d", d->dtype);
   CGAN_REQUIRE(d->pad_mode == CGAN_PAD_ZERO || d->pad_mode == CGAN_PAD_REFLECT, "conv2d_nhwc_bwd_weight: bad pad mode");
@@ -228,21 +319,36 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   a.reflect = d->pad_mode == CGAN_PAD_REFLECT;
   a.nchunks = ceil_div(a.npix, 128);
   a.ci_blocks = ceil_div(a.cin_s, 64);
-  const int blocks = ceil_div(a.cout_s, 64) * a.ci_blocks;
+  a.co_blocks = ceil_div(a.cout_s, 64);
+  const int blocks = a.co_blocks * a.ci_blocks;
   const int taps = d->kh * d->kw;
-  int splits = ceil_div(2048, taps * blocks);
-  if (splits > a.nchunks) splits = a.nchunks;
-  if (splits < 1) splits = 1;
-  CGAN_REQUIRE(blocks <= 65535, "conv2d_nhwc_bwd_weight: grid too large");
-  a.splits = splits;
-  const int gx = ceil_div(splits, 8) * 8 * taps;
+  a.dbg = g_wgrad_dbg;
+  a.splits = wgrad_splits(d);
+  const long items = (long)a.splits * taps * blocks;
+  a.per_xcd = (int)((items + 7) / 8);
+  CGAN_REQUIRE(items < (1L << 30), "conv2d_nhwc_bwd_weight: grid too large");
+  const unsigned gx = (unsigned)a.per_xcd * 8;
+  a.ws = nullptr;
+  if (workspace) {
+    CGAN_REQUIRE(workspace_bytes >= cgan_conv2d_bwd_weight_workspace_bytes(d),
+                 "conv2d_nhwc_bwd_weight: workspace too small (%zu bytes)", workspace_bytes);
+    a.ws = (float*)workspace;
+  }
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = 4 * WAVE_LDS;   // 64 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
   if (d->dtype == CGAN_F16)
-    hipLaunchKernelGGL(conv_wgrad_kernel<F16>, dim3(gx, blocks), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<F16>, dim3(gx), dim3(256), smem, s, a);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(gx, blocks), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(gx), dim3(256), smem, s, a);
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
+  if (a.ws) {
+    const int elems = taps * blocks * 1024;
+    int groups = a.splits / 8;
+    groups = groups < 1 ? 1 : (groups > 16 ? 16 : groups);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(elems, 256), groups), dim3(256), 0, s,
+                       (const f32x4*)a.ws, a.dw, a.splits, taps, a.ci_blocks, a.co_blocks, a.cout, a.cin);
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(reduce)");
+  }
   if (dbias) {
     const int cs = a.cout_s;
     const int threads = 256;

@@ -456,7 +456,7 @@ def sumpool2x2(x: NHWC) -> NHWC:
 
 def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, want_bias=True,
                       dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, in_upsample=False,
-                      pad_mode=PAD_ZERO):
+                      pad_mode=PAD_ZERO, use_workspace=True):
     """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given.
     ``in_upsample``: x is the stored (half-resolution) tensor the forward read through the folded x2 upsample."""
     _need_cuda(x.t, dy.t, dw, dbias)
@@ -471,8 +471,11 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
     if want_bias and dbias is None:
         dbias = torch.zeros((c_out,), dtype=torch.float32, device=x.t.device)
     lib = _lib.load()
+    ws_bytes = lib.cgan_conv2d_bwd_weight_workspace_bytes(C.byref(d)) if use_workspace else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.t.device) if ws_bytes else None
     _lib.check(lib.cgan_conv2d_nhwc_bwd_weight(_ptr(x.t), _ptr(dy.t), _ptr(dw), _ptr(dbias if want_bias else None),
-                                               C.byref(d), _stream()), "cgan_conv2d_nhwc_bwd_weight")
+                                               C.byref(d), _ptr(ws), ws_bytes, _stream()),
+               "cgan_conv2d_nhwc_bwd_weight")
     return dw, (dbias if want_bias else None)
 
 

@@ -107,13 +107,18 @@ int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t co
  *  - bwd_data:   dx[n][h_in][w_in][cgan_cs(c_in)] = conv_transpose(dy, w)  (rows / columns no window reached are zero);
  *                packed_w_dgrad comes from cgan_conv2d_pack_weight_dgrad (channel-transposed, tap-flipped, / *sigma).
  *  - bwd_weight: dw_oihw[c_out][c_in][kh][kw] += sum_pixels dy * x(shifted)   and   dbias[c_out] += sum_pixels dy
- *                (fp32, ACCUMULATED with atomics: zero them first; dbias may be NULL). */
+ *                (fp32, ACCUMULATED: zero them first; dbias may be NULL).  The pixel range is split over many
+ *                workgroups; with a workspace (cgan_conv2d_bwd_weight_workspace_bytes, fp32 partial tiles) they are summed
+ *                by a second kernel, with workspace == NULL every workgroup adds its tile to dw with fp32 atomics
+ *                (same result up to summation order; several times slower on small-channel layers: cross-XCD atomics). */
 size_t cgan_conv2d_dgrad_packed_weight_bytes(const CganConvDesc* fwd);
 int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* sigma, void* packed, const CganConvDesc* fwd,
                                   void* stream);
 int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
                               void* stream);
+size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* fwd);
 int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias, const CganConvDesc* fwd,
+                                void* workspace, size_t workspace_bytes,
                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -75,9 +75,9 @@ def test_conv2d_backward(dt, case):
     assert e <= 2e-4, "wgrad %s: rel err %.3g" % (case, e)
     e = rel_err(db.cpu(), b.grad)
     assert e <= 2e-4, "bias grad %s: rel err %.3g" % (case, e)
-    # accumulation semantics: a second call adds
+    # accumulation semantics: a second call adds (this one through the workspace-free atomic path)
     dw2, _ = ops.conv2d_bwd_weight(to_nhwc(x.detach(), dt), dyg, tuple(w.shape), stride=stride, pad=pad, dilation=dil,
-                                   want_bias=False, dw=dw.clone())
+                                   want_bias=False, dw=dw.clone(), use_workspace=False)
     assert rel_err(dw2.cpu(), 2 * w.grad) <= 2e-4
 
 
