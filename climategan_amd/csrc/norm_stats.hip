@@ -125,31 +125,45 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   }
 }
 
+// A thread keeps its 8 channels (mean / rstd in registers) and walks the pixels of image blockIdx.y: no per-element
+// index division and no per-element statistic loads (the first version spent more on those than on the data).
 template <typename T>
-__global__ void norm_act_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
-                                      const float* __restrict__ rstd, uint16_t* __restrict__ y, int hw, int cs, int c,
-                                      long total_groups, int act, float slope) {
+__global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, uint16_t* __restrict__ y,
+                                                             int hw, int cs, int c, int act, float slope) {
   const int cg_total = cs / 8;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_groups;
-       idx += (long)gridDim.x * blockDim.x) {
-    int cg = (int)(idx % cg_total);
-    long pix = idx / cg_total;
-    int n = (int)(pix / hw);
-    u32x4 v = reinterpret_cast<const u32x4*>(x)[idx];
-    const float* m = mean + (size_t)n * cs + cg * 8;
-    const float* r = rstd + (size_t)n * cs + cg * 8;
-    u32x4 o;
+  const int tpp = cg_total < 256 ? cg_total : 256;   // threads per pixel
+  const int rows = 256 / tpp;
+  const int cgl = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+  if (prow >= rows) return;
+  const int n = blockIdx.y;
+  const uint16_t* xn = x + (size_t)n * hw * cs;
+  uint16_t* yn = y + (size_t)n * hw * cs;
+  for (int cg = cgl; cg < cg_total; cg += tpp) {
+    float m[8], r[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a, b;
-      unpack2<T>(v[e], a, b);
-      a = act_apply((a - m[2 * e]) * r[2 * e], act, slope);
-      b = act_apply((b - m[2 * e + 1]) * r[2 * e + 1], act, slope);
-      if (cg * 8 + 2 * e >= c) a = 0.f;
-      if (cg * 8 + 2 * e + 1 >= c) b = 0.f;
-      o[e] = pack2<T>(a, b);
+    for (int e = 0; e < 8; ++e) {
+      m[e] = mean[(size_t)n * cs + cg * 8 + e];
+      r[e] = rstd[(size_t)n * cs + cg * 8 + e];
     }
-    reinterpret_cast<u32x4*>(y)[idx] = o;
+#pragma unroll 2
+    for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
+      const size_t off = (size_t)p * cs + cg * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xn + off);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a, b;
+        unpack2<T>(v[e], a, b);
+        a = act_apply((a - m[2 * e]) * r[2 * e], act, slope);
+        b = act_apply((b - m[2 * e + 1]) * r[2 * e + 1], act, slope);
+        if (cg * 8 + 2 * e >= c) a = 0.f;
+        if (cg * 8 + 2 * e + 1 >= c) b = 0.f;
+        o[e] = pack2<T>(a, b);
+      }
+      *reinterpret_cast<u32x4*>(yn + off) = o;
+    }
   }
 }
 
@@ -217,15 +231,21 @@ extern "C" int cgan_norm_act_apply(const void* x, const float* mean, const float
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(x && mean && rstd && y, "norm_act_apply: null pointer");
   const int cs = cgan_cs(d->c);
-  long groups = (long)d->n * d->hw * (cs / 8);
-  int blocks = (int)((groups + 255) / 256 < 4096 ? (groups + 255) / 256 : 4096);
+  const int cg_total = cs / 8;
+  const int tpp = cg_total < 256 ? cg_total : 256;
+  const int rows = 256 / tpp;
+  // ~4 pixels per thread, at most ~4096 workgroups over the batch
+  long bx = ((long)d->hw + (long)rows * 4 - 1) / ((long)rows * 4);
+  const long cap = 4096 / d->n > 1 ? 4096 / d->n : 1;
+  bx = bx < 1 ? 1 : (bx > cap ? cap : bx);
+  CGAN_REQUIRE(d->n <= 65535, "norm_act_apply: batch too large");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CGAN_F16)
-    hipLaunchKernelGGL(norm_act_apply_kernel<F16>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)x, mean, rstd,
-                       (uint16_t*)y, d->hw, cs, d->c, groups, act, act_slope);
+    hipLaunchKernelGGL(norm_act_apply_kernel<F16>, dim3((unsigned)bx, d->n), dim3(256), 0, s, (const uint16_t*)x, mean,
+                       rstd, (uint16_t*)y, d->hw, cs, d->c, act, act_slope);
   else
-    hipLaunchKernelGGL(norm_act_apply_kernel<BF16>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)x, mean, rstd,
-                       (uint16_t*)y, d->hw, cs, d->c, groups, act, act_slope);
+    hipLaunchKernelGGL(norm_act_apply_kernel<BF16>, dim3((unsigned)bx, d->n), dim3(256), 0, s, (const uint16_t*)x, mean,
+                       rstd, (uint16_t*)y, d->hw, cs, d->c, act, act_slope);
   CGAN_CHECK_LAUNCH("norm_act_apply");
   return CGAN_OK;
 }

@@ -234,11 +234,14 @@ __global__ void bn_train_prepare_kernel(const float* __restrict__ mean, const fl
   rstd_out[ch] = r;
 }
 
-// out = act(gamma xh + beta), xh = (x - mean) rstd.  dz = dy act'(out);  sums[c] = (sum dz, sum dz xh) over n*h*w
+// out = act(gamma xh + beta), xh = (x - mean) rstd.  dz = dy act'(out).
+// Stage 1: partial[chunk][cs][2] = (sum dz, sum dz xh) over the chunk's pixels (plain stores: fp32 atomics from 1000+
+// workgroups to the same 2*cs addresses cross the XCDs and were ~2/3 of this kernel's time).
+constexpr int BN_BWD_MAX_CHUNKS = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
                                                             const uint16_t* __restrict__ dy, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ sums,
+                                                            const float* __restrict__ rstd, float* __restrict__ partial,
                                                             long npix, int cs, int ppb, int act, float slope) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL][cgb*8][2]
   const int cg_total = cs / 8;
@@ -252,11 +255,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
   if (pl < PL && cg < cg_total) {
+    float mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = mean[cg * 8 + e];
+      rs[e] = rstd[cg * 8 + e];
+    }
+    const uint16_t* xp = x + cg * 8;
+    const uint16_t* op = out + cg * 8;
+    const uint16_t* gp = dy + cg * 8;
+#pragma unroll 2
     for (long p = p0 + pl; p < p1; p += PL) {
-      const size_t off = (size_t)p * cs + cg * 8;
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(x + off);
-      const u32x4 vo = *reinterpret_cast<const u32x4*>(out + off);
-      const u32x4 vg = *reinterpret_cast<const u32x4*>(dy + off);
+      const size_t off = (size_t)p * cs;
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(xp + off);
+      const u32x4 vo = *reinterpret_cast<const u32x4*>(op + off);
+      const u32x4 vg = *reinterpret_cast<const u32x4*>(gp + off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float xv[2], ov[2], gv[2];
@@ -265,9 +278,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
         unpack2<T>(vg[e], gv[0], gv[1]);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const int ch = cg * 8 + 2 * e + hh;
           const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
-          const float xh = (xv[hh] - mean[ch]) * rstd[ch];
+          const float xh = (xv[hh] - mu[2 * e + hh]) * rs[2 * e + hh];
           s1[2 * e + hh] += dz;
           s2[2 * e + hh] += dz * xh;
         }
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
     }
   }
   __syncthreads();
+  float* prow = partial + (size_t)blockIdx.x * cs * 2;
   for (int c = t; c < cgb * 8; c += 256) {
     if (cg0 * 8 + c >= cs) continue;
     float a = 0.f, b = 0.f;
@@ -289,52 +302,98 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
       a += sm[((l * cgb) * 8 + c) * 2];
       b += sm[((l * cgb) * 8 + c) * 2 + 1];
     }
-    atomicAdd(sums + (size_t)(cg0 * 8 + c) * 2, a);
-    atomicAdd(sums + (size_t)(cg0 * 8 + c) * 2 + 1, b);
+    prow[(size_t)(cg0 * 8 + c) * 2] = a;
+    prow[(size_t)(cg0 * 8 + c) * 2 + 1] = b;
   }
 }
 
-// dx = rstd gamma (dz - mean(dz) - xh mean(dz xh));  dgamma = sum dz xh, dbeta = sum dz (block 0 writes them)
-template <typename T>
-__global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
-                                    const uint16_t* __restrict__ dy, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums, uint16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, float inv_count, int cs, int c, int act, float slope,
-                                    long groups) {
-  const int cg_total = cs / 8;
-  if (blockIdx.x == 0) {
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-      if (dgamma) dgamma[ch] += sums[2 * ch + 1];
-      if (dbeta) dbeta[ch] += sums[2 * ch];
+// Stage 2: totals over the chunks, dgamma += sum dz xh, dbeta += sum dz, and the three per-channel coefficients of
+//   dx = rstd gamma (dz - mean(dz) - xh mean(dz xh))  =  A dz + B x + C
+// block = 32 channels x 8 chunk lanes
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, float inv_count,
+                                                              float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int c, int cs) {
+  __shared__ float red[8][32][2];
+  const int chl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + chl;
+  float a = 0.f, b = 0.f;
+  if (ch < cs)
+    for (int k = kl; k < chunks; k += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)k * cs + ch) * 2);
+      a += v.x;
+      b += v.y;
     }
+  red[kl][chl][0] = a;
+  red[kl][chl][1] = b;
+  __syncthreads();
+  if (kl != 0 || ch >= cs) return;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    s1 += red[l][chl][0];
+    s2 += red[l][chl][1];
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % cg_total);
-    const u32x4 vx = reinterpret_cast<const u32x4*>(x)[i];
-    const u32x4 vo = reinterpret_cast<const u32x4*>(out)[i];
-    const u32x4 vg = reinterpret_cast<const u32x4*>(dy)[i];
-    u32x4 r;
+  float A = 0.f, B = 0.f, C = 0.f;
+  if (ch < c) {
+    if (dgamma) dgamma[ch] += s2;
+    if (dbeta) dbeta[ch] += s1;
+    const float rs = rstd[ch], mu = mean[ch];
+    A = rs * (gamma ? gamma[ch] : 1.f);
+    const float m1 = s1 * inv_count, m2 = s2 * inv_count;
+    B = -A * rs * m2;
+    C = A * (mu * rs * m2 - m1);
+  }
+  coef[ch] = A;
+  coef[cs + ch] = B;
+  coef[2 * cs + ch] = C;
+}
+
+// Stage 3: dx = A dz + B x + C.  A thread keeps its 8 channels (coefficients in registers) and walks pixels: no
+// per-element index division, no per-element coefficient loads.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
+                                                           const uint16_t* __restrict__ dy, const float* __restrict__ coef,
+                                                           uint16_t* __restrict__ dx, long npix, int cs, int act,
+                                                           float slope) {
+  const int cg_total = cs / 8;
+  const int tpp = cg_total < 256 ? cg_total : 256;   // threads per pixel
+  const int rows = 256 / tpp;
+  const int cgl = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+  if (prow >= rows) return;
+  for (int cg = cgl; cg < cg_total; cg += tpp) {
+    float A[8], B[8], Cc[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float xv[2], ov[2], gv[2], res[2];
-      unpack2<T>(vx[e], xv[0], xv[1]);
-      unpack2<T>(vo[e], ov[0], ov[1]);
-      unpack2<T>(vg[e], gv[0], gv[1]);
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int ch = cg * 8 + 2 * e + hh;
-        float v = 0.f;
-        if (ch < c) {
-          const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
-          const float xh = (xv[hh] - mean[ch]) * rstd[ch];
-          v = rstd[ch] * (gamma ? gamma[ch] : 1.f) * (dz - sums[2 * ch] * inv_count - xh * sums[2 * ch + 1] * inv_count);
-        }
-        res[hh] = v;
-      }
-      r[e] = pack2<T>(res[0], res[1]);
+    for (int e = 0; e < 8; ++e) {
+      A[e] = coef[cg * 8 + e];
+      B[e] = coef[cs + cg * 8 + e];
+      Cc[e] = coef[2 * cs + cg * 8 + e];
     }
-    reinterpret_cast<u32x4*>(dx)[i] = r;
+#pragma unroll 2
+    for (long p = (long)blockIdx.x * rows + prow; p < npix; p += (long)gridDim.x * rows) {
+      const size_t off = (size_t)p * cs + cg * 8;
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(x + off);
+      const u32x4 vo = *reinterpret_cast<const u32x4*>(out + off);
+      const u32x4 vg = *reinterpret_cast<const u32x4*>(dy + off);
+      u32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xv[2], ov[2], gv[2], res[2];
+        unpack2<T>(vx[e], xv[0], xv[1]);
+        unpack2<T>(vo[e], ov[0], ov[1]);
+        unpack2<T>(vg[e], gv[0], gv[1]);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int k = 2 * e + hh;
+          const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
+          res[hh] = A[k] * dz + B[k] * xv[hh] + Cc[k];
+        }
+        r[e] = pack2<T>(res[0], res[1]);
+      }
+      *reinterpret_cast<u32x4*>(dx + off) = r;
+    }
   }
 }
 
@@ -523,7 +582,8 @@ extern "C" int cgan_bn_train_prepare(const float* batch_mean, const float* batch
 }
 
 extern "C" size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c) {
-  return c > 0 ? (size_t)cgan_cs(c) * 2 * sizeof(float) : 0;
+  // 3 coefficient rows + up to BN_BWD_MAX_CHUNKS rows of (sum dz, sum dz xh) partials
+  return c > 0 ? (size_t)cgan_cs(c) * (3 + 2 * (size_t)BN_BWD_MAX_CHUNKS) * sizeof(float) : 0;
 }
 
 extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
@@ -538,27 +598,30 @@ extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void
   CGAN_REQUIRE(workspace_bytes >= cgan_batchnorm_act_bwd_workspace_bytes(c), "batchnorm_act_bwd: workspace too small");
   const int cs = cgan_cs(c);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, cgan_batchnorm_act_bwd_workspace_bytes(c), s);
-  if (e != hipSuccess) {
-    cgan_set_error("batchnorm_act_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CGAN_ERR_HIP;
-  }
+  float* coef = (float*)workspace;
+  float* partial = coef + 3 * (size_t)cs;
   const int cg_total = cs / 8;
   const int cgb = cg_total < 256 ? cg_total : 256;
   const int PL = 256 / cgb;
-  long chunks = 2048 / ceil_div(cg_total, cgb);
+  const int cgblocks = ceil_div(cg_total, cgb);
+  long chunks = BN_BWD_MAX_CHUNKS / cgblocks;
   if (chunks < 1) chunks = 1;
   long ppb = (npix + chunks - 1) / chunks;
-  if (ppb < 4 * PL) ppb = 4 * PL;
+  if (ppb < 8 * PL) ppb = 8 * PL;
   chunks = (npix + ppb - 1) / ppb;
   const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
-  DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, ceil_div(cg_total, cgb)), dim3(256), smem, s,
-             (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, (float*)workspace,
+  DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, cgblocks), dim3(256), smem, s,
+             (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, partial,
              (long)npix, cs, (int)ppb, act, act_slope);
-  const long groups = (long)npix * cg_total;
-  DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)x,
-             (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, gamma, (const float*)workspace,
-             (uint16_t*)dx, dgamma, dbeta, 1.f / (float)npix, cs, c, act, act_slope, groups);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cs, 32)), dim3(256), 0, s, (const float*)partial, (int)chunks,
+                     batch_mean, batch_rstd, gamma, 1.f / (float)npix, coef, dgamma, dbeta, (int)c, cs);
+  const int tpp = cg_total < 256 ? cg_total : 256;
+  const int rows = 256 / tpp;
+  long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x,
+             (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, (uint16_t*)dx, (long)npix, cs, act,
+             act_slope);
   CGAN_CHECK_LAUNCH("batchnorm_act_bwd");
   return CGAN_OK;
 }

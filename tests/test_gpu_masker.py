@@ -54,12 +54,28 @@ def test_masker_matches_reference_golden(dt):
             assert np.abs(sd[k[5:]].cpu().numpy() - gold[k]).max() < 2e-5, k
 
 
-def test_training_mode_batchnorm_refused():
+def test_training_mode_batchnorm_uses_batch_statistics():
+    """G.train(): the encoder's BatchNorms normalise with batch statistics and move their running statistics (as
+    nn.BatchNorm2d does, resnet101_v3.py:30-50); an eval-mode BatchNorm under autograd has no HIP backward and says so.
+    (Value parity of the training-mode forward / backward: tests/test_gpu_backward.py, tests/test_gpu_train.py.)"""
     case = golden_cases()["masker_small"]
     G = build(case, torch.float16)
-    G.train()
     x = t(case_inputs("masker_small", case)["x"]).cuda()
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="training mode"):
+    bn = G.encoder.bn1 if hasattr(G.encoder, "bn1") else next(m for m in G.encoder.modules()
+                                                              if isinstance(m, torch.nn.BatchNorm2d))
+    before = bn.running_mean.clone()
+    with torch.no_grad():
+        z_eval = G.encode(x)
+        G.train()
+        z_train = G.encode(x)
+    assert not torch.equal(before, bn.running_mean)
+    ze = z_eval.t if hasattr(z_eval, "t") else z_eval
+    zt = z_train.t if hasattr(z_train, "t") else z_train
+    assert torch.isfinite(zt.float()).all() and not torch.equal(ze, zt)
+    G.eval()
+    for p_ in G.encoder.parameters():
+        p_.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="eval-mode BatchNorm"):
         G.encode(x)
 
 
