@@ -237,7 +237,7 @@ __global__ void bn_train_prepare_kernel(const float* __restrict__ mean, const fl
 // out = act(gamma xh + beta), xh = (x - mean) rstd.  dz = dy act'(out).
 // Stage 1: partial[chunk][cs][2] = (sum dz, sum dz xh) over the chunk's pixels (plain stores: fp32 atomics from 1000+
 // workgroups to the same 2*cs addresses cross the XCDs and were ~2/3 of this kernel's time).
-constexpr int BN_BWD_MAX_CHUNKS = 1024;
+constexpr int BN_BWD_MAX_CHUNKS = 512;
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
                                                             const uint16_t* __restrict__ dy, const float* __restrict__ mean,
@@ -309,19 +309,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 
 // Stage 2: totals over the chunks, dgamma += sum dz xh, dbeta += sum dz, and the three per-channel coefficients of
 //   dx = rstd gamma (dz - mean(dz) - xh mean(dz xh))  =  A dz + B x + C
-// block = 32 channels x 8 chunk lanes
+// block = 16 channels x 16 chunk lanes
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, float inv_count,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int c, int cs) {
-  __shared__ float red[8][32][2];
-  const int chl = threadIdx.x & 31, kl = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + chl;
+  __shared__ float red[16][16][2];
+  const int chl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + chl;
   float a = 0.f, b = 0.f;
   if (ch < cs)
-    for (int k = kl; k < chunks; k += 8) {
+    for (int k = kl; k < chunks; k += 16) {
       const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)k * cs + ch) * 2);
       a += v.x;
       b += v.y;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (kl != 0 || ch >= cs) return;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int l = 0; l < 8; ++l) {
+  for (int l = 0; l < 16; ++l) {
     s1 += red[l][chl][0];
     s2 += red[l][chl][1];
   }
@@ -613,7 +613,7 @@ extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void
   DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, cgblocks), dim3(256), smem, s,
              (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, partial,
              (long)npix, cs, (int)ppb, act, act_slope);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cs, 32)), dim3(256), 0, s, (const float*)partial, (int)chunks,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cs, 16)), dim3(256), 0, s, (const float*)partial, (int)chunks,
                      batch_mean, batch_rstd, gamma, 1.f / (float)npix, coef, dgamma, dbeta, (int)c, cs);
   const int tpp = cg_total < 256 ? cg_total : 256;
   const int rows = 256 / tpp;

@@ -46,6 +46,12 @@ class NHWC:
     t: torch.Tensor
     c: int
 
+    def __post_init__(self):
+        # the kernels read cs8(c) (conditioning maps: cs4(c)) storage channels per pixel: anything else is out of bounds
+        if self.t.dim() != 4 or self.t.shape[3] not in (cs8(self.c), cs4(self.c)):
+            raise RuntimeError("NHWC: a [N,H,W,Cs] tensor with Cs = %d (or %d) storage channels is needed for %d logical "
+                               "channels, got shape %s" % (cs8(self.c), cs4(self.c), self.c, tuple(self.t.shape)))
+
     @property
     def n(self): return self.t.shape[0]
     @property

@@ -67,7 +67,11 @@ class ExtraAdam(Optimizer):
                     items[i] = AdamItem(p.data.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                         st["exp_avg_sq"].data_ptr(), self.params_copy[id(p)].data_ptr(), p.numel())
                     mx = max(mx, p.numel())
-                table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(ps[0].device)
+                # pinned + non_blocking: a pageable copy would make the host wait here for the whole backward pass
+                # instead of running ahead into the next forward; the pinned buffer is kept until the next call
+                host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
+                table = host.to(ps[0].device, non_blocking=True)
+                self._tables = getattr(self, "_tables", [])[-7:] + [(host, table)]
                 _lib.check(lib.cgan_extra_adam_multi_tensor(_ptr(table), len(ps), mx, mode,
                                                             int(mode == 0 and not self._has_copy), step, group["lr"],
                                                             beta1, beta2, group["eps"], group["weight_decay"],

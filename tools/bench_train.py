@@ -19,6 +19,57 @@ from climategan_amd.config import default_opts  # noqa: E402
 from climategan_amd.trainer import Trainer  # noqa: E402
 
 
+def wgrad_table(T, batch):
+    """Record the (shape, flags) of every conv2d_bwd_weight call of one train step, then time each unique one alone."""
+    from collections import Counter
+    from climategan_amd import ops
+    calls = Counter()
+    orig = ops.conv2d_bwd_weight
+
+    def rec(x, dy, w_shape, stride=1, pad=0, dilation=1, want_bias=True, dw=None, dbias=None, in_upsample=False,
+            pad_mode=ops.PAD_ZERO, **kw):
+        calls[(x.n, x.h, x.w, tuple(w_shape), stride, pad, dilation, bool(want_bias), bool(in_upsample), pad_mode,
+               str(x.t.dtype))] += 1
+        return orig(x, dy, w_shape, stride, pad, dilation, want_bias, dw, dbias, in_upsample, pad_mode, **kw)
+
+    ops.conv2d_bwd_weight = rec
+    try:
+        T.train_step(batch)
+    finally:
+        ops.conv2d_bwd_weight = orig
+    torch.cuda.synchronize()
+    rows = []
+    for key, cnt in calls.items():
+        n, h, w, ws, stride, pad, dil, wb, ups, pm, dts = key
+        dt = torch.bfloat16 if "bfloat16" in dts else torch.float16
+        co, ci, kh, kw_ = ws
+        x = ops.NHWC(torch.randn(n, h, w, ops.cs8(ci), device="cuda").to(dt), ci)
+        hi, wi = (h * 2, w * 2) if ups else (h, w)
+        ho = (hi + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (wi + 2 * pad - dil * (kw_ - 1) - 1) // stride + 1
+        dy = ops.NHWC(torch.randn(n, ho, wo, ops.cs8(co), device="cuda").to(dt), co)
+        dw = torch.zeros(ws, device="cuda")
+        db = torch.zeros(co, device="cuda")
+        for _ in range(2):
+            orig(x, dy, ws, stride, pad, dil, wb, dw, db if wb else None, ups, pm)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            orig(x, dy, ws, stride, pad, dil, wb, dw, db if wb else None, ups, pm)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        fl = 2.0 * n * ho * wo * co * ci * kh * kw_
+        rows.append((ms * cnt, cnt, ms, fl / ms / 1e9, key))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows)
+    print("weight-gradient calls of one step: %d calls, %d shapes, %.2f ms in isolation" % (sum(calls.values()), len(rows), tot))
+    for t, cnt, ms, tf, key in rows[:40]:
+        n, h, w, ws, stride, pad, dil, wb, ups, pm, dts = key
+        print("%7.2f ms  x%-3d %7.3f ms %6.1f TF  n%d %dx%d w%s s%d p%d d%d bias%d ups%d pm%d" % (
+            t, cnt, ms, tf, n, h, w, ws, stride, pad, dil, wb, ups, pm))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bs", type=int, default=8)
@@ -28,6 +79,8 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-vgg", action="store_true")
     ap.add_argument("--tasks", default="p", help="'p' (Painter step) or 'dsmp' (joint Masker + Painter step: domains r, s, rf)")
+    ap.add_argument("--cprofile", action="store_true", help="host-side cProfile of one train step")
+    ap.add_argument("--wgrad-table", action="store_true", help="per-shape table of the weight-gradient calls of one step")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     opts = default_opts()
@@ -56,6 +109,30 @@ def main():
     for _ in range(args.warmup):
         T.train_step(batch)
     torch.cuda.synchronize()
+    if args.wgrad_table:
+        return wgrad_table(T, batch)
+    if args.cprofile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        T.train_step(batch)
+        torch.cuda.synchronize()
+        pr.disable()
+        st = pstats.Stats(pr)
+        st.sort_stats("tottime").print_stats(45)
+        st.sort_stats("cumtime").print_stats(60)
+        return
+    # host-side enqueue time of one step (no synchronisation inside) vs the time the GPU needs to drain it
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    T.update_G(batch)
+    T.update_D(batch)
+    b = time.perf_counter()
+    torch.cuda.synchronize()
+    c = time.perf_counter()
+    T.global_step += 1
+    enqueue_ms, drain_ms = (b - a) * 1e3, (c - b) * 1e3
     tg = td = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -74,6 +151,7 @@ def main():
         "workload": "%s train step (update_G + update_D, ExtraAdam), %dx%d bs %d per domain %s, vgg=%s" % (
             "Painter" if args.tasks == "p" else "joint Masker+Painter (domains r, s, rf)", args.size, args.size, args.bs, args.dtype, not args.no_vgg),
         "images_per_s": round(args.bs * args.steps / dtot, 2), "raw_images_per_s": round(args.bs * len(batch) * args.steps / dtot, 2), "ms_per_step": round(dtot / args.steps * 1e3, 1),
+        "host_enqueue_ms": round(enqueue_ms, 1), "gpu_drain_after_enqueue_ms": round(drain_ms, 1),
         "update_G_ms": round(tg / args.steps * 1e3, 1), "update_D_ms": round(td / args.steps * 1e3, 1),
         "losses": {k: round(float(v), 4) for k, v in T.loss_log.items()},
         "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
