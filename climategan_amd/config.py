@@ -41,10 +41,13 @@ class Opts(dict):
 def default_opts() -> Opts:
     """Hot-path subset of shared/trainer/defaults.yaml (line numbers of the reference file in comments)."""
     return Opts({
+        "output_path": "output",                                         # :2
+        "load_paths": {"p": "none", "m": "none", "pm": "none"},          # :11-14
         "tasks": ["d", "s", "m", "p"],                                   # :19
         "data": {"transforms": [{"name": "resize", "new_size": {"default": 640, "d": 160, "s": 160}}]},   # :61-67
         "gen": {
-            "opt": {"optimizer": "ExtraAdam", "beta1": 0.9, "lr": {"default": 0.00005}},   # :73-77
+            "opt": {"optimizer": "ExtraAdam", "beta1": 0.9, "lr": {"default": 0.00005}, "lr_policy": "step",
+                    "lr_step_size": 5, "lr_milestones": 15, "lr_gamma": 0.5},   # :73-88
             "encoder": {"architecture": "deeplabv3"},                    # :103
             "deeplabv3": {"backbone": "resnet", "output_stride": 8},     # :115-116
             "d": {"architecture": "dada", "upsample_featuremaps": True, "output_dim": 1, "norm": "batch"},   # :122-134
@@ -64,7 +67,8 @@ def default_opts() -> Opts:
         },
         "dis": {
             "soft_shift": 0.2, "flip_prob": 0.05,                        # :194-195
-            "opt": {"optimizer": "ExtraAdam", "beta1": 0.5, "lr": {"default": 0.00002}},   # :196-200
+            "opt": {"optimizer": "ExtraAdam", "beta1": 0.5, "lr": {"default": 0.00002}, "lr_policy": "step",
+                    "lr_step_size": 15, "lr_milestones": 5, "lr_gamma": 0.5},   # :196-211
             "p": {"input_nc": 3, "ndf": 64, "n_layers": 4, "norm": "instance", "use_sigmoid": False, "num_D": 3,
                   "get_intermediate_features": True, "use_local_discriminator": False},   # :213-227
             "m": {"architecture": "base", "gan_type": "WGAN_norm"},      # :229-235
@@ -74,7 +78,9 @@ def default_opts() -> Opts:
                    "fire": {"kernel_size": 281, "kernel_sigma": 140.5, "transparency": 200, "sky_inc_factor": 0.12,
                             "contrast_factor": 1.5, "brightness_factor": 0.95, "crop_bottom_sky_mask": True}},
         # shared/trainer/events.yaml:1-14
-        "train": {"lambdas": {"advent": {"ent_main": 0.5, "ent_aux": 0.0, "ent_var": 0.1, "adv_main": 1.0,
+        "val": {"val_painter": "none"},   # :323 (a cluster path in the reference: "none" here = no validation painter)
+        "train": {"save_n_epochs": 25, "min_save_epoch": 28, "resume": False,   # :313-315
+                  "lambdas": {"advent": {"ent_main": 0.5, "ent_aux": 0.0, "ent_var": 0.1, "adv_main": 1.0,
                                          "adv_aux": 0.0, "dis_main": 1.0, "dis_aux": 0.0},      # :303-310
                               "G": {"d": {"main": 1, "gml": 0.5},
                                     "s": {"crossent": 1, "crossent_pseudo": 0.001, "minent": 0.001, "advent": 0.001},

@@ -1,9 +1,9 @@
 """Host-side mirror of the reference's ``climategan/generator.py`` (the model API boundary).
 
-Built so far: the Painter branch -- ``create_generator``, ``OmniGenerator.painter``, ``paint``,
-``sample_painter_z`` -- with the masking ``x * (1 - m)`` and the paste ``x * (1 - m) + fake * m`` folded
-into the NCHW<->NHWC edge kernels.  The Masker branch (encoder / depth / seg / mask decoders) raises
-NotImplementedError until its kernels land.
+``create_generator``, ``OmniGenerator.{encoder, decoders, painter}``, ``encode`` / ``decode`` / ``mask`` / ``depth`` /
+``make_m_cond`` / ``paint`` / ``paint_cloudy`` / ``sample_painter_z`` / ``load_val_painter``; the masking ``x * (1 - m)``
+and the paste ``x * (1 - m) + fake * m`` are folded into the NCHW<->NHWC edge kernels.  Under autograd the NHWC
+variants (``paint_nhwc``, ``mask_nhwc``, ``decoders[t].forward_nhwc``) are the ones with HIP backward passes.
 """
 import torch
 import torch.nn as nn
@@ -43,6 +43,43 @@ class OmniGenerator(nn.Module):
         self.painter = nn.Module()
         if "p" in opts.tasks:
             self.painter = create_painter(opts, no_init, verbose)
+
+    def load_val_painter(self):
+        """reference generator.py:357-411: graft a validation-only Painter from another run.  ``opts.val.val_painter``
+        must be a checkpoint FILE whose run directory (two levels up) holds the ``opts.yaml`` that Painter was built
+        with; its ``G`` entries are loaded with the ``painter.`` prefix stripped, the module is put in eval mode on this
+        generator's device with gradients disabled.  Any failure is reported and answered with False, as in the
+        reference (the trainer then simply has no painter, trainer.py:725)."""
+        import traceback
+        from pathlib import Path
+
+        import yaml
+
+        from .config import Opts
+        try:
+            assert self.opts.val.val_painter
+            ckpt_path = Path(self.opts.val.val_painter).resolve()
+            assert ckpt_path.exists()
+            assert ckpt_path.is_file()
+            opts_path = ckpt_path.parent.parent / "opts.yaml"
+            assert opts_path.exists()
+            with opts_path.open("r") as f:
+                val_painter_opts = Opts(yaml.safe_load(f))
+            device = next(self.parameters()).device
+            state_dict = torch.load(ckpt_path, map_location=device, weights_only=False)
+            painter = create_painter(val_painter_opts)
+            painter.load_state_dict({k.replace("painter.", ""): v for k, v in state_dict["G"].items()})
+            self.painter = painter.eval().to(device)
+            self.painter.compute_dtype = self.compute_dtype
+            for p in self.painter.parameters():
+                p.requires_grad = False
+            print("    - Loaded validation-only painter")
+            return True
+        except Exception as e:
+            print(traceback.format_exc())
+            print(e)
+            print(">>> WARNING: error (^) in load_val_painter, aborting.")
+            return False
 
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.float16, torch.bfloat16):

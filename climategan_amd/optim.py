@@ -39,8 +39,8 @@ class ExtraAdam(Optimizer):
             by_step = {}
             for p in group["params"]:
                 if p.grad is None:
-                    if mode == 0 and not self._has_copy:
-                        self.params_copy[id(p)] = p.data.clone()   # reference saves every parameter (optim.py:166-168)
+                    # the reference also saves a copy of gradient-less parameters here (optim.py:166-168) but never
+                    # reads it back (step() skips them, optim.py:186-188): not observable, not reproduced
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.data.is_contiguous():
                     raise RuntimeError("ExtraAdam (HIP): contiguous fp32 device parameters expected")
@@ -93,3 +93,71 @@ class ExtraAdam(Optimizer):
         self.params_copy = {}
         self._has_copy = False
         return loss
+
+
+def get_scheduler(optimizer, hyperparameters, iterations=-1):
+    """Learning-rate scheduler from ``<model>.opt`` (reference optim.py:10-51): ``constant`` / None -> no scheduler,
+    ``step`` -> StepLR(lr_step_size, lr_gamma), ``multi_step`` -> MultiStepLR (``lr_milestones`` a list, or an int
+    expanded to ``range(lr_milestones, 1000 or iterations, lr_step_size)``).  Host logic only (it edits
+    ``param_groups[i]["lr"]``, which the HIP update reads per launch)."""
+    from torch.optim import lr_scheduler
+
+    get = hyperparameters.get if hasattr(hyperparameters, "get") else (lambda k: getattr(hyperparameters, k, None))
+    policy, lr_step_size, lr_gamma, milestones = (get(k) for k in ("lr_policy", "lr_step_size", "lr_gamma",
+                                                                   "lr_milestones"))
+    if policy is None or policy == "constant":
+        return None
+    if policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=lr_step_size, gamma=lr_gamma, last_epoch=iterations)
+    if policy == "multi_step":
+        if isinstance(milestones, int):
+            if lr_step_size is None:
+                raise AssertionError("multi_step with an int lr_milestones needs lr_step_size")
+            milestones = list(range(milestones, 1000 if iterations == -1 else iterations, lr_step_size))
+        return lr_scheduler.MultiStepLR(optimizer, milestones=list(milestones), gamma=lr_gamma, last_epoch=iterations)
+    # the reference RETURNS (does not raise) the exception object here (optim.py:48-50); callers would fail later on
+    # ``scheduler.step()``.  Raising at once is the same failure, earlier.
+    raise NotImplementedError("learning rate policy [%s] is not implemented" % policy)
+
+
+def get_optimizer(net, opt_conf, tasks=None, is_disc=False, iterations=-1):
+    """(optimizer, scheduler, lr_names) from ``opts.gen.opt`` / ``opts.dis.opt`` (reference optim.py:54-124): one
+    parameter group over ``net.parameters()`` when ``lr`` is a float or holds only ``default``; otherwise one group per
+    task with its own learning rate (G: encoder for "m", painter for "p", ``decoders[task]`` for the others; D:
+    ``net[task]``).  Group and parameter order are the reference's, so ``state_dict()`` of the optimizer is
+    interchangeable with the reference's ``g_opt`` / ``d_opt`` checkpoint entries.  Only ExtraAdam has a HIP update
+    (the reference's default for both models, defaults.yaml:74,197); the other names raise."""
+    lr_names = []
+    lr = opt_conf.lr
+    if tasks is None or isinstance(lr, float) or len(lr) == 1:
+        lr_default = lr if isinstance(lr, float) else lr.default
+        params = net.parameters()
+        lr_names.append("full")
+    else:
+        lr_default = lr.default
+        params = []
+        for task in tasks:
+            task_lr = lr.get(task, lr_default)
+            parameters = None
+            if not is_disc:
+                if task == "m":
+                    # the encoder rides on the masker's learning rate, as its own group ahead of decoders["m"]
+                    params.append({"params": net.encoder.parameters(), "lr": task_lr})
+                    lr_names.append("encoder")
+                if task == "p":
+                    if hasattr(net, "painter"):
+                        parameters = net.painter.parameters()
+                        lr_names.append("painter")
+                else:
+                    parameters = net.decoders[task].parameters()
+                    lr_names.append("decoder_%s" % task)
+            elif task in net:
+                parameters = net[task].parameters()
+                lr_names.append("disc_%s" % task)
+            if parameters is not None:
+                params.append({"params": parameters, "lr": task_lr})
+    name = str(opt_conf.optimizer).lower()
+    if name != "extraadam":
+        raise NotImplementedError("get_optimizer: only ExtraAdam has a HIP update (got %r)" % opt_conf.optimizer)
+    opt = ExtraAdam(params, lr=lr_default, betas=(opt_conf.beta1, 0.999))
+    return opt, get_scheduler(opt, opt_conf, iterations), lr_names

@@ -6,10 +6,11 @@ Built: the flood event (Masker -> mask -> Painter, optionally through ``paint_cl
 transmission model) and the wildfire event (``fire.add_fire``; its torchvision / kornia arithmetic is restated from those
 libraries' documentation because they are not in the reference tree, so that event is pinned by the oracle only).
 
-Training half (row H2), Painter tasks only (``opts.tasks == ["p"]``): ``setup(inference=False)`` builds G, D, the
-losses and the two ExtraAdam optimisers; ``update_G`` / ``update_D`` / ``train_step`` reproduce the "rf" branch of
-``get_painter_loss`` (trainer.py:1256-1387) and ``get_D_loss`` (trainer.py:1073-1107) and the extrapolate / step
-schedule (trainer.py:674-694).  Masker domains raise (training-mode BatchNorm and the masker losses are not built).
+Training half (row H2): ``setup(inference=False)`` builds G, D, the losses, the two ExtraAdam optimisers and their
+schedulers (``get_optimizer``); ``update_G`` / ``update_D`` / ``train_step`` reproduce ``get_masker_loss``
+(trainer.py:1184-1254, 1389-1616), ``get_painter_loss`` (trainer.py:1256-1387), ``get_D_loss`` (trainer.py:1034-1160)
+and the extrapolate / step schedule (trainer.py:674-694); ``save`` / ``resume`` / ``update_learning_rates`` are the
+checkpoint half (trainer.py:396-579): same file layout, same path rules.
 """
 import time
 
@@ -44,6 +45,17 @@ class Timer:
         return False
 
 
+def _merge(source, destination):
+    """reference utils.py:68-105: recursive dict merge, ``source`` entries overwrite ``destination``'s."""
+    for key, value in source.items():
+        if isinstance(value, dict):
+            node = destination.setdefault(key, {})
+            _merge(value, node)
+        else:
+            destination[key] = value
+    return destination
+
+
 class Trainer:
     """Inference-side subset of the reference Trainer (trainer.py:63-216): owns ``G``; no logger / comet / data."""
 
@@ -60,9 +72,14 @@ class Trainer:
     def setup(self, inference=False):
         """reference trainer.py:701-789."""
         self.G = create_generator(self.opts, device=self.device, no_init=inference, verbose=self.verbose)
+        # trainer.py:725: a generator without its own Painter may borrow a validation-only one (opts.val.val_painter)
+        own_painter = sum(p.numel() for p in self.G.painter.parameters()) > 0
+        self.has_painter = own_painter or (str(self.opts.val.val_painter) != "none" and self.G.load_val_painter())
         if self.has_painter:
             self.G.painter.set_latent_shape(find_target_size(self.opts, "x"), True)       # trainer.py:727-728
         if inference:
+            if self.opts.train.resume:                                                    # trainer.py:735-736
+                self.resume(True)
             self.G.eval()
             self.is_setup = True
             return self
@@ -71,7 +88,7 @@ class Trainer:
                                       "backward kernels; train with gen.m.use_spade = False")
         from .discriminator import create_discriminator
         from .losses import get_losses
-        from .optim import ExtraAdam
+        from .optim import get_optimizer
 
         o = self.opts
         self.D = create_discriminator(o, self.device, verbose=self.verbose)
@@ -89,9 +106,13 @@ class Trainer:
             self.losses["G"]["p"]["vgg"] = None
         g_params = [p for p in self.G.parameters() if p.requires_grad]
         d_params = [p for p in self.D.parameters() if p.requires_grad]
-        self.g_opt = ExtraAdam(g_params, lr=o.gen.opt.lr.default, betas=(o.gen.opt.beta1, 0.999))
-        self.d_opt = ExtraAdam(d_params, lr=o.dis.opt.lr.default, betas=(o.dis.opt.beta1, 0.999))
-        self.global_step = 0
+        # get_optimizer (trainer.py:758-767): groups / parameter order of the reference, so g_opt / d_opt state dicts are
+        # interchangeable with its checkpoints
+        self.lr_names = {}
+        self.g_opt, self.g_scheduler, self.lr_names["G"] = get_optimizer(self.G, o.gen.opt, o.tasks)
+        self.d_opt, self.d_scheduler, self.lr_names["D"] = get_optimizer(self.D, o.dis.opt, o.tasks, True)
+        self.global_step = 0                                           # reference: self.logger.global_step
+        self.epoch = 0                                                 # reference: self.logger.epoch
         self.loss_log = {}
         # data parallel (one process per GPU, launched by torchrun): identical replicas, bucketed gradient all-reduce
         # overlapped with the backward
@@ -386,6 +407,103 @@ class Trainer:
         d = self.update_D(multi_domain_batch)
         self.global_step += 1
         return g, d
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def update_learning_rates(self):
+        """reference trainer.py:696-700 (called once per epoch by run_epoch, and epoch+1 times by resume)."""
+        if self.g_scheduler is not None:
+            self.g_scheduler.step()
+        if self.d_scheduler is not None:
+            self.d_scheduler.step()
+
+    def save(self):
+        """reference trainer.py:396-420: ``{epoch, G, g_opt, step[, D, d_opt]}`` to ``<output_path>/checkpoints/
+        latest_ckpt.pth`` every call, plus ``epoch_<n>_ckpt.pth`` when ``epoch >= min_save_epoch`` and ``epoch %
+        save_n_epochs == 0``.  Same keys, same state-dict layouts: the reference's ``resume`` reads these files."""
+        from pathlib import Path
+
+        save_dir = Path(self.opts.output_path) / "checkpoints"
+        save_dir.mkdir(exist_ok=True, parents=True)   # the reference relies on output_path existing (train.py creates it)
+        save_dict = {"epoch": self.epoch, "G": self.G.state_dict(), "g_opt": self.g_opt.state_dict(),
+                     "step": self.global_step}
+        if self.D is not None and sum(p.numel() for p in self.D.parameters()) > 0:
+            save_dict["D"] = self.D.state_dict()
+            save_dict["d_opt"] = self.d_opt.state_dict()
+        if self.epoch >= self.opts.train.min_save_epoch and self.epoch % self.opts.train.save_n_epochs == 0:
+            torch.save(save_dict, save_dir / ("epoch_%d_ckpt.pth" % self.epoch))
+        torch.save(save_dict, save_dir / "latest_ckpt.pth")
+
+    def _resolve_checkpoint(self):
+        """The path rules of reference trainer.py:422-525: returns the checkpoint dict."""
+        from pathlib import Path
+
+        o = self.opts
+        m_path, p_path, pm_path = Path(str(o.load_paths.m)), Path(str(o.load_paths.p)), Path(str(o.load_paths.pm))
+        output_path = Path(o.output_path)
+
+        def load(path):
+            return torch.load(path, map_location=self.device, weights_only=False)
+
+        def ckpt_file(path):
+            if not path.exists():
+                raise AssertionError("checkpoint path %s does not exist" % path)
+            if path.is_dir():
+                return path / "checkpoints/latest_ckpt.pth"
+            if path.suffix != ".pth":
+                raise AssertionError("checkpoint file %s is not a .pth" % path)
+            return path
+
+        if "m" in o.tasks and "p" in o.tasks:
+            if all(str(p) == "none" for p in (m_path, p_path, pm_path)):
+                return load(output_path / "checkpoints/latest_ckpt.pth")
+            if str(pm_path) != "none":
+                return load(ckpt_file(pm_path))
+            if m_path != p_path:
+                m_ckpt, p_ckpt = load(ckpt_file(m_path)), load(ckpt_file(p_path))
+                return _merge(m_ckpt, p_ckpt)         # utils.merge(source=m, destination=p): m's entries win
+            raise ValueError("Cannot resume a P+M model with provided load_paths:\n{}".format(o.load_paths))
+        if str(m_path) != "none" and str(p_path) != "none":
+            raise ValueError("Opts tasks are {} but received 2 values for the load_paths".format(o.tasks))
+        if str(m_path) != "none":
+            if "m" not in o.tasks:
+                raise AssertionError("load_paths.m given but 'm' is not in opts.tasks")
+            path = ckpt_file(m_path) if m_path.is_dir() else m_path
+            if not m_path.exists():
+                raise AssertionError("checkpoint path %s does not exist" % m_path)
+            return load(path)
+        if str(p_path) != "none":
+            if "p" not in o.tasks:
+                raise AssertionError("load_paths.p given but 'p' is not in opts.tasks")
+            if not p_path.exists():
+                raise AssertionError("checkpoint path %s does not exist" % p_path)
+            return load(p_path / "checkpoints/latest_ckpt.pth" if p_path.is_dir() else p_path)
+        return load(output_path / "checkpoints/latest_ckpt.pth")
+
+    def resume(self, inference=False):
+        """reference trainer.py:422-579: load G (``strict=False`` with warnings in inference mode, then stop), g_opt,
+        replay the schedulers ``epoch + 1`` times, D and d_opt, epoch / step, and round the step up to an even number
+        (extragradient: extrapolation happens on even steps)."""
+        checkpoint = self._resolve_checkpoint()
+        if inference:
+            bad = self.G.load_state_dict(checkpoint["G"], strict=False)
+            if bad.missing_keys:
+                print("WARNING: Missing keys in self.G.load_state_dict, keeping inits")
+                print(bad.missing_keys)
+            if bad.unexpected_keys:
+                print("WARNING: Ignoring Unexpected keys in self.G.load_state_dict")
+                print(bad.unexpected_keys)
+            return
+        self.G.load_state_dict(checkpoint["G"])
+        self.g_opt.load_state_dict(checkpoint["g_opt"])
+        for _ in range(self.epoch + 1):              # trainer.py:557-558 (self.logger.epoch is still the pre-resume value)
+            self.update_learning_rates()
+        if self.D is not None and sum(p.numel() for p in self.D.parameters()) > 0:
+            self.D.load_state_dict(checkpoint["D"])
+            self.d_opt.load_state_dict(checkpoint["d_opt"])
+        self.epoch = checkpoint["epoch"]
+        self.global_step = checkpoint["step"]
+        if self.global_step % 2 != 0:
+            self.global_step += 1
 
     # ------------------------------------------------------------------------------------------ events
     def compute_flood(self, x, z=None, z_depth=None, m=None, s=None, cloudy=None, bin_value=-1):

@@ -69,8 +69,7 @@ def test_training_mode_batchnorm_uses_batch_statistics():
         G.train()
         z_train = G.encode(x)
     assert not torch.equal(before, bn.running_mean)
-    ze = z_eval.t if hasattr(z_eval, "t") else z_eval
-    zt = z_train.t if hasattr(z_train, "t") else z_train
+    ze, zt = z_eval[0].t, z_train[0].t           # (z_high, z_low) NHWC containers
     assert torch.isfinite(zt.float()).all() and not torch.equal(ze, zt)
     G.eval()
     for p_ in G.encoder.parameters():

@@ -87,3 +87,70 @@ def test_infer_state_dict_layout_matches_reference_trainer():
     case = golden_cases()["infer_small"]
     _, shapes = reference_trainer(case)
     assert shapes == infer_shapes(case)
+
+
+def test_reference_resume_reads_a_checkpoint_saved_by_the_mirror(tmp_path):
+    """The other direction of tests/test_checkpoint.py: ``climategan_amd.Trainer.save`` writes, the reference's own
+    ``Trainer.resume`` (trainer.py:422-579) reads -- strict G / D loads, optimizer state accepted, counters restored."""
+    import contextlib
+    import io
+    from types import SimpleNamespace
+
+    from oracle.make_golden_ckpt import build, small_opts
+    from test_checkpoint import FIX, make_trainer
+
+    T = make_trainer(tmp_path)
+    with pytest.warns(UserWarning):
+        T._resolve_checkpoint = lambda: torch.load(FIX / "checkpoints" / "latest_ckpt.pth", weights_only=False)
+        T.resume()
+    T.epoch, T.global_step = 4, 22
+    T.save()
+    opts = small_opts(ref_shim.default_opts())
+    opts.output_path = str(tmp_path)
+    tr = ref_shim.ref("trainer")
+    G, D, g_opt, g_sched, d_opt, d_sched = build(ref_shim, opts)
+    ns = SimpleNamespace(opts=opts, device=torch.device("cpu"), logger=SimpleNamespace(epoch=0, global_step=0), G=G, D=D,
+                         g_opt=g_opt, d_opt=d_opt, g_scheduler=g_sched, d_scheduler=d_sched,
+                         exp=SimpleNamespace(log_text=lambda *a, **k: None))
+    ns.update_learning_rates = lambda: tr.Trainer.update_learning_rates(ns)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.Trainer.resume(ns)
+    assert ns.logger.epoch == 4 and ns.logger.global_step == 22
+    for mine, theirs in ((T.G, G), (T.D, D)):
+        a, b = mine.state_dict(), theirs.state_dict()
+        assert list(a) == list(b)
+        assert all(torch.equal(a[k], b[k]) for k in a)
+    params = [p for g in g_opt.param_groups for p in g["params"]]
+    mine = [p for g in T.g_opt.param_groups for p in g["params"]]
+    for i, p in enumerate(params):
+        if p.requires_grad:
+            assert torch.equal(g_opt.state[p]["exp_avg"], T.g_opt.state[mine[i]]["exp_avg"])
+            assert g_opt.state[p]["step"] == T.g_opt.state[mine[i]]["step"]
+
+
+def test_get_optimizer_groups_match_reference():
+    """Per-task learning rates (optim.py:82-108): same groups, same parameter order, same rates, same lr_names."""
+    import contextlib
+    import io
+
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+    from climategan_amd.optim import get_optimizer
+
+    ropts = ref_shim.default_opts()
+    ropts.tasks = ["m", "s", "d"]
+    ropts.gen.opt.lr = {"default": 5e-5, "m": 1e-4, "s": 2e-4}
+    with contextlib.redirect_stdout(io.StringIO()):
+        RG = ref_shim.ref("generator").create_generator(ropts, "cpu", no_init=True)
+    r_opt, r_sched, r_names = ref_shim.ref("optim").get_optimizer(RG, ropts.gen.opt, ropts.tasks)
+    o = default_opts()
+    o.tasks = ["m", "s", "d"]
+    o.gen.opt.lr = {"default": 5e-5, "m": 1e-4, "s": 2e-4}
+    G = create_generator(o, device="cpu", no_init=True)
+    opt, sched, names = get_optimizer(G, o.gen.opt, o.tasks)
+    assert names == r_names == ["encoder", "decoder_m", "decoder_s", "decoder_d"]
+    assert [g["lr"] for g in opt.param_groups] == [g["lr"] for g in r_opt.param_groups] == [1e-4, 1e-4, 2e-4, 5e-5]
+    assert [[tuple(p.shape) for p in g["params"]] for g in opt.param_groups] == \
+           [[tuple(p.shape) for p in g["params"]] for g in r_opt.param_groups]
+    assert type(sched).__name__ == type(r_sched).__name__ == "StepLR"
+    assert sched.step_size == r_sched.step_size and sched.gamma == r_sched.gamma
