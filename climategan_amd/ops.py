@@ -777,3 +777,51 @@ class SpectralNormGroup:
         _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(self.pk_table), self.n, _DT[self.dtype], self.max_frag,
                                                        _stream()), "cgan_conv2d_pack_weight_batched")
         return self.packed
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline
+def _gaussian_taps(sigma: float):
+    """scipy.ndimage's 1-D Gaussian taps for ``gaussian_filter(truncate=4)``: radius int(4 sigma + 0.5), weights
+    exp(-0.5 x^2 / sigma^2) normalised to sum 1 (float64, numpy)."""
+    import numpy as np
+
+    radius = int(4.0 * float(sigma) + 0.5)
+    if sigma <= 1e-15 or radius == 0:
+        return 0, None
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return radius, phi / phi.sum()
+
+
+def resize_crop_geometry(h: int, w: int, to: int):
+    """(rows, cols, top, left) of apply_events.resize_and_crop for an h x w image (apply_events.py:224-238)."""
+    lib = _lib.load()
+    r, c, t, l = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(lib.cgan_resize_crop_geometry(h, w, to, C.byref(r), C.byref(c), C.byref(t), C.byref(l)),
+               "cgan_resize_crop_geometry")
+    return r.value, c.value, t.value, l.value
+
+
+def resize_and_crop_u8(img: torch.Tensor, to: int = 640, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 HWC device image -> fp32 [3, to, to] in [-1, 1] = to_m1_p1(resize_and_crop(img, to))
+    (apply_events.py:179-195, 211-241).  ``out``: an existing [c, to, to] fp32 slot (e.g. one image of a batch)."""
+    _need_cuda(img, out)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] not in (1, 3, 4):
+        raise RuntimeError("resize_and_crop_u8: a uint8 [H, W, C] image is expected, got %s %s" % (img.dtype, tuple(img.shape)))
+    img = img.contiguous()
+    h, w, c = img.shape
+    rows, cols, _, _ = resize_crop_geometry(h, w, to)
+    taps = []
+    for scale in (h / rows, w / cols):                       # skimage: sigma = max(0, (factor - 1) / 2)
+        radius, wts = _gaussian_taps(max(0.0, (scale - 1.0) / 2.0))
+        taps.append((radius, None if wts is None else torch.from_numpy(wts).to(img.device)))
+    if out is None:
+        out = torch.empty((c, to, to), dtype=torch.float32, device=img.device)
+    elif out.shape != (c, to, to) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("resize_and_crop_u8: out must be a contiguous fp32 [%d, %d, %d] tensor" % (c, to, to))
+    lib = _lib.load()
+    ws_bytes = lib.cgan_resize_crop_u8_workspace_bytes(h, w, c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+    _lib.check(lib.cgan_resize_crop_u8(_ptr(img), h, w, c, to, _ptr(taps[0][1]), taps[0][0], _ptr(taps[1][1]),
+                                       taps[1][0], _ptr(out), _ptr(ws), ws_bytes, _stream()), "cgan_resize_crop_u8")
+    return out

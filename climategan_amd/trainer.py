@@ -552,6 +552,12 @@ class Trainer:
         return out.to(x.dtype)
 
     @torch.no_grad()
+    def _resize_input(self, x, size):
+        """F.interpolate(x, size, mode="bilinear") of an NCHW batch on the 16-bit NHWC representation -> fp32 NCHW."""
+        x16 = ops.resize_bilinear(ops.nchw_to_nhwc(x.float(), self.G.compute_dtype), size, align_corners=False)
+        return ops.nhwc_to_nchw(x16)
+
+    @torch.no_grad()
     def infer_all(self, x, numpy=True, stores={}, bin_value=-1, half=False, xla=False, cloudy=False,
                   auto_resize_640=False, ignore_event=set(), return_masks=False):
         """reference trainer.py:217-334.  ``half`` selects fp16 I/O tensors (the kernels compute in 16-bit either
@@ -567,10 +573,13 @@ class Trainer:
             x = x.permute(0, 3, 1, 2)
         if x.device != self.device:
             x = x.to(self.device)
-        if auto_resize_640 and (x.shape[-1] != 640 or x.shape[-2] != 640):
-            raise NotImplementedError("auto_resize_640: the input-side resize (SURVEY row N3) has no HIP path yet")
         x = x.half() if half else x.float()
         x = x.contiguous()
+        if auto_resize_640 and (x.shape[-1] != 640 or x.shape[-2] != 640):
+            # trainer.py:259-261: F.interpolate(x, (640, 640), mode="bilinear").  The Masker reads x as 16-bit NHWC
+            # anyway, so the resize runs on that representation (same kernel as the decoders' bilinear resizes).
+            x = self._resize_input(x, (640, 640))
+            x = x.half() if half else x.float()
 
         self.G.painter.set_latent_shape(x.shape, True)                                   # trainer.py:266
 

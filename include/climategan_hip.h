@@ -455,6 +455,21 @@ int cgan_wildfire_nchw(const float* x_nchw, const void* seg_nhwc, int32_t dtype,
                        float kernel_sigma, float transparency, int32_t crop_bottom, float filter_green, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Input pipeline of apply_events (apply_events.py:179-195 to_m1_p1, :211-241 resize_and_crop): uint8 HWC
+ * photo -> aspect-preserving resize (smaller side = `to`) -> centre crop `to` x `to` -> uint8 truncation -> [-1, 1] fp32
+ * CHW.  The resize is scikit-image 0.18.3 resize(img, size, preserve_range=True, anti_aliasing=True) (a dependency that is
+ * NOT in the reference tree): float64 Gaussian pre-filter (sigma = max(0, (scale - 1) / 2) per axis, truncate 4, mirror
+ * border) + bilinear warp with pixel-centre alignment, restated from that library's published algorithm.
+ *  - cgan_resize_crop_geometry: resized extent (rows, cols) and crop origin (top, left) for an h x w input (host only);
+ *  - weights_rows / weights_cols: the normalised 1-D Gaussian taps [2 radius + 1] (fp64, device) the caller computes
+ *    as scipy does (exp(-0.5 x^2 / sigma^2) / sum, radius = int(4 sigma + 0.5)); radius 0 = no filter on that axis;
+ *  - out_chw: fp32 [c][to][to]; workspace cgan_resize_crop_u8_workspace_bytes(h, w, c). */
+int cgan_resize_crop_geometry(int32_t h, int32_t w, int32_t to, int32_t* rows, int32_t* cols, int32_t* top, int32_t* left);
+size_t cgan_resize_crop_u8_workspace_bytes(int32_t h, int32_t w, int32_t c);
+int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int32_t to, const double* weights_rows,
+                        int32_t radius_rows, const double* weights_cols, int32_t radius_cols, float* out_chw,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -665,3 +665,60 @@ def add_fire(x, seg_preds, filter_green: float, kernel_size=281, kernel_sigma=14
     w_t[:, :, 0, 0] = 255.0
     w_t[:, :, -1, -1] = 0.0
     return w_t
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline (N3)
+def skimage_resize_018(image, output_shape):
+    """RESTATEMENT of scikit-image 0.18.3 ``skimage.transform.resize(image, output_shape, preserve_range=True,
+    anti_aliasing=True)`` for an [H, W, C] image and a (rows, cols) shape (order 1, mode 'reflect', clip True) --
+    **parity unpinned**: scikit-image (requirements-3.8.2.txt:69) is a third-party dependency that is neither in
+    /root/reference nor installed here, so this follows the library's published source (transform/_warps.py: resize,
+    warp; _shared/interpolation.pxd: bilinear_interpolation, coord_map) and is anchored only on the reference's call site
+    apply_events.py:230.  The Gaussian pre-filter IS the library's own call (scipy.ndimage.gaussian_filter, installed).
+    The one deliberate deviation: skimage estimates the scale / offset of the warp with a least-squares AffineTransform
+    (last-ulp jitter on the sampling coordinates); the closed form is used here."""
+    import numpy as np
+    from scipy import ndimage as ndi
+
+    image = np.asarray(image).astype(np.float64)                        # convert_to_float(image, preserve_range=True)
+    rows, cols = output_shape
+    h, w = image.shape[:2]
+    factors = np.array([h / rows, w / cols, 1.0])
+    sigma = np.maximum(0, (factors - 1) / 2)
+    image = ndi.gaussian_filter(image, sigma, cval=0, mode="mirror")    # _to_ndimage_mode("reflect") == "mirror"
+    r = factors[0] * (np.arange(rows) + 0.5) - 0.5                      # pixel 0 sits at (0.5, 0.5)
+    c = factors[1] * (np.arange(cols) + 0.5) - 0.5
+
+    def mirror(i, n):                                                   # coord_map mode 'R'
+        i = np.where(i < 0, -i, i)
+        return np.where(i >= n, 2 * (n - 1) - i, i)
+
+    minr, maxr = np.floor(r).astype(int), np.ceil(r).astype(int)
+    minc, maxc = np.floor(c).astype(int), np.ceil(c).astype(int)
+    dr, dc = (r - minr)[:, None, None], (c - minc)[None, :, None]
+    r0, r1, c0, c1 = mirror(minr, h), mirror(maxr, h), mirror(minc, w), mirror(maxc, w)
+    top = (1 - dc) * image[r0][:, c0] + dc * image[r0][:, c1]
+    bottom = (1 - dc) * image[r1][:, c0] + dc * image[r1][:, c1]
+    out = (1 - dr) * top + dr * bottom
+    return np.clip(out, image.min(), image.max())                       # clip=True
+
+
+def resize_and_crop(img, to=640):
+    """apply_events.py:211-241: aspect-preserving resize (smaller side = ``to``), uint8 truncation, centre crop, / 255."""
+    import numpy as np
+
+    h, w = img.shape[:2]
+    size = (to, int(to * w / h)) if h < w else (int(to * h / w), to)
+    r_img = skimage_resize_018(img, size).astype(np.uint8)
+    H, W = r_img.shape[:2]
+    top, left = (H - to) // 2, (W - to) // 2
+    return r_img[top:top + to, left:left + to, :] / 255.0
+
+
+def to_m1_p1(img):
+    """apply_events.py:179-195"""
+    import numpy as np
+
+    if img.min() >= 0 and img.max() <= 1:
+        return (img.astype(np.float32) - 0.5) * 2
+    raise ValueError("Data range mismatch for image : ({}, {})".format(img.min(), img.max()))

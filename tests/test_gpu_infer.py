@@ -223,3 +223,18 @@ def test_paint_cloudy_matches_reference_golden():
     assert (err > 2 * 0.008357).mean() <= 2e-3 and err.max() <= 0.3, stats
     outside = (gold["m_bin"] == 0).repeat(3, axis=1)
     assert np.array_equal(flood.cpu().numpy()[outside], case_inputs(name, case)["x"][outside])   # pasted on the ORIGINAL x
+
+
+def test_auto_resize_640_step():
+    """infer_all(auto_resize_640=True) resizes with F.interpolate(x, (640, 640), mode="bilinear") (trainer.py:259-261);
+    here on the 16-bit representation the Masker reads anyway: within fp16 rounding of the fp32 resize."""
+    import torch.nn.functional as F
+    from climategan_amd import fill
+
+    case = golden_cases()[NAME]
+    T = build_trainer(case)
+    x = torch.from_numpy(fill.uniform((2, 3, 200, 330), 9)).cuda()
+    got = T._resize_input(x, (640, 640))
+    ref = F.interpolate(x.half().float(), (640, 640), mode="bilinear")
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert (got - ref).abs().max().item() <= 2e-3
