@@ -139,3 +139,72 @@ extern "C" int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w,
   CGAN_CHECK_LAUNCH("resize_crop_u8");
   return CGAN_OK;
 }
+
+// ---- validation metrics (climategan/eval_metrics.py:67-130 accuracy, mIOU): per-class counts of argmax(pred) ----------
+namespace {
+
+constexpr int METRIC_MAX_C = 64;
+
+// counts[0][k] = #pixels predicted k, counts[1][k] = #pixels labelled k, counts[2][k] = #pixels both
+template <typename T>
+__global__ __launch_bounds__(256) void seg_counts_kernel(const void* __restrict__ pred, int layout, long hw, long npix,
+                                                         int c, int cs, const float* __restrict__ labels,
+                                                         unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int hist[3][METRIC_MAX_C];
+  for (int i = threadIdx.x; i < 3 * METRIC_MAX_C; i += 256) (&hist[0][0])[i] = 0u;
+  __syncthreads();
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    int best = 0;
+    float bv;
+    if (layout == 0) {                       // NHWC 16-bit, cs storage channels
+      const uint16_t* row = reinterpret_cast<const uint16_t*>(pred) + p * cs;
+      bv = f32_of_bits<T>(row[0]);
+      for (int k = 1; k < c; ++k) {
+        const float v = f32_of_bits<T>(row[k]);
+        if (v > bv) { bv = v; best = k; }    // first maximum wins, as torch.argmax / np.argmax
+      }
+    } else {                                 // NCHW fp32
+      const long n = p / hw, r = p - n * hw;
+      const float* base = reinterpret_cast<const float*>(pred) + n * c * hw + r;
+      bv = base[0];
+      for (int k = 1; k < c; ++k) {
+        const float v = base[(long)k * hw];
+        if (v > bv) { bv = v; best = k; }
+      }
+    }
+    const float lab = labels[p];
+    atomicAdd(&hist[0][best], 1u);
+    const int li = (int)lab;
+    if (lab >= 0.f && lab < (float)c && (float)li == lab) {
+      atomicAdd(&hist[1][li], 1u);
+      if (li == best) atomicAdd(&hist[2][best], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * c; i += 256) {
+    const unsigned int v = hist[i / c][i % c];
+    if (v) atomicAdd(counts + i, (unsigned long long)v);
+  }
+}
+
+}  // namespace
+
+extern "C" int cgan_seg_counts(const void* pred, int32_t layout, int32_t dtype, int32_t n, int64_t hw, int32_t c,
+                               const float* labels, unsigned long long* counts, void* stream) {
+  CGAN_REQUIRE(pred && labels && counts, "seg_counts: null pointer");
+  CGAN_REQUIRE(layout == 0 || layout == 1, "seg_counts: layout must be 0 (NHWC 16-bit) or 1 (NCHW fp32)");
+  CGAN_REQUIRE(layout == 1 || dtype == CGAN_F16 || dtype == CGAN_BF16, "seg_counts: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && hw > 0 && c > 0 && c <= METRIC_MAX_C, "seg_counts: bad shape (at most %d classes)", METRIC_MAX_C);
+  const long npix = (long)n * hw;
+  long blocks = (npix + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipStream_t s = (hipStream_t)stream;
+  if (layout == 0 && dtype == CGAN_BF16)
+    hipLaunchKernelGGL(seg_counts_kernel<BF16>, dim3((unsigned)blocks), dim3(256), 0, s, pred, layout, (long)hw, npix, c,
+                       cgan_cs(c), labels, counts);
+  else
+    hipLaunchKernelGGL(seg_counts_kernel<F16>, dim3((unsigned)blocks), dim3(256), 0, s, pred, layout, (long)hw, npix, c,
+                       cgan_cs(c), labels, counts);
+  CGAN_CHECK_LAUNCH("seg_counts");
+  return CGAN_OK;
+}

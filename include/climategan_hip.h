@@ -470,6 +470,15 @@ int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c,
                         int32_t radius_rows, const double* weights_cols, int32_t radius_cols, float* out_chw,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Validation metrics (climategan/eval_metrics.py:67-130 accuracy, mIOU; used by Trainer.eval_images, trainer.py:1706-1790):
+ * per-class pixel counts of argmax_c(pred) against a label map.  pred: layout 0 = NHWC 16-bit [n][hw][cgan_cs(c)],
+ * layout 1 = NCHW fp32 [n][c][hw]; labels fp32 [n][hw] (class ids as floats; anything that is not an integer in [0, c)
+ * counts for no class, like the reference's ignore index).  counts u64 [3][c] ACCUMULATED (zero first):
+ * [0][k] pixels predicted k, [1][k] pixels labelled k, [2][k] both.  accuracy = sum_k [2][k] / (n hw);
+ * IoU_k = [2][k] / ([0][k] + [1][k] - [2][k]).  First maximum wins on ties (np.argmax / torch.argmax). */
+int cgan_seg_counts(const void* pred, int32_t layout, int32_t dtype, int32_t n, int64_t hw, int32_t c,
+                    const float* labels, unsigned long long* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
