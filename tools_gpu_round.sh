@@ -12,6 +12,8 @@ TAG=${1:-r01}
 (timeout 600 python tools/bench_infer.py 2>&1 | tail -1) > gpurun_out/bench_infer.log 2>&1
 (timeout 600 python tools/bench_train.py 2>&1 | tail -1) > gpurun_out/bench_train.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_train -o ${TAG}_train -- python tools/bench_train.py --steps 2 --warmup 1 2>&1 | tail -1) > gpurun_out/rocprof_train.log 2>&1
+(timeout 600 python tools/bench_train.py --tasks dsmp --bs 4 --steps 4 --warmup 2 2>&1 | tail -1) > gpurun_out/bench_train_joint.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_joint -o ${TAG}_joint -- python tools/bench_train.py --tasks dsmp --bs 4 --steps 2 --warmup 1 2>&1 | tail -1) > gpurun_out/rocprof_joint.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_infer -o ${TAG}_infer -- python tools/bench_infer.py --steps 3 --warmup 1 2>&1 | tail -1) > gpurun_out/rocprof_infer.log 2>&1
-for f in pytest_gpu smoke bench rocprof bench_infer bench_train; do echo "=== $f"; tail -n 4 gpurun_out/$f.log | cut -c1-600; done
+for f in pytest_gpu smoke bench rocprof bench_infer bench_train bench_train_joint; do echo "=== $f"; tail -n 4 gpurun_out/$f.log | cut -c1-600; done
 ls gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_train gpurun_out/prof_${TAG}_infer
