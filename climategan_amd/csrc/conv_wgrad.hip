@@ -28,6 +28,7 @@ struct WgradArgs {
   int kh, kw, stride, pad, dil;
   int h_out, w_out, npix;
   int nchunks, ci_blocks, co_blocks, splits, per_xcd;
+  int fold, cpt, tpt, tap_slots;   // tap folding for cin_s <= 32 (see wgrad_plan): 16-byte chunks per tap, taps per 64-wide tile, tap groups
   int dbg;     // debug ablation bits (tools/bench_wgrad.py): 1 = skip the atomics, 2 = skip the MFMAs
   int reflect; // 1: nn.ReflectionPad2d(pad) in front of the conv (index math instead of the zero page)
   int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
@@ -52,6 +53,22 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* slab, int tile, in
   return r;
 }
 
+// Column `col` (0..63) of the N tile (tap slot `slot`, ci block `cib`) -> (tap, ci).  Normal layout: one tap per slot,
+// 64 consecutive input channels.  Folded layout (cin_s <= 32): a tile row holds `tpt` taps x `cpt` 16-byte channel chunks,
+// so a 3-channel 3x3 conv needs 2 tiles per co block instead of 9 that are 7/8 zero padding.
+__device__ __forceinline__ bool wgrad_column(int fold, int cpt, int tpt, int taps, int cin, int slot, int cib, int col,
+                                             int& tap, int& ci) {
+  if (!fold) {
+    tap = slot;
+    ci = cib * 64 + col;
+    return ci < cin;
+  }
+  const int q = col >> 3, tl = q / cpt;
+  tap = slot * tpt + tl;
+  ci = (q - tl * cpt) * 8 + (col & 7);
+  return tl < tpt && tap < taps && ci < cin;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -62,21 +79,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   // together on one XCD and walk the same chunks: their x / dy slabs are L2 hits instead of HBM re-reads.
   const int taps_n = p.kh * p.kw;
   int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
-  const int tiles_n = taps_n * p.ci_blocks * p.co_blocks;
+  const int tiles_n = p.tap_slots * p.ci_blocks * p.co_blocks;
   if ((int)(blockIdx.x >> 3) >= p.per_xcd || item >= tiles_n * p.splits) return;
   const int cob = item % p.co_blocks;
   item /= p.co_blocks;
-  const int tap = item % taps_n;
-  item /= taps_n;
+  const int slot = item % p.tap_slots;    // tap (normal layout) or group of tpt taps (folded layout)
+  item /= p.tap_slots;
   const int cib = item % p.ci_blocks;
   const int split = item / p.ci_blocks;
-  const int ky = tap / p.kw, kx = tap - ky * p.kw;
-  const int co0 = cob * 64, ci0 = cib * 64;
+  const int co0 = cob * 64;
   unsigned char* wl = smem + wave * WAVE_LDS;
 
   const int prow = lane >> 3;          // pixel within an 8-pixel DMA piece
   const int q8 = (lane & 7) * 8;       // first channel of this lane's 16-byte chunk
-  const bool co_ok = co0 + q8 < p.cout_s, ci_ok = ci0 + q8 < p.cin_s;
+  const bool co_ok = co0 + q8 < p.cout_s;
+  // this lane's 16-byte chunk of an x row: (tap, first channel)
+  int ky, kx, cch;
+  bool ci_ok;
+  if (p.fold) {
+    const int q = lane & 7, tl = q / p.cpt;
+    const int tap_l = slot * p.tpt + tl;
+    ci_ok = tl < p.tpt && tap_l < taps_n;
+    const int tcl = ci_ok ? tap_l : 0;
+    ky = tcl / p.kw;
+    kx = tcl - ky * p.kw;
+    cch = (q - tl * p.cpt) * 8;
+  } else {
+    ky = slot / p.kw;
+    kx = slot - ky * p.kw;
+    cch = cib * 64 + q8;
+    ci_ok = cch < p.cin_s;
+  }
   const long zero_dy = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.dy);
   const long zero_x = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.x);
 
@@ -116,8 +149,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         ix = ix < 0 ? -ix : (ix >= p.w_in ? 2 * p.w_in - 2 - ix : ix);
       }
       const bool xv = pv && ci_ok && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
-      const long off_x = xv ? (p.x_ups ? ((((long)nn * (p.h_in >> 1) + (iy >> 1)) * (p.w_in >> 1) + (ix >> 1)) * p.cin_s + ci0 + q8) * 2
-                                       : ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + ci0 + q8) * 2)
+      const long off_x = xv ? (p.x_ups ? ((((long)nn * (p.h_in >> 1) + (iy >> 1)) * (p.w_in >> 1) + (ix >> 1)) * p.cin_s + cch) * 2
+                                       : ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + cch) * 2)
                             : zero_x;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.x) + off_x),
@@ -174,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int j = lane & 15, g = lane >> 4;
   f32x4* wst = nullptr;
   if (p.ws) {
-    const int tile = (tap * p.ci_blocks + cib) * p.co_blocks + cob;
+    const int tile = (slot * p.ci_blocks + cib) * p.co_blocks + cob;
     wst = reinterpret_cast<f32x4*>(p.ws) + ((size_t)split * tiles_n + tile) * 1024;
   }
 #pragma unroll
@@ -190,11 +223,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       wst[(a * 4 + b) * 64 + lane] = s;   // fragment order: 16 B per lane, coalesced
       continue;
     }
-    const int ci = ci0 + b * 16 + j;
+    int tap, ci;
+    const bool col_ok = wgrad_column(p.fold, p.cpt, p.tpt, taps_n, p.cin, slot, cib, b * 16 + j, tap, ci);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = co0 + a * 16 + 4 * g + r;
-      if (co < p.cout && ci < p.cin && !(p.dbg & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, s[r]);
+      if (co < p.cout && col_ok && !(p.dbg & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, s[r]);
     }
   }
 }
@@ -203,9 +237,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 // tile; blockIdx.y strides the splits (G groups) so small-channel layers with hundreds of splits still fill the chip;
 // G > 1 finishes with (at most G-way contended) atomics, G == 1 with a plain read-modify-write.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw,
-                                                           int splits, int taps, int ci_blocks, int co_blocks,
-                                                           int cout, int cin) {
-  const int tiles_n = taps * ci_blocks * co_blocks;
+                                                           int splits, int taps, int tap_slots, int ci_blocks,
+                                                           int co_blocks, int cout, int cin, int fold, int cpt,
+                                                           int tpt) {
+  const int tiles_n = tap_slots * ci_blocks * co_blocks;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= tiles_n * 1024) return;
   f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -217,9 +252,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
   const int frag = (e >> 6) & 15, lane = e & 63;
   const int cob = tile % co_blocks;
   tile /= co_blocks;
-  const int cib = tile % ci_blocks, tap = tile / ci_blocks;
-  const int ci = cib * 64 + (frag & 3) * 16 + (lane & 15);
-  if (ci >= cin) return;
+  const int cib = tile % ci_blocks, slot = tile / ci_blocks;
+  int tap, ci;
+  if (!wgrad_column(fold, cpt, tpt, taps, cin, slot, cib, (frag & 3) * 16 + (lane & 15), tap, ci)) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = cob * 64 + (frag >> 2) * 16 + 4 * (lane >> 4) + r;
@@ -271,23 +306,40 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
   g_wgrad_dbg = dbg;
 }
 
-static int wgrad_splits(const CganConvDesc* d) {
+// Tiling of one weight-gradient call: N tiles (tap slots x ci blocks), M tiles (co blocks), pixel splits.
+struct WgradPlan {
+  int fold, cpt, tpt, tap_slots, ci_blocks, co_blocks, splits;
+  long tiles() const { return (long)tap_slots * ci_blocks * co_blocks; }
+};
+
+static WgradPlan wgrad_plan(const CganConvDesc* d) {
+  WgradPlan pl;
+  const int taps = d->kh * d->kw, cin_s = cgan_cs(d->c_in);
+  pl.co_blocks = ceil_div(cgan_cs(d->c_out), 64);
+  // cin_s <= 32 with several taps: fold taps into the 64-wide N tile (cpt 16-byte channel chunks per tap, tpt taps per
+  // tile) instead of padding every tap's few channels to 64
+  pl.fold = (cin_s <= 32 && taps > 1 && g_wgrad_dbg != 4) ? 1 : 0;
+  pl.cpt = pl.fold ? cin_s / 8 : 8;
+  pl.tpt = pl.fold ? 8 / pl.cpt : 1;
+  pl.tap_slots = pl.fold ? ceil_div(taps, pl.tpt) : taps;
+  pl.ci_blocks = pl.fold ? 1 : ceil_div(cin_s, 64);
   const long npix = (long)d->n * d->h_out * d->w_out;
   const int nchunks = (int)((npix + 127) / 128);
-  const int tiles = d->kh * d->kw * ceil_div(cgan_cs(d->c_in), 64) * ceil_div(cgan_cs(d->c_out), 64);
+  const long tiles = pl.tiles();
   // ~4 workgroups per CU for layers with many (tap, channel block) tiles or very long pixel ranges, ~2 otherwise
   // (measured per layer shape with tools/bench_wgrad.py: the partial-tile workspace traffic grows with the splits)
   const int target = g_wgrad_target > 0 ? g_wgrad_target : ((tiles >= 512 || tiles <= 16) ? 2048 : 1024);
-  int splits = ceil_div(target, tiles);
+  long splits = (target + tiles - 1) / tiles;
   if (splits > nchunks) splits = nchunks;
-  return splits < 1 ? 1 : splits;
+  pl.splits = splits < 1 ? 1 : (int)splits;
+  return pl;
 }
 
 extern "C" size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* d) {
   if (!d || d->n <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->kh <= 0 || d->kw <= 0)
     return 0;
-  const size_t tiles = (size_t)d->kh * d->kw * ceil_div(cgan_cs(d->c_in), 64) * ceil_div(cgan_cs(d->c_out), 64);
-  return tiles * (size_t)wgrad_splits(d) * 64 * 64 * sizeof(float);
+  const WgradPlan pl = wgrad_plan(d);
+  return (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64 * sizeof(float);
 }
 
 extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias,
@@ -318,13 +370,12 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   a.x_ups = d->in_upsample;
   a.reflect = d->pad_mode == CGAN_PAD_REFLECT;
   a.nchunks = ceil_div(a.npix, 128);
-  a.ci_blocks = ceil_div(a.cin_s, 64);
-  a.co_blocks = ceil_div(a.cout_s, 64);
-  const int blocks = a.co_blocks * a.ci_blocks;
+  const WgradPlan pl = wgrad_plan(d);
+  a.ci_blocks = pl.ci_blocks; a.co_blocks = pl.co_blocks; a.splits = pl.splits;
+  a.fold = pl.fold; a.cpt = pl.cpt; a.tpt = pl.tpt; a.tap_slots = pl.tap_slots;
   const int taps = d->kh * d->kw;
   a.dbg = g_wgrad_dbg;
-  a.splits = wgrad_splits(d);
-  const long items = (long)a.splits * taps * blocks;
+  const long items = (long)a.splits * pl.tiles();
   a.per_xcd = (int)((items + 7) / 8);
   CGAN_REQUIRE(items < (1L << 30), "conv2d_nhwc_bwd_weight: grid too large");
   const unsigned gx = (unsigned)a.per_xcd * 8;
@@ -342,11 +393,12 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(gx), dim3(256), smem, s, a);
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
   if (a.ws) {
-    const int elems = taps * blocks * 1024;
+    const int elems = (int)pl.tiles() * 1024;
     int groups = a.splits / 8;
     groups = groups < 1 ? 1 : (groups > 16 ? 16 : groups);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(elems, 256), groups), dim3(256), 0, s,
-                       (const f32x4*)a.ws, a.dw, a.splits, taps, a.ci_blocks, a.co_blocks, a.cout, a.cin);
+                       (const f32x4*)a.ws, a.dw, a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold,
+                       a.cpt, a.tpt);
     CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(reduce)");
   }
   if (dbias) {
