@@ -243,6 +243,9 @@ def result_line(world, steps, warmup, elapsed, dtype_name):
 TRAIN_BS = 4   # per domain per GPU: BASELINE configs[3] is global batch 32 over 8 GPUs
 
 
+TRAIN_BLOCK_TIMEOUT_S = 420     # watchdog of the supplementary block (see main)
+
+
 def train_block(train_steps, rank, world, device, dtype, dist, barrier):
     """Supplementary measurement (not `value`): BASELINE's "G+D step" -- the full joint Masker + Painter training
     iteration of the default config (Trainer.train_step = update_G over the real, sim and flooded domains: ResNet-101
@@ -350,13 +353,10 @@ def main():
     assert y.shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(y).all()
     elapsed = max_over_ranks(elapsed, dist, device)
 
-    train = None
-    if args.train_steps > 0:
-        try:
-            train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier)
-        except Exception as e:  # the main line must survive a failure of the supplementary block
-            train = {"error": "%s: %s" % (type(e).__name__, e)}
-
+    # ---- the result line is complete before the supplementary block starts, so that nothing in that block (first
+    # RCCL use of the training path on a multi-GPU node, a hung collective, an exception on one rank) can take the
+    # headline measurement down with it: a watchdog prints the line and ends the process if the block overruns.
+    res = None
     if rank == 0:
         layers, flops_img = spade_layer_table(LATENT, N_UP, H, W)
         spade_ms = timer.total_ms()
@@ -386,15 +386,34 @@ def main():
                 "share_of_step": round(spade_ms / (elapsed * 1e3), 3),
             },
         })
-        res["train_step"] = train
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd)
-        else:
-            res["cpu_baseline"] = None
-        print(json.dumps(res))
+        res["cpu_baseline"] = cpu_baseline(sd) if (world == 1 and not args.no_cpu_baseline) else None
+
+    import threading
+    emitted = threading.Lock()
+    finished = threading.Event()
+
+    def emit(train):
+        if rank == 0 and emitted.acquire(blocking=False):
+            res["train_step"] = train
+            print(json.dumps(res), flush=True)
+
+    def watchdog():
+        if not finished.wait(TRAIN_BLOCK_TIMEOUT_S):
+            emit({"error": "supplementary train block did not finish within %d s" % TRAIN_BLOCK_TIMEOUT_S})
+            os._exit(0)
+
+    train = None
+    if args.train_steps > 0:
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier)
+        except Exception as e:  # the main line must survive a failure of the supplementary block
+            train = {"error": "%s: %s" % (type(e).__name__, e)}
+    emit(train)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    finished.set()
 
 
 if __name__ == "__main__":

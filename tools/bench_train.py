@@ -70,6 +70,70 @@ def wgrad_table(T, batch):
             t, cnt, ms, tf, n, h, w, ws, stride, pad, dil, wb, ups, pm))
 
 
+def conv_table(T, batch):
+    """Record every ops.conv2d (forward) and ops.conv2d_bwd_data call of one train step, time each unique shape alone."""
+    from collections import Counter
+    from climategan_amd import ops
+    calls = Counter()
+    o_fwd, o_dg = ops.conv2d, ops.conv2d_bwd_data
+
+    def rec_fwd(x, pw, stride=1, pad=0, dilation=1, pad_mode=ops.PAD_ZERO, act=ops.ACT_NONE, slope=0.2, residual=None,
+                in_upsample=False, residual_upsample=False):
+        calls[("fwd", x.n, x.h, x.w, pw.c_in, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode, bool(in_upsample),
+               residual is not None, str(x.t.dtype))] += 1
+        return o_fwd(x, pw, stride, pad, dilation, pad_mode, act, slope, residual, in_upsample, residual_upsample)
+
+    def rec_dg(dy, w, x_shape, stride=1, pad=0, dilation=1, sigma=None, pad_mode=ops.PAD_ZERO):
+        if not (pad_mode == ops.PAD_REFLECT and pad > 0):
+            co, ci, kh, kw = w.shape
+            calls[("dgrad", x_shape[0], x_shape[1], x_shape[2], ci, co, kh, kw, stride, pad, dilation, 0, False, False,
+                   str(dy.t.dtype))] += 1
+        return o_dg(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode)
+
+    ops.conv2d, ops.conv2d_bwd_data = rec_fwd, rec_dg
+    import climategan_amd.norms as norms_mod
+    import climategan_amd.autograd as ag_mod
+    try:
+        T.train_step(batch)
+    finally:
+        ops.conv2d, ops.conv2d_bwd_data = o_fwd, o_dg
+    torch.cuda.synchronize()
+    rows = []
+    for key, cnt in calls.items():
+        kind, n, h, w, ci, co, kh, kw, stride, pad, dil, pm, ups, res, dts = key
+        dt = torch.bfloat16 if "bfloat16" in dts else torch.float16
+        hi, wi = (h * 2, w * 2) if ups else (h, w)
+        ho = (hi + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (wi + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        wt = torch.randn(co, ci, kh, kw, device="cuda") * 0.02
+        if kind == "fwd":
+            x = ops.NHWC(torch.randn(n, h, w, ops.cs8(ci), device="cuda").to(dt), ci)
+            pw = ops.pack_conv_weight(wt, None, dt)
+            r = ops.NHWC(torch.randn(n, ho, wo, ops.cs8(co), device="cuda").to(dt), co) if res else None
+            fn = lambda: o_fwd(x, pw, stride, pad, dil, pm, ops.ACT_NONE, 0.2, r, ups, False)
+        else:
+            dy = ops.NHWC(torch.randn(n, ho, wo, ops.cs8(co), device="cuda").to(dt), co)
+            fn = lambda: o_dg(dy, wt, (n, h, w), stride, pad, dil)
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        fl = 2.0 * n * ho * wo * co * ci * kh * kw
+        rows.append((ms * cnt, cnt, ms, fl / ms / 1e9, key))
+    rows.sort(reverse=True)
+    print("conv calls of one step: %d calls, %d shapes, %.2f ms in isolation (dgrad rows include their weight pack)" % (
+        sum(calls.values()), len(rows), sum(r[0] for r in rows)))
+    for t, cnt, ms, tf, key in rows[:45]:
+        kind, n, h, w, ci, co, kh, kw, stride, pad, dil, pm, ups, res, dts = key
+        print("%7.2f ms  x%-3d %7.3f ms %6.1f TF  %-5s n%d %dx%d %d->%d k%dx%d s%d p%d d%d pm%d ups%d res%d" % (
+            t, cnt, ms, tf, kind, n, h, w, ci, co, kh, kw, stride, pad, dil, pm, ups, res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bs", type=int, default=8)
@@ -79,6 +143,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-vgg", action="store_true")
     ap.add_argument("--tasks", default="p", help="'p' (Painter step) or 'dsmp' (joint Masker + Painter step: domains r, s, rf)")
+    ap.add_argument("--conv-table", action="store_true", help="per-shape table of the forward / data-gradient conv calls of one step")
     ap.add_argument("--cprofile", action="store_true", help="host-side cProfile of one train step")
     ap.add_argument("--wgrad-table", action="store_true", help="per-shape table of the weight-gradient calls of one step")
     args = ap.parse_args()
@@ -111,6 +176,8 @@ def main():
     torch.cuda.synchronize()
     if args.wgrad_table:
         return wgrad_table(T, batch)
+    if args.conv_table:
+        return conv_table(T, batch)
     if args.cprofile:
         import cProfile
         import pstats
