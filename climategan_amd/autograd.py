@@ -191,7 +191,7 @@ class BatchNormActFn(torch.autograd.Function):
     momentum / unbiased variance as nn.BatchNorm2d).  gamma / beta may be None (affine=False)."""
 
     @staticmethod
-    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope):
+    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None):
         from . import _lib
         lib = _lib.load()
         n, h, w, cs = x_t.shape
@@ -202,7 +202,8 @@ class BatchNormActFn(torch.autograd.Function):
         rstd_f = torch.empty_like(rstd)
         _lib.check(lib.cgan_bn_train_prepare(
             ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma), ops._ptr(beta), float(eps), float(momentum), npix,
-            ops._ptr(running_mean), ops._ptr(running_var), ops._ptr(mean_f), ops._ptr(rstd_f), c, ops._stream()),
+            ops._ptr(running_mean), ops._ptr(running_var), ops._ptr(mean_f), ops._ptr(rstd_f), ops._ptr(nbt), c,
+            ops._stream()),
             "cgan_bn_train_prepare")
         out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope).t.view(n, h, w, cs)
         ctx.cfg = (c, act, slope)
@@ -219,13 +220,14 @@ class BatchNormActFn(torch.autograd.Function):
         nbytes = lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
         dx = torch.empty_like(x_t)
-        dg = torch.zeros(c, dtype=torch.float32, device=x_t.device) if gamma is not None else None
-        db = torch.zeros(c, dtype=torch.float32, device=x_t.device) if gamma is not None else None
+        dg = db = None
+        if gamma is not None:
+            dg, db = torch.zeros((2, c), dtype=torch.float32, device=x_t.device).unbind(0)   # one fill for both
         _lib.check(lib.cgan_batchnorm_act_bwd(
             ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t.contiguous()), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
             ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._DT[x_t.dtype], n * h * w, c, act, slope, ops._ptr(ws), nbytes,
             ops._stream()), "cgan_batchnorm_act_bwd")
-        return dx, dg, db, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None
 
 
 class BceLogitsFn(torch.autograd.Function):

@@ -215,8 +215,10 @@ __global__ void bn_train_prepare_kernel(const float* __restrict__ mean, const fl
                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                         float momentum, float count, float* __restrict__ running_mean,
                                         float* __restrict__ running_var, float* __restrict__ mean_out,
-                                        float* __restrict__ rstd_out, int c, int cs) {
+                                        float* __restrict__ rstd_out, long long* __restrict__ num_batches_tracked, int c,
+                                        int cs) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm2d's step counter
   if (ch >= cs) return;
   float m = 0.f, r = 0.f;
   if (ch < c) {
@@ -569,14 +571,15 @@ extern "C" int cgan_spade_bwd_prepare(const void* dy, const void* y, const void*
 
 extern "C" int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma,
                                      const float* beta, float eps, float momentum, int64_t count, float* running_mean,
-                                     float* running_var, float* mean_out, float* rstd_out, int32_t c, void* stream) {
+                                     float* running_var, float* mean_out, float* rstd_out,
+                                     int64_t* num_batches_tracked, int32_t c, void* stream) {
   CGAN_REQUIRE(batch_mean && batch_rstd && mean_out && rstd_out, "bn_train_prepare: null pointer");
   CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_prepare: running stats go together");
   CGAN_REQUIRE(c > 0 && count > 0, "bn_train_prepare: bad shape");
   const int cs = cgan_cs(c);
   hipLaunchKernelGGL(bn_train_prepare_kernel, dim3((cs + 255) / 256), dim3(256), 0, (hipStream_t)stream, batch_mean,
-                     batch_rstd, gamma, beta, eps, momentum, (float)count, running_mean, running_var, mean_out, rstd_out, c,
-                     cs);
+                     batch_rstd, gamma, beta, eps, momentum, (float)count, running_mean, running_var, mean_out, rstd_out,
+                     (long long*)num_batches_tracked, c, cs);
   CGAN_CHECK_LAUNCH("bn_train_prepare");
   return CGAN_OK;
 }

@@ -202,9 +202,7 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
     bn_act = act if residual is None else ops.ACT_NONE
     out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.running_mean,
                                  bn.running_var, y.c, bn.eps, bn.momentum if bn.momentum is not None else 0.1, bn_act,
-                                 slope)
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+                                 slope, bn.num_batches_tracked if bn.track_running_stats else None)   # counter += 1 in-kernel
     out = ops.NHWC(out_t, y.c)
     return out if residual is None else Fn.add_act(out, residual, act, slope)
 

@@ -472,6 +472,10 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
                    in_upsample=in_upsample)
     if (d.h_out, d.w_out) != (dy.h, dy.w) or dy.c != c_out or x.c != c_in or dy.n != x.n:
         raise RuntimeError("conv2d_bwd_weight: shapes do not match the forward conv")
+    if dw is None and want_bias and dbias is None:
+        nw = c_out * c_in * kh * kw                      # one zero fill for both gradients
+        flat = torch.zeros(nw + c_out, dtype=torch.float32, device=x.t.device)
+        dw, dbias = flat[:nw].view(c_out, c_in, kh, kw), flat[nw:]
     if dw is None:
         dw = torch.zeros((c_out, c_in, kh, kw), dtype=torch.float32, device=x.t.device)
     if want_bias and dbias is None:

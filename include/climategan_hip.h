@@ -290,12 +290,13 @@ int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const f
  * resnet101_v3.py:30-50, deeplab_v3.py:54-57, depth.py:56-114).  Batch statistics = cgan_instnorm_stats on the tensor
  * viewed as one image of n*h*w pixels; then
  *  bn_train_prepare   folds gamma / beta into the (mean', rstd') pair cgan_norm_act_apply consumes and updates the
- *                     running statistics (momentum, unbiased variance) as nn.BatchNorm2d does; count = n*h*w
+ *                     running statistics (momentum, unbiased variance) as nn.BatchNorm2d does; count = n*h*w;
+ *                     num_batches_tracked (device int64 scalar, may be NULL) is incremented by one
  *  batchnorm_act_bwd  given x (the BN input), out = act(bn(x)) and dy: dx, and dgamma / dbeta ACCUMULATED (fp32);
  *                     workspace cgan_batchnorm_act_bwd_workspace_bytes(c) */
 int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma, const float* beta,
                           float eps, float momentum, int64_t count, float* running_mean, float* running_var,
-                          float* mean_out, float* rstd_out, int32_t c, void* stream);
+                          float* mean_out, float* rstd_out, int64_t* num_batches_tracked, int32_t c, void* stream);
 size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);
 int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
                            const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,

@@ -304,7 +304,9 @@ def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
     g = bn.weight.detach().clone().cuda().requires_grad_(True) if affine else None
     b = bn.bias.detach().clone().cuda().requires_grad_(True) if affine else None
     rm, rv = rm0.cuda(), rv0.cuda()
-    out = BatchNormActFn.apply(xt, g, b, rm, rv, c, bn.eps, bn.momentum, a, 0.2)
+    nbt = torch.tensor(41, dtype=torch.int64, device="cuda")          # num_batches_tracked: += 1 per training forward
+    out = BatchNormActFn.apply(xt, g, b, rm, rv, c, bn.eps, bn.momentum, a, 0.2, nbt)
+    assert nbt.item() == 42 and bn.num_batches_tracked.item() == 1
     assert rel_err(back(ops.NHWC(out.detach(), c)), y.detach()) <= TOL[dt]
     assert rel_err(rm.cpu(), bn.running_mean) <= 1e-5 and rel_err(rv.cpu(), bn.running_var) <= 1e-5
     out.backward(to_nhwc(dy, dt).t)
