@@ -33,8 +33,25 @@ struct ConvParams {
   int kgroups, ksteps;
   int in_ups, act, has_res, res_ups;
   int in_zs;   // > 1: x is read through zero insertion (stride of the forward conv whose data gradient this is)
+  int cls_s;   // > 1: data gradient of a stride-cls_s conv by output parity classes (blockIdx.z), see cls_axis
+  int cls_pad; // pad' = k - 1 - pad of that data gradient
   float slope;
 };
+
+// Parity-class decomposition of the data gradient of a stride-s convolution (dilation 1).  dx[y] = sum over the
+// flipped taps ky' with (y - pad' + ky') divisible by s of dy[(y - pad' + ky') / s] w'[ky'].  All outputs y = a (mod s)
+// use the same taps ky' = r + s t, t < nt, and read dy at consecutive rows base + t: a dense stride-1 convolution with
+// nt taps per axis instead of a k-tap convolution over a zero-inserted map that is (s^2 - 1) / s^2 zeros.
+__host__ __device__ inline void cls_axis(int s, int k, int padp, int a, int& r, int& nt) {
+  r = ((padp - a) % s + s) % s;
+  nt = r < k ? (k - r + s - 1) / s : 0;
+}
+__host__ __device__ inline int cls_ksteps(int s, int kh, int kw, int padp, int cg, int cls) {
+  int r, nty, ntx;
+  cls_axis(s, kh, padp, cls / s, r, nty);
+  cls_axis(s, kw, padp, cls % s, r, ntx);
+  return (nty * ntx * cg + 3) / 4;
+}
 
 // K layout of the packed weights: k = tap * cin_p + c.  3x3 kernels pad the per-tap channel extent to a multiple
 // of 32 (one MFMA k-step never straddles a tap), which is what the LDS-tiled 3x3 kernel (conv3x3_lds.hip) needs;
@@ -57,21 +74,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   const int j = lane & 15;
   const int g = lane >> 4;
 
+  // ---- parity-class mode (strided data gradient): this workgroup's class, its taps and its block of the weights
+  int kw_eff = p.kw, ksteps = p.ksteps, kgroups = p.kgroups, npix = p.npix, wc = p.w_out, hc = p.h_out;
+  int ca = 0, cb = 0, ry = 0, rx = 0;
+  const u32x4* wbase = p.w;
+  if (p.cls_s) {
+    const int cs_ = p.cls_s, cls = blockIdx.z;
+    ca = cls / cs_;
+    cb = cls - ca * cs_;
+    int koff = 0;
+    for (int c = 0; c < cls; ++c) koff += cls_ksteps(cs_, p.kh, p.kw, p.cls_pad, p.cg, c);
+    int nty, ntx;
+    cls_axis(cs_, p.kh, p.cls_pad, ca, ry, nty);
+    cls_axis(cs_, p.kw, p.cls_pad, cb, rx, ntx);
+    kw_eff = ntx;
+    kgroups = nty * ntx * p.cg;
+    ksteps = (kgroups + 3) / 4;
+    wbase = p.w + (size_t)p.ctiles * koff * 64;
+    hc = p.h_out > ca ? (p.h_out - ca + cs_ - 1) / cs_ : 0;
+    wc = p.w_out > cb ? (p.w_out - cb + cs_ - 1) / cs_ : 0;
+    npix = p.n * hc * wc;
+  }
+
   // ---- per-lane pixel coordinates for the PT pixel tiles of this wave
-  int pn[PT], py0[PT], px0[PT];
+  int pn[PT], py0[PT], px0[PT], opix[PT];
   bool pvalid[PT];
   const int ptile0 = (blockIdx.x * 4 + wave) * PT;
+  if (ptile0 * 16 >= npix) return;
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
     int pix = (ptile0 + t) * 16 + j;
-    pvalid[t] = pix < p.npix;
+    pvalid[t] = pix < npix;
     int pc = pvalid[t] ? pix : 0;
-    int ox = pc % p.w_out;
-    int r = pc / p.w_out;
-    int oy = r % p.h_out;
-    pn[t] = r / p.h_out;
-    py0[t] = oy * p.stride - p.pad;
-    px0[t] = ox * p.stride - p.pad;
+    int ox = pc % wc;
+    int r = pc / wc;
+    int oy = r % hc;
+    pn[t] = r / hc;
+    if (p.cls_s) {
+      oy = oy * p.cls_s + ca;
+      ox = ox * p.cls_s + cb;
+      py0[t] = (oy - p.cls_pad + ry) / p.cls_s;     // exact: first dy row this output row reads
+      px0[t] = (ox - p.cls_pad + rx) / p.cls_s;
+      opix[t] = pvalid[t] ? (pn[t] * p.h_out + oy) * p.w_out + ox : -1;
+    } else {
+      py0[t] = oy * p.stride - p.pad;
+      px0[t] = ox * p.stride - p.pad;
+      opix[t] = pvalid[t] ? pix : -1;
+    }
   }
 
   f32x4 acc[CT][PT];
@@ -86,18 +135,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   int c8 = g, ky = 0, kx = 0;
   while (c8 >= p.cg) {
     c8 -= p.cg;
-    if (++kx == p.kw) { kx = 0; ++ky; }
+    if (++kx == kw_eff) { kx = 0; ++ky; }
   }
 
   // operand fetch of one k-step (A: packed weights [ctile][ks][lane] x 16 B; B: 8 channels of the tap-shifted
   // input pixel), then advance this lane's K group by 4
   auto fetch = [&](int ks, u32x4 (&a)[CT], u32x4 (&b)[PT]) {
-    const bool kvalid = (ks * 4 + g) < p.kgroups;
+    const bool kvalid = (ks * 4 + g) < kgroups;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       int ct = ctile0 + c;
       a[c] = (u32x4){0u, 0u, 0u, 0u};
-      if (ct < p.ctiles) a[c] = p.w[((size_t)ct * p.ksteps + ks) * 64 + lane];
+      if (ct < p.ctiles) a[c] = wbase[((size_t)ct * ksteps + ks) * 64 + lane];
     }
     const int dy = ky * p.dil, dx = kx * p.dil;
 #pragma unroll
@@ -125,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     c8 += 4;
     while (c8 >= p.cg) {
       c8 -= p.cg;
-      if (++kx == p.kw) { kx = 0; ++ky; }
+      if (++kx == kw_eff) { kx = 0; ++ky; }
     }
   };
   auto mma = [&](const u32x4 (&a)[CT], const u32x4 (&b)[PT]) {
@@ -141,17 +190,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     // come from L1/L2: ~500+ cycles, which a small grid cannot hide by occupancy alone; on large grids the extra
     // registers cost more occupancy than the pipelining buys, so those use the plain loop)
     u32x4 a0[CT], b0[PT], a1[CT], b1[PT];
-    fetch(0, a0, b0);
+    if (ksteps > 0) fetch(0, a0, b0);
     int ks = 0;
-    for (; ks + 2 <= p.ksteps; ks += 2) {
+    for (; ks + 2 <= ksteps; ks += 2) {
       fetch(ks + 1, a1, b1);
       mma(a0, b0);
-      if (ks + 2 < p.ksteps) fetch(ks + 2, a0, b0);
+      if (ks + 2 < ksteps) fetch(ks + 2, a0, b0);
       mma(a1, b1);
     }
-    if (ks < p.ksteps) mma(a0, b0);
+    if (ks < ksteps) mma(a0, b0);
   } else {
-    for (int ks = 0; ks < p.ksteps; ++ks) {
+    for (int ks = 0; ks < ksteps; ++ks) {
       u32x4 a[CT], b[PT];
       fetch(ks, a, b);
       mma(a, b);
@@ -161,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   // ---- epilogue: lane holds channels ct*16 + 4g + {0..3} of pixel (tile, j)
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    int pix = (ptile0 + t) * 16 + j;
-    if (pix >= p.npix) continue;
+    const int pix = opix[t];
+    if (pix < 0) continue;
     size_t rbase = 0;
     if (p.has_res) {
       if (p.res_ups) {
@@ -312,6 +361,48 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
     it.bias_out[i] = (it.bias && i < it.c_out) ? it.bias[i] : 0.f;
 }
 
+// Packed weights of the parity-class data gradient: one [ctile][ks][lane][8] block per class (blockIdx.y), K order
+// (t_y, t_x, channel) over the class's taps ky' = ry + s t_y, kx' = rx + s t_x of the flipped, channel-transposed
+// operator.  w is the FORWARD OIHW weight [c_out_fwd = K channels][c_in_fwd = rows][kh][kw].
+template <typename T>
+__global__ void pack_dgrad_classes_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                          uint16_t* __restrict__ packed, int rows, int kch, int cin_p, int kh, int kw,
+                                          int ctiles, int cs_, int padp) {
+  const int cls = blockIdx.y, cg = cin_p / 8;
+  int koff = 0;
+  for (int c = 0; c < cls; ++c) koff += cls_ksteps(cs_, kh, kw, padp, cg, c);
+  int ry, rx, nty, ntx;
+  cls_axis(cs_, kh, padp, cls / cs_, ry, nty);
+  cls_axis(cs_, kw, padp, cls % cs_, rx, ntx);
+  const int ksteps = (nty * ntx * cg + 3) / 4, taps = kh * kw;
+  const float sig = sigma ? sigma[0] : 1.f;
+  u32x4* out = reinterpret_cast<u32x4*>(packed) + (size_t)ctiles * koff * 64;
+  const int total = ctiles * ksteps * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, ks = (idx >> 6) % ksteps, ct = (idx >> 6) / ksteps;
+    const int row = ct * 16 + (lane & 15);
+    const int k0 = ks * 32 + (lane >> 4) * 8;
+    uint16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + e, tp = k / cin_p, c = k - tp * cin_p;
+      float v = 0.f;
+      if (row < rows && tp < nty * ntx && c < kch) {
+        const int ty = tp / ntx, tx = tp - ty * ntx;
+        const int tap = (ry + cs_ * ty) * kw + rx + cs_ * tx;          // flipped tap index
+        v = __fdiv_rn(w[((size_t)c * rows + row) * taps + (taps - 1 - tap)], sig);
+      }
+      o[e] = bits_of<T>(v);
+    }
+    u32x4 pk;
+    pk[0] = o[0] | ((uint32_t)o[1] << 16);
+    pk[1] = o[2] | ((uint32_t)o[3] << 16);
+    pk[2] = o[4] | ((uint32_t)o[5] << 16);
+    pk[3] = o[6] | ((uint32_t)o[7] << 16);
+    out[idx] = pk;
+  }
+}
+
 int fill_params(ConvParams& p, const CganConvDesc* d) {
   CGAN_REQUIRE(d != nullptr, "conv2d: null descriptor");
   CGAN_REQUIRE(d->dtype == CGAN_F16 || d->dtype == CGAN_BF16, "conv2d: bad dtype %d", d->dtype);
@@ -340,24 +431,31 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   CGAN_REQUIRE(npix < (1L << 31) - 64, "conv2d: too many output pixels");
   p.npix = (int)npix;
   p.kgroups = d->kh * d->kw * p.cg; p.ksteps = ceil_div(p.kgroups, 4);
-  p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1;
+  p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1; p.cls_s = 0; p.cls_pad = 0;
   p.has_res = d->has_residual; p.res_ups = d->residual_upsample;
   return CGAN_OK;
 }
 
+// pixels the grid has to cover: all of them, or (parity-class mode) those of the largest class, per blockIdx.z
+int grid_pixels(const ConvParams& p) {
+  if (!p.cls_s) return p.npix;
+  return p.n * ceil_div(p.h_out, p.cls_s) * ceil_div(p.w_out, p.cls_s);
+}
+
 template <typename T, int CT>
 void launch_ct(const ConvParams& p, hipStream_t s) {
-  const int ptiles = ceil_div(p.npix, 16);
+  const int ptiles = ceil_div(grid_pixels(p), 16);
   const int gy = ceil_div(p.ctiles, CT);
+  const int gz = p.cls_s ? p.cls_s * p.cls_s : 1;
   // enough blocks to fill 256 CUs: shrink the per-wave pixel register tile for small problems
-  if ((long)ceil_div(ptiles, 16) * gy >= 512) {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 4, false>), dim3(ceil_div(ptiles, 16), gy), dim3(256), 0, s, p);
-  } else if ((long)ceil_div(ptiles, 8) * gy >= 512) {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 2, false>), dim3(ceil_div(ptiles, 8), gy), dim3(256), 0, s, p);
-  } else if ((long)ceil_div(ptiles, 4) * gy >= 2048) {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1, false>), dim3(ceil_div(ptiles, 4), gy), dim3(256), 0, s, p);
+  if ((long)ceil_div(ptiles, 16) * gy * gz >= 512) {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 4, false>), dim3(ceil_div(ptiles, 16), gy, gz), dim3(256), 0, s, p);
+  } else if ((long)ceil_div(ptiles, 8) * gy * gz >= 512) {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 2, false>), dim3(ceil_div(ptiles, 8), gy, gz), dim3(256), 0, s, p);
+  } else if ((long)ceil_div(ptiles, 4) * gy * gz >= 2048) {
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1, false>), dim3(ceil_div(ptiles, 4), gy, gz), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1, true>), dim3(ceil_div(ptiles, 4), gy), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, CT, 1, true>), dim3(ceil_div(ptiles, 4), gy, gz), dim3(256), 0, s, p);
   }
 }
 
@@ -365,7 +463,7 @@ template <typename T>
 void launch(const ConvParams& p, hipStream_t s) {
   // channel tiles per workgroup: as many as divide ctiles (more reuse of the gathered B fragments), unless the
   // grid would then be too small to fill the chip (few pixels, many channels: the 5x5..20x20 Painter layers)
-  const long pblocks = ceil_div(ceil_div(p.npix, 16), 4);
+  const long pblocks = (long)ceil_div(ceil_div(grid_pixels(p), 16), 4) * (p.cls_s ? p.cls_s * p.cls_s : 1);
   int ct = 1;
   if (p.ctiles >= 4 && p.ctiles % 4 == 0) ct = 4;
   else if (p.ctiles % 3 == 0) ct = 3;
@@ -387,6 +485,9 @@ void launch(const ConvParams& p, hipStream_t s) {
 // (A/B measurements, parity tests of every kernel)
 int g_conv_force = 0;
 extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; }
+// 1: strided data gradients read dy through zero insertion (the first implementation) instead of by parity classes
+int g_dgrad_zero_insert = 0;
+extern "C" void cgan_debug_set_dgrad_zero_insert(int v) { g_dgrad_zero_insert = v; }
 
 extern "C" size_t cgan_conv2d_packed_weight_bytes(const CganConvDesc* d) {
   ConvParams p;
@@ -512,15 +613,28 @@ static int dgrad_params(ConvParams& p, const CganConvDesc* f, CganConvDesc* t) {
   p.npix = f->n * f->h_in * f->w_in;
   p.hx = f->h_out; p.wx = f->w_out;                // stored extent of dy
   p.in_zs = f->stride;
+  if (f->stride > 1 && f->dilation == 1 && pad_t >= 0 && g_dgrad_zero_insert == 0) {
+    // parity classes: coordinates are those of the stored dy, no zero insertion
+    p.cls_s = f->stride; p.cls_pad = pad_t; p.in_zs = 1;
+    p.h_in = p.hx; p.w_in = p.wx;
+  }
   t->h_out = f->h_in; t->w_out = f->w_in;
   return CGAN_OK;
+}
+
+static size_t dgrad_packed_fragments(const ConvParams& p) {
+  if (!p.cls_s) return (size_t)p.ctiles * p.ksteps * 64;
+  size_t ks = 0;
+  for (int c = 0; c < p.cls_s * p.cls_s; ++c) ks += cls_ksteps(p.cls_s, p.kh, p.kw, p.cls_pad, p.cg, c);
+  return (size_t)p.ctiles * ks * 64;
 }
 
 extern "C" size_t cgan_conv2d_dgrad_packed_weight_bytes(const CganConvDesc* fwd) {
   ConvParams p;
   CganConvDesc t;
   if (dgrad_params(p, fwd, &t) != CGAN_OK) return 0;
-  return (size_t)p.ctiles * p.ksteps * 64 * 16;
+  const size_t fr = dgrad_packed_fragments(p);
+  return (fr ? fr : 64) * 16;
 }
 
 extern "C" int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* sigma, void* packed,
@@ -530,6 +644,24 @@ extern "C" int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* s
   int rc = dgrad_params(p, fwd, &t);
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(w_oihw && packed, "conv2d_pack_weight_dgrad: null pointer");
+  if (p.cls_s) {
+    int max_ks = 1;
+    for (int c = 0; c < p.cls_s * p.cls_s; ++c) {
+      const int k = cls_ksteps(p.cls_s, p.kh, p.kw, p.cls_pad, p.cg, c);
+      max_ks = k > max_ks ? k : max_ks;
+    }
+    const int tot = p.ctiles * max_ks * 64;
+    const dim3 grid(ceil_div(tot, 256) < 1024 ? ceil_div(tot, 256) : 1024, p.cls_s * p.cls_s);
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd->dtype == CGAN_F16)
+      hipLaunchKernelGGL(pack_dgrad_classes_kernel<F16>, grid, dim3(256), 0, st, w_oihw, sigma, (uint16_t*)packed, t.c_out,
+                         t.c_in, p.cin_p, t.kh, t.kw, p.ctiles, p.cls_s, p.cls_pad);
+    else
+      hipLaunchKernelGGL(pack_dgrad_classes_kernel<BF16>, grid, dim3(256), 0, st, w_oihw, sigma, (uint16_t*)packed, t.c_out,
+                         t.c_in, p.cin_p, t.kh, t.kw, p.ctiles, p.cls_s, p.cls_pad);
+    CGAN_CHECK_LAUNCH("conv2d_pack_weight_dgrad(classes)");
+    return CGAN_OK;
+  }
   const int total = p.ctiles * p.ksteps * 64;
   const int blocks = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
   hipStream_t s = (hipStream_t)stream;

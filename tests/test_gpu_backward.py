@@ -46,6 +46,8 @@ BWD_CASES = [
     (128, 128, 3, 2, 1, 1, 1, 33, 35),     # ResNet strided 3x3, odd size (unreached rows -> zero grad)
     (3, 64, 7, 2, 3, 1, 1, 40, 48),        # ResNet stem
     (11, 64, 4, 2, 1, 1, 2, 32, 32),       # ADVENT FC discriminator first conv
+    (64, 128, 1, 2, 0, 1, 1, 17, 20),      # ResNet 1x1 stride-2 shortcut (three of the four parity classes have no tap)
+    (256, 512, 4, 2, 1, 1, 1, 12, 10),     # PatchGAN deep stride-2 4x4 (dgrad by parity classes, 4 k-steps per tap)
     (3, 128, 3, 1, 1, 1, 2, 20, 24),       # SPADE mlp_shared on the 3-channel cond (wgrad: 8 taps folded per N tile)
     (32, 80, 3, 1, 1, 1, 1, 18, 22),       # cin_s = 32: 2 taps per N tile
     (16, 8, 3, 1, 1, 1, 2, 16, 16),        # mask decoder tail: 4 taps per N tile
