@@ -39,12 +39,21 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int SLAB_BYTES = 32 * 128;        // 32 pixels x 64 channels x 2 B
 constexpr int WAVE_LDS = 4 * SLAB_BYTES;    // {dy, x} x double buffer
 
+// LDS slabs are [pixel row][8 slots of 16 B]; row r keeps channel chunk c in slot c ^ swz(r): un-swizzled, the 16 rows a
+// transposing read touches all start on the same banks (row pitch 128 B = one full bank cycle).  With swz the 4 rows x
+// 32 B of a 16-lane group cover all 32 banks.  (Measured: 0-4 % -- the kernel is bound by the L2 -> LDS DMA path and by
+// per-workgroup overheads, not by LDS reads; kept because it is free.)
+__device__ __forceinline__ int swz(int r) { return ((r & 3) << 1) | ((r >> 2) & 1); }
+
 __device__ __forceinline__ u32x4 tr_frag(const unsigned char* slab, int tile, int lane) {
   // rows 8g..8g+7 (pixels) of channel tile `tile`: two transposing reads of [4 pixels][16 channels] blocks
   const int i = lane & 15, g = lane >> 4;
-  const unsigned char* a0 = slab + (8 * g + (i >> 2)) * 128 + tile * 32 + (i & 3) * 8;
+  const int k = i >> 2;                                   // row within the 4-row block
+  const int chunk = tile * 2 + ((i & 3) >> 1);
+  const unsigned char* a0 = slab + (8 * g + k) * 128 + ((chunk ^ (k << 1)) << 4) + (i & 1) * 8;          // rows 8g + k
+  const unsigned char* a1 = slab + (8 * g + 4 + k) * 128 + ((chunk ^ ((k << 1) | 1)) << 4) + (i & 1) * 8;   // rows 8g + 4 + k
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 128));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
   u32x4 r;
   r[0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
   r[1] = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
@@ -91,13 +100,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   unsigned char* wl = smem + wave * WAVE_LDS;
 
   const int prow = lane >> 3;          // pixel within an 8-pixel DMA piece
-  const int q8 = (lane & 7) * 8;       // first channel of this lane's 16-byte chunk
+  const int qs = (lane & 7) ^ swz(prow);   // channel chunk this lane stages (LDS slot lane & 7 of row prow, swizzled)
+  const int q8 = qs * 8;               // first channel of this lane's 16-byte chunk
   const bool co_ok = co0 + q8 < p.cout_s;
   // this lane's 16-byte chunk of an x row: (tap, first channel)
   int ky, kx, cch;
   bool ci_ok;
   if (p.fold) {
-    const int q = lane & 7, tl = q / p.cpt;
+    const int q = qs, tl = q / p.cpt;
     const int tap_l = slot * p.tpt + tl;
     ci_ok = tl < p.tpt && tap_l < taps_n;
     const int tcl = ci_ok ? tap_l : 0;
@@ -328,7 +338,9 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
   const long tiles = pl.tiles();
   // ~4 workgroups per CU for layers with many (tap, channel block) tiles or very long pixel ranges, ~2 otherwise
   // (measured per layer shape with tools/bench_wgrad.py: the partial-tile workspace traffic grows with the splits)
-  const int target = g_wgrad_target > 0 ? g_wgrad_target : ((tiles >= 512 || tiles <= 16) ? 2048 : 1024);
+  // (kernel durations by rocprofv3, tools/prof_wgrad.sh; 1x1 layers: ~2 workgroups per CU)
+  const int target = g_wgrad_target > 0 ? g_wgrad_target
+                                        : (taps == 1 && tiles < 512 ? 512 : ((tiles >= 512 || tiles <= 16) ? 2048 : 1024));
   long splits = (target + tiles - 1) / tiles;
   if (splits > nchunks) splits = nchunks;
   pl.splits = splits < 1 ? 1 : (int)splits;

@@ -1,4 +1,7 @@
-"""Time the weight-gradient kernel on the Masker / Painter layer shapes through the C ABI.
+"""NOTE: shapes that take < ~0.1 ms are host-bound in this loop (Python + ctypes per call): read kernel durations with
+rocprofv3 (tools/prof_wgrad.sh) for those.
+
+Time the weight-gradient kernel on the Masker / Painter layer shapes through the C ABI.
 usage (GPU box): python tools/bench_wgrad.py [--target WGS] [--dbg BITS] [--bs N]"""
 import argparse
 import ctypes
@@ -35,12 +38,15 @@ def main():
     ap.add_argument("--bs", type=int, default=12)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--atomic", action="store_true")
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     lib = _lib.load()
     lib.cgan_debug_set_wgrad(ctypes.c_int(args.target), ctypes.c_int(args.dbg))
     print("target %d dbg %d bs %d" % (args.target, args.dbg, args.bs))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
+        if args.only not in name:
+            continue
         bs = args.bs if H < 640 else max(args.bs // 3, 1)
         x = ops.NHWC(torch.randn(bs, H, H, cin, device="cuda").to(dt), cin)
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
