@@ -262,10 +262,23 @@ int launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
                                         : launch_cfg2<T, WAVES_C, WC, WP, false>(a, s);
 }
 
+int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 1..4 = force a block tile
+
 template <typename T>
 int launch(const ConvGemmArgs& a, hipStream_t s) {
   const int ptiles = ceil_div(a.npix, 16);
+  switch (g_gemm_cfg) {
+    case 1: return launch_cfg<T, 1, 4, 4>(a, s);
+    case 2: if (a.ctiles <= 16) return launch_cfg<T, 2, 8, 4>(a, s); break;
+    case 3: return launch_cfg<T, 2, 4, 8>(a, s);
+    case 4: return launch_cfg<T, 2, 4, 4>(a, s);
+    default: break;
+  }
   if (a.ctiles <= 4) return launch_cfg<T, 1, 4, 4>(a, s);                       // 64 couts x 256 pixels
+  // 1x1 layers with a short K (bottleneck expands, K <= 512): the workgroup is all prologue / epilogue, and 128 x 128
+  // blocks (twice as many, half the epilogue each) overlap them better: 256 -> 1024 at 16 x 80^2: 175 -> 120 us,
+  // 64 -> 256 at 16 x 160^2: 128 -> 80 us (rocprofv3 kernel durations, tools/prof_conv.sh)
+  if (a.kh * a.kw == 1 && a.ksteps <= 16) return launch_cfg<T, 2, 4, 4>(a, s);
   // all couts in one block (activations read once) when cout <= 256 and the grid still fills the chip
   if (a.ctiles > 8 && a.ctiles <= 16 && ceil_div(ptiles, 8) >= 384) return launch_cfg<T, 2, 8, 4>(a, s);
   // 128 couts x 256 pixels while that still gives every CU a couple of workgroups, else 128 x 128
@@ -282,6 +295,8 @@ bool conv_gemm_applicable(const CganConvDesc* d) {
   return (cin_s % 32) == 0 && cout_s >= 64 && !d->in_upsample && npix >= 2048 && in_elems < (1L << 31) - (1L << 20) &&
          (long)ceil_div((int)ceil_div((int)npix, 16), 8) * ceil_div(ceil_div(cout_s, 16), 8) >= 128;
 }
+
+extern "C" void cgan_debug_set_gemm_cfg(int v) { g_gemm_cfg = v; }
 
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);

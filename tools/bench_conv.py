@@ -34,11 +34,19 @@ def main():
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--abl", type=int, default=0)
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--cfg", type=int, default=0, help="cgan_debug_set_gemm_cfg: 1 64x256, 2 256x128, 3 128x256, 4 128x128")
+    ap.add_argument("--hw", type=int, default=0, help="override the input extent of every shape")
+    ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     lib = _lib.load()
     lib.cgan_debug_set_conv_kernel(ctypes.c_int(args.force))
+    lib.cgan_debug_set_gemm_cfg(ctypes.c_int(args.cfg))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
+        if args.only not in name:
+            continue
+        H = args.hw or H
         x = ops.NHWC(torch.randn(args.bs, H, H, cin, device="cuda").to(dt), cin)
         w = torch.randn(cout, cin, k, k, device="cuda") * 0.02
         pw = ops.pack_conv_weight(w, None, dt)
