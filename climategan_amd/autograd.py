@@ -6,6 +6,8 @@ reference, trainer.py:1011,1028).
 Activations travel as raw 16-bit NHWC tensors ``[N,H,W,Cs]`` (the ``t`` of an ``ops.NHWC``) because autograd tracks
 tensors, with the logical channel count passed alongside.
 """
+import ctypes as C
+
 import torch
 
 from . import ops
@@ -197,14 +199,16 @@ class BatchNormActFn(torch.autograd.Function):
         n, h, w, cs = x_t.shape
         npix = n * h * w
         flat = ops.NHWC(x_t.view(1, npix, 1, cs), c)                   # one "image" of n*h*w pixels
-        mean, rstd = ops.instnorm_stats(flat, eps=eps)                  # [1, cs] batch statistics
-        mean_f = torch.empty_like(mean)
-        rstd_f = torch.empty_like(rstd)
-        _lib.check(lib.cgan_bn_train_prepare(
-            ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma), ops._ptr(beta), float(eps), float(momentum), npix,
-            ops._ptr(running_mean), ops._ptr(running_var), ops._ptr(mean_f), ops._ptr(rstd_f), ops._ptr(nbt), c,
-            ops._stream()),
-            "cgan_bn_train_prepare")
+        # batch statistics + (mean', rstd') for the apply kernel + running statistics + step counter: two launches
+        d = ops.NormStatsDesc(flat.dtype_id, 1, npix, c, float(eps))
+        ws_bytes = lib.cgan_instnorm_stats_workspace_bytes(C.byref(d))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x_t.device)
+        stats = torch.empty((4, 1, cs), dtype=torch.float32, device=x_t.device)
+        mean, rstd, mean_f, rstd_f = stats[0], stats[1], stats[2], stats[3]
+        _lib.check(lib.cgan_batchnorm_train_stats(
+            ops._ptr(x_t), ops._ptr(gamma), ops._ptr(beta), float(momentum), ops._ptr(running_mean),
+            ops._ptr(running_var), ops._ptr(nbt), ops._ptr(mean), ops._ptr(rstd), ops._ptr(mean_f), ops._ptr(rstd_f),
+            C.byref(d), ops._ptr(ws), ws_bytes, ops._stream()), "cgan_batchnorm_train_stats")
         out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope).t.view(n, h, w, cs)
         ctx.cfg = (c, act, slope)
         ctx.save_for_backward(x_t, out, mean, rstd, gamma)

@@ -94,11 +94,26 @@ __global__ __launch_bounds__(STATS_THREADS) void instnorm_partial_kernel(const u
   }
 }
 
+// Optional training-mode BatchNorm epilogue of the finalize step (n_total == 1: the batch viewed as one image): the
+// (mean', rstd') pair cgan_norm_act_apply consumes, the running statistics and the step counter, exactly as
+// bn_train_prepare_kernel (train_ops.hip) computes them -- one launch less per BatchNorm forward.
+struct BnEpilogue {
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* mean_out;     // null: plain instance-norm statistics
+  float* rstd_out;
+  long long* num_batches_tracked;
+  float momentum;
+  int c;
+};
+
 // one wave per (n, c): lanes stride over the chunk partials, then a 6-step shuffle tree of Chan merges
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ partial,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
                                                                 int n_total, int hw, int cs, int chunks, int ppb,
-                                                                float eps) {
+                                                                float eps, BnEpilogue bn) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (idx >= n_total * cs) return;
@@ -120,8 +135,26 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     acc = chan_merge(acc, b);
   }
   if (lane == 0) {
-    mean[idx] = acc.mean;
-    rstd[idx] = rsqrtf(acc.m2 / (float)hw + eps);
+    const float mu = acc.mean, rs = rsqrtf(acc.m2 / (float)hw + eps);
+    mean[idx] = mu;
+    rstd[idx] = rs;
+    if (bn.mean_out) {
+      if (idx == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
+      float m = 0.f, r = 0.f;
+      if (c < bn.c) {
+        r = rs * (bn.gamma ? bn.gamma[c] : 1.f);
+        m = mu - ((bn.beta && r != 0.f) ? bn.beta[c] / r : 0.f);
+        if (bn.running_mean) {
+          const float count = (float)hw;
+          const float var_b = 1.f / (rs * rs) - eps;
+          const float var_u = count > 1.f ? var_b * count / (count - 1.f) : var_b;
+          bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * mu;
+          bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * var_u;
+        }
+      }
+      bn.mean_out[c] = m;
+      bn.rstd_out[c] = r;
+    }
   }
 }
 
@@ -192,8 +225,8 @@ extern "C" size_t cgan_instnorm_stats_workspace_bytes(const CganNormStatsDesc* d
   return (size_t)d->n * chunks * cgan_cs(d->c) * 2 * sizeof(float);
 }
 
-extern "C" int cgan_instnorm_stats(const void* x, float* mean, float* rstd, const CganNormStatsDesc* d, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+static int stats_impl(const void* x, float* mean, float* rstd, const CganNormStatsDesc* d, void* workspace,
+                      size_t workspace_bytes, void* stream, const BnEpilogue& bn) {
   int rc = check(d);
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(x && mean && rstd && workspace, "instnorm_stats: null pointer");
@@ -220,9 +253,28 @@ extern "C" int cgan_instnorm_stats(const void* x, float* mean, float* rstd, cons
   CGAN_CHECK_LAUNCH("instnorm_stats(partial)");
   int total = d->n * cs;
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, (const float*)workspace,
-                     mean, rstd, d->n, d->hw, cs, chunks, ppb, d->eps);
+                     mean, rstd, d->n, d->hw, cs, chunks, ppb, d->eps, bn);
   CGAN_CHECK_LAUNCH("instnorm_stats(finalize)");
   return CGAN_OK;
+}
+
+extern "C" int cgan_instnorm_stats(const void* x, float* mean, float* rstd, const CganNormStatsDesc* d, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  BnEpilogue none = {};
+  return stats_impl(x, mean, rstd, d, workspace, workspace_bytes, stream, none);
+}
+
+extern "C" int cgan_batchnorm_train_stats(const void* x, const float* gamma, const float* beta, float momentum,
+                                          float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                          float* batch_mean, float* batch_rstd, float* mean_out, float* rstd_out,
+                                          const CganNormStatsDesc* d, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  CGAN_REQUIRE(d != nullptr && d->n == 1, "batchnorm_train_stats: describe the batch as ONE image of n*h*w pixels");
+  CGAN_REQUIRE(mean_out && rstd_out, "batchnorm_train_stats: null pointer");
+  CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_stats: running stats go together");
+  BnEpilogue bn = {gamma, beta, running_mean, running_var, mean_out, rstd_out, (long long*)num_batches_tracked, momentum,
+                   d->c};
+  return stats_impl(x, batch_mean, batch_rstd, d, workspace, workspace_bytes, stream, bn);
 }
 
 extern "C" int cgan_norm_act_apply(const void* x, const float* mean, const float* rstd, void* y,

@@ -297,6 +297,12 @@ int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const f
 int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma, const float* beta,
                           float eps, float momentum, int64_t count, float* running_mean, float* running_var,
                           float* mean_out, float* rstd_out, int64_t* num_batches_tracked, int32_t c, void* stream);
+/* cgan_instnorm_stats + cgan_bn_train_prepare in one call (the prepare step rides in the statistics' finalize kernel):
+ * d describes the batch as ONE image (n = 1, hw = n*h*w); workspace cgan_instnorm_stats_workspace_bytes(d). */
+int cgan_batchnorm_train_stats(const void* x, const float* gamma, const float* beta, float momentum, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* batch_mean, float* batch_rstd,
+                               float* mean_out, float* rstd_out, const CganNormStatsDesc* d, void* workspace,
+                               size_t workspace_bytes, void* stream);
 size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);
 int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
                            const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
