@@ -437,7 +437,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
     for (int dx = 0; dx < 3; ++dx) {
       const int s = q * 3 + dx;
       COUNTED_BARRIER(0);
-      if (s + 1 < NSTAGES) issue_stage(s + 1);
+      if (s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
       if (q == 3 && dx == 0) {
         // the last quarter has no successor: its spare hidden-map buffer (actv[0]) receives the x tile now, as
         // whole 16-byte channel chunks, lane-linear over [256 pixels][NCT chunks] (id = k*256 + tid -> pixel id / NCT,

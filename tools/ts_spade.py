@@ -8,6 +8,9 @@ from climategan_amd import _lib, fill, ops
 dt = torch.bfloat16
 B = 8
 lib = _lib.load()
+if len(sys.argv) > 1:
+    lib.cgan_debug_set_spade_ablation(ctypes.c_int(int(sys.argv[1])))
+    print('ablation bits', sys.argv[1])
 cond = ops.nchw_to_nhwc(torch.from_numpy(fill.uniform((B, 3, 640, 640), 1)).cuda(), dt, cs=4)
 for C, R in [(40, 640), (20, 640)]:
     g = torch.Generator(device="cuda"); g.manual_seed(C + R)
