@@ -16,12 +16,12 @@
 
 namespace {
 
-__device__ __attribute__((aligned(16))) unsigned int g_wgrad_zeros[4];
 
 struct WgradArgs {
   const uint16_t* x;
   const uint16_t* dy;
   float* dw;
+  unsigned x_bytes, dy_bytes;   // extents for the buffer descriptors (out-of-range DMA lanes read zeros)
   float* ws;   // non-null: partial tiles go to ws[split][tile][16 fragments][64 lanes] (f32x4) for wgrad_reduce_kernel
   int n, h_in, w_in, cin, cin_s;
   int cout, cout_s;
@@ -78,7 +78,8 @@ __device__ __forceinline__ bool wgrad_column(int fold, int cpt, int tpt, int tap
   return tl < tpt && tap < taps && ci < cin;
 }
 
-template <typename T>
+// MODE 0: zero padding; 1: x stored at half resolution and read through the folded nearest x2 upsample; 2: reflect padding
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -120,25 +121,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     cch = cib * 64 + q8;
     ci_ok = cch < p.cin_s;
   }
-  const long zero_dy = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.dy);
-  const long zero_x = reinterpret_cast<const unsigned char*>(g_wgrad_zeros) - reinterpret_cast<const unsigned char*>(p.x);
+  // ---- addressing of the DMA pieces.  Everything is 32-bit and incremental: the first version recomputed 64-bit
+  // offsets ((n h + iy) w + ix) cin per piece, ~35 instructions with quarter-rate 64-bit multiplies behind exec-masked
+  // branches -- 8 pieces per chunk cost several times the chunk's 16 MFMAs and bound the kernel (ablation: without the
+  // DMA *and its address math* it ran twice as fast).  Byte offsets fit 32 bits (host check: tensors < 4 GiB).
+  // Buffer descriptors: a lane whose pixel / tap / channel chunk does not exist sends an out-of-range offset and the
+  // hardware writes zeros to its LDS slot -- no zero page, no 64-bit pointer selects.
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+  const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
+  const unsigned cch2 = (unsigned)cch * 2u;
+  const int tap_y = ky * p.dil - p.pad, tap_x = kx * p.dil - p.pad;
+  const int hx = MODE == 1 ? (p.h_in >> 1) : p.h_in, wx = MODE == 1 ? (p.w_in >> 1) : p.w_in;   // stored extent of x
+  const unsigned row_b = (unsigned)wx * cin_b;                                                    // bytes per stored row
 
-  // Pixel coordinates of this lane's 4 DMA pieces for the NEXT chunk to issue.  They are advanced by the (uniform)
-  // chunk stride with carries instead of being re-derived by integer division every chunk: the first version spent
-  // ~12 divisions per lane per chunk, several times the chunk's 16 MFMAs.
-  int c_pix[4], c_ox[4], c_oy[4], c_n[4];
+  // State of this lane's 4 pieces for the NEXT chunk to issue: linear pixel, (ox, oy) pre-multiplied by the stride,
+  // n * (stored rows per image), dy byte offset.  Advanced by the uniform chunk stride with carries.
+  int c_pix[4], c_sx[4], c_sy[4], c_nh[4];
+  unsigned c_dy[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int pix = split * 128 + wave * 32 + i * 8 + prow;
     c_pix[i] = pix;
-    c_ox[i] = pix % p.w_out;
     const int r = pix / p.w_out;
-    c_oy[i] = r % p.h_out;
-    c_n[i] = r / p.h_out;
+    c_sx[i] = (pix - r * p.w_out) * p.stride;
+    const int nn = r / p.h_out;
+    c_sy[i] = (r - nn * p.h_out) * p.stride;
+    c_nh[i] = nn * hx;
+    c_dy[i] = (unsigned)pix * cout_b + (unsigned)(co0 + q8) * 2u;
   }
   const int step = p.splits * 128;                                   // pixels between two chunks of this workgroup
-  const int step_x = step % p.w_out, step_r = step / p.w_out;
-  const int step_y = step_r % p.h_out, step_n = step_r / p.h_out;
+  const int step_r = step / p.w_out;
+  const int step_sx = (step - step_r * p.w_out) * p.stride;
+  const int step_n = step_r / p.h_out;
+  const int step_sy = (step_r - step_n * p.h_out) * p.stride;
+  const int step_nh = step_n * hx;
+  const int wrap_x = p.w_out * p.stride, wrap_y = p.h_out * p.stride;
+  const unsigned step_dy = (unsigned)step * cout_b;
 
   // DMA of this wave's 32-pixel slab of the next chunk into buffer b: 4 pieces of dy, 4 pieces of (tap-shifted) x
   auto issue = [&](int b) {
@@ -146,31 +165,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     unsigned char* dst_x = dst_dy + SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int pix = c_pix[i];
-      const bool pv = pix < p.npix;
-      const int ox = c_ox[i], oy = c_oy[i], nn = c_n[i];
-      const long off_dy = (pv && co_ok) ? ((long)pix * p.cout_s + co0 + q8) * 2 : zero_dy;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.dy) + off_dy),
-          (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16, 0, 0);
-      int iy = oy * p.stride - p.pad + ky * p.dil, ix = ox * p.stride - p.pad + kx * p.dil;
-      if (p.reflect) {
+      const bool pv = c_pix[i] < p.npix;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16,
+                                               (pv && co_ok) ? c_dy[i] : 0xffffffffu, 0, 0, 0);
+      int iy = c_sy[i] + tap_y, ix = c_sx[i] + tap_x;
+      if (MODE == 2) {
         iy = iy < 0 ? -iy : (iy >= p.h_in ? 2 * p.h_in - 2 - iy : iy);
         ix = ix < 0 ? -ix : (ix >= p.w_in ? 2 * p.w_in - 2 - ix : ix);
       }
       const bool xv = pv && ci_ok && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
-      const long off_x = xv ? (p.x_ups ? ((((long)nn * (p.h_in >> 1) + (iy >> 1)) * (p.w_in >> 1) + (ix >> 1)) * p.cin_s + cch) * 2
-                                       : ((((long)nn * p.h_in + iy) * p.w_in + ix) * p.cin_s + cch) * 2)
-                            : zero_x;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(p.x) + off_x),
-          (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16, 0, 0);
+      const unsigned row = (unsigned)(c_nh[i] + (MODE == 1 ? (iy >> 1) : iy));
+      const unsigned col = (unsigned)(MODE == 1 ? (ix >> 1) : ix);
+      const unsigned off = row * row_b + col * cin_b + cch2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16,
+                                               xv ? off : 0xffffffffu, 0, 0, 0);
       // advance to the following chunk
-      c_pix[i] = pix + step;
-      int nx = ox + step_x, ny = oy + step_y, n2 = nn + step_n;
-      if (nx >= p.w_out) { nx -= p.w_out; ++ny; }
-      if (ny >= p.h_out) { ny -= p.h_out; ++n2; }
-      c_ox[i] = nx; c_oy[i] = ny; c_n[i] = n2;
+      c_pix[i] += step;
+      c_dy[i] += step_dy;
+      int sx = c_sx[i] + step_sx, sy = c_sy[i] + step_sy, nh = c_nh[i] + step_nh;
+      const bool cx = sx >= wrap_x;
+      sx = cx ? sx - wrap_x : sx;
+      sy = cx ? sy + p.stride : sy;
+      const bool cy = sy >= wrap_y;
+      sy = cy ? sy - wrap_y : sy;
+      nh = cy ? nh + hx : nh;
+      c_sx[i] = sx; c_sy[i] = sy; c_nh[i] = nh;
     }
   };
 
@@ -399,10 +418,20 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = 4 * WAVE_LDS;   // 64 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
-  if (d->dtype == CGAN_F16)
-    hipLaunchKernelGGL(conv_wgrad_kernel<F16>, dim3(gx), dim3(256), smem, s, a);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<BF16>, dim3(gx), dim3(256), smem, s, a);
+  // 32-bit byte offsets inside the kernel
+  CGAN_REQUIRE((double)d->n * (a.x_ups ? d->h_in / 2 : d->h_in) * (a.x_ups ? d->w_in / 2 : d->w_in) * a.cin_s * 2.0 < 4294967295.0 &&
+                   (double)a.npix * a.cout_s * 2.0 < 4294967295.0,
+               "conv2d_nhwc_bwd_weight: activation tensors of 4 GiB or more are not supported");
+  a.x_bytes = (unsigned)((size_t)d->n * (a.x_ups ? d->h_in / 2 : d->h_in) * (a.x_ups ? d->w_in / 2 : d->w_in) * a.cin_s * 2);
+  a.dy_bytes = (unsigned)((size_t)a.npix * a.cout_s * 2);
+  const int mode = a.x_ups ? 1 : (a.reflect ? 2 : 0);
+#define WGRAD_LAUNCH(TT, MM) hipLaunchKernelGGL((conv_wgrad_kernel<TT, MM>), dim3(gx), dim3(256), smem, s, a)
+  if (d->dtype == CGAN_F16) {
+    if (mode == 0) WGRAD_LAUNCH(F16, 0); else if (mode == 1) WGRAD_LAUNCH(F16, 1); else WGRAD_LAUNCH(F16, 2);
+  } else {
+    if (mode == 0) WGRAD_LAUNCH(BF16, 0); else if (mode == 1) WGRAD_LAUNCH(BF16, 1); else WGRAD_LAUNCH(BF16, 2);
+  }
+#undef WGRAD_LAUNCH
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
   if (a.ws) {
     const int elems = (int)pl.tiles() * 1024;
