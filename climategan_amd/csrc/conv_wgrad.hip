@@ -79,7 +79,9 @@ __device__ __forceinline__ bool wgrad_column(int fold, int cpt, int tpt, int tap
 }
 
 // MODE 0: zero padding; 1: x stored at half resolution and read through the folded nearest x2 upsample; 2: reflect padding
-template <typename T, int MODE>
+// UNI: w_out % 8 == 0, so the 8 pixels of a DMA piece lie in one output row and the piece's coordinates are wave-uniform:
+// they live in scalar registers and advance on the scalar unit; a lane only adds its constant part.
+template <typename T, int MODE, bool UNI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -159,10 +161,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int wrap_x = p.w_out * p.stride, wrap_y = p.h_out * p.stride;
   const unsigned step_dy = (unsigned)step * cout_b;
 
+  // ---- UNI: per-piece state from wave-uniform values only (row 0 of the piece), per-lane constants on top
+  int u_sx[4], u_sy[4], u_nh[4];
+  unsigned u_dy[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = split * 128 + wave * 32 + i * 8;
+    const int r = pix / p.w_out;
+    u_sx[i] = (pix - r * p.w_out) * p.stride;
+    const int nn = r / p.h_out;
+    u_sy[i] = (r - nn * p.h_out) * p.stride;
+    u_nh[i] = nn * hx;
+    u_dy[i] = (unsigned)pix * cout_b;
+  }
+  const int lx = prow * p.stride + tap_x;
+  const int ly = ci_ok ? tap_y : -(1 << 20);                    // a lane without a tap / channel chunk is always out of bounds
+  const unsigned lane_dyc = co_ok ? (unsigned)prow * cout_b + (unsigned)(co0 + q8) * 2u : 0x80000000u;   // dy_bytes < 2^31
+  const unsigned lane_xc = (unsigned)((tap_y * wx + lx) * (int)cin_b) + cch2;                            // MODE 0
+
   // DMA of this wave's 32-pixel slab of the next chunk into buffer b: 4 pieces of dy, 4 pieces of (tap-shifted) x
   auto issue = [&](int b) {
     unsigned char* dst_dy = wl + b * 2 * SLAB_BYTES;
     unsigned char* dst_x = dst_dy + SLAB_BYTES;
+    if constexpr (UNI) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // pixels past the end: the dy offset is out of range by itself (zeros), which also neutralises whatever x holds
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16,
+                                                 u_dy[i] + lane_dyc, 0, 0, 0);
+        const int iy = u_sy[i] + ly, ix = u_sx[i] + lx;
+        const bool xv = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+        unsigned off;
+        if (MODE == 1) {
+          off = (unsigned)(u_nh[i] + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
+        } else {
+          off = (unsigned)((u_nh[i] + u_sy[i]) * wx + u_sx[i]) * cin_b + lane_xc;   // scalar part + lane constant
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16,
+                                                 xv ? off : 0xffffffffu, 0, 0, 0);
+        u_dy[i] += step_dy;
+        int sx = u_sx[i] + step_sx, sy = u_sy[i] + step_sy, nh = u_nh[i] + step_nh;
+        const bool cx = sx >= wrap_x;
+        sx = cx ? sx - wrap_x : sx;
+        sy = cx ? sy + p.stride : sy;
+        const bool cy = sy >= wrap_y;
+        sy = cy ? sy - wrap_y : sy;
+        nh = cy ? nh + hx : nh;
+        u_sx[i] = sx; u_sy[i] = sy; u_nh[i] = nh;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool pv = c_pix[i] < p.npix;
@@ -425,12 +473,19 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   a.x_bytes = (unsigned)((size_t)d->n * (a.x_ups ? d->h_in / 2 : d->h_in) * (a.x_ups ? d->w_in / 2 : d->w_in) * a.cin_s * 2);
   a.dy_bytes = (unsigned)((size_t)a.npix * a.cout_s * 2);
   const int mode = a.x_ups ? 1 : (a.reflect ? 2 : 0);
-#define WGRAD_LAUNCH(TT, MM) hipLaunchKernelGGL((conv_wgrad_kernel<TT, MM>), dim3(gx), dim3(256), smem, s, a)
-  if (d->dtype == CGAN_F16) {
-    if (mode == 0) WGRAD_LAUNCH(F16, 0); else if (mode == 1) WGRAD_LAUNCH(F16, 1); else WGRAD_LAUNCH(F16, 2);
-  } else {
-    if (mode == 0) WGRAD_LAUNCH(BF16, 0); else if (mode == 1) WGRAD_LAUNCH(BF16, 1); else WGRAD_LAUNCH(BF16, 2);
-  }
+  // uniform-piece addressing: pieces must not straddle output rows, and the "always out of range" lane constant needs
+  // the dy offsets (one chunk stride past the end included) below 2^31
+  const bool uni = mode != 2 && (d->w_out % 8) == 0 && g_wgrad_dbg != 16 &&
+                   ((double)a.npix + (double)a.splits * 128.0 + 128.0) * a.cout_s * 2.0 < 2147483648.0;
+#define WGRAD_LAUNCH(TT, MM, UU) hipLaunchKernelGGL((conv_wgrad_kernel<TT, MM, UU>), dim3(gx), dim3(256), smem, s, a)
+#define WGRAD_MODE(TT)                                                          \
+  do {                                                                          \
+    if (mode == 2) WGRAD_LAUNCH(TT, 2, false);                                  \
+    else if (mode == 1) { if (uni) WGRAD_LAUNCH(TT, 1, true); else WGRAD_LAUNCH(TT, 1, false); } \
+    else { if (uni) WGRAD_LAUNCH(TT, 0, true); else WGRAD_LAUNCH(TT, 0, false); }                \
+  } while (0)
+  if (d->dtype == CGAN_F16) WGRAD_MODE(F16); else WGRAD_MODE(BF16);
+#undef WGRAD_MODE
 #undef WGRAD_LAUNCH
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
   if (a.ws) {
