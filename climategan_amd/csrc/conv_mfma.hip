@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       }
       if (ok) {
         if (p.in_ups) { iy >>= 1; ix >>= 1; }
-        size_t off = (((size_t)pn[t] * p.hx + iy) * p.wx + ix) * p.cin_s + c8 * 8;
+        // 32-bit element offset (fill_params checks the tensor has < 2^32 elements): a 64-bit multiply chain here
+        // costs more issue slots than the MFMAs it feeds
+        const unsigned off = ((unsigned)(pn[t] * p.hx + iy) * (unsigned)p.wx + (unsigned)ix) * (unsigned)p.cin_s + (unsigned)(c8 * 8);
         b[t] = *reinterpret_cast<const u32x4*>(p.x + off);
       }
     }
@@ -429,6 +431,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   p.h_out = d->h_out; p.w_out = d->w_out;
   long npix = (long)d->n * d->h_out * d->w_out;
   CGAN_REQUIRE(npix < (1L << 31) - 64, "conv2d: too many output pixels");
+  CGAN_REQUIRE((double)d->n * d->h_in * d->w_in * cgan_cs(d->c_in) < 4294967296.0, "conv2d: input tensor has 2^32 elements or more");
   p.npix = (int)npix;
   p.kgroups = d->kh * d->kw * p.cg; p.ksteps = ceil_div(p.kgroups, 4);
   p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1; p.cls_s = 0; p.cls_pad = 0;
