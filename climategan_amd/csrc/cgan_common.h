@@ -87,14 +87,16 @@ __device__ __forceinline__ typename T::vec8 as_vec8(u32x4 v) {
   return __builtin_bit_cast(typename T::vec8, v);
 }
 
+// NONE / ReLU / LeakyReLU share one select with a (uniform) negative-side factor: a per-value switch over the five
+// activations compiled to ~4 scalar branches per VALUE in the conv epilogues (hundreds per workgroup, a visible share of
+// the short-K 1x1 layers).  `+ 0.f` keeps ReLU's negative side at +0 (v * 0 alone would be -0).
+static_assert(CGAN_ACT_NONE == 0 && CGAN_ACT_RELU == 1 && CGAN_ACT_LRELU == 2, "act_apply relies on the enum order");
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
-  switch (act) {
-    case CGAN_ACT_RELU: return v > 0.f ? v : 0.f;
-    case CGAN_ACT_LRELU: return v > 0.f ? v : v * slope;
-    case CGAN_ACT_TANH: return tanhf(v);
-    case CGAN_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-    default: return v;
+  if (act <= CGAN_ACT_LRELU) {
+    const float ns = act == CGAN_ACT_NONE ? 1.f : (act == CGAN_ACT_RELU ? 0.f : slope);
+    return v > 0.f ? v : v * ns + 0.f;
   }
+  return act == CGAN_ACT_TANH ? tanhf(v) : 1.f / (1.f + __expf(-v));
 }
 
 // F.interpolate(mode="nearest") legacy source index: min(floor(dst * scale), in - 1), scale = in / out in f32
