@@ -71,6 +71,8 @@ _SIGNATURES = {
     "cgan_seg_counts": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     "cgan_resize_crop_geometry": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cgan_resize_u8": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P,
+                                 _P, C.c_size_t, _P]),
     "cgan_resize_crop_u8_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "cgan_resize_crop_u8": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P,
                                       _P, C.c_size_t, _P]),

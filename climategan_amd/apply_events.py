@@ -32,3 +32,27 @@ def prepare_batch(images, to=640, device="cuda"):
             raise ValueError("prepare_batch: image %d is not [H, W, 3] (convert RGBA / grey first)" % i)
         ops.resize_and_crop_u8(t.to(device), to, out=batch[i])
     return batch
+
+
+def to_128(im, w_target=-1):
+    """reference utils.py:998-1007: (nh, nw) = the largest multiples of 128 not above w_target and nw * h / w."""
+    h, w = im.shape[:2]
+    aspect_ratio = h / w
+    if w_target < 0:
+        w_target = w
+    nw = int(w_target / 128) * 128
+    nh = int(nw * aspect_ratio / 128) * 128
+    return nh, nw
+
+
+def resize_keep_ratio(img, max_im_width=-1, device="cuda"):
+    """The keep_ratio branch of the reference loop (apply_events.py:494-497, 502): uint8 HWC image -> fp32
+    [3, nh, nw] in [-1, 1] with (nh, nw) = to_128(img, max_im_width); images of different sizes cannot be stacked, so
+    ``infer_all`` takes them one at a time (batch_size 1, as the reference requires for keep_ratio)."""
+    t = img if isinstance(img, torch.Tensor) else torch.from_numpy(img)
+    if t.dtype != torch.uint8:
+        raise ValueError("resize_keep_ratio: np.uint8 255 image expected, got %s" % t.dtype)
+    nh, nw = to_128(t, max_im_width)
+    if nh <= 0 or nw <= 0:
+        raise ValueError("resize_keep_ratio: image %s is smaller than 128 pixels in one direction" % (tuple(t.shape),))
+    return ops.resize_u8(t.to(device), (nh, nw))

@@ -56,13 +56,13 @@ __global__ __launch_bounds__(256) void prep_gauss_cols_kernel(const double* __re
 // bilinear warp of the cropped window + uint8 truncation + [-1, 1]; one thread per output pixel and channel
 __global__ __launch_bounds__(256) void prep_warp_crop_kernel(const double* __restrict__ in, float* __restrict__ out, int h,
                                                              int w, int c, double fr, double fc, int top, int left,
-                                                             int to) {
+                                                             int oh, int ow, int truncate) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= to * to * c) return;
-  const int ch = i / (to * to);
-  const int rem = i - ch * to * to;
-  const int oy = rem / to, ox = rem - oy * to;
+  if (i >= oh * ow * c) return;
+  const int ch = i / (oh * ow);
+  const int rem = i - ch * oh * ow;
+  const int oy = rem / ow, ox = rem - oy * ow;
   // pixel-centre alignment: src = scale * (dst + 0.5) - 0.5  (skimage resize: the 0th pixel is at (0.5, 0.5))
   const double r = fr * ((double)(top + oy) + 0.5) - 0.5;
   const double cc = fc * ((double)(left + ox) + 0.5) - 0.5;
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void prep_warp_crop_kernel(const double* __res
   const double botv = (1.0 - dc) * bl + dc * br;
   double v = (1.0 - dr) * topv + dr * botv;
   v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);       // clip=True: the filtered image never leaves [0, 255]
-  const double u = (double)(int)v / 255.0;           // astype(uint8) truncation, then rc_img / 255.0 (float64)
+  // resize_and_crop: astype(uint8) truncation, then rc_img / 255.0 (float64); keep_ratio: the float image / 255
+  const double u = (truncate ? (double)(int)v : v) / 255.0;
   out[i] = ((float)u - 0.5f) * 2.0f;                 // to_m1_p1: (img.astype(float32) - 0.5) * 2
 }
 
@@ -107,25 +108,22 @@ extern "C" size_t cgan_resize_crop_u8_workspace_bytes(int32_t h, int32_t w, int3
   return (size_t)h * w * c * sizeof(double) * 2;
 }
 
-extern "C" int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int32_t to,
-                                   const double* weights_rows, int32_t radius_rows, const double* weights_cols,
-                                   int32_t radius_cols, float* out_chw, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
-  CGAN_REQUIRE(img_hwc_u8 && out_chw && workspace, "resize_crop_u8: null pointer");
-  CGAN_REQUIRE(h > 0 && w > 0 && c > 0 && c <= 4 && to > 0, "resize_crop_u8: bad shape");
-  CGAN_REQUIRE(workspace_bytes >= cgan_resize_crop_u8_workspace_bytes(h, w, c), "resize_crop_u8: workspace too small");
+static int resize_impl(const void* img, int h, int w, int c, int R, int C, int top, int left, int oh, int ow, int truncate,
+                       const double* weights_rows, int radius_rows, const double* weights_cols, int radius_cols,
+                       float* out_chw, void* workspace, size_t workspace_bytes, void* stream, const char* what) {
+  CGAN_REQUIRE(img && out_chw && workspace, "%s: null pointer", what);
+  CGAN_REQUIRE(h > 0 && w > 0 && c > 0 && c <= 4 && R > 0 && C > 0 && oh > 0 && ow > 0, "%s: bad shape", what);
+  CGAN_REQUIRE(top >= 0 && left >= 0 && top + oh <= R && left + ow <= C, "%s: output window outside the resized image", what);
+  CGAN_REQUIRE(workspace_bytes >= cgan_resize_crop_u8_workspace_bytes(h, w, c), "%s: workspace too small", what);
   CGAN_REQUIRE(radius_rows >= 0 && radius_cols >= 0 && radius_rows < h && radius_cols < w,
-               "resize_crop_u8: Gaussian radius must be smaller than the image");
-  CGAN_REQUIRE((radius_rows == 0 || weights_rows) && (radius_cols == 0 || weights_cols), "resize_crop_u8: missing weights");
-  int32_t R, C, top, left;
-  cgan_resize_crop_geometry(h, w, to, &R, &C, &top, &left);
-  CGAN_REQUIRE(R >= to && C >= to, "resize_crop_u8: inconsistent geometry");
+               "%s: Gaussian radius must be smaller than the image", what);
+  CGAN_REQUIRE((radius_rows == 0 || weights_rows) && (radius_cols == 0 || weights_cols), "%s: missing weights", what);
   hipStream_t s = (hipStream_t)stream;
   double* a = (double*)workspace;
   double* b = a + (size_t)h * w * c;
   const long n = (long)h * w * c;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(prep_gauss_rows_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)img_hwc_u8, a, weights_rows,
+  hipLaunchKernelGGL(prep_gauss_rows_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)img, a, weights_rows,
                      radius_rows, h, w * c);
   const double* filtered = a;
   if (radius_cols > 0) {
@@ -134,10 +132,28 @@ extern "C" int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w,
     filtered = b;
   }
   const double fr = (double)h / (double)R, fc = (double)w / (double)C;
-  hipLaunchKernelGGL(prep_warp_crop_kernel, dim3((unsigned)((to * to * c + 255) / 256)), dim3(256), 0, s, filtered, out_chw,
-                     h, w, c, fr, fc, top, left, to);
-  CGAN_CHECK_LAUNCH("resize_crop_u8");
+  hipLaunchKernelGGL(prep_warp_crop_kernel, dim3((unsigned)(((long)oh * ow * c + 255) / 256)), dim3(256), 0, s, filtered,
+                     out_chw, h, w, c, fr, fc, top, left, oh, ow, truncate);
+  CGAN_CHECK_LAUNCH(what);
   return CGAN_OK;
+}
+
+extern "C" int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int32_t to,
+                                   const double* weights_rows, int32_t radius_rows, const double* weights_cols,
+                                   int32_t radius_cols, float* out_chw, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  CGAN_REQUIRE(h > 0 && w > 0 && to > 0, "resize_crop_u8: bad shape");
+  int32_t R, C, top, left;
+  cgan_resize_crop_geometry(h, w, to, &R, &C, &top, &left);
+  return resize_impl(img_hwc_u8, h, w, c, R, C, top, left, to, to, 1, weights_rows, radius_rows, weights_cols, radius_cols,
+                     out_chw, workspace, workspace_bytes, stream, "resize_crop_u8");
+}
+
+extern "C" int cgan_resize_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int32_t rows, int32_t cols,
+                              const double* weights_rows, int32_t radius_rows, const double* weights_cols,
+                              int32_t radius_cols, float* out_chw, void* workspace, size_t workspace_bytes, void* stream) {
+  return resize_impl(img_hwc_u8, h, w, c, rows, cols, 0, 0, rows, cols, 0, weights_rows, radius_rows, weights_cols,
+                     radius_cols, out_chw, workspace, workspace_bytes, stream, "resize_u8");
 }
 
 // ---- validation metrics (climategan/eval_metrics.py:67-130 accuracy, mIOU): per-class counts of argmax(pred) ----------

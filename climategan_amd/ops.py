@@ -829,3 +829,27 @@ def resize_and_crop_u8(img: torch.Tensor, to: int = 640, out: Optional[torch.Ten
     _lib.check(lib.cgan_resize_crop_u8(_ptr(img), h, w, c, to, _ptr(taps[0][1]), taps[0][0], _ptr(taps[1][1]),
                                        taps[1][0], _ptr(out), _ptr(ws), ws_bytes, _stream()), "cgan_resize_crop_u8")
     return out
+
+
+def resize_u8(img: torch.Tensor, size) -> torch.Tensor:
+    """uint8 HWC device image -> fp32 [C, rows, cols] in [-1, 1] = to_m1_p1(resize(img, size, anti_aliasing=True)), the
+    keep_ratio branch of apply_events (apply_events.py:494-497, 502): no crop, no uint8 truncation."""
+    _need_cuda(img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] not in (1, 3, 4):
+        raise RuntimeError("resize_u8: a uint8 [H, W, C] image is expected, got %s %s" % (img.dtype, tuple(img.shape)))
+    img = img.contiguous()
+    h, w, c = img.shape
+    rows, cols = int(size[0]), int(size[1])
+    if rows <= 0 or cols <= 0:
+        raise RuntimeError("resize_u8: empty output size %s" % (size,))
+    taps = []
+    for scale in (h / rows, w / cols):
+        radius, wts = _gaussian_taps(max(0.0, (scale - 1.0) / 2.0))
+        taps.append((radius, None if wts is None else torch.from_numpy(wts).to(img.device)))
+    out = torch.empty((c, rows, cols), dtype=torch.float32, device=img.device)
+    lib = _lib.load()
+    ws_bytes = lib.cgan_resize_crop_u8_workspace_bytes(h, w, c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+    _lib.check(lib.cgan_resize_u8(_ptr(img), h, w, c, rows, cols, _ptr(taps[0][1]), taps[0][0], _ptr(taps[1][1]), taps[1][0],
+                                  _ptr(out), _ptr(ws), ws_bytes, _stream()), "cgan_resize_u8")
+    return out

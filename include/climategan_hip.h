@@ -476,6 +476,12 @@ size_t cgan_resize_crop_u8_workspace_bytes(int32_t h, int32_t w, int32_t c);
 int cgan_resize_crop_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int32_t to, const double* weights_rows,
                         int32_t radius_rows, const double* weights_cols, int32_t radius_cols, float* out_chw,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The keep_ratio branch of apply_events (apply_events.py:494-497, 502): to_m1_p1(resize(img, (rows, cols),
+ * anti_aliasing=True)) -- the same resize to an arbitrary extent (rows, cols from utils.to_128), no crop, no uint8
+ * truncation (the float image / 255).  out_chw fp32 [c][rows][cols]; same workspace. */
+int cgan_resize_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int32_t rows, int32_t cols,
+                   const double* weights_rows, int32_t radius_rows, const double* weights_cols, int32_t radius_cols,
+                   float* out_chw, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Validation metrics (climategan/eval_metrics.py:67-130 accuracy, mIOU; used by Trainer.eval_images, trainer.py:1706-1790):
  * per-class pixel counts of argmax_c(pred) against a label map.  pred: layout 0 = NHWC 16-bit [n][hw][cgan_cs(c)],

@@ -722,3 +722,16 @@ def to_m1_p1(img):
     if img.min() >= 0 and img.max() <= 1:
         return (img.astype(np.float32) - 0.5) * 2
     raise ValueError("Data range mismatch for image : ({}, {})".format(img.min(), img.max()))
+
+
+def resize_keep_ratio(img, max_im_width=-1):
+    """keep_ratio branch of apply_events.py:494-497 + 502: ``to_m1_p1(resize(img, to_128(img, w), anti_aliasing=True))``.
+    Without ``preserve_range`` skimage first scales uint8 to [0, 1] (img_as_float); the filter and the warp are linear, so
+    the restatement divides afterwards (differences: last-bit rounding of the float64 pipeline)."""
+    import numpy as np
+
+    h, w = img.shape[:2]
+    w_target = w if max_im_width < 0 else max_im_width
+    nw = int(w_target / 128) * 128
+    nh = int(nw * (h / w) / 128) * 128
+    return to_m1_p1(np.clip(skimage_resize_018(img, (nh, nw)) / 255.0, 0.0, 1.0))

@@ -238,3 +238,21 @@ def test_auto_resize_640_step():
     ref = F.interpolate(x.half().float(), (640, 640), mode="bilinear")
     assert got.shape == ref.shape and got.dtype == torch.float32
     assert (got - ref).abs().max().item() <= 2e-3
+
+
+def test_keep_ratio_flow():
+    """apply_events' keep_ratio branch end to end: photo -> to_128 resize on the device -> infer_all, one image per call
+    (apply_events.py:494-497: sizes differ between images, so the reference forces batch_size 1 there)."""
+    from climategan_amd import apply_events
+    from test_prep import photo
+
+    case = golden_cases()[NAME]
+    T = build_trainer(case)
+    T.opts.events.fire.kernel_size, T.opts.events.fire.kernel_sigma = 61, 30.5
+    for h, w in ((300, 420), (530, 400)):
+        x = apply_events.resize_keep_ratio(photo(h, w, h), -1)
+        nh, nw = apply_events.to_128(np.zeros((h, w, 3)), -1)
+        assert x.shape == (3, nh, nw)
+        out = T.infer_all(x, numpy=True, bin_value=0.5)
+        for k in ("flood", "wildfire", "smog"):
+            assert out[k].shape == (1, nh, nw, 3) and out[k].dtype == np.uint8

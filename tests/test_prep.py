@@ -80,3 +80,16 @@ def test_prepare_batch_feeds_infer_all_layout():
         apply_events.prepare_batch([np.zeros((10, 10, 4), np.uint8)], to=8)
     with pytest.raises(ValueError):
         apply_events.resize_and_crop(np.zeros((10, 10, 3), np.float32), 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,max_w", [(700, 900, -1), (1300, 1000, 640), (512, 768, -1), (400, 650, 1024)])
+def test_resize_keep_ratio_matches_oracle(h, w, max_w):
+    """apply_events' keep_ratio branch: multiples of 128, no crop, no uint8 truncation (float image)."""
+    from climategan_amd import apply_events
+    img = photo(h, w, 3 * h + w)
+    ref = cpu_ref.resize_keep_ratio(img, max_w)                                # HWC float32
+    got = apply_events.resize_keep_ratio(img, max_w).cpu().numpy().transpose(1, 2, 0)
+    nh, nw = apply_events.to_128(img, max_w)
+    assert got.shape == ref.shape == (nh, nw, 3) and nh % 128 == 0 and nw % 128 == 0
+    assert np.abs(got - ref).max() <= 3e-7                                      # float32 rounding of values in [-1, 1]
