@@ -28,6 +28,7 @@ struct WgradArgs {
   int kh, kw, stride, pad, dil;
   int h_out, w_out, npix;
   int nchunks, ci_blocks, co_blocks, splits, per_xcd;
+  int coop, co_pairs, n_pairs;     // cooperative 128 x 128 kernel: pairs of co blocks x pairs of N tiles
   int fold, cpt, tpt, tap_slots;   // tap folding for cin_s <= 32 (see wgrad_plan): 16-byte chunks per tap, taps per 64-wide tile, tap groups
   int dbg;     // debug ablation bits (tools/bench_wgrad.py): 1 = skip the atomics, 2 = skip the MFMAs
   int reflect; // 1: nn.ReflectionPad2d(pad) in front of the conv (index math instead of the zero page)
@@ -310,19 +311,217 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   }
 }
 
-// Second stage of the workspace path: dW += sum over pixel splits of the partial tiles.  One thread per f32x4 of a
-// tile; blockIdx.y strides the splits (G groups) so small-channel layers with hundreds of splits still fill the chip;
-// G > 1 finishes with (at most G-way contended) atomics, G == 1 with a plain read-modify-write.
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cooperative variant for large-pixel layers (w_out % 8 == 0, zero padding or folded upsample): one workgroup = a
+// 128 co x 128 column tile (2 co blocks x 2 N tiles), the four waves each own a 64 x 64 quadrant and SHARE the staged
+// slabs: per 64-pixel chunk wave 0 / 1 stage the dy slab of co half 0 / 1, wave 2 / 3 the x slab of N tile 0 / 1 (8 KiB
+// each), then every wave reads one dy and one x slab: 32 KiB of L2 -> LDS traffic per 128 MFMAs instead of per 64.
+// One barrier per chunk; a wave's quadrant is a complete tile (no cross-wave reduction).  Needs 4x the pixel splits of
+// the single-wave kernel for the same number of workgroups, i.e. 4x the partial-tile workspace: only layers with
+// enough pixels per split use it (wgrad_plan).
+constexpr int CHUNK2 = 64;                       // pixels per stage
+constexpr int SUB2 = CHUNK2 * 128;               // one sub-slab: 64 pixels x 64 channels x 2 B = 8 KiB
+constexpr int STAGE2 = 4 * SUB2;                 // dy half 0 | dy half 1 | x tile 0 | x tile 1
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int taps_n = p.kh * p.kw;
+  int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.per_xcd || item >= p.co_pairs * p.n_pairs * p.splits) return;
+  const int cop = item % p.co_pairs;
+  item /= p.co_pairs;
+  const int np = item % p.n_pairs;
+  const int split = item / p.n_pairs;
+  const int cpairs = p.fold ? 1 : (p.ci_blocks + 1) / 2;        // N-tile pairs per tap slot (normal layout)
+  // N tile (slot, cib) of pair member m
+  auto n_tile = [&](int m, int& slot, int& cib) {
+    if (p.fold) { slot = np * 2 + m; cib = 0; return slot < p.tap_slots; }
+    slot = np / cpairs;
+    cib = (np - slot * cpairs) * 2 + m;
+    return cib < p.ci_blocks;
+  };
+
+  // ---- staging role of this wave
+  const int prow = lane >> 3, qs = (lane & 7) ^ swz(prow), q8 = qs * 8;
+  const bool is_x = wave >= 2;
+  const int mem = wave & 1;
+  const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
+  const int hx = MODE == 1 ? (p.h_in >> 1) : p.h_in, wx = MODE == 1 ? (p.w_in >> 1) : p.w_in;
+  const unsigned row_b = (unsigned)wx * cin_b;
+  const __amdgpu_buffer_rsrc_t rs = is_x ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000)
+                                         : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  int lx = 0, ly = -(1 << 20);
+  unsigned lane_c = 0x80000000u, cch2 = 0;      // dy: lane constant (or the always-out-of-range marker); x, MODE 0: lane constant
+  if (!is_x) {
+    const int co = (cop * 2 + mem) * 64 + q8;
+    if ((cop * 2 + mem) < p.co_blocks && co < p.cout_s) lane_c = (unsigned)prow * cout_b + (unsigned)co * 2u;
+  } else {
+    int slot, cib, ky, kx, cch;
+    bool ok = n_tile(mem, slot, cib);
+    if (p.fold) {
+      const int tl = qs / p.cpt, tap_l = slot * p.tpt + tl;
+      ok = ok && tl < p.tpt && tap_l < taps_n;
+      const int tcl = ok ? tap_l : 0;
+      ky = tcl / p.kw;
+      kx = tcl - ky * p.kw;
+      cch = (qs - tl * p.cpt) * 8;
+    } else {
+      ky = slot / p.kw;
+      kx = slot - ky * p.kw;
+      cch = cib * 64 + q8;
+      ok = ok && cch < p.cin_s;
+    }
+    const int tap_y = ky * p.dil - p.pad, tap_x = kx * p.dil - p.pad;
+    lx = prow * p.stride + tap_x;
+    if (ok) ly = tap_y;
+    cch2 = (unsigned)cch * 2u;
+    lane_c = (unsigned)((tap_y * wx + lx) * (int)cin_b) + cch2;
+  }
+
+  // wave-uniform state of the 8 pieces (8 pixels each) of the next chunk to stage
+  int u_sx[8], u_sy[8], u_nh[8];
+  unsigned u_dy = (unsigned)(split * CHUNK2) * cout_b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int pix = split * CHUNK2 + i * 8;
+    const int r = pix / p.w_out;
+    u_sx[i] = (pix - r * p.w_out) * p.stride;
+    const int nn = r / p.h_out;
+    u_sy[i] = (r - nn * p.h_out) * p.stride;
+    u_nh[i] = nn * hx;
+  }
+  const int step = p.splits * CHUNK2;
+  const int step_r = step / p.w_out;
+  const int step_sx = (step - step_r * p.w_out) * p.stride;
+  const int step_n = step_r / p.h_out;
+  const int step_sy = (step_r - step_n * p.h_out) * p.stride;
+  const int step_nh = step_n * hx;
+  const int wrap_x = p.w_out * p.stride, wrap_y = p.h_out * p.stride;
+  const unsigned step_dy = (unsigned)step * cout_b;
+
+  auto issue = [&](int b) {
+    unsigned char* dst = smem + b * STAGE2 + wave * SUB2;
+    if (!is_x) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                                 u_dy + (unsigned)(i * 8) * cout_b + lane_c, 0, 0, 0);
+      u_dy += step_dy;
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int iy = u_sy[i] + ly, ix = u_sx[i] + lx;
+      const bool xv = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+      unsigned off;
+      if (MODE == 1) off = (unsigned)(u_nh[i] + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
+      else off = (unsigned)((u_nh[i] + u_sy[i]) * wx + u_sx[i]) * cin_b + lane_c;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                               xv ? off : 0xffffffffu, 0, 0, 0);
+      int sx = u_sx[i] + step_sx, sy = u_sy[i] + step_sy, nh = u_nh[i] + step_nh;
+      const bool cx = sx >= wrap_x;
+      sx = cx ? sx - wrap_x : sx;
+      sy = cx ? sy + p.stride : sy;
+      const bool cy = sy >= wrap_y;
+      sy = cy ? sy - wrap_y : sy;
+      nh = cy ? nh + hx : nh;
+      u_sx[i] = sx; u_sy[i] = sy; u_nh[i] = nh;
+    }
+  };
+
+  // ---- compute role: quadrant (co half wc, N tile wn)
+  const int wc = wave & 1, wn = wave >> 1;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (p.npix + CHUNK2 - 1) / CHUNK2;
+  int c = split, buf = 0;
+  if (c < nchunks) issue(0);
+  for (; c < nchunks; c += p.splits) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces landed, own fragment reads done
+    __syncthreads();                                              // everyone's pieces landed; the other buffer is free
+    if (c + p.splits < nchunks) issue(buf ^ 1);
+    const unsigned char* sdy = smem + buf * STAGE2 + wc * SUB2;
+    const unsigned char* sx = smem + buf * STAGE2 + (2 + wn) * SUB2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[4], fb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = tr_frag(sdy + ks * 32 * 128, a, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = tr_frag(sx + ks * 32 * 128, b, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb[b]), acc[a][b]);
+    }
+    buf ^= 1;
+  }
+
+  // ---- the quadrant is a complete 64 x 64 tile of this pixel split
+  const int cob = cop * 2 + wc;
+  int slot_c, cib_c;
+  const bool nt_ok = n_tile(wn, slot_c, cib_c);
+  if (cob >= p.co_blocks || !nt_ok) return;
+  if (p.ws) {
+    const int tiles_n = p.tap_slots * p.ci_blocks * p.co_blocks;
+    const int tile = (slot_c * p.ci_blocks + cib_c) * p.co_blocks + cob;
+    f32x4* wst = reinterpret_cast<f32x4*>(p.ws) + ((size_t)split * tiles_n + tile) * 1024;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) wst[(a * 4 + b) * 64 + lane] = acc[a][b];
+    return;
+  }
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    int tap, ci;
+    const bool col_ok = wgrad_column(p.fold, p.cpt, p.tpt, taps_n, p.cin, slot_c, cib_c, b * 16 + j, tap, ci);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cob * 64 + a * 16 + 4 * g + r;
+        if (co < p.cout && col_ok && !(p.dbg & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, acc[a][b][r]);
+      }
+  }
+}
+
+// Second stage of the workspace path: dW += sum over pixel splits of the partial tiles.  A block = 32 consecutive
+// f32x4 of a tile x 8 split lanes: each thread sums every 8th split, the 8 lanes meet in LDS, lane 0 does the
+// read-modify-write of dW.  No atomics (the first version finished its split groups with up-to-16-way contended
+// cross-XCD atomics, which cost more than the 65 MB of partial tiles they followed).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw,
                                                            int splits, int taps, int tap_slots, int ci_blocks,
                                                            int co_blocks, int cout, int cin, int fold, int cpt,
                                                            int tpt) {
+  __shared__ f32x4 red[8][32];
   const int tiles_n = tap_slots * ci_blocks * co_blocks;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= tiles_n * 1024) return;
+  const int el = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
   f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int sp = blockIdx.y; sp < splits; sp += gridDim.y) {
-    const f32x4 v = ws[(size_t)sp * tiles_n * 1024 + e];
+  if (e < tiles_n * 1024) {
+    const size_t stride = (size_t)tiles_n * 1024;
+#pragma unroll 4
+    for (int sp = kl; sp < splits; sp += 8) {
+      const f32x4 v = ws[(size_t)sp * stride + e];
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+  }
+  red[kl][el] = s;
+  __syncthreads();
+  if (kl != 0 || e >= tiles_n * 1024) return;
+#pragma unroll
+  for (int l = 1; l < 8; ++l) {
+    const f32x4 v = red[l][el];
     s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
   }
   int tile = e >> 10;
@@ -336,9 +535,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
   for (int r = 0; r < 4; ++r) {
     const int co = cob * 64 + (frag >> 2) * 16 + 4 * (lane >> 4) + r;
     if (co >= cout) continue;
-    float* dst = dw + ((size_t)co * cin + ci) * taps + tap;
-    if (gridDim.y > 1) atomicAdd(dst, s[r]);
-    else *dst += s[r];
+    dw[((size_t)co * cin + ci) * taps + tap] += s[r];
   }
 }
 
@@ -375,8 +572,10 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
-int g_wgrad_target = 0, g_wgrad_dbg = 0;
+int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 262144;
 }  // namespace
+
+extern "C" void cgan_debug_set_wgrad_coop_min_pixels(int v) { g_wgrad_coop_min_pix = v; }
 
 extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
   g_wgrad_target = target_workgroups > 0 ? target_workgroups : 0;
@@ -386,6 +585,7 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
 // Tiling of one weight-gradient call: N tiles (tap slots x ci blocks), M tiles (co blocks), pixel splits.
 struct WgradPlan {
   int fold, cpt, tpt, tap_slots, ci_blocks, co_blocks, splits;
+  int coop, co_pairs, n_pairs;
   long tiles() const { return (long)tap_slots * ci_blocks * co_blocks; }
 };
 
@@ -401,10 +601,18 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
   pl.tap_slots = pl.fold ? ceil_div(taps, pl.tpt) : taps;
   pl.ci_blocks = pl.fold ? 1 : ceil_div(cin_s, 64);
   const long npix = (long)d->n * d->h_out * d->w_out;
-  const int nchunks = (int)((npix + 127) / 128);
-  const long tiles = pl.tiles();
+  // cooperative 128 x 128 kernel: needs 2 co blocks and 2 N tiles to pair, rows of whole 8-pixel pieces, no reflect
+  // padding, and so many pixels that 4x the splits still leaves long pixel ranges (workspace grows with the splits)
+  pl.co_pairs = (pl.co_blocks + 1) / 2;
+  pl.n_pairs = pl.fold ? (pl.tap_slots + 1) / 2 : pl.tap_slots * ((pl.ci_blocks + 1) / 2);
+  // (odd block counts would leave a quarter of the quadrants idle: 128 -> 160 at 4 x 320^2 is 6 % slower that way)
+  pl.coop = ((pl.co_blocks % 2) == 0 && ((pl.fold ? pl.tap_slots : pl.ci_blocks) % 2) == 0 && (d->w_out % 8) == 0 &&
+             d->pad_mode != CGAN_PAD_REFLECT && (g_wgrad_dbg & 8) == 0 && (double)npix * cgan_cs(d->c_out) * 2.0 < 1.9e9 &&
+             npix >= (long)g_wgrad_coop_min_pix)
+                ? 1 : 0;
+  const int nchunks = (int)((npix + (pl.coop ? 63 : 127)) / (pl.coop ? 64 : 128));
+  const long tiles = pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles();
   // ~4 workgroups per CU for layers with many (tap, channel block) tiles or very long pixel ranges, ~2 otherwise
-  // (measured per layer shape with tools/bench_wgrad.py: the partial-tile workspace traffic grows with the splits)
   // (kernel durations by rocprofv3, tools/prof_wgrad.sh; 1x1 layers: ~2 workgroups per CU)
   const int target = g_wgrad_target > 0 ? g_wgrad_target
                                         : (taps == 1 && tiles < 512 ? 512 : ((tiles >= 512 || tiles <= 16) ? 2048 : 1024));
@@ -452,9 +660,10 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   const WgradPlan pl = wgrad_plan(d);
   a.ci_blocks = pl.ci_blocks; a.co_blocks = pl.co_blocks; a.splits = pl.splits;
   a.fold = pl.fold; a.cpt = pl.cpt; a.tpt = pl.tpt; a.tap_slots = pl.tap_slots;
+  a.coop = pl.coop; a.co_pairs = pl.co_pairs; a.n_pairs = pl.n_pairs;
   const int taps = d->kh * d->kw;
   a.dbg = g_wgrad_dbg;
-  const long items = (long)a.splits * pl.tiles();
+  const long items = (long)a.splits * (pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles());
   a.per_xcd = (int)((items + 7) / 8);
   CGAN_REQUIRE(items < (1L << 30), "conv2d_nhwc_bwd_weight: grid too large");
   const unsigned gx = (unsigned)a.per_xcd * 8;
@@ -484,17 +693,23 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     else if (mode == 1) { if (uni) WGRAD_LAUNCH(TT, 1, true); else WGRAD_LAUNCH(TT, 1, false); } \
     else { if (uni) WGRAD_LAUNCH(TT, 0, true); else WGRAD_LAUNCH(TT, 0, false); }                \
   } while (0)
-  if (d->dtype == CGAN_F16) WGRAD_MODE(F16); else WGRAD_MODE(BF16);
+  if (pl.coop) {
+    static_assert(2 * STAGE2 == 4 * WAVE_LDS, "both kernels use 64 KiB of LDS");
+    if (d->dtype == CGAN_F16) {
+      if (mode == 1) hipLaunchKernelGGL((conv_wgrad_coop_kernel<F16, 1>), dim3(gx), dim3(256), smem, s, a);
+      else hipLaunchKernelGGL((conv_wgrad_coop_kernel<F16, 0>), dim3(gx), dim3(256), smem, s, a);
+    } else {
+      if (mode == 1) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 1>), dim3(gx), dim3(256), smem, s, a);
+      else hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0>), dim3(gx), dim3(256), smem, s, a);
+    }
+  } else if (d->dtype == CGAN_F16) WGRAD_MODE(F16); else WGRAD_MODE(BF16);
 #undef WGRAD_MODE
 #undef WGRAD_LAUNCH
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
   if (a.ws) {
     const int elems = (int)pl.tiles() * 1024;
-    int groups = a.splits / 8;
-    groups = groups < 1 ? 1 : (groups > 16 ? 16 : groups);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(elems, 256), groups), dim3(256), 0, s,
-                       (const f32x4*)a.ws, a.dw, a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold,
-                       a.cpt, a.tpt);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(elems, 32)), dim3(256), 0, s, (const f32x4*)a.ws, a.dw, a.splits,
+                       taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt);
     CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(reduce)");
   }
   if (dbias) {

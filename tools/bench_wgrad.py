@@ -28,6 +28,10 @@ SHAPES = [
     ("painter 3x3 40->40 @640", 40, 40, 3, 1, 1, 1, 640),
     ("vgg 3x3 64->64 @640", 64, 64, 3, 1, 1, 1, 640),
     ("D 4x4s2 64->128 @320", 64, 128, 4, 2, 2, 1, 320),
+    ("spade gb 128->80 @640", 128, 80, 3, 1, 1, 1, 640),
+    ("spade gb 128->160 @320", 128, 160, 3, 1, 1, 1, 320),
+    ("vgg 3x3 128->128 @320", 128, 128, 3, 1, 1, 1, 320),
+    ("vgg 3x3 256->256 @160", 256, 256, 3, 1, 1, 1, 160),
 ]
 
 
@@ -47,7 +51,7 @@ def main():
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
         if args.only not in name:
             continue
-        bs = args.bs if H < 640 else max(args.bs // 3, 1)
+        bs = args.bs if H < 320 else max(args.bs // 3, 1)
         x = ops.NHWC(torch.randn(bs, H, H, cin, device="cuda").to(dt), cin)
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
         dy = ops.NHWC(torch.randn(bs, Ho, Ho, cout, device="cuda").to(dt), cout)
