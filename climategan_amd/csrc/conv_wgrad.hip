@@ -499,31 +499,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
 // f32x4 of a tile x 8 split lanes: each thread sums every 8th split, the 8 lanes meet in LDS, lane 0 does the
 // read-modify-write of dW.  No atomics (the first version finished its split groups with up-to-16-way contended
 // cross-XCD atomics, which cost more than the 65 MB of partial tiles they followed).
+// (KL = 1 for layers with <= 4 splits: 256 elements per block, no LDS step.)
+template <int KL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw,
                                                            int splits, int taps, int tap_slots, int ci_blocks,
                                                            int co_blocks, int cout, int cin, int fold, int cpt,
                                                            int tpt) {
-  __shared__ f32x4 red[8][32];
+  constexpr int EL = 256 / KL;
+  __shared__ f32x4 red[KL][EL];
   const int tiles_n = tap_slots * ci_blocks * co_blocks;
-  const int el = threadIdx.x & 31, kl = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;
+  const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+  const int e = blockIdx.x * EL + el;
   f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (e < tiles_n * 1024) {
     const size_t stride = (size_t)tiles_n * 1024;
 #pragma unroll 4
-    for (int sp = kl; sp < splits; sp += 8) {
+    for (int sp = kl; sp < splits; sp += KL) {
       const f32x4 v = ws[(size_t)sp * stride + e];
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
   }
-  red[kl][el] = s;
-  __syncthreads();
-  if (kl != 0 || e >= tiles_n * 1024) return;
+  if (KL > 1) {
+    red[kl][el] = s;
+    __syncthreads();
+    if (kl != 0) return;
 #pragma unroll
-  for (int l = 1; l < 8; ++l) {
-    const f32x4 v = red[l][el];
-    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    for (int l = 1; l < KL; ++l) {
+      const f32x4 v = red[l][el];
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
   }
+  if (e >= tiles_n * 1024) return;
   int tile = e >> 10;
   const int frag = (e >> 6) & 15, lane = e & 63;
   const int cob = tile % co_blocks;
@@ -602,13 +608,14 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
   pl.ci_blocks = pl.fold ? 1 : ceil_div(cin_s, 64);
   const long npix = (long)d->n * d->h_out * d->w_out;
   // cooperative 128 x 128 kernel: needs 2 co blocks and 2 N tiles to pair, rows of whole 8-pixel pieces, no reflect
-  // padding, and so many pixels that 4x the splits still leaves long pixel ranges (workspace grows with the splits)
+  // padding, and either so many pixels that 4x the splits still leaves long pixel ranges or so many tiles that the
+  // splits stay few (the partial-tile workspace grows with the splits)
   pl.co_pairs = (pl.co_blocks + 1) / 2;
   pl.n_pairs = pl.fold ? (pl.tap_slots + 1) / 2 : pl.tap_slots * ((pl.ci_blocks + 1) / 2);
   // (odd block counts would leave a quarter of the quadrants idle: 128 -> 160 at 4 x 320^2 is 6 % slower that way)
   pl.coop = ((pl.co_blocks % 2) == 0 && ((pl.fold ? pl.tap_slots : pl.ci_blocks) % 2) == 0 && (d->w_out % 8) == 0 &&
              d->pad_mode != CGAN_PAD_REFLECT && (g_wgrad_dbg & 8) == 0 && (double)npix * cgan_cs(d->c_out) * 2.0 < 1.9e9 &&
-             npix >= (long)g_wgrad_coop_min_pix)
+             (npix >= (long)g_wgrad_coop_min_pix || pl.tiles() >= 256))
                 ? 1 : 0;
   const int nchunks = (int)((npix + (pl.coop ? 63 : 127)) / (pl.coop ? 64 : 128));
   const long tiles = pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles();
@@ -708,8 +715,12 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
   if (a.ws) {
     const int elems = (int)pl.tiles() * 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(elems, 32)), dim3(256), 0, s, (const f32x4*)a.ws, a.dw, a.splits,
-                       taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt);
+    if (a.splits <= 4)
+      hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(ceil_div(elems, 256)), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
+                         a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(ceil_div(elems, 32)), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
+                         a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt);
     CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(reduce)");
   }
   if (dbias) {

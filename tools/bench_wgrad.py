@@ -42,11 +42,14 @@ def main():
     ap.add_argument("--bs", type=int, default=12)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--atomic", action="store_true")
+    ap.add_argument("--coop-min", type=int, default=-1, help="cgan_debug_set_wgrad_coop_min_pixels")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     lib = _lib.load()
     lib.cgan_debug_set_wgrad(ctypes.c_int(args.target), ctypes.c_int(args.dbg))
+    if args.coop_min >= 0:
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(args.coop_min))
     print("target %d dbg %d bs %d" % (args.target, args.dbg, args.bs))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
         if args.only not in name:
