@@ -17,6 +17,7 @@ reducer works on the parameter list:
 ``broadcast_parameters`` makes replicas identical at start (parameters AND buffers, incl. the spectral-norm ``u``/``v``
 vectors, which are parameters with ``requires_grad=False``).
 """
+import os
 from typing import List
 
 import torch
@@ -24,7 +25,11 @@ import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """More than one rank in the default process group -- or, for the single-GPU test of the RCCL code path
+    (tests/test_gpu_train.py), a one-rank group with CGAN_DDP_SINGLE_RANK_TEST=1."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CGAN_DDP_SINGLE_RANK_TEST") == "1"
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
@@ -49,7 +54,8 @@ class GradBucketReducer:
 
     def __init__(self, params, bucket_mb: float = 25.0):
         self.params = [p for p in params if p.requires_grad]
-        self.world = dist.get_world_size() if is_distributed() else 1
+        self.active = is_distributed()
+        self.world = dist.get_world_size() if self.active else 1
         cap = int(bucket_mb * 2 ** 20)
         self.buckets: List[_Bucket] = []
         cur, cur_bytes = [], 0
@@ -82,7 +88,7 @@ class GradBucketReducer:
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
-        if self.world == 1:
+        if not self.active:
             return
         b = self._bucket_of[id(p)]
         b.pending -= 1
@@ -92,7 +98,7 @@ class GradBucketReducer:
     def finish(self):
         """Wait for every bucket (launching the ones whose parameters received no gradient this step as zeros would be
         wrong: parameters without a gradient are skipped on every rank alike) and write the averages back."""
-        if self.world == 1:
+        if not self.active:
             self.reset()
             return
         for b in self.buckets:

@@ -325,3 +325,50 @@ def test_masker_train_step_runs():
     assert not torch.equal(T.G.encoder.layer4[2].conv3.weight.detach(), w0)
     assert not torch.equal(T.G.encoder.bn1.running_mean.detach(), rm0)
     assert not torch.equal(T.D["s"]["Advent"][0].module.weight_bar.detach(), dw0)
+
+
+def test_gradient_reducer_over_rccl_single_rank():
+    """The data-parallel path (broadcast of the replicas, bucketed all-reduce from post-accumulate-grad hooks, finish()
+    before extrapolation / step) on a ONE-rank RCCL group: the only way to run the RCCL code on a single-GPU box.  With
+    one rank the average is the identity, so the step must reproduce the reducer-free step (up to the run-to-run jitter
+    of the fp32 atomics in the bias-gradient and loss reductions)."""
+    import os
+    import torch.distributed as dist
+
+    case = golden_cases()[GNAME]
+    inp = {k: t(v).cuda() for k, v in case_inputs(GNAME, case).items()}
+    batch = {"rf": {"data": {"x": inp["x"], "m": inp["m"]}}}
+
+    def run():
+        T = build_trainer(case, torch.bfloat16)
+        outs = [T.train_step(batch) for _ in range(2)]
+        return T, outs
+
+    T0, ref = run()
+    assert T0.g_reducer is None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", CGAN_DDP_SINGLE_RANK_TEST="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        T1, got = run()
+        assert T1.g_reducer is not None and T1.g_reducer.active and len(T1.g_reducer.buckets) >= 1
+        assert all(b.work is None and b.pending == len(b.params) for b in T1.g_reducer.buckets)   # re-armed by finish()
+        for (g0, d0), (g1, d1) in zip(ref, got):
+            assert torch.allclose(g0, g1, rtol=2e-3, atol=1e-5) and torch.allclose(d0, d1, rtol=2e-3, atol=1e-5)
+        # the Masker trainer (17 G buckets at the default sizes, 3 discriminators) under the same group: every bucket
+        # of G and D must fill from the hooks or be completed by finish() -- a parameter that got no gradient while
+        # its bucket-mates did would raise
+        mcase = golden_cases()[MNAME]
+        TM = build_masker_trainer(mcase)
+        assert TM.g_reducer.active and len(TM.g_reducer.buckets) > 4
+        for _ in range(2):
+            g, d = TM.train_step(masker_batch(mcase))
+            assert torch.isfinite(g) and torch.isfinite(d)
+        for mod0, mod1 in ((T0.G, T1.G), (T0.D, T1.D)):
+            for (k, a), (_, b) in zip(mod0.state_dict().items(), mod1.state_dict().items()):
+                # Adam moves every weight by ~lr per update whatever the gradient's scale: tensors whose true gradient is
+                # zero (biases in front of an instance norm) follow the sign of rounding noise, so two runs may differ
+                # by a few lr (5e-5) there
+                assert torch.allclose(a.float(), b.float(), rtol=1e-3, atol=3e-4), k
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("CGAN_DDP_SINGLE_RANK_TEST", None)
