@@ -1,6 +1,8 @@
-"""Painter training step (G update + D update, ExtraAdam) throughput at the default config: 640x640, bs 8 per GPU,
-default Painter (latent 640, 7 up-samplings) and 3-scale PatchGAN, GAN + feature-matching + VGG losses.
-BASELINE metric M1 restricted to the Painter tasks (the Masker has no training path yet).
+"""Training-step throughput (G update + D update, ExtraAdam) at the default config, 640x640:
+--tasks p     Painter step, bs 8 per GPU: default Painter (latent 640, 7 up-samplings), 3-scale PatchGAN, GAN +
+              feature-matching + VGG losses;
+--tasks dsmp  the joint Masker + Painter step of BASELINE metric M1 (domains r, s, rf; --bs samples per domain).
+Also: --wgrad-table / --conv-table (per-shape tables of the conv calls of one step), --cprofile (host side).
 
 usage (GPU box): python tools/bench_train.py [--bs 8] [--steps 6] [--dtype bf16] [--no-vgg]
 """
