@@ -369,6 +369,7 @@ class Trainer:
             if self.has_painter and "rf" in multi_domain_batch:
                 g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
             g_loss.backward()
+            self._unscale_grads(self.G)
             if self.g_reducer is not None:
                 self.g_reducer.finish()                                 # before extrapolation AND step (trainer.py:678-683)
             if self.global_step % 2 == 0:
@@ -378,6 +379,17 @@ class Trainer:
         finally:
             self._restore_d_grad_flags()                                # trainer.py:971-973
         return g_loss.detach()
+
+    @staticmethod
+    def _unscale_grads(module):
+        """fp16 loss scaling (autograd.set_grad_scale): every loss kernel wrote its input gradient times GRAD_SCALE, so
+        the parameter gradients carry that factor; divide it out before the all-reduce / optimizer (one fused
+        multi-tensor multiply, nothing at the default scale of 1)."""
+        from . import autograd as ag
+        if ag.GRAD_SCALE != 1.0:
+            grads = [p.grad for p in module.parameters() if p.grad is not None]
+            if grads:
+                torch._foreach_mul_(grads, 1.0 / ag.GRAD_SCALE)
 
     def _restore_d_grad_flags(self):
         for name, p in self.D.named_parameters():
@@ -393,6 +405,7 @@ class Trainer:
         if self.has_masker and any(d != "rf" for d in multi_domain_batch):
             d_loss = d_loss + self.get_masker_d_loss(multi_domain_batch)
         d_loss.backward()
+        self._unscale_grads(self.D)
         if self.d_reducer is not None:
             self.d_reducer.finish()
         if self.global_step % 2 == 0:

@@ -372,3 +372,33 @@ def test_gradient_reducer_over_rccl_single_rank():
     finally:
         dist.destroy_process_group()
         os.environ.pop("CGAN_DDP_SINGLE_RANK_TEST", None)
+
+
+def test_fp16_loss_scale_is_divided_out():
+    """autograd.set_grad_scale(S): the activation gradients travel S times larger (fp16 range), the parameter gradients
+    the optimizer sees do not (Adam would hide a forgotten unscale: it is invariant to the gradient's scale)."""
+    from climategan_amd import autograd as ag
+
+    case = golden_cases()[GNAME]
+    inp = {k: t(v).cuda() for k, v in case_inputs(GNAME, case).items()}
+    batch = {"rf": {"data": {"x": inp["x"], "m": inp["m"]}}}
+
+    def d_grads(scale):
+        ag.set_grad_scale(scale)
+        try:
+            T = build_trainer(case, torch.float16)
+            seen = {}
+            T.d_opt.extrapolation = lambda: seen.update({n: p.grad.detach().clone() for n, p in T.D.named_parameters()
+                                                          if p.grad is not None})
+            T.update_D(batch)
+            return seen
+        finally:
+            ag.set_grad_scale(1.0)
+
+    g1, g64 = d_grads(1.0), d_grads(64.0)
+    assert g1.keys() == g64.keys() and len(g1) > 10
+    gmax = max(v.abs().max().item() for v in g1.values())
+    for k in g1:
+        a, b = g1[k].float(), g64[k].float()
+        # same magnitude (not 64x), up to 16-bit rounding; biases in front of an instance norm hold pure rounding noise
+        assert (a - b).abs().max().item() <= 0.1 * a.abs().max().item() + 1e-4 * gmax, k
