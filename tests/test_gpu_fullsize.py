@@ -76,3 +76,46 @@ def test_batch_equals_single_samples_and_state_advances(painter):
     assert d.max().item() <= 5e-2 and d.mean().item() <= 2e-3, (d.max().item(), d.mean().item())
     outside = (m == 0).expand_as(x)
     assert torch.equal(y[outside], x[outside])                          # paste: original pixels outside the mask
+
+
+def test_extra_adam_at_generator_scale():
+    """ExtraAdam over a parameter list of the default generator's size (105 M elements in ~1500 tensors, incl. tensors
+    past the 320-per-launch table limit): extrapolation then step against the update formula of the reference
+    (optim.py:242-291) written with torch ops on the device -- the oracle class is pinned on small tensors in
+    tests/test_gpu_optim.py; this checks the multi-launch bookkeeping at scale."""
+    from climategan_amd.optim import ExtraAdam
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sizes = [2048 * 512 * 9] * 6 + [256 * 256 * 9] * 120 + [1024 * 256] * 150 + [4096] * 900 + [7, 1, 33] * 100
+    params = [torch.nn.Parameter(torch.randn(n, device="cuda", generator=g) * 0.05) for n in sizes]
+    total = sum(sizes)
+    assert total > 100_000_000 and len(params) > 1400
+    lr, b1, b2, eps = 5e-5, 0.9, 0.999, 1e-8
+    opt = ExtraAdam(params, lr=lr, betas=(b1, b2))
+    p0 = [p.detach().clone() for p in params]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+
+    def ref_update(step, grads):
+        out = []
+        for i, gr in enumerate(grads):
+            m[i].mul_(b1).add_(gr, alpha=1 - b1)
+            v[i].mul_(b2).addcmul_(gr, gr, value=1 - b2)
+            step_size = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
+            out.append(-step_size * m[i] / (v[i].sqrt() + eps))
+        return out
+
+    g1 = [torch.randn(n, device="cuda", generator=g) * 1e-2 for n in sizes]
+    for p, gr in zip(params, g1):
+        p.grad = gr
+    opt.extrapolation()
+    u1 = ref_update(1, g1)
+    for p, a, u in zip(params, p0, u1):
+        assert (p.detach() - (a + u)).abs().max().item() <= 2e-7 + 2e-6 * lr
+    g2 = [torch.randn(n, device="cuda", generator=g) * 1e-2 for n in sizes]
+    for p, gr in zip(params, g2):
+        p.grad = gr
+    opt.step()
+    u2 = ref_update(2, g2)
+    worst = max((p.detach() - (a + u)).abs().max().item() for p, a, u in zip(params, p0, u2))
+    assert worst <= 2e-7 + 2e-6 * lr, worst
