@@ -146,10 +146,17 @@ def main():
     ap.add_argument("--no-vgg", action="store_true")
     ap.add_argument("--tasks", default="p", help="'p' (Painter step) or 'dsmp' (joint Masker + Painter step: domains r, s, rf)")
     ap.add_argument("--conv-table", action="store_true", help="per-shape table of the forward / data-gradient conv calls of one step")
+    ap.add_argument("--ddp-single", action="store_true",
+                    help="run under a ONE-rank RCCL group with the gradient reducers active (their single-GPU overhead)")
     ap.add_argument("--cprofile", action="store_true", help="host-side cProfile of one train step")
     ap.add_argument("--wgrad-table", action="store_true", help="per-shape table of the weight-gradient calls of one step")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    if args.ddp_single:
+        import os
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CGAN_DDP_SINGLE_RANK_TEST="1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     opts = default_opts()
     opts.tasks = list(args.tasks)
     if args.no_vgg:
