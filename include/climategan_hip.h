@@ -492,6 +492,10 @@ int cgan_resize_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int3
 int cgan_seg_counts(const void* pred, int32_t layout, int32_t dtype, int32_t n, int64_t hw, int32_t c,
                     const float* labels, unsigned long long* counts, void* stream);
 
+/* Not part of the ABI: the library also exports a few cgan_debug_set_* development knobs (kernel selection, ablation
+ * bits, split targets) used by tools/ and by the tests that run every kernel variant on the same cases.  They are
+ * process-global, not thread-safe, and may change between builds. */
+
 #ifdef __cplusplus
 }
 #endif
