@@ -1,0 +1,97 @@
+"""Seeded random-shape sweep of the convolution entry points (forward, data gradient, weight / bias gradient) through
+the C ABI against torch fp32 on 16-bit-rounded operands.  The kernel families pick different code paths by shape --
+general gather / 3x3 LDS tile / wide-layer GEMM, zero-insertion-free parity classes for strided data gradients, tap
+folding (cin_s <= 32), wave-uniform vs per-lane addressing (w_out % 8), the cooperative 128 x 128 weight-gradient tile,
+workspace vs atomic reduction, out-of-range buffer lanes for padding / tails -- so the sweep draws ragged sizes, odd
+channel counts, strides, dilations and paddings, and repeats the weight gradient with each development knob that forces
+or disables a path."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from climategan_amd import fill
+
+pytestmark = pytest.mark.gpu
+
+
+def q(a, dt):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dt).float()
+
+
+def rel_err(got, ref):
+    return (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+
+
+def draw_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(rng.choice([1, 3, 3, 3, 4, 5, 7]))
+        stride = int(rng.choice([1, 1, 1, 2])) if k > 1 else int(rng.choice([1, 1, 2]))
+        dil = int(rng.choice([1, 1, 2, 3])) if (k == 3 and stride == 1) else 1
+        pad = int(rng.choice([0, dil * (k // 2), 1])) if k > 1 else int(rng.choice([0, 0, 1]))
+        cin = int(rng.choice([1, 3, 4, 8, 11, 16, 20, 24, 32, 40, 64, 96, 128, 160, 256]))
+        cout = int(rng.choice([1, 3, 8, 20, 40, 64, 80, 128, 130, 256]))
+        B = int(rng.choice([1, 2, 3]))
+        H = int(rng.choice([5, 8, 9, 16, 17, 24, 31, 32, 40]))
+        W = int(rng.choice([5, 8, 11, 16, 24, 25, 32, 40, 48]))
+        eff = dil * (k - 1) + 1
+        if H + 2 * pad < eff or W + 2 * pad < eff:
+            continue
+        if cin * cout * k * k * B * H * W > 3e9:
+            continue
+        cases.append((cin, cout, k, stride, pad, dil, B, H, W))
+    return cases
+
+
+CASES = draw_cases(36, 20240928) + [
+    # shapes that satisfy the cooperative weight-gradient tile's conditions (even block counts, w_out % 8 == 0)
+    (128, 128, 3, 1, 1, 1, 2, 16, 16), (256, 128, 1, 1, 0, 1, 2, 8, 24), (8, 128, 3, 1, 1, 1, 2, 16, 16),
+    (128, 256, 3, 1, 2, 2, 1, 24, 16), (128, 128, 4, 2, 1, 1, 2, 32, 32),
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward_dgrad_wgrad(dt, case):
+    from climategan_amd import _lib, ops
+    cin, cout, k, stride, pad, dil, B, H, W = case
+    tol16 = 1e-3 if dt == torch.float16 else 8e-3
+    x = q(fill.uniform((B, cin, H, W), 100 + cin + H), dt).requires_grad_(True)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = q(fill.uniform((cout, cin, k, k), 200 + cout + k, -bound, bound), dt).requires_grad_(True)
+    b = torch.from_numpy(fill.uniform((cout,), 300 + cout, -bound, bound)).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    dy = q(fill.uniform(tuple(y.shape), 400 + cout + W), dt)
+    y.backward(dy)
+
+    xg = ops.nchw_to_nhwc(x.detach().cuda(), dt)
+    dyg = ops.nchw_to_nhwc(dy.cuda(), dt)
+    # forward (bias in the epilogue)
+    pw = ops.pack_conv_weight(w.detach().cuda(), b.detach().cuda(), dt)
+    yg = ops.conv2d(xg, pw, stride=stride, pad=pad, dilation=dil)
+    assert rel_err(ops.nhwc_to_nchw(yg).cpu(), y.detach()) <= tol16, "forward"
+    if ops.cs8(cout) != cout:
+        assert yg.t[..., cout:].abs().max().item() == 0
+    # data gradient
+    dx = ops.conv2d_bwd_data(dyg, w.detach().cuda(), (B, H, W), stride=stride, pad=pad, dilation=dil)
+    assert rel_err(ops.nhwc_to_nchw(dx).cpu(), x.grad) <= tol16, "dgrad"
+    # weight / bias gradient under every path selector: default; no tap folding; per-lane addressing; cooperative tile
+    # forced on small shapes; workspace-free atomic reduction
+    lib = _lib.load()
+    variants = [("default", 0, -1, True), ("no fold", 4, -1, True), ("per-lane addressing", 16, -1, True),
+                ("cooperative tile", 0, 0, True), ("single-wave tile", 8, -1, True), ("atomic reduction", 0, -1, False)]
+    try:
+        for name, dbg, coop_min, use_ws in variants:
+            lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(dbg))
+            lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 262144))
+            dw, db = ops.conv2d_bwd_weight(xg, dyg, tuple(w.shape), stride=stride, pad=pad, dilation=dil,
+                                           use_workspace=use_ws)
+            assert rel_err(dw.cpu(), w.grad) <= 3e-4, "wgrad (%s)" % name
+            assert rel_err(db.cpu(), b.grad) <= 3e-4, "bias grad (%s)" % name
+    finally:
+        lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(262144))
