@@ -297,9 +297,14 @@ def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
     bn.train()
     x = q(fill.uniform((B, c, h, w), 7104 + c, -2, 2), dt).requires_grad_(True)
     f = {"relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "none": lambda v: v}[act]
-    y = f(bn(x))
+    pre = bn(x)
+    y = f(pre)
     dy = q(fill.uniform((B, c, h, w), 7105), dt)
     y.backward(dy)
+    # The HIP backward recovers the activation mask from the stored 16-bit output: a pre-activation within the type's
+    # flush-to-zero range of the kink (x exactly at the batch mean: found by tests/test_gpu_norm_fuzz.py) lands on the
+    # other side of it.  Such elements are excluded; their effect on the channel's sums stays inside the tolerance.
+    kink_ok = torch.ones_like(pre, dtype=torch.bool) if act == "none" else pre.detach().abs() > 1e-5
 
     a = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act]
     xt = to_nhwc(x.detach(), dt).t.requires_grad_(True)
@@ -312,7 +317,8 @@ def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
     assert rel_err(back(ops.NHWC(out.detach(), c)), y.detach()) <= TOL[dt]
     assert rel_err(rm.cpu(), bn.running_mean) <= 1e-5 and rel_err(rv.cpu(), bn.running_var) <= 1e-5
     out.backward(to_nhwc(dy, dt).t)
-    assert rel_err(back(ops.NHWC(xt.grad, c)), x.grad) <= (4e-3 if dt == torch.float16 else 4e-2)
+    assert kink_ok.float().mean().item() > 0.999
+    assert rel_err(back(ops.NHWC(xt.grad, c)) * kink_ok, x.grad * kink_ok) <= (4e-3 if dt == torch.float16 else 4e-2)
     if affine:
         assert rel_err(g.grad.cpu(), bn.weight.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
         assert rel_err(b.grad.cpu(), bn.bias.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
