@@ -735,3 +735,64 @@ def resize_keep_ratio(img, max_im_width=-1):
     nw = int(w_target / 128) * 128
     nh = int(nw * (h / w) / 128) * 128
     return to_m1_p1(np.clip(skimage_resize_018(img, (nh, nw)) / 255.0, 0.0, 1.0))
+
+
+# ------------------------------------------------------------------------------------------------ masker losses (A19)
+def cross_entropy(logits, target):
+    """losses.py:106-112: nn.CrossEntropyLoss() on [N, C, H, W] logits and [N, H, W] class ids (mean over pixels)."""
+    lp = torch.log_softmax(logits, dim=1)
+    return -lp.gather(1, target.long().unsqueeze(1)).mean()
+
+
+def tv_loss(x, weight=1.0):
+    """losses.py:142-169: 2 w (sum dh^2 / count_h + sum dw^2 / count_w) / batch, counts = C (H-1) W and C H (W-1)."""
+    b, c, h, w = x.shape
+    h_tv = ((x[:, :, 1:, :] - x[:, :, :-1, :]) ** 2).sum()
+    w_tv = ((x[:, :, :, 1:] - x[:, :, :, :-1]) ** 2).sum()
+    return weight * 2 * (h_tv / (c * (h - 1) * w) + w_tv / (c * h * (w - 1))) / b
+
+
+def prob_2_entropy(prob):
+    """losses.py:453-458: -p log2(p + 1e-30) / log2(C)."""
+    import numpy as np
+
+    return -prob * torch.log2(prob + 1e-30) / np.log2(prob.shape[1])
+
+
+def minent_loss(pred, version=1, lambda_var=0.1):
+    """losses.py:172-196: mean entropy per pixel (v1); v2 adds lambda_var times the squared deviation from that mean."""
+    n, c, h, w = pred.shape
+    ent = prob_2_entropy(pred)
+    if version == 1:
+        return ent.sum() / (n * h * w)
+    dem = ent - ent.sum() / (n * h * w)
+    return (ent + lambda_var * dem * dem).sum() / (n * h * w)
+
+
+def ground_intersection_loss(pred, pseudo_ground):
+    """losses.py:444-450: mean of 1[(ground - pred) > 0.5]."""
+    return ((pseudo_ground - pred) > 0.5).float().mean()
+
+
+def advent_wgan(d_out, target):
+    """The WGAN branch of ADVENTAdversarialLoss (losses.py:498-499): -mean(y D + (1 - y)(1 - D))."""
+    return -(target * d_out + (1 - target) * (1 - d_out)).mean()
+
+
+def sigm_loss(prediction, target, gmweight=0.5, scale=4):
+    """losses.py:237-278 (MiDaS scale-and-shift-invariant loss): medians (torch.median: the LOWER middle element), mean
+    absolute deviations, residual R; 4-scale Sobel gradient-matching term.  Quirk reproduced: the Sobel filters are
+    expanded to [B, 1, 3, 3] and applied by F.conv2d to the 1-channel residual, so every image's maps are computed with
+    B identical output channels and the summed term carries a factor B."""
+    t_pred, t_targ = torch.median(prediction), torch.median(target)
+    s_pred, s_targ = (prediction - t_pred).abs().mean(), (target - t_targ).abs().mean()
+    R = (prediction - t_pred) / s_pred - (target - t_targ) / s_targ
+    b = prediction.shape[0]
+    num_pix = prediction.shape[-1] * prediction.shape[-2]
+    sobelx = torch.tensor([[1.0, 0, -1], [2, 0, -2], [1, 0, -1]]).expand(b, 1, 3, 3)
+    sobely = torch.tensor([[1.0, 2, 1], [0, 0, 0], [-1, -2, -1]]).expand(b, 1, 3, 3)
+    gm = 0
+    for k in range(scale):
+        R_ = F.interpolate(R, scale_factor=1 / 2 ** k)
+        gm = gm + F.conv2d(R_, sobelx).abs().sum() + F.conv2d(R_, sobely).abs().sum()
+    return 0.5 / num_pix * R.abs().sum() + gmweight / num_pix * gm

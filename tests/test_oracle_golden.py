@@ -145,3 +145,42 @@ def test_oracle_matches_golden_mask_spade_decoder():
         scale = max(np.abs(gold[k]).max(), 1e-6)
         err = np.abs(gold[k].astype(np.float64) - got[k].astype(np.float64)).max()
         assert err <= 1e-4 * scale, "%s/%s: max abs err %.3g (scale %.3g)" % (name, k, err, scale)
+
+
+def test_masker_loss_restatements_match_reference_golden():
+    """oracle.cpu_ref's loss restatements against the values and input gradients the reference's own loss classes
+    produced (fixture masker_losses, oracle/make_golden.py::run_reference_masker_losses)."""
+    import torch
+    from helpers import t
+    from oracle import cpu_ref
+    from oracle.make_golden import case_inputs
+
+    name = "masker_losses"
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+
+    def check(key, fn, leaf_name, half=False):
+        leaf = inp[leaf_name].clone()
+        if half:
+            leaf = leaf.half().float()
+        leaf.requires_grad_(True)
+        loss = fn(leaf)
+        assert abs(loss.item() - float(gold[key][0])) <= 1e-6 * max(1.0, abs(float(gold[key][0]))), key
+        if key + ".grad" in gold:
+            (g,) = torch.autograd.grad(loss, leaf)
+            ref = gold[key + ".grad"]
+            assert np.abs(g.numpy() - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-12) + 1e-9, key
+
+    check("crossent", lambda s: cpu_ref.cross_entropy(s, inp["s_target"]), "s_logits")
+    check("minent_v1", lambda s: cpu_ref.minent_loss(torch.softmax(s, dim=1)), "s_logits")
+    check("entropy_dada_sum", lambda s: (cpu_ref.prob_2_entropy(torch.softmax(s, dim=1)) * inp["d_pred"] * 0.37).sum(),
+          "s_logits")
+    check("bce", lambda m: torch.nn.functional.binary_cross_entropy_with_logits(m, inp["m_target"]), "m_logits")
+    check("tv", lambda m: cpu_ref.tv_loss(torch.sigmoid(m)), "m_logits")
+    check("minent_v2", lambda m: cpu_ref.minent_loss(torch.cat([torch.sigmoid(m), 1 - torch.sigmoid(m)], dim=1), 2, 0.1),
+          "m_logits")
+    assert cpu_ref.ground_intersection_loss(torch.sigmoid(inp["m_logits"]), inp["ground"]).item() == float(gold["gi"][0])
+    check("advent_wgan_0", lambda d: cpu_ref.advent_wgan(d, 0), "d_out")
+    check("advent_wgan_1", lambda d: cpu_ref.advent_wgan(d, 1), "d_out")
+    check("sigm", lambda d: cpu_ref.sigm_loss(d, inp["depth_target"]), "depth_pred", half=True)
