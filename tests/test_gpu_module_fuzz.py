@@ -90,3 +90,34 @@ def test_multiscale_discriminator_random_configurations(case):
             assert fa.shape == fb.shape
             scale = max(fb.abs().max().item(), 1e-6)
             assert (fa.cpu() - fb).abs().max().item() <= 2e-2 * scale, (tuple(fb.shape), scale)
+
+
+@pytest.mark.parametrize("H,W,B,seed", [(72, 104, 1, 301), (96, 64, 2, 302), (120, 88, 1, 303)])
+def test_masker_other_extents(H, W, B, seed):
+    """The full default Masker (ResNet-101 OS 8, DADA depth, DeepLab-v3+ seg with its 82x82-style padded ASPP output,
+    mask decoder) at extents other than the golden fixture's 128x160, against the oracle: feature-map sizes of strided
+    convs on non-multiples of 16, align_corners resizes to other targets, the mask decoder's x8 upsampling."""
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+    from helpers import masker_state_dict
+
+    case = {"seed": seed, "gain": 1.6}
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    G = create_generator(opts, device="cuda")
+    sd = masker_state_dict(case)
+    G.load_state_dict(sd, strict=True)
+    G.eval()
+    G.set_compute_dtype(torch.float16)
+    G.decoders["d"]._target_size = W // 4
+    G.decoders["s"].set_target_size((H // 4, W // 4))
+    x = t(fill.uniform((B, 3, H, W), seed + 5))
+    with torch.no_grad():
+        ref = cpu_ref.masker_forward(sd, x, (H // 4, W // 4), d_target=W // 4)
+        got = G.masker_forward(x.cuda())
+    for k in ("d", "s", "m"):
+        a, b = got[k].cpu(), ref[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        scale = max(b.abs().max().item(), 1e-6)
+        err = (a - b).abs()
+        assert err.max().item() <= 3e-2 * scale and err.mean().item() <= 4e-3 * scale, (k, err.max().item(), scale)
