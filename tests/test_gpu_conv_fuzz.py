@@ -95,3 +95,53 @@ def test_conv_forward_dgrad_wgrad(dt, case):
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(262144))
+
+
+def draw_mode_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.choice([3, 8, 20, 40, 64, 128])), int(rng.choice([3, 20, 64, 128, 130])), int(rng.choice([1, 2])),
+                    int(rng.choice([4, 8, 9, 12, 16])), int(rng.choice([4, 8, 10, 16, 20]))))
+    return out
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", draw_mode_cases(12, 99))
+def test_wgrad_upsample_and_reflect_modes(dt, case):
+    """The weight gradient's two other addressing modes: x stored at half resolution and read through the folded nearest
+    x2 upsample (SPADE ResNet blocks), and reflect padding (mask / depth decoder convs), each under the per-lane and the
+    wave-uniform addressing and with the cooperative tile forced."""
+    from climategan_amd import _lib, ops
+    cin, cout, B, h, w = case            # stored (half-resolution) extent for the upsample mode
+    lib = _lib.load()
+    xs = q(fill.uniform((B, cin, h, w), 500 + cin + h), dt)
+    wt = q(fill.uniform((cout, cin, 3, 3), 600 + cout, -0.1, 0.1), dt).requires_grad_(True)
+    # --- folded upsample
+    xu = F.interpolate(xs, scale_factor=2).requires_grad_(False)
+    y = F.conv2d(xu, wt, None, padding=1)
+    dy = q(fill.uniform(tuple(y.shape), 700 + w), dt)
+    y.backward(dy)
+    ref_up = wt.grad.clone()
+    wt.grad = None
+    # --- reflect padding (on the stored extent)
+    if h > 1 and w > 1:
+        y2 = F.conv2d(F.pad(xs, (1, 1, 1, 1), mode="reflect"), wt, None)
+        dy2 = q(fill.uniform(tuple(y2.shape), 800 + w), dt)
+        y2.backward(dy2)
+        ref_rf = wt.grad.clone()
+    xg = ops.nchw_to_nhwc(xs.cuda(), dt)
+    try:
+        for dbg, coop_min in ((0, -1), (16, -1), (0, 0)):
+            lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(dbg))
+            lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 262144))
+            dw, _ = ops.conv2d_bwd_weight(xg, ops.nchw_to_nhwc(dy.cuda(), dt), (cout, cin, 3, 3), pad=1, want_bias=False,
+                                          in_upsample=True)
+            assert rel_err(dw.cpu(), ref_up) <= 3e-4, ("upsample", dbg, coop_min)
+            if h > 1 and w > 1:
+                dw, _ = ops.conv2d_bwd_weight(xg, ops.nchw_to_nhwc(dy2.cuda(), dt), (cout, cin, 3, 3), pad=1,
+                                              want_bias=False, pad_mode=ops.PAD_REFLECT)
+                assert rel_err(dw.cpu(), ref_rf) <= 3e-4, ("reflect", dbg, coop_min)
+    finally:
+        lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(262144))
