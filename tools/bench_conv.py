@@ -47,7 +47,7 @@ def main():
         if args.only not in name:
             continue
         H = args.hw or H
-        x = ops.NHWC(torch.randn(args.bs, H, H, cin, device="cuda").to(dt), cin)
+        x = ops.NHWC(torch.randn(args.bs, H, H, ops.cs8(cin), device="cuda").to(dt), cin)   # storage channels: round_up(cin, 8)
         w = torch.randn(cout, cin, k, k, device="cuda") * 0.02
         pw = ops.pack_conv_weight(w, None, dt)
         for _ in range(3):

@@ -3,7 +3,7 @@
 # usage: prof_conv.sh "<shape substring>" "<cfg list>" [extra bench_conv args]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 for t in $2; do
-  rm -rf /tmp/pc; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o pc -- python tools/bench_conv.py --only "$1" --cfg $t $3 > /dev/null 2>&1
+  rm -rf /tmp/pc; timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o pc -- python tools/bench_conv.py --only "$1" --cfg $t $3 > /dev/null 2>&1
   python - "$t" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open('/tmp/pc/pc_kernel_stats.csv')))

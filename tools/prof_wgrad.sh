@@ -3,7 +3,7 @@
 # usage: prof_wgrad.sh "<shape substring>" "<target list>" [dbg]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 for t in $2; do
-  rm -rf /tmp/pw; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw -o pw -- python tools/bench_wgrad.py --only "$1" --target $t --dbg ${3:-0} ${4:-} > /dev/null 2>&1
+  rm -rf /tmp/pw; timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw -o pw -- python tools/bench_wgrad.py --only "$1" --target $t --dbg ${3:-0} ${4:-} > /dev/null 2>&1
   python - "$t" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open('/tmp/pw/pw_kernel_stats.csv')))
