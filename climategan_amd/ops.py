@@ -33,6 +33,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _need_cs8(what, *xs):
+    """The conv / norm kernels read round_up(c, 8) storage channels per pixel; only the conditioning image of the SPADE
+    kernels is stored with round_up(c, 4)."""
+    for x in xs:
+        if x is not None and x.cs != cs8(x.c):
+            raise RuntimeError("%s: tensor with %d logical channels must be stored with %d channels, got %d"
+                               % (what, x.c, cs8(x.c), x.cs))
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -390,6 +399,7 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
            residual: Optional[NHWC] = None, in_upsample=False, residual_upsample=False) -> NHWC:
     """y = act(conv(x) + bias + residual) on NHWC tensors; x may be read through a folded x2 nearest upsample."""
     _need_cuda(x.t)
+    _need_cs8("conv2d", x, residual)
     if x.c != pw.c_in:
         raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.c, pw.c_in))
     if x.t.dtype != pw.dtype:
@@ -429,6 +439,7 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
                               sigma=sigma)
         return reflect_pad_bwd(dxp, pad)
     _need_cuda(dy.t, w, sigma)
+    _need_cs8("conv2d_bwd_data", dy)
     w = w.detach().contiguous().float()
     c_out, c_in, kh, kw = w.shape
     n, h_in, w_in = x_shape
@@ -466,6 +477,7 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
     """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given.
     ``in_upsample``: x is the stored (half-resolution) tensor the forward read through the folded x2 upsample."""
     _need_cuda(x.t, dy.t, dw, dbias)
+    _need_cs8("conv2d_bwd_weight", x, dy)
     c_out, c_in, kh, kw = w_shape
     h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
     d = _conv_desc(x.dtype_id, x.n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dilation, pad_mode,
