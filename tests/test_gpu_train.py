@@ -346,7 +346,11 @@ def test_gradient_reducer_over_rccl_single_rank():
 
     T0, ref = run()
     assert T0.g_reducer is None
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", CGAN_DDP_SINGLE_RANK_TEST="1")
+    import socket
+    with socket.socket() as sk:                       # a free port: nothing else may be listening on a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CGAN_DDP_SINGLE_RANK_TEST="1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         T1, got = run()

@@ -155,7 +155,11 @@ def main():
     if args.ddp_single:
         import os
         import torch.distributed as dist
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CGAN_DDP_SINGLE_RANK_TEST="1")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CGAN_DDP_SINGLE_RANK_TEST="1")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     opts = default_opts()
     opts.tasks = list(args.tasks)
