@@ -7,6 +7,9 @@ and (b) the reported ``cpu_baseline`` in ``bench.py`` -- never on the product pa
 
 Pinned by: tests/test_oracle_golden.py (committed vectors produced by the real reference) and
 tests/test_oracle_vs_reference.py (direct comparison with the imported reference, dev container only).
+Parity UNPINNED for two functions whose arithmetic lives in third-party libraries that are neither in the reference tree
+nor in this image: ``add_fire`` (kornia / torchvision calls of fire.py) and ``skimage_resize_018`` (scikit-image 0.18.3
+``resize`` behind apply_events.resize_and_crop); both say so in their docstrings and DESIGN.md section 3.
 """
 from typing import Dict, List, Optional, Tuple
 
