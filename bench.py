@@ -296,6 +296,36 @@ def train_block(train_steps, rank, world, device, dtype, dist, barrier):
             "global_batch_per_domain": world * bs, "losses_last_step": losses}
 
 
+def infer_block(steps, rank, world, device, dist, barrier):
+    """Supplementary: BASELINE metric M2 -- the apply_events inference loop (Trainer.infer_all: Masker + flood painter
+    + wildfire + smog, uint8 outputs copied to the host), 640x640, 16 images per GPU, fp16; images/s over all ranks."""
+    from climategan_amd import fill
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    bs = 16
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    T = Trainer(opts, device=device).setup(inference=True)
+    shapes = {k: tuple(v.shape) for k, v in T.G.state_dict().items()}
+    T.G.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=0, gain=1.6).items()})
+    T.G.set_compute_dtype(torch.float16)
+    x = torch.from_numpy(fill.uniform((bs, 3, H, W), 3000 + rank)).to(device)
+    out = {}
+
+    def step():
+        out.update(T.infer_all(x, numpy=True, bin_value=0.5, half=True))
+
+    for _ in range(2):
+        step()
+    elapsed = max_over_ranks(timed_steps(step, steps, 0, barrier), dist, device)
+    assert set(out) >= {"flood", "wildfire", "smog"} and out["flood"].shape == (bs, H, W, 3)
+    return {"workload": "apply_events inference (Trainer.infer_all: flood + wildfire + smog, uint8 results on the host), "
+                        "640x640, 16 images per GPU, fp16",
+            "images_per_s": round(world * bs * steps / elapsed, 2), "ms_per_batch": round(elapsed / steps * 1e3, 2),
+            "steps": steps, "warmup": 2}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +333,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--infer-steps", type=int, default=3,
+                    help="timed batches of the supplementary apply_events inference measurement (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="timed steps of the supplementary joint G+D training-step measurement (0 = skip)")
     args = ap.parse_args()
@@ -402,9 +434,18 @@ def main():
             emit({"error": "supplementary train block did not finish within %d s" % TRAIN_BLOCK_TIMEOUT_S})
             os._exit(0)
 
-    train = None
-    if args.train_steps > 0:
+    train = infer = None
+    if args.train_steps > 0 or args.infer_steps > 0:
         threading.Thread(target=watchdog, daemon=True).start()
+    if args.infer_steps > 0:
+        try:
+            infer = infer_block(args.infer_steps, rank, world, device, dist, barrier)
+        except Exception as e:
+            infer = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    if rank == 0:
+        res["apply_events"] = infer
+    if args.train_steps > 0:
         try:
             train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier)
         except Exception as e:  # the main line must survive a failure of the supplementary block
