@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-vgg", action="store_true")
     ap.add_argument("--tasks", default="p", help="'p' (Painter step) or 'dsmp' (joint Masker + Painter step: domains r, s, rf)")
     ap.add_argument("--conv-table", action="store_true", help="per-shape table of the forward / data-gradient conv calls of one step")
+    ap.add_argument("--only", default="", choices=["", "G", "D"], help="time / profile only update_G or only update_D")
     ap.add_argument("--ddp-single", action="store_true",
                     help="run under a ONE-rank RCCL group with the gradient reducers active (their single-GPU overhead)")
     ap.add_argument("--cprofile", action="store_true", help="host-side cProfile of one train step")
@@ -217,10 +218,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         a = time.perf_counter()
-        T.update_G(batch)
+        if args.only != "D":
+            T.update_G(batch)
         torch.cuda.synchronize()
         b = time.perf_counter()
-        T.update_D(batch)
+        if args.only != "G":
+            T.update_D(batch)
         torch.cuda.synchronize()
         c = time.perf_counter()
         T.global_step += 1
