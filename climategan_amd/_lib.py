@@ -81,6 +81,7 @@ _SIGNATURES = {
     "cgan_instnorm_stats_workspace_bytes": (C.c_size_t, [C.POINTER(NormStatsDesc)]),
     "cgan_instnorm_stats": (C.c_int, [_P, _P, _P, C.POINTER(NormStatsDesc), _P, C.c_size_t, _P]),
     "cgan_norm_act_apply": (C.c_int, [_P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P]),
+    "cgan_norm_add_act_apply": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P]),
     "cgan_spade_packed_weight_bytes": (C.c_size_t, [C.POINTER(SpadeDesc)]),
     "cgan_spade_pack_weights": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
     "cgan_spade_fused_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
@@ -113,7 +114,7 @@ _SIGNATURES = {
                                              C.c_size_t, _P]),
     "cgan_bn_train_prepare": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "cgan_batchnorm_act_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
-    "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+    "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_float, _P, C.c_size_t, _P]),
     "cgan_bce_logits_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "cgan_l1_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),

@@ -189,11 +189,13 @@ class MaxPool2x2Fn(torch.autograd.Function):
 
 
 class BatchNormActFn(torch.autograd.Function):
-    """out = act(batch_norm(x)) in TRAINING mode (batch statistics over n, h, w; running statistics updated in place,
-    momentum / unbiased variance as nn.BatchNorm2d).  gamma / beta may be None (affine=False)."""
+    """out = act(batch_norm(x) [+ residual]) in TRAINING mode (batch statistics over n, h, w; running statistics
+    updated in place, momentum / unbiased variance as nn.BatchNorm2d).  gamma / beta may be None (affine=False).
+    The residual (the bottleneck's skip connection, resnet101_v3.py:62-70) rides in the apply kernel; its gradient
+    dy * act'(out) is a second output of the backward's apply kernel."""
 
     @staticmethod
-    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None):
+    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None, res_t=None):
         from . import _lib
         lib = _lib.load()
         n, h, w, cs = x_t.shape
@@ -209,8 +211,14 @@ class BatchNormActFn(torch.autograd.Function):
             ops._ptr(x_t), ops._ptr(gamma), ops._ptr(beta), float(momentum), ops._ptr(running_mean),
             ops._ptr(running_var), ops._ptr(nbt), ops._ptr(mean), ops._ptr(rstd), ops._ptr(mean_f), ops._ptr(rstd_f),
             C.byref(d), ops._ptr(ws), ws_bytes, ops._stream()), "cgan_batchnorm_train_stats")
-        out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope).t.view(n, h, w, cs)
+        res = None
+        if res_t is not None:
+            if res_t.shape != x_t.shape:
+                raise ValueError("BatchNormActFn: residual %s does not match %s" % (tuple(res_t.shape), tuple(x_t.shape)))
+            res = ops.NHWC(res_t.contiguous().view(1, npix, 1, cs), c)
+        out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope, residual=res).t.view(n, h, w, cs)
         ctx.cfg = (c, act, slope)
+        ctx.has_res = res_t is not None
         ctx.save_for_backward(x_t, out, mean, rstd, gamma)
         return out
 
@@ -224,14 +232,20 @@ class BatchNormActFn(torch.autograd.Function):
         nbytes = lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
         dx = torch.empty_like(x_t)
+        want_res = ctx.has_res and ctx.needs_input_grad[11]
+        dy_t = dy_t.contiguous()
+        if want_res and act == ops.ACT_NONE:
+            dres = dy_t                                       # no activation: the residual's gradient is dy itself
+        else:
+            dres = torch.empty_like(x_t) if want_res else None
         dg = db = None
         if gamma is not None:
             dg, db = torch.zeros((2, c), dtype=torch.float32, device=x_t.device).unbind(0)   # one fill for both
         _lib.check(lib.cgan_batchnorm_act_bwd(
-            ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t.contiguous()), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
-            ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._DT[x_t.dtype], n * h * w, c, act, slope, ops._ptr(ws), nbytes,
-            ops._stream()), "cgan_batchnorm_act_bwd")
-        return dx, dg, db, None, None, None, None, None, None, None, None
+            ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
+            ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._ptr(dres) if dres is not None and dres is not dy_t else None,
+            ops._DT[x_t.dtype], n * h * w, c, act, slope, ops._ptr(ws), nbytes, ops._stream()), "cgan_batchnorm_act_bwd")
+        return dx, dg, db, None, None, None, None, None, None, None, None, dres
 
 
 class BceLogitsFn(torch.autograd.Function):

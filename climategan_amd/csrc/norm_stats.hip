@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
 template <typename T>
 __global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __restrict__ x,
                                                              const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, uint16_t* __restrict__ y,
-                                                             int hw, int cs, int c, int act, float slope) {
+                                                             const float* __restrict__ rstd,
+                                                             const uint16_t* __restrict__ res,
+                                                             uint16_t* __restrict__ y, int hw, int cs, int c, int act,
+                                                             float slope) {
   const int cg_total = cs / 8;
   const int tpp = cg_total < 256 ? cg_total : 256;   // threads per pixel
   const int rows = 256 / tpp;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __r
   const int n = blockIdx.y;
   const uint16_t* xn = x + (size_t)n * hw * cs;
   uint16_t* yn = y + (size_t)n * hw * cs;
+  const uint16_t* rn = res ? res + (size_t)n * hw * cs : nullptr;
   for (int cg = cgl; cg < cg_total; cg += tpp) {
     float m[8], r[8];
 #pragma unroll
@@ -184,13 +187,16 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __r
     for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
       const size_t off = (size_t)p * cs + cg * 8;
       const u32x4 v = *reinterpret_cast<const u32x4*>(xn + off);
+      u32x4 rv = {0u, 0u, 0u, 0u};                        // 16-bit zeros: the residual term vanishes
+      if (rn) rv = *reinterpret_cast<const u32x4*>(rn + off);
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a, b;
+        float a, b, ra, rb;
         unpack2<T>(v[e], a, b);
-        a = act_apply((a - m[2 * e]) * r[2 * e], act, slope);
-        b = act_apply((b - m[2 * e + 1]) * r[2 * e + 1], act, slope);
+        unpack2<T>(rv[e], ra, rb);
+        a = act_apply((a - m[2 * e]) * r[2 * e] + ra, act, slope);
+        b = act_apply((b - m[2 * e + 1]) * r[2 * e + 1] + rb, act, slope);
         if (cg * 8 + 2 * e >= c) a = 0.f;
         if (cg * 8 + 2 * e + 1 >= c) b = 0.f;
         o[e] = pack2<T>(a, b);
@@ -277,8 +283,9 @@ extern "C" int cgan_batchnorm_train_stats(const void* x, const float* gamma, con
   return stats_impl(x, batch_mean, batch_rstd, d, workspace, workspace_bytes, stream, bn);
 }
 
-extern "C" int cgan_norm_act_apply(const void* x, const float* mean, const float* rstd, void* y,
-                                   const CganNormStatsDesc* d, int32_t act, float act_slope, void* stream) {
+extern "C" int cgan_norm_add_act_apply(const void* x, const float* mean, const float* rstd, const void* residual,
+                                       void* y, const CganNormStatsDesc* d, int32_t act, float act_slope,
+                                       void* stream) {
   int rc = check(d);
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(x && mean && rstd && y, "norm_act_apply: null pointer");
@@ -294,10 +301,15 @@ extern "C" int cgan_norm_act_apply(const void* x, const float* mean, const float
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CGAN_F16)
     hipLaunchKernelGGL(norm_act_apply_kernel<F16>, dim3((unsigned)bx, d->n), dim3(256), 0, s, (const uint16_t*)x, mean,
-                       rstd, (uint16_t*)y, d->hw, cs, d->c, act, act_slope);
+                       rstd, (const uint16_t*)residual, (uint16_t*)y, d->hw, cs, d->c, act, act_slope);
   else
     hipLaunchKernelGGL(norm_act_apply_kernel<BF16>, dim3((unsigned)bx, d->n), dim3(256), 0, s, (const uint16_t*)x, mean,
-                       rstd, (uint16_t*)y, d->hw, cs, d->c, act, act_slope);
+                       rstd, (const uint16_t*)residual, (uint16_t*)y, d->hw, cs, d->c, act, act_slope);
   CGAN_CHECK_LAUNCH("norm_act_apply");
   return CGAN_OK;
+}
+
+extern "C" int cgan_norm_act_apply(const void* x, const float* mean, const float* rstd, void* y,
+                                   const CganNormStatsDesc* d, int32_t act, float act_slope, void* stream) {
+  return cgan_norm_add_act_apply(x, mean, rstd, nullptr, y, d, act, act_slope, stream);
 }

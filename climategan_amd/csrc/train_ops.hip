@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
                                                            const uint16_t* __restrict__ dy, const float* __restrict__ coef,
-                                                           uint16_t* __restrict__ dx, long npix, int cs, int act,
-                                                           float slope) {
+                                                           uint16_t* __restrict__ dx, uint16_t* __restrict__ dz_out,
+                                                           long npix, int cs, int act, float slope) {
   const int cg_total = cs / 8;
   const int tpp = cg_total < 256 ? cg_total : 256;   // threads per pixel
   const int rows = 256 / tpp;
@@ -379,22 +379,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
       const u32x4 vx = *reinterpret_cast<const u32x4*>(x + off);
       const u32x4 vo = *reinterpret_cast<const u32x4*>(out + off);
       const u32x4 vg = *reinterpret_cast<const u32x4*>(dy + off);
-      u32x4 r;
+      u32x4 r, z;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float xv[2], ov[2], gv[2], res[2];
+        float xv[2], ov[2], gv[2], res[2], dzv[2];
         unpack2<T>(vx[e], xv[0], xv[1]);
         unpack2<T>(vo[e], ov[0], ov[1]);
         unpack2<T>(vg[e], gv[0], gv[1]);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int k = 2 * e + hh;
-          const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
-          res[hh] = A[k] * dz + B[k] * xv[hh] + Cc[k];
+          dzv[hh] = gv[hh] * act_grad_from_out(ov[hh], act, slope);
+          res[hh] = A[k] * dzv[hh] + B[k] * xv[hh] + Cc[k];
         }
         r[e] = pack2<T>(res[0], res[1]);
+        z[e] = pack2<T>(dzv[0], dzv[1]);
       }
       *reinterpret_cast<u32x4*>(dx + off) = r;
+      if (dz_out) *reinterpret_cast<u32x4*>(dz_out + off) = z;   // the fused residual branch's gradient
     }
   }
 }
@@ -591,8 +593,8 @@ extern "C" size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c) {
 
 extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
                                       const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                                      int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+                                      void* dz_out, int32_t dtype, int64_t npix, int32_t c, int32_t act,
+                                      float act_slope, void* workspace, size_t workspace_bytes, void* stream) {
   CGAN_REQUIRE(x && out && dy && batch_mean && batch_rstd && dx && workspace, "batchnorm_act_bwd: null pointer");
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "batchnorm_act_bwd: bad dtype %d", dtype);
   CGAN_REQUIRE(npix > 0 && c > 0, "batchnorm_act_bwd: bad shape");
@@ -623,8 +625,8 @@ extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void
   long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x,
-             (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, (uint16_t*)dx, (long)npix, cs, act,
-             act_slope);
+             (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, (uint16_t*)dx, (uint16_t*)dz_out, (long)npix,
+             cs, act, act_slope);
   CGAN_CHECK_LAUNCH("batchnorm_act_bwd");
   return CGAN_OK;
 }

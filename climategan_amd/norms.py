@@ -157,14 +157,17 @@ def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.N
     return ops.conv2d(x, pw, stride=conv.stride[0], pad=conv.padding[0], dilation=conv.dilation[0], **kw)
 
 
+FUSE_BN_RESIDUAL = True      # relu(bn3(.) + residual) in one apply pass (and one backward apply pass)
+
+
 def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mode=ops.PAD_ZERO, pad=None, **kw) -> ops.NHWC:
     """``act(bn(conv(x)) + residual)``; ``bn`` may be None.
 
     * inference (no gradient wanted, BatchNorm in eval mode): the BatchNorm is folded into the conv weights (the same
       algebra as the reference's ``--fuse`` path, bn_fusion.py:121-132) and everything rides in the conv epilogue;
     * training (BatchNorm in training mode and / or a gradient wanted): conv (``autograd.ConvFn``) -> batch-statistics
-      BatchNorm + activation (``autograd.BatchNormActFn``, running statistics updated like nn.BatchNorm2d) -> residual
-      add + activation (``autograd.AddActFn``), each with its HIP backward."""
+      BatchNorm + residual add + activation in one apply pass (``autograd.BatchNormActFn``, running statistics
+      updated like nn.BatchNorm2d), each with its HIP backward."""
     train_bn = bn is not None and bn.training
     grad = needs_grad(conv, x.t) or (bn is not None and needs_grad(bn))
     p = conv.padding[0] if pad is None else pad
@@ -187,7 +190,6 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
         raise NotImplementedError("climategan_amd: an eval-mode BatchNorm under autograd has no HIP backward (the "
                                   "reference trains with BatchNorm in training mode)")
     from .autograd import BatchNormActFn
-    from . import functional as Fn
 
     act, slope, residual = kw.pop("act", ops.ACT_NONE), kw.pop("slope", 0.2), kw.pop("residual", None)
     if kw.get("in_upsample") or kw.get("residual_upsample"):
@@ -199,12 +201,21 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
         return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0],
                            dict(act=act, slope=slope, residual=residual, pad_mode=pad_mode))
     y = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0], dict(pad_mode=pad_mode))
-    bn_act = act if residual is None else ops.ACT_NONE
+    if residual is not None and not FUSE_BN_RESIDUAL:              # A/B switch for tools / tests: the unfused tail
+        from . import functional as Fn
+        out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                                     bn.running_mean, bn.running_var, y.c, bn.eps,
+                                     bn.momentum if bn.momentum is not None else 0.1, ops.ACT_NONE, slope,
+                                     bn.num_batches_tracked if bn.track_running_stats else None)
+        return Fn.add_act(ops.NHWC(out_t, y.c), residual, act, slope)
+    if residual is not None and (residual.c != y.c or residual.t.shape != y.t.shape):
+        raise ValueError("conv_bn_forward: residual %s does not match the conv output %s"
+                         % (tuple(residual.t.shape), tuple(y.t.shape)))
     out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.running_mean,
-                                 bn.running_var, y.c, bn.eps, bn.momentum if bn.momentum is not None else 0.1, bn_act,
-                                 slope, bn.num_batches_tracked if bn.track_running_stats else None)   # counter += 1 in-kernel
-    out = ops.NHWC(out_t, y.c)
-    return out if residual is None else Fn.add_act(out, residual, act, slope)
+                                 bn.running_var, y.c, bn.eps, bn.momentum if bn.momentum is not None else 0.1, act,
+                                 slope, bn.num_batches_tracked if bn.track_running_stats else None,   # counter += 1 in-kernel
+                                 residual.t if residual is not None else None)
+    return ops.NHWC(out_t, y.c)
 
 
 class SPADE(nn.Module):

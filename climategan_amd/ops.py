@@ -516,13 +516,20 @@ def instnorm_stats(x: NHWC, eps: float = 1e-5):
     return mean, rstd
 
 
-def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2) -> NHWC:
+def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2, residual: NHWC = None) -> NHWC:
+    """y = act((x - mean) * rstd [+ residual])."""
     _need_cuda(x.t, mean, rstd)
     d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, 0.0)
     y = torch.empty_like(x.t)
     lib = _lib.load()
-    _lib.check(lib.cgan_norm_act_apply(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(y), C.byref(d), act, slope, _stream()),
-               "cgan_norm_act_apply")
+    if residual is not None:
+        _need_cuda(residual.t)
+        if residual.t.shape != x.t.shape or residual.t.dtype != x.t.dtype or not residual.t.is_contiguous():
+            raise ValueError("norm_act_apply: the residual must match x (shape %s, dtype %s, contiguous)"
+                             % (tuple(x.t.shape), x.t.dtype))
+    _lib.check(lib.cgan_norm_add_act_apply(_ptr(x.t), _ptr(mean), _ptr(rstd),
+                                           _ptr(residual.t) if residual is not None else None, _ptr(y), C.byref(d),
+                                           act, slope, _stream()), "cgan_norm_add_act_apply")
     return NHWC(y, x.c)
 
 

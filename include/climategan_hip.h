@@ -138,6 +138,10 @@ int cgan_instnorm_stats(const void* x, float* mean, float* rstd, const CganNormS
  * climategan/discriminator.py:113-154) */
 int cgan_norm_act_apply(const void* x, const float* mean, const float* rstd, void* y, const CganNormStatsDesc* d,
                         int32_t act, float act_slope, void* stream);
+/* y = act((x - mean) * rstd + residual): the tail of a ResNet bottleneck, relu(bn3(conv3(.)) + residual)
+ * (climategan/deeplab/resnet101_v3.py:43-72), in one pass; residual (same layout as x) may be NULL. */
+int cgan_norm_add_act_apply(const void* x, const float* mean, const float* rstd, const void* residual, void* y,
+                            const CganNormStatsDesc* d, int32_t act, float act_slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused SPADE (climategan/norms.py:146-186):
@@ -292,8 +296,9 @@ int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const f
  *  bn_train_prepare   folds gamma / beta into the (mean', rstd') pair cgan_norm_act_apply consumes and updates the
  *                     running statistics (momentum, unbiased variance) as nn.BatchNorm2d does; count = n*h*w;
  *                     num_batches_tracked (device int64 scalar, may be NULL) is incremented by one
- *  batchnorm_act_bwd  given x (the BN input), out = act(bn(x)) and dy: dx, and dgamma / dbeta ACCUMULATED (fp32);
- *                     workspace cgan_batchnorm_act_bwd_workspace_bytes(c) */
+ *  batchnorm_act_bwd  given x (the BN input), out = act(bn(x) [+ residual]) and dy: dx, and dgamma / dbeta
+ *                     ACCUMULATED (fp32); dz_out (may be NULL) receives dz = dy * act'(out), the gradient of the
+ *                     residual fused by cgan_norm_add_act_apply; workspace cgan_batchnorm_act_bwd_workspace_bytes(c) */
 int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma, const float* beta,
                           float eps, float momentum, int64_t count, float* running_mean, float* running_var,
                           float* mean_out, float* rstd_out, int64_t* num_batches_tracked, int32_t c, void* stream);
@@ -306,8 +311,8 @@ int cgan_batchnorm_train_stats(const void* x, const float* gamma, const float* b
 size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);
 int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
                            const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                           int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           void* dz_out, int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* nn.BCEWithLogitsLoss(x, target) pieces against a constant target (GANLoss, climategan/losses.py:50-83; ADVENT
  * D-side BCE, losses.py:461-477) over the c logical channels of x [npix][cgan_cs(c)]:
  * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */

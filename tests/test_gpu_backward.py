@@ -325,6 +325,51 @@ def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,h,w,act", [(64, 9, 11, "relu"), (20, 7, 5, "relu"), (256, 6, 6, "none"), (24, 5, 9, "lrelu")])
+def test_batchnorm_training_fused_residual(dt, c, h, w, act):
+    """relu(bn3(.) + residual), the bottleneck tail (resnet101_v3.py:62-70), with the residual in the BatchNorm apply
+    kernel: output and the gradients of x, the residual, gamma, beta vs torch."""
+    from climategan_amd import ops
+    from climategan_amd.autograd import BatchNormActFn
+    B = 3
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(1.0 + 0.3 * fill.uniform((c,), 7200)))
+        bn.bias.copy_(torch.from_numpy(0.2 * fill.uniform((c,), 7201)))
+    bn.train()
+    x = q(fill.uniform((B, c, h, w), 7204 + c, -2, 2), dt).requires_grad_(True)
+    r = q(fill.uniform((B, c, h, w), 7304 + c, -1, 1), dt).requires_grad_(True)
+    f = {"relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "none": lambda v: v}[act]
+    pre = bn(x) + r
+    y = f(pre)
+    dy = q(fill.uniform((B, c, h, w), 7205), dt)
+    y.backward(dy)
+    kink_ok = torch.ones_like(pre, dtype=torch.bool) if act == "none" else pre.detach().abs() > 1e-5
+
+    a = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act]
+    xt = to_nhwc(x.detach(), dt).t.requires_grad_(True)
+    rt = to_nhwc(r.detach(), dt).t.requires_grad_(True)
+    g = bn.weight.detach().clone().cuda().requires_grad_(True)
+    b = bn.bias.detach().clone().cuda().requires_grad_(True)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    out = BatchNormActFn.apply(xt, g, b, rm, rv, c, bn.eps, bn.momentum, a, 0.2, None, rt)
+    assert rel_err(back(ops.NHWC(out.detach(), c)), y.detach()) <= TOL[dt]
+    assert (out.detach()[..., c:] == 0).all()                    # storage padding stays zero
+    out.backward(to_nhwc(dy, dt).t)
+    assert kink_ok.float().mean().item() > 0.999
+    assert rel_err(back(ops.NHWC(xt.grad, c)) * kink_ok, x.grad * kink_ok) <= (4e-3 if dt == torch.float16 else 4e-2)
+    assert rel_err(back(ops.NHWC(rt.grad, c)) * kink_ok, r.grad * kink_ok) <= TOL[dt]
+    assert rel_err(g.grad.cpu(), bn.weight.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
+    assert rel_err(b.grad.cpu(), bn.bias.grad) <= (3e-3 if dt == torch.float16 else 2e-2)
+    # a residual that wants no gradient gets none
+    xt2 = xt.detach().clone().requires_grad_(True)
+    out2 = BatchNormActFn.apply(xt2, g, b, rm, rv, c, bn.eps, bn.momentum, a, 0.2, None, rt.detach())
+    assert torch.equal(out2.detach(), out.detach())
+    out2.backward(to_nhwc(dy, dt).t)
+    assert torch.equal(xt2.grad, xt.grad)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,pad,H,W", [(64, 64, 3, 1, 20, 24), (16, 32, 3, 1, 9, 13), (8, 8, 7, 3, 12, 10)])
 def test_conv_reflect_pad_backward(dt, cin, cout, k, pad, H, W):
     """Reflect-padded conv (Conv2dBlock of the mask / depth decoders): data gradient = pad-0 dgrad over the padded extent
