@@ -94,8 +94,9 @@ class InstNormActFn(torch.autograd.Function):
 
 
 class SpadeFn(torch.autograd.Function):
-    """y = act(instance_norm(up?(x)) * (1 + gamma(cond)) + beta(cond)) (reference norms.py:174-186 + the block's
-    LeakyReLU).  Forward: the fused HIP kernel (the 128-channel hidden map never leaves LDS).  Backward: the hidden map
+    """y = act(param_free_norm(up?(x)) * (1 + gamma(cond)) + beta(cond)) (reference norms.py:174-186 + the block's
+    LeakyReLU); the norm is an instance norm (Painter) or, with cfg["batch_stats"], a training-mode batch norm whose
+    (mean, rstd) rows are the batch statistics repeated per sample (MaskSpadeDecoder).  Forward: the fused HIP kernel (the 128-channel hidden map never leaves LDS).  Backward: the hidden map
     and gamma are RE-COMPUTED at full resolution (conv kernels), the elementwise stage splits dy into the gradients of
     gamma / beta / the normalised input, and the conv backward kernels produce the gradients of mlp_gamma, mlp_beta,
     mlp_shared and (through the ReLU) nothing further: cond is data.  The instance-norm backward then gives dx.
@@ -136,7 +137,16 @@ class SpadeFn(torch.autograd.Function):
         dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
         del d_pre
         # instance norm backward on the normalised tensor at full resolution, then back through the folded upsample
-        dx = ops.instnorm_act_bwd(xhat, dxhat, rstd, act=ops.ACT_NONE)
+        if cfg.get("batch_stats"):
+            # batch param-free norm (MaskSpadeDecoder): the same algebra with the sums taken over n, h, w -- the batch
+            # viewed as one image
+            nn_, hh, ww, cs = xhat.t.shape
+            dx = ops.instnorm_act_bwd(ops.NHWC(xhat.t.view(1, nn_ * hh * ww, 1, cs), c),
+                                      ops.NHWC(dxhat.t.view(1, nn_ * hh * ww, 1, cs), c), rstd[0:1].contiguous(),
+                                      act=ops.ACT_NONE)
+            dx = ops.NHWC(dx.t.view(nn_, hh, ww, cs), c)
+        else:
+            dx = ops.instnorm_act_bwd(xhat, dxhat, rstd, act=ops.ACT_NONE)
         if cfg["x_upsample"]:
             dx = ops.sumpool2x2(dx)
         dx_t = dx.t if ctx.needs_input_grad[0] else None
@@ -196,21 +206,12 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None, res_t=None):
-        from . import _lib
-        lib = _lib.load()
         n, h, w, cs = x_t.shape
         npix = n * h * w
         flat = ops.NHWC(x_t.view(1, npix, 1, cs), c)                   # one "image" of n*h*w pixels
         # batch statistics + (mean', rstd') for the apply kernel + running statistics + step counter: two launches
-        d = ops.NormStatsDesc(flat.dtype_id, 1, npix, c, float(eps))
-        ws_bytes = lib.cgan_instnorm_stats_workspace_bytes(C.byref(d))
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x_t.device)
-        stats = torch.empty((4, 1, cs), dtype=torch.float32, device=x_t.device)
-        mean, rstd, mean_f, rstd_f = stats[0], stats[1], stats[2], stats[3]
-        _lib.check(lib.cgan_batchnorm_train_stats(
-            ops._ptr(x_t), ops._ptr(gamma), ops._ptr(beta), float(momentum), ops._ptr(running_mean),
-            ops._ptr(running_var), ops._ptr(nbt), ops._ptr(mean), ops._ptr(rstd), ops._ptr(mean_f), ops._ptr(rstd_f),
-            C.byref(d), ops._ptr(ws), ws_bytes, ops._stream()), "cgan_batchnorm_train_stats")
+        mean, rstd, mean_f, rstd_f = ops.batchnorm_train_stats(flat, gamma, beta, running_mean, running_var, nbt, eps,
+                                                               momentum)
         res = None
         if res_t is not None:
             if res_t.shape != x_t.shape:

@@ -100,12 +100,20 @@ class Conv2dBlock(nn.Module):
             return ops.norm_act_apply(y, mean, rstd, act=act, slope=0.2)
         if sn:
             if self.norm is not None:                                   # spectral_batch: SN conv -> BatchNorm -> act
-                if self.norm.training:
-                    raise NotImplementedError("BatchNorm2d in training mode (batch statistics) has no HIP path yet; "
-                                              "call .eval()")
                 if residual is not None:
                     raise NotImplementedError("Conv2dBlock: residual + spectral_batch cannot be fused")
                 y = self.conv(x, pad=self.padding, pad_mode=pad_mode)
+                if self.norm.training:                                  # batch statistics, HIP backward
+                    from .autograd import BatchNormActFn
+                    bn = self.norm
+                    out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                                                 bn.running_mean, bn.running_var, y.c, bn.eps,
+                                                 bn.momentum if bn.momentum is not None else 0.1, act, 0.2,
+                                                 bn.num_batches_tracked if bn.track_running_stats else None)
+                    return ops.NHWC(out_t, y.c)
+                if y.t.requires_grad:
+                    raise NotImplementedError("climategan_amd: an eval-mode BatchNorm under autograd has no HIP "
+                                              "backward (the reference trains with BatchNorm in training mode)")
                 mean, rstd = ops.bn_eval_stats(self.norm, y.n)
                 return ops.norm_act_apply(y, mean, rstd, act=act, slope=0.2)
             return self.conv(x, pad=self.padding, pad_mode=pad_mode, act=act, slope=0.2, residual=residual)

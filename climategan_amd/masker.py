@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from . import ops
 from .blocks import BaseDecoder, Conv2dBlock, InterpolateNearest2d, SPADEResnetBlock
+from .norms import SpectralNorm
 
 
 def create_mask_decoder(opts, no_init=False, verbose=0):
@@ -33,7 +34,9 @@ class MaskBaseDecoder(BaseDecoder):
 class MaskSpadeDecoder(nn.Module):
     """reference masker.py:59-231 (resnet deeplabv3 backbone): projection convs (spectral norm + BatchNorm, reflect
     padding), ``num_layers`` SPADE ResNet blocks with a batch param-free norm, each followed by a x2 nearest upsample
-    (folded into the next consumer), then a spectral-norm 3x3 conv to one channel.  Inference (eval-mode BatchNorm)."""
+    (folded into the next consumer), then a spectral-norm 3x3 conv to one channel.  Eval mode normalises with the
+    running statistics; training mode with batch statistics (HIP backward; the conditioning map carries no gradient:
+    ``gen.m.spade.detach = True``)."""
 
     def __init__(self, opts):
         super().__init__()
@@ -62,6 +65,9 @@ class MaskSpadeDecoder(nn.Module):
         self.mask_conv = Conv2dBlock(self.final_nc, 1, 3, padding=1, activation="none", pad_type="reflect",
                                      norm="spectral")
         self.upsample = InterpolateNearest2d(scale_factor=2)
+        for m in self.modules():          # every op of this decoder has a backward kernel: allow autograd
+            if isinstance(m, SpectralNorm):
+                m.trainable = True
 
     def forward_nhwc(self, z, cond: ops.NHWC, z_depth=None) -> ops.NHWC:
         if not isinstance(z, (list, tuple)):
@@ -76,6 +82,11 @@ class MaskSpadeDecoder(nn.Module):
             y = self.spade_blocks[i].forward_nhwc(y, cond, x_upsample=(i > 0))          # upsample folded: :227-229
         # the last upsample, read through the conv (reflect padding on the up-sampled extent)
         c = self.mask_conv
+        if y.t.requires_grad:
+            # training: the weight-gradient kernel reads x either through the upsample or through the reflection, not
+            # both -- materialise the (16-channel) up-sampled map
+            from . import functional as Fn
+            return c.conv(Fn.upsample_nearest2x(y), pad=c.padding, pad_mode=ops.PAD_REFLECT)
         return c.conv(y, pad=c.padding, pad_mode=ops.PAD_REFLECT, in_upsample=True)
 
     def forward(self, z, cond, z_depth=None):

@@ -251,18 +251,36 @@ class SPADE(nn.Module):
     def forward_nhwc(self, x: ops.NHWC, cond: ops.NHWC, stats=None, act=ops.ACT_NONE, x_upsample=False) -> ops.NHWC:
         if self.kernel_size != 3:
             raise NotImplementedError("SPADE: only kernel_size 3 is supported")
+        batch_stats = False
         if self.param_free_norm_type == "batch":
             # nn.BatchNorm2d(affine=False) (norms.py:152-153): eval mode normalises with the running statistics
-            if self.param_free_norm.training:
-                raise NotImplementedError("SPADE with a batch param-free norm in training mode (batch statistics) has "
-                                          "no HIP path yet; call .eval()")
-            _grad_guard(self)
-            stats = ops.bn_eval_stats(self.param_free_norm, x.n)
+            bn = self.param_free_norm
+            if bn.training:
+                # batch statistics over (n, h, w) -- those of the up-sampled tensor when the x2 nearest upsample is
+                # folded in: every pixel repeated four times gives the same mean and biased variance, only the running
+                # variance's n/(n-1) factor sees the four-fold count (corrected below)
+                flat = ops.NHWC(x.t.view(1, x.n * x.h * x.w, 1, x.t.shape[-1]), x.c)
+                mean, rstd, _, _ = ops.batchnorm_train_stats(
+                    flat, None, None, bn.running_mean if bn.track_running_stats else None,
+                    bn.running_var if bn.track_running_stats else None,
+                    bn.num_batches_tracked if bn.track_running_stats else None, bn.eps,
+                    bn.momentum if bn.momentum is not None else 0.1)
+                if x_upsample and bn.track_running_stats:
+                    n0 = x.n * x.h * x.w
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    with torch.no_grad():
+                        bn.running_var.add_(rstd[0, :x.c].pow(-2) - bn.eps,
+                                            alpha=mom * (4 * n0 / (4 * n0 - 1.0) - n0 / (n0 - 1.0)))
+                stats = (mean.expand(x.n, -1).contiguous(), rstd.expand(x.n, -1).contiguous())
+                batch_stats = True
+            else:
+                _grad_guard(self)
+                stats = ops.bn_eval_stats(bn, x.n)
         elif stats is None:
             stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
         if needs_grad(self, x.t):
             from .autograd import SpadeFn
-            cfg = dict(c=x.c, cond_c=cond.c, act=act, slope=0.2, x_upsample=bool(x_upsample))
+            cfg = dict(c=x.c, cond_c=cond.c, act=act, slope=0.2, x_upsample=bool(x_upsample), batch_stats=batch_stats)
             y_t = SpadeFn.apply(x.t, cond.t, stats[0], stats[1], self.mlp_shared[0].weight, self.mlp_shared[0].bias,
                                 self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias,
                                 self.packed(x.t.dtype), cfg)

@@ -83,9 +83,11 @@ class Trainer:
             self.G.eval()
             self.is_setup = True
             return self
-        if self.opts.gen.m.use_spade and "m" in self.opts.tasks:
-            raise NotImplementedError("Trainer.setup(inference=False): the SPADE mask decoder (batch-norm SPADE) has no "
-                                      "backward kernels; train with gen.m.use_spade = False")
+        if self.opts.gen.m.use_spade and "m" in self.opts.tasks and not self.opts.gen.m.spade.detach:
+            raise NotImplementedError("Trainer.setup(inference=False): the SPADE mask decoder trains with a DETACHED "
+                                      "conditioning map only (gen.m.spade.detach = True, generator.py:216-218): the "
+                                      "gradient through make_m_cond into the depth / segmentation decoders has no HIP "
+                                      "kernels")
         from .discriminator import create_discriminator
         from .losses import get_losses
         from .optim import get_optimizer
@@ -305,7 +307,10 @@ class Trainer:
                 elif task == "s":
                     loss, s_pred = self.masker_s_loss(x, z, d_pred, z_depth, target, domain, "G")
                 else:
-                    loss, _ = self.masker_m_loss(x, z, target, domain, "G", cond=None, z_depth=z_depth,
+                    cond = None
+                    if self.opts.gen.m.use_spade:                                          # trainer.py:1233-1238
+                        cond = self.G.make_m_cond(d_pred, s_pred, x)                       # detached (see setup)
+                    loss, _ = self.masker_m_loss(x, z, target, domain, "G", cond=cond, z_depth=z_depth,
                                                  depth_preds=d_pred)
                 m_loss = m_loss + loss
         return m_loss
@@ -321,7 +326,7 @@ class Trainer:
             x = batch["data"]["x"]
             with torch.no_grad():
                 z = self.G.encode(x)
-                d_pred = z_depth = None
+                d_pred = z_depth = s_pred = None
                 if "d" in self.opts.tasks and (self.opts.gen.s.use_dada or self.opts.gen.m.use_dada):
                     d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
             if "s" in batch["data"] and "s" in self.opts.tasks:
@@ -331,7 +336,14 @@ class Trainer:
                 total = total + loss * adv
             if "m" in batch["data"] and "m" in self.opts.tasks:
                 with torch.no_grad():
-                    logits = self.G.mask_nhwc(z, cond=None, z_depth=z_depth)
+                    cond = None
+                    if self.opts.gen.m.use_spade and "d" in self.opts.tasks:               # trainer.py:1127-1131
+                        if d_pred is None:
+                            d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
+                        if s_pred is None:
+                            s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
+                        cond = self.G.make_m_cond(d_pred, s_pred, x)
+                    logits = self.G.mask_nhwc(z, cond=cond, z_depth=z_depth)
                 loss, _ = self._advent_d_term("m", logits, None, domain)
                 total = total + loss * adv
         return total

@@ -279,6 +279,123 @@ def test_spade_fn_backward(dt, C, H, W, ups, act):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,H,W,ups,act", [(64, 12, 16, False, "lrelu"), (32, 16, 12, True, "lrelu"), (16, 10, 14, True, "none")])
+def test_spade_batch_norm_training(dt, C, H, W, ups, act):
+    """SPADE with a batch param-free norm in TRAINING mode (the mask decoder's SPADE, norms.py:152-153 with
+    masker.py:120-150): batch statistics over (n, h, w), running statistics updated, and the gradients of x and the six
+    mlp parameters against torch autograd of the reference expression."""
+    from climategan_amd import ops
+    from climategan_amd.norms import SPADE
+    from oracle import cpu_ref
+    B, CN = 3, 15
+    hs, ws = (H // 2, W // 2) if ups else (H, W)
+    mod = SPADE("batch", 3, C, CN)
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if k.startswith("mlp_")}
+    sd = {k: q(v, dt).requires_grad_(True) for k, v in fill.fill_state_dict(shapes, 5202).items()}
+    x = q(fill.uniform((B, C, hs, ws), 5200 + C, -2, 2), dt).requires_grad_(True)
+    cond = q(fill.uniform((B, CN, 2 * H, 2 * W), 5201), dt)
+    bn = torch.nn.BatchNorm2d(C, affine=False).train()
+    xu = cpu_ref.nearest_resize(x, (H, W)) if ups else x
+    seg = cpu_ref.nearest_resize(cond, (H, W))
+    actv = F.relu(F.conv2d(seg, sd["mlp_shared.0.weight"], sd["mlp_shared.0.bias"], padding=1))
+    gamma = F.conv2d(actv, sd["mlp_gamma.weight"], sd["mlp_gamma.bias"], padding=1)
+    beta = F.conv2d(actv, sd["mlp_beta.weight"], sd["mlp_beta.bias"], padding=1)
+    pre = bn(xu) * (1 + gamma) + beta
+    y = F.leaky_relu(pre, 0.2) if act == "lrelu" else pre
+    dy = q(fill.uniform(tuple(y.shape), 5203), dt)
+    y.backward(dy)
+    # the 16-bit hidden map / gamma / beta move a pre-activation by ~1 % of its scale: within that distance of the
+    # LeakyReLU kink the two sides disagree about the slope (a factor 5 on that element's gradient); such elements
+    # (about 1 %) are left out of the max-norm comparison of dx, their effect on the sums stays inside the tolerance
+    thr = 0.0 if act == "none" else (4e-3 if dt == torch.float16 else 3e-2)
+    kink_ok = pre.detach().abs() >= thr
+    if ups:
+        kink_ok = kink_ok.reshape(B, C, hs, 2, ws, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, hs, ws, 4).all(-1)
+    assert kink_ok.float().mean().item() > 0.9
+
+    mod.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=False)
+    mod = mod.cuda().train()
+    xt = to_nhwc(x.detach(), dt).t.requires_grad_(True)
+    condg = ops.nchw_to_nhwc(cond.cuda(), dt, cs=ops.cs4(CN))
+    a = ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE
+    out = mod.forward_nhwc(ops.NHWC(xt, C), condg, act=a, x_upsample=ups)
+    assert rel_err(back(ops.NHWC(out.t.detach(), C)), y.detach()) <= TOL[dt]
+    assert mod.param_free_norm.num_batches_tracked.item() == 1
+    assert rel_err(mod.param_free_norm.running_mean.cpu(), bn.running_mean) <= 1e-4
+    assert rel_err(mod.param_free_norm.running_var.cpu(), bn.running_var) <= 1e-4
+    out.t.backward(to_nhwc(dy, dt).t)
+    assert rel_err(back(ops.NHWC(xt.grad, C)) * kink_ok, x.grad * kink_ok) <= (4e-3 if dt == torch.float16 else 1e-1)
+    for k in shapes:
+        g = dict(mod.named_parameters())[k].grad
+        e = rel_err(g.cpu(), sd[k].grad)
+        assert e <= (5e-3 if dt == torch.float16 else 8e-2), "%s: rel err %.3g" % (k, e)
+    # eval mode: running statistics, no graph wanted
+    mod.eval()
+    with torch.no_grad():
+        ev = mod.forward_nhwc(ops.NHWC(xt.detach(), C), condg, act=a, x_upsample=ups)
+    bn.eval()
+    with torch.no_grad():
+        ye = bn(xu) * (1 + gamma) + beta
+        ye = F.leaky_relu(ye, 0.2) if act == "lrelu" else ye
+    assert rel_err(back(ev), ye) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv2dblock_spectral_batch_training(dt):
+    """Conv2dBlock(norm="spectral_batch", reflect padding, LeakyReLU) in training mode (the projection convs of the
+    SPADE mask decoder, masker.py:85-118): spectral-norm conv -> batch-statistics BatchNorm -> activation, forward and
+    the gradients of x, weight_bar, gamma, beta against torch."""
+    from climategan_amd import ops
+    from climategan_amd.blocks import Conv2dBlock
+    from climategan_amd.norms import spectral_norm_step_all
+    B, cin, cout, H, W = 2, 32, 24, 12, 10
+    blk = Conv2dBlock(cin, cout, 3, padding=1, activation="lrelu", pad_type="reflect", norm="spectral_batch")
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items() if "num_batches" not in k}
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, 5300).items()}, strict=False)
+    with torch.no_grad():
+        blk.norm.running_var.abs_().add_(0.5)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = q(fill.uniform((B, cin, H, W), 5301, -1, 1), dt).requires_grad_(True)
+    # torch restatement: one power iteration (norms.py:66-87), conv with w_bar / sigma, BatchNorm (training), LeakyReLU
+    wb = sd["conv.module.weight_bar"].clone().requires_grad_(True)
+    u, v = sd["conv.module.weight_u"], sd["conv.module.weight_v"]
+    wm = wb.detach().reshape(cout, -1)
+    v2 = F.normalize(wm.t() @ u, dim=0, eps=1e-12)
+    u2 = F.normalize(wm @ v2, dim=0, eps=1e-12)
+    sigma = u2 @ (wb.reshape(cout, -1) @ v2)
+    bn = torch.nn.BatchNorm2d(cout).train()
+    bn.load_state_dict({k[5:]: t for k, t in sd.items() if k.startswith("norm.")})
+    bias = sd.get("conv.module.bias")
+    pre = F.conv2d(F.pad(x, (1,) * 4, mode="reflect"), wb / sigma, bias)
+    z = bn(pre)
+    y = F.leaky_relu(z, 0.2)
+    dy = q(fill.uniform(tuple(y.shape), 5302), dt)
+    y.backward(dy)
+    frac_near_kink = (z.detach().abs() < (4e-3 if dt == torch.float16 else 3e-2)).float().mean().item()
+    assert frac_near_kink < 0.05          # 16-bit conv outputs that close to the kink may take the other slope
+
+    blk = blk.cuda().train()
+    xt = to_nhwc(x.detach(), dt).t.requires_grad_(True)
+    spectral_norm_step_all(blk, dt)
+    out = blk.forward_nhwc(ops.NHWC(xt, cin))
+    assert rel_err(back(ops.NHWC(out.t.detach(), cout)), y.detach()) <= TOL[dt]
+    out.t.backward(to_nhwc(dy, dt).t)
+    tol = 6e-3 if dt == torch.float16 else 6e-2
+    # dx sums 9 taps x 24 channels of dz: a flipped slope on a few of them moves single elements of dx, so dx is
+    # compared in the mean (relative L1) and loosely in the max norm
+    got, ref = back(ops.NHWC(xt.grad, cin)), x.grad
+    assert ((got - ref).abs().mean() / ref.abs().mean()).item() <= tol
+    assert rel_err(got, ref) <= 4 * tol
+    # (bf16: the BatchNorm backward subtracts two means from 8-bit-mantissa values before the 240-pixel weight sums)
+    assert rel_err(blk.conv.module.weight_bar.grad.cpu(), wb.grad) <= (tol if dt == torch.float16 else 1e-1)
+    # (a few of each channel's 240 pre-activations sit close enough to the kink to take the other slope in bf16)
+    assert rel_err(blk.norm.weight.grad.cpu(), bn.weight.grad) <= (tol if dt == torch.float16 else 1e-1)
+    assert rel_err(blk.norm.bias.grad.cpu(), bn.bias.grad) <= (tol if dt == torch.float16 else 1e-1)
+    assert rel_err(blk.norm.running_mean.cpu(), bn.running_mean) <= 2e-3      # statistics of a 16-bit conv output
+    assert rel_err(blk.norm.running_var.cpu(), bn.running_var) <= 2e-3
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("c,h,w,act,affine", [(64, 20, 24, "relu", True), (256, 9, 11, "none", True), (20, 13, 7, "lrelu", False)])
 def test_batchnorm_training_forward_backward(dt, c, h, w, act, affine):
     """autograd.BatchNormActFn (training-mode BatchNorm2d + activation) vs torch: output, running statistics after the

@@ -207,13 +207,16 @@ def test_painter_train_steps_run_and_learn():
 MNAME = "mstep"
 
 
-def build_masker_trainer(case, dt=torch.bfloat16):
+def build_masker_trainer(case, dt=torch.bfloat16, use_spade=False):
     from climategan_amd import fill
     from climategan_amd.config import default_opts
     from climategan_amd.trainer import Trainer
 
     opts = default_opts()
     opts.tasks = ["d", "s", "m"]
+    if use_spade:
+        opts.gen.m.use_spade = True
+        opts.gen.m.spade.detach = True
     T = Trainer(opts, device="cuda").setup(inference=False)
     for mod, seed in ((T.G, case["seed"]), (T.D, case["seed"] + 1)):
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
@@ -351,6 +354,44 @@ def test_masker_train_step_runs():
     assert not torch.equal(T.G.encoder.layer4[2].conv3.weight.detach(), w0)
     assert not torch.equal(T.G.encoder.bn1.running_mean.detach(), rm0)
     assert not torch.equal(T.D["s"]["Advent"][0].module.weight_bar.detach(), dw0)
+
+
+def test_masker_spade_decoder_train_step():
+    """The SPADE mask decoder (gen.m.use_spade, batch-norm SPADE blocks conditioned on the DETACHED depth / seg / image
+    map) trains: two update_G + update_D steps, finite losses, the decoder's parameters and its BatchNorm running
+    statistics move, and the gradient reaches the encoder through z.  A non-detached conditioning map is refused."""
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    case = golden_cases()[MNAME]
+    T = build_masker_trainer(case, use_spade=True)
+    batch = masker_batch(case)
+    dec = T.G.decoders["m"]
+    w0 = dec.spade_blocks[0].norm_0.mlp_gamma.weight.detach().clone()
+    p0 = dec.merge_feats_conv.conv.module.weight_bar.detach().clone()
+    rm0 = dec.spade_blocks[1].norm_1.param_free_norm.running_mean.detach().clone()
+    loss = T.get_masker_loss(batch)
+    assert torch.isfinite(loss)
+    T.G.zero_grad()
+    loss.backward()
+    g = dec.spade_blocks[0].norm_0.mlp_shared[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    ge = T.G.encoder.layer4[2].conv3.weight.grad
+    assert ge is not None and torch.isfinite(ge).all() and ge.abs().max() > 0
+    T.G.zero_grad()
+    for _ in range(2):
+        gl, dl = T.train_step(batch)
+        assert torch.isfinite(gl) and torch.isfinite(dl)
+    assert not torch.equal(dec.spade_blocks[0].norm_0.mlp_gamma.weight.detach(), w0)
+    assert not torch.equal(dec.merge_feats_conv.conv.module.weight_bar.detach(), p0)
+    assert not torch.equal(dec.spade_blocks[1].norm_1.param_free_norm.running_mean.detach(), rm0)
+
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    opts.gen.m.use_spade = True
+    opts.gen.m.spade.detach = False
+    with pytest.raises(NotImplementedError, match="detach"):
+        Trainer(opts, device="cuda").setup(inference=False)
 
 
 def test_gradient_reducer_over_rccl_single_rank():

@@ -136,6 +136,34 @@ def conv_table(T, batch):
             t, cnt, ms, tf, kind, n, h, w, ci, co, kh, kw, stride, pad, dil, pm, ups, res))
 
 
+def copy_trace(T, batch):
+    """Which Python lines issue the device copies / fills of one train step (each is a launch of its own)."""
+    import collections
+    import traceback
+    counts = collections.Counter()
+    nbytes = collections.Counter()
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class Mode(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = func.__name__
+            if name.split(".")[0] in ("copy_", "clone", "_to_copy", "fill_", "zero_", "zeros", "zeros_like", "contiguous",
+                                      "add", "add_", "mul", "mul_", "cat", "_foreach_copy_"):
+                st = [f for f in traceback.extract_stack()[:-1] if "climategan_amd" in f.filename or "tools/" in f.filename]
+                site = "%s:%d" % (st[-1].filename.split("/")[-1], st[-1].lineno) if st else "autograd-engine"
+                counts[(name, site)] += 1
+                t = args[0] if args and isinstance(args[0], torch.Tensor) else None
+                if t is not None:
+                    nbytes[(name, site)] += t.numel() * t.element_size()
+            return func(*args, **(kwargs or {}))
+
+    with Mode():
+        T.train_step(batch)
+    torch.cuda.synchronize()
+    for (name, site), n in counts.most_common(40):
+        print("%6d  %-28s %-34s %8.1f MB" % (n, name, site, nbytes[(name, site)] / 1e6))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bs", type=int, default=8)
@@ -150,6 +178,7 @@ def main():
     ap.add_argument("--ddp-single", action="store_true",
                     help="run under a ONE-rank RCCL group with the gradient reducers active (their single-GPU overhead)")
     ap.add_argument("--cprofile", action="store_true", help="host-side cProfile of one train step")
+    ap.add_argument("--copy-trace", action="store_true", help="count the aten::copy_ / fill_ calls of one step by Python call site")
     ap.add_argument("--wgrad-table", action="store_true", help="per-shape table of the weight-gradient calls of one step")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -192,6 +221,8 @@ def main():
         return wgrad_table(T, batch)
     if args.conv_table:
         return conv_table(T, batch)
+    if args.copy_trace:
+        return copy_trace(T, batch)
     if args.cprofile:
         import cProfile
         import pstats
