@@ -81,6 +81,10 @@ _SIGNATURES = {
     "cgan_instnorm_stats_workspace_bytes": (C.c_size_t, [C.POINTER(NormStatsDesc)]),
     "cgan_instnorm_stats": (C.c_int, [_P, _P, _P, C.POINTER(NormStatsDesc), _P, C.c_size_t, _P]),
     "cgan_norm_act_apply": (C.c_int, [_P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P]),
+    "cgan_make_m_cond_bwd_nhwc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, _P]),
+    "cgan_resize_nearest_bwd_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_norm_add_act_apply": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P]),
     "cgan_spade_packed_weight_bytes": (C.c_size_t, [C.POINTER(SpadeDesc)]),
     "cgan_spade_pack_weights": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),

@@ -99,7 +99,9 @@ class SpadeFn(torch.autograd.Function):
     (mean, rstd) rows are the batch statistics repeated per sample (MaskSpadeDecoder).  Forward: the fused HIP kernel (the 128-channel hidden map never leaves LDS).  Backward: the hidden map
     and gamma are RE-COMPUTED at full resolution (conv kernels), the elementwise stage splits dy into the gradients of
     gamma / beta / the normalised input, and the conv backward kernels produce the gradients of mlp_gamma, mlp_beta,
-    mlp_shared and (through the ReLU) nothing further: cond is data.  The instance-norm backward then gives dx.
+    mlp_shared and -- only when the conditioning map wants a gradient (the SPADE mask decoder conditioned on the
+    non-detached depth / segmentation predictions; for the Painter cond is data) -- of cond, through mlp_shared's data
+    gradient and the adjoint of the nearest resize.  The instance-norm backward then gives dx.
     The re-materialised maps cost HBM traffic the fused forward avoids (a fused backward is future work)."""
 
     @staticmethod
@@ -135,6 +137,12 @@ class SpadeFn(torch.autograd.Function):
         d_pre = ops.act_bwd(actv, d_actv, ops.ACT_RELU)
         del d_actv, actv
         dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
+        dcond_t = None
+        if ctx.needs_input_grad[1]:
+            # the conditioning map is a prediction (SPADE mask decoder with gen.m.spade.detach = false): back through
+            # mlp_shared's conv and the nearest resize
+            d_seg = ops.conv2d_bwd_data(d_pre, w_sh.detach(), (seg.n, h, w), pad=1)
+            dcond_t = ops.resize_nearest_bwd(d_seg, (cond_t.shape[1], cond_t.shape[2]), cond_t.shape[3]).t
         del d_pre
         # instance norm backward on the normalised tensor at full resolution, then back through the folded upsample
         if cfg.get("batch_stats"):
@@ -150,8 +158,27 @@ class SpadeFn(torch.autograd.Function):
         if cfg["x_upsample"]:
             dx = ops.sumpool2x2(dx)
         dx_t = dx.t if ctx.needs_input_grad[0] else None
-        return (dx_t, None, None, None, dw_sh, db_sh, dw_gb[:c].contiguous(), db_gb[:c].contiguous(),
+        return (dx_t, dcond_t, None, None, dw_sh, db_sh, dw_gb[:c].contiguous(), db_gb[:c].contiguous(),
                 dw_gb[c:].contiguous(), db_gb[c:].contiguous(), None, None)
+
+
+class MakeMCondFn(torch.autograd.Function):
+    """cond = cat[normalize(d), softmax(s), bilinear(x)] (OmniGenerator.make_m_cond, generator.py:196-230) with the
+    gradient flowing back into d and s (gen.m.spade.detach = false)."""
+
+    @staticmethod
+    def forward(ctx, d_t, s_t, x, s_c):
+        ctx.s_c, ctx.with_x = s_c, x is not None
+        ctx.save_for_backward(d_t, s_t)
+        return ops.make_m_cond(ops.NHWC(d_t, 1), ops.NHWC(s_t, s_c), x).t
+
+    @staticmethod
+    def backward(ctx, dcond_t):
+        d_t, s_t = ctx.saved_tensors
+        cond_c = 1 + ctx.s_c + (3 if ctx.with_x else 0)
+        dd, ds = ops.make_m_cond_bwd(ops.NHWC(dcond_t.contiguous(), cond_c), ops.NHWC(d_t, 1), ops.NHWC(s_t, ctx.s_c),
+                                     ctx.with_x)
+        return dd.t, ds.t, None, None
 
 
 class PainterHeadsFn(torch.autograd.Function):

@@ -152,8 +152,14 @@ class OmniGenerator(nn.Module):
         if self.opts.gen.m.spade.cond_nc == 15:
             if x is None:
                 raise ValueError("When using spade for the Masker with 15 channels, x MUST be provided")
-            return ops.make_m_cond(d, s, x)
-        return ops.make_m_cond(d, s, None)
+        else:
+            x = None
+        if (torch.is_grad_enabled() and not self.opts.gen.m.spade.detach                 # generator.py:216-218
+                and (d.t.requires_grad or s.t.requires_grad)):
+            from .autograd import MakeMCondFn
+            cond_c = 1 + s.c + (3 if x is not None else 0)
+            return ops.NHWC(MakeMCondFn.apply(d.t, s.t, x, s.c), cond_c)
+        return ops.make_m_cond(d, s, x)
 
     def mask(self, x=None, z=None, cond=None, z_depth=None, sigmoid=True):
         """reference generator.py:232-277: logits = decoders["m"](z, cond, z_depth); sigmoid by default."""

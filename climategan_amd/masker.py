@@ -35,8 +35,8 @@ class MaskSpadeDecoder(nn.Module):
     """reference masker.py:59-231 (resnet deeplabv3 backbone): projection convs (spectral norm + BatchNorm, reflect
     padding), ``num_layers`` SPADE ResNet blocks with a batch param-free norm, each followed by a x2 nearest upsample
     (folded into the next consumer), then a spectral-norm 3x3 conv to one channel.  Eval mode normalises with the
-    running statistics; training mode with batch statistics (HIP backward; the conditioning map carries no gradient:
-    ``gen.m.spade.detach = True``)."""
+    running statistics; training mode with batch statistics (HIP backward, including the gradient of the conditioning
+    map when ``gen.m.spade.detach`` is false)."""
 
     def __init__(self, opts):
         super().__init__()

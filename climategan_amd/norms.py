@@ -278,7 +278,7 @@ class SPADE(nn.Module):
                 stats = ops.bn_eval_stats(bn, x.n)
         elif stats is None:
             stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
-        if needs_grad(self, x.t):
+        if needs_grad(self, x.t, cond.t):
             from .autograd import SpadeFn
             cfg = dict(c=x.c, cond_c=cond.c, act=act, slope=0.2, x_upsample=bool(x_upsample), batch_stats=batch_stats)
             y_t = SpadeFn.apply(x.t, cond.t, stats[0], stats[1], self.mlp_shared[0].weight, self.mlp_shared[0].bias,

@@ -117,6 +117,17 @@ def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None)
     return NHWC(y, x.c)
 
 
+def resize_nearest_bwd(dy: NHWC, size_in: Tuple[int, int], cs_in: int) -> NHWC:
+    """Adjoint of ``resize_nearest``: the gradient of the (h_in, w_in) source map with ``cs_in`` storage channels."""
+    _need_cuda(dy.t)
+    hi, wi = size_in
+    dx = torch.empty((dy.n, hi, wi, cs_in), dtype=dy.t.dtype, device=dy.t.device)
+    lib = _lib.load()
+    _lib.check(lib.cgan_resize_nearest_bwd_nhwc(_ptr(dy.t), _ptr(dx), dy.dtype_id, dy.n, dy.c, hi, wi, cs_in, dy.h, dy.w,
+                                                dy.cs, _stream()), "cgan_resize_nearest_bwd_nhwc")
+    return NHWC(dx, dy.c)
+
+
 def avgpool3x3s2(x: NHWC) -> NHWC:
     _need_cuda(x.t)
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
@@ -335,6 +346,18 @@ def bn_eval_stats(bn, n: int):
     _lib.check(lib.cgan_bn_eval_stats(_ptr(g), _ptr(b), _ptr(rm.float().contiguous()), _ptr(rv.float().contiguous()),
                                       float(bn.eps), _ptr(mean), _ptr(rstd), n, c, _stream()), "cgan_bn_eval_stats")
     return mean, rstd
+
+
+def make_m_cond_bwd(dcond: NHWC, d: NHWC, s: NHWC, with_x: bool):
+    """Gradients of ``make_m_cond`` w.r.t. the depth and segmentation maps (the image channels are data)."""
+    _need_cuda(dcond.t, d.t, s.t)
+    if dcond.c != 1 + s.c + (3 if with_x else 0) or (dcond.n, dcond.h, dcond.w) != (s.n, s.h, s.w):
+        raise RuntimeError("make_m_cond_bwd: the conditioning gradient does not match d / s")
+    dd, ds = torch.empty_like(d.t), torch.empty_like(s.t)
+    lib = _lib.load()
+    _lib.check(lib.cgan_make_m_cond_bwd_nhwc(_ptr(dcond.t), _ptr(d.t), _ptr(s.t), _ptr(dd), _ptr(ds), d.dtype_id, d.n, d.h,
+                                             d.w, s.c, int(bool(with_x)), _stream()), "cgan_make_m_cond_bwd_nhwc")
+    return NHWC(dd, 1), NHWC(ds, s.c)
 
 
 def make_m_cond(d: NHWC, s: NHWC, x: Optional[torch.Tensor]) -> NHWC:

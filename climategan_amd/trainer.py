@@ -83,11 +83,6 @@ class Trainer:
             self.G.eval()
             self.is_setup = True
             return self
-        if self.opts.gen.m.use_spade and "m" in self.opts.tasks and not self.opts.gen.m.spade.detach:
-            raise NotImplementedError("Trainer.setup(inference=False): the SPADE mask decoder trains with a DETACHED "
-                                      "conditioning map only (gen.m.spade.detach = True, generator.py:216-218): the "
-                                      "gradient through make_m_cond into the depth / segmentation decoders has no HIP "
-                                      "kernels")
         from .discriminator import create_discriminator
         from .losses import get_losses
         from .optim import get_optimizer
@@ -309,7 +304,7 @@ class Trainer:
                 else:
                     cond = None
                     if self.opts.gen.m.use_spade:                                          # trainer.py:1233-1238
-                        cond = self.G.make_m_cond(d_pred, s_pred, x)                       # detached (see setup)
+                        cond = self.G.make_m_cond(d_pred, s_pred, x)     # differentiable unless spade.detach
                     loss, _ = self.masker_m_loss(x, z, target, domain, "G", cond=cond, z_depth=z_depth,
                                                  depth_preds=d_pred)
                 m_loss = m_loss + loss

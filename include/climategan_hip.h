@@ -453,6 +453,17 @@ size_t cgan_make_m_cond_workspace_bytes(int32_t n);
 int cgan_make_m_cond_nhwc(const void* depth_nhwc, const void* seg_nhwc, const float* x_nchw, void* cond_nhwc,
                           int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t seg_c, int32_t x_h, int32_t x_w,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Autograd of make_m_cond with gen.m.spade.detach = false (generator.py:216-221): given the gradient of the
+ * conditioning map, ddepth [n][h][w][8] (channel 0; the per-sample min / max of tutils.normalize, tutils.py:567-576, send
+ * their gradient to the first arg-min / arg-max pixel as torch's min(1) / max(1) do) and dseg [n][h][w][cgan_cs(seg_c)]
+ * (softmax backward).  The image channels carry no gradient (x is data). */
+int cgan_make_m_cond_bwd_nhwc(const void* dcond_nhwc, const void* depth_nhwc, const void* seg_nhwc, void* ddepth_nhwc,
+                              void* dseg_nhwc, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t seg_c,
+                              int32_t with_x, void* stream);
+/* Adjoint of cgan_resize_nearest_nhwc (autograd of F.interpolate(segmap, mode="nearest"), norms.py:179): dx[n][h_in][w_in]
+ * [cs_in] = sum of the dy[n][h_out][w_out][cs_out] pixels that read it (fp32 accumulation; storage padding zeroed). */
+int cgan_resize_nearest_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                 int32_t w_in, int32_t cs_in, int32_t h_out, int32_t w_out, int32_t cs_out, void* stream);
 
 /* Wildfire event (climategan/fire.py:68-126 add_fire, parameters shared/trainer/events.yaml:1-8): normalize(x, 0, 255),
  * warm, uint8, adjust_contrast(1.5), adjust_brightness(0.73); sky = argmax(seg) == sky_idx (bottom third cleared when

@@ -293,7 +293,7 @@ def test_spade_batch_norm_training(dt, C, H, W, ups, act):
     shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if k.startswith("mlp_")}
     sd = {k: q(v, dt).requires_grad_(True) for k, v in fill.fill_state_dict(shapes, 5202).items()}
     x = q(fill.uniform((B, C, hs, ws), 5200 + C, -2, 2), dt).requires_grad_(True)
-    cond = q(fill.uniform((B, CN, 2 * H, 2 * W), 5201), dt)
+    cond = q(fill.uniform((B, CN, 2 * H, 2 * W), 5201), dt).requires_grad_(True)   # a prediction: wants a gradient
     bn = torch.nn.BatchNorm2d(C, affine=False).train()
     xu = cpu_ref.nearest_resize(x, (H, W)) if ups else x
     seg = cpu_ref.nearest_resize(cond, (H, W))
@@ -316,7 +316,8 @@ def test_spade_batch_norm_training(dt, C, H, W, ups, act):
     mod.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=False)
     mod = mod.cuda().train()
     xt = to_nhwc(x.detach(), dt).t.requires_grad_(True)
-    condg = ops.nchw_to_nhwc(cond.cuda(), dt, cs=ops.cs4(CN))
+    condg = ops.nchw_to_nhwc(cond.detach().cuda(), dt, cs=ops.cs4(CN))
+    condg.t.requires_grad_(True)
     a = ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE
     out = mod.forward_nhwc(ops.NHWC(xt, C), condg, act=a, x_upsample=ups)
     assert rel_err(back(ops.NHWC(out.t.detach(), C)), y.detach()) <= TOL[dt]
@@ -329,15 +330,80 @@ def test_spade_batch_norm_training(dt, C, H, W, ups, act):
         g = dict(mod.named_parameters())[k].grad
         e = rel_err(g.cpu(), sd[k].grad)
         assert e <= (5e-3 if dt == torch.float16 else 8e-2), "%s: rel err %.3g" % (k, e)
+    # the conditioning map's gradient: mlp_shared's data gradient summed over the pixels that read each cond pixel
+    # (only every other row / column of the 2H x 2W map is read: the rest must be exactly zero)
+    gc, rc = back(ops.NHWC(condg.t.grad, CN)), cond.grad
+    assert torch.equal(gc == 0, rc == 0) or ((gc == 0) | (rc != 0)).all()
+    assert ((gc - rc).abs().mean() / rc.abs().mean()).item() <= (1e-2 if dt == torch.float16 else 8e-2)
+    assert rel_err(gc, rc) <= (2e-2 if dt == torch.float16 else 2e-1)
     # eval mode: running statistics, no graph wanted
     mod.eval()
     with torch.no_grad():
-        ev = mod.forward_nhwc(ops.NHWC(xt.detach(), C), condg, act=a, x_upsample=ups)
+        ev = mod.forward_nhwc(ops.NHWC(xt.detach(), C), ops.NHWC(condg.t.detach(), CN), act=a, x_upsample=ups)
     bn.eval()
     with torch.no_grad():
         ye = bn(xu) * (1 + gamma) + beta
         ye = F.leaky_relu(ye, 0.2) if act == "lrelu" else ye
     assert rel_err(back(ev), ye) <= TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,cs_in,src,dst", [(15, 16, (8, 10), (16, 20)), (15, 16, (8, 10), (4, 5)), (3, 4, (7, 9), (7, 9)),
+                                             (6, 8, (5, 7), (13, 11)), (20, 24, (12, 9), (5, 4)), (1, 8, (3, 2), (10, 9))])
+def test_resize_nearest_backward(dt, c, cs_in, src, dst):
+    """cgan_resize_nearest_bwd_nhwc: the adjoint of F.interpolate(mode="nearest") (norms.py:179) vs torch autograd,
+    up- and down-sampling, non-integer ratios."""
+    from climategan_amd import ops
+    B = 2
+    x = q(fill.uniform((B, c) + src, 7400 + c), dt).requires_grad_(True)
+    y = F.interpolate(x, size=dst, mode="nearest")
+    dy = q(fill.uniform(tuple(y.shape), 7401), dt)
+    y.backward(dy)
+    dyg = to_nhwc(dy, dt)
+    got = ops.resize_nearest_bwd(dyg, src, cs_in)
+    assert got.t.shape == (B,) + src + (cs_in,)
+    assert (got.t[..., c:] == 0).all()
+    assert rel_err(back(got), x.grad) <= TOL[dt]
+    # forward / adjoint consistency: <resize(x), dy> == <x, resize_bwd(dy)>
+    xg = ops.nchw_to_nhwc(x.detach().cuda(), dt, cs=cs_in)
+    fwd = ops.resize_nearest(xg, dst, cs_out=dyg.t.shape[-1])
+    lhs = (fwd.t.float() * dyg.t.float()).sum().item()
+    rhs = (xg.t.float() * got.t.float()).sum().item()
+    assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("with_x", [True, False])
+def test_make_m_cond_backward(dt, with_x):
+    """cgan_make_m_cond_bwd_nhwc vs torch autograd of cat[normalize(d), softmax(s), bilinear(x)] (generator.py:196-230
+    with tutils.normalize, tutils.py:567-576): gradients of d (including the arg-min / arg-max terms) and of s."""
+    from climategan_amd import ops
+    from climategan_amd.autograd import MakeMCondFn
+    from oracle import cpu_ref
+    B, H, W, SC = 3, 20, 24, 11
+    d = q(fill.uniform((B, 1, H, W), 7500, 0.3, 6.9), dt)
+    with torch.no_grad():                                      # unique extrema per sample (ties are a 16-bit artefact)
+        for i in range(B):
+            d[i, 0, 3 + i, 5] = 0.125
+            d[i, 0, 7, 2 + i] = 7.5
+    d.requires_grad_(True)
+    s = q(fill.uniform((B, SC, H, W), 7501, -3, 3), dt).requires_grad_(True)
+    x = q(fill.uniform((B, 3, 4 * H, 4 * W), 7502), dt) if with_x else None
+    cond = cpu_ref.make_m_cond(d, s, x)
+    g = q(fill.uniform(tuple(cond.shape), 7503), dt)
+    cond.backward(g)
+
+    dg, sg = to_nhwc(d.detach(), dt), to_nhwc(s.detach(), dt)
+    dg.t.requires_grad_(True)
+    sg.t.requires_grad_(True)
+    out = MakeMCondFn.apply(dg.t, sg.t, x.cuda() if with_x else None, SC)
+    cc = 1 + SC + (3 if with_x else 0)
+    assert rel_err(back(ops.NHWC(out.detach(), cc)), cond.detach()) <= TOL[dt]
+    out.backward(ops.nchw_to_nhwc(g.cuda(), dt, cs=ops.cs4(cc)).t)
+    assert (dg.t.grad[..., 1:] == 0).all() and (sg.t.grad[..., SC:] == 0).all()
+    # the arg-min / arg-max pixels carry sums over the whole sample (large values): max-norm comparison covers them
+    assert rel_err(back(ops.NHWC(dg.t.grad, 1)), d.grad) <= 2 * TOL[dt]
+    assert rel_err(back(ops.NHWC(sg.t.grad, SC)), s.grad) <= 2 * TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -359,7 +359,8 @@ def test_masker_train_step_runs():
 def test_masker_spade_decoder_train_step():
     """The SPADE mask decoder (gen.m.use_spade, batch-norm SPADE blocks conditioned on the DETACHED depth / seg / image
     map) trains: two update_G + update_D steps, finite losses, the decoder's parameters and its BatchNorm running
-    statistics move, and the gradient reaches the encoder through z.  A non-detached conditioning map is refused."""
+    statistics move, and the gradient reaches the encoder through z.  With the non-detached map (the reference's default)
+    the mask terms also reach the depth / segmentation decoders."""
     from climategan_amd.config import default_opts
     from climategan_amd.trainer import Trainer
 
@@ -386,12 +387,32 @@ def test_masker_spade_decoder_train_step():
     assert not torch.equal(dec.merge_feats_conv.conv.module.weight_bar.detach(), p0)
     assert not torch.equal(dec.spade_blocks[1].norm_1.param_free_norm.running_mean.detach(), rm0)
 
-    opts = default_opts()
-    opts.tasks = ["d", "s", "m"]
-    opts.gen.m.use_spade = True
-    opts.gen.m.spade.detach = False
-    with pytest.raises(NotImplementedError, match="detach"):
-        Trainer(opts, device="cuda").setup(inference=False)
+    # the reference's default: the conditioning map is NOT detached (defaults.yaml:182) -- the mask losses reach the
+    # depth and segmentation decoders through make_m_cond as well
+    def decoder_grads(detach):
+        T2 = build_masker_trainer(case, use_spade=True)
+        T2.opts.gen.m.spade.detach = detach
+        for k in ("d", "s"):
+            for terms in (T2.opts.train.lambdas.G[k],):
+                for name in list(terms.keys()):
+                    terms[name] = 0                       # only the mask terms: d / s gradients can only come via cond
+        T2.G.zero_grad()
+        T2.get_masker_loss(batch).backward()
+        gd = T2.G.decoders["d"].enc4_2.conv.weight.grad
+        gs = T2.G.decoders["s"].decoder.conv_cat[0].conv.weight.grad
+        return gd, gs
+
+    gd0, gs0 = decoder_grads(True)
+    gd1, gs1 = decoder_grads(False)
+    for g0 in (gd0, gs0):
+        assert g0 is None or g0.abs().max() == 0
+    for g1 in (gd1, gs1):
+        assert g1 is not None and torch.isfinite(g1).all() and g1.abs().max() > 0
+    T3 = build_masker_trainer(case, use_spade=True)
+    T3.opts.gen.m.spade.detach = False
+    for _ in range(2):
+        gl, dl = T3.train_step(batch)
+        assert torch.isfinite(gl) and torch.isfinite(dl)
 
 
 def test_gradient_reducer_over_rccl_single_rank():
