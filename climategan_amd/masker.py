@@ -74,10 +74,11 @@ class MaskSpadeDecoder(nn.Module):
             raise NotImplementedError("MaskSpadeDecoder: the deeplabv2 single-tensor latent has no HIP path")
         z_h, z_l = z
         z_l = self.low_level_conv.forward_nhwc(z_l)
-        z_l = ops.resize_bilinear(z_l, (z_h.h, z_h.w), align_corners=False)             # masker.py:217,221
+        from . import functional as Fn                    # grad-aware: HIP backward when the latent carries a graph
+        z_l = Fn.resize_bilinear(z_l, (z_h.h, z_h.w), align_corners=False)              # masker.py:217,221
         if self.opts.gen.m.use_proj:
             z_h = self.high_level_conv.forward_nhwc(z_h)
-        y = self.merge_feats_conv.forward_nhwc(ops.concat_channels([z_h, z_l]))         # masker.py:222-223
+        y = self.merge_feats_conv.forward_nhwc(Fn.concat_channels([z_h, z_l]))          # masker.py:222-223
         for i in range(self.num_layers):
             y = self.spade_blocks[i].forward_nhwc(y, cond, x_upsample=(i > 0))          # upsample folded: :227-229
         # the last upsample, read through the conv (reflect padding on the up-sampled extent)
@@ -85,7 +86,6 @@ class MaskSpadeDecoder(nn.Module):
         if y.t.requires_grad:
             # training: the weight-gradient kernel reads x either through the upsample or through the reflection, not
             # both -- materialise the (16-channel) up-sampled map
-            from . import functional as Fn
             return c.conv(Fn.upsample_nearest2x(y), pad=c.padding, pad_mode=ops.PAD_REFLECT)
         return c.conv(y, pad=c.padding, pad_mode=ops.PAD_REFLECT, in_upsample=True)
 

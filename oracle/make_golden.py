@@ -38,6 +38,8 @@ def golden_cases():
         "maskspade_small": dict(kind="maskspade", H=128, W=160, B=2, seed=62, gain=1.6),
         "masker_losses": dict(kind="masker_losses", H=24, W=32, B=2, seed=95),
         "mstep": dict(kind="mstep", H=128, W=160, B=2, seed=66, gain=1.6, sub=512),
+        # the same step with the SPADE mask decoder conditioned on the NON-detached predictions (defaults.yaml:168,182)
+        "mstep_spade": dict(kind="mstep", H=128, W=160, B=2, seed=67, gain=1.6, sub=512, use_spade=True),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
@@ -373,11 +375,18 @@ def run_reference_mstep(name, case):
 
     opts = ref_shim.default_opts()
     opts.tasks = ["d", "s", "m"]
+    use_spade = bool(case.get("use_spade"))
+    opts.gen.m.use_spade = use_spade
     L = ref_shim.ref("losses")
     disc = ref_shim.ref("discriminator")
-    with contextlib.redirect_stdout(io.StringIO()):
-        G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
-        D = disc.OmniDiscriminator(opts)
+    orig_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self       # MaskSpadeDecoder's hard-coded .cuda() (masker.py:196)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+            D = disc.OmniDiscriminator(opts)
+    finally:
+        torch.nn.Module.cuda = orig_cuda
     for mod, seed in ((G, case["seed"]), (D, case["seed"] + 1)):
         shapes = {key: tuple(v.shape) for key, v in mod.state_dict().items()}
         mod.load_state_dict({key: t(v) for key, v in fill.fill_state_dict(shapes, seed, gain=case["gain"]).items()})
@@ -415,7 +424,8 @@ def run_reference_mstep(name, case):
             terms["s.minent.r"] = l.detach(); total = total + l
             l = adv_s(sm, 0, D["s"]["Advent"], d_pred.detach()) * lam.G.s.advent
             terms["s.advent.r"] = l.detach(); total = total + l
-        logits = G.decoders["m"](z, cond=None, z_depth=z_depth)
+        cond = G.make_m_cond(d_pred, s_pred, x) if use_spade else None       # trainer.py:1233-1238 (not detached)
+        logits = G.decoders["m"](z, cond=cond, z_depth=z_depth)
         p = torch.sigmoid(logits)
         prob = torch.cat([p, 1 - p], dim=1)
         l = tv(p) * lam.G.m.tv
@@ -444,6 +454,8 @@ def run_reference_mstep(name, case):
         out["post." + key] = sd[key].numpy().copy()
     for key in sd:
         if key.endswith("weight_u") and key.startswith("decoders.m."):
+            out["post." + key] = sd[key].numpy().copy()
+        if use_spade and key.startswith("decoders.m.") and (key.endswith("running_mean") or key.endswith("running_var")):
             out["post." + key] = sd[key].numpy().copy()
     return out
 

@@ -207,7 +207,7 @@ def test_painter_train_steps_run_and_learn():
 MNAME = "mstep"
 
 
-def build_masker_trainer(case, dt=torch.bfloat16, use_spade=False):
+def build_masker_trainer(case, dt=torch.bfloat16, use_spade=False, detach=True):
     from climategan_amd import fill
     from climategan_amd.config import default_opts
     from climategan_amd.trainer import Trainer
@@ -216,7 +216,7 @@ def build_masker_trainer(case, dt=torch.bfloat16, use_spade=False):
     opts.tasks = ["d", "s", "m"]
     if use_spade:
         opts.gen.m.use_spade = True
-        opts.gen.m.spade.detach = True
+        opts.gen.m.spade.detach = detach
     T = Trainer(opts, device="cuda").setup(inference=False)
     for mod, seed in ((T.G, case["seed"]), (T.D, case["seed"] + 1)):
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
@@ -228,8 +228,8 @@ def build_masker_trainer(case, dt=torch.bfloat16, use_spade=False):
     return T
 
 
-def masker_batch(case):
-    inp = {k: t(v).cuda() for k, v in case_inputs(MNAME, case).items()}
+def masker_batch(case, name=MNAME):
+    inp = {k: t(v).cuda() for k, v in case_inputs(name, case).items()}
     return {dom: {"data": {"x": inp["x_" + dom], "d": inp["d_" + dom], "s": inp["s_" + dom], "m": inp["m_" + dom]}}
             for dom in ("r", "s")}
 
@@ -257,24 +257,37 @@ def _check_masker_terms(T, gold, loss, rel, gi_abs):
     for gk, hk in MASKER_TERMS.items():
         ref, got = float(gold[gk][0]), float(T.loss_log[hk])
         if gk == "term.m.gi.r":                                   # GI counts pixels across a 0.5 threshold
-            assert abs(got - ref) <= gi_abs, (gk, got, ref)
+            assert abs(got - ref) <= max(gi_abs, 0.25 * abs(ref)), (gk, got, ref)
         else:
             assert abs(got - ref) <= rel * max(abs(ref), 1e-4), (gk, got, ref)
     assert abs(loss.item() - float(gold["loss"][0])) <= rel * abs(float(gold["loss"][0]))
 
 
-def test_masker_loss_terms_fp16():
-    """The ten loss terms of the golden masker step with fp16 storage (10-bit mantissa: the forward error of the
-    chaotic untrained encoder stays small), within 2.5 % of the reference's fp32 values."""
-    case = golden_cases()[MNAME]
-    gold = load_golden(MNAME)
-    T = build_masker_trainer(case, torch.float16)
+@pytest.mark.parametrize("name", [MNAME, "mstep_spade"])
+def test_masker_loss_terms_fp16(name):
+    """The ten loss terms of the golden masker steps (base and SPADE mask decoder) with fp16 storage (10-bit mantissa:
+    the forward error of the chaotic untrained encoder stays small), within 2.5 % of the reference's fp32 values."""
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    T = build_masker_trainer(case, torch.float16, use_spade=bool(case.get("use_spade")), detach=False)
     with torch.no_grad():
-        loss = T.get_masker_loss(masker_batch(case))
+        loss = T.get_masker_loss(masker_batch(case, name))
     _check_masker_terms(T, gold, loss, rel=2.5e-2, gi_abs=3e-5)
 
 
-def test_masker_g_step_matches_reference():
+# The same measurement for the SPADE mask decoder (tools/measure_ref_grad_quant.py bf16|fp16 spade).
+REF_QUANT_COS_SPADE = {
+    "float16": {"decoders.m.low_level_conv.conv.module.weight_bar": 0.51, "decoders.m.spade_blocks.0.conv_0.module.weight_bar": 0.47,
+                "decoders.m.spade_blocks.1.conv_0.module.weight_bar": 0.74, "decoders.m.spade_blocks.2.conv_0.module.weight_bar": 0.97,
+                "decoders.m.spade_blocks.2.conv_1.module.weight_bar": 0.989, "decoders.m.mask_conv.conv.module.weight_bar": 0.998},
+    "bfloat16": {"decoders.m.low_level_conv.conv.module.weight_bar": 0.08, "decoders.m.spade_blocks.0.conv_0.module.weight_bar": 0.11,
+                 "decoders.m.spade_blocks.1.conv_0.module.weight_bar": 0.54, "decoders.m.spade_blocks.2.conv_0.module.weight_bar": 0.91,
+                 "decoders.m.spade_blocks.2.conv_1.module.weight_bar": 0.981, "decoders.m.mask_conv.conv.module.weight_bar": 0.993},
+}
+
+
+@pytest.mark.parametrize("name", [MNAME, "mstep_spade"])
+def test_masker_g_step_matches_reference(name):
     """get_masker_loss + backward on the HIP path (ResNet-101 with batch-statistics BatchNorm, DADA depth, DeepLab-v3+
     seg, mask decoder, frozen ADVENT discriminators, 10 loss terms over a real and a sim batch) vs the reference's own
     modules / loss classes / backward (golden ``mstep``), in bf16.
@@ -283,15 +296,18 @@ def test_masker_g_step_matches_reference():
     reference's own 16-bit-rounded run keeps norms within 4 %); the gradient DIRECTION where 16-bit storage preserves
     it in the reference itself (mask decoder >= 0.99, end of the seg decoder >= 0.84, see REF_QUANT_COS): deeper in
     this untrained network the reference's own direction is lost too (encoder cosine 0.0 - 0.4), so no bound is put
-    there.  Also the running statistics of four BatchNorm layers and the mask decoder's spectral-norm vectors."""
+    there.  Also the running statistics of four BatchNorm layers and the mask decoder's spectral-norm vectors.
+    ``mstep_spade``: the same step with the SPADE mask decoder conditioned on the non-detached depth / segmentation
+    predictions (defaults.yaml:168,182): batch-statistics SPADE, spectral_batch projections, make_m_cond's backward;
+    its BatchNorm running statistics are compared too."""
     from climategan_amd import fill
 
-    case = golden_cases()[MNAME]
-    gold = load_golden(MNAME)
-    T = build_masker_trainer(case)
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    T = build_masker_trainer(case, use_spade=bool(case.get("use_spade")), detach=False)
     for p in T.D.parameters():
         p.requires_grad_(False)
-    loss = T.get_masker_loss(masker_batch(case))
+    loss = T.get_masker_loss(masker_batch(case, name))
     loss.backward()
     # bf16 through 33 training-mode bottlenecks of an untrained network: a few per cent on the loss terms, and which
     # way depends on every rounding on the way (fusing the residual add into the BatchNorm pass moved G.d.s from +1.8 %
@@ -327,8 +343,17 @@ def test_masker_g_step_matches_reference():
     dec = np.array([v for k, v in big.items() if not k.startswith("encoder.")])
     assert 0.95 <= np.median(dec) <= 1.06, np.median(dec)
     assert np.mean((r > 0.75) & (r < 1.35)) >= 0.95, sorted(big.items(), key=lambda kv: abs(np.log(kv[1])))[-8:]
-    mdec = [v for k, v in cos.items() if k.startswith("decoders.m.") and k.endswith("weight_bar")]
-    assert len(mdec) >= 10 and np.median(mdec) >= 0.95 and min(mdec) >= 0.85, (np.median(mdec), min(mdec))
+    if case.get("use_spade"):
+        # three training-mode batch-norm SPADE blocks behind chaotic conditioning maps: the reference's own 16-bit run
+        # keeps the direction at the end of the decoder only (REF_QUANT_COS_SPADE); this build: 0.98-0.995 there,
+        # 0.27-0.5 (bf16) / 0.5-0.65 (fp16) at block 0, above the reference's own 0.08-0.17 / 0.44-0.51
+        for k, ref_cos in REF_QUANT_COS_SPADE["bfloat16"].items():
+            if ref_cos >= 0.97:
+                assert cos[k] >= 0.95, (k, cos[k])
+        assert cos["decoders.m.spade_blocks.0.conv_0.module.weight_bar"] >= 0.15
+    else:
+        mdec = [v for k, v in cos.items() if k.startswith("decoders.m.") and k.endswith("weight_bar")]
+        assert len(mdec) >= 10 and np.median(mdec) >= 0.95 and min(mdec) >= 0.85, (np.median(mdec), min(mdec))
     sdec = [v for k, v in cos.items() if k.startswith("decoders.s.decoder.conv_cat") and k.endswith("conv.weight")]
     assert min(sdec) >= 0.75, sdec
     sd = T.G.state_dict()
@@ -400,6 +425,11 @@ def test_masker_spade_decoder_train_step():
         T2.get_masker_loss(batch).backward()
         gd = T2.G.decoders["d"].enc4_2.conv.weight.grad
         gs = T2.G.decoders["s"].decoder.conv_cat[0].conv.weight.grad
+        # the mask terms alone must reach the projection convs and, through z, the encoder (the latent's bilinear
+        # resize and concat are differentiable)
+        for g in (T2.G.decoders["m"].low_level_conv.conv.module.weight_bar.grad, T2.G.encoder.layer1[0].conv1.weight.grad,
+                  T2.G.encoder.layer4[2].conv3.weight.grad):
+            assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
         return gd, gs
 
     gd0, gs0 = decoder_grads(True)

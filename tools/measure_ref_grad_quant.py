@@ -1,7 +1,7 @@
 """Dev-container measurement (needs /root/reference): how far do the REFERENCE's own masker gradients move when every
 conv / norm / activation output and every gradient flowing back through them is rounded to a 16-bit type (the storage
 precision of this package's training path)?  Prints cosine vs the fp32 gradients for a selection of parameters.
-usage: python tools/measure_ref_grad_quant.py [fp16|bf16]"""
+usage: python tools/measure_ref_grad_quant.py [fp16|bf16] [spade]   (spade: the SPADE mask decoder, golden case mstep_spade)"""
 import contextlib, io, sys
 from pathlib import Path
 import numpy as np, torch
@@ -11,13 +11,21 @@ from oracle.make_golden import golden_cases, case_inputs, t
 from climategan_amd import fill
 
 qdt = torch.bfloat16 if "bf16" in sys.argv else torch.float16
-case = golden_cases()["mstep"]
+SPADE = "spade" in sys.argv
+CASE = "mstep_spade" if SPADE else "mstep"
+case = golden_cases()[CASE]
 opts = ref_shim.default_opts(); opts.tasks = ["d", "s", "m"]
+opts.gen.m.use_spade = SPADE
 L = ref_shim.ref("losses")
 
 def build():
-    with contextlib.redirect_stdout(io.StringIO()):
-        G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+    orig = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self          # MaskSpadeDecoder's hard-coded .cuda() (masker.py:196)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            G = ref_shim.ref("generator").create_generator(opts, "cpu", no_init=True)
+    finally:
+        torch.nn.Module.cuda = orig
     shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
     G.load_state_dict({k: t(v) for k, v in fill.fill_state_dict(shapes, case["seed"], gain=case["gain"]).items()})
     G.train()
@@ -26,12 +34,12 @@ def build():
     return G
 
 def run(G):
-    inp = {k: t(v) for k, v in case_inputs("mstep", case).items()}
+    inp = {k: t(v) for k, v in case_inputs(CASE, case).items()}
     x = inp["x_r"]
     z = G.encode(x)
     d, zd = G.decoders["d"](z)
     s = G.decoders["s"](z, zd)
-    m = G.decoders["m"](z, cond=None, z_depth=zd)
+    m = G.decoders["m"](z, cond=G.make_m_cond(d, s, x) if SPADE else None, z_depth=zd)
     p = torch.sigmoid(m)
     loss = L.MinentLoss()(torch.softmax(s, 1)) * 0.001 + L.TVLoss()(p) + L.MinentLoss(2, 0.1)(torch.cat([p, 1 - p], 1)) * 0.5
     loss.backward()
@@ -52,7 +60,13 @@ for mod in G.modules():
             return o
         mod.register_forward_hook(fwd_hook)
 gq = run(G)
-for k in ("encoder.conv1.weight", "encoder.layer1.0.conv1.weight", "encoder.layer3.1.conv3.weight", "encoder.layer3.16.conv3.weight",
+KEYS_SPADE = ("decoders.d.dec4.conv.weight", "decoders.s.decoder.conv_cat.0.conv.weight",
+              "decoders.m.low_level_conv.conv.module.weight_bar", "decoders.m.merge_feats_conv.conv.module.weight_bar",
+              "decoders.m.spade_blocks.0.conv_0.module.weight_bar", "decoders.m.spade_blocks.0.norm_0.mlp_gamma.weight",
+              "decoders.m.spade_blocks.1.conv_0.module.weight_bar", "decoders.m.spade_blocks.1.conv_s.module.weight_bar",
+              "decoders.m.spade_blocks.2.conv_0.module.weight_bar", "decoders.m.spade_blocks.2.conv_1.module.weight_bar",
+              "decoders.m.spade_blocks.2.norm_0.mlp_gamma.weight", "decoders.m.mask_conv.conv.module.weight_bar")
+for k in KEYS_SPADE if SPADE else ("encoder.conv1.weight", "encoder.layer1.0.conv1.weight", "encoder.layer3.1.conv3.weight", "encoder.layer3.16.conv3.weight",
           "encoder.layer4.2.conv2.weight", "decoders.d.enc4_2.conv.weight", "decoders.s.aspp.conv1.conv.weight",
           "decoders.s.decoder.conv_cat.0.conv.weight", "decoders.m.model.4.conv.module.weight_bar", "decoders.m.model.7.conv.weight"):
     a, b = g32[k].flatten().double(), gq[k].flatten().double()
