@@ -247,7 +247,9 @@ class SPADEResnetBlock(nn.Module):
             raise NotImplementedError(
                 "The type of activation is not supported: {}".format(self.last_activation))
         # instance-norm statistics are shared by norm_0 and norm_s (same x); a batch param-free norm brings its own
-        stats = None if self.param_free_norm == "batch" else ops.instnorm_stats(x, eps=self.norm_0.param_free_norm.eps)
+        # (computed outside the graph: SpadeFn's backward carries the statistics' dependence on x itself)
+        stats = (None if self.param_free_norm == "batch" else
+                 ops.instnorm_stats(ops.detached(x), eps=self.norm_0.param_free_norm.eps))
         if self.learned_shortcut:
             s = self.norm_s.forward_nhwc(x, cond, stats, act=ops.ACT_NONE, x_upsample=x_upsample)
             x_s = conv_forward(self.conv_s, self._caches["conv_s"], s, **self._tr(self.conv_s))

@@ -159,7 +159,7 @@ class OmniGenerator(nn.Module):
             from .autograd import MakeMCondFn
             cond_c = 1 + s.c + (3 if x is not None else 0)
             return ops.NHWC(MakeMCondFn.apply(d.t, s.t, x, s.c), cond_c)
-        return ops.make_m_cond(d, s, x)
+        return ops.make_m_cond(ops.detached(d), ops.detached(s), x)      # spade.detach, or nothing to differentiate
 
     def mask(self, x=None, z=None, cond=None, z_depth=None, sigmoid=True):
         """reference generator.py:232-277: logits = decoders["m"](z, cond, z_depth); sigmoid by default."""

@@ -259,7 +259,7 @@ class SPADE(nn.Module):
                 # batch statistics over (n, h, w) -- those of the up-sampled tensor when the x2 nearest upsample is
                 # folded in: every pixel repeated four times gives the same mean and biased variance, only the running
                 # variance's n/(n-1) factor sees the four-fold count (corrected below)
-                flat = ops.NHWC(x.t.view(1, x.n * x.h * x.w, 1, x.t.shape[-1]), x.c)
+                flat = ops.NHWC(x.t.detach().view(1, x.n * x.h * x.w, 1, x.t.shape[-1]), x.c)   # SpadeFn differentiates
                 mean, rstd, _, _ = ops.batchnorm_train_stats(
                     flat, None, None, bn.running_mean if bn.track_running_stats else None,
                     bn.running_var if bn.track_running_stats else None,
@@ -277,7 +277,7 @@ class SPADE(nn.Module):
                 _grad_guard(self)
                 stats = ops.bn_eval_stats(bn, x.n)
         elif stats is None:
-            stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
+            stats = ops.instnorm_stats(ops.detached(x), eps=self.param_free_norm.eps)
         if needs_grad(self, x.t, cond.t):
             from .autograd import SpadeFn
             cfg = dict(c=x.c, cond_c=cond.c, act=act, slope=0.2, x_upsample=bool(x_upsample), batch_stats=batch_stats)

@@ -47,6 +47,20 @@ def _need_cuda(*ts):
         if t is not None and not t.is_cuda:
             raise RuntimeError("climategan_amd ops need device tensors (got a %s tensor); there is no CPU path"
                                % t.device)
+    # These functions launch kernels and record nothing for autograd.  Inside an ``autograd.Function`` (forward and
+    # backward run with grad mode off) that is the point; anywhere else a tensor that carries a graph would come out
+    # silently detached -- refuse, the caller wants the grad-aware wrapper (``functional`` / ``autograd``).
+    if torch.is_grad_enabled():
+        for t in ts:
+            if t is not None and t.requires_grad and not t.is_leaf:
+                raise RuntimeError("climategan_amd.ops: called with grad mode on and a tensor that carries an autograd "
+                                   "graph: the result would be silently detached; use climategan_amd.functional / "
+                                   "autograd (HIP backward) or detach() / no_grad() explicitly")
+
+
+def detached(x: "NHWC") -> "NHWC":
+    """The same map without its autograd graph (an explicit stop-gradient for the ops that need one)."""
+    return NHWC(x.t.detach(), x.c)
 
 
 @dataclass
