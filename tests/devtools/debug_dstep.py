@@ -1,7 +1,7 @@
 import sys
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent / "tests"))
 from helpers import golden_cases, load_golden, t
 from oracle.make_golden import case_inputs
 import test_gpu_train as T

@@ -1,11 +1,11 @@
 """Dev-container measurement (needs /root/reference): how far do the REFERENCE's own masker gradients move when every
 conv / norm / activation output and every gradient flowing back through them is rounded to a 16-bit type (the storage
 precision of this package's training path)?  Prints cosine vs the fp32 gradients for a selection of parameters.
-usage: python tools/measure_ref_grad_quant.py [fp16|bf16] [spade]   (spade: the SPADE mask decoder, golden case mstep_spade)"""
+usage: python tests/devtools/measure_ref_grad_quant.py [fp16|bf16] [spade]   (spade: the SPADE mask decoder, golden case mstep_spade)"""
 import contextlib, io, sys
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from oracle import ref_shim
 from oracle.make_golden import golden_cases, case_inputs, t
 from climategan_amd import fill

@@ -6,7 +6,7 @@ Tolerances.  north_star asks for "1e-3 fp16 tolerance"; that is what the per-op 
 every inter-layer activation in 16 bit, so rounding accumulates through ~30 conv/SPADE layers; outputs are
 tanh-bounded in [-1,1].  For scale: the reference's OWN ``.half()`` path run on the CPU deviates from its
 fp32 output by max 6.5e-3 / mean 8.1e-4 on the painter_up4 fixture (bf16: 5.1e-2 / 6.6e-3), measured in
-the dev container (tools/measure_ref_half.py -> REF_HALF_DEV below).  Bound enforced here against the reference's
+the dev container (tests/devtools/measure_ref_half.py -> REF_HALF_DEV below).  Bound enforced here against the reference's
 fp32 golden vectors: the HIP path must be no further from fp32 than 2x what the reference's own 16-bit path is
 (max and mean abs error, per fixture and dtype).
 """
@@ -21,7 +21,7 @@ from oracle.make_golden import case_inputs, summarize
 pytestmark = pytest.mark.gpu
 
 CASES = golden_cases()
-# (max, mean) abs deviation of the reference's own .to(dtype) CPU path from its fp32 output (tools/measure_ref_half.py)
+# (max, mean) abs deviation of the reference's own .to(dtype) CPU path from its fp32 output (tests/devtools/measure_ref_half.py)
 REF_HALF_DEV = {
     ("painter_up4", "float16"): (0.006537, 0.0008081),
     ("painter_up4", "bfloat16"): (0.05128, 0.006619),

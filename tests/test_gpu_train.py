@@ -235,7 +235,7 @@ def masker_batch(case, name=MNAME):
 
 
 # Cosine between the REFERENCE's fp32 gradients and the reference's own gradients when every conv / norm / activation
-# output and the gradient flowing back through it is rounded to 16 bit (tools/measure_ref_grad_quant.py, dev container):
+# output and the gradient flowing back through it is rounded to 16 bit (tests/devtools/measure_ref_grad_quant.py, dev container):
 # this untrained ResNet-101 in training mode is chaotic enough that 16-bit storage alone decorrelates the encoder's
 # gradient direction (norms stay within 4 %), for the reference exactly as for this build.
 REF_QUANT_COS = {
@@ -275,7 +275,7 @@ def test_masker_loss_terms_fp16(name):
     _check_masker_terms(T, gold, loss, rel=2.5e-2, gi_abs=3e-5)
 
 
-# The same measurement for the SPADE mask decoder (tools/measure_ref_grad_quant.py bf16|fp16 spade).
+# The same measurement for the SPADE mask decoder (tests/devtools/measure_ref_grad_quant.py bf16|fp16 spade).
 REF_QUANT_COS_SPADE = {
     "float16": {"decoders.m.low_level_conv.conv.module.weight_bar": 0.51, "decoders.m.spade_blocks.0.conv_0.module.weight_bar": 0.47,
                 "decoders.m.spade_blocks.1.conv_0.module.weight_bar": 0.74, "decoders.m.spade_blocks.2.conv_0.module.weight_bar": 0.97,
