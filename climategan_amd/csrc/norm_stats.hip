@@ -119,12 +119,28 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   if (idx >= n_total * cs) return;
   const int n = idx / cs, c = idx - n * cs;
   MeanM2 acc = {0.f, 0.f, 0.f};
-  for (int k = lane; k < chunks; k += 64) {
-    int p0 = k * ppb;
-    int cnt = min(hw, p0 + ppb) - p0;
-    const float* o = partial + (((size_t)n * chunks + k) * cs + c) * 2;
-    MeanM2 b = {(float)cnt, o[0], o[1]};
-    acc = chan_merge(acc, b);
+  // four partial rows in flight per lane (the rows of one lane are cs * 8 bytes apart: every load is its own cache
+  // line, so the latency has to be overlapped); merged in the same order as a plain loop
+  for (int k0 = lane; k0 < chunks; k0 += 256) {
+    float2 v[4];
+    int cnt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 64 * j;
+      cnt[j] = 0;
+      v[j] = make_float2(0.f, 0.f);
+      if (k < chunks) {
+        const int p0 = k * ppb;
+        cnt[j] = min(hw, p0 + ppb) - p0;
+        v[j] = *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * cs + c) * 2);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (cnt[j] > 0) {
+        MeanM2 b = {(float)cnt[j], v[j].x, v[j].y};
+        acc = chan_merge(acc, b);
+      }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

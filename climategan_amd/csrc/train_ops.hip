@@ -323,10 +323,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int ch = blockIdx.x * 16 + chl;
   float a = 0.f, b = 0.f;
   if (ch < cs)
-    for (int k = kl; k < chunks; k += 16) {
-      const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)k * cs + ch) * 2);
-      a += v.x;
-      b += v.y;
+    for (int k0 = kl; k0 < chunks; k0 += 64) {             // four rows in flight, summed in loop order
+      float2 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 16 * j;
+        v[j] = k < chunks ? *reinterpret_cast<const float2*>(partial + ((size_t)k * cs + ch) * 2) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a += v[j].x;
+        b += v[j].y;
+      }
     }
   red[kl][chl][0] = a;
   red[kl][chl][1] = b;
