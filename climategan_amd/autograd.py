@@ -268,7 +268,7 @@ class BatchNormActFn(torch.autograd.Function):
             dres = torch.empty_like(x_t) if want_res else None
         dg = db = None
         if gamma is not None:
-            dg, db = torch.zeros((2, c), dtype=torch.float32, device=x_t.device).unbind(0)   # one fill for both
+            dg, db = torch.empty((2, c), dtype=torch.float32, device=x_t.device).unbind(0)   # written by the kernel
         _lib.check(lib.cgan_batchnorm_act_bwd(
             ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
             ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._ptr(dres) if dres is not None and dres is not dy_t else None,

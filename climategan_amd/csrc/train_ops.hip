@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
   }
 }
 
-// Stage 2: totals over the chunks, dgamma += sum dz xh, dbeta += sum dz, and the three per-channel coefficients of
+// Stage 2: totals over the chunks, dgamma = sum dz xh, dbeta = sum dz (written, not accumulated), and the three per-channel
+// coefficients of
 //   dx = rstd gamma (dz - mean(dz) - xh mean(dz xh))  =  A dz + B x + C
 // block = 16 channels x 16 chunk lanes
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks,
@@ -348,8 +349,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
   float A = 0.f, B = 0.f, C = 0.f;
   if (ch < c) {
-    if (dgamma) dgamma[ch] += s2;
-    if (dbeta) dbeta[ch] += s1;
+    if (dgamma) dgamma[ch] = s2;
+    if (dbeta) dbeta[ch] = s1;
     const float rs = rstd[ch], mu = mean[ch];
     A = rs * (gamma ? gamma[ch] : 1.f);
     const float m1 = s1 * inv_count, m2 = s2 * inv_count;

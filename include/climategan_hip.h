@@ -297,7 +297,7 @@ int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const f
  *                     running statistics (momentum, unbiased variance) as nn.BatchNorm2d does; count = n*h*w;
  *                     num_batches_tracked (device int64 scalar, may be NULL) is incremented by one
  *  batchnorm_act_bwd  given x (the BN input), out = act(bn(x) [+ residual]) and dy: dx, and dgamma / dbeta
- *                     ACCUMULATED (fp32); dz_out (may be NULL) receives dz = dy * act'(out), the gradient of the
+ *                     WRITTEN (fp32 [c], no zero fill needed; either may be NULL); dz_out (may be NULL) receives dz = dy * act'(out), the gradient of the
  *                     residual fused by cgan_norm_add_act_apply; workspace cgan_batchnorm_act_bwd_workspace_bytes(c) */
 int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma, const float* beta,
                           float eps, float momentum, int64_t count, float* running_mean, float* running_var,
