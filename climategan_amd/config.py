@@ -48,18 +48,20 @@ def default_opts() -> Opts:
         "gen": {
             "opt": {"optimizer": "ExtraAdam", "beta1": 0.9, "lr": {"default": 0.00005}, "lr_policy": "step",
                     "lr_step_size": 5, "lr_milestones": 15, "lr_gamma": 0.5},   # :73-88
-            "encoder": {"architecture": "deeplabv3"},                    # :103
+            "encoder": {"architecture": "deeplabv3", "init_type": "xavier", "init_gain": 0.02},   # :92-93,103
             "deeplabv3": {"backbone": "resnet", "output_stride": 8},     # :115-116
-            "d": {"architecture": "dada", "upsample_featuremaps": True, "output_dim": 1, "norm": "batch"},   # :122-134
+            "d": {"architecture": "dada", "upsample_featuremaps": True, "output_dim": 1, "norm": "batch",
+                  "init_type": "xavier", "init_gain": 0.02},             # :92-93,122-134
             "s": {"use_advent": True, "use_dada": True, "use_minent": True, "architecture": "deeplabv3", "output_dim": 11,
-                  "num_classes": 11},                                    # :135-143
-            "m": {"use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
+                  "num_classes": 11, "init_type": "xavier", "init_gain": 0.02},                                    # :135-143
+            "m": {"init_type": "xavier", "init_gain": 0.02, "use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
                   "use_dada": False, "use_minent": True, "use_minent_var": True, "use_ground_intersection": True, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
                   "activ": "lrelu", "pad_type": "reflect", "use_proj": True,
                   "spade": {"latent_dim": 128, "detach": False, "cond_nc": 15, "spade_use_spectral_norm": True,
                             "spade_param_free_norm": "batch", "num_layers": 3,
                             "activations": {"all_lrelu": True}}},       # :166-190 (+ default-gen :89-99)
             "p": {                                                       # :144-165
+                "init_type": "xavier", "init_gain": 0.02, "loss": "gan",
                 "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True,
                 "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",
                 "spade_use_spectral_norm": True, "use_final_shortcut": False,
@@ -69,10 +71,10 @@ def default_opts() -> Opts:
             "soft_shift": 0.2, "flip_prob": 0.05,                        # :194-195
             "opt": {"optimizer": "ExtraAdam", "beta1": 0.5, "lr": {"default": 0.00002}, "lr_policy": "step",
                     "lr_step_size": 15, "lr_milestones": 5, "lr_gamma": 0.5},   # :196-211
-            "p": {"input_nc": 3, "ndf": 64, "n_layers": 4, "norm": "instance", "use_sigmoid": False, "num_D": 3,
+            "p": {"init_type": "xavier", "init_gain": 0.02, "input_nc": 3, "ndf": 64, "n_layers": 4, "norm": "instance", "use_sigmoid": False, "num_D": 3,
                   "get_intermediate_features": True, "use_local_discriminator": False},   # :213-227
-            "m": {"architecture": "base", "gan_type": "WGAN_norm"},      # :229-235
-            "s": {"gan_type": "WGAN_norm"},                              # :236-240
+            "m": {"architecture": "base", "gan_type": "WGAN_norm", "init_type": "xavier", "init_gain": 0.02},   # :229-235
+            "s": {"gan_type": "WGAN_norm", "init_type": "xavier", "init_gain": 0.02},                              # :236-240
         },
         "events": {"smog": {"airlight": 0.76, "beta": 2, "vr": 1, "yellow_color": [224, 192, 29], "alpha": 20},
                    "fire": {"kernel_size": 281, "kernel_sigma": 140.5, "transparency": 200, "sky_inc_factor": 0.12,

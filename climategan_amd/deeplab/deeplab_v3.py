@@ -20,6 +20,15 @@ class ConvBNReLU(nn.Module):
                               bias=True)
         self.bn = nn.BatchNorm2d(out_chan)
         self._cache = _PackCache()
+        self.init_weight()          # unconditional in the reference too (deeplab_v3.py:52), whatever ``no_init`` says
+
+    def init_weight(self):
+        """reference deeplab_v3.py:59-64: kaiming-normal with a=1 (gain 1: std = 1/sqrt(fan_in)), zero bias."""
+        for ly in self.children():
+            if isinstance(ly, nn.Conv2d):
+                nn.init.kaiming_normal_(ly.weight, a=1)
+                if ly.bias is not None:
+                    nn.init.constant_(ly.bias, 0)
 
     def forward_nhwc(self, x):
         return conv_bn_forward(self.conv, self.bn, self._cache, x)
@@ -39,6 +48,17 @@ class ASPPv3Plus(nn.Module):
         self.conv3 = ConvBNReLU(in_chan, 256, ks=3, dilation=12, padding=12)
         self.conv4 = ConvBNReLU(in_chan, 256, ks=3, dilation=18, padding=18)
         self.conv_out = ConvBNReLU(256 * 4, 256, ks=1)   # padding=1 default: output grows by 2 (reference quirk)
+        if not no_init:
+            self.init_weight()
+
+    def init_weight(self):
+        """reference deeplab_v3.py:111-116: loops over the DIRECT children looking for ``nn.Conv2d`` -- they are all
+        ``ConvBNReLU`` blocks, so this touches nothing (each block already initialised itself); kept for the API."""
+        for ly in self.children():
+            if isinstance(ly, nn.Conv2d):
+                nn.init.kaiming_normal_(ly.weight, a=1)
+                if ly.bias is not None:
+                    nn.init.constant_(ly.bias, 0)
 
     def forward_nhwc(self, x):
         feats = [c.forward_nhwc(x) for c in (self.conv1, self.conv2, self.conv3, self.conv4)]
@@ -80,6 +100,40 @@ class DeepLabV3Decoder(nn.Module):
         from ..utils import find_target_size
 
         self._target_size = find_target_size(opts, "s")
+        if not no_init:
+            # reference deeplab_v3.py:178-190: every conv kaiming-normal on fan_out (this overrides the blocks' own
+            # a=1 draw), zero biases, BatchNorm weight 1 / bias 0; then the pretrained ASPP + decoder
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                    if m.bias is not None:
+                        nn.init.zeros_(m.bias)
+                elif isinstance(m, nn.BatchNorm2d):
+                    nn.init.ones_(m.weight)
+                    nn.init.zeros_(m.bias)
+                elif isinstance(m, nn.Linear):
+                    nn.init.normal_(m.weight, 0, 0.01)
+                    nn.init.zeros_(m.bias)
+            self.load_pretrained(opts)
+
+    def load_pretrained(self, opts):
+        """reference deeplab_v3.py:192-229 (resnet branch): ``aspp.*`` strictly, ``decoder.*`` minus the 19-class
+        Cityscapes head, from the checkpoint ``opts.gen.deeplabv3.pretrained_model.resnet``.  The reference asserts the
+        file exists; so does this -- unless the option is unset / "none" (the checkpoints are not redistributable: an
+        explicit opt-out keeps the from-scratch initialisation above, and says so)."""
+        from . import pretrained_path
+        path = pretrained_path(opts)
+        if path is None:
+            print("- DeepLabV3Decoder: no pretrained_model.resnet configured, keeping the kaiming initialisation")
+            return
+        assert path.exists(), path
+        import torch
+        std = torch.load(path, map_location="cpu")
+        self.aspp.load_state_dict({k.replace("aspp.", ""): v for k, v in std.items() if k.startswith("aspp.")})
+        self.decoder.load_state_dict({k.replace("decoder.", ""): v for k, v in std.items()
+                                      if k.startswith("decoder.") and not (len(v.shape) > 0 and v.shape[0] == 19)},
+                                     strict=False)
+        print("- Loaded pre-trained DeepLabv3+ (Resnet) Decoder & ASPP as Seg Decoder")
 
     def set_target_size(self, size):
         self._target_size = size[:2] if isinstance(size, (list, tuple)) else (size, size)

@@ -18,10 +18,26 @@ from .norms import DEFAULT_COMPUTE_DTYPE, SpectralNorm, needs_grad, spectral_nor
 
 
 def create_discriminator(opts, device, no_init=False, verbose=0):
-    """reference discriminator.py:16-39.  (Weight init as in the reference is a no-op for spectral-norm wrapped
-    convs -- ``init_weights`` looks for a ``weight`` attribute they do not have, tutils.py:58-60 -- so the
-    parameters keep torch's default conv init; nothing else to initialise.)"""
-    return OmniDiscriminator(opts).to(device)
+    """reference discriminator.py:16-39: unless ``no_init``, ``init_weights`` per task with
+    ``opts.dis[task].init_type / init_gain`` (defaults.yaml:218-219,231-232,237-238: xavier, 0.02).  Spectral-norm
+    wrapped convs (the PatchGAN and, with ``gan_type: WGAN_norm``, the ADVENT nets) have no ``weight`` attribute and are
+    skipped (tutils.py:58-60); with ``gan_type`` in {GAN, WGAN, WGAN_gp} the ADVENT discriminators are plain
+    ``nn.Conv2d`` stacks and do get drawn.  (With ``no_init`` the reference returns the module without moving it to
+    ``device``, discriminator.py:18-19; the mirror always moves it -- a CPU discriminator cannot run here.)"""
+    from .tutils import init_weights
+
+    disc = OmniDiscriminator(opts)
+    if no_init:
+        return disc.to(device)
+    for task, model in disc.items():
+        nets = list(model.items()) if isinstance(model, nn.ModuleDict) else [("", model)]
+        for domain, net in nets:
+            node = opts.dis[task]
+            it = node["init_type"] if "init_type" in node else "xavier"
+            ig = node["init_gain"] if "init_gain" in node else 0.02
+            init_weights(net, init_type=it, init_gain=ig, verbose=verbose,
+                         caller=("create_discriminator %s %s" % (task, domain)).strip())
+    return disc.to(device)
 
 
 def get_norm_layer(norm_type="instance"):

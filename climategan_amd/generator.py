@@ -14,13 +14,43 @@ from .depth import create_depth_decoder
 from .masker import create_mask_decoder
 from .norms import DEFAULT_COMPUTE_DTYPE, _grad_guard, spectral_norm_step_all
 from .painter import create_painter
+from .tutils import init_weights
 
 
 def create_generator(opts, device="cpu", latent_shape=None, no_init=False, verbose=0):
-    """reference generator.py:24-61.  The reference never re-initialises the Painter (it keeps torch's default
-    conv init, generator.py:30-58 only loops over ``G.decoders``), so there is nothing to init here."""
+    """reference generator.py:24-61.  Unless ``no_init``: ``init_weights`` with ``opts.gen[task].init_type / init_gain``
+    (defaults.yaml:92-93: xavier, 0.02) on every decoder EXCEPT the segmentation head "s" (which initialises itself,
+    deeplab_v3.py:178-190) -- i.e. the depth decoder's convs and BatchNorms, the mask decoder's plain output conv and,
+    for the SPADE mask decoder, its ``mlp_shared / mlp_gamma / mlp_beta`` convs and BatchNorms (spectral-norm wrapped
+    convs have no ``weight`` and are skipped, tutils.py:58-60); the encoder only when its architecture is "base".  The
+    Painter is never re-initialised by the reference (it keeps torch's default conv init)."""
     G = OmniGenerator(opts, latent_shape, verbose, no_init)
+    if no_init:
+        return G.to(device)
+    for model in G.decoders:
+        if model == "s":
+            continue
+        net = G.decoders[model]
+        nets = [(dom, sub) for dom, sub in net.items()] if isinstance(net, nn.ModuleDict) else [("", net)]
+        for dom, sub in nets:
+            init_weights(sub, init_type=_opt(opts.gen[model], "init_type", "xavier"),
+                         init_gain=_opt(opts.gen[model], "init_gain", 0.02), verbose=verbose,
+                         caller=("create_generator decoder %s %s" % (model, dom)).strip())
+    if G.encoder is not None and opts.gen.encoder.architecture == "base":
+        init_weights(G.encoder, init_type=_opt(opts.gen.encoder, "init_type", "xavier"),
+                     init_gain=_opt(opts.gen.encoder, "init_gain", 0.02), verbose=verbose,
+                     caller="create_generator encoder")
     return G.to(device)
+
+
+def _opt(node, key, default):
+    """``node[key]`` with the value of ``gen.default`` (defaults.yaml:89-99, merged into every task by the reference's
+    ``load_opts``, utils.py:183-188) when the key is absent or an empty auto-vivified node."""
+    try:
+        v = node[key]
+    except (KeyError, TypeError):
+        return default
+    return default if (isinstance(v, dict) and not v) else v
 
 
 class OmniGenerator(nn.Module):

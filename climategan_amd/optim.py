@@ -39,8 +39,12 @@ class ExtraAdam(Optimizer):
             by_step = {}
             for p in group["params"]:
                 if p.grad is None:
-                    # the reference also saves a copy of gradient-less parameters here (optim.py:166-168) but never
-                    # reads it back (step() skips them, optim.py:186-188): not observable, not reproduced
+                    # the reference saves a copy of EVERY parameter at the first extrapolation (optim.py:166-168); the
+                    # copy of a gradient-less one is read back only if that parameter does receive a gradient by the
+                    # following step() (domain batches that differ between the two calls).  Parameters that can never
+                    # get one (requires_grad=False: the spectral-norm u / v vectors) are skipped: not observable.
+                    if mode == 0 and not self._has_copy and p.requires_grad:
+                        self.params_copy[id(p)] = p.data.clone()
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.data.is_contiguous():
                     raise RuntimeError("ExtraAdam (HIP): contiguous fp32 device parameters expected")

@@ -327,9 +327,10 @@ class Trainer:
             if "s" in batch["data"] and "s" in self.opts.tasks:
                 with torch.no_grad():
                     s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
-                loss, _ = self._advent_d_term("s", s_pred, d_pred, domain)
-                total = total + loss * adv
-            if "m" in batch["data"] and "m" in self.opts.tasks:
+                if self.opts.gen.s.use_advent:                                             # trainer.py:1452
+                    loss, _ = self._advent_d_term("s", s_pred, d_pred, domain)
+                    total = total + loss * adv
+            if "m" in batch["data"] and "m" in self.opts.tasks and self.opts.gen.m.use_advent:   # trainer.py:1563
                 with torch.no_grad():
                     cond = None
                     if self.opts.gen.m.use_spade and "d" in self.opts.tasks:               # trainer.py:1127-1131
@@ -375,10 +376,14 @@ class Trainer:
                 g_loss = g_loss + self.get_masker_loss(multi_domain_batch)
             if self.has_painter and "rf" in multi_domain_batch:
                 g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
+            if not isinstance(g_loss, torch.Tensor):
+                # every term switched off (all lambdas 0): the reference would fail on ``int.backward()``; nothing to
+                # differentiate and nothing for the optimizer to do
+                return torch.zeros((), device=self.device)
             g_loss.backward()
-            self._unscale_grads(self.G)
             if self.g_reducer is not None:
                 self.g_reducer.finish()                                 # before extrapolation AND step (trainer.py:678-683)
+            self._unscale_grads(self.G)
             if self.global_step % 2 == 0:
                 self.g_opt.extrapolation()
             else:
@@ -390,8 +395,10 @@ class Trainer:
     @staticmethod
     def _unscale_grads(module):
         """fp16 loss scaling (autograd.set_grad_scale): every loss kernel wrote its input gradient times GRAD_SCALE, so
-        the parameter gradients carry that factor; divide it out before the all-reduce / optimizer (one fused
-        multi-tensor multiply, nothing at the default scale of 1)."""
+        the parameter gradients carry that factor; divide it out before the optimizer -- AFTER the reducer's
+        ``finish()``: the bucket all-reduces were launched from hooks during the backward on the still-scaled
+        gradients and ``finish()`` writes those averages back over ``p.grad`` (one fused multi-tensor multiply, nothing
+        at the default scale of 1)."""
         from . import autograd as ag
         if ag.GRAD_SCALE != 1.0:
             grads = [p.grad for p in module.parameters() if p.grad is not None]
@@ -411,10 +418,12 @@ class Trainer:
             d_loss = d_loss + self.get_D_loss(multi_domain_batch)
         if self.has_masker and any(d != "rf" for d in multi_domain_batch):
             d_loss = d_loss + self.get_masker_d_loss(multi_domain_batch)
+        if not isinstance(d_loss, torch.Tensor):     # no discriminator term is active (use_advent off, no Painter)
+            return torch.zeros((), device=self.device)
         d_loss.backward()
-        self._unscale_grads(self.D)
         if self.d_reducer is not None:
             self.d_reducer.finish()
+        self._unscale_grads(self.D)
         if self.global_step % 2 == 0:
             self.d_opt.extrapolation()
         else:
