@@ -197,7 +197,7 @@ class PainterHeadsFn(torch.autograd.Function):
         (m,) = ctx.saved_tensors
         want_d, want_vgg = ctx.want
         dd = ops.NHWC(dd_t.contiguous(), 4) if want_d and dd_t is not None else None
-        dv = ops.NHWC(dv_t.contiguous(), 3) if want_vgg and dv_t is not None else None
+        dv = ops.NHWC(dv_t.contiguous(), 6) if want_vgg and dv_t is not None else None   # d/d(hi) = d/d(value)
         return ops.painter_heads_bwd(dd, dv, m).t, None, None, None, None
 
 

@@ -11,7 +11,7 @@ __host__ __device__ inline int grid_pt(long total) {
 
 // p = fake ? x (1 - m) + fake m : x          (OmniGenerator.paint's paste, generator.py:295-296)
 // d_in  = [m, p_r, p_g, p_b]                  (torch.cat([m, x], axis=1), trainer.py:1101-1102)        4 ch -> cs 8
-// vgg_in = vgg_preprocess(p * m)              (tutils.py:416-427: BGR, [0,255], mean-subtracted)        3 ch -> cs 8
+// vgg_in = vgg_preprocess(p * m)              (tutils.py:416-427: BGR, [0,255], mean-subtracted)  3 ch as hi | lo -> cs 8
 template <typename T>
 __global__ void painter_heads_fwd_kernel(const uint16_t* __restrict__ fake, const float* __restrict__ x,
                                          const float* __restrict__ m, uint16_t* __restrict__ d_in,
@@ -34,13 +34,17 @@ __global__ void painter_heads_fwd_kernel(const uint16_t* __restrict__ fake, cons
       reinterpret_cast<u32x4*>(d_in)[i] = o;
     }
     if (vgg_in) {
+      // values of magnitude 100-150 in 16 bit would carry +-0.5 (bf16) / +-0.06 (fp16) of rounding into the first VGG
+      // conv: store v = hi + lo (hi = v rounded to 16 bit, lo = the remainder, also 16 bit) in channels 0-2 / 3-5; the
+      // first conv is linear, so running it on 6 input channels with its weights repeated gives conv(w, hi + lo)
       const float b = (pc[2] * mv + 1.f) * 255.f * 0.5f - 103.939f;
       const float g = (pc[1] * mv + 1.f) * 255.f * 0.5f - 116.779f;
       const float r = (pc[0] * mv + 1.f) * 255.f * 0.5f - 123.680f;
+      const float bh = f32_of_bits<T>(bits_of<T>(b)), gh = f32_of_bits<T>(bits_of<T>(g)), rh = f32_of_bits<T>(bits_of<T>(r));
       u32x4 o;
-      o[0] = pack2<T>(b, g);
-      o[1] = pack2<T>(r, 0.f);
-      o[2] = 0u;
+      o[0] = pack2<T>(bh, gh);
+      o[1] = pack2<T>(rh, b - bh);
+      o[2] = pack2<T>(g - gh, r - rh);
       o[3] = 0u;
       reinterpret_cast<u32x4*>(vgg_in)[i] = o;
     }

@@ -109,7 +109,8 @@ class Vgg19(nn.Module):
         self._caches = {}
 
     def forward(self, X: ops.NHWC):
-        """X: vgg_preprocess-ed NHWC map (3 channels); returns [relu1_1, relu2_1, relu3_1, relu4_1, relu5_1]."""
+        """X: vgg_preprocess-ed NHWC map (3 channels, or the 6-channel hi | lo pair form of ``ops.painter_heads``);
+        returns [relu1_1, relu2_1, relu3_1, relu4_1, relu5_1]."""
         outs = []
         y = X
         for k in range(5):
@@ -120,11 +121,22 @@ class Vgg19(nn.Module):
                 name, mod = mods[j]
                 if isinstance(mod, nn.Conv2d):                      # conv + the ReLU that follows it, fused
                     cache = self._caches.setdefault(name, _PackCache())
-                    pw = cache.get((mod.weight, mod.bias), y.t.dtype,
-                                   lambda mod=mod: ops.pack_conv_weight(mod.weight.data, mod.bias.data, y.t.dtype))
+                    weight = mod.weight
+                    if y.c == 2 * mod.in_channels:
+                        # the (hi | lo) pair form of the pre-processed image (ops.painter_heads): conv(w, hi + lo) =
+                        # conv([w | w], [hi | lo]); the doubled weight is rebuilt only when the parameter changes
+                        if mod.weight.requires_grad:
+                            raise NotImplementedError("Vgg19: the (hi | lo) input form needs a frozen first conv")
+                        key = (mod.weight._version, mod.weight.data_ptr())
+                        if getattr(self, "_w2_key", None) != key:
+                            self._w2, self._w2_key = torch.cat([mod.weight.data, mod.weight.data], dim=1), key
+                        weight = self._w2
+                    pw = cache.get((weight, mod.bias), y.t.dtype,
+                                   lambda weight=weight, mod=mod: ops.pack_conv_weight(weight.data, mod.bias.data,
+                                                                                       y.t.dtype))
                     if torch.is_grad_enabled() and (y.t.requires_grad or mod.weight.requires_grad):
                         cfg = dict(c_in=y.c, stride=1, pad=1, dilation=1, act=ops.ACT_RELU, slope=0.0)
-                        y = ops.NHWC(ConvFn.apply(y.t, mod.weight, mod.bias, None, pw, cfg, None), mod.out_channels)
+                        y = ops.NHWC(ConvFn.apply(y.t, weight, mod.bias, None, pw, cfg, None), mod.out_channels)
                     else:
                         y = ops.conv2d(y, pw, pad=1, act=ops.ACT_RELU)
                     j += 2

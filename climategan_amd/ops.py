@@ -715,7 +715,9 @@ def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=A
 
 def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype, want_d=True, want_vgg=False):
     """(d_in, vgg_in) of the pasted image p = x (1 - m) + fake m (or p = x when ``fake`` is None): the discriminator
-    input [m | p] (4 channels) and vgg_preprocess(p * m) (3 channels), NHWC 16-bit; x, m NCHW fp32."""
+    input [m | p] (4 channels) and vgg_preprocess(p * m), NHWC 16-bit; x, m NCHW fp32.  The VGG input is stored as a
+    16-bit pair per colour, channels [b_hi, g_hi, r_hi, b_lo, g_lo, r_lo] with value = hi + lo: its magnitudes (100-150)
+    would otherwise lose +-0.5 (bf16) in the store; ``losses.Vgg19`` runs its first conv on the six channels."""
     _need_cuda(x, m, fake.t if fake is not None else None)
     x = x.contiguous().float()
     m = m.contiguous().float()
@@ -725,7 +727,7 @@ def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype,
     lib = _lib.load()
     _lib.check(lib.cgan_painter_heads_fwd(_ptr(fake.t if fake is not None else None), _ptr(x), _ptr(m), _ptr(d_in),
                                           _ptr(v_in), _DT[dtype], n, h, w, _stream()), "cgan_painter_heads_fwd")
-    return (NHWC(d_in, 4) if want_d else None), (NHWC(v_in, 3) if want_vgg else None)
+    return (NHWC(d_in, 4) if want_d else None), (NHWC(v_in, 6) if want_vgg else None)
 
 
 def painter_heads_bwd(d_d_in: Optional[NHWC], d_vgg_in: Optional[NHWC], m: torch.Tensor) -> NHWC:

@@ -146,7 +146,7 @@ class Trainer:
         real_fake_cat = ops.NHWC(torch.cat([real_in.t, fake_in_t], dim=0), 4)            # trainer.py:1103,1363
         real_fake_d = self.D["p"](real_fake_cat, nhwc=True)
         real_d, fake_d = divide_pred(real_fake_d)
-        vgg = (ops.NHWC(vgg_fake_t, 3), vgg_real) if want_vgg else None
+        vgg = (ops.NHWC(vgg_fake_t, 6), vgg_real) if want_vgg else None
         return real_d, fake_d, vgg
 
     def get_painter_loss(self, multi_domain_batch):

@@ -519,6 +519,81 @@ def painter_g_step(sd_p: SD, sd_d: SD, m: torch.Tensor, x: torch.Tensor, z_h: in
 
 
 # --------------------------------------------------------------------------------------------------
+# VGG loss: losses.py:304-350 (Vgg19 slices + VGGLoss), tutils.py:416-427 (vgg_preprocess)
+# --------------------------------------------------------------------------------------------------
+# torchvision's published configuration "E" (VGG-19) up to features[29] (relu5_1): the reference takes
+# ``models.vgg19(pretrained=True).features`` and cuts it into slices [0,2) [2,7) [7,12) [12,21) [21,30) (losses.py:313-322).
+# The ARCHITECTURE is pinned through the reference's own Vgg19 / VGGLoss classes (golden ``vgg_small``); the pretrained
+# WEIGHTS are a download that is not in the tree, so loss VALUES with the real weights stay unpinned.
+VGG19_E = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512)
+VGG_SLICE_ENDS = (2, 7, 12, 21, 30)
+VGG_WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)
+
+
+def vgg19_layers():
+    """[(feature index, "conv", cin, cout) | (index, "relu") | (index, "pool")] for features[0:30]."""
+    layers, i, cin = [], 0, 3
+    for v in VGG19_E:
+        if v == "M":
+            layers.append((i, "pool"))
+            i += 1
+        else:
+            layers += [(i, "conv", cin, v), (i + 1, "relu")]
+            cin = v
+            i += 2
+    return [l for l in layers if l[0] < 30]
+
+
+def vgg19_shapes() -> Dict[str, Tuple[int, ...]]:
+    """State-dict layout of the reference's ``Vgg19`` module: ``slice<k>.<feature index>.{weight,bias}``."""
+    out = {}
+    for l in vgg19_layers():
+        if l[1] == "conv":
+            k = next(j for j, e in enumerate(VGG_SLICE_ENDS) if l[0] < e) + 1
+            out["slice%d.%d.weight" % (k, l[0])] = (l[3], l[2], 3, 3)
+            out["slice%d.%d.bias" % (k, l[0])] = (l[3],)
+    return out
+
+
+def vgg_preprocess(batch: torch.Tensor) -> torch.Tensor:
+    """tutils.py:416-427: RGB -> BGR, [-1, 1] -> [0, 255], minus the caffe means (103.939, 116.779, 123.680)."""
+    r, g, b = torch.chunk(batch, 3, dim=1)
+    bgr = (torch.cat((b, g, r), dim=1) + 1) * 255 * 0.5
+    return bgr - torch.tensor([103.939, 116.779, 123.680], dtype=bgr.dtype).reshape(1, 3, 1, 1)
+
+
+def vgg19_features(x: torch.Tensor, sd: SD) -> List[torch.Tensor]:
+    """``Vgg19.forward`` (losses.py:326-334): [relu1_1, relu2_1, relu3_1, relu4_1, relu5_1]."""
+    outs, k = [], 1
+    for l in vgg19_layers():
+        if l[0] == VGG_SLICE_ENDS[k - 1]:
+            outs.append(x)
+            k += 1
+        if l[1] == "conv":
+            p = "slice%d.%d" % (k, l[0])
+            x = F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+        elif l[1] == "relu":
+            x = F.relu(x)
+        else:
+            x = F.max_pool2d(x, 2, 2)
+    outs.append(x)
+    return outs
+
+
+def vgg_loss(sd: SD, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """``VGGLoss.forward`` (losses.py:345-350): sum_i w_i * L1(vgg_i(x), vgg_i(y).detach())."""
+    fx, fy = vgg19_features(x, sd), vgg19_features(y, sd)
+    return sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(VGG_WEIGHTS, fx, fy))
+
+
+def painter_vgg_term(sd_vgg: SD, fake: torch.Tensor, x: torch.Tensor, m: torch.Tensor, lambda_vgg: float = 10.0):
+    """The VGG term of ``get_painter_loss`` (trainer.py:1276-1287) on a painter output ``fake`` BEFORE the paste:
+    fake_flooded = x (1 - m) + fake m (generator.py:295-296); lambda * VGGLoss(pre(fake_flooded * m), pre(x * m))."""
+    fake_flooded = x * (1.0 - m) + fake * m
+    return vgg_loss(sd_vgg, vgg_preprocess(fake_flooded * m), vgg_preprocess(x * m)) * lambda_vgg
+
+
+# --------------------------------------------------------------------------------------------------
 # Smog event: Trainer.compute_smog (climategan/trainer.py:1879-1939), tutils.srgb2lrgb / lrgb2srgb (:534-565)
 # --------------------------------------------------------------------------------------------------
 def srgb2lrgb(x: torch.Tensor) -> torch.Tensor:

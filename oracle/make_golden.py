@@ -42,6 +42,9 @@ def golden_cases():
         "mstep_spade": dict(kind="mstep", H=128, W=160, B=2, seed=67, gain=1.6, sub=512, use_spade=True),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
+        # VGG term of get_painter_loss through the reference's own Vgg19 / VGGLoss / vgg_preprocess; VGG-19 weights from
+        # the portable fill with a He-preserving bound (gain sqrt(6): activations keep the input's 0-255 scale)
+        "vgg_small": dict(kind="vgg", H=64, W=96, B=2, seed=85, gain=2.449489742783178, lambda_vgg=10.0),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -94,6 +97,10 @@ def case_inputs(name, case):
                     depth_target=fill.uniform((B, 1, h, w), s * 100 + 9, 0.35, 6.95))
     if k == "gstep_p":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
+                    m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
+    if k == "vgg":
+        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
+                    fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
                     m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
     if k == "dstep_p":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
@@ -537,6 +544,64 @@ def run_reference_gstep(name, case):
     return out
 
 
+def reference_vgg_loss(case):
+    """The reference's ``VGGLoss`` (losses.py:337-350) around its own ``Vgg19`` (losses.py:304-334).  ``Vgg19`` asks
+    torchvision for ``models.vgg19(pretrained=True).features``; torchvision is not installed, so the shim's dummy
+    ``models`` gets a ``vgg19`` that returns torchvision's published configuration E as a plain ``nn.Sequential``
+    (conv3x3-ReLU(inplace) stacks with 2x2 max pools) -- the slicing, the five taps, the weights (1/32 ... 1) and the
+    L1 criterion are the reference's code.  Parameters: the portable fill."""
+    from oracle import cpu_ref, ref_shim
+
+    losses = ref_shim.ref("losses")
+
+    def vgg19(pretrained=True, **kw):
+        mods, cin = [], 3
+        for v in cpu_ref.VGG19_E + ("M",):        # torchvision's features has 37 entries; the reference reads [0, 30)
+            if v == "M":
+                mods.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                mods += [torch.nn.Conv2d(cin, v, kernel_size=3, padding=1), torch.nn.ReLU(inplace=True)]
+                cin = v
+        holder = torch.nn.Module()
+        holder.features = torch.nn.Sequential(*mods)
+        return holder
+
+    losses.models.vgg19 = vgg19
+    crit = losses.VGGLoss("cpu")
+    shapes = {key: tuple(v.shape) for key, v in crit.vgg.state_dict().items()}
+    assert shapes == cpu_ref.vgg19_shapes(), "reference Vgg19 layout changed"
+    crit.vgg.load_state_dict({key: t(v) for key, v in fill.fill_state_dict(shapes, case["seed"], gain=case["gain"]).items()})
+    return crit, shapes
+
+
+def run_reference_vgg(name, case):
+    """VGG term of ``get_painter_loss`` (trainer.py:1276-1287) with the reference's ``vgg_preprocess`` (its hard-coded
+    ``.cuda()``, tutils.py:422, patched to the identity), on the pasted image of ``OmniGenerator.paint``
+    (generator.py:295-296); value, per-tap L1 terms and the gradient w.r.t. the painter's (pre-paste) output."""
+    from oracle import ref_shim
+
+    tutils = ref_shim.ref("tutils")
+    crit, _ = reference_vgg_loss(case)
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    x, m = inp["x"], inp["m"]
+    fake = inp["fake"].clone().requires_grad_(True)
+    saved = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        fake_flooded = x * (1.0 - m) + fake * m
+        a, b = tutils.vgg_preprocess(fake_flooded * m), tutils.vgg_preprocess(x * m)
+        loss = crit(a, b) * case["lambda_vgg"]
+        loss.backward()
+        with torch.no_grad():
+            fa, fb = crit.vgg(a), crit.vgg(b)
+    finally:
+        torch.Tensor.cuda = saved
+    return {"loss": loss.detach().numpy().reshape(1), "dfake": fake.grad.numpy().copy(),
+            "terms": np.array([(u - v).abs().mean().item() for u, v in zip(fa, fb)], dtype=np.float32),
+            "feat_absmean": np.array([u.abs().mean().item() for u in fa], dtype=np.float32),
+            "pre_fake": a.detach().numpy()}
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -586,6 +651,8 @@ def run_reference(name, case):
         return run_reference_dstep(name, case)
     if case["kind"] == "gstep_p":
         return run_reference_gstep(name, case)
+    if case["kind"] == "vgg":
+        return run_reference_vgg(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}

@@ -256,6 +256,26 @@ def run_oracle_maskspade(name, case):
     return {"d": d.numpy(), "s": s.numpy(), "cond": cond.numpy(), "m": m.numpy(), "logits2": logits2.numpy()}
 
 
+def vgg_state_dict(case):
+    return {k: t(v) for k, v in fill.fill_state_dict(cpu_ref.vgg19_shapes(), case["seed"], gain=case["gain"]).items()}
+
+
+def run_oracle_vgg(name, case):
+    sd = vgg_state_dict(case)
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+    x, m = inp["x"], inp["m"]
+    fake = inp["fake"].clone().requires_grad_(True)
+    loss = cpu_ref.painter_vgg_term(sd, fake, x, m, case["lambda_vgg"])
+    (dfake,) = torch.autograd.grad(loss, fake)
+    with torch.no_grad():
+        a = cpu_ref.vgg_preprocess((x * (1.0 - m) + fake * m) * m)
+        fa, fb = cpu_ref.vgg19_features(a, sd), cpu_ref.vgg19_features(cpu_ref.vgg_preprocess(x * m), sd)
+    return {"loss": loss.detach().numpy().reshape(1), "dfake": dfake.numpy(),
+            "terms": np.array([(u - v).abs().mean().item() for u, v in zip(fa, fb)], dtype=np.float32),
+            "feat_absmean": np.array([u.abs().mean().item() for u in fa], dtype=np.float32),
+            "pre_fake": a.numpy()}
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
@@ -272,6 +292,8 @@ def run_oracle(name, case, dtype=torch.float32):
         return run_oracle_dstep(name, case)
     if case["kind"] == "gstep_p":
         return run_oracle_gstep(name, case)
+    if case["kind"] == "vgg":
+        return run_oracle_vgg(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}

@@ -1,0 +1,87 @@
+"""A18: the VGG term of the Painter's generator loss on the HIP path vs the golden produced by the reference's own
+``vgg_preprocess`` / ``Vgg19`` / ``VGGLoss`` (tests/golden/vgg_small.npz, oracle/make_golden.py::run_reference_vgg).
+
+Checked: the pre-processed image the heads kernel hands to VGG (hi + lo pair, see ops.painter_heads), the weighted loss
+value, and d(loss)/d(fake) through five VGG slices, the max pools, the paste and the pre-processing -- fp16 and bf16.
+
+Yardstick (dev container, the reference arithmetic with weights and activations rounded to 16 bit, fp32 otherwise):
+loss within 1.3e-4 (bf16) / 9e-5 (fp16) relative; gradient relative L2 0.285 / 0.099 and cosine 0.959 / 0.995 -- an L1
+criterion's gradient is sign(a - b) per feature, so every feature pair that 16-bit rounding pushes across a - b = 0
+flips a whole back-propagated contribution.  Rounding the 0-255-scale INPUT alone to bf16 accounts for 0.165 of that
+(0.055 in fp16): the reason the heads kernel stores it as a 16-bit pair."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_inputs, golden_cases, load_golden, t, vgg_state_dict
+
+pytestmark = pytest.mark.gpu
+
+NAME = "vgg_small"
+# (loss rel, grad rel L2, grad cosine): never looser than the reference's own 16-bit run above
+BOUNDS = {torch.float16: (3e-4, 0.099, 0.995), torch.bfloat16: (1e-3, 0.285, 0.959)}
+
+
+def _run(dt, split=True):
+    from climategan_amd import ops
+    from climategan_amd.autograd import PainterHeadsFn
+    from climategan_amd.losses import VGGLoss
+
+    case = golden_cases()[NAME]
+    crit = VGGLoss("cuda")
+    crit.vgg.load_state_dict(vgg_state_dict(case))
+    inp = {k: t(v).cuda() for k, v in case_inputs(NAME, case).items()}
+    x, m = inp["x"], inp["m"]
+    fake_t = ops.nchw_to_nhwc(inp["fake"], dt).t.detach().requires_grad_(True)
+    _, v_fake = PainterHeadsFn.apply(fake_t, x, m, False, True)
+    _, v_real = ops.painter_heads(None, x, m, dt, False, True)
+    if not split:   # the plain 16-bit store (hi only) for comparison: what a single-tensor input would carry
+        v_fake = v_fake * torch.tensor([1, 1, 1, 0, 0, 0, 0, 0], device="cuda", dtype=dt)
+        v_real = ops.NHWC(v_real.t * torch.tensor([1, 1, 1, 0, 0, 0, 0, 0], device="cuda", dtype=dt), 6)
+    loss = crit(ops.NHWC(v_fake, 6), v_real) * case["lambda_vgg"]
+    loss.backward()
+    dfake = ops.nhwc_to_nchw(ops.NHWC(fake_t.grad, 3)).float().cpu()
+    pre = v_fake.detach().float()
+    pre = (pre[..., 0:3] + pre[..., 3:6]).permute(0, 3, 1, 2).cpu()
+    return loss.item(), dfake, pre
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_vgg_term_matches_reference_golden(dt):
+    gold = load_golden(NAME)
+    loss, dfake, pre = _run(dt)
+    # fake is 16-bit on entry, so the pre-processed value differs from the fp32 golden by the rounding of fake itself
+    # (127.5 * 2^-9 relative to |fake| <= 1 in bf16), not by the 0-255-scale store
+    tol_in = 127.5 * (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11)
+    assert (pre - t(gold["pre_fake"])).abs().max().item() <= tol_in
+    gr = t(gold["dfake"])
+    rel = abs(loss - float(gold["loss"][0])) / float(gold["loss"][0])
+    l2 = ((dfake - gr).norm() / gr.norm()).item()
+    cos = ((dfake * gr).sum() / (dfake.norm() * gr.norm())).item()
+    l0, d0, _ = _run(dt, split=False)
+    rel0 = abs(l0 - float(gold["loss"][0])) / float(gold["loss"][0])
+    l20 = ((d0 - gr).norm() / gr.norm()).item()
+    print("\nvgg %s: loss rel %.3g, grad rel L2 %.3g, cos %.5f   (single 16-bit input store: loss rel %.3g, grad rel L2 "
+          "%.3g)" % (dt, rel, l2, cos, rel0, l20))
+    b = BOUNDS[dt]
+    assert rel <= b[0] and l2 <= b[1] and cos >= b[2], (rel, l2, cos)
+    # outside the mask nothing reaches fake (paste + fake * m)
+    m = t(case_inputs(NAME, golden_cases()[NAME])["m"])
+    assert (dfake * (1 - m)).abs().max() == 0
+
+
+def test_vgg_input_pair_is_exact():
+    """hi + lo reproduces vgg_preprocess(p * m) to fp32 rounding when fake is exactly representable."""
+    from climategan_amd import ops
+    from oracle import cpu_ref
+
+    case = golden_cases()[NAME]
+    inp = {k: t(v) for k, v in case_inputs(NAME, case).items()}
+    for dt in (torch.float16, torch.bfloat16):
+        fake = inp["fake"].to(dt).float()
+        _, v = ops.painter_heads(ops.nchw_to_nhwc(fake.cuda(), dt), inp["x"].cuda(), inp["m"].cuda(), dt, False, True)
+        got = (v.t[..., 0:3].float() + v.t[..., 3:6].float()).permute(0, 3, 1, 2).cpu()
+        ref = cpu_ref.vgg_preprocess((inp["x"] * (1 - inp["m"]) + fake * inp["m"]) * inp["m"])
+        # lo is itself rounded to 16 bit: 2^-8 (bf16) of a remainder that is at most 2^-8 of 151
+        assert (got - ref).abs().max().item() <= 151 * (2.0 ** -16 if dt == torch.bfloat16 else 2.0 ** -21) + 2e-5
+        assert (v.t[..., 6:] == 0).all()

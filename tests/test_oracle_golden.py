@@ -10,7 +10,7 @@ CASES = golden_cases()
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p", "gstep_p", "cloudy_small", "maskspade_small", "masker_losses", "mstep", "mstep_spade")])
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p", "gstep_p", "cloudy_small", "maskspade_small", "masker_losses", "mstep", "mstep_spade", "vgg_small")])
 def test_oracle_matches_golden(name):
     gold = load_golden(name)
     got = run_oracle(name, CASES[name])
@@ -184,3 +184,18 @@ def test_masker_loss_restatements_match_reference_golden():
     check("advent_wgan_0", lambda d: cpu_ref.advent_wgan(d, 0), "d_out")
     check("advent_wgan_1", lambda d: cpu_ref.advent_wgan(d, 1), "d_out")
     check("sigm", lambda d: cpu_ref.sigm_loss(d, inp["depth_target"]), "depth_pred", half=True)
+
+
+def test_oracle_vgg_term_matches_reference_golden():
+    """A18: ``cpu_ref.vgg_preprocess`` / ``vgg19_features`` / ``vgg_loss`` vs the reference's own ``vgg_preprocess``,
+    ``Vgg19`` and ``VGGLoss`` (golden ``vgg_small``): pre-processed image, the five per-tap L1 terms, the weighted loss and
+    its gradient w.r.t. the painter output."""
+    name = "vgg_small"
+    gold = load_golden(name)
+    got = run_oracle(name, CASES[name])
+    assert sorted(gold) == sorted(got)
+    np.testing.assert_allclose(got["pre_fake"], gold["pre_fake"], rtol=0, atol=2e-5)
+    for k in ("loss", "terms", "feat_absmean"):
+        np.testing.assert_allclose(got[k], gold[k], rtol=2e-5, atol=0)
+    scale = np.abs(gold["dfake"]).max()
+    assert np.abs(got["dfake"] - gold["dfake"]).max() <= 1e-4 * scale
