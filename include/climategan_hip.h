@@ -330,8 +330,10 @@ int cgan_spectral_norm_bwd(float* grad_w, const float* w_bar, const float* u, co
 /* Painter training-step glue (climategan/trainer.py:1256-1387 G side, 1073-1107 D side).
  * heads_fwd: p = fake ? x (1 - m) + fake m : x  (the paste of generator.py:295-296; fake NHWC 3 channels stored as 8,
  *   x / m NCHW fp32), then d_in = [m | p] (torch.cat([m, x], axis=1), trainer.py:1101-1102; 4 channels stored as 8)
- *   and vgg_in = vgg_preprocess(p * m) (tutils.py:416-427: BGR, (t + 1) * 255 * 0.5 - mean; 3 channels stored as 8);
- *   either output may be NULL.  heads_bwd: d_fake = m * (d_d_in[1..3] + 127.5 m d_vgg_in[BGR -> RGB]). */
+ *   and vgg_in = vgg_preprocess(p * m) (tutils.py:416-427: BGR, (t + 1) * 255 * 0.5 - mean), stored as a 16-bit PAIR
+ *   per colour -- channels [b_hi g_hi r_hi b_lo g_lo r_lo 0 0], value = hi + lo -- because a single 16-bit store of
+ *   magnitudes 100-150 loses +-0.5 (bf16); the first VGG conv runs on the six channels with its weights repeated;
+ *   either output may be NULL.  heads_bwd: d_fake = m * (d_d_in[1..3] + 127.5 m d_vgg_in[BGR -> RGB]) (d_vgg_in: the hi channels' gradient). */
 int cgan_painter_heads_fwd(const void* fake_nhwc, const float* x_nchw, const float* m_nchw, void* d_in, void* vgg_in,
                            int32_t dtype, int32_t n, int32_t h, int32_t w, void* stream);
 int cgan_painter_heads_bwd(const void* d_d_in, const void* d_vgg_in, const float* m_nchw, void* d_fake, int32_t dtype,
