@@ -7,9 +7,12 @@ and (b) the reported ``cpu_baseline`` in ``bench.py`` -- never on the product pa
 
 Pinned by: tests/test_oracle_golden.py (committed vectors produced by the real reference) and
 tests/test_oracle_vs_reference.py (direct comparison with the imported reference, dev container only).
-Parity UNPINNED for two functions whose arithmetic lives in third-party libraries that are neither in the reference tree
-nor in this image: ``add_fire`` (kornia / torchvision calls of fire.py) and ``skimage_resize_018`` (scikit-image 0.18.3
-``resize`` behind apply_events.resize_and_crop); both say so in their docstrings and DESIGN.md section 3.
+Parity UNPINNED for arithmetic that lives in third-party libraries which are neither in the reference tree nor in this
+image: the three library formulas inside ``add_fire`` (kornia's Gaussian kernel / ``filter2d``, torchvision's
+``adjust_contrast`` / ``adjust_brightness`` -- everything ELSE in ``add_fire`` is pinned by the reference's own fire.py run
+with those three bound to their documented formulas, golden ``fire_small``), ``skimage_resize_018`` (scikit-image 0.18.3
+``resize`` behind apply_events.resize_and_crop) and the pretrained VGG-19 WEIGHTS (the VGG loss itself is pinned by the
+reference's Vgg19 / VGGLoss classes with portable-fill weights, golden ``vgg_small``); DESIGN.md section 3.
 """
 from typing import Dict, List, Optional, Tuple
 

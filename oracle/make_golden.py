@@ -45,6 +45,9 @@ def golden_cases():
         # VGG term of get_painter_loss through the reference's own Vgg19 / VGGLoss / vgg_preprocess; VGG-19 weights from
         # the portable fill with a He-preserving bound (gain sqrt(6): activations keep the input's 0-255 scale)
         "vgg_small": dict(kind="vgg", H=64, W=96, B=2, seed=85, gain=2.449489742783178, lambda_vgg=10.0),
+        # fire.add_fire itself (warm / contrast / sky mask / 18 % dilation / blur / paste / brightness); its three
+        # third-party calls are bound to the documented formulas (see run_reference_fire)
+        "fire_small": dict(kind="fire", H=160, W=192, B=2, seed=86, sky_idx=9, rng_seed=1234),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -98,6 +101,13 @@ def case_inputs(name, case):
     if k == "gstep_p":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
+    if k == "fire":
+        H, W = case["H"], case["W"]
+        seg = fill.uniform((B, 11, H // 4, W // 4), s * 100 + 2, -1, 1)
+        seg[:, case["sky_idx"], : H // 11, W // 20: W // 5] += 2.5      # a sky band in the upper part
+        seg[:, case["sky_idx"], H // 16: H // 8, W // 8: W // 6] += 2.5  # a small detached blob
+        seg[:, case["sky_idx"], 3 * H // 16:, : W // 10] += 2.5         # and one in the bottom third (cropped away)
+        return dict(x=fill.uniform((B, 3, H, W), s * 100 + 1), seg=seg.astype(np.float16).astype(np.float32))
     if k == "vgg":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
@@ -602,6 +612,51 @@ def run_reference_vgg(name, case):
             "pre_fake": a.detach().numpy()}
 
 
+def run_reference_fire(name, case):
+    """The reference's own ``fire.add_fire`` (fire.py:70-133) -- normalisation to [0, 255], the warm shift, the sky mask
+    from the segmentation (``retrieve_sky_mask``, bottom third cropped), nearest resize, ``increase_sky_mask`` (18 %),
+    the blurred-mask paste with transparency 200 and the dummy range pixels are the reference's code.  Its three
+    third-party calls are NOT in the tree (kornia 0.5.10, torchvision 0.8) and are bound to the formulas their
+    documentation gives: ``adjust_brightness(img, f) = clamp(f * img)`` and ``adjust_contrast(img, f) =
+    clamp(f * img + (1 - f) * mean(gray(img)))`` on uint8 with gray = 0.2989 R + 0.587 G + 0.114 B truncated to uint8;
+    ``get_gaussian_kernel2d`` = outer product of sum-normalised 1-D Gaussians centred at k // 2; ``filter2d`` =
+    reflect-pad k // 2, depthwise correlation -- here as a DIRECT 2-D correlation (no separable shortcut).  Only those
+    three formulas stay unpinned.  ``random.randint(100, 150)`` (fire.py:115) is seeded and recorded."""
+    import random
+
+    from oracle import cpu_ref, ref_shim
+
+    fire = ref_shim.ref("fire")
+
+    def gaussian_kernel2d(kernel_size, sigma, *a, **k):
+        gy = cpu_ref._kornia_gaussian_1d(kernel_size[0], sigma[0])
+        gx = cpu_ref._kornia_gaussian_1d(kernel_size[1], sigma[1])
+        return torch.outer(gy, gx)
+
+    def filter2d(inp, kernel, border_type="reflect", *a, **k):
+        assert border_type == "reflect" and kernel.dim() == 3 and kernel.shape[0] == 1
+        kh, kw = kernel.shape[-2:]
+        pad = F_.pad(inp.double(), (kw // 2, kw // 2, kh // 2, kh // 2), mode="reflect")
+        c = inp.shape[1]
+        w = kernel.double().reshape(1, 1, kh, kw).expand(c, 1, kh, kw)
+        return F_.conv2d(pad, w, groups=c).float()
+
+    import torch.nn.functional as F_
+    fire.adjust_contrast = lambda img, contrast_factor: cpu_ref._tv_adjust_contrast_u8(img, contrast_factor)
+    fire.adjust_brightness = lambda img, brightness_factor: cpu_ref._tv_adjust_brightness_u8(img, brightness_factor)
+    fire.filter2d = filter2d
+    fire.kornia.filters.kernels.get_gaussian_kernel2d = gaussian_kernel2d
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    opts = ref_shim.default_opts()
+    random.seed(case["rng_seed"])
+    green = random.randint(100, 150)
+    random.seed(case["rng_seed"])
+    with torch.no_grad():
+        y = fire.add_fire(inp["x"].clone(), inp["seg"], opts.events.fire)
+    assert (y == y.round()).all() and y.min() >= 0 and y.max() <= 255
+    return {"y_u8": y.numpy().astype(np.uint8), "green": np.array([green], dtype=np.int64)}
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -653,6 +708,8 @@ def run_reference(name, case):
         return run_reference_gstep(name, case)
     if case["kind"] == "vgg":
         return run_reference_vgg(name, case)
+    if case["kind"] == "fire":
+        return run_reference_fire(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}

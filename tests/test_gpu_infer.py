@@ -182,6 +182,22 @@ def test_wildfire_event_matches_oracle(sky_idx):
     assert ref[:, 0].max() == 255 and ((ref[:, 0] - ref[:, 2]) > 100).float().mean() > 0.02   # fire really pasted
 
 
+def test_wildfire_event_matches_reference_fire_py_golden():
+    """The HIP wildfire vs the reference's OWN ``fire.add_fire`` (golden ``fire_small``, oracle/make_golden.py::
+    run_reference_fire: normalise / warm shift / sky mask / crop / 18 % dilation / paste / dummy pixels are the reference's
+    code; only the kornia / torchvision formulas were bound to their documentation).  Same byte-image bar as above."""
+    from climategan_amd import ops
+
+    name = "fire_small"
+    case, gold = golden_cases()[name], load_golden(name)
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+    got = ops.wildfire(inp["x"].cuda(), ops.nchw_to_nhwc(inp["seg"].cuda(), torch.float16), float(gold["green"][0]),
+                       sky_idx=case["sky_idx"]).cpu().numpy()
+    d = np.abs(got - gold["y_u8"].astype(np.float32))
+    print("wildfire vs fire.py golden: max %g, differing %.3g" % (d.max(), (d > 0).mean()))
+    assert d.max() <= 1.0 and (d > 0).mean() < 1e-2, (d.max(), (d > 0).mean())
+
+
 def test_infer_all_three_events():
     """apply_events' default call: flood + wildfire + smog out of one infer_all (uint8 HWC), masks on request."""
     case = golden_cases()[NAME]
