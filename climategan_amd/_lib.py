@@ -121,6 +121,7 @@ _SIGNATURES = {
     "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_float, _P, C.c_size_t, _P]),
     "cgan_bce_logits_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
+    "cgan_hinge_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "cgan_l1_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),
     "cgan_spectral_norm_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "cgan_painter_heads_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

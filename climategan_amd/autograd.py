@@ -295,6 +295,26 @@ class BceLogitsFn(torch.autograd.Function):
         return ops.scale_by_scalar(ops.NHWC(dx_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None
 
 
+class HingeFn(torch.autograd.Function):
+    """weight * sum of HingeLoss.loss's per-element terms (reference losses.py:565-579) -> fp32 device scalar."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, target_is_real, for_discriminator, weight):
+        ctx.c = c
+        acc = torch.zeros(1, dtype=torch.float32, device=x_t.device)
+        dx = ops.hinge_loss(ops.NHWC(x_t, c), target_is_real, for_discriminator, weight * GRAD_SCALE, acc,
+                            want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(dx.t if dx is not None else None)
+        return acc[0] / GRAD_SCALE if GRAD_SCALE != 1.0 else acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx_t,) = ctx.saved_tensors
+        if dx_t is None:
+            return None, None, None, None, None
+        return ops.scale_by_scalar(ops.NHWC(dx_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None, None
+
+
 class L1Fn(torch.autograd.Function):
     """weight * sum |a - b| (b is a constant, as FeatMatchLoss detaches the real features, losses.py:99-101)."""
 

@@ -452,6 +452,45 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const uint16_t* __restr
   block_atomic_add(acc * weight, loss);
 }
 
+// HingeLoss (climategan/losses.py:550-593) over the c logical channels: discriminator side (hinged)
+// loss += weight * sum max(0, 1 - sgn x)   [= -mean(min(sgn x - 1, 0))],  dx = -sgn weight where 1 - sgn x > 0 (half of it
+// on an exact tie, torch.min's rule); generator side (not hinged) loss += weight * sum(-sgn x), dx = -sgn weight
+template <typename T>
+__global__ __launch_bounds__(256) void hinge_kernel(const uint16_t* __restrict__ x, float sgn, int hinged, float weight,
+                                                    float* __restrict__ loss, uint16_t* __restrict__ dx, int cs, int c,
+                                                    long groups) {
+  const int cg_total = cs / 8;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a[2], gr[2];
+      unpack2<T>(v[e], a[0], a[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool live = cg * 8 + 2 * e + h < c;
+        const float mval = sgn * a[h] - 1.f;                 // min(mval, 0) is what the reference averages
+        float l, g;
+        if (hinged) {
+          l = mval < 0.f ? -mval : 0.f;
+          g = mval < 0.f ? -sgn : (mval == 0.f ? -0.5f * sgn : 0.f);
+        } else {
+          l = -sgn * a[h];
+          g = -sgn;
+        }
+        acc += live ? l : 0.f;
+        gr[h] = live ? weight * g : 0.f;
+      }
+      r[e] = pack2<T>(gr[0], gr[1]);
+    }
+    if (dx) reinterpret_cast<u32x4*>(dx)[i] = r;
+  }
+  block_atomic_add(acc * weight, loss);
+}
+
 // nn.L1Loss pieces: loss += weight * sum|a - b|;  da = weight * sign(a - b)
 template <typename T>
 __global__ __launch_bounds__(256) void l1_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
@@ -650,6 +689,20 @@ extern "C" int cgan_bce_logits_nhwc(const void* x, int32_t dtype, int64_t npix, 
   DISPATCH_T(dtype, bce_logits_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
              target, weight, loss_accum, (uint16_t*)dx, cs, c, groups);
   CGAN_CHECK_LAUNCH("bce_logits");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_hinge_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, int32_t target_is_real,
+                               int32_t for_discriminator, float weight, float* loss_accum, void* dx, void* stream) {
+  CGAN_REQUIRE(x && loss_accum, "hinge: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "hinge: bad dtype %d", dtype);
+  CGAN_REQUIRE(npix > 0 && c > 0, "hinge: bad shape");
+  CGAN_REQUIRE(for_discriminator || target_is_real, "hinge: The generator's hinge loss must be aiming for real");
+  const int cs = cgan_cs(c);
+  const long groups = npix * (cs / 8);
+  DISPATCH_T(dtype, hinge_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+             target_is_real ? 1.f : -1.f, for_discriminator ? 1 : 0, weight, loss_accum, (uint16_t*)dx, cs, c, groups);
+  CGAN_CHECK_LAUNCH("hinge");
   return CGAN_OK;
 }
 

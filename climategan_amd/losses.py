@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import ops
 from . import autograd as ag
-from .autograd import BceLogitsFn, ConvFn, L1Fn, MaxPool2x2Fn
+from .autograd import BceLogitsFn, ConvFn, HingeFn, L1Fn, MaxPool2x2Fn
 from .norms import _PackCache
 
 
@@ -63,6 +63,34 @@ class GANLoss(nn.Module):
         if r < self.flip_prob:
             target_is_real = not target_is_real
         return self._one(input, target_is_real)
+
+
+class HingeLoss(nn.Module):
+    """reference losses.py:550-593 (the Painter's GAN criterion when ``gen.p.loss == "hinge"``, losses.py:381-383):
+    discriminator side ``-mean(min(x - 1, 0))`` for a real target / ``-mean(min(-x - 1, 0))`` for a fake one, generator
+    side ``-mean(x)`` (which must aim for real); a list of per-scale outputs (lists: last entry) is averaged."""
+
+    def __init__(self, tensor=torch.FloatTensor):
+        super().__init__()
+        self.zero_tensor = None
+        self.Tensor = tensor
+
+    def loss(self, input, target_is_real, for_discriminator=True):
+        if not for_discriminator:
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+        pred = _as_nhwc(input, "HingeLoss")
+        n = pred.n * pred.h * pred.w * pred.c
+        return HingeFn.apply(pred.t, pred.c, bool(target_is_real), bool(for_discriminator), 1.0 / n)
+
+    def __call__(self, input, target_is_real, for_discriminator=True):
+        if isinstance(input, list):
+            loss = 0
+            for pred_i in input:
+                if isinstance(pred_i, list):
+                    pred_i = pred_i[-1]
+                loss = loss + self.loss(pred_i, target_is_real, for_discriminator)
+            return loss / len(input)
+        return self.loss(input, target_is_real, for_discriminator)
 
 
 class FeatMatchLoss(nn.Module):
@@ -289,10 +317,11 @@ class SIGMLoss(nn.Module):
 
 
 def get_losses(opts, verbose, device=None):
-    """reference losses.py:353-441: the same nested dictionary (classifier / hinge / DADA-depth options excluded)."""
+    """reference losses.py:353-441: the same nested dictionary (classifier / DADA-depth options excluded)."""
     losses = {"G": {"a": {}, "p": {}, "tasks": {}}, "D": {"default": {}, "advent": {}}, "C": {}}
     if "p" in opts.tasks:
-        losses["G"]["p"]["gan"] = GANLoss(use_lsgan=False, soft_shift=opts.dis.soft_shift, flip_prob=opts.dis.flip_prob)
+        losses["G"]["p"]["gan"] = (HingeLoss() if opts.gen.p.get("loss", "gan") == "hinge" else
+                                   GANLoss(use_lsgan=False, soft_shift=opts.dis.soft_shift, flip_prob=opts.dis.flip_prob))
         losses["G"]["p"]["vgg"] = VGGLoss(device)
         losses["G"]["p"]["tv"] = TVLoss()
         losses["G"]["p"]["featmatch"] = FeatMatchLoss()

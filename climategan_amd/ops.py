@@ -625,6 +625,19 @@ def bce_logits(x: NHWC, target: float, weight: float, loss_accum: torch.Tensor, 
     return NHWC(dx, x.c) if want_grad else None
 
 
+def hinge_loss(x: NHWC, target_is_real: bool, for_discriminator: bool, weight: float, loss_accum: torch.Tensor,
+               want_grad=True):
+    """loss_accum += weight * sum HingeLoss.loss terms of x's logical channels (reference losses.py:565-579); returns
+    d(loss)/dx or None."""
+    _need_cuda(x.t, loss_accum)
+    dx = torch.empty_like(x.t) if want_grad else None
+    lib = _lib.load()
+    _lib.check(lib.cgan_hinge_nhwc(_ptr(x.t), x.dtype_id, x.n * x.h * x.w, x.c, int(bool(target_is_real)),
+                                   int(bool(for_discriminator)), float(weight), _ptr(loss_accum), _ptr(dx), _stream()),
+               "cgan_hinge_nhwc")
+    return NHWC(dx, x.c) if want_grad else None
+
+
 def l1_loss(a: NHWC, b: NHWC, weight: float, loss_accum: torch.Tensor, want_grad=True):
     """loss_accum += weight * sum|a - b|; returns d(loss)/da or None."""
     _need_cuda(a.t, b.t, loss_accum)

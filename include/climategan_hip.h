@@ -318,6 +318,12 @@ int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const
  * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */
 int cgan_bce_logits_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float target, float weight,
                          float* loss_accum, void* dx, void* stream);
+/* HingeLoss.loss (climategan/losses.py:565-579; selected by gen.p.loss == "hinge", losses.py:381-383) over the c logical
+ * channels of x [npix][cgan_cs(c)]: for_discriminator: *loss_accum += weight * sum(-min(+-x - 1, 0)) (+ for a real
+ * target, - for a fake one), dx = weight * d/dx (half on an exact tie, torch.min's rule); generator side (target must
+ * be real, else negative rc like the reference's assert): *loss_accum += weight * sum(-x), dx = -weight. dx may be NULL. */
+int cgan_hinge_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, int32_t target_is_real,
+                    int32_t for_discriminator, float weight, float* loss_accum, void* dx, void* stream);
 /* nn.L1Loss pieces (FeatMatchLoss, climategan/losses.py:86-103): *loss_accum += weight * sum|a - b|,
  * da = weight * sign(a - b); da may be NULL. */
 int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t numel, float weight, float* loss_accum, void* da,

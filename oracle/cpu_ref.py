@@ -471,6 +471,23 @@ def gan_loss(preds, target_is_real: bool, real_label=1.0, fake_label=0.0) -> tor
     return loss / len(preds)
 
 
+def hinge_loss(preds, target_is_real: bool, for_discriminator: bool = True) -> torch.Tensor:
+    """``HingeLoss.__call__`` (losses.py:550-593): per scale (last entry of a list) -mean(min(+-x - 1, 0)) on the
+    discriminator side, -mean(x) on the generator side; mean over scales."""
+    if not isinstance(preds, (list, tuple)):
+        preds = [preds]
+    loss = 0
+    for p in preds:
+        p = p[-1] if isinstance(p, (list, tuple)) else p
+        if for_discriminator:
+            v = (p - 1) if target_is_real else (-p - 1)
+            loss = loss - torch.minimum(v, torch.zeros_like(v)).mean()
+        else:
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            loss = loss - p.mean()
+    return loss / len(preds)
+
+
 def painter_d_step(sd_d: SD, m: torch.Tensor, x: torch.Tensor, fake: torch.Tensor, num_D: int, n_layers: int):
     """D-side painter loss and parameter gradients: D(cat_batch[cat_ch(m, x), cat_ch(m, fake)]) -> divide ->
     GANLoss(fake, False) + GANLoss(real, True); returns (loss, {key: grad}).  ``sd_d`` holds D["p"]'s tensors."""

@@ -48,6 +48,7 @@ def golden_cases():
         # fire.add_fire itself (warm / contrast / sky mask / 18 % dilation / blur / paste / brightness); its three
         # third-party calls are bound to the documented formulas (see run_reference_fire)
         "fire_small": dict(kind="fire", H=160, W=192, B=2, seed=86, sky_idx=9, rng_seed=1234),
+        "hinge_small": dict(kind="hinge", sizes=[(12, 16), (6, 8), (3, 4)], B=2, seed=87),
         "extra_adam": dict(kind="extra_adam", shapes=[(33, 7), (128,), (5, 3, 3, 3)], steps=4, lr=5e-5, betas=(0.9, 0.999),
                            B=1, seed=51),
     }
@@ -108,6 +109,10 @@ def case_inputs(name, case):
         seg[:, case["sky_idx"], H // 16: H // 8, W // 8: W // 6] += 2.5  # a small detached blob
         seg[:, case["sky_idx"], 3 * H // 16:, : W // 10] += 2.5         # and one in the bottom third (cropped away)
         return dict(x=fill.uniform((B, 3, H, W), s * 100 + 1), seg=seg.astype(np.float16).astype(np.float32))
+    if k == "hinge":
+        # multiples of 1/8 in [-3, 3]: exact in fp16 / bf16 (the 16-bit path then sees the same logits), exact ties at +-1
+        return {"p%d" % i: (np.round(fill.uniform((B, 1) + tuple(hw), s * 100 + i, -3, 3) * 8) / 8).astype(np.float32)
+                for i, hw in enumerate(case["sizes"])}
     if k == "vgg":
         return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
                     fake=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 2),
@@ -657,6 +662,24 @@ def run_reference_fire(name, case):
     return {"y_u8": y.numpy().astype(np.uint8), "green": np.array([green], dtype=np.int64)}
 
 
+def run_reference_hinge(name, case):
+    """The reference's ``HingeLoss`` (losses.py:550-593) on a 3-scale list of lists: D-real, D-fake and G values and
+    the gradients w.r.t. every scale's prediction."""
+    from oracle import ref_shim
+
+    crit = ref_shim.ref("losses").HingeLoss()
+    inp = case_inputs(name, case)
+    out = {}
+    for tag, real, for_d in (("d_real", True, True), ("d_fake", False, True), ("g", True, False)):
+        preds = [t(inp["p%d" % i]).clone().requires_grad_(True) for i in range(len(case["sizes"]))]
+        loss = crit([[p * 0, p] for p in preds], real, for_d)
+        loss.backward()
+        out[tag] = loss.detach().numpy().reshape(1)
+        for i, p in enumerate(preds):
+            out["%s.grad%d" % (tag, i)] = p.grad.numpy().copy()
+    return out
+
+
 def run_reference_extra_adam(name, case):
     """4-call trajectory extrapolation/step/extrapolation/step of the reference's ExtraAdam (optim.py:200-291)."""
     from oracle import ref_shim
@@ -710,6 +733,8 @@ def run_reference(name, case):
         return run_reference_vgg(name, case)
     if case["kind"] == "fire":
         return run_reference_fire(name, case)
+    if case["kind"] == "hinge":
+        return run_reference_hinge(name, case)
     mod, _ = build_reference_module(case)
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     out = {}

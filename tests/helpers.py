@@ -276,6 +276,19 @@ def run_oracle_vgg(name, case):
             "pre_fake": a.numpy()}
 
 
+def run_oracle_hinge(name, case):
+    inp = case_inputs(name, case)
+    out = {}
+    for tag, real, for_d in (("d_real", True, True), ("d_fake", False, True), ("g", True, False)):
+        preds = [t(inp["p%d" % i]).clone().requires_grad_(True) for i in range(len(case["sizes"]))]
+        loss = cpu_ref.hinge_loss([[p * 0, p] for p in preds], real, for_d)
+        grads = torch.autograd.grad(loss, preds)
+        out[tag] = loss.detach().numpy().reshape(1)
+        for i, g in enumerate(grads):
+            out["%s.grad%d" % (tag, i)] = g.numpy()
+    return out
+
+
 def run_oracle(name, case, dtype=torch.float32):
     """Run oracle.cpu_ref on the seeded inputs of a golden case; same output keys as make_golden."""
     if case["kind"] == "extra_adam":
@@ -294,6 +307,8 @@ def run_oracle(name, case, dtype=torch.float32):
         return run_oracle_gstep(name, case)
     if case["kind"] == "vgg":
         return run_oracle_vgg(name, case)
+    if case["kind"] == "hinge":
+        return run_oracle_hinge(name, case)
     sd = case_state_dict(case, dtype)
     inp = {k: t(v).to(dtype) for k, v in case_inputs(name, case).items()}
     out = {}
