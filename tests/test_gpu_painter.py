@@ -7,8 +7,9 @@ every inter-layer activation in 16 bit, so rounding accumulates through ~30 conv
 tanh-bounded in [-1,1].  For scale: the reference's OWN ``.half()`` path run on the CPU deviates from its
 fp32 output by max 6.5e-3 / mean 8.1e-4 on the painter_up4 fixture (bf16: 5.1e-2 / 6.6e-3), measured in
 the dev container (tests/devtools/measure_ref_half.py -> REF_HALF_DEV below).  Bound enforced here against the reference's
-fp32 golden vectors: the HIP path must be no further from fp32 than 2x what the reference's own 16-bit path is
-(max and mean abs error, per fixture and dtype).
+fp32 golden vectors: the HIP path must be no further from fp32 than 1.25x what the reference's own 16-bit path is
+(max and mean abs error, per fixture and dtype; the observed errors are printed: they sit BELOW the reference's own
+16-bit deviation, fp32 accumulation and fp32 statistics being the difference).
 """
 import numpy as np
 import pytest
@@ -32,7 +33,7 @@ REF_HALF_DEV = {
     ("paint_up4", "float16"): (0.008357, 0.0003513),
     ("paint_up4", "bfloat16"): (0.06977, 0.003019),
 }
-SLACK = 2.0
+SLACK = 1.25
 
 
 def tol(name, dt):
@@ -69,12 +70,14 @@ def test_painter_matches_reference_golden(name, dt):
     max_tol, mean_tol = tol(name, dt)
     if case["full"]:
         err = np.abs(y - gold["y"])
+        print("\n%s %s: max err %.3g (bound %.3g), mean err %.3g (bound %.3g)" % (name, dt, err.max(), max_tol, err.mean(), mean_tol))
         assert err.max() <= max_tol, "max err %.3g" % err.max()
         assert err.mean() <= mean_tol, "mean err %.3g" % err.mean()
     else:
         s = summarize(y)
         for k in ("crop_tl", "crop_c", "crop_br"):
             err = np.abs(s[k] - gold["y_" + k])
+            print("\n%s %s %s: max err %.3g (bound %.3g), mean err %.3g (bound %.3g)" % (name, dt, k, err.max(), max_tol, err.mean(), mean_tol))
             assert err.max() <= max_tol, "%s max err %.3g" % (k, err.max())
             assert err.mean() <= mean_tol, "%s mean err %.3g" % (k, err.mean())
         assert np.abs(s["pooled8"] - gold["y_pooled8"]).max() <= max_tol
@@ -130,3 +133,47 @@ def test_training_mode_refuses_autograd():
     cond = t(case_inputs("painter_up4", case)["cond"]).cuda()
     with pytest.raises(NotImplementedError):
         G.painter(None, cond)  # grad enabled + trainable params: no silent graph-less output
+
+
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("name", ["spade_c20", "spade_c40"])
+def test_spade_module_matches_reference_golden(name, dt, rel):
+    """A1 through the module API (``SPADE.forward``, reference norms.py:174-186) vs the reference module's own output on
+    fp32 inputs (golden): one fused kernel, so north_star's 1e-3 of the output scale in fp16 (2^-8 output rounding: 8e-3
+    in bf16) -- the inputs are rounded to 16 bit on entry here and are fp32 in the reference."""
+    from climategan_amd.norms import SPADE
+
+    case, gold = CASES[name], load_golden(name)
+    mod = SPADE("instance", 3, case["C"], case["cond_nc"]).cuda()
+    mod.load_state_dict(case_state_dict(case))
+    inp = {k: t(v).cuda() for k, v in case_inputs(name, case).items()}
+    with torch.no_grad():
+        y = mod(inp["x"], inp["seg"], compute_dtype=dt).float().cpu().numpy()
+    err = np.abs(y - gold["y"]).max()
+    scale = np.abs(gold["y"]).max()
+    print("\n%s %s: max err %.3g of scale %.3g" % (name, dt, err, scale))
+    assert err <= 2 * rel * scale          # input rounding + output rounding
+
+
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("name", ["resblk_16_8", "resblk_8_8"])
+def test_spade_resnet_block_matches_reference_golden(name, dt, rel):
+    """A2 through the module API (``SPADEResnetBlock.forward``, reference blocks.py:369-395, learned and identity
+    shortcut) vs the reference module's output, and the spectral-norm state it leaves behind (u after one power
+    iteration, norms.py:100-112).  Four 16-bit stores deep (SPADE, conv, SPADE, conv + residual)."""
+    from climategan_amd.blocks import SPADEResnetBlock
+
+    case, gold = CASES[name], load_golden(name)
+    mod = SPADEResnetBlock(case["fin"], case["fout"], 3, True, "instance", 3).cuda()
+    mod.load_state_dict(case_state_dict(case))
+    inp = {k: t(v).cuda() for k, v in case_inputs(name, case).items()}
+    with torch.no_grad():
+        y = mod(inp["x"], inp["seg"], compute_dtype=dt).float().cpu().numpy()
+    err = np.abs(y - gold["y"]).max()
+    scale = np.abs(gold["y"]).max()
+    print("\n%s %s: max err %.3g of scale %.3g" % (name, dt, err, scale))
+    assert err <= 4 * rel * scale
+    sd = mod.state_dict()
+    for k, v in gold.items():
+        if k.startswith("post."):
+            assert np.abs(sd[k[5:]].cpu().numpy() - v).max() <= 2e-5, k
