@@ -52,7 +52,7 @@ def rect_mask(batch: int, h: int, w: int, seed: int = 0) -> np.ndarray:
     return m
 
 
-def fill_state_dict(shapes: dict, seed: int = 0, gain: float = 1.0) -> dict:
+def fill_state_dict(shapes: dict, seed: int = 0, gain: float = 1.0, res_gamma: float = 1.0) -> dict:
     """Fill a {key: shape} dict the way an (untrained) reference module is populated.
 
     * conv weights / ``weight_bar``: U(-1/sqrt(fan_in), 1/sqrt(fan_in))  (torch's default conv init, which is
@@ -64,7 +64,10 @@ def fill_state_dict(shapes: dict, seed: int = 0, gain: float = 1.0) -> dict:
     * BatchNorm ``weight``: 1 + 0.1 U(-1,1); ``bias``: 0.1 U(-1,1); ``running_mean``: 0.1 U(-1,1);
       ``running_var``: 1 + 0.2 U(0,1); ``num_batches_tracked``: 0
     ``gain`` scales the conv-weight bound (the ResNet-101 fixtures use 1.6 so that 33 residual blocks neither
-    vanish nor overflow fp16 with untrained weights).
+    vanish nor overflow fp16 with untrained weights).  ``res_gamma`` scales the LAST BatchNorm weight of every ResNet
+    bottleneck (``*.bn3.weight``): values around 0.1-0.3 give the well-conditioned residual stack of a trained (or
+    zero-gamma initialised) ResNet, whose gradients keep their direction under 16-bit storage -- unlike gain-1.6
+    untrained weights with unit gammas, where each of the 33 blocks doubles the signal and the gradient is chaotic.
     """
     out = {}
     fan_in = {}
@@ -86,6 +89,8 @@ def fill_state_dict(shapes: dict, seed: int = 0, gain: float = 1.0) -> dict:
             out[k] = (v / (np.linalg.norm(v) + 1e-12)).astype(np.float32)
         elif leaf == "weight":  # norm scale
             out[k] = (1.0 + 0.1 * uniform(shp, s)).astype(np.float32)
+            if res_gamma != 1.0 and base.endswith(".bn3"):
+                out[k] = (out[k] * res_gamma).astype(np.float32)
         elif leaf == "bias":
             out[k] = (0.1 * uniform(shp, s)).astype(np.float32)
         elif leaf == "running_mean":

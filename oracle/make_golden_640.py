@@ -1,0 +1,264 @@
+"""Full-size (640x640) golden fixtures produced by the REAL reference (dev container only; TEST INFRASTRUCTURE).
+
+    python -m oracle.make_golden_640 [jstep_640] [infer_640]       # minutes of CPU each, ~15 GB of RAM
+
+* ``jstep_640``  -- the reference's OWN ``Trainer.update_G`` + ``Trainer.update_D`` (trainer.py:989-1032: ``get_G_loss`` /
+  ``get_D_loss``, ``backward()``, ExtraAdam extrapolation) on one multi-domain batch (r, s, rf; 2 samples per domain) of the
+  default task set [d, s, m, p] with the default 42 M-parameter Painter, 3-scale PatchGAN, ADVENT discriminators and the
+  VGG term, all at 640x640.  Stored: every logged loss scalar, the norm and a seeded sub-sample of the gradient of every
+  trainable G and D tensor, BatchNorm running statistics after the step.  The trainer object is the reference's class,
+  set up by its own ``setup()`` with the data loaders / display images / comet logging switched off and the pretrained
+  DeepLab / VGG downloads replaced by the portable fill.
+* ``infer_640``  -- the reference's own ``Trainer.infer_all`` (trainer.py:217-334) on 2 images: flood + wildfire + smog
+  uint8 images and the binary mask, with the float tensors captured on the way, as crops / 8x pooled maps / per-channel
+  statistics (``make_golden.summarize``); the wildfire's kornia / torchvision calls are bound to their documented
+  formulas exactly as for ``fire_small``.
+
+Weights are the WELL-CONDITIONED portable fill (``fill.fill_state_dict(gain=1, res_gamma=0.05)``): the last BatchNorm of
+every ResNet bottleneck has gamma ~ 0.05, like a trained / zero-gamma-initialised ResNet, so that the reference's own
+gradients keep their direction when activations and activation gradients are rounded to 16 bit
+(tests/devtools/measure_ref_grad_quant2.py: cosine >= 0.94 on every encoder tensor in bf16) and the test can assert
+directions; ``infer_640`` additionally scales the mask decoder's output conv so that the mask is bimodal (the
+binarisation is then decided away from the threshold on all but a sliver of the pixels).
+"""
+import contextlib
+import io
+import json
+import random
+import sys
+
+import numpy as np
+import torch
+
+from climategan_amd import fill
+from oracle.make_golden import GOLDEN_DIR, grad_subsample, reference_vgg_loss, summarize, t
+
+CASES_640 = {
+    "jstep_640": dict(kind="jstep", H=640, W=640, B=2, seed=68, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
+                      vgg_gain=2.449489742783178),
+    "infer_640": dict(kind="infer640", H=640, W=640, B=2, seed=72, gain=1.0, res_gamma=0.05, mask_gain=1000.0, mask_bias=-25.8,
+                      bin_value=0.5, rng_seed=99),
+}
+MASK_OUT = "decoders.m.model.7.conv"          # MaskBaseDecoder's plain output conv (blocks.py:279-289)
+
+
+def generator_fill(shapes, case):
+    """Portable fill of the generator for a 640 case (shared with the tests)."""
+    sd = fill.fill_state_dict(shapes, case["seed"], gain=case["gain"], res_gamma=case["res_gamma"])
+    g = case.get("mask_gain")
+    if g:
+        # eval-mode logits of this untrained net: median 0.0258 + bias, std 0.0075 (measured once in the dev container);
+        # gain 1000 and bias -25.8 centre them on 0 with std ~7.5: sigmoid saturates, ~50 % of the pixels flooded
+        sd[MASK_OUT + ".weight"] = (sd[MASK_OUT + ".weight"] * g).astype(np.float32)
+        sd[MASK_OUT + ".bias"] = np.full_like(sd[MASK_OUT + ".bias"], case["mask_bias"])
+    return sd
+
+
+def jstep_inputs(case):
+    """Seeded multi-domain batch (numpy): r / s with x, d, s, m; rf with x, m."""
+    s, B, H, W = case["seed"], case["B"], case["H"], case["W"]
+    h, w = H // 4, W // 4
+    out = {}
+    for i, dom in enumerate(("r", "s")):
+        out[dom] = {"x": fill.uniform((B, 3, H, W), s * 100 + 10 * i + 1),
+                    "d": fill.uniform((B, 1, h, w), s * 100 + 10 * i + 2, 0.35, 6.95),
+                    "s": (fill.uniform01((B, 1, h, w), s * 100 + 10 * i + 3) * 11).astype(np.int64).clip(0, 10),
+                    "m": fill.rect_mask(B, H, W, s * 100 + 10 * i + 4)}
+    out["rf"] = {"x": fill.uniform((B, 3, H, W), s * 100 + 31), "m": fill.rect_mask(B, H, W, s * 100 + 32)}
+    return out
+
+
+def infer_inputs(case):
+    return {"x": fill.uniform((case["B"], 3, case["H"], case["W"]), case["seed"] * 100 + 1)}
+
+
+class _NullTimer:
+    def __init__(self, *a, **k): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+def reference_training_trainer(case):
+    """The reference ``Trainer`` after its own ``setup(inference=False)`` on CPU.  Switched off: data loaders (no data in
+    the tree), display images, comet / architecture logging, CUDA timers.  ``create_generator`` / ``create_discriminator``
+    run with ``no_init`` (the pretrained DeepLab checkpoint is a cluster path) and every parameter is then overwritten by
+    the portable fill; ``torchvision.models.vgg19`` is the configuration-E stand-in of ``reference_vgg_loss``."""
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    opts.dis.soft_shift = 0.0            # RNG-free GANLoss targets (parity runs)
+    opts.dis.flip_prob = 0.0
+    tr = ref_shim.ref("trainer")
+    reference_vgg_loss(dict(seed=case["vgg_seed"], gain=case["vgg_gain"]))     # installs the vgg19 stand-in
+    tr.Timer = _NullTimer
+    tr.get_all_loaders = lambda o: {}
+    cg, cd = tr.create_generator, tr.create_discriminator
+    tr.create_generator = lambda o, device="cpu", no_init=False, verbose=0: cg(o, device=device, no_init=True, verbose=verbose)
+    tr.create_discriminator = lambda o, device, no_init=False, verbose=0: cd(o, device, no_init=True, verbose=verbose)
+    T = tr.Trainer(opts, device=torch.device("cpu"))
+    T.set_display_images = lambda *a, **k: None
+    T.switch_data = lambda *a, **k: None
+    T.logger.log_architecture = lambda *a, **k: None
+    T.logger.log_losses = lambda *a, **k: None
+    L = ref_shim.ref("losses")
+    sigm_defaults = L.SIGMLoss.__init__.__defaults__
+    assert sigm_defaults[-1] == "cuda"                             # SIGMLoss(gmweight, scale, device="cuda") (losses.py:243)
+    L.SIGMLoss.__init__.__defaults__ = sigm_defaults[:-1] + ("cpu",)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            T.setup(inference=False)
+    finally:
+        tr.create_generator, tr.create_discriminator = cg, cd
+        L.SIGMLoss.__init__.__defaults__ = sigm_defaults
+    shapes = {k: tuple(v.shape) for k, v in T.G.state_dict().items()}
+    T.G.load_state_dict({k: t(v) for k, v in generator_fill(shapes, case).items()})
+    dshapes = {k: tuple(v.shape) for k, v in T.D.state_dict().items()}
+    T.D.load_state_dict({k: t(v) for k, v in fill.fill_state_dict(dshapes, case["seed"] + 1).items()})
+    vgg = T.losses["G"]["p"]["vgg"].vgg
+    vshapes = {k: tuple(v.shape) for k, v in vgg.state_dict().items()}
+    vgg.load_state_dict({k: t(v) for k, v in fill.fill_state_dict(vshapes, case["vgg_seed"], gain=case["vgg_gain"]).items()})
+    T.G.train()
+    T.D.train()
+    return T
+
+
+def _flatten(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flatten(v, prefix + k + "."))
+        elif isinstance(v, (int, float)):
+            out[prefix + k] = float(v)
+    return out
+
+
+def run_jstep(case):
+    T = reference_training_trainer(case)
+    batch = {dom: {"data": {k: t(v) for k, v in d.items()}} for dom, d in jstep_inputs(case).items()}
+    saved = (torch.Tensor.cuda, torch.Tensor.get_device)
+    torch.Tensor.cuda = lambda self, *a, **k: self                 # vgg_preprocess's hard-coded .cuda() (tutils.py:422)
+    torch.Tensor.get_device = lambda self: torch.device("cpu")     # CustomBCELoss: .to(prediction.get_device()) (losses.py:476)
+    out = {}
+    try:
+        T.update_G(batch)
+        out.update({"G." + k: np.array([v], dtype=np.float32) for k, v in _flatten(T.logger.losses.gen).items()})
+        for key, p in T.G.named_parameters():
+            if p.requires_grad and p.grad is not None:
+                out["gsub.G." + key] = grad_subsample(key, p.grad, case["sub"])
+                out["gnorm.G." + key] = np.array([p.grad.norm().item()], dtype=np.float32)
+        sd = T.G.state_dict()
+        for key in ("encoder.bn1.running_mean", "encoder.layer3.5.bn2.running_var",
+                    "decoders.s.aspp.conv2.bn.running_mean", "decoders.d.enc4_2.norm.running_var"):
+            out["post.G." + key] = sd[key].numpy().copy()
+        T.update_D(batch)
+        out.update({"D." + k: np.array([v], dtype=np.float32) for k, v in _flatten(T.logger.losses.disc).items()})
+        for key, p in T.D.named_parameters():
+            if p.requires_grad and p.grad is not None:
+                out["gsub.D." + key] = grad_subsample(key, p.grad, case["sub"])
+                out["gnorm.D." + key] = np.array([p.grad.norm().item()], dtype=np.float32)
+    finally:
+        torch.Tensor.cuda, torch.Tensor.get_device = saved
+    return out
+
+
+def bind_fire_formulas():
+    """fire.py's three third-party calls -> their documented formulas (see make_golden.run_reference_fire)."""
+    import torch.nn.functional as F
+
+    from oracle import cpu_ref, ref_shim
+
+    fire = ref_shim.ref("fire")
+
+    def gaussian_kernel2d(kernel_size, sigma, *a, **k):
+        return torch.outer(cpu_ref._kornia_gaussian_1d(kernel_size[0], sigma[0]),
+                           cpu_ref._kornia_gaussian_1d(kernel_size[1], sigma[1]))
+
+    def filter2d(inp, kernel, border_type="reflect", *a, **k):
+        # separable evaluation of the same 2-D correlation, in fp64 (a direct 281 x 281 correlation of a 640 x 640 map is
+        # 32 G MACs per image; the direct form is what pins the small fixture fire_small)
+        assert border_type == "reflect" and kernel.shape[0] == 1
+        kh, kw = kernel.shape[-2:]
+        k2 = kernel[0].double()
+        gy, gx = k2.sum(1), k2.sum(0)
+        gy, gx = gy / gy.sum(), gx / gx.sum()
+        assert (torch.outer(gy, gx) - k2).abs().max() < 1e-10      # entries ~1e-5, fp32 kernel
+        y = F.conv2d(F.pad(inp.double(), (kw // 2, kw // 2, 0, 0), mode="reflect"), gx.view(1, 1, 1, -1))
+        y = F.conv2d(F.pad(y, (0, 0, kh // 2, kh // 2), mode="reflect"), gy.view(1, 1, -1, 1))
+        return y.float()
+
+    fire.adjust_contrast = lambda img, contrast_factor: cpu_ref._tv_adjust_contrast_u8(img, contrast_factor)
+    fire.adjust_brightness = lambda img, brightness_factor: cpu_ref._tv_adjust_brightness_u8(img, brightness_factor)
+    fire.filter2d = filter2d
+    fire.kornia.filters.kernels.get_gaussian_kernel2d = gaussian_kernel2d
+    return fire
+
+
+def run_infer640(case):
+    from oracle import ref_shim
+
+    opts = ref_shim.default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    tr = ref_shim.ref("trainer")
+    tr.Timer = _NullTimer
+    bind_fire_formulas()
+    T = tr.Trainer(opts, device=torch.device("cpu"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        T.setup(inference=True)
+    shapes = {k: tuple(v.shape) for k, v in T.G.state_dict().items()}
+    T.G.load_state_dict({k: t(v) for k, v in generator_fill(shapes, case).items()})
+    T.G.eval()
+    x = t(infer_inputs(case)["x"])
+    cap = {}
+
+    def capture(fn, key):
+        def wrapped(*a, **kw):
+            r = fn(*a, **kw)
+            cap[key] = r.detach().clone()
+            cap[key + "_kw"] = {k2: (v.detach().clone() if torch.is_tensor(v) else v) for k2, v in kw.items()}
+            return r
+        return wrapped
+
+    T.compute_flood = capture(T.compute_flood, "flood")
+    T.compute_smog = capture(T.compute_smog, "smog")
+    T.compute_fire = capture(T.compute_fire, "wildfire")
+    random.seed(case["rng_seed"])
+    green = random.randint(100, 150)
+    random.seed(case["rng_seed"])
+    res = T.infer_all(x, numpy=True, bin_value=case["bin_value"], return_masks=True)
+    m = cap["flood_kw"]["m"].numpy()
+    out = {"green": np.array([green], dtype=np.int64),
+           "mask_bits": np.packbits(res["mask"] > 0),                       # [B,1,H,W] booleans, 8 per byte
+           "band_frac": np.array([(np.abs(m - case["bin_value"]) < 0.01).mean()], dtype=np.float32),
+           "m_band": np.packbits(np.abs(m - case["bin_value"]) < 0.01)}
+    for k in ("flood", "smog", "wildfire"):
+        u8 = np.ascontiguousarray(res[k].transpose(0, 3, 1, 2))              # [B,3,H,W] uint8
+        out.update({k + "_u8_" + a: b for a, b in summarize(u8.astype(np.float32)).items()})
+    for k, v in (("m", m), ("s", cap["flood_kw"]["s"].numpy()), ("d", cap["smog_kw"]["d"].numpy()),
+                 ("flood", cap["flood"].numpy())):
+        out.update({k + "_" + a: b for a, b in summarize(v).items()})
+    return out
+
+
+def main():
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        sys.exit("make_golden_640 needs /root/reference (dev container only)")
+    torch.set_num_threads(8)
+    only = set(sys.argv[1:]) or set(CASES_640)
+    manifest_path = GOLDEN_DIR / "manifest_640.json"
+    manifest = json.loads(manifest_path.read_text()) if manifest_path.exists() else {}
+    for name, case in CASES_640.items():
+        if name not in only:
+            continue
+        out = run_jstep(case) if case["kind"] == "jstep" else run_infer640(case)
+        path = GOLDEN_DIR / (name + ".npz")
+        np.savez_compressed(path, **out)
+        manifest[name] = dict(case=case, n_keys=len(out), bytes=path.stat().st_size)
+        print("%-12s %9d B  %d keys" % (name, path.stat().st_size, len(out)))
+    manifest_path.write_text(json.dumps(manifest, indent=1, default=list))
+
+
+if __name__ == "__main__":
+    main()
