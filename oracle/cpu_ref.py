@@ -286,8 +286,31 @@ class ExtraAdamRef:
 # --------------------------------------------------------------------------------------------------
 # Masker (inference / eval-mode BatchNorm): deeplab/resnet101_v3.py, deeplab/deeplab_v3.py, depth.py, blocks.py
 # --------------------------------------------------------------------------------------------------
+_BN_TRAINING = [False]
+
+
+class bn_training:
+    """``with bn_training():`` -- every ``_bn`` inside behaves like ``nn.BatchNorm2d`` in TRAINING mode (batch
+    statistics, running statistics moved with momentum 0.1 into the state dict, ``num_batches_tracked`` + 1): the Masker
+    under ``G.train()`` (reference trainer.py:933).  Default (outside): eval mode."""
+
+    def __enter__(self):
+        self.prev = _BN_TRAINING[0]
+        _BN_TRAINING[0] = True
+
+    def __exit__(self, *a):
+        _BN_TRAINING[0] = self.prev
+
+
 def _bn(x, sd: SD, prefix: str, eps: float = 1e-5):
-    """eval-mode nn.BatchNorm2d"""
+    """nn.BatchNorm2d: eval mode, or training mode inside ``bn_training()``"""
+    if _BN_TRAINING[0]:
+        rm, rv = sd[prefix + ".running_mean"].clone(), sd[prefix + ".running_var"].clone()
+        y = F.batch_norm(x, rm, rv, sd.get(prefix + ".weight"), sd.get(prefix + ".bias"), True, 0.1, eps)
+        sd[prefix + ".running_mean"], sd[prefix + ".running_var"] = rm, rv
+        if prefix + ".num_batches_tracked" in sd:
+            sd[prefix + ".num_batches_tracked"] = sd[prefix + ".num_batches_tracked"] + 1
+        return y
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd.get(prefix + ".weight"),
                         sd.get(prefix + ".bias"), False, 0.0, eps)
 
@@ -894,3 +917,193 @@ def sigm_loss(prediction, target, gmweight=0.5, scale=4):
         R_ = F.interpolate(R, scale_factor=1 / 2 ** k)
         gm = gm + F.conv2d(R_, sobelx).abs().sum() + F.conv2d(R_, sobely).abs().sum()
     return 0.5 / num_pix * R.abs().sum() + gmweight / num_pix * gm
+
+
+# --------------------------------------------------------------------------------------------------
+# One training iteration of the default task set [d, s, m, p]: Trainer.update_G + Trainer.update_D
+# (trainer.py:989-1032) = get_G_loss (get_masker_loss :1184-1254 with masker_{d,s,m}_loss :1389-1616, get_painter_loss
+# :1256-1387) and get_D_loss (:1034-1160), each followed by backward().  SURVEY Appendix A lists the terms.
+# --------------------------------------------------------------------------------------------------
+DEFAULT_LAMBDAS = {  # shared/trainer/defaults.yaml:278-311
+    "d.main": 1.0, "d.gml": 0.5, "s.crossent": 1.0, "s.minent": 0.001, "s.advent": 0.001, "m.bce": 1.0, "m.tv": 1.0,
+    "m.gi": 0.05, "advent.ent_main": 0.5, "advent.ent_var": 0.1, "advent.adv_main": 1.0, "p.vgg": 10.0,
+    "p.featmatch": 10.0,
+}
+
+
+def _trainable(sd: SD) -> SD:
+    """Clones of a state dict with requires_grad on what the reference trains: everything floating point except the
+    spectral-norm u / v vectors (``requires_grad=False`` parameters, norms.py:129-130) and the BatchNorm buffers."""
+    out = {}
+    for k, v in sd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        frozen = leaf in ("weight_u", "weight_v", "running_mean", "running_var", "num_batches_tracked")
+        out[k] = v.clone().requires_grad_(v.is_floating_point() and not frozen)
+    return out
+
+
+def _masker_preds(g: SD, x, s_size, d_size):
+    z = resnet101(x, g, "encoder")
+    d_pred, z_depth = dada_depth_decoder(z, g, "decoders.d", d_size)
+    s_pred = deeplab_v3_decoder(z, g, "decoders.s", s_size, z_depth, use_dada=True)
+    logits = mask_base_decoder(z, g, "decoders.m")
+    return d_pred, s_pred, logits
+
+
+def masker_g_loss(g: SD, dd: SD, batch: dict, lam: dict, terms: dict):
+    """``get_masker_loss`` for the domains of ``batch`` other than rf, in their order (trainer.py:1200-1254)."""
+    total = 0
+    for dom, b in batch.items():
+        if dom == "rf":
+            continue
+        x = b["x"]
+        d_pred, s_pred, logits = _masker_preds(g, x, tuple(b["s"].shape[-2:]), b["d"].shape[-1])
+        l = sigm_loss(d_pred, b["d"], lam["d.gml"]) * lam["d.main"]          # computed, then dropped for domain r
+        terms["G.task.d." + dom] = l.detach() if dom == "s" else torch.zeros(())     # (trainer.py:1403-1405)
+        if dom == "s":
+            total = total + l
+            l = cross_entropy(s_pred, b["s"].squeeze(1)) * lam["s.crossent"]
+            terms["G.task.s.crossent.s"] = l.detach(); total = total + l
+        else:
+            sm = torch.softmax(s_pred, dim=1)
+            l = minent_loss(sm) * lam["s.minent"]
+            terms["G.task.s.minent.r"] = l.detach(); total = total + l
+            ent = prob_2_entropy(sm) * d_pred.detach()                        # gen.s.use_dada (trainer.py:1455-1456)
+            l = advent_wgan(fc_discriminator(ent, dd, "s.Advent"), 0) * lam["s.advent"]
+            terms["G.task.s.advent.r"] = l.detach(); total = total + l
+        p = torch.sigmoid(logits)
+        prob = torch.cat([p, 1 - p], dim=1)
+        l = tv_loss(p) * lam["m.tv"]
+        terms["G.task.m.tv." + dom] = l.detach(); total = total + l
+        if dom == "s":
+            l = F.binary_cross_entropy_with_logits(logits, b["m"]) * lam["m.bce"]
+            terms["G.task.m.bce.s"] = l.detach(); total = total + l
+        else:
+            l = ground_intersection_loss(p, b["m"]) * lam["m.gi"]
+            terms["G.task.m.gi.r"] = l.detach(); total = total + l
+            l = minent_loss(prob, 2, lam["advent.ent_var"]) * lam["advent.ent_main"]
+            terms["G.task.m.minent.r"] = l.detach(); total = total + l
+            l = advent_wgan(fc_discriminator(prob_2_entropy(prob), dd, "m.Advent"), 0) * lam["advent.adv_main"]
+            terms["G.task.m.advent.r"] = l.detach(); total = total + l
+    return total
+
+
+class sub_view(dict):
+    """A prefix view of a state dict that WRITES THROUGH (the functional modules store the power-iterated u / v back
+    into the dict they are given; ``sub()`` would hand them a copy)."""
+
+    def __init__(self, parent: SD, prefix: str):
+        super().__init__()
+        self._parent, self._p = parent, prefix + "."
+        for k, v in parent.items():
+            if k.startswith(self._p):
+                dict.__setitem__(self, k[len(self._p):], v)
+
+    def __setitem__(self, k, v):
+        dict.__setitem__(self, k, v)
+        self._parent[self._p + k] = v
+
+
+def joint_d_loss(g: SD, dd: SD, batch: dict, z_hw, num_D, n_layers, lam: dict, terms: dict):
+    """``get_D_loss`` (trainer.py:1034-1160): Painter branch on a fake painted without a graph, ADVENT branches with the
+    BCE form (losses.py:440,496-497) on the detached predictions; ``adv_main`` is applied twice, as in the reference
+    (masker_s_loss / masker_m_loss and again at trainer.py:1122,1145)."""
+    total = 0
+    adv = lam["advent.adv_main"]
+    acc = {"s": 0, "m": 0}
+    for dom, b in batch.items():
+        if dom == "rf":
+            x, m = b["x"], b["m"]
+            with torch.no_grad():
+                fake = paint(sub_view(g, "painter"), m, x, z_hw[0], z_hw[1])
+            out = multiscale_discriminator(torch.cat([torch.cat([m, x], 1), torch.cat([m, fake], 1)], 0),
+                                           sub_view(dd, "p"), num_D, n_layers)
+            real_d = [[t[: t.size(0) // 2] for t in p] for p in out]
+            fake_d = [[t[t.size(0) // 2:] for t in p] for p in out]
+            l = gan_loss(fake_d, False) + gan_loss(real_d, True)
+            terms["D.p.gan"] = l.detach(); total = total + l
+            continue
+        label = {"s": 0.0, "r": 1.0}[dom]
+        with torch.no_grad():
+            d_pred, s_pred, logits = _masker_preds(g, b["x"], tuple(b["s"].shape[-2:]), b["d"].shape[-1])
+            ent_s = prob_2_entropy(torch.softmax(s_pred, dim=1)) * d_pred
+            p = torch.sigmoid(logits)
+            ent_m = prob_2_entropy(torch.cat([p, 1 - p], dim=1))
+        for task, ent in (("s", ent_s), ("m", ent_m)):
+            o = fc_discriminator(ent, dd, task + ".Advent")
+            l = F.binary_cross_entropy_with_logits(o, torch.full_like(o, label)) * adv * adv
+            acc[task] = acc[task] + l.detach(); total = total + l
+    for task in ("s", "m"):
+        if torch.is_tensor(acc[task]):
+            terms["D.%s.Advent" % task] = acc[task]
+    return total
+
+
+def joint_train_step(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: dict, n_up: int, num_D: int = 3, n_layers: int = 4,
+                     lam: Optional[dict] = None, want_grads: bool = True, g_lr: float = 5e-5, g_betas=(0.9, 0.999)):
+    """``Trainer.update_G`` (loss, ``backward()``, ExtraAdam extrapolation of G as at ``global_step`` 0) then
+    ``Trainer.update_D`` up to and including its ``backward()`` (the D optimizer step changes nothing observable here) on a
+    multi-domain batch ``{"r": {x, d, s, m}, "s": {...}, "rf": {x, m}}`` (plain tensors), generator and discriminators in
+    training mode.  Returns {"terms": {...}, "g_grads": {...}, "d_grads": {...}, "g_state": sd, "d_state": sd}: loss terms
+    under the names the reference logs them (logger.losses.gen / .disc), gradients of every trainable tensor, and the
+    states after the step (spectral-norm vectors power-iterated by every forward, BatchNorm running statistics)."""
+    lam = dict(DEFAULT_LAMBDAS, **(lam or {}))
+    terms = {}
+    g, dd = _trainable(sd_g), _trainable(sd_d)
+    for v in dd.values():                       # D frozen during the G update (trainer.py:959-962)
+        v.requires_grad_(False)
+    rf = batch.get("rf")
+    z_hw = (rf["x"].shape[-2] // 2 ** n_up, rf["x"].shape[-1] // 2 ** n_up) if rf is not None else None
+    with bn_training():
+        g_loss = masker_g_loss(g, dd, batch, lam, terms) if any(d != "rf" for d in batch) else 0
+        if rf is not None:
+            gp = sub_view(g, "painter")
+            g_loss = g_loss + painter_g_loss(gp, dd, sd_vgg, rf, z_hw, num_D, n_layers, lam, terms)
+        g_keys = [k for k, v in g.items() if v.requires_grad]
+        g_grads = {}
+        if want_grads:
+            grads = torch.autograd.grad(g_loss, [g[k] for k in g_keys], allow_unused=True)
+            g_grads = {k: gr for k, gr in zip(g_keys, grads) if gr is not None}
+        terms["G.total_loss"] = g_loss.detach()
+        g = {k: v.detach() for k, v in g.items()}
+        if g_lr and want_grads:
+            # g_opt_step() at global_step 0 (trainer.py:674-683): ExtraAdam extrapolation -- the D update sees the
+            # EXTRAPOLATED generator (lr 5e-5, betas (0.9, 0.999), defaults.yaml:73-77)
+            keys = list(g_grads)
+            opt = ExtraAdamRef([g[k] for k in keys], lr=g_lr, betas=g_betas)
+            opt.extrapolation([g_grads[k] for k in keys])
+            for k, v in zip(keys, opt.params):
+                g[k] = v
+        for k, v in dd.items():                 # D trains again (trainer.py:971-973)
+            leaf = k.rsplit(".", 1)[-1]
+            dd[k] = v.detach().requires_grad_(leaf not in ("weight_u", "weight_v"))
+        d_loss = joint_d_loss(g, dd, batch, z_hw, num_D, n_layers, lam, terms)
+        d_keys = [k for k, v in dd.items() if v.requires_grad]
+        d_grads = {}
+        if want_grads:
+            grads = torch.autograd.grad(d_loss, [dd[k] for k in d_keys], allow_unused=True)
+            d_grads = {k: gr for k, gr in zip(d_keys, grads) if gr is not None}
+        terms["D.total_loss"] = d_loss.detach()
+    return {"terms": terms, "g_grads": g_grads, "d_grads": d_grads, "g_state": g,
+            "d_state": {k: v.detach() for k, v in dd.items()}}
+
+
+def painter_g_loss(gp: SD, dd: SD, vgg: Optional[SD], b: dict, z_hw, num_D, n_layers, lam: dict, terms: dict):
+    """``get_painter_loss`` (trainer.py:1256-1387), single-discriminator branch, default lambdas (TV / context /
+    reconstruction 0): VGG on ``fake_flooded * m`` with the already pasted image, unscaled GAN term (trainer.py:1369-1371),
+    feature matching.  ``gp``: the painter's tensors (a write-through view of the generator's)."""
+    x, m = b["x"], b["m"]
+    fake = paint(gp, m, x, z_hw[0], z_hw[1])
+    total = 0
+    if vgg is not None and lam["p.vgg"] != 0:
+        l = vgg_loss(vgg, vgg_preprocess(fake * m), vgg_preprocess(x * m)) * lam["p.vgg"]
+        terms["G.p.vgg"] = l.detach(); total = total + l
+    out = multiscale_discriminator(torch.cat([torch.cat([m, x], 1), torch.cat([m, fake], 1)], 0), sub_view(dd, "p"),
+                                   num_D, n_layers)
+    real_d = [[t[: t.size(0) // 2] for t in p] for p in out]
+    fake_d = [[t[t.size(0) // 2:] for t in p] for p in out]
+    l = gan_loss(fake_d, True)
+    terms["G.p.gan"] = l.detach(); total = total + l
+    l = feat_match_loss(real_d, fake_d) * lam["p.featmatch"]
+    terms["G.p.featmatch"] = l.detach(); total = total + l
+    return total

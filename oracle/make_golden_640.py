@@ -36,6 +36,10 @@ from oracle.make_golden import GOLDEN_DIR, grad_subsample, reference_vgg_loss, s
 CASES_640 = {
     "jstep_640": dict(kind="jstep", H=640, W=640, B=2, seed=68, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
                       vgg_gain=2.449489742783178),
+    # the same two reference calls on a small configuration (Painter latent 32 / 4 up-samplings, PatchGAN ndf 16 / 3
+    # layers, 128 x 160): pins oracle.cpu_ref.joint_train_step on the CPU in seconds
+    "jstep_small": dict(kind="jstep", H=128, W=160, B=2, seed=69, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
+                        vgg_gain=2.449489742783178, latent_dim=32, n_up=4, ndf=16, n_layers=3),
     "infer_640": dict(kind="infer640", H=640, W=640, B=2, seed=72, gain=1.0, res_gamma=0.05, mask_gain=1000.0, mask_bias=-25.8,
                       bin_value=0.5, rng_seed=99),
 }
@@ -89,6 +93,9 @@ def reference_training_trainer(case):
     opts.tasks = ["d", "s", "m", "p"]
     opts.dis.soft_shift = 0.0            # RNG-free GANLoss targets (parity runs)
     opts.dis.flip_prob = 0.0
+    if "latent_dim" in case:             # the small configuration
+        opts.gen.p.latent_dim, opts.gen.p.spade_n_up = case["latent_dim"], case["n_up"]
+        opts.dis.p.ndf, opts.dis.p.n_layers = case["ndf"], case["n_layers"]
     tr = ref_shim.ref("trainer")
     reference_vgg_loss(dict(seed=case["vgg_seed"], gain=case["vgg_gain"]))     # installs the vgg19 stand-in
     tr.Timer = _NullTimer
@@ -120,6 +127,10 @@ def reference_training_trainer(case):
     vgg.load_state_dict({k: t(v) for k, v in fill.fill_state_dict(vshapes, case["vgg_seed"], gain=case["vgg_gain"]).items()})
     T.G.train()
     T.D.train()
+    if (case["H"], case["W"]) != (640, 640):
+        T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
+        T.G.decoders["d"]._target_size = case["W"] // 4
+        T.G.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
     return T
 
 

@@ -33,7 +33,14 @@ def _load(mod, sd_np):
 # ------------------------------------------------------------------------------------------------ configs[4]
 # (max, mean) deviation of the reference's OWN 16-bit run (G.half() / G.bfloat16() on the CPU) from its fp32 run on this
 # fixture, per stage output, relative to the output's max |value| (tests/devtools/measure_ref_half_masker.py)
-REF_HALF_MASKER = {}
+REF_HALF_MASKER = {
+    ("d", "bfloat16"): (0.003363, 0.002988),
+    ("s", "bfloat16"): (0.009623, 0.002166),
+    ("m", "bfloat16"): (0.09604, 0.002767),
+    ("d", "float16"): (0.0004954, 8.861e-05),
+    ("s", "float16"): (0.001237, 0.0002538),
+    ("m", "float16"): (0.006944, 0.0004777),
+}
 
 
 @pytest.fixture(scope="module")
