@@ -1066,6 +1066,7 @@ def joint_train_step(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: dict, n_up
             g_grads = {k: gr for k, gr in zip(g_keys, grads) if gr is not None}
         terms["G.total_loss"] = g_loss.detach()
         g = {k: v.detach() for k, v in g.items()}
+        bn_after_g = {k: v.clone() for k, v in g.items() if k.endswith(("running_mean", "running_var"))}
         if g_lr and want_grads:
             # g_opt_step() at global_step 0 (trainer.py:674-683): ExtraAdam extrapolation -- the D update sees the
             # EXTRAPOLATED generator (lr 5e-5, betas (0.9, 0.999), defaults.yaml:73-77)
@@ -1084,7 +1085,7 @@ def joint_train_step(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: dict, n_up
             grads = torch.autograd.grad(d_loss, [dd[k] for k in d_keys], allow_unused=True)
             d_grads = {k: gr for k, gr in zip(d_keys, grads) if gr is not None}
         terms["D.total_loss"] = d_loss.detach()
-    return {"terms": terms, "g_grads": g_grads, "d_grads": d_grads, "g_state": g,
+    return {"terms": terms, "g_grads": g_grads, "d_grads": d_grads, "g_state": g, "bn_after_update_G": bn_after_g,
             "d_state": {k: v.detach() for k, v in dd.items()}}
 
 

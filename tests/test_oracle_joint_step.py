@@ -62,4 +62,4 @@ def test_joint_train_step_matches_reference_update_g_and_update_d():
     assert checked > 500
     for k in gold:
         if k.startswith("post.G."):
-            np.testing.assert_allclose(out["g_state"][k[7:]].numpy(), gold[k], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(out["bn_after_update_G"][k[7:]].numpy(), gold[k], rtol=1e-4, atol=1e-6)
