@@ -1,22 +1,33 @@
 """bench.py -- throughput of the ClimateGAN hot path on MI355X.
 
-Workload (BASELINE.json configs[1], the single-GPU configuration the metric is quoted on):
-  Painter-only SPADE generator forward, 640x640, batch 8 per GPU, bf16 activations / fp32 accumulate,
-  synthetic mask + context: one step = ``OmniGenerator.paint(m, x)`` (mask the image, run the 9-block SPADE
-  Painter incl. the per-forward spectral-norm power iterations, paste) with inputs resident in HBM.
+Headline (BASELINE.json ``metric``: "640x640 images/sec (G+D step) at 1/2/4/8 MI355X"; BASELINE configs[3], per-GPU slice):
+  one step = ``Trainer.train_step`` = ``update_G`` + ``update_D`` of the reference's default task set [d, s, m, p]
+  (reference trainer.py:989-1032) on one multi-domain batch -- domains r and s through the Masker (ResNet-101 encoder
+  with batch-statistics BatchNorm, depth / segmentation / mask decoders, 10 loss terms, ADVENT discriminators), domain rf
+  through the Painter (GAN + feature-matching + VGG losses, 3-scale PatchGAN) -- 640x640, **4 samples per domain per
+  GPU** (global batch 32 per domain on 8 GPUs), bf16 activations / fp32 accumulation and parameters, ExtraAdam
+  extrapolation / step.  ``value`` = per-domain sample slots per second over all ranks (a step consumes
+  ``bs`` samples from each of the three domains; the raw-image figure is 3x and reported next to it).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-N > 1: the path shards by image with no data-path collective (inference): every rank runs the same
-per-GPU batch (weak scaling); timing is barrier + synchronize on both sides, max over ranks.
+N > 1: data parallel, one process per GPU, identical replicas, per-rank batches (weak scaling), the G and the D gradients
+averaged by the bucketed RCCL all-reduce of ``climategan_amd/parallel.py`` launched from gradient hooks during the
+backward; timing is barrier + synchronize on both sides of the K timed steps, max over ranks.
 
 The JSON line also carries
-  roofline     : the dominant kernel (fused SPADE, MFMA-bound) -- algorithmic FLOPs of the SPADE layers /
-                 their summed duration, timed with events on the launch stream inside the timed region
-  cpu_baseline : the oracle's CPU restatement (oracle.cpu_ref, torch fp32 on the host cores) on a bounded
-                 sample of the same workload (rank 0, N=1 only)
+  roofline      the dominant kernel family of the step -- the wide-layer implicit-GEMM convolution kernel
+                (``conv_gemm_kernel``: forward and data-gradient convs of the ResNet / ASPP / decoders / VGG / PatchGAN layers
+                with >= 64 output channels; MFMA-bound): every launch inside the timed region is bracketed by events on
+                the launch stream, achieved = algorithmic FLOPs (2 * output pixels * c_out * c_in * taps, from the call's
+                own descriptor) / summed duration;
+  cpu_baseline  the oracle's CPU restatement of the same step (``oracle.cpu_ref.joint_train_step``, torch fp32 autograd)
+                on a bounded sample -- one step at 1 sample per domain, 640x640 -- on the host cores (rank 0, N = 1);
+  sub_blocks    the other BASELINE configurations on the same box, each with >= 20 timed steps: configs[1] Painter
+                forward bs 8 bf16 (with the fused-SPADE kernel's MFMA roofline, the kernel north_star names),
+                configs[2] Masker train step bs 8, configs[4] apply_events inference bs 16 fp16.
 """
 import argparse
 import json
@@ -31,11 +42,15 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-BATCH_PER_GPU = 8
+BATCH_PER_GPU = 8      # configs[1]: Painter forward
+TRAIN_BS = 4           # configs[3]: per domain per GPU (global batch 32 per domain over 8 GPUs)
+MASKER_BS = 8          # configs[2]
+INFER_BS = 16          # configs[4]
 H = W = 640
 LATENT = 640
 N_UP = 7
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md chip table
+WELL_CONDITIONED = dict(gain=1.0, res_gamma=0.05)   # the fill of the 640x640 parity fixtures (tests/test_gpu_configs_640.py)
 
 
 def painter_shapes(latent_dim, n_up):
@@ -97,19 +112,177 @@ def spade_layer_table(latent_dim, n_up, h, w):
     return layers, flops
 
 
-def recorded_spade_traffic():
-    """HBM bytes per fused-SPADE launch from the committed PMC summary (tools/summarize_pmc.py); None if absent.
-    The PMC passes cannot run inside the timed bench (rocprofv3 wraps the process), so the number is recorded."""
+def recorded_traffic(pattern):
+    """HBM bytes per launch from the newest committed PMC summary matching ``profiles/<pattern>`` (tools/summarize_pmc.py);
+    None if absent.  The PMC passes cannot run inside the timed bench (rocprofv3 wraps the process): recorded."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_spade_hbm_pmc.csv")))
+    files = sorted(glob.glob(str(ROOT / "profiles" / pattern)))
     if not files:
         return None
     m = re.search(r"= ([0-9.]+) MB per launch", open(files[-1]).read())
     return int(float(m.group(1)) * 1e6) if m else None
 
 
+# ------------------------------------------------------------------------------------------------ timing helpers
+def timed_steps(step, steps, warmup, barrier):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier() on both sides."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(elapsed, dist, device):
+    """Whole-job time = the slowest rank's."""
+    if dist is None:
+        return elapsed
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return el.item()
+
+
+def result_line(world, steps, warmup, elapsed, dtype_name):
+    return {
+        "metric": "640x640 images/sec (G+D step): per-domain sample slots per second of the joint Masker+Painter "
+                  "training step (update_G + update_D), 4 per domain per GPU",
+        "value": round(world * TRAIN_BS * steps / elapsed, 3),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype_name,
+        "data": "synthetic (counter-hash fill: U(-1,1) images, 3-rectangle masks ~35%, uniform depth / class targets; "
+                "untrained weights from the portable fill, VGG-19 random He-scale weights)",
+        "raw_images_per_s": round(3 * world * TRAIN_BS * steps / elapsed, 3),
+        "config": {"workload": "BASELINE configs[3] per-GPU slice: full Masker+Painter joint G/D train step "
+                               "(Trainer.train_step; tasks d,s,m,p; domains r,s,rf; all default loss terms incl. VGG; "
+                               "ExtraAdam), 640x640, 4 samples per domain per GPU",
+                   "batch_per_domain_per_gpu": TRAIN_BS, "global_batch": TRAIN_BS * world,
+                   "global_raw_images_per_step": 3 * TRAIN_BS * world, "latent_dim": LATENT, "spade_n_up": N_UP,
+                   "parallelism": "dp%d: replicas + bucketed RCCL all-reduce of G and D gradients from backward hooks" % world
+                                  if world > 1 else "single GPU"},
+    }
+
+
+class LaunchTimer:
+    """Event pairs (recorded on torch's current stream = the stream the library launches on) around selected launches."""
+
+    def __init__(self):
+        self.pairs = []          # (event0, event1, flops)
+        self.enabled = False
+
+    def bracket(self, fn, flops):
+        if not self.enabled:
+            return fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.pairs.append((e0, e1, flops))
+        return out
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b, _ in self.pairs)
+
+    def total_flops(self):
+        return sum(f for _, _, f in self.pairs)
+
+
+def install_conv_gemm_timer(timer):
+    """Bracket every launch of the wide-layer implicit-GEMM kernel (forward and data-gradient entry points): the C ABI says
+    which kernel a descriptor selects (``cgan_conv2d_kernel_kind``), and the algorithmic FLOPs come from the same
+    descriptor: 2 * n * h_out * w_out * c_out * c_in * kh * kw (forward) / 2 * n * h_in * w_in * c_in * c_out * kh * kw
+    (data gradient), logical channels."""
+    from climategan_amd import _lib
+
+    lib = _lib.load()
+    fwd, bwd, kind = lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_kernel_kind
+    GEMM = 2
+
+    def timed_fwd(x, w, b, r, y, dref, stream):
+        if timer.enabled and kind(dref, 0) == GEMM:
+            d = dref._obj
+            return timer.bracket(lambda: fwd(x, w, b, r, y, dref, stream),
+                                 2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw)
+        return fwd(x, w, b, r, y, dref, stream)
+
+    def timed_bwd(dy, w, dx, dref, stream):
+        if timer.enabled and kind(dref, 1) == GEMM:
+            d = dref._obj
+            return timer.bracket(lambda: bwd(dy, w, dx, dref, stream),
+                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw)
+        return bwd(dy, w, dx, dref, stream)
+
+    lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data = timed_fwd, timed_bwd
+
+    def uninstall():
+        lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data = fwd, bwd
+    return uninstall
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def _dev(a, device):
+    return torch.from_numpy(a).to(device)
+
+
+def joint_batch(bs, rank, device, domains=("r", "s", "rf")):
+    """SURVEY 8d synthetic inputs: x ~ U(-1, 1); 3-rectangle masks; depth ~ U(0.35, 6.95); classes uniform in 0..10."""
+    import numpy as np
+
+    from climategan_amd import fill
+
+    hs = H // 4
+    batch = {}
+    if "rf" in domains:
+        batch["rf"] = {"data": {"x": _dev(fill.uniform((bs, 3, H, W), 100 + rank), device),
+                                "m": _dev(fill.rect_mask(bs, H, W, 200 + rank), device)}}
+    for i, dom in enumerate(("r", "s")):
+        if dom not in domains:
+            continue
+        sd = 300 + 10 * i + 1000 * rank
+        batch[dom] = {"data": {"x": _dev(fill.uniform((bs, 3, H, W), sd), device),
+                               "d": _dev(fill.uniform((bs, 1, hs, hs), sd + 1, 0.35, 6.95), device),
+                               "s": _dev((fill.uniform01((bs, 1, hs, hs), sd + 2) * 11).astype(np.int64).clip(0, 10), device),
+                               "m": _dev(fill.rect_mask(bs, H, W, sd + 3), device)}}
+    return {d: batch[d] for d in domains}
+
+
+def build_trainer(device, dtype, tasks=("d", "s", "m", "p")):
+    """``Trainer.setup(inference=False)`` of the default config, every parameter overwritten by the portable fill."""
+    from climategan_amd import fill
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    opts = default_opts()
+    opts.tasks = list(tasks)
+    opts.gen.p.latent_dim = LATENT
+    opts.gen.p.spade_n_up = N_UP
+    T = Trainer(opts, device=device).setup(inference=False)
+    for mod, seed, kw in ((T.G, 0, WELL_CONDITIONED), (T.D, 1, {})):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=seed, **kw).items()})
+    if "p" in tasks:
+        vgg = T.losses["G"]["p"]["vgg"].vgg
+        shapes = {k: tuple(v.shape) for k, v in vgg.state_dict().items()}
+        vgg.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=2, gain=6 ** 0.5).items()})
+    # (under torchrun the replicas were broadcast inside setup(); every rank then loads the same portable fill)
+    T.G.set_compute_dtype(dtype)
+    T.D.set_compute_dtype(dtype)
+    return T
+
+
 def build(device, dtype):
+    """configs[1]: the default Painter alone (also used by tests/test_gpu_fullsize.py)."""
     from climategan_amd import fill
     from climategan_amd.config import default_opts
     from climategan_amd.generator import create_generator
@@ -134,41 +307,81 @@ def synthetic_batch(rank, device):
     return x, m
 
 
-class SpadeTimer:
-    """Event pairs around every fused-SPADE launch (recorded on the stream the kernel is launched on)."""
-
-    def __init__(self):
-        self.pairs = []
-        self.enabled = False
-
-    def install(self):
-        from climategan_amd import ops
-
-        orig = ops.spade_fused
-        timer = self
-
-        def timed(*a, **k):
-            if not timer.enabled:
-                return orig(*a, **k)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(*a, **k)
-            e1.record()
-            timer.pairs.append((e0, e1))
-            return out
-
-        ops.spade_fused = timed
-        import climategan_amd.norms as norms_mod
-
-        norms_mod.ops.spade_fused = timed
-
-    def total_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.pairs)
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def host_cores():
+    """(physical cores, hardware threads) of the host from /proc/cpuinfo."""
+    threads = os.cpu_count() or 1
+    try:
+        phys = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        return (len(phys) or threads), threads
+    except OSError:
+        return threads, threads
 
 
-def cpu_baseline(sd):
-    """Oracle (CPU restatement of the reference path, torch fp32) on a bounded sample: bs=1, 640x640."""
+def cpu_baseline_train():
+    """Oracle (``oracle.cpu_ref.joint_train_step``: the CPU restatement of update_G + ExtraAdam extrapolation + update_D,
+    torch fp32 autograd, pinned by the reference's own step -- tests/test_oracle_joint_step.py) on a bounded sample of the
+    headline workload: ONE step at 1 sample per domain, 640x640, default networks."""
+    import numpy as np
+
+    from climategan_amd import fill
+    from oracle import cpu_ref
+
+    phys, threads = host_cores()
+    use = max(1, min(32, phys))        # torch's intra-op threading stops scaling well before a 2-socket host's core count
+    torch.set_num_threads(use)
+    shapes_g = json.loads((ROOT / "tests" / "golden" / "generator_masker_shapes.json").read_text())
+    shapes_g = {k: tuple(v) for k, v in shapes_g.items()}
+    shapes_g.update({"painter." + k: v for k, v in painter_shapes(LATENT, N_UP).items()})
+    sd_g = {k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes_g, 0, **WELL_CONDITIONED).items()}
+
+    def sn(prefix, cin, cout, k):
+        return {prefix + ".module.weight_u": (cout,), prefix + ".module.weight_v": (cin * k * k,),
+                prefix + ".module.weight_bar": (cout, cin, k, k), prefix + ".module.bias": (cout,)}
+
+    shapes_d = {}
+    for i in range(3):                                     # define_D(4, ndf 64, n_layers 4, num_D 3): discriminator.py:83-169
+        chans = [4, 64, 128, 256, 512, 512, 1]
+        for j in range(6):
+            shapes_d.update(sn("p.discriminator_%d.model%d.0" % (i, j), chans[j], chans[j + 1], 4))
+    for task, nc in (("m", 2), ("s", 11)):                 # get_fc_discriminator: discriminator.py:327-361
+        chans = [nc, 64, 128, 256, 512, 1]
+        for j, idx in enumerate((0, 2, 4, 6, 8)):
+            shapes_d.update(sn("%s.Advent.%d" % (task, idx), chans[j], chans[j + 1], 4))
+    sd_d = {k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes_d, 1).items()}
+    sd_v = {k: torch.from_numpy(v) for k, v in fill.fill_state_dict(cpu_ref.vgg19_shapes(), 2, gain=6 ** 0.5).items()}
+    hs = H // 4
+    batch = {}
+    for i, dom in enumerate(("r", "s")):
+        sd = 300 + 10 * i
+        batch[dom] = {"x": torch.from_numpy(fill.uniform((1, 3, H, W), sd)),
+                      "d": torch.from_numpy(fill.uniform((1, 1, hs, hs), sd + 1, 0.35, 6.95)),
+                      "s": torch.from_numpy((fill.uniform01((1, 1, hs, hs), sd + 2) * 11).astype(np.int64).clip(0, 10)),
+                      "m": torch.from_numpy(fill.rect_mask(1, H, W, sd + 3))}
+    batch["rf"] = {"x": torch.from_numpy(fill.uniform((1, 3, H, W), 100)), "m": torch.from_numpy(fill.rect_mask(1, H, W, 200))}
+    t0 = time.perf_counter()
+    out = cpu_ref.joint_train_step(sd_g, sd_d, sd_v, batch, N_UP, 3, 4)
+    dt = time.perf_counter() - t0
+    assert all(torch.isfinite(v).all() for v in out["terms"].values())
+    return {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": use, "kind": "port",
+            "sample": "oracle.cpu_ref.joint_train_step (torch fp32 CPU restatement of trainer.py:989-1032 incl. the ExtraAdam "
+                      "extrapolation between the G and the D update), ONE step at 1 sample per domain (3 images) 640x640, "
+                      "no warm-up, %d torch threads on a host with %d physical cores / %d hardware threads; %.1f s"
+                      % (use, phys, threads, dt)}
+
+
+def cpu_baseline_paint(sd):
+    """configs[1] beside its GPU number: oracle ``cpu_ref.paint`` bs 1, 640x640 (1 warm-up + 2 runs, best of 2 thread counts)."""
     from climategan_amd import fill
     from oracle import cpu_ref
 
@@ -176,154 +389,117 @@ def cpu_baseline(sd):
     m = torch.from_numpy(fill.rect_mask(1, H, W, seed=2))
     sdc = {k: v.clone() for k, v in sd.items()}
     z = H // 2 ** N_UP
-    ncpu = os.cpu_count() or 1
+    phys, threads = host_cores()
     best = None
-    # torch's intra-op threading stops scaling on this workload well before a 2-socket host's thread count
-    # (256 threads: 77 s/image; 8 threads: 1.6 s/image on the same box), so report the best of a short sweep
-    for threads in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
-        torch.set_num_threads(threads)
+    for use in sorted({min(8, phys), min(32, phys)}):
+        torch.set_num_threads(use)
         with torch.no_grad():
-            cpu_ref.paint(sdc, m, x, z, z)  # warm-up
-            runs = 2
+            cpu_ref.paint(sdc, m, x, z, z)
             t0 = time.perf_counter()
-            for _ in range(runs):
+            for _ in range(2):
                 cpu_ref.paint(sdc, m, x, z, z)
-            dt = (time.perf_counter() - t0) / runs
+            dt = (time.perf_counter() - t0) / 2
         if best is None or dt < best[0]:
-            best = (dt, threads)
-    dt, threads = best
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "oracle.cpu_ref.paint (torch fp32 CPU restatement of generator.py:279-297), bs=1 640x640, "
-                      "best of {8,16,32} torch threads (2 runs after 1 warm-up each) on a %d-thread host" % ncpu}
+            best = (dt, use)
+    return {"value": round(1.0 / best[0], 4), "unit": "images/s", "cores": best[1], "kind": "port",
+            "sample": "oracle.cpu_ref.paint bs 1 640x640, 1 warm-up + 2 runs, %d torch threads (host: %d physical cores)"
+                      % (best[1], phys)}
 
 
-def timed_steps(step, steps, warmup, barrier):
-    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier() on both sides."""
-    for _ in range(warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    return time.perf_counter() - t0
+# ------------------------------------------------------------------------------------------------ sub-blocks
+def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with_cpu):
+    """configs[1]: ``OmniGenerator.paint`` bs 8 bf16 with the fused-SPADE MFMA roofline (the kernel north_star names)."""
+    from climategan_amd import ops
+    import climategan_amd.norms as norms_mod
+
+    G, sd = build(device, dtype)
+    x, m = synthetic_batch(rank, device)
+    timer = LaunchTimer()
+    orig = ops.spade_fused
+    layers, flops_img = spade_layer_table(LATENT, N_UP, H, W)
+    per_launch = {}
+
+    def timed(xn, *a, **k):
+        c, hw = xn.c, (xn.h * (2 if k.get("x_upsample") else 1), xn.w * (2 if k.get("x_upsample") else 1))
+        return timer.bracket(lambda: orig(xn, *a, **k), xn.n * hw[0] * hw[1] * 2.0 * (3 * 9 * 128 + 2 * 128 * 9 * c))
+
+    ops.spade_fused = norms_mod.ops.spade_fused = timed
+    out = {}
+
+    def step():
+        out["y"] = G.paint(m, x)
+
+    try:
+        with torch.no_grad():
+            for _ in range(warmup):
+                step()
+            timer.enabled = True
+            elapsed = max_over_ranks(timed_steps(step, steps, 0, barrier), dist, device)
+            timer.enabled = False
+    finally:
+        ops.spade_fused = norms_mod.ops.spade_fused = orig
+    assert out["y"].shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(out["y"]).all()
+    ms, n = timer.total_ms(), len(timer.pairs)
+    achieved = timer.total_flops() / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    assert abs(timer.total_flops() - flops_img * BATCH_PER_GPU * steps) <= 1e-6 * timer.total_flops()
+    alg_bytes = sum(BATCH_PER_GPU * a * b * 2 * (2 * ((c + 7) // 8 * 8) + 4) for c, (a, b) in layers)
+    res = {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 (OmniGenerator.paint incl. mask, "
+                       "spectral-norm power iterations, paste), %s" % str(dtype).split(".")[1],
+           "images_per_s": round(world * BATCH_PER_GPU * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup,
+           "roofline": {"bound": "mfma", "kernel": "spade_fused_kernel (23 launches/step: all SPADE layers of the Painter)",
+                        "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                        "traffic": recorded_traffic("*_spade_hbm_pmc.csv"),
+                        "algorithmic_bytes_per_launch": alg_bytes // max(len(layers), 1),
+                        "algorithmic_flops_per_step": flops_img * BATCH_PER_GPU,
+                        "launches_per_step": n // max(steps, 1), "avg_launch_ms": round(ms / max(n, 1), 4),
+                        "share_of_step": round(ms / (elapsed * 1e3), 3)}}
+    if with_cpu:
+        res["cpu_baseline"] = cpu_baseline_paint(sd)
+    return res
 
 
-def max_over_ranks(elapsed, dist, device):
-    """Whole-job time = the slowest rank's (the only collective on this path)."""
-    if dist is None:
-        return elapsed
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    return el.item()
+def masker_block(steps, warmup, rank, world, device, dtype, dist, barrier):
+    """configs[2]: Masker train step (encoder + depth / seg / mask decoders + ADVENT discriminators), bs 8."""
+    T = build_trainer(device, dtype, tasks=("d", "s", "m"))
+    batch = joint_batch(MASKER_BS, rank, device, domains=("r", "s"))
+    elapsed = max_over_ranks(timed_steps(lambda: T.train_step(batch), steps, warmup, barrier), dist, device)
+    assert all(torch.isfinite(v) for v in T.loss_log.values())
+    return {"workload": "BASELINE configs[2]: Masker train step (Trainer.train_step, tasks d,s,m; domains r,s), 640x640, "
+                        "bs 8 per domain per GPU, bf16",
+            "images_per_s": round(world * MASKER_BS * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "steps": steps, "warmup": warmup}
 
 
-def result_line(world, steps, warmup, elapsed, dtype_name):
-    return {
-        "metric": "640x640 images/sec, Painter (SPADE generator) forward, batch 8 per GPU",
-        "value": round(world * BATCH_PER_GPU * steps / elapsed, 3),
-        "unit": "images/s",
-        "n_gpus": world,
-        "steps": steps,
-        "warmup": warmup,
-        "ms_per_step": round(elapsed / steps * 1e3, 3),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": dtype_name,
-        "data": "synthetic (counter-hash fill: U(-1,1) images, 3-rectangle masks ~35%, untrained weights "
-                "with torch-default conv init ranges)",
-        "config": {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 "
-                               "(OmniGenerator.paint incl. mask, spectral-norm power iterations, paste)",
-                   "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
-                   "latent_dim": LATENT, "spade_n_up": N_UP, "parallelism": "independent replicas, image-sharded"},
-    }
-
-
-TRAIN_BS = 4   # per domain per GPU: BASELINE configs[3] is global batch 32 over 8 GPUs
-
-
-TRAIN_BLOCK_TIMEOUT_S = 420     # watchdog of the supplementary block (see main)
-
-
-def train_block(train_steps, rank, world, device, dtype, dist, barrier):
-    """Supplementary measurement (not `value`): BASELINE's "G+D step" -- the full joint Masker + Painter training
-    iteration of the default config (Trainer.train_step = update_G over the real, sim and flooded domains: ResNet-101
-    encoder with batch-statistics BatchNorm, depth / seg / mask decoders and their 10 loss terms, ADVENT
-    discriminators, Painter with GAN + feature-matching + VGG losses; then update_D; ExtraAdam extrapolate / step),
-    640x640, 4 samples per domain per GPU, bf16, data-parallel over the ranks with the bucketed RCCL all-reduce of
-    climategan_amd/parallel.py.  Same barrier / synchronize / max-over-ranks timing as the main line.  `images_per_s`
-    counts one per-domain sample slot per image; `raw_images_per_s` counts all three domains."""
-    import numpy as np
-
+def infer_block(steps, warmup, rank, world, device, dist, barrier):
+    """configs[4]: the apply_events inference loop (Trainer.infer_all: Masker + flood painter + wildfire + smog, uint8
+    results copied to the host), 640x640, 16 images per GPU, fp16."""
     from climategan_amd import fill
     from climategan_amd.config import default_opts
     from climategan_amd.trainer import Trainer
 
-    opts = default_opts()
-    opts.tasks = ["d", "s", "m", "p"]
-    opts.gen.p.latent_dim = LATENT
-    opts.gen.p.spade_n_up = N_UP
-    T = Trainer(opts, device=device).setup(inference=False)
-    for mod, seed in ((T.G, 0), (T.D, 1)):
-        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
-        mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=seed, gain=1.6).items()})
-    T.G.set_compute_dtype(dtype)
-    T.D.set_compute_dtype(dtype)
-    bs, hs = TRAIN_BS, H // 4
-
-    def dev(a):
-        return torch.from_numpy(a).to(device)
-
-    batch = {"rf": {"data": {"x": dev(fill.uniform((bs, 3, H, W), 100 + rank)),
-                             "m": dev(fill.rect_mask(bs, H, W, 200 + rank))}}}
-    for i, dom in enumerate(("r", "s")):
-        sd = 300 + 10 * i + 1000 * rank
-        batch[dom] = {"data": {"x": dev(fill.uniform((bs, 3, H, W), sd)),
-                               "d": dev(fill.uniform((bs, 1, hs, hs), sd + 1, 0.35, 6.95)),
-                               "s": dev((fill.uniform01((bs, 1, hs, hs), sd + 2) * 11).astype(np.int64).clip(0, 10)),
-                               "m": dev(fill.rect_mask(bs, H, W, sd + 3))}}
-    T.G.painter.set_latent_shape((bs, 3, H, W), True)
-    elapsed = timed_steps(lambda: T.train_step(batch), train_steps, 1, barrier)
-    elapsed = max_over_ranks(elapsed, dist, device)
-    losses = {k: round(float(v), 4) for k, v in T.loss_log.items()}
-    return {"workload": "joint Masker+Painter G+D train step (Trainer.train_step; domains r, s, rf; all default loss "
-                        "terms, VGG with random-init weights), 640x640, %d samples per domain per GPU, data-parallel "
-                        "bucketed gradient all-reduce" % bs,
-            "images_per_s": round(world * bs * train_steps / elapsed, 2),
-            "raw_images_per_s": round(world * bs * 3 * train_steps / elapsed, 2),
-            "ms_per_step": round(elapsed / train_steps * 1e3, 1), "steps": train_steps, "warmup": 1,
-            "global_batch_per_domain": world * bs, "losses_last_step": losses}
-
-
-def infer_block(steps, rank, world, device, dist, barrier):
-    """Supplementary: BASELINE metric M2 -- the apply_events inference loop (Trainer.infer_all: Masker + flood painter
-    + wildfire + smog, uint8 outputs copied to the host), 640x640, 16 images per GPU, fp16; images/s over all ranks."""
-    from climategan_amd import fill
-    from climategan_amd.config import default_opts
-    from climategan_amd.trainer import Trainer
-
-    bs = 16
     opts = default_opts()
     opts.tasks = ["d", "s", "m", "p"]
     T = Trainer(opts, device=device).setup(inference=True)
     shapes = {k: tuple(v.shape) for k, v in T.G.state_dict().items()}
-    T.G.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=0, gain=1.6).items()})
+    T.G.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state_dict(shapes, seed=0, **WELL_CONDITIONED).items()})
     T.G.set_compute_dtype(torch.float16)
-    x = torch.from_numpy(fill.uniform((bs, 3, H, W), 3000 + rank)).to(device)
+    x = torch.from_numpy(fill.uniform((INFER_BS, 3, H, W), 3000 + rank)).to(device)
     out = {}
 
     def step():
         out.update(T.infer_all(x, numpy=True, bin_value=0.5, half=True))
 
-    for _ in range(2):
-        step()
-    elapsed = max_over_ranks(timed_steps(step, steps, 0, barrier), dist, device)
-    assert set(out) >= {"flood", "wildfire", "smog"} and out["flood"].shape == (bs, H, W, 3)
-    return {"workload": "apply_events inference (Trainer.infer_all: flood + wildfire + smog, uint8 results on the host), "
-                        "640x640, 16 images per GPU, fp16",
-            "images_per_s": round(world * bs * steps / elapsed, 2), "ms_per_batch": round(elapsed / steps * 1e3, 2),
-            "steps": steps, "warmup": 2}
+    elapsed = max_over_ranks(timed_steps(step, steps, warmup, barrier), dist, device)
+    assert set(out) >= {"flood", "wildfire", "smog"} and out["flood"].shape == (INFER_BS, H, W, 3)
+    return {"workload": "BASELINE configs[4]: apply_events inference (Trainer.infer_all: flood + wildfire + smog, uint8 "
+                        "results on the host), 640x640, 16 images per GPU, fp16",
+            "images_per_s": round(world * INFER_BS * steps / elapsed, 2), "ms_per_batch": round(elapsed / steps * 1e3, 2),
+            "steps": steps, "warmup": warmup}
+
+
+SUB_BLOCK_TIMEOUT_S = 600     # watchdog of the sub-blocks (the headline line is complete before they start)
 
 
 def main():
@@ -333,10 +509,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--infer-steps", type=int, default=3,
-                    help="timed batches of the supplementary apply_events inference measurement (0 = skip)")
-    ap.add_argument("--train-steps", type=int, default=3,
-                    help="timed steps of the supplementary joint G+D training-step measurement (0 = skip)")
+    ap.add_argument("--no-launch-events", action="store_true", help="do not bracket the conv_gemm launches (no roofline)")
+    ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each sub-block (0 = skip the sub-blocks)")
+    ap.add_argument("--only", default="", help="run ONE workload as the only measurement (profiling aid): "
+                                               "painter | masker | infer")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -355,102 +531,111 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    G, sd = build(device, dtype)
-    x, m = synthetic_batch(rank, device)
-    timer = SpadeTimer()
-    timer.install()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = {}
+    if args.only:
+        if args.only == "painter":
+            r = painter_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier, False)
+        elif args.only == "masker":
+            r = masker_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier)
+        else:
+            r = infer_block(args.steps, args.warmup, rank, world, device, dist, barrier)
+        if rank == 0:
+            print(json.dumps(r), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- headline: the joint G+D training step
+    T = build_trainer(device, dtype)
+    batch = joint_batch(TRAIN_BS, rank, device)
+    T.G.painter.set_latent_shape((TRAIN_BS, 3, H, W), True)
+    timer = LaunchTimer()
+    uninstall = (lambda: None) if args.no_launch_events else install_conv_gemm_timer(timer)
 
     def step():
-        out["y"] = G.paint(m, x)
+        T.train_step(batch)
 
-    def timed_step():
-        timer.enabled = True
+    for _ in range(args.warmup):
         step()
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        elapsed = timed_steps(timed_step, args.steps, 0, barrier)
-        timer.enabled = False
-    y = out["y"]
-    assert y.shape == (BATCH_PER_GPU, 3, H, W) and torch.isfinite(y).all()
+    timer.enabled = not args.no_launch_events
+    elapsed = timed_steps(step, args.steps, 0, barrier)
+    timer.enabled = False
+    uninstall()
     elapsed = max_over_ranks(elapsed, dist, device)
+    losses = {k: float(v) for k, v in T.loss_log.items()}
+    assert all(v == v and abs(v) != float("inf") for v in losses.values()), losses
+    mem_gb = torch.cuda.max_memory_allocated() / 2 ** 30
 
-    # ---- the result line is complete before the supplementary block starts, so that nothing in that block (first
-    # RCCL use of the training path on a multi-GPU node, a hung collective, an exception on one rank) can take the
-    # headline measurement down with it: a watchdog prints the line and ends the process if the block overruns.
     res = None
     if rank == 0:
-        layers, flops_img = spade_layer_table(LATENT, N_UP, H, W)
-        spade_ms = timer.total_ms()
-        n_launch = len(timer.pairs)
-        flops_step = flops_img * BATCH_PER_GPU
-        achieved = flops_step * args.steps / (spade_ms * 1e-3) / 1e12 if spade_ms > 0 else 0.0
         res = result_line(world, args.steps, args.warmup, elapsed, args.dtype)
-        traffic = recorded_spade_traffic()
-        # minimum HBM bytes of the SPADE launches: x read + 4-channel cond read + output write (16-bit, cs8 padding)
-        alg_bytes = sum(BATCH_PER_GPU * a * b * 2 * (2 * ((c + 7) // 8 * 8) + 4) for c, (a, b) in layers)
-        res.update({
-            "roofline": {
+        ms, n = timer.total_ms(), len(timer.pairs)
+        if n:
+            achieved = timer.total_flops() / (ms * 1e-3) / 1e12
+            res["roofline"] = {
                 "bound": "mfma",
-                "kernel": "spade_fused_kernel (23 launches/step: all SPADE layers of the Painter)",
-                "achieved": round(achieved, 2),
-                "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
+                "kernel": "conv_gemm_kernel (wide-layer implicit GEMM: forward + data-gradient convolutions with >= 64 "
+                          "output channels of ResNet-101 / ASPP / decoders / VGG-19 / PatchGAN)",
+                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (mean over the 23 launches), from profiles/*_spade_hbm_pmc.csv: "
-                                "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE "
-                                "doubled per the gfx950 correction",
-                "algorithmic_bytes_per_launch": alg_bytes // max(len(layers), 1),
-                "algorithmic_flops_per_step": flops_step,
-                "launches_per_step": n_launch // max(args.steps, 1),
-                "avg_launch_ms": round(spade_ms / max(n_launch, 1), 4),
-                "share_of_step": round(spade_ms / (elapsed * 1e3), 3),
-            },
-        })
-        res["cpu_baseline"] = cpu_baseline(sd) if (world == 1 and not args.no_cpu_baseline) else None
+                "traffic": recorded_traffic("*_conv_gemm_hbm_pmc.csv"),
+                "traffic_unit": "HBM bytes per launch (mean), from the newest profiles/*_conv_gemm_hbm_pmc.csv: separate "
+                                "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction",
+                "algorithmic_flops_per_step": timer.total_flops() / args.steps,
+                "launches_per_step": n // max(args.steps, 1), "avg_launch_ms": round(ms / n, 5),
+                "share_of_step": round(ms / (elapsed * 1e3), 3)}
+        else:
+            res["roofline"] = None
+        res["losses_last_step"] = {k: round(v, 4) for k, v in losses.items()}
+        res["max_mem_GB"] = round(mem_gb, 1)
+        res["cpu_baseline"] = None
 
+    # ---- the line is complete (minus cpu_baseline / sub-blocks) before anything else runs: a watchdog prints it and
+    # ends the process if a sub-block hangs (first RCCL use of a path on a multi-GPU node, an exception on one rank ...)
     import threading
     emitted = threading.Lock()
     finished = threading.Event()
 
-    def emit(train):
+    def emit():
         if rank == 0 and emitted.acquire(blocking=False):
-            res["train_step"] = train
             print(json.dumps(res), flush=True)
 
     def watchdog():
-        if not finished.wait(TRAIN_BLOCK_TIMEOUT_S):
-            emit({"error": "supplementary train block did not finish within %d s" % TRAIN_BLOCK_TIMEOUT_S})
+        if not finished.wait(SUB_BLOCK_TIMEOUT_S):
+            if rank == 0:
+                res.setdefault("sub_blocks", {})["error"] = "sub-blocks did not finish within %d s" % SUB_BLOCK_TIMEOUT_S
+            emit()
             os._exit(0)
 
-    train = infer = None
-    if args.train_steps > 0 or args.infer_steps > 0:
-        threading.Thread(target=watchdog, daemon=True).start()
-    if args.infer_steps > 0:
-        try:
-            infer = infer_block(args.infer_steps, rank, world, device, dist, barrier)
-        except Exception as e:
-            infer = {"error": "%s: %s" % (type(e).__name__, e)}
-        torch.cuda.empty_cache()
+    threading.Thread(target=watchdog, daemon=True).start()
+    del T, batch
+    torch.cuda.empty_cache()
+    sub = {}
+    if args.sub_steps > 0:
+        blocks = (("painter_forward", lambda: painter_block(args.sub_steps, 5, rank, world, device, dtype, dist, barrier,
+                                                           world == 1 and not args.no_cpu_baseline)),
+                  ("masker_train", lambda: masker_block(args.sub_steps, 3, rank, world, device, dtype, dist, barrier)),
+                  ("apply_events", lambda: infer_block(args.sub_steps, 2, rank, world, device, dist, barrier)))
+        for name, fn in blocks:
+            try:
+                sub[name] = fn()
+            except Exception as e:          # the headline must survive a failing sub-block
+                sub[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     if rank == 0:
-        res["apply_events"] = infer
-    if args.train_steps > 0:
-        try:
-            train = train_block(args.train_steps, rank, world, device, dtype, dist, barrier)
-        except Exception as e:  # the main line must survive a failure of the supplementary block
-            train = {"error": "%s: %s" % (type(e).__name__, e)}
-    emit(train)
+        res["sub_blocks"] = sub
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline_train()
+            except Exception as e:
+                res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

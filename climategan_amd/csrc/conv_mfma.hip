@@ -532,10 +532,17 @@ extern "C" int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device,
 }
 
 // kernel selection shared by the forward and the stride-1 data-gradient entry points
-static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, const char* what) {
+static int select_conv_kernel(const ConvParams& p, const CganConvDesc* d) {
   // narrow 3x3 / stride-1 layers (< 256 channels in) are faster in the spatially tiled 3x3 kernel (halo reuse in LDS)
   const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256;
-  if (g_conv_force == 0 && p.in_zs == 1 && !prefer_3x3 && conv_gemm_applicable(d)) {
+  if (g_conv_force == 0 && p.in_zs == 1 && !prefer_3x3 && conv_gemm_applicable(d)) return CGAN_CONV_KERNEL_GEMM;
+  if (g_conv_force != 1 && p.in_zs == 1 && conv3x3_lds_applicable(d)) return CGAN_CONV_KERNEL_LDS3X3;
+  return CGAN_CONV_KERNEL_GENERAL;
+}
+
+static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, const char* what) {
+  const int kind = select_conv_kernel(p, d);
+  if (kind == CGAN_CONV_KERNEL_GEMM) {
     ConvGemmArgs a;
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
     a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
@@ -548,7 +555,7 @@ static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, co
     CGAN_CHECK_LAUNCH(what);
     return CGAN_OK;
   }
-  if (g_conv_force != 1 && p.in_zs == 1 && conv3x3_lds_applicable(d)) {
+  if (kind == CGAN_CONV_KERNEL_LDS3X3) {
     Conv3x3LdsArgs a;
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
     a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
@@ -677,6 +684,22 @@ extern "C" int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* s
                        (uint16_t*)packed, (float*)nullptr, t.c_out, t.c_in, p.cin_p, t.kh, t.kw, p.ctiles, p.ksteps, 1);
   CGAN_CHECK_LAUNCH("conv2d_pack_weight_dgrad");
   return CGAN_OK;
+}
+
+extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) {
+  ConvParams p;
+  if (!bwd_data) {
+    int rc = fill_params(p, d);
+    return rc != CGAN_OK ? rc : select_conv_kernel(p, d);
+  }
+  CganConvDesc t;
+  int rc = dgrad_params(p, d, &t);
+  if (rc != CGAN_OK) return rc;
+  const bool plain = d->stride == 1 && p.pad >= 0 && t.h_in + 2 * p.pad - t.dilation * (t.kh - 1) == t.h_out &&
+                     t.w_in + 2 * p.pad - t.dilation * (t.kw - 1) == t.w_out;
+  if (!plain) return CGAN_CONV_KERNEL_GENERAL;
+  t.pad = p.pad;
+  return select_conv_kernel(p, &t);
 }
 
 extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,

@@ -97,6 +97,12 @@ typedef struct {
 int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t count, int32_t dtype,
                                     int32_t max_fragments, void* stream);
 
+/* Which kernel the forward (bwd_data = 0) or the data-gradient (bwd_data = 1) entry point runs for a descriptor --
+ * the selection is a pure function of the descriptor: CGAN_CONV_KERNEL_GENERAL (gather implicit GEMM, conv_mfma.hip),
+ * _LDS3X3 (spatially tiled 3x3, conv3x3_lds.hip) or _GEMM (wide-layer implicit GEMM, conv_gemm.hip); negative = the
+ * descriptor is invalid.  Measurement aid: bench.py brackets the launches of one kernel family with events. */
+enum { CGAN_CONV_KERNEL_GENERAL = 0, CGAN_CONV_KERNEL_LDS3X3 = 1, CGAN_CONV_KERNEL_GEMM = 2 };
+int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data);
 /* Backward of the convolution above (autograd of nn.Conv2d, reached from g_loss.backward() / d_loss.backward(),
  * climategan/trainer.py:1011,1028).  All take the FORWARD descriptor; act / bias / residual fields are ignored (their
  * backward is elementwise and lives in the callers).  bwd_data takes zero padding only: for a reflect-padded conv call it
