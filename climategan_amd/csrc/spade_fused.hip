@@ -108,8 +108,17 @@ __device__ __forceinline__ int actv_addr(int q, int slot) { return q * (QC * 2) 
     asm volatile("" ::: "memory");                                      \
   } while (0)
 
-template <typename T, int NCT, bool C4>
-__global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams p) {
+// NW = 4: one wave per SIMD and workgroup, each owning 4 pixel rows x all NCT channel tiles (two workgroups per CU ->
+//         2 waves per SIMD, ~250 VGPRs each).
+// NW = 8: TWO waves per SIMD and workgroup -- waves w and w + 4 share the pixel rows 4 (w & 3) .. +3 and split the channel
+//         tiles (first ceil(NCT / 2) | the rest), so each holds half the accumulators and stays below 128 VGPRs: with two
+//         co-resident workgroups a SIMD has 4 waves to pick from while one sits in a barrier, an LDS round trip or its
+//         share of the hidden-map production (21 tiles over 8 waves: one per stage).  The B (hidden-map) fragments are
+//         read by both waves of a pair; the A (weight) fragments are not duplicated.
+template <typename T, int NCT, bool C4, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(SpadeParams p) {   // 2nd arg: waves per SIMD
+  constexpr int WAVES = NW;               // shadows the namespace constant inside this kernel
+  constexpr int NA = NW == 8 ? (NCT + 1) / 2 : NCT;      // channel tiles of the first wave of a pair
   constexpr int STAGE_BYTES = 3 * NCT * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* actv = smem;                                              // 2 * ACTV_Q_BYTES
@@ -121,6 +130,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wrow = wave & 3;              // pixel-row group of this wave (rows 4 wrow .. 4 wrow + 3 of the tile)
   const int j = lane & 15;
   const int g = lane >> 4;
 
@@ -335,190 +345,208 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_fused_kernel(SpadeParams 
   const int chan_in_tile = (g & 1) * 4 + (g >> 1) * 2;
   const int nchunk = min(NCT, p.nt - nt0);   // channel tiles that exist in this workgroup's chunk
 
-  f32x4 acc[NCT][PT];
-#pragma unroll
-  for (int c = 0; c < NCT; ++c)
-#pragma unroll
-    for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Everything from here to the output stores is written once for "a wave that owns the channel tiles C0 .. C0 + CN - 1
+  // of the workgroup's NCT" and instantiated for the whole set (NW = 4) or for the two halves of a wave pair (NW = 8).
+  auto run = [&](auto c0_tag, auto cn_tag) {
+    constexpr int C0 = decltype(c0_tag)::value;
+    constexpr int CN = decltype(cn_tag)::value;
+    constexpr int TPS = NW == 8 ? 1 : 2;       // hidden tiles per wave and stage (21 tiles / quarter over 3 stages x NW)
 
-  // ---------------- K loop: 12 stages = (quarter q, dx), three dy taps (60 MFMAs per wave at NCT = 5) each.
-  // Stage s: barrier (weights of stage s landed, hidden map of quarter q visible) -> start the DMA of stage s+1 ->
-  // B fragments of this dx -> three MFMA blocks.  A wave issues about one instruction per 4 cycles and a 16x16x32
-  // MFMA occupies the matrix pipe for 16, so the stage body is ONE basic block in which the A-fragment reads of the
-  // next block and the wave's share of the NEXT quarter's hidden map (two tiles: gather / multiply / store) are
-  // interleaved with the MFMAs at instruction granularity (sched_group_barrier pattern below).
-  auto stage_body = [&](auto hid_tag, int q, int dx, int s) {
-    constexpr bool HID = decltype(hid_tag)::value;
-    const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;   // this quarter's hidden map
-    unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;   // next quarter's, written during this one
-    const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
-    // hidden tiles of this stage (clamped: a duplicate tile stores identical values)
-    const int htA = min(wave + (dx * 2) * WAVES, NHT - 1), htB = min(wave + (dx * 2 + 1) * WAVES, NHT - 1);
-    u32x4 bfr[PT + 2], a[NCT];
+    f32x4 acc[CN][PT];
 #pragma unroll
-    for (int r = 0; r < PT + 2; ++r) {
-      const int qq = (wave * PT + r) * HPW + (j + dx);
-      bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
-    }
+    for (int c = 0; c < CN; ++c)
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + c * 1024);
-    if (HID) hid_gather(htA);
-    // three MFMA blocks (dy).  The A fragment of the next block is fetched into the same registers right after the
-    // last MFMA that reads them has been issued: one register set, LDS latency covered by the other channel tiles.
+      for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---------------- K loop: 12 stages = (quarter q, dx), three dy taps each.
+    // Stage s: barrier (weights of stage s landed, hidden map of quarter q visible) -> start the DMA of stage s+1 ->
+    // B fragments of this dx -> three MFMA blocks.  A wave issues about one instruction per 4 cycles and a 16x16x32
+    // MFMA occupies the matrix pipe for 16, so the stage body is ONE basic block in which the A-fragment reads of the
+    // next block and the wave's share of the NEXT quarter's hidden map (gather / multiply / store) are interleaved with
+    // the MFMAs at instruction granularity (sched_group_barrier pattern below).
+    auto stage_body = [&](auto hid_tag, int q, int dx, int s) {
+      constexpr bool HIDP = decltype(hid_tag)::value;
+      const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;   // this quarter's hidden map
+      unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;   // next quarter's, written during this one
+      const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16 + C0 * 1024;
+      // hidden tiles of this stage (clamped: a duplicate tile stores identical values)
+      const int htA = min(wave + (dx * TPS) * WAVES, NHT - 1), htB = min(wave + (dx * TPS + 1) * WAVES, NHT - 1);
+      u32x4 bfr[PT + 2], a[CN];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-        for (int t = 0; t < PT; ++t) acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
-        if (dy < 2) a[c] = *reinterpret_cast<const u32x4*>(wb + ((dy + 1) * NCT + c) * 1024);
+      for (int r = 0; r < PT + 2; ++r) {
+        const int qq = (wrow * PT + r) * HPW + (j + dx);
+        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
       }
-      if (HID) {
-        if (dy == 0) {
-          hid_mma();
-        } else if (dy == 1) {
-          hid_finish(htA, nbuf);
-          hid_gather(htB);
+#pragma unroll
+      for (int c = 0; c < CN; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + c * 1024);
+      if (HIDP) hid_gather(htA);
+      // three MFMA blocks (dy).  The A fragment of the next block is fetched into the same registers right after the
+      // last MFMA that reads them has been issued: one register set, LDS latency covered by the other channel tiles.
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+#pragma unroll
+          for (int t = 0; t < PT; ++t) acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+          if (dy < 2) a[c] = *reinterpret_cast<const u32x4*>(wb + ((dy + 1) * NCT + c) * 1024);
+        }
+        if (HIDP) {
+          if (dy == 0) {
+            hid_mma();
+          } else if (dy == 1) {
+            hid_finish(htA, nbuf);
+            if (TPS == 2) hid_gather(htB);
+          } else if (TPS == 2) {
+            hid_mma();
+            hid_finish(htB, nbuf);
+          }
+        }
+      }
+      // issue order: one MFMA, then up to three other instructions (VALU / LDS / SALU), repeated
+#pragma unroll
+      for (int i = 0; i < 3 * CN * PT + 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+        __builtin_amdgcn_sched_group_barrier(0x180, 1, 0);   // DS read/write
+      }
+    };
+
+    // plain stage (4-wave kernel with NCT >= 4): MFMA blocks with the hidden pieces between them, no forced interleave
+    auto stage_plain = [&](int q, int dx, int s) {
+      const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;
+      unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
+      const bool hid = C4 && q < 3 && !(p.dbg & 1);
+      u32x4 bfr[PT + 2];
+#pragma unroll
+      for (int r = 0; r < PT + 2; ++r) {
+        const int qq = (wrow * PT + r) * HPW + (j + dx);
+        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
+      }
+      const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;   // wave-uniform
+      const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16 + C0 * 1024;
+      if (hid && htA < NHT) hid_gather(htA);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        u32x4 a[CN];
+#pragma unroll
+        for (int c = 0; c < CN; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c) * 1024);
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+            acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+        if (hid) {
+          if (dy == 0) {
+            if (htA < NHT) hid_mma();
+          } else if (dy == 1) {
+            if (htA < NHT) hid_finish(htA, nbuf);
+            if (htB < NHT) hid_gather(htB);
+          } else if (htB < NHT) {
+            hid_mma();
+            hid_finish(htB, nbuf);
+          }
+        }
+      }
+    };
+
+    for (int q = 0; q < 4; ++q) {
+      if (C4 && q < 3) load_wsh(q + 1);
+      for (int dx = 0; dx < 3; ++dx) {
+        const int s = q * 3 + dx;
+        COUNTED_BARRIER(0);
+        if (s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
+        if (q == 3 && dx == 0) {
+          // the last quarter has no successor: its spare hidden-map buffer (actv[0]) receives the x tile now, as
+          // whole 16-byte channel chunks, lane-linear over [256 pixels][NCT chunks] (id = k*NW*64 + tid -> pixel
+          // id / NCT, chunk id % NCT), so the epilogue finds x in LDS
+#pragma unroll
+          for (int k = 0; k < (NCT * 256 + WAVES * 64 - 1) / (WAVES * 64); ++k) {
+            const int id = k * (WAVES * 64) + threadIdx.x;
+            if ((k + 1) * (WAVES * 64) <= NCT * 256 || id < NCT * 256) {
+              const int pix = id / NCT, cc = id - pix * NCT;
+              const int yy = min(ty0 + (pix >> 4), p.h - 1), xx = min(tx0 + (pix & 15), p.w - 1);
+              const int sy = p.x_ups ? (yy >> 1) : yy, sx = p.x_ups ? (xx >> 1) : xx;
+              const int nt = min(nt0 + cc, p.nt - 1);
+              const uint16_t* src = p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cs + nt * 8;
+              __builtin_amdgcn_global_load_lds(
+                  (const __attribute__((address_space(1))) void*)src,
+                  (__attribute__((address_space(3))) void*)(actv + (k * (WAVES * 64) + wave * 64) * 16), 16, 0, 0);
+            }
+          }
+        }
+        constexpr bool ILV = NW == 8 || NCT <= 3;   // the 4-wave NCT >= 4 body has no VGPRs left for the interleave
+        if (ILV) {
+          if (C4 && q < 3 && !(p.dbg & 1)) stage_body(std::true_type{}, q, dx, s);
+          else stage_body(std::false_type{}, q, dx, s);
         } else {
-          hid_mma();
-          hid_finish(htB, nbuf);
+          stage_plain(q, dx, s);
+        }
+        if (!C4 && q < 3) {   // generic conditioning: not interleaved
+          unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
+          for (int ht = wave + dx * TPS * WAVES; ht < min(NHT, (dx + 1) * TPS * WAVES); ht += WAVES)
+            hidden_tile_generic(ht, q + 1, nbuf);
         }
       }
     }
-    // issue order: one MFMA, then up to three other instructions (VALU / LDS / SALU), repeated
+    TS(5);
+
+    // ---------------- epilogue.  The hidden-map region of LDS is free now: use it to turn the lane-linear x chunks
+    // into per-lane values and the per-lane results back into lane-linear chunks.
+    // x already sits in LDS (actv[0], DMA'd during the last quarter; the stage barriers since then made it visible);
+    // every lane reads and rewrites only its own 4-byte slots, so no barrier is needed before the arithmetic
+    __builtin_amdgcn_s_setprio(2);
+    unsigned char* xt = actv;   // [256 px][NCT * 16 B]
 #pragma unroll
-    for (int i = 0; i < 3 * NCT * PT + 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-      __builtin_amdgcn_sched_group_barrier(0x180, 1, 0);   // DS read/write
+    for (int c = 0; c < CN; ++c) {
+      const int cg = C0 + c;      // channel tile within the workgroup's chunk
+      const int ch = (nt0 + cg) * 8 + chan_in_tile;
+      const f32x4 eb = *reinterpret_cast<const f32x4*>(prm + cg * 32 + g * 4);
+      const float em0 = prm[cg * 32 + 16 + chan_in_tile], em1 = prm[cg * 32 + 17 + chan_in_tile];
+      const float er0 = prm[cg * 32 + 24 + chan_in_tile], er1 = prm[cg * 32 + 25 + chan_in_tile];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        unsigned a0 = __builtin_bit_cast(unsigned, acc[c][t][0] + eb[0]);
+        unsigned a1 = __builtin_bit_cast(unsigned, acc[c][t][1] + eb[1]);
+        unsigned a2 = __builtin_bit_cast(unsigned, acc[c][t][2] + eb[2]);
+        unsigned a3 = __builtin_bit_cast(unsigned, acc[c][t][3] + eb[3]);
+        auto s02 = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+        const float gm0 = __builtin_bit_cast(float, (unsigned)s02[0]);
+        const float bt0 = __builtin_bit_cast(float, (unsigned)s02[1]);
+        const float gm1 = __builtin_bit_cast(float, (unsigned)s13[0]);
+        const float bt1 = __builtin_bit_cast(float, (unsigned)s13[1]);
+        const int pix = (wrow * PT + t) * 16 + j;
+        uint32_t* slot = reinterpret_cast<uint32_t*>(xt + (pix * NCT + cg) * 16 + chan_in_tile * 2);
+        float x0, x1;
+        unpack2<T>(*slot, x0, x1);
+        float o0 = (x0 - em0) * er0 * gm0 + bt0;
+        float o1 = (x1 - em1) * er1 * gm1 + bt1;
+        if (p.act == CGAN_ACT_LRELU) {
+          o0 = o0 > 0.f ? o0 : o0 * p.slope;
+          o1 = o1 > 0.f ? o1 : o1 * p.slope;
+        }
+        if (ch >= p.c) o0 = 0.f;
+        if (ch + 1 >= p.c) o1 = 0.f;
+        *slot = pack2<T>(o0, o1);   // each lane reads and rewrites only its own 4 bytes
+      }
     }
   };
-
-  // plain stage (NCT >= 4): MFMA blocks with the hidden pieces between them, no forced interleave
-  auto stage_plain = [&](int q, int dx, int s) {
-    const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;
-    unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
-    const bool hid = C4 && q < 3 && !(p.dbg & 1);
-    u32x4 bfr[PT + 2];
-#pragma unroll
-    for (int r = 0; r < PT + 2; ++r) {
-      const int qq = (wave * PT + r) * HPW + (j + dx);
-      bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
-    }
-    const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;   // wave-uniform
-    const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
-    if (hid && htA < NHT) hid_gather(htA);
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      u32x4 a[NCT];
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c) * 1024);
-#pragma unroll
-      for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int t = 0; t < PT; ++t)
-          acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
-      if (hid) {
-        if (dy == 0) {
-          if (htA < NHT) hid_mma();
-        } else if (dy == 1) {
-          if (htA < NHT) hid_finish(htA, nbuf);
-          if (htB < NHT) hid_gather(htB);
-        } else if (htB < NHT) {
-          hid_mma();
-          hid_finish(htB, nbuf);
-        }
-      }
-    }
-  };
-
-  for (int q = 0; q < 4; ++q) {
-    if (C4 && q < 3) load_wsh(q + 1);
-    for (int dx = 0; dx < 3; ++dx) {
-      const int s = q * 3 + dx;
-      COUNTED_BARRIER(0);
-      if (s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
-      if (q == 3 && dx == 0) {
-        // the last quarter has no successor: its spare hidden-map buffer (actv[0]) receives the x tile now, as
-        // whole 16-byte channel chunks, lane-linear over [256 pixels][NCT chunks] (id = k*256 + tid -> pixel id / NCT,
-        // chunk id % NCT), so the epilogue finds x in LDS
-#pragma unroll
-        for (int k = 0; k < NCT; ++k) {
-          const int id = k * (WAVES * 64) + threadIdx.x;
-          const int pix = id / NCT, cc = id - pix * NCT;
-          const int yy = min(ty0 + (pix >> 4), p.h - 1), xx = min(tx0 + (pix & 15), p.w - 1);
-          const int sy = p.x_ups ? (yy >> 1) : yy, sx = p.x_ups ? (xx >> 1) : xx;
-          const int nt = min(nt0 + cc, p.nt - 1);
-          const uint16_t* src = p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cs + nt * 8;
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)src,
-              (__attribute__((address_space(3))) void*)(actv + (k * (WAVES * 64) + wave * 64) * 16), 16, 0, 0);
-        }
-      }
-      constexpr bool ILV = NCT <= 3;   // the interleaved body needs ~16 more VGPRs than NCT >= 4 leaves free
-      if (ILV) {
-        if (C4 && q < 3 && !(p.dbg & 1)) stage_body(std::true_type{}, q, dx, s);
-        else stage_body(std::false_type{}, q, dx, s);
-      } else {
-        stage_plain(q, dx, s);
-      }
-      if (!C4 && q < 3) {   // generic conditioning: not interleaved
-        const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;
-        unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
-        if (htA < NHT) hidden_tile_generic(htA, q + 1, nbuf);
-        if (htB < NHT) hidden_tile_generic(htB, q + 1, nbuf);
-      }
-    }
-  }
-  TS(5);
-
-  // ---------------- epilogue.  The hidden-map region of LDS is free now: use it to turn the lane-linear x chunks
-  // into per-lane values and the per-lane results back into lane-linear chunks.
-  // x already sits in LDS (actv[0], DMA'd during the last quarter; the stage barriers since then made it visible);
-  // every lane reads and rewrites only its own 4-byte slots, so no barrier is needed before the arithmetic
-  __builtin_amdgcn_s_setprio(2);
-  unsigned char* xt = actv;   // [256 px][NCT * 16 B]
-#pragma unroll
-  for (int c = 0; c < NCT; ++c) {
-    const int ch = (nt0 + c) * 8 + chan_in_tile;
-    const f32x4 eb = *reinterpret_cast<const f32x4*>(prm + c * 32 + g * 4);
-    const float em0 = prm[c * 32 + 16 + chan_in_tile], em1 = prm[c * 32 + 17 + chan_in_tile];
-    const float er0 = prm[c * 32 + 24 + chan_in_tile], er1 = prm[c * 32 + 25 + chan_in_tile];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      unsigned a0 = __builtin_bit_cast(unsigned, acc[c][t][0] + eb[0]);
-      unsigned a1 = __builtin_bit_cast(unsigned, acc[c][t][1] + eb[1]);
-      unsigned a2 = __builtin_bit_cast(unsigned, acc[c][t][2] + eb[2]);
-      unsigned a3 = __builtin_bit_cast(unsigned, acc[c][t][3] + eb[3]);
-      auto s02 = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
-      auto s13 = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
-      const float gm0 = __builtin_bit_cast(float, (unsigned)s02[0]);
-      const float bt0 = __builtin_bit_cast(float, (unsigned)s02[1]);
-      const float gm1 = __builtin_bit_cast(float, (unsigned)s13[0]);
-      const float bt1 = __builtin_bit_cast(float, (unsigned)s13[1]);
-      const int pix = (wave * PT + t) * 16 + j;
-      uint32_t* slot = reinterpret_cast<uint32_t*>(xt + (pix * NCT + c) * 16 + chan_in_tile * 2);
-      float x0, x1;
-      unpack2<T>(*slot, x0, x1);
-      float o0 = (x0 - em0) * er0 * gm0 + bt0;
-      float o1 = (x1 - em1) * er1 * gm1 + bt1;
-      if (p.act == CGAN_ACT_LRELU) {
-        o0 = o0 > 0.f ? o0 : o0 * p.slope;
-        o1 = o1 > 0.f ? o1 : o1 * p.slope;
-      }
-      if (ch >= p.c) o0 = 0.f;
-      if (ch + 1 >= p.c) o1 = 0.f;
-      *slot = pack2<T>(o0, o1);   // each lane reads and rewrites only its own 4 bytes
-    }
+  if (NW == 4) {
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, NCT>{});
+  } else if (wave < 4) {
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+  } else {
+    run(std::integral_constant<int, NA>{}, std::integral_constant<int, (NW == 8 ? NCT - NA : NCT)>{});
   }
   __syncthreads();
+  const unsigned char* xt = actv;   // [256 px][NCT * 16 B], now holding the results
   if (!(p.dbg & 8)) {
 #pragma unroll
-    for (int k = 0; k < NCT; ++k) {
+    for (int k = 0; k < (NCT * 256 + WAVES * 64 - 1) / (WAVES * 64); ++k) {
       const int id = k * (WAVES * 64) + threadIdx.x;
       const int pix = id / NCT, cc = id - pix * NCT;
       const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
-      if (yy < p.h && xx < p.w && cc < nchunk)
+      if (id < NCT * 256 && yy < p.h && xx < p.w && cc < nchunk)
         *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w + xx) * p.cs + (nt0 + cc) * 8) =
             *reinterpret_cast<const u32x4*>(xt + id * 16);
     }
@@ -630,7 +658,7 @@ int check(const CganSpadeDesc* d) {
   return CGAN_OK;
 }
 
-template <typename T, int NCT, bool C4>
+template <typename T, int NCT, bool C4, int NW>
 int launch(const SpadeParams& p0, hipStream_t s) {
   SpadeParams p = p0;
   p.tiles_y = ceil_div(p.h, TH);
@@ -640,7 +668,7 @@ int launch(const SpadeParams& p0, hipStream_t s) {
   size_t smem = (size_t)2 * ACTV_Q_BYTES + (size_t)NBUF * 3 * NCT * 1024 + (size_t)NCT * 32 * 4 + align16((size_t)CTH * CTW * p.cond_cs * 2) + (C4 ? 0 : (size_t)p.ksh * 32 * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_kernel<T, NCT, C4>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_kernel<T, NCT, C4, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("spade_fused_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -648,30 +676,41 @@ int launch(const SpadeParams& p0, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((spade_fused_kernel<T, NCT, C4>), dim3(tiles, chunks), dim3(WAVES * 64), smem, s, p);
+  hipLaunchKernelGGL((spade_fused_kernel<T, NCT, C4, NW>), dim3(tiles, chunks), dim3(NW * 64), smem, s, p);
   return CGAN_OK;
 }
 
 template <typename T, bool C4>
-int launch_nct(const SpadeParams& p, int nct, hipStream_t s) {
+int launch_nct(const SpadeParams& p, int nct, int nw, hipStream_t s) {
+  if (nw == 8) {     // two waves per SIMD and workgroup (channel tiles split over a wave pair): needs >= 2 tiles
+    switch (nct) {
+      case 2: return launch<T, 2, C4, 8>(p, s);
+      case 3: return launch<T, 3, C4, 8>(p, s);
+      case 4: return launch<T, 4, C4, 8>(p, s);
+      case 5: return launch<T, 5, C4, 8>(p, s);
+      default: break;
+    }
+  }
   switch (nct) {
-    case 1: return launch<T, 1, C4>(p, s);
-    case 2: return launch<T, 2, C4>(p, s);
-    case 3: return launch<T, 3, C4>(p, s);
-    case 4: return launch<T, 4, C4>(p, s);
-    default: return launch<T, 5, C4>(p, s);
+    case 1: return launch<T, 1, C4, 4>(p, s);
+    case 2: return launch<T, 2, C4, 4>(p, s);
+    case 3: return launch<T, 3, C4, 4>(p, s);
+    case 4: return launch<T, 4, C4, 4>(p, s);
+    default: return launch<T, 5, C4, 4>(p, s);
   }
 }
 
 // Development knobs (not part of the stable ABI): force the channel tiles per workgroup / ablation bits /
 // timestamp buffer.
 int g_spade_variant = 0;
+int g_spade_waves = 4;
 int g_spade_dbg = 0;
 unsigned long long* g_spade_tsbuf = nullptr;
 
 }  // namespace
 
 extern "C" void cgan_debug_set_spade_variant(int v) { g_spade_variant = v; }
+extern "C" void cgan_debug_set_spade_waves(int v) { g_spade_waves = v == 8 ? 8 : 4; }
 extern "C" void cgan_debug_set_spade_ablation(int bits) { g_spade_dbg = bits; }
 extern "C" void cgan_debug_set_spade_tsbuf(void* p) { g_spade_tsbuf = (unsigned long long*)p; }
 
@@ -737,8 +776,9 @@ extern "C" int cgan_spade_fused_fwd(const void* x, const float* mean, const floa
   }
   if (g_spade_variant >= 1 && g_spade_variant <= MAX_NCT) nct = g_spade_variant;
   const bool c4 = is_c4(d->cond_c);
-  if (d->dtype == CGAN_F16) rc = c4 ? launch_nct<F16, true>(p, nct, s) : launch_nct<F16, false>(p, nct, s);
-  else rc = c4 ? launch_nct<BF16, true>(p, nct, s) : launch_nct<BF16, false>(p, nct, s);
+  const int nw = g_spade_waves;
+  if (d->dtype == CGAN_F16) rc = c4 ? launch_nct<F16, true>(p, nct, nw, s) : launch_nct<F16, false>(p, nct, nw, s);
+  else rc = c4 ? launch_nct<BF16, true>(p, nct, nw, s) : launch_nct<BF16, false>(p, nct, nw, s);
   if (rc != CGAN_OK) return rc;
   CGAN_CHECK_LAUNCH("spade_fused_fwd");
   return CGAN_OK;

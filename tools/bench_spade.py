@@ -12,7 +12,7 @@ from climategan_amd import _lib, fill, ops  # noqa: E402
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float16
 B = 8
 shapes = [(40, 640), (20, 640), (80, 320), (160, 160), (640, 20), (640, 5)]
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]   # 0 = default tiles; 1-5 force NCT; +10 = 8-wave kernel
 lib = _lib.load()
 cond = ops.nchw_to_nhwc(torch.from_numpy(fill.uniform((B, 3, 640, 640), 1)).cuda(), dt, cs=4)
 for C, R in shapes:
@@ -25,7 +25,13 @@ for C, R in shapes:
     flops = B * R * R * 2 * (27 * 128 + 2 * 1152 * C)
     line = "C=%3d R=%3d  %6.1f GFLOP |" % (C, R, flops / 1e9)
     for v in variants:
-        lib.cgan_debug_set_spade_variant(ctypes.c_int(v))
+        lib.cgan_debug_set_spade_variant(ctypes.c_int(v % 10))
+        lib.cgan_debug_set_spade_waves(ctypes.c_int(8 if v >= 10 else 4))
+        ref = ops.spade_fused(x, mean, rstd, cond, pk, act=ops.ACT_LRELU).t.float()
+        if v == variants[0]:
+            ref0 = ref
+        else:
+            line += " (maxdiff %.2g)" % (ref - ref0).abs().max().item()
         for _ in range(2):
             ops.spade_fused(x, mean, rstd, cond, pk, act=ops.ACT_LRELU)
         torch.cuda.synchronize()
@@ -38,4 +44,5 @@ for C, R in shapes:
         us = e0.elapsed_time(e1) / n * 1e3
         line += "  v%d %8.1f us %6.0f TF |" % (v, us, flops / us / 1e6)
     lib.cgan_debug_set_spade_variant(ctypes.c_int(0))
+    lib.cgan_debug_set_spade_waves(ctypes.c_int(4))
     print(line)
