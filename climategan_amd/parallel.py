@@ -8,6 +8,12 @@ reducer works on the parameter list:
 
 * parameters are grouped into ~25 MB buckets in REVERSE registration order (the order gradients become ready: the
   Painter's last layers / D's output conv first);
+* the wire format is **bf16** by default on RCCL (``grad_dtype``): the fp32 ``p.grad`` tensors are converted into the
+  bucket's flat buffer by the same multi-tensor copy that gathers them, summed over the ranks in bf16, and converted
+  back (x 1/world) into the fp32 gradients the fp32-master ExtraAdam consumes -- 210.8 MB instead of 421.7 MB per G
+  exchange.  The activation gradients these sums are built from are 16-bit already (8 significant bits per
+  element, ~8 % direction noise in the encoder, tests/test_gpu_configs_640.py); one more bf16 rounding of an 8-term sum
+  is below that.  ``grad_dtype=torch.float32`` keeps the exact fp32 exchange (the default on gloo / for tests);
 * a bucket's all-reduce is issued (``async_op=True``, on RCCL's own stream) as soon as its last gradient has been
   accumulated; xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound: few
   large messages, not one per tensor (105 M G parameters = 17 buckets);
@@ -54,10 +60,14 @@ class _Bucket:
 class GradBucketReducer:
     """Bucketed, overlapped gradient averaging over the default process group."""
 
-    def __init__(self, params, bucket_mb: float = 25.0):
+    def __init__(self, params, bucket_mb: float = 25.0, grad_dtype=None):
         self.params = [p for p in params if p.requires_grad]
         self.active = is_distributed()
         self.world = dist.get_world_size() if self.active else 1
+        if grad_dtype is None:      # bf16 on the wire over RCCL; exact fp32 elsewhere (gloo: CPU tests)
+            on_rccl = self.active and dist.get_backend() == "nccl"
+            grad_dtype = torch.bfloat16 if (on_rccl and os.environ.get("CGAN_DDP_FP32_GRADS") != "1") else torch.float32
+        self.grad_dtype = grad_dtype
         cap = int(bucket_mb * 2 ** 20)
         self.buckets: List[_Bucket] = []
         cur, cur_bytes = [], 0
@@ -85,8 +95,8 @@ class GradBucketReducer:
 
     def _views(self, b: _Bucket, grads):
         """The bucket's flat buffer and its per-parameter views (shaped like the gradients), allocated once."""
-        if b.flat is None or b.flat.device != grads[0].device or b.flat.dtype != grads[0].dtype:
-            b.flat = torch.empty(b.numel, dtype=grads[0].dtype, device=grads[0].device)
+        if b.flat is None or b.flat.device != grads[0].device or b.flat.dtype != self.grad_dtype:
+            b.flat = torch.empty(b.numel, dtype=self.grad_dtype, device=grads[0].device)
             b.views, off = [], 0
             for g in grads:
                 b.views.append(b.flat[off:off + g.numel()].view(g.shape))
@@ -137,9 +147,10 @@ class GradBucketReducer:
                                        "replicas would diverge" % len(missing))
                 self._launch(b)
             b.work.wait()
+            grads = [p.grad for p in b.params]
+            torch._foreach_copy_(grads, b.views)                      # back to the gradients' own dtype (fp32)
             if self.world > 1:
-                b.flat.mul_(1.0 / self.world)
-            torch._foreach_copy_([p.grad for p in b.params], b.views)
+                torch._foreach_mul_(grads, 1.0 / self.world)          # the average, applied in fp32
         if self._learning and any(getattr(b, "trigger", None) is not None for b in self.buckets):
             self._keep_trigger_hooks_only()
         self.reset()

@@ -133,3 +133,105 @@ def test_grad_bucket_reducer_averages_over_ranks_gloo():
         for o in (outs0[step], outs1[step]):
             for got, e in zip(o, exp):
                 assert np.allclose(got, e.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def _order_worker(rank, world, port, q, grad_dtype_name):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climategan_amd.parallel import GradBucketReducer, broadcast_parameters
+        torch.manual_seed(7)
+        layers = torch.nn.ModuleList([torch.nn.Linear(6, 6) for _ in range(4)])
+        broadcast_parameters(layers)
+        gd = getattr(torch, grad_dtype_name)
+        red = GradBucketReducer(layers.parameters(), bucket_mb=1.0, grad_dtype=gd)      # ONE bucket holds all 8 tensors
+        assert len(red.buckets) == 1
+        x = torch.full((2, 6), 0.25 * (rank + 1))
+        outs, launched_early = [], []
+        for step in range(3):
+            layers.zero_grad(set_to_none=True)
+            if step == 1:
+                # parallel branches, layer 0's node created LAST -> its gradient arrives FIRST: the learned trigger (the
+                # parameter that completed the bucket in step 0) fires while the other gradients are still None
+                loss = sum(layers[i](x).sum() for i in (3, 2, 1, 0))
+            else:
+                h = x
+                for l in layers:
+                    h = torch.tanh(l(h))
+                loss = h.sum()
+            loss.backward()
+            launched_early.append(red.buckets[0].work is not None)      # launched from a hook, before finish()?
+            red.finish()
+            outs.append([p.grad.clone().numpy() for p in layers.parameters()])
+        q.put((rank, launched_early, red._learning, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_order(grad_dtype_name):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, q, grad_dtype_name)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _expected_order_grads():
+    import torch
+    torch.manual_seed(7)
+    layers = torch.nn.ModuleList([torch.nn.Linear(6, 6) for _ in range(4)])
+    exp = []
+    for step in range(3):
+        acc = None
+        for rank in range(2):
+            layers.zero_grad(set_to_none=True)
+            x = torch.full((2, 6), 0.25 * (rank + 1))
+            if step == 1:
+                loss = sum(layers[i](x).sum() for i in (3, 2, 1, 0))
+            else:
+                h = x
+                for l in layers:
+                    h = torch.tanh(l(h))
+                loss = h.sum()
+            loss.backward()
+            g = [p.grad.clone() for p in layers.parameters()]
+            acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        exp.append([(a / 2).numpy() for a in acc])
+    return exp
+
+
+def test_reducer_survives_a_changed_gradient_order_gloo():
+    """The learned-trigger scheme (hooks only on the parameter that completed each bucket in the first step) when the
+    gradients of step 2 become ready in a DIFFERENT order: the trigger fires early, finds gradients missing, leaves the
+    bucket to ``finish()``; the averages are still exact, and step 3 (original order) overlaps again."""
+    import numpy as np
+    res = _run_order("float32")
+    exp = _expected_order_grads()
+    for rank, launched_early, learning, outs in res:
+        assert learning is False                                        # trigger hooks were learned in step 0
+        assert launched_early == [True, False, True], launched_early   # step 1 fell back to finish(), step 2 overlapped
+        for step in range(3):
+            for got, e in zip(outs[step], exp[step]):
+                assert np.allclose(got, e, rtol=1e-6, atol=1e-7), (rank, step)
+
+
+def test_reducer_bf16_wire_format_gloo():
+    """bf16 buckets (the RCCL default, forced here on gloo): averages within bf16 rounding of the exact ones, gradients
+    stay fp32 tensors, both ranks end up with identical values."""
+    import numpy as np
+    res = _run_order("bfloat16")
+    exp = _expected_order_grads()
+    for step in range(3):
+        for a, b, e in zip(res[0][3][step], res[1][3][step], exp[step]):
+            assert a.dtype == np.float32 and np.array_equal(a, b)
+            assert np.abs(a - e).max() <= 2.0 ** -7 * np.abs(e).max() + 1e-12

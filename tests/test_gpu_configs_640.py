@@ -331,11 +331,14 @@ def test_train_step_640_matches_reference_update(config):
         assert abs(got - ref) <= 1e-2 * abs(ref)
     rows = []
     _compare_grads(T.D, "D", gold, case["sub"], rows)
-    # Yardstick (same emulation, jstep_small, dev container): D.p cos median 0.9970, D.m 0.9982, D.s 0.9399 -- the ADVENT
-    # seg discriminator reads the ENTROPY of a softmax times the depth map, the most rounding-sensitive input of the step;
-    # all three see a generator that ExtraAdam has just moved by lr * g / (|g| + eps) ~ lr * sign(g) per element, so sign
-    # flips of near-zero 16-bit generator gradients are part of their input noise.
-    for grp, floor in (("p.", 0.97), ("m.", 0.95), ("s.", 0.85)):
+    # Yardstick (the same emulation run through update_D, jstep_640, dev container): D.p cos median 0.9907, D.s 0.9832,
+    # D.m 0.9996.  All three see a generator that ExtraAdam has just moved by lr * g / (|g| + eps) ~ lr * sign(g) per
+    # element, so sign flips of near-zero 16-bit generator gradients are part of their input noise.  Bound: (1 - cos) <=
+    # 2.5 x the yardstick's for D.p / D.s (measured D.p 1.95 x).  D.m is the exception: its input is the ENTROPY map of
+    # an untrained mask (p ~ 0.5 -> entropy = 1 - O((p - 0.5)^2)), which this path stores in bf16 -- resolution 2^-8 at
+    # 1.0, coarser than the signal -- while the emulation only rounds module outputs, not that functional op; measured
+    # cos 0.968 (norm ratio 1.004); floor 0.95.
+    for grp, floor in (("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 0.95), ("s.", 1 - 2.5 * (1 - 0.9832))):
         if not any(r[0].startswith(grp) for r in rows):
             continue
         st = _summ(rows, lambda k, grp=grp: k.startswith(grp))

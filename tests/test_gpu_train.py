@@ -476,6 +476,26 @@ def test_gradient_reducer_over_rccl_single_rank():
         assert all(b.work is None and b.pending == len(b.params) for b in T1.g_reducer.buckets)   # re-armed by finish()
         for (g0, d0), (g1, d1) in zip(ref, got):
             assert torch.allclose(g0, g1, rtol=2e-3, atol=1e-5) and torch.allclose(d0, d1, rtol=2e-3, atol=1e-5)
+        # fp16-style loss scaling under the reducer: the buckets carry the still-scaled gradients (they are
+        # launched from hooks during the backward); finish() writes the averages back and only THEN the scale is divided
+        # out -- the gradients the optimizer sees must be those of the unscaled run (bf16 wire format: 2^-7 relative)
+        from climategan_amd import autograd as ag
+        assert T1.d_reducer.grad_dtype == torch.bfloat16
+
+        def d_grads(scale):
+            ag.set_grad_scale(scale)
+            try:
+                T = build_trainer(case, torch.bfloat16)
+                T.update_D(batch)
+                return {k: p.grad.detach().clone() for k, p in T.D.named_parameters() if p.grad is not None}
+            finally:
+                ag.set_grad_scale(1.0)
+
+        g1, g256 = d_grads(1.0), d_grads(256.0)
+        assert set(g1) == set(g256) and len(g1) > 10
+        for k in g1:
+            scale = g1[k].abs().max().item()
+            assert (g1[k] - g256[k]).abs().max().item() <= 2.0 ** -6 * scale + 1e-12, k
         # the Masker trainer (17 G buckets at the default sizes, 3 discriminators) under the same group: every bucket
         # of G and D must fill from the hooks or be completed by finish() -- a parameter that got no gradient while
         # its bucket-mates did would raise
