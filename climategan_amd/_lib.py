@@ -121,6 +121,8 @@ _SIGNATURES = {
     "cgan_batchnorm_act_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_float, _P, C.c_size_t, _P]),
+    "cgan_batchnorm_act_bwd_grouped": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.c_float, _P, C.c_size_t, _P]),
     "cgan_bce_logits_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "cgan_hinge_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "cgan_l1_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),

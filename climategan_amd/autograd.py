@@ -25,6 +25,55 @@ def set_grad_scale(s: float):
     GRAD_SCALE = float(s)
 
 
+BN_GROUPS = 1
+
+
+class bn_groups:
+    """``with bn_groups(G):`` -- every training-mode BatchNorm inside treats its input batch as G equal slices that are
+    normalised independently (own batch statistics, running statistics updated once per slice, in order): bit for bit
+    what G separate forward calls on the slices compute, in one launch sequence.  The trainer uses it to push the real
+    and the simulated domain batch through the Masker TOGETHER (reference trainer.py:1200-1254 calls it per domain)."""
+
+    def __init__(self, groups: int):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global BN_GROUPS
+        self.prev, BN_GROUPS = BN_GROUPS, self.groups
+
+    def __exit__(self, *a):
+        global BN_GROUPS
+        BN_GROUPS = self.prev
+
+
+class SplitBatchFn(torch.autograd.Function):
+    """x [G*b, ...] -> G contiguous slices [b, ...] along the batch; the backward concatenates the slices' gradients
+    (zeros for a slice nobody used) in ONE pass instead of autograd's G zero-filled full-size tensors and G - 1 adds."""
+
+    @staticmethod
+    def forward(ctx, x_t, groups):
+        b = x_t.shape[0] // groups
+        ctx.shape, ctx.groups = x_t.shape, groups
+        return tuple(x_t[i * b:(i + 1) * b] for i in range(groups))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        b = ctx.shape[0] // ctx.groups
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros((b,) + tuple(ctx.shape[1:])) for g in grads]
+        return torch.cat(parts, dim=0), None
+
+
+def split_batch(x: "ops.NHWC", groups: int):
+    """NHWC map of a concatenated batch -> list of per-group NHWC maps (views in the forward)."""
+    if groups == 1:
+        return [x]
+    if x.t.requires_grad and torch.is_grad_enabled():
+        return [ops.NHWC(t, x.c) for t in SplitBatchFn.apply(x.t, groups)]
+    b = x.t.shape[0] // groups
+    return [ops.NHWC(x.t[i * b:(i + 1) * b], x.c) for i in range(groups)]
+
+
 class ConvFn(torch.autograd.Function):
     """y = act(conv(up?(x), w[/sigma]) + b + up?(res)).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under
     spectral norm, in which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped
@@ -234,8 +283,12 @@ class BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None, res_t=None):
         n, h, w, cs = x_t.shape
-        npix = n * h * w
-        flat = ops.NHWC(x_t.view(1, npix, 1, cs), c)                   # one "image" of n*h*w pixels
+        G = BN_GROUPS                                                  # see bn_groups
+        if n % G:
+            raise ValueError("BatchNormActFn: batch %d does not divide into %d groups" % (n, G))
+        npix = n * h * w // G
+        x_t = x_t.contiguous()
+        flat = ops.NHWC(x_t.view(G, npix, 1, cs), c)                   # G "images" of n/G*h*w pixels
         # batch statistics + (mean', rstd') for the apply kernel + running statistics + step counter: two launches
         mean, rstd, mean_f, rstd_f = ops.batchnorm_train_stats(flat, gamma, beta, running_mean, running_var, nbt, eps,
                                                                momentum)
@@ -243,9 +296,9 @@ class BatchNormActFn(torch.autograd.Function):
         if res_t is not None:
             if res_t.shape != x_t.shape:
                 raise ValueError("BatchNormActFn: residual %s does not match %s" % (tuple(res_t.shape), tuple(x_t.shape)))
-            res = ops.NHWC(res_t.contiguous().view(1, npix, 1, cs), c)
+            res = ops.NHWC(res_t.contiguous().view(G, npix, 1, cs), c)
         out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope, residual=res).t.view(n, h, w, cs)
-        ctx.cfg = (c, act, slope)
+        ctx.cfg = (c, act, slope, G)
         ctx.has_res = res_t is not None
         ctx.save_for_backward(x_t, out, mean, rstd, gamma)
         return out
@@ -255,9 +308,9 @@ class BatchNormActFn(torch.autograd.Function):
         from . import _lib
         lib = _lib.load()
         x_t, out, mean, rstd, gamma = ctx.saved_tensors
-        c, act, slope = ctx.cfg
+        c, act, slope, G = ctx.cfg
         n, h, w, cs = x_t.shape
-        nbytes = lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
+        nbytes = G * lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
         dx = torch.empty_like(x_t)
         want_res = ctx.has_res and ctx.needs_input_grad[11]
@@ -269,10 +322,11 @@ class BatchNormActFn(torch.autograd.Function):
         dg = db = None
         if gamma is not None:
             dg, db = torch.empty((2, c), dtype=torch.float32, device=x_t.device).unbind(0)   # written by the kernel
-        _lib.check(lib.cgan_batchnorm_act_bwd(
+        _lib.check(lib.cgan_batchnorm_act_bwd_grouped(
             ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
             ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._ptr(dres) if dres is not None and dres is not dy_t else None,
-            ops._DT[x_t.dtype], n * h * w, c, act, slope, ops._ptr(ws), nbytes, ops._stream()), "cgan_batchnorm_act_bwd")
+            ops._DT[x_t.dtype], n * h * w, c, G, act, slope, ops._ptr(ws), nbytes, ops._stream()),
+            "cgan_batchnorm_act_bwd_grouped")
         return dx, dg, db, None, None, None, None, None, None, None, None, dres
 
 

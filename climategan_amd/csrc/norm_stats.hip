@@ -114,10 +114,17 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
                                                                 int n_total, int hw, int cs, int chunks, int ppb,
                                                                 float eps, BnEpilogue bn) {
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int idx0 = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (idx >= n_total * cs) return;
-  const int n = idx / cs, c = idx - n * cs;
+  // instance norm: one wave per (n, c).  Batch norm with several GROUPS (n_total > 1: the batch is a concatenation of
+  // groups that the reference normalises in separate forward calls, e.g. the real and the simulated domain batch): one
+  // wave per channel walks the groups IN ORDER, because the running statistics are updated once per group, sequentially.
+  const bool grouped_bn = bn.mean_out != nullptr && n_total > 1;
+  if (idx0 >= (grouped_bn ? cs : n_total * cs)) return;
+  const int n_first = grouped_bn ? 0 : idx0 / cs, n_last = grouped_bn ? n_total : n_first + 1;
+  const int c = grouped_bn ? idx0 : idx0 - n_first * cs;
+  for (int n = n_first; n < n_last; ++n) {
+  const int idx = n * cs + c;
   MeanM2 acc = {0.f, 0.f, 0.f};
   // four partial rows in flight per lane (the rows of one lane are cs * 8 bytes apart: every load is its own cache
   // line, so the latency has to be overlapped); merged in the same order as a plain loop
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     mean[idx] = mu;
     rstd[idx] = rs;
     if (bn.mean_out) {
-      if (idx == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
+      if (c == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;     // once per group = per reference forward
       float m = 0.f, r = 0.f;
       if (c < bn.c) {
         r = rs * (bn.gamma ? bn.gamma[c] : 1.f);
@@ -168,9 +175,10 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
           bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * var_u;
         }
       }
-      bn.mean_out[c] = m;
-      bn.rstd_out[c] = r;
+      bn.mean_out[idx] = m;
+      bn.rstd_out[idx] = r;
     }
+  }
   }
 }
 
@@ -273,7 +281,7 @@ static int stats_impl(const void* x, float* mean, float* rstd, const CganNormSta
     hipLaunchKernelGGL(instnorm_partial_kernel<BF16>, grid, dim3(STATS_THREADS), smem, s, (const uint16_t*)x,
                        (float*)workspace, d->hw, cs, chunks, ppb);
   CGAN_CHECK_LAUNCH("instnorm_stats(partial)");
-  int total = d->n * cs;
+  int total = (bn.mean_out != nullptr && d->n > 1) ? cs : d->n * cs;      // grouped batch norm: one wave per channel
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, (const float*)workspace,
                      mean, rstd, d->n, d->hw, cs, chunks, ppb, d->eps, bn);
   CGAN_CHECK_LAUNCH("instnorm_stats(finalize)");
@@ -291,7 +299,10 @@ extern "C" int cgan_batchnorm_train_stats(const void* x, const float* gamma, con
                                           float* batch_mean, float* batch_rstd, float* mean_out, float* rstd_out,
                                           const CganNormStatsDesc* d, void* workspace, size_t workspace_bytes,
                                           void* stream) {
-  CGAN_REQUIRE(d != nullptr && d->n == 1, "batchnorm_train_stats: describe the batch as ONE image of n*h*w pixels");
+  // d->n = number of GROUPS normalised independently (1: the whole batch, as nn.BatchNorm2d; G > 1: G equal slices of
+  // the batch, each what the reference would have passed through the layer in its own forward call), d->hw = pixels per
+  // group (n/G * h * w).  Outputs are [G][cs]; running statistics are updated group after group.
+  CGAN_REQUIRE(d != nullptr && d->n >= 1 && d->n <= 16, "batchnorm_train_stats: 1..16 groups of n/G*h*w pixels each");
   CGAN_REQUIRE(mean_out && rstd_out, "batchnorm_train_stats: null pointer");
   CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_stats: running stats go together");
   BnEpilogue bn = {gamma, beta, running_mean, running_var, mean_out, rstd_out, (long long*)num_batches_tracked, momentum,

@@ -250,6 +250,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
   const int cgb = cg_total < 256 ? cg_total : 256;
   const int PL = 256 / cgb;
   const int cg0 = blockIdx.y * cgb;
+  // blockIdx.z = group (npix = pixels PER GROUP): its slice of the tensors, its statistics row, its partial rows
+  const size_t gofs = (size_t)blockIdx.z * npix * cs;
+  x += gofs; out += gofs; dy += gofs;
+  mean += (size_t)blockIdx.z * cs; rstd += (size_t)blockIdx.z * cs;
+  partial += (size_t)blockIdx.z * gridDim.x * cs * 2;
   const long p0 = (long)blockIdx.x * ppb, p1 = min(npix, p0 + ppb);
   const int t = threadIdx.x, cgl = t % cgb, pl = t / cgb;
   const int cg = cg0 + cgl;
@@ -318,10 +323,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, float inv_count,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int c, int cs) {
+                                                              float* __restrict__ dbeta, int c, int cs, int groups) {
   __shared__ float red[16][16][2];
   const int chl = threadIdx.x & 15, kl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + chl;
+  float dg_sum = 0.f, db_sum = 0.f;       // dgamma / dbeta: summed over the groups (one parameter, several forward calls)
+  for (int grp = 0; grp < groups; ++grp) {
   float a = 0.f, b = 0.f;
   if (ch < cs)
     for (int k0 = kl; k0 < chunks; k0 += 64) {             // four rows in flight, summed in loop order
@@ -340,26 +347,34 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   red[kl][chl][0] = a;
   red[kl][chl][1] = b;
   __syncthreads();
-  if (kl != 0 || ch >= cs) return;
-  float s1 = 0.f, s2 = 0.f;
+  if (kl == 0 && ch < cs) {
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int l = 0; l < 16; ++l) {
-    s1 += red[l][chl][0];
-    s2 += red[l][chl][1];
+    for (int l = 0; l < 16; ++l) {
+      s1 += red[l][chl][0];
+      s2 += red[l][chl][1];
+    }
+    float A = 0.f, B = 0.f, C = 0.f;
+    if (ch < c) {
+      dg_sum += s2;
+      db_sum += s1;
+      const float rs = rstd[ch], mu = mean[ch];
+      A = rs * (gamma ? gamma[ch] : 1.f);
+      const float m1 = s1 * inv_count, m2 = s2 * inv_count;
+      B = -A * rs * m2;
+      C = A * (mu * rs * m2 - m1);
+    }
+    coef[ch] = A;
+    coef[cs + ch] = B;
+    coef[2 * cs + ch] = C;
   }
-  float A = 0.f, B = 0.f, C = 0.f;
-  if (ch < c) {
-    if (dgamma) dgamma[ch] = s2;
-    if (dbeta) dbeta[ch] = s1;
-    const float rs = rstd[ch], mu = mean[ch];
-    A = rs * (gamma ? gamma[ch] : 1.f);
-    const float m1 = s1 * inv_count, m2 = s2 * inv_count;
-    B = -A * rs * m2;
-    C = A * (mu * rs * m2 - m1);
+  __syncthreads();
+  partial += (size_t)chunks * cs * 2; mean += cs; rstd += cs; coef += 3 * (size_t)cs;
   }
-  coef[ch] = A;
-  coef[cs + ch] = B;
-  coef[2 * cs + ch] = C;
+  if (kl == 0 && ch < c) {
+    if (dgamma) dgamma[ch] = dg_sum;
+    if (dbeta) dbeta[ch] = db_sum;
+  }
 }
 
 // Stage 3: dx = A dz + B x + C.  A thread keeps its 8 channels (coefficients in registers) and walks pixels: no
@@ -374,6 +389,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
   const int rows = 256 / tpp;
   const int cgl = threadIdx.x % tpp, prow = threadIdx.x / tpp;
   if (prow >= rows) return;
+  {   // blockIdx.y = group (npix = pixels per group): its slice, its coefficient rows
+    const size_t gofs = (size_t)blockIdx.y * npix * cs;
+    x += gofs; out += gofs; dy += gofs; dx += gofs;
+    if (dz_out) dz_out += gofs;
+    coef += (size_t)blockIdx.y * 3 * cs;
+  }
   for (int cg = cgl; cg < cg_total; cg += tpp) {
     float A[8], B[8], Cc[8];
 #pragma unroll
@@ -635,7 +656,7 @@ extern "C" int cgan_bn_train_prepare(const float* batch_mean, const float* batch
 }
 
 extern "C" size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c) {
-  // 3 coefficient rows + up to BN_BWD_MAX_CHUNKS rows of (sum dz, sum dz xh) partials
+  // per group: 3 coefficient rows + up to BN_BWD_MAX_CHUNKS rows of (sum dz, sum dz xh) partials
   return c > 0 ? (size_t)cgan_cs(c) * (3 + 2 * (size_t)BN_BWD_MAX_CHUNKS) * sizeof(float) : 0;
 }
 
@@ -643,16 +664,28 @@ extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void
                                       const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
                                       void* dz_out, int32_t dtype, int64_t npix, int32_t c, int32_t act,
                                       float act_slope, void* workspace, size_t workspace_bytes, void* stream) {
+  return cgan_batchnorm_act_bwd_grouped(x, out, dy, batch_mean, batch_rstd, gamma, dx, dgamma, dbeta, dz_out, dtype, npix,
+                                        c, 1, act, act_slope, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, const void* dy, const float* batch_mean,
+                                              const float* batch_rstd, const float* gamma, void* dx, float* dgamma,
+                                              float* dbeta, void* dz_out, int32_t dtype, int64_t npix_total, int32_t c,
+                                              int32_t groups, int32_t act, float act_slope, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
   CGAN_REQUIRE(x && out && dy && batch_mean && batch_rstd && dx && workspace, "batchnorm_act_bwd: null pointer");
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "batchnorm_act_bwd: bad dtype %d", dtype);
-  CGAN_REQUIRE(npix > 0 && c > 0, "batchnorm_act_bwd: bad shape");
+  CGAN_REQUIRE(groups >= 1 && groups <= 16 && npix_total > 0 && c > 0 && npix_total % groups == 0,
+               "batchnorm_act_bwd: bad shape (the pixel count must divide into the groups)");
   CGAN_REQUIRE(act == CGAN_ACT_NONE || act == CGAN_ACT_RELU || act == CGAN_ACT_LRELU,
                "batchnorm_act_bwd: Unsupported activation: %d", act);
-  CGAN_REQUIRE(workspace_bytes >= cgan_batchnorm_act_bwd_workspace_bytes(c), "batchnorm_act_bwd: workspace too small");
+  CGAN_REQUIRE(workspace_bytes >= (size_t)groups * cgan_batchnorm_act_bwd_workspace_bytes(c),
+               "batchnorm_act_bwd: workspace too small");
+  const long npix = npix_total / groups;      // per group
   const int cs = cgan_cs(c);
   hipStream_t s = (hipStream_t)stream;
-  float* coef = (float*)workspace;
-  float* partial = coef + 3 * (size_t)cs;
+  float* coef = (float*)workspace;            // [groups][3][cs]
+  float* partial = coef + (size_t)groups * 3 * cs;   // [groups][chunks][cs][2]
   const int cg_total = cs / 8;
   const int cgb = cg_total < 256 ? cg_total : 256;
   const int PL = 256 / cgb;
@@ -663,16 +696,16 @@ extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void
   if (ppb < 8 * PL) ppb = 8 * PL;
   chunks = (npix + ppb - 1) / ppb;
   const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
-  DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, cgblocks), dim3(256), smem, s,
+  DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, cgblocks, groups), dim3(256), smem, s,
              (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, partial,
              (long)npix, cs, (int)ppb, act, act_slope);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cs, 16)), dim3(256), 0, s, (const float*)partial, (int)chunks,
-                     batch_mean, batch_rstd, gamma, 1.f / (float)npix, coef, dgamma, dbeta, (int)c, cs);
+                     batch_mean, batch_rstd, gamma, 1.f / (float)npix, coef, dgamma, dbeta, (int)c, cs, (int)groups);
   const int tpp = cg_total < 256 ? cg_total : 256;
   const int rows = 256 / tpp;
   long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
-  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x,
+  blocks = blocks < 1 ? 1 : (blocks > 4096 / groups ? 4096 / groups : blocks);
+  DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, s, (const uint16_t*)x,
              (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, (uint16_t*)dx, (uint16_t*)dz_out, (long)npix,
              cs, act, act_slope);
   CGAN_CHECK_LAUNCH("batchnorm_act_bwd");

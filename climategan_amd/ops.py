@@ -327,19 +327,19 @@ def cloudy_cond(x: torch.Tensor, m: torch.Tensor, seg: NHWC, angles: torch.Tenso
 
 
 def batchnorm_train_stats(x: NHWC, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum):
-    """Training-mode nn.BatchNorm2d statistics of ``x`` viewed as ONE image of n*h*w pixels (``x.n`` must be 1):
-    returns fp32 [1, Cs] tensors (batch_mean, batch_rstd, mean', rstd') with ``bn(x) == (x - mean') * rstd'`` (gamma /
-    beta folded in; identical to the batch pair without them) and updates the running statistics (momentum, unbiased
-    variance) and the step counter in the same two launches."""
+    """Training-mode nn.BatchNorm2d statistics of ``x`` viewed as ``x.n`` GROUPS of ``x.h * x.w`` pixels each (1 group =
+    the whole batch as ONE image of n*h*w pixels; G groups = G equal slices of the batch normalised independently, as if
+    each had gone through the layer in its own forward call): returns fp32 [G, Cs] tensors (batch_mean, batch_rstd, mean',
+    rstd') with ``bn(x) == (x - mean') * rstd'`` (gamma / beta folded in; identical to the batch pair without them) and
+    updates the running statistics (momentum, unbiased variance; once per group, in order) and the step counter (+G) in
+    the same two launches."""
     _need_cuda(x.t)
-    if x.n != 1:
-        raise ValueError("batchnorm_train_stats: view the batch as one image of n*h*w pixels")
     lib = _lib.load()
     cs = x.t.shape[-1]
-    d = NormStatsDesc(x.dtype_id, 1, x.h * x.w, x.c, float(eps))
+    d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, float(eps))
     ws_bytes = lib.cgan_instnorm_stats_workspace_bytes(C.byref(d))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.t.device)
-    stats = torch.empty((4, 1, cs), dtype=torch.float32, device=x.t.device)
+    stats = torch.empty((4, x.n, cs), dtype=torch.float32, device=x.t.device)
     _lib.check(lib.cgan_batchnorm_train_stats(
         _ptr(x.t), _ptr(gamma), _ptr(beta), float(momentum), _ptr(running_mean), _ptr(running_var),
         _ptr(num_batches_tracked), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), C.byref(d), _ptr(ws),

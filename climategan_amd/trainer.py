@@ -68,6 +68,9 @@ class Trainer:
         self.D = None
         self.is_setup = False
         self.has_painter = "p" in opts.tasks
+        # the real and the simulated domain batch share the Masker's encoder / depth / segmentation launches (grouped
+        # BatchNorm keeps the per-domain statistics of the reference's separate calls); False = one pass per domain
+        self.merge_domains = True
 
     def setup(self, inference=False):
         """reference trainer.py:701-789."""
@@ -180,10 +183,11 @@ class Trainer:
         return loss
 
     # ------------------------------------------------------------------------------------------ masker losses
-    def masker_d_loss(self, x, z, target, domain, for_="G"):
+    def masker_d_loss(self, x, z, target, domain, for_="G", pre=None):
         """reference trainer.py:1389-1407.  The reference evaluates the depth loss and then discards it for real-domain
-        batches; here it is only evaluated where it is kept."""
-        prediction, z_depth = self.G.decoders["d"].forward_nhwc(z)
+        batches; here it is only evaluated where it is kept.  ``pre``: (prediction, z_depth) already computed by the
+        merged-domain trunk."""
+        prediction, z_depth = pre if pre is not None else self.G.decoders["d"].forward_nhwc(z)
         weight = self.opts.train.lambdas.G.d.main
         if weight == 0 or domain == "r":
             return torch.zeros((), device=self.device), prediction, z_depth
@@ -191,8 +195,8 @@ class Trainer:
         self.loss_log["G.d." + domain] = loss.detach()
         return loss, prediction, z_depth
 
-    def masker_s_loss(self, x, z, depth_preds, z_depth, target, domain, for_="G"):
-        """reference trainer.py:1409-1504"""
+    def masker_s_loss(self, x, z, depth_preds, z_depth, target, domain, for_="G", pre=None):
+        """reference trainer.py:1409-1504 (``pre``: the segmentation logits already computed by the merged-domain trunk)"""
         from . import losses as L
 
         assert for_ in {"G", "D"} and domain in {"r", "s"}
@@ -200,7 +204,9 @@ class Trainer:
         full_loss = 0
         softmax_preds = None
         pred = None
-        if for_ == "G" or o.gen.s.use_advent:
+        if pre is not None:
+            pred = pre
+        elif for_ == "G" or o.gen.s.use_advent:
             pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
         if for_ == "G":
             if domain == "s":
@@ -284,23 +290,64 @@ class Trainer:
                 full_loss = full_loss + loss
         return full_loss, prob
 
+    def _merged_masker_domains(self, multi_domain_batch):
+        """The masker domains of a batch that can go through the encoder and the depth / segmentation decoders as ONE
+        concatenated batch (``autograd.bn_groups``: every BatchNorm keeps per-domain batch statistics and updates its
+        running statistics domain after domain, so the arithmetic is that of the reference's per-domain calls,
+        trainer.py:1200-1254): same image shapes, at least two domains, and ``self.merge_domains``.  None otherwise."""
+        doms = [d for d in multi_domain_batch if d != "rf"]
+        if not getattr(self, "merge_domains", True) or len(doms) < 2:
+            return None
+        shapes = {tuple(multi_domain_batch[d]["data"]["x"].shape) for d in doms}
+        return doms if len(shapes) == 1 else None
+
+    def _masker_trunk(self, multi_domain_batch, doms, want_s):
+        """encode + depth decoder (+ segmentation decoder) on the concatenated domain batches; returns per-domain lists
+        (z, d_pred, z_depth, s_pred) of NHWC maps."""
+        from .autograd import bn_groups, split_batch
+
+        G = len(doms)
+        x = torch.cat([multi_domain_batch[d]["data"]["x"] for d in doms], dim=0)
+        with bn_groups(G):
+            z = self.G.encode(x)
+            d_pred = z_depth = s_pred = None
+            if "d" in self.opts.tasks:
+                d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
+            if want_s and "s" in self.opts.tasks:
+                s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
+
+        def parts(t):
+            return split_batch(t, G) if t is not None else [None] * G
+
+        zs = list(zip(parts(z[0]), parts(z[1])))
+        return zs, parts(d_pred), parts(z_depth), parts(s_pred)
+
     def get_masker_loss(self, multi_domain_batch):
         """reference trainer.py:1184-1254"""
         m_loss = 0
+        doms = self._merged_masker_domains(multi_domain_batch)
+        trunk = None
+        if doms is not None and all(t in self.opts.tasks for t in "ds") and all(
+                all(t in multi_domain_batch[d]["data"] for t in "ds") for d in doms):
+            zs, d_preds, z_depths, s_preds = self._masker_trunk(multi_domain_batch, doms, want_s=True)
+            trunk = {d: (zs[i], d_preds[i], z_depths[i], s_preds[i]) for i, d in enumerate(doms)}
         for domain, batch in multi_domain_batch.items():
             if domain == "rf":
                 continue
             x = batch["data"]["x"]
-            z = self.G.encode(x)
+            pre = trunk[domain] if trunk is not None else None
+            z = pre[0] if pre is not None else self.G.encode(x)
             d_pred = s_pred = z_depth = None
             for task in ["d", "s", "m"]:
                 if task not in batch["data"] or task not in self.opts.tasks:
                     continue
                 target = batch["data"][task]
                 if task == "d":
-                    loss, d_pred, z_depth = self.masker_d_loss(x, z, target, domain, "G")
+                    loss, d_pred, z_depth = self.masker_d_loss(x, z, target, domain, "G",
+                                                               pre=None if pre is None else (pre[1], pre[2]))
                 elif task == "s":
-                    loss, s_pred = self.masker_s_loss(x, z, d_pred, z_depth, target, domain, "G")
+                    loss, s_pred = self.masker_s_loss(x, z, d_pred, z_depth, target, domain, "G",
+                                                      pre=None if pre is None else pre[3])
                 else:
                     cond = None
                     if self.opts.gen.m.use_spade:                                          # trainer.py:1233-1238
@@ -315,18 +362,29 @@ class Trainer:
         reference builds one and detaches the predictions, trainer.py:1113,1464,1578)."""
         total = 0
         adv = self.opts.train.lambdas.advent.adv_main
+        doms = self._merged_masker_domains(multi_domain_batch)
+        need_d = "d" in self.opts.tasks and (self.opts.gen.s.use_dada or self.opts.gen.m.use_dada or
+                                             self.opts.gen.m.use_spade)
+        trunk = None
+        if doms is not None and need_d and all("s" in multi_domain_batch[d]["data"] for d in doms):
+            with torch.no_grad():
+                zs, d_preds, z_depths, s_preds = self._masker_trunk(multi_domain_batch, doms, want_s=True)
+            trunk = {d: (zs[i], d_preds[i], z_depths[i], s_preds[i]) for i, d in enumerate(doms)}
         for domain, batch in multi_domain_batch.items():
             if domain == "rf":
                 continue
             x = batch["data"]["x"]
+            pre = trunk[domain] if trunk is not None else None
             with torch.no_grad():
-                z = self.G.encode(x)
+                z = pre[0] if pre is not None else self.G.encode(x)
                 d_pred = z_depth = s_pred = None
-                if "d" in self.opts.tasks and (self.opts.gen.s.use_dada or self.opts.gen.m.use_dada):
+                if pre is not None:
+                    d_pred, z_depth = pre[1], pre[2]
+                elif "d" in self.opts.tasks and (self.opts.gen.s.use_dada or self.opts.gen.m.use_dada):
                     d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
             if "s" in batch["data"] and "s" in self.opts.tasks:
                 with torch.no_grad():
-                    s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
+                    s_pred = pre[3] if pre is not None else self.G.decoders["s"].forward_nhwc(z, z_depth)
                 if self.opts.gen.s.use_advent:                                             # trainer.py:1452
                     loss, _ = self._advent_d_term("s", s_pred, d_pred, domain)
                     total = total + loss * adv

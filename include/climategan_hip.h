@@ -314,11 +314,20 @@ int cgan_batchnorm_train_stats(const void* x, const float* gamma, const float* b
                                float* running_var, int64_t* num_batches_tracked, float* batch_mean, float* batch_rstd,
                                float* mean_out, float* rstd_out, const CganNormStatsDesc* d, void* workspace,
                                size_t workspace_bytes, void* stream);
-size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);
+size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);   /* per group */
 int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
                            const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
                            void* dz_out, int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the batch split into `groups` equal slices that are normalised independently (cgan_batchnorm_train_stats
+ * with d->n = groups): what the reference does when it passes the real and the simulated domain batch through the
+ * Masker in separate forward calls (trainer.py:1200-1254) -- here one launch sequence over the concatenated batch.
+ * batch_mean / batch_rstd: [groups][cgan_cs(c)]; dgamma / dbeta: summed over the groups; npix_total = all pixels;
+ * workspace: groups * cgan_batchnorm_act_bwd_workspace_bytes(c). */
+int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, const void* dy, const float* batch_mean,
+                                   const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                                   void* dz_out, int32_t dtype, int64_t npix_total, int32_t c, int32_t groups,
+                                   int32_t act, float act_slope, void* workspace, size_t workspace_bytes, void* stream);
 /* nn.BCEWithLogitsLoss(x, target) pieces against a constant target (GANLoss, climategan/losses.py:50-83; ADVENT
  * D-side BCE, losses.py:461-477) over the c logical channels of x [npix][cgan_cs(c)]:
  * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */
