@@ -90,7 +90,8 @@ class ConvFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
-        ctx.sn = None if sn is None else tuple(t.clone() for t in sn)      # (sigma, u, v) as used in this forward
+        # (sigma, u, v) as used in this forward: private copies (the batched step hands them over already copied)
+        ctx.sn = None if sn is None else (tuple(sn) if cfg.get("sn_owned") else tuple(t.clone() for t in sn))
         ctx.save_for_backward(x_t, weight, y.t if cfg["act"] != ops.ACT_NONE else None)
         return y.t
 

@@ -41,7 +41,8 @@ def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw
     res = kw.get("residual")
     cfg = dict(c_in=x.c, stride=stride, pad=pad, dilation=dilation, act=kw.get("act", ops.ACT_NONE),
                slope=kw.get("slope", 0.2), in_upsample=bool(kw.get("in_upsample", False)),
-               residual_upsample=bool(kw.get("residual_upsample", False)), pad_mode=pad_mode)
+               residual_upsample=bool(kw.get("residual_upsample", False)), pad_mode=pad_mode,
+               sn_owned=bool(kw.get("sn_owned", False)))
     y_t = ConvFn.apply(x.t, weight, bias, res.t if res is not None else None, packed, cfg, sn)
     return ops.NHWC(y_t, weight.shape[0])
 
@@ -101,7 +102,8 @@ class SpectralNorm(nn.Module):
     def packed(self, dtype) -> ops.PackedConv:
         """Power-iterate (updates u, v) and return w_bar / sigma packed for the MFMA conv kernel."""
         pre, self._prepacked = self._prepacked, None
-        if pre is not None and pre.dtype == dtype:
+        self._pre_used = pre is not None and pre.dtype == dtype
+        if self._pre_used:
             return pre
         m = self.module
         w_bar = getattr(m, self.name + "_bar")
@@ -112,6 +114,8 @@ class SpectralNorm(nn.Module):
         return ops.pack_conv_weight(w_bar.data, m.bias.data if m.bias is not None else None, dtype, sigma)
 
     _sigma = None       # device scalar of the latest power iteration (needed by the backward of w_bar / sigma)
+    _sn_snapshot = None  # (sigma, u, v) copies of the batched step, for ONE use by forward() (spectral_norm_step_all)
+    _pre_used = False
     trainable = False   # set by modules whose whole forward has backward kernels (the discriminators)
 
     def forward(self, x, **conv_kwargs):
@@ -121,7 +125,12 @@ class SpectralNorm(nn.Module):
         pw = self.packed(x.t.dtype)
         pad = conv_kwargs.pop("pad", m.padding[0])   # Conv2dBlock pads with a separate module (padding=0 on the conv)
         if self.trainable and needs_grad(self, x.t):
-            sn = (self._sigma, getattr(m, self.name + "_u").data, getattr(m, self.name + "_v").data)
+            snap, self._sn_snapshot = self._sn_snapshot, None         # consumed once, like the pre-packed weight
+            if self._pre_used and snap is not None:
+                sn = snap
+                conv_kwargs = dict(conv_kwargs, sn_owned=True)        # already private copies: ConvFn need not clone
+            else:
+                sn = (self._sigma, getattr(m, self.name + "_u").data, getattr(m, self.name + "_v").data)
             return _conv_train(x, getattr(m, self.name + "_bar"), m.bias, pw, sn, m.stride[0], pad, m.dilation[0],
                                conv_kwargs)
         return ops.conv2d(x, pw, stride=m.stride[0], pad=pad, dilation=m.dilation[0], **conv_kwargs)
@@ -308,6 +317,15 @@ def spectral_norm_step_all(root: nn.Module, dtype) -> None:
     if grp is None or not grp.matches(params, dtype):
         grp = ops.SpectralNormGroup(params, dtype)
         object.__setattr__(root, "_sn_group", grp)
-    for i, (m, pk) in enumerate(zip(sns, grp.step())):
+    packed = grp.step()
+    snap = None
+    if torch.is_grad_enabled():
+        # the backward of w_bar / sigma needs THIS forward's sigma, u, v (the next forward power-iterates them in
+        # place): one multi-tensor copy per kind for the whole network instead of three clones per layer
+        us = torch._foreach_mul([p[1] for p in params], 1.0)
+        vs = torch._foreach_mul([p[2] for p in params], 1.0)
+        snap = (grp.sigma.clone(), us, vs)
+    for i, (m, pk) in enumerate(zip(sns, packed)):
         m._prepacked = pk
         m._sigma = grp.sigma[i:i + 1]
+        m._sn_snapshot = None if snap is None else (snap[0][i:i + 1], snap[1][i], snap[2][i])

@@ -529,6 +529,42 @@ def sumpool2x2(x: NHWC) -> NHWC:
     return NHWC(y, x.c)
 
 
+class ZeroArena:
+    """One zero-filled fp32 buffer per optimizer update that the weight-gradient calls carve their outputs from (the
+    kernels accumulate into zero-initialised dW / db): one fill instead of one per layer (254 per joint step).  The
+    gradients handed to autograd are views of it; a fresh arena is made for every update."""
+
+    def __init__(self, numel: int, device):
+        self.buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, n: int):
+        n_al = (n + 63) // 64 * 64                        # 256-byte aligned slices
+        if self.off + n_al > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return t
+
+
+_ZERO_ARENA = None
+
+
+def set_zero_arena(arena):
+    """Install (or, with None, remove) the arena ``zeros_f32`` serves from; returns the previous one."""
+    global _ZERO_ARENA
+    prev, _ZERO_ARENA = _ZERO_ARENA, arena
+    return prev
+
+
+def zeros_f32(n: int, device) -> torch.Tensor:
+    if _ZERO_ARENA is not None and _ZERO_ARENA.buf.device == device:
+        t = _ZERO_ARENA.take(n)
+        if t is not None:
+            return t
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, want_bias=True,
                       dw: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None, in_upsample=False,
                       pad_mode=PAD_ZERO, use_workspace=True):
@@ -544,12 +580,12 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
         raise RuntimeError("conv2d_bwd_weight: shapes do not match the forward conv")
     if dw is None and want_bias and dbias is None:
         nw = c_out * c_in * kh * kw                      # one zero fill for both gradients
-        flat = torch.zeros(nw + c_out, dtype=torch.float32, device=x.t.device)
+        flat = zeros_f32(nw + c_out, x.t.device)
         dw, dbias = flat[:nw].view(c_out, c_in, kh, kw), flat[nw:]
     if dw is None:
-        dw = torch.zeros((c_out, c_in, kh, kw), dtype=torch.float32, device=x.t.device)
+        dw = zeros_f32(c_out * c_in * kh * kw, x.t.device).view(c_out, c_in, kh, kw)
     if want_bias and dbias is None:
-        dbias = torch.zeros((c_out,), dtype=torch.float32, device=x.t.device)
+        dbias = zeros_f32(c_out, x.t.device)
     lib = _lib.load()
     ws_bytes = lib.cgan_conv2d_bwd_weight_workspace_bytes(C.byref(d)) if use_workspace else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.t.device) if ws_bytes else None

@@ -438,7 +438,7 @@ class Trainer:
                 # every term switched off (all lambdas 0): the reference would fail on ``int.backward()``; nothing to
                 # differentiate and nothing for the optimizer to do
                 return torch.zeros((), device=self.device)
-            g_loss.backward()
+            self._backward(g_loss, self.G)
             if self.g_reducer is not None:
                 self.g_reducer.finish()                                 # before extrapolation AND step (trainer.py:678-683)
             self._unscale_grads(self.G)
@@ -449,6 +449,21 @@ class Trainer:
         finally:
             self._restore_d_grad_flags()                                # trainer.py:971-973
         return g_loss.detach()
+
+    def _backward(self, loss, module):
+        """``loss.backward()`` with the weight-gradient outputs of ``module`` carved from ONE zero-filled arena
+        (ops.ZeroArena) instead of a fill launch per layer."""
+        key = "_arena_numel_%d" % id(module)
+        n = getattr(self, key, None)
+        if n is None:
+            n = sum((p.numel() + 63) // 64 * 64 + 64 for p in module.parameters() if p.requires_grad)
+            setattr(self, key, n)
+        dev = next(module.parameters()).device
+        prev = ops.set_zero_arena(ops.ZeroArena(n, dev))
+        try:
+            loss.backward()
+        finally:
+            ops.set_zero_arena(prev)
 
     @staticmethod
     def _unscale_grads(module):
@@ -478,7 +493,7 @@ class Trainer:
             d_loss = d_loss + self.get_masker_d_loss(multi_domain_batch)
         if not isinstance(d_loss, torch.Tensor):     # no discriminator term is active (use_advent off, no Painter)
             return torch.zeros((), device=self.device)
-        d_loss.backward()
+        self._backward(d_loss, self.D)
         if self.d_reducer is not None:
             self.d_reducer.finish()
         self._unscale_grads(self.D)
