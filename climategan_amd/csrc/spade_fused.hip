@@ -91,7 +91,14 @@ __host__ inline PackedLayout packed_layout(int cs, int cond_c) {
 
 // hidden map in LDS: [buffer][halo pixel q][4 slots of 16 B = 32 channels]; the slot is XOR-swizzled with bits
 // 2..3 of q (four pixels share a 256-B bank row)
-__device__ __forceinline__ int actv_addr(int q, int slot) { return q * (QC * 2) + ((slot ^ ((q >> 2) & 3)) << 4); }
+// SWZ = false (the wave-specialised kernel): plain [pixel][slot] order.  A B-fragment address is then one per-lane
+// constant plus compile-time / wave-uniform offsets -- the swizzled form needs a separate address register per (row, dx),
+// which the compiler hoists out of the K loop: 18+ long-lived VGPRs that the 128-register consumers do not have.  Cost: a
+// 2-way bank conflict on every B-fragment read (6 of the 21 reads of a stage; measured irrelevant next to 60 MFMAs).
+template <bool SWZ>
+__device__ __forceinline__ int actv_addr(int q, int slot) {
+  return q * (QC * 2) + ((SWZ ? (slot ^ ((q >> 2) & 3)) : slot) << 4);
+}
 
 #define TS(i)                                                                                          \
   do {                                                                                                 \
@@ -108,17 +115,18 @@ __device__ __forceinline__ int actv_addr(int q, int slot) { return q * (QC * 2) 
     asm volatile("" ::: "memory");                                      \
   } while (0)
 
-// NW = 4: one wave per SIMD and workgroup, each owning 4 pixel rows x all NCT channel tiles (two workgroups per CU ->
-//         2 waves per SIMD, ~250 VGPRs each).
-// NW = 8: TWO waves per SIMD and workgroup -- waves w and w + 4 share the pixel rows 4 (w & 3) .. +3 and split the channel
-//         tiles (first ceil(NCT / 2) | the rest), so each holds half the accumulators and stays below 128 VGPRs: with two
-//         co-resident workgroups a SIMD has 4 waves to pick from while one sits in a barrier, an LDS round trip or its
-//         share of the hidden-map production (21 tiles over 8 waves: one per stage).  The B (hidden-map) fragments are
-//         read by both waves of a pair; the A (weight) fragments are not duplicated.
+// NW = 4: one wave per SIMD and workgroup, each owning 4 pixel rows x all NCT channel tiles AND its share of the
+//         hidden-map production (two workgroups per CU -> 2 waves per SIMD, ~250 VGPRs each).
+// NW = 8: WAVE SPECIALISATION -- waves 0-3 are CONSUMERS (the 4-wave kernel's MFMA stream: fragment reads + the
+//         gamma||beta MFMAs, nothing else), waves 4-7 are PRODUCERS (the weight-stage LDS-DMA and the next quarter's
+//         hidden map: cond gather -> small MFMAs -> ReLU -> LDS).  All 8 waves fit the 128-VGPR budget of 4 waves per
+//         SIMD (NCT <= 4), so with two co-resident workgroups every SIMD has two MFMA streams and two producer streams to
+//         pick from: the MFMA stream of a workgroup no longer waits on the producer chains of its own wave.
 template <typename T, int NCT, bool C4, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(SpadeParams p) {   // 2nd arg: waves per SIMD
   constexpr int WAVES = NW;               // shadows the namespace constant inside this kernel
-  constexpr int NA = NW == 8 ? (NCT + 1) / 2 : NCT;      // channel tiles of the first wave of a pair
+  constexpr bool SPEC = NW == 8;          // wave-specialised: consumers 0-3, producers 4-7
+  constexpr bool SWZ = !SPEC || NCT <= 4;  // hidden-map slot swizzle (see actv_addr): off where the VGPRs are needed
   constexpr int STAGE_BYTES = 3 * NCT * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* actv = smem;                                              // 2 * ACTV_Q_BYTES
@@ -153,8 +161,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
     const int q = s / 3, dx = s - q * 3;
     unsigned char* dstbuf = wbuf + (s & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int i0 = 0; i0 < 3 * NCT; i0 += WAVES) {
-      const int i = i0 + wave;            // wave-uniform
+    for (int i0 = 0; i0 < 3 * NCT; i0 += 4) {
+      const int i = i0 + (wave & 3);      // wave-uniform; 4 issuing waves (all of them, or the producers)
       if (i < 3 * NCT) {
         const int dy = i / NCT, c = i - dy * NCT;
         const int nt = min(nt0 + c, p.nt - 1);
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
       }
     }
   };
-  issue_stage(0);
+  if (!SPEC || wave >= 4) issue_stage(0);
 
   // shared-conv weights of one hidden-channel quarter, kept in registers (C4 path): per 16-channel tile one full
   // k-step-0 fragment and the k-step-1 fragment (tap 8 + bias; only lane group 0 is non-zero)
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
       o[0] = pack2<T>(fmaxf(hacc[c][0], 0.f), fmaxf(hacc[c][1], 0.f));
       o[1] = pack2<T>(fmaxf(hacc[c][2], 0.f), fmaxf(hacc[c][3], 0.f));
       // local channel = c*16 + 4g + r  ->  slot c*2 + (g>>1), byte (g&1)*8
-      *reinterpret_cast<u32x2*>(dst + actv_addr(q, c * 2 + (g >> 1)) + (g & 1) * 8) = o;
+      *reinterpret_cast<u32x2*>(dst + actv_addr<SWZ>(q, c * 2 + (g >> 1)) + (g & 1) * 8) = o;
     }
   };
   // generic conditioning (cond_c > 4): K lookup table, weights from global memory; not split
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
   auto run = [&](auto c0_tag, auto cn_tag) {
     constexpr int C0 = decltype(c0_tag)::value;
     constexpr int CN = decltype(cn_tag)::value;
-    constexpr int TPS = NW == 8 ? 1 : 2;       // hidden tiles per wave and stage (21 tiles / quarter over 3 stages x NW)
+    constexpr int TPS = 2;                     // hidden tiles per producing wave and stage (21 per quarter, 3 stages x 4)
 
     f32x4 acc[CN][PT];
 #pragma unroll
@@ -370,12 +378,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
       unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;   // next quarter's, written during this one
       const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16 + C0 * 1024;
       // hidden tiles of this stage (clamped: a duplicate tile stores identical values)
-      const int htA = min(wave + (dx * TPS) * WAVES, NHT - 1), htB = min(wave + (dx * TPS + 1) * WAVES, NHT - 1);
+      const int htA = min((wave & 3) + (dx * TPS) * 4, NHT - 1), htB = min((wave & 3) + (dx * TPS + 1) * 4, NHT - 1);
       u32x4 bfr[PT + 2], a[CN];
 #pragma unroll
       for (int r = 0; r < PT + 2; ++r) {
         const int qq = (wrow * PT + r) * HPW + (j + dx);
-        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
+        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr<SWZ>(qq, g));
       }
 #pragma unroll
       for (int c = 0; c < CN; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + c * 1024);
@@ -415,26 +423,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
     auto stage_plain = [&](int q, int dx, int s) {
       const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;
       unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
-      const bool hid = C4 && q < 3 && !(p.dbg & 1);
+      const bool hid = !SPEC && C4 && q < 3 && !(p.dbg & 1);
       u32x4 bfr[PT + 2];
 #pragma unroll
       for (int r = 0; r < PT + 2; ++r) {
         const int qq = (wrow * PT + r) * HPW + (j + dx);
-        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr(qq, g));
+        bfr[r] = *reinterpret_cast<const u32x4*>(abuf + actv_addr<SWZ>(qq, g));
       }
-      const int htA = wave + (dx * 2) * WAVES, htB = wave + (dx * 2 + 1) * WAVES;   // wave-uniform
+      const int htA = (wave & 3) + (dx * 2) * 4, htB = (wave & 3) + (dx * 2 + 1) * 4;   // wave-uniform
       const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16 + C0 * 1024;
       if (hid && htA < NHT) hid_gather(htA);
+      // A fragments in flight: all CN, or (specialised consumers with 5 tiles: 80 accumulator + 24 B registers of a
+      // 128-register budget) three at a time
+      constexpr int AC = (SPEC && CN > 4) ? 2 : CN;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        u32x4 a[CN];
 #pragma unroll
-        for (int c = 0; c < CN; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c) * 1024);
+        for (int c0 = 0; c0 < CN; c0 += AC) {
+          u32x4 a[AC];
 #pragma unroll
-        for (int c = 0; c < CN; ++c)
+          for (int c = 0; c < AC; ++c)
+            if (c0 + c < CN) a[c] = *reinterpret_cast<const u32x4*>(wb + (dy * NCT + c0 + c) * 1024);
 #pragma unroll
-          for (int t = 0; t < PT; ++t)
-            acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c][t]);
+          for (int c = 0; c < AC; ++c)
+            if (c0 + c < CN) {
+#pragma unroll
+              for (int t = 0; t < PT; ++t)
+                acc[c0 + c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bfr[t + dy]), acc[c0 + c][t]);
+            }
+        }
         if (hid) {
           if (dy == 0) {
             if (htA < NHT) hid_mma();
@@ -450,11 +467,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
     };
 
     for (int q = 0; q < 4; ++q) {
-      if (C4 && q < 3) load_wsh(q + 1);
+      if (!SPEC && C4 && q < 3) load_wsh(q + 1);
       for (int dx = 0; dx < 3; ++dx) {
         const int s = q * 3 + dx;
         COUNTED_BARRIER(0);
-        if (s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
+        if (!SPEC && s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
         if (q == 3 && dx == 0) {
           // the last quarter has no successor: its spare hidden-map buffer (actv[0]) receives the x tile now, as
           // whole 16-byte channel chunks, lane-linear over [256 pixels][NCT chunks] (id = k*NW*64 + tid -> pixel
@@ -474,16 +491,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
             }
           }
         }
-        constexpr bool ILV = NW == 8 || NCT <= 3;   // the 4-wave NCT >= 4 body has no VGPRs left for the interleave
+        // the interleaved body only pays where a wave has hidden-map work to weave in and VGPRs to spare: the 4-wave
+        // kernel with NCT <= 3; the specialised consumers (nothing but fragment reads and MFMAs, two more waves on the
+        // SIMD to cover the reads) take the plain one
+        constexpr bool ILV = !SPEC && NCT <= 3;
         if (ILV) {
-          if (C4 && q < 3 && !(p.dbg & 1)) stage_body(std::true_type{}, q, dx, s);
+          if (!SPEC && C4 && q < 3 && !(p.dbg & 1)) stage_body(std::true_type{}, q, dx, s);
           else stage_body(std::false_type{}, q, dx, s);
         } else {
           stage_plain(q, dx, s);
         }
-        if (!C4 && q < 3) {   // generic conditioning: not interleaved
+        if (!SPEC && !C4 && q < 3) {   // generic conditioning: not interleaved
           unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
-          for (int ht = wave + dx * TPS * WAVES; ht < min(NHT, (dx + 1) * TPS * WAVES); ht += WAVES)
+          for (int ht = wave + dx * TPS * 4; ht < min(NHT, (dx + 1) * TPS * 4); ht += 4)
             hidden_tile_generic(ht, q + 1, nbuf);
         }
       }
@@ -531,12 +551,47 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
       }
     }
   };
-  if (NW == 4) {
+  // producer waves of the specialised kernel: the same barrier sequence as the consumers' K loop, with the weight-stage
+  // DMA and the hidden-map tiles of the next quarter in between
+  auto run_producer = [&]() {
+    const int pw = wave & 3;
+    for (int q = 0; q < 4; ++q) {
+      if (C4 && q < 3) load_wsh(q + 1);
+      for (int dx = 0; dx < 3; ++dx) {
+        const int s = q * 3 + dx;
+        COUNTED_BARRIER(0);
+        if (s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
+        if (q == 3 && dx == 0) {       // x tile -> the idle hidden buffer (all 8 waves take part; see the consumers)
+#pragma unroll
+          for (int k = 0; k < (NCT * 256 + WAVES * 64 - 1) / (WAVES * 64); ++k) {
+            const int id = k * (WAVES * 64) + threadIdx.x;
+            if ((k + 1) * (WAVES * 64) <= NCT * 256 || id < NCT * 256) {
+              const int pix = id / NCT, cc = id - pix * NCT;
+              const int yy = min(ty0 + (pix >> 4), p.h - 1), xx = min(tx0 + (pix & 15), p.w - 1);
+              const int sy = p.x_ups ? (yy >> 1) : yy, sx = p.x_ups ? (xx >> 1) : xx;
+              const int nt = min(nt0 + cc, p.nt - 1);
+              const uint16_t* src = p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cs + nt * 8;
+              __builtin_amdgcn_global_load_lds(
+                  (const __attribute__((address_space(1))) void*)src,
+                  (__attribute__((address_space(3))) void*)(actv + (k * (WAVES * 64) + wave * 64) * 16), 16, 0, 0);
+            }
+          }
+        }
+        if (q < 3 && !(p.dbg & 1)) {
+          unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
+          for (int ht = pw + dx * 8; ht < min(NHT, (dx + 1) * 8); ht += 4) {
+            if (C4) hidden_tile(ht, q + 1, nbuf);
+            else hidden_tile_generic(ht, q + 1, nbuf);
+          }
+        }
+      }
+    }
+    TS(5);
+  };
+  if (!SPEC || wave < 4) {
     run(std::integral_constant<int, 0>{}, std::integral_constant<int, NCT>{});
-  } else if (wave < 4) {
-    run(std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
   } else {
-    run(std::integral_constant<int, NA>{}, std::integral_constant<int, (NW == 8 ? NCT - NA : NCT)>{});
+    run_producer();
   }
   __syncthreads();
   const unsigned char* xt = actv;   // [256 px][NCT * 16 B], now holding the results
@@ -703,14 +758,14 @@ int launch_nct(const SpadeParams& p, int nct, int nw, hipStream_t s) {
 // Development knobs (not part of the stable ABI): force the channel tiles per workgroup / ablation bits /
 // timestamp buffer.
 int g_spade_variant = 0;
-int g_spade_waves = 4;
+int g_spade_waves = 8;   // default: the wave-specialised kernel wherever a workgroup has >= 2 channel tiles
 int g_spade_dbg = 0;
 unsigned long long* g_spade_tsbuf = nullptr;
 
 }  // namespace
 
 extern "C" void cgan_debug_set_spade_variant(int v) { g_spade_variant = v; }
-extern "C" void cgan_debug_set_spade_waves(int v) { g_spade_waves = v == 8 ? 8 : 4; }
+extern "C" void cgan_debug_set_spade_waves(int v) { g_spade_waves = v == 4 ? 4 : 8; }
 extern "C" void cgan_debug_set_spade_ablation(int bits) { g_spade_dbg = bits; }
 extern "C" void cgan_debug_set_spade_tsbuf(void* p) { g_spade_tsbuf = (unsigned long long*)p; }
 
@@ -765,10 +820,11 @@ extern "C" int cgan_spade_fused_fwd(const void* x, const float* mean, const floa
   p.act = d->act; p.slope = d->act_slope; p.dbg = g_spade_dbg; p.tsbuf = g_spade_tsbuf;
   hipStream_t s = (hipStream_t)stream;
   // channel tiles per workgroup: as many as divide nt with the least padded work (nt = 3 -> 3, 5/10/20.. -> 5)
-  int nct = p.nt < MAX_NCT ? p.nt : MAX_NCT;
-  if (p.nt > MAX_NCT) {
-    int best = MAX_NCT, waste = ceil_div(p.nt, MAX_NCT) * MAX_NCT - p.nt;
-    for (int k = MAX_NCT - 1; k >= 3; --k) {
+  const int max_nct = MAX_NCT;
+  int nct = p.nt < max_nct ? p.nt : max_nct;
+  if (p.nt > max_nct) {
+    int best = max_nct, waste = ceil_div(p.nt, max_nct) * max_nct - p.nt;
+    for (int k = max_nct - 1; k >= 3; --k) {
       int w = ceil_div(p.nt, k) * k - p.nt;
       if (w < waste) { waste = w; best = k; }
     }

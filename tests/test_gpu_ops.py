@@ -148,16 +148,48 @@ def _set_variant(v):
     _lib.load().cgan_debug_set_spade_variant(ctypes.c_int(v))
 
 
+def _set_waves(n):
+    import ctypes
+    from climategan_amd import _lib
+    _lib.load().cgan_debug_set_spade_waves(ctypes.c_int(n))
+
+
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", [(40, 36, 52, (72, 104), False, "lrelu"), (88, 18, 16, (36, 32), True, "none")])
-def test_spade_fused_tile_variants(variant, case):
-    """Every channel-tiles-per-workgroup instantiation (NCT = 1..5) on multi-tile, ragged images, including
-    a channel count (C=88 -> 11 channel tiles) that leaves a partial last chunk."""
+def test_spade_fused_tile_variants(variant, case, waves):
+    """Every channel-tiles-per-workgroup instantiation (NCT = 1..5) of both kernels -- the wave-specialised one (8 waves:
+    consumers + producers, the default) and the 4-wave one -- on multi-tile, ragged images, including a channel count
+    (C=88 -> 11 channel tiles) that leaves a partial last chunk; bf16 and fp16."""
     _set_variant(variant)
+    _set_waves(waves)
     try:
         test_spade_fused(torch.float16, case)
+        test_spade_fused(torch.bfloat16, case)
     finally:
         _set_variant(0)
+        _set_waves(8)
+
+
+def test_spade_kernels_agree_bitwise():
+    """The specialised and the 4-wave kernel run the same arithmetic in the same order: identical bits."""
+    from climategan_amd import fill, ops
+    from helpers import spade_shapes, t
+    C, H, W = 40, 48, 64
+    dt = torch.bfloat16
+    sd_np = fill.fill_state_dict(spade_shapes("s", C, 3), seed=77)
+    pk = ops.pack_spade_weights(*[t(sd_np["s." + k]).cuda() for k in (
+        "mlp_shared.0.weight", "mlp_shared.0.bias", "mlp_gamma.weight", "mlp_gamma.bias", "mlp_beta.weight",
+        "mlp_beta.bias")], dt)
+    x = ops.nchw_to_nhwc(t(fill.uniform((2, C, H, W), 5, -2, 2)).cuda(), dt)
+    cond = ops.nchw_to_nhwc(t(fill.uniform((2, 3, 96, 128), 6)).cuda(), dt, cs=4)
+    mean, rstd = ops.instnorm_stats(x)
+    outs = []
+    for waves in (8, 4):
+        _set_waves(waves)
+        outs.append(ops.spade_fused(x, mean, rstd, cond, pk, act=ops.ACT_LRELU).t.clone())
+    _set_waves(8)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -26,7 +26,7 @@ for C, R in shapes:
     line = "C=%3d R=%3d  %6.1f GFLOP |" % (C, R, flops / 1e9)
     for v in variants:
         lib.cgan_debug_set_spade_variant(ctypes.c_int(v % 10))
-        lib.cgan_debug_set_spade_waves(ctypes.c_int(8 if v >= 10 else 4))
+        lib.cgan_debug_set_spade_waves(ctypes.c_int(8 if v >= 10 else 4))   # 0-5: 4-wave kernel, 10-15: specialised
         ref = ops.spade_fused(x, mean, rstd, cond, pk, act=ops.ACT_LRELU).t.float()
         if v == variants[0]:
             ref0 = ref
@@ -44,5 +44,5 @@ for C, R in shapes:
         us = e0.elapsed_time(e1) / n * 1e3
         line += "  v%d %8.1f us %6.0f TF |" % (v, us, flops / us / 1e6)
     lib.cgan_debug_set_spade_variant(ctypes.c_int(0))
-    lib.cgan_debug_set_spade_waves(ctypes.c_int(4))
+    lib.cgan_debug_set_spade_waves(ctypes.c_int(8))
     print(line)
