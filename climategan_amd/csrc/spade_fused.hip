@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
   f32x4 hacc[2];
   hacc[0] = hacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto hid_gather = [&](int ht) {
+  auto gather_to = [&](int ht, u32x4& b0, u32x4& b1) {
     const int q = ht * 16 + j;
     const bool qv = q < HP;
     const int qc = qv ? q : HP - 1;
@@ -261,29 +261,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
     const u32x2 p0 = *reinterpret_cast<const u32x2*>(cb + tapoff0 * 4);
     const u32x2 p1 = *reinterpret_cast<const u32x2*>(cb + tapoff1 * 4);
     const u32x2 p8 = *reinterpret_cast<const u32x2*>(cb + (2 * CTW + 2) * 4);
-    hb0[0] = inside ? p0[0] : 0u; hb0[1] = inside ? p0[1] : 0u;
-    hb0[2] = inside ? p1[0] : 0u; hb0[3] = inside ? p1[1] : 0u;
+    b0[0] = inside ? p0[0] : 0u; b0[1] = inside ? p0[1] : 0u;
+    b0[2] = inside ? p1[0] : 0u; b0[3] = inside ? p1[1] : 0u;
     const bool k1 = inside && g == 0;
-    hb1[0] = k1 ? p8[0] : 0u; hb1[1] = k1 ? p8[1] : 0u; hb1[2] = k1 ? one : 0u; hb1[3] = 0u;
+    b1[0] = k1 ? p8[0] : 0u; b1[1] = k1 ? p8[1] : 0u; b1[2] = k1 ? one : 0u; b1[3] = 0u;
   };
-  auto hid_mma = [&]() {
+  auto mma_to = [&](const u32x4& b0, const u32x4& b1, f32x4 (&ha)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      hacc[c] = mfma16(as_vec8<T>(wsh0[c]), as_vec8<T>(hb0), (f32x4){0.f, 0.f, 0.f, 0.f});
-      hacc[c] = mfma16(as_vec8<T>(wsh1[c]), as_vec8<T>(hb1), hacc[c]);
+      ha[c] = mfma16(as_vec8<T>(wsh0[c]), as_vec8<T>(b0), (f32x4){0.f, 0.f, 0.f, 0.f});
+      ha[c] = mfma16(as_vec8<T>(wsh1[c]), as_vec8<T>(b1), ha[c]);
     }
   };
-  auto hid_finish = [&](int ht, unsigned char* dst) {
+  auto finish_from = [&](int ht, unsigned char* dst, const f32x4 (&ha)[2]) {
     const int q = ht * 16 + j;   // buffers hold 21 full tiles: pixels >= 324 are written (zeros) and never read
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       u32x2 o;
-      o[0] = pack2<T>(fmaxf(hacc[c][0], 0.f), fmaxf(hacc[c][1], 0.f));
-      o[1] = pack2<T>(fmaxf(hacc[c][2], 0.f), fmaxf(hacc[c][3], 0.f));
+      o[0] = pack2<T>(fmaxf(ha[c][0], 0.f), fmaxf(ha[c][1], 0.f));
+      o[1] = pack2<T>(fmaxf(ha[c][2], 0.f), fmaxf(ha[c][3], 0.f));
       // local channel = c*16 + 4g + r  ->  slot c*2 + (g>>1), byte (g&1)*8
       *reinterpret_cast<u32x2*>(dst + actv_addr<SWZ>(q, c * 2 + (g >> 1)) + (g & 1) * 8) = o;
     }
   };
+  auto hid_gather = [&](int ht) { gather_to(ht, hb0, hb1); };
+  auto hid_mma = [&]() { mma_to(hb0, hb1, hacc); };
+  auto hid_finish = [&](int ht, unsigned char* dst) { finish_from(ht, dst, hacc); };
   // generic conditioning (cond_c > 4): K lookup table, weights from global memory; not split
   auto hidden_tile_generic = [&](int ht, int qq, unsigned char* dst) {
     const int q = ht * 16 + j;
@@ -555,6 +558,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
   // DMA and the hidden-map tiles of the next quarter in between
   auto run_producer = [&]() {
     const int pw = wave & 3;
+    // The cond values a hidden tile is computed from do not depend on the quarter (only the shared-conv weights do):
+    // gather the B fragments of this wave's six tiles ONCE and keep them in registers (48 VGPRs the producers have to
+    // spare); per quarter a tile then costs 4 small MFMAs + ReLU / pack + two LDS stores.
+    u32x4 gb0[6], gb1[6];
+    if (C4) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gather_to(min(pw + (k >> 1) * 8 + (k & 1) * 4, NHT - 1), gb0[k], gb1[k]);
+    }
     for (int q = 0; q < 4; ++q) {
       if (C4 && q < 3) load_wsh(q + 1);
       for (int dx = 0; dx < 3; ++dx) {
@@ -579,9 +590,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
         }
         if (q < 3 && !(p.dbg & 1)) {
           unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
-          for (int ht = pw + dx * 8; ht < min(NHT, (dx + 1) * 8); ht += 4) {
-            if (C4) hidden_tile(ht, q + 1, nbuf);
-            else hidden_tile_generic(ht, q + 1, nbuf);
+          if (C4) {
+            // the two tiles of this stage in lock step (gather | gather, multiply | multiply, store | store): the
+            // LDS round trip of one covers the dependent MFMA pair of the other.  A tile index past the last one is
+            // clamped: the duplicate stores identical values.
+            const int htA = min(pw + dx * 8, NHT - 1), htB = min(pw + dx * 8 + 4, NHT - 1);
+            f32x4 ha[2], hb[2];
+            // dx is a run-time loop variable: pick the register pair with selects (no dynamic VGPR indexing)
+            const u32x4 a0 = dx == 0 ? gb0[0] : (dx == 1 ? gb0[2] : gb0[4]), a1 = dx == 0 ? gb1[0] : (dx == 1 ? gb1[2] : gb1[4]);
+            const u32x4 b0 = dx == 0 ? gb0[1] : (dx == 1 ? gb0[3] : gb0[5]), b1 = dx == 0 ? gb1[1] : (dx == 1 ? gb1[3] : gb1[5]);
+            mma_to(a0, a1, ha);
+            mma_to(b0, b1, hb);
+            finish_from(htA, nbuf, ha);
+            finish_from(htB, nbuf, hb);
+          } else {
+            for (int ht = pw + dx * 8; ht < min(NHT, (dx + 1) * 8); ht += 4) hidden_tile_generic(ht, q + 1, nbuf);
           }
         }
       }

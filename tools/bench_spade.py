@@ -8,6 +8,9 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from climategan_amd import _lib, fill, ops  # noqa: E402
+import os
+if os.environ.get("CGAN_LIB"):      # A/B against another build of the library (same box, same call)
+    _lib.LIB_PATH = Path(os.environ["CGAN_LIB"]).resolve()
 
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float16
 B = 8
