@@ -24,7 +24,7 @@
 //             normalised, activated and written back through LDS as whole 16-byte channel chunks.
 // The 128-channel hidden map (105 MB/img at 640x640 in 16-bit) never touches HBM; HBM traffic is x (read) +
 // y (write) + the 4-channel cond halo.  LDS fragment reads per MFMA: (3*NCT A + 6 B) / (12*NCT) = 0.35 at NCT 5.
-// Conditioning with more than 4 channels (the SPADE mask decoder's 15) takes a generic, non-interleaved hidden path.
+// Conditioning with more than 3 channels (the SPADE mask decoder's 15) takes a generic, non-interleaved hidden path.
 //
 // MFMA operand roles: A = weights (rows = output channels), B = activations (cols = pixels), so that
 // D's per-lane 4 registers are 4 consecutive channel rows of one pixel (col = lane&15, row = 4*(lane>>4)+r).
@@ -54,8 +54,7 @@ struct SpadeParams {
   const float* mean;
   const float* rstd;
   const uint16_t* cond;
-  const u32x4* w_sh;    // C4 path: [8][64] k-step-0 fragments, then [8][16] compact k-step-1 fragments
-                        // generic:  [8][ksh][64]
+  const u32x4* w_sh;    // C4 path: [8][64] fragments of the single k-step;  generic: [8][ksh][64]
   const u32x4* w_gb;    // [nt][36][64]
   const float* b_gb;    // [nt][16]  (gamma bias + 1 | beta bias), zero on pad channels
   uint16_t* y;
@@ -72,8 +71,11 @@ struct SpadeParams {
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-__host__ inline bool is_c4(int cond_c) { return cond_c <= 4; }
-__host__ inline int ksh_of(int cond_c) { return is_c4(cond_c) ? 2 : ceil_div(9 * cond_c + 1, 32); }
+// "C4" path: cond stored as 4 channels per pixel of which at most 3 are used (the Painter's RGB conditioning): the
+// shared conv then is ONE k-step of 32 -- K = tap * 4 + c for taps 0..7, and the unused 4th-channel slots of taps 0..3
+// carry tap 8's three channels and the constant one of the bias (half the hidden-map MFMAs of a two-k-step layout)
+__host__ inline bool is_c4(int cond_c) { return cond_c <= 3; }
+__host__ inline int ksh_of(int cond_c) { return is_c4(cond_c) ? 1 : ceil_div(9 * cond_c + 1, 32); }
 
 struct PackedLayout {
   size_t w_sh, w_gb, b_gb, total;
@@ -82,7 +84,7 @@ __host__ inline PackedLayout packed_layout(int cs, int cond_c) {
   PackedLayout L;
   int nt = cs / 8;
   L.w_sh = 0;
-  size_t wsh_bytes = is_c4(cond_c) ? (size_t)8 * 1024 + 8 * 256 : (size_t)8 * ksh_of(cond_c) * 1024;
+  size_t wsh_bytes = (size_t)8 * ksh_of(cond_c) * 1024;
   L.w_gb = align16(L.w_sh + wsh_bytes);
   L.b_gb = align16(L.w_gb + (size_t)nt * KS_GB * 64 * 16);
   L.total = align16(L.b_gb + (size_t)nt * 16 * sizeof(float));
@@ -174,17 +176,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
   };
   if (!SPEC || wave >= 4) issue_stage(0);
 
-  // shared-conv weights of one hidden-channel quarter, kept in registers (C4 path): per 16-channel tile one full
-  // k-step-0 fragment and the k-step-1 fragment (tap 8 + bias; only lane group 0 is non-zero)
-  u32x4 wsh0[2], wsh1[2];
+  // shared-conv weights of one hidden-channel quarter, kept in registers (C4 path): one fragment per 16-channel tile
+  u32x4 wsh0[2];
   auto load_wsh = [&](int qq) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ct = qq * 2 + c;
-      wsh0[c] = p.w_sh[(size_t)ct * 64 + lane];
-      wsh1[c] = p.w_sh[(size_t)8 * 64 + ct * 16 + j];
-      if (g != 0) wsh1[c] = (u32x4){0u, 0u, 0u, 0u};
-    }
+    for (int c = 0; c < 2; ++c) wsh0[c] = p.w_sh[(size_t)(qq * 2 + c) * 64 + lane];
   };
   if (C4) load_wsh(0);
 
@@ -234,21 +230,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
   TS(1);
 
   const uint32_t one = bits_of<T>(1.f);
-  // C4 gather: K = (tap, c4) -> lane group g holds taps 2g and 2g+1 of k-step 0 = two whole cond pixels (8 B each)
-  // at these pixel offsets of the 20-wide cond tile; k-step 1 = tap 8 (pixel offset 42) + the bias one (g == 0 only)
+  // C4 gather: K = (tap, c4) -> lane group g holds taps 2g and 2g+1 = two whole cond pixels (8 B each) at these pixel
+  // offsets of the 20-wide cond tile.  The 4th channel of a cond pixel is padding, so those K slots (k = 8g + 3 and
+  // 8g + 7) carry tap 8 (pixel offset 2*CTW + 2) and the bias column instead: g = 0: tap8.c0, tap8.c1;
+  // g = 1: tap8.c2, the constant one; g = 2, 3: zero.
   const int tapoff0 = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? CTW + 1 : 2 * CTW));
   const int tapoff1 = g == 0 ? 1 : (g == 1 ? CTW : (g == 2 ? CTW + 2 : 2 * CTW + 1));
 
-  // One hidden tile = 16 halo pixels x the 32 channels of a quarter, computed in three pieces so that inside the
-  // K loop each piece's latency is covered by a whole MFMA stage:
-  //   hid_gather(ht)      cond values of the tile -> B fragments (registers hb0, hb1)
-  //   hid_mma()           4 small MFMAs: hb x the shared weights held in wsh0/wsh1 -> hacc
-  //   hid_finish(ht, dst) ReLU, pack, store hacc to the LDS hidden-map buffer dst
-  u32x4 hb0 = (u32x4){0u, 0u, 0u, 0u}, hb1 = (u32x4){0u, 0u, 0u, 0u};
+  // One hidden tile = 16 halo pixels x the 32 channels of a quarter, in three pieces:
+  //   gather_to(ht, b)        cond values of the tile -> the B fragment
+  //   mma_to(b, acc)          2 small MFMAs: b x the shared weights held in wsh0
+  //   finish_from(ht, dst, acc) ReLU, pack, store to the LDS hidden-map buffer dst
+  u32x4 hb0 = (u32x4){0u, 0u, 0u, 0u};
   f32x4 hacc[2];
   hacc[0] = hacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto gather_to = [&](int ht, u32x4& b0, u32x4& b1) {
+  auto gather_to = [&](int ht, u32x4& b0) {
     const int q = ht * 16 + j;
     const bool qv = q < HP;
     const int qc = qv ? q : HP - 1;
@@ -261,17 +258,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
     const u32x2 p0 = *reinterpret_cast<const u32x2*>(cb + tapoff0 * 4);
     const u32x2 p1 = *reinterpret_cast<const u32x2*>(cb + tapoff1 * 4);
     const u32x2 p8 = *reinterpret_cast<const u32x2*>(cb + (2 * CTW + 2) * 4);
-    b0[0] = inside ? p0[0] : 0u; b0[1] = inside ? p0[1] : 0u;
-    b0[2] = inside ? p1[0] : 0u; b0[3] = inside ? p1[1] : 0u;
-    const bool k1 = inside && g == 0;
-    b1[0] = k1 ? p8[0] : 0u; b1[1] = k1 ? p8[1] : 0u; b1[2] = k1 ? one : 0u; b1[3] = 0u;
+    // extras in their LOW halves: xa -> slot k = 8g + 3, xb -> slot k = 8g + 7
+    const uint32_t xa = g == 0 ? p8[0] : (g == 1 ? p8[1] : 0u);
+    const uint32_t xb = g == 0 ? (p8[0] >> 16) : (g == 1 ? one : 0u);
+    // v_perm: bytes 0, 1 from the second operand, bytes 2, 3 = bytes 0, 1 of the first
+    const uint32_t w1 = __builtin_amdgcn_perm(xa, p0[1], 0x05040100u);
+    const uint32_t w3 = __builtin_amdgcn_perm(xb, p1[1], 0x05040100u);
+    b0[0] = inside ? p0[0] : 0u; b0[1] = inside ? w1 : 0u;
+    b0[2] = inside ? p1[0] : 0u; b0[3] = inside ? w3 : 0u;
   };
-  auto mma_to = [&](const u32x4& b0, const u32x4& b1, f32x4 (&ha)[2]) {
+  auto mma_to = [&](const u32x4& b0, f32x4 (&ha)[2]) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      ha[c] = mfma16(as_vec8<T>(wsh0[c]), as_vec8<T>(b0), (f32x4){0.f, 0.f, 0.f, 0.f});
-      ha[c] = mfma16(as_vec8<T>(wsh1[c]), as_vec8<T>(b1), ha[c]);
-    }
+    for (int c = 0; c < 2; ++c) ha[c] = mfma16(as_vec8<T>(wsh0[c]), as_vec8<T>(b0), (f32x4){0.f, 0.f, 0.f, 0.f});
   };
   auto finish_from = [&](int ht, unsigned char* dst, const f32x4 (&ha)[2]) {
     const int q = ht * 16 + j;   // buffers hold 21 full tiles: pixels >= 324 are written (zeros) and never read
@@ -284,8 +282,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
       *reinterpret_cast<u32x2*>(dst + actv_addr<SWZ>(q, c * 2 + (g >> 1)) + (g & 1) * 8) = o;
     }
   };
-  auto hid_gather = [&](int ht) { gather_to(ht, hb0, hb1); };
-  auto hid_mma = [&]() { mma_to(hb0, hb1, hacc); };
+  auto hid_gather = [&](int ht) { gather_to(ht, hb0); };
+  auto hid_mma = [&]() { mma_to(hb0, hacc); };
   auto hid_finish = [&](int ht, unsigned char* dst) { finish_from(ht, dst, hacc); };
   // generic conditioning (cond_c > 4): K lookup table, weights from global memory; not split
   auto hidden_tile_generic = [&](int ht, int qq, unsigned char* dst) {
@@ -329,18 +327,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
   if (!(p.dbg & 1)) {
     if (C4) {
       constexpr int TPW = (NHT + WAVES - 1) / WAVES;   // 6 tiles per wave
-      u32x4 gb0[TPW], gb1[TPW];
+      u32x4 gb0[TPW];
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
         hid_gather(min(wave + i * WAVES, NHT - 1));
         gb0[i] = hb0;
-        gb1[i] = hb1;
       }
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
         const int ht = wave + i * WAVES;
         hb0 = gb0[i];
-        hb1 = gb1[i];
         hid_mma();
         if (ht < NHT) hid_finish(ht, actv);
       }
@@ -560,11 +556,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
     const int pw = wave & 3;
     // The cond values a hidden tile is computed from do not depend on the quarter (only the shared-conv weights do):
     // gather the B fragments of this wave's six tiles ONCE and keep them in registers (48 VGPRs the producers have to
-    // spare); per quarter a tile then costs 4 small MFMAs + ReLU / pack + two LDS stores.
-    u32x4 gb0[6], gb1[6];
+    // spare); per quarter a tile then costs 2 small MFMAs + ReLU / pack + two LDS stores.
+    u32x4 gb0[6];
     if (C4) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) gather_to(min(pw + (k >> 1) * 8 + (k & 1) * 4, NHT - 1), gb0[k], gb1[k]);
+      for (int k = 0; k < 6; ++k) gather_to(min(pw + (k >> 1) * 8 + (k & 1) * 4, NHT - 1), gb0[k]);
     }
     for (int q = 0; q < 4; ++q) {
       if (C4 && q < 3) load_wsh(q + 1);
@@ -597,10 +593,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
             const int htA = min(pw + dx * 8, NHT - 1), htB = min(pw + dx * 8 + 4, NHT - 1);
             f32x4 ha[2], hb[2];
             // dx is a run-time loop variable: pick the register pair with selects (no dynamic VGPR indexing)
-            const u32x4 a0 = dx == 0 ? gb0[0] : (dx == 1 ? gb0[2] : gb0[4]), a1 = dx == 0 ? gb1[0] : (dx == 1 ? gb1[2] : gb1[4]);
-            const u32x4 b0 = dx == 0 ? gb0[1] : (dx == 1 ? gb0[3] : gb0[5]), b1 = dx == 0 ? gb1[1] : (dx == 1 ? gb1[3] : gb1[5]);
-            mma_to(a0, a1, ha);
-            mma_to(b0, b1, hb);
+            const u32x4 a0 = dx == 0 ? gb0[0] : (dx == 1 ? gb0[2] : gb0[4]);
+            const u32x4 b0 = dx == 0 ? gb0[1] : (dx == 1 ? gb0[3] : gb0[5]);
+            mma_to(a0, ha);
+            mma_to(b0, hb);
             finish_from(htA, nbuf, ha);
             finish_from(htB, nbuf, hb);
           } else {
@@ -633,8 +629,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(S
 }
 
 // ---- weight packing
-// shared conv, C4 path (cond_c <= 4): K = tap*4 + c4.  k-step 0 (taps 0..7): [8 hidden tiles][64 lanes] fragments;
-//   k-step 1 (tap 8 in k = 32..35, bias in k = 36): compact [8][16 rows] fragments (only lane group 0 is non-zero)
+// shared conv, C4 path (cond_c <= 3): one k-step, K = tap*4 + c for taps 0..7 and c < 3; the 4th-channel slots hold
+//   tap 8 (k = 3, 7, 11) and the bias (k = 15): [8 hidden tiles][64 lanes] fragments
 // shared conv, generic path: K = tap*cond_c + c, bias in column 9*cond_c -> [8][ksh][64] fragments
 // gamma||beta: tile t rows 0-7 = gamma[8t+i], rows 8-15 = beta[8t+i]; K = tap*128 + hidden -> [nt][36][64]
 template <typename T>
@@ -643,33 +639,28 @@ __global__ void spade_pack_kernel(const float* __restrict__ w_sh, const float* _
                                   const float* __restrict__ w_b, const float* __restrict__ b_b,
                                   uint16_t* __restrict__ p_wsh, uint16_t* __restrict__ p_wgb, float* __restrict__ p_bgb,
                                   int c, int nt, int cond_c, int ksh, int c4) {
-  const int n_sh = c4 ? (8 * 64 + 8 * 16) : 8 * ksh * 64;
+  const int n_sh = 8 * ksh * 64;
   const int n_gb = nt * KS_GB * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_sh + n_gb; idx += gridDim.x * blockDim.x) {
     uint16_t o[8];
     u32x4* dst;
     if (idx < n_sh) {
       if (c4) {
-        if (idx < 8 * 64) {
-          const int lane = idx & 63, ct = idx >> 6;
-          const int hc = ct * 16 + (lane & 15);
-          const int k0 = (lane >> 4) * 8;
+        const int lane = idx & 63, ct = idx >> 6;
+        const int hc = ct * 16 + (lane & 15);
+        const int gg = lane >> 4;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int k = k0 + e, tap = k >> 2, cc = k & 3;
-            o[e] = bits_of<T>(cc < cond_c ? w_sh[((size_t)hc * cond_c + cc) * 9 + tap] : 0.f);
+        for (int e = 0; e < 8; ++e) {
+          const int k = gg * 8 + e, tap = k >> 2, cc = k & 3;
+          float v = 0.f;
+          if (cc < 3) {
+            v = cc < cond_c ? w_sh[((size_t)hc * cond_c + cc) * 9 + tap] : 0.f;
+          } else if (gg < 2) {                       // the 4th-channel slots of taps 0..3: tap 8 and the bias
+            const int x = gg * 2 + (e >> 2);         // 0, 1, 2 -> tap 8 channel x;  3 -> bias
+            if (x < 3) v = x < cond_c ? w_sh[((size_t)hc * cond_c + x) * 9 + 8] : 0.f;
+            else v = b_sh[hc];
           }
-        } else {
-          const int i2 = idx - 8 * 64;
-          const int row = i2 & 15, ct = i2 >> 4;
-          const int hc = ct * 16 + row;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = 0.f;
-            if (e < 4) v = e < cond_c ? w_sh[((size_t)hc * cond_c + e) * 9 + 8] : 0.f;
-            else if (e == 4) v = b_sh[hc];
-            o[e] = bits_of<T>(v);
-          }
+          o[e] = bits_of<T>(v);
         }
       } else {
         const int lane = idx & 63;
@@ -807,7 +798,7 @@ extern "C" int cgan_spade_pack_weights(const float* w_shared, const float* b_sha
   const bool c4 = is_c4(d->cond_c);
   PackedLayout L = packed_layout(cs, d->cond_c);
   unsigned char* base = (unsigned char*)packed;
-  const int total = (c4 ? 8 * 64 + 8 * 16 : 8 * ksh * 64) + nt * KS_GB * 64;
+  const int total = 8 * ksh * 64 + nt * KS_GB * 64;
   const int blocks = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CGAN_F16)
