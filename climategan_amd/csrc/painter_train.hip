@@ -199,47 +199,70 @@ __global__ void maxpool2x2_bwd_kernel(const uint16_t* __restrict__ x, const uint
 
 
 // ---- backward passes the Masker's graph needs ----------------------------------------------------------------------
-// bilinear resize backward (F.interpolate(mode="bilinear"), both align_corners conventions): scatter with fp32 atomics
-// into an accumulation buffer [n][h_in][w_in][cs] (zeroed by the host entry), converted to 16 bit afterwards
+// bilinear resize backward (F.interpolate(mode="bilinear"), both align_corners conventions), GATHER form: every input
+// pixel sums the output pixels that read it.  The forward maps an output coordinate o to f(o) (monotonic), taps floor(f)
+// and floor(f) + 1 (clamped) with weights 1 - frac, frac; the outputs that touch input coordinate i form a short
+// contiguous range around i / scale, which is re-evaluated with the forward's own index rule (so clamped borders and the
+// y0 == y1 case get exactly the forward's weights).  No atomics, no fp32 accumulation buffer, one pass.  (The first
+// version scattered with fp32 atomics: 0.5 ms for the 256-channel 160^2 -> 82^2 map of the DeepLab decoder.)
+struct AxisTap {
+  int lo, hi;   // candidate output range [lo, hi]
+};
+__device__ __forceinline__ AxisTap axis_candidates(int i, float s, int align, int n_out) {
+  AxisTap t;
+  if (s <= 0.f) {   // n_out == 1 with align_corners: everything reads coordinate 0
+    t.lo = 0; t.hi = i == 0 ? n_out - 1 : -1;
+    return t;
+  }
+  const float inv = 1.f / s;
+  float a = align ? (i - 1) * inv : (i - 0.5f) * inv - 0.5f;
+  float b = align ? (i + 1) * inv : (i + 1.5f) * inv - 0.5f;
+  t.lo = max(0, (int)floorf(a) - 1);
+  t.hi = min(n_out - 1, (int)ceilf(b) + 1);
+  return t;
+}
+// weight with which output coordinate o reads input coordinate i (0 if it does not)
+__device__ __forceinline__ float axis_weight(int o, int i, float s, int align, int n_in) {
+  const float f = align ? o * s : fmaxf((o + 0.5f) * s - 0.5f, 0.f);
+  int i0 = (int)f;
+  i0 = i0 < n_in - 1 ? i0 : n_in - 1;
+  const int i1 = i0 < n_in - 1 ? i0 + 1 : i0;
+  const float l = f - i0;
+  return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
 template <typename T>
-__global__ void bilinear_bwd_scatter_kernel(const uint16_t* __restrict__ dy, float* __restrict__ acc, int h_in, int w_in,
-                                            int h_out, int w_out, int cs, float sy, float sx, int align, long total) {
+__global__ void bilinear_bwd_gather_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int h_in, int w_in,
+                                           int h_out, int w_out, int cs, float sy, float sx, int align, long total) {
   const int cg_total = cs / 8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int cg = (int)(idx % cg_total);
     const long pix = idx / cg_total;
-    const int ox = (int)(pix % w_out);
-    const long r = pix / w_out;
-    const int oy = (int)(r % h_out);
-    const long n = r / h_out;
-    const float fy = align ? oy * sy : fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
-    const float fx = align ? ox * sx : fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
-    int y0 = (int)fy, x0 = (int)fx;
-    y0 = y0 < h_in - 1 ? y0 : h_in - 1;
-    x0 = x0 < w_in - 1 ? x0 : w_in - 1;
-    const int y1 = y0 < h_in - 1 ? y0 + 1 : y0, x1 = x0 < w_in - 1 ? x0 + 1 : x0;
-    const float ly = fy - y0, lx = fx - x0;
-    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-    const u32x4 g = *reinterpret_cast<const u32x4*>(dy + pix * cs + cg * 8);
-    float gv[8];
+    const int ix = (int)(pix % w_in);
+    const long r = pix / w_in;
+    const int iy = (int)(r % h_in);
+    const long n = r / h_in;
+    const AxisTap ty = axis_candidates(iy, sy, align, h_out), tx = axis_candidates(ix, sx, align, w_out);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint16_t* base = dy + n * (long)h_out * w_out * cs + cg * 8;
+    for (int oy = ty.lo; oy <= ty.hi; ++oy) {
+      const float wy = axis_weight(oy, iy, sy, align, h_in);
+      if (wy == 0.f) continue;
+      for (int ox = tx.lo; ox <= tx.hi; ++ox) {
+        const float wgt = wy * axis_weight(ox, ix, sx, align, w_in);
+        if (wgt == 0.f) continue;
+        const u32x4 g = *reinterpret_cast<const u32x4*>(base + ((long)oy * w_out + ox) * cs);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) unpack2<T>(g[e], gv[2 * e], gv[2 * e + 1]);
-    float* base = acc + n * (long)h_in * w_in * cs + cg * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(base + ((long)y0 * w_in + x0) * cs + e, w00 * gv[e]);
-      atomicAdd(base + ((long)y0 * w_in + x1) * cs + e, w01 * gv[e]);
-      atomicAdd(base + ((long)y1 * w_in + x0) * cs + e, w10 * gv[e]);
-      atomicAdd(base + ((long)y1 * w_in + x1) * cs + e, w11 * gv[e]);
+        for (int e = 0; e < 4; ++e) {
+          float g0, g1;
+          unpack2<T>(g[e], g0, g1);
+          acc[2 * e] += wgt * g0;
+          acc[2 * e + 1] += wgt * g1;
+        }
+      }
     }
-  }
-}
-template <typename T>
-__global__ void f32_to_16_kernel(const float* __restrict__ a, uint16_t* __restrict__ y, long groups) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 v0 = reinterpret_cast<const f32x4*>(a)[2 * i], v1 = reinterpret_cast<const f32x4*>(a)[2 * i + 1];
-    u32x4 o = (u32x4){pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3])};
-    reinterpret_cast<u32x4*>(y)[i] = o;
+    u32x4 o = (u32x4){pack2<T>(acc[0], acc[1]), pack2<T>(acc[2], acc[3]), pack2<T>(acc[4], acc[5]), pack2<T>(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(dx + pix * cs + cg * 8) = o;
   }
 }
 
@@ -414,23 +437,18 @@ extern "C" int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx,
 }
 
 extern "C" size_t cgan_resize_bilinear_bwd_workspace_bytes(int32_t n, int32_t c, int32_t h_in, int32_t w_in) {
-  return (n > 0 && c > 0 && h_in > 0 && w_in > 0) ? (size_t)n * h_in * w_in * cgan_cs(c) * sizeof(float) : 0;
+  (void)n; (void)c; (void)h_in; (void)w_in;
+  return 0;   // the gather form needs none (kept in the ABI: callers size and pass a workspace)
 }
 
 extern "C" int cgan_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
                                              int32_t w_in, int32_t h_out, int32_t w_out, int32_t align_corners,
                                              void* workspace, size_t workspace_bytes, void* stream) {
-  CGAN_REQUIRE(dy && dx && workspace, "resize_bilinear_bwd: null pointer");
+  (void)workspace; (void)workspace_bytes;
+  CGAN_REQUIRE(dy && dx, "resize_bilinear_bwd: null pointer");
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "resize_bilinear_bwd: bad dtype %d", dtype);
   CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "resize_bilinear_bwd: bad shape");
-  const size_t need = cgan_resize_bilinear_bwd_workspace_bytes(n, c, h_in, w_in);
-  CGAN_REQUIRE(workspace_bytes >= need, "resize_bilinear_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, need, s);
-  if (e != hipSuccess) {
-    cgan_set_error("resize_bilinear_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CGAN_ERR_HIP;
-  }
   const int cs = cgan_cs(c);
   float sy, sx;
   if (align_corners) {
@@ -440,12 +458,9 @@ extern "C" int cgan_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int32_t d
     sy = (float)h_in / (float)h_out;
     sx = (float)w_in / (float)w_out;
   }
-  const long total = (long)n * h_out * w_out * (cs / 8);
-  DISPATCH_PT(dtype, bilinear_bwd_scatter_kernel, dim3(grid_pt(total)), dim3(256), 0, s, (const uint16_t*)dy,
-              (float*)workspace, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners, total);
-  const long groups = (long)n * h_in * w_in * (cs / 8);
-  DISPATCH_PT(dtype, f32_to_16_kernel, dim3(grid_pt(groups)), dim3(256), 0, s, (const float*)workspace, (uint16_t*)dx,
-              groups);
+  const long total = (long)n * h_in * w_in * (cs / 8);
+  DISPATCH_PT(dtype, bilinear_bwd_gather_kernel, dim3(grid_pt(total)), dim3(256), 0, s, (const uint16_t*)dy,
+              (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners, total);
   CGAN_CHECK_LAUNCH("resize_bilinear_bwd");
   return CGAN_OK;
 }

@@ -401,7 +401,8 @@ int cgan_affine_sum_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, 
                          void* dx, void* stream);
 
 /* Backward / training-mode pieces of the Masker's graph:
- *  resize_bilinear_bwd   adjoint of cgan_resize_bilinear_nhwc (fp32 atomic accumulation, workspace n*h_in*w_in*cs floats)
+ *  resize_bilinear_bwd   adjoint of cgan_resize_bilinear_nhwc (gather form: every input pixel sums the outputs that read it;
+ *                        no workspace is used any more -- workspace_bytes() returns 0, the arguments are ignored)
  *  maxpool3x3s2_bwd      adjoint of cgan_maxpool3x3s2_nhwc (gradient to the first maximum of each window)
  *  add_act               y = act(a + b): the residual add + ReLU of a bottleneck when BatchNorm cannot be folded
  *                        (climategan/deeplab/resnet101_v3.py:46-48); its backward is cgan_act_bwd on y, to both inputs

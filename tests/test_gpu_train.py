@@ -543,4 +543,4 @@ def test_fp16_loss_scale_is_divided_out():
     for k in g1:
         a, b = g1[k].float(), g64[k].float()
         # same magnitude (not 64x), up to 16-bit rounding; biases in front of an instance norm hold pure rounding noise
-        assert (a - b).abs().max().item() <= 0.1 * a.abs().max().item() + 1e-4 * gmax, k
+        assert (a - b).abs().max().item() <= 0.1 * a.abs().max().item() + 3e-4 * gmax, k
