@@ -177,10 +177,10 @@ class LaunchTimer:
     """Event pairs (recorded on torch's current stream = the stream the library launches on) around selected launches."""
 
     def __init__(self):
-        self.pairs = []          # (event0, event1, flops)
+        self.pairs = []          # (event0, event1, flops, algorithmic bytes)
         self.enabled = False
 
-    def bracket(self, fn, flops):
+    def bracket(self, fn, flops, nbytes=0):
         if not self.enabled:
             return fn()
         e0 = torch.cuda.Event(enable_timing=True)
@@ -188,14 +188,17 @@ class LaunchTimer:
         e0.record()
         out = fn()
         e1.record()
-        self.pairs.append((e0, e1, flops))
+        self.pairs.append((e0, e1, flops, nbytes))
         return out
 
     def total_ms(self):
-        return sum(a.elapsed_time(b) for a, b, _ in self.pairs)
+        return sum(p[0].elapsed_time(p[1]) for p in self.pairs)
 
     def total_flops(self):
-        return sum(f for _, _, f in self.pairs)
+        return sum(p[2] for p in self.pairs)
+
+    def total_bytes(self):
+        return sum(p[3] for p in self.pairs)
 
 
 def install_conv_gemm_timer(timer):
@@ -209,18 +212,26 @@ def install_conv_gemm_timer(timer):
     fwd, bwd, kind = lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_kernel_kind
     GEMM = 2
 
+    def cs8(c):
+        return (c + 7) // 8 * 8
+
+    def alg_bytes(d):
+        # minimum HBM traffic of the conv: input + output (+ residual) once, 16-bit, stored channel counts; + the weights
+        act = d.n * (d.h_in * d.w_in * cs8(d.c_in) + d.h_out * d.w_out * cs8(d.c_out) * (2 if d.has_residual else 1))
+        return 2 * (act + d.c_out * d.c_in * d.kh * d.kw)
+
     def timed_fwd(x, w, b, r, y, dref, stream):
         if timer.enabled and kind(dref, 0) == GEMM:
             d = dref._obj
             return timer.bracket(lambda: fwd(x, w, b, r, y, dref, stream),
-                                 2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw)
+                                 2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw, alg_bytes(d))
         return fwd(x, w, b, r, y, dref, stream)
 
     def timed_bwd(dy, w, dx, dref, stream):
         if timer.enabled and kind(dref, 1) == GEMM:
             d = dref._obj
             return timer.bracket(lambda: bwd(dy, w, dx, dref, stream),
-                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw)
+                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d))
         return bwd(dy, w, dx, dref, stream)
 
     lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data = timed_fwd, timed_bwd
@@ -423,6 +434,7 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
         c, hw = xn.c, (xn.h * (2 if k.get("x_upsample") else 1), xn.w * (2 if k.get("x_upsample") else 1))
         return timer.bracket(lambda: orig(xn, *a, **k), xn.n * hw[0] * hw[1] * 2.0 * (3 * 9 * 128 + 2 * 128 * 9 * c))
 
+
     ops.spade_fused = norms_mod.ops.spade_fused = timed
     out = {}
 
@@ -588,6 +600,7 @@ def main():
                 "traffic_unit": "HBM bytes per launch (mean), from the newest profiles/*_conv_gemm_hbm_pmc.csv: separate "
                                 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction",
                 "algorithmic_flops_per_step": timer.total_flops() / args.steps,
+                "algorithmic_bytes_per_launch": int(timer.total_bytes() / n),
                 "launches_per_step": n // max(args.steps, 1), "avg_launch_ms": round(ms / n, 5),
                 "share_of_step": round(ms / (elapsed * 1e3), 3)}
         else:
