@@ -138,6 +138,8 @@ _SIGNATURES = {
     "cgan_sigmoid_pair_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P]),
     "cgan_softmax_ce_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_float, _P, _P, _P]),
     "cgan_tv_nhwc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
+    "cgan_advent_entropy_pair_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "cgan_advent_entropy_pair_bwd_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
     "cgan_entropy_map_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "cgan_entropy_map_bwd_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "cgan_minent_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P]),

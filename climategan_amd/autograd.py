@@ -106,18 +106,22 @@ class ConvFn(torch.autograd.Function):
             dy = ops.act_bwd(ops.NHWC(y_t, c_out), dy, cfg["act"], cfg["slope"])
         sigma = ctx.sn[0] if ctx.sn is not None else None
         dx_t = dres_t = None
+        pair = cfg.get("pair_in", False)     # x is a (hi | lo) pair map: the conv ran on input-duplicated weights
+        w_eff = torch.cat([weight.detach(), weight.detach()], 1) if pair else weight
         if ctx.needs_input_grad[0]:
             h_in, w_in = (x_t.shape[1] * 2, x_t.shape[2] * 2) if ups else (x_t.shape[1], x_t.shape[2])
-            dx = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], h_in, w_in), stride=cfg["stride"], pad=cfg["pad"],
+            dx = ops.conv2d_bwd_data(dy, w_eff, (x_t.shape[0], h_in, w_in), stride=cfg["stride"], pad=cfg["pad"],
                                      dilation=cfg["dilation"], sigma=sigma, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
             dx_t = (ops.sumpool2x2(dx) if ups else dx).t
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres_t = (ops.sumpool2x2(dy) if cfg.get("residual_upsample", False) else dy).t
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"],
+            dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(w_eff.shape), stride=cfg["stride"],
                                            pad=cfg["pad"], dilation=cfg["dilation"], want_bias=ctx.has_bias,
                                            in_upsample=ups, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+            if pair:
+                dw = dw[:, :weight.shape[1]] + dw[:, weight.shape[1]:]
             if ctx.sn is not None:
                 dw = ops.spectral_norm_bwd(dw, weight.detach(), ctx.sn[1], ctx.sn[2], ctx.sn[0])
         return dx_t, dw, db, dres_t, None, None, None
@@ -475,6 +479,31 @@ class EntropyMapFn(torch.autograd.Function):
         _call("cgan_entropy_map_bwd_nhwc", ops._ptr(p_t), ops._ptr(depth_t), ops._ptr(dy.contiguous()), ops._ptr(dp),
               ops._DT[p_t.dtype], _npix(p_t), ctx.c, ops._stream())
         return dp, None, None
+
+
+class AdventPairFn(torch.autograd.Function):
+    """The ADVENT discriminators' input from the logits: prob_2_entropy(softmax(s)) [* depth], or of the mask's
+    cat[sigmoid(x), 1 - sigmoid(x)], evaluated in fp32 and stored as a (hi | lo) 16-bit pair with 2C channels
+    (``cgan_advent_entropy_pair_nhwc``); the first discriminator conv takes it with duplicated weights (ConvFn
+    ``pair_in``).  One 16-bit entropy value is coarser than the signal an untrained prediction carries."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, sigmoid_pair, depth_t):
+        C = 2 if sigmoid_pair else c
+        y = torch.empty(x_t.shape[:-1] + (ops.cs8(2 * C),), dtype=x_t.dtype, device=x_t.device)
+        _call("cgan_advent_entropy_pair_nhwc", ops._ptr(x_t), ops._ptr(depth_t), ops._ptr(y), ops._DT[x_t.dtype],
+              _npix(x_t), c, int(sigmoid_pair), ops._stream())
+        ctx.c, ctx.sig = c, int(sigmoid_pair)
+        ctx.save_for_backward(x_t, depth_t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_t, depth_t = ctx.saved_tensors
+        dx = torch.empty_like(x_t)
+        _call("cgan_advent_entropy_pair_bwd_nhwc", ops._ptr(x_t), ops._ptr(depth_t), ops._ptr(dy.contiguous()),
+              ops._ptr(dx), ops._DT[x_t.dtype], _npix(x_t), ctx.c, ctx.sig, ops._stream())
+        return dx, None, None, None
 
 
 class _ScalarLossFn(torch.autograd.Function):

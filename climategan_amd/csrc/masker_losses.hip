@@ -155,6 +155,77 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(const uint16_t* __rest
     dp[i] = bits_of<T>(v);
   }
 }
+// ---- the ADVENT discriminators' input straight from the logits, as a 16-bit PAIR --------------------------------------
+// ent(softmax(s)) [* depth] (trainer.py:1433, 1455-1456, losses.py:453-458, 517-519), or ent([sigmoid(x), 1 - sigmoid(x)])
+// for the mask (trainer.py:1533-1534), evaluated in fp32 from the 16-bit logits and stored as hi = round16(v),
+// lo = round16(v - hi) in channels [0, C) and [C, 2C) of the output.  An untrained prediction has p ~ 1/C, i.e.
+// ent = const - O((p - 1/C)^2): one 16-bit value (8 or 11 significant bits) is coarser than the signal the discriminator
+// is meant to see.  The discriminator's first conv runs on the 2C channels with its weights duplicated.
+constexpr int ADV_MAXC = 16;
+template <typename T, bool SIGMOID>
+__device__ __forceinline__ int advent_probs(const uint16_t* __restrict__ xp, int c, float* pr) {
+  if (SIGMOID) {
+    const float x = f32_of_bits<T>(xp[0]);
+    pr[0] = 1.f / (1.f + __expf(-x));
+    pr[1] = 1.f / (1.f + __expf(x));
+    return 2;
+  }
+  float mx = -__builtin_inff();
+  for (int k = 0; k < c; ++k) mx = fmaxf(mx, f32_of_bits<T>(xp[k]));
+  float sum = 0.f;
+  for (int k = 0; k < c; ++k) {
+    pr[k] = __expf(f32_of_bits<T>(xp[k]) - mx);
+    sum += pr[k];
+  }
+  const float inv = 1.f / sum;
+  for (int k = 0; k < c; ++k) pr[k] *= inv;
+  return c;
+}
+template <typename T, bool SIGMOID>
+__global__ __launch_bounds__(256) void advent_pair_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ depth,
+                                                              uint16_t* __restrict__ y, int c, int cs_in, int cs_out,
+                                                              long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float pr[ADV_MAXC];
+    const int C = advent_probs<T, SIGMOID>(x + i * cs_in, c, pr);
+    const float ilc = 1.f / log2f((float)C);
+    const float dv = depth ? f32_of_bits<T>(depth[i * 8]) : 1.f;
+    uint16_t* yp = y + i * cs_out;
+    for (int k = 0; k < C; ++k) {
+      const float v = ent(pr[k], ilc) * dv;
+      const uint16_t hi = bits_of<T>(v);
+      yp[k] = hi;
+      yp[C + k] = bits_of<T>(v - f32_of_bits<T>(hi));
+    }
+    for (int k = 2 * C; k < cs_out; ++k) yp[k] = 0;
+  }
+}
+// d(logits) from d(pair): the hi and the lo half of d(pair) are the same data gradient (duplicated weights): the hi half
+// is read.  softmax: dl_j = p_j (g_j - sum_i g_i p_i), g_i = dy_i ent'(p_i) depth; sigmoid pair: dx = p (1 - p)(g_0 - g_1)
+template <typename T, bool SIGMOID>
+__global__ __launch_bounds__(256) void advent_pair_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ depth,
+                                                              const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+                                                              int c, int cs_in, int cs_out, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float pr[ADV_MAXC], g[ADV_MAXC];
+    const int C = advent_probs<T, SIGMOID>(x + i * cs_in, c, pr);
+    const float ilc = 1.f / log2f((float)C);
+    const float dv = depth ? f32_of_bits<T>(depth[i * 8]) : 1.f;
+    float dot = 0.f;
+    for (int k = 0; k < C; ++k) {
+      g[k] = f32_of_bits<T>(dy[i * cs_out + k]) * ent_grad(pr[k], ilc) * dv;
+      dot += g[k] * pr[k];
+    }
+    uint16_t* dp = dx + i * cs_in;
+    if (SIGMOID) {
+      dp[0] = bits_of<T>(pr[0] * pr[1] * (g[0] - g[1]));
+      for (int k = 1; k < cs_in; ++k) dp[k] = 0;
+    } else {
+      for (int k = 0; k < cs_in; ++k) dp[k] = k < c ? bits_of<T>(pr[k] * (g[k] - dot)) : 0;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void minent_sum_kernel(const uint16_t* __restrict__ p, float* __restrict__ sum, int c,
                                                          int cs, long total) {
@@ -238,6 +309,11 @@ __global__ __launch_bounds__(256) void affine_sum_kernel(const uint16_t* __restr
     if ((dtype) == CGAN_F16) hipLaunchKernelGGL(KERNEL<F16>, __VA_ARGS__);  \
     else hipLaunchKernelGGL(KERNEL<BF16>, __VA_ARGS__);                     \
   } while (0)
+#define ML_DISPATCH2(dtype, KERNEL, FLAG, ...)                                  \
+  do {                                                                          \
+    if ((dtype) == CGAN_F16) hipLaunchKernelGGL((KERNEL<F16, FLAG>), __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<BF16, FLAG>), __VA_ARGS__);                 \
+  } while (0)
 #define ML_CHECK_DT(name) CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, name ": bad dtype %d", dtype)
 
 extern "C" int cgan_softmax_nhwc(const void* x, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream) {
@@ -311,6 +387,39 @@ extern "C" int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const
   ML_DISPATCH(dtype, entropy_bwd_kernel, dim3(grid_ml(npix * cs)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)p,
               (const uint16_t*)depth, (const uint16_t*)dy, (uint16_t*)dp, c, cs, (long)npix * cs);
   CGAN_CHECK_LAUNCH("entropy_map_bwd");
+  return CGAN_OK;
+}
+extern "C" int cgan_advent_entropy_pair_nhwc(const void* logits, const void* depth, void* y, int32_t dtype, int64_t npix,
+                                             int32_t c, int32_t sigmoid_pair, void* stream) {
+  CGAN_REQUIRE(logits && y && npix > 0, "advent_entropy_pair: bad arguments");
+  CGAN_REQUIRE(sigmoid_pair ? c == 1 : (c > 1 && c <= ADV_MAXC), "advent_entropy_pair: %d channels (softmax: 2..%d, sigmoid pair: 1)",
+               c, ADV_MAXC);
+  ML_CHECK_DT("advent_entropy_pair");
+  const int C = sigmoid_pair ? 2 : c;
+  if (sigmoid_pair)
+    ML_DISPATCH2(dtype, advent_pair_fwd_kernel, true, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream,
+                 (const uint16_t*)logits, (const uint16_t*)depth, (uint16_t*)y, c, cgan_cs(c), cgan_cs(2 * C), (long)npix);
+  else
+    ML_DISPATCH2(dtype, advent_pair_fwd_kernel, false, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream,
+                 (const uint16_t*)logits, (const uint16_t*)depth, (uint16_t*)y, c, cgan_cs(c), cgan_cs(2 * C), (long)npix);
+  CGAN_CHECK_LAUNCH("advent_entropy_pair");
+  return CGAN_OK;
+}
+extern "C" int cgan_advent_entropy_pair_bwd_nhwc(const void* logits, const void* depth, const void* dy, void* dlogits,
+                                                 int32_t dtype, int64_t npix, int32_t c, int32_t sigmoid_pair, void* stream) {
+  CGAN_REQUIRE(logits && dy && dlogits && npix > 0, "advent_entropy_pair_bwd: bad arguments");
+  CGAN_REQUIRE(sigmoid_pair ? c == 1 : (c > 1 && c <= ADV_MAXC), "advent_entropy_pair_bwd: %d channels", c);
+  ML_CHECK_DT("advent_entropy_pair_bwd");
+  const int C = sigmoid_pair ? 2 : c;
+  if (sigmoid_pair)
+    ML_DISPATCH2(dtype, advent_pair_bwd_kernel, true, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream,
+                 (const uint16_t*)logits, (const uint16_t*)depth, (const uint16_t*)dy, (uint16_t*)dlogits, c, cgan_cs(c),
+                 cgan_cs(2 * C), (long)npix);
+  else
+    ML_DISPATCH2(dtype, advent_pair_bwd_kernel, false, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream,
+                 (const uint16_t*)logits, (const uint16_t*)depth, (const uint16_t*)dy, (uint16_t*)dlogits, c, cgan_cs(c),
+                 cgan_cs(2 * C), (long)npix);
+  CGAN_CHECK_LAUNCH("advent_entropy_pair_bwd");
   return CGAN_OK;
 }
 extern "C" int cgan_minent_nhwc(const void* p, int32_t dtype, int64_t npix, int32_t c, int32_t version, float lambda_var,

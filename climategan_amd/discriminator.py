@@ -199,6 +199,9 @@ class FCDiscriminator(nn.Sequential):
         y = input if isinstance(input, ops.NHWC) else ops.nchw_to_nhwc(input, self.compute_dtype)
         for i, idx in enumerate((0, 2, 4, 6, 8)):
             cache = self._caches.setdefault(idx, _PackCache())
+            if i == 0 and y.c == 2 * self._in_channels():
+                y = self._first_conv_on_pair(y)
+                continue
             if isinstance(self[idx], SpectralNorm):
                 self[idx].trainable = True
                 y = conv_forward(self[idx], cache, y, act=ops.ACT_LRELU if i < 4 else ops.ACT_NONE, slope=0.2)
@@ -206,6 +209,36 @@ class FCDiscriminator(nn.Sequential):
                 y = conv_forward(self[idx], cache, y, act=ops.ACT_LRELU if i < 4 else ops.ACT_NONE, slope=0.2,
                                  trainable=True)
         return y if nhwc else _to_nchw(y, self, input.dtype if torch.is_tensor(input) else None)
+
+
+    def _in_channels(self):
+        m = self[0].module if isinstance(self[0], SpectralNorm) else self[0]
+        return m.in_channels
+
+    def _first_conv_on_pair(self, y: ops.NHWC) -> ops.NHWC:
+        """The first conv on a (hi | lo) pair map (losses.advent_input): conv(hi + lo) = conv([hi | lo], [w | w]).  The
+        power iteration of this forward has run (spectral_norm_step_all); its sigma scales the duplicated weights."""
+        from .norms import _conv_train, needs_grad
+
+        sn = self[0] if isinstance(self[0], SpectralNorm) else None
+        m = sn.module if sn is not None else self[0]
+        w = getattr(m, sn.name + "_bar") if sn is not None else m.weight
+        sigma = snap = None
+        if sn is not None:
+            sn.packed(y.t.dtype)                                 # consumes the batched step's result (or iterates)
+            sigma = sn._sigma
+            snap, sn._sn_snapshot = sn._sn_snapshot, None
+            owned = sn._pre_used and snap is not None
+            if not owned:
+                snap = (sn._sigma, getattr(m, sn.name + "_u").data, getattr(m, sn.name + "_v").data)
+        pw = ops.pack_conv_weight(torch.cat([w.data, w.data], 1), m.bias.data if m.bias is not None else None,
+                                  y.t.dtype, sigma)
+        kw = dict(act=ops.ACT_LRELU, slope=0.2)
+        if needs_grad(m, y.t):
+            kw.update(pair_in=True, sn_owned=bool(sn is not None and owned))
+            return _conv_train(y, w, m.bias, pw, snap if sn is not None else None, m.stride[0], m.padding[0],
+                               m.dilation[0], kw)
+        return ops.conv2d(y, pw, stride=m.stride[0], pad=m.padding[0], dilation=m.dilation[0], **kw)
 
 
 def get_fc_discriminator(num_classes=2, ndf=64, use_norm=False):

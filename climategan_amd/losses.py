@@ -256,6 +256,17 @@ def prob_2_entropy(prob, depth=None):
     return ops.NHWC(y, prob.c)
 
 
+def advent_input(logits, depth=None, sigmoid_pair=False):
+    """prob_2_entropy(softmax(logits)) [* depth] -- or, ``sigmoid_pair``, prob_2_entropy(cat[sigmoid(x), 1 - sigmoid(x)])
+    of the 1-channel mask logits -- as the (hi | lo) 16-bit pair map the ADVENT discriminators take (2C channels;
+    ``FCDiscriminator`` recognises it by the channel count).  Same function of the logits as the reference's
+    ``prob_2_entropy(prob)`` (losses.py:453-458, 517-519), without the 16-bit round trips through prob and entropy."""
+    logits = _as_nhwc(logits, "advent_input")
+    C = 2 if sigmoid_pair else logits.c
+    y = ag.AdventPairFn.apply(logits.t, logits.c, bool(sigmoid_pair), depth.t if depth is not None else None)
+    return ops.NHWC(y, 2 * C)
+
+
 def softmax(logits):
     """torch.softmax(s, dim=1) on an NHWC map (trainer.py:1433)."""
     logits = _as_nhwc(logits, "softmax")
@@ -292,10 +303,16 @@ class ADVENTAdversarialLoss(nn.Module):
         self.opts = opts
         self.bce = CustomBCELoss() if gan_type == "GAN" else None
 
-    def __call__(self, prediction, target, discriminator, depth_preds=None):
-        d_in = prob_2_entropy(prediction, depth_preds)
+    def __call__(self, prediction, target, discriminator, depth_preds=None, logits=None, sigmoid_pair=False):
+        """``logits`` (the trainer passes them): the discriminator's input is computed from the logits in fp32 and handed
+        over as a 16-bit pair (``advent_input``); ``prediction`` (the probabilities) is then unused.  Without ``logits``:
+        the reference's call signature, through 16-bit probability and entropy maps."""
         if self.opts.dis.m.architecture == "OmniDiscriminator":
             raise NotImplementedError("ADVENT with the OmniDiscriminator architecture has no HIP path (default: base)")
+        if logits is not None:
+            d_in = advent_input(logits, depth_preds, sigmoid_pair)
+        else:
+            d_in = prob_2_entropy(prediction, depth_preds)
         d_out = discriminator(d_in, nhwc=True)
         if self.bce is not None:
             return self.bce(d_out, target)

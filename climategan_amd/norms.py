@@ -42,7 +42,7 @@ def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw
     cfg = dict(c_in=x.c, stride=stride, pad=pad, dilation=dilation, act=kw.get("act", ops.ACT_NONE),
                slope=kw.get("slope", 0.2), in_upsample=bool(kw.get("in_upsample", False)),
                residual_upsample=bool(kw.get("residual_upsample", False)), pad_mode=pad_mode,
-               sn_owned=bool(kw.get("sn_owned", False)))
+               sn_owned=bool(kw.get("sn_owned", False)), pair_in=bool(kw.get("pair_in", False)))
     y_t = ConvFn.apply(x.t, weight, bias, res.t if res is not None else None, packed, cfg, sn)
     return ops.NHWC(y_t, weight.shape[0])
 

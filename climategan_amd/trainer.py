@@ -233,9 +233,9 @@ class Trainer:
             else:
                 label, loss_func, w = "s", self.losses["G"]["tasks"]["s"]["advent"], o.train.lambdas.G["s"]["advent"]
             if (for_ == "D" or domain == "r") and w != 0:
-                if softmax_preds is None:
-                    softmax_preds = L.softmax(pred)
-                loss = loss_func(softmax_preds, self.domain_labels[label], self.D["s"]["Advent"], dp) * w
+                # the discriminator's input is computed from the logits (losses.advent_input): same function as
+                # prob_2_entropy(softmax(pred)) * depth, trainer.py:1433, 1455-1456
+                loss = loss_func(softmax_preds, self.domain_labels[label], self.D["s"]["Advent"], dp, logits=pred) * w
                 self.loss_log["%s.s.advent.%s" % (for_, domain)] = loss.detach()
                 full_loss = full_loss + loss
         return full_loss, pred
@@ -285,7 +285,8 @@ class Trainer:
                 label, loss_func = "s", self.losses["G"]["tasks"]["m"]["advent"]
             w = o.train.lambdas.advent.adv_main
             if (for_ == "D" or domain == "r") and w != 0:
-                loss = loss_func(prob, self.domain_labels[label], self.D["m"]["Advent"], None) * w
+                loss = loss_func(prob, self.domain_labels[label], self.D["m"]["Advent"], None, logits=logits,
+                                 sigmoid_pair=True) * w
                 self.loss_log["%s.m.advent.%s" % (for_, domain)] = loss.detach()
                 full_loss = full_loss + loss
         return full_loss, prob
@@ -403,18 +404,15 @@ class Trainer:
         return total
 
     def _advent_d_term(self, task, pred, depth_preds, domain):
-        from . import losses as L
-
         w = self.opts.train.lambdas.advent.adv_main
-        if task == "s":
-            prob = L.softmax(ops.NHWC(pred.t.detach(), pred.c))
-            dp = ops.NHWC(depth_preds.t.detach(), depth_preds.c) if (self.opts.gen.s.use_dada and depth_preds is not None) else None
-        else:
-            prob = L.sigmoid_pair(ops.NHWC(pred.t.detach(), pred.c))
-            dp = None
-        loss = self.losses["D"]["advent"](prob, self.domain_labels[domain], self.D[task]["Advent"], dp) * w
+        logits = ops.NHWC(pred.t.detach(), pred.c)
+        dp = None
+        if task == "s" and self.opts.gen.s.use_dada and depth_preds is not None:
+            dp = ops.NHWC(depth_preds.t.detach(), depth_preds.c)
+        loss = self.losses["D"]["advent"](None, self.domain_labels[domain], self.D[task]["Advent"], dp, logits=logits,
+                                          sigmoid_pair=task == "m") * w
         self.loss_log["D.%s.advent.%s" % (task, domain)] = loss.detach()
-        return loss, prob
+        return loss, None
 
     def _check_batch(self, multi_domain_batch):
         if not self.has_painter and "rf" in multi_domain_batch:

@@ -388,6 +388,16 @@ int cgan_softmax_ce_nhwc(const void* logits, const int64_t* target, int32_t dtyp
                          float* loss_accum, void* dlogits, void* stream);
 int cgan_tv_nhwc(const void* x, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, float weight_h, float weight_w,
                  float* loss_accum, void* dx, void* stream);
+/* The ADVENT discriminators' input from the LOGITS (round 2): prob_2_entropy(softmax(s)) [* depth] (trainer.py:1433,
+ * 1455-1456, losses.py:453-458, 517-519; c = 2..16 logit channels) or, with sigmoid_pair, prob_2_entropy(cat[sigmoid(x),
+ * 1 - sigmoid(x)]) of the 1-channel mask logits (trainer.py:1533-1534), evaluated in fp32 and written as a 16-bit pair:
+ * channels [0, C) = round16(v), [C, 2C) = round16(v - hi) of an NHWC map with 2C channels (C = c, or 2).  The
+ * discriminator's first conv runs on it with input-duplicated weights.  _bwd: dlogits from the gradient of the pair map
+ * (its first C channels are read: both halves carry the same data gradient). */
+int cgan_advent_entropy_pair_nhwc(const void* logits, const void* depth, void* y, int32_t dtype, int64_t npix, int32_t c,
+                                  int32_t sigmoid_pair, void* stream);
+int cgan_advent_entropy_pair_bwd_nhwc(const void* logits, const void* depth, const void* dy, void* dlogits, int32_t dtype,
+                                      int64_t npix, int32_t c, int32_t sigmoid_pair, void* stream);
 int cgan_entropy_map_nhwc(const void* p, const void* depth, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream);
 int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const void* dy, void* dp, int32_t dtype, int64_t npix,
                               int32_t c, void* stream);

@@ -176,3 +176,97 @@ def test_get_losses_selects_hinge():
     assert isinstance(ls["G"]["p"]["gan"], L.HingeLoss) and ls["D"]["p"] is ls["G"]["p"]["gan"]
     o.gen.p.loss = "gan"
     assert isinstance(L.get_losses(o, 0, "cuda")["G"]["p"]["gan"], L.GANLoss)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_advent_input_pair_from_logits(dt):
+    """losses.advent_input: the ADVENT discriminators' input from the logits as a (hi | lo) pair.  hi + lo must equal
+    prob_2_entropy(softmax(s)) * depth (and the mask form) of the SAME 16-bit logits to ~2^-16 (bf16) / 2^-21 (fp16) of the
+    value -- one 16-bit entropy map would be off by 2^-9 / 2^-12 -- and agree with the reference's tensor (fp32 logits)
+    within the logits' own rounding; the backward reads d(pair)'s hi half."""
+    from climategan_amd import losses as L, ops
+    from oracle import cpu_ref
+
+    case = golden_cases()[NAME]
+    gold = load_golden(NAME)
+    inp = case_inputs(NAME, case)
+    s = ops.nchw_to_nhwc(t(inp["s_logits"]).cuda(), dt)
+    s.t.requires_grad_(True)
+    d = ops.nchw_to_nhwc(t(inp["d_pred"]).cuda(), dt)
+    pair = L.advent_input(s, d)
+    C = s.c
+    assert pair.c == 2 * C
+    got = (pair.t[..., :C].float() + pair.t[..., C:2 * C].float()).permute(0, 3, 1, 2).cpu()
+    assert (pair.t[..., 2 * C:] == 0).all()
+    s16 = ops.nhwc_to_nchw(ops.NHWC(s.t.detach(), C)).float().cpu().requires_grad_(True)
+    d16 = ops.nhwc_to_nchw(ops.NHWC(d.t, 1)).float().cpu()
+    ref = cpu_ref.prob_2_entropy(torch.softmax(s16, 1)) * d16
+    lo_ulp = 2.0 ** -16 if dt == torch.bfloat16 else 2.0 ** -21
+    err = (got - ref.detach()).abs().max().item()
+    single = (pair.t[..., :C].float().permute(0, 3, 1, 2).cpu() - ref.detach()).abs().max().item()
+    print("\nadvent pair %s: |hi + lo - ref| max %.3g (hi alone %.3g), scale %.3g" % (dt, err, single, ref.abs().max().item()))
+    assert err <= 2 * lo_ulp * ref.abs().max().item() + 2e-6          # + the fast exp / log2 of the kernel
+    assert np.abs(got.numpy() - gold["entropy_dada"]).max() <= (3e-2 if dt == torch.bfloat16 else 4e-3) * np.abs(gold["entropy_dada"]).max()
+    # backward: upstream gradient on both halves (the data gradient of a conv with duplicated weights); only hi is read
+    up = torch.zeros_like(pair.t)
+    g = torch.randn(pair.t.shape[:-1] + (C,), device="cuda").to(dt)
+    up[..., :C] = g
+    up[..., C:2 * C] = g
+    pair.t.backward(up)
+    (ref * g.float().permute(0, 3, 1, 2).cpu()).sum().backward()
+    mine = ops.nhwc_to_nchw(ops.NHWC(s.t.grad, C)).float().cpu()
+    tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert (mine - s16.grad).abs().max().item() <= 2 * tol * s16.grad.abs().max().item()
+
+    # the mask form: cat[sigmoid(x), 1 - sigmoid(x)] -> entropy, C = 2
+    m = ops.nchw_to_nhwc(t(inp["m_logits"]).cuda(), dt)
+    m.t.requires_grad_(True)
+    pair = L.advent_input(m, None, sigmoid_pair=True)
+    assert pair.c == 4
+    got = (pair.t[..., :2].float() + pair.t[..., 2:4].float()).permute(0, 3, 1, 2).cpu()
+    m16 = ops.nhwc_to_nchw(ops.NHWC(m.t.detach(), 1)).float().cpu().requires_grad_(True)
+    p = torch.sigmoid(m16)
+    ref = cpu_ref.prob_2_entropy(torch.cat([p, 1 - p], 1))
+    assert (got - ref.detach()).abs().max().item() <= 2 * lo_ulp * ref.abs().max().item() + 2e-6
+    g = torch.randn(pair.t.shape[:-1] + (2,), device="cuda").to(dt)
+    up = torch.zeros_like(pair.t)
+    up[..., :2] = g
+    up[..., 2:4] = g
+    pair.t.backward(up)
+    (ref * g.float().permute(0, 3, 1, 2).cpu()).sum().backward()
+    mine = ops.nhwc_to_nchw(ops.NHWC(m.t.grad, 1)).float().cpu()
+    assert (mine - m16.grad).abs().max().item() <= 2 * tol * m16.grad.abs().max().item()
+
+
+def test_fc_discriminator_on_pair_matches_single_map():
+    """FCDiscriminator on the (hi | lo) pair = the same network on hi + lo: for an input whose lo half is zero the two
+    forwards and all gradients agree bit for bit up to the wgrad summation order; spectral-norm state advances once."""
+    from climategan_amd import ops
+    from climategan_amd.discriminator import get_fc_discriminator
+
+    torch.manual_seed(0)
+    dt = torch.float16
+    for use_norm in (True, False):
+        D = get_fc_discriminator(num_classes=3, use_norm=use_norm).cuda()
+        D.compute_dtype = dt
+        D2 = get_fc_discriminator(num_classes=3, use_norm=use_norm).cuda()
+        D2.compute_dtype = dt
+        D2.load_state_dict(D.state_dict())
+        x = torch.rand(2, 3, 64, 64, device="cuda")
+        single = ops.nchw_to_nhwc(x, dt)
+        pair_t = torch.zeros(2, 64, 64, 8, device="cuda", dtype=dt)
+        pair_t[..., :3] = single.t[..., :3]
+        single.t.requires_grad_(True)
+        pair_t.requires_grad_(True)
+        y1 = D(single, nhwc=True)
+        y2 = D2(ops.NHWC(pair_t, 6), nhwc=True)
+        assert torch.equal(y1.t, y2.t)
+        y1.t.float().sum().backward()
+        y2.t.float().sum().backward()
+        assert torch.equal(single.t.grad[..., :3], pair_t.grad[..., :3])
+        assert torch.equal(pair_t.grad[..., :3], pair_t.grad[..., 3:6])
+        for (k, p1), (_, p2) in zip(D.named_parameters(), D2.named_parameters()):
+            assert torch.equal(p1.data, p2.data), k                       # u, v advanced identically
+            if p1.grad is not None:
+                scale = p1.grad.abs().max().item() + 1e-12
+                assert (p1.grad - p2.grad).abs().max().item() <= 1e-5 * scale, k
