@@ -17,6 +17,17 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CGAN_BF
 _DT = {torch.float16: CGAN_F16, torch.bfloat16: CGAN_BF16}
 
 
+def touch(*tensors) -> None:
+    """Tell torch that these tensors were modified in place.  The HIP kernels write module state (parameters in the
+    optimizer, BatchNorm running statistics) through raw pointers; the packed-weight caches (norms._PackCache) key on
+    ``tensor._version``, so every such write must bump it -- without this the forward keeps using the weights packed
+    before the first optimizer step.  No kernel launch.  Pass the module's own tensor objects, not ``.data`` aliases
+    (those carry their own counter)."""
+    ts = [t for t in tensors if t is not None]
+    if ts:
+        torch.autograd.graph.increment_version(ts)
+
+
 def cs8(c: int) -> int:
     return (c + 7) & ~7
 
@@ -344,6 +355,7 @@ def batchnorm_train_stats(x: NHWC, gamma, beta, running_mean, running_var, num_b
         _ptr(x.t), _ptr(gamma), _ptr(beta), float(momentum), _ptr(running_mean), _ptr(running_var),
         _ptr(num_batches_tracked), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), C.byref(d), _ptr(ws),
         ws_bytes, _stream()), "cgan_batchnorm_train_stats")
+    touch(running_mean, running_var, num_batches_tracked)
     return stats[0], stats[1], stats[2], stats[3]
 
 

@@ -13,7 +13,7 @@ from torch.optim import Optimizer
 
 from . import _lib
 from ._lib import AdamItem
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, touch
 
 
 class ExtraAdam(Optimizer):
@@ -80,6 +80,9 @@ class ExtraAdam(Optimizer):
                                                             int(mode == 0 and not self._has_copy), step, group["lr"],
                                                             beta1, beta2, group["eps"], group["weight_decay"],
                                                             _stream()), "cgan_extra_adam_multi_tensor")
+                # the kernel wrote the parameters through raw pointers: bump their version counters, or every cached
+                # packed weight (norms._PackCache keys on them) stays the one packed before this update
+                touch(*ps)
 
     @torch.no_grad()
     def extrapolation(self):

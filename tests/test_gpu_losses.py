@@ -206,7 +206,7 @@ def test_advent_input_pair_from_logits(dt):
     single = (pair.t[..., :C].float().permute(0, 3, 1, 2).cpu() - ref.detach()).abs().max().item()
     print("\nadvent pair %s: |hi + lo - ref| max %.3g (hi alone %.3g), scale %.3g" % (dt, err, single, ref.abs().max().item()))
     assert err <= 2 * lo_ulp * ref.abs().max().item() + 2e-6          # + the fast exp / log2 of the kernel
-    assert np.abs(got.numpy() - gold["entropy_dada"]).max() <= (3e-2 if dt == torch.bfloat16 else 4e-3) * np.abs(gold["entropy_dada"]).max()
+    assert np.abs(got.detach().numpy() - gold["entropy_dada"]).max() <= (3e-2 if dt == torch.bfloat16 else 4e-3) * np.abs(gold["entropy_dada"]).max()
     # backward: upstream gradient on both halves (the data gradient of a conv with duplicated weights); only hi is read
     up = torch.zeros_like(pair.t)
     g = torch.randn(pair.t.shape[:-1] + (C,), device="cuda").to(dt)

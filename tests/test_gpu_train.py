@@ -381,6 +381,40 @@ def test_masker_train_step_runs():
     assert not torch.equal(T.D["s"]["Advent"][0].module.weight_bar.detach(), dw0)
 
 
+def test_forward_uses_the_parameters_the_optimizer_wrote():
+    """The HIP optimizer and the BatchNorm kernels write parameters / running statistics through raw pointers; the
+    packed-weight caches key on ``tensor._version``.  After train steps the trained modules' forward must equal, bit for
+    bit, the forward of FRESH modules (empty caches) loaded from their state dict -- in training mode (packed conv
+    weights) and in eval mode (BatchNorm folded from the running statistics)."""
+    from climategan_amd.generator import create_generator
+
+    case = golden_cases()[MNAME]
+    T = build_masker_trainer(case)
+    batch = masker_batch(case)
+    x = batch["r"]["data"]["x"]
+    with torch.no_grad():
+        before = {k: v.clone() for k, v in T.G.masker_forward(x).items()}
+    for _ in range(2):
+        T.train_step(batch)
+    sd = {k: v.detach().clone() for k, v in T.G.state_dict().items()}
+    fresh = create_generator(T.opts, device="cuda", no_init=True)
+    fresh.load_state_dict(sd)
+    fresh.set_compute_dtype(torch.bfloat16)
+    fresh.decoders["d"]._target_size = case["W"] // 4
+    fresh.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
+    for mode in ("train", "eval"):
+        getattr(T.G, mode)()
+        getattr(fresh, mode)()
+        T.G.load_state_dict(sd)            # both start from the same running statistics / spectral-norm vectors
+        fresh.load_state_dict(sd)
+        with torch.no_grad():
+            outs = [G.masker_forward(x) for G in (T.G, fresh)]
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (mode, k, (outs[0][k] - outs[1][k]).abs().max().item())
+        if mode == "train":                # and the update is visible in the output at all
+            assert all(not torch.equal(outs[0][k], before[k]) for k in before)
+
+
 def test_masker_spade_decoder_train_step():
     """The SPADE mask decoder (gen.m.use_spade, batch-norm SPADE blocks conditioned on the DETACHED depth / seg / image
     map) trains: two update_G + update_D steps, finite losses, the decoder's parameters and its BatchNorm running
