@@ -17,7 +17,6 @@ import torch.nn.functional as F
 ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import test_gpu_configs_640 as TG            # noqa: E402
-from test_oracle_joint_step import _shapes    # noqa: E402
 from climategan_amd import fill, losses as L, ops   # noqa: E402
 from helpers import t                          # noqa: E402
 from oracle import cpu_ref                     # noqa: E402
@@ -74,13 +73,14 @@ def hybrid_grads(call_list):
 keys, hybrid = hybrid_grads(calls)
 
 # oracle: the full fp32 step
-gs, ds = _shapes(case)
+gs = {k: tuple(v.shape) for k, v in T.G.state_dict().items()}
+ds = {k: tuple(v.shape) for k, v in T.D.state_dict().items()}
 sd_g = {k: t(v) for k, v in generator_fill(gs, case).items()}
 sd_d = {k: t(v) for k, v in fill.fill_state_dict(ds, case["seed"] + 1).items()}
 sd_v = {k: t(v) for k, v in fill.fill_state_dict(cpu_ref.vgg19_shapes(), case["vgg_seed"], gain=case["vgg_gain"]).items()}
 cb = {dom: {k: t(v) for k, v in d.items()} for dom, d in jstep_inputs(case).items()}
-torch.set_num_threads(16)
-out = cpu_ref.joint_train_step(sd_g, sd_d, sd_v, cb, case["n_up"], 3, case["n_layers"])
+torch.set_num_threads(32)
+out = cpu_ref.joint_train_step(sd_g, sd_d, sd_v, cb, case.get("n_up", 7), 3, case.get("n_layers", 4))
 oracle = out["d_grads"]
 
 

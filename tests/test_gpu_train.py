@@ -403,10 +403,11 @@ def test_forward_uses_the_parameters_the_optimizer_wrote():
     fresh.decoders["d"]._target_size = case["W"] // 4
     fresh.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
     for mode in ("train", "eval"):
+        # no load_state_dict into T.G here: copy_ would bump the version counters and hide a stale cache.  Both
+        # generators go through the same sequence of forwards from the same state, so their running statistics and
+        # spectral-norm vectors stay identical.
         getattr(T.G, mode)()
         getattr(fresh, mode)()
-        T.G.load_state_dict(sd)            # both start from the same running statistics / spectral-norm vectors
-        fresh.load_state_dict(sd)
         with torch.no_grad():
             outs = [G.masker_forward(x) for G in (T.G, fresh)]
         for k in outs[0]:
