@@ -126,3 +126,43 @@ for vn, cl in variants.items():
     _, hv = hybrid_grads(cl + m_calls)
     cs = [cos(hv[k], oracle[k]) for k in keys if k.startswith("s.") and k in hv and float(oracle[k].norm()) > 1e-3]
     print("%-32s cos(hybrid, oracle) over D.s tensors: median %.4f min %.4f" % (vn, sorted(cs)[len(cs) // 2], min(cs)))
+
+# the discriminators' own 16-bit pipeline: which rounding costs the direction?  fp32 discriminator on the captured
+# inputs with (a) conv WEIGHTS rounded to bf16 per call (what any bf16 MFMA path does: w_bar / sigma differs between the
+# two domain calls, so the rounding differs too), (b) LeakyReLU outputs and the gradients through them rounded to bf16
+real_conv2d, real_lrelu = F.conv2d, F.leaky_relu
+rq = lambda v: v.to(torch.bfloat16).float()
+
+
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return rq(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return rq(g)
+
+
+def run_variant(wq, aq):
+    F.conv2d = (lambda x, w, *a, **k: real_conv2d(x, w + (rq(w) - w).detach(), *a, **k)) if wq else real_conv2d
+    F.leaky_relu = (lambda x, *a, **k: _RoundGrad.apply(real_lrelu(x, *a, **k))) if aq else real_lrelu
+    try:
+        return hybrid_grads(calls)[1]
+    finally:
+        F.conv2d, F.leaky_relu = real_conv2d, real_lrelu
+
+
+for vn, (wq, aq) in {"weights bf16": (True, False), "activations + gradients bf16": (False, True), "both": (True, True)}.items():
+    hv = run_variant(wq, aq)
+    for task in ("m", "s"):
+        cs = [cos(hv[k], hybrid[k]) for k in keys if k.startswith(task + ".") and float(hybrid[k].norm()) > 1e-3]
+        cm = [cos(hv[k], mine[k]) for k in keys if k.startswith(task + ".") and k in mine and float(hybrid[k].norm()) > 1e-3]
+        print("%-30s D.%s: cos(variant, fp32 hybrid) median %.4f min %.4f   cos(variant, mine) median %.4f" % (
+            vn, task, sorted(cs)[len(cs) // 2], min(cs), sorted(cm)[len(cm) // 2]))
+# cancellation between the two domain calls: |g_r + g_s| / |g_r|
+for task in ("m", "s"):
+    one = [c for c in calls if c[2] == (task == "m")]
+    _, g_r = hybrid_grads([one[0]])
+    k = task + ".Advent.2.module.weight_bar"
+    print("D.%s layer 2: |g_r| %.4g   |g_r + g_s| %.4g" % (task, float(g_r[k].norm()), float(hybrid[k].norm())))

@@ -352,14 +352,21 @@ def test_train_step_640_matches_reference_update(config):
     # Yardstick (the same emulation run through update_D, jstep_640, dev container): D.p cos median 0.9907, D.s 0.9832,
     # D.m 0.9996.  All three see a generator that ExtraAdam has just moved by lr * g / (|g| + eps) ~ lr * sign(g) per
     # element, so sign flips of near-zero 16-bit generator gradients are part of their input noise.  Bound for D.p:
-    # (1 - cos) <= 2.5 x the yardstick's (measured 1.95 x).  The two ADVENT discriminators are the exception: their input is
-    # the ENTROPY map of an untrained prediction (p ~ uniform -> entropy = 1 - O((p - 1/C)^2)), which this path stores in
-    # bf16 -- resolution 2^-8 at 1.0, coarser than the signal -- while the emulation only rounds module outputs, not that
-    # functional op: measured D.m 0.968, D.s 0.942 (norm ratios 1.00 / 0.97); floors 0.95 / 0.92.
-    # On the 128 x 160 fixture the seg discriminator sees 32 x 40 entropy maps: the same quantisation leaves cos 0.64
-    # (emulation 0.94; its last bias gradient, a +-0.25 / N cancellation between the two domains, rounds to exactly 0).
-    floors = ((("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 0.95), ("s.", 0.92)) if name == "jstep_640" else
-              (("p.", 0.98), ("m.", 0.97), ("s.", 0.55)))
+    # (1 - cos) <= 2.5 x the yardstick's (measured 1.6 x), for D.s 1.4 x (measured 1.05 - 1.15 x).
+    # D.m is the one discriminator whose gradient is a small difference of two large terms: the real and the simulated
+    # call push the weights in opposite directions (labels 1 / 0 on near-identical entropy maps; |g_r + g_s| = 0.17 |g_r|),
+    # and each call runs on its own w_bar / sigma (one power iteration per call), ROUNDED TO bf16 for the MFMA -- a
+    # rounding the emulation above does not have.  tests/devtools/diag_advent_d.py jstep_640 (GPU box): the reference-exact
+    # fp32 discriminator on the inputs this path produced reproduces the reference's gradients (cos 1.0000); rounding its
+    # conv weights to bf16 per call costs cos 0.9558 (median; min 0.898), weights + activations 0.9677, and THAT variant
+    # agrees with this path to 0.9999.  Bound: (1 - cos) <= 1.4 x (1 - 0.9677); measured 0.9606 - 0.9616.
+    # (Round 2 found the real cause of the earlier 0.64 - 0.94 on D.s: the forward kept using the weights packed before
+    # the optimizer step, so the D update saw the un-extrapolated generator; tests/test_gpu_train.py::
+    # test_forward_uses_the_parameters_the_optimizer_wrote.)
+    # On the 128 x 160 fixture the seg discriminator sees 32 x 40 entropy maps and its last bias gradient is a +-0.25 / N
+    # cancellation between the two domains that rounds to exactly 0: emulation 0.94, measured 0.906 - 0.918.
+    floors = ((("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 1 - 1.4 * (1 - 0.9677)), ("s.", 1 - 1.4 * (1 - 0.9832))) if name == "jstep_640" else
+              (("p.", 0.985), ("m.", 0.98), ("s.", 0.89)))
     for grp, floor in floors:
         if not any(r[0].startswith(grp) for r in rows):
             continue
