@@ -50,6 +50,7 @@ H = W = 640
 LATENT = 640
 N_UP = 7
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md chip table
+HBM_PEAK_BYTES = 8.0e12    # HBM3E peak, same table
 WELL_CONDITIONED = dict(gain=1.0, res_gamma=0.05)   # the fill of the 640x640 parity fixtures (tests/test_gpu_configs_640.py)
 
 
@@ -180,7 +181,7 @@ class LaunchTimer:
         self.pairs = []          # (event0, event1, flops, algorithmic bytes)
         self.enabled = False
 
-    def bracket(self, fn, flops, nbytes=0):
+    def bracket(self, fn, flops, nbytes=0, tag=None):
         if not self.enabled:
             return fn()
         e0 = torch.cuda.Event(enable_timing=True)
@@ -188,8 +189,27 @@ class LaunchTimer:
         e0.record()
         out = fn()
         e1.record()
-        self.pairs.append((e0, e1, flops, nbytes))
+        self.pairs.append((e0, e1, flops, nbytes, tag))
         return out
+
+    def table(self, steps):
+        """Per distinct launch shape: launches per step, mean duration, achieved TFLOP/s and algorithmic GB/s, and the
+        time the better of the two rooflines would allow (MFMA_PEAK, HBM_PEAK): where the family loses its time."""
+        agg = {}
+        for e0, e1, fl, nb, tag in self.pairs:
+            a = agg.setdefault(tag, [0, 0.0, fl, nb])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+        rows = []
+        for tag, (n, ms, fl, nb) in agg.items():
+            us = ms / n * 1e3
+            bound_us = max(fl / (MFMA_PEAK_TFLOPS * 1e12), nb / HBM_PEAK_BYTES) * 1e6
+            rows.append((ms / steps, n / steps, us, fl / (us * 1e-6) / 1e12, nb / (us * 1e-6) / 1e9, bound_us, tag))
+        rows.sort(reverse=True)
+        lines = ["%8s %6s %9s %8s %8s %9s  %s" % ("ms/step", "n/step", "us", "TFLOP/s", "GB/s", "bound us", "shape")]
+        for r in rows:
+            lines.append("%8.3f %6.1f %9.1f %8.1f %8.1f %9.1f  %s" % r)
+        return "\n".join(lines)
 
     def total_ms(self):
         return sum(p[0].elapsed_time(p[1]) for p in self.pairs)
@@ -220,18 +240,22 @@ def install_conv_gemm_timer(timer):
         act = d.n * (d.h_in * d.w_in * cs8(d.c_in) + d.h_out * d.w_out * cs8(d.c_out) * (2 if d.has_residual else 1))
         return 2 * (act + d.c_out * d.c_in * d.kh * d.kw)
 
+    def tag(d, what):
+        return "%-8s n%d %dx%d c%d -> %dx%d c%d k%d s%d d%d%s" % (what, d.n, d.h_in, d.w_in, d.c_in, d.h_out, d.w_out, d.c_out,
+                                                            d.kh, d.stride, d.dilation, " +res" if d.has_residual else "")
+
     def timed_fwd(x, w, b, r, y, dref, stream):
         if timer.enabled and kind(dref, 0) == GEMM:
             d = dref._obj
             return timer.bracket(lambda: fwd(x, w, b, r, y, dref, stream),
-                                 2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw, alg_bytes(d))
+                                 2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw, alg_bytes(d), tag(d, "fwd"))
         return fwd(x, w, b, r, y, dref, stream)
 
     def timed_bwd(dy, w, dx, dref, stream):
         if timer.enabled and kind(dref, 1) == GEMM:
             d = dref._obj
             return timer.bracket(lambda: bwd(dy, w, dx, dref, stream),
-                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d))
+                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d), tag(d, "bwd_data"))
         return bwd(dy, w, dx, dref, stream)
 
     lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data = timed_fwd, timed_bwd
@@ -522,6 +546,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-events", action="store_true", help="do not bracket the conv_gemm launches (no roofline)")
+    ap.add_argument("--conv-table", default="", help="write the per-shape table of the bracketed conv_gemm launches here")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each sub-block (0 = skip the sub-blocks)")
     ap.add_argument("--only", default="", help="run ONE workload as the only measurement (profiling aid): "
                                                "painter | masker | infer")
@@ -605,6 +630,9 @@ def main():
                 "share_of_step": round(ms / (elapsed * 1e3), 3)}
         else:
             res["roofline"] = None
+        if n and args.conv_table:
+            with open(args.conv_table, "w") as f:
+                f.write(timer.table(args.steps) + "\n")
         res["losses_last_step"] = {k: round(v, 4) for k, v in losses.items()}
         res["max_mem_GB"] = round(mem_gb, 1)
         res["cpu_baseline"] = None

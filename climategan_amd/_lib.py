@@ -9,7 +9,8 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libcgan_hip.so"
+# CGAN_LIB: another build of the same library (same-box A/B measurements of a kernel change); default: the in-tree build
+LIB_PATH = Path(os.environ["CGAN_LIB"]).resolve() if os.environ.get("CGAN_LIB") else _HERE / "libcgan_hip.so"
 
 CGAN_F16, CGAN_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4

@@ -27,6 +27,12 @@ namespace {
 __device__ __attribute__((aligned(16))) unsigned int g_gemm_zeros[4];
 
 constexpr int NSTAGE = 3;
+// ring depth of the wave-specialised kernel: what fits beside the epilogue staging in 160 KiB, at most 6 stages
+constexpr int ws_stages(int stage_bytes, int staging_bytes) {
+  const int n = (160 * 1024 - staging_bytes) / stage_bytes;
+  return n > 6 ? 6 : n;
+}
+int g_gemm_ws = 0;   // development knob (cgan_debug_set_gemm_ws): 0 = automatic, 1 = never, 2.. = force a specialised tile
 
 __device__ __forceinline__ int reflect_i(int i, int n) {
   if (i < 0) i = -i;
@@ -142,12 +148,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned char* buf = smem + r_buf * STAGE_BYTES;
+    // the operand every MFMA of the first group needs goes first (LDS returns in order): the MFMAs start after
+    // 1 + inner-count fragments instead of after all WC + WP
     u32x4 a[WC], b[WP];
-#pragma unroll
-    for (int c = 0; c < WC; ++c) a[c] = *reinterpret_cast<const u32x4*>(buf + (wc * WC + c) * 1024 + lane * 16);
 #pragma unroll
     for (int t = 0; t < WP; ++t)
       b[t] = *reinterpret_cast<const u32x4*>(buf + (CT_BLK + wp * WP + t) * 1024 + lane * 16);
+#pragma unroll
+    for (int c = 0; c < WC; ++c) a[c] = *reinterpret_cast<const u32x4*>(buf + (wc * WC + c) * 1024 + lane * 16);
     // stage ks+2 refills the slot every wave finished reading before this barrier; its DMA pieces are issued one
     // at a time between groups of MFMAs (hard scheduling fences keep them there)
     constexpr int NM = WC * WP;
@@ -234,6 +242,323 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised, persistent variant (round 2).  The kernel above interleaves, in every wave, the LDS-DMA issues of the
+// stage after next (each with its address arithmetic) with the MFMAs of the current stage; rocprofv3 counters put it at
+// 31-33 % MFMA busy on the long-K layers with the waves waiting on their own instruction stream, and no re-ordering at
+// source level moves that (the "one barrier per k-step, everyone does everything" structure tops out around 900 TFLOP/s
+// on this chip).  Here a workgroup is 8 waves on ONE CU (the only workgroup there: ~155 KiB of LDS):
+//   * waves 4-7 = PRODUCERS: nothing but address arithmetic + LDS-DMA, running up to NS - 1 stages ahead through a deep
+//     ring (5 x 24 KiB for the 128 x 256 tile), across tile boundaries (the workgroup walks a list of tiles: the next
+//     tile's first stages are in flight while the consumers are still in the epilogue of the current one);
+//   * waves 0-3 = CONSUMERS (2 x 2 over the block tile, one per SIMD): per k-step one barrier, the WC + WP fragment reads
+//     of the NEXT stage into the second register set, then the WC * WP MFMAs of the current stage from the first --
+//     the MFMA stream never waits on an LDS read or a DMA issue of its own wave.  Epilogue through a wave-private
+//     staging area (not the ring, which the producers are refilling meanwhile).
+// Hand-over (one s_barrier per stage, numbered like the stages): a producer passes barrier j only after its share of stage
+// j has landed (counted vmcnt: NS - 2 younger stages may stay in flight); a consumer reads stage j between barrier j and
+// barrier j + 1 and has its reads back (lgkmcnt(0)) before it arrives at barrier j + 1; the producers refill that slot
+// (stage j + NS) only after barrier j + 1.  LDS-DMA data is visible to another wave's ds_read exactly under that
+// sequence: issuing wave's counted vmcnt, then a barrier the reader has passed.
+// Tiles: XCD x (blockIdx & 7) owns a contiguous range of (pixel block, cout block) tiles, cout blocks fastest, its
+// workgroups take them round-robin: concurrently running workgroups of an XCD read neighbouring tiles (shared
+// activations / halos in that XCD's L2), as in the kernel above.
+template <typename T, int WC, int WP, bool REFLECT>
+__global__ __launch_bounds__(512, 2) void conv_gemm_ws_kernel(ConvGemmArgs p, int npb, int ncb, int tiles_total) {
+  constexpr int CT_BLK = 2 * WC, PT_BLK = 2 * WP;
+  constexpr int STAGE_BYTES = (CT_BLK + PT_BLK) * 1024;
+  constexpr int ROWB = WC * 64 + 16;
+  constexpr int PP = WC >= 8 ? 1 : 2;                        // pixel tiles per epilogue pass
+  constexpr int STG_WAVE = PP * 16 * ROWB;
+  constexpr int NS = ws_stages(STAGE_BYTES, 4 * STG_WAVE);
+  constexpr int W_PER = CT_BLK / 4, P_PER = PT_BLK / 4, PIECES = W_PER + P_PER;
+  static_assert(CT_BLK % 4 == 0 && PT_BLK % 4 == 0 && WP % PP == 0, "tile split");
+  static_assert((NS - 2) * PIECES <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j16 = lane & 15, g = lane >> 4;
+
+  // this workgroup's tiles: first + i * step, i < my_n
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int per = (tiles_total + 7) >> 3;
+  const int t0 = xcd * per;
+  const int t1 = min(t0 + per, tiles_total);
+  const int my_n = (t1 - t0 > slot) ? (t1 - t0 - slot + nslot - 1) / nslot : 0;
+  if (my_n <= 0) return;
+  const int first = t0 + slot;
+  const int n_it = my_n * p.ksteps;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ producers
+    const int pw = wave - 4;
+    const int ccn = p.cin_s >> 5;
+    const long zero_off = reinterpret_cast<const unsigned char*>(g_gemm_zeros) - reinterpret_cast<const unsigned char*>(p.x);
+    int pbase[P_PER], py0[P_PER], px0[P_PER];
+    // zero-padded layers: everything that depends on the lane is folded, once per tile, into a 32-bit byte offset of tap
+    // (0, 0) and a bit mask of the taps that fall inside the image; a stage then costs a handful of VALU operations per
+    // piece (the stage's tap / channel-chunk offset is wave-uniform: scalar arithmetic).  A producer wave is bound by the
+    // latency of its own instruction stream, so this IS the fill rate.
+    int poff[P_PER];
+    unsigned vmask[P_PER];
+    const u32x4* wtile[W_PER];
+    int cblk = 0;
+    auto set_tile = [&](int ti) {
+      const int gt = first + ti * nslot;
+      const int pblk = gt / ncb;
+      cblk = gt - pblk * ncb;
+#pragma unroll
+      for (int m = 0; m < W_PER; ++m)
+        wtile[m] = p.w + (size_t)min(cblk * CT_BLK + pw + 4 * m, p.ctiles - 1) * p.ksteps * 64;
+#pragma unroll
+      for (int m = 0; m < P_PER; ++m) {
+        int pix = (pblk * PT_BLK + pw + 4 * m) * 16 + j16;
+        bool v = pix < p.npix;
+        int pc = v ? pix : 0;
+        int ox = pc % p.w_out;
+        int r = pc / p.w_out;
+        int oy = r % p.h_out;
+        int nn = r / p.h_out;
+        pbase[m] = nn * p.h_in * p.w_in * p.cin_s + g * 8;
+        py0[m] = v ? oy * p.stride - p.pad : -(1 << 28);
+        px0[m] = ox * p.stride - p.pad;
+        if (!REFLECT) {
+          poff[m] = (pbase[m] + ((oy * p.stride - p.pad) * p.w_in + px0[m]) * p.cin_s) * 2;
+          unsigned mk = 0;
+          for (int ky = 0; ky < p.kh; ++ky)
+            for (int kx = 0; kx < p.kw; ++kx) {
+              const bool ok = v && (unsigned)(py0[m] + ky * p.dil) < (unsigned)p.h_in &&
+                              (unsigned)(px0[m] + kx * p.dil) < (unsigned)p.w_in;
+              mk |= (ok ? 1u : 0u) << (ky * p.kw + kx);
+            }
+          vmask[m] = mk;
+        }
+      }
+    };
+    int i_ky = 0, i_kx = 0, i_cc = 0, i_buf = 0, i_ks = 0, i_tile = 0, issued = 0;
+    auto issue_stage = [&]() {
+      unsigned char* buf = smem + i_buf * STAGE_BYTES;
+      const int tap = i_ky * p.kw + i_kx;                                  // wave-uniform
+      const int w_ks = tap * ccn + i_cc;
+#pragma unroll
+      for (int m = 0; m < W_PER; ++m) {
+        const u32x4* src = wtile[m] + (size_t)w_ks * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + (pw + 4 * m) * 1024), 16, 0, 0);
+      }
+      const int tap_off = ((i_ky * p.w_in + i_kx) * p.dil * p.cin_s + i_cc * 32) * 2;   // wave-uniform
+#pragma unroll
+      for (int m = 0; m < P_PER; ++m) {
+        const int i = pw + 4 * m;
+        long off;
+        if (REFLECT) {
+          int iy = py0[m] + i_ky * p.dil, ix = px0[m] + i_kx * p.dil;
+          const bool ok = py0[m] > -(1 << 27);
+          iy = reflect_i(ok ? iy : 0, p.h_in);
+          ix = reflect_i(ix, p.w_in);
+          off = ok ? (long)(pbase[m] + (iy * p.w_in + ix) * p.cin_s + i_cc * 32) * 2 : zero_off;
+        } else {
+          off = ((vmask[m] >> tap) & 1u) ? (long)(poff[m] + tap_off) : zero_off;
+        }
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + (CT_BLK + i) * 1024), 16, 0, 0);
+      }
+      // next stage: taps innermost, channel chunks outermost, then the next tile
+      ++issued;
+      i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
+      if (++i_ks == p.ksteps) {
+        i_ks = 0; i_ky = 0; i_kx = 0; i_cc = 0;
+        if (++i_tile < my_n) set_tile(i_tile);
+      } else if (++i_kx == p.kw) {
+        i_kx = 0;
+        if (++i_ky == p.kh) {
+          i_ky = 0;
+          ++i_cc;
+        }
+      }
+    };
+    set_tile(0);
+    for (int s2 = 0; s2 < NS - 1; ++s2)
+      if (issued < n_it) issue_stage();
+    for (int j = 0; j < n_it; ++j) {
+      // stage j has landed once at most the NS - 2 younger stages are still in flight (in-order completion)
+      if (issued - 1 - j >= NS - 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (issued < n_it) issue_stage();           // into the slot of stage j - 1: every consumer read it before barrier j
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumers
+  const int wc = wave & 1, wp = wave >> 1;
+  f32x4 acc[WC][WP];
+#pragma unroll
+  for (int c = 0; c < WC; ++c)
+#pragma unroll
+    for (int t = 0; t < WP; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 a0[WC], b0[WP], a1[WC], b1[WP];
+  int r_buf = 0;
+  unsigned char* stg = smem + NS * STAGE_BYTES + wave * STG_WAVE;
+
+  // One pipeline step: barrier (the next stage has landed), then the WC * WP MFMAs of the CURRENT stage (fragments in
+  // ca / cb, fetched one step earlier) with the WC + WP fragment reads of the NEXT stage slotted between them, one read
+  // per MFMA pair: the reads ride in the issue gaps of the MFMAs instead of in front of them.  Hard scheduling fences:
+  // register-only MFMAs are not ordered by an asm "memory" clobber, and the machine scheduler would regroup the stream.
+  auto step = [&](const u32x4* ca, const u32x4* cb, u32x4* na, u32x4* nb, bool fetch) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (fetch) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the current stage's fragments are in registers
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* buf = smem + r_buf * STAGE_BYTES;
+    constexpr int NM = WC * WP, NR = WC + WP;
+    constexpr int EVERY = NM / NR >= 2 ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int c = i / WP, t = i % WP;
+      acc[c][t] = mfma16(as_vec8<T>(ca[c]), as_vec8<T>(cb[t]), acc[c][t]);
+      if (fetch && i % EVERY == EVERY - 1 && i / EVERY < NR) {
+        const int q = i / EVERY;                             // b first: the next step's first MFMAs need all of b
+        if (q < WP)
+          nb[q] = *reinterpret_cast<const u32x4*>(buf + (CT_BLK + wp * WP + q) * 1024 + lane * 16);
+        else
+          na[q - WP] = *reinterpret_cast<const u32x4*>(buf + (wc * WC + q - WP) * 1024 + lane * 16);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (fetch) r_buf = (r_buf + 1 == NS) ? 0 : r_buf + 1;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto first_read = [&](u32x4* a, u32x4* b) {               // a tile's first stage: nothing to overlap it with
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* buf = smem + r_buf * STAGE_BYTES;
+#pragma unroll
+    for (int t = 0; t < WP; ++t)
+      b[t] = *reinterpret_cast<const u32x4*>(buf + (CT_BLK + wp * WP + t) * 1024 + lane * 16);
+#pragma unroll
+    for (int c = 0; c < WC; ++c) a[c] = *reinterpret_cast<const u32x4*>(buf + (wc * WC + c) * 1024 + lane * 16);
+    r_buf = (r_buf + 1 == NS) ? 0 : r_buf + 1;
+  };
+  auto epilogue = [&](int ti) {
+    const int gt = first + ti * nslot;
+    const int pblk = gt / ncb;
+    const int cblk = gt - pblk * ncb;
+    const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
+    constexpr int CH = WC * 2;
+#pragma unroll
+    for (int pass = 0; pass < WP / PP; ++pass) {
+#pragma unroll
+      for (int tt = 0; tt < PP; ++tt)
+#pragma unroll
+        for (int c = 0; c < WC; ++c) {
+          *reinterpret_cast<f32x4*>(stg + (tt * 16 + j16) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
+          acc[c][pass * PP + tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int pix_base = (pblk * PT_BLK + wp * WP + pass * PP) * 16;
+#pragma unroll
+      for (int it = 0; it < PP * 16 * CH / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int pl = idx / CH, qc = idx % CH;
+        const int pix = pix_base + pl;
+        const int ch = cout_base + qc * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
+        if (pix >= p.npix || ch >= p.cout_s) continue;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
+        }
+        if (p.has_res) {
+          size_t rbase;
+          if (p.res_ups) {
+            int ox = pix % p.w_out;
+            int r = pix / p.w_out;
+            int oy = r % p.h_out;
+            int nn = r / p.h_out;
+            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+          } else {
+            rbase = (size_t)pix * p.cout_s;
+          }
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r0, r1;
+            unpack2<T>(rv[e], r0, r1);
+            v[2 * e] += r0;
+            v[2 * e + 1] += r1;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          v[r] = act_apply(v[r], p.act, p.slope);
+          if (ch + r >= p.cout) v[r] = 0.f;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  // one barrier per stage, in stage order (the producers count the same barriers)
+  for (int ti = 0; ti < my_n; ++ti) {
+    first_read(a0, b0);
+    int ks = 0;
+    for (; ks + 2 < p.ksteps; ks += 2) {
+      step(a0, b0, a1, b1, true);
+      step(a1, b1, a0, b0, true);
+    }
+    if (p.ksteps - ks == 2) {
+      step(a0, b0, a1, b1, true);
+      step(a1, b1, a0, b0, false);
+    } else {
+      step(a0, b0, a1, b1, false);
+    }
+    epilogue(ti);
+  }
+}
+
+template <typename T, int WC, int WP, bool REFLECT>
+int launch_ws2(const ConvGemmArgs& a, hipStream_t s) {
+  constexpr int CT_BLK = 2 * WC, PT_BLK = 2 * WP;
+  constexpr int STAGE_BYTES = (CT_BLK + PT_BLK) * 1024;
+  constexpr int STG = 4 * (WC >= 8 ? 1 : 2) * 16 * (WC * 64 + 16);
+  constexpr size_t smem = (size_t)ws_stages(STAGE_BYTES, STG) * STAGE_BYTES + STG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_ws_kernel<T, WC, WP, REFLECT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      cgan_set_error("conv_gemm_ws: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return CGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int npb = ceil_div(ceil_div(a.npix, 16), PT_BLK);
+  const int ncb = ceil_div(a.ctiles, CT_BLK);
+  const int tiles = npb * ncb;
+  const int per = ceil_div(tiles, 8);
+  const int nslot = per < 32 ? per : 32;               // one workgroup per CU: 32 CUs per XCD
+  hipLaunchKernelGGL((conv_gemm_ws_kernel<T, WC, WP, REFLECT>), dim3(8 * nslot), dim3(512), smem, s, a, npb, ncb,
+                     tiles);
+  return CGAN_OK;
+}
+template <typename T, int WC, int WP>
+int launch_ws(const ConvGemmArgs& a, hipStream_t s) {
+  return a.pad_mode == CGAN_PAD_REFLECT ? launch_ws2<T, WC, WP, true>(a, s) : launch_ws2<T, WC, WP, false>(a, s);
+}
+
+
 template <typename T, int WAVES_C, int WC, int WP, bool REFLECT>
 int launch_cfg2(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -267,6 +592,12 @@ int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 
 template <typename T>
 int launch(const ConvGemmArgs& a, hipStream_t s) {
   const int ptiles = ceil_div(a.npix, 16);
+  switch (g_gemm_ws) {
+    case 2: return launch_ws<T, 4, 8>(a, s);      // 128 couts x 256 pixels
+    case 3: return launch_ws<T, 4, 4>(a, s);      // 128 x 128
+    case 4: return launch_ws<T, 8, 4>(a, s);      // 256 x 128
+    default: break;
+  }
   switch (g_gemm_cfg) {
     case 1: return launch_cfg<T, 1, 4, 4>(a, s);
     case 2: if (a.ctiles <= 16) return launch_cfg<T, 2, 8, 4>(a, s); break;
@@ -297,6 +628,7 @@ bool conv_gemm_applicable(const CganConvDesc* d) {
 }
 
 extern "C" void cgan_debug_set_gemm_cfg(int v) { g_gemm_cfg = v; }
+extern "C" void cgan_debug_set_gemm_ws(int v) { g_gemm_ws = v; }
 
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);

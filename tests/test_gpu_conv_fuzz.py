@@ -145,3 +145,42 @@ def test_wgrad_upsample_and_reflect_modes(dt, case):
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(262144))
+
+
+WS_CASES = [
+    # (cin, cout, k, stride, pad, dil, B, H, W, reflect, residual): wide layers the implicit-GEMM kernel takes
+    (256, 256, 3, 1, 2, 2, 2, 40, 40, False, False), (512, 192, 3, 1, 1, 1, 1, 33, 47, False, True),
+    (1024, 256, 1, 1, 0, 1, 2, 40, 40, False, True), (64, 320, 1, 1, 0, 1, 1, 64, 64, False, False),
+    (128, 128, 3, 1, 1, 1, 1, 40, 56, True, False), (256, 512, 4, 2, 1, 1, 2, 48, 48, False, False),
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_wave_specialised_gemm_is_bitwise_the_plain_kernel(case):
+    """The persistent producer / consumer variant of the wide-layer GEMM (opt-in: cgan_debug_set_gemm_ws)
+    walks K in the same order with the same fragments, so each of its three block tiles must reproduce the plain kernel
+    bit for bit -- ragged pixel counts, partial cout blocks, dilation, stride, reflect padding, residual + activation,
+    several tiles per workgroup."""
+    from climategan_amd import _lib, ops
+
+    cin, cout, k, stride, pad, dil, B, H, W, reflect, residual = case
+    lib = _lib.load()
+    dt = torch.bfloat16
+    torch.manual_seed(1)
+    x = ops.nchw_to_nhwc(torch.randn(B, cin, H, W, device="cuda"), dt)
+    pw = ops.pack_conv_weight(torch.randn(cout, cin, k, k, device="cuda") * 0.05, torch.randn(cout, device="cuda"), dt)
+    kw = dict(stride=stride, pad=pad, dilation=dil, act=ops.ACT_LRELU, slope=0.2,
+              pad_mode=ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+    try:
+        lib.cgan_debug_set_gemm_ws(ctypes.c_int(1))
+        y0 = ops.conv2d(x, pw, **kw)
+        res = ops.NHWC(torch.randn_like(y0.t), cout) if residual else None
+        if residual:
+            y0 = ops.conv2d(x, pw, residual=res, **kw)
+        for ws in (2, 3, 4):
+            lib.cgan_debug_set_gemm_ws(ctypes.c_int(ws))
+            for _ in range(2):
+                y = ops.conv2d(x, pw, residual=res, **kw)
+                assert torch.equal(y.t, y0.t), (ws, (y.t.float() - y0.t.float()).abs().max().item())
+    finally:
+        lib.cgan_debug_set_gemm_ws(ctypes.c_int(0))

@@ -9,6 +9,10 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from climategan_amd import _lib, ops  # noqa: E402
+import os  # noqa: E402
+
+if os.environ.get("CGAN_LIB"):      # A/B against another build of the library (same box, same call)
+    _lib.LIB_PATH = Path(os.environ["CGAN_LIB"]).resolve()
 
 SHAPES = [
     # name, cin, cout, k, stride, pad, dil, H (input), count-in-resnet
@@ -36,6 +40,8 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--cfg", type=int, default=0, help="cgan_debug_set_gemm_cfg: 1 64x256, 2 256x128, 3 128x256, 4 128x128")
+    ap.add_argument("--ws", type=int, default=0, help="cgan_debug_set_gemm_ws: 1 never, 2 128x256, 3 128x128, 4 256x128 specialised")
+    ap.add_argument("--check", action="store_true", help="compare with the non-specialised kernel (bitwise)")
     ap.add_argument("--hw", type=int, default=0, help="override the input extent of every shape")
     ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
     args = ap.parse_args()
@@ -43,6 +49,7 @@ def main():
     lib = _lib.load()
     lib.cgan_debug_set_conv_kernel(ctypes.c_int(args.force))
     lib.cgan_debug_set_gemm_cfg(ctypes.c_int(args.cfg))
+    lib.cgan_debug_set_gemm_ws(ctypes.c_int(args.ws))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
         if args.only not in name:
             continue
@@ -62,7 +69,14 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         flops = 2.0 * y.n * y.h * y.w * cout * cin * k * k
-        print("%-24s %8.3f ms  %7.1f TFLOP/s" % (name, ms, flops / ms / 1e9))
+        chk = ""
+        if args.check:
+            lib.cgan_debug_set_gemm_ws(ctypes.c_int(1))
+            y0 = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_RELU)
+            lib.cgan_debug_set_gemm_ws(ctypes.c_int(args.ws))
+            torch.cuda.synchronize()
+            chk = "  identical to the plain kernel: %s (max |diff| %.3g)" % (torch.equal(y.t, y0.t), (y.t.float() - y0.t.float()).abs().max().item())
+        print("%-24s %8.3f ms  %7.1f TFLOP/s%s" % (name, ms, flops / ms / 1e9, chk))
 
 
 if __name__ == "__main__":

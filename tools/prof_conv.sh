@@ -11,7 +11,7 @@ out = []
 for r in rows:
     if 'conv_' in r['Name'] and 'pack' not in r['Name']:
         nm = r['Name'].split('(')[0].replace('void (anonymous namespace)::', '')[:44]
-        out.append("%s x%s avg %.1f us" % (nm, r['Calls'], float(r['AverageNs']) / 1e3))
+        out.append("%s x%s avg %.1f us (min %.1f)" % (nm, r['Calls'], float(r['AverageNs']) / 1e3, float(r['MinNs']) / 1e3))
 print("cfg", sys.argv[1], " | ".join(out))
 PY
 done
