@@ -40,8 +40,8 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--cfg", type=int, default=0, help="cgan_debug_set_gemm_cfg: 1 64x256, 2 256x128, 3 128x256, 4 128x128")
-    ap.add_argument("--ws", type=int, default=0, help="cgan_debug_set_gemm_ws: 1 never, 2 128x256, 3 128x128, 4 256x128 specialised")
-    ap.add_argument("--check", action="store_true", help="compare with the non-specialised kernel (bitwise)")
+    ap.add_argument("--ws", type=int, default=0, help="cgan_debug_set_gemm_ws: 1 never the K = 64 kernel, 5 force it (256 x 128), 6 (128 x 256)")
+    ap.add_argument("--check", action="store_true", help="compare with the plain kernel")
     ap.add_argument("--hw", type=int, default=0, help="override the input extent of every shape")
     ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
     args = ap.parse_args()
