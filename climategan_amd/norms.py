@@ -50,16 +50,57 @@ def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw
 class _PackCache:
     """Re-pack fp32 parameters into MFMA fragment order only when they change."""
 
+    _plain = {}          # id(cache) -> weakref(cache): the caches holding a plain conv weight (get_plain)
+
     def __init__(self):
         self.key = None
         self.value = None
+        self._plain_src = None
+
+    @staticmethod
+    def _key_of(params, dtype):
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) if torch.is_tensor(p) else p
+                     for p in params if p is not None) + (dtype,)
 
     def get(self, params, dtype, build):
-        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) if torch.is_tensor(p) else p
-                    for p in params if p is not None) + (dtype,)
+        key = self._key_of(params, dtype)
         if key != self.key:
             self.value = build()
             self.key = key
+        return self.value
+
+    def get_plain(self, weight, bias, dtype):
+        """The packed form of a plain conv's (weight, bias) for the training path.  An optimizer step makes EVERY such
+        cache stale at once and the next forward asks for them one by one: on the first miss all stale ones (same device,
+        same dtype) are re-packed together in ONE batched launch (ops.pack_conv_weights_batched; the same arithmetic as
+        ops.pack_conv_weight) instead of one launch per layer -- ~200 launches per optimizer update for the Masker."""
+        import weakref
+
+        key = self._key_of((weight, bias, "plain"), dtype)
+        if key == self.key:
+            return self.value
+        self._plain_src = (weakref.ref(weight), weakref.ref(bias) if bias is not None else None, dtype)
+        _PackCache._plain[id(self)] = weakref.ref(self)
+        stale = []
+        for cid, ref in list(_PackCache._plain.items()):
+            c = ref()
+            src = c._plain_src if c is not None else None
+            w = src[0]() if src is not None else None
+            if c is None or w is None:
+                del _PackCache._plain[cid]
+                continue
+            b = src[1]() if src[1] is not None else None
+            if src[2] != dtype or w.device != weight.device:
+                continue
+            k = self._key_of((w, b, "plain"), dtype)
+            if k != c.key:
+                stale.append((c, w, b, k))
+        reuse = [c.value if (c.value is not None and c.key is not None and c.key[-1] == dtype and
+                             isinstance(c.value, ops.PackedConv)) else None for c, _, _, _ in stale]
+        packed = ops.pack_conv_weights_batched([(w.data, b.data if b is not None else None) for _, w, b, _ in stale], dtype,
+                                               reuse)
+        for (c, _, _, k), pk in zip(stale, packed):
+            c.value, c.key = pk, k
         return self.value
 
 
@@ -158,6 +199,9 @@ def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.N
     trainable = kw.pop("trainable", False)
     if not trainable:
         _grad_guard(conv)
+    if trainable and needs_grad(conv, x.t):
+        pw = cache.get_plain(conv.weight, conv.bias, x.t.dtype)
+        return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], conv.padding[0], conv.dilation[0], kw)
     pw = cache.get((conv.weight, conv.bias), x.t.dtype,
                    lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None,
                                                 x.t.dtype))
@@ -203,9 +247,7 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
     act, slope, residual = kw.pop("act", ops.ACT_NONE), kw.pop("slope", 0.2), kw.pop("residual", None)
     if kw.get("in_upsample") or kw.get("residual_upsample"):
         raise NotImplementedError("conv_bn_forward: folded upsamples are not used on the training path")
-    pw = cache.get((conv.weight, conv.bias, "plain"), x.t.dtype,
-                   lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data if conv.bias is not None else None,
-                                                x.t.dtype))
+    pw = cache.get_plain(conv.weight, conv.bias, x.t.dtype)
     if bn is None:
         return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0],
                            dict(act=act, slope=slope, residual=residual, pad_mode=pad_mode))

@@ -465,6 +465,52 @@ def pack_conv_weight(w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch
     return PackedConv(packed, bias_out, c_in, c_out, kh, kw, bias is not None, dtype)
 
 
+def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
+    """``pack_conv_weight`` for a list of (weight, bias-or-None) fp32 OIHW device tensors in ONE launch
+    (cgan_conv2d_pack_weight_batched: same arithmetic, bit for bit).  ``reuse[i]``: a PackedConv of the same shape whose
+    buffers are overwritten instead of allocated (nothing may still be reading them on another stream)."""
+    if not params:
+        return []
+    lib = _lib.load()
+    dev = params[0][0].device
+    items = (PackItem * len(params))()
+    out, keep, max_frag = [], [], 0
+    for i, (w, bias) in enumerate(params):
+        _need_cuda(w, bias)
+        w = w.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.contiguous().float()
+        b = bias.detach() if bias is not None else None
+        if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
+            b = b.contiguous().float()
+        keep.append((w, b))
+        c_out, c_in, kh, kw = w.shape
+        d = _conv_desc(_DT[dtype], 1, max(kh, 1), max(kw, 1), c_in, c_out, kh, kw, 1, 0, 1, PAD_ZERO)
+        nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
+        if nbytes == 0:
+            _lib.check(-1, "cgan_conv2d_packed_weight_bytes")
+        pk = reuse[i] if reuse is not None else None
+        if pk is None or pk.w.numel() != nbytes or pk.dtype != dtype or (pk.c_out, pk.c_in, pk.kh, pk.kw) != (c_out, c_in, kh, kw) \
+                or pk.has_bias != (b is not None) or pk.w.device != dev:
+            pk = PackedConv(torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                            torch.empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=dev),
+                            c_in, c_out, kh, kw, b is not None, dtype)
+        out.append(pk)
+        max_frag = max(max_frag, nbytes // 16)
+        items[i] = PackItem(w.data_ptr(), b.data_ptr() if b is not None else 0, 0, pk.w.data_ptr(), pk.bias.data_ptr(),
+                            c_out, c_in, kh, kw)
+    host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
+    table = host.to(dev, non_blocking=True)
+    _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(table), len(params), _DT[dtype], max_frag, _stream()),
+               "cgan_conv2d_pack_weight_batched")
+    _PACK_TABLES.append((host, table, keep))          # alive until the copy / kernel that read them are long done
+    del _PACK_TABLES[:-8]
+    return out
+
+
+_PACK_TABLES = []
+
+
 def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2,
            residual: Optional[NHWC] = None, in_upsample=False, residual_upsample=False) -> NHWC:
     """y = act(conv(x) + bias + residual) on NHWC tensors; x may be read through a folded x2 nearest upsample."""
