@@ -658,7 +658,9 @@ def main():
     del T, batch
     torch.cuda.empty_cache()
     sub = {}
-    if args.sub_steps > 0:
+    # the sub-blocks are single-GPU measurements (BASELINE configs[1], [2], [4]); under torchrun only the headline runs: one
+    # collective-bearing path less that could leave ranks waiting on each other after the line is out
+    if args.sub_steps > 0 and world == 1:
         blocks = (("painter_forward", lambda: painter_block(args.sub_steps, 5, rank, world, device, dtype, dist, barrier,
                                                            world == 1 and not args.no_cpu_baseline)),
                   ("masker_train", lambda: masker_block(args.sub_steps, 3, rank, world, device, dtype, dist, barrier)),
