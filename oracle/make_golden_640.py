@@ -38,7 +38,7 @@ CASES_640 = {
                       vgg_gain=2.449489742783178),
     # the same two reference calls on a small configuration (Painter latent 32 / 4 up-samplings, PatchGAN ndf 16 / 3
     # layers, 128 x 160): pins oracle.cpu_ref.joint_train_step on the CPU in seconds
-    "jstep_small": dict(kind="jstep", H=128, W=160, B=2, seed=69, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
+    "jstep_small": dict(kind="jstep", iterations=4, H=128, W=160, B=2, seed=69, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
                         vgg_gain=2.449489742783178, latent_dim=32, n_up=4, ndf=16, n_layers=3),
     # eval-mode BatchNorm (running statistics from the fill, not batch statistics) needs variance-preserving conv weights
     # to keep a signal: gain sqrt(6) (He bound for the uniform fill) -- depth range 2.1, seg logits std 3.3, all 11 classes
@@ -172,6 +172,18 @@ def run_jstep(case):
             if p.requires_grad and p.grad is not None:
                 out["gsub.D." + key] = grad_subsample(key, p.grad, case["sub"])
                 out["gnorm.D." + key] = np.array([p.grad.norm().item()], dtype=np.float32)
+        # the following iterations of run_epoch's loop body on the same batch (trainer.py:955-980: D frozen during the G
+        # update, step counter, ExtraAdam alternating extrapolation / step): the logged loss terms of iterations 2 .. n
+        for it in range(2, case.get("iterations", 1) + 1):
+            T.logger.global_step += 1
+            for p_ in T.D.parameters():
+                p_.requires_grad = False
+            T.update_G(batch)
+            for p_ in T.D.parameters():
+                p_.requires_grad = True
+            T.update_D(batch)
+            out.update({"it%d.G.%s" % (it, k): np.array([v], dtype=np.float32) for k, v in _flatten(T.logger.losses.gen).items()})
+            out.update({"it%d.D.%s" % (it, k): np.array([v], dtype=np.float32) for k, v in _flatten(T.logger.losses.disc).items()})
     finally:
         torch.Tensor.cuda, torch.Tensor.get_device = saved
     return out

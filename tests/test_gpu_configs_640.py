@@ -376,3 +376,42 @@ def test_train_step_640_matches_reference_update(config):
                 print("    low: %-40s ref norm %.3g ratio %.3f cos %.3f" % (r[0], r[1], r[2], r[3]))
         print("  %-13s n=%4d  norm ratio median %.3f [%.3f, %.3f]   cos median %.4f p10 %.4f min %.4f" % (("D." + grp[0],) + st))
         assert 0.90 <= st[1] <= 1.05 and st[4] >= floor, (grp, st)
+
+
+TRAJECTORY_TERMS = {  # golden key suffix -> Trainer.loss_log key(s) (summed)
+    "G.task.d.s": ("G.d.s",), "G.task.s.crossent.s": ("G.s.crossent.s",), "G.task.m.bce.s": ("G.m.bce.s",),
+    "G.task.m.minent.r": ("G.m.minent.r",), "G.task.m.advent.r": ("G.m.advent.r",),
+    "G.p.vgg": ("G.p.vgg",), "G.p.featmatch": ("G.p.featmatch",), "G.p.gan": ("G.p.gan",),
+    "D.p.gan": ("D.p.gan",), "D.s.Advent": ("D.s.advent.r", "D.s.advent.s"), "D.m.Advent": ("D.m.advent.r", "D.m.advent.s"),
+}
+
+
+def test_four_train_iterations_follow_the_reference_trajectory():
+    """Four consecutive iterations of the training loop body on one batch (D frozen during the G update, ExtraAdam
+    alternating extrapolation / step on both optimizers, step counter) vs the loss terms the REFERENCE's own loop logs
+    (golden ``jstep_small``, keys it2.* .. it4.*: trainer.py:955-980 run four times).  Every iteration after the first sees
+    parameters the optimizer wrote -- this is the test that would have caught the forward running on stale packed weights
+    (the terms would simply not move).  The first ExtraAdam updates are lr * sign(g) per element, so 16-bit gradient noise
+    on near-zero elements moves the trajectory a little; bounds: every term within 3 % of the reference's, and the CHANGE of
+    the terms that move by more than 2 % over the four iterations (depth, cross-entropy, VGG) within 25 % of the reference's
+    change."""
+    case = CASES_640["jstep_small"]
+    gold = load_golden("jstep_small")
+    T = _build_train(("d", "s", "m", "p"), case, 1)
+    batch = _batch(case, 1, ("r", "s", "rf"))
+    T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
+    got = {}
+    for it in range(1, case["iterations"] + 1):
+        g, d = T.train_step(batch)
+        assert torch.isfinite(g) and torch.isfinite(d)
+        got[it] = {k: float(sum(T.loss_log[x] for x in v)) for k, v in TRAJECTORY_TERMS.items()}
+    assert T.global_step == case["iterations"]
+    print()
+    for k in TRAJECTORY_TERMS:
+        ref = [float(gold[("" if it == 1 else "it%d." % it) + k][0]) for it in range(1, case["iterations"] + 1)]
+        mine = [got[it][k] for it in range(1, case["iterations"] + 1)]
+        print("  %-22s reference %s\n  %-22s hip       %s" % (k, " ".join("%+.5f" % v for v in ref), "", " ".join("%+.5f" % v for v in mine)))
+        for r, m in zip(ref, mine):
+            assert abs(m - r) <= 3e-2 * max(abs(r), 1e-3), (k, ref, mine)
+        if abs(ref[-1] - ref[0]) > 2e-2 * abs(ref[0]):
+            assert abs((mine[-1] - mine[0]) - (ref[-1] - ref[0])) <= 0.25 * abs(ref[-1] - ref[0]), (k, ref, mine)
