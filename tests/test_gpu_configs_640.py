@@ -392,9 +392,10 @@ def test_four_train_iterations_follow_the_reference_trajectory():
     (golden ``jstep_small``, keys it2.* .. it4.*: trainer.py:955-980 run four times).  Every iteration after the first sees
     parameters the optimizer wrote -- this is the test that would have caught the forward running on stale packed weights
     (the terms would simply not move).  The first ExtraAdam updates are lr * sign(g) per element, so 16-bit gradient noise
-    on near-zero elements moves the trajectory a little; bounds: every term within 3 % of the reference's, and the CHANGE of
-    the terms that move by more than 2 % over the four iterations (depth, cross-entropy, VGG) within 25 % of the reference's
-    change."""
+    on near-zero elements moves the trajectory a little (measured on MI355X: depth term 11.358 vs 11.319 after four iterations,
+    cross-entropy 2.15704 vs 2.15687, VGG 402.35 vs 402.55, every other term to 3-4 digits); bounds: every term within 1.5 % of
+    the reference's, and the CHANGE of the terms that move by more than 2 % over the four iterations (depth, cross-entropy,
+    VGG, D.p) within 10 % of the reference's change."""
     case = CASES_640["jstep_small"]
     gold = load_golden("jstep_small")
     T = _build_train(("d", "s", "m", "p"), case, 1)
@@ -412,6 +413,6 @@ def test_four_train_iterations_follow_the_reference_trajectory():
         mine = [got[it][k] for it in range(1, case["iterations"] + 1)]
         print("  %-22s reference %s\n  %-22s hip       %s" % (k, " ".join("%+.5f" % v for v in ref), "", " ".join("%+.5f" % v for v in mine)))
         for r, m in zip(ref, mine):
-            assert abs(m - r) <= 3e-2 * max(abs(r), 1e-3), (k, ref, mine)
+            assert abs(m - r) <= 1.5e-2 * max(abs(r), 1e-3), (k, ref, mine)
         if abs(ref[-1] - ref[0]) > 2e-2 * abs(ref[0]):
-            assert abs((mine[-1] - mine[0]) - (ref[-1] - ref[0])) <= 0.25 * abs(ref[-1] - ref[0]), (k, ref, mine)
+            assert abs((mine[-1] - mine[0]) - (ref[-1] - ref[0])) <= 0.10 * abs(ref[-1] - ref[0]), (k, ref, mine)
