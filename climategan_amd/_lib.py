@@ -69,6 +69,7 @@ _SIGNATURES = {
     "cgan_conv2d_dgrad_packed_weight_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "cgan_conv2d_pack_weight_dgrad": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_kernel_kind": (C.c_int, [C.POINTER(ConvDesc), C.c_int32]),
     "cgan_seg_counts": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     "cgan_resize_crop_geometry": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

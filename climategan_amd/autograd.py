@@ -127,6 +127,43 @@ class ConvFn(torch.autograd.Function):
         return dx_t, dw, db, dres_t, None, None, None
 
 
+class ConvPassFn(torch.autograd.Function):
+    """(y, x) = (conv(x, w) + b, x): a plain conv (no activation, no residual) that also hands its input through.  A
+    consumer of the second output (the residual add at the end of a ResNet bottleneck) sends its gradient back through
+    THIS node, and the backward adds it in the data-gradient kernel's epilogue (``conv2d_bwd_data(add=...)``) -- instead
+    of x collecting two gradients that the autograd engine sums with an element-wise pass of its own (33 such adds of
+    50-200 MB per train step)."""
+
+    @staticmethod
+    def forward(ctx, x_t, weight, bias, packed, cfg):
+        x = ops.NHWC(x_t, cfg["c_in"])
+        y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"],
+                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x_t, weight)
+        return y.t, x_t                   # (returned as-is: autograd makes it an output of this node)
+
+    @staticmethod
+    def backward(ctx, dy_t, dpass_t):
+        cfg = ctx.cfg
+        x_t, weight = ctx.saved_tensors
+        c_out = weight.shape[0]
+        dy = ops.NHWC(dy_t.contiguous(), c_out)
+        dx_t = None
+        if ctx.needs_input_grad[0]:
+            add = ops.NHWC(dpass_t.contiguous(), cfg["c_in"]) if dpass_t is not None else None
+            dx_t = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], x_t.shape[1], x_t.shape[2]), stride=cfg["stride"],
+                                       pad=cfg["pad"], dilation=cfg["dilation"],
+                                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO), add=add).t
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"],
+                                           pad=cfg["pad"], dilation=cfg["dilation"], want_bias=ctx.has_bias,
+                                           pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+        return dx_t, dw, db, None, None
+
+
 class InstNormActFn(torch.autograd.Function):
     """out = act(instance_norm(x)) (affine-free, biased variance; act none or LeakyReLU)."""
 

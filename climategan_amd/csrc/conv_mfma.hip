@@ -702,8 +702,8 @@ extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) 
   return select_conv_kernel(p, &t);
 }
 
-extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
-                                         void* stream) {
+static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx, const CganConvDesc* fwd,
+                         void* stream) {
   ConvParams p;
   CganConvDesc t;
   int rc = dgrad_params(p, fwd, &t);
@@ -713,6 +713,13 @@ extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dg
   hipStream_t s = (hipStream_t)stream;
   const bool plain = fwd->stride == 1 && p.pad >= 0 && t.h_in + 2 * p.pad - t.dilation * (t.kh - 1) == t.h_out &&
                      t.w_in + 2 * p.pad - t.dilation * (t.kw - 1) == t.w_out;
+  CGAN_REQUIRE(dx_add == nullptr || plain, "conv2d_nhwc_bwd_data_add: only for stride-1 'same' convolutions");
+  if (dx_add) {             // the other gradient contribution of the same tensor rides in the epilogue's residual slot
+    p.res = (const uint16_t*)dx_add;
+    p.has_res = 1;
+    p.res_ups = 0;
+    t.has_residual = 1;
+  }
   if (plain) {
     t.pad = p.pad;
     return dispatch_conv(p, &t, s, "conv2d_nhwc_bwd_data");
@@ -721,4 +728,15 @@ extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dg
   else launch<BF16>(p, s);
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_data");
   return CGAN_OK;
+}
+
+extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
+                                         void* stream) {
+  return bwd_data_impl(dy, packed_w_dgrad, nullptr, dx, fwd, stream);
+}
+
+extern "C" int cgan_conv2d_nhwc_bwd_data_add(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx,
+                                             const CganConvDesc* fwd, void* stream) {
+  CGAN_REQUIRE(dx_add != nullptr, "conv2d_nhwc_bwd_data_add: null pointer");
+  return bwd_data_impl(dy, packed_w_dgrad, dx_add, dx, fwd, stream);
 }

@@ -7,7 +7,10 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .. import ops
-from ..norms import DEFAULT_COMPUTE_DTYPE, _PackCache, conv_bn_forward
+from ..norms import DEFAULT_COMPUTE_DTYPE, _PackCache, conv_bn_forward, needs_grad
+
+
+FUSE_RESIDUAL_GRADIENT = True      # A/B switch for tools / tests: False = the engine's own gradient accumulation
 
 
 class Bottleneck(nn.Module):
@@ -30,9 +33,14 @@ class Bottleneck(nn.Module):
         self._c = [_PackCache() for _ in range(4)]
 
     def forward_nhwc(self, x):
-        out = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU)
-        out = conv_bn_forward(self.conv2, self.bn2, self._c[1], out, act=ops.ACT_RELU)
         residual = x
+        if FUSE_RESIDUAL_GRADIENT and self.downsample is None and self.bn1.training and needs_grad(self, x.t):
+            # training: conv1 hands x through for the residual add, so that x has ONE consumer in the autograd graph and
+            # the two gradient contributions are summed inside conv1's data-gradient kernel (autograd.ConvPassFn)
+            out, residual = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU, passthrough=True)
+        else:
+            out = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU)
+        out = conv_bn_forward(self.conv2, self.bn2, self._c[1], out, act=ops.ACT_RELU)
         if self.downsample is not None:
             residual = conv_bn_forward(self.downsample[0], self.downsample[1], self._c[3], x)
         return conv_bn_forward(self.conv3, self.bn3, self._c[2], out, act=ops.ACT_RELU, residual=residual)

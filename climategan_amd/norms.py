@@ -248,10 +248,20 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
     if kw.get("in_upsample") or kw.get("residual_upsample"):
         raise NotImplementedError("conv_bn_forward: folded upsamples are not used on the training path")
     pw = cache.get_plain(conv.weight, conv.bias, x.t.dtype)
+    passthrough = None
+    if kw.pop("passthrough", False):
+        # (ResNet bottleneck) the conv also hands x through for the block's residual add: see autograd.ConvPassFn
+        from .autograd import ConvPassFn
+
+        assert bn is not None and residual is None
+        y_t, pass_t = ConvPassFn.apply(x.t, conv.weight, conv.bias, pw,
+                                       dict(c_in=x.c, stride=conv.stride[0], pad=p, dilation=conv.dilation[0], pad_mode=pad_mode))
+        y, passthrough = ops.NHWC(y_t, conv.weight.shape[0]), ops.NHWC(pass_t, x.c)
     if bn is None:
         return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0],
                            dict(act=act, slope=slope, residual=residual, pad_mode=pad_mode))
-    y = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0], dict(pad_mode=pad_mode))
+    if passthrough is None:
+        y = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0], dict(pad_mode=pad_mode))
     if residual is not None and not FUSE_BN_RESIDUAL:              # A/B switch for tools / tests: the unfused tail
         from . import functional as Fn
         out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
@@ -266,7 +276,7 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
                                  bn.running_var, y.c, bn.eps, bn.momentum if bn.momentum is not None else 0.1, act,
                                  slope, bn.num_batches_tracked if bn.track_running_stats else None,   # counter += 1 in-kernel
                                  residual.t if residual is not None else None)
-    return ops.NHWC(out_t, y.c)
+    return ops.NHWC(out_t, y.c) if passthrough is None else (ops.NHWC(out_t, y.c), passthrough)
 
 
 class SPADE(nn.Module):

@@ -546,9 +546,15 @@ def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
 
 
 def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilation=1,
-                    sigma: Optional[torch.Tensor] = None, pad_mode=PAD_ZERO) -> NHWC:
+                    sigma: Optional[torch.Tensor] = None, pad_mode=PAD_ZERO, add: Optional[NHWC] = None) -> NHWC:
     """dx of y = conv(x, w / sigma): ``w`` fp32 OIHW, ``x_shape`` = (n, h_in, w_in) of the forward input.  Reflect
-    padding: data gradient of the pad-0 conv over the padded extent, folded back by the reflection's adjoint."""
+    padding: data gradient of the pad-0 conv over the padded extent, folded back by the reflection's adjoint.
+    ``add``: another gradient contribution of the same input tensor, summed in the kernel's epilogue (stride-1 'same'
+    convolutions with zero padding; otherwise by a separate pass)."""
+    if add is not None and not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1)
+                                and w.shape[2] == w.shape[3]):
+        dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode)
+        return NHWC(dx.t + add.t, dx.c)
     if pad_mode == PAD_REFLECT and pad > 0:
         n, h_in, w_in = x_shape
         dxp = conv2d_bwd_data(dy, w, (n, h_in + 2 * pad, w_in + 2 * pad), stride=stride, pad=0, dilation=dilation,
@@ -570,6 +576,12 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
                "cgan_conv2d_pack_weight_dgrad")
     dx = torch.empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
+    if add is not None:
+        if add.t.shape != dx.shape or add.t.dtype != dx.dtype or not add.t.is_contiguous():
+            raise RuntimeError("conv2d_bwd_data: ``add`` %s does not match dx %s" % (tuple(add.t.shape), tuple(dx.shape)))
+        _lib.check(lib.cgan_conv2d_nhwc_bwd_data_add(_ptr(dy.t), _ptr(packed), _ptr(add.t), _ptr(dx), C.byref(d), _stream()),
+                   "cgan_conv2d_nhwc_bwd_data_add")
+        return NHWC(dx, c_in)
     _lib.check(lib.cgan_conv2d_nhwc_bwd_data(_ptr(dy.t), _ptr(packed), _ptr(dx), C.byref(d), _stream()),
                "cgan_conv2d_nhwc_bwd_data")
     return NHWC(dx, c_in)
