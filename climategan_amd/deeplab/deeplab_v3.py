@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .. import ops
-from ..norms import _PackCache, conv_bn_forward
+from ..norms import _PackCache, conv_bn_forward, needs_grad
 
 
 class ConvBNReLU(nn.Module):
@@ -30,7 +30,11 @@ class ConvBNReLU(nn.Module):
                 if ly.bias is not None:
                     nn.init.constant_(ly.bias, 0)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, passthrough=False):
+        """``passthrough``: also return x as an output of this conv's autograd node (norms.conv_bn_forward), for the next
+        consumer of the same tensor."""
+        if passthrough:
+            return conv_bn_forward(self.conv, self.bn, self._cache, x, passthrough=True)
         return conv_bn_forward(self.conv, self.bn, self._cache, x)
 
 
@@ -61,7 +65,17 @@ class ASPPv3Plus(nn.Module):
                     nn.init.constant_(ly.bias, 0)
 
     def forward_nhwc(self, x):
-        feats = [c.forward_nhwc(x) for c in (self.conv1, self.conv2, self.conv3, self.conv4)]
+        if self.conv1.bn.training and needs_grad(self, x.t):
+            # training: the four branches read x one after the other through pass-through nodes, so that their data
+            # gradients are summed in the conv kernels' epilogues (autograd.ConvPassFn) instead of by three element-wise
+            # passes over the 2048-channel map
+            feats = []
+            for c in (self.conv1, self.conv2, self.conv3):
+                f, x = c.forward_nhwc(x, passthrough=True)
+                feats.append(f)
+            feats.append(self.conv4.forward_nhwc(x))
+        else:
+            feats = [c.forward_nhwc(x) for c in (self.conv1, self.conv2, self.conv3, self.conv4)]
         return self.conv_out.forward_nhwc(Fn.concat_channels(feats))
 
 

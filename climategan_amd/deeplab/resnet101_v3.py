@@ -34,10 +34,12 @@ class Bottleneck(nn.Module):
 
     def forward_nhwc(self, x):
         residual = x
-        if FUSE_RESIDUAL_GRADIENT and self.downsample is None and self.bn1.training and needs_grad(self, x.t):
-            # training: conv1 hands x through for the residual add, so that x has ONE consumer in the autograd graph and
-            # the two gradient contributions are summed inside conv1's data-gradient kernel (autograd.ConvPassFn)
+        if FUSE_RESIDUAL_GRADIENT and self.bn1.training and needs_grad(self, x.t):
+            # training: conv1 hands x through to the residual branch (the identity, or the downsample conv), so that x has
+            # ONE consumer in the autograd graph and the two gradient contributions are summed inside conv1's
+            # data-gradient kernel (autograd.ConvPassFn)
             out, residual = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU, passthrough=True)
+            x = residual
         else:
             out = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU)
         out = conv_bn_forward(self.conv2, self.bn2, self._c[1], out, act=ops.ACT_RELU)
