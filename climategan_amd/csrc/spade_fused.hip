@@ -32,6 +32,9 @@
 
 #include <type_traits>
 
+#ifndef CGAN_SPADE_WPE
+#define CGAN_SPADE_WPE 4
+#endif
 namespace {
 
 constexpr int TW = 16;       // pixel-tile width == MFMA N
@@ -125,7 +128,7 @@ __device__ __forceinline__ int actv_addr(int q, int slot) {
 //         SIMD (NCT <= 4), so with two co-resident workgroups every SIMD has two MFMA streams and two producer streams to
 //         pick from: the MFMA stream of a workgroup no longer waits on the producer chains of its own wave.
 template <typename T, int NCT, bool C4, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void spade_fused_kernel(SpadeParams p) {   // 2nd arg: waves per SIMD
+__global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_fused_kernel(SpadeParams p) {   // 2nd arg: waves per SIMD
   constexpr int WAVES = NW;               // shadows the namespace constant inside this kernel
   constexpr bool SPEC = NW == 8;          // wave-specialised: consumers 0-3, producers 4-7
   constexpr bool SWZ = !SPEC || NCT <= 4;  // hidden-map slot swizzle (see actv_addr): off where the VGPRs are needed
@@ -833,16 +836,22 @@ extern "C" int cgan_spade_fused_fwd(const void* x, const float* mean, const floa
   p.sy = (float)d->cond_h / (float)d->h; p.sx = (float)d->cond_w / (float)d->w;
   p.act = d->act; p.slope = d->act_slope; p.dbg = g_spade_dbg; p.tsbuf = g_spade_tsbuf;
   hipStream_t s = (hipStream_t)stream;
-  // channel tiles per workgroup: as many as divide nt with the least padded work (nt = 3 -> 3, 5/10/20.. -> 5)
-  const int max_nct = MAX_NCT;
-  int nct = p.nt < max_nct ? p.nt : max_nct;
-  if (p.nt > max_nct) {
-    int best = max_nct, waste = ceil_div(p.nt, max_nct) * max_nct - p.nt;
-    for (int k = max_nct - 1; k >= 3; --k) {
-      int w = ceil_div(p.nt, k) * k - p.nt;
-      if (w < waste) { waste = w; best = k; }
+  // Channel tiles per workgroup (3 .. 5 when the layer has that many).  A workgroup costs a fixed part (hidden-map
+  // production, prologue, epilogue: ~2.5 tile-equivalents) plus its tiles, and the chip takes 512 workgroups per round
+  // (2 per CU): minimise rounds x (k + 2.5).  On the 5^2 .. 80^2 layers of the Painter, where the grid is 1-2 rounds, this
+  // picks 3 or 4 tiles instead of 5 (e.g. 320 channels at 40^2: 576 workgroups of 5 tiles = 2 rounds, 40.8 us; 720 of 4
+  // tiles: 33.6 us; 640 channels at 5^2 / 10^2: 18 -> 13.7 us); large grids keep 5 (least hidden-map recomputation).
+  // (tools/bench_spade.py sweep, bs 8.)
+  const int kmax = p.nt < MAX_NCT ? p.nt : MAX_NCT;
+  int nct = kmax;
+  if (p.nt > 3) {
+    const long tiles = (long)p.n * ceil_div(p.h, 16) * ceil_div(p.w, 16);
+    double best = 1e30;
+    for (int k = kmax; k >= 3; --k) {                       // ties keep the larger k
+      const long wgs = tiles * ceil_div(p.nt, k);
+      const double cost = (double)((wgs + 511) / 512) * (k + 2.5);
+      if (cost < best) { best = cost; nct = k; }
     }
-    nct = best;
   }
   if (g_spade_variant >= 1 && g_spade_variant <= MAX_NCT) nct = g_spade_variant;
   const bool c4 = is_c4(d->cond_c);

@@ -15,6 +15,8 @@ if os.environ.get("CGAN_LIB"):      # A/B against another build of the library (
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float16
 B = 8
 shapes = [(40, 640), (20, 640), (80, 320), (160, 160), (640, 20), (640, 5)]
+if os.environ.get("SPADE_SHAPES"):   # "C:R,C:R,..."
+    shapes = [tuple(int(v) for v in cr.split(":")) for cr in os.environ["SPADE_SHAPES"].split(",")]
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]   # 0 = default tiles; 1-5 force NCT; +10 = 8-wave kernel
 lib = _lib.load()
 cond = ops.nchw_to_nhwc(torch.from_numpy(fill.uniform((B, 3, 640, 640), 1)).cuda(), dt, cs=4)
@@ -39,7 +41,7 @@ for C, R in shapes:
             ops.spade_fused(x, mean, rstd, cond, pk, act=ops.ACT_LRELU)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 5
+        n = 20
         e0.record()
         for _ in range(n):
             ops.spade_fused(x, mean, rstd, cond, pk, act=ops.ACT_LRELU)

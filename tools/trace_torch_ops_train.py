@@ -28,6 +28,8 @@ class Mode(TorchDispatchMode):
         if name not in SKIP:
             st = [f for f in traceback.extract_stack()[:-1] if "climategan_amd" in f.filename]
             site = "%s:%d" % (st[-1].filename.split("/")[-1], st[-1].lineno) if st else "autograd engine"
+            if site == "autograd engine" and args and isinstance(args[0], torch.Tensor):
+                site = "autograd engine %s %s" % (tuple(args[0].shape), str(args[0].dtype).replace("torch.", ""))
             counts[(func.__name__, site)] += 1
             t = args[0] if args and isinstance(args[0], torch.Tensor) else None
             if t is not None:
