@@ -258,10 +258,21 @@ def install_conv_gemm_timer(timer):
                                  2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d), tag(d, "bwd_data"))
         return bwd(dy, w, dx, dref, stream)
 
-    lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data = timed_fwd, timed_bwd
+    bwd_add = lib.cgan_conv2d_nhwc_bwd_data_add
+
+    def timed_bwd_add(dy, w, dx_add, dx, dref, stream):        # data gradient + the other contribution of the same tensor
+        if timer.enabled and kind(dref, 1) == GEMM:
+            d = dref._obj
+            extra = 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)     # the added tensor is read once more
+            return timer.bracket(lambda: bwd_add(dy, w, dx_add, dx, dref, stream),
+                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d) + extra,
+                                 tag(d, "bwd_data+"))
+        return bwd_add(dy, w, dx_add, dx, dref, stream)
+
+    lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = timed_fwd, timed_bwd, timed_bwd_add
 
     def uninstall():
-        lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data = fwd, bwd
+        lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = fwd, bwd, bwd_add
     return uninstall
 
 
