@@ -319,7 +319,7 @@ class MaxPool2x2Fn(torch.autograd.Function):
 class BatchNormActFn(torch.autograd.Function):
     """out = act(batch_norm(x) [+ residual]) in TRAINING mode (batch statistics over n, h, w; running statistics
     updated in place, momentum / unbiased variance as nn.BatchNorm2d).  gamma / beta may be None (affine=False).
-    The residual (the bottleneck's skip connection, resnet101_v3.py:62-70) rides in the apply kernel; its gradient
+    The residual (the bottleneck's skip connection, resnet101_v3.py:30-50) rides in the apply kernel; its gradient
     dy * act'(out) is a second output of the backward's apply kernel."""
 
     @staticmethod

@@ -123,7 +123,7 @@ int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* sigma, void*
 int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
                               void* stream);
 /* dx = (data gradient of the conv) + dx_add, for stride-1 'same' convolutions: the gradient that reaches the conv's INPUT
- * tensor through another consumer (the residual branch of a ResNet bottleneck, resnet101_v3.py:62-70) is added in the
+ * tensor through another consumer (the residual branch of a ResNet bottleneck, resnet101_v3.py:30-50) is added in the
  * conv kernel's epilogue instead of by a separate element-wise pass (autograd's gradient accumulation). */
 int cgan_conv2d_nhwc_bwd_data_add(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx,
                                   const CganConvDesc* fwd, void* stream);
