@@ -11,7 +11,15 @@ args = sys.argv[1:]
 split = args.index("--") if "--" in args else len(args)
 for kv in args[:split]:
     k, v = kv.split("=")
-    mod, attr = k.rsplit(".", 1)
-    setattr(importlib.import_module(mod), attr, type(getattr(importlib.import_module(mod), attr))(int(v)))
+    parts = k.split(".")
+    for n in range(len(parts) - 1, 0, -1):           # longest importable module prefix, then attributes
+        try:
+            obj = importlib.import_module(".".join(parts[:n]))
+            break
+        except ImportError:
+            continue
+    for a in parts[n:-1]:
+        obj = getattr(obj, a)
+    setattr(obj, parts[-1], type(getattr(obj, parts[-1]))(int(v)))
 sys.argv = [str(ROOT / "bench.py")] + args[split + 1:]
 runpy.run_path(str(ROOT / "bench.py"), run_name="__main__")
