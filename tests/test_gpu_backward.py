@@ -625,3 +625,74 @@ def test_conv_backward_padded_1x1_quirk():
     assert rel_err(back(dx), x.grad) <= TOL[dt]
     dw, db = ops.conv2d_bwd_weight(to_nhwc(x.detach(), dt), dyg, tuple(w.shape), pad=1)
     assert rel_err(dw.cpu(), w.grad) <= 2e-4 and rel_err(db.cpu(), b.grad) <= 2e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(256, 64, 1, 0, 1, 2, 24, 40), (128, 96, 3, 2, 2, 1, 33, 21), (40, 24, 3, 1, 1, 2, 16, 16)])
+def test_dgrad_with_added_gradient(dt, case):
+    """cgan_conv2d_nhwc_bwd_data_add (ops.conv2d_bwd_data(add=...)): dx = data gradient + the other gradient contribution of
+    the same tensor, summed in the conv kernel's epilogue -- every kernel family (wide-layer GEMM, 3x3 LDS tile, general).
+    The sum happens in fp32 before the one 16-bit rounding, so it must be at least as close to the fp32 result as the
+    two-pass form (gradient rounded, then added in 16 bit)."""
+    from climategan_amd import ops
+
+    cin, cout, k, pad, dil, B, H, W = case
+    rng = np.random.RandomState(5)
+    w = torch.from_numpy(rng.randn(cout, cin, k, k).astype(np.float32) * 0.05).cuda()
+    dy = to_nhwc(torch.from_numpy(rng.randn(B, cout, H, W).astype(np.float32)), dt)
+    add = to_nhwc(torch.from_numpy(rng.randn(B, cin, H, W).astype(np.float32)), dt)
+    dx = ops.conv2d_bwd_data(dy, w, (B, H, W), stride=1, pad=pad, dilation=dil, add=add)
+    ref = F.conv_transpose2d(back(dy).float(), q(w.cpu().numpy(), dt), stride=1, padding=pad, dilation=dil) + back(add).float()
+    two_pass = ops.conv2d_bwd_data(dy, w, (B, H, W), stride=1, pad=pad, dilation=dil)
+    two_pass = (two_pass.t + add.t)
+    e1 = rel_err(back(dx).float(), ref)
+    e2 = rel_err(back(ops.NHWC(two_pass, cin)).float(), ref)
+    assert e1 <= TOL[dt] and e1 <= 1.5 * e2 + 1e-5, (e1, e2)
+    assert (dx.t[..., cin:] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_pass_fn_matches_autograd_on_a_residual_block(dt):
+    """autograd.ConvPassFn: y = act(bn(conv1(x))) ... + x with x handed through conv1's node.  Gradients of x, the conv
+    weight and the tail must equal those of the plain graph (two consumers of x, autograd's own accumulation) up to the
+    one rounding the fused sum saves."""
+    from climategan_amd import ops
+    from climategan_amd.deeplab import resnet101_v3 as R
+
+    torch.manual_seed(3)
+    blk = R.Bottleneck(64, 16, 1, 1, None, torch.nn.BatchNorm2d).cuda().train()
+    x0 = torch.randn(2, 64, 24, 20, device="cuda")
+    grads = {}
+    for fuse in (True, False):
+        R.FUSE_RESIDUAL_GRADIENT = fuse
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            x = ops.nchw_to_nhwc(x0, dt)
+            x.t.requires_grad_(True)
+            y = blk.forward_nhwc(x)
+            (y.t.float() * torch.linspace(-1, 1, y.t.numel(), device="cuda").view_as(y.t)).sum().backward()
+            grads[fuse] = [x.t.grad.float().clone()] + [p.grad.float().clone() for p in blk.parameters()]
+        finally:
+            R.FUSE_RESIDUAL_GRADIENT = True
+    for a, b in zip(grads[True], grads[False]):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= (2 * TOL[dt]) * scale
+
+
+def test_batched_weight_pack_is_bitwise_the_single_pack():
+    """ops.pack_conv_weights_batched (what norms._PackCache.get_plain uses to refresh every stale plain conv weight after an
+    optimizer step in one launch) vs ops.pack_conv_weight, byte for byte, incl. buffer reuse."""
+    from climategan_amd import ops
+
+    torch.manual_seed(0)
+    shapes = [(64, 3, 7, 7), (256, 64, 1, 1), (64, 64, 3, 3), (20, 40, 3, 3), (1, 8, 3, 3), (512, 2048, 1, 1)]
+    params = [(torch.randn(s, device="cuda") * 0.1, torch.randn(s[0], device="cuda") if i % 2 else None)
+              for i, s in enumerate(shapes)]
+    for dt in DTYPES:
+        got = ops.pack_conv_weights_batched(params, dt)
+        again = ops.pack_conv_weights_batched([(w * 2, b) for w, b in params], dt, got)       # reuse the buffers
+        for (w, b), g, a in zip(params, got, again):
+            assert a.w.data_ptr() == g.w.data_ptr()
+            ref2 = ops.pack_conv_weight(w * 2, b, dt)
+            assert torch.equal(a.w, ref2.w) and torch.equal(a.bias, ref2.bias)
