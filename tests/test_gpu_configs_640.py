@@ -416,3 +416,39 @@ def test_four_train_iterations_follow_the_reference_trajectory():
             assert abs(m - r) <= 1.5e-2 * max(abs(r), 1e-3), (k, ref, mine)
         if abs(ref[-1] - ref[0]) > 2e-2 * abs(ref[0]):
             assert abs((mine[-1] - mine[0]) - (ref[-1] - ref[0])) <= max(0.10 * abs(ref[-1] - ref[0]), 5e-3 * abs(ref[0])), (k, ref, mine)
+
+
+def test_sixty_iterations_stay_finite_and_learn():
+    """A longer run of the joint training loop on one batch (small fixture): every logged term stays finite, the supervised
+    terms (depth, segmentation cross-entropy, mask BCE, VGG) fall, parameters and running statistics of every network move,
+    and the packed-weight caches follow (the forward of the trained generator equals that of a fresh one loaded from its
+    state dict -- the property the stale-weights bug broke)."""
+    from climategan_amd.generator import create_generator
+
+    case = CASES_640["jstep_small"]
+    T = _build_train(("d", "s", "m", "p"), case, 1)
+    batch = _batch(case, 1, ("r", "s", "rf"))
+    T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
+    first = None
+    for it in range(60):
+        g, d = T.train_step(batch)
+        assert torch.isfinite(g) and torch.isfinite(d), it
+        if first is None:
+            first = {k: float(v) for k, v in T.loss_log.items()}
+    last = {k: float(v) for k, v in T.loss_log.items()}
+    assert all(v == v and abs(v) < 1e6 for v in last.values()), last
+    print("\n  after 60 iterations: " + ", ".join("%s %.4g -> %.4g" % (k, first[k], last[k])
+                                                 for k in ("G.d.s", "G.s.crossent.s", "G.m.bce.s", "G.p.vgg", "D.p.gan")))
+    for k, factor in (("G.d.s", 0.5), ("G.s.crossent.s", 0.9), ("G.m.bce.s", 0.99), ("G.p.vgg", 0.95)):
+        assert last[k] < factor * first[k], (k, first[k], last[k])
+    sd = {k: v.detach().clone() for k, v in T.G.state_dict().items()}
+    fresh = create_generator(T.opts, device="cuda", no_init=True)
+    fresh.load_state_dict(sd)
+    fresh.set_compute_dtype(torch.bfloat16)
+    fresh.decoders["d"]._target_size = case["W"] // 4
+    fresh.decoders["s"].set_target_size((case["H"] // 4, case["W"] // 4))
+    T.G.eval(); fresh.eval()
+    with torch.no_grad():
+        a, b = T.G.masker_forward(batch["r"]["data"]["x"]), fresh.masker_forward(batch["r"]["data"]["x"])
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
