@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
-int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 262144;
+int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768;
 }  // namespace
 
 extern "C" void cgan_debug_set_wgrad_coop_min_pixels(int v) { g_wgrad_coop_min_pix = v; }
