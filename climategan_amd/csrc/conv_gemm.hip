@@ -36,7 +36,7 @@ __device__ __forceinline__ int reflect_i(int i, int n) {
   return i;
 }
 
-template <typename T, int WAVES_C, int WC, int WP, bool REFLECT>
+template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int npb, int ncb) {
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int CT_BLK = WAVES_C * WC;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
     i_ky = wy ? 0 : ky1;
     const int cc1 = i_cc + (wy ? 1 : 0);
     i_cc = cc1 == ccn ? 0 : cc1;
-    i_buf = (i_buf + 1 == NSTAGE) ? 0 : i_buf + 1;
+    i_buf = (i_buf + 1 == NS) ? 0 : i_buf + 1;
   };
   auto issue = [&]() {
 #pragma unroll
@@ -137,11 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   // be spread between the MFMAs: issued back to back right after the barrier they serialise every wave of the CU on
   // the vector-memory path before any MFMA starts.
   issue();
-  issue();
+  if (NS > 2) issue();
   int r_buf = 0;
   for (int ks = 0; ks < p.ksteps; ++ks) {
-    // stage ks has landed once at most the DMAs of stage ks+1 are still in flight (in-order completion)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_PER_WAVE) : "memory");
+    // stage ks has landed once at most the DMAs of the NS - 2 younger stages are still in flight (in-order completion)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * DMA_PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned char* buf = smem + r_buf * STAGE_BYTES;
     // the operand every MFMA of the first group needs goes first (LDS returns in order): the MFMAs start after
@@ -167,15 +167,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
       }
     }
     issue_advance();
-    r_buf = (r_buf + 1 == NSTAGE) ? 0 : r_buf + 1;
+    r_buf = (r_buf + 1 == NS) ? 0 : r_buf + 1;
   }
 
   // ---- epilogue: lane holds channels ct*16 + 4g + {0..3} of pixel (tile, j).  Staged through LDS (fp32, row =
   // one pixel x the wave's WC*16 couts, +16 B pad) PP pixel tiles at a time, then written as 16-byte chunks.
   constexpr int ROWB = WC * 64 + 16;
-  constexpr int PP = (4 * 4 * 16 * ROWB <= NSTAGE * STAGE_BYTES && WP % 4 == 0) ? 4 : 2;   // pixel tiles per pass
+  constexpr int PP = (4 * 4 * 16 * ROWB <= NS * STAGE_BYTES && WP % 4 == 0) ? 4
+                     : (4 * 2 * 16 * ROWB <= NS * STAGE_BYTES ? 2 : 1);                // pixel tiles per pass
   constexpr int CH = WC * 2;                                  // 8-channel chunks per staged row
-  static_assert(4 * PP * 16 * ROWB <= NSTAGE * STAGE_BYTES, "epilogue staging does not fit");
+  static_assert(4 * PP * 16 * ROWB <= NS * STAGE_BYTES, "epilogue staging does not fit");
   static_assert(WP % PP == 0, "WP must be a multiple of PP");
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                               // every wave is done with the operand ring
@@ -522,14 +523,14 @@ int launch_k64(const ConvGemmArgs& a, hipStream_t s) {
 bool k64_ok(const ConvGemmArgs& a) { return (a.cin_s & 63) == 0 && a.pad_mode != CGAN_PAD_REFLECT && a.kh * a.kw <= 32; }
 
 
-template <typename T, int WAVES_C, int WC, int WP, bool REFLECT>
+template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE>
 int launch_cfg2(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int CT_BLK = WAVES_C * WC, PT_BLK = WAVES_P * WP;
-  constexpr size_t smem = (size_t)NSTAGE * (CT_BLK + PT_BLK) * 1024;
+  constexpr size_t smem = (size_t)NS * (CT_BLK + PT_BLK) * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -540,14 +541,14 @@ int launch_cfg2(const ConvGemmArgs& a, hipStream_t s) {
   const int npb = ceil_div(ceil_div(a.npix, 16), PT_BLK);
   const int ncb = ceil_div(a.ctiles, CT_BLK);
   const int grid = ceil_div(npb, 8) * 8 * ncb;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT>), dim3(grid), dim3(256), smem, s, a, npb, ncb);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT, NS>), dim3(grid), dim3(256), smem, s, a, npb, ncb);
   return CGAN_OK;
 }
 
-template <typename T, int WAVES_C, int WC, int WP>
+template <typename T, int WAVES_C, int WC, int WP, int NS = NSTAGE>
 int launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
-  return a.pad_mode == CGAN_PAD_REFLECT ? launch_cfg2<T, WAVES_C, WC, WP, true>(a, s)
-                                        : launch_cfg2<T, WAVES_C, WC, WP, false>(a, s);
+  return a.pad_mode == CGAN_PAD_REFLECT ? launch_cfg2<T, WAVES_C, WC, WP, true, NS>(a, s)
+                                        : launch_cfg2<T, WAVES_C, WC, WP, false, NS>(a, s);
 }
 
 int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 1..4 = force a block tile
@@ -575,13 +576,16 @@ int launch(const ConvGemmArgs& a, hipStream_t s) {
     case 2: if (a.ctiles <= 16) return launch_cfg<T, 2, 8, 4>(a, s); break;
     case 3: return launch_cfg<T, 2, 4, 8>(a, s);
     case 4: return launch_cfg<T, 2, 4, 4>(a, s);
+    case 5: return launch_cfg<T, 2, 4, 4, 2>(a, s);      // 128 x 128 with a 2-stage ring (32 KiB: 4 workgroups per CU)
     default: break;
   }
   if (a.ctiles <= 4) return launch_cfg<T, 1, 4, 4>(a, s);                       // 64 couts x 256 pixels
   // 1x1 layers with a short K (bottleneck expands, K <= 512): the workgroup is all prologue / epilogue, and 128 x 128
   // blocks (twice as many, half the epilogue each) overlap them better: 256 -> 1024 at 16 x 80^2: 175 -> 120 us,
   // 64 -> 256 at 16 x 160^2: 128 -> 80 us (rocprofv3 kernel durations, tools/prof_conv.sh)
-  if (a.kh * a.kw == 1 && a.ksteps <= 16) return launch_cfg<T, 2, 4, 4>(a, s);
+  // (with a 2-stage ring: 32 KiB per workgroup, so four of them share a CU and cover each other's prologue / epilogue:
+  // 64 -> 256 at 8 x 160^2 41 -> 37 us, 256 -> 1024 at 8 x 80^2 61.3 -> 60.4 us)
+  if (a.kh * a.kw == 1 && a.ksteps <= 16) return launch_cfg<T, 2, 4, 4, 2>(a, s);
   // all couts in one block (activations read once) when cout <= 256 and the grid still fills the chip
   if (a.ctiles > 8 && a.ctiles <= 16 && ceil_div(ptiles, 8) >= 384) return launch_cfg<T, 2, 8, 4>(a, s);
   // 128 couts x 256 pixels while that still gives every CU a couple of workgroups, else 128 x 128
