@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import ops
-from .norms import (DEFAULT_COMPUTE_DTYPE, SPADE, SpectralNorm, _grad_guard, _PackCache, conv_bn_forward,
+from .norms import (DEFAULT_COMPUTE_DTYPE, SPADE, SpectralNorm, _PackCache, conv_bn_forward,
                     conv_forward)
 
 

@@ -5,7 +5,6 @@ The reference moves predictions to the CPU and loops over classes with ``.item()
 (``cgan_seg_counts``) produces the per-class counts (predicted / labelled / both) in one pass over the device tensors
 and the ratios are formed from 3 x C integers.  Integer work: results are exactly the reference's for the same logits.
 """
-import ctypes as C
 
 import numpy as np
 import torch

@@ -12,7 +12,7 @@ from . import ops
 from .deeplab import create_encoder, create_segmentation_decoder
 from .depth import create_depth_decoder
 from .masker import create_mask_decoder
-from .norms import DEFAULT_COMPUTE_DTYPE, _grad_guard, spectral_norm_step_all
+from .norms import DEFAULT_COMPUTE_DTYPE, spectral_norm_step_all
 from .painter import create_painter
 from .tutils import init_weights
 

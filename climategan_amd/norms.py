@@ -5,8 +5,6 @@ checkpoints load unchanged; the arithmetic runs in libcgan_hip.so (HIP, gfx950) 
 AdaptiveInstanceNorm2d / LayerNorm of the reference are dead options in the default configs (SURVEY.md
 section 2a) and are not provided.
 """
-import math
-
 import torch
 import torch.nn as nn
 

@@ -6,8 +6,6 @@ steps (trainer.py:674-694) -- with the whole update of every parameter tensor fu
 exp_avg_sq}``) so ``state_dict()`` round-trips with the reference's checkpoints (``g_opt`` / ``d_opt``,
 trainer.py:403-420).
 """
-import ctypes as C
-
 import torch
 from torch.optim import Optimizer
 
