@@ -13,7 +13,7 @@ if os.environ.get("CGAN_LIB"):      # A/B against another build of the library (
     _lib.LIB_PATH = Path(os.environ["CGAN_LIB"]).resolve()
 
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float16
-B = 8
+B = int(os.environ.get("SPADE_B", "8"))
 shapes = [(40, 640), (20, 640), (80, 320), (160, 160), (640, 20), (640, 5)]
 if os.environ.get("SPADE_SHAPES"):   # "C:R,C:R,..."
     shapes = [tuple(int(v) for v in cr.split(":")) for cr in os.environ["SPADE_SHAPES"].split(",")]
