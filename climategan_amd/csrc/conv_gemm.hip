@@ -520,7 +520,11 @@ int launch_k64(const ConvGemmArgs& a, hipStream_t s) {
   return CGAN_OK;
 }
 // the K = 64 kernel's preconditions (beyond conv_gemm_applicable): whole 64-channel chunks, zero padding
-bool k64_ok(const ConvGemmArgs& a) { return (a.cin_s & 63) == 0 && a.pad_mode != CGAN_PAD_REFLECT && a.kh * a.kw <= 32; }
+// (32-bit BYTE offsets per lane: the input must stay below 2 GiB)
+bool k64_ok(const ConvGemmArgs& a) {
+  return (a.cin_s & 63) == 0 && a.pad_mode != CGAN_PAD_REFLECT && a.kh * a.kw <= 32 &&
+         (long)a.n * a.h_in * a.w_in * a.cin_s < (1L << 30) - (1L << 20);
+}
 
 
 template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE>
