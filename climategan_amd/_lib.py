@@ -141,6 +141,8 @@ _SIGNATURES = {
     "cgan_softmax_ce_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_float, _P, _P, _P]),
     "cgan_tv_nhwc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "cgan_advent_entropy_pair_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "cgan_entropy_pair_from_nchw": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_entropy_pair_from_nchw_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_advent_entropy_pair_bwd_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
     "cgan_entropy_map_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "cgan_entropy_map_bwd_nhwc": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),

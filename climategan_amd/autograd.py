@@ -74,6 +74,80 @@ def split_batch(x: "ops.NHWC", groups: int):
     return [ops.NHWC(x.t[i * b:(i + 1) * b], x.c) for i in range(groups)]
 
 
+class ToNchwFn(torch.autograd.Function):
+    """16-bit NHWC map -> fp32 NCHW tensor (``cgan_nhwc_to_nchw``; with ``paste_x / paste_m``: x (1 - m) + y m, reference
+    generator.py:295-296).  The backward is the opposite layout kernel on the incoming gradient (times m under a paste):
+    what lets ``G.paint`` / ``G.mask`` / ``decoders[t](z)`` / ``D[...](x)`` hand out the reference's NCHW tensors WITH
+    their graph, so that the reference's trainer.py (which feeds them to torch ops and to the loss classes) binds
+    unchanged."""
+
+    @staticmethod
+    def forward(ctx, y_t, c, paste_x, paste_m):
+        ctx.cfg = (c, y_t.dtype, y_t.shape[3])
+        ctx.save_for_backward(paste_m)
+        return ops.nhwc_to_nchw(ops.NHWC(y_t, c), paste_x, paste_m)
+
+    @staticmethod
+    def backward(ctx, g):
+        c, dt, cs = ctx.cfg
+        (paste_m,) = ctx.saved_tensors
+        # the forward kernel computes x (1 - mask): hand it 1 - m to get g * m
+        keep = (1.0 - paste_m.float()) if paste_m is not None else None
+        return ops.nchw_to_nhwc(g, dt, cs=cs, mask=keep).t, None, None, None
+
+
+class FromNchwFn(torch.autograd.Function):
+    """fp32 (or 16-bit) NCHW tensor -> 16-bit NHWC map (``cgan_nchw_to_nhwc``; with ``mask``: x (1 - mask), reference
+    generator.py:294); the gradient goes back to ``x`` through the opposite layout kernel."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, cs, mask):
+        y = ops.nchw_to_nhwc(x, dtype, cs=cs, mask=mask)
+        ctx.c, ctx.in_dtype = x.shape[1], x.dtype
+        ctx.save_for_backward(mask)
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        (mask,) = ctx.saved_tensors
+        dx = ops.nhwc_to_nchw(ops.NHWC(dy_t.contiguous(), ctx.c))
+        if mask is not None:
+            dx = dx * (1.0 - mask.float())
+        return dx.to(ctx.in_dtype), None, None, None
+
+
+class FromNchwPairFn(torch.autograd.Function):
+    """fp32 NCHW tensor -> NHWC (hi | lo) 16-bit pair map with 2C channels, value = hi + lo (the form the first VGG conv
+    takes for its pre-processed input, whose magnitudes of 100-150 would lose +-0.5 in one bf16 value); d/dx = d/d(hi)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = x.float()
+        hi = x.to(dtype).float()
+        y = ops.nchw_to_nhwc(torch.cat([hi, x - hi], dim=1), dtype)
+        ctx.c = x.shape[1]
+        return y.t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        return ops.nhwc_to_nchw(ops.NHWC(dy_t.contiguous(), 2 * ctx.c))[:, :ctx.c].contiguous(), None
+
+
+class ResizeNearestFn(torch.autograd.Function):
+    """F.interpolate(mode="nearest") to an arbitrary size (the Painter's latent from the conditioning image,
+    painter.py:152) with its adjoint: only reached when the conditioning image itself carries a graph (pl4m)."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, size, cs_out):
+        ctx.cfg = (c, x_t.shape[1], x_t.shape[2], x_t.shape[3])
+        return ops.resize_nearest(ops.NHWC(x_t, c), size, cs_out=cs_out).t
+
+    @staticmethod
+    def backward(ctx, dy_t):
+        c, h, w, cs = ctx.cfg
+        return ops.resize_nearest_bwd(ops.NHWC(dy_t.contiguous(), c), (h, w), cs).t, None, None, None
+
+
 class ConvFn(torch.autograd.Function):
     """y = act(conv(up?(x), w[/sigma]) + b + up?(res)).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under
     spectral norm, in which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped
@@ -222,12 +296,16 @@ class SpadeFn(torch.autograd.Function):
         del gamma
         # mlp_gamma / mlp_beta as ONE conv with 2C outputs: weight and bias gradients, then the hidden map's gradient
         w_gb = torch.cat([w_g.detach(), w_b.detach()], dim=0)
-        dw_gb, db_gb = ops.conv2d_bwd_weight(actv, dgb, tuple(w_gb.shape), pad=1)
+        want_gb, want_sh = any(ctx.needs_input_grad[6:10]), any(ctx.needs_input_grad[4:6])   # frozen under pl4m
+        dw_gb = db_gb = dw_sh = db_sh = None
+        if want_gb:
+            dw_gb, db_gb = ops.conv2d_bwd_weight(actv, dgb, tuple(w_gb.shape), pad=1)
         d_actv = ops.conv2d_bwd_data(dgb, w_gb, (actv.n, h, w), pad=1)
         del dgb
         d_pre = ops.act_bwd(actv, d_actv, ops.ACT_RELU)
         del d_actv, actv
-        dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
+        if want_sh:
+            dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
         dcond_t = None
         if ctx.needs_input_grad[1]:
             # the conditioning map is a prediction (SPADE mask decoder with gen.m.spade.detach = false): back through
@@ -249,6 +327,8 @@ class SpadeFn(torch.autograd.Function):
         if cfg["x_upsample"]:
             dx = ops.sumpool2x2(dx)
         dx_t = dx.t if ctx.needs_input_grad[0] else None
+        if not want_gb:
+            return (dx_t, dcond_t, None, None, dw_sh, db_sh, None, None, None, None, None, None)
         return (dx_t, dcond_t, None, None, dw_sh, db_sh, dw_gb[:c].contiguous(), db_gb[:c].contiguous(),
                 dw_gb[c:].contiguous(), db_gb[c:].contiguous(), None, None)
 
@@ -541,6 +621,33 @@ class AdventPairFn(torch.autograd.Function):
         _call("cgan_advent_entropy_pair_bwd_nhwc", ops._ptr(x_t), ops._ptr(depth_t), ops._ptr(dy.contiguous()),
               ops._ptr(dx), ops._DT[x_t.dtype], _npix(x_t), ctx.c, ctx.sig, ops._stream())
         return dx, None, None, None
+
+
+class EntropyPairFromNchwFn(torch.autograd.Function):
+    """prob_2_entropy(prob) [* depth] of fp32 NCHW probabilities (the reference's ADVENT call signature, losses.py:517-519)
+    -> the (hi | lo) pair map the ADVENT discriminators take; backward: fp32 NCHW d(prob)."""
+
+    @staticmethod
+    def forward(ctx, prob, depth, dtype):
+        prob = prob.contiguous().float()
+        depth = depth.contiguous().float() if depth is not None else None
+        n, c, h, w = prob.shape
+        if depth is not None and tuple(depth.shape) != (n, 1, h, w):
+            raise ValueError("advent: depth %s does not match the probabilities %s" % (tuple(depth.shape), tuple(prob.shape)))
+        y = torch.empty((n, h, w, ops.cs8(2 * c)), dtype=dtype, device=prob.device)
+        _call("cgan_entropy_pair_from_nchw", ops._ptr(prob), ops._ptr(depth), ops._ptr(y), ops._DT[dtype], n, c, h, w,
+              ops._stream())
+        ctx.save_for_backward(prob, depth)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        prob, depth = ctx.saved_tensors
+        n, c, h, w = prob.shape
+        dp = torch.empty_like(prob)
+        _call("cgan_entropy_pair_from_nchw_bwd", ops._ptr(prob), ops._ptr(depth), ops._ptr(dy.contiguous()), ops._ptr(dp),
+              ops._DT[dy.dtype], n, c, h, w, ops._stream())
+        return dp, None, None
 
 
 class _ScalarLossFn(torch.autograd.Function):

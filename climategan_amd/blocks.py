@@ -28,8 +28,8 @@ class InterpolateNearest2d(nn.Module):
                 return Fn.upsample_nearest2x(x)
             return ops.resize_nearest(x, (x.h * self.scale_factor, x.w * self.scale_factor))
         dt = DEFAULT_COMPUTE_DTYPE
-        y = ops.resize_nearest(ops.nchw_to_nhwc(x, dt), (x.shape[-2] * self.scale_factor, x.shape[-1] * self.scale_factor))
-        return ops.nhwc_to_nchw(y).to(x.dtype)
+        y = Fn.resize_nearest(Fn.from_nchw(x, dt), (x.shape[-2] * self.scale_factor, x.shape[-1] * self.scale_factor))
+        return Fn.to_nchw(y).to(x.dtype)
 
 
 _ACTS = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH, "sigmoid": ops.ACT_SIGMOID,
@@ -122,7 +122,7 @@ class Conv2dBlock(nn.Module):
 
     def forward(self, x, compute_dtype=None):
         dt = compute_dtype or DEFAULT_COMPUTE_DTYPE
-        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x, dt))).to(x.dtype)
+        return Fn.to_nchw(self.forward_nhwc(Fn.from_nchw(x, dt))).to(x.dtype)
 
 
 class ResBlock(nn.Module):
@@ -273,9 +273,9 @@ class SPADEResnetBlock(nn.Module):
     def forward(self, x, seg, compute_dtype=None):
         """Reference signature: NCHW tensors in, NCHW out."""
         dt = compute_dtype or DEFAULT_COMPUTE_DTYPE
-        xs = ops.nchw_to_nhwc(x, dt)
-        cond = ops.nchw_to_nhwc(seg, dt, cs=ops.cs4(seg.shape[1]))
-        return ops.nhwc_to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
+        xs = Fn.from_nchw(x, dt)
+        cond = Fn.from_nchw(seg, dt, cs=ops.cs4(seg.shape[1]))
+        return Fn.to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
 
     def shortcut(self, x, seg):
         raise NotImplementedError("SPADEResnetBlock.shortcut is fused into forward() in this build")

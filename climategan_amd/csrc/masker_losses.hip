@@ -302,6 +302,40 @@ __global__ __launch_bounds__(256) void affine_sum_kernel(const uint16_t* __restr
   block_add(acc, loss);
 }
 
+// ---- the same pair map from fp32 NCHW PROBABILITIES (the reference's call signature: ADVENTAdversarialLoss receives
+// softmax(pred) / cat[p, 1 - p] as NCHW tensors, losses.py:517-519) and its backward (fp32 NCHW d(prob)) --------------------
+template <typename T>
+__global__ __launch_bounds__(256) void entropy_pair_nchw_fwd_kernel(const float* __restrict__ p, const float* __restrict__ depth,
+                                                                    uint16_t* __restrict__ y, int c, long hw, int cs_out,
+                                                                    long npix) {
+  const float ilc = 1.f / log2f((float)c);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, r = i - n * hw;
+    const float dv = depth ? depth[i] : 1.f;
+    uint16_t* yp = y + i * cs_out;
+    for (int k = 0; k < c; ++k) {
+      const float v = ent(p[(n * c + k) * hw + r], ilc) * dv;
+      const uint16_t hi = bits_of<T>(v);
+      yp[k] = hi;
+      yp[c + k] = bits_of<T>(v - f32_of_bits<T>(hi));
+    }
+    for (int k = 2 * c; k < cs_out; ++k) yp[k] = 0;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void entropy_pair_nchw_bwd_kernel(const float* __restrict__ p, const float* __restrict__ depth,
+                                                                    const uint16_t* __restrict__ dy, float* __restrict__ dp,
+                                                                    int c, long hw, int cs_out, long npix) {
+  const float ilc = 1.f / log2f((float)c);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, r = i - n * hw;
+    const float dv = depth ? depth[i] : 1.f;
+    for (int k = 0; k < c; ++k) {
+      const long j = (n * c + k) * hw + r;
+      dp[j] = f32_of_bits<T>(dy[i * cs_out + k]) * ent_grad(p[j], ilc) * dv;     // the hi half carries d/d(value)
+    }
+  }
+}
 }  // namespace
 
 #define ML_DISPATCH(dtype, KERNEL, ...)                                     \
@@ -387,6 +421,28 @@ extern "C" int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const
   ML_DISPATCH(dtype, entropy_bwd_kernel, dim3(grid_ml(npix * cs)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)p,
               (const uint16_t*)depth, (const uint16_t*)dy, (uint16_t*)dp, c, cs, (long)npix * cs);
   CGAN_CHECK_LAUNCH("entropy_map_bwd");
+  return CGAN_OK;
+}
+extern "C" int cgan_entropy_pair_from_nchw(const float* prob, const float* depth, void* y, int32_t dtype, int32_t n,
+                                           int32_t c, int32_t h, int32_t w, void* stream) {
+  CGAN_REQUIRE(prob && y && n > 0 && h > 0 && w > 0, "entropy_pair_from_nchw: bad arguments");
+  CGAN_REQUIRE(c > 1 && c <= ADV_MAXC, "entropy_pair_from_nchw: %d channels (2..%d)", c, ADV_MAXC);
+  ML_CHECK_DT("entropy_pair_from_nchw");
+  const long npix = (long)n * h * w;
+  ML_DISPATCH(dtype, entropy_pair_nchw_fwd_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, prob, depth,
+              (uint16_t*)y, c, (long)h * w, cgan_cs(2 * c), npix);
+  CGAN_CHECK_LAUNCH("entropy_pair_from_nchw");
+  return CGAN_OK;
+}
+extern "C" int cgan_entropy_pair_from_nchw_bwd(const float* prob, const float* depth, const void* dy, float* dprob,
+                                               int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  CGAN_REQUIRE(prob && dy && dprob && n > 0 && h > 0 && w > 0, "entropy_pair_from_nchw_bwd: bad arguments");
+  CGAN_REQUIRE(c > 1 && c <= ADV_MAXC, "entropy_pair_from_nchw_bwd: %d channels (2..%d)", c, ADV_MAXC);
+  ML_CHECK_DT("entropy_pair_from_nchw_bwd");
+  const long npix = (long)n * h * w;
+  ML_DISPATCH(dtype, entropy_pair_nchw_bwd_kernel, dim3(grid_ml(npix)), dim3(256), 0, (hipStream_t)stream, prob, depth,
+              (const uint16_t*)dy, dprob, c, (long)h * w, cgan_cs(2 * c), npix);
+  CGAN_CHECK_LAUNCH("entropy_pair_from_nchw_bwd");
   return CGAN_OK;
 }
 extern "C" int cgan_advent_entropy_pair_nhwc(const void* logits, const void* depth, void* y, int32_t dtype, int64_t npix,

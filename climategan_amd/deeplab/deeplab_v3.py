@@ -166,4 +166,4 @@ class DeepLabV3Decoder(nn.Module):
         return Fn.resize_bilinear(s, tuple(ts), align_corners=True)
 
     def forward(self, z, z_depth=None):
-        return ops.nhwc_to_nchw(self.forward_nhwc(z, z_depth))
+        return Fn.to_nchw(self.forward_nhwc(z, z_depth))

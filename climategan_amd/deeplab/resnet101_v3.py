@@ -107,7 +107,7 @@ class ResNet(nn.Module):
 
     def forward(self, input):
         """NCHW in; returns (z_high, z_low) as NHWC containers (consumed by the decoders of this package)."""
-        x = input if isinstance(input, ops.NHWC) else ops.nchw_to_nhwc(input, self.compute_dtype)
+        x = Fn.from_nchw(input, self.compute_dtype)
         return self.forward_nhwc(x)
 
 

@@ -70,4 +70,4 @@ class DADADepthDecoder(nn.Module):
 
     def forward(self, z):
         d, zd = self.forward_nhwc(z)
-        return ops.nhwc_to_nchw(d), zd
+        return Fn.to_nchw(d), zd

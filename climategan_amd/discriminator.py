@@ -13,6 +13,7 @@ import functools
 import torch
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 from .norms import DEFAULT_COMPUTE_DTYPE, SpectralNorm, needs_grad, spectral_norm_step_all
 
@@ -66,12 +67,9 @@ def _is_instance_norm(norm_layer):
 
 
 def _to_nchw(o: ops.NHWC, module, dtype=None):
-    """NCHW fp32 view of a feature map for callers that want the reference's tensors.  The layout kernel has no
-    backward: under autograd ask for ``nhwc=True`` and feed the maps to ``climategan_amd.losses``."""
-    if needs_grad(module, o.t):
-        raise NotImplementedError("climategan_amd discriminators: under autograd call D(x, nhwc=True) and use "
-                                  "climategan_amd.losses (the NHWC -> NCHW layout pass has no backward kernel)")
-    y = ops.nhwc_to_nchw(o)
+    """The reference's NCHW fp32 tensor of a feature map, with its graph under autograd (``autograd.ToNchwFn``).  The
+    package's own trainer asks for ``nhwc=True`` instead and skips the 18 layout passes per call."""
+    y = Fn.to_nchw(o)
     return y if dtype is None else y.to(dtype)
 
 
@@ -90,6 +88,7 @@ class NLayerDiscriminator(nn.Module):
         use_bias = True  # norm_layer == InstanceNorm2d (reference discriminator.py:93-96)
         self.get_intermediate_features = get_intermediate_features
         self.n_layers = n_layers
+        self.compute_dtype = DEFAULT_COMPUTE_DTYPE
         kw, padw = 4, 1
         seq = [[SpectralNorm(nn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw)), nn.LeakyReLU(0.2, True)]]
         nf_mult = 1
@@ -126,7 +125,7 @@ class NLayerDiscriminator(nn.Module):
         return outs
 
     def forward(self, input, nhwc=False):
-        x = input if isinstance(input, ops.NHWC) else ops.nchw_to_nhwc(input, DEFAULT_COMPUTE_DTYPE)
+        x = Fn.from_nchw(input, self.compute_dtype)
         outs = self.forward_nhwc(x)
         if not nhwc:
             outs = [_to_nchw(o, self) for o in outs]
@@ -152,13 +151,7 @@ class MultiscaleDiscriminator(nn.Module):
         """``nhwc=False``: the reference's list[num_D] of list[n_layers+2] NCHW tensors (no-grad callers);
         ``nhwc=True``: the same structure of ``ops.NHWC`` maps, differentiable (training path)."""
         spectral_norm_step_all(self, self.compute_dtype)      # all 6*num_D power iterations + packs, batched
-        if isinstance(input, ops.NHWC):
-            x = input
-        else:
-            if torch.is_grad_enabled() and input.requires_grad:
-                raise NotImplementedError("MultiscaleDiscriminator: a gradient w.r.t. an NCHW input needs the layout "
-                                          "backward (not built); pass an ops.NHWC input")
-            x = ops.nchw_to_nhwc(input, self.compute_dtype)
+        x = Fn.from_nchw(input, self.compute_dtype)        # differentiable w.r.t. an NCHW input (autograd.FromNchwFn)
         result = []
         for i in range(self.num_D):
             D = getattr(self, "discriminator_%d" % i)
@@ -196,7 +189,7 @@ class FCDiscriminator(nn.Sequential):
         from .norms import _PackCache, conv_forward
 
         spectral_norm_step_all(self, self.compute_dtype)
-        y = input if isinstance(input, ops.NHWC) else ops.nchw_to_nhwc(input, self.compute_dtype)
+        y = Fn.from_nchw(input, self.compute_dtype)
         for i, idx in enumerate((0, 2, 4, 6, 8)):
             cache = self._caches.setdefault(idx, _PackCache())
             if i == 0 and y.c == 2 * self._in_channels():
@@ -280,7 +273,27 @@ class OmniDiscriminator(nn.ModuleDict):
                 num_classes=11, use_norm=opts.dis.s.gan_type == "WGAN_norm")})
 
     def set_compute_dtype(self, dtype):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
         for m in self.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = dtype
+        return self
+
+    # dtype casts select the kernels' 16-bit type; the fp32 master parameters stay (see OmniGenerator.half)
+    def half(self):
+        return self.set_compute_dtype(torch.float16)
+
+    def bfloat16(self):
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def float(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        device, dtype, non_blocking, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype in (torch.float16, torch.bfloat16):
+            self.set_compute_dtype(dtype)
+        if device is not None:
+            return super().to(device, non_blocking=non_blocking)
         return self

@@ -48,3 +48,45 @@ def mul(a: ops.NHWC, b: ops.NHWC) -> ops.NHWC:
 def add_act(a: ops.NHWC, b: ops.NHWC, act=ops.ACT_NONE, slope=0.2) -> ops.NHWC:
     from .autograd import AddActFn
     return ops.NHWC(AddActFn.apply(a.t, b.t, a.c, act, slope), a.c)
+
+
+def to_nchw(y: ops.NHWC, paste_x=None, paste_m=None) -> torch.Tensor:
+    """fp32 NCHW tensor of an NHWC map (optionally pasted: x (1 - m) + y m), with its graph when ``y`` carries one."""
+    if _tracked(y):
+        from .autograd import ToNchwFn
+        return ToNchwFn.apply(y.t, y.c, paste_x, paste_m)
+    return ops.nhwc_to_nchw(y, paste_x, paste_m)
+
+
+def from_nchw(x, dtype, cs=None, mask=None) -> ops.NHWC:
+    """16-bit NHWC map of an NCHW tensor (optionally times (1 - mask)); differentiable w.r.t. ``x``.  An ``ops.NHWC``
+    argument is handed through."""
+    if isinstance(x, ops.NHWC):
+        return x
+    if torch.is_grad_enabled() and x.requires_grad:
+        from .autograd import FromNchwFn
+        return ops.NHWC(FromNchwFn.apply(x, dtype, cs, mask), x.shape[1])
+    return ops.nchw_to_nhwc(x, dtype, cs=cs, mask=mask)
+
+
+def from_nchw_pair(x, dtype) -> ops.NHWC:
+    """(hi | lo) 16-bit pair map of an fp32 NCHW tensor (2C channels, hi + lo = x to ~16 bits of mantissa)."""
+    from .autograd import FromNchwPairFn
+    if torch.is_grad_enabled() and x.requires_grad:
+        return ops.NHWC(FromNchwPairFn.apply(x, dtype), 2 * x.shape[1])
+    with torch.no_grad():
+        return ops.NHWC(FromNchwPairFn.apply(x.detach(), dtype), 2 * x.shape[1])
+
+
+def resize_nearest(x: ops.NHWC, size, cs_out=None) -> ops.NHWC:
+    if _tracked(x):
+        from .autograd import ResizeNearestFn
+        return ops.NHWC(ResizeNearestFn.apply(x.t, x.c, tuple(int(s) for s in size), cs_out), x.c)
+    return ops.resize_nearest(x, size, cs_out=cs_out)
+
+
+def sigmoid(x: ops.NHWC) -> ops.NHWC:
+    if _tracked(x):
+        from .autograd import SigmoidFn
+        return ops.NHWC(SigmoidFn.apply(x.t, x.c), x.c)
+    return ops.sigmoid(x)

@@ -8,6 +8,7 @@ variants (``paint_nhwc``, ``mask_nhwc``, ``decoders[t].forward_nhwc``) are the o
 import torch
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 from .deeplab import create_encoder, create_segmentation_decoder
 from .depth import create_depth_decoder
@@ -120,6 +121,27 @@ class OmniGenerator(nn.Module):
         self.compute_dtype = dtype
         return self
 
+    # nn.Module's dtype casts (reference apply_events.py:467-468 ``trainer.G.half()``; trainer.py's ``.to(device)``).  The
+    # parameters of this package ARE the fp32 masters -- spectral norm power-iterates them, ExtraAdam steps them and the
+    # kernels read 16-bit packs made from them -- so a cast selects the 16-bit type the kernels compute and store in and
+    # leaves the parameters alone; ``.float()`` keeps the current 16-bit compute type (there is no fp32 activation path).
+    def half(self):
+        return self.set_compute_dtype(torch.float16)
+
+    def bfloat16(self):
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def float(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        device, dtype, non_blocking, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype in (torch.float16, torch.bfloat16):
+            self.set_compute_dtype(dtype)
+        if device is not None:
+            return super().to(device, non_blocking=non_blocking)
+        return self
+
     def encode(self, x):
         """reference generator.py:107-118.  x: [B,3,H,W] NCHW; returns (z_high, z_low) as NHWC containers."""
         assert self.encoder is not None
@@ -134,11 +156,11 @@ class OmniGenerator(nn.Module):
         z_depth = None
         if "d" in self.decoders:
             d, z_depth = self.decoders["d"].forward_nhwc(z)
-            out["d"] = ops.nhwc_to_nchw(d).to(x.dtype)
+            out["d"] = Fn.to_nchw(d).to(x.dtype)
         s_nhwc = None
         if "s" in self.decoders:
             s_nhwc = self.decoders["s"].forward_nhwc(z, z_depth)
-            out["s"] = ops.nhwc_to_nchw(s_nhwc).to(x.dtype)
+            out["s"] = Fn.to_nchw(s_nhwc).to(x.dtype)
         if "m" in self.decoders:
             cond = self.make_m_cond(d, s_nhwc, x) if self.opts.gen.m.use_spade else None     # trainer.py:285-286
             out["m"] = self.mask(z=z, cond=cond, z_depth=z_depth, sigmoid=sigmoid).to(x.dtype)
@@ -153,9 +175,9 @@ class OmniGenerator(nn.Module):
         z_depth = None
         if "d" in self.decoders:
             d, z_depth = self.decoders["d"].forward_nhwc(z)
-            out["d"] = ops.nhwc_to_nchw(d)
+            out["d"] = Fn.to_nchw(d)
         if "s" in self.decoders:
-            out["s"] = ops.nhwc_to_nchw(self.decoders["s"].forward_nhwc(z, z_depth))
+            out["s"] = Fn.to_nchw(self.decoders["s"].forward_nhwc(z, z_depth))
         if "m" in self.decoders:
             out["m"] = self.mask(z=z, z_depth=z_depth)
         if return_z:
@@ -171,14 +193,16 @@ class OmniGenerator(nn.Module):
         if z is None:
             z = self.encode(x)
         d, z_depth = self.decoders["d"].forward_nhwc(z)
-        d = ops.nhwc_to_nchw(d)
+        d = Fn.to_nchw(d)
         return (d, z_depth) if return_z_depth else d
 
     def make_m_cond(self, d, s, x=None):
         """reference generator.py:196-230: cat[normalize(d), softmax(s), bilinear(x)] (x when cond_nc == 15).  d, s:
         the NHWC maps of this package's depth / segmentation decoders; returns the NHWC conditioning map."""
-        if not (isinstance(d, ops.NHWC) and isinstance(s, ops.NHWC)):
-            raise TypeError("make_m_cond: d and s must be the NHWC maps of this package's decoders")
+        # the reference hands over the decoders' NCHW predictions (trainer.py:1233-1238); this package's own callers
+        # pass the NHWC maps.  A 16-bit round trip of values that came out of 16-bit maps is exact.
+        dt = self.compute_dtype
+        d, s = Fn.from_nchw(d, dt), Fn.from_nchw(s, dt)
         if self.opts.gen.m.spade.cond_nc == 15:
             if x is None:
                 raise ValueError("When using spade for the Masker with 15 channels, x MUST be provided")
@@ -206,12 +230,9 @@ class OmniGenerator(nn.Module):
             _, z_depth = self.decoders["d"].forward_nhwc(z)
         spectral_norm_step_all(dec, z[0].t.dtype if isinstance(z, (tuple, list)) else z.t.dtype)
         logits = dec.forward_nhwc(z, cond, z_depth)
-        if logits.t.requires_grad:
-            raise NotImplementedError("OmniGenerator.mask: under autograd use mask_nhwc() (the NHWC -> NCHW layout pass "
-                                      "has no backward kernel)")
         if sigmoid:
-            logits = ops.sigmoid(logits)
-        return ops.nhwc_to_nchw(logits)
+            logits = Fn.sigmoid(logits)
+        return Fn.to_nchw(logits)
 
     def mask_nhwc(self, z, cond=None, z_depth=None):
         """Training-path form of ``mask``: the mask decoder's LOGITS as a differentiable NHWC map (the sigmoid / pair /
@@ -271,15 +292,19 @@ class OmniGenerator(nn.Module):
         dt = p.compute_dtype
         z = self.sample_painter_z(x.shape[0], x.device)
         m = m.to(x.dtype)
-        cond = ops.nchw_to_nhwc(x, dt, cs=4, mask=m)                     # x * (1 - m)
         zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
+        paste = self.opts.gen.p.paste_original_content and not no_paste
+        if torch.is_grad_enabled() and (m.requires_grad or x.requires_grad):
+            # the mask (or the image) is itself a prediction -- painter_loss_for_masker, trainer.py:1618-1651: the
+            # masking and the paste are torch expressions so that autograd carries their gradients; the Painter's
+            # conditioning map then wants a gradient too (SpadeFn's cond branch, ResizeNearestFn)
+            fake = Fn.to_nchw(p.forward_nhwc(zz, Fn.from_nchw(x * (1.0 - m), dt, cs=4)))
+            return (x * (1.0 - m) + fake * m).to(x.dtype) if paste else fake.to(x.dtype)
+        cond = ops.nchw_to_nhwc(x, dt, cs=4, mask=m)                     # x * (1 - m)
         fake = p.forward_nhwc(zz, cond)
-        if fake.t.requires_grad:
-            raise NotImplementedError("OmniGenerator.paint: under autograd use paint_nhwc() (the NHWC -> NCHW layout "
-                                      "pass has no backward kernel)")
-        if self.opts.gen.p.paste_original_content and not no_paste:
+        if paste:
             if tuple(fake.t.shape[1:3]) != tuple(x.shape[-2:]):
                 raise RuntimeError("paint: painter output %s does not match x %s (input must be a multiple of %d)"
                                    % (tuple(fake.t.shape[1:3]), tuple(x.shape[-2:]), 2 ** p.spade_n_up))
-            return ops.nhwc_to_nchw(fake, paste_x=x, paste_m=m).to(x.dtype)
-        return ops.nhwc_to_nchw(fake).to(x.dtype)
+            return Fn.to_nchw(fake, paste_x=x, paste_m=m).to(x.dtype)
+        return Fn.to_nchw(fake).to(x.dtype)

@@ -15,11 +15,27 @@ from .autograd import BceLogitsFn, ConvFn, HingeFn, L1Fn, MaxPool2x2Fn
 from .norms import _PackCache
 
 
+# The 16-bit type NCHW tensor arguments are converted to (the reference's call signatures hand the loss classes NCHW
+# fp32 tensors; the package's own trainer hands them NHWC maps, which carry their type).  Training runs in bf16.
+COMPUTE_DTYPE = torch.bfloat16
+
+
+def set_compute_dtype(dtype):
+    global COMPUTE_DTYPE
+    if dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
+    COMPUTE_DTYPE = dtype
+
+
 def _as_nhwc(t, what):
-    if not isinstance(t, ops.NHWC):
-        raise TypeError("%s: expected the NHWC maps of a climategan_amd discriminator called with nhwc=True, got %s"
-                        % (what, type(t).__name__))
-    return t
+    """An ``ops.NHWC`` map as is; an NCHW tensor (the reference's signatures) through the layout kernel, keeping its
+    graph (``autograd.FromNchwFn``)."""
+    if isinstance(t, ops.NHWC):
+        return t
+    if torch.is_tensor(t) and t.dim() == 4:
+        from . import functional as Fn
+        return Fn.from_nchw(t, COMPUTE_DTYPE)
+    raise TypeError("%s: expected an ops.NHWC map or an NCHW tensor, got %s" % (what, type(t).__name__))
 
 
 class GANLoss(nn.Module):
@@ -188,7 +204,14 @@ class VGGLoss(nn.Module):
             self.vgg = self.vgg.to(device)
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
 
-    def forward(self, x: ops.NHWC, y: ops.NHWC):
+    def forward(self, x, y):
+        """x, y: ``vgg_preprocess``-ed images -- NHWC maps (3 channels or the 6-channel pair form) or, as the reference
+        passes them (trainer.py:1282-1284), NCHW fp32 tensors, which become pair maps here."""
+        from . import functional as Fn
+        if torch.is_tensor(x):
+            x = Fn.from_nchw_pair(x, COMPUTE_DTYPE)
+        if torch.is_tensor(y):
+            y = Fn.from_nchw_pair(y.detach(), COMPUTE_DTYPE)
         x_vgg = self.vgg(_as_nhwc(x, "VGGLoss"))
         with torch.no_grad():
             y_vgg = self.vgg(_as_nhwc(y, "VGGLoss"))
@@ -309,10 +332,19 @@ class ADVENTAdversarialLoss(nn.Module):
         the reference's call signature, through 16-bit probability and entropy maps."""
         if self.opts.dis.m.architecture == "OmniDiscriminator":
             raise NotImplementedError("ADVENT with the OmniDiscriminator architecture has no HIP path (default: base)")
-        if logits is not None:
-            d_in = advent_input(logits, depth_preds, sigmoid_pair)
+        if logits is None and torch.is_tensor(prediction):
+            # the reference's signature: fp32 NCHW probabilities (and depth); the entropy is evaluated in fp32 and handed
+            # to the discriminator as the same (hi | lo) pair map the logits path produces
+            if isinstance(depth_preds, ops.NHWC):
+                depth_preds = ops.nhwc_to_nchw(ops.detached(depth_preds))
+            d_in = ops.NHWC(ag.EntropyPairFromNchwFn.apply(prediction, depth_preds, COMPUTE_DTYPE), 2 * prediction.shape[1])
         else:
-            d_in = prob_2_entropy(prediction, depth_preds)
+            if depth_preds is not None:
+                depth_preds = _as_nhwc(depth_preds, "ADVENTAdversarialLoss")
+            if logits is not None:
+                d_in = advent_input(logits, depth_preds, sigmoid_pair)
+            else:
+                d_in = prob_2_entropy(prediction, depth_preds)
         d_out = discriminator(d_in, nhwc=True)
         if self.bce is not None:
             return self.bce(d_out, target)

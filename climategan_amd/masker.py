@@ -2,6 +2,7 @@
 (``gen.m.use_spade``: the paper's final masker, SPADE blocks conditioned on depth / segmentation / image)."""
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 from .blocks import BaseDecoder, Conv2dBlock, InterpolateNearest2d, SPADEResnetBlock
 from .norms import SpectralNorm
@@ -28,7 +29,12 @@ class MaskBaseDecoder(BaseDecoder):
                          low_level_feats_dim=low, use_dada=("d" in opts.tasks) and opts.gen.m.use_dada)
 
     def forward(self, z, cond=None, z_depth=None):
-        return ops.nhwc_to_nchw(self.forward_nhwc(z, cond, z_depth))
+        """reference signature (blocks.py:292-313): the mask LOGITS as an NCHW fp32 tensor (with its graph under autograd).
+        Every call is one forward of the spectral-norm convs: one power iteration each (norms.py:141-143)."""
+        from .norms import spectral_norm_step_all
+        zz = z[0] if isinstance(z, (tuple, list)) else z
+        spectral_norm_step_all(self, zz.t.dtype)
+        return Fn.to_nchw(self.forward_nhwc(z, cond, z_depth))
 
 
 class MaskSpadeDecoder(nn.Module):
@@ -90,4 +96,7 @@ class MaskSpadeDecoder(nn.Module):
         return c.conv(y, pad=c.padding, pad_mode=ops.PAD_REFLECT, in_upsample=True)
 
     def forward(self, z, cond, z_depth=None):
-        return ops.nhwc_to_nchw(self.forward_nhwc(z, cond, z_depth))
+        from . import functional as Fn
+        from .norms import spectral_norm_step_all
+        spectral_norm_step_all(self, z[0].t.dtype)
+        return Fn.to_nchw(self.forward_nhwc(z, cond, z_depth))

@@ -349,9 +349,10 @@ class SPADE(nn.Module):
     def forward(self, x, segmap, compute_dtype=None):
         """Reference signature: NCHW tensors in, NCHW fp32 out."""
         dt = compute_dtype or DEFAULT_COMPUTE_DTYPE
-        xs = ops.nchw_to_nhwc(x, dt)
-        cond = ops.nchw_to_nhwc(segmap, dt, cs=ops.cs4(segmap.shape[1]))
-        return ops.nhwc_to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
+        from . import functional as Fn
+        xs = Fn.from_nchw(x, dt)
+        cond = Fn.from_nchw(segmap, dt, cs=ops.cs4(segmap.shape[1]))
+        return Fn.to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
 
 
 def spectral_norm_step_all(root: nn.Module, dtype) -> None:

@@ -96,6 +96,13 @@ class NHWC:
     def cs(self): return self.t.shape[3]
     @property
     def dtype_id(self): return _DT[self.t.dtype]
+    @property
+    def shape(self):
+        """The logical NCHW shape: what the reference's callers read off a latent (``z[0].shape[0]``, trainer.py:602-607)."""
+        return torch.Size((self.t.shape[0], self.c, self.t.shape[1], self.t.shape[2]))
+
+    def detach(self) -> "NHWC":
+        return NHWC(self.t.detach(), self.c)
 
 
 # ------------------------------------------------------------------------------------------------ layout

@@ -7,6 +7,7 @@ NHWC 16-bit activations, fused SPADE, MFMA convs, upsamples folded into the cons
 import torch
 import torch.nn as nn
 
+from . import functional as Fn
 from . import ops
 from .blocks import InterpolateNearest2d, SPADEResnetBlock
 from .norms import (DEFAULT_COMPUTE_DTYPE, SpectralNorm, _grad_guard, _PackCache, conv_forward,  # noqa: F401
@@ -75,7 +76,7 @@ class PainterSpadeDecoder(nn.Module):
         spectral_norm_step_all(self, cond.t.dtype)   # all 23 power iterations + w_bar/sigma packs, batched
         if z is None:
             assert self.z_h is not None and self.z_w is not None
-            zin = ops.resize_nearest(cond, (self.z_h, self.z_w), cs_out=8)       # painter.py:152
+            zin = Fn.resize_nearest(cond, (self.z_h, self.z_w), cs_out=8)       # painter.py:152
             y = conv_forward(self.fc, self._fc_cache, zin, trainable=True)
         else:
             y = z
@@ -90,10 +91,6 @@ class PainterSpadeDecoder(nn.Module):
     def forward(self, z, cond):
         """Reference signature (painter.py:149): z None or [B,latent,z_h,z_w]; cond [B,3,H,W] NCHW."""
         dt = self.compute_dtype
-        c = ops.nchw_to_nhwc(cond, dt, cs=4)
-        zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
-        y = self.forward_nhwc(zz, c)
-        if y.t.requires_grad:
-            raise NotImplementedError("PainterSpadeDecoder.forward: under autograd use forward_nhwc / "
-                                      "OmniGenerator.paint(..., nhwc=True) (the layout pass has no backward kernel)")
-        return ops.nhwc_to_nchw(y).to(cond.dtype)
+        c = Fn.from_nchw(cond, dt, cs=4)
+        zz = Fn.from_nchw(z, dt) if z is not None else None
+        return Fn.to_nchw(self.forward_nhwc(zz, c)).to(cond.dtype)

@@ -68,6 +68,7 @@ class Trainer:
         self.D = None
         self.is_setup = False
         self.has_painter = "p" in opts.tasks
+        self.use_pl4m = False            # trainer.py:94; run_epoch switches it on at opts.gen.p.pl4m_epoch (trainer.py:899-909)
         # the real and the simulated domain batch share the Masker's encoder / depth / segmentation launches (grouped
         # BatchNorm keeps the per-domain statistics of the reference's separate calls); False = one pass per domain
         self.merge_domains = True
@@ -269,27 +270,56 @@ class Trainer:
                     loss = self.losses["G"]["tasks"]["m"]["gi"](pred_prob, target) * w
                     self.loss_log["G.m.gi.r"] = loss.detach()
                     full_loss = full_loss + loss
-                if o.gen.m.get("use_pl4m", False) and o.train.lambdas.G.m.pl4m != 0:
-                    raise NotImplementedError("pl4m (painter loss for the masker) has no HIP path")
+                w = o.train.lambdas.G.m.pl4m
+                if self.use_pl4m and w != 0:                                              # trainer.py:1548-1554
+                    loss = self.painter_loss_for_masker(x, pred_prob) * w
+                    self.loss_log["G.m.pl4m.r"] = loss.detach()
+                    full_loss = full_loss + loss
                 w = o.train.lambdas.advent.ent_main
                 if o.gen.m.use_minent and w != 0:
                     loss = self.losses["G"]["tasks"]["m"]["minent"](prob) * w
                     self.loss_log["G.m.minent.r"] = loss.detach()
                     full_loss = full_loss + loss
         if o.gen.m.use_advent:
+            dp = None
             if o.gen.m.use_dada and depth_preds is not None:
-                raise NotImplementedError("gen.m.use_dada (depth-weighted ADVENT for the mask) has no HIP path")
+                # trainer.py:1566-1570: the detached depth prediction, nearest-resized to the image, weights the entropy map
+                dp = ops.resize_nearest(ops.detached(depth_preds), (x.shape[-2], x.shape[-1]))
             if for_ == "D":
                 label, loss_func = domain, self.losses["D"]["advent"]
             else:
                 label, loss_func = "s", self.losses["G"]["tasks"]["m"]["advent"]
             w = o.train.lambdas.advent.adv_main
             if (for_ == "D" or domain == "r") and w != 0:
-                loss = loss_func(prob, self.domain_labels[label], self.D["m"]["Advent"], None, logits=logits,
+                loss = loss_func(prob, self.domain_labels[label], self.D["m"]["Advent"], dp, logits=logits,
                                  sigmoid_pair=True) * w
                 self.loss_log["%s.m.advent.%s" % (for_, domain)] = loss.detach()
                 full_loss = full_loss + loss
         return full_loss, prob
+
+    def painter_loss_for_masker(self, x, m):
+        """reference trainer.py:1618-1651 (pl4m, single-discriminator branch): the GAN term of the Painter's discriminator
+        on ``paint(m, x)`` with the PREDICTED mask probability ``m`` -- the Painter (and D, frozen throughout the G update)
+        is not updated; the gradient reaches the Masker through the paste, through the discriminator's mask channel and
+        through the Painter's conditioning image x (1 - m) (``SpadeFn``'s cond branch).  ``m``: NHWC map or NCHW tensor."""
+        from . import functional as Fn
+        from .tutils import divide_pred
+
+        if self.opts.dis.p.use_local_discriminator:
+            raise NotImplementedError("pl4m with the local / global discriminator pair has no HIP path")
+        frozen = [p for p in self.G.painter.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        try:
+            m = Fn.to_nchw(m) if isinstance(m, ops.NHWC) else m
+            fake = self.G.paint(m, x)
+            real_fake_cat = torch.cat([torch.cat([m, x], dim=1), torch.cat([m, fake], dim=1)], dim=0)
+            _, fake_d = divide_pred(self.D["p"](real_fake_cat, nhwc=True))
+            return self.losses["G"]["p"]["gan"](fake_d, True, False)
+        finally:
+            if "p" in self.opts.tasks:
+                for p in frozen:
+                    p.requires_grad_(True)
 
     def _merged_masker_domains(self, multi_domain_batch):
         """The masker domains of a batch that can go through the encoder and the depth / segmentation decoders as ONE
@@ -399,16 +429,18 @@ class Trainer:
                             s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
                         cond = self.G.make_m_cond(d_pred, s_pred, x)
                     logits = self.G.mask_nhwc(z, cond=cond, z_depth=z_depth)
-                loss, _ = self._advent_d_term("m", logits, None, domain)
+                loss, _ = self._advent_d_term("m", logits, d_pred if self.opts.gen.m.use_dada else None, domain, x)
                 total = total + loss * adv
         return total
 
-    def _advent_d_term(self, task, pred, depth_preds, domain):
+    def _advent_d_term(self, task, pred, depth_preds, domain, x=None):
         w = self.opts.train.lambdas.advent.adv_main
         logits = ops.NHWC(pred.t.detach(), pred.c)
         dp = None
         if task == "s" and self.opts.gen.s.use_dada and depth_preds is not None:
             dp = ops.NHWC(depth_preds.t.detach(), depth_preds.c)
+        if task == "m" and depth_preds is not None:                    # gen.m.use_dada, trainer.py:1566-1570
+            dp = ops.resize_nearest(ops.detached(depth_preds), (x.shape[-2], x.shape[-1]))
         loss = self.losses["D"]["advent"](None, self.domain_labels[domain], self.D[task]["Advent"], dp, logits=logits,
                                           sigmoid_pair=task == "m") * w
         self.loss_log["D.%s.advent.%s" % (task, domain)] = loss.detach()

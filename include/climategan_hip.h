@@ -403,6 +403,13 @@ int cgan_advent_entropy_pair_nhwc(const void* logits, const void* depth, void* y
                                   int32_t sigmoid_pair, void* stream);
 int cgan_advent_entropy_pair_bwd_nhwc(const void* logits, const void* depth, const void* dy, void* dlogits, int32_t dtype,
                                       int64_t npix, int32_t c, int32_t sigmoid_pair, void* stream);
+/* The same pair map from fp32 NCHW PROBABILITIES [n, c, h, w] (+ optional fp32 depth [n, 1, h, w]): the reference's call
+ * signature hands ADVENTAdversarialLoss softmax(pred) / cat[p, 1 - p] as NCHW tensors (losses.py:517-519,
+ * trainer.py:1470-1476, 1588-1594); prob_2_entropy (losses.py:453-458) is evaluated in fp32 here.  _bwd: fp32 NCHW d(prob). */
+int cgan_entropy_pair_from_nchw(const float* prob, const float* depth, void* y, int32_t dtype, int32_t n, int32_t c,
+                                int32_t h, int32_t w, void* stream);
+int cgan_entropy_pair_from_nchw_bwd(const float* prob, const float* depth, const void* dy, float* dprob, int32_t dtype,
+                                    int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 int cgan_entropy_map_nhwc(const void* p, const void* depth, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream);
 int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const void* dy, void* dp, int32_t dtype, int64_t npix,
                               int32_t c, void* stream);

@@ -40,6 +40,12 @@ CASES_640 = {
     # layers, 128 x 160): pins oracle.cpu_ref.joint_train_step on the CPU in seconds
     "jstep_small": dict(kind="jstep", iterations=4, H=128, W=160, B=2, seed=69, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
                         vgg_gain=2.449489742783178, latent_dim=32, n_up=4, ndf=16, n_layers=3),
+    # the two non-default Masker options inside A20's range: painter_loss_for_masker (trainer.py:1618-1651,
+    # switched on by run_epoch at gen.p.pl4m_epoch, trainer.py:899-909) and the depth-weighted ADVENT / DADA fusion of the
+    # mask decoder (gen.m.use_dada, trainer.py:1566-1570, blocks.py:304-305), one update_G + update_D on the small fixture
+    "jstep_pl4m_small": dict(kind="jstep", H=128, W=160, B=2, seed=69, gain=1.0, res_gamma=0.05, sub=256, vgg_seed=85,
+                             vgg_gain=2.449489742783178, latent_dim=32, n_up=4, ndf=16, n_layers=3, pl4m=True,
+                             m_use_dada=True),
     # eval-mode BatchNorm (running statistics from the fill, not batch statistics) needs variance-preserving conv weights
     # to keep a signal: gain sqrt(6) (He bound for the uniform fill) -- depth range 2.1, seg logits std 3.3, all 11 classes
     # in the arg-max map; with gain 1 the depth map's std was 1.7e-5, below fp16 resolution of its own offset
@@ -100,6 +106,10 @@ def reference_training_trainer(case):
     if "latent_dim" in case:             # the small configuration
         opts.gen.p.latent_dim, opts.gen.p.spade_n_up = case["latent_dim"], case["n_up"]
         opts.dis.p.ndf, opts.dis.p.n_layers = case["ndf"], case["n_layers"]
+    if case.get("m_use_dada"):
+        opts.gen.m.use_dada = True
+    if case.get("pl4m"):
+        opts.gen.m.use_pl4m = True
     tr = ref_shim.ref("trainer")
     reference_vgg_loss(dict(seed=case["vgg_seed"], gain=case["vgg_gain"]))     # installs the vgg19 stand-in
     tr.Timer = _NullTimer
@@ -131,6 +141,7 @@ def reference_training_trainer(case):
     vgg.load_state_dict({k: t(v) for k, v in fill.fill_state_dict(vshapes, case["vgg_seed"], gain=case["vgg_gain"]).items()})
     T.G.train()
     T.D.train()
+    T.use_pl4m = bool(case.get("pl4m"))            # what run_epoch does at epoch gen.p.pl4m_epoch (trainer.py:899-909)
     if (case["H"], case["W"]) != (640, 640):
         T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
         T.G.decoders["d"]._target_size = case["W"] // 4

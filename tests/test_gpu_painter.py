@@ -136,12 +136,22 @@ def test_second_forward_tracks_oracle():
             assert (v.cpu() - sd[k]).abs().max() < 2e-5, k
 
 
-def test_training_mode_refuses_autograd():
+def test_reference_signature_forward_carries_a_graph_in_training_mode():
+    """``painter(z, cond)`` with grad mode on and trainable parameters returns the reference's NCHW tensor WITH its graph
+    (never a silently detached one): same values as the no-grad call, and ``backward()`` reaches every trainable tensor."""
     case = CASES["painter_up4"]
     G = build_generator(case, torch.float16)
+    sd = {k: v.clone() for k, v in G.painter.state_dict().items()}
     cond = t(case_inputs("painter_up4", case)["cond"]).cuda()
-    with pytest.raises(NotImplementedError):
-        G.painter(None, cond)  # grad enabled + trainable params: no silent graph-less output
+    y = G.painter(None, cond)
+    assert y.requires_grad and y.dtype == cond.dtype and y.shape[1] == 3
+    G.painter.load_state_dict(sd)                       # the spectral-norm u / v of the first call
+    with torch.no_grad():
+        y0 = G.painter(None, cond)
+    assert torch.equal(y.detach(), y0)
+    y.square().mean().backward()
+    missing = [k for k, p in G.painter.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
 
 
 @pytest.mark.parametrize("dt,rel", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])

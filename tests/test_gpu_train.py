@@ -107,15 +107,28 @@ def test_d_update_with_extra_adam_moves_parameters():
     assert losses[-1] < losses[0], losses
 
 
-def test_nchw_outputs_refused_under_autograd():
+def test_nchw_outputs_carry_a_graph_under_autograd():
+    """``D(x)`` with the reference's signature (NCHW in, list of lists of NCHW tensors out, discriminator.py:172-182,
+    227-239): under autograd the tensors carry their graph back to the parameters AND to an NCHW input that wants a
+    gradient (the reference's ``fake.requires_grad_()``, trainer.py:1085); values equal the NHWC maps'."""
+    from climategan_amd import ops
     case = golden_cases()[NAME]
     D = build_D(case, torch.float16)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
     inp = {k: t(v).cuda() for k, v in case_inputs(NAME, case).items()}
-    with pytest.raises(NotImplementedError, match="nhwc=True"):
-        D(torch.cat([inp["m"], inp["x"]], dim=1))
+    x = torch.cat([inp["m"], inp["x"]], dim=1).requires_grad_(True)
+    out = D(x)
+    assert len(out) == case["num_D"] and out[0][0].shape[1] == case["ndf"] and out[0][-1].requires_grad
+    D.load_state_dict(sd)
     with torch.no_grad():
-        out = D(torch.cat([inp["m"], inp["x"]], dim=1))
-    assert len(out) == case["num_D"] and out[0][0].shape[1] == case["ndf"]
+        ref = D(x.detach(), nhwc=True)
+    for a, b in zip(out, ref):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta.detach(), ops.nhwc_to_nchw(tb))
+    sum(o[-1].mean() for o in out).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
+    missing = [k for k, p in D.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
 
 
 # ------------------------------------------------------------------------------------------------ G side
