@@ -93,7 +93,10 @@ class _PackCache:
             k = self._key_of((w, b, "plain"), dtype)
             if k != c.key:
                 stale.append((c, w, b, k))
-        reuse = [c.value if (c.value is not None and c.key is not None and c.key[-1] == dtype and
+        # buffers are overwritten in place only where the previous content was a plain pack of the same dtype made on this
+        # path (key tagged "plain"): an eval-mode pack (BatchNorm folded, made by get()) may still be in use by an
+        # inference call on another stream, and switching train <-> eval must not alias the two
+        reuse = [c.value if (c.value is not None and c.key is not None and c.key[-1] == dtype and "plain" in c.key and
                              isinstance(c.value, ops.PackedConv)) else None for c, _, _, _ in stale]
         packed = ops.pack_conv_weights_batched([(w.data, b.data if b is not None else None) for _, w, b, _ in stale], dtype,
                                                reuse)
@@ -315,6 +318,12 @@ class SPADE(nn.Module):
             # nn.BatchNorm2d(affine=False) (norms.py:152-153): eval mode normalises with the running statistics
             bn = self.param_free_norm
             if bn.training:
+                from . import autograd as _ag
+                if _ag.BN_GROUPS != 1:
+                    # the grouped-BatchNorm context (the trainer's merged-domain trunk) covers autograd.BatchNormActFn only;
+                    # here it would silently normalise with merged-batch statistics instead of per-domain ones
+                    raise NotImplementedError("SPADE with a batch param-free norm inside autograd.bn_groups(%d): run the "
+                                              "SPADE mask decoder per domain (as the trainer does)" % _ag.BN_GROUPS)
                 # batch statistics over (n, h, w) -- those of the up-sampled tensor when the x2 nearest upsample is
                 # folded in: every pixel repeated four times gives the same mean and biased variance, only the running
                 # variance's n/(n-1) factor sees the four-fold count (corrected below)

@@ -8,12 +8,12 @@ reducer works on the parameter list:
 
 * parameters are grouped into ~25 MB buckets in REVERSE registration order (the order gradients become ready: the
   Painter's last layers / D's output conv first);
-* the wire format is **bf16** by default on RCCL (``grad_dtype``): the fp32 ``p.grad`` tensors are converted into the
-  bucket's flat buffer by the same multi-tensor copy that gathers them, summed over the ranks in bf16, and converted
-  back (x 1/world) into the fp32 gradients the fp32-master ExtraAdam consumes -- 210.8 MB instead of 421.7 MB per G
-  exchange.  The activation gradients these sums are built from are 16-bit already (8 significant bits per
-  element, ~8 % direction noise in the encoder, tests/test_gpu_configs_640.py); one more bf16 rounding of an 8-term sum
-  is below that.  ``grad_dtype=torch.float32`` keeps the exact fp32 exchange (the default on gloo / for tests);
+* the wire format is **fp32** by default: the ranks' ``p.grad`` tensors are gathered into the bucket's flat buffer by one
+  multi-tensor copy, summed by the collective and scaled by 1/world -- exactly the mean the single-process reference
+  would see on the concatenated batch.  ``CGAN_DDP_BF16_GRADS=1`` (or ``grad_dtype=torch.bfloat16``) halves the bytes
+  (210.8 MB instead of 421.7 MB per G exchange) at the price of one bf16 rounding of the inputs and of the sum
+  (relative error <= 2^-8 per element, unbiased; tests/test_distributed_cpu.py) -- opt-in, because nothing in this
+  repository can check it against an fp32 exchange on more than one RCCL rank; the chosen type is printed at setup;
 * a bucket's all-reduce is issued (``async_op=True``, on RCCL's own stream) as soon as its last gradient has been
   accumulated; xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound: few
   large messages, not one per tensor (105 M G parameters = 17 buckets);
@@ -64,9 +64,9 @@ class GradBucketReducer:
         self.params = [p for p in params if p.requires_grad]
         self.active = is_distributed()
         self.world = dist.get_world_size() if self.active else 1
-        if grad_dtype is None:      # bf16 on the wire over RCCL; exact fp32 elsewhere (gloo: CPU tests)
+        if grad_dtype is None:      # exact fp32 exchange unless bf16 is asked for (RCCL only: gloo has no bf16 sum)
             on_rccl = self.active and dist.get_backend() == "nccl"
-            grad_dtype = torch.bfloat16 if (on_rccl and os.environ.get("CGAN_DDP_FP32_GRADS") != "1") else torch.float32
+            grad_dtype = torch.bfloat16 if (on_rccl and os.environ.get("CGAN_DDP_BF16_GRADS") == "1") else torch.float32
         self.grad_dtype = grad_dtype
         cap = int(bucket_mb * 2 ** 20)
         self.buckets: List[_Bucket] = []
@@ -81,6 +81,10 @@ class GradBucketReducer:
         if cur:
             self.buckets.append(_Bucket(cur))
         self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        if self.active and dist.get_rank() == 0:
+            print("GradBucketReducer: %d parameters, %.1f MB in %d buckets, %s on the wire, %d ranks over %s"
+                  % (len(self.params), sum(p.numel() for p in self.params) * torch.finfo(grad_dtype).bits / 8e6,
+                     len(self.buckets), str(grad_dtype).split(".")[1], self.world, dist.get_backend()), flush=True)
         # First step: a hook on EVERY parameter counts the bucket down and remembers which parameter completed it.
         # Afterwards only those trigger parameters keep a hook (the backward graph is the same every step): ~1500 calls
         # from the autograd engine into Python per step cost more (~15 ms of a 160 ms step) than the overlap buys.
@@ -91,6 +95,8 @@ class GradBucketReducer:
     def reset(self):
         for b in self.buckets:
             b.pending = len(b.params)
+            b.seen = set()
+            b.stale = False
             b.work = None
 
     def _views(self, b: _Bucket, grads):
@@ -113,12 +119,19 @@ class GradBucketReducer:
         if not self.active:
             return
         b = self._bucket_of[id(p)]
+        if b.work is not None:
+            # a gradient of a bucket whose exchange is already in flight was accumulated again (a second backward()
+            # before the optimizer step: gradient accumulation, two loss.backward() calls per update): what is on the
+            # wire is stale -- finish() waits for it, discards it and exchanges the bucket again
+            b.stale = True
+            return
         if self._learning:
-            b.pending -= 1
+            b.seen.add(id(p))                     # per parameter, not per hook call: accumulations do not count twice
+            b.pending = len(b.params) - len(b.seen)
             if b.pending == 0:
                 b.trigger = p
                 self._launch(b)
-        elif b.work is None and all(q.grad is not None for q in b.params):
+        elif all(q.grad is not None for q in b.params):
             # learned trigger: the bucket's last gradient of the first step.  Should the order ever differ, some gradient
             # is still None (zero_grad sets them to None) and the bucket is left to finish()
             b.pending = 0
@@ -147,6 +160,9 @@ class GradBucketReducer:
                                        "replicas would diverge" % len(missing))
                 self._launch(b)
             b.work.wait()
+            if b.stale:                                            # see _on_grad
+                self._launch(b)
+                b.work.wait()
             grads = [p.grad for p in b.params]
             torch._foreach_copy_(grads, b.views)                      # back to the gradients' own dtype (fp32)
             if self.world > 1:

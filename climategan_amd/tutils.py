@@ -67,6 +67,11 @@ def init_weights(net, init_type="normal", init_gain=0.02, verbose=0, caller=""):
     if verbose > 0:
         print("initialize %s with %s" % (net.__class__.__name__, init_type))
     net.apply(visit)
+    # the draws above write through ``.data`` (as the reference does), which does not move the parameters' version
+    # counters: a module re-initialised AFTER it has run a forward would keep serving its old packed weights
+    # (norms._PackCache keys on ``tensor._version``)
+    from . import ops
+    ops.touch(*net.parameters())
 
 
 def get_num_params(model):

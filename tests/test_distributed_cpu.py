@@ -226,7 +226,7 @@ def test_reducer_survives_a_changed_gradient_order_gloo():
 
 
 def test_reducer_bf16_wire_format_gloo():
-    """bf16 buckets (the RCCL default, forced here on gloo): averages within bf16 rounding of the exact ones, gradients
+    """bf16 buckets (opt-in on RCCL: CGAN_DDP_BF16_GRADS=1; forced here on gloo): averages within bf16 rounding of the exact ones, gradients
     stay fp32 tensors, both ranks end up with identical values."""
     import numpy as np
     res = _run_order("bfloat16")
@@ -235,3 +235,61 @@ def test_reducer_bf16_wire_format_gloo():
         for a, b, e in zip(res[0][3][step], res[1][3][step], exp[step]):
             assert a.dtype == np.float32 and np.array_equal(a, b)
             assert np.abs(a - e).max() <= 2.0 ** -7 * np.abs(e).max() + 1e-12
+
+
+def _accum_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climategan_amd.parallel import GradBucketReducer, broadcast_parameters
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 9), torch.nn.Tanh(), torch.nn.Linear(9, 2))
+        broadcast_parameters(net)
+        red = GradBucketReducer(net.parameters(), bucket_mb=0.0001)      # one bucket per tensor or so
+        outs = []
+        for step in range(3):                                           # step 0 learns the triggers, 1 and 2 use them
+            net.zero_grad(set_to_none=True)
+            xa = torch.full((2, 5), 0.5 * (rank + 1) + step)
+            xb = torch.full((2, 5), -0.25 * (rank + 2) - step)
+            net(xa).sum().backward()                                    # buckets fill and go on the wire ...
+            net(xb).pow(2).sum().backward()                             # ... then every gradient is accumulated AGAIN
+            red.finish()
+            outs.append([p.grad.clone().numpy() for p in net.parameters()])
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_two_backward_calls_per_update_gloo():
+    """Gradient accumulation (two ``backward()`` calls before one ``finish()``): the buckets launched during the first
+    backward are stale once the second one has accumulated into them; ``finish()`` must exchange the FINAL gradients
+    (round-2 review: the hooks assumed exactly one backward per update)."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 9), torch.nn.Tanh(), torch.nn.Linear(9, 2))
+    for step in range(3):
+        acc = None
+        for rank in range(2):
+            net.zero_grad(set_to_none=True)
+            net(torch.full((2, 5), 0.5 * (rank + 1) + step)).sum().backward()
+            net(torch.full((2, 5), -0.25 * (rank + 2) - step)).pow(2).sum().backward()
+            g = [p.grad.clone() for p in net.parameters()]
+            acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        for rank in range(2):
+            for got, e in zip(res[rank][1][step], acc):
+                assert np.allclose(got, (e / 2).numpy(), rtol=1e-6, atol=1e-7), (rank, step)

@@ -528,16 +528,19 @@ def test_gradient_reducer_over_rccl_single_rank():
         # launched from hooks during the backward); finish() writes the averages back and only THEN the scale is divided
         # out -- the gradients the optimizer sees must be those of the unscaled run (bf16 wire format: 2^-7 relative)
         from climategan_amd import autograd as ag
-        assert T1.d_reducer.grad_dtype == torch.bfloat16
+        assert T1.d_reducer.grad_dtype == torch.float32            # exact exchange by default; bf16 buckets are opt-in
 
         def d_grads(scale):
             ag.set_grad_scale(scale)
+            os.environ["CGAN_DDP_BF16_GRADS"] = "1"                # ... and exercised here
             try:
                 T = build_trainer(case, torch.bfloat16)
+                assert T.d_reducer.grad_dtype == torch.bfloat16
                 T.update_D(batch)
                 return {k: p.grad.detach().clone() for k, p in T.D.named_parameters() if p.grad is not None}
             finally:
                 ag.set_grad_scale(1.0)
+                os.environ.pop("CGAN_DDP_BF16_GRADS", None)
 
         g1, g256 = d_grads(1.0), d_grads(256.0)
         assert set(g1) == set(g256) and len(g1) > 10

@@ -1,0 +1,149 @@
+"""Two data-parallel ranks running the REAL ``Trainer.train_step`` on ONE GPU.
+
+RCCL refuses two ranks on the same device, so the process group here is gloo -- on DEVICE tensors (gloo stages them
+through the host): everything above the collective is the code the 8-GPU run executes: ``broadcast_parameters``, the
+``GradBucketReducer`` hooks firing inside the HIP backward of the joint Masker + Painter step, ``finish()`` before
+ExtraAdam's extrapolation / step, per-rank batches, per-rank BatchNorm statistics.  Checked:
+
+* replicas (parameters, spectral-norm u / v, BatchNorm buffers) are identical after ``broadcast_parameters`` although
+  rank 1 starts from different values;
+* the gradients the optimizer sees after ``finish()`` are the MEAN of the two ranks' local gradients (each rank's local
+  gradients come from a reducer-free twin trainer in the same state on the same shard);
+* three train steps keep the replicas in lock-step: every parameter incl. u / v bit-identical on both ranks, while the
+  BatchNorm running statistics (per-rank batches, no SyncBN, as the reference at the per-rank batch size) differ."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, str(ROOT))
+        sys.path.insert(0, str(ROOT / "tests"))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        from oracle.make_golden_640 import CASES_640, jstep_inputs
+        from test_gpu_configs_640 import _build_train
+
+        case = CASES_640["jstep_small"]
+
+        def build():
+            T = _build_train(("d", "s", "m", "p"), case, 1)
+            T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
+            return T
+
+        def shard(r):                                   # rank-specific data: the golden batch with rank-specific seeds
+            c = dict(case, seed=case["seed"] + 7 * r)
+            return {dom: {"data": {k: torch.from_numpy(v).cuda() for k, v in d.items()}} for dom, d in jstep_inputs(c).items()}
+
+        batch = shard(rank)
+        local = build()                                  # no process group yet: a reducer-free trainer, same fill
+        assert local.g_reducer is None
+        local.update_G(batch)
+        g_local = {k: p.grad.detach().clone() for k, p in local.G.named_parameters() if p.grad is not None}
+        local.update_D(batch)
+        d_local = {k: p.grad.detach().clone() for k, p in local.D.named_parameters() if p.grad is not None}
+        del local
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from climategan_amd.parallel import broadcast_parameters
+        T = build()                                      # setup() broadcast + reducers (is_distributed() is true now)
+        assert T.g_reducer is not None and T.g_reducer.active and T.g_reducer.world == 2
+        assert T.g_reducer.grad_dtype == torch.float32
+        # replicas identical after a broadcast although rank 1 perturbs everything first
+        if rank == 1:
+            with torch.no_grad():
+                for t in list(T.G.parameters()) + list(T.G.buffers()):
+                    if t.dtype.is_floating_point:
+                        t.add_(0.01)
+        broadcast_parameters(T.G)
+        from climategan_amd import ops
+        ops.touch(*T.G.parameters(), *T.G.buffers())
+
+        def digest(mod, what):
+            ts = {"p": dict(mod.named_parameters()), "b": dict(mod.named_buffers())}[what]
+            v = torch.stack([t.detach().double().sum() + t.detach().double().abs().sum() * 1e-3 for t in ts.values()]).cpu()
+            both = [torch.empty_like(v) for _ in range(world)]          # (gloo gathers host tensors only)
+            dist.all_gather(both, v)
+            return both
+
+        a, b = digest(T.G, "p")
+        same_after_broadcast = bool(torch.equal(a, b))
+        a, b = digest(T.G, "b")
+        same_buffers_after_broadcast = bool(torch.equal(a, b))
+
+        # step 1 by hand: gradients after finish() vs the mean of the ranks' local gradients
+        T.update_G(batch)
+        worst = {}
+        for name, mod, loc in (("G", T.G, g_local),):
+            for k, p in mod.named_parameters():
+                if p.grad is None:
+                    continue
+                mine = loc[k].cpu()
+                other = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(other, mine)
+                mean = (other[0] + other[1]) * 0.5
+                scale = float(mean.abs().max())
+                worst[name + "." + k] = (float((p.grad.cpu() - mean).abs().max()), scale)
+        T.update_D(batch)
+        for k, p in T.D.named_parameters():
+            if p.grad is None:
+                continue
+            mine = d_local[k].cpu()
+            other = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(other, mine)
+            mean = (other[0] + other[1]) * 0.5
+            worst["D." + k] = (float((p.grad.cpu() - mean).abs().max()), float(mean.abs().max()))
+        T.global_step += 1
+        for _ in range(2):
+            g, d = T.train_step(batch)
+            assert torch.isfinite(g) and torch.isfinite(d)
+        pa, pb = digest(T.G, "p")
+        da, db = digest(T.D, "p")
+        ba, bb = digest(T.G, "b")
+        q.put((rank, "ok", same_after_broadcast, same_buffers_after_broadcast, worst, bool(torch.equal(pa, pb)),
+               bool(torch.equal(da, db)), bool(torch.equal(ba, bb)), len(T.g_reducer.buckets), T.g_reducer._learning))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_two_ranks_on_one_gpu_train_in_lock_step():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    for rank, _, same_p, same_b, worst, lock_g, lock_d, same_bn, nb, learning in res:
+        assert same_p and same_b, "broadcast_parameters left the replicas different"
+        # mean of the local gradients: the twin trainer's backward is the same computation up to the fp32 atomics of the
+        # weight-gradient / bias-gradient kernels (run-to-run 1e-3 of a tensor's scale at most); tensors whose true
+        # gradient is zero (biases in front of a norm layer) are noise on both sides
+        top = {pre: max(v[1] for k, v in worst.items() if k.startswith(pre)) for pre in ("G.", "D.")}
+        bad = {k: v for k, v in worst.items() if v[0] > 2e-2 * v[1] + 1e-4 * top[k[:2]]}
+        assert len(worst) > 400 and not bad, (rank, list(bad.items())[:5])
+        assert lock_g and lock_d, "replicas diverged over three train steps"
+        assert not same_bn, "BatchNorm running statistics are per rank (different shards): they must differ"
+        assert nb >= 1 and learning is False
+    print("\n  two ranks: %d tensors, worst |grad - mean| / scale = %.2e"
+          % (len(res[0][4]), max(v[0] / max(v[1], 1e-30) for v in res[0][4].values() if v[1] > 1e-6)))
