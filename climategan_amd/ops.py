@@ -28,6 +28,9 @@ def touch(*tensors) -> None:
         torch.autograd.graph.increment_version(ts)
 
 
+MAX_MAP_BYTES = 2 ** 31
+
+
 def cs8(c: int) -> int:
     return (c + 7) & ~7
 
@@ -85,6 +88,11 @@ class NHWC:
         if self.t.dim() != 4 or self.t.shape[3] not in (cs8(self.c), cs4(self.c)):
             raise RuntimeError("NHWC: a [N,H,W,Cs] tensor with Cs = %d (or %d) storage channels is needed for %d logical "
                                "channels, got shape %s" % (cs8(self.c), cs4(self.c), self.c, tuple(self.t.shape)))
+        # several kernels address activations with 32-bit byte offsets (buffer descriptors, LDS-DMA lane offsets): a map of
+        # 2 GiB or more is refused here rather than wrapped around there (shard the batch: 288 GB holds many such maps)
+        if self.t.numel() * self.t.element_size() >= MAX_MAP_BYTES:
+            raise RuntimeError("NHWC: a %s map of %.2f GiB exceeds the 2 GiB the kernels' 32-bit offsets cover; use a smaller "
+                               "batch per call" % (tuple(self.t.shape), self.t.numel() * self.t.element_size() / 2 ** 30))
 
     @property
     def n(self): return self.t.shape[0]

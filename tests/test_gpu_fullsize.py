@@ -9,8 +9,8 @@
   selection depend on the batch size (different fp32 summation orders);
 * the per-call spectral-norm power iteration (norms.py:100-112) advances u / v: two calls from the same state differ
   by the second iteration, reloading the state reproduces the first output exactly (the whole path is deterministic);
-* against the committed 640 x 640 golden summary of the reference (fixture painter_640) the first image keeps the
-  16-bit bound of tests/test_gpu_painter.py."""
+(the golden comparison at the benchmark batch size -- 8 x the reference's painter_640 fixture -- is
+tests/test_gpu_painter.py::test_painter_640_at_benchmark_batch_matches_reference_golden)."""
 import numpy as np
 import pytest
 import torch

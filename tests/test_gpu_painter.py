@@ -98,6 +98,39 @@ def test_painter_matches_reference_golden(name, dt):
             assert np.abs(sd[k[5:]].cpu().numpy() - gold[k]).max() < 2e-5, k
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_painter_640_at_benchmark_batch_matches_reference_golden(dt):
+    """BASELINE configs[1] at ITS batch size: the default Painter (latent 640, 7 up-samplings) forward at 8 x 640 x 640 --
+    the golden conditioning image repeated eight times (samples are independent: instance norm only, so every image of
+    the batch must reproduce the reference's single-image output; kernel selection, statistics chunking and grid shapes
+    are those of bs 8, not of the B = 1 golden run above)."""
+    name = "painter_640"
+    case = CASES[name]
+    gold = load_golden(name)
+    G = build_generator(case, dt)
+    B = 8
+    G.painter.set_latent_shape((B, 3, case["H"], case["W"]), True)
+    cond = t(case_inputs(name, case)["cond"]).cuda().repeat(B, 1, 1, 1)
+    with torch.no_grad():
+        y = G.painter(None, cond)
+    assert y.shape == (B, 3, case["H"], case["W"])
+    for i in range(1, B):                  # one launch sequence, identical inputs: the images are identical bit for bit
+        assert torch.equal(y[i], y[0]), i
+    max_tol, mean_tol = tol(name, dt)
+    for i in (0, B - 1):
+        s = summarize(y[i:i + 1].cpu().numpy())
+        err = np.concatenate([np.abs(s[k] - gold["y_" + k]).ravel() for k in ("crop_tl", "crop_c", "crop_br")])
+        print("\n%s %s bs 8 image %d crops: max err %.3g (bound %.3g), mean err %.3g (bound %.3g)"
+              % (name, dt, i, err.max(), max_tol, err.mean(), mean_tol))
+        check_err(err, max_tol, mean_tol, name)
+        assert np.abs(s["pooled8"] - gold["y_pooled8"]).max() <= max_tol
+        assert np.abs(s["mean"] - gold["y_mean"]).max() <= mean_tol * 2
+    sd = G.painter.state_dict()
+    for k in gold:
+        if k.startswith("post."):
+            assert np.abs(sd[k[5:]].cpu().numpy() - gold[k]).max() < 2e-5, k
+
+
 @pytest.mark.parametrize("dt", [torch.float16])
 def test_paint_matches_reference_golden(dt):
     name = "paint_up4"
