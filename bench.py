@@ -392,7 +392,7 @@ def host_cores():
         return threads, threads
 
 
-CPU_BUDGET_S = 110.0     # wall-clock bound of the CPU leg (the default run must finish within minutes)
+CPU_BUDGET_S = 130.0     # wall-clock bound of the CPU leg (the default run must finish within minutes)
 
 
 def cpu_thread_sweep(phys):
@@ -479,7 +479,7 @@ def cpu_baseline_train():
         runs1.append(one_step(b1))
     best1 = min(runs1)
     bs4 = None
-    if time.perf_counter() - t_start + 3.6 * best1 < CPU_BUDGET_S:
+    if time.perf_counter() - t_start + 6.0 * best1 < CPU_BUDGET_S:   # measured: 72 s at 4 per domain against 12 s at 1
         dt4 = one_step(make_batch(4))
         bs4 = {"images_per_s": round(4.0 / dt4, 5), "s_per_step": round(dt4, 2), "runs": 1}
     return {"value": round(1.0 / best1, 5), "unit": "images/s", "cores": use, "kind": "port",
@@ -487,7 +487,7 @@ def cpu_baseline_train():
             "thread_sweep_s": {str(k): round(v, 4) for k, v in sweep.items()},
             "bs1": {"warmup_s": round(warm, 2), "timed_s": [round(v, 2) for v in runs1]},
             "bs4": bs4 if bs4 is not None else "skipped: a step at 4 per domain (~%.0f s) does not fit the %.0f s CPU budget"
-                                               % (3.6 * best1, CPU_BUDGET_S),
+                                               % (6.0 * best1, CPU_BUDGET_S),
             "sample": "oracle.cpu_ref.joint_train_step (torch fp32 CPU restatement of trainer.py:989-1032 incl. the ExtraAdam "
                       "extrapolation between the G and the D update), 640x640: 1 sample per domain (3 images per step), one "
                       "warm-up + %d timed steps, best %.1f s; %d torch threads (the fastest of a measured sweep) on a host "

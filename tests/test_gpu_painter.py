@@ -176,11 +176,11 @@ def test_reference_signature_forward_carries_a_graph_in_training_mode():
     G = build_generator(case, torch.float16)
     sd = {k: v.clone() for k, v in G.painter.state_dict().items()}
     cond = t(case_inputs("painter_up4", case)["cond"]).cuda()
-    y = G.painter(None, cond)
-    assert y.requires_grad and y.dtype == cond.dtype and y.shape[1] == 3
-    G.painter.load_state_dict(sd)                       # the spectral-norm u / v of the first call
     with torch.no_grad():
         y0 = G.painter(None, cond)
+    G.painter.load_state_dict(sd)                       # the spectral-norm u / v of the first call
+    y = G.painter(None, cond)
+    assert y.requires_grad and y.dtype == cond.dtype and y.shape[1] == 3
     assert torch.equal(y.detach(), y0)
     y.square().mean().backward()
     missing = [k for k, p in G.painter.named_parameters() if p.requires_grad and p.grad is None]

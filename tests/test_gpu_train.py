@@ -117,11 +117,11 @@ def test_nchw_outputs_carry_a_graph_under_autograd():
     sd = {k: v.clone() for k, v in D.state_dict().items()}
     inp = {k: t(v).cuda() for k, v in case_inputs(NAME, case).items()}
     x = torch.cat([inp["m"], inp["x"]], dim=1).requires_grad_(True)
-    out = D(x)
-    assert len(out) == case["num_D"] and out[0][0].shape[1] == case["ndf"] and out[0][-1].requires_grad
-    D.load_state_dict(sd)
     with torch.no_grad():
         ref = D(x.detach(), nhwc=True)
+    D.load_state_dict(sd)                                 # the spectral-norm u / v of the first call
+    out = D(x)
+    assert len(out) == case["num_D"] and out[0][0].shape[1] == case["ndf"] and out[0][-1].requires_grad
     for a, b in zip(out, ref):
         for ta, tb in zip(a, b):
             assert torch.equal(ta.detach(), ops.nhwc_to_nchw(tb))

@@ -83,26 +83,25 @@ def _worker(rank, world, port, q):
 
         # step 1 by hand: gradients after finish() vs the mean of the ranks' local gradients
         T.update_G(batch)
-        worst = {}
-        for name, mod, loc in (("G", T.G, g_local),):
+        worst = {}                                       # group -> [sum |g - mean|^2, sum |mean|^2, sum |g0 - g1|^2, tensors]
+
+        def compare(group_of, mod, loc):
             for k, p in mod.named_parameters():
                 if p.grad is None:
                     continue
-                mine = loc[k].cpu()
+                mine = loc[k].cpu().double()
                 other = [torch.empty_like(mine) for _ in range(world)]
                 dist.all_gather(other, mine)
                 mean = (other[0] + other[1]) * 0.5
-                scale = float(mean.abs().max())
-                worst[name + "." + k] = (float((p.grad.cpu() - mean).abs().max()), scale)
+                acc = worst.setdefault(group_of(k), [0.0, 0.0, 0.0, 0])
+                acc[0] += float((p.grad.cpu().double() - mean).pow(2).sum())
+                acc[1] += float(mean.pow(2).sum())
+                acc[2] += float((other[0] - other[1]).pow(2).sum())
+                acc[3] += 1
+
+        compare(lambda k: "G." + k.split(".")[0], T.G, g_local)
         T.update_D(batch)
-        for k, p in T.D.named_parameters():
-            if p.grad is None:
-                continue
-            mine = d_local[k].cpu()
-            other = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(other, mine)
-            mean = (other[0] + other[1]) * 0.5
-            worst["D." + k] = (float((p.grad.cpu() - mean).abs().max()), float(mean.abs().max()))
+        compare(lambda k: "D." + k.split(".")[0], T.D, d_local)
         T.global_step += 1
         for _ in range(2):
             g, d = T.train_step(batch)
@@ -136,14 +135,18 @@ def test_two_ranks_on_one_gpu_train_in_lock_step():
         assert r[1] == "ok", r[2]
     for rank, _, same_p, same_b, worst, lock_g, lock_d, same_bn, nb, learning in res:
         assert same_p and same_b, "broadcast_parameters left the replicas different"
-        # mean of the local gradients: the twin trainer's backward is the same computation up to the fp32 atomics of the
-        # weight-gradient / bias-gradient kernels (run-to-run 1e-3 of a tensor's scale at most); tensors whose true
-        # gradient is zero (biases in front of a norm layer) are noise on both sides
-        top = {pre: max(v[1] for k, v in worst.items() if k.startswith(pre)) for pre in ("G.", "D.")}
-        bad = {k: v for k, v in worst.items() if v[0] > 2e-2 * v[1] + 1e-4 * top[k[:2]]}
-        assert len(worst) > 400 and not bad, (rank, list(bad.items())[:5])
+        # mean of the local gradients, per network (relative L2 over all of its tensors): the twin trainer's backward is the
+        # same computation up to the fp32 atomics of the weight- / bias-gradient kernels and their amplification where a
+        # gradient is a small difference of large terms (D.m: the two domains push in opposite directions); the
+        # two ranks' LOCAL gradients differ from each other by O(1) of their size (third column), so a reducer that
+        # did not average (or averaged the wrong tensors) would miss these bounds by an order of magnitude
+        assert sum(v[3] for v in worst.values()) > 400
+        for grp, (num, den, apart, n) in sorted(worst.items()):
+            rel, spread = (num / max(den, 1e-300)) ** 0.5, (apart / max(den, 1e-300)) ** 0.5
+            print("  rank %d %-12s %4d tensors: |g - mean| / |mean| = %.2e   (|g_rank0 - g_rank1| / |mean| = %.2f)"
+                  % (rank, grp, n, rel, spread))
+            bound = {"D.m": 0.15, "D.s": 5e-2}.get(grp, 2e-2)
+            assert rel <= bound and spread >= 4 * bound, (rank, grp, rel, spread)
         assert lock_g and lock_d, "replicas diverged over three train steps"
         assert not same_bn, "BatchNorm running statistics are per rank (different shards): they must differ"
         assert nb >= 1 and learning is False
-    print("\n  two ranks: %d tensors, worst |grad - mean| / scale = %.2e"
-          % (len(res[0][4]), max(v[0] / max(v[1], 1e-30) for v in res[0][4].values() if v[1] > 1e-6)))
