@@ -20,3 +20,9 @@ struct ConvGemmArgs {
 // true for convs whose channel counts make the 128x256 (cout x pixel) LDS tiling worthwhile
 bool conv_gemm_applicable(const CganConvDesc* d);
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
+// conv_gemm_big.hip: the 256 couts x 256 pixels / K = 64 kernel (eight waves, one workgroup per CU)
+bool conv_gemm_big_ok(const ConvGemmArgs& a);
+// conv1x1_direct.hip: 1x1 layers with <= 256 couts, activations straight into B-fragment registers, all couts per workgroup
+bool conv1x1_allc_ok(const ConvGemmArgs& a);
+int conv1x1_allc_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
+int conv_gemm_big_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);

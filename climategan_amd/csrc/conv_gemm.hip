@@ -28,7 +28,10 @@ namespace {
 __device__ __attribute__((aligned(16))) unsigned int g_gemm_zeros[4];
 
 constexpr int NSTAGE = 3;
-int g_gemm_ws = 0;   // development knob (cgan_debug_set_gemm_ws): 0 = automatic, 1 = never the K = 64 kernel, 5 / 6 = force it
+// development knob (cgan_debug_set_gemm_ws): 0 = automatic, 1 = never a K = 64 kernel, 5 / 6 = force conv_gemm_k64_kernel,
+// 8 = force the 256 x 256 kernel of conv_gemm_big.hip, 10 = force the direct 1x1 kernel of conv1x1_direct.hip,
+// 9 = automatic without those two
+int g_gemm_ws = 0;
 
 __device__ __forceinline__ int reflect_i(int i, int n) {
   if (i < 0) i = -i;
@@ -560,11 +563,29 @@ int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 
 template <typename T>
 int launch(const ConvGemmArgs& a, hipStream_t s) {
   const int ptiles = ceil_div(a.npix, 16);
-  switch (g_gemm_ws) {
+  const bool no_big = g_gemm_ws == 9;
+  const int ws = no_big ? 0 : g_gemm_ws;
+  switch (ws) {
     case 5: if (k64_ok(a)) return launch_k64<T, 8, 4>(a, s); break;      // K = 64 stages, 256 couts x 128 pixels
     case 6: if (k64_ok(a)) return launch_k64<T, 4, 8>(a, s); break;      // K = 64 stages, 128 x 256
+    case 8: if (conv_gemm_big_ok(a)) return conv_gemm_big_launch(a, T::id, s); break;
+    case 10: if (conv1x1_allc_ok(a)) return conv1x1_allc_launch(a, T::id, s); break;
     default: break;
   }
+  // 1x1 layers with <= 256 output channels: activations straight from global memory into the B-fragment registers of the
+  // wave that owns the pixels, all couts per workgroup (conv1x1_direct.hip)
+  if (ws == 0 && !no_big && g_gemm_cfg == 0 && std::is_same<T, BF16>::value && conv1x1_allc_ok(a) && a.npix >= 16384)
+    return conv1x1_allc_launch(a, T::id, s);
+  // layers with >= 256 output channels (ResNet layer2-4 incl. the bottlenecks' 1x1 layers, ASPP, the 512-channel decoder
+  // convs, VGG / PatchGAN from 256 channels): 256 x 256 block tiles halve the L2 -> LDS fill per FLOP (conv_gemm_big.hip);
+  // bf16 only for the reason given below for the K = 64 kernel (fp16 fixtures were made with the plain summation order)
+  // Same-box A/B over the step's shapes (tools/gpu_ab_conv.sh): it wins where K is long enough to amortise a prologue and
+  // an epilogue that nothing overlaps with one workgroup per CU -- 512 -> 512 3x3 at 8 x 80^2 289 -> 256 us, at 4 x 80^2
+  // 163 -> 135 us, 2048 -> 512 1x1 181 -> 157 us -- and loses on the short-K bottleneck layers (256 -> 1024 1x1: 68 -> 118 us,
+  // 256 -> 256 3x3: 72 -> 84 us at 200 tiles for 256 CUs)
+  if (ws == 0 && !no_big && g_gemm_cfg == 0 && std::is_same<T, BF16>::value && conv_gemm_big_ok(a) && a.npix >= 16384 &&
+      a.cin_s * a.kh * a.kw >= 4096 && a.cin_s >= 512 && !(a.kh * a.kw >= 9 && a.cin_s >= 2048))
+    return conv_gemm_big_launch(a, T::id, s);
   // long-K 3x3 layers (>= 512 input channels: ResNet layer4, ASPP, the decoders' 512-channel convs): the K = 64 /
   // whole-line specialised kernel, 14-16 % faster than the plain one there (rocprofv3, bs 8: 80^2 512 -> 512 d4 337 -> 283 us,
   // 2048 -> 256 d6 538 -> 459 us); everywhere else it is slower (one workgroup per CU: short K loops are all prologue /
@@ -572,7 +593,7 @@ int launch(const ConvGemmArgs& a, hipStream_t s) {
   // bf16 (the training dtype) only: fp16 is what apply_events runs in, and its wildfire fixture turns single arg-max flips
   // of the untrained segmentation into a one-level contrast shift of a tenth of the image -- the two kernels agree within
   // an fp16 rounding step, but the fixture was verified with the plain kernel's summation order
-  if (g_gemm_ws == 0 && g_gemm_cfg == 0 && sizeof(typename T::vec8) && std::is_same<T, BF16>::value && k64_ok(a) &&
+  if (ws == 0 && g_gemm_cfg == 0 && sizeof(typename T::vec8) && std::is_same<T, BF16>::value && k64_ok(a) &&
       a.kh * a.kw >= 9 && a.cin_s >= 512 && a.npix >= 16384)
     return launch_k64<T, 8, 4>(a, s);
   switch (g_gemm_cfg) {

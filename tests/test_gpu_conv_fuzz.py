@@ -153,6 +153,10 @@ WS_CASES = [
     (1024, 256, 1, 1, 0, 1, 2, 40, 40, False, True), (64, 320, 1, 1, 0, 1, 1, 64, 64, False, False),
     (128, 128, 3, 1, 1, 1, 1, 40, 56, True, False), (256, 512, 4, 2, 1, 1, 2, 48, 48, False, False),
     (512, 320, 3, 1, 3, 3, 1, 130, 131, False, True),        # the automatic K = 64 choice: ragged pixels, partial cout block
+    (128, 512, 1, 1, 0, 1, 2, 40, 40, False, False), (256, 1024, 1, 1, 0, 1, 1, 80, 80, False, True),   # 2 / 4 K = 64 stages
+    (320, 256, 3, 1, 1, 1, 2, 64, 72, False, False),           # five 64-channel chunks x nine taps, 18 pixel blocks
+    (256, 64, 1, 1, 0, 1, 2, 96, 96, False, False), (512, 128, 1, 1, 0, 1, 2, 96, 101, False, True),   # direct 1x1 kernel: 4 / 8 cout tiles, ragged
+    (1024, 256, 1, 1, 0, 1, 8, 80, 80, False, True), (2048, 200, 1, 1, 0, 1, 3, 80, 80, False, False),  # ... 16 tiles; 13 of 16
 ]
 
 
@@ -179,7 +183,7 @@ def test_k64_specialised_gemm_matches_the_plain_kernel(case):
         res = ops.NHWC(torch.randn_like(y0.t), cout) if residual else None
         if residual:
             y0 = ops.conv2d(x, pw, residual=res, **kw)
-        for ws in (5, 6, 0):                                   # 256 x 128, 128 x 256, the automatic choice
+        for ws in (5, 6, 8, 10, 9, 0):    # 256 x 128, 128 x 256, the 256 x 256 kernel, the direct 1x1 kernel, automatic without / with them
             lib.cgan_debug_set_gemm_ws(ctypes.c_int(ws))
             y = ops.conv2d(x, pw, residual=res, **kw)
             y2 = ops.conv2d(x, pw, residual=res, **kw)

@@ -138,15 +138,19 @@ def test_two_ranks_on_one_gpu_train_in_lock_step():
         # mean of the local gradients, per network (relative L2 over all of its tensors): the twin trainer's backward is the
         # same computation up to the fp32 atomics of the weight- / bias-gradient kernels and their amplification where a
         # gradient is a small difference of large terms (D.m: the two domains push in opposite directions); the
-        # two ranks' LOCAL gradients differ from each other by O(1) of their size (third column), so a reducer that
-        # did not average (or averaged the wrong tensors) would miss these bounds by an order of magnitude
+        # two ranks' LOCAL gradients differ from each other by far more than that (last column), so a reducer that
+        # did not average (or averaged the wrong tensors) would miss these bounds
         assert sum(v[3] for v in worst.values()) > 400
         for grp, (num, den, apart, n) in sorted(worst.items()):
             rel, spread = (num / max(den, 1e-300)) ** 0.5, (apart / max(den, 1e-300)) ** 0.5
             print("  rank %d %-12s %4d tensors: |g - mean| / |mean| = %.2e   (|g_rank0 - g_rank1| / |mean| = %.2f)"
                   % (rank, grp, n, rel, spread))
+            # (the ADVENT discriminators of an untrained Masker see nearly the same entropy maps on both ranks: their local
+            # gradients are only 0.1 apart, and the averaging can only be seen on the other networks)
             bound = {"D.m": 0.15, "D.s": 5e-2}.get(grp, 2e-2)
-            assert rel <= bound and spread >= 4 * bound, (rank, grp, rel, spread)
+            assert rel <= bound, (rank, grp, rel, spread)
+            if grp.startswith("G.") or grp == "D.p":
+                assert spread >= 5 * rel, (rank, grp, rel, spread)
         assert lock_g and lock_d, "replicas diverged over three train steps"
         assert not same_bn, "BatchNorm running statistics are per rank (different shards): they must differ"
         assert nb >= 1 and learning is False
