@@ -49,7 +49,7 @@ class SnItem(C.Structure):
 class PackItem(C.Structure):
     _fields_ = [("w_oihw", C.c_void_p), ("bias", C.c_void_p), ("sigma", C.c_void_p), ("packed", C.c_void_p),
                 ("bias_out", C.c_void_p), ("c_out", C.c_int32), ("c_in", C.c_int32), ("kh", C.c_int32),
-                ("kw", C.c_int32)]
+                ("kw", C.c_int32), ("transposed", C.c_int32)]
 
 
 class AdamItem(C.Structure):

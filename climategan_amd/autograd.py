@@ -166,6 +166,11 @@ class ConvFn(torch.autograd.Function):
         ctx.has_res = res_t is not None
         # (sigma, u, v) as used in this forward: private copies (the batched step hands them over already copied)
         ctx.sn = None if sn is None else (tuple(sn) if cfg.get("sn_owned") else tuple(t.clone() for t in sn))
+        ctx.dgrad = None
+        if ctx.needs_input_grad[0] and not cfg.get("pair_in", False):
+            # the data-gradient operator of this call (w / THIS forward's sigma): packed with all the others of the
+            # backward pass in one launch (ops.dgrad_prepack_run, Trainer._backward)
+            ctx.dgrad = ops.dgrad_register(weight, ctx.sn[0] if ctx.sn is not None else None, x_t.dtype, cfg["stride"])
         ctx.save_for_backward(x_t, weight, y.t if cfg["act"] != ops.ACT_NONE else None)
         return y.t
 
@@ -185,7 +190,8 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             h_in, w_in = (x_t.shape[1] * 2, x_t.shape[2] * 2) if ups else (x_t.shape[1], x_t.shape[2])
             dx = ops.conv2d_bwd_data(dy, w_eff, (x_t.shape[0], h_in, w_in), stride=cfg["stride"], pad=cfg["pad"],
-                                     dilation=cfg["dilation"], sigma=sigma, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+                                     dilation=cfg["dilation"], sigma=sigma, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO),
+                                     prepacked=ctx.dgrad)
             dx_t = (ops.sumpool2x2(dx) if ups else dx).t
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres_t = (ops.sumpool2x2(dy) if cfg.get("residual_upsample", False) else dy).t
@@ -215,6 +221,7 @@ class ConvPassFn(torch.autograd.Function):
                        pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.dgrad = ops.dgrad_register(weight, None, x_t.dtype, cfg["stride"]) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x_t, weight)
         return y.t, x_t                   # (returned as-is: autograd makes it an output of this node)
 
@@ -229,7 +236,7 @@ class ConvPassFn(torch.autograd.Function):
             add = ops.NHWC(dpass_t.contiguous(), cfg["c_in"]) if dpass_t is not None else None
             dx_t = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], x_t.shape[1], x_t.shape[2]), stride=cfg["stride"],
                                        pad=cfg["pad"], dilation=cfg["dilation"],
-                                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO), add=add).t
+                                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO), add=add, prepacked=ctx.dgrad).t
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.conv2d_bwd_weight(ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"],

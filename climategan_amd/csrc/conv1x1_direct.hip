@@ -19,9 +19,14 @@
 
 namespace {
 
-template <typename T, int CT>
+// CTW cout tiles per wave x WAVES_C wave rows = all couts; 8 / WAVES_C wave columns x WP pixel tiles x 16 = pixels per
+// workgroup.  <8, 2, 4>: 256 couts (a wave: 128 couts x 64 pixels, one A fragment read per FOUR MFMAs; every pixel's B
+// fragments are loaded by the two waves of its column -- the second load is an L1 / L2 hit); <8, 1, 2>: 128 couts;
+// <4, 1, 2>: 64 couts.  (The first version gave every wave all 16 cout tiles x 2 pixel tiles: one LDS read per two MFMAs at
+// 256 registers, no room to prefetch the A fragments -- LDS latency bound, 1024 -> 256 at 8 x 80^2 68 us against 55.)
+template <typename T, int CTW, int WAVES_C, int WP>
 __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
-  constexpr int NWAVE = 8, WP = 2;
+  constexpr int NWAVE = 8, CT = CTW * WAVES_C, NPG = NWAVE / WAVES_C;
   constexpr int PIECES = CT * 2;                                   // 1-KiB weight pieces per K = 64 stage
   constexpr int PPW = (PIECES + NWAVE - 1) / NWAVE;                // per wave
   constexpr int STAGE_BYTES = PIECES * 1024;
@@ -30,7 +35,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j16 = lane & 15, g = lane >> 4;
-  const int pix0 = (blockIdx.x * NWAVE + wave) * (WP * 16);
+  const int wc = wave % WAVES_C, wpg = wave / WAVES_C;
+  const int pix0 = (blockIdx.x * NPG + wpg) * (WP * 16);
   const int n_st = p.cin_s >> 6;
 
   // B fragments straight from global memory: pixel (tile t, j), channels 64 s + 32 h + 8 g ..
@@ -66,9 +72,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
         *reinterpret_cast<u32x4*>(smem + slot * STAGE_BYTES + (wave + NWAVE * m) * 1024 + lane * 16) = wreg[m];
   };
 
-  f32x4 acc[CT][WP];
+  f32x4 acc[CTW][WP];
 #pragma unroll
-  for (int c = 0; c < CT; ++c)
+  for (int c = 0; c < CTW; ++c)
 #pragma unroll
     for (int t = 0; t < WP; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -87,11 +93,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
       load_b(bn, s + 1);
     }
     if (s + 2 < n_st) load_w(s + 2);
-    const unsigned char* wl = smem + slot * STAGE_BYTES + lane * 16;
+    const unsigned char* wl = smem + slot * STAGE_BYTES + wc * CTW * 2048 + lane * 16;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
+      for (int c = 0; c < CTW; ++c) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(wl + (c * 2 + h) * 1024);
 #pragma unroll
         for (int t = 0; t < WP; ++t) acc[c][t] = mfma16(as_vec8<T>(a), as_vec8<T>(bc[h][t]), acc[c][t]);
@@ -104,13 +110,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
   }
 
   // ---- epilogue: one pixel tile at a time through LDS (fp32 rows of CT*16 couts + 16 B pad), 16-byte stores
-  constexpr int ROWB = CT * 64 + 16;
-  constexpr int CH = CT * 2;
+  constexpr int ROWB = CTW * 64 + 16;
+  constexpr int CH = CTW * 2;
   unsigned char* stg = smem + wave * (16 * ROWB);
+  const int cout_base = wc * CTW * 16;
 #pragma unroll
   for (int t = 0; t < WP; ++t) {
 #pragma unroll
-    for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(stg + j16 * ROWB + c * 64 + g * 16) = acc[c][t];
+    for (int c = 0; c < CTW; ++c) *reinterpret_cast<f32x4*>(stg + j16 * ROWB + c * 64 + g * 16) = acc[c][t];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int pix_base = pix0 + t * 16;
 #pragma unroll
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
       const int idx = it * 64 + lane;
       const int pl = idx / CH, qc = idx % CH;
       const int pix = pix_base + pl;
-      const int ch = qc * 8;
+      const int ch = cout_base + qc * 8;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
       if (pix >= p.npix || ch >= p.cout_s) continue;
@@ -161,13 +168,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
   }
 }
 
-template <typename T, int CT>
+template <typename T, int CTW, int WAVES_C, int WP>
 int launch_allc(const ConvGemmArgs& a, hipStream_t s) {
-  constexpr size_t stage2 = (size_t)2 * CT * 2 * 1024, epi = (size_t)8 * 16 * (CT * 64 + 16);
+  constexpr int CT = CTW * WAVES_C, PB = (8 / WAVES_C) * WP * 16;
+  constexpr size_t stage2 = (size_t)2 * CT * 2 * 1024, epi = (size_t)8 * 16 * (CTW * 64 + 16);
   constexpr size_t smem = stage2 > epi ? stage2 : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_allc_kernel<T, CT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_allc_kernel<T, CTW, WAVES_C, WP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("conv1x1_direct: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -175,8 +183,15 @@ int launch_allc(const ConvGemmArgs& a, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1_allc_kernel<T, CT>), dim3(ceil_div(a.npix, 256)), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((conv1x1_allc_kernel<T, CTW, WAVES_C, WP>), dim3(ceil_div(a.npix, PB)), dim3(512), smem, s, a);
   return CGAN_OK;
+}
+
+template <typename T>
+int launch_any(const ConvGemmArgs& a, hipStream_t s) {
+  if (a.ctiles <= 4) return launch_allc<T, 4, 1, 2>(a, s);
+  if (a.ctiles <= 8) return launch_allc<T, 8, 1, 2>(a, s);
+  return launch_allc<T, 8, 2, 4>(a, s);
 }
 
 }  // namespace
@@ -188,13 +203,5 @@ bool conv1x1_allc_ok(const ConvGemmArgs& a) {
 }
 
 int conv1x1_allc_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
-  const int ct = a.ctiles <= 4 ? 4 : (a.ctiles <= 8 ? 8 : 16);
-  if (dtype == CGAN_F16) {
-    if (ct == 4) return launch_allc<F16, 4>(a, s);
-    if (ct == 8) return launch_allc<F16, 8>(a, s);
-    return launch_allc<F16, 16>(a, s);
-  }
-  if (ct == 4) return launch_allc<BF16, 4>(a, s);
-  if (ct == 8) return launch_allc<BF16, 8>(a, s);
-  return launch_allc<BF16, 16>(a, s);
+  return dtype == CGAN_F16 ? launch_any<F16>(a, s) : launch_any<BF16>(a, s);
 }

@@ -574,7 +574,12 @@ int launch(const ConvGemmArgs& a, hipStream_t s) {
   }
   // 1x1 layers with <= 256 output channels: activations straight from global memory into the B-fragment registers of the
   // wave that owns the pixels, all couts per workgroup (conv1x1_direct.hip)
-  if (ws == 0 && !no_big && g_gemm_cfg == 0 && std::is_same<T, BF16>::value && conv1x1_allc_ok(a) && a.npix >= 16384)
+  // Same-box A/B (tools/gpu_ab_conv.sh): it wins for <= 64 output channels (256 -> 64 at 8 x 160^2 50 -> 37 us, 128 -> 64
+  // 14.7 -> 10.2 us, their data gradients 48 -> 38 us) and loses from 128 up: at 1024 input channels the B-fragment loads are
+  // 16 rows x 64 B at a 2-KiB stride per instruction (1024 -> 256: 55 -> 68 us with all 16 cout tiles per wave, 126 us with a
+  // 2 x 4 wave grid) -- the row-strided half-line pattern costs more on the vector-memory path than the LDS-DMA pieces do
+  if (ws == 0 && !no_big && g_gemm_cfg == 0 && std::is_same<T, BF16>::value && conv1x1_allc_ok(a) && a.ctiles <= 4 &&
+      a.npix >= 16384)
     return conv1x1_allc_launch(a, T::id, s);
   // layers with >= 256 output channels (ResNet layer2-4 incl. the bottlenecks' 1x1 layers, ASPP, the 512-channel decoder
   // convs, VGG / PatchGAN from 256 channels): 256 x 256 block tiles halve the L2 -> LDS fill per FLOP (conv_gemm_big.hip);

@@ -304,8 +304,10 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
   constexpr int CB = 32;                       // channels per unit
   __shared__ float tile[16][CB * 16 + 1];      // [cout row][c * taps + tap], taps <= 16 staged per pass; +1: bank spread
   const CganPackItem it = items[blockIdx.y];
-  const int cin_p = conv_cin_p((it.c_in + 7) & ~7, it.kh, it.kw);
-  const int cout_s = (it.c_out + 7) & ~7;
+  // rows / K channels of the packed operator: the forward weight's (c_out, c_in), or -- data-gradient operator -- swapped
+  const int n_rows = it.transposed ? it.c_in : it.c_out, n_k = it.transposed ? it.c_out : it.c_in;
+  const int cin_p = conv_cin_p((n_k + 7) & ~7, it.kh, it.kw);
+  const int cout_s = (n_rows + 7) & ~7;
   const int ctiles = (cout_s + 15) / 16;
   const int taps = it.kh * it.kw;
   const int ksteps = (taps * (cin_p / 8) + 3) / 4;
@@ -322,14 +324,28 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
     const int nt = min(16, taps - t0);         // taps staged in this pass
     __syncthreads();
     // ---- load: rows of the OIHW tensor, contiguous in (c, tap)
-    for (int idx = threadIdx.x; idx < 16 * CB * taps; idx += blockDim.x) {
-      const int row = idx / (CB * taps), r = idx - row * (CB * taps);
-      const int c = r / taps, tap = r - c * taps;
-      if (tap < t0 || tap >= t0 + nt) continue;
-      const int co = ct * 16 + row, ci = c0 + c;
-      float v = 0.f;
-      if (co < it.c_out && ci < it.c_in) v = __fdiv_rn(it.w_oihw[((size_t)co * it.c_in + ci) * taps + tap], sig);
-      tile[row][c * 16 + (tap - t0)] = v;
+    if (!it.transposed) {
+      for (int idx = threadIdx.x; idx < 16 * CB * taps; idx += blockDim.x) {
+        const int row = idx / (CB * taps), r = idx - row * (CB * taps);
+        const int c = r / taps, tap = r - c * taps;
+        if (tap < t0 || tap >= t0 + nt) continue;
+        const int co = ct * 16 + row, ci = c0 + c;
+        float v = 0.f;
+        if (co < it.c_out && ci < it.c_in) v = __fdiv_rn(it.w_oihw[((size_t)co * it.c_in + ci) * taps + tap], sig);
+        tile[row][c * 16 + (tap - t0)] = v;
+      }
+    } else {
+      // operator element (row r, K channel k, tap t) = w[k][r][taps - 1 - t]: for one k the 16 rows x taps of a unit are
+      // contiguous in the forward tensor
+      for (int idx = threadIdx.x; idx < 16 * CB * taps; idx += blockDim.x) {
+        const int c = idx / (16 * taps), r = idx - c * (16 * taps);
+        const int row = r / taps, tap = taps - 1 - (r - row * taps);
+        if (tap < t0 || tap >= t0 + nt) continue;
+        const int ro = ct * 16 + row, k = c0 + c;
+        float v = 0.f;
+        if (ro < n_rows && k < n_k) v = __fdiv_rn(it.w_oihw[((size_t)k * n_rows + ro) * taps + (taps - 1 - tap)], sig);
+        tile[row][c * 16 + (tap - t0)] = v;
+      }
     }
     __syncthreads();
     // ---- store: one 16-byte fragment entry per (tap, 8-channel group, row)
@@ -359,8 +375,9 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
       }
     }
   }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ctiles * 16; i += gridDim.x * blockDim.x)
-    it.bias_out[i] = (it.bias && i < it.c_out) ? it.bias[i] : 0.f;
+  if (it.bias_out)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ctiles * 16; i += gridDim.x * blockDim.x)
+      it.bias_out[i] = (it.bias && i < it.c_out) ? it.bias[i] : 0.f;
 }
 
 // Packed weights of the parity-class data gradient: one [ctile][ks][lane][8] block per class (blockIdx.y), K order

@@ -549,6 +549,62 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
     return NHWC(y, pw.c_out)
 
 
+class DgradPack:
+    """A stride-1 convolution's data-gradient weights, registered during the forward so that ALL of a backward pass's
+    operators can be packed in one launch (``dgrad_prepack_run``) instead of one launch per layer inside the backward
+    (274 per joint train step).  ``packed`` stays None until that launch; ``conv2d_bwd_data`` then packs on its own."""
+    __slots__ = ("w", "sigma", "dtype", "packed")
+
+    def __init__(self, w, sigma, dtype):
+        self.w, self.sigma, self.dtype, self.packed = w, sigma, dtype, None
+
+
+_DGRAD_PENDING = []
+
+
+def dgrad_register(w: torch.Tensor, sigma, dtype, stride: int) -> Optional[DgradPack]:
+    """Called by the autograd Functions' forward for a conv whose input wants a gradient.  Stride-1 only (strided convs
+    use the parity-class pack).  The list is bounded: nobody may ever call ``dgrad_prepack_run`` (plain ``backward()``)."""
+    if stride != 1 or w.dtype != torch.float32 or not w.is_contiguous():
+        return None
+    if len(_DGRAD_PENDING) >= 4096:
+        del _DGRAD_PENDING[:2048]
+    h = DgradPack(w.detach(), sigma, dtype)
+    _DGRAD_PENDING.append(h)
+    return h
+
+
+def dgrad_prepack_run() -> int:
+    """Pack every registered, not yet packed operator (one launch per 16-bit type) and forget the list."""
+    todo = [h for h in _DGRAD_PENDING if h.packed is None]
+    del _DGRAD_PENDING[:]
+    lib = _lib.load()
+    for dtype in (torch.bfloat16, torch.float16):
+        hs = [h for h in todo if h.dtype == dtype]
+        if not hs:
+            continue
+        dev = hs[0].w.device
+        items = (PackItem * len(hs))()
+        max_frag = 0
+        for i, h in enumerate(hs):
+            c_out, c_in, kh, kw = h.w.shape
+            d = _conv_desc(_DT[dtype], 1, max(kh, 1), max(kw, 1), c_out, c_in, kh, kw, 1, 0, 1, PAD_ZERO)   # the operator's dims
+            nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
+            if nbytes == 0:
+                _lib.check(-1, "cgan_conv2d_packed_weight_bytes")
+            h.packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            max_frag = max(max_frag, nbytes // 16)
+            items[i] = PackItem(h.w.data_ptr(), 0, h.sigma.data_ptr() if h.sigma is not None else 0, h.packed.data_ptr(), 0,
+                                c_out, c_in, kh, kw, 1)
+        host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
+        table = host.to(dev, non_blocking=True)
+        _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(table), len(hs), _DT[dtype], max_frag, _stream()),
+                   "cgan_conv2d_pack_weight_batched")
+        _PACK_TABLES.append((host, table, hs))
+        del _PACK_TABLES[:-8]
+    return len(todo)
+
+
 def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
     """Backward of nn.ReflectionPad2d(pad): folds the gradient of the padded tensor onto the unpadded extent."""
     _need_cuda(dxp.t)
@@ -561,19 +617,20 @@ def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
 
 
 def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilation=1,
-                    sigma: Optional[torch.Tensor] = None, pad_mode=PAD_ZERO, add: Optional[NHWC] = None) -> NHWC:
+                    sigma: Optional[torch.Tensor] = None, pad_mode=PAD_ZERO, add: Optional[NHWC] = None,
+                    prepacked: Optional[DgradPack] = None) -> NHWC:
     """dx of y = conv(x, w / sigma): ``w`` fp32 OIHW, ``x_shape`` = (n, h_in, w_in) of the forward input.  Reflect
     padding: data gradient of the pad-0 conv over the padded extent, folded back by the reflection's adjoint.
     ``add``: another gradient contribution of the same input tensor, summed in the kernel's epilogue (stride-1 'same'
     convolutions with zero padding; otherwise by a separate pass)."""
     if add is not None and not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1)
                                 and w.shape[2] == w.shape[3]):
-        dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode)
+        dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode, prepacked=prepacked)
         return NHWC(dx.t + add.t, dx.c)
     if pad_mode == PAD_REFLECT and pad > 0:
         n, h_in, w_in = x_shape
         dxp = conv2d_bwd_data(dy, w, (n, h_in + 2 * pad, w_in + 2 * pad), stride=stride, pad=0, dilation=dilation,
-                              sigma=sigma)
+                              sigma=sigma, prepacked=prepacked)
         return reflect_pad_bwd(dxp, pad)
     _need_cuda(dy.t, w, sigma)
     _need_cs8("conv2d_bwd_data", dy)
@@ -587,9 +644,13 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     nbytes = lib.cgan_conv2d_dgrad_packed_weight_bytes(C.byref(d))
     if nbytes == 0:
         _lib.check(-1, "cgan_conv2d_dgrad_packed_weight_bytes")
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
-               "cgan_conv2d_pack_weight_dgrad")
+    if (prepacked is not None and prepacked.packed is not None and stride == 1 and prepacked.dtype == dy.t.dtype
+            and prepacked.packed.numel() == nbytes and tuple(prepacked.w.shape) == tuple(w.shape)):
+        packed = prepacked.packed                            # packed with the whole backward's operators in one launch
+    else:
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
+                   "cgan_conv2d_pack_weight_dgrad")
     dx = torch.empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
     if add is not None:
         if add.t.shape != dx.shape or add.t.dtype != dx.dtype or not add.t.is_contiguous():

@@ -491,6 +491,7 @@ class Trainer:
         dev = next(module.parameters()).device
         prev = ops.set_zero_arena(ops.ZeroArena(n, dev))
         try:
+            ops.dgrad_prepack_run()          # every stride-1 data-gradient operator of this backward, one pack launch
             loss.backward()
         finally:
             ops.set_zero_arena(prev)

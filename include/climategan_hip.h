@@ -93,6 +93,9 @@ typedef struct {
   void* packed;          /* cgan_conv2d_packed_weight_bytes */
   float* bias_out;       /* fp32 [round_up(round_up(c_out,8),16)] */
   int32_t c_out, c_in, kh, kw;
+  int32_t transposed;    /* 0: the forward operator; 1: the stride-1 data-gradient operator of the FORWARD weight
+                          * [c_out][c_in][kh][kw] (rows = c_in, K channels = c_out, taps flipped) -- what
+                          * cgan_conv2d_pack_weight_dgrad writes for a stride-1 descriptor; bias / bias_out unused */
 } CganPackItem;
 int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t count, int32_t dtype,
                                     int32_t max_fragments, void* stream);

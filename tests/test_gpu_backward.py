@@ -696,3 +696,41 @@ def test_batched_weight_pack_is_bitwise_the_single_pack():
             assert a.w.data_ptr() == g.w.data_ptr()
             ref2 = ops.pack_conv_weight(w * 2, b, dt)
             assert torch.equal(a.w, ref2.w) and torch.equal(a.bias, ref2.bias)
+
+
+def test_batched_dgrad_pack_equals_the_per_layer_pack():
+    """``ops.dgrad_prepack_run`` (all stride-1 data-gradient operators of a backward pass in ONE launch,
+    cgan_conv2d_pack_weight_batched with ``transposed``) writes exactly the bytes ``cgan_conv2d_pack_weight_dgrad`` writes
+    per layer -- with and without a spectral-norm sigma, 1x1 / 3x3 / 4x4 / 7x7, channel counts that are not multiples of
+    the tile sizes -- and ``conv2d_bwd_data`` then gives identical gradients from either."""
+    import ctypes as C
+    from climategan_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(64, 256, 1), (256, 64, 1), (20, 40, 3), (3, 20, 3), (128, 128, 3), (48, 256, 1), (512, 4, 4), (1, 8, 3),
+              (64, 3, 7), (304, 256, 3)]
+    for dt in (torch.bfloat16, torch.float16):
+        hs, refs = [], []
+        for i, (co, ci, k) in enumerate(shapes):
+            w = torch.randn(co, ci, k, k, device="cuda", generator=g) * 0.1
+            sigma = torch.rand(1, device="cuda", generator=g) + 0.5 if i % 2 else None
+            h = ops.dgrad_register(w, sigma, dt, 1)
+            assert h is not None
+            hs.append(h)
+            d = ops._conv_desc(ops._DT[dt], 2, 24, 24, ci, co, k, k, 1, k // 2, 1, ops.PAD_ZERO, has_bias=False)
+            nbytes = lib.cgan_conv2d_dgrad_packed_weight_bytes(C.byref(d))
+            ref = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.cgan_conv2d_pack_weight_dgrad(ops._ptr(w), ops._ptr(sigma), ops._ptr(ref), C.byref(d), ops._stream()),
+                       "cgan_conv2d_pack_weight_dgrad")
+            refs.append(ref)
+        assert ops.dgrad_register(torch.randn(8, 8, 4, 4, device="cuda"), None, dt, 2) is None      # strided: per-call pack
+        assert ops.dgrad_prepack_run() == len(shapes)
+        for h, ref, shp in zip(hs, refs, shapes):
+            assert h.packed is not None and h.packed.numel() == ref.numel(), shp
+            assert torch.equal(h.packed, ref), shp
+        co, ci, k = shapes[4]
+        dy = ops.NHWC(torch.randn(2, 24, 24, co, device="cuda", generator=g).to(dt), co)
+        a = ops.conv2d_bwd_data(dy, hs[4].w, (2, 24, 24), pad=1, sigma=hs[4].sigma, prepacked=hs[4])
+        b = ops.conv2d_bwd_data(dy, hs[4].w, (2, 24, 24), pad=1, sigma=hs[4].sigma)
+        assert torch.equal(a.t, b.t)
