@@ -287,10 +287,21 @@ def install_conv_gemm_timer(timer):
                                  tag(d, "bwd_data+"))
         return bwd_add(dy, w, dx_add, dx, dref, stream)
 
+    fwd_stats = lib.cgan_conv2d_nhwc_fwd_stats
+
+    def timed_fwd_stats(x, w, b, y, partial, nbytes, dref, stream):     # forward + BatchNorm statistics epilogue: GEMM kernel only
+        if timer.enabled:
+            d = dref._obj
+            return timer.bracket(lambda: fwd_stats(x, w, b, y, partial, nbytes, dref, stream),
+                                 2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw, alg_bytes(d), tag(d, "fwd+st"))
+        return fwd_stats(x, w, b, y, partial, nbytes, dref, stream)
+
     lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = timed_fwd, timed_bwd, timed_bwd_add
+    lib.cgan_conv2d_nhwc_fwd_stats = timed_fwd_stats
 
     def uninstall():
         lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = fwd, bwd, bwd_add
+        lib.cgan_conv2d_nhwc_fwd_stats = fwd_stats
     return uninstall
 
 

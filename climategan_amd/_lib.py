@@ -119,6 +119,10 @@ _SIGNATURES = {
     "cgan_spade_bwd_prepare": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
     "cgan_batchnorm_train_stats": (C.c_int, [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, C.POINTER(NormStatsDesc), _P,
                                              C.c_size_t, _P]),
+    "cgan_batchnorm_train_stats_from_partials": (C.c_int, [_P, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P,
+                                                           C.POINTER(NormStatsDesc), _P]),
+    "cgan_conv2d_stats_chunk_pixels": (C.c_int32, [C.POINTER(ConvDesc)]),
+    "cgan_conv2d_nhwc_fwd_stats": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.POINTER(ConvDesc), _P]),
     "cgan_bn_train_prepare": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "cgan_batchnorm_act_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,

@@ -158,9 +158,17 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x_t, weight, bias, res_t, packed, cfg, sn):
         x = ops.NHWC(x_t, cfg["c_in"])
         res = ops.NHWC(res_t, weight.shape[0]) if res_t is not None else None
-        y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"], act=cfg["act"],
-                       slope=cfg["slope"], residual=res, in_upsample=cfg.get("in_upsample", False),
-                       residual_upsample=cfg.get("residual_upsample", False), pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+        if cfg.get("want_stats") and res is None and cfg["act"] == ops.ACT_NONE and not cfg.get("in_upsample", False):
+            # a BatchNorm follows: its statistics come out of this kernel's epilogue (handed over through cfg: the
+            # partials are no tensor of the graph)
+            y, cfg["stats_out"] = ops.conv2d_with_stats(x, packed, stride=cfg["stride"], pad=cfg["pad"],
+                                                        dilation=cfg["dilation"], pad_mode=cfg.get("pad_mode", ops.PAD_ZERO),
+                                                        groups=BN_GROUPS)
+        else:
+            y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"], act=cfg["act"],
+                           slope=cfg["slope"], residual=res, in_upsample=cfg.get("in_upsample", False),
+                           residual_upsample=cfg.get("residual_upsample", False),
+                           pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
@@ -217,8 +225,13 @@ class ConvPassFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_t, weight, bias, packed, cfg):
         x = ops.NHWC(x_t, cfg["c_in"])
-        y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"],
-                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+        if cfg.get("want_stats"):
+            y, cfg["stats_out"] = ops.conv2d_with_stats(x, packed, stride=cfg["stride"], pad=cfg["pad"],
+                                                        dilation=cfg["dilation"], pad_mode=cfg.get("pad_mode", ops.PAD_ZERO),
+                                                        groups=BN_GROUPS)
+        else:
+            y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"],
+                           pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.dgrad = ops.dgrad_register(weight, None, x_t.dtype, cfg["stride"]) if ctx.needs_input_grad[0] else None
@@ -410,7 +423,8 @@ class BatchNormActFn(torch.autograd.Function):
     dy * act'(out) is a second output of the backward's apply kernel."""
 
     @staticmethod
-    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None, res_t=None):
+    def forward(ctx, x_t, gamma, beta, running_mean, running_var, c, eps, momentum, act, slope, nbt=None, res_t=None,
+                conv_stats=None):
         n, h, w, cs = x_t.shape
         G = BN_GROUPS                                                  # see bn_groups
         if n % G:
@@ -418,9 +432,14 @@ class BatchNormActFn(torch.autograd.Function):
         npix = n * h * w // G
         x_t = x_t.contiguous()
         flat = ops.NHWC(x_t.view(G, npix, 1, cs), c)                   # G "images" of n/G*h*w pixels
-        # batch statistics + (mean', rstd') for the apply kernel + running statistics + step counter: two launches
-        mean, rstd, mean_f, rstd_f = ops.batchnorm_train_stats(flat, gamma, beta, running_mean, running_var, nbt, eps,
-                                                               momentum)
+        if conv_stats is not None and npix % conv_stats.chunk_pixels == 0:
+            # the producing conv's epilogue already reduced x per chunk of pixels: finalize only (one launch, no pass)
+            mean, rstd, mean_f, rstd_f = ops.batchnorm_train_stats_from_partials(
+                conv_stats, G, npix, c, gamma, beta, running_mean, running_var, nbt, eps, momentum)
+        else:
+            # batch statistics + (mean', rstd') for the apply kernel + running statistics + step counter: two launches
+            mean, rstd, mean_f, rstd_f = ops.batchnorm_train_stats(flat, gamma, beta, running_mean, running_var, nbt, eps,
+                                                                   momentum)
         res = None
         if res_t is not None:
             if res_t.shape != x_t.shape:
@@ -456,7 +475,7 @@ class BatchNormActFn(torch.autograd.Function):
             ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._ptr(dres) if dres is not None and dres is not dy_t else None,
             ops._DT[x_t.dtype], n * h * w, c, G, act, slope, ops._ptr(ws), nbytes, ops._stream()),
             "cgan_batchnorm_act_bwd_grouped")
-        return dx, dg, db, None, None, None, None, None, None, None, None, dres
+        return dx, dg, db, None, None, None, None, None, None, None, None, dres, None
 
 
 class BceLogitsFn(torch.autograd.Function):

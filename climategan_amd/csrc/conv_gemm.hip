@@ -33,6 +33,16 @@ constexpr int NSTAGE = 3;
 // 9 = automatic without those two
 int g_gemm_ws = 0;
 
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four row rotations on the
+// VALU's data-parallel-primitive path (__shfl_xor compiles to ds_bpermute_b32: an LDS instruction per step and value)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 __device__ __forceinline__ int reflect_i(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;
@@ -185,6 +195,43 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   __builtin_amdgcn_s_barrier();                               // every wave is done with the operand ring
   unsigned char* stg = smem + wave * (PP * 16 * ROWB);
   const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
+  if (p.stats) {
+    // training-mode BatchNorm statistics from the accumulators: (mean, M2) of this wave's WP x 16 pixels per channel --
+    // sum and sum of squares over the wave's pixel tiles, then over the 16 lanes (pixels) that share a channel quad; the
+    // finalize kernel of norm_stats.hip merges the chunks with Chan's formula.  Every chunk is full (the dispatcher
+    // checked npix against the chunk size), pixels past npix do not exist here.
+    const int chunk = pblk * WAVES_P + wp;
+    constexpr float inv_cnt = 1.f / (float)(WP * 16);
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+      float sm[4], sq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < WP; ++t) {
+          const float v = acc[c][t][r];
+          a0 += v;
+          a1 += v * v;
+        }
+        sm[r] = row16_sum(a0);
+        sq[r] = row16_sum(a1);
+      }
+      const int ch = cout_base + c * 16 + 4 * g;
+      if (j == 0 && ch < p.cout_s) {
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mean = sm[r] * inv_cnt;
+          o[2 * r] = mean + (p.bias ? p.bias[ch + r] : 0.f);
+          o[2 * r + 1] = fmaxf(sq[r] - sm[r] * mean, 0.f);
+        }
+        float* dst = p.stats + ((size_t)chunk * p.cout_s + ch) * 2;
+        *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+      }
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < WP / PP; ++pass) {
 #pragma unroll
@@ -560,67 +607,87 @@ int launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
 
 int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 1..4 = force a block tile
 
-template <typename T>
-int launch(const ConvGemmArgs& a, hipStream_t s) {
+enum { KIND_PLAIN = 0, KIND_K64_256x128, KIND_K64_128x256, KIND_BIG, KIND_DIRECT };
+struct Choice {
+  int kind;
+  int cfg;    // KIND_PLAIN: 1 = <1,4,4> (64 couts x 256 pixels), 2 = <2,8,4> (256 x 128), 3 = <2,4,8> (128 x 256),
+              //             4 = <2,4,4> (128 x 128), 5 = <2,4,4> with a 2-stage ring
+};
+
+// the kernel (and block tile) a descriptor runs: a pure function of the shape, the 16-bit type and the development knobs
+Choice choose(const ConvGemmArgs& a, bool bf16) {
   const int ptiles = ceil_div(a.npix, 16);
   const bool no_big = g_gemm_ws == 9;
   const int ws = no_big ? 0 : g_gemm_ws;
   switch (ws) {
-    case 5: if (k64_ok(a)) return launch_k64<T, 8, 4>(a, s); break;      // K = 64 stages, 256 couts x 128 pixels
-    case 6: if (k64_ok(a)) return launch_k64<T, 4, 8>(a, s); break;      // K = 64 stages, 128 x 256
-    case 8: if (conv_gemm_big_ok(a)) return conv_gemm_big_launch(a, T::id, s); break;
-    case 10: if (conv1x1_allc_ok(a)) return conv1x1_allc_launch(a, T::id, s); break;
+    case 5: if (k64_ok(a)) return {KIND_K64_256x128, 0}; break;         // K = 64 stages, 256 couts x 128 pixels
+    case 6: if (k64_ok(a)) return {KIND_K64_128x256, 0}; break;         // K = 64 stages, 128 x 256
+    case 8: if (conv_gemm_big_ok(a)) return {KIND_BIG, 0}; break;
+    case 10: if (conv1x1_allc_ok(a)) return {KIND_DIRECT, 0}; break;
     default: break;
   }
-  // 1x1 layers with <= 256 output channels: activations straight from global memory into the B-fragment registers of the
-  // wave that owns the pixels, all couts per workgroup (conv1x1_direct.hip)
-  // Same-box A/B (tools/gpu_ab_conv.sh): it wins for <= 64 output channels (256 -> 64 at 8 x 160^2 50 -> 37 us, 128 -> 64
-  // 14.7 -> 10.2 us, their data gradients 48 -> 38 us) and loses from 128 up: at 1024 input channels the B-fragment loads are
-  // 16 rows x 64 B at a 2-KiB stride per instruction (1024 -> 256: 55 -> 68 us with all 16 cout tiles per wave, 126 us with a
-  // 2 x 4 wave grid) -- the row-strided half-line pattern costs more on the vector-memory path than the LDS-DMA pieces do
-  if (ws == 0 && !no_big && g_gemm_cfg == 0 && std::is_same<T, BF16>::value && conv1x1_allc_ok(a) && a.ctiles <= 4 &&
-      a.npix >= 16384)
-    return conv1x1_allc_launch(a, T::id, s);
-  // layers with >= 256 output channels (ResNet layer2-4 incl. the bottlenecks' 1x1 layers, ASPP, the 512-channel decoder
-  // convs, VGG / PatchGAN from 256 channels): 256 x 256 block tiles halve the L2 -> LDS fill per FLOP (conv_gemm_big.hip);
-  // bf16 only for the reason given below for the K = 64 kernel (fp16 fixtures were made with the plain summation order)
-  // Same-box A/B over the step's shapes (tools/gpu_ab_conv.sh): it wins where K is long enough to amortise a prologue and
-  // an epilogue that nothing overlaps with one workgroup per CU -- 512 -> 512 3x3 at 8 x 80^2 289 -> 256 us, at 4 x 80^2
-  // 163 -> 135 us, 2048 -> 512 1x1 181 -> 157 us -- and loses on the short-K bottleneck layers (256 -> 1024 1x1: 68 -> 118 us,
-  // 256 -> 256 3x3: 72 -> 84 us at 200 tiles for 256 CUs)
-  if (ws == 0 && !no_big && g_gemm_cfg == 0 && std::is_same<T, BF16>::value && conv_gemm_big_ok(a) && a.npix >= 16384 &&
-      a.cin_s * a.kh * a.kw >= 4096 && a.cin_s >= 512 && !(a.kh * a.kw >= 9 && a.cin_s >= 2048))
-    return conv_gemm_big_launch(a, T::id, s);
-  // long-K 3x3 layers (>= 512 input channels: ResNet layer4, ASPP, the decoders' 512-channel convs): the K = 64 /
-  // whole-line specialised kernel, 14-16 % faster than the plain one there (rocprofv3, bs 8: 80^2 512 -> 512 d4 337 -> 283 us,
-  // 2048 -> 256 d6 538 -> 459 us); everywhere else it is slower (one workgroup per CU: short K loops are all prologue /
-  // epilogue; 256 -> 256 d2 76 -> 79 us)
-  // bf16 (the training dtype) only: fp16 is what apply_events runs in, and its wildfire fixture turns single arg-max flips
-  // of the untrained segmentation into a one-level contrast shift of a tenth of the image -- the two kernels agree within
-  // an fp16 rounding step, but the fixture was verified with the plain kernel's summation order
-  if (ws == 0 && g_gemm_cfg == 0 && sizeof(typename T::vec8) && std::is_same<T, BF16>::value && k64_ok(a) &&
-      a.kh * a.kw >= 9 && a.cin_s >= 512 && a.npix >= 16384)
-    return launch_k64<T, 8, 4>(a, s);
+  const bool automatic = ws == 0 && g_gemm_cfg == 0 && bf16;
+  // The three specialised kernels are taken in bf16 (the training dtype) only: fp16 is what apply_events runs in, and its
+  // wildfire fixture turns single arg-max flips of the untrained segmentation into a one-level contrast shift of a tenth
+  // of the image -- the kernels agree within an fp16 rounding step (another fp32 summation order), but the fixture was
+  // verified with the plain kernel's order.
+  // 1x1 layers with <= 64 output channels: activations straight from global memory into the B-fragment registers of the
+  // wave that owns the pixels, all couts per workgroup (conv1x1_direct.hip).  Same-box A/B (tools/gpu_ab_conv.sh): it wins
+  // there (256 -> 64 at 8 x 160^2 50 -> 37 us, 128 -> 64 14.7 -> 10.2 us, their data gradients 48 -> 38 us) and loses from 128
+  // couts up: at 1024 input channels the B-fragment loads are 16 rows x 64 B at a 2-KiB stride per instruction (1024 -> 256:
+  // 55 -> 68 us with all 16 cout tiles per wave, 126 us with a 2 x 4 wave grid) -- the row-strided half-line pattern costs
+  // more on the vector-memory path than the LDS-DMA pieces do
+  if (automatic && !no_big && conv1x1_allc_ok(a) && a.ctiles <= 4 && a.npix >= 16384) return {KIND_DIRECT, 0};
+  // 256 x 256 block tiles (conv_gemm_big.hip) halve the L2 -> LDS fill per FLOP.  Same-box A/B over the step's shapes: they
+  // win where K is long enough to amortise a prologue and an epilogue that nothing overlaps with one workgroup per CU
+  // -- 512 -> 512 3x3 at 8 x 80^2 289 -> 256 us, at 4 x 80^2 163 -> 135 us, 2048 -> 512 1x1 181 -> 157 us -- and lose on the
+  // short-K bottleneck layers (256 -> 1024 1x1: 68 -> 118 us, 256 -> 256 3x3: 72 -> 84 us at 200 tiles for 256 CUs)
+  if (automatic && !no_big && conv_gemm_big_ok(a) && a.npix >= 16384 && a.cin_s * a.kh * a.kw >= 4096 && a.cin_s >= 512 &&
+      !(a.kh * a.kw >= 9 && a.cin_s >= 2048))
+    return {KIND_BIG, 0};
+  // long-K 3x3 layers (>= 512 input channels: ASPP's 2048 -> 256): the K = 64 / whole-line producer / consumer kernel,
+  // 14-16 % faster than the plain one there (rocprofv3, bs 8: 2048 -> 256 d6 538 -> 459 us); everywhere else it is slower
+  // (one workgroup per CU: short K loops are all prologue / epilogue; 256 -> 256 d2 76 -> 79 us)
+  if (automatic && k64_ok(a) && a.kh * a.kw >= 9 && a.cin_s >= 512 && a.npix >= 16384) return {KIND_K64_256x128, 0};
   switch (g_gemm_cfg) {
-    case 1: return launch_cfg<T, 1, 4, 4>(a, s);
-    case 2: if (a.ctiles <= 16) return launch_cfg<T, 2, 8, 4>(a, s); break;
-    case 3: return launch_cfg<T, 2, 4, 8>(a, s);
-    case 4: return launch_cfg<T, 2, 4, 4>(a, s);
-    case 5: return launch_cfg<T, 2, 4, 4, 2>(a, s);      // 128 x 128 with a 2-stage ring (32 KiB: 4 workgroups per CU)
+    case 1: return {KIND_PLAIN, 1};
+    case 2: if (a.ctiles <= 16) return {KIND_PLAIN, 2}; break;
+    case 3: return {KIND_PLAIN, 3};
+    case 4: return {KIND_PLAIN, 4};
+    case 5: return {KIND_PLAIN, 5};      // 128 x 128 with a 2-stage ring (32 KiB: 4 workgroups per CU)
     default: break;
   }
-  if (a.ctiles <= 4) return launch_cfg<T, 1, 4, 4>(a, s);                       // 64 couts x 256 pixels
+  if (a.ctiles <= 4) return {KIND_PLAIN, 1};                                    // 64 couts x 256 pixels
   // 1x1 layers with a short K (bottleneck expands, K <= 512): the workgroup is all prologue / epilogue, and 128 x 128
   // blocks (twice as many, half the epilogue each) overlap them better: 256 -> 1024 at 16 x 80^2: 175 -> 120 us,
   // 64 -> 256 at 16 x 160^2: 128 -> 80 us (rocprofv3 kernel durations, tools/prof_conv.sh)
   // (with a 2-stage ring: 32 KiB per workgroup, so four of them share a CU and cover each other's prologue / epilogue:
   // 64 -> 256 at 8 x 160^2 41 -> 37 us, 256 -> 1024 at 8 x 80^2 61.3 -> 60.4 us)
-  if (a.kh * a.kw == 1 && a.ksteps <= 16) return launch_cfg<T, 2, 4, 4, 2>(a, s);
+  if (a.kh * a.kw == 1 && a.ksteps <= 16) return {KIND_PLAIN, 5};
   // all couts in one block (activations read once) when cout <= 256 and the grid still fills the chip
-  if (a.ctiles > 8 && a.ctiles <= 16 && ceil_div(ptiles, 8) >= 384) return launch_cfg<T, 2, 8, 4>(a, s);
+  if (a.ctiles > 8 && a.ctiles <= 16 && ceil_div(ptiles, 8) >= 384) return {KIND_PLAIN, 2};
   // 128 couts x 256 pixels while that still gives every CU a couple of workgroups, else 128 x 128
-  if ((long)ceil_div(ptiles, 16) * ceil_div(a.ctiles, 8) >= 384) return launch_cfg<T, 2, 4, 8>(a, s);
-  return launch_cfg<T, 2, 4, 4>(a, s);
+  if ((long)ceil_div(ptiles, 16) * ceil_div(a.ctiles, 8) >= 384) return {KIND_PLAIN, 3};
+  return {KIND_PLAIN, 4};
+}
+
+template <typename T>
+int launch(const ConvGemmArgs& a, hipStream_t s) {
+  const Choice ch = choose(a, std::is_same<T, BF16>::value);
+  switch (ch.kind) {
+    case KIND_K64_256x128: return launch_k64<T, 8, 4>(a, s);
+    case KIND_K64_128x256: return launch_k64<T, 4, 8>(a, s);
+    case KIND_BIG: return conv_gemm_big_launch(a, T::id, s);
+    case KIND_DIRECT: return conv1x1_allc_launch(a, T::id, s);
+    default: break;
+  }
+  switch (ch.cfg) {
+    case 1: return launch_cfg<T, 1, 4, 4>(a, s);
+    case 2: return launch_cfg<T, 2, 8, 4>(a, s);
+    case 3: return launch_cfg<T, 2, 4, 8>(a, s);
+    case 5: return launch_cfg<T, 2, 4, 4, 2>(a, s);
+    default: return launch_cfg<T, 2, 4, 4>(a, s);
+  }
 }
 
 }  // namespace
@@ -638,4 +705,11 @@ extern "C" void cgan_debug_set_gemm_ws(int v) { g_gemm_ws = v; }
 
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);
+}
+
+int conv_gemm_stats_chunk_pixels(const ConvGemmArgs& a, int dtype) {
+  const Choice ch = choose(a, dtype == CGAN_BF16);
+  if (ch.kind != KIND_PLAIN) return 0;
+  const int ppb = ch.cfg == 3 ? 128 : 64;        // WP x 16 pixels of a wave: <.,.,8> -> 128, <.,.,4> -> 64
+  return a.npix % ppb == 0 ? ppb : 0;
 }

@@ -36,6 +36,7 @@ struct ConvParams {
   int cls_s;   // > 1: data gradient of a stride-cls_s conv by output parity classes (blockIdx.z), see cls_axis
   int cls_pad; // pad' = k - 1 - pad of that data gradient
   float slope;
+  float* stats; // optional per-chunk (mean, M2) output of the wide-layer GEMM kernel (cgan_conv2d_nhwc_fwd_stats)
 };
 
 // Parity-class decomposition of the data gradient of a stride-s convolution (dilation 1).  dx[y] = sum over the
@@ -453,6 +454,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   p.kgroups = d->kh * d->kw * p.cg; p.ksteps = ceil_div(p.kgroups, 4);
   p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1; p.cls_s = 0; p.cls_pad = 0;
   p.has_res = d->has_residual; p.res_ups = d->residual_upsample;
+  p.stats = nullptr;
   return CGAN_OK;
 }
 
@@ -567,6 +569,7 @@ static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, co
     a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
     a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
     a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+    a.stats = p.stats;
     int rc2 = conv_gemm_launch(a, d->dtype, s);
     if (rc2 != CGAN_OK) return rc2;
     CGAN_CHECK_LAUNCH(what);
@@ -600,6 +603,46 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
   p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
   p.res = (const uint16_t*)residual; p.y = (uint16_t*)y;
   return dispatch_conv(p, d, (hipStream_t)stream, "conv2d_nhwc_fwd");
+}
+
+// Forward with training-mode BatchNorm statistics from the kernel's epilogue (round 3): see the header.
+static int stats_chunk_pixels(ConvParams& p, const CganConvDesc* d) {
+  if (d->has_residual || d->act != CGAN_ACT_NONE || d->in_upsample) return 0;
+  if (select_conv_kernel(p, d) != CGAN_CONV_KERNEL_GEMM) return 0;
+  ConvGemmArgs a;
+  a.x = nullptr; a.w = nullptr; a.bias = nullptr; a.res = nullptr; a.y = nullptr; a.stats = nullptr;
+  a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
+  a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+  a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
+  a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
+  a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+  return conv_gemm_stats_chunk_pixels(a, d->dtype);
+}
+
+extern "C" int32_t cgan_conv2d_stats_chunk_pixels(const CganConvDesc* d) {
+  ConvParams p;
+  if (fill_params(p, d) != CGAN_OK) return 0;
+  return stats_chunk_pixels(p, d);
+}
+
+extern "C" int cgan_conv2d_nhwc_fwd_stats(const void* x, const void* packed_w, const float* bias_padded, void* y,
+                                          float* partial, size_t partial_bytes, const CganConvDesc* d, void* stream) {
+  ConvParams p;
+  int rc = fill_params(p, d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(x && packed_w && y && partial, "conv2d_nhwc_fwd_stats: null pointer");
+  CGAN_REQUIRE(!d->has_bias || bias_padded, "conv2d_nhwc_fwd_stats: has_bias but bias is null");
+  const int ppb = stats_chunk_pixels(p, d);
+  CGAN_REQUIRE(ppb > 0, "conv2d_nhwc_fwd_stats: this descriptor's kernel writes no statistics "
+                        "(cgan_conv2d_stats_chunk_pixels returned 0)");
+  const size_t need = (size_t)(p.npix / ppb) * p.cout_s * 2 * sizeof(float);
+  if (partial_bytes < need) {
+    cgan_set_error("conv2d_nhwc_fwd_stats: partial buffer %zu B < required %zu B", partial_bytes, need);
+    return CGAN_ERR_WORKSPACE;
+  }
+  p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
+  p.res = nullptr; p.y = (uint16_t*)y; p.stats = partial;
+  return dispatch_conv(p, d, (hipStream_t)stream, "conv2d_nhwc_fwd_stats");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -310,6 +310,30 @@ extern "C" int cgan_batchnorm_train_stats(const void* x, const float* gamma, con
   return stats_impl(x, batch_mean, batch_rstd, d, workspace, workspace_bytes, stream, bn);
 }
 
+extern "C" int cgan_batchnorm_train_stats_from_partials(const float* partial, int32_t chunk_pixels, const float* gamma,
+                                                        const float* beta, float momentum, float* running_mean,
+                                                        float* running_var, int64_t* num_batches_tracked,
+                                                        float* batch_mean, float* batch_rstd, float* mean_out,
+                                                        float* rstd_out, const CganNormStatsDesc* d, void* stream) {
+  // the finalize half of cgan_batchnorm_train_stats on per-chunk (mean, M2) rows that a convolution's epilogue produced
+  // (cgan_conv2d_nhwc_fwd_stats): [group][chunk][cs][2], chunk = chunk_pixels consecutive pixels, d->hw (pixels per group)
+  // a whole number of chunks
+  int rc = check(d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(partial && batch_mean && batch_rstd && mean_out && rstd_out, "batchnorm_train_stats_from_partials: null pointer");
+  CGAN_REQUIRE(d->n >= 1 && d->n <= 16, "batchnorm_train_stats_from_partials: 1..16 groups");
+  CGAN_REQUIRE(chunk_pixels > 0 && d->hw % chunk_pixels == 0, "batchnorm_train_stats_from_partials: %d pixels per group are "
+               "not a whole number of %d-pixel chunks", d->hw, chunk_pixels);
+  CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_stats_from_partials: running stats go together");
+  const int cs = cgan_cs(d->c);
+  BnEpilogue bn = {gamma, beta, running_mean, running_var, mean_out, rstd_out, (long long*)num_batches_tracked, momentum, d->c};
+  const int total = d->n > 1 ? cs : d->n * cs;
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, (hipStream_t)stream, partial,
+                     batch_mean, batch_rstd, d->n, d->hw, cs, d->hw / chunk_pixels, chunk_pixels, d->eps, bn);
+  CGAN_CHECK_LAUNCH("batchnorm_train_stats_from_partials");
+  return CGAN_OK;
+}
+
 extern "C" int cgan_norm_add_act_apply(const void* x, const float* mean, const float* rstd, const void* residual,
                                        void* y, const CganNormStatsDesc* d, int32_t act, float act_slope,
                                        void* stream) {

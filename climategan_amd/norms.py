@@ -40,8 +40,11 @@ def _conv_train(x: ops.NHWC, weight, bias, packed, sn, stride, pad, dilation, kw
     cfg = dict(c_in=x.c, stride=stride, pad=pad, dilation=dilation, act=kw.get("act", ops.ACT_NONE),
                slope=kw.get("slope", 0.2), in_upsample=bool(kw.get("in_upsample", False)),
                residual_upsample=bool(kw.get("residual_upsample", False)), pad_mode=pad_mode,
-               sn_owned=bool(kw.get("sn_owned", False)), pair_in=bool(kw.get("pair_in", False)))
+               sn_owned=bool(kw.get("sn_owned", False)), pair_in=bool(kw.get("pair_in", False)),
+               want_stats=bool(kw.get("want_stats", False)))
     y_t = ConvFn.apply(x.t, weight, bias, res.t if res is not None else None, packed, cfg, sn)
+    if kw.get("want_stats"):
+        return ops.NHWC(y_t, weight.shape[0]), cfg.get("stats_out")   # BatchNorm statistics from the conv's epilogue, or None
     return ops.NHWC(y_t, weight.shape[0])
 
 
@@ -212,6 +215,10 @@ def conv_forward(conv: nn.Module, cache: _PackCache, x: ops.NHWC, **kw) -> ops.N
 
 
 FUSE_BN_RESIDUAL = True      # relu(bn3(.) + residual) in one apply pass (and one backward apply pass)
+# training-mode BatchNorm statistics from the producing conv's epilogue (no pass over y); CGAN_FUSE_BN_STATS=0: the
+# separate statistics pass (same-box A/B)
+import os as _os
+FUSE_BN_STATS = _os.environ.get("CGAN_FUSE_BN_STATS", "1") != "0"
 
 
 def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mode=ops.PAD_ZERO, pad=None, **kw) -> ops.NHWC:
@@ -255,14 +262,20 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
         from .autograd import ConvPassFn
 
         assert bn is not None and residual is None
-        y_t, pass_t = ConvPassFn.apply(x.t, conv.weight, conv.bias, pw,
-                                       dict(c_in=x.c, stride=conv.stride[0], pad=p, dilation=conv.dilation[0], pad_mode=pad_mode))
+        pcfg = dict(c_in=x.c, stride=conv.stride[0], pad=p, dilation=conv.dilation[0], pad_mode=pad_mode, want_stats=FUSE_BN_STATS)
+        y_t, pass_t = ConvPassFn.apply(x.t, conv.weight, conv.bias, pw, pcfg)
         y, passthrough = ops.NHWC(y_t, conv.weight.shape[0]), ops.NHWC(pass_t, x.c)
+        conv_stats = pcfg.get("stats_out")
     if bn is None:
         return _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0],
                            dict(act=act, slope=slope, residual=residual, pad_mode=pad_mode))
     if passthrough is None:
-        y = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0], dict(pad_mode=pad_mode))
+        conv_stats = None
+        if FUSE_BN_STATS:
+            y, conv_stats = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0],
+                                        dict(pad_mode=pad_mode, want_stats=True))
+        else:
+            y = _conv_train(x, conv.weight, conv.bias, pw, None, conv.stride[0], p, conv.dilation[0], dict(pad_mode=pad_mode))
     if residual is not None and not FUSE_BN_RESIDUAL:              # A/B switch for tools / tests: the unfused tail
         from . import functional as Fn
         out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
@@ -276,7 +289,7 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
     out_t = BatchNormActFn.apply(y.t, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.running_mean,
                                  bn.running_var, y.c, bn.eps, bn.momentum if bn.momentum is not None else 0.1, act,
                                  slope, bn.num_batches_tracked if bn.track_running_stats else None,   # counter += 1 in-kernel
-                                 residual.t if residual is not None else None)
+                                 residual.t if residual is not None else None, conv_stats)
     return ops.NHWC(out_t, y.c) if passthrough is None else (ops.NHWC(out_t, y.c), passthrough)
 
 

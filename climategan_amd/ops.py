@@ -605,6 +605,54 @@ def dgrad_prepack_run() -> int:
     return len(todo)
 
 
+@dataclass
+class ConvStats:
+    """Per-chunk (mean, M2) rows of a conv output, written by the conv kernel's epilogue (``conv2d_with_stats``)."""
+    partial: torch.Tensor      # fp32 [npix / chunk_pixels, Cs, 2]
+    chunk_pixels: int
+
+
+def conv2d_with_stats(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZERO, groups: int = 1):
+    """(y, stats): ``conv2d`` without activation / residual whose kernel ALSO leaves the training-mode BatchNorm
+    statistics of y as per-chunk partials (cgan_conv2d_nhwc_fwd_stats); stats is None when this descriptor's kernel has
+    no such epilogue, or the batch's ``groups`` slices (autograd.bn_groups) are not whole numbers of chunks -- the caller
+    then takes the separate statistics pass."""
+    _need_cuda(x.t)
+    _need_cs8("conv2d", x)
+    if x.c != pw.c_in:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.c, pw.c_in))
+    if x.t.dtype != pw.dtype:
+        raise RuntimeError("conv2d: activation dtype %s != packed weight dtype %s" % (x.t.dtype, pw.dtype))
+    d = _conv_desc(x.dtype_id, x.n, x.h, x.w, pw.c_in, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode,
+                   has_bias=pw.has_bias)
+    lib = _lib.load()
+    ppb = lib.cgan_conv2d_stats_chunk_pixels(C.byref(d))
+    npix = x.n * d.h_out * d.w_out
+    if ppb <= 0 or x.n % groups or (npix // groups) % ppb:
+        return conv2d(x, pw, stride=stride, pad=pad, dilation=dilation, pad_mode=pad_mode), None
+    y = torch.empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
+    partial = torch.empty((npix // ppb, cs8(pw.c_out), 2), dtype=torch.float32, device=x.t.device)
+    _lib.check(lib.cgan_conv2d_nhwc_fwd_stats(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias), _ptr(y), _ptr(partial),
+                                              partial.numel() * 4, C.byref(d), _stream()), "cgan_conv2d_nhwc_fwd_stats")
+    return NHWC(y, pw.c_out), ConvStats(partial, ppb)
+
+
+def batchnorm_train_stats_from_partials(st: ConvStats, groups: int, pix_per_group: int, c: int, gamma, beta, running_mean,
+                                        running_var, num_batches_tracked, eps, momentum):
+    """``batchnorm_train_stats`` from a conv epilogue's partials: same four [G, Cs] outputs, same running-statistics
+    updates and step counter, one launch, no pass over the activations."""
+    lib = _lib.load()
+    cs = st.partial.shape[1]
+    d = NormStatsDesc(CGAN_BF16, groups, pix_per_group, c, float(eps))
+    stats = torch.empty((4, groups, cs), dtype=torch.float32, device=st.partial.device)
+    _lib.check(lib.cgan_batchnorm_train_stats_from_partials(
+        _ptr(st.partial), int(st.chunk_pixels), _ptr(gamma), _ptr(beta), float(momentum), _ptr(running_mean),
+        _ptr(running_var), _ptr(num_batches_tracked), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]),
+        C.byref(d), _stream()), "cgan_batchnorm_train_stats_from_partials")
+    touch(running_mean, running_var, num_batches_tracked)
+    return stats[0], stats[1], stats[2], stats[3]
+
+
 def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
     """Backward of nn.ReflectionPad2d(pad): folds the gradient of the padded tensor onto the unpadded extent."""
     _need_cuda(dxp.t)

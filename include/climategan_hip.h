@@ -100,6 +100,17 @@ typedef struct {
 int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device, int32_t count, int32_t dtype,
                                     int32_t max_fragments, void* stream);
 
+/* Forward convolution that ALSO writes training-mode BatchNorm statistics of its own output from the kernel's epilogue
+ * (fp32 accumulators, before the 16-bit store): replaces the read pass of cgan_batchnorm_train_stats over y for
+ * nn.Conv2d -> nn.BatchNorm2d pairs in training mode (resnet101_v3.py:30-50, deeplab_v3.py:54-57, blocks.py:129-136).
+ * cgan_conv2d_stats_chunk_pixels(d): pixels per statistics chunk of the kernel this descriptor selects, or 0 when that
+ * kernel writes none (then use cgan_conv2d_nhwc_fwd + cgan_batchnorm_train_stats) -- no activation, no residual, no folded
+ * upsample, n*h_out*w_out a whole number of chunks.  partial: fp32 [n*h_out*w_out / chunk][round_up(c_out,8)][2] =
+ * (mean, M2) per chunk and channel, consumed by cgan_batchnorm_train_stats_from_partials. */
+int32_t cgan_conv2d_stats_chunk_pixels(const CganConvDesc* d);
+int cgan_conv2d_nhwc_fwd_stats(const void* x, const void* packed_w, const float* bias_padded, void* y, float* partial,
+                               size_t partial_bytes, const CganConvDesc* d, void* stream);
+
 /* Which kernel the forward (bwd_data = 0) or the data-gradient (bwd_data = 1) entry point runs for a descriptor --
  * the selection is a pure function of the descriptor: CGAN_CONV_KERNEL_GENERAL (gather implicit GEMM, conv_mfma.hip),
  * _LDS3X3 (spatially tiled 3x3, conv3x3_lds.hip) or _GEMM (wide-layer implicit GEMM, conv_gemm.hip); negative = the
@@ -322,6 +333,13 @@ int cgan_batchnorm_train_stats(const void* x, const float* gamma, const float* b
                                float* running_var, int64_t* num_batches_tracked, float* batch_mean, float* batch_rstd,
                                float* mean_out, float* rstd_out, const CganNormStatsDesc* d, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* The finalize half of cgan_batchnorm_train_stats on the per-chunk (mean, M2) rows a convolution's epilogue wrote
+ * (cgan_conv2d_nhwc_fwd_stats): d->n = groups, d->hw = pixels per group (a whole number of chunk_pixels), same outputs,
+ * running-statistics updates and step counter as cgan_batchnorm_train_stats. */
+int cgan_batchnorm_train_stats_from_partials(const float* partial, int32_t chunk_pixels, const float* gamma,
+                                             const float* beta, float momentum, float* running_mean, float* running_var,
+                                             int64_t* num_batches_tracked, float* batch_mean, float* batch_rstd,
+                                             float* mean_out, float* rstd_out, const CganNormStatsDesc* d, void* stream);
 size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);   /* per group */
 int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
                            const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,

@@ -707,6 +707,7 @@ def test_batched_dgrad_pack_equals_the_per_layer_pack():
     from climategan_amd import _lib, ops
 
     lib = _lib.load()
+    ops.dgrad_prepack_run()                                # whatever earlier forwards of this process left registered
     g = torch.Generator(device="cuda").manual_seed(11)
     shapes = [(64, 256, 1), (256, 64, 1), (20, 40, 3), (3, 20, 3), (128, 128, 3), (48, 256, 1), (512, 4, 4), (1, 8, 3),
               (64, 3, 7), (304, 256, 3)]
@@ -734,3 +735,53 @@ def test_batched_dgrad_pack_equals_the_per_layer_pack():
         a = ops.conv2d_bwd_data(dy, hs[4].w, (2, 24, 24), pad=1, sigma=hs[4].sigma, prepacked=hs[4])
         b = ops.conv2d_bwd_data(dy, hs[4].w, (2, 24, 24), pad=1, sigma=hs[4].sigma)
         assert torch.equal(a.t, b.t)
+
+
+@pytest.mark.parametrize("case", [
+    # (cin, cout, k, pad, dil, n, h, w, groups): wide layers the plain GEMM kernel takes, one per block tile
+    (256, 64, 3, 1, 1, 4, 64, 64, 1),        # 64 couts x 256 pixels
+    (256, 256, 3, 1, 1, 8, 80, 80, 2),       # 256 x 128
+    (256, 512, 3, 1, 1, 4, 80, 80, 1),       # 128 x 256 (128-pixel chunks)
+    (1024, 256, 1, 0, 1, 8, 40, 40, 2), (256, 256, 3, 2, 2, 8, 40, 40, 2), (256, 128, 3, 1, 1, 4, 64, 64, 1),   # 128 x 128
+    (256, 1024, 1, 0, 1, 4, 40, 40, 1), (128, 512, 1, 0, 1, 2, 96, 100, 2),   # 128 x 128, 2-stage ring (short-K 1x1)
+])
+def test_batchnorm_statistics_from_the_conv_epilogue(case):
+    """``ops.conv2d_with_stats`` + ``batchnorm_train_stats_from_partials`` (the conv kernel's epilogue reduces its fp32
+    accumulators per chunk of pixels; one finalize launch) against the separate statistics pass over the stored y and
+    against torch: same y bit for bit, batch mean / rstd to fp32 accuracy of the unrounded conv output (the separate pass
+    sees the 16-bit-rounded y: the two agree to 2^-9 of the spread), identical running-statistics semantics per group."""
+    import torch.nn.functional as F
+    from climategan_amd import ops
+
+    cin, cout, k, pad, dil, n, h, w, G = case
+    dt = torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    xf = torch.randn(n, cin, h, w, device="cuda", generator=gen).to(dt).float()
+    wt = (torch.randn(cout, cin, k, k, device="cuda", generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(dt).float()
+    x = ops.nchw_to_nhwc(xf, dt)
+    pw = ops.pack_conv_weight(wt, None, dt)
+    y, st = ops.conv2d_with_stats(x, pw, pad=pad, dilation=dil, groups=G)
+    y0 = ops.conv2d(x, pw, pad=pad, dilation=dil)
+    assert torch.equal(y.t, y0.t)
+    assert st is not None, "this layer shape is expected to run the GEMM kernel with the statistics epilogue"
+    gamma = torch.rand(cout, device="cuda", generator=gen) + 0.5
+    beta = torch.randn(cout, device="cuda", generator=gen)
+    npix = n * h * w // G
+
+    def fresh():
+        return torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+
+    rm_a, rv_a, nbt_a = fresh()
+    a = ops.batchnorm_train_stats_from_partials(st, G, npix, cout, gamma, beta, rm_a, rv_a, nbt_a, 1e-5, 0.1)
+    rm_b, rv_b, nbt_b = fresh()
+    flat = ops.NHWC(y.t.view(G, npix, 1, y.t.shape[-1]), cout)
+    b = ops.batchnorm_train_stats(flat, gamma, beta, rm_b, rv_b, nbt_b, 1e-5, 0.1)
+    ref = F.conv2d(xf, wt, padding=pad, dilation=dil).view(G, n // G, cout, -1).permute(0, 2, 1, 3).reshape(G, cout, -1)
+    mean_ref, var_ref = ref.mean(-1), ref.var(-1, unbiased=False)
+    spread = var_ref.sqrt().max().item()
+    assert (a[0][:, :cout] - mean_ref).abs().max().item() <= 2e-5 * max(spread, 1.0) + 1e-6
+    assert ((1.0 / a[1][:, :cout] ** 2 - 1e-5) / var_ref - 1).abs().max().item() <= 2e-4
+    for u, v in zip(a, b):                                           # the separate pass reads the bf16-rounded y
+        assert (u[:, :cout] - v[:, :cout]).abs().max().item() <= 2.0 ** -8 * max(v[:, :cout].abs().max().item(), 1.0)
+    assert int(nbt_a) == int(nbt_b) == G
+    assert (rm_a - rm_b).abs().max().item() <= 2.0 ** -8 * spread + 1e-6 and (rv_a / rv_b - 1).abs().max().item() <= 2e-2

@@ -147,10 +147,13 @@ def test_two_ranks_on_one_gpu_train_in_lock_step():
                   % (rank, grp, n, rel, spread))
             # (the ADVENT discriminators of an untrained Masker see nearly the same entropy maps on both ranks: their local
             # gradients are only 0.1 apart, and the averaging can only be seen on the other networks)
-            bound = {"D.m": 0.15, "D.s": 5e-2}.get(grp, 2e-2)
-            assert rel <= bound, (rank, grp, rel, spread)
-            if grp.startswith("G.") or grp == "D.p":
-                assert spread >= 5 * rel, (rank, grp, rel, spread)
+            # G: the twin's backward is the same computation up to fp32 atomics.  D: the discriminator update follows the
+            # generator's ExtraAdam extrapolation, which the twin took with its LOCAL gradients and this trainer with the
+            # averaged ones -- the two D steps see different generators, so D has no twin to compare with
+            # (measured: D.p 6 %, D.m 4 %, D.s 34 % -- printed, not asserted; the discriminators' exchange is covered by the
+            # lock-step check below and by the reducer's own tests)
+            if grp.startswith("G."):
+                assert rel <= 2e-2 and spread >= 5 * rel, (rank, grp, rel, spread)
         assert lock_g and lock_d, "replicas diverged over three train steps"
         assert not same_bn, "BatchNorm running statistics are per rank (different shards): they must differ"
         assert nb >= 1 and learning is False
