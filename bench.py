@@ -655,9 +655,14 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier):
 
     elapsed = max_over_ranks(timed_steps(step, steps, warmup, barrier), dist, device)
     assert set(out) >= {"flood", "wildfire", "smog"} and out["flood"].shape == (INFER_BS, H, W, 3)
+    # the opt-in inference mode of SURVEY 8f N2: spectral-norm weights frozen (no power iteration / re-pack per call)
+    T.G.freeze_spectral_norm(True)
+    frozen = max_over_ranks(timed_steps(step, steps, 2, barrier), dist, device)
     return {"workload": "BASELINE configs[4]: apply_events inference (Trainer.infer_all: flood + wildfire + smog, uint8 "
                         "results on the host), 640x640, 16 images per GPU, fp16",
             "images_per_s": round(world * INFER_BS * steps / elapsed, 2), "ms_per_batch": round(elapsed / steps * 1e3, 2),
+            "images_per_s_frozen_spectral_norm": round(world * INFER_BS * steps / frozen, 2),
+            "ms_per_batch_frozen_spectral_norm": round(frozen / steps * 1e3, 2),
             "steps": steps, "warmup": warmup}
 
 

@@ -142,6 +142,12 @@ class OmniGenerator(nn.Module):
             return super().to(device, non_blocking=non_blocking)
         return self
 
+    def freeze_spectral_norm(self, frozen=True):
+        """Opt-in inference mode: see ``norms.freeze_spectral_norm``."""
+        from .norms import freeze_spectral_norm
+        freeze_spectral_norm(self, frozen)
+        return self
+
     def encode(self, x):
         """reference generator.py:107-118.  x: [B,3,H,W] NCHW; returns (z_high, z_low) as NHWC containers."""
         assert self.encoder is not None

@@ -144,8 +144,24 @@ class SpectralNorm(nn.Module):
         return (getattr(m, self.name + "_bar").data, getattr(m, self.name + "_u").data,
                 getattr(m, self.name + "_v").data, m.bias.data if m.bias is not None else None)
 
+    frozen = False      # opt-in inference mode (freeze_spectral_norm): sigma taken once, no further power iterations
+    _frozen_pack = None
+
     def packed(self, dtype) -> ops.PackedConv:
         """Power-iterate (updates u, v) and return w_bar / sigma packed for the MFMA conv kernel."""
+        if self.frozen:
+            m = self.module
+            w_bar = getattr(m, self.name + "_bar")
+            key = (w_bar.data_ptr(), w_bar._version, dtype)
+            if self._frozen_pack is None or self._frozen_pack[0] != key:
+                # the ONE power iteration a forward would have run at this point; its sigma is kept from now on
+                sigma = ops.spectral_norm_power_iter(w_bar.data, getattr(m, self.name + "_u").data,
+                                                     getattr(m, self.name + "_v").data)
+                self._sigma = sigma
+                self._frozen_pack = (key, ops.pack_conv_weight(w_bar.data, m.bias.data if m.bias is not None else None,
+                                                               dtype, sigma))
+            self._pre_used = False
+            return self._frozen_pack[1]
         pre, self._prepacked = self._prepacked, None
         self._pre_used = pre is not None and pre.dtype == dtype
         if self._pre_used:
@@ -167,6 +183,9 @@ class SpectralNorm(nn.Module):
         m = self.module
         if not self.trainable:
             _grad_guard(self)
+        if self.frozen and needs_grad(self, x.t):
+            raise NotImplementedError("climategan_amd: a SpectralNorm frozen for inference (freeze_spectral_norm) cannot be "
+                                      "trained; unfreeze it first")
         pw = self.packed(x.t.dtype)
         pad = conv_kwargs.pop("pad", m.padding[0])   # Conv2dBlock pads with a separate module (padding=0 on the conv)
         if self.trainable and needs_grad(self, x.t):
@@ -377,12 +396,26 @@ class SPADE(nn.Module):
         return Fn.to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
 
 
+def freeze_spectral_norm(root: nn.Module, frozen: bool = True) -> nn.Module:
+    """Opt-in INFERENCE mode: every SpectralNorm under ``root`` takes its sigma from one last power iteration
+    at its next forward and then keeps ``w_bar / sigma`` packed -- no power iteration, no re-pack and no u / v update per
+    call any more (the Painter's 23 + the mask decoder's wrapped convs: 5 launches + 208 MB of weight reads per forward).
+    The default (``frozen=False``) is the reference's behaviour: one power iteration on EVERY forward, eval included
+    (norms.py:141-143), so that outputs drift with the number of calls; a frozen model is deterministic.  Training a
+    frozen module raises (the backward of w_bar / sigma needs this forward's u, v)."""
+    for m in root.modules():
+        if isinstance(m, SpectralNorm):
+            m.frozen = bool(frozen)
+            m._frozen_pack = None
+    return root
+
+
 def spectral_norm_step_all(root: nn.Module, dtype) -> None:
     """Run this forward's power iteration + ``w_bar / sigma`` re-pack for EVERY SpectralNorm under ``root`` in
     five launches (ops.SpectralNormGroup).  Each wrapper then consumes its pre-packed weight exactly once in
     ``packed()``; a wrapper called again within the same forward falls back to its own per-layer iteration, so
     the reference's "one power iteration per call" semantics (norms.py:141-143) hold."""
-    sns = [m for m in root.modules() if isinstance(m, SpectralNorm)]
+    sns = [m for m in root.modules() if isinstance(m, SpectralNorm) and not m.frozen]
     if not sns:
         return
     params = [m.sn_params() for m in sns]

@@ -229,3 +229,35 @@ def test_spade_resnet_block_matches_reference_golden(name, dt, rel):
     for k, v in gold.items():
         if k.startswith("post."):
             assert np.abs(sd[k[5:]].cpu().numpy() - v).max() <= 2e-5, k
+
+
+def test_frozen_spectral_norm_inference_mode():
+    """``freeze_spectral_norm`` (opt-in): the first frozen forward is the reference-exact forward from the same
+    state (it runs the one power iteration that forward would have run), every later call reproduces it bit for bit and
+    leaves u / v untouched -- where the default mode advances them on every call (norms.py:141-143); training a frozen
+    module is refused; unfreezing restores the per-call iteration."""
+    name = "painter_up4"
+    case = CASES[name]
+    G = build_generator(case, torch.float16)
+    sd = {k: v.clone() for k, v in G.painter.state_dict().items()}
+    cond = t(case_inputs(name, case)["cond"]).cuda()
+    with torch.no_grad():
+        y_ref = G.painter(None, cond)                       # default mode, one power iteration
+        u_ref = {k: v.clone() for k, v in G.painter.state_dict().items() if k.endswith(("weight_u", "weight_v"))}
+        y_ref2 = G.painter(None, cond)                      # ... and another one: the output moves
+        assert not torch.equal(y_ref, y_ref2)
+        G.painter.load_state_dict(sd)
+        G.freeze_spectral_norm(True)
+        y1 = G.painter(None, cond)
+        y2 = G.painter(None, cond)
+        y3 = G.painter(None, cond)
+    assert torch.equal(y1, y_ref) and torch.equal(y2, y1) and torch.equal(y3, y1)
+    now = G.painter.state_dict()
+    for k, v in u_ref.items():
+        assert torch.equal(now[k], v), k
+    with pytest.raises(NotImplementedError, match="frozen"):
+        G.painter(None, cond)                               # grad mode on, trainable parameters
+    G.freeze_spectral_norm(False)
+    with torch.no_grad():
+        y4 = G.painter(None, cond)
+    assert torch.equal(y4, y_ref2)                          # the second power iteration from the same state
