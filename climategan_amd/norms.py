@@ -82,6 +82,16 @@ class _PackCache:
             return self.value
         self._plain_src = (weakref.ref(weight), weakref.ref(bias) if bias is not None else None, dtype)
         _PackCache._plain[id(self)] = weakref.ref(self)
+        _PackCache.repack_stale(dtype, weight.device)
+        return self.value
+
+    @staticmethod
+    def repack_stale(dtype, device) -> int:
+        """Re-pack, in one batched launch on the current stream, every registered plain-conv cache of ``device`` / ``dtype``
+        whose parameters changed since it was filled (an optimizer step makes all of them stale at once).  The trainer
+        calls it before it forks the Masker and the Painter branches of an update onto two streams: no cache is then
+        touched while both branches run."""
+        self = _PackCache
         stale = []
         for cid, ref in list(_PackCache._plain.items()):
             c = ref()
@@ -91,7 +101,7 @@ class _PackCache:
                 del _PackCache._plain[cid]
                 continue
             b = src[1]() if src[1] is not None else None
-            if src[2] != dtype or w.device != weight.device:
+            if src[2] != dtype or w.device != device:
                 continue
             k = self._key_of((w, b, "plain"), dtype)
             if k != c.key:
@@ -105,7 +115,7 @@ class _PackCache:
                                                reuse)
         for (c, _, _, k), pk in zip(stale, packed):
             c.value, c.key = pk, k
-        return self.value
+        return len(stale)
 
 
 class SpectralNorm(nn.Module):

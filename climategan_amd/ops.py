@@ -574,8 +574,10 @@ def dgrad_register(w: torch.Tensor, sigma, dtype, stride: int) -> Optional[Dgrad
     return h
 
 
-def dgrad_prepack_run() -> int:
-    """Pack every registered, not yet packed operator (one launch per 16-bit type) and forget the list."""
+def dgrad_prepack_run(also_used_on=None) -> int:
+    """Pack every registered, not yet packed operator (one launch per 16-bit type) and forget the list.  ``also_used_on``:
+    a second stream whose kernels will read the packed buffers (the trainer's side stream): the caching allocator is told,
+    so that a buffer released by the backward is not handed out again while that stream still reads it."""
     todo = [h for h in _DGRAD_PENDING if h.packed is None]
     del _DGRAD_PENDING[:]
     lib = _lib.load()
@@ -600,7 +602,10 @@ def dgrad_prepack_run() -> int:
         table = host.to(dev, non_blocking=True)
         _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(table), len(hs), _DT[dtype], max_frag, _stream()),
                    "cgan_conv2d_pack_weight_batched")
-        _PACK_TABLES.append((host, table, hs))
+        if also_used_on is not None:
+            for h in hs:
+                h.packed.record_stream(also_used_on)
+        _PACK_TABLES.append((host, table, [(h.w, h.sigma) for h in hs]))   # the launch's sources, not its outputs
         del _PACK_TABLES[:-8]
     return len(todo)
 

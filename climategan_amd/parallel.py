@@ -81,6 +81,9 @@ class GradBucketReducer:
         if cur:
             self.buckets.append(_Bucket(cur))
         self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        # streams on which gradients of these parameters are produced besides the one a hook happens to run on (the
+        # trainer issues the Masker and the Painter branch of a backward on two streams): a bucket's gather waits for them
+        self.streams = []
         if self.active and dist.get_rank() == 0:
             print("GradBucketReducer: %d parameters, %.1f MB in %d buckets, %s on the wire, %d ranks over %s"
                   % (len(self.params), sum(p.numel() for p in self.params) * torch.finfo(grad_dtype).bits / 8e6,
@@ -111,6 +114,11 @@ class GradBucketReducer:
 
     def _launch(self, b: _Bucket):
         grads = [p.grad for p in b.params]
+        if self.streams and grads[0].is_cuda:
+            cur = torch.cuda.current_stream(grads[0].device)
+            for st in self.streams:
+                if st != cur:
+                    cur.wait_stream(st)
         # multi-tensor copies (a handful of launches per bucket instead of one per parameter: 1500 parameters)
         torch._foreach_copy_(self._views(b, grads), grads)
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)

@@ -72,6 +72,12 @@ class Trainer:
         # the real and the simulated domain batch share the Masker's encoder / depth / segmentation launches (grouped
         # BatchNorm keeps the per-domain statistics of the reference's separate calls); False = one pass per domain
         self.merge_domains = True
+        # the Masker branch and the Painter branch of an update (disjoint parameters, independent until the optimizer
+        # step) are issued on two HIP streams: the tail of one kernel overlaps the head of the other branch's next one
+        # instead of every launch draining the chip on its own (CGAN_OVERLAP=0: one stream, same-box A/B)
+        import os
+        self.overlap_branches = os.environ.get("CGAN_OVERLAP", "1") != "0"
+        self._side = None
 
     def setup(self, inference=False):
         """reference trainer.py:701-789."""
@@ -460,15 +466,30 @@ class Trainer:
         try:
             self.g_opt.zero_grad(set_to_none=True)
             g_loss = 0                                                  # get_G_loss, trainer.py:1162-1182
-            if self.has_masker and any(d != "rf" for d in multi_domain_batch):
-                g_loss = g_loss + self.get_masker_loss(multi_domain_batch)
-            if self.has_painter and "rf" in multi_domain_batch:
-                g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
+            do_m = self.has_masker and any(d != "rf" for d in multi_domain_batch)
+            do_p = self.has_painter and "rf" in multi_domain_batch
+            side = self._fork(self.G.compute_dtype) if (do_m and do_p and not self.use_pl4m) else None
+            if side is not None:
+                with torch.cuda.stream(side):
+                    p_loss = self.get_painter_loss(multi_domain_batch)
+                m_loss = self.get_masker_loss(multi_domain_batch)
+                if not (isinstance(p_loss, torch.Tensor) and isinstance(m_loss, torch.Tensor)):
+                    side = self._join(side)
+                    g_loss = m_loss + p_loss
+                else:
+                    self._backward([m_loss, p_loss], self.G, side)
+                    g_loss = m_loss.detach() + p_loss.detach()
+            else:
+                if do_m:
+                    g_loss = g_loss + self.get_masker_loss(multi_domain_batch)
+                if do_p:
+                    g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
             if not isinstance(g_loss, torch.Tensor):
                 # every term switched off (all lambdas 0): the reference would fail on ``int.backward()``; nothing to
                 # differentiate and nothing for the optimizer to do
                 return torch.zeros((), device=self.device)
-            self._backward(g_loss, self.G)
+            if side is None:
+                self._backward(g_loss, self.G)
             if self.g_reducer is not None:
                 self.g_reducer.finish()                                 # before extrapolation AND step (trainer.py:678-683)
             self._unscale_grads(self.G)
@@ -480,9 +501,32 @@ class Trainer:
             self._restore_d_grad_flags()                                # trainer.py:971-973
         return g_loss.detach()
 
-    def _backward(self, loss, module):
+    def _fork(self, dtype):
+        """The side stream for one branch of an update, or None (overlap off / no device).  Everything both branches share
+        is brought up to date on the calling stream first: the packed forms of the plain conv weights an optimizer step
+        made stale (norms._PackCache: one batched launch that would otherwise be triggered by whichever branch gets there
+        first, on ITS stream, while the other may be reading the buffers)."""
+        if not self.overlap_branches or self.device.type != "cuda":
+            return None
+        from .norms import _PackCache
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            for red in (self.g_reducer, self.d_reducer):           # gradients now come from two streams
+                if red is not None:
+                    red.streams = [torch.cuda.current_stream(self.device), self._side]
+        _PackCache.repack_stale(dtype, self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        return self._side
+
+    def _join(self, side):
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return None
+
+    def _backward(self, loss, module, side=None):
         """``loss.backward()`` with the weight-gradient outputs of ``module`` carved from ONE zero-filled arena
-        (ops.ZeroArena) instead of a fill launch per layer."""
+        (ops.ZeroArena) instead of a fill launch per layer.  ``loss`` may be a list of independent losses whose graphs
+        were recorded on two streams (``side``: the second one): autograd runs every node's backward on its forward's
+        stream, so the two branches' kernels interleave on the device."""
         key = "_arena_numel_%d" % id(module)
         n = getattr(self, key, None)
         if n is None:
@@ -491,8 +535,13 @@ class Trainer:
         dev = next(module.parameters()).device
         prev = ops.set_zero_arena(ops.ZeroArena(n, dev))
         try:
-            ops.dgrad_prepack_run()          # every stride-1 data-gradient operator of this backward, one pack launch
-            loss.backward()
+            ops.dgrad_prepack_run(side)      # every stride-1 data-gradient operator of this backward, one pack launch
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))        # the arena's zeros, the packed operators
+                torch.autograd.backward(list(loss))
+                torch.cuda.current_stream(dev).wait_stream(side)        # the optimizer runs on the calling stream
+            else:
+                loss.backward()
         finally:
             ops.set_zero_arena(prev)
 
@@ -518,13 +567,28 @@ class Trainer:
         self._check_batch(multi_domain_batch)
         self.d_opt.zero_grad(set_to_none=True)
         d_loss = 0
-        if self.has_painter and "rf" in multi_domain_batch:
-            d_loss = d_loss + self.get_D_loss(multi_domain_batch)
-        if self.has_masker and any(d != "rf" for d in multi_domain_batch):
-            d_loss = d_loss + self.get_masker_d_loss(multi_domain_batch)
+        do_p = self.has_painter and "rf" in multi_domain_batch
+        do_m = self.has_masker and any(d != "rf" for d in multi_domain_batch)
+        side = self._fork(self.G.compute_dtype) if (do_m and do_p) else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                p_loss = self.get_D_loss(multi_domain_batch)
+            m_loss = self.get_masker_d_loss(multi_domain_batch)
+            if isinstance(m_loss, torch.Tensor) and isinstance(p_loss, torch.Tensor):
+                self._backward([m_loss, p_loss], self.D, side)
+                d_loss = m_loss.detach() + p_loss.detach()
+            else:
+                side = self._join(side)
+                d_loss = m_loss + p_loss
+        else:
+            if do_p:
+                d_loss = d_loss + self.get_D_loss(multi_domain_batch)
+            if do_m:
+                d_loss = d_loss + self.get_masker_d_loss(multi_domain_batch)
         if not isinstance(d_loss, torch.Tensor):     # no discriminator term is active (use_advent off, no Painter)
             return torch.zeros((), device=self.device)
-        self._backward(d_loss, self.D)
+        if side is None:
+            self._backward(d_loss, self.D)
         if self.d_reducer is not None:
             self.d_reducer.finish()
         self._unscale_grads(self.D)
