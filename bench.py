@@ -51,7 +51,7 @@ LATENT = 640
 N_UP = 7
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md chip table
 HBM_PEAK_BYTES = 8.0e12    # HBM3E peak, same table
-EVENT_EVERY = 4            # timed steps between two steps whose launches are bracketed by events (see main)
+EVENT_EVERY = 10           # timed steps between two steps whose launches are bracketed by events (see main)
 WELL_CONDITIONED = dict(gain=1.0, res_gamma=0.05)   # the fill of the 640x640 parity fixtures (tests/test_gpu_configs_640.py)
 
 
@@ -726,13 +726,18 @@ def main():
     timer = LaunchTimer()
     uninstall = (lambda: None) if args.no_launch_events else install_conv_gemm_timer(timer)
 
-    # The launch brackets (two events per launch, 890 per step) cost 1.7-2.6 ms of a 137 ms step when every timed step
-    # carries them: they go on every EVENT_EVERY-th timed step (the first, fifth, ...), inside the timed region all the same.
+    # The launch brackets (two events per launch, 890 per step) go on every EVENT_EVERY-th timed step (the first, eleventh,
+    # ...), inside the timed region.  Those steps run the Masker and the Painter branch on ONE stream: with the two-stream
+    # overlap of Trainer.update_G / update_D a bracket would time a kernel that shares the chip with the other branch's
+    # kernels, which says nothing about the kernel (measured: the same launches read 0.17 of the MFMA peak overlapped,
+    # 0.25 alone).  The bracketed steps are therefore ~20 ms slower than the others; ``ms_per_step`` is the mean over all.
     count = {"i": 0}
     sampled = len(range(0, args.steps, EVENT_EVERY)) if not args.no_launch_events else 0
+    overlap_default = T.overlap_branches
 
     def step():
         timer.enabled = timer.armed and count["i"] % EVENT_EVERY == 0
+        T.overlap_branches = overlap_default and not timer.enabled
         count["i"] += 1
         T.train_step(batch)
 
@@ -776,7 +781,9 @@ def main():
                 "algorithmic_flops_per_step": timer.total_flops() / sampled,
                 "algorithmic_bytes_per_launch": int(timer.total_bytes() / n),
                 "launches_per_step": n // max(sampled, 1), "avg_launch_ms": round(ms / n, 5),
-                "bracketed_steps": "%d of the %d timed steps (every %d-th)" % (sampled, args.steps, EVENT_EVERY),
+                "bracketed_steps": "%d of the %d timed steps (every %d-th), run single-stream so that a bracket times the "
+                                   "kernel alone; the other steps overlap the Masker and the Painter branch on two streams"
+                                   % (sampled, args.steps, EVENT_EVERY),
                 "share_of_step": round((ms / sampled) / (elapsed / args.steps * 1e3), 3),
                 "by_class": timer.classes()}
         else:
@@ -784,6 +791,7 @@ def main():
         if n and args.conv_table:
             with open(args.conv_table, "w") as f:
                 f.write(timer.table(sampled) + "\n")
+        res["config"]["two_stream_overlap"] = bool(overlap_default)
         res["losses_last_step"] = {k: round(v, 4) for k, v in losses.items()}
         res["max_mem_GB"] = round(mem_gb, 1)
         res["cpu_baseline"] = None
