@@ -73,9 +73,15 @@ template <typename T>
 __device__ __forceinline__ float f32_of_bits(uint16_t b) {
   return (float)__builtin_bit_cast(typename T::scalar, b);
 }
+// two fp32 -> one packed pair of T, as ONE vector conversion (gfx950: v_cvt_pk_bf16_f32 / v_cvt_pkrtz-free
+// v_cvt_pk_f16_f32, round to nearest even like the scalar casts): written as two scalar conversions + shift + or the
+// compiler emitted four instructions per pair in every conv / norm epilogue
 template <typename T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)bits_of<T>(lo) | ((uint32_t)bits_of<T>(hi) << 16);
+  typedef typename T::scalar s2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, s2));
 }
 template <typename T>
 __device__ __forceinline__ void unpack2(uint32_t p, float& lo, float& hi) {

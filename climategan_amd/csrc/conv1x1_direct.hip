@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
   constexpr int CH = CTW * 2;
   unsigned char* stg = smem + wave * (16 * ROWB);
   const int cout_base = wc * CTW * 16;
+  const bool plain = !p.bias && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
 #pragma unroll
   for (int t = 0; t < WP; ++t) {
 #pragma unroll
@@ -130,34 +131,36 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (p.bias) {
+      if (!plain) {     // wave-uniform: convs without bias / residual / activation / pad channels skip all of it
+        if (p.bias) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
-      }
-      if (p.has_res) {
-        size_t rbase;
-        if (p.res_ups) {
-          int ox = pix % p.w_out;
-          int r = pix / p.w_out;
-          int oy = r % p.h_out;
-          int nn = r / p.h_out;
-          rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
-        } else {
-          rbase = (size_t)pix * p.cout_s;
+          for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
         }
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
+        if (p.has_res) {
+          size_t rbase;
+          if (p.res_ups) {
+            int ox = pix % p.w_out;
+            int r = pix / p.w_out;
+            int oy = r % p.h_out;
+            int nn = r / p.h_out;
+            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+          } else {
+            rbase = (size_t)pix * p.cout_s;
+          }
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float r0, r1;
-          unpack2<T>(rv[e], r0, r1);
-          v[2 * e] += r0;
-          v[2 * e + 1] += r1;
+          for (int e = 0; e < 4; ++e) {
+            float r0, r1;
+            unpack2<T>(rv[e], r0, r1);
+            v[2 * e] += r0;
+            v[2 * e + 1] += r1;
+          }
         }
-      }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        v[r] = act_apply(v[r], p.act, p.slope);
-        if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+        for (int r = 0; r < 8; ++r) {
+          v[r] = act_apply(v[r], p.act, p.slope);
+          if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+        }
       }
       u32x4 o;
 #pragma unroll

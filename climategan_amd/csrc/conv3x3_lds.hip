@@ -44,6 +44,14 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
   // ---------------- epilogue: lane holds channels (ct0+c)*16 + 4g + {0..3} of pixel (row wave*PT+t, column j)
   __syncthreads();                                   // everyone is done with xbuf / wbuf
   unsigned char* yt = smem;                          // [256 px][NCT * 32 B]
+  // the bias quad of a cout tile is loaded once (not per pixel row); the pad-channel test only runs when there are any
+  const bool pad_c = p.cout < p.cout_s;
+  f32x4 bias_q[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int ch = (ct0 + c) * 16 + g * 4;           // (the bias vector is padded to whole cout tiles)
+    bias_q[c] = (p.bias && ch < p.cout_s) ? *reinterpret_cast<const f32x4*>(p.bias + ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
     const int row = wave * PT + t;
@@ -61,10 +69,8 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r];
       if (ch < p.cout_s) {
-        if (p.bias) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
-        }
+        for (int r = 0; r < 4; ++r) v[r] += bias_q[c][r];
         if (p.has_res && pin) {
           const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
           float r0, r1, r2, r3;
@@ -73,9 +79,11 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
           v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = act_apply(v[r], p.act, p.slope);
-          if (ch + r >= p.cout) v[r] = 0.f;          // keep pad channels zero
+        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.slope);
+        if (pad_c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ch + r >= p.cout) v[r] = 0.f;        // keep pad channels zero
         }
       }
       u32x2 o;

@@ -27,10 +27,13 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_gemm_zeros[4];
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int NSTAGE = 3;
 // development knob (cgan_debug_set_gemm_ws): 0 = automatic, 1 = never a K = 64 kernel, 5 / 6 = force conv_gemm_k64_kernel,
 // 8 = force the 256 x 256 kernel of conv_gemm_big.hip, 10 = force the direct 1x1 kernel of conv1x1_direct.hip,
-// 9 = automatic without those two
+// 9 = automatic without those two and without the x-resident 1x1 kernel, 11 = force conv1x1_xres.hip, 12 = automatic
+// without it
 int g_gemm_ws = 0;
 
 // sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four row rotations on the
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   __builtin_amdgcn_s_barrier();                               // every wave is done with the operand ring
   unsigned char* stg = smem + wave * (PP * 16 * ROWB);
   const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
+  const bool plain = !p.bias && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
   if (p.stats) {
     // training-mode BatchNorm statistics from the accumulators: (mean, M2) of this wave's WP x 16 pixels per channel --
     // sum and sum of squares over the wave's pixel tiles, then over the 16 lanes (pixels) that share a channel quad; the
@@ -204,18 +208,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
     constexpr float inv_cnt = 1.f / (float)(WP * 16);
 #pragma unroll
     for (int c = 0; c < WC; ++c) {
+      // pairs of channels on the packed-fp32 VALU path (v_pk_add_f32 / v_pk_fma_f32): same sums, half the instructions
+      f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}}, s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < WP; ++t) {
+        const f32x2 lo = {acc[c][t][0], acc[c][t][1]}, hi = {acc[c][t][2], acc[c][t][3]};
+        s0[0] += lo;
+        s0[1] += hi;
+        s1[0] += lo * lo;
+        s1[1] += hi * hi;
+      }
       float sm[4], sq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int t = 0; t < WP; ++t) {
-          const float v = acc[c][t][r];
-          a0 += v;
-          a1 += v * v;
-        }
-        sm[r] = row16_sum(a0);
-        sq[r] = row16_sum(a1);
+        sm[r] = row16_sum(s0[r >> 1][r & 1]);
+        sq[r] = row16_sum(s1[r >> 1][r & 1]);
       }
       const int ch = cout_base + c * 16 + 4 * g;
       if (j == 0 && ch < p.cout_s) {
@@ -223,8 +230,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float mean = sm[r] * inv_cnt;
-          o[2 * r] = mean + (p.bias ? p.bias[ch + r] : 0.f);
+          o[2 * r] = mean;
           o[2 * r + 1] = fmaxf(sq[r] - sm[r] * mean, 0.f);
+        }
+        if (p.bias) {       // (one wave-uniform branch, not one per channel)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[2 * r] += p.bias[ch + r];
         }
         float* dst = p.stats + ((size_t)chunk * p.cout_s + ch) * 2;
         *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
@@ -251,34 +262,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (p.bias) {
+      if (!plain) {     // wave-uniform: the BatchNorm-followed convs (no bias / residual / activation / pad channels) skip all of it
+        if (p.bias) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
-      }
-      if (p.has_res) {
-        size_t rbase;
-        if (p.res_ups) {
-          int ox = pix % p.w_out;
-          int r = pix / p.w_out;
-          int oy = r % p.h_out;
-          int nn = r / p.h_out;
-          rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
-        } else {
-          rbase = (size_t)pix * p.cout_s;
+          for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
         }
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
+        if (p.has_res) {
+          size_t rbase;
+          if (p.res_ups) {
+            int ox = pix % p.w_out;
+            int r = pix / p.w_out;
+            int oy = r % p.h_out;
+            int nn = r / p.h_out;
+            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+          } else {
+            rbase = (size_t)pix * p.cout_s;
+          }
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float r0, r1;
-          unpack2<T>(rv[e], r0, r1);
-          v[2 * e] += r0;
-          v[2 * e + 1] += r1;
+          for (int e = 0; e < 4; ++e) {
+            float r0, r1;
+            unpack2<T>(rv[e], r0, r1);
+            v[2 * e] += r0;
+            v[2 * e + 1] += r1;
+          }
         }
-      }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        v[r] = act_apply(v[r], p.act, p.slope);
-        if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+        for (int r = 0; r < 8; ++r) {
+          v[r] = act_apply(v[r], p.act, p.slope);
+          if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+        }
       }
       u32x4 o;
 #pragma unroll
@@ -607,7 +620,7 @@ int launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
 
 int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 1..4 = force a block tile
 
-enum { KIND_PLAIN = 0, KIND_K64_256x128, KIND_K64_128x256, KIND_BIG, KIND_DIRECT };
+enum { KIND_PLAIN = 0, KIND_K64_256x128, KIND_K64_128x256, KIND_BIG, KIND_DIRECT, KIND_XRES };
 struct Choice {
   int kind;
   int cfg;    // KIND_PLAIN: 1 = <1,4,4> (64 couts x 256 pixels), 2 = <2,8,4> (256 x 128), 3 = <2,4,8> (128 x 256),
@@ -618,12 +631,14 @@ struct Choice {
 Choice choose(const ConvGemmArgs& a, bool bf16) {
   const int ptiles = ceil_div(a.npix, 16);
   const bool no_big = g_gemm_ws == 9;
-  const int ws = no_big ? 0 : g_gemm_ws;
+  const bool no_xres = g_gemm_ws == 9 || g_gemm_ws == 12;
+  const int ws = (no_big || no_xres) ? 0 : g_gemm_ws;
   switch (ws) {
     case 5: if (k64_ok(a)) return {KIND_K64_256x128, 0}; break;         // K = 64 stages, 256 couts x 128 pixels
     case 6: if (k64_ok(a)) return {KIND_K64_128x256, 0}; break;         // K = 64 stages, 128 x 256
     case 8: if (conv_gemm_big_ok(a)) return {KIND_BIG, 0}; break;
     case 10: if (conv1x1_allc_ok(a)) return {KIND_DIRECT, 0}; break;
+    case 11: if (conv1x1_xres_ok(a)) return {KIND_XRES, 0}; break;
     default: break;
   }
   const bool automatic = ws == 0 && g_gemm_cfg == 0 && bf16;
@@ -638,6 +653,9 @@ Choice choose(const ConvGemmArgs& a, bool bf16) {
   // 55 -> 68 us with all 16 cout tiles per wave, 126 us with a 2 x 4 wave grid) -- the row-strided half-line pattern costs
   // more on the vector-memory path than the LDS-DMA pieces do
   if (automatic && !no_big && conv1x1_allc_ok(a) && a.ctiles <= 4 && a.npix >= 16384) return {KIND_DIRECT, 0};
+  // short-K 1x1 layers with >= 256 couts (bottleneck expands and the reduce layers' data gradients): the activation tile
+  // resident in LDS, weights straight into registers, all couts per workgroup (conv1x1_xres.hip)
+  if (automatic && !no_xres && conv1x1_xres_ok(a) && a.ctiles >= 16 && a.npix >= 16384) return {KIND_XRES, 0};
   // 256 x 256 block tiles (conv_gemm_big.hip) halve the L2 -> LDS fill per FLOP.  Same-box A/B over the step's shapes: they
   // win where K is long enough to amortise a prologue and an epilogue that nothing overlaps with one workgroup per CU
   // -- 512 -> 512 3x3 at 8 x 80^2 289 -> 256 us, at 4 x 80^2 163 -> 135 us, 2048 -> 512 1x1 181 -> 157 us -- and lose on the
@@ -679,6 +697,7 @@ int launch(const ConvGemmArgs& a, hipStream_t s) {
     case KIND_K64_128x256: return launch_k64<T, 4, 8>(a, s);
     case KIND_BIG: return conv_gemm_big_launch(a, T::id, s);
     case KIND_DIRECT: return conv1x1_allc_launch(a, T::id, s);
+    case KIND_XRES: return conv1x1_xres_launch(a, T::id, s);
     default: break;
   }
   switch (ch.cfg) {
@@ -709,6 +728,7 @@ int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
 
 int conv_gemm_stats_chunk_pixels(const ConvGemmArgs& a, int dtype) {
   const Choice ch = choose(a, dtype == CGAN_BF16);
+  if (ch.kind == KIND_XRES) return a.npix % 128 == 0 ? 128 : 0;   // a wave's 8 pixel tiles
   if (ch.kind != KIND_PLAIN) return 0;
   const int ppb = ch.cfg == 3 ? 128 : 64;        // WP x 16 pixels of a wave: <.,.,8> -> 128, <.,.,4> -> 64
   return a.npix % ppb == 0 ? ppb : 0;

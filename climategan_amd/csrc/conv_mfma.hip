@@ -210,7 +210,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
   }
 
-  // ---- epilogue: lane holds channels ct*16 + 4g + {0..3} of pixel (tile, j)
+  // ---- epilogue: lane holds channels ct*16 + 4g + {0..3} of pixel (tile, j).  The bias quad of a cout tile is loaded once
+  // (not per pixel tile); the pad-channel test runs only when the layer has pad channels (wave-uniform).
+  const bool pad_c = p.cout < p.cout_s;
+  f32x4 bias_q[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int ch = (ctile0 + c) * 16 + g * 4;       // (the bias vector is padded to whole cout tiles)
+    bias_q[c] = (p.bias && ch < p.cout_s) ? *reinterpret_cast<const f32x4*>(p.bias + ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
     const int pix = opix[t];
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       if (ch >= p.cout_s) continue;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r] + (p.bias ? p.bias[ch + r] : 0.f);
+      for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r] + bias_q[c][r];
       if (p.has_res) {
         u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
         float r0, r1, r2, r3;
@@ -242,9 +250,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = act_apply(v[r], p.act, p.slope);
-        if (ch + r >= p.cout) v[r] = 0.f;  // keep pad channels zero
+      for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.slope);
+      if (pad_c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ch + r >= p.cout) v[r] = 0.f;  // keep pad channels zero
       }
       u32x2 o;
       o[0] = pack2<T>(v[0], v[1]);

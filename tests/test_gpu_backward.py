@@ -744,6 +744,7 @@ def test_batched_dgrad_pack_equals_the_per_layer_pack():
     (256, 512, 3, 1, 1, 4, 80, 80, 1),       # 128 x 256 (128-pixel chunks)
     (1024, 256, 1, 0, 1, 8, 40, 40, 2), (256, 256, 3, 2, 2, 8, 40, 40, 2), (256, 128, 3, 1, 1, 4, 64, 64, 1),   # 128 x 128
     (256, 1024, 1, 0, 1, 4, 40, 40, 1), (128, 512, 1, 0, 1, 2, 96, 100, 2),   # 128 x 128, 2-stage ring (short-K 1x1)
+    (256, 1024, 1, 0, 1, 8, 80, 80, 2), (128, 512, 1, 0, 1, 4, 64, 64, 1), (64, 256, 1, 0, 1, 2, 128, 128, 2),   # x-resident 1x1 kernel
 ])
 def test_batchnorm_statistics_from_the_conv_epilogue(case):
     """``ops.conv2d_with_stats`` + ``batchnorm_train_stats_from_partials`` (the conv kernel's epilogue reduces its fp32

@@ -183,7 +183,8 @@ def test_k64_specialised_gemm_matches_the_plain_kernel(case):
         res = ops.NHWC(torch.randn_like(y0.t), cout) if residual else None
         if residual:
             y0 = ops.conv2d(x, pw, residual=res, **kw)
-        for ws in (5, 6, 8, 10, 9, 0):    # 256 x 128, 128 x 256, the 256 x 256 kernel, the direct 1x1 kernel, automatic without / with them
+        for ws in (5, 6, 8, 10, 11, 12, 9, 0):    # 256 x 128, 128 x 256, the 256 x 256 kernel, the direct 1x1 kernel, the x-resident
+            # 1x1 kernel, automatic without it, without any of the three, with all
             lib.cgan_debug_set_gemm_ws(ctypes.c_int(ws))
             y = ops.conv2d(x, pw, residual=res, **kw)
             y2 = ops.conv2d(x, pw, residual=res, **kw)
@@ -192,3 +193,37 @@ def test_k64_specialised_gemm_matches_the_plain_kernel(case):
             assert (d <= 2.0 ** -7 * y0.t.float().abs() + 1e-3).all(), (ws, d.max().item())
     finally:
         lib.cgan_debug_set_gemm_ws(ctypes.c_int(0))
+
+
+@pytest.mark.parametrize("case", [
+    # (cin, cout, B, H, W): 4 / 2 / 1 / 3 64-channel chunks; ragged pixel blocks; partial cout blocks and tiles; one cout block
+    (256, 1024, 2, 80, 80), (128, 512, 3, 37, 41), (64, 328, 2, 64, 64), (192, 256, 2, 50, 50), (256, 64, 2, 96, 96),
+    (256, 1024, 8, 80, 80), (64, 256, 4, 160, 160),
+])
+def test_x_resident_1x1_kernel_matches_the_plain_kernel(case):
+    """conv1x1_xres.hip (short-K 1x1 layers without bias / activation / residual: the bottleneck expands in training mode and
+    the reduce layers' data gradients; automatic in bf16 from 256 couts and 16384 pixels, forced here) against the plain
+    kernel: same K order, so the same bits; also as a data gradient (transposed pack) and in fp16."""
+    from climategan_amd import _lib, ops
+
+    cin, cout, B, H, W = case
+    lib = _lib.load()
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(2)
+        x = ops.nchw_to_nhwc(torch.randn(B, cin, H, W, device="cuda"), dt)
+        wt = torch.randn(cout, cin, 1, 1, device="cuda") * 0.05
+        pw = ops.pack_conv_weight(wt, None, dt)
+        dy = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, device="cuda"), dt)
+        try:
+            lib.cgan_debug_set_gemm_ws(ctypes.c_int(1))
+            y0 = ops.conv2d(x, pw)
+            dx0 = ops.conv2d_bwd_data(dy, wt, (B, H, W)) if cout <= 256 else None
+            lib.cgan_debug_set_gemm_ws(ctypes.c_int(11))
+            y = [ops.conv2d(x, pw).t.clone() for _ in range(3)]
+            assert torch.equal(y[0], y[1]) and torch.equal(y[0], y[2])
+            assert torch.equal(y[0], y0.t), (dt, (y[0].float() - y0.t.float()).abs().max().item())
+            if dx0 is not None:                   # cout -> cin as a 1x1 conv with K = cout <= 256
+                dx = ops.conv2d_bwd_data(dy, wt, (B, H, W))
+                assert torch.equal(dx.t, dx0.t)
+        finally:
+            lib.cgan_debug_set_gemm_ws(ctypes.c_int(0))

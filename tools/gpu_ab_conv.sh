@@ -5,9 +5,9 @@ mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 TAG=${1:-ab}
-(timeout 900 python -m pytest tests/test_gpu_conv_fuzz.py tests/test_gpu_ops.py -m gpu -q -x 2>&1 | tail -30) > gpurun_out/pytest_conv_$TAG.log 2>&1
+(timeout 900 python -m pytest tests/test_gpu_conv_fuzz.py tests/test_gpu_ops.py tests/test_gpu_backward.py -m gpu -q -x 2>&1 | tail -30) > gpurun_out/pytest_conv_$TAG.log 2>&1
 (timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --sub-steps 0 --conv-table gpurun_out/conv_table_${TAG}_big.txt 2>&1 | tail -1) > gpurun_out/bench_${TAG}_big.log 2>&1
-(timeout 600 python tools/bench_with_knobs.py gemm_ws=9 -- --steps 8 --warmup 3 --no-cpu-baseline --sub-steps 0 --conv-table gpurun_out/conv_table_${TAG}_old.txt 2>&1 | tail -1) > gpurun_out/bench_${TAG}_old.log 2>&1
+(timeout 600 python tools/bench_with_knobs.py gemm_ws=${OLD_WS:-9} -- --steps 8 --warmup 3 --no-cpu-baseline --sub-steps 0 --conv-table gpurun_out/conv_table_${TAG}_old.txt 2>&1 | tail -1) > gpurun_out/bench_${TAG}_old.log 2>&1
 (timeout 900 python -m pytest tests/test_gpu_configs_640.py tests/test_gpu_train.py -m gpu -q -x 2>&1 | tail -30) > gpurun_out/pytest_train_$TAG.log 2>&1
 for f in pytest_conv_$TAG pytest_train_$TAG; do echo "=== $f"; tail -n 25 gpurun_out/$f.log | cut -c1-300; done
 for f in bench_${TAG}_big bench_${TAG}_old; do echo "=== $f"; python - <<PY
@@ -20,4 +20,4 @@ else:
     print(open("gpurun_out/$f.log").read()[-1500:])
 PY
 done
-head -30 gpurun_out/conv_table_${TAG}_big.txt
+head -30 gpurun_out/conv_table_${TAG}_big.txt | grep k1
