@@ -132,9 +132,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (!plain) {     // wave-uniform: convs without bias / residual / activation / pad channels skip all of it
-        if (p.bias) {
+        if (p.bias) {     // (padded to whole cout tiles: two 16-byte loads)
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch + 4);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += p.bias[ch + r];
+          for (int r = 0; r < 4; ++r) {
+            v[r] += b0[r];
+            v[4 + r] += b1[r];
+          }
         }
         if (p.has_res) {
           size_t rbase;
@@ -157,9 +161,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
           }
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          v[r] = act_apply(v[r], p.act, p.slope);
-          if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+        for (int r = 0; r < 8; ++r) v[r] = act_apply(v[r], p.act, p.slope);
+        if (p.cout < p.cout_s) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
         }
       }
       u32x4 o;

@@ -10,6 +10,7 @@ struct Conv3x3LdsArgs {
   uint16_t* y;
   int n, h, w_;         // output extent (== logical input extent: stride 1, pad 1)
   int hx, wx;           // stored input extent (h/2, w/2 when in_ups)
+  int cin;              // logical input channels (<= 4: the folded-tap kernel)
   int cin_s, cin_p, cout, cout_s, ctiles, ksteps;
   int in_ups, act, has_res, res_ups;
   float slope;

@@ -22,6 +22,7 @@ constexpr int HPW = TW + 2, HPH = TH + 2, HP = HPH * HPW;   // 18 x 18 halo
 constexpr int XDMA = (HP * 4 + 63) / 64;                    // 21 wave-wide DMAs per input chunk
 constexpr int XBUF_BYTES = XDMA * 1024;                     // 21504 (324 px x 64 B + tail of the last DMA)
 constexpr int MAX_NCT = 5;
+int g_c4_enabled = 1;    // development knob (cgan_debug_set_conv3x3_c4): 0 = never the folded-tap kernel
 
 // [halo pixel q][4 slots of 16 B]: logical slot s of pixel q lives at slot position s ^ ((q >> 2) & 3)
 __device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 2) & 3)) << 4); }
@@ -288,6 +289,99 @@ __global__ __launch_bounds__(WAVES * 64, 4) void conv3x3_lds_onechunk_kernel(Con
   conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);
 }
 
+// <= 4 input channels (mlp_shared of every SPADE layer re-materialised in the backward, conv 3 -> 128 on the conditioning
+// image: reference norms.py:158-162; round 3).  The kernels above spend one MFMA k-step (32 K values) per TAP, i.e. 9 MFMAs
+// per tile pair for 27 real K values: at 4 x 640^2 -> 128 channels 343 us, four times the 84 us the 420 MB of output take
+// at the HBM write rate.  Here the taps are FOLDED into K: k-step 0 = taps 0..7 x 4 channels, k-step 1 = tap 8 (+ 28
+// zeros): two MFMAs instead of nine.
+//   * the 18 x 18 x 4-channel halo (2.6 KiB) is staged in LDS with plain 8-byte loads (channels 0..3 of each stored pixel);
+//   * B fragment of a pixel tile (one output row): lane (j, g) needs taps 2g and 2g + 1 of pixel j = two 8-byte LDS reads;
+//   * A fragments come straight from the standard packed weights (one k-step per tap, channel = K index): lane (j, g) of
+//     the folded fragment is the first 8 bytes of lane (j, 0) of the k-steps of taps 2g and 2g + 1 -- 3 small loads per cout
+//     tile, once per workgroup;
+//   * all couts (<= 8 tiles) in one workgroup, epilogue shared with the kernels above.
+template <typename T, int NCT>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c4_kernel(Conv3x3LdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int g = lane >> 4;
+  const int tiles_x = (p.w_ + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
+  int tile = blockIdx.x;
+  const int txi = tile % tiles_x;
+  tile /= tiles_x;
+  const int tyi = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int ct0 = blockIdx.y * NCT;
+
+  // ---- halo -> LDS: 8 bytes (channels 0..3) per pixel, zeros outside the image
+  u32x2* xh = reinterpret_cast<u32x2*>(smem);        // [18 * 18]
+  for (int pix = threadIdx.x; pix < HP; pix += WAVES * 64) {
+    const int py = pix / HPW, px = pix - py * HPW;
+    const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+    u32x2 v = {0u, 0u};
+    if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_) {
+      const int sy = p.in_ups ? (yy >> 1) : yy, sx = p.in_ups ? (xx >> 1) : xx;
+      v = *reinterpret_cast<const u32x2*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cin_s);
+    }
+    xh[pix] = v;
+  }
+  // ---- folded A fragments
+  u32x4 a0[NCT], a1[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int ct = min(ct0 + c, p.ctiles - 1);
+    const u32x2* wt = reinterpret_cast<const u32x2*>(p.w + (size_t)ct * p.ksteps * 64);   // lane l of k-step ks: wt[(ks * 64 + l) * 2]
+    const u32x2 lo = wt[((2 * g) * 64 + j) * 2], hi = wt[((2 * g + 1) * 64 + j) * 2];
+    const u32x2 last = wt[(8 * 64 + j) * 2];
+    a0[c] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    a1[c] = g == 0 ? (u32x4){last[0], last[1], 0u, 0u} : (u32x4){0u, 0u, 0u, 0u};
+  }
+  f32x4 acc[NCT][PT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int tA = 2 * g, tB = 2 * g + 1;               // this lane's taps of k-step 0
+  const int offA = (tA / 3) * HPW + tA % 3, offB = (tB / 3) * HPW + tB % 3;
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int base = (wave * PT + t) * HPW + j;       // halo pixel of tap (0, 0) for output (row, j)
+    const u32x2 lo = xh[base + offA], hi = xh[base + offB];
+    const u32x2 last = xh[base + 2 * HPW + 2];
+    const u32x4 b0 = {lo[0], lo[1], hi[0], hi[1]};
+    const u32x4 b1 = g == 0 ? (u32x4){last[0], last[1], 0u, 0u} : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      acc[c][t] = mfma16(as_vec8<T>(a0[c]), as_vec8<T>(b0), acc[c][t]);
+      acc[c][t] = mfma16(as_vec8<T>(a1[c]), as_vec8<T>(b1), acc[c][t]);
+    }
+  }
+  conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);
+}
+
+template <typename T, int NCT>
+int launch_c4(const Conv3x3LdsArgs& a, hipStream_t s) {
+  const int tiles = a.n * ((a.h + TH - 1) / TH) * ((a.w_ + TW - 1) / TW);
+  const size_t smem = (size_t)256 * NCT * 32;          // the epilogue's staging area (>= the 2.6 KiB halo)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c4_kernel<T, NCT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      cgan_set_error("conv3x3_c4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return CGAN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_c4_kernel<T, NCT>), dim3(tiles, ceil_div(a.ctiles, NCT)), dim3(WAVES * 64), smem, s, a);
+  return CGAN_OK;
+}
+
 template <typename T, int NCT>
 int launch(const Conv3x3LdsArgs& a, hipStream_t s) {
   const int tiles = a.n * ((a.h + TH - 1) / TH) * ((a.w_ + TW - 1) / TW);
@@ -328,6 +422,12 @@ int launch(const Conv3x3LdsArgs& a, hipStream_t s) {
 
 template <typename T>
 int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
+  // folded taps for <= 4 input channels stored as 4 / 8 / ... channels per pixel (the packed weights keep one k-step per tap)
+  if (g_c4_enabled && a.cin <= 4 && a.cin_p == 32 && a.ksteps == 9 && (a.cin_s & 3) == 0) {
+    if (a.ctiles <= 2) return launch_c4<T, 2>(a, s);
+    if (a.ctiles <= 4) return launch_c4<T, 4>(a, s);
+    return launch_c4<T, 8>(a, s);
+  }
   // channel tiles per workgroup: the divisor of ctiles (<= 5) with the least padding
   int nct = a.ctiles < MAX_NCT ? a.ctiles : MAX_NCT;
   if (a.ctiles > MAX_NCT) {
@@ -348,6 +448,8 @@ int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" void cgan_debug_set_conv3x3_c4(int v) { g_c4_enabled = v; }
 
 bool conv3x3_lds_applicable(const CganConvDesc* d) {
   return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && d->pad == 1 &&

@@ -588,7 +588,7 @@ static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, co
   if (kind == CGAN_CONV_KERNEL_LDS3X3) {
     Conv3x3LdsArgs a;
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
-    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
+    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin = d->c_in; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
     a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
     a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
     int rc2 = conv3x3_lds_launch(a, d->dtype, s);

@@ -78,6 +78,8 @@ class Trainer:
         import os
         self.overlap_branches = os.environ.get("CGAN_OVERLAP", "1") != "0"
         self._side = None
+        # development aid (tools/branch_times.py): [(fork event, end of the main-stream branch, end of the side-stream branch)]
+        self.branch_events = [] if os.environ.get("CGAN_BRANCH_TIMES") == "1" else None
 
     def setup(self, inference=False):
         """reference trainer.py:701-789."""
@@ -516,6 +518,10 @@ class Trainer:
                     red.streams = [torch.cuda.current_stream(self.device), self._side]
         _PackCache.repack_stale(dtype, self.device)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
+        if self.branch_events is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+            self.branch_events.append([e0, None, None])
         return self._side
 
     def _join(self, side):
@@ -539,6 +545,11 @@ class Trainer:
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dev))        # the arena's zeros, the packed operators
                 torch.autograd.backward(list(loss))
+                if self.branch_events is not None:
+                    em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    em.record(torch.cuda.current_stream(dev))
+                    es.record(side)
+                    self.branch_events[-1][1:] = [em, es]
                 torch.cuda.current_stream(dev).wait_stream(side)        # the optimizer runs on the calling stream
             else:
                 loss.backward()

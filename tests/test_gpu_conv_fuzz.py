@@ -227,3 +227,50 @@ def test_x_resident_1x1_kernel_matches_the_plain_kernel(case):
                 assert torch.equal(dx.t, dx0.t)
         finally:
             lib.cgan_debug_set_gemm_ws(ctypes.c_int(0))
+
+
+@pytest.mark.parametrize("case", [
+    # (cin, cout, B, H, W, upsample, residual, stored channels): the SPADE shared conv (3 -> 128), VGG's first conv (3 -> 64),
+    # ragged tiles, <= 2 / <= 4 / 8 cout tiles per workgroup, 13 tiles in two workgroups, the folded x2 upsample
+    (3, 128, 2, 64, 64, False, False, 8), (3, 64, 1, 50, 37, False, False, 8), (4, 32, 2, 40, 48, False, True, 8),
+    (1, 20, 1, 33, 65, False, False, 8), (3, 200, 1, 48, 48, False, False, 8), (3, 128, 1, 64, 64, True, False, 8),
+])
+def test_folded_tap_3x3_kernel_for_few_input_channels(case):
+    """conv3x3_c4_kernel (<= 4 input channels: the 9 taps folded into two MFMA k-steps instead of one k-step per tap) against
+    the per-tap kernel it replaces (cgan_debug_set_conv3x3_c4(0)) and against torch: same products, another fp32 summation
+    order, so within a rounding step of the 16-bit output."""
+    import torch.nn.functional as F
+    from climategan_amd import _lib, ops
+
+    cin, cout, B, H, W, ups, residual, cs = case
+    lib = _lib.load()
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(3)
+        hx, wx = (H // 2, W // 2) if ups else (H, W)
+        xf = torch.randn(B, cin, hx, wx, device="cuda").to(dt).float()
+        wt = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.2).to(dt).float()
+        bias = torch.randn(cout, device="cuda")
+        x = ops.nchw_to_nhwc(xf, dt, cs=cs)
+        pw = ops.pack_conv_weight(wt, bias, dt)
+        res = ops.NHWC(torch.randn(B, H, W, ops.cs8(cout), device="cuda").to(dt), cout) if residual else None
+        kw = dict(pad=1, act=ops.ACT_LRELU, slope=0.2, in_upsample=ups, residual=res)
+        try:
+            lib.cgan_debug_set_conv3x3_c4(ctypes.c_int(0))
+            y0 = ops.conv2d(x, pw, **kw)
+            lib.cgan_debug_set_conv3x3_c4(ctypes.c_int(1))
+            y = ops.conv2d(x, pw, **kw)
+            y2 = ops.conv2d(x, pw, **kw)
+        finally:
+            lib.cgan_debug_set_conv3x3_c4(ctypes.c_int(1))
+        assert torch.equal(y.t, y2.t)
+        xin = F.interpolate(xf, scale_factor=2, mode="nearest") if ups else xf
+        ref = F.conv2d(xin, wt, bias, padding=1)
+        if residual:
+            ref = ref + ops.nhwc_to_nchw(res)
+        ref = F.leaky_relu(ref, 0.2)
+        got = ops.nhwc_to_nchw(y)
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        assert (got - ref).abs().max().item() <= 1.5 * eps * ref.abs().max().item() + 1e-3, dt
+        d = (y.t.float() - y0.t.float()).abs()
+        assert (d <= 2 * eps * y0.t.float().abs() + 1e-3).all(), (dt, d.max().item())
+        assert y.t[..., cout:].abs().max().item() == 0 if y.t.shape[-1] > cout else True
