@@ -209,6 +209,10 @@ def load():
     v = lib.cgan_version()
     if v != ABI_VERSION:
         raise RuntimeError("climategan_amd: libcgan_hip.so ABI version %d != expected %d" % (v, ABI_VERSION))
+    # development knobs from the environment (same-box A/B of whole test / bench runs): CGAN_DEBUG_GEMM_WS=<n>
+    ws = os.environ.get("CGAN_DEBUG_GEMM_WS")
+    if ws:
+        lib.cgan_debug_set_gemm_ws(C.c_int(int(ws)))
     _lib = lib
     return lib
 

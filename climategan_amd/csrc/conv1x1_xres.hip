@@ -172,22 +172,36 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
       constexpr float inv_cnt = 1.f / (float)(WP * 16);
 #pragma unroll
       for (int c = 0; c < WC; ++c) {
-        f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}}, s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+        // of the values as stored (rounded), chunk mean first, then M2 = sum (v - mean)^2: see conv_gemm_kernel
+        f32x2 vr[WP][2];
+        f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
 #pragma unroll
         for (int t = 0; t < WP; ++t) {
-          const f32x2 lo = {acc[c][t][0], acc[c][t][1]}, hi = {acc[c][t][2], acc[c][t][3]};
-          s0[0] += lo;
-          s0[1] += hi;
-          s1[0] += lo * lo;
-          s1[1] += hi * hi;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float r0, r1;
+            unpack2<T>(pack2<T>(acc[c][t][2 * hh], acc[c][t][2 * hh + 1]), r0, r1);
+            vr[t][hh] = (f32x2){r0, r1};
+            s0[hh] += vr[t][hh];
+          }
         }
+        float mean[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mean[r] = row16_sum_x(s0[r >> 1][r & 1]) * inv_cnt;
+        const f32x2 m2[2] = {(f32x2){mean[0], mean[1]}, (f32x2){mean[2], mean[3]}};
+        f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < WP; ++t)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 dv = vr[t][hh] - m2[hh];
+            s1[hh] += dv * dv;
+          }
         float o[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float sm = row16_sum_x(s0[r >> 1][r & 1]), sq = row16_sum_x(s1[r >> 1][r & 1]);
-          const float mean = sm * inv_cnt;
-          o[2 * r] = mean;
-          o[2 * r + 1] = fmaxf(sq - sm * mean, 0.f);
+          o[2 * r] = mean[r];
+          o[2 * r + 1] = row16_sum_x(s1[r >> 1][r & 1]);
         }
         const int ch = cout_base + c * 16 + 4 * g;
         if (j16 == 0 && ch < p.cout_s) {

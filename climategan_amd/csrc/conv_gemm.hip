@@ -208,30 +208,46 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
     constexpr float inv_cnt = 1.f / (float)(WP * 16);
 #pragma unroll
     for (int c = 0; c < WC; ++c) {
-      // pairs of channels on the packed-fp32 VALU path (v_pk_add_f32 / v_pk_fma_f32): same sums, half the instructions
-      f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}}, s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+      // Statistics of the values AS STORED (rounded to the 16-bit type), not of the fp32 accumulators: a channel whose
+      // spread is below the rounding step of its mean (post-ReLU inputs make such channels) is pure rounding noise in y,
+      // and only the stored values' own variance normalises that noise to unit size -- with the accumulators' (true,
+      // much smaller) variance it was amplified (batch variances up to 30 % apart in layer3 / layer4, the encoder's
+      // gradient 2 % longer and 0.02 further from the reference's direction: tests/test_gpu_configs_640.py).
+      // Two passes, pairs of channels on the packed-fp32 VALU path: the chunk mean first, then M2 = sum (v - mean)^2
+      // (the one-pass form sum v^2 - (sum v)^2 / n cancels where the mean is large against the spread).
+      f32x2 vr[WP][2];
+      f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
 #pragma unroll
       for (int t = 0; t < WP; ++t) {
-        const f32x2 lo = {acc[c][t][0], acc[c][t][1]}, hi = {acc[c][t][2], acc[c][t][3]};
-        s0[0] += lo;
-        s0[1] += hi;
-        s1[0] += lo * lo;
-        s1[1] += hi * hi;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float r0, r1;
+          unpack2<T>(pack2<T>(acc[c][t][2 * hh], acc[c][t][2 * hh + 1]), r0, r1);
+          vr[t][hh] = (f32x2){r0, r1};
+          s0[hh] += vr[t][hh];
+        }
       }
       float sm[4], sq[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sm[r] = row16_sum(s0[r >> 1][r & 1]);
-        sq[r] = row16_sum(s1[r >> 1][r & 1]);
-      }
+      for (int r = 0; r < 4; ++r) sm[r] = row16_sum(s0[r >> 1][r & 1]) * inv_cnt;     // the chunk mean, in every lane of the row
+      const f32x2 m2[2] = {(f32x2){sm[0], sm[1]}, (f32x2){sm[2], sm[3]}};
+      f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < WP; ++t)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x2 dv = vr[t][hh] - m2[hh];
+          s1[hh] += dv * dv;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq[r] = row16_sum(s1[r >> 1][r & 1]);
       const int ch = cout_base + c * 16 + 4 * g;
       if (j == 0 && ch < p.cout_s) {
         float o[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float mean = sm[r] * inv_cnt;
-          o[2 * r] = mean;
-          o[2 * r + 1] = fmaxf(sq[r] - sm[r] * mean, 0.f);
+          o[2 * r] = sm[r];
+          o[2 * r + 1] = sq[r];
         }
         if (p.bias) {       // (one wave-uniform branch, not one per channel)
 #pragma unroll

@@ -517,11 +517,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
     // x already sits in LDS (actv[0], DMA'd during the last quarter; the stage barriers since then made it visible);
     // every lane reads and rewrites only its own 4-byte slots, so no barrier is needed before the arithmetic
     __builtin_amdgcn_s_setprio(2);
+    const bool lrelu_max = p.slope >= 0.f && p.slope <= 1.f;
     unsigned char* xt = actv;   // [256 px][NCT * 16 B]
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
       const int cg = C0 + c;      // channel tile within the workgroup's chunk
       const int ch = (nt0 + cg) * 8 + chan_in_tile;
+      const bool tile_pad = (nt0 + cg) * 8 + 8 > p.c;
       const f32x4 eb = *reinterpret_cast<const f32x4*>(prm + cg * 32 + g * 4);
       const float em0 = prm[cg * 32 + 16 + chan_in_tile], em1 = prm[cg * 32 + 17 + chan_in_tile];
       const float er0 = prm[cg * 32 + 24 + chan_in_tile], er1 = prm[cg * 32 + 25 + chan_in_tile];
@@ -544,11 +546,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
         float o0 = (x0 - em0) * er0 * gm0 + bt0;
         float o1 = (x1 - em1) * er1 * gm1 + bt1;
         if (p.act == CGAN_ACT_LRELU) {
-          o0 = o0 > 0.f ? o0 : o0 * p.slope;
-          o1 = o1 > 0.f ? o1 : o1 * p.slope;
+          if (lrelu_max) {            // wave-uniform: slope in [0, 1] -> max(o, slope * o), two instructions instead of three
+            o0 = fmaxf(o0, o0 * p.slope);
+            o1 = fmaxf(o1, o1 * p.slope);
+          } else {
+            o0 = o0 > 0.f ? o0 : o0 * p.slope;
+            o1 = o1 > 0.f ? o1 : o1 * p.slope;
+          }
         }
-        if (ch >= p.c) o0 = 0.f;
-        if (ch + 1 >= p.c) o1 = 0.f;
+        if (tile_pad) {               // wave-uniform: only the last channel tile of a layer has pad channels
+          if (ch >= p.c) o0 = 0.f;
+          if (ch + 1 >= p.c) o1 = 0.f;
+        }
         *slot = pack2<T>(o0, o1);   // each lane reads and rewrites only its own 4 bytes
       }
     }

@@ -201,9 +201,22 @@ __global__ void spade_bwd_prepare_kernel(const uint16_t* __restrict__ dy, const 
       for (int e = 0; e < 8; ++e)
         if (cg * 8 + e < c) row[cg * 8 + e] = (uint16_t)((odg[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
     }
+    // d_beta: channels c + cg*8 ..: one 16-byte store when c is a multiple of 8, two 8-byte stores when of 4 (C = 20: the
+    // range starts 40 bytes into the row), element-wise only for a group that straddles the end of the range
+    if (cg * 8 + 8 <= c && (c & 3) == 0) {
+      const u32x4 obt = {pack2<T>(dbeta[0], dbeta[1]), pack2<T>(dbeta[2], dbeta[3]), pack2<T>(dbeta[4], dbeta[5]),
+                         pack2<T>(dbeta[6], dbeta[7])};
+      if ((c & 7) == 0) {
+        *reinterpret_cast<u32x4*>(row + c + cg * 8) = obt;
+      } else {
+        *reinterpret_cast<u32x2*>(row + c + cg * 8) = (u32x2){obt[0], obt[1]};
+        *reinterpret_cast<u32x2*>(row + c + cg * 8 + 4) = (u32x2){obt[2], obt[3]};
+      }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (cg * 8 + e < c) row[c + cg * 8 + e] = bits_of<T>(dbeta[e]);
+      for (int e = 0; e < 8; ++e)
+        if (cg * 8 + e < c) row[c + cg * 8 + e] = bits_of<T>(dbeta[e]);
+    }
   }
 }
 
@@ -627,10 +640,12 @@ extern "C" int cgan_spade_bwd_prepare(const void* dy, const void* y, const void*
   const int cs = cgan_cs(d->c), cs2 = cgan_cs(2 * d->c);
   const long npix = (long)d->n * d->h * d->w;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dgb, 0, (size_t)npix * cs2 * 2, s);
-  if (e != hipSuccess) {
-    cgan_set_error("spade_bwd_prepare: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CGAN_ERR_HIP;
+  if (cs2 != 2 * d->c) {     // pad channels past 2c exist and the kernel does not write them (C = 20 / 40: none)
+    hipError_t e = hipMemsetAsync(dgb, 0, (size_t)npix * cs2 * 2, s);
+    if (e != hipSuccess) {
+      cgan_set_error("spade_bwd_prepare: hipMemsetAsync failed: %s", hipGetErrorString(e));
+      return CGAN_ERR_HIP;
+    }
   }
   const long groups = npix * (cs / 8);
   DISPATCH_T(d->dtype, spade_bwd_prepare_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)dy,

@@ -232,7 +232,8 @@ def test_conv_fn_upsample_residual_autograd(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("C,H,W,ups,act", [(20, 12, 16, False, "lrelu"), (40, 8, 12, True, "none"), (16, 10, 10, True, "lrelu")])
+@pytest.mark.parametrize("C,H,W,ups,act", [(20, 12, 16, False, "lrelu"), (40, 8, 12, True, "none"), (16, 10, 10, True, "lrelu"),
+                                           (10, 8, 8, False, "lrelu"), (12, 8, 12, False, "none")])   # pad channels past 2C; a straddling group
 def test_spade_fn_backward(dt, C, H, W, ups, act):
     """autograd.SpadeFn (fused forward, re-materialising backward) against torch autograd of the reference expression
     (norms.py:174-186): gradients of x and of the six mlp parameters."""
@@ -747,10 +748,23 @@ def test_batched_dgrad_pack_equals_the_per_layer_pack():
     (256, 1024, 1, 0, 1, 8, 80, 80, 2), (128, 512, 1, 0, 1, 4, 64, 64, 1), (64, 256, 1, 0, 1, 2, 128, 128, 2),   # x-resident 1x1 kernel
 ])
 def test_batchnorm_statistics_from_the_conv_epilogue(case):
+    _bn_stats_from_epilogue(case, shifted=False)
+
+
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 80, 80, 2), (256, 1024, 1, 0, 1, 8, 80, 80, 2), (1024, 256, 1, 0, 1, 8, 40, 40, 2)])
+def test_batchnorm_statistics_from_the_conv_epilogue_with_large_channel_means(case):
+    """Post-ReLU inputs and weights with a common sign give conv outputs whose channel mean is ten or more standard deviations
+    away from zero: the epilogue's M2 must not be formed as sum v^2 - (sum v)^2 / n (round 3: that form cost the encoder 2 %
+    of its gradient norm against the reference's step)."""
+    _bn_stats_from_epilogue(case, shifted=True)
+
+
+def _bn_stats_from_epilogue(case, shifted):
     """``ops.conv2d_with_stats`` + ``batchnorm_train_stats_from_partials`` (the conv kernel's epilogue reduces its fp32
-    accumulators per chunk of pixels; one finalize launch) against the separate statistics pass over the stored y and
-    against torch: same y bit for bit, batch mean / rstd to fp32 accuracy of the unrounded conv output (the separate pass
-    sees the 16-bit-rounded y: the two agree to 2^-9 of the spread), identical running-statistics semantics per group."""
+    accumulators, rounded as they are stored, per chunk of pixels; one finalize launch) against the separate statistics pass
+    over the stored y and against float64 over y: same y bit for bit, batch mean / rstd of the STORED values to fp32 accuracy
+    (round 3: statistics of the unrounded accumulators amplified the rounding noise of near-constant channels), identical
+    running-statistics semantics per group."""
     import torch.nn.functional as F
     from climategan_amd import ops
 
@@ -759,6 +773,9 @@ def test_batchnorm_statistics_from_the_conv_epilogue(case):
     gen = torch.Generator(device="cuda").manual_seed(3)
     xf = torch.randn(n, cin, h, w, device="cuda", generator=gen).to(dt).float()
     wt = (torch.randn(cout, cin, k, k, device="cuda", generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(dt).float()
+    if shifted:
+        xf = (xf.abs() + 1.0).to(dt).float()
+        wt = (wt * 0.05 + 1.0 / (cin * k * k)).to(dt).float()
     x = ops.nchw_to_nhwc(xf, dt)
     pw = ops.pack_conv_weight(wt, None, dt)
     y, st = ops.conv2d_with_stats(x, pw, pad=pad, dilation=dil, groups=G)
@@ -777,12 +794,17 @@ def test_batchnorm_statistics_from_the_conv_epilogue(case):
     rm_b, rv_b, nbt_b = fresh()
     flat = ops.NHWC(y.t.view(G, npix, 1, y.t.shape[-1]), cout)
     b = ops.batchnorm_train_stats(flat, gamma, beta, rm_b, rv_b, nbt_b, 1e-5, 0.1)
-    ref = F.conv2d(xf, wt, padding=pad, dilation=dil).view(G, n // G, cout, -1).permute(0, 2, 1, 3).reshape(G, cout, -1)
-    mean_ref, var_ref = ref.mean(-1), ref.var(-1, unbiased=False)
+    # the statistics are those of the STORED (16-bit) values: the float64 reference is taken over y itself
+    ref = ops.nhwc_to_nchw(y).double().view(G, n // G, cout, -1).permute(0, 2, 1, 3).reshape(G, cout, -1)
+    mean_ref, var_ref = ref.mean(-1).float(), ref.var(-1, unbiased=False).float()
+    if shifted:
+        exact = F.conv2d(xf.double(), wt.double(), padding=pad, dilation=dil)
+        ratio = (exact.mean((0, 2, 3)).abs() / exact.var((0, 2, 3), unbiased=False).sqrt()).median().item()
+        assert ratio > 8, ratio                                                 # the regime this variant is about
     spread = var_ref.sqrt().max().item()
-    assert (a[0][:, :cout] - mean_ref).abs().max().item() <= 2e-5 * max(spread, 1.0) + 1e-6
+    assert (a[0][:, :cout] - mean_ref).abs().max().item() <= 2e-5 * max(spread, mean_ref.abs().max().item(), 1.0) + 1e-6
     assert ((1.0 / a[1][:, :cout] ** 2 - 1e-5) / var_ref - 1).abs().max().item() <= 2e-4
-    for u, v in zip(a, b):                                           # the separate pass reads the bf16-rounded y
-        assert (u[:, :cout] - v[:, :cout]).abs().max().item() <= 2.0 ** -8 * max(v[:, :cout].abs().max().item(), 1.0)
+    for u, v in zip(a, b):                                           # the separate pass reads the same stored values
+        assert (u[:, :cout] - v[:, :cout]).abs().max().item() <= 1e-4 * max(v[:, :cout].abs().max().item(), 1.0)
     assert int(nbt_a) == int(nbt_b) == G
-    assert (rm_a - rm_b).abs().max().item() <= 2.0 ** -8 * spread + 1e-6 and (rv_a / rv_b - 1).abs().max().item() <= 2e-2
+    assert (rm_a - rm_b).abs().max().item() <= 1e-4 * max(spread, 1.0) + 1e-6 and (rv_a / rv_b - 1).abs().max().item() <= 1e-3
