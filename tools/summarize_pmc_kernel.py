@@ -3,7 +3,7 @@
 FETCH_SIZE / WRITE_SIZE are in KiB.  Per MI355X_MICROARCH.md (HBM section) gfx950's FETCH_SIZE counts wide coalesced reads
 at half their bytes -> doubled here; WRITE_SIZE is taken as reported (uncalibrated).  The launches of the LAST step of
 the run are matched between the two passes by their order.
-usage: python tools/summarize_pmc_kernel.py gpurun_out <tag> <kernel substring> <launches per step> <out csv name>
+usage: python tools/summarize_pmc_kernel.py gpurun_out <tag> <kernel substring[|substring...]> <launches per step> <out csv name>
 """
 import collections
 import csv
@@ -14,7 +14,7 @@ root, tag, sub, per_step, outname = Path(sys.argv[1]), sys.argv[2], sys.argv[3],
 res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in csv.DictReader(open(root / f"pmc_{tag}_{ctr}" / f"{tag}_counter_collection.csv"))
-            if sub in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if any(x in r["Kernel_Name"] for x in sub.split("|")) and r["Counter_Name"] == ctr]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     res[ctr] = rows[-per_step:]
 assert len(res["FETCH_SIZE"]) == len(res["WRITE_SIZE"]) == per_step, (len(res["FETCH_SIZE"]), len(res["WRITE_SIZE"]))
