@@ -563,7 +563,8 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
 
     def timed(xn, *a, **k):
         c, hw = xn.c, (xn.h * (2 if k.get("x_upsample") else 1), xn.w * (2 if k.get("x_upsample") else 1))
-        return timer.bracket(lambda: orig(xn, *a, **k), xn.n * hw[0] * hw[1] * 2.0 * (3 * 9 * 128 + 2 * 128 * 9 * c))
+        return timer.bracket(lambda: orig(xn, *a, **k), xn.n * hw[0] * hw[1] * 2.0 * (3 * 9 * 128 + 2 * 128 * 9 * c),
+                             tag="%dx%d c%d" % (hw[0], hw[1], c))
 
 
     ops.spade_fused = norms_mod.ops.spade_fused = timed
@@ -592,6 +593,19 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
     achieved = timer.total_flops() / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     assert abs(timer.total_flops() - flops_img * BATCH_PER_GPU * sampled) <= 1e-6 * timer.total_flops()
     alg_bytes = sum(BATCH_PER_GPU * a * b * 2 * (2 * ((c + 7) // 8 * 8) + 4) for c, (a, b) in layers)
+    # the five full-resolution launches (up_spades' last block + final_spade: 60 % of the 23 launches' FLOPs), on their own
+    full = [p for p in timer.pairs if p[4].startswith("%dx%d " % (H, W))]
+    full_ms = sum(p[0].elapsed_time(p[1]) for p in full)
+    full_tf = sum(p[2] for p in full) / (full_ms * 1e-3) / 1e12 if full_ms > 0 else 0.0
+    agg = {}
+    for e0, e1, fl, _, tag in timer.pairs:
+        a = agg.setdefault(tag, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += fl
+    by_shape = {tag: {"launches_per_step": a[0] // max(sampled, 1), "avg_us": round(a[1] / a[0] * 1e3, 1),
+                      "tflops": round(a[2] / a[1] / 1e9, 1), "frac": round(a[2] / a[1] / 1e9 / MFMA_PEAK_TFLOPS, 3)}
+                for tag, a in agg.items() if a[1] > 0}
     res = {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 (OmniGenerator.paint incl. mask, "
                        "spectral-norm power iterations, paste), %s" % str(dtype).split(".")[1],
            "images_per_s": round(world * BATCH_PER_GPU * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
@@ -604,7 +618,14 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
                         "algorithmic_flops_per_step": flops_img * BATCH_PER_GPU,
                         "launches_per_step": n // max(sampled, 1), "avg_launch_ms": round(ms / max(n, 1), 4),
                         "bracketed_steps": "%d of the %d timed steps (every %d-th)" % (sampled, steps, EVENT_EVERY),
-                        "share_of_step": round((ms / max(sampled, 1)) / (elapsed / steps * 1e3), 3)}}
+                        "share_of_step": round((ms / max(sampled, 1)) / (elapsed / steps * 1e3), 3),
+                        "by_shape": by_shape,
+                        "roofline_target_set": {
+                            "launches": "the %d launches per step at %dx%d (C = 40, 40, 20, 20, 20: up_spades' last block and "
+                                        "final_spade)" % (len(full) // max(sampled, 1), H, W),
+                            "algorithmic_flops_per_step": sum(p[2] for p in full) / max(sampled, 1),
+                            "achieved": round(full_tf, 2), "frac": round(full_tf / MFMA_PEAK_TFLOPS, 4),
+                            "avg_launch_ms": round(full_ms / max(len(full), 1), 4)}}}
     if with_cpu:
         res["cpu_baseline"] = cpu_baseline_paint(sd)
     return res

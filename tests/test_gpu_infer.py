@@ -51,7 +51,11 @@ def test_infer_all_flood_matches_reference_golden():
     assert set(np.unique(out["mask"])) <= {0, 255}
     # the whole flood image: same picture up to the pixels whose mask bit flipped
     agree = (out["mask"] == gold["mask_u8"]).mean()
-    assert agree > 0.8, agree
+    print("flood mask: %.4f of the pixels agree with the fp32 reference's binary mask; %.4f of them are further than 0.01 from "
+          "the threshold" % (agree, sure.mean()))
+    # measured 0.9983 (fp16 kernels against the fp32 reference; the reference's own G.half() run flips 0.2 % of this fixture's
+    # pixels): a band of 0.5 %
+    assert agree >= 0.995, agree
 
 
 def test_float_mask_and_depth_seg_stages():
