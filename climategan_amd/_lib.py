@@ -12,7 +12,7 @@ _HERE = Path(__file__).resolve().parent
 # CGAN_LIB: another build of the same library (same-box A/B measurements of a kernel change); default: the in-tree build
 LIB_PATH = Path(os.environ["CGAN_LIB"]).resolve() if os.environ.get("CGAN_LIB") else _HERE / "libcgan_hip.so"
 
-CGAN_F16, CGAN_BF16 = 0, 1
+CGAN_F16, CGAN_BF16, CGAN_F32 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 ABI_VERSION = 1
@@ -71,6 +71,12 @@ _SIGNATURES = {
     "cgan_conv2d_nhwc_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_kernel_kind": (C.c_int, [C.POINTER(ConvDesc), C.c_int32]),
+    "cgan_rccl_load": (C.c_int, [C.c_char_p]),
+    "cgan_rccl_loaded": (C.c_int, []),
+    "cgan_comm_unique_id": (C.c_int, [_P]),
+    "cgan_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, _P, C.c_int32]),
+    "cgan_comm_destroy": (C.c_int, [_P]),
+    "cgan_allreduce_bucket": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "cgan_seg_counts": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     "cgan_resize_crop_geometry": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -20,6 +20,12 @@ reducer works on the parameter list:
 * ``finish()`` waits for the outstanding buckets, and copies the averaged values back into ``param.grad``.  ExtraAdam
   needs it before both ``extrapolation()`` and ``step()`` (reference trainer.py:678-683).
 
+``CGAN_DDP_DIRECT_RCCL=1`` (RCCL backend only) takes torch out of the collective: the reducer creates its OWN communicator
+through the C ABI (``cgan_rccl_load`` / ``cgan_comm_unique_id`` / ``cgan_comm_init_rank``: the unique id travels over the
+existing process group) and enqueues ``cgan_allreduce_bucket`` on a stream of its own, ordered after the bucket's gather
+by an event and before ``finish()``'s copy-back by another -- the path a host without torch.distributed would take
+(INTEGRATION.md); the default stays ``dist.all_reduce``.
+
 ``broadcast_parameters`` makes replicas identical at start (parameters AND buffers, incl. the spectral-norm ``u``/``v``
 vectors, which are parameters with ``requires_grad=False``).
 """
@@ -44,6 +50,16 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+class _EventWork:
+    """``wait()`` of a collective enqueued on the reducer's own stream: the calling stream waits for its event."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
 
 
 class _Bucket:
@@ -81,19 +97,46 @@ class GradBucketReducer:
         if cur:
             self.buckets.append(_Bucket(cur))
         self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self.direct = False
+        self._comm = None
+        if self.active and dist.get_backend() == "nccl" and os.environ.get("CGAN_DDP_DIRECT_RCCL") == "1":
+            self._init_direct()
         # streams on which gradients of these parameters are produced besides the one a hook happens to run on (the
         # trainer issues the Masker and the Painter branch of a backward on two streams): a bucket's gather waits for them
         self.streams = []
         if self.active and dist.get_rank() == 0:
-            print("GradBucketReducer: %d parameters, %.1f MB in %d buckets, %s on the wire, %d ranks over %s"
+            print("GradBucketReducer: %d parameters, %.1f MB in %d buckets, %s on the wire, %d ranks over %s%s"
                   % (len(self.params), sum(p.numel() for p in self.params) * torch.finfo(grad_dtype).bits / 8e6,
-                     len(self.buckets), str(grad_dtype).split(".")[1], self.world, dist.get_backend()), flush=True)
+                     len(self.buckets), str(grad_dtype).split(".")[1], self.world, dist.get_backend(),
+                     " (own communicator, cgan_allreduce_bucket)" if os.environ.get("CGAN_DDP_DIRECT_RCCL") == "1" else ""),
+                  flush=True)
         # First step: a hook on EVERY parameter counts the bucket down and remembers which parameter completed it.
         # Afterwards only those trigger parameters keep a hook (the backward graph is the same every step): ~1500 calls
         # from the autograd engine into Python per step cost more (~15 ms of a 160 ms step) than the overlap buys.
         self._learning = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.reset()
+
+    def _init_direct(self):
+        """Own RCCL communicator through the C ABI (include/climategan_hip.h, "Data-parallel gradient exchange")."""
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _lib.check(lib.cgan_rccl_load(path.encode()), "cgan_rccl_load")
+        uid = C.create_string_buffer(128)
+        if dist.get_rank() == 0:
+            _lib.check(lib.cgan_comm_unique_id(uid), "cgan_comm_unique_id")
+        box = [uid.raw]
+        dist.broadcast_object_list(box, src=0)
+        uid = C.create_string_buffer(box[0], 128)
+        comm = C.c_void_p()
+        _lib.check(lib.cgan_comm_init_rank(C.byref(comm), self.world, uid, dist.get_rank()), "cgan_comm_init_rank")
+        self._comm, self._lib = comm, lib
+        self._comm_stream = torch.cuda.Stream()
+        self._wire = {torch.float32: _lib.CGAN_F32, torch.bfloat16: _lib.CGAN_BF16, torch.float16: _lib.CGAN_F16}[self.grad_dtype]
+        self.direct = True
 
     def reset(self):
         for b in self.buckets:
@@ -121,6 +164,17 @@ class GradBucketReducer:
                     cur.wait_stream(st)
         # multi-tensor copies (a handful of launches per bucket instead of one per parameter: 1500 parameters)
         torch._foreach_copy_(self._views(b, grads), grads)
+        if self.direct:
+            from . import _lib
+            gathered = torch.cuda.Event()
+            gathered.record()
+            self._comm_stream.wait_event(gathered)
+            _lib.check(self._lib.cgan_allreduce_bucket(b.flat.data_ptr(), b.numel, self._wire, self._comm,
+                                                       self._comm_stream.cuda_stream), "cgan_allreduce_bucket")
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+            b.work = _EventWork(done)
+            return
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
@@ -182,3 +236,7 @@ class GradBucketReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        if self._comm is not None:
+            torch.cuda.synchronize()
+            self._lib.cgan_comm_destroy(self._comm)
+            self._comm, self.direct = None, False

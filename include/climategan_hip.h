@@ -41,7 +41,7 @@ typedef enum {
   CGAN_ERR_HIP = -4           /* HIP runtime error (launch failure ...) */
 } cgan_status_t;
 
-typedef enum { CGAN_F16 = 0, CGAN_BF16 = 1 } cgan_dtype_t;
+typedef enum { CGAN_F16 = 0, CGAN_BF16 = 1, CGAN_F32 = 2 /* cgan_allreduce_bucket only */ } cgan_dtype_t;
 typedef enum { CGAN_ACT_NONE = 0, CGAN_ACT_RELU = 1, CGAN_ACT_LRELU = 2, CGAN_ACT_TANH = 3, CGAN_ACT_SIGMOID = 4 } cgan_act_t;
 typedef enum { CGAN_PAD_ZERO = 0, CGAN_PAD_REFLECT = 1 } cgan_pad_t;
 
@@ -574,6 +574,26 @@ int cgan_resize_u8(const void* img_hwc_u8, int32_t h, int32_t w, int32_t c, int3
  * IoU_k = [2][k] / ([0][k] + [1][k] - [2][k]).  First maximum wins on ties (np.argmax / torch.argmax). */
 int cgan_seg_counts(const void* pred, int32_t layout, int32_t dtype, int32_t n, int64_t hw, int32_t c,
                     const float* labels, unsigned long long* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange on RCCL.  The reference trains in ONE process on one device
+ * (trainer.py:674-683: backward, then the optimizer on the local gradients); data parallelism over per-GPU slices needs the
+ * average of the ranks' gradients before ExtraAdam's extrapolation / step.  The host mirror's default path runs that
+ * all-reduce through torch.distributed (backend "nccl" = RCCL); these entry points are the same collective for a host that
+ * owns its communicator (and the reducer's opt-in direct path, CGAN_DDP_DIRECT_RCCL=1).
+ *  - librccl is loaded at run time, never linked: cgan_rccl_load(path) (the copy torch ships: one RCCL per process); all
+ *    other entry points return CGAN_ERR_BAD_ARG until it has succeeded.
+ *  - cgan_comm_unique_id: rank 0 fills 128 bytes (ncclGetUniqueId) and distributes them out of band;
+ *    cgan_comm_init_rank: every rank, collectively (ncclCommInitRank); cgan_comm_destroy.
+ *  - cgan_allreduce_bucket: IN-PLACE SUM of one flat bucket (count elements of CGAN_F32, CGAN_BF16 or CGAN_F16) over the
+ *    communicator's ranks, enqueued on `stream`; the caller divides by the world size.
+ * ------------------------------------------------------------------------------------------------ */
+int cgan_rccl_load(const char* librccl_path);
+int cgan_rccl_loaded(void);
+int cgan_comm_unique_id(void* id128);
+int cgan_comm_init_rank(void** comm, int32_t nranks, const void* id128, int32_t rank);
+int cgan_comm_destroy(void* comm);
+int cgan_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* comm, void* stream);
 
 /* Not part of the ABI: the library also exports a few cgan_debug_set_* development knobs (kernel selection, ablation
  * bits, split targets) used by tools/ and by the tests that run every kernel variant on the same cases.  They are

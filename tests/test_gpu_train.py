@@ -556,6 +556,32 @@ def test_gradient_reducer_over_rccl_single_rank():
         for _ in range(2):
             g, d = TM.train_step(masker_batch(mcase))
             assert torch.isfinite(g) and torch.isfinite(d)
+        # the same exchange WITHOUT torch in the collective (CGAN_DDP_DIRECT_RCCL=1): the reducer's own communicator
+        # through the C ABI (cgan_rccl_load / cgan_comm_unique_id / cgan_comm_init_rank), cgan_allreduce_bucket on its own
+        # stream between two events; with one rank the sum is the identity, so the steps must match the reducer-free ones
+        os.environ["CGAN_DDP_DIRECT_RCCL"] = "1"
+        try:
+            T2, got2 = run()
+            assert T2.g_reducer.direct and T2.d_reducer.direct and T2.g_reducer._comm is not None
+            for (g0, d0), (g1, d1) in zip(ref, got2):
+                assert torch.allclose(g0, g1, rtol=2e-3, atol=1e-5) and torch.allclose(d0, d1, rtol=2e-3, atol=1e-5)
+            for (k, a), (_, b) in zip(T0.G.state_dict().items(), T2.G.state_dict().items()):
+                assert torch.allclose(a.float(), b.float(), rtol=1e-3, atol=3e-4), k
+            # the entry point on a buffer of its own: sum over one rank = the buffer, in fp32 and on the bf16 wire
+            from climategan_amd import _lib
+            lib = _lib.load()
+            for dt, code in ((torch.float32, _lib.CGAN_F32), (torch.bfloat16, _lib.CGAN_BF16)):
+                buf = torch.randn(1 << 20, device="cuda").to(dt)
+                keep = buf.clone()
+                _lib.check(lib.cgan_allreduce_bucket(buf.data_ptr(), buf.numel(), code, T2.g_reducer._comm,
+                                                     torch.cuda.current_stream().cuda_stream), "cgan_allreduce_bucket")
+                torch.cuda.synchronize()
+                assert torch.equal(buf, keep)
+            T2.g_reducer.remove()
+            T2.d_reducer.remove()
+            assert T2.g_reducer._comm is None
+        finally:
+            os.environ.pop("CGAN_DDP_DIRECT_RCCL", None)
         for mod0, mod1 in ((T0.G, T1.G), (T0.D, T1.D)):
             for (k, a), (_, b) in zip(mod0.state_dict().items(), mod1.state_dict().items()):
                 # Adam moves every weight by ~lr per update whatever the gradient's scale: tensors whose true gradient is
