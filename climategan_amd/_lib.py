@@ -219,6 +219,8 @@ def load():
     ws = os.environ.get("CGAN_DEBUG_GEMM_WS")
     if ws:
         lib.cgan_debug_set_gemm_ws(C.c_int(int(ws)))
+    if os.environ.get("CGAN_DEBUG_GEMM_FP16_AUTO"):
+        lib.cgan_debug_set_gemm_fp16_auto(C.c_int(int(os.environ["CGAN_DEBUG_GEMM_FP16_AUTO"])))
     _lib = lib
     return lib
 

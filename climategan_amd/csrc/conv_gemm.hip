@@ -35,6 +35,7 @@ constexpr int NSTAGE = 3;
 // 9 = automatic without those two and without the x-resident 1x1 kernel, 11 = force conv1x1_xres.hip, 12 = automatic
 // without it
 int g_gemm_ws = 0;
+int g_gemm_fp16_auto = 0;   // development knob (cgan_debug_set_gemm_fp16_auto): 1 = the specialised kernels in fp16 too
 
 // sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four row rotations on the
 // VALU's data-parallel-primitive path (__shfl_xor compiles to ds_bpermute_b32: an LDS instruction per step and value)
@@ -663,7 +664,7 @@ Choice choose(const ConvGemmArgs& a, bool bf16) {
     case 11: if (conv1x1_xres_ok(a)) return {KIND_XRES, 0}; break;
     default: break;
   }
-  const bool automatic = ws == 0 && g_gemm_cfg == 0 && bf16;
+  const bool automatic = ws == 0 && g_gemm_cfg == 0 && (bf16 || g_gemm_fp16_auto);
   // The three specialised kernels are taken in bf16 (the training dtype) only: fp16 is what apply_events runs in, and its
   // wildfire fixture turns single arg-max flips of the untrained segmentation into a one-level contrast shift of a tenth
   // of the image -- the kernels agree within an fp16 rounding step (another fp32 summation order), but the fixture was
@@ -743,6 +744,7 @@ bool conv_gemm_applicable(const CganConvDesc* d) {
 
 extern "C" void cgan_debug_set_gemm_cfg(int v) { g_gemm_cfg = v; }
 extern "C" void cgan_debug_set_gemm_ws(int v) { g_gemm_ws = v; }
+extern "C" void cgan_debug_set_gemm_fp16_auto(int v) { g_gemm_fp16_auto = v; }
 
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);

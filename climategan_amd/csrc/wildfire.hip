@@ -136,9 +136,75 @@ __device__ __forceinline__ int reflect101(int i, int n) {   // F.pad(mode="refle
   return i;
 }
 
-// one pass of the separable Gaussian (taps in `g`, ks of them), along x (axis 0) or y (axis 1), reflect border
-__global__ void wf_blur_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ g, int h,
-                               int w, int ks, int axis, long total) {
+// one pass of the separable Gaussian (taps in `g`, ks of them), along x (AXIS 0) or y (AXIS 1), reflect border.
+// A thread computes 8 consecutive outputs along the blur axis from ONE walk over their ks + 7 inputs: every input value
+// is loaded once and feeds up to 8 accumulators (the first version loaded ks = 301 inputs per output and ran at the L1
+// load rate: 710 us per pass at 16 x 640 x 640).  Each output still sums its taps in ascending k with one FMA per tap
+// (written as __builtin_fmaf: left to the vectoriser, "acc += tap * v" became v_pk_mul_f32 + v_pk_add_f32 on register
+// pairs whose other half was never written -- not the reference kernel's arithmetic, and on gfx950 the result then
+// depended on what the other half happened to hold: wrong values in every second output as soon as another stream's
+// kernels had used those registers), so the result is bit-identical to the one-output-per-thread form.
+template <int AXIS>
+__global__ __launch_bounds__(256) void wf_blur_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                      const float* __restrict__ g, int h, int w, int ks, long groups) {
+  extern __shared__ float gs[];
+  for (int i = threadIdx.x; i < ks; i += blockDim.x) gs[i] = g[i];
+  __syncthreads();
+  const int half = ks / 2;
+  const int ga = AXIS == 0 ? (w + 7) / 8 : w;          // fastest index: x groups (AXIS 0) or columns (AXIS 1)
+  const int gb = AXIS == 0 ? h : (h + 7) / 8;
+  const int ext = AXIS == 0 ? w : h;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % ga);
+    const long r = i / ga;
+    const int b = (int)(r % gb);
+    const long n = r / gb;
+    const float* base = in + n * (long)h * w;
+    const int x0 = AXIS == 0 ? a * 8 : a, y0 = AXIS == 0 ? b : b * 8;
+    const int p0 = (AXIS == 0 ? x0 : y0) - half;        // input position of (output 0, tap 0) along the axis
+    auto load = [&](int m) {
+      const int q = min(max(reflect101(p0 + m, ext), 0), ext - 1);     // (clamp: positions only a tail group's unused outputs reach)
+      return AXIS == 0 ? base[(long)y0 * w + q] : base[(long)q * w + x0];
+    };
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // output r uses input m with tap k = m - r
+    for (int m = 0; m < 7 && m < ks; ++m) {
+      const float v = load(m);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+        if (m - rr >= 0) acc[rr] = __builtin_fmaf(gs[m - rr], v, acc[rr]);
+    }
+    for (int m = 7; m < ks; ++m) {                       // all eight taps in range
+      const float v = load(m);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) acc[rr] = __builtin_fmaf(gs[m - rr], v, acc[rr]);
+    }
+    for (int m = max(ks, 7); m < ks + 7; ++m) {
+      const float v = load(m);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+        if (m - rr < ks) acc[rr] = __builtin_fmaf(gs[m - rr], v, acc[rr]);
+    }
+    if (AXIS == 0 && x0 + 8 <= w && (w & 3) == 0) {           // two 16-byte stores (x0 is a multiple of 8)
+      float* o = out + (n * h + y0) * (long)w + x0;
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        if (AXIS == 0) {
+          if (x0 + rr < w) out[(n * h + y0) * (long)w + x0 + rr] = acc[rr];
+        } else {
+          if (y0 + rr < h) out[(n * h + y0 + rr) * (long)w + x0] = acc[rr];
+        }
+      }
+    }
+  }
+}
+
+// the first version (one output per thread), kept behind cgan_debug_set_wf_blur(1) for the tests that compare the two
+__global__ void wf_blur_ref_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ g, int h,
+                                   int w, int ks, int axis, long total) {
   const int half = ks / 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % w);
@@ -155,6 +221,7 @@ __global__ void wf_blur_kernel(const float* __restrict__ in, float* __restrict__
     out[i] = acc;
   }
 }
+int g_wf_blur = 0;
 
 // paste_tensor(img, filter, mask, transparency) -> uint8 -> adjust_brightness(0.8) -> float, dummy corner pixels
 __global__ void wf_compose_kernel(const uint8_t* __restrict__ img, const float* __restrict__ mask,
@@ -200,6 +267,8 @@ __global__ void __launch_bounds__(1024) wf_taps_kernel(float* __restrict__ g, in
 inline unsigned grid1(long total) { return (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256); }
 
 }  // namespace
+
+extern "C" void cgan_debug_set_wf_blur(int v) { g_wf_blur = v; }
 
 extern "C" size_t cgan_wildfire_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t seg_h, int32_t seg_w,
                                                 int32_t kernel_size) {
@@ -263,10 +332,19 @@ extern "C" int cgan_wildfire_nchw(const float* x_nchw, const void* seg_nhwc, int
                      n_cols < 1 ? 1 : n_cols, ry, rx, tot);
   hipLaunchKernelGGL(wf_dilate_v_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const uint8_t*)dil, m0, h, w,
                      n_lines < 1 ? 1 : n_lines, tot);
-  hipLaunchKernelGGL(wf_blur_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const float*)m0, m1, (const float*)taps, h, w,
-                     kernel_size, 0, tot);
-  hipLaunchKernelGGL(wf_blur_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const float*)m1, m0, (const float*)taps, h, w,
-                     kernel_size, 1, tot);
+  if (g_wf_blur == 1) {
+    hipLaunchKernelGGL(wf_blur_ref_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const float*)m0, m1, (const float*)taps, h, w,
+                       kernel_size, 0, tot);
+    hipLaunchKernelGGL(wf_blur_ref_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const float*)m1, m0, (const float*)taps, h, w,
+                       kernel_size, 1, tot);
+  } else {
+  const long gx = (long)n * h * ((w + 7) / 8), gy = (long)n * ((h + 7) / 8) * w;     // 8 outputs per thread along the blur axis
+  const size_t taps_b = (size_t)kernel_size * sizeof(float);
+  hipLaunchKernelGGL(wf_blur_kernel<0>, dim3(grid1(gx)), dim3(256), taps_b, s, (const float*)m0, m1, (const float*)taps, h, w,
+                     kernel_size, gx);
+  hipLaunchKernelGGL(wf_blur_kernel<1>, dim3(grid1(gy)), dim3(256), taps_b, s, (const float*)m1, m0, (const float*)taps, h, w,
+                     kernel_size, gy);
+  }
   hipLaunchKernelGGL(wf_compose_kernel, dim3(grid1(tot)), dim3(256), 0, s, (const uint8_t*)img, (const float*)m0,
                      out_nchw, h, w, transparency, 255.f, filter_green, 0.f, 0.8f, tot);
   CGAN_CHECK_LAUNCH("wildfire");

@@ -12,6 +12,7 @@ schedulers (``get_optimizer``); ``update_G`` / ``update_D`` / ``train_step`` rep
 and the extrapolate / step schedule (trainer.py:674-694); ``save`` / ``resume`` / ``update_learning_rates`` are the
 checkpoint half (trainer.py:396-579): same file layout, same path rules.
 """
+import os
 import time
 
 import torch

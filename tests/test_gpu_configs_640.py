@@ -91,7 +91,11 @@ def test_apply_events_bs16_fp16_matches_reference_infer_all(infer_trainer):
     # --- independence of the samples: every repeat of an image gives the same bytes
     for k in ("flood", "wildfire", "smog", "mask"):
         for i in range(B, 16):
-            assert np.array_equal(out[k][i], out[k][i % B]), (k, i)
+            if not np.array_equal(out[k][i], out[k][i % B]):
+                d = np.argwhere(out[k][i] != out[k][i % B])
+                raise AssertionError("%s: sample %d differs from its original %d in %d values, index ranges %s .. %s, largest "
+                                     "difference %d" % (k, i, i % B, len(d), d.min(0).tolist(), d.max(0).tolist(),
+                                                        np.abs(out[k][i].astype(int) - out[k][i % B].astype(int)).max()))
 
     # --- the three uint8 events vs the reference's own uint8 images (crops, 8x pooled map, per-channel statistics)
     report = {}

@@ -276,3 +276,46 @@ def test_keep_ratio_flow():
         out = T.infer_all(x, numpy=True, bin_value=0.5)
         for k in ("flood", "wildfire", "smog"):
             assert out[k].shape == (1, nh, nw, 3) and out[k].dtype == np.uint8
+
+
+def test_wildfire_next_to_another_streams_kernels():
+    """The wildfire event on a batch of repeats while a second stream runs LDS-DMA / MFMA kernels (the flood painter of
+    ``infer_all`` does): every repeat must give the same bytes as its original, and the 8-outputs-per-thread blur must equal
+    the one-output-per-thread reference kernel bit for bit.  (Round 3: compiler-formed packed-fp32 operations on register
+    pairs with an undefined half made every second blur output depend on what other kernels had left in the registers;
+    fixed by explicit FMAs and -fno-slp-vectorize.)"""
+    import ctypes
+
+    from climategan_amd import _lib, ops
+
+    lib = _lib.load()
+    dt = torch.float16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x2 = torch.rand(2, 3, 640, 640, device="cuda", generator=g) * 2 - 1
+    s2 = torch.randn(2, 11, 160, 160, device="cuda", generator=g)
+    s2[:, 9, :60] += 3.0
+    x, seg = x2.repeat(8, 1, 1, 1), ops.nchw_to_nhwc(s2.repeat(8, 1, 1, 1), dt)
+    xg = ops.NHWC(torch.randn((16, 80, 80, 256), device="cuda", generator=g).to(dt), 256)
+    pwg = ops.pack_conv_weight(torch.randn(256, 256, 3, 3, device="cuda", generator=g) * 0.05, None, dt)
+    xc = ops.NHWC(torch.randn((16, 320, 320, 80), device="cuda", generator=g).to(dt), 80)
+    pwc = ops.pack_conv_weight(torch.randn(80, 80, 3, 3, device="cuda", generator=g) * 0.05, None, dt)
+    side = torch.cuda.Stream()
+    try:
+        lib.cgan_debug_set_wf_blur(ctypes.c_int(1))
+        ref = ops.wildfire(x, seg, 120.0, kernel_size=301, kernel_sigma=150.5)
+        lib.cgan_debug_set_wf_blur(ctypes.c_int(0))
+        for rep in range(3):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(6):
+                    ops.conv2d(xg, pwg, pad=1)              # wide-layer GEMM kernel (LDS-DMA + MFMA)
+                    ops.conv2d(xc, pwc, pad=1)              # 3x3 LDS kernel
+            out = ops.wildfire(x, seg, 120.0, kernel_size=301, kernel_sigma=150.5)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), rep
+            for i in range(2, 16):
+                assert torch.equal(out[i], out[i % 2]), (rep, i)
+    finally:
+        lib.cgan_debug_set_wf_blur(ctypes.c_int(0))
