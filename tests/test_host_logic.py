@@ -51,6 +51,24 @@ def test_host_side_validation_without_gpu(lib):
     assert lib.cgan_spectral_norm_workspace_bytes(640, 5760) == (20 * 5760 + 5760 + 640 + 4) * 4
 
 
+def test_rccl_entry_points_refuse_before_load(lib):
+    """The gradient-bucket collective of the C ABI loads RCCL at run time: before cgan_rccl_load has succeeded every entry
+    point fails with a message (no crash, no link-time dependency: this test runs on a box without a GPU), and a bad path
+    is an error."""
+    if lib.cgan_rccl_loaded():
+        pytest.skip("RCCL already loaded in this process")
+    buf = (ctypes.c_float * 4)()
+    comm = ctypes.c_void_p()
+    uid = ctypes.create_string_buffer(128)
+    assert lib.cgan_allreduce_bucket(buf, 4, 2, ctypes.c_void_p(1), None) != 0
+    assert b"cgan_rccl_load" in lib.cgan_last_error()
+    assert lib.cgan_comm_unique_id(uid) != 0
+    assert lib.cgan_comm_init_rank(ctypes.byref(comm), 1, uid, 0) != 0
+    assert lib.cgan_rccl_load(b"/nonexistent/librccl.so") != 0
+    assert b"dlopen" in lib.cgan_last_error()
+    assert lib.cgan_rccl_loaded() == 0
+
+
 def test_product_path_has_no_cpu_fallback():
     from climategan_amd import ops
 
