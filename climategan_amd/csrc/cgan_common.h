@@ -105,6 +105,22 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   return act == CGAN_ACT_TANH ? tanhf(v) : 1.f / (1.f + __expf(-v));
 }
 
+// the same on N values with the activation decided once per wave (uniform branches): NONE costs nothing; ReLU and LeakyReLU
+// with 0 <= slope <= 1 a fused multiply-add and a max per value -- max(v, slope v + 0) is the select's value for every v:
+// NaN propagates (NaN * s + 0 = NaN), the negative side of ReLU is +0 as in act_apply; everything else the general form
+template <int N>
+__device__ __forceinline__ void act_apply_n(float (&v)[N], int act, float slope) {
+  if (act == CGAN_ACT_NONE) return;
+  const float ns = act == CGAN_ACT_RELU ? 0.f : slope;
+  if (act <= CGAN_ACT_LRELU && ns >= 0.f && ns <= 1.f) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) v[r] = fmaxf(v[r], __builtin_fmaf(v[r], ns, 0.f));
+  } else {
+#pragma unroll
+    for (int r = 0; r < N; ++r) v[r] = act_apply(v[r], act, slope);
+  }
+}
+
 // F.interpolate(mode="nearest") legacy source index: min(floor(dst * scale), in - 1), scale = in / out in f32
 __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
   int s = (int)floorf((float)dst * scale);

@@ -160,8 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
             v[2 * e + 1] += r1;
           }
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = act_apply(v[r], p.act, p.slope);
+        act_apply_n(v, p.act, p.slope);
         if (p.cout < p.cout_s) {
 #pragma unroll
           for (int r = 0; r < 8; ++r)

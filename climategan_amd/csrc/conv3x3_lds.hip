@@ -79,8 +79,7 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
           unpack2<T>(rv[1], r2, r3);
           v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act, p.slope);
+        act_apply_n(v, p.act, p.slope);
         if (pad_c) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
