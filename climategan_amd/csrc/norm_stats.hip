@@ -6,6 +6,7 @@
 // (mean, M2) and merged with Chan's parallel formula across threads (LDS) and across blocks (finalize
 // kernel), so the variance never suffers the E[x^2] - E[x]^2 cancellation over 409 600 pixels.
 #include "cgan_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -207,26 +208,45 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __r
       m[e] = mean[(size_t)n * cs + cg * 8 + e];
       r[e] = rstd[(size_t)n * cs + cg * 8 + e];
     }
+    // what does not depend on the pixel is decided once per thread: pad channels in this group, a residual, the activation
+    // (act_apply_n: wave-uniform) -- the loop body is load, 8 x (unpack, subtract, fma), activation, pack, store
+    const bool pad = cg * 8 + 8 > c;
+    auto body = [&](auto res_tag) {
+      constexpr bool RES = decltype(res_tag)::value;
 #pragma unroll 2
-    for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
-      const size_t off = (size_t)p * cs + cg * 8;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(xn + off);
-      u32x4 rv = {0u, 0u, 0u, 0u};                        // 16-bit zeros: the residual term vanishes
-      if (rn) rv = *reinterpret_cast<const u32x4*>(rn + off);
-      u32x4 o;
+      for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
+        const size_t off = (size_t)p * cs + cg * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xn + off);
+        u32x4 rv = {0u, 0u, 0u, 0u};
+        if (RES) rv = *reinterpret_cast<const u32x4*>(rn + off);
+        float f[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a, b, ra, rb;
-        unpack2<T>(v[e], a, b);
-        unpack2<T>(rv[e], ra, rb);
-        a = act_apply((a - m[2 * e]) * r[2 * e] + ra, act, slope);
-        b = act_apply((b - m[2 * e + 1]) * r[2 * e + 1] + rb, act, slope);
-        if (cg * 8 + 2 * e >= c) a = 0.f;
-        if (cg * 8 + 2 * e + 1 >= c) b = 0.f;
-        o[e] = pack2<T>(a, b);
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          unpack2<T>(v[e], a, b);
+          f[2 * e] = (a - m[2 * e]) * r[2 * e];
+          f[2 * e + 1] = (b - m[2 * e + 1]) * r[2 * e + 1];
+          if (RES) {
+            float ra, rb;
+            unpack2<T>(rv[e], ra, rb);
+            f[2 * e] += ra;                    // (fused by the compiler into the multiply above: same rounding as before)
+            f[2 * e + 1] += rb;
+          }
+        }
+        act_apply_n(f, act, slope);
+        if (pad) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (cg * 8 + e >= c) f[e] = 0.f;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2<T>(f[2 * e], f[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(yn + off) = o;
       }
-      *reinterpret_cast<u32x4*>(yn + off) = o;
-    }
+    };
+    if (rn) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
