@@ -382,7 +382,9 @@ def assert_d_side(T, gold, case, name, config, tasks):
     # Yardstick (the same emulation run through update_D, jstep_640, dev container): D.p cos median 0.9907, D.s 0.9832,
     # D.m 0.9996.  All three see a generator that ExtraAdam has just moved by lr * g / (|g| + eps) ~ lr * sign(g) per
     # element, so sign flips of near-zero 16-bit generator gradients are part of their input noise.  Bound for D.p:
-    # (1 - cos) <= 2.5 x the yardstick's (measured 1.6 x), for D.s 1.4 x (measured 1.05 - 1.15 x).
+    # (1 - cos) <= 2.5 x the yardstick's (measured 1.6 x), for D.s 1.6 x: the value moves from run to run with the fp32
+    # atomics of the generator's bias gradients (they decide the sign ExtraAdam gives near-zero entries), round 3 measured
+    # cos median 0.9760 - 0.9809 over seven runs of the same build = 1.14 - 1.43 x (the 1.4 x of round 2 sat inside that band).
     # D.m is the one discriminator whose gradient is a small difference of two large terms: the real and the simulated
     # call push the weights in opposite directions (labels 1 / 0 on near-identical entropy maps; |g_r + g_s| = 0.17 |g_r|),
     # and each call runs on its own w_bar / sigma (one power iteration per call), ROUNDED TO bf16 for the MFMA -- a
@@ -395,7 +397,7 @@ def assert_d_side(T, gold, case, name, config, tasks):
     # test_forward_uses_the_parameters_the_optimizer_wrote.)
     # On the 128 x 160 fixture the seg discriminator sees 32 x 40 entropy maps and its last bias gradient is a +-0.25 / N
     # cancellation between the two domains that rounds to exactly 0: emulation 0.94, measured 0.906 - 0.918.
-    floors = ((("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 1 - 1.4 * (1 - 0.9677)), ("s.", 1 - 1.4 * (1 - 0.9832))) if name == "jstep_640" else
+    floors = ((("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 1 - 1.4 * (1 - 0.9677)), ("s.", 1 - 1.6 * (1 - 0.9832))) if name == "jstep_640" else
               (("p.", 0.985), ("m.", 0.98), ("s.", 0.89)))
     for grp, floor in floors:
         if not any(r[0].startswith(grp) for r in rows):
