@@ -829,6 +829,12 @@ def main():
         if n and args.conv_table:
             with open(args.conv_table, "w") as f:
                 f.write(timer.table(sampled) + "\n")
+            # the launches of the LAST bracketed step in launch order (tag, algorithmic bytes, microseconds): joined with the
+            # per-dispatch PMC rows of the same command by tools/pmc_by_class.py
+            per = n // sampled
+            with open(args.conv_table + ".launches", "w") as f:
+                for e0, e1, fl, nb, tag in timer.pairs[-per:]:
+                    f.write("%s\t%d\t%.1f\n" % (tag, nb, e0.elapsed_time(e1) * 1e3))
         res["config"]["two_stream_overlap"] = bool(overlap_default)
         res["losses_last_step"] = {k: round(v, 4) for k, v in losses.items()}
         res["max_mem_GB"] = round(mem_gb, 1)
