@@ -174,7 +174,6 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
       for (int c = 0; c < WC; ++c) {
         // of the values as stored (rounded), chunk mean first, then M2 = sum (v - mean)^2: see conv_gemm_kernel
         f32x2 vr[WP][2];
-        f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
 #pragma unroll
         for (int t = 0; t < WP; ++t) {
 #pragma unroll
@@ -182,16 +181,26 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
             float r0, r1;
             unpack2<T>(pack2<T>(acc[c][t][2 * hh], acc[c][t][2 * hh + 1]), r0, r1);
             vr[t][hh] = (f32x2){r0, r1};
-            s0[hh] += vr[t][hh];
           }
+        }
+        f32x2 s0[2] = {vr[0][0], vr[0][1]};      // (no "0 + v": that is a packed add with an op_sel-modified constant)
+#pragma unroll
+        for (int t = 1; t < WP; ++t) {
+          s0[0] += vr[t][0];
+          s0[1] += vr[t][1];
         }
         float mean[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) mean[r] = row16_sum_x(s0[r >> 1][r & 1]) * inv_cnt;
         const f32x2 m2[2] = {(f32x2){mean[0], mean[1]}, (f32x2){mean[2], mean[3]}};
-        f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+        f32x2 s1[2];
 #pragma unroll
-        for (int t = 0; t < WP; ++t)
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x2 dv = vr[0][hh] - m2[hh];
+          s1[hh] = dv * dv;
+        }
+#pragma unroll
+        for (int t = 1; t < WP; ++t)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             const f32x2 dv = vr[t][hh] - m2[hh];

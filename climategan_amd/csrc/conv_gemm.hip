@@ -217,7 +217,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
       // Two passes, pairs of channels on the packed-fp32 VALU path: the chunk mean first, then M2 = sum (v - mean)^2
       // (the one-pass form sum v^2 - (sum v)^2 / n cancels where the mean is large against the spread).
       f32x2 vr[WP][2];
-      f32x2 s0[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
 #pragma unroll
       for (int t = 0; t < WP; ++t) {
 #pragma unroll
@@ -225,16 +224,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
           float r0, r1;
           unpack2<T>(pack2<T>(acc[c][t][2 * hh], acc[c][t][2 * hh + 1]), r0, r1);
           vr[t][hh] = (f32x2){r0, r1};
-          s0[hh] += vr[t][hh];
         }
+      }
+      f32x2 s0[2] = {vr[0][0], vr[0][1]};      // (no "0 + v": that is a packed add with an op_sel-modified constant)
+#pragma unroll
+      for (int t = 1; t < WP; ++t) {
+        s0[0] += vr[t][0];
+        s0[1] += vr[t][1];
       }
       float sm[4], sq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) sm[r] = row16_sum(s0[r >> 1][r & 1]) * inv_cnt;     // the chunk mean, in every lane of the row
       const f32x2 m2[2] = {(f32x2){sm[0], sm[1]}, (f32x2){sm[2], sm[3]}};
-      f32x2 s1[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+      f32x2 s1[2];
 #pragma unroll
-      for (int t = 0; t < WP; ++t)
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x2 dv = vr[0][hh] - m2[hh];
+        s1[hh] = dv * dv;
+      }
+#pragma unroll
+      for (int t = 1; t < WP; ++t)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const f32x2 dv = vr[t][hh] - m2[hh];
