@@ -488,8 +488,8 @@ def cpu_baseline_train():
     # 2x slower on the step than 32 threads), and the fastest of those gets the remaining timed runs
     b1 = make_batch(1)
     cands = sorted(sweep, key=sweep.get)[:2]
-    if 32 <= phys and 32 not in cands:
-        cands.append(32)
+    if 32 <= phys:                       # 16 / 32 threads won on every host so far: warm up and start there
+        cands = [32] + [t for t in cands if t != 32]
     torch.set_num_threads(cands[0])
     warm = one_step(b1)
     by_threads = {}
