@@ -33,6 +33,7 @@ struct WgradArgs {
   int dbg;     // debug ablation bits (tools/bench_wgrad.py): 1 = skip the atomics, 2 = skip the MFMAs
   int reflect; // 1: nn.ReflectionPad2d(pad) in front of the conv (index math instead of the zero page)
   int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
+  unsigned long long* ts;   // development aid (tools/ts_wgrad.py): per-wave phase tick sums of the cooperative kernel
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -324,7 +325,7 @@ constexpr int CHUNK2 = 64;                       // pixels per stage
 constexpr int SUB2 = CHUNK2 * 128;               // one sub-slab: 64 pixels x 64 channels x 2 B = 8 KiB
 constexpr int STAGE2 = 4 * SUB2;                 // dy half 0 | dy half 1 | x tile 0 | x tile 1
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool TS = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -345,21 +346,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
     return cib < p.ci_blocks;
   };
 
-  // ---- staging role of this wave
+  // ---- staging: wave (mem, half) stages pieces half*4 .. half*4+3 (8 pixels each) of dy sub-slab `mem` (co half) AND of x
+  // sub-slab `mem` (N tile).  (The first version gave whole sub-slabs to the waves, dy to waves 0 / 1 and x to waves 2 / 3:
+  // an x piece cost ~4x a dy piece in issue time -- ~28 scalar instructions of coordinate carries per piece -- and the dy
+  // waves spent 40 % of their life at the barrier waiting for the x waves, tools/ts_wgrad.py.)
   const int prow = lane >> 3, qs = (lane & 7) ^ swz(prow), q8 = qs * 8;
-  const bool is_x = wave >= 2;
-  const int mem = wave & 1;
+  const int mem = wave >> 1, half = wave & 1;
   const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
   const int hx = MODE == 1 ? (p.h_in >> 1) : p.h_in, wx = MODE == 1 ? (p.w_in >> 1) : p.w_in;
   const unsigned row_b = (unsigned)wx * cin_b;
-  const __amdgpu_buffer_rsrc_t rs = is_x ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000)
-                                         : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
-  int lx = 0, ly = -(1 << 20);
-  unsigned lane_c = 0x80000000u, cch2 = 0;      // dy: lane constant (or the always-out-of-range marker); x, MODE 0: lane constant
-  if (!is_x) {
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  unsigned dy_c = 0x80000000u;                  // dy lane constant (or the always-out-of-range marker)
+  {
     const int co = (cop * 2 + mem) * 64 + q8;
-    if ((cop * 2 + mem) < p.co_blocks && co < p.cout_s) lane_c = (unsigned)prow * cout_b + (unsigned)co * 2u;
-  } else {
+    if ((cop * 2 + mem) < p.co_blocks && co < p.cout_s) dy_c = (unsigned)prow * cout_b + (unsigned)co * 2u;
+  }
+  int lx, ly;                                   // x: the lane's tap offset (lx far out of range for a dead lane)
+  unsigned cch2, x_c;
+  {
     int slot, cib, ky, kx, cch;
     bool ok = n_tile(mem, slot, cib);
     if (p.fold) {
@@ -376,24 +381,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
       ok = ok && cch < p.cin_s;
     }
     const int tap_y = ky * p.dil - p.pad, tap_x = kx * p.dil - p.pad;
-    lx = prow * p.stride + tap_x;
-    if (ok) ly = tap_y;
+    const int lxr = prow * p.stride + tap_x;
+    ly = tap_y;
+    lx = ok ? lxr : -(1 << 20);
     cch2 = (unsigned)cch * 2u;
-    lane_c = (unsigned)((tap_y * wx + lx) * (int)cin_b) + cch2;
+    x_c = (unsigned)((tap_y * wx + lxr) * (int)cin_b) + cch2;     // MODE 0: added to the piece's pixel offset
   }
 
-  // wave-uniform state of the 8 pieces (8 pixels each) of the next chunk to stage
-  int u_sx[8], u_sy[8], u_nh[8];
-  unsigned u_dy = (unsigned)(split * CHUNK2) * cout_b;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int pix = split * CHUNK2 + i * 8;
+  // coordinates of the 8 pieces of the next chunk to stage, piece i in lanes with (lane & 7) == i (every lane keeps one
+  // piece's state and one vector update per chunk advances all eight; the issue loop reads its pieces with v_readlane)
+  int v_sx, v_sy, v_nh;
+  {
+    const int pix = split * CHUNK2 + (lane & 7) * 8;
     const int r = pix / p.w_out;
-    u_sx[i] = (pix - r * p.w_out) * p.stride;
+    v_sx = (pix - r * p.w_out) * p.stride;
     const int nn = r / p.h_out;
-    u_sy[i] = (r - nn * p.h_out) * p.stride;
-    u_nh[i] = nn * hx;
+    v_sy = (r - nn * p.h_out) * p.stride;
+    v_nh = nn * hx;
   }
+  unsigned u_dy = (unsigned)(split * CHUNK2) * cout_b;
   const int step = p.splits * CHUNK2;
   const int step_r = step / p.w_out;
   const int step_sx = (step - step_r * p.w_out) * p.stride;
@@ -403,34 +409,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
   const int wrap_x = p.w_out * p.stride, wrap_y = p.h_out * p.stride;
   const unsigned step_dy = (unsigned)step * cout_b;
 
-  auto issue = [&](int b) {
-    unsigned char* dst = smem + b * STAGE2 + wave * SUB2;
-    if (!is_x) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
-                                                 u_dy + (unsigned)(i * 8) * cout_b + lane_c, 0, 0, 0);
-      u_dy += step_dy;
+  // piece k of the chunk to stage into buffer b: k < 4 the wave's dy pieces, k >= 4 its x pieces.  All eight are issued
+  // right after the chunk barrier, before the fragment reads: spreading them between the MFMA rows was tried and is slower
+  // (the MFMAs queue behind a piece's issue stall either way, and the pieces land later: l3 3x3 115 -> 125 us).
+  unsigned v_off = 0;
+  auto issue_piece = [&](int b, int k) {
+    unsigned char* dst = smem + b * STAGE2 + mem * SUB2 + half * 4096;
+    if (k < 4) {
+      const unsigned off = u_dy + (unsigned)((half * 4 + k) * 8) * cout_b + dy_c;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16,
+                                               off, 0, 0, 0);
       return;
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int iy = u_sy[i] + ly, ix = u_sx[i] + lx;
-      const bool xv = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
-      unsigned off;
-      if (MODE == 1) off = (unsigned)(u_nh[i] + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
-      else off = (unsigned)((u_nh[i] + u_sy[i]) * wx + u_sx[i]) * cin_b + lane_c;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
-                                               xv ? off : 0xffffffffu, 0, 0, 0);
-      int sx = u_sx[i] + step_sx, sy = u_sy[i] + step_sy, nh = u_nh[i] + step_nh;
-      const bool cx = sx >= wrap_x;
-      sx = cx ? sx - wrap_x : sx;
-      sy = cx ? sy + p.stride : sy;
-      const bool cy = sy >= wrap_y;
-      sy = cy ? sy - wrap_y : sy;
-      nh = cy ? nh + hx : nh;
-      u_sx[i] = sx; u_sy[i] = sy; u_nh[i] = nh;
-    }
+    const int j = k - 4, i = half * 4 + j;
+    if (j == 0) v_off = (unsigned)((v_nh + v_sy) * wx + v_sx) * cin_b;
+    const int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
+    const bool xv = ((unsigned)iy < (unsigned)p.h_in) & ((unsigned)ix < (unsigned)p.w_in);   // (no short-circuit branches)
+    unsigned off;
+    if (MODE == 1) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
+    else off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + x_c;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + 2 * SUB2 + j * 1024), 16,
+                                             xv ? off : 0xffffffffu, 0, 0, 0);
+  };
+  auto advance = [&]() {
+    u_dy += step_dy;
+    int sx = v_sx + step_sx, sy = v_sy + step_sy, nh = v_nh + step_nh;
+    const bool cx = sx >= wrap_x;
+    sx = cx ? sx - wrap_x : sx;
+    sy = cx ? sy + p.stride : sy;
+    const bool cy = sy >= wrap_y;
+    sy = cy ? sy - wrap_y : sy;
+    nh = cy ? nh + hx : nh;
+    v_sx = sx; v_sy = sy; v_nh = nh;
   };
 
   // ---- compute role: quadrant (co half wc, N tile wn)
@@ -443,11 +453,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
 
   const int nchunks = (p.npix + CHUNK2 - 1) / CHUNK2;
   int c = split, buf = 0;
-  if (c < nchunks) issue(0);
+  unsigned long long t_a = 0, t_b = 0, ts_sum[4] = {0, 0, 0, 0}, t_start = 0;
+  if (TS) t_start = __builtin_readcyclecounter();
+  if (c < nchunks) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) issue_piece(0, k);
+    advance();
+  }
   for (; c < nchunks; c += p.splits) {
+    if (TS) t_a = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces landed, own fragment reads done
+    if (TS) { t_b = __builtin_readcyclecounter(); ts_sum[0] += t_b - t_a; }
     __syncthreads();                                              // everyone's pieces landed; the other buffer is free
-    if (c + p.splits < nchunks) issue(buf ^ 1);
+    if (TS) { t_a = __builtin_readcyclecounter(); ts_sum[1] += t_a - t_b; }
+    if (c + p.splits < nchunks) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) issue_piece(buf ^ 1, k);
+      advance();
+    }
+    if (TS) { t_b = __builtin_readcyclecounter(); ts_sum[2] += t_b - t_a; }
     const unsigned char* sdy = smem + buf * STAGE2 + wc * SUB2;
     const unsigned char* sx = smem + buf * STAGE2 + (2 + wn) * SUB2;
 #pragma unroll
@@ -463,6 +487,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb[b]), acc[a][b]);
     }
     buf ^= 1;
+    if (TS) { t_a = __builtin_readcyclecounter(); ts_sum[3] += t_a - t_b; }
+  }
+  if (TS && p.ts && lane == 0) {
+    unsigned long long* o = p.ts + ((size_t)blockIdx.x * 4 + wave) * 8;
+    o[0] = t_start;
+    o[1] = __builtin_readcyclecounter();
+    for (int i = 0; i < 4; ++i) o[2 + i] = ts_sum[i];
+    o[6] = (unsigned long long)((nchunks - split + p.splits - 1) / p.splits);
   }
 
   // ---- the quadrant is a complete 64 x 64 tile of this pixel split
@@ -579,12 +611,15 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
 }
 
 int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768;
+unsigned long long* g_wgrad_ts = nullptr;
 }  // namespace
+
+extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
 
 extern "C" void cgan_debug_set_wgrad_coop_min_pixels(int v) { g_wgrad_coop_min_pix = v; }
 
 extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
-  g_wgrad_target = target_workgroups > 0 ? target_workgroups : 0;
+  g_wgrad_target = target_workgroups;          // > 0: target number of workgroups; < 0: -target pixel splits, as given
   g_wgrad_dbg = dbg;
 }
 
@@ -619,11 +654,31 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
                 ? 1 : 0;
   const int nchunks = (int)((npix + (pl.coop ? 63 : 127)) / (pl.coop ? 64 : 128));
   const long tiles = pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles();
-  // ~4 workgroups per CU for layers with many (tap, channel block) tiles or very long pixel ranges, ~2 otherwise
-  // (kernel durations by rocprofv3, tools/prof_wgrad.sh; 1x1 layers: ~2 workgroups per CU)
-  const int target = g_wgrad_target > 0 ? g_wgrad_target
-                                        : (taps == 1 && tiles < 512 ? 512 : ((tiles >= 512 || tiles <= 16) ? 2048 : 1024));
-  long splits = (target + tiles - 1) / tiles;
+  // Pixel splits.  Both kernels keep 64 KiB of LDS per workgroup, so 2 workgroups x 256 CUs = 512 run at a time and equal
+  // workgroups finish together: a grid of 513 takes twice as long as one of 512 (tools/sweep_wgrad_splits.py: SPADE
+  // gamma|beta gradient 128 -> 80 at 4 x 640^2, 56 splits = 504 workgroups 623 us, 57 splits 1101 us; the first planner
+  // aimed at "about 1024 / 2048 workgroups" and landed just past a multiple as often as not: layer3 3x3 118 -> 84 us,
+  // layer2 3x3 61 -> 32 us with the splits below).  Candidates: the largest split counts that still fit m rounds; cost in
+  // chunk times = rounds x (chunks per workgroup + ~2 for prologue / tile store) + workgroups x (partial tile written to
+  // and read back from the workspace), fitted to that sweep.
+  long splits;
+  if (g_wgrad_target > 0) {
+    splits = (g_wgrad_target + tiles - 1) / tiles;
+  } else if (g_wgrad_target < 0) {
+    splits = -g_wgrad_target;
+  } else {
+    const double t_ws = pl.coop ? 0.024 : 0.008;
+    double best = 1e30;
+    splits = 1;
+    for (int m = 0; m <= 8; ++m) {
+      long sp = m == 0 ? 1 : (512L * m) / tiles;
+      if (sp < 1) continue;
+      if (sp > nchunks) sp = nchunks;
+      const long wgs = sp * tiles;
+      const double cost = (double)((wgs + 511) / 512) * ((double)((nchunks + sp - 1) / sp) + 2.0) + (double)wgs * t_ws;
+      if (cost < best) { best = cost; splits = sp; }
+    }
+  }
   if (splits > nchunks) splits = nchunks;
   pl.splits = splits < 1 ? 1 : (int)splits;
   return pl;
@@ -670,6 +725,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   a.coop = pl.coop; a.co_pairs = pl.co_pairs; a.n_pairs = pl.n_pairs;
   const int taps = d->kh * d->kw;
   a.dbg = g_wgrad_dbg;
+  a.ts = g_wgrad_ts;
   const long items = (long)a.splits * (pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles());
   a.per_xcd = (int)((items + 7) / 8);
   CGAN_REQUIRE(items < (1L << 30), "conv2d_nhwc_bwd_weight: grid too large");
@@ -707,6 +763,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
       else hipLaunchKernelGGL((conv_wgrad_coop_kernel<F16, 0>), dim3(gx), dim3(256), smem, s, a);
     } else {
       if (mode == 1) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 1>), dim3(gx), dim3(256), smem, s, a);
+      else if (a.ts) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, true>), dim3(gx), dim3(256), smem, s, a);
       else hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0>), dim3(gx), dim3(256), smem, s, a);
     }
   } else if (d->dtype == CGAN_F16) WGRAD_MODE(F16); else WGRAD_MODE(BF16);

@@ -87,14 +87,14 @@ def test_conv_forward_dgrad_wgrad(dt, case):
     try:
         for name, dbg, coop_min, use_ws in variants:
             lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(dbg))
-            lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 262144))
+            lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 32768))
             dw, db = ops.conv2d_bwd_weight(xg, dyg, tuple(w.shape), stride=stride, pad=pad, dilation=dil,
                                            use_workspace=use_ws)
             assert rel_err(dw.cpu(), w.grad) <= 3e-4, "wgrad (%s)" % name
             assert rel_err(db.cpu(), b.grad) <= 3e-4, "bias grad (%s)" % name
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
-        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(262144))
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
 
 
 def draw_mode_cases(n, seed):
@@ -134,7 +134,7 @@ def test_wgrad_upsample_and_reflect_modes(dt, case):
     try:
         for dbg, coop_min in ((0, -1), (16, -1), (0, 0)):
             lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(dbg))
-            lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 262144))
+            lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 32768))
             dw, _ = ops.conv2d_bwd_weight(xg, ops.nchw_to_nhwc(dy.cuda(), dt), (cout, cin, 3, 3), pad=1, want_bias=False,
                                           in_upsample=True)
             assert rel_err(dw.cpu(), ref_up) <= 3e-4, ("upsample", dbg, coop_min)
@@ -144,7 +144,7 @@ def test_wgrad_upsample_and_reflect_modes(dt, case):
                 assert rel_err(dw.cpu(), ref_rf) <= 3e-4, ("reflect", dbg, coop_min)
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
-        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(262144))
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
 
 
 WS_CASES = [
