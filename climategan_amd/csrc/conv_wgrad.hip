@@ -163,19 +163,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int wrap_x = p.w_out * p.stride, wrap_y = p.h_out * p.stride;
   const unsigned step_dy = (unsigned)step * cout_b;
 
-  // ---- UNI: per-piece state from wave-uniform values only (row 0 of the piece), per-lane constants on top
-  int u_sx[4], u_sy[4], u_nh[4];
-  unsigned u_dy[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pix = split * 128 + wave * 32 + i * 8;
+  // ---- UNI: per-piece state from wave-uniform values only (row 0 of the piece), per-lane constants on top.  The four
+  // pieces' coordinates live in the lanes with (lane & 3) == i: ONE vector update per chunk advances all of them and the
+  // issue loop fetches a piece's values with v_readlane (the first version kept them in scalar registers: ~28 scalar
+  // instructions of carries per piece, more issue time than the chunk's 16 MFMAs -- see the cooperative kernel)
+  int v_sx, v_sy, v_nh;
+  {
+    const int pix = split * 128 + wave * 32 + (lane & 3) * 8;
     const int r = pix / p.w_out;
-    u_sx[i] = (pix - r * p.w_out) * p.stride;
+    v_sx = (pix - r * p.w_out) * p.stride;
     const int nn = r / p.h_out;
-    u_sy[i] = (r - nn * p.h_out) * p.stride;
-    u_nh[i] = nn * hx;
-    u_dy[i] = (unsigned)pix * cout_b;
+    v_sy = (r - nn * p.h_out) * p.stride;
+    v_nh = nn * hx;
   }
+  unsigned u_dy0 = (unsigned)(split * 128 + wave * 32) * cout_b;
   const int lx = prow * p.stride + tap_x;
   const int ly = ci_ok ? tap_y : -(1 << 20);                    // a lane without a tap / channel chunk is always out of bounds
   const unsigned lane_dyc = co_ok ? (unsigned)prow * cout_b + (unsigned)(co0 + q8) * 2u : 0x80000000u;   // dy_bytes < 2^31
@@ -186,31 +187,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     unsigned char* dst_dy = wl + b * 2 * SLAB_BYTES;
     unsigned char* dst_x = dst_dy + SLAB_BYTES;
     if constexpr (UNI) {
+      const unsigned v_off = (unsigned)((v_nh + v_sy) * wx + v_sx) * cin_b;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         // pixels past the end: the dy offset is out of range by itself (zeros), which also neutralises whatever x holds
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16,
-                                                 u_dy[i] + lane_dyc, 0, 0, 0);
-        const int iy = u_sy[i] + ly, ix = u_sx[i] + lx;
-        const bool xv = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+                                                 u_dy0 + (unsigned)(i * 8) * cout_b + lane_dyc, 0, 0, 0);
+        const int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
+        const bool xv = ((unsigned)iy < (unsigned)p.h_in) & ((unsigned)ix < (unsigned)p.w_in);
         unsigned off;
         if (MODE == 1) {
-          off = (unsigned)(u_nh[i] + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
+          off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
         } else {
-          off = (unsigned)((u_nh[i] + u_sy[i]) * wx + u_sx[i]) * cin_b + lane_xc;   // scalar part + lane constant
+          off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + lane_xc;   // piece part + lane constant
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16,
                                                  xv ? off : 0xffffffffu, 0, 0, 0);
-        u_dy[i] += step_dy;
-        int sx = u_sx[i] + step_sx, sy = u_sy[i] + step_sy, nh = u_nh[i] + step_nh;
-        const bool cx = sx >= wrap_x;
-        sx = cx ? sx - wrap_x : sx;
-        sy = cx ? sy + p.stride : sy;
-        const bool cy = sy >= wrap_y;
-        sy = cy ? sy - wrap_y : sy;
-        nh = cy ? nh + hx : nh;
-        u_sx[i] = sx; u_sy[i] = sy; u_nh[i] = nh;
       }
+      u_dy0 += step_dy;
+      int sx = v_sx + step_sx, sy = v_sy + step_sy, nh = v_nh + step_nh;
+      const bool cx = sx >= wrap_x;
+      sx = cx ? sx - wrap_x : sx;
+      sy = cx ? sy + p.stride : sy;
+      const bool cy = sy >= wrap_y;
+      sy = cy ? sy - wrap_y : sy;
+      nh = cy ? nh + hx : nh;
+      v_sx = sx; v_sy = sy; v_nh = nh;
       return;
     }
 #pragma unroll
