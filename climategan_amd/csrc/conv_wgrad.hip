@@ -323,12 +323,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 // One barrier per chunk; a wave's quadrant is a complete tile (no cross-wave reduction).  Needs 4x the pixel splits of
 // the single-wave kernel for the same number of workgroups, i.e. 4x the partial-tile workspace: only layers with
 // enough pixels per split use it (wgrad_plan).
-constexpr int CHUNK2 = 64;                       // pixels per stage
-constexpr int SUB2 = CHUNK2 * 128;               // one sub-slab: 64 pixels x 64 channels x 2 B = 8 KiB
-constexpr int STAGE2 = 4 * SUB2;                 // dy half 0 | dy half 1 | x tile 0 | x tile 1
+// CH = pixels per stage (64 or 32); a sub-slab is CH pixels x 64 channels x 2 B; a stage = dy half 0 | dy half 1 |
+// x tile 0 | x tile 1; two stages: 64 KiB (2 workgroups per CU) or 32 KiB (4 per CU) of LDS.
 
-template <typename T, int MODE, bool TS = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
+template <typename T, int MODE, int CH = 64, bool TS = false>
+__global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(WgradArgs p) {
+  constexpr int CHUNK2 = CH, SUB2 = CH * 128, STAGE2 = 4 * SUB2;
+  constexpr int PPS = CH / 8, PW = PPS / 2;      // pieces per sub-slab, pieces of each operand a wave stages
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
   // piece's state and one vector update per chunk advances all eight; the issue loop reads its pieces with v_readlane)
   int v_sx, v_sy, v_nh;
   {
-    const int pix = split * CHUNK2 + (lane & 7) * 8;
+    const int pix = split * CHUNK2 + (lane & (PPS - 1)) * 8;
     const int r = pix / p.w_out;
     v_sx = (pix - r * p.w_out) * p.stride;
     const int nn = r / p.h_out;
@@ -411,19 +412,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
   const int wrap_x = p.w_out * p.stride, wrap_y = p.h_out * p.stride;
   const unsigned step_dy = (unsigned)step * cout_b;
 
-  // piece k of the chunk to stage into buffer b: k < 4 the wave's dy pieces, k >= 4 its x pieces.  All eight are issued
+  // piece k of the chunk to stage into buffer b: k < PW the wave's dy pieces, k >= PW its x pieces.  All are issued
   // right after the chunk barrier, before the fragment reads: spreading them between the MFMA rows was tried and is slower
   // (the MFMAs queue behind a piece's issue stall either way, and the pieces land later: l3 3x3 115 -> 125 us).
   unsigned v_off = 0;
   auto issue_piece = [&](int b, int k) {
-    unsigned char* dst = smem + b * STAGE2 + mem * SUB2 + half * 4096;
-    if (k < 4) {
-      const unsigned off = u_dy + (unsigned)((half * 4 + k) * 8) * cout_b + dy_c;
+    unsigned char* dst = smem + b * STAGE2 + mem * SUB2 + half * (PW * 1024);
+    if (k < PW) {
+      const unsigned off = u_dy + (unsigned)((half * PW + k) * 8) * cout_b + dy_c;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16,
                                                off, 0, 0, 0);
       return;
     }
-    const int j = k - 4, i = half * 4 + j;
+    const int j = k - PW, i = half * PW + j;
     if (j == 0) v_off = (unsigned)((v_nh + v_sy) * wx + v_sx) * cin_b;
     const int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
     const bool xv = ((unsigned)iy < (unsigned)p.h_in) & ((unsigned)ix < (unsigned)p.w_in);   // (no short-circuit branches)
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
   if (TS) t_start = __builtin_readcyclecounter();
   if (c < nchunks) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) issue_piece(0, k);
+    for (int k = 0; k < 2 * PW; ++k) issue_piece(0, k);
     advance();
   }
   for (; c < nchunks; c += p.splits) {
@@ -470,14 +471,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_coop_kernel(WgradArgs p) {
     if (TS) { t_a = __builtin_readcyclecounter(); ts_sum[1] += t_a - t_b; }
     if (c + p.splits < nchunks) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) issue_piece(buf ^ 1, k);
+      for (int k = 0; k < 2 * PW; ++k) issue_piece(buf ^ 1, k);
       advance();
     }
     if (TS) { t_b = __builtin_readcyclecounter(); ts_sum[2] += t_b - t_a; }
     const unsigned char* sdy = smem + buf * STAGE2 + wc * SUB2;
     const unsigned char* sx = smem + buf * STAGE2 + (2 + wn) * SUB2;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < CH / 32; ++ks) {
       u32x4 fa[4], fb[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) fa[a] = tr_frag(sdy + ks * 32 * 128, a, lane);
@@ -612,11 +613,12 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
-int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768;
+int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768, g_wgrad_coop_chunk = 0;
 unsigned long long* g_wgrad_ts = nullptr;
 }  // namespace
 
 extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
+extern "C" void cgan_debug_set_wgrad_coop_chunk(int v) { g_wgrad_coop_chunk = (v == 32 || v == 64) ? v : 0; }   // 0: automatic
 
 extern "C" void cgan_debug_set_wgrad_coop_min_pixels(int v) { g_wgrad_coop_min_pix = v; }
 
@@ -628,7 +630,7 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
 // Tiling of one weight-gradient call: N tiles (tap slots x ci blocks), M tiles (co blocks), pixel splits.
 struct WgradPlan {
   int fold, cpt, tpt, tap_slots, ci_blocks, co_blocks, splits;
-  int coop, co_pairs, n_pairs;
+  int coop, co_pairs, n_pairs, chunk;   // chunk: pixels per stage of the cooperative kernel (64 / 32)
   long tiles() const { return (long)tap_slots * ci_blocks * co_blocks; }
 };
 
@@ -654,32 +656,48 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
              d->pad_mode != CGAN_PAD_REFLECT && (g_wgrad_dbg & 8) == 0 && (double)npix * cgan_cs(d->c_out) * 2.0 < 1.9e9 &&
              (npix >= (long)g_wgrad_coop_min_pix || pl.tiles() >= 256))
                 ? 1 : 0;
-  const int nchunks = (int)((npix + (pl.coop ? 63 : 127)) / (pl.coop ? 64 : 128));
   const long tiles = pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles();
-  // Pixel splits.  Both kernels keep 64 KiB of LDS per workgroup, so 2 workgroups x 256 CUs = 512 run at a time and equal
-  // workgroups finish together: a grid of 513 takes twice as long as one of 512 (tools/sweep_wgrad_splits.py: SPADE
-  // gamma|beta gradient 128 -> 80 at 4 x 640^2, 56 splits = 504 workgroups 623 us, 57 splits 1101 us; the first planner
-  // aimed at "about 1024 / 2048 workgroups" and landed just past a multiple as often as not: layer3 3x3 118 -> 84 us,
-  // layer2 3x3 61 -> 32 us with the splits below).  Candidates: the largest split counts that still fit m rounds; cost in
-  // chunk times = rounds x (chunks per workgroup + ~2 for prologue / tile store) + workgroups x (partial tile written to
-  // and read back from the workspace), fitted to that sweep.
-  long splits;
-  if (g_wgrad_target > 0) {
-    splits = (g_wgrad_target + tiles - 1) / tiles;
-  } else if (g_wgrad_target < 0) {
-    splits = -g_wgrad_target;
-  } else {
-    const double t_ws = pl.coop ? 0.024 : 0.008;
-    double best = 1e30;
-    splits = 1;
-    for (int m = 0; m <= 8; ++m) {
-      long sp = m == 0 ? 1 : (512L * m) / tiles;
-      if (sp < 1) continue;
-      if (sp > nchunks) sp = nchunks;
-      const long wgs = sp * tiles;
-      const double cost = (double)((wgs + 511) / 512) * ((double)((nchunks + sp - 1) / sp) + 2.0) + (double)wgs * t_ws;
-      if (cost < best) { best = cost; splits = sp; }
+  // Pixel splits.  The single-wave kernel and the cooperative kernel with 64-pixel stages keep 64 KiB of LDS per
+  // workgroup, so 2 workgroups x 256 CUs = 512 run at a time and equal workgroups finish together: a grid of 513 takes
+  // twice as long as one of 512 (tools/sweep_wgrad_splits.py: SPADE gamma|beta gradient 128 -> 80 at 4 x 640^2, 56 splits
+  // = 504 workgroups 623 us, 57 splits 1101 us; the first planner aimed at "about 1024 / 2048 workgroups" and landed just
+  // past a multiple as often as not: layer3 3x3 118 -> 84 us, layer2 3x3 61 -> 32 us with the splits below).
+  // Candidates: the largest split counts that still fit m rounds; cost in chunk times = rounds x (chunks per workgroup
+  // + ~2 for prologue / tile store) + workgroups x (partial tile written to and read back from the workspace), fitted
+  // to that sweep.
+  auto plan_splits = [&](int chunk, long slots, int& nchunks_out) {
+    const int nchunks = (int)((npix + chunk - 1) / chunk);
+    nchunks_out = nchunks;
+    long sp_best = 1;
+    if (g_wgrad_target > 0) {
+      sp_best = (g_wgrad_target + tiles - 1) / tiles;
+    } else if (g_wgrad_target < 0) {
+      sp_best = -g_wgrad_target;
+    } else {
+      const double t_ws = pl.coop ? 0.024 : 0.008;
+      double best = 1e30;
+      for (int m = 0; m <= 8; ++m) {
+        long sp = m == 0 ? 1 : (slots * m) / tiles;
+        if (sp < 1) continue;
+        if (sp > nchunks) sp = nchunks;
+        const long wgs = sp * tiles;
+        const double cost = (double)((wgs + slots - 1) / slots) * ((double)((nchunks + sp - 1) / sp) + 2.0) + (double)wgs * t_ws;
+        if (cost < best) { best = cost; sp_best = sp; }
+      }
     }
+    if (sp_best > nchunks) sp_best = nchunks;
+    return sp_best < 1 ? 1L : sp_best;
+  };
+  int nchunks = 0;
+  pl.chunk = pl.coop ? 64 : 128;
+  long splits = plan_splits(pl.chunk, 512, nchunks);
+  // cooperative kernel with 32-pixel stages (32 KiB of LDS, 4 workgroups per CU = 1024 at a time): pays on long pixel
+  // ranges (ASPP 3x3 2048 -> 256: 612 -> 583 us, SPADE gamma|beta 128 -> 80 at 4 x 640^2: 586 -> 550 us, layer4) and
+  // costs on short ones (layer3 1x1: 45 -> 53 us, layer2 3x3: 31 -> 40 us): taken from ~100 64-pixel chunks per
+  // workgroup on
+  if (pl.coop && (g_wgrad_coop_chunk == 32 || (g_wgrad_coop_chunk == 0 && nchunks / splits >= 96))) {
+    pl.chunk = 32;
+    splits = plan_splits(32, 1024, nchunks);
   }
   if (splits > nchunks) splits = nchunks;
   pl.splits = splits < 1 ? 1 : (int)splits;
@@ -759,15 +777,20 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     else { if (uni) WGRAD_LAUNCH(TT, 0, true); else WGRAD_LAUNCH(TT, 0, false); }                \
   } while (0)
   if (pl.coop) {
-    static_assert(2 * STAGE2 == 4 * WAVE_LDS, "both kernels use 64 KiB of LDS");
-    if (d->dtype == CGAN_F16) {
-      if (mode == 1) hipLaunchKernelGGL((conv_wgrad_coop_kernel<F16, 1>), dim3(gx), dim3(256), smem, s, a);
-      else hipLaunchKernelGGL((conv_wgrad_coop_kernel<F16, 0>), dim3(gx), dim3(256), smem, s, a);
-    } else {
-      if (mode == 1) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 1>), dim3(gx), dim3(256), smem, s, a);
-      else if (a.ts) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, true>), dim3(gx), dim3(256), smem, s, a);
-      else hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0>), dim3(gx), dim3(256), smem, s, a);
-    }
+    const size_t smem2 = (size_t)2 * 4 * pl.chunk * 128;
+#define COOP_LAUNCH(TT, MM, CC) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC>), dim3(gx), dim3(256), smem2, s, a)
+#define COOP_MODE(TT)                                                                       \
+  do {                                                                                      \
+    if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32); else COOP_LAUNCH(TT, 0, 32); } \
+    else { if (mode == 1) COOP_LAUNCH(TT, 1, 64); else COOP_LAUNCH(TT, 0, 64); }            \
+  } while (0)
+    if (a.ts && d->dtype == CGAN_BF16 && mode == 0) {
+      if (pl.chunk == 32) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 32, true>), dim3(gx), dim3(256), smem2, s, a);
+      else hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 64, true>), dim3(gx), dim3(256), smem2, s, a);
+    } else if (d->dtype == CGAN_F16) COOP_MODE(F16);
+    else COOP_MODE(BF16);
+#undef COOP_MODE
+#undef COOP_LAUNCH
   } else if (d->dtype == CGAN_F16) WGRAD_MODE(F16); else WGRAD_MODE(BF16);
 #undef WGRAD_MODE
 #undef WGRAD_LAUNCH

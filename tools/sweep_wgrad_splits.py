@@ -31,6 +31,9 @@ SHAPES = [
     ("D 4x4 s2 256->512 n4 80", 256, 512, 4, 2, 1, 1, 4, 80, 64),
 ]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 0           # cooperative kernel: pixels per stage (64 / 32; 0 = the planner decides)
+lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(chunk))
+slots = 1024 if chunk == 32 else 512
 for name, cin, cout, k, stride, pad, dil, bs, H, tiles in SHAPES:
     if only not in name:
         continue
@@ -55,8 +58,8 @@ for name, cin, cout, k, stride, pad, dil, bs, H, tiles in SHAPES:
     lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
     base = timed()
     out = []
-    cands = sorted({max(1, round(f * 512 / tiles)) for f in (0.5, 1, 1.5, 2, 3, 4, 6, 8)} |
-                   {max(1, (m * 512) // tiles) for m in (1, 2, 3, 4, 6, 8)})
+    cands = sorted({max(1, round(f * slots / tiles)) for f in (0.5, 1, 1.5, 2, 3, 4)} |
+                   {max(1, (m * slots) // tiles) for m in (1, 2, 3, 4, 6)})
     for sp in cands:
         lib.cgan_debug_set_wgrad(ctypes.c_int(-sp), ctypes.c_int(0))
         out.append((sp, timed()))
