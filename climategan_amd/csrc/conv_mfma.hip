@@ -512,7 +512,8 @@ void launch(const ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
-// development knob: 1 = always use the general gather kernel, 2 = never use the wide-layer GEMM kernel
+// development knob: 1 = always use the general gather kernel, 2 = never use the wide-layer GEMM kernel, 3 = the GEMM
+// kernel also where the spatially tiled 3x3 kernel would be preferred
 // (A/B measurements, parity tests of every kernel)
 int g_conv_force = 0;
 extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; }
@@ -562,8 +563,8 @@ extern "C" int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device,
 // kernel selection shared by the forward and the stride-1 data-gradient entry points
 static int select_conv_kernel(const ConvParams& p, const CganConvDesc* d) {
   // narrow 3x3 / stride-1 layers (< 256 channels in) are faster in the spatially tiled 3x3 kernel (halo reuse in LDS)
-  const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256;
-  if (g_conv_force == 0 && p.in_zs == 1 && !prefer_3x3 && conv_gemm_applicable(d)) return CGAN_CONV_KERNEL_GEMM;
+  const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256 && g_conv_force != 3;
+  if ((g_conv_force == 0 || g_conv_force == 3) && p.in_zs == 1 && !prefer_3x3 && conv_gemm_applicable(d)) return CGAN_CONV_KERNEL_GEMM;
   if (g_conv_force != 1 && p.in_zs == 1 && conv3x3_lds_applicable(d)) return CGAN_CONV_KERNEL_LDS3X3;
   return CGAN_CONV_KERNEL_GENERAL;
 }

@@ -82,11 +82,16 @@ def test_conv_forward_dgrad_wgrad(dt, case):
     # weight / bias gradient under every path selector: default; no tap folding; per-lane addressing; cooperative tile
     # forced on small shapes; workspace-free atomic reduction
     lib = _lib.load()
-    variants = [("default", 0, -1, True), ("no fold", 4, -1, True), ("per-lane addressing", 16, -1, True),
-                ("cooperative tile", 0, 0, True), ("single-wave tile", 8, -1, True), ("atomic reduction", 0, -1, False)]
+    # (name, debug bits, cooperative-tile pixel threshold, workspace, cooperative stage pixels, forced pixel splits)
+    variants = [("default", 0, -1, True, 0, 0), ("no fold", 4, -1, True, 0, 0), ("per-lane addressing", 16, -1, True, 0, 0),
+                ("cooperative tile", 0, 0, True, 64, 0), ("cooperative tile, 32-pixel stages", 0, 0, True, 32, 0),
+                ("cooperative tile, 32-pixel stages, 3 splits", 0, 0, True, 32, 3), ("one split", 0, -1, True, 0, 1),
+                ("5 splits", 0, -1, True, 0, 5), ("single-wave tile", 8, -1, True, 0, 0),
+                ("atomic reduction", 0, -1, False, 0, 0), ("atomic reduction, cooperative tile", 0, 0, False, 32, 2)]
     try:
-        for name, dbg, coop_min, use_ws in variants:
-            lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(dbg))
+        for name, dbg, coop_min, use_ws, chunk, splits in variants:
+            lib.cgan_debug_set_wgrad(ctypes.c_int(-splits), ctypes.c_int(dbg))
+            lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(chunk))
             lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 32768))
             dw, db = ops.conv2d_bwd_weight(xg, dyg, tuple(w.shape), stride=stride, pad=pad, dilation=dil,
                                            use_workspace=use_ws)
@@ -94,6 +99,7 @@ def test_conv_forward_dgrad_wgrad(dt, case):
             assert rel_err(db.cpu(), b.grad) <= 3e-4, "bias grad (%s)" % name
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
 
 
@@ -132,8 +138,9 @@ def test_wgrad_upsample_and_reflect_modes(dt, case):
         ref_rf = wt.grad.clone()
     xg = ops.nchw_to_nhwc(xs.cuda(), dt)
     try:
-        for dbg, coop_min in ((0, -1), (16, -1), (0, 0)):
+        for dbg, coop_min, chunk in ((0, -1, 0), (16, -1, 0), (0, 0, 64), (0, 0, 32)):
             lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(dbg))
+            lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(chunk))
             lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(coop_min if coop_min >= 0 else 32768))
             dw, _ = ops.conv2d_bwd_weight(xg, ops.nchw_to_nhwc(dy.cuda(), dt), (cout, cin, 3, 3), pad=1, want_bias=False,
                                           in_upsample=True)
@@ -144,6 +151,7 @@ def test_wgrad_upsample_and_reflect_modes(dt, case):
                 assert rel_err(dw.cpu(), ref_rf) <= 3e-4, ("reflect", dbg, coop_min)
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
 
 

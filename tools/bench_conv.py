@@ -29,6 +29,12 @@ SHAPES = [
     ("painter 3x3 160->160 @80", 160, 160, 3, 1, 1, 1, 80),
     ("painter 3x3 320->320 @40", 320, 320, 3, 1, 1, 1, 40),
     ("seg 3x3 256->256 @82", 256, 256, 3, 1, 1, 1, 82),
+    ("vgg 3x3 64->64 @640", 64, 64, 3, 1, 1, 1, 640),
+    ("vgg 3x3 64->128 @320", 64, 128, 3, 1, 1, 1, 320),
+    ("vgg 3x3 128->128 @320", 128, 128, 3, 1, 1, 1, 320),
+    ("vgg 3x3 128->256 @160", 128, 256, 3, 1, 1, 1, 160),
+    ("spade gb 3x3 128->80 @640", 128, 80, 3, 1, 1, 1, 640),
+    ("spade gb 3x3 128->160 @320", 128, 160, 3, 1, 1, 1, 320),
 ]
 
 
