@@ -613,11 +613,12 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
-int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768, g_wgrad_coop_chunk = 0;
+int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768, g_wgrad_coop_chunk = 0, g_wgrad_slots = 512;
 unsigned long long* g_wgrad_ts = nullptr;
 }  // namespace
 
 extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
+extern "C" void cgan_debug_set_wgrad_slots(int v) { g_wgrad_slots = v > 0 ? v : 512; }   // resident workgroups the planner assumes
 extern "C" void cgan_debug_set_wgrad_coop_chunk(int v) { g_wgrad_coop_chunk = (v == 32 || v == 64) ? v : 0; }   // 0: automatic
 
 extern "C" void cgan_debug_set_wgrad_coop_min_pixels(int v) { g_wgrad_coop_min_pix = v; }
@@ -690,14 +691,14 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
   };
   int nchunks = 0;
   pl.chunk = pl.coop ? 64 : 128;
-  long splits = plan_splits(pl.chunk, 512, nchunks);
+  long splits = plan_splits(pl.chunk, g_wgrad_slots, nchunks);
   // cooperative kernel with 32-pixel stages (32 KiB of LDS, 4 workgroups per CU = 1024 at a time): pays on long pixel
   // ranges (ASPP 3x3 2048 -> 256: 612 -> 583 us, SPADE gamma|beta 128 -> 80 at 4 x 640^2: 586 -> 550 us, layer4) and
   // costs on short ones (layer3 1x1: 45 -> 53 us, layer2 3x3: 31 -> 40 us): taken from ~100 64-pixel chunks per
   // workgroup on
   if (pl.coop && (g_wgrad_coop_chunk == 32 || (g_wgrad_coop_chunk == 0 && nchunks / splits >= 96))) {
     pl.chunk = 32;
-    splits = plan_splits(32, 1024, nchunks);
+    splits = plan_splits(32, 2 * g_wgrad_slots, nchunks);
   }
   if (splits > nchunks) splits = nchunks;
   pl.splits = splits < 1 ? 1 : (int)splits;
