@@ -193,11 +193,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         // pixels past the end: the dy offset is out of range by itself (zeros), which also neutralises whatever x holds
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16,
                                                  u_dy0 + (unsigned)(i * 8) * cout_b + lane_dyc, 0, 0, 0);
-        const int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
+        int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
+        if (MODE == 2) {      // nn.ReflectionPad2d: mirror without repeating the border (a dead lane stays out of range)
+          iy = iy < 0 ? -iy : (iy >= p.h_in ? 2 * p.h_in - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= p.w_in ? 2 * p.w_in - 2 - ix : ix);
+        }
         const bool xv = ((unsigned)iy < (unsigned)p.h_in) & ((unsigned)ix < (unsigned)p.w_in);
         unsigned off;
         if (MODE == 1) {
           off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
+        } else if (MODE == 2) {
+          off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + iy) * row_b + (unsigned)ix * cin_b + cch2;
         } else {
           off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + lane_xc;   // piece part + lane constant
         }
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Cooperative variant for large-pixel layers (w_out % 8 == 0, zero padding or folded upsample): one workgroup = a
+// Cooperative variant for large-pixel layers (w_out % 8 == 0; zero or reflect padding, folded upsample): one workgroup = a
 // 128 co x 128 column tile (2 co blocks x 2 N tiles), the four waves each own a 64 x 64 quadrant and SHARE the staged
 // slabs: per 64-pixel chunk wave 0 / 1 stage the dy slab of co half 0 / 1, wave 2 / 3 the x slab of N tile 0 / 1 (8 KiB
 // each), then every wave reads one dy and one x slab: 32 KiB of L2 -> LDS traffic per 128 MFMAs instead of per 64.
@@ -426,10 +432,15 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
     }
     const int j = k - PW, i = half * PW + j;
     if (j == 0) v_off = (unsigned)((v_nh + v_sy) * wx + v_sx) * cin_b;
-    const int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
+    int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
+    if (MODE == 2) {          // nn.ReflectionPad2d (a dead lane stays out of range)
+      iy = iy < 0 ? -iy : (iy >= p.h_in ? 2 * p.h_in - 2 - iy : iy);
+      ix = ix < 0 ? -ix : (ix >= p.w_in ? 2 * p.w_in - 2 - ix : ix);
+    }
     const bool xv = ((unsigned)iy < (unsigned)p.h_in) & ((unsigned)ix < (unsigned)p.w_in);   // (no short-circuit branches)
     unsigned off;
     if (MODE == 1) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
+    else if (MODE == 2) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + iy) * row_b + (unsigned)ix * cin_b + cch2;
     else off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + x_c;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + 2 * SUB2 + j * 1024), 16,
                                              xv ? off : 0xffffffffu, 0, 0, 0);
@@ -647,14 +658,13 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
   pl.tap_slots = pl.fold ? ceil_div(taps, pl.tpt) : taps;
   pl.ci_blocks = pl.fold ? 1 : ceil_div(cin_s, 64);
   const long npix = (long)d->n * d->h_out * d->w_out;
-  // cooperative 128 x 128 kernel: needs 2 co blocks and 2 N tiles to pair, rows of whole 8-pixel pieces, no reflect
-  // padding, and either so many pixels that 4x the splits still leaves long pixel ranges or so many tiles that the
+  // cooperative 128 x 128 kernel: needs 2 co blocks and 2 N tiles to pair, rows of whole 8-pixel pieces, and either so many pixels that 4x the splits still leaves long pixel ranges or so many tiles that the
   // splits stay few (the partial-tile workspace grows with the splits)
   pl.co_pairs = (pl.co_blocks + 1) / 2;
   pl.n_pairs = pl.fold ? (pl.tap_slots + 1) / 2 : pl.tap_slots * ((pl.ci_blocks + 1) / 2);
   // (odd block counts would leave a quarter of the quadrants idle: 128 -> 160 at 4 x 320^2 is 6 % slower that way)
   pl.coop = ((pl.co_blocks % 2) == 0 && ((pl.fold ? pl.tap_slots : pl.ci_blocks) % 2) == 0 && (d->w_out % 8) == 0 &&
-             d->pad_mode != CGAN_PAD_REFLECT && (g_wgrad_dbg & 8) == 0 && (double)npix * cgan_cs(d->c_out) * 2.0 < 1.9e9 &&
+             (g_wgrad_dbg & 8) == 0 && (double)npix * cgan_cs(d->c_out) * 2.0 < 1.9e9 &&
              (npix >= (long)g_wgrad_coop_min_pix || pl.tiles() >= 256))
                 ? 1 : 0;
   const long tiles = pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles();
@@ -768,12 +778,12 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   const int mode = a.x_ups ? 1 : (a.reflect ? 2 : 0);
   // uniform-piece addressing: pieces must not straddle output rows, and the "always out of range" lane constant needs
   // the dy offsets (one chunk stride past the end included) below 2^31
-  const bool uni = mode != 2 && (d->w_out % 8) == 0 && g_wgrad_dbg != 16 &&
+  const bool uni = (d->w_out % 8) == 0 && g_wgrad_dbg != 16 &&
                    ((double)a.npix + (double)a.splits * 128.0 + 128.0) * a.cout_s * 2.0 < 2147483648.0;
 #define WGRAD_LAUNCH(TT, MM, UU) hipLaunchKernelGGL((conv_wgrad_kernel<TT, MM, UU>), dim3(gx), dim3(256), smem, s, a)
 #define WGRAD_MODE(TT)                                                          \
   do {                                                                          \
-    if (mode == 2) WGRAD_LAUNCH(TT, 2, false);                                  \
+    if (mode == 2) { if (uni) WGRAD_LAUNCH(TT, 2, true); else WGRAD_LAUNCH(TT, 2, false); }     \
     else if (mode == 1) { if (uni) WGRAD_LAUNCH(TT, 1, true); else WGRAD_LAUNCH(TT, 1, false); } \
     else { if (uni) WGRAD_LAUNCH(TT, 0, true); else WGRAD_LAUNCH(TT, 0, false); }                \
   } while (0)
@@ -782,8 +792,8 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #define COOP_LAUNCH(TT, MM, CC) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC>), dim3(gx), dim3(256), smem2, s, a)
 #define COOP_MODE(TT)                                                                       \
   do {                                                                                      \
-    if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32); else COOP_LAUNCH(TT, 0, 32); } \
-    else { if (mode == 1) COOP_LAUNCH(TT, 1, 64); else COOP_LAUNCH(TT, 0, 64); }            \
+    if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32); else if (mode == 2) COOP_LAUNCH(TT, 2, 32); else COOP_LAUNCH(TT, 0, 32); } \
+    else { if (mode == 1) COOP_LAUNCH(TT, 1, 64); else if (mode == 2) COOP_LAUNCH(TT, 2, 64); else COOP_LAUNCH(TT, 0, 64); }            \
   } while (0)
     if (a.ts && d->dtype == CGAN_BF16 && mode == 0) {
       if (pl.chunk == 32) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 32, true>), dim3(gx), dim3(256), smem2, s, a);
