@@ -266,65 +266,92 @@ __global__ void bilinear_bwd_gather_kernel(const uint16_t* __restrict__ dy, uint
   }
 }
 
-// nn.MaxPool2d(3, 2, 1) backward (ResNet stem): every input pixel checks the (<= 4) windows that contain it and takes
-// dy where it is that window's FIRST maximum in row-major order (torch's tie rule)
+// nn.MaxPool2d(3, 2, 1) backward (ResNet stem).  A thread owns a 2 x 2 block of input pixels (rows 2a, 2a+1; columns 2b,
+// 2b+1) x 8 channels: the only windows that contain them are (a..a+1) x (b..b+1), whose inputs are the 5 x 5 patch around
+// the block.  It finds each window's FIRST maximum in row-major order (torch's tie rule: a later element wins only if
+// strictly greater) and gives dy to that position: 25 + 4 loads per 4 pixels.  (The first version worked per input pixel
+// and re-scanned every window that contains it: 32 neighbour loads per pixel, 464 us for the 8 x 320 x 320 x 64 stem map,
+// 9x its HBM time.)
 template <typename T>
-__global__ void maxpool3x3s2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-                                        uint16_t* __restrict__ dx, int h_in, int w_in, int h_out, int w_out, int cs,
-                                        long total) {
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                               uint16_t* __restrict__ dx, int h_in, int w_in, int h_out,
+                                                               int w_out, int cs, long total) {
   const int cg_total = cs / 8;
+  const int hb = (h_in + 1) >> 1, wb = (w_in + 1) >> 1;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int cg = (int)(idx % cg_total);
-    const long pix = idx / cg_total;
-    const int ix = (int)(pix % w_in);
-    const long r = pix / w_in;
-    const int iy = (int)(r % h_in);
-    const long n = r / h_in;
+    const long blk = idx / cg_total;
+    const int b = (int)(blk % wb);
+    const long r0 = blk / wb;
+    const int a = (int)(r0 % hb);
+    const long n = r0 / hb;
     const uint16_t* xb = x + n * (long)h_in * w_in * cs + cg * 8;
-    float me[8], acc[8];
-    {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * w_in + ix) * cs);
+    u32x4 patch[5][5];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) unpack2<T>(v[e], me[2 * e], me[2 * e + 1]);
-    }
+    for (int r = 0; r < 5; ++r)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
-      if (oy >= h_out) continue;
-      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-        if (ox >= w_out) continue;
-        bool win[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) win[e] = true;
-        for (int ky = 0; ky < 3; ++ky)
-          for (int kx = 0; kx < 3; ++kx) {
-            const int yy = 2 * oy - 1 + ky, xx = 2 * ox - 1 + kx;
-            if (yy < 0 || yy >= h_in || xx < 0 || xx >= w_in || (yy == iy && xx == ix)) continue;
-            const bool before = yy < iy || (yy == iy && xx < ix);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((long)yy * w_in + xx) * cs);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float a, b;
-              unpack2<T>(v[e], a, b);
-              // an earlier element wins ties, a later one only if strictly greater
-              if (before ? a >= me[2 * e] : a > me[2 * e]) win[2 * e] = false;
-              if (before ? b >= me[2 * e + 1] : b > me[2 * e + 1]) win[2 * e + 1] = false;
-            }
-          }
-        const u32x4 g = *reinterpret_cast<const u32x4*>(dy + ((n * h_out + oy) * (long)w_out + ox) * cs + cg * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a, b;
-          unpack2<T>(g[e], a, b);
-          if (win[2 * e]) acc[2 * e] += a;
-          if (win[2 * e + 1]) acc[2 * e + 1] += b;
-        }
+      for (int c = 0; c < 5; ++c) {
+        const int yy = 2 * a - 1 + r, xx = 2 * b - 1 + c;
+        patch[r][c] = (u32x4){0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < h_in && xx >= 0 && xx < w_in)
+          patch[r][c] = *reinterpret_cast<const u32x4*>(xb + ((long)yy * w_in + xx) * cs);
       }
-    }
-    u32x4 o;
+    u32x4 g[2][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
-    *reinterpret_cast<u32x4*>(dx + pix * cs + cg * 8) = o;
+    for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        g[wy][wx] = (u32x4){0u, 0u, 0u, 0u};
+        if (a + wy < h_out && b + wx < w_out)
+          g[wy][wx] = *reinterpret_cast<const u32x4*>(dy + ((n * h_out + a + wy) * (long)w_out + b + wx) * cs + cg * 8);
+      }
+    u32x4 o[2][2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc[2][2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+#pragma unroll
+      for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < 2; ++wx) {
+          if (!(a + wy < h_out && b + wx < w_out)) continue;
+          float best[2] = {0.f, 0.f};
+          int at[2] = {-1, -1};                       // local position r * 5 + c of the first maximum
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const int r = 2 * wy + ky, c = 2 * wx + kx;
+              const int yy = 2 * a - 1 + r, xx = 2 * b - 1 + c;
+              if (yy < 0 || yy >= h_in || xx < 0 || xx >= w_in) continue;
+              float v[2];
+              unpack2<T>(patch[r][c][e], v[0], v[1]);
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                if (at[h] < 0 || v[h] > best[h]) { best[h] = v[h]; at[h] = r * 5 + c; }
+            }
+          float d[2];
+          unpack2<T>(g[wy][wx][e], d[0], d[1]);
+#pragma unroll
+          for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                if (at[h] == (1 + py) * 5 + 1 + px) acc[py][px][h] += d[h];
+        }
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) o[py][px][e] = pack2<T>(acc[py][px][0], acc[py][px][1]);
+    }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int iy = 2 * a + py, ix = 2 * b + px;
+        if (iy < h_in && ix < w_in)
+          *reinterpret_cast<u32x4*>(dx + ((n * h_in + iy) * (long)w_in + ix) * cs + cg * 8) = o[py][px];
+      }
   }
 }
 
@@ -471,7 +498,7 @@ extern "C" int cgan_maxpool3x3s2_bwd_nhwc(const void* x, const void* dy, void* d
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "maxpool3x3s2_bwd: bad dtype %d", dtype);
   CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0, "maxpool3x3s2_bwd: bad shape");
   const int h_out = (h_in + 2 - 3) / 2 + 1, w_out = (w_in + 2 - 3) / 2 + 1, cs = cgan_cs(c);
-  const long total = (long)n * h_in * w_in * (cs / 8);
+  const long total = (long)n * ((h_in + 1) / 2) * ((w_in + 1) / 2) * (cs / 8);     // 2 x 2 input blocks x channel groups
   DISPATCH_PT(dtype, maxpool3x3s2_bwd_kernel, dim3(grid_pt(total)), dim3(256), 0, (hipStream_t)stream,
               (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, total);
   CGAN_CHECK_LAUNCH("maxpool3x3s2_bwd");
