@@ -333,28 +333,51 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
     const int c0 = cc * CB, t0 = tp * 16;
     const int nt = min(16, taps - t0);         // taps staged in this pass
     __syncthreads();
-    // ---- load: rows of the OIHW tensor, contiguous in (c, tap)
+    // ---- load: rows of the OIHW tensor, contiguous in (c, tap).  (c, tap) of a thread's elements advance by constants
+    // with a carry -- the first version divided twice per element and always divided by sigma: the pack of the
+    // generator's 105 M weights ran at a quarter of the HBM rate on instruction count alone
+    const bool plain = it.sigma == nullptr;
     if (!it.transposed) {
-      for (int idx = threadIdx.x; idx < 16 * CB * taps; idx += blockDim.x) {
-        const int row = idx / (CB * taps), r = idx - row * (CB * taps);
-        const int c = r / taps, tap = r - c * taps;
-        if (tap < t0 || tap >= t0 + nt) continue;
-        const int co = ct * 16 + row, ci = c0 + c;
-        float v = 0.f;
-        if (co < it.c_out && ci < it.c_in) v = __fdiv_rn(it.w_oihw[((size_t)co * it.c_in + ci) * taps + tap], sig);
-        tile[row][c * 16 + (tap - t0)] = v;
+      // thread = (row, 16 lanes along the row's CB * taps contiguous floats)
+      const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
+      const int co = ct * 16 + row;
+      const int dc = 16 / taps, dt = 16 - dc * taps;
+      int c = l / taps, tap = l - c * taps;
+      const float* src = it.w_oihw + ((size_t)co * it.c_in + c0) * taps;
+      for (int r = l; r < CB * taps; r += 16) {
+        if (tap >= t0 && tap < t0 + nt) {
+          float v = 0.f;
+          if (co < it.c_out && c0 + c < it.c_in) {
+            v = src[r];
+            if (!plain) v = __fdiv_rn(v, sig);
+          }
+          tile[row][c * 16 + (tap - t0)] = v;
+        }
+        tap += dt;
+        c += dc;
+        if (tap >= taps) { tap -= taps; ++c; }
       }
     } else {
       // operator element (row r, K channel k, tap t) = w[k][r][taps - 1 - t]: for one k the 16 rows x taps of a unit are
-      // contiguous in the forward tensor
-      for (int idx = threadIdx.x; idx < 16 * CB * taps; idx += blockDim.x) {
-        const int c = idx / (16 * taps), r = idx - c * (16 * taps);
-        const int row = r / taps, tap = taps - 1 - (r - row * taps);
-        if (tap < t0 || tap >= t0 + nt) continue;
-        const int ro = ct * 16 + row, k = c0 + c;
-        float v = 0.f;
-        if (ro < n_rows && k < n_k) v = __fdiv_rn(it.w_oihw[((size_t)k * n_rows + ro) * taps + (taps - 1 - tap)], sig);
-        tile[row][c * 16 + (tap - t0)] = v;
+      // contiguous in the forward tensor.  thread = (k, 8 lanes along those 16 * taps floats)
+      const int c = threadIdx.x >> 3, l = threadIdx.x & 7;
+      const int k = c0 + c;
+      const int dr = 8 / taps, dt = 8 - dr * taps;
+      int row = l / taps, ft = l - row * taps;            // ft: tap index in the forward tensor (flipped below)
+      const float* src = it.w_oihw + ((size_t)k * n_rows + ct * 16) * taps;
+      for (int r = l; r < 16 * taps; r += 8) {
+        const int tap = taps - 1 - ft;
+        if (tap >= t0 && tap < t0 + nt) {
+          float v = 0.f;
+          if (ct * 16 + row < n_rows && k < n_k) {
+            v = src[r];
+            if (!plain) v = __fdiv_rn(v, sig);
+          }
+          tile[row][c * 16 + (tap - t0)] = v;
+        }
+        ft += dt;
+        row += dr;
+        if (ft >= taps) { ft -= taps; ++row; }
       }
     }
     __syncthreads();
