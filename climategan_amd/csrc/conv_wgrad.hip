@@ -541,6 +541,134 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Spatially tiled variant for 3 x 3 / stride 1 / pad 1 layers on large maps (the SPADE gamma|beta gradients: 128 hidden
+// channels at 160^2 ... 640^2).  The kernels above treat every tap as its own N tile, so each tap's workgroups stream
+// their own shifted copy of x through L2 -> LDS: 9 x 419 MB of the 6.2 GB a 128 -> 40 call at 4 x 640^2 moved.  Here a
+// workgroup owns a (64 co) x (64 ci x 9 taps) block of dW -- 36 accumulator tiles per wave -- and walks 4 x 32 pixel
+// tiles: per tile it stages the dy tile (128 px) and the x tile WITH ITS HALO (6 rows x 40 px) once, and all nine taps
+// read their shifted windows from that one copy (the transposing LDS read takes a row address per lane, so a shifted
+// window costs nothing): 46 DMA pieces per 576 MFMAs instead of 8 per 32.
+// wave w owns N tiles 9w .. 9w+8 of the 36 (N tile j = tap j / 4, 16-channel group j % 4).
+constexpr int TL_W = 32, TL_H = 4, TL_XP = 40;                 // pixel tile, LDS pitch (pixels) of a halo row
+constexpr int TL_XH_BYTES = (TL_H + 2) * TL_XP * 128;           // 30720
+constexpr int TL_DY_BYTES = TL_H * TL_W * 128;                 // 16384
+
+__device__ __forceinline__ u32x4 tr_frag_at(const unsigned char* slab, int q0, int tile, int lane) {
+  // the 32 pixel rows q0 .. q0+31 (any q0) of channel tile `tile`; a row q keeps chunk c in slot c ^ swz(q & 7)
+  const int i = lane & 15, g = lane >> 4;
+  const int k = i >> 2;
+  const int chunk = tile * 2 + ((i & 3) >> 1);
+  const int qa = q0 + 8 * g + k, qb = qa + 4;
+  const unsigned char* a0 = slab + qa * 128 + ((chunk ^ swz(qa & 7)) << 4) + (i & 1) * 8;
+  const unsigned char* a1 = slab + qb * 128 + ((chunk ^ swz(qb & 7)) << 4) + (i & 1) * 8;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  u32x4 r;
+  r[0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+  r[1] = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+  r[2] = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+  r[3] = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* xh = smem;
+  unsigned char* dyt = smem + TL_XH_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.per_xcd || item >= p.co_blocks * p.ci_blocks * p.splits) return;
+  const int cob = item % p.co_blocks;
+  item /= p.co_blocks;
+  const int cib = item % p.ci_blocks;
+  const int split = item / p.ci_blocks;
+
+  const int prow = lane >> 3, qs = (lane & 7) ^ swz(prow);
+  const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const bool ci_ok = cib * 64 + qs * 8 < p.cin_s, co_ok = cob * 64 + qs * 8 < p.cout_s;
+  const unsigned x_c = (unsigned)(cib * 64 + qs * 8) * 2u, dy_c = (unsigned)(cob * 64 + qs * 8) * 2u;
+
+  const int tw = p.w_out / TL_W, th = p.h_out / TL_H;
+  const int ntiles = p.n * th * tw;
+
+  // staging of one spatial tile: x rows {wave, wave + 4} of the 6 halo rows (5 pieces each), dy pieces: waves 0 / 1 two
+  // each, waves 2 / 3 six each (12 / 12 / 11 / 11 pieces per wave)
+  auto stage = [&](int t) {
+    const int tc = t % tw;
+    const int r0 = t / tw;
+    const int tr = r0 % th, img = r0 / th;
+    const int ty0 = tr * TL_H, tx0 = tc * TL_W;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = wave + 4 * rr;
+      if (r < TL_H + 2) {
+        const int iy = ty0 - 1 + r;
+        const unsigned row_off = (unsigned)((img * p.h_in + iy) * p.w_in) * cin_b + x_c;
+#pragma unroll
+        for (int i5 = 0; i5 < 5; ++i5) {
+          const int ix = tx0 - 4 + 8 * i5 + prow;
+          const bool ok = ci_ok & ((unsigned)iy < (unsigned)p.h_in) & ((unsigned)ix < (unsigned)p.w_in);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(xh + (r * TL_XP + 8 * i5) * 128), 16,
+                                                   ok ? row_off + (unsigned)ix * cin_b : 0xffffffffu, 0, 0, 0);
+        }
+      }
+    }
+    const int j0 = wave < 2 ? wave * 2 : 4 + (wave - 2) * 6, nj = wave < 2 ? 2 : 6;
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+      if (jj < nj) {
+        const int j = j0 + jj, r = j >> 2, c8 = (j & 3) * 8;
+        const unsigned off = (unsigned)((img * p.h_out + ty0 + r) * p.w_out + tx0 + c8 + prow) * cout_b + dy_c;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dyt + (r * TL_W + c8) * 128), 16,
+                                                 co_ok ? off : 0xffffffffu, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int t = split; t < ntiles; t += p.splits) {
+    __syncthreads();                                              // the previous tile's fragment reads are done
+    stage(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int ty = 0; ty < TL_H; ++ty) {
+      u32x4 fa[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = tr_frag_at(dyt, ty * TL_W, a, lane);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int jn = wave * 9 + i, tap = jn >> 2, grp = jn & 3;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const u32x4 fb = tr_frag_at(xh, (ty + ky) * TL_XP + 3 + kx, grp, lane);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][i] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb), acc[a][i]);
+      }
+    }
+  }
+
+  // partial tiles to the workspace in the layout wgrad_reduce_kernel sums: [split][64 x 64 tile (tap, cib, cob)][a * 4 + b][lane]
+  const int tiles_n = 9 * p.ci_blocks * p.co_blocks;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int jn = wave * 9 + i, tap = jn >> 2, grp = jn & 3;
+    const int tile = (tap * p.ci_blocks + cib) * p.co_blocks + cob;
+    f32x4* wst = reinterpret_cast<f32x4*>(p.ws) + ((size_t)split * tiles_n + tile) * 1024;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wst[(a * 4 + grp) * 64 + lane] = acc[a][i];
+  }
+}
+
 // Second stage of the workspace path: dW += sum over pixel splits of the partial tiles.  A block = 32 consecutive
 // f32x4 of a tile x 8 split lanes: each thread sums every 8th split, the 8 lanes meet in LDS, lane 0 does the
 // read-modify-write of dW.  No atomics (the first version finished its split groups with up-to-16-way contended
@@ -624,11 +752,12 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
-int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768, g_wgrad_coop_chunk = 0, g_wgrad_slots = 512;
+int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768, g_wgrad_coop_chunk = 0, g_wgrad_slots = 512, g_wgrad_tile = 1;
 unsigned long long* g_wgrad_ts = nullptr;
 }  // namespace
 
 extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
+extern "C" void cgan_debug_set_wgrad_tile3x3(int v) { g_wgrad_tile = v; }   // 0: never the spatially tiled 3 x 3 kernel, 2: wherever it applies
 extern "C" void cgan_debug_set_wgrad_slots(int v) { g_wgrad_slots = v > 0 ? v : 512; }   // resident workgroups the planner assumes
 extern "C" void cgan_debug_set_wgrad_coop_chunk(int v) { g_wgrad_coop_chunk = (v == 32 || v == 64) ? v : 0; }   // 0: automatic
 
@@ -643,10 +772,11 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
 struct WgradPlan {
   int fold, cpt, tpt, tap_slots, ci_blocks, co_blocks, splits;
   int coop, co_pairs, n_pairs, chunk;   // chunk: pixels per stage of the cooperative kernel (64 / 32)
+  int tile;                             // the spatially tiled 3 x 3 kernel (conv_wgrad_tile3x3_kernel)
   long tiles() const { return (long)tap_slots * ci_blocks * co_blocks; }
 };
 
-static WgradPlan wgrad_plan(const CganConvDesc* d) {
+static WgradPlan wgrad_plan(const CganConvDesc* d, bool have_ws = true) {
   WgradPlan pl;
   const int taps = d->kh * d->kw, cin_s = cgan_cs(d->c_in);
   pl.co_blocks = ceil_div(cgan_cs(d->c_out), 64);
@@ -667,6 +797,22 @@ static WgradPlan wgrad_plan(const CganConvDesc* d) {
              (g_wgrad_dbg & 8) == 0 && (double)npix * cgan_cs(d->c_out) * 2.0 < 1.9e9 &&
              (npix >= (long)g_wgrad_coop_min_pix || pl.tiles() >= 256))
                 ? 1 : 0;
+  // spatially tiled 3 x 3 kernel: large maps of whole 4 x 32 pixel tiles, 64-channel input blocks, partial tiles through
+  // the workspace only; where the cooperative kernel cannot pair blocks (SPADE gamma|beta 128 -> 40 at 4 x 640^2: 438 ->
+  // 287 us, 128 -> 160 at 4 x 320^2: 292 -> 217 us; with paired blocks the cooperative kernel is as fast: 128 -> 80 548
+  // against 586 us).  Knob 2 forces it wherever it applies (tests).
+  pl.tile = ((g_wgrad_tile == 2 || (g_wgrad_tile == 1 && !pl.coop)) && have_ws && !pl.fold && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+             d->dilation == 1 && d->pad_mode == CGAN_PAD_ZERO && !d->in_upsample && (d->w_out % TL_W) == 0 &&
+             (d->h_out % TL_H) == 0 && (cin_s % 64) == 0 && npix >= 65536 && (g_wgrad_dbg & (8 | 16)) == 0) ? 1 : 0;
+  if (pl.tile) {
+    pl.coop = 0;
+    pl.chunk = TL_W * TL_H;
+    const long pairs = (long)pl.co_blocks * pl.ci_blocks, ntiles = npix / (TL_W * TL_H);
+    long sp = g_wgrad_target < 0 ? -g_wgrad_target : (long)g_wgrad_slots / pairs;
+    if (sp > ntiles) sp = ntiles;
+    pl.splits = sp < 1 ? 1 : (int)sp;
+    return pl;
+  }
   const long tiles = pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles();
   // Pixel splits.  The single-wave kernel and the cooperative kernel with 64-pixel stages keep 64 KiB of LDS per
   // workgroup, so 2 workgroups x 256 CUs = 512 run at a time and equal workgroups finish together: a grid of 513 takes
@@ -750,14 +896,15 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   a.x_ups = d->in_upsample;
   a.reflect = d->pad_mode == CGAN_PAD_REFLECT;
   a.nchunks = ceil_div(a.npix, 128);
-  const WgradPlan pl = wgrad_plan(d);
+  const WgradPlan pl = wgrad_plan(d, workspace != nullptr);
   a.ci_blocks = pl.ci_blocks; a.co_blocks = pl.co_blocks; a.splits = pl.splits;
   a.fold = pl.fold; a.cpt = pl.cpt; a.tpt = pl.tpt; a.tap_slots = pl.tap_slots;
   a.coop = pl.coop; a.co_pairs = pl.co_pairs; a.n_pairs = pl.n_pairs;
   const int taps = d->kh * d->kw;
   a.dbg = g_wgrad_dbg;
   a.ts = g_wgrad_ts;
-  const long items = (long)a.splits * (pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles());
+  const long items = (long)a.splits * (pl.tile ? (long)pl.co_blocks * pl.ci_blocks
+                                              : (pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles()));
   a.per_xcd = (int)((items + 7) / 8);
   CGAN_REQUIRE(items < (1L << 30), "conv2d_nhwc_bwd_weight: grid too large");
   const unsigned gx = (unsigned)a.per_xcd * 8;
@@ -787,7 +934,11 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     else if (mode == 1) { if (uni) WGRAD_LAUNCH(TT, 1, true); else WGRAD_LAUNCH(TT, 1, false); } \
     else { if (uni) WGRAD_LAUNCH(TT, 0, true); else WGRAD_LAUNCH(TT, 0, false); }                \
   } while (0)
-  if (pl.coop) {
+  if (pl.tile) {
+    const size_t smem3 = TL_XH_BYTES + TL_DY_BYTES;
+    if (d->dtype == CGAN_F16) hipLaunchKernelGGL(conv_wgrad_tile3x3_kernel<F16>, dim3(gx), dim3(256), smem3, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_tile3x3_kernel<BF16>, dim3(gx), dim3(256), smem3, s, a);
+  } else if (pl.coop) {
     const size_t smem2 = (size_t)2 * 4 * pl.chunk * 128;
 #define COOP_LAUNCH(TT, MM, CC) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC>), dim3(gx), dim3(256), smem2, s, a)
 #define COOP_MODE(TT)                                                                       \

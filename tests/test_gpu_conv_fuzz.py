@@ -103,6 +103,36 @@ def test_conv_forward_dgrad_wgrad(dt, case):
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(64, 40, 1, 256, 256), (128, 24, 2, 128, 256), (64, 130, 1, 256, 256), (192, 8, 1, 260, 288)])
+def test_spatially_tiled_3x3_wgrad(dt, case):
+    """The spatially tiled weight-gradient kernel of 3 x 3 / pad 1 layers on large maps (conv_wgrad_tile3x3_kernel: halo tile
+    staged once for all nine taps): against torch's fp32 gradient of the 16-bit-rounded operands, and against the
+    per-tap kernels it replaces (knob off), with the default and with a forced number of spatial splits."""
+    from climategan_amd import _lib, ops
+    cin, cout, B, H, W = case
+    lib = _lib.load()
+    x = q(fill.uniform((B, cin, H, W), 900 + cin), dt)
+    w = q(fill.uniform((cout, cin, 3, 3), 901 + cout, -0.05, 0.05), dt).requires_grad_(True)
+    y = F.conv2d(x, w, None, padding=1)
+    dy = q(fill.uniform(tuple(y.shape), 902 + W), dt)
+    y.backward(dy)
+    xg, dyg = ops.nchw_to_nhwc(x.cuda(), dt), ops.nchw_to_nhwc(dy.cuda(), dt)
+    try:
+        lib.cgan_debug_set_wgrad_tile3x3(ctypes.c_int(0))
+        dw_old, db_old = ops.conv2d_bwd_weight(xg, dyg, (cout, cin, 3, 3), pad=1)
+        lib.cgan_debug_set_wgrad_tile3x3(ctypes.c_int(2))           # also where the cooperative kernel would be taken
+        for splits in (0, 1, 5):
+            lib.cgan_debug_set_wgrad(ctypes.c_int(-splits), ctypes.c_int(0))
+            dw, db = ops.conv2d_bwd_weight(xg, dyg, (cout, cin, 3, 3), pad=1)
+            assert rel_err(dw.cpu(), w.grad) <= 3e-4, ("tiled", splits)
+            assert rel_err(dw.cpu(), dw_old.cpu()) <= 1e-5, ("tiled vs per-tap", splits)
+            assert rel_err(db.cpu(), db_old.cpu()) <= 1e-5          # (the channel sum ends in atomics: order varies)
+    finally:
+        lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_tile3x3(ctypes.c_int(1))
+
+
 def draw_mode_cases(n, seed):
     rng = np.random.RandomState(seed)
     out = []
