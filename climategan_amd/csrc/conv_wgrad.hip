@@ -572,7 +572,7 @@ __device__ __forceinline__ u32x4 tr_frag_at(const unsigned char* slab, int q0, i
   return r;
 }
 
-template <typename T>
+template <typename T, int NA = 4>      // NA: 16-row co tiles per block that exist (a 40-channel gradient: 3)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* xh = smem;
@@ -630,9 +630,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
     }
   };
 
-  f32x4 acc[4][9];
+  f32x4 acc[NA][9];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -643,16 +643,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
     __syncthreads();
 #pragma unroll 1
     for (int ty = 0; ty < TL_H; ++ty) {
-      u32x4 fa[4];
+      u32x4 fa[NA];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) fa[a] = tr_frag_at(dyt, ty * TL_W, a, lane);
+      for (int a = 0; a < NA; ++a) fa[a] = tr_frag_at(dyt, ty * TL_W, a, lane);
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int jn = wave * 9 + i, tap = jn >> 2, grp = jn & 3;
         const int ky = tap / 3, kx = tap - ky * 3;
         const u32x4 fb = tr_frag_at(xh, (ty + ky) * TL_XP + 3 + kx, grp, lane);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a][i] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb), acc[a][i]);
+        for (int a = 0; a < NA; ++a) acc[a][i] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb), acc[a][i]);
       }
     }
   }
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
     const int tile = (tap * p.ci_blocks + cib) * p.co_blocks + cob;
     f32x4* wst = reinterpret_cast<f32x4*>(p.ws) + ((size_t)split * tiles_n + tile) * 1024;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) wst[(a * 4 + grp) * 64 + lane] = acc[a][i];
+    for (int a = 0; a < 4; ++a) wst[(a * 4 + grp) * 64 + lane] = a < NA ? acc[a < NA ? a : 0][i] : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 }
 
@@ -936,8 +936,13 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   } while (0)
   if (pl.tile) {
     const size_t smem3 = TL_XH_BYTES + TL_DY_BYTES;
-    if (d->dtype == CGAN_F16) hipLaunchKernelGGL(conv_wgrad_tile3x3_kernel<F16>, dim3(gx), dim3(256), smem3, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_tile3x3_kernel<BF16>, dim3(gx), dim3(256), smem3, s, a);
+    // a single co block of <= 48 channels: only the co tiles that exist (the 16-row tiles past cout_s would multiply zeros)
+    const int na = pl.co_blocks == 1 ? ceil_div(a.cout_s, 16) : 4;
+#define TILE_LAUNCH(TT, NN) hipLaunchKernelGGL((conv_wgrad_tile3x3_kernel<TT, NN>), dim3(gx), dim3(256), smem3, s, a)
+#define TILE_NA(TT) do { if (na == 1) TILE_LAUNCH(TT, 1); else if (na == 2) TILE_LAUNCH(TT, 2); else if (na == 3) TILE_LAUNCH(TT, 3); else TILE_LAUNCH(TT, 4); } while (0)
+    if (d->dtype == CGAN_F16) TILE_NA(F16); else TILE_NA(BF16);
+#undef TILE_NA
+#undef TILE_LAUNCH
   } else if (pl.coop) {
     const size_t smem2 = (size_t)2 * 4 * pl.chunk * 128;
 #define COOP_LAUNCH(TT, MM, CC) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC>), dim3(gx), dim3(256), smem2, s, a)
