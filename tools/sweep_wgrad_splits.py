@@ -34,6 +34,8 @@ only = sys.argv[1] if len(sys.argv) > 1 else ""
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 0           # cooperative kernel: pixels per stage (64 / 32; 0 = the planner decides)
 lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(chunk))
 slots = 1024 if chunk == 32 else 512
+if len(sys.argv) > 3:                                         # cgan_debug_set_wgrad_tile3x3: 0 off, 1 default, 2 wherever it applies
+    lib.cgan_debug_set_wgrad_tile3x3(ctypes.c_int(int(sys.argv[3])))
 for name, cin, cout, k, stride, pad, dil, bs, H, tiles in SHAPES:
     if only not in name:
         continue
