@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
     // gradients): convert and store.  FULL (wave-uniform: no pixel / cout tail in this wave's tile) stores unguarded.
     const int cout_base = (cb * 16 + wc * WC) * 16;
     const bool full = pix_wave + WP * 16 <= p.npix && cout_base + WC * 16 <= p.cout_s;
-    if (p.stats) {
+    if (p.stats && pix_wave < p.npix) {     // (a trailing wave of the last block owns no chunk: npix % 128 == 0 only)
       // (mean, M2) of this wave's 128 pixels per channel; pairs of channels on the packed-fp32 VALU path
       const int chunk = pblk * 2 + wp;
       constexpr float inv_cnt = 1.f / (float)(WP * 16);

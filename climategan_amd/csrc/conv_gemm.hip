@@ -199,8 +199,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   __builtin_amdgcn_s_barrier();                               // every wave is done with the operand ring
   unsigned char* stg = smem + wave * (PP * 16 * ROWB);
   const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
-  const bool plain = !p.bias && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
-  if (p.stats) {
+  const float* bias_ep = p.bias;       // the bias the store path still has to add
+  // A wave's statistics chunk is whole or absent: npix is a multiple of the chunk (the dispatcher checked), but not
+  // necessarily of the workgroup's pixel count -- the trailing waves of the last block own no pixel and no partial row.
+  if (p.stats && (pblk * PT_BLK + wp * WP) * 16 < p.npix) {
+    if (p.bias) {
+      // statistics are of the values AS STORED = round(acc + bias): fold the bias into the accumulators here and let the
+      // store path skip it (wave-uniform branch)
+#pragma unroll
+      for (int c = 0; c < WC; ++c) {
+        const int chb = cout_base + c * 16 + 4 * g;
+        const f32x4 b = chb < p.cout_s ? *reinterpret_cast<const f32x4*>(p.bias + chb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < WP; ++t) acc[c][t] += b;
+      }
+      bias_ep = nullptr;
+    }
     // training-mode BatchNorm statistics from the accumulators: (mean, M2) of this wave's WP x 16 pixels per channel --
     // sum and sum of squares over the wave's pixel tiles, then over the 16 lanes (pixels) that share a channel quad; the
     // finalize kernel of norm_stats.hip merges the chunks with Chan's formula.  Every chunk is full (the dispatcher
@@ -259,16 +273,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
           o[2 * r] = sm[r];
           o[2 * r + 1] = sq[r];
         }
-        if (p.bias) {       // (one wave-uniform branch, not one per channel)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[2 * r] += p.bias[ch + r];
-        }
         float* dst = p.stats + ((size_t)chunk * p.cout_s + ch) * 2;
         *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
         *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
       }
     }
   }
+  const bool plain = !bias_ep && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
 #pragma unroll
   for (int pass = 0; pass < WP / PP; ++pass) {
 #pragma unroll
@@ -289,8 +300,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (!plain) {     // wave-uniform: the BatchNorm-followed convs (no bias / residual / activation / pad channels) skip all of it
-        if (p.bias) {     // (padded to whole cout tiles: two 16-byte loads)
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch + 4);
+        if (bias_ep) {     // (padded to whole cout tiles: two 16-byte loads)
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] += b0[r];

@@ -639,11 +639,13 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
 }
 
 // Forward with training-mode BatchNorm statistics from the kernel's epilogue (round 3): see the header.
+static const float k_bias_sentinel = 0.f;    // never dereferenced
 static int stats_chunk_pixels(ConvParams& p, const CganConvDesc* d) {
   if (d->has_residual || d->act != CGAN_ACT_NONE || d->in_upsample) return 0;
   if (select_conv_kernel(p, d) != CGAN_CONV_KERNEL_GEMM) return 0;
   ConvGemmArgs a;
-  a.x = nullptr; a.w = nullptr; a.bias = nullptr; a.res = nullptr; a.y = nullptr; a.stats = nullptr;
+  a.x = nullptr; a.w = nullptr; a.bias = d->has_bias ? &k_bias_sentinel : nullptr;   // choose() keys on it: the query must pick what the launch picks
+  a.res = nullptr; a.y = nullptr; a.stats = nullptr;
   a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
   a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
   a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;

@@ -759,6 +759,56 @@ def test_batchnorm_statistics_from_the_conv_epilogue_with_large_channel_means(ca
     _bn_stats_from_epilogue(case, shifted=True)
 
 
+@pytest.mark.parametrize("case", [
+    # npix a multiple of a wave's statistics chunk but NOT of the workgroup's pixel count: the trailing waves of the last
+    # block own no chunk (round-3 builds wrote their rows past the end of ``partial``)
+    (256, 1024, 1, 0, 1, 4, 28, 28, 1),      # 3136 px = 49 x 64: plain 128-pixel blocks
+    (256, 256, 3, 1, 1, 3, 40, 40, 1),       # 4800 px
+    (128, 512, 1, 0, 1, 6, 56, 56, 1),       # 18816 px = 147 x 128: x-resident kernel, 256-pixel blocks
+    (512, 128, 1, 0, 1, 5, 24, 24, 1),       # 2880 px = 45 x 64
+])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_conv_epilogue_statistics_stay_inside_their_buffer(case, with_bias):
+    """The partial rows a conv epilogue writes are exactly npix / chunk: a canary behind them stays untouched, the rows
+    themselves equal the statistics of the stored y; with a bias (``spectral_batch`` blocks: conv + bias -> BatchNorm) the
+    query and the launch agree on the kernel and the statistics are those of round(acc + bias)."""
+    import ctypes as C
+    from climategan_amd import _lib, ops
+
+    cin, cout, k, pad, dil, n, h, w, _ = case
+    dt = torch.bfloat16
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    xf = torch.randn(n, cin, h, w, device="cuda", generator=gen).to(dt).float()
+    wt = (torch.randn(cout, cin, k, k, device="cuda", generator=gen) * (2.0 / (cin * k * k)) ** 0.5).to(dt).float()
+    bias = torch.randn(cout, device="cuda", generator=gen) * 3 if with_bias else None
+    x = ops.nchw_to_nhwc(xf, dt)
+    pw = ops.pack_conv_weight(wt, bias, dt)
+    d = ops._conv_desc(x.dtype_id, n, h, w, cin, cout, k, k, 1, pad, dil, ops.PAD_ZERO, has_bias=with_bias)
+    lib = _lib.load()
+    ppb = lib.cgan_conv2d_stats_chunk_pixels(C.byref(d))
+    npix = n * d.h_out * d.w_out
+    if ppb <= 0:
+        pytest.skip("this descriptor's kernel has no statistics epilogue")
+    assert npix % ppb == 0
+    rows, cs = npix // ppb, ops.cs8(cout)
+    CANARY = 12345.0
+    buf = torch.full((rows + 8, cs, 2), CANARY, dtype=torch.float32, device="cuda")
+    y = torch.empty((n, d.h_out, d.w_out, cs), dtype=dt, device="cuda")
+    _lib.check(lib.cgan_conv2d_nhwc_fwd_stats(ops._ptr(x.t), ops._ptr(pw.w), ops._ptr(pw.bias), ops._ptr(y), ops._ptr(buf),
+                                              rows * cs * 2 * 4, C.byref(d), ops._stream()), "cgan_conv2d_nhwc_fwd_stats")
+    torch.cuda.synchronize()
+    assert bool((buf[rows:] == CANARY).all()), "the epilogue wrote past its npix / chunk partial rows"
+    assert bool((buf[:rows, :cout] != CANARY).all()), "a partial row was left unwritten"
+    y0 = ops.conv2d(x, pw, pad=pad, dilation=dil)
+    assert torch.equal(y, y0.t)
+    yv = y.float().view(rows, ppb, cs)[:, :, :cout].double()
+    mean_ref = yv.mean(1)
+    m2_ref = ((yv - mean_ref[:, None]) ** 2).sum(1)
+    scale = max(yv.abs().max().item(), 1.0)
+    assert (buf[:rows, :cout, 0].double() - mean_ref).abs().max().item() <= 2e-5 * scale
+    assert (buf[:rows, :cout, 1].double() - m2_ref).abs().max().item() <= 2e-4 * max(m2_ref.max().item(), 1.0)
+
+
 def _bn_stats_from_epilogue(case, shifted):
     """``ops.conv2d_with_stats`` + ``batchnorm_train_stats_from_partials`` (the conv kernel's epilogue reduces its fp32
     accumulators, rounded as they are stored, per chunk of pixels; one finalize launch) against the separate statistics pass
