@@ -55,14 +55,14 @@ def default_opts() -> Opts:
             "s": {"use_advent": True, "use_dada": True, "use_minent": True, "architecture": "deeplabv3", "output_dim": 11,
                   "num_classes": 11, "init_type": "xavier", "init_gain": 0.02},                                    # :135-143
             "m": {"init_type": "xavier", "init_gain": 0.02, "use_advent": True, "use_spade": False, "output_dim": 1, "use_low_level_feats": True,
-                  "use_dada": False, "use_minent": True, "use_minent_var": True, "use_ground_intersection": True, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
+                  "use_dada": False, "use_pl4m": False, "use_minent": True, "use_minent_var": True, "use_ground_intersection": True, "proj_dim": 64, "n_res": 3, "n_upsample": 3, "norm": "spectral",
                   "activ": "lrelu", "pad_type": "reflect", "use_proj": True,
                   "spade": {"latent_dim": 128, "detach": False, "cond_nc": 15, "spade_use_spectral_norm": True,
                             "spade_param_free_norm": "batch", "num_layers": 3,
                             "activations": {"all_lrelu": True}}},       # :166-190 (+ default-gen :89-99)
             "p": {                                                       # :144-165
                 "init_type": "xavier", "init_gain": 0.02, "loss": "gan",
-                "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True,
+                "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True, "pl4m_epoch": 49,
                 "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",
                 "spade_use_spectral_norm": True, "use_final_shortcut": False,
             },

@@ -178,11 +178,11 @@ __global__ __launch_bounds__(256) void wf_blur_kernel(const float* __restrict__ 
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) acc[rr] = __builtin_fmaf(gs[m - rr], v, acc[rr]);
     }
-    for (int m = max(ks, 7); m < ks + 7; ++m) {
+    for (int m = ks; m < ks + 7; ++m) {                  // (ks < 7: inputs ks..6 are still below some outputs' tap 0)
       const float v = load(m);
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr)
-        if (m - rr < ks) acc[rr] = __builtin_fmaf(gs[m - rr], v, acc[rr]);
+        if (m - rr < ks && m - rr >= 0) acc[rr] = __builtin_fmaf(gs[m - rr], v, acc[rr]);
     }
     if (AXIS == 0 && x0 + 8 <= w && (w & 3) == 0) {           // two 16-byte stores (x0 is a multiple of 8)
       float* o = out + (n * h + y0) * (long)w + x0;

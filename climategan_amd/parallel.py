@@ -164,6 +164,10 @@ class GradBucketReducer:
                     cur.wait_stream(st)
         # multi-tensor copies (a handful of launches per bucket instead of one per parameter: 1500 parameters)
         torch._foreach_copy_(self._views(b, grads), grads)
+        # what went on the wire: finish() compares (a later backward() that accumulates into a gradient of this bucket
+        # WITHOUT reaching its trigger parameter -- another sub-graph, e.g. a masker-only pass after a joint one -- fires
+        # no hook once only the triggers keep theirs)
+        b.sent = [(g.data_ptr(), g._version) for g in grads]
         if self.direct:
             from . import _lib
             gathered = torch.cuda.Event()
@@ -222,10 +226,10 @@ class GradBucketReducer:
                                        "replicas would diverge" % len(missing))
                 self._launch(b)
             b.work.wait()
-            if b.stale:                                            # see _on_grad
+            grads = [p.grad for p in b.params]
+            if b.stale or b.sent != [(g.data_ptr(), g._version) for g in grads]:      # see _on_grad / _launch
                 self._launch(b)
                 b.work.wait()
-            grads = [p.grad for p in b.params]
             torch._foreach_copy_(grads, b.views)                      # back to the gradients' own dtype (fp32)
             if self.world > 1:
                 torch._foreach_mul_(grads, 1.0 / self.world)          # the average, applied in fp32

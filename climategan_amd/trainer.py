@@ -69,7 +69,7 @@ class Trainer:
         self.D = None
         self.is_setup = False
         self.has_painter = "p" in opts.tasks
-        self.use_pl4m = False            # trainer.py:94; run_epoch switches it on at opts.gen.p.pl4m_epoch (trainer.py:899-909)
+        self.use_pl4m = False            # trainer.py:94; maybe_enable_pl4m() / run_epoch() switch it on at opts.gen.p.pl4m_epoch
         # the real and the simulated domain batch share the Masker's encoder / depth / segmentation launches (grouped
         # BatchNorm keeps the per-domain statistics of the reference's separate calls); False = one pass per domain
         self.merge_domains = True
@@ -616,6 +616,29 @@ class Trainer:
         d = self.update_D(multi_domain_batch)
         self.global_step += 1
         return g, d
+
+    def maybe_enable_pl4m(self):
+        """The epoch check of the reference's ``train`` loop (trainer.py:899-909): from ``opts.gen.p.pl4m_epoch`` on, with a
+        Painter of its own, task "p" and ``gen.m.use_pl4m``, the Painter's discriminator loss is back-propagated to the
+        Masker.  ``run_epoch`` calls it; a host loop that drives ``train_step`` itself must call it once per epoch."""
+        if (not self.use_pl4m and self.epoch == self.opts.gen.p.pl4m_epoch and "p" in self.opts.tasks
+                and self.opts.gen.m.use_pl4m and sum(p.numel() for p in self.G.painter.parameters()) > 0):
+            print("\n\n >>> Enabling pl4m at epoch {}\n\n".format(self.epoch))
+            self.use_pl4m = True
+        return self.use_pl4m
+
+    def run_epoch(self, batches):
+        """One epoch of the reference's loop (``train``'s pl4m check trainer.py:899-909, then ``run_epoch`` trainer.py:924-987)
+        over an iterable of multi-domain batches (the zipped loaders are the caller's: data loading is out of scope):
+        per batch ``update_G`` + ``update_D`` + step counter; per epoch the learning-rate schedulers and the epoch
+        counter.  Returns the last (g_loss, d_loss)."""
+        self.maybe_enable_pl4m()
+        last = None
+        for multi_domain_batch in batches:
+            last = self.train_step(multi_domain_batch)
+        self.update_learning_rates()                                    # trainer.py:983-984
+        self.epoch += 1
+        return last
 
     # ------------------------------------------------------------------------------------------ checkpoints
     def update_learning_rates(self):

@@ -293,3 +293,66 @@ def test_reducer_two_backward_calls_per_update_gloo():
         for rank in range(2):
             for got, e in zip(res[rank][1][step], acc):
                 assert np.allclose(got, (e / 2).numpy(), rtol=1e-6, atol=1e-7), (rank, step)
+
+
+def _subgraph_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climategan_amd.parallel import GradBucketReducer, broadcast_parameters
+        torch.manual_seed(4)
+        # ONE bucket holding two independent heads: head a's gradients arrive last in the joint backward (the learned
+        # trigger is one of its parameters), head b alone is reached by the second backward
+        a, b = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+        net = torch.nn.ModuleList([a, b])
+        broadcast_parameters(net)
+        red = GradBucketReducer(net.parameters(), bucket_mb=25.0)
+        outs = []
+        for step in range(3):                                           # step 0 learns the trigger, 1 and 2 rely on it
+            net.zero_grad(set_to_none=True)
+            x = torch.full((2, 4), 0.5 * (rank + 1) + step)
+            (a(x).sum() + b(x).pow(2).sum()).backward()                 # the bucket goes on the wire ...
+            b(-x).pow(2).sum().backward()                               # ... then ONLY head b accumulates again
+            red.finish()
+            outs.append([p.grad.clone().numpy() for p in net.parameters()])
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_second_backward_over_another_subgraph_gloo():
+    """A second ``backward()`` that accumulates into a launched bucket without reaching its trigger parameter (a
+    masker-only pass after a joint one) fires no hook once only the triggers keep theirs; ``finish()`` must still see that
+    what went on the wire is stale (round-3 advisor finding) and exchange the final gradients."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgraph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(4)
+    a, b = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    params = list(a.parameters()) + list(b.parameters())
+    for step in range(3):
+        want = [torch.zeros_like(p) for p in params]
+        for rank in range(2):
+            for p in params:
+                p.grad = None
+            x = torch.full((2, 4), 0.5 * (rank + 1) + step)
+            (a(x).sum() + b(x).pow(2).sum()).backward()
+            b(-x).pow(2).sum().backward()
+            for w, p in zip(want, params):
+                w += p.grad / 2
+        for rank in range(2):
+            for got, w in zip(res[rank][1][step], want):
+                np.testing.assert_allclose(got, w.numpy(), rtol=1e-5, atol=1e-6)

@@ -319,3 +319,30 @@ def test_wildfire_next_to_another_streams_kernels():
                 assert torch.equal(out[i], out[i % 2]), (rep, i)
     finally:
         lib.cgan_debug_set_wf_blur(ctypes.c_int(0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks", [1, 3, 5, 7, 9, 15])
+def test_wildfire_blur_short_kernels_match_the_one_output_per_thread_form(ks):
+    """The 8-outputs-per-thread blur walks ks + 7 inputs per thread in three loops; for ks < 7 the inputs ks..6 belong to
+    the tail loop (round-3 builds dropped them: only the reference default of 301 taps was exercised)."""
+    import ctypes
+
+    from climategan_amd import _lib, ops
+
+    lib = _lib.load()
+    dt = torch.float16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    x = torch.rand(2, 3, 96, 104, device="cuda", generator=g) * 2 - 1
+    s = torch.randn(2, 11, 24, 26, device="cuda", generator=g)
+    s[:, 9, :10] += 3.0
+    seg = ops.nchw_to_nhwc(s, dt)
+    try:
+        lib.cgan_debug_set_wf_blur(ctypes.c_int(1))
+        ref = ops.wildfire(x, seg, 120.0, kernel_size=ks, kernel_sigma=ks / 2.0)
+        lib.cgan_debug_set_wf_blur(ctypes.c_int(0))
+        out = ops.wildfire(x, seg, 120.0, kernel_size=ks, kernel_sigma=ks / 2.0)
+    finally:
+        lib.cgan_debug_set_wf_blur(ctypes.c_int(0))
+    assert torch.equal(out, ref)

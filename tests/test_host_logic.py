@@ -143,3 +143,36 @@ def test_generator_masker_state_dict_layout():
     sd = {k: tuple(v.shape) for k, v in G.state_dict().items() if not k.startswith("painter.")}
     assert sd == masker_shapes()
     assert sum(p.numel() for p in G.parameters()) == 105414209
+
+
+def test_pl4m_is_enabled_at_its_epoch():
+    """``Trainer.maybe_enable_pl4m`` = the epoch check of the reference's ``train`` loop (trainer.py:899-909)."""
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    class _P(torch.nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(n)) if n else None
+
+    class _G:
+        painter = _P(3)
+
+    opts = default_opts()
+    assert opts.gen.p.pl4m_epoch == 49 and opts.gen.m.use_pl4m is False          # defaults.yaml:152,176
+    T = Trainer(opts, device="cpu")
+    T.G, T.epoch = _G(), 0
+    opts.gen.m.use_pl4m = True
+    opts.gen.p.pl4m_epoch = 2
+    assert T.maybe_enable_pl4m() is False
+    T.epoch = 2
+    assert T.maybe_enable_pl4m() is True and T.use_pl4m
+    T.epoch = 3
+    assert T.maybe_enable_pl4m() is True                                          # stays on
+    T2 = Trainer(opts, device="cpu")
+    T2.G, T2.epoch = _G(), 2
+    opts.gen.m.use_pl4m = False
+    assert T2.maybe_enable_pl4m() is False
+    opts.gen.m.use_pl4m = True
+    T2.G = type("G0", (), {"painter": _P(0)})()
+    assert T2.maybe_enable_pl4m() is False                                        # no Painter of its own
