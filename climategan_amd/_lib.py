@@ -225,7 +225,24 @@ def load():
     return lib
 
 
+# Development aid (bench.py --call-log, tools/step_hbm_budget.py): when CALL_LOG is a list, every checked C-ABI call appends
+# (entry point, bytes of the device operands handed to it through ops._ptr since the previous call) -- the bytes the call has to
+# touch at least once; calls that take item tables add their operands with log_bytes().
+CALL_LOG = None
+_pending_bytes = 0
+
+
+def log_bytes(n):
+    global _pending_bytes
+    if CALL_LOG is not None:
+        _pending_bytes += int(n)
+
+
 def check(rc, what):
+    global _pending_bytes
+    if CALL_LOG is not None:
+        CALL_LOG.append((what, _pending_bytes))
+        _pending_bytes = 0
     if rc != 0:
         msg = load().cgan_last_error()
         raise RuntimeError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

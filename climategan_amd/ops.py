@@ -55,7 +55,11 @@ def _stream():
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    if t is None:
+        return C.c_void_p(0)
+    if _lib.CALL_LOG is not None:          # development aid, see _lib.CALL_LOG
+        _lib.log_bytes(t.numel() * t.element_size())
+    return C.c_void_p(t.data_ptr())
 
 
 def _need_cs8(what, *xs):
@@ -527,6 +531,8 @@ def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
                             c_out, c_in, kh, kw)
     host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
     table = host.to(dev, non_blocking=True)
+    if _lib.CALL_LOG is not None:
+        _lib.log_bytes(sum(w.numel() * 4 for w, _ in params) + sum(pk.w.numel() for pk in out))
     _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(table), len(params), _DT[dtype], max_frag, _stream()),
                "cgan_conv2d_pack_weight_batched")
     _PACK_TABLES.append((host, table, keep))          # alive until the copy / kernel that read them are long done
@@ -611,6 +617,8 @@ def dgrad_prepack_run(also_used_on=None) -> int:
                                 c_out, c_in, kh, kw, 1)
         host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
         table = host.to(dev, non_blocking=True)
+        if _lib.CALL_LOG is not None:
+            _lib.log_bytes(sum(h.w.numel() * 4 + h.packed.numel() for h in hs))
         _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(table), len(hs), _DT[dtype], max_frag, _stream()),
                    "cgan_conv2d_pack_weight_batched")
         if also_used_on is not None:
@@ -1114,8 +1122,12 @@ class SpectralNormGroup:
     def step(self):
         """One power iteration of every layer (u, v updated in place) + re-pack of every w_bar / sigma."""
         lib = _lib.load()
+        if _lib.CALL_LOG is not None:            # w_bar is read twice per power iteration (W^T u, W v)
+            _lib.log_bytes(2 * sum(pk.c_out * pk.c_in * pk.kh * pk.kw * 4 for pk in self.packed))
         _lib.check(lib.cgan_spectral_norm_power_iter_batched(_ptr(self.sn_table), self.n, self.max_rows, self.max_cols,
                                                              _stream()), "cgan_spectral_norm_power_iter_batched")
+        if _lib.CALL_LOG is not None:
+            _lib.log_bytes(sum(pk.c_out * pk.c_in * pk.kh * pk.kw * 4 + pk.w.numel() for pk in self.packed))
         _lib.check(lib.cgan_conv2d_pack_weight_batched(_ptr(self.pk_table), self.n, _DT[self.dtype], self.max_frag,
                                                        _stream()), "cgan_conv2d_pack_weight_batched")
         return self.packed

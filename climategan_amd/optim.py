@@ -74,6 +74,8 @@ class ExtraAdam(Optimizer):
                 host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).pin_memory()
                 table = host.to(ps[0].device, non_blocking=True)
                 self._tables = getattr(self, "_tables", [])[-7:] + [(host, table)]
+                if _lib.CALL_LOG is not None:        # p, g, m, v read; p, m, v (+ the saved copy on an extrapolation) written
+                    _lib.log_bytes(sum(p.numel() for p in ps) * 4 * (8 if mode == 0 else 7))
                 _lib.check(lib.cgan_extra_adam_multi_tensor(_ptr(table), len(ps), mx, mode,
                                                             int(mode == 0 and not self._has_copy), step, group["lr"],
                                                             beta1, beta2, group["eps"], group["weight_decay"],

@@ -40,9 +40,10 @@ class Mode(TorchDispatchMode):
 for _ in range(2):
     T.train_step(batch)
 torch.cuda.synchronize()
-with Mode():
+# (the engine runs a device's backward on its own thread, where a thread-local dispatch mode is not active: one thread here)
+with torch.autograd.set_multithreading_enabled(False), Mode():
     T.train_step(batch)
 torch.cuda.synchronize()
 print("torch-side ops of one joint train step:", sum(counts.values()))
-for (name, site), n in counts.most_common(60):
+for (name, site), n in counts.most_common(90):
     print("%5d  %-32s %-28s %9.3f MB" % (n, name, site, nbytes[(name, site)] / 1e6))
