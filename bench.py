@@ -787,7 +787,7 @@ def main():
                     help="extra single-stream steps after the timed region with EVERY MFMA-kernel launch bracketed (0 = skip)")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each sub-block (0 = skip the sub-blocks)")
     ap.add_argument("--only", default="", help="run ONE workload as the only measurement (profiling aid): "
-                                               "painter | masker | infer")
+                                               "painter | masker | large | infer")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -818,6 +818,8 @@ def main():
             r = painter_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier, False)
         elif args.only == "masker":
             r = masker_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier)
+        elif args.only == "large":
+            r = large_batch_block(args.steps, args.warmup, rank, device, dtype, barrier)
         else:
             r = infer_block(args.steps, args.warmup, rank, world, device, dist, barrier)
         if rank == 0:

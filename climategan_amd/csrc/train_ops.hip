@@ -53,10 +53,13 @@ __device__ __forceinline__ void in_bwd_terms(float out, float dy, int act, float
   }
 }
 
-// sums[n][cs][2] += (sum dz, sum dz*y) over this block's pixel range; grid (chunks, channel-group blocks, n)
+// partial[n][chunk][cs][2] = (sum dz, sum dz*y) over this block's pixel range; grid (chunks, channel-group blocks, n).
+// Plain stores, one row per block; in_bwd_finalize_kernel sums the rows in a fixed order: the result does not depend on the
+// order the blocks ran in (the first version added into sums[n][cs][2] with fp32 atomics behind a memset: run-to-run
+// different in the last bits, and the chunk count depended on the batch size).
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const uint16_t* __restrict__ out,
-                                                            const uint16_t* __restrict__ dy, float* __restrict__ sums,
+                                                            const uint16_t* __restrict__ dy, float* __restrict__ partial,
                                                             int hw, int cs, int ppb, int act, float slope) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL][cgb*8][2]
   const int cg_total = cs / 8;
@@ -101,10 +104,32 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const uint16_t* __re
       a += sm[((l * cgb) * 8 + c) * 2];
       b += sm[((l * cgb) * 8 + c) * 2 + 1];
     }
-    float* o = sums + ((size_t)n * cs + cg0 * 8 + c) * 2;
-    atomicAdd(o, a);
-    atomicAdd(o + 1, b);
+    float* o = partial + (((size_t)n * gridDim.x + blockIdx.x) * cs + cg0 * 8 + c) * 2;
+    o[0] = a;
+    o[1] = b;
   }
+}
+
+// sums[n][cs][2] = sum over the chunk rows: one wave per (n, c); lane l adds rows l, l + 64, ... in order, then a fixed
+// butterfly over the lanes
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums,
+                                                              int n_total, int cs, int chunks) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (idx >= n_total * cs) return;
+  const int n = idx / cs, c = idx - n * cs;
+  float a = 0.f, b = 0.f;
+  for (int k = lane; k < chunks; k += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * cs + c) * 2);
+    a += v.x;
+    b += v.y;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  if (lane == 0) *reinterpret_cast<float2*>(sums + (size_t)idx * 2) = make_float2(a, b);
 }
 
 template <typename T>
@@ -589,9 +614,23 @@ extern "C" int cgan_act_bwd(const void* out, const void* dy, void* dx, int32_t d
   return CGAN_OK;
 }
 
+// pixel chunks of the reduction: a function of the image size and the channel count only (NOT of the batch size: a batch
+// slice must give the same per-sample result as the whole batch), at most IN_BWD_MAX_CHUNKS rows per sample
+constexpr int IN_BWD_MAX_CHUNKS = 1024;
+static void in_bwd_plan(const CganNormStatsDesc* d, int& cgb, int& PL, int& ppb, int& chunks) {
+  const int cg_total = cgan_cs(d->c) / 8;
+  cgb = cg_total < 256 ? cg_total : 256;
+  PL = 256 / cgb;
+  ppb = ceil_div(d->hw, IN_BWD_MAX_CHUNKS);
+  if (ppb < 4 * PL) ppb = 4 * PL;            // at least 4 pixels per pixel lane
+  chunks = ceil_div(d->hw, ppb);
+}
+
 extern "C" size_t cgan_instnorm_act_bwd_workspace_bytes(const CganNormStatsDesc* d) {
-  if (!d || d->n <= 0 || d->c <= 0) return 0;
-  return (size_t)d->n * cgan_cs(d->c) * 2 * sizeof(float);
+  if (!d || d->n <= 0 || d->c <= 0 || d->hw <= 0) return 0;
+  int cgb, PL, ppb, chunks;
+  in_bwd_plan(d, cgb, PL, ppb, chunks);
+  return (size_t)d->n * cgan_cs(d->c) * 2 * sizeof(float) * (1 + (size_t)chunks);      // sums | chunk rows
 }
 
 extern "C" int cgan_instnorm_act_bwd(const void* out, const void* dy, const float* rstd, void* dx,
@@ -606,22 +645,16 @@ extern "C" int cgan_instnorm_act_bwd(const void* out, const void* dy, const floa
   CGAN_REQUIRE(workspace_bytes >= cgan_instnorm_act_bwd_workspace_bytes(d), "instnorm_act_bwd: workspace too small");
   const int cs = cgan_cs(d->c);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, cgan_instnorm_act_bwd_workspace_bytes(d), s);
-  if (e != hipSuccess) {
-    cgan_set_error("instnorm_act_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CGAN_ERR_HIP;
-  }
   const int cg_total = cs / 8;
-  const int cgb = cg_total < 256 ? cg_total : 256;
-  const int PL = 256 / cgb;
-  // pixels per block: enough blocks to fill the chip, at least 4 pixels per pixel lane
-  int chunks = ceil_div(2048, d->n * ceil_div(cg_total, cgb));
-  int ppb = ceil_div(d->hw, chunks < 1 ? 1 : chunks);
-  if (ppb < 4 * PL) ppb = 4 * PL;
-  chunks = ceil_div(d->hw, ppb);
+  int cgb, PL, ppb, chunks;
+  in_bwd_plan(d, cgb, PL, ppb, chunks);
+  float* sums = (float*)workspace;
+  float* partial = sums + (size_t)d->n * cs * 2;
   const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
   DISPATCH_T(d->dtype, in_bwd_reduce_kernel, dim3(chunks, ceil_div(cg_total, cgb), d->n), dim3(256), smem, s,
-             (const uint16_t*)out, (const uint16_t*)dy, (float*)workspace, d->hw, cs, ppb, act, act_slope);
+             (const uint16_t*)out, (const uint16_t*)dy, partial, d->hw, cs, ppb, act, act_slope);
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(d->n * cs, 4)), dim3(256), 0, s, (const float*)partial, sums,
+                     d->n, cs, chunks);
   const long groups = (long)d->n * d->hw * cg_total;
   DISPATCH_T(d->dtype, in_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)out,
              (const uint16_t*)dy, rstd, (const float*)workspace, (uint16_t*)dx, d->hw, cs, d->c, act, act_slope, groups);

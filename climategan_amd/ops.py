@@ -5,6 +5,8 @@ torch.cuda.current_stream()).  Every op here runs a hand-written HIP kernel from
 torch fallback.
 """
 import ctypes as C
+import functools
+import inspect
 import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -29,7 +31,8 @@ def touch(*tensors) -> None:
         torch.autograd.graph.increment_version(ts)
 
 
-MAX_MAP_BYTES = 2 ** 31
+MAX_MAP_BYTES = 2 ** 31      # the sample-independent ops slice the batch from here on (_batch_chunked; tests lower it)
+ABI_MAX_BYTES = 2 ** 31      # nothing this large is ever handed to a C-ABI call (_ptr)
 
 
 def cs8(c: int) -> int:
@@ -57,8 +60,16 @@ def _stream():
 def _ptr(t: Optional[torch.Tensor]):
     if t is None:
         return C.c_void_p(0)
+    nb = t.nbytes
+    if nb >= ABI_MAX_BYTES:
+        # several kernels address a tensor with 32-bit byte offsets (buffer descriptors, LDS-DMA lane offsets): nothing of
+        # 2 GiB or more is ever handed to the C ABI.  The sample-independent ops split the batch themselves
+        # (``_batch_chunked``); an op that reaches this line has no such split
+        raise RuntimeError("climategan_amd.ops: a %s %s tensor of %.2f GiB exceeds the 2 GiB one C-ABI call covers (32-bit "
+                           "offsets in the kernels) and this op does not split the batch; use a smaller batch per call"
+                           % (tuple(t.shape), t.dtype, nb / 2 ** 30))
     if _lib.CALL_LOG is not None:          # development aid, see _lib.CALL_LOG
-        _lib.log_bytes(t.numel() * t.element_size())
+        _lib.log_bytes(nb)
     return C.c_void_p(t.data_ptr())
 
 
@@ -103,11 +114,6 @@ class NHWC:
         if self.t.dim() != 4 or self.t.shape[3] not in (cs8(self.c), cs4(self.c)):
             raise RuntimeError("NHWC: a [N,H,W,Cs] tensor with Cs = %d (or %d) storage channels is needed for %d logical "
                                "channels, got shape %s" % (cs8(self.c), cs4(self.c), self.c, tuple(self.t.shape)))
-        # several kernels address activations with 32-bit byte offsets (buffer descriptors, LDS-DMA lane offsets): a map of
-        # 2 GiB or more is refused here rather than wrapped around there (shard the batch: 288 GB holds many such maps)
-        if self.t.numel() * self.t.element_size() >= MAX_MAP_BYTES:
-            raise RuntimeError("NHWC: a %s map of %.2f GiB exceeds the 2 GiB the kernels' 32-bit offsets cover; use a smaller "
-                               "batch per call" % (tuple(self.t.shape), self.t.numel() * self.t.element_size() / 2 ** 30))
 
     @property
     def n(self): return self.t.shape[0]
@@ -128,7 +134,95 @@ class NHWC:
         return NHWC(self.t.detach(), self.c)
 
 
+# ------------------------------------------------------------------------------------------------ maps of 2 GiB and more
+def _cat_results(outs):
+    """Concatenate per-chunk results along the batch: NHWC maps, [N, ...] tensors, tuples of those (None stays None)."""
+    first = outs[0]
+    if first is None:
+        return None
+    if isinstance(first, NHWC):
+        return NHWC(torch.cat([o.t for o in outs], 0), first.c)
+    if isinstance(first, torch.Tensor):
+        return torch.cat(outs, 0)
+    if isinstance(first, tuple):
+        return tuple(_cat_results([o[i] for o in outs]) for i in range(len(first)))
+    raise TypeError("cannot join chunk results of type %s" % type(first))
+
+
+def _batch_chunked(*split, out_bytes_per_sample=None):
+    """For ops whose samples are independent (NHWC keeps a sample contiguous: a batch slice is a view).  One C-ABI call
+    covers maps below MAX_MAP_BYTES (32-bit offsets in the kernels); when an operand named in ``split`` (NHWC maps or
+    [N, ...] tensors) or the result (``out_bytes_per_sample(get)`` with ``get(name)`` -> the call's argument) would reach
+    that, the op runs on batch slices and the results are concatenated (one extra pass over the result, only in that
+    regime): configs[3]'s global batch of 32 per domain on ONE GPU has 3.4 GB maps (the SPADE hidden map, VGG's first
+    block).  Below 1/256 of the limit nothing is examined (no op grows a map 256-fold)."""
+    def deco(fn):
+        params = list(inspect.signature(fn).parameters)
+        defaults = {k: v.default for k, v in inspect.signature(fn).parameters.items()}
+        idx = [(params.index(name), name) for name in split]
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            big = 0
+            for v in args:
+                if type(v) is NHWC:
+                    big = max(big, v.t.nbytes)
+                elif type(v) is torch.Tensor:
+                    big = max(big, v.nbytes)
+            for v in kwargs.values():
+                if type(v) is NHWC:
+                    big = max(big, v.t.nbytes)
+                elif type(v) is torch.Tensor:
+                    big = max(big, v.nbytes)
+            if big * 256 < MAX_MAP_BYTES:
+                return fn(*args, **kwargs)
+
+            def get(name):
+                i = params.index(name)
+                return args[i] if i < len(args) else kwargs.get(name, defaults[name])
+
+            n, per_sample = None, 0
+            for i, name in idx:
+                v = args[i] if i < len(args) else kwargs.get(name)
+                if v is None:
+                    continue
+                t = v.t if type(v) is NHWC else v
+                n = t.shape[0]
+                per_sample = max(per_sample, t.nbytes // max(n, 1))
+            if n is None:
+                return fn(*args, **kwargs)
+            if out_bytes_per_sample is not None:
+                per_sample = max(per_sample, int(out_bytes_per_sample(get)))
+            if n * per_sample < MAX_MAP_BYTES:
+                return fn(*args, **kwargs)
+            k = (MAX_MAP_BYTES - 1) // per_sample
+            if k < 1:
+                raise RuntimeError("%s: ONE sample's map (%.2f GiB) exceeds the 2 GiB a C-ABI call covers"
+                                   % (fn.__name__, per_sample / 2 ** 30))
+            outs = []
+            for lo in range(0, n, k):
+                a, kw = list(args), dict(kwargs)
+                for i, name in idx:
+                    v = a[i] if i < len(a) else kw.get(name)
+                    if v is None:
+                        continue
+                    piece = NHWC(v.t[lo:lo + k], v.c) if type(v) is NHWC else v[lo:lo + k]
+                    if i < len(a):
+                        a[i] = piece
+                    else:
+                        kw[name] = piece
+                outs.append(fn(*a, **kw))
+            return _cat_results(outs)
+        return wrapper
+    return deco
+
+
+def _conv_out_hw(h, w, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
 # ------------------------------------------------------------------------------------------------ layout
+@_batch_chunked("x", "mask", out_bytes_per_sample=lambda g: g("x").shape[2] * g("x").shape[3] * (g("cs") or cs8(g("x").shape[1])) * 2)
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cs: Optional[int] = None,
                  mask: Optional[torch.Tensor] = None) -> NHWC:
     """fp32 NCHW -> 16-bit NHWC (optionally times (1 - mask): cond = x * (1 - m), reference generator.py:294)."""
@@ -146,6 +240,7 @@ def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cs: Optional[int] = None,
     return NHWC(y, c)
 
 
+@_batch_chunked("y", "paste_x", "paste_m", out_bytes_per_sample=lambda g: g("y").h * g("y").w * g("y").c * 4)
 def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optional[torch.Tensor] = None):
     """16-bit NHWC -> fp32 NCHW; with paste: out = paste_x * (1 - m) + y * m (reference generator.py:295-296)."""
     _need_cuda(y.t, paste_x, paste_m)
@@ -161,6 +256,7 @@ def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optio
     return out
 
 
+@_batch_chunked("x", out_bytes_per_sample=lambda g: g("size")[0] * g("size")[1] * (g("cs_out") or g("x").cs) * 2)
 def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None) -> NHWC:
     _need_cuda(x.t)
     oh, ow = size
@@ -172,6 +268,7 @@ def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None)
     return NHWC(y, x.c)
 
 
+@_batch_chunked("dy", out_bytes_per_sample=lambda g: g("size_in")[0] * g("size_in")[1] * g("cs_in") * 2)
 def resize_nearest_bwd(dy: NHWC, size_in: Tuple[int, int], cs_in: int) -> NHWC:
     """Adjoint of ``resize_nearest``: the gradient of the (h_in, w_in) source map with ``cs_in`` storage channels."""
     _need_cuda(dy.t)
@@ -183,6 +280,7 @@ def resize_nearest_bwd(dy: NHWC, size_in: Tuple[int, int], cs_in: int) -> NHWC:
     return NHWC(dx, dy.c)
 
 
+@_batch_chunked("x")
 def avgpool3x3s2(x: NHWC) -> NHWC:
     _need_cuda(x.t)
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
@@ -245,6 +343,7 @@ def concat_channels(xs) -> NHWC:
     return NHWC(y, c_total)
 
 
+@_batch_chunked("a", "b")
 def eltwise_mul(a: NHWC, b: NHWC) -> NHWC:
     _need_cuda(a.t, b.t)
     if a.t.shape != b.t.shape or a.c != b.c:
@@ -543,6 +642,9 @@ def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
 _PACK_TABLES = []
 
 
+@_batch_chunked("x", "residual", out_bytes_per_sample=lambda g: (lambda hw: hw[0] * hw[1] * cs8(g("pw").c_out) * 2)(
+    _conv_out_hw(g("x").h * (2 if g("in_upsample") else 1), g("x").w * (2 if g("in_upsample") else 1), g("pw").kh, g("stride"),
+                 g("pad"), g("dilation"))))
 def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2,
            residual: Optional[NHWC] = None, in_upsample=False, residual_upsample=False) -> NHWC:
     """y = act(conv(x) + bias + residual) on NHWC tensors; x may be read through a folded x2 nearest upsample."""
@@ -677,6 +779,7 @@ def batchnorm_train_stats_from_partials(st: ConvStats, groups: int, pix_per_grou
     return stats[0], stats[1], stats[2], stats[3]
 
 
+@_batch_chunked("dxp")
 def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
     """Backward of nn.ReflectionPad2d(pad): folds the gradient of the padded tensor onto the unpadded extent."""
     _need_cuda(dxp.t)
@@ -695,6 +798,15 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     padding: data gradient of the pad-0 conv over the padded extent, folded back by the reflection's adjoint.
     ``add``: another gradient contribution of the same input tensor, summed in the kernel's epilogue (stride-1 'same'
     convolutions with zero padding; otherwise by a separate pass)."""
+    per_sample = max(dy.t.nbytes // max(dy.n, 1), (x_shape[1] + 2 * pad) * (x_shape[2] + 2 * pad) * cs8(w.shape[1]) * 2)
+    if x_shape[0] * per_sample >= MAX_MAP_BYTES:                 # see _batch_chunked
+        k = (MAX_MAP_BYTES - 1) // per_sample
+        if k < 1:
+            raise RuntimeError("conv2d_bwd_data: ONE sample's map exceeds the 2 GiB a C-ABI call covers")
+        return _cat_results([conv2d_bwd_data(NHWC(dy.t[lo:lo + k], dy.c), w, (min(k, x_shape[0] - lo), x_shape[1], x_shape[2]),
+                                             stride, pad, dilation, sigma, pad_mode,
+                                             NHWC(add.t[lo:lo + k], add.c) if add is not None else None, prepacked)
+                             for lo in range(0, x_shape[0], k)])
     if add is not None and not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1)
                                 and w.shape[2] == w.shape[3]):
         dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode, prepacked=prepacked)
@@ -735,6 +847,7 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     return NHWC(dx, c_in)
 
 
+@_batch_chunked("x")
 def sumpool2x2(x: NHWC) -> NHWC:
     """Backward of the nearest x2 upsample: sums of 2x2 blocks."""
     _need_cuda(x.t)
@@ -788,6 +901,15 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
                       pad_mode=PAD_ZERO, use_workspace=True):
     """(dw fp32 OIHW, dbias fp32 [c_out]) of y = conv(x, w) + b; accumulates into ``dw`` / ``dbias`` when given.
     ``in_upsample``: x is the stored (half-resolution) tensor the forward read through the folded x2 upsample."""
+    per_sample = max(x.t.nbytes, dy.t.nbytes) // max(x.n, 1)
+    if x.n * per_sample >= MAX_MAP_BYTES:                        # see _batch_chunked: the gradient sums over batch slices
+        k = (MAX_MAP_BYTES - 1) // per_sample
+        if k < 1:
+            raise RuntimeError("conv2d_bwd_weight: ONE sample's map exceeds the 2 GiB a C-ABI call covers")
+        for lo in range(0, x.n, k):
+            dw, dbias = conv2d_bwd_weight(NHWC(x.t[lo:lo + k], x.c), NHWC(dy.t[lo:lo + k], dy.c), w_shape, stride, pad, dilation,
+                                          want_bias, dw, dbias, in_upsample, pad_mode, use_workspace)
+        return dw, dbias
     _need_cuda(x.t, dy.t, dw, dbias)
     _need_cs8("conv2d_bwd_weight", x, dy)
     c_out, c_in, kh, kw = w_shape
@@ -814,6 +936,7 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
 
 
 # ------------------------------------------------------------------------------------------------ norms
+@_batch_chunked("x")
 def instnorm_stats(x: NHWC, eps: float = 1e-5):
     """Per-(n,c) mean and 1/sqrt(var+eps) (biased var over H*W) -> two fp32 [N, Cs] tensors."""
     _need_cuda(x.t)
@@ -828,6 +951,7 @@ def instnorm_stats(x: NHWC, eps: float = 1e-5):
     return mean, rstd
 
 
+@_batch_chunked("x", "mean", "rstd", "residual")
 def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2, residual: NHWC = None) -> NHWC:
     """y = act((x - mean) * rstd [+ residual])."""
     _need_cuda(x.t, mean, rstd)
@@ -846,6 +970,7 @@ def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2, residual: NHWC 
 
 
 # ------------------------------------------------------------------------------------------------ training path
+@_batch_chunked("out", "dy")
 def act_bwd(out: NHWC, dy: NHWC, act, slope=0.2) -> NHWC:
     """dx = dy * act'(.) with the derivative taken from the activation's output."""
     _need_cuda(out.t, dy.t)
@@ -856,6 +981,7 @@ def act_bwd(out: NHWC, dy: NHWC, act, slope=0.2) -> NHWC:
     return NHWC(dx, out.c)
 
 
+@_batch_chunked("out", "dy", "rstd")
 def instnorm_act_bwd(out: NHWC, dy: NHWC, rstd: torch.Tensor, act=ACT_NONE, slope=0.2) -> NHWC:
     """Backward of out = act(instance_norm(x)) given out, dy and the forward's rstd (act none or LeakyReLU)."""
     _need_cuda(out.t, dy.t, rstd)
@@ -869,6 +995,7 @@ def instnorm_act_bwd(out: NHWC, dy: NHWC, rstd: torch.Tensor, act=ACT_NONE, slop
     return NHWC(dx, out.c)
 
 
+@_batch_chunked("x")
 def bce_logits(x: NHWC, target: float, weight: float, loss_accum: torch.Tensor, want_grad=True):
     """loss_accum += weight * sum BCEWithLogits(x, target) over x's logical channels; returns d(loss)/dx or None."""
     _need_cuda(x.t, loss_accum)
@@ -879,6 +1006,7 @@ def bce_logits(x: NHWC, target: float, weight: float, loss_accum: torch.Tensor, 
     return NHWC(dx, x.c) if want_grad else None
 
 
+@_batch_chunked("x")
 def hinge_loss(x: NHWC, target_is_real: bool, for_discriminator: bool, weight: float, loss_accum: torch.Tensor,
                want_grad=True):
     """loss_accum += weight * sum HingeLoss.loss terms of x's logical channels (reference losses.py:565-579); returns
@@ -892,6 +1020,7 @@ def hinge_loss(x: NHWC, target_is_real: bool, for_discriminator: bool, weight: f
     return NHWC(dx, x.c) if want_grad else None
 
 
+@_batch_chunked("a", "b")
 def l1_loss(a: NHWC, b: NHWC, weight: float, loss_accum: torch.Tensor, want_grad=True):
     """loss_accum += weight * sum|a - b|; returns d(loss)/da or None."""
     _need_cuda(a.t, b.t, loss_accum)
@@ -947,6 +1076,7 @@ def pack_spade_weights(w_shared, b_shared, w_gamma, b_gamma, w_beta, b_beta, dty
     return PackedSpade(buf, c, cond_c, dtype)
 
 
+@_batch_chunked("x", "mean", "rstd", "cond", out_bytes_per_sample=lambda g: g("x").h * g("x").w * g("x").cs * 2 * (4 if g("x_upsample") else 1))
 def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, slope=0.2, x_upsample=False) -> NHWC:
     """Fused SPADE: act((x-mean)*rstd*(1+gamma(cond))+beta(cond)); x optionally read through x2 nearest."""
     _need_cuda(x.t, cond.t, mean, rstd)
@@ -965,6 +1095,7 @@ def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, 
     return NHWC(y, x.c)
 
 
+@_batch_chunked("dy", "y", "x", "mean", "rstd", "gamma", out_bytes_per_sample=lambda g: g("y").h * g("y").w * cs8(2 * g("y").c) * 2)
 def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=ACT_NONE, slope=0.2, x_upsample=False):
     """Elementwise stage of the SPADE backward: returns (dgb [2C channels: d_gamma | d_beta], xhat, dxhat)."""
     _need_cuda(dy.t, y.t, x.t, mean, rstd, gamma.t)
@@ -980,6 +1111,7 @@ def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=A
     return NHWC(dgb, 2 * c), NHWC(xhat, c), NHWC(dxhat, c)
 
 
+@_batch_chunked("fake", "x", "m")
 def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype, want_d=True, want_vgg=False):
     """(d_in, vgg_in) of the pasted image p = x (1 - m) + fake m (or p = x when ``fake`` is None): the discriminator
     input [m | p] (4 channels) and vgg_preprocess(p * m), NHWC 16-bit; x, m NCHW fp32.  The VGG input is stored as a
@@ -997,6 +1129,7 @@ def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype,
     return (NHWC(d_in, 4) if want_d else None), (NHWC(v_in, 6) if want_vgg else None)
 
 
+@_batch_chunked("d_d_in", "d_vgg_in", "m")
 def painter_heads_bwd(d_d_in: Optional[NHWC], d_vgg_in: Optional[NHWC], m: torch.Tensor) -> NHWC:
     ref = d_d_in if d_d_in is not None else d_vgg_in
     _need_cuda(ref.t, m)
@@ -1010,6 +1143,7 @@ def painter_heads_bwd(d_d_in: Optional[NHWC], d_vgg_in: Optional[NHWC], m: torch
     return NHWC(dfake, 3)
 
 
+@_batch_chunked("dy", out_bytes_per_sample=lambda g: g("in_hw")[0] * g("in_hw")[1] * g("dy").cs * 2)
 def avgpool3x3s2_bwd(dy: NHWC, in_hw) -> NHWC:
     _need_cuda(dy.t)
     h, w = in_hw
@@ -1020,6 +1154,7 @@ def avgpool3x3s2_bwd(dy: NHWC, in_hw) -> NHWC:
     return NHWC(dx, dy.c)
 
 
+@_batch_chunked("x")
 def maxpool2x2(x: NHWC) -> NHWC:
     _need_cuda(x.t)
     y = torch.empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
@@ -1029,6 +1164,7 @@ def maxpool2x2(x: NHWC) -> NHWC:
     return NHWC(y, x.c)
 
 
+@_batch_chunked("x", "dy")
 def maxpool2x2_bwd(x: NHWC, dy: NHWC) -> NHWC:
     _need_cuda(x.t, dy.t)
     dx = torch.empty_like(x.t)
