@@ -718,7 +718,7 @@ def tv_loss(x: ops.NHWC, tvloss_weight=1.0):
 def minent_loss(p: ops.NHWC, version=1, lambda_var=0.1):
     """MinentLoss.__call__ (losses.py:185-196) on a probability map."""
     n = _npix(p.t)
-    ws = torch.empty(1, dtype=torch.float32, device=p.t.device)
+    ws = torch.empty(4096, dtype=torch.float32, device=p.t.device)          # CGAN_MINENT_WORKSPACE_FLOATS
     return _ScalarLossFn.apply(p.t, p.c, lambda acc, dx: _call(
         "cgan_minent_nhwc", ops._ptr(p.t), p.dtype_id, n, p.c, int(version), float(lambda_var), GRAD_SCALE, ops._ptr(acc),
         ops._ptr(dx), ops._ptr(ws), ops._stream()))

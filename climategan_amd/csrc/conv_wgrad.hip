@@ -674,11 +674,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
 // read-modify-write of dW.  No atomics (the first version finished its split groups with up-to-16-way contended
 // cross-XCD atomics, which cost more than the 65 MB of partial tiles they followed).
 // (KL = 1 for layers with <= 4 splits: 256 elements per block, no LDS step.)
+// The blocks past ``main_blocks`` finish the bias gradient the same way: dbias[ch] += the channel_sum_kernel blocks' partial
+// rows, summed in block order (one thread per channel).
 template <int KL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dw,
                                                            int splits, int taps, int tap_slots, int ci_blocks,
                                                            int co_blocks, int cout, int cin, int fold, int cpt,
-                                                           int tpt) {
+                                                           int tpt, int main_blocks, const float* __restrict__ bpart,
+                                                           int bias_rows, int cout_s, float* __restrict__ dbias) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int ch = ((int)blockIdx.x - main_blocks) * 256 + (int)threadIdx.x;
+    if (ch < cout) {
+      float acc = 0.f;
+      for (int r = 0; r < bias_rows; ++r) acc += bpart[(size_t)r * cout_s + ch];
+      dbias[ch] += acc;
+    }
+    return;
+  }
   constexpr int EL = 256 / KL;
   __shared__ f32x4 red[KL][EL];
   const int tiles_n = tap_slots * ci_blocks * co_blocks;
@@ -720,10 +732,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
 }
 
 // per-channel sum over pixels of an NHWC tensor (bias gradient): per-thread partial sums over a strided pixel subset,
-// reduced across the block's pixel lanes in LDS, then ONE fp32 atomic per channel per block
+// reduced across the block's pixel lanes in LDS, then one row of per-block sums to ``part`` (plain stores; the split-reduce
+// kernel adds the rows in block order: run-to-run identical) -- or, without a workspace, ONE fp32 atomic per channel per block
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
-                                                          long npix, int cs, int c) {
+                                                          long npix, int cs, int c, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float sm_cs[];   // [ppb][groups * 8]
   const int groups = cs / 8;
   const int ppb = blockDim.x / groups;               // pixel lanes per block
@@ -748,7 +761,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
     if (ch >= c) continue;
     float acc = 0.f;
     for (int l = 0; l < ppb; ++l) acc += sm_cs[l * groups * 8 + ch];
-    atomicAdd(out + ch, acc);
+    if (part) part[(size_t)blockIdx.x * cs + ch] = acc;
+    else atomicAdd(out + ch, acc);
   }
 }
 
@@ -767,6 +781,8 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
   g_wgrad_target = target_workgroups;          // > 0: target number of workgroups; < 0: -target pixel splits, as given
   g_wgrad_dbg = dbg;
 }
+
+constexpr int BIAS_MAX_BLOCKS = 512;
 
 // Tiling of one weight-gradient call: N tiles (tap slots x ci blocks), M tiles (co blocks), pixel splits.
 struct WgradPlan {
@@ -865,7 +881,8 @@ extern "C" size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* d) 
   if (!d || d->n <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->kh <= 0 || d->kw <= 0)
     return 0;
   const WgradPlan pl = wgrad_plan(d);
-  return (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64 * sizeof(float);
+  // partial tiles | up to BIAS_MAX_BLOCKS rows of per-block channel sums (the bias gradient's deterministic reduction)
+  return (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64 * sizeof(float) + (size_t)BIAS_MAX_BLOCKS * cgan_cs(d->c_out) * sizeof(float);
 }
 
 extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias,
@@ -962,31 +979,43 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #undef WGRAD_MODE
 #undef WGRAD_LAUNCH
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
-  if (a.ws) {
-    const int elems = (int)pl.tiles() * 1024;
-    if (a.splits <= 4)
-      hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(ceil_div(elems, 256)), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
-                         a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt);
-    else
-      hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(ceil_div(elems, 32)), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
-                         a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt);
-    CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(reduce)");
-  }
+  float* bpart = nullptr;
+  int bias_rows = 0;
   if (dbias) {
     const int cs = a.cout_s;
     const int threads = 256;
     const int ppb = threads / (cs / 8) > 0 ? threads / (cs / 8) : 1;
     CGAN_REQUIRE(cs / 8 <= threads, "conv2d_nhwc_bwd_weight: too many channels for the bias reduction");
     long want = (npix + (long)ppb * 16 - 1) / ((long)ppb * 16);
-    const int grid = (int)(want < 1 ? 1 : (want > 512 ? 512 : want));
+    const int grid = (int)(want < 1 ? 1 : (want > BIAS_MAX_BLOCKS ? BIAS_MAX_BLOCKS : want));
     const size_t smem_b = (size_t)ppb * (cs / 8) * 8 * sizeof(float);
+    if (a.ws) {       // per-block rows behind the partial tiles, summed in order by the reduce kernel below
+      bpart = a.ws + (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64;
+      bias_rows = grid;
+    }
     if (d->dtype == CGAN_F16)
       hipLaunchKernelGGL(channel_sum_kernel<F16>, dim3(grid), dim3(threads), smem_b, s, (const uint16_t*)dy, dbias, npix,
-                         cs, d->c_out);
+                         cs, d->c_out, bpart);
     else
       hipLaunchKernelGGL(channel_sum_kernel<BF16>, dim3(grid), dim3(threads), smem_b, s, (const uint16_t*)dy, dbias, npix,
-                         cs, d->c_out);
+                         cs, d->c_out, bpart);
     CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(bias)");
+  }
+  if (a.ws) {
+    const int elems = (int)pl.tiles() * 1024;
+    const int bias_blocks = bpart ? ceil_div(d->c_out, 256) : 0;
+    if (a.splits <= 4) {
+      const int mb = ceil_div(elems, 256);
+      hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(mb + bias_blocks), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
+                         a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt, mb,
+                         (const float*)bpart, bias_rows, a.cout_s, dbias);
+    } else {
+      const int mb = ceil_div(elems, 32);
+      hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(mb + bias_blocks), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
+                         a.splits, taps, a.tap_slots, a.ci_blocks, a.co_blocks, a.cout, a.cin, a.fold, a.cpt, a.tpt, mb,
+                         (const float*)bpart, bias_rows, a.cout_s, dbias);
+    }
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight(reduce)");
   }
   return CGAN_OK;
 }

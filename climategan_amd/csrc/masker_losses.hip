@@ -233,16 +233,28 @@ __global__ __launch_bounds__(256) void minent_sum_kernel(const uint16_t* __restr
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
     if ((int)(i % cs) < c) acc += ent(f32_of_bits<T>(p[i]), ilc);
-  block_add(acc, sum);
+  // one partial per block, plain store: minent_kernel adds the rows in a fixed order (the mean entropy feeds the gradient of
+  // version 2: with an atomic sum it differed in the last bits from run to run)
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 // version 1: loss = S / nhw.  version 2: mu = S / nhw, loss = sum(e + lam (e - mu)^2) / nhw, whose gradient is
 // e'/nhw * (1 + 2 lam (e - mu) + 2 lam (c - 1) mu)  (the "mean" divides by n h w while the sums run over n c h w).
 template <typename T>
 __global__ __launch_bounds__(256) void minent_kernel(const uint16_t* __restrict__ p, const float* __restrict__ sum, int version,
                                                      float lam, float weight, float inv_nhw, float* __restrict__ loss,
-                                                     uint16_t* __restrict__ dp, int c, int cs, long total) {
+                                                     uint16_t* __restrict__ dp, int c, int cs, long total, int sum_rows) {
   const float ilc = 1.f / log2f((float)c);
-  const float mu = sum[0] * inv_nhw;
+  float tot = 0.f;
+  for (int r = threadIdx.x; r < sum_rows; r += 256) tot += sum[r];
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  __shared__ float tpart[4];
+  if ((threadIdx.x & 63) == 0) tpart[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  const float mu = (tpart[0] + tpart[1] + tpart[2] + tpart[3]) * inv_nhw;
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % cs);
@@ -479,22 +491,17 @@ extern "C" int cgan_advent_entropy_pair_bwd_nhwc(const void* logits, const void*
   return CGAN_OK;
 }
 extern "C" int cgan_minent_nhwc(const void* p, int32_t dtype, int64_t npix, int32_t c, int32_t version, float lambda_var,
-                                float weight, float* loss_accum, void* dp, float* workspace_scalar, void* stream) {
-  CGAN_REQUIRE(p && loss_accum && workspace_scalar && npix > 0 && c > 1, "minent: bad arguments");
+                                float weight, float* loss_accum, void* dp, float* workspace, void* stream) {
+  CGAN_REQUIRE(p && loss_accum && workspace && npix > 0 && c > 1, "minent: bad arguments");
   CGAN_REQUIRE(version == 1 || version == 2, "minent: version must be 1 or 2");
   ML_CHECK_DT("minent");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace_scalar, 0, sizeof(float), s);
-  if (e != hipSuccess) {
-    cgan_set_error("minent: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CGAN_ERR_HIP;
-  }
   const int cs = cgan_cs(c);
   const long total = (long)npix * cs;
-  ML_DISPATCH(dtype, minent_sum_kernel, dim3(grid_ml(total)), dim3(256), 0, s, (const uint16_t*)p, workspace_scalar, c, cs,
-              total);
-  ML_DISPATCH(dtype, minent_kernel, dim3(grid_ml(total)), dim3(256), 0, s, (const uint16_t*)p, (const float*)workspace_scalar,
-              version, lambda_var, weight, 1.f / (float)npix, loss_accum, (uint16_t*)dp, c, cs, total);
+  const int rows = grid_ml(total);          // <= CGAN_MINENT_WORKSPACE_FLOATS
+  ML_DISPATCH(dtype, minent_sum_kernel, dim3(rows), dim3(256), 0, s, (const uint16_t*)p, workspace, c, cs, total);
+  ML_DISPATCH(dtype, minent_kernel, dim3(grid_ml(total)), dim3(256), 0, s, (const uint16_t*)p, (const float*)workspace,
+              version, lambda_var, weight, 1.f / (float)npix, loss_accum, (uint16_t*)dp, c, cs, total, rows);
   CGAN_CHECK_LAUNCH("minent");
   return CGAN_OK;
 }

@@ -65,9 +65,42 @@ __global__ void sel_pick_kernel(SelState* st, int shift) {
   if (threadIdx.x < 256) st->hist[threadIdx.x] = 0;
 }
 
+// Deterministic reductions: a kernel's block b leaves its partial sums in parts[j][b] (plain stores, j < 3 quantities, at
+// most PARTS_ROWS blocks); finish_sums_kernel (one block) adds the rows in a fixed order into stats[slot_j] (scaled,
+// accumulating when asked: the Sobel sum runs over the scales).  The first version used fp32 atomics: s_p, s_q and the
+// chain-rule sums feed the gradient, which then differed in its last bits from run to run.
+constexpr int PARTS_ROWS = 1024;
+__device__ __forceinline__ void block_partial(float v, float* __restrict__ row) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __shared__ float pp[4];      // (called up to three times per kernel with distinct rows: every call ends in a barrier)
+  if ((threadIdx.x & 63) == 0) pp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) row[blockIdx.x] = pp[0] + pp[1] + pp[2] + pp[3];
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void finish_sums_kernel(const float* __restrict__ parts, int rows, float* __restrict__ stats,
+                                                          int slot0, int slot1, int slot2, float scale, int accumulate) {
+  __shared__ float wsum[4];
+  const int slots[3] = {slot0, slot1, slot2};
+  for (int j = 0; j < 3; ++j) {
+    if (slots[j] < 0) continue;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) acc += parts[j * PARTS_ROWS + r];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float tot = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale;
+      stats[slots[j]] = accumulate ? stats[slots[j]] + tot : tot;
+    }
+    __syncthreads();
+  }
+}
+
 // stats: [0] t_p [1] s_p [2] t_q [3] s_q [4] sum|R| [5] sobel sum [6] sumG [7] sumG*(p-t) [8] sum sign(p-t)  [9] (int) median idx
 template <typename T, bool PRED>
-__global__ __launch_bounds__(256) void absdev_kernel(const void* v, const SelState* st, float* stats, int slot, long n) {
+__global__ __launch_bounds__(256) void absdev_kernel(const void* v, const SelState* st, float* stats, float* parts, int slot,
+                                                     long n) {
   const float t = fkey_inv(st->prefix);
   float acc = 0.f;
   int best = 0x7fffffff;
@@ -76,14 +109,14 @@ __global__ __launch_bounds__(256) void absdev_kernel(const void* v, const SelSta
     acc += fabsf(x - t);
     if (PRED && x == t && (int)i < best) best = (int)i;
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&stats[slot + 1], acc / (float)n);
-  if (PRED && best != 0x7fffffff) atomicMin(reinterpret_cast<int*>(&stats[9]), best);
+  if (PRED && best != 0x7fffffff) atomicMin(reinterpret_cast<int*>(&stats[9]), best);     // (integer: order-independent)
   if (blockIdx.x == 0 && threadIdx.x == 0) stats[slot] = t;
+  block_partial(acc, parts);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void residual_kernel(const uint16_t* p, const float* q, float* stats, float* R, long n) {
+__global__ __launch_bounds__(256) void residual_kernel(const uint16_t* p, const float* q, const float* stats, float* parts,
+                                                       float* R, long n) {
   const float tp = stats[0], sp = stats[1], tq = stats[2], sq = stats[3];
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -91,54 +124,74 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint16_t* p, const 
     R[i] = r;
     acc += fabsf(r);
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&stats[4], acc);
+  block_partial(acc, parts);
 }
 
-// one thread per valid Sobel position of scale k: accumulates |Rx| + |Ry| and scatters their sub-gradients into G
-__global__ __launch_bounds__(256) void sobel_kernel(const float* R, float* G, float* stats, int b, int h, int w, int k,
-                                                    float gscale) {
+// Sobel responses of scale k at (y, x) of the strided map R[::st, ::st]
+__device__ __forceinline__ void sobel_at(const float* __restrict__ base, int w, int st, int y, int x, float& rx, float& ry) {
+  float v[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[a][c] = base[(long)((y + a) * st) * w + (x + c) * st];
+  // sobelx = [[1,0,-1],[2,0,-2],[1,0,-1]], sobely = [[1,2,1],[0,0,0],[-1,-2,-1]]   (cross-correlation, losses.py:245-246)
+  rx = v[0][0] - v[0][2] + 2.f * (v[1][0] - v[1][2]) + v[2][0] - v[2][2];
+  ry = v[0][0] + 2.f * v[0][1] + v[0][2] - v[2][0] - 2.f * v[2][1] - v[2][2];
+}
+
+// one thread per valid Sobel position of scale k: |Rx| + |Ry| into per-block partial rows
+__global__ __launch_bounds__(256) void sobel_kernel(const float* R, float* parts, int b, int h, int w, int k) {
   const int st = 1 << k, hk = h >> k, wk = w >> k;
   const int oh = hk - 2, ow = wk - 2;
-  if (oh <= 0 || ow <= 0) return;
-  const long total = (long)b * oh * ow;
+  const long total = (oh > 0 && ow > 0) ? (long)b * oh * ow : 0;
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % ow);
     const long r = i / ow;
     const int y = (int)(r % oh);
     const long n = r / oh;
+    float rx, ry;
+    sobel_at(R + n * (long)h * w, w, st, y, x, rx, ry);
+    acc += fabsf(rx) + fabsf(ry);
+  }
+  block_partial(acc, parts);
+}
+
+// The gradient of that sum in GATHER form: one thread per pixel of the scale-k grid adds the sub-gradients of the <= 9
+// windows that contain it (re-evaluating their responses) -- G[pixel] += ..., one writer per pixel, the scales in launch
+// order: no atomics (the first version scattered with fp32 atomics).
+__global__ __launch_bounds__(256) void sobel_grad_kernel(const float* R, float* G, int b, int h, int w, int k, float gscale) {
+  const int st = 1 << k, hk = h >> k, wk = w >> k;
+  const int oh = hk - 2, ow = wk - 2;
+  if (oh <= 0 || ow <= 0) return;
+  const long total = (long)b * hk * wk;
+  const float wx[3][3] = {{1, 0, -1}, {2, 0, -2}, {1, 0, -1}}, wy[3][3] = {{1, 2, 1}, {0, 0, 0}, {-1, -2, -1}};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % wk);
+    const long r = i / wk;
+    const int Y = (int)(r % hk);
+    const long n = r / hk;
     const float* base = R + n * (long)h * w;
-    float v[3][3];
+    float g = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[a][c] = base[(long)((y + a) * st) * w + (x + c) * st];
-    // sobelx = [[1,0,-1],[2,0,-2],[1,0,-1]], sobely = [[1,2,1],[0,0,0],[-1,-2,-1]]   (cross-correlation, losses.py:245-246)
-    const float rx = v[0][0] - v[0][2] + 2.f * (v[1][0] - v[1][2]) + v[2][0] - v[2][2];
-    const float ry = v[0][0] + 2.f * v[0][1] + v[0][2] - v[2][0] - 2.f * v[2][1] - v[2][2];
-    acc += fabsf(rx) + fabsf(ry);
-    if (G) {
-      const float sx = rx > 0.f ? gscale : (rx < 0.f ? -gscale : 0.f), sy = ry > 0.f ? gscale : (ry < 0.f ? -gscale : 0.f);
-      float* gb = G + n * (long)h * w;
-      const float wx[3][3] = {{1, 0, -1}, {2, 0, -2}, {1, 0, -1}}, wy[3][3] = {{1, 2, 1}, {0, 0, 0}, {-1, -2, -1}};
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float g = wx[a][c] * sx + wy[a][c] * sy;
-          if (g != 0.f) atomicAdd(gb + (long)((y + a) * st) * w + (x + c) * st, g);
-        }
-    }
+      for (int c = 0; c < 3; ++c) {
+        const int y = Y - a, x = X - c;                  // the window whose tap (a, c) is this pixel
+        if (y < 0 || y >= oh || x < 0 || x >= ow) continue;
+        float rx, ry;
+        sobel_at(base, w, st, y, x, rx, ry);
+        const float sx = rx > 0.f ? gscale : (rx < 0.f ? -gscale : 0.f), sy = ry > 0.f ? gscale : (ry < 0.f ? -gscale : 0.f);
+        g += wx[a][c] * sx + wy[a][c] * sy;
+      }
+    if (g != 0.f) G[n * (long)h * w + (long)(Y * st) * w + X * st] += g;
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&stats[5], acc);
 }
 
 // G += simse term; reductions for the chain rule through (p - t)/s
 template <typename T>
-__global__ __launch_bounds__(256) void grad_sums_kernel(const uint16_t* p, const float* R, float* G, float* stats,
-                                                        float simse_w, long n) {
+__global__ __launch_bounds__(256) void grad_sums_kernel(const uint16_t* p, const float* R, float* G, const float* stats,
+                                                        float* parts, float simse_w, long n) {
   const float tp = stats[0];
   float a = 0.f, b = 0.f, c = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -150,8 +203,9 @@ __global__ __launch_bounds__(256) void grad_sums_kernel(const uint16_t* p, const
     b += g * d;
     c += d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
   }
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[6], a); atomicAdd(&stats[7], b); atomicAdd(&stats[8], c); }
+  block_partial(a, parts);
+  block_partial(b, parts + PARTS_ROWS);
+  block_partial(c, parts + 2 * PARTS_ROWS);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void grad_final_kernel(const uint16_t* p, const float* G, const float* stats,
@@ -183,6 +237,7 @@ int run(const void* pred, const float* target, float* loss, void* dpred, int b, 
   SelState* st_p = (SelState*)wp; wp += 2048;
   SelState* st_q = (SelState*)wp; wp += 2048;
   float* stats = (float*)wp; wp += 256;
+  float* parts = (float*)wp; wp += 3 * PARTS_ROWS * sizeof(float);
   float* R = (float*)wp; wp += ((size_t)n * 4 + 255) / 256 * 256;
   float* G = (float*)wp;
   hipError_t e = hipMemsetAsync(stats, 0, 64, s);
@@ -205,22 +260,36 @@ int run(const void* pred, const float* target, float* loss, void* dpred, int b, 
     cgan_set_error("sigm: hipMemsetAsync failed: %s", hipGetErrorString(e));
     return CGAN_ERR_HIP;
   }
-  hipLaunchKernelGGL((absdev_kernel<T, true>), dim3(g1(n)), dim3(256), 0, s, pred, (const SelState*)st_p, stats, 0, n);
-  hipLaunchKernelGGL((absdev_kernel<T, false>), dim3(g1(n)), dim3(256), 0, s, (const void*)target, (const SelState*)st_q,
-                     stats, 2, n);
-  hipLaunchKernelGGL(residual_kernel<T>, dim3(g1(n)), dim3(256), 0, s, (const uint16_t*)pred, target, stats, R, n);
+#define FINISH(rows, s0, s1, s2, scale, accum) \
+  hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(256), 0, s, (const float*)parts, rows, stats, s0, s1, s2, scale, accum)
+  const int gn = g1(n);
+  hipLaunchKernelGGL((absdev_kernel<T, true>), dim3(gn), dim3(256), 0, s, pred, (const SelState*)st_p, stats, parts, 0, n);
+  FINISH(gn, 1, -1, -1, 1.f / (float)n, 0);
+  hipLaunchKernelGGL((absdev_kernel<T, false>), dim3(gn), dim3(256), 0, s, (const void*)target, (const SelState*)st_q,
+                     stats, parts, 2, n);
+  FINISH(gn, 3, -1, -1, 1.f / (float)n, 0);
+  hipLaunchKernelGGL(residual_kernel<T>, dim3(gn), dim3(256), 0, s, (const uint16_t*)pred, target, (const float*)stats, parts,
+                     R, n);
+  FINISH(gn, 4, -1, -1, 1.f, 0);
   const float inv_np = 1.f / (float)((long)h * w);
-  for (int kk = 0; kk < scales; ++kk)
-    hipLaunchKernelGGL(sobel_kernel, dim3(g1(n >> (2 * kk))), dim3(256), 0, s, (const float*)R, dpred ? G : nullptr, stats,
-                       b, h, w, kk, gmweight * inv_np * (float)b);
+  for (int kk = 0; kk < scales; ++kk) {
+    const int gk = g1(n >> (2 * kk));
+    hipLaunchKernelGGL(sobel_kernel, dim3(gk), dim3(256), 0, s, (const float*)R, parts, b, h, w, kk);
+    FINISH(gk, 5, -1, -1, 1.f, 1);                                   // (stats[5] starts at 0: the memset above)
+    if (dpred)
+      hipLaunchKernelGGL(sobel_grad_kernel, dim3(gk), dim3(256), 0, s, (const float*)R, G, b, h, w, kk,
+                         gmweight * inv_np * (float)b);
+  }
   hipLaunchKernelGGL(sigm_loss_kernel, dim3(1), dim3(64), 0, s, (const float*)stats, loss, weight, inv_np, gmweight,
                      (float)b);
   if (dpred) {
-    hipLaunchKernelGGL(grad_sums_kernel<T>, dim3(g1(n)), dim3(256), 0, s, (const uint16_t*)pred, (const float*)R, G, stats,
-                       0.5f * inv_np, n);
-    hipLaunchKernelGGL(grad_final_kernel<T>, dim3(g1(n)), dim3(256), 0, s, (const uint16_t*)pred, (const float*)G,
+    hipLaunchKernelGGL(grad_sums_kernel<T>, dim3(gn), dim3(256), 0, s, (const uint16_t*)pred, (const float*)R, G,
+                       (const float*)stats, parts, 0.5f * inv_np, n);
+    FINISH(gn, 6, 7, 8, 1.f, 0);
+    hipLaunchKernelGGL(grad_final_kernel<T>, dim3(gn), dim3(256), 0, s, (const uint16_t*)pred, (const float*)G,
                        (const float*)stats, (uint16_t*)dpred, weight, n);
   }
+#undef FINISH
   return CGAN_OK;
 }
 
@@ -229,7 +298,7 @@ int run(const void* pred, const float* target, float* loss, void* dpred, int b, 
 extern "C" size_t cgan_sigm_loss_workspace_bytes(int32_t b, int32_t h, int32_t w) {
   if (b <= 0 || h <= 0 || w <= 0) return 0;
   const size_t n = (size_t)b * h * w;
-  return 2048 * 2 + 256 + 2 * ((n * 4 + 255) / 256 * 256);
+  return 2048 * 2 + 256 + 3 * PARTS_ROWS * sizeof(float) + 2 * ((n * 4 + 255) / 256 * 256);
 }
 
 extern "C" int cgan_sigm_loss_nhwc(const void* pred, const float* target, int32_t dtype, int32_t b, int32_t h, int32_t w,

@@ -575,18 +575,32 @@ __global__ __launch_bounds__(256) void l1_kernel(const uint16_t* __restrict__ a,
 }
 
 // ---- spectral norm: gradient w.r.t. w_bar from the gradient w.r.t. w = w_bar / sigma, sigma = u^T w_bar v ------
+// Deterministic: block b leaves its partial <g, w_bar> in part[b] (plain store); every block of the apply kernel adds the
+// rows in the same fixed order (SN_BWD_ROWS floats from L2) -- no memset, no atomics, run-to-run identical gradients.
+constexpr int SN_BWD_ROWS = 1024;
 __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ g, const float* __restrict__ w_bar,
-                                                         float* __restrict__ dot, long numel) {
+                                                         float* __restrict__ part, long numel) {
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x)
     acc += g[i] * w_bar[i];
-  block_atomic_add(acc, dot);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ float wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
-__global__ void sn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
-                                    const float* __restrict__ sigma, const float* __restrict__ dot, int cols,
-                                    long numel) {
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ u,
+                                                           const float* __restrict__ v, const float* __restrict__ sigma,
+                                                           const float* __restrict__ part, int rows_n, int cols, long numel) {
+  float acc = 0.f;
+  for (int r = threadIdx.x; r < rows_n; r += 256) acc += part[r];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ float wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const float dot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   const float inv = 1.f / sigma[0];
-  const float k = dot[0] * inv * inv;
+  const float k = dot * inv * inv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
     g[i] = g[i] * inv - k * u[r] * v[c];
@@ -800,22 +814,17 @@ extern "C" int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t
 }
 
 extern "C" int cgan_spectral_norm_bwd(float* grad_w, const float* w_bar, const float* u, const float* v,
-                                      const float* sigma, int32_t rows, int32_t cols, float* workspace_scalar,
+                                      const float* sigma, int32_t rows, int32_t cols, float* workspace,
                                       void* stream) {
-  CGAN_REQUIRE(grad_w && w_bar && u && v && sigma && workspace_scalar, "spectral_norm_bwd: null pointer");
+  CGAN_REQUIRE(grad_w && w_bar && u && v && sigma && workspace, "spectral_norm_bwd: null pointer");
   CGAN_REQUIRE(rows > 0 && cols > 0, "spectral_norm_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace_scalar, 0, sizeof(float), s);
-  if (e != hipSuccess) {
-    cgan_set_error("spectral_norm_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CGAN_ERR_HIP;
-  }
   const long numel = (long)rows * cols;
   int g = grid_for_n(numel);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(g), dim3(256), 0, s, (const float*)grad_w, w_bar, workspace_scalar, numel);
+  if (g > SN_BWD_ROWS) g = SN_BWD_ROWS;
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(g), dim3(256), 0, s, (const float*)grad_w, w_bar, workspace, numel);
   hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(grid_for_n(numel)), dim3(256), 0, s, grad_w, u, v, sigma,
-                     (const float*)workspace_scalar, cols, numel);
+                     (const float*)workspace, g, cols, numel);
   CGAN_CHECK_LAUNCH("spectral_norm_bwd");
   return CGAN_OK;
 }

@@ -1039,7 +1039,7 @@ def spectral_norm_bwd(grad_w: torch.Tensor, w_bar: torch.Tensor, u: torch.Tensor
     _need_cuda(grad_w, w_bar, u, v, sigma)
     rows = w_bar.shape[0]
     cols = w_bar.numel() // rows
-    scratch = torch.empty(1, dtype=torch.float32, device=grad_w.device)
+    scratch = torch.empty(1024, dtype=torch.float32, device=grad_w.device)      # CGAN_SN_BWD_WORKSPACE_FLOATS
     lib = _lib.load()
     _lib.check(lib.cgan_spectral_norm_bwd(_ptr(grad_w), _ptr(w_bar), _ptr(u), _ptr(v), _ptr(sigma), rows, cols,
                                           _ptr(scratch), _stream()), "cgan_spectral_norm_bwd")

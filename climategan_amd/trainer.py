@@ -483,10 +483,16 @@ class Trainer:
                     self._backward([m_loss, p_loss], self.G, side)
                     g_loss = m_loss.detach() + p_loss.detach()
             else:
+                # The Painter's terms first, as on the forked path above: the label-noise draws of GANLoss come in the same
+                # order whether or not the branches overlap (the reference shuffles the domain order per iteration,
+                # trainer.py:948).  With pl4m the Masker's loss runs the Painter itself (one more power iteration of its
+                # spectral norms): there the Masker domains go first, the order the pl4m fixtures were captured in.
+                p_loss = self.get_painter_loss(multi_domain_batch) if (do_p and not self.use_pl4m) else 0
                 if do_m:
                     g_loss = g_loss + self.get_masker_loss(multi_domain_batch)
-                if do_p:
-                    g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
+                if do_p and self.use_pl4m:
+                    p_loss = self.get_painter_loss(multi_domain_batch)
+                g_loss = g_loss + p_loss
             if not isinstance(g_loss, torch.Tensor):
                 # every term switched off (all lambdas 0): the reference would fail on ``int.backward()``; nothing to
                 # differentiate and nothing for the optimizer to do

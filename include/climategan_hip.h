@@ -370,9 +370,11 @@ int cgan_hinge_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, int32
 int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t numel, float weight, float* loss_accum, void* da,
                  void* stream);
 /* spectral norm backward (autograd of climategan/norms.py:107-112, u and v constants): in place
- * grad_w <- grad_w / sigma - (<grad_w, w_bar> / sigma^2) u v^T; workspace_scalar: one device float. */
+ * grad_w <- grad_w / sigma - (<grad_w, w_bar> / sigma^2) u v^T; workspace: CGAN_SN_BWD_WORKSPACE_FLOATS device floats
+ * (per-block partial dot products, summed in a fixed order: no memset, no atomics, run-to-run identical). */
+#define CGAN_SN_BWD_WORKSPACE_FLOATS 1024
 int cgan_spectral_norm_bwd(float* grad_w, const float* w_bar, const float* u, const float* v, const float* sigma,
-                           int32_t rows, int32_t cols, float* workspace_scalar, void* stream);
+                           int32_t rows, int32_t cols, float* workspace, void* stream);
 
 /* Painter training-step glue (climategan/trainer.py:1256-1387 G side, 1073-1107 D side).
  * heads_fwd: p = fake ? x (1 - m) + fake m : x  (the paste of generator.py:295-296; fake NHWC 3 channels stored as 8,
@@ -434,8 +436,10 @@ int cgan_entropy_pair_from_nchw_bwd(const float* prob, const float* depth, const
 int cgan_entropy_map_nhwc(const void* p, const void* depth, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream);
 int cgan_entropy_map_bwd_nhwc(const void* p, const void* depth, const void* dy, void* dp, int32_t dtype, int64_t npix,
                               int32_t c, void* stream);
+/* workspace: CGAN_MINENT_WORKSPACE_FLOATS device floats (per-block partial sums of the mean entropy, added in a fixed order) */
+#define CGAN_MINENT_WORKSPACE_FLOATS 4096
 int cgan_minent_nhwc(const void* p, int32_t dtype, int64_t npix, int32_t c, int32_t version, float lambda_var,
-                     float weight, float* loss_accum, void* dp, float* workspace_scalar, void* stream);
+                     float weight, float* loss_accum, void* dp, float* workspace, void* stream);
 int cgan_bce_logits_map_nhwc(const void* x, const float* target, int32_t dtype, int64_t npix, float weight,
                              float* loss_accum, void* dx, void* stream);
 int cgan_ground_intersection_nhwc(const void* p, const float* ground, int32_t dtype, int64_t npix, float weight,
