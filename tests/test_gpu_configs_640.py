@@ -349,11 +349,11 @@ def assert_g_side(T, gold, case, name, config, tasks):
     for grp in ("encoder conv", "encoder bn"):
         within(stats[grp], yard[grp][0], yard[grp][1], 1.4)
     # decoders: the tenth percentile is set by the depth decoder's three BatchNorm'd layers (enc4_1 / enc4_2 / enc4_3: the
-    # same common-mode cancellation as the encoder's, cos 0.93-0.94 here against the encoder's 0.90); round 3 moved them to
-    # the 256 x 256 GEMM kernel (another fp32 summation order: K in 64-channel chunks) and their BatchNorm statistics into
-    # the conv epilogue: (1 - p10) went from <= 1.4 x to 1.45-1.53 x the yardstick's on the 640 fixture (median unchanged
-    # at 0.9999)
-    within(stats["decoders"], yard["decoders"][0], yard["decoders"][1], 1.7)
+    # same common-mode cancellation as the encoder's, cos 0.93-0.95 here against the encoder's 0.90).  Round 3 had loosened
+    # this bound to 1.7 x (measured 1.45-1.53 x with fp32 atomics in the bias-gradient / loss-statistics reductions); round 4
+    # made every reduction of the gradient path order-fixed (tests/test_gpu_determinism.py): (1 - p10) is now 1.13-1.27 x
+    # the yardstick's, the same from run to run, and the bound is back at 1.4 x
+    within(stats["decoders"], yard["decoders"][0], yard["decoders"][1], 1.4)
     if "p" in tasks:
         assert stats["painter"][0] >= 100
         within(stats["painter"], yard["painter"][0], yard["painter"][1], 2.5)
@@ -382,9 +382,10 @@ def assert_d_side(T, gold, case, name, config, tasks):
     # Yardstick (the same emulation run through update_D, jstep_640, dev container): D.p cos median 0.9907, D.s 0.9832,
     # D.m 0.9996.  All three see a generator that ExtraAdam has just moved by lr * g / (|g| + eps) ~ lr * sign(g) per
     # element, so sign flips of near-zero 16-bit generator gradients are part of their input noise.  Bound for D.p:
-    # (1 - cos) <= 2.5 x the yardstick's (measured 1.6 x), for D.s 1.6 x: the value moves from run to run with the fp32
-    # atomics of the generator's bias gradients (they decide the sign ExtraAdam gives near-zero entries), round 3 measured
-    # cos median 0.9760 - 0.9809 over seven runs of the same build = 1.14 - 1.43 x (the 1.4 x of round 2 sat inside that band).
+    # (1 - cos) <= 2.5 x the yardstick's (measured 1.6 x), for D.s 1.4 x.  (Round 3 had 1.6 x here: the value moved from
+    # run to run with the fp32 atomics of the generator's bias gradients -- they decide the sign ExtraAdam gives near-zero
+    # entries -- cos median 0.9760 - 0.9809 over seven runs of one build.  Round 4: no atomics on the gradient path, the
+    # step is bit-reproducible (tests/test_gpu_determinism.py), measured 0.9814 / 0.9824 = 1.05 - 1.11 x, every run.)
     # D.m is the one discriminator whose gradient is a small difference of two large terms: the real and the simulated
     # call push the weights in opposite directions (labels 1 / 0 on near-identical entropy maps; |g_r + g_s| = 0.17 |g_r|),
     # and each call runs on its own w_bar / sigma (one power iteration per call), ROUNDED TO bf16 for the MFMA -- a
@@ -397,7 +398,7 @@ def assert_d_side(T, gold, case, name, config, tasks):
     # test_forward_uses_the_parameters_the_optimizer_wrote.)
     # On the 128 x 160 fixture the seg discriminator sees 32 x 40 entropy maps and its last bias gradient is a +-0.25 / N
     # cancellation between the two domains that rounds to exactly 0: emulation 0.94, measured 0.906 - 0.918.
-    floors = ((("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 1 - 1.4 * (1 - 0.9677)), ("s.", 1 - 1.6 * (1 - 0.9832))) if name == "jstep_640" else
+    floors = ((("p.", 1 - 2.5 * (1 - 0.9907)), ("m.", 1 - 1.4 * (1 - 0.9677)), ("s.", 1 - 1.4 * (1 - 0.9832))) if name == "jstep_640" else
               (("p.", 0.985), ("m.", 0.98), ("s.", 0.89)))
     for grp, floor in floors:
         if not any(r[0].startswith(grp) for r in rows):
