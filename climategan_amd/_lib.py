@@ -193,36 +193,66 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
-def load():
-    """Load (once) and return the ctypes handle.  Raises RuntimeError if the library is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
+def _open(path):
+    if not path.exists():
         raise RuntimeError(
             "climategan_amd: %s not found -- the HIP extension is not built (run __graft_entry__.build() or "
-            "`make -C climategan_amd/csrc`).  There is no CPU/PyTorch fallback on the product path." % LIB_PATH)
+            "`make -C climategan_amd/csrc both`).  There is no CPU/PyTorch fallback on the product path." % path)
     try:
         # import torch first so that libamdhip64.so.7 resolves to the runtime torch already loaded
         import torch  # noqa: F401
     except Exception:
         pass
-    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    lib = C.CDLL(str(path), mode=getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError -> missing symbol: let it propagate loudly
         fn.restype = res
         fn.argtypes = args
     v = lib.cgan_version()
     if v != ABI_VERSION:
-        raise RuntimeError("climategan_amd: libcgan_hip.so ABI version %d != expected %d" % (v, ABI_VERSION))
-    # development knobs from the environment (same-box A/B of whole test / bench runs): CGAN_DEBUG_GEMM_WS=<n>
-    ws = os.environ.get("CGAN_DEBUG_GEMM_WS")
-    if ws:
-        lib.cgan_debug_set_gemm_ws(C.c_int(int(ws)))
-    if os.environ.get("CGAN_DEBUG_GEMM_FP16_AUTO"):
-        lib.cgan_debug_set_gemm_fp16_auto(C.c_int(int(os.environ["CGAN_DEBUG_GEMM_FP16_AUTO"])))
-    _lib = lib
+        raise RuntimeError("climategan_amd: %s ABI version %d != expected %d" % (path.name, v, ABI_VERSION))
     return lib
+
+
+def load():
+    """Load (once) and return the ctypes handle of the library in use (the product library unless ``load_dev`` switched).
+    Raises RuntimeError if the library is not built."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    _product = _open(LIB_PATH)
+    _lib = _product
+    if os.environ.get("CGAN_DEV_LIB") == "1":        # a whole run on the development build (same-box A/B with knobs)
+        load_dev()
+    return _lib
+
+
+_product = None
+_dev = None
+DEV_LIB_PATH = _HERE / "libcgan_hip_dev.so"
+
+
+def load_dev():
+    """Switch this process to the DEVELOPMENT build (libcgan_hip_dev.so = the same sources with -DCGAN_DEV: the
+    ``cgan_debug_set_*`` knobs for kernel selection, ablation bits and in-kernel timestamps) and return its handle.  The
+    product library exports none of them.  tools/ and the tests that run every kernel variant on the same cases use this;
+    ``use_product()`` switches back.  Knob from the environment: CGAN_DEBUG_GEMM_WS=<n>."""
+    global _lib, _dev
+    if _dev is None:
+        _dev = _open(DEV_LIB_PATH)
+        ws = os.environ.get("CGAN_DEBUG_GEMM_WS")
+        if ws:
+            _dev.cgan_debug_set_gemm_ws(C.c_int(int(ws)))
+    _lib = _dev
+    return _dev
+
+
+def use_product():
+    """Back to the product library (after ``load_dev``)."""
+    global _lib
+    load()
+    _lib = _product
+    return _lib
 
 
 # Development aid (bench.py --call-log, tools/step_hbm_budget.py): when CALL_LOG is a list, every checked C-ABI call appends

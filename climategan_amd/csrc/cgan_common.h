@@ -30,6 +30,25 @@ void cgan_set_error(const char* fmt, ...);
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
+// development knobs
+// ------------------------------------------------------------------------------------------------
+// Kernel-selection / ablation / in-kernel-timestamp knobs (cgan_debug_set_*) exist only in the CGAN_DEV build
+// (libcgan_hip_dev.so: `make dev`; tools/ and the tests that run every kernel variant on the same cases load that one).
+// In the product library they are compile-time constants: no process-global mutable state behind the ABI, no debug
+// fields in the kernels' parameter structs, the branches on them fold away.
+#ifdef CGAN_DEV
+#define CGAN_KNOB(type, name, init) type name = init
+#define CGAN_DEV_ONLY(...) __VA_ARGS__
+#define CGAN_DBG(p) ((p).dbg)
+#define CGAN_TSBUF(p) ((p).tsbuf)
+#else
+#define CGAN_KNOB(type, name, init) [[maybe_unused]] constexpr type name = init
+#define CGAN_DEV_ONLY(...)
+#define CGAN_DBG(p) 0
+#define CGAN_TSBUF(p) ((unsigned long long*)nullptr)
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // 16-bit element types and MFMA wrappers
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
   }
 }
 
-unsigned long long* g_xres_ts = nullptr;
+CGAN_KNOB(unsigned long long*, g_xres_ts, nullptr);
 
 template <typename T, int KC, int PF>
 int launch_xres(const ConvGemmArgs& a, hipStream_t s) {
@@ -283,7 +283,7 @@ int launch_any(const ConvGemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" void cgan_debug_set_xres_tsbuf(void* p) { g_xres_ts = (unsigned long long*)p; }
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_xres_tsbuf(void* p) { g_xres_ts = (unsigned long long*)p; })
 
 // 1x1, stride 1, no padding, no residual / bias / activation / pad channels, whole 64-channel chunks up to 256 channels, 32-bit byte offsets
 bool conv1x1_xres_ok(const ConvGemmArgs& a) {

@@ -22,7 +22,7 @@ constexpr int HPW = TW + 2, HPH = TH + 2, HP = HPH * HPW;   // 18 x 18 halo
 constexpr int XDMA = (HP * 4 + 63) / 64;                    // 21 wave-wide DMAs per input chunk
 constexpr int XBUF_BYTES = XDMA * 1024;                     // 21504 (324 px x 64 B + tail of the last DMA)
 constexpr int MAX_NCT = 5;
-int g_c4_enabled = 1;    // development knob (cgan_debug_set_conv3x3_c4): 0 = never the folded-tap kernel
+CGAN_KNOB(int, g_c4_enabled, 1);    // development knob (cgan_debug_set_conv3x3_c4): 0 = never the folded-tap kernel
 
 // [halo pixel q][4 slots of 16 B]: logical slot s of pixel q lives at slot position s ^ ((q >> 2) & 3)
 __device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 2) & 3)) << 4); }
@@ -448,7 +448,7 @@ int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" void cgan_debug_set_conv3x3_c4(int v) { g_c4_enabled = v; }
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv3x3_c4(int v) { g_c4_enabled = v; })
 
 bool conv3x3_lds_applicable(const CganConvDesc* d) {
   return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && d->pad == 1 &&

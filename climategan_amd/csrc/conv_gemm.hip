@@ -34,8 +34,7 @@ constexpr int NSTAGE = 3;
 // 8 = force the 256 x 256 kernel of conv_gemm_big.hip, 10 = force the direct 1x1 kernel of conv1x1_direct.hip,
 // 9 = automatic without those two and without the x-resident 1x1 kernel, 11 = force conv1x1_xres.hip, 12 = automatic
 // without it
-int g_gemm_ws = 0;
-int g_gemm_fp16_auto = 0;   // development knob (cgan_debug_set_gemm_fp16_auto): 1 = the specialised kernels in fp16 too
+CGAN_KNOB(int, g_gemm_ws, 0);
 
 // sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four row rotations on the
 // VALU's data-parallel-primitive path (__shfl_xor compiles to ds_bpermute_b32: an LDS instruction per step and value)
@@ -660,7 +659,7 @@ int launch_cfg(const ConvGemmArgs& a, hipStream_t s) {
                                         : launch_cfg2<T, WAVES_C, WC, WP, false, NS>(a, s);
 }
 
-int g_gemm_cfg = 0;   // development knob (tools/bench_conv.py): 0 = automatic, 1..4 = force a block tile
+CGAN_KNOB(int, g_gemm_cfg, 0);   // development knob (tools/bench_conv.py): 0 = automatic, 1..4 = force a block tile
 
 enum { KIND_PLAIN = 0, KIND_K64_256x128, KIND_K64_128x256, KIND_BIG, KIND_DIRECT, KIND_XRES };
 struct Choice {
@@ -669,7 +668,7 @@ struct Choice {
               //             4 = <2,4,4> (128 x 128), 5 = <2,4,4> with a 2-stage ring
 };
 
-// the kernel (and block tile) a descriptor runs: a pure function of the shape, the 16-bit type and the development knobs
+// the kernel (and block tile) a descriptor runs: a pure function of the shape (and, in the dev build, of the knobs)
 Choice choose(const ConvGemmArgs& a, bool bf16) {
   const int ptiles = ceil_div(a.npix, 16);
   const bool no_big = g_gemm_ws == 9;
@@ -683,11 +682,10 @@ Choice choose(const ConvGemmArgs& a, bool bf16) {
     case 11: if (conv1x1_xres_ok(a)) return {KIND_XRES, 0}; break;
     default: break;
   }
-  const bool automatic = ws == 0 && g_gemm_cfg == 0 && (bf16 || g_gemm_fp16_auto);
-  // The three specialised kernels are taken in bf16 (the training dtype) only: fp16 is what apply_events runs in, and its
-  // wildfire fixture turns single arg-max flips of the untrained segmentation into a one-level contrast shift of a tenth
-  // of the image -- the kernels agree within an fp16 rounding step (another fp32 summation order), but the fixture was
-  // verified with the plain kernel's order.
+  // (Shape-only: fp16 and bf16 take the same kernel.  Until round 3 the specialised kernels were bf16-only because an fp16
+  // apply_events fixture had been captured with the plain kernel's fp32 summation order.)
+  const bool automatic = ws == 0 && g_gemm_cfg == 0;
+  (void)bf16;
   // 1x1 layers with <= 64 output channels: activations straight from global memory into the B-fragment registers of the
   // wave that owns the pixels, all couts per workgroup (conv1x1_direct.hip).  Same-box A/B (tools/gpu_ab_conv.sh): it wins
   // there (256 -> 64 at 8 x 160^2 50 -> 37 us, 128 -> 64 14.7 -> 10.2 us, their data gradients 48 -> 38 us) and loses from 128
@@ -761,9 +759,8 @@ bool conv_gemm_applicable(const CganConvDesc* d) {
          (long)ceil_div((int)ceil_div((int)npix, 16), 8) * ceil_div(ceil_div(cout_s, 16), 8) >= 128;
 }
 
-extern "C" void cgan_debug_set_gemm_cfg(int v) { g_gemm_cfg = v; }
-extern "C" void cgan_debug_set_gemm_ws(int v) { g_gemm_ws = v; }
-extern "C" void cgan_debug_set_gemm_fp16_auto(int v) { g_gemm_fp16_auto = v; }
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_gemm_cfg(int v) { g_gemm_cfg = v; })
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_gemm_ws(int v) { g_gemm_ws = v; })
 
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);

@@ -538,11 +538,11 @@ void launch(const ConvParams& p, hipStream_t s) {
 // development knob: 1 = always use the general gather kernel, 2 = never use the wide-layer GEMM kernel, 3 = the GEMM
 // kernel also where the spatially tiled 3x3 kernel would be preferred
 // (A/B measurements, parity tests of every kernel)
-int g_conv_force = 0;
-extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; }
+CGAN_KNOB(int, g_conv_force, 0);
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; })
 // 1: strided data gradients read dy through zero insertion (the first implementation) instead of by parity classes
-int g_dgrad_zero_insert = 0;
-extern "C" void cgan_debug_set_dgrad_zero_insert(int v) { g_dgrad_zero_insert = v; }
+CGAN_KNOB(int, g_dgrad_zero_insert, 0);
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_dgrad_zero_insert(int v) { g_dgrad_zero_insert = v; })
 
 extern "C" size_t cgan_conv2d_packed_weight_bytes(const CganConvDesc* d) {
   ConvParams p;

@@ -30,11 +30,16 @@ struct WgradArgs {
   int nchunks, ci_blocks, co_blocks, splits, per_xcd;
   int coop, co_pairs, n_pairs;     // cooperative 128 x 128 kernel: pairs of co blocks x pairs of N tiles
   int fold, cpt, tpt, tap_slots;   // tap folding for cin_s <= 32 (see wgrad_plan): 16-byte chunks per tap, taps per 64-wide tile, tap groups
-  int dbg;     // debug ablation bits (tools/bench_wgrad.py): 1 = skip the atomics, 2 = skip the MFMAs
+  CGAN_DEV_ONLY(int dbg;)     // dev build: ablation bits (tools/bench_wgrad.py): 1 = skip the atomics, 2 = skip the MFMAs
   int reflect; // 1: nn.ReflectionPad2d(pad) in front of the conv (index math instead of the zero page)
   int x_ups;   // 1: x is stored at (h_in/2, w_in/2) and read through the folded nearest x2 upsample
-  unsigned long long* ts;   // development aid (tools/ts_wgrad.py): per-wave phase tick sums of the cooperative kernel
+  CGAN_DEV_ONLY(unsigned long long* ts;)   // dev build (tools/ts_wgrad.py): per-wave phase tick sums of the cooperative kernel
 };
+#ifdef CGAN_DEV
+#define CGAN_WTS(p) ((p).ts)
+#else
+#define CGAN_WTS(p) ((unsigned long long*)nullptr)
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = co0 + a * 16 + 4 * g + r;
-      if (co < p.cout && col_ok && !(p.dbg & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, s[r]);
+      if (co < p.cout && col_ok && !(CGAN_DBG(p) & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, s[r]);
     }
   }
 }
@@ -503,8 +508,8 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
     buf ^= 1;
     if (TS) { t_a = __builtin_readcyclecounter(); ts_sum[3] += t_a - t_b; }
   }
-  if (TS && p.ts && lane == 0) {
-    unsigned long long* o = p.ts + ((size_t)blockIdx.x * 4 + wave) * 8;
+  if (TS && CGAN_WTS(p) && lane == 0) {
+    unsigned long long* o = CGAN_WTS(p) + ((size_t)blockIdx.x * 4 + wave) * 8;
     o[0] = t_start;
     o[1] = __builtin_readcyclecounter();
     for (int i = 0; i < 4; ++i) o[2 + i] = ts_sum[i];
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = cob * 64 + a * 16 + 4 * g + r;
-        if (co < p.cout && col_ok && !(p.dbg & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, acc[a][b][r]);
+        if (co < p.cout && col_ok && !(CGAN_DBG(p) & 1)) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * taps_n + tap, acc[a][b][r]);
       }
   }
 }
@@ -766,10 +771,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   }
 }
 
-int g_wgrad_target = 0, g_wgrad_dbg = 0, g_wgrad_coop_min_pix = 32768, g_wgrad_coop_chunk = 0, g_wgrad_slots = 512, g_wgrad_tile = 1;
-unsigned long long* g_wgrad_ts = nullptr;
+CGAN_KNOB(int, g_wgrad_target, 0);
+CGAN_KNOB(int, g_wgrad_dbg, 0);
+CGAN_KNOB(int, g_wgrad_coop_min_pix, 32768);
+CGAN_KNOB(int, g_wgrad_coop_chunk, 0);
+CGAN_KNOB(int, g_wgrad_slots, 512);
+CGAN_KNOB(int, g_wgrad_tile, 1);
+CGAN_KNOB(unsigned long long*, g_wgrad_ts, nullptr);
 }  // namespace
 
+#ifdef CGAN_DEV
 extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
 extern "C" void cgan_debug_set_wgrad_tile3x3(int v) { g_wgrad_tile = v; }   // 0: never the spatially tiled 3 x 3 kernel, 2: wherever it applies
 extern "C" void cgan_debug_set_wgrad_slots(int v) { g_wgrad_slots = v > 0 ? v : 512; }   // resident workgroups the planner assumes
@@ -781,6 +792,7 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
   g_wgrad_target = target_workgroups;          // > 0: target number of workgroups; < 0: -target pixel splits, as given
   g_wgrad_dbg = dbg;
 }
+#endif
 
 constexpr int BIAS_MAX_BLOCKS = 512;
 
@@ -918,8 +930,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   a.fold = pl.fold; a.cpt = pl.cpt; a.tpt = pl.tpt; a.tap_slots = pl.tap_slots;
   a.coop = pl.coop; a.co_pairs = pl.co_pairs; a.n_pairs = pl.n_pairs;
   const int taps = d->kh * d->kw;
-  a.dbg = g_wgrad_dbg;
-  a.ts = g_wgrad_ts;
+  CGAN_DEV_ONLY(a.dbg = g_wgrad_dbg; a.ts = g_wgrad_ts;)
   const long items = (long)a.splits * (pl.tile ? (long)pl.co_blocks * pl.ci_blocks
                                               : (pl.coop ? (long)pl.co_pairs * pl.n_pairs : pl.tiles()));
   a.per_xcd = (int)((items + 7) / 8);
@@ -968,10 +979,13 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32); else if (mode == 2) COOP_LAUNCH(TT, 2, 32); else COOP_LAUNCH(TT, 0, 32); } \
     else { if (mode == 1) COOP_LAUNCH(TT, 1, 64); else if (mode == 2) COOP_LAUNCH(TT, 2, 64); else COOP_LAUNCH(TT, 0, 64); }            \
   } while (0)
-    if (a.ts && d->dtype == CGAN_BF16 && mode == 0) {
+#ifdef CGAN_DEV
+    if (CGAN_WTS(a) && d->dtype == CGAN_BF16 && mode == 0) {
       if (pl.chunk == 32) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 32, true>), dim3(gx), dim3(256), smem2, s, a);
       else hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 64, true>), dim3(gx), dim3(256), smem2, s, a);
-    } else if (d->dtype == CGAN_F16) COOP_MODE(F16);
+    } else
+#endif
+    if (d->dtype == CGAN_F16) COOP_MODE(F16);
     else COOP_MODE(BF16);
 #undef COOP_MODE
 #undef COOP_LAUNCH

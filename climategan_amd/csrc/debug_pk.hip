@@ -4,6 +4,8 @@
 // result can be compared alone and next to another stream's MFMA / LDS-DMA kernels.
 #include "cgan_common.h"
 
+#ifdef CGAN_DEV      // dev build only (libcgan_hip_dev.so): the product library has no development entry point
+
 namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -45,3 +47,4 @@ extern "C" int cgan_debug_pk_opsel(const float* x, const unsigned* junk, const f
   CGAN_CHECK_LAUNCH("debug_pk_opsel");
   return CGAN_OK;
 }
+#endif  // CGAN_DEV

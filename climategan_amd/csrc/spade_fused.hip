@@ -68,8 +68,8 @@ struct SpadeParams {
   int tiles_y, tiles_x;
   int act;
   float slope;
-  unsigned long long* tsbuf;  // development: per-workgroup phase timestamps, or null
-  int dbg;                    // development ablation bits: 1 skip hidden map, 2 skip main MFMAs, 8 skip stores
+  CGAN_DEV_ONLY(unsigned long long* tsbuf;)  // dev build: per-workgroup phase timestamps, or null
+  CGAN_DEV_ONLY(int dbg;)                    // dev build: ablation bits: 1 skip hidden map, 2 skip main MFMAs, 8 skip stores
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -107,8 +107,8 @@ __device__ __forceinline__ int actv_addr(int q, int slot) {
 
 #define TS(i)                                                                                          \
   do {                                                                                                 \
-    if (p.tsbuf && threadIdx.x == 0)                                                                   \
-      p.tsbuf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); \
+    if (CGAN_TSBUF(p) && threadIdx.x == 0)                                                                   \
+      CGAN_TSBUF(p)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 
 // wait until at most N of this wave's vector-memory ops are outstanding and all its LDS ops are done, then
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
   const int ty0 = tyi * TH, tx0 = txi * TW;
   const int nt0 = blockIdx.y * NCT;       // first channel tile of this workgroup
   TS(0);
-  if (p.tsbuf && threadIdx.x == 0)
-    p.tsbuf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+  if (CGAN_TSBUF(p) && threadIdx.x == 0)
+    CGAN_TSBUF(p)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
         ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 
   // ---- LDS-DMA of weight stage s = (quarter q, dx): the three dy taps x NCT channel tiles = 3*NCT fragments of
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
   };
 
   // ---------------- hidden map of quarter 0 (not overlapped with MFMA stages: keep all of a wave's tiles in flight)
-  if (!(p.dbg & 1)) {
+  if (!(CGAN_DBG(p) & 1)) {
     if (C4) {
       constexpr int TPW = (NHT + WAVES - 1) / WAVES;   // 6 tiles per wave
       u32x4 gb0[TPW];
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
     auto stage_plain = [&](int q, int dx, int s) {
       const unsigned char* abuf = actv + (q & 1) * ACTV_Q_BYTES;
       unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
-      const bool hid = !SPEC && C4 && q < 3 && !(p.dbg & 1);
+      const bool hid = !SPEC && C4 && q < 3 && !(CGAN_DBG(p) & 1);
       u32x4 bfr[PT + 2];
 #pragma unroll
       for (int r = 0; r < PT + 2; ++r) {
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
       for (int dx = 0; dx < 3; ++dx) {
         const int s = q * 3 + dx;
         COUNTED_BARRIER(0);
-        if (!SPEC && s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
+        if (!SPEC && s + 1 < NSTAGES && !(CGAN_DBG(p) & 4)) issue_stage(s + 1);
         if (q == 3 && dx == 0) {
           // the last quarter has no successor: its spare hidden-map buffer (actv[0]) receives the x tile now, as
           // whole 16-byte channel chunks, lane-linear over [256 pixels][NCT chunks] (id = k*NW*64 + tid -> pixel
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
         // SIMD to cover the reads) take the plain one
         constexpr bool ILV = !SPEC && NCT <= 3;
         if (ILV) {
-          if (!SPEC && C4 && q < 3 && !(p.dbg & 1)) stage_body(std::true_type{}, q, dx, s);
+          if (!SPEC && C4 && q < 3 && !(CGAN_DBG(p) & 1)) stage_body(std::true_type{}, q, dx, s);
           else stage_body(std::false_type{}, q, dx, s);
         } else {
           stage_plain(q, dx, s);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
       for (int dx = 0; dx < 3; ++dx) {
         const int s = q * 3 + dx;
         COUNTED_BARRIER(0);
-        if (s + 1 < NSTAGES && !(p.dbg & 4)) issue_stage(s + 1);
+        if (s + 1 < NSTAGES && !(CGAN_DBG(p) & 4)) issue_stage(s + 1);
         if (q == 3 && dx == 0) {       // x tile -> the idle hidden buffer (all 8 waves take part; see the consumers)
 #pragma unroll
           for (int k = 0; k < (NCT * 256 + WAVES * 64 - 1) / (WAVES * 64); ++k) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
             }
           }
         }
-        if (q < 3 && !(p.dbg & 1)) {
+        if (q < 3 && !(CGAN_DBG(p) & 1)) {
           unsigned char* nbuf = actv + ((q + 1) & 1) * ACTV_Q_BYTES;
           if (C4) {
             // the two tiles of this stage in lock step (gather | gather, multiply | multiply, store | store): the
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
   }
   __syncthreads();
   const unsigned char* xt = actv;   // [256 px][NCT * 16 B], now holding the results
-  if (!(p.dbg & 8)) {
+  if (!(CGAN_DBG(p) & 8)) {
 #pragma unroll
     for (int k = 0; k < (NCT * 256 + WAVES * 64 - 1) / (WAVES * 64); ++k) {
       const int id = k * (WAVES * 64) + threadIdx.x;
@@ -783,17 +783,17 @@ int launch_nct(const SpadeParams& p, int nct, int nw, hipStream_t s) {
 
 // Development knobs (not part of the stable ABI): force the channel tiles per workgroup / ablation bits /
 // timestamp buffer.
-int g_spade_variant = 0;
-int g_spade_waves = 8;   // default: the wave-specialised kernel wherever a workgroup has >= 2 channel tiles
-int g_spade_dbg = 0;
-unsigned long long* g_spade_tsbuf = nullptr;
+CGAN_KNOB(int, g_spade_variant, 0);
+CGAN_KNOB(int, g_spade_waves, 8);   // default: the wave-specialised kernel wherever a workgroup has >= 2 channel tiles
+CGAN_KNOB(int, g_spade_dbg, 0);
+CGAN_KNOB(unsigned long long*, g_spade_tsbuf, nullptr);
 
 }  // namespace
 
-extern "C" void cgan_debug_set_spade_variant(int v) { g_spade_variant = v; }
-extern "C" void cgan_debug_set_spade_waves(int v) { g_spade_waves = v == 4 ? 4 : 8; }
-extern "C" void cgan_debug_set_spade_ablation(int bits) { g_spade_dbg = bits; }
-extern "C" void cgan_debug_set_spade_tsbuf(void* p) { g_spade_tsbuf = (unsigned long long*)p; }
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_spade_variant(int v) { g_spade_variant = v; })
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_spade_waves(int v) { g_spade_waves = v == 4 ? 4 : 8; })
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_spade_ablation(int bits) { g_spade_dbg = bits; })
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_spade_tsbuf(void* p) { g_spade_tsbuf = (unsigned long long*)p; })
 
 extern "C" size_t cgan_spade_packed_weight_bytes(const CganSpadeDesc* d) {
   if (check(d) != CGAN_OK) return 0;
@@ -843,7 +843,7 @@ extern "C" int cgan_spade_fused_fwd(const void* x, const float* mean, const floa
   p.cond_h = d->cond_h; p.cond_w = d->cond_w; p.cond_c = d->cond_c; p.cond_cs = cgan_cond_cs(d->cond_c);
   p.ksh = ksh_of(d->cond_c);
   p.sy = (float)d->cond_h / (float)d->h; p.sx = (float)d->cond_w / (float)d->w;
-  p.act = d->act; p.slope = d->act_slope; p.dbg = g_spade_dbg; p.tsbuf = g_spade_tsbuf;
+  p.act = d->act; p.slope = d->act_slope; CGAN_DEV_ONLY(p.dbg = g_spade_dbg; p.tsbuf = g_spade_tsbuf;)
   hipStream_t s = (hipStream_t)stream;
   // Channel tiles per workgroup (3 .. 5 when the layer has that many).  A workgroup costs a fixed part (hidden-map
   // production, prologue, epilogue: ~2.5 tile-equivalents) plus its tiles, and the chip takes 512 workgroups per round

@@ -220,7 +220,7 @@ __global__ void wf_blur_ref_kernel(const float* __restrict__ in, float* __restri
     out[i] = acc;
   }
 }
-int g_wf_blur = 0;
+CGAN_KNOB(int, g_wf_blur, 0);
 
 // paste_tensor(img, filter, mask, transparency) -> uint8 -> adjust_brightness(0.8) -> float, dummy corner pixels
 __global__ void wf_compose_kernel(const uint8_t* __restrict__ img, const float* __restrict__ mask,
@@ -267,7 +267,7 @@ inline unsigned grid1(long total) { return (unsigned)((total + 255) / 256 > 1638
 
 }  // namespace
 
-extern "C" void cgan_debug_set_wf_blur(int v) { g_wf_blur = v; }
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_wf_blur(int v) { g_wf_blur = v; })
 
 extern "C" size_t cgan_wildfire_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t seg_h, int32_t seg_w,
                                                 int32_t kernel_size) {

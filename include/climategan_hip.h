@@ -599,9 +599,11 @@ int cgan_comm_init_rank(void** comm, int32_t nranks, const void* id128, int32_t 
 int cgan_comm_destroy(void* comm);
 int cgan_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* comm, void* stream);
 
-/* Not part of the ABI: the library also exports a few cgan_debug_set_* development knobs (kernel selection, ablation
- * bits, split targets) used by tools/ and by the tests that run every kernel variant on the same cases.  They are
- * process-global, not thread-safe, and may change between builds. */
+/* libcgan_hip.so exports exactly the entry points declared above: no development knob, no process-global mutable state
+ * behind the ABI besides the thread-local error string and the lazily loaded RCCL handle.  The kernel-selection /
+ * ablation / timestamp knobs (cgan_debug_set_*) that tools/ and the every-kernel-variant tests use exist only in the
+ * DEVELOPMENT build of the same sources (-DCGAN_DEV -> libcgan_hip_dev.so, `make -C climategan_amd/csrc dev`); in the
+ * product build they are compile-time constants (csrc/cgan_common.h). */
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ CASES_640 = {
     # in the arg-max map; with gain 1 the depth map's std was 1.7e-5, below fp16 resolution of its own offset
     "infer_640": dict(kind="infer640", H=640, W=640, B=2, seed=72, gain=2.449489742783178, res_gamma=0.05, mask_gain=40.0,
                       mask_bias=0.93,
-                      bin_value=0.5, rng_seed=99, band=0.11),
+                      bin_value=0.5, rng_seed=99, band=0.11, seg_band=0.1),
 }
 MASK_OUT = "decoders.m.model.7.conv"          # MaskBaseDecoder's plain output conv (blocks.py:279-289)
 
@@ -272,6 +272,15 @@ def run_infer640(case):
            # 0.45, i.e. |m - 0.5| < 0.11 (4.8 % of the pixels)
            "band_frac": np.array([(np.abs(m - case["bin_value"]) < case["band"]).mean()], dtype=np.float32),
            "m_band": np.packbits(np.abs(m - case["bin_value"]) < case["band"])}
+    # the wildfire's only input from the network is the segmentation arg-max (fire.py: sky = argmax == 9): stored so that
+    # the event can be compared on the SAME sky mask, next to the classes' top-2 margin band -- where the untrained logits
+    # nearly tie, a 16-bit activation chain decides the arg-max differently (the reference's own fp16 run does), exactly
+    # like the flood mask's threshold band above
+    seg = cap["flood_kw"]["s"]                                               # [B,11,160,160] logits
+    top2 = seg.topk(2, dim=1).values
+    out["seg_argmax"] = seg.argmax(1).numpy().astype(np.uint8)
+    out["seg_tie_band"] = np.packbits((top2[:, 0] - top2[:, 1]).numpy() < case["seg_band"])
+    out["seg_tie_frac"] = np.array([((top2[:, 0] - top2[:, 1]).numpy() < case["seg_band"]).mean()], dtype=np.float32)
     for k in ("flood", "smog", "wildfire"):
         u8 = np.ascontiguousarray(res[k].transpose(0, 3, 1, 2))              # [B,3,H,W] uint8
         out.update({k + "_u8_" + a: b for a, b in summarize(u8.astype(np.float32)).items()})

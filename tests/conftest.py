@@ -29,3 +29,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def dev_lib():
+    """The DEVELOPMENT build of the library (libcgan_hip_dev.so: the same sources with -DCGAN_DEV) for the duration of a
+    test: the tests that run every kernel variant on the same cases force kernels through its ``cgan_debug_set_*`` knobs; the
+    product library (what every other test runs on) exports none of them."""
+    from climategan_amd import _lib
+
+    lib = _lib.load_dev()
+    yield lib
+    _lib.use_product()

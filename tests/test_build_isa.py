@@ -17,8 +17,9 @@ ROOT = Path(__file__).resolve().parent.parent
 OBJDUMP = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
 
 
-def test_no_op_sel_modified_packed_fp32_instructions(tmp_path):
-    lib = ROOT / "climategan_amd" / "libcgan_hip.so"
+@pytest.mark.parametrize("libname", ["libcgan_hip.so", "libcgan_hip_dev.so"])
+def test_no_op_sel_modified_packed_fp32_instructions(tmp_path, libname):
+    lib = ROOT / "climategan_amd" / libname
     if not lib.exists() or not OBJDUMP.exists():
         pytest.skip("needs the built library and llvm-objdump")
     shutil.copy(lib, tmp_path / lib.name)                       # --offloading writes the code objects next to its input

@@ -107,9 +107,42 @@ def test_apply_events_bs16_fp16_matches_reference_infer_all(infer_trainer):
         report[k] = (crops.max(), crops.mean(), (crops > 1).mean(), pooled.max(), np.abs(s["mean"] - gold[k + "_u8_mean"]).max())
         print("%s u8 vs reference: crops max %g mean %.3g, >1 level on %.3g; pooled8 max %.3g; channel mean %.3g"
               % ((k,) + report[k]))
-    # wildfire / smog are byte-image arithmetic on x, the segmentation arg-max and the depth map: levels agree except
-    # where a 16-bit depth / logit difference crosses a rounding boundary
-    assert report["wildfire"][2] < 1e-2 and report["wildfire"][4] < 0.1, report["wildfire"]
+    # smog is byte-image arithmetic on x and the depth map: levels agree except where a 16-bit depth difference crosses a
+    # rounding boundary.  The wildfire's only input from the network is the segmentation ARG-MAX (sky = class 9, fire.py):
+    # like the flood mask it is a decision, and where the untrained logits nearly tie (top-2 margin < 0.1 on 5.9 % of the
+    # pixels of this fixture) a 16-bit activation chain decides differently -- the reference's own fp16 run does.  So, as
+    # for the mask: (1) the arg-max equals the reference's OUTSIDE its near-tie band, (2) the event on the REFERENCE's
+    # arg-max reproduces the reference's bytes (the wildfire kernels themselves), (3) end to end only a loose bound (a
+    # flipped sky pixel moves the image-wide mean of adjust_contrast and, dilated and blurred, its neighbourhood).
+    # (Until round 3 (2) was asserted end to end, which pinned the fp16 path to the plain GEMM kernel's fp32 summation
+    # order: the dispatch was keyed on the dtype for this fixture's sake.  It is shape-only now.)
+    with torch.no_grad():
+        zz = T.G.encode(x2.half())
+        _, zd = T.G.decoders["d"].forward_nhwc(zz)
+        seg_hip = T.G.decoders["s"].forward_nhwc(zz, zd)
+    am_hip = seg_hip.t[..., :11].float().argmax(-1).cpu().numpy()
+    am_ref = gold["seg_argmax"]
+    tie = np.unpackbits(gold["seg_tie_band"])[: am_ref.size].reshape(am_ref.shape).astype(bool)
+    assert float(gold["seg_tie_frac"][0]) < 0.08
+    assert np.array_equal(am_hip[~tie], am_ref[~tie]), "segmentation arg-max differs outside the near-tie band"
+    assert (am_hip == am_ref).mean() >= 0.985, (am_hip == am_ref).mean()
+    print("seg arg-max: agreement %.4f overall, %.4f inside the near-tie band (%.3g of the pixels)"
+          % ((am_hip == am_ref).mean(), (am_hip == am_ref)[tie].mean(), tie.mean()))
+    from climategan_amd import ops
+    onehot = torch.zeros((B, am_ref.shape[1], am_ref.shape[2], 16), dtype=torch.float16, device="cuda")
+    onehot.scatter_(3, torch.from_numpy(am_ref.astype(np.int64)).cuda()[..., None], 10.0)
+    f = T.opts.events.fire
+    wf = ops.wildfire(x2.half(), ops.NHWC(onehot, 11), float(gold["green"][0]), kernel_size=f.get("kernel_size", 301),
+                      kernel_sigma=f.get("kernel_sigma", 150.5), transparency=200, crop_bottom=bool(f.get("crop_bottom_sky_mask")))
+    wf_u8 = ops.normalize_to_uint8(wf.to(torch.float16)).cpu().numpy().transpose(0, 3, 1, 2)      # as infer_all does
+    sw = summarize(np.ascontiguousarray(wf_u8).astype(np.float32))
+    wcrops = np.concatenate([np.abs(sw[c] - gold["wildfire_u8_%s" % c]).ravel() for c in ("crop_tl", "crop_c", "crop_br")])
+    wrep = (wcrops.max(), wcrops.mean(), (wcrops > 1).mean(), np.abs(sw["pooled8"] - gold["wildfire_u8_pooled8"]).max(),
+            np.abs(sw["mean"] - gold["wildfire_u8_mean"]).max())
+    print("wildfire on the reference's arg-max, u8 vs reference: crops max %g mean %.3g, >1 level on %.3g; pooled8 max %.3g; "
+          "channel mean %.3g" % wrep)
+    assert wrep[2] < 1e-2 and wrep[4] < 0.1, wrep
+    assert report["wildfire"][4] < 2.0 and report["wildfire"][3] < 16.0, report["wildfire"]
     assert report["smog"][1] < 0.75 and report["smog"][3] < 2.0 and report["smog"][4] < 0.5, report["smog"]
     # end to end the flood also carries the mask bits that flipped inside the band (each flips a pixel between "painted"
     # and "original": up to 255 levels): only its channel means are compared here, the painter itself below

@@ -54,6 +54,7 @@ CASES = draw_cases(36, 20240928) + [
 ]
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_forward_dgrad_wgrad(dt, case):
@@ -103,6 +104,7 @@ def test_conv_forward_dgrad_wgrad(dt, case):
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(64, 40, 1, 256, 256), (128, 24, 2, 128, 256), (64, 130, 1, 256, 256), (192, 8, 1, 260, 288)])
 def test_spatially_tiled_3x3_wgrad(dt, case):
@@ -142,6 +144,7 @@ def draw_mode_cases(n, seed):
     return out
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", draw_mode_cases(12, 99))
 def test_wgrad_upsample_and_reflect_modes(dt, case):
@@ -198,6 +201,7 @@ WS_CASES = [
 ]
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("case", WS_CASES)
 def test_k64_specialised_gemm_matches_the_plain_kernel(case):
     """The persistent producer / consumer variant of the wide-layer GEMM with K = 64 stages (automatic for long-K 3x3 layers
@@ -238,6 +242,7 @@ def test_k64_specialised_gemm_matches_the_plain_kernel(case):
     (256, 1024, 2, 80, 80), (128, 512, 3, 37, 41), (64, 328, 2, 64, 64), (192, 256, 2, 50, 50), (256, 64, 2, 96, 96),
     (256, 1024, 8, 80, 80), (64, 256, 4, 160, 160),
 ])
+@pytest.mark.usefixtures("dev_lib")
 def test_x_resident_1x1_kernel_matches_the_plain_kernel(case):
     """conv1x1_xres.hip (short-K 1x1 layers without bias / activation / residual: the bottleneck expands in training mode and
     the reduce layers' data gradients; automatic in bf16 from 256 couts and 16384 pixels, forced here) against the plain
@@ -273,6 +278,7 @@ def test_x_resident_1x1_kernel_matches_the_plain_kernel(case):
     (3, 128, 2, 64, 64, False, False, 8), (3, 64, 1, 50, 37, False, False, 8), (4, 32, 2, 40, 48, False, True, 8),
     (1, 20, 1, 33, 65, False, False, 8), (3, 200, 1, 48, 48, False, False, 8), (3, 128, 1, 64, 64, True, False, 8),
 ])
+@pytest.mark.usefixtures("dev_lib")
 def test_folded_tap_3x3_kernel_for_few_input_channels(case):
     """conv3x3_c4_kernel (<= 4 input channels: the 9 taps folded into two MFMA k-steps instead of one k-step per tap) against
     the per-tap kernel it replaces (cgan_debug_set_conv3x3_c4(0)) and against torch: same products, another fp32 summation

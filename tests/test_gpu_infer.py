@@ -278,6 +278,7 @@ def test_keep_ratio_flow():
             assert out[k].shape == (1, nh, nw, 3) and out[k].dtype == np.uint8
 
 
+@pytest.mark.usefixtures("dev_lib")
 def test_wildfire_next_to_another_streams_kernels():
     """The wildfire event on a batch of repeats while a second stream runs LDS-DMA / MFMA kernels (the flood painter of
     ``infer_all`` does): every repeat must give the same bytes as its original, and the 8-outputs-per-thread blur must equal
@@ -322,6 +323,7 @@ def test_wildfire_next_to_another_streams_kernels():
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("ks", [1, 3, 5, 7, 9, 15])
 def test_wildfire_blur_short_kernels_match_the_one_output_per_thread_form(ks):
     """The 8-outputs-per-thread blur walks ks + 7 inputs per thread in three loops; for ks < 7 the inputs ks..6 belong to

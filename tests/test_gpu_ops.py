@@ -154,6 +154,7 @@ def _set_waves(n):
     _lib.load().cgan_debug_set_spade_waves(ctypes.c_int(n))
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", [(40, 36, 52, (72, 104), False, "lrelu"), (88, 18, 16, (36, 32), True, "none")])
@@ -171,6 +172,7 @@ def test_spade_fused_tile_variants(variant, case, waves):
         _set_waves(8)
 
 
+@pytest.mark.usefixtures("dev_lib")
 def test_spade_kernels_agree_bitwise():
     """The specialised and the 4-wave kernel run the same arithmetic in the same order: identical bits."""
     from climategan_amd import fill, ops
@@ -297,6 +299,7 @@ LDS_CONV_CASES = [
 ]
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", LDS_CONV_CASES)
 def test_conv3x3_lds_tiled(dt, case):
@@ -352,6 +355,7 @@ GEMM_CONV_CASES = [
 ]
 
 
+@pytest.mark.usefixtures("dev_lib")
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", GEMM_CONV_CASES)
 def test_conv_gemm_wide_layers(dt, case):

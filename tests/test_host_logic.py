@@ -176,3 +176,25 @@ def test_pl4m_is_enabled_at_its_epoch():
     opts.gen.m.use_pl4m = True
     T2.G = type("G0", (), {"painter": _P(0)})()
     assert T2.maybe_enable_pl4m() is False                                        # no Painter of its own
+
+
+def test_product_library_exports_no_development_knob():
+    """libcgan_hip.so exports the declared ABI and nothing else of ours: the cgan_debug_* knobs live in the development build
+    only (-DCGAN_DEV -> libcgan_hip_dev.so), which exports the same ABI plus the knobs."""
+    import subprocess
+    from climategan_amd import _lib
+
+    if not _lib.LIB_PATH.exists() or not _lib.DEV_LIB_PATH.exists():
+        import __graft_entry__ as g
+        g.build()
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", str(path)], check=True, capture_output=True, text=True).stdout
+        return {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("cgan_")}
+
+    prod, dev = exported(_lib.LIB_PATH), exported(_lib.DEV_LIB_PATH)
+    assert prod == set(_lib.EXPORTED_SYMBOLS), sorted(prod ^ set(_lib.EXPORTED_SYMBOLS))
+    assert not [s for s in prod if "debug" in s]
+    knobs = dev - prod
+    assert knobs and all(s.startswith("cgan_debug_") for s in knobs), sorted(knobs)
+    assert prod <= dev

@@ -7,7 +7,7 @@ sys.path.insert(0, str(ROOT))
 from climategan_amd import _lib, fill, ops
 dt = torch.bfloat16
 B = 8
-lib = _lib.load()
+lib = _lib.load_dev()
 cond = ops.nchw_to_nhwc(torch.from_numpy(fill.uniform((B, 3, 640, 640), 1)).cuda(), dt, cs=4)
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 lib.cgan_debug_set_spade_variant(ctypes.c_int(variant))

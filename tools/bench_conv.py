@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    lib = _lib.load()
+    lib = _lib.load_dev()
     lib.cgan_debug_set_conv_kernel(ctypes.c_int(args.force))
     lib.cgan_debug_set_gemm_cfg(ctypes.c_int(args.cfg))
     lib.cgan_debug_set_gemm_ws(ctypes.c_int(args.ws))

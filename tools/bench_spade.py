@@ -18,7 +18,7 @@ shapes = [(40, 640), (20, 640), (80, 320), (160, 160), (640, 20), (640, 5)]
 if os.environ.get("SPADE_SHAPES"):   # "C:R,C:R,..."
     shapes = [tuple(int(v) for v in cr.split(":")) for cr in os.environ["SPADE_SHAPES"].split(",")]
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]   # 0 = default tiles; 1-5 force NCT; +10 = 8-wave kernel
-lib = _lib.load()
+lib = _lib.load_dev()
 cond = ops.nchw_to_nhwc(torch.from_numpy(fill.uniform((B, 3, 640, 640), 1)).cuda(), dt, cs=4)
 for C, R in shapes:
     g = torch.Generator(device="cuda"); g.manual_seed(C + R)

@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    lib = _lib.load()
+    lib = _lib.load_dev()
     lib.cgan_debug_set_wgrad(ctypes.c_int(args.target), ctypes.c_int(args.dbg))
     if args.coop_min >= 0:
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(args.coop_min))

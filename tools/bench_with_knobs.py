@@ -11,7 +11,7 @@ from climategan_amd import _lib  # noqa: E402
 
 args = sys.argv[1:]
 split = args.index("--") if "--" in args else len(args)
-lib = _lib.load()
+lib = _lib.load_dev()
 for kv in args[:split]:
     k, v = kv.split("=")
     getattr(lib, "cgan_debug_set_" + k)(ctypes.c_int(int(v)))

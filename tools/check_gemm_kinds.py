@@ -15,7 +15,7 @@ CASES = [  # cin, cout, B, H, W, bias, act
     (256, 1024, 2, 80, 80, False, ops.ACT_NONE), (128, 512, 3, 37, 41, True, ops.ACT_LRELU), (192, 256, 2, 50, 50, True, ops.ACT_RELU),
     (64, 256, 8, 160, 160, False, ops.ACT_NONE),
 ]
-lib = _lib.load()
+lib = _lib.load_dev()
 dt = torch.bfloat16
 for cin, cout, B, H, W, bias, act in CASES:
     torch.manual_seed(1)

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from climategan_amd import _lib, ops  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_dev()
 lib.cgan_debug_pk_opsel.restype = C.c_int
 lib.cgan_debug_pk_opsel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
 n = 1 << 22

@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from climategan_amd import _lib, ops  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_dev()
 dt = torch.float16
 g = torch.Generator(device="cuda")
 g.manual_seed(1)

@@ -10,7 +10,7 @@ B, C, R = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 40, 640
 if len(sys.argv) > 2:     # development ablation bits of the fused kernel (1 skip hidden map, 2 skip main MFMAs, 8 skip stores)
     import ctypes
     from climategan_amd import _lib
-    _lib.load().cgan_debug_set_spade_ablation(ctypes.c_int(int(sys.argv[2])))
+    _lib.load_dev().cgan_debug_set_spade_ablation(ctypes.c_int(int(sys.argv[2])))
 cond = ops.nchw_to_nhwc(torch.from_numpy(fill.uniform((B, 3, 640, 640), 1)).cuda(), dt, cs=4)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 w = [torch.randn(s, device="cuda", generator=g) * 0.05 for s in [(128, 3, 3, 3), (128,), (C, 128, 3, 3), (C,), (C, 128, 3, 3), (C,)]]

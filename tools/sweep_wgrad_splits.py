@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from climategan_amd import _lib, ops  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_dev()
 dt = torch.bfloat16
 SHAPES = [
     # name, cin, cout, k, stride, pad, dil, bs, H, tiles (cooperative: pairs)

@@ -7,7 +7,7 @@ sys.path.insert(0, str(ROOT))
 from climategan_amd import _lib, fill, ops
 dt = torch.bfloat16
 B = 8
-lib = _lib.load()
+lib = _lib.load_dev()
 if len(sys.argv) > 1:
     lib.cgan_debug_set_spade_ablation(ctypes.c_int(int(sys.argv[1])))
     print('ablation bits', sys.argv[1])

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from climategan_amd import _lib, ops  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_dev()
 dt = torch.bfloat16
 for cin, cout, B, H, W, stats in [(256, 1024, 8, 80, 80, False), (256, 1024, 8, 80, 80, True), (64, 256, 8, 160, 160, False), (128, 512, 8, 80, 80, False)]:
     torch.manual_seed(1)
