@@ -688,10 +688,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
                                                            int tpt, int main_blocks, const float* __restrict__ bpart,
                                                            int bias_rows, int cout_s, float* __restrict__ dbias) {
   if ((int)blockIdx.x >= main_blocks) {
-    const int ch = ((int)blockIdx.x - main_blocks) * 256 + (int)threadIdx.x;
+    // 16 channels x 16 row lanes per block: lane rl adds rows rl, rl + 16, ... (four loads in flight), the 16 lanes of a
+    // channel meet in LDS and are added in lane order -- a fixed order whatever the launch looks like
+    __shared__ float bsum[16][17];
+    const int c16 = (int)threadIdx.x & 15, rl = (int)threadIdx.x >> 4;
+    const int ch = ((int)blockIdx.x - main_blocks) * 16 + c16;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (ch < cout) {
+      int r = rl;
+      for (; r + 48 < bias_rows; r += 64) {
+        a0 += bpart[(size_t)r * cout_s + ch];
+        a1 += bpart[(size_t)(r + 16) * cout_s + ch];
+        a2 += bpart[(size_t)(r + 32) * cout_s + ch];
+        a3 += bpart[(size_t)(r + 48) * cout_s + ch];
+      }
+      for (; r < bias_rows; r += 16) a0 += bpart[(size_t)r * cout_s + ch];
+    }
+    bsum[rl][c16] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && ch < cout) {
       float acc = 0.f;
-      for (int r = 0; r < bias_rows; ++r) acc += bpart[(size_t)r * cout_s + ch];
+#pragma unroll
+      for (int l = 0; l < 16; ++l) acc += bsum[l][c16];
       dbias[ch] += acc;
     }
     return;
@@ -1017,7 +1035,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   }
   if (a.ws) {
     const int elems = (int)pl.tiles() * 1024;
-    const int bias_blocks = bpart ? ceil_div(d->c_out, 256) : 0;
+    const int bias_blocks = bpart ? ceil_div(d->c_out, 16) : 0;
     if (a.splits <= 4) {
       const int mb = ceil_div(elems, 256);
       hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(mb + bias_blocks), dim3(256), 0, s, (const f32x4*)a.ws, a.dw,
