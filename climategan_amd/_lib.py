@@ -69,6 +69,18 @@ _SIGNATURES = {
     "cgan_conv2d_dgrad_packed_weight_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "cgan_conv2d_pack_weight_dgrad": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_conv2d_nhwc_fwd_pair": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_pair_expand_weight": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_pair_from_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_pair_to_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_pair_to_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    "cgan_pair_maxpool3x3s2": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_pair_resize_bilinear": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, _P]),
+    "cgan_pair_resize_nearest": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           _P]),
+    "cgan_pair_mul": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
+    "cgan_pair_copy_channels": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_kernel_kind": (C.c_int, [C.POINTER(ConvDesc), C.c_int32]),
     "cgan_rccl_load": (C.c_int, [C.c_char_p]),

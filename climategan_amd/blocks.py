@@ -23,6 +23,8 @@ class InterpolateNearest2d(nn.Module):
         self.scale_factor = scale_factor
 
     def forward(self, x):
+        if isinstance(x, ops.PairMap):
+            return ops.resize_nearest(x, (x.h * self.scale_factor, x.w * self.scale_factor))
         if isinstance(x, ops.NHWC):
             if self.scale_factor == 2:
                 return Fn.upsample_nearest2x(x)

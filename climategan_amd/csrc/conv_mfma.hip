@@ -37,6 +37,8 @@ struct ConvParams {
   int cls_pad; // pad' = k - 1 - pad of that data gradient
   float slope;
   float* stats; // optional per-chunk (mean, M2) output of the wide-layer GEMM kernel (cgan_conv2d_nhwc_fwd_stats)
+  int pair;     // 1: split-precision output (cgan_conv2d_nhwc_fwd_pair): y and the residual are split maps of Split<T>::NB
+                // blocks of cout_s channels per pixel (the fp32 result carried in two / three 16-bit numbers)
 };
 
 // Parity-class decomposition of the data gradient of a stride-s convolution (dilation 1).  dx[y] = sum over the
@@ -234,6 +236,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       } else {
         rbase = (size_t)pix * p.cout_s;
       }
+    }
+    if (p.pair) {
+      // split-precision epilogue: bias / residual / activation in fp32, then v -> its 16-bit components (c0 = round16(v),
+      // c1 = round16(v - c0), ...), stored as the channel blocks the next conv multiplies by the matching weight blocks
+      // (cgan_common.h, Split<T>)
+      constexpr int NB = Split<T>::NB, NC = Split<T>::NC;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int ch = (ctile0 + c) * 16 + g * 4;
+        if (ch >= p.cout_s) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r] + bias_q[c][r];
+        if (p.has_res) {
+          const uint16_t* rp = p.res + rbase * NB + ch;
+          float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = NC - 1; k >= 0; --k) {
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp + k * p.cout_s);
+            float a0, a1, a2, a3;
+            unpack2<T>(rv[0], a0, a1);
+            unpack2<T>(rv[1], a2, a3);
+            rs[0] += a0; rs[1] += a1; rs[2] += a2; rs[3] += a3;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rs[r];
+        }
+        act_apply_n(v, p.act, p.slope);
+        if (pad_c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ch + r >= p.cout) v[r] = 0.f;
+        }
+        u32x2 comp[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          comp[k][0] = pack2<T>(v[0], v[1]);
+          comp[k][1] = pack2<T>(v[2], v[3]);
+          float q0, q1, q2, q3;
+          unpack2<T>(comp[k][0], q0, q1);
+          unpack2<T>(comp[k][1], q2, q3);
+          v[0] -= q0; v[1] -= q1; v[2] -= q2; v[3] -= q3;
+        }
+        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NB + ch;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) *reinterpret_cast<u32x2*>(yp + b * p.cout_s) = comp[Split<T>::xcomp(b)];
+      }
+      continue;
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -487,6 +537,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1; p.cls_s = 0; p.cls_pad = 0;
   p.has_res = d->has_residual; p.res_ups = d->residual_upsample;
   p.stats = nullptr;
+  p.pair = 0;
   return CGAN_OK;
 }
 
@@ -636,6 +687,28 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
   p.x = (const uint16_t*)x; p.w = (const u32x4*)packed_w; p.bias = d->has_bias ? bias_padded : nullptr;
   p.res = (const uint16_t*)residual; p.y = (uint16_t*)y;
   return dispatch_conv(p, d, (hipStream_t)stream, "conv2d_nhwc_fwd");
+}
+
+// Split-precision forward (round 4): see the header.  Always the general gather kernel: one epilogue variant, opt-in mode.
+extern "C" int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, const float* bias_padded,
+                                         const void* residual3, void* y3, const CganConvDesc* d, void* stream) {
+  ConvParams p;
+  int rc = fill_params(p, d);
+  if (rc != CGAN_OK) return rc;
+  CGAN_REQUIRE(x3 && packed_w3 && y3, "conv2d_nhwc_fwd_pair: null pointer");
+  CGAN_REQUIRE(!d->has_bias || bias_padded, "conv2d_nhwc_fwd_pair: has_bias but bias is null");
+  CGAN_REQUIRE(!d->has_residual || residual3, "conv2d_nhwc_fwd_pair: has_residual but residual is null");
+  const int nb = cgan_split_blocks(d->dtype);
+  CGAN_REQUIRE((d->c_in % (8 * nb)) == 0, "conv2d_nhwc_fwd_pair: c_in must be the %d * round_up(C, 8) storage channels of a split map", nb);
+  CGAN_REQUIRE((double)p.npix * p.cout_s * nb * 2.0 < 4294967295.0, "conv2d_nhwc_fwd_pair: output map of 4 GiB or more");
+  p.x = (const uint16_t*)x3; p.w = (const u32x4*)packed_w3; p.bias = d->has_bias ? bias_padded : nullptr;
+  p.res = (const uint16_t*)residual3; p.y = (uint16_t*)y3;
+  p.pair = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == CGAN_F16) launch<F16>(p, s);
+  else launch<BF16>(p, s);
+  CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd_pair");
+  return CGAN_OK;
 }
 
 // Forward with training-mode BatchNorm statistics from the kernel's epilogue (round 3): see the header.

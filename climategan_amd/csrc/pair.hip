@@ -1,0 +1,377 @@
+// Split-precision ("pair16") activation maps for the inference-time Masker (round 4).
+//
+// The reference's default apply_events run and its binarised flood mask are fp32 (apply_events.py:465-468,
+// trainer.py:1866-1871); every conv kernel of this library multiplies 16-bit operands on the MFMA units.  A value v is
+// therefore carried as several 16-bit numbers (cgan_common.h, Split<T>: fp16 pairs hi + lo, bf16 triples hi + mid + lo) and
+// a map is stored per pixel as NB channel blocks of round_up(C, 8) channels each -- (hi | lo | hi) resp.
+// (hi | mid | lo | hi | mid | hi) -- multiplied by packed weights (W_hi | W_hi | W_lo) resp. (W_hi | W_hi | W_hi | W_mid |
+// W_mid | W_lo) along K: an existing conv kernel then accumulates every cross product above the type's precision floor in
+// fp32.  cgan_conv2d_nhwc_fwd_pair (conv_mfma.hip) stores its fp32 result as such a map again; the few glue ops of the Masker
+// between convs (max-pool, bilinear / nearest resize, channel concatenation, the DADA product, sigmoid, the layout edges) are
+// here, each in fp32 on the sum of the components.
+#include "cgan_common.h"
+
+namespace {
+
+inline int grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g));
+}
+
+// 8 channels (group cg) of pixel `px` of a split map with per-block stride cs: v = sum of the components
+template <typename T>
+__device__ __forceinline__ void pair_load8(const uint16_t* __restrict__ px, int cs, int cg, float* v) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+  for (int k = Split<T>::NC - 1; k >= 0; --k) {       // smallest component first
+    const u32x4 q = *reinterpret_cast<const u32x4*>(px + k * cs + cg * 8);     // blocks 0 .. NC-1 hold components 0 .. NC-1
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a, b;
+      unpack2<T>(q[e], a, b);
+      v[2 * e] += a;
+      v[2 * e + 1] += b;
+    }
+  }
+}
+// split 8 fp32 values into the components and store every block
+template <typename T>
+__device__ __forceinline__ void pair_store8(uint16_t* __restrict__ px, int cs, int cg, const float* v) {
+  u32x4 comp[Split<T>::NC];
+  float rem[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rem[e] = v[e];
+#pragma unroll
+  for (int k = 0; k < Split<T>::NC; ++k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      comp[k][e] = pack2<T>(rem[2 * e], rem[2 * e + 1]);
+      float q0, q1;
+      unpack2<T>(comp[k][e], q0, q1);
+      rem[2 * e] -= q0;
+      rem[2 * e + 1] -= q1;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < Split<T>::NB; ++b) *reinterpret_cast<u32x4*>(px + b * cs + cg * 8) = comp[Split<T>::xcomp(b)];
+}
+
+// fp32 NCHW -> pair NHWC (pad channels zero)
+template <typename T>
+__global__ void pair_from_nchw_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int c, int hw, int cs, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const long n = pix / hw, p = pix % hw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cg * 8 + e;
+      v[e] = ch < c ? x[(n * c + ch) * (long)hw + p] : 0.f;
+    }
+    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, v);
+  }
+}
+
+// pair NHWC -> fp32 NCHW (op 1: sigmoid first, generator.py:277)
+template <typename T>
+__global__ void pair_to_nchw_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, int c, int hw, int cs, int op,
+                                    long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const long n = pix / hw, p = pix % hw;
+    float v[8];
+    pair_load8<T>(x + pix * Split<T>::NB * cs, cs, cg, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cg * 8 + e;
+      if (ch < c) y[(n * c + ch) * (long)hw + p] = op == 1 ? 1.f / (1.f + expf(-v[e])) : v[e];
+    }
+  }
+}
+
+// pair NHWC -> ordinary 16-bit NHWC (hi + lo rounded once): what the event kernels (wildfire, smog, flood painter) read
+template <typename T>
+__global__ void pair_to_nhwc_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int cs, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    float v[8];
+    pair_load8<T>(x + pix * Split<T>::NB * cs, cs, cg, v);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(y + pix * cs + cg * 8) = o;
+  }
+}
+
+// nn.MaxPool2d(3, stride 2, padding 1) (resnet101_v3.py:69)
+template <typename T>
+__global__ void pair_maxpool3x3s2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h, int w, int ho, int wo,
+                                         int cs, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int ox = (int)(pix % wo);
+    const long r = pix / wo;
+    const int oy = (int)(r % ho);
+    const long n = r / ho;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy - 1 + dy;
+      if (iy < 0 || iy >= h) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox - 1 + dx;
+        if (ix < 0 || ix >= w) continue;
+        float v[8];
+        pair_load8<T>(x + ((n * h + iy) * (long)w + ix) * Split<T>::NB * cs, cs, cg, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, m);
+  }
+}
+
+// F.interpolate(mode="bilinear", align_corners=...) in fp32, torch's index rule (as resize_bilinear_kernel, edge.hip)
+template <typename T>
+__global__ void pair_resize_bilinear_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_in, int w_in,
+                                            int h_out, int w_out, int cs, float sy, float sx, int align, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int ox = (int)(pix % w_out);
+    const long r = pix / w_out;
+    const int oy = (int)(r % h_out);
+    const long n = r / h_out;
+    const float fy = align ? oy * sy : fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+    const float fx = align ? ox * sx : fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < h_in - 1 ? y0 : h_in - 1;
+    x0 = x0 < w_in - 1 ? x0 : w_in - 1;
+    const int y1 = y0 < h_in - 1 ? y0 + 1 : y0, x1 = x0 < w_in - 1 ? x0 + 1 : x0;
+    const float ly = fy - y0, lx = fx - x0;
+    const uint16_t* base = x + n * (long)h_in * w_in * Split<T>::NB * cs;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    pair_load8<T>(base + ((long)y0 * w_in + x0) * Split<T>::NB * cs, cs, cg, v00);
+    pair_load8<T>(base + ((long)y0 * w_in + x1) * Split<T>::NB * cs, cs, cg, v01);
+    pair_load8<T>(base + ((long)y1 * w_in + x0) * Split<T>::NB * cs, cs, cg, v10);
+    pair_load8<T>(base + ((long)y1 * w_in + x1) * Split<T>::NB * cs, cs, cg, v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = (1.f - ly) * ((1.f - lx) * v00[e] + lx * v01[e]) + ly * ((1.f - lx) * v10[e] + lx * v11[e]);
+    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, o);
+  }
+}
+
+// F.interpolate(mode="nearest") (legacy index rule floor(dst * in / out), blocks.py:28-43): a copy of both halves
+__global__ void pair_resize_nearest_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_in, int w_in,
+                                           int h_out, int w_out, int cs3, float sy, float sx, long total) {
+  const int g_total = cs3 / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx % g_total);
+    const long pix = idx / g_total;
+    const int ox = (int)(pix % w_out);
+    const long r = pix / w_out;
+    const int oy = (int)(r % h_out);
+    const long n = r / h_out;
+    int iy = (int)floorf(oy * sy), ix = (int)floorf(ox * sx);
+    iy = iy < h_in - 1 ? iy : h_in - 1;
+    ix = ix < w_in - 1 ? ix : w_in - 1;
+    *reinterpret_cast<u32x4*>(y + pix * cs3 + gi * 8) =
+        *reinterpret_cast<const u32x4*>(x + ((n * h_in + iy) * (long)w_in + ix) * cs3 + gi * 8);
+  }
+}
+
+// y = a * b (DADA feature fusion, deeplab_v3.py:253-254) in fp32
+template <typename T>
+__global__ void pair_mul_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
+                                int cs, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    float va[8], vb[8];
+    pair_load8<T>(a + pix * Split<T>::NB * cs, cs, cg, va);
+    pair_load8<T>(b + pix * Split<T>::NB * cs, cs, cg, vb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) va[e] *= vb[e];
+    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, va);
+  }
+}
+
+// the c channels of every block of src into channels [c_off, c_off + c) of the same block of dst (torch.cat on channels:
+// one call per input; c_off a multiple of 8)
+__global__ void pair_copy_channels_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int cs_src, int cs_dst,
+                                          int c_off, int nb, long total) {
+  const int groups = cs_src / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx % groups);
+    const long r = idx / groups;
+    const int blk = (int)(r % nb);
+    const long pix = r / nb;
+    *reinterpret_cast<u32x4*>(dst + pix * nb * cs_dst + blk * cs_dst + c_off + gi * 8) =
+        *reinterpret_cast<const u32x4*>(src + pix * nb * cs_src + blk * cs_src + gi * 8);
+  }
+}
+
+// fp32 OIHW weight [cout][cin][taps] (optionally / sigma) -> fp32 [cout][NB * cs_in][taps]: block b holds component
+// wcomp(b) of the weight (w0 = round16(W), w1 = round16(W - w0), ...); zeros on the pad channels.  The ordinary weight pack
+// then rounds nothing.
+template <typename T>
+__global__ void pair_expand_weight_kernel(const float* __restrict__ w, const float* __restrict__ sigma, float* __restrict__ w3,
+                                          int cin, int cs_in, int taps, long total) {
+  const float sg = sigma ? sigma[0] : 1.f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % taps);
+    const long r = idx / taps;
+    const int k = (int)(r % (Split<T>::NB * cs_in));
+    const long co = r / (Split<T>::NB * cs_in);
+    const int blk = k / cs_in, ci = k - blk * cs_in;
+    float v = 0.f;
+    if (ci < cin) {
+      float rem = __fdiv_rn(w[(co * cin + ci) * taps + tap], sg);
+      const int want = Split<T>::wcomp(blk);
+#pragma unroll
+      for (int q = 0; q < Split<T>::NC; ++q) {
+        const float c = f32_of_bits<T>(bits_of<T>(rem));
+        if (q == want) v = c;
+        rem -= c;
+      }
+    }
+    w3[idx] = v;
+  }
+}
+
+}  // namespace
+
+#define PAIR_DISPATCH(dtype, KERNEL, ...)                                  \
+  do {                                                                     \
+    if ((dtype) == CGAN_F16) hipLaunchKernelGGL(KERNEL<F16>, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<BF16>, __VA_ARGS__);                    \
+  } while (0)
+#define PAIR_CHECK_DT(what) CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, what ": bad dtype %d", dtype)
+
+extern "C" int cgan_pair_from_nchw(const float* x, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                                   void* stream) {
+  CGAN_REQUIRE(x && y3 && n > 0 && c > 0 && h > 0 && w > 0, "pair_from_nchw: bad arguments");
+  PAIR_CHECK_DT("pair_from_nchw");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h * w * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_from_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y3, c,
+                h * w, cs, total);
+  CGAN_CHECK_LAUNCH("pair_from_nchw");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_to_nchw(const void* x3, float* y, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                                 int32_t sigmoid, void* stream) {
+  CGAN_REQUIRE(x3 && y && n > 0 && c > 0 && h > 0 && w > 0, "pair_to_nchw: bad arguments");
+  PAIR_CHECK_DT("pair_to_nchw");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h * w * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3, y, c,
+                h * w, cs, sigmoid ? 1 : 0, total);
+  CGAN_CHECK_LAUNCH("pair_to_nchw");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_to_nhwc(const void* x3, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream) {
+  CGAN_REQUIRE(x3 && y && npix > 0 && c > 0, "pair_to_nhwc: bad arguments");
+  PAIR_CHECK_DT("pair_to_nhwc");
+  const int cs = cgan_cs(c);
+  const long total = (long)npix * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3,
+                (uint16_t*)y, cs, total);
+  CGAN_CHECK_LAUNCH("pair_to_nhwc");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_maxpool3x3s2(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w,
+                                      void* stream) {
+  CGAN_REQUIRE(x3 && y3 && n > 0 && c > 0 && h > 0 && w > 0, "pair_maxpool3x3s2: bad arguments");
+  PAIR_CHECK_DT("pair_maxpool3x3s2");
+  const int cs = cgan_cs(c), ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const long total = (long)n * ho * wo * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3,
+                (uint16_t*)y3, h, w, ho, wo, cs, total);
+  CGAN_CHECK_LAUNCH("pair_maxpool3x3s2");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_resize_bilinear(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                         int32_t w_in, int32_t h_out, int32_t w_out, int32_t align_corners, void* stream) {
+  CGAN_REQUIRE(x3 && y3 && n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "pair_resize_bilinear: bad arguments");
+  PAIR_CHECK_DT("pair_resize_bilinear");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h_out * w_out * (cs / 8);
+  float sy, sx;
+  if (align_corners) {
+    sy = h_out > 1 ? (float)(h_in - 1) / (float)(h_out - 1) : 0.f;
+    sx = w_out > 1 ? (float)(w_in - 1) / (float)(w_out - 1) : 0.f;
+  } else {
+    sy = (float)h_in / (float)h_out;
+    sx = (float)w_in / (float)w_out;
+  }
+  PAIR_DISPATCH(dtype, pair_resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                (const uint16_t*)x3, (uint16_t*)y3, h_in, w_in, h_out, w_out, cs, sy, sx, align_corners ? 1 : 0, total);
+  CGAN_CHECK_LAUNCH("pair_resize_bilinear");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_resize_nearest(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                        int32_t w_in, int32_t h_out, int32_t w_out, void* stream) {
+  CGAN_REQUIRE(x3 && y3 && n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "pair_resize_nearest: bad arguments");
+  PAIR_CHECK_DT("pair_resize_nearest");
+  const int cs3 = cgan_split_blocks(dtype) * cgan_cs(c);
+  const long total = (long)n * h_out * w_out * (cs3 / 8);
+  hipLaunchKernelGGL(pair_resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3,
+                     (uint16_t*)y3, h_in, w_in, h_out, w_out, cs3, (float)h_in / (float)h_out, (float)w_in / (float)w_out, total);
+  CGAN_CHECK_LAUNCH("pair_resize_nearest");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_mul(const void* a3, const void* b3, void* y3, int32_t dtype, int64_t npix, int32_t c, void* stream) {
+  CGAN_REQUIRE(a3 && b3 && y3 && npix > 0 && c > 0, "pair_mul: bad arguments");
+  PAIR_CHECK_DT("pair_mul");
+  const int cs = cgan_cs(c);
+  const long total = (long)npix * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_mul_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a3,
+                (const uint16_t*)b3, (uint16_t*)y3, cs, total);
+  CGAN_CHECK_LAUNCH("pair_mul");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_copy_channels(const void* src3, void* dst3, int32_t dtype, int64_t npix, int32_t c, int32_t c_dst,
+                                       int32_t c_off, void* stream) {
+  CGAN_REQUIRE(src3 && dst3 && npix > 0 && c > 0 && c_dst > 0, "pair_copy_channels: bad arguments");
+  PAIR_CHECK_DT("pair_copy_channels");
+  CGAN_REQUIRE((c_off % 8) == 0 && c_off + cgan_cs(c) <= cgan_cs(c_dst), "pair_copy_channels: bad channel offset %d", c_off);
+  const int nb = cgan_split_blocks(dtype);
+  const long total = (long)npix * nb * (cgan_cs(c) / 8);
+  hipLaunchKernelGGL(pair_copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src3,
+                     (uint16_t*)dst3, cgan_cs(c), cgan_cs(c_dst), c_off, nb, total);
+  CGAN_CHECK_LAUNCH("pair_copy_channels");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_expand_weight(const float* w_oihw, const float* sigma, float* w3, int32_t dtype, int32_t c_out,
+                                       int32_t c_in, int32_t kh, int32_t kw, void* stream) {
+  CGAN_REQUIRE(w_oihw && w3 && c_out > 0 && c_in > 0 && kh > 0 && kw > 0, "pair_expand_weight: bad arguments");
+  PAIR_CHECK_DT("pair_expand_weight");
+  const int cs_in = cgan_cs(c_in), taps = kh * kw;
+  const long total = (long)c_out * cgan_split_blocks(dtype) * cs_in * taps;
+  PAIR_DISPATCH(dtype, pair_expand_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, sigma, w3,
+                c_in, cs_in, taps, total);
+  CGAN_CHECK_LAUNCH("pair_expand_weight");
+  return CGAN_OK;
+}

@@ -71,6 +71,7 @@ class ResNet(nn.Module):
         self.layer3 = self._make_layer(block, 256, layers[2], strides[2], dilations[2], BatchNorm)
         self.layer4 = self._make_MG_unit(block, 512, blocks, strides[3], dilations[3], BatchNorm)
         self.compute_dtype = DEFAULT_COMPUTE_DTYPE
+        self.pair_precision = False
         self._stem = _PackCache()
 
     def _downsample(self, block, planes, stride, BatchNorm):
@@ -107,6 +108,12 @@ class ResNet(nn.Module):
 
     def forward(self, input):
         """NCHW in; returns (z_high, z_low) as NHWC containers (consumed by the decoders of this package)."""
+        if getattr(self, "pair_precision", False):
+            # split-precision inference (G.set_compute_dtype("pair16")): every activation of the Masker as hi + lo
+            import torch
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+                raise NotImplementedError("pair16 is an inference mode (eval(), no_grad())")
+            return self.forward_nhwc(ops.pair_from_nchw(input, self.compute_dtype))
         x = Fn.from_nchw(input, self.compute_dtype)
         return self.forward_nhwc(x)
 

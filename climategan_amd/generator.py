@@ -61,6 +61,7 @@ class OmniGenerator(nn.Module):
         self.verbose = verbose
         self.encoder = None
         self.compute_dtype = DEFAULT_COMPUTE_DTYPE
+        self.pair_precision = False      # set_compute_dtype("pair16"): split-precision Masker inference
         if any(t in opts.tasks for t in "msd"):
             self.encoder = create_encoder(opts, no_init, verbose)
         decoders = {}
@@ -113,18 +114,31 @@ class OmniGenerator(nn.Module):
             return False
 
     def set_compute_dtype(self, dtype):
+        """torch.float16 / torch.bfloat16: the 16-bit type the kernels compute and store in.  "split24" / "pair16": the
+        split-precision INFERENCE modes of the Masker -- every activation carried as several 16-bit numbers whose sum it is
+        (ops.PairMap, csrc/pair.hip) through the same MFMA kernels: bf16 triples hi + mid + lo (24 bits of mantissa at any
+        magnitude, 6x the multiply work: the fp32 arithmetic of the reference's default, non ``--half`` apply_events run --
+        what ``G.float()`` selects, for the literal flood-mask parity north_star asks for) or fp16 pairs hi + lo (3x the
+        work; 22 bits where the low part stays a normal fp16 number, an absolute floor of 2^-24 below |v| ~ 0.1).  The
+        Painter and the event kernels keep running in 16 bit on the maps rounded once."""
+        pair = dtype in ("pair16", "split24")
+        if pair:
+            dtype = torch.float16 if dtype == "pair16" else torch.bfloat16
         if dtype not in (torch.float16, torch.bfloat16):
-            raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
+            raise ValueError("compute dtype must be torch.float16, torch.bfloat16, \"split24\" or \"pair16\"")
         for m in self.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = dtype
+            if hasattr(m, "pair_precision"):
+                m.pair_precision = pair
         self.compute_dtype = dtype
+        self.pair_precision = pair
         return self
 
     # nn.Module's dtype casts (reference apply_events.py:467-468 ``trainer.G.half()``; trainer.py's ``.to(device)``).  The
     # parameters of this package ARE the fp32 masters -- spectral norm power-iterates them, ExtraAdam steps them and the
     # kernels read 16-bit packs made from them -- so a cast selects the 16-bit type the kernels compute and store in and
-    # leaves the parameters alone; ``.float()`` keeps the current 16-bit compute type (there is no fp32 activation path).
+    # leaves the parameters alone; ``.float()`` on an eval-mode generator selects the split-precision Masker (below).
     def half(self):
         return self.set_compute_dtype(torch.float16)
 
@@ -132,6 +146,11 @@ class OmniGenerator(nn.Module):
         return self.set_compute_dtype(torch.bfloat16)
 
     def float(self):
+        """The reference's fp32 inference (apply_events without --half): in eval mode the split-precision mode of the
+        Masker ("split24", see set_compute_dtype); a generator in training mode keeps its 16-bit compute type (the reference
+        trains in fp32; this package trains in bf16 with fp32 masters)."""
+        if not self.training:
+            return self.set_compute_dtype("split24")
         return self
 
     def to(self, *args, **kwargs):

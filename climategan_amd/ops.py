@@ -134,6 +134,71 @@ class NHWC:
         return NHWC(self.t.detach(), self.c)
 
 
+def split_blocks(dtype) -> int:
+    """Channel blocks per pixel of a split-precision map (csrc/cgan_common.h, Split<T>): fp16 pairs (hi | lo | hi) = 3,
+    bf16 triples (hi | mid | lo | hi | mid | hi) = 6."""
+    return 6 if dtype == torch.bfloat16 else 3
+
+
+@dataclass
+class PairMap:
+    """Split-precision activation map of the inference-time Masker (``G.float()`` / ``set_compute_dtype("split24" |
+    "pair16")``, csrc/pair.hip): every value is carried as several 16-bit numbers whose sum it is -- fp16: hi + lo, bf16:
+    hi + mid + lo; ``t`` is [N,H,W,NB*Cs] with NB = ``split_blocks`` channel blocks, Cs = round_up(c, 8).  ``sigmoid``: a sigmoid still to be applied when the map leaves as fp32 NCHW (generator.py:277)."""
+    t: torch.Tensor
+    c: int
+    sigmoid: bool = False
+
+    def __post_init__(self):
+        if self.t.dim() != 4 or self.t.shape[3] != split_blocks(self.t.dtype) * cs8(self.c):
+            raise RuntimeError("PairMap: a [N,H,W,%d*%d] tensor is needed for %d logical channels, got shape %s"
+                               % (split_blocks(self.t.dtype), cs8(self.c), self.c, tuple(self.t.shape)))
+
+    @property
+    def n(self): return self.t.shape[0]
+    @property
+    def h(self): return self.t.shape[1]
+    @property
+    def w(self): return self.t.shape[2]
+    @property
+    def cs(self): return self.t.shape[3] // split_blocks(self.t.dtype)
+    @property
+    def nb(self): return split_blocks(self.t.dtype)
+    @property
+    def dtype_id(self): return _DT[self.t.dtype]
+    @property
+    def shape(self):
+        return torch.Size((self.t.shape[0], self.c, self.t.shape[1], self.t.shape[2]))
+
+    def detach(self) -> "PairMap":
+        return PairMap(self.t.detach(), self.c, self.sigmoid)
+
+
+def _plain_pair(x: "PairMap", what: str):
+    if x.sigmoid:
+        raise RuntimeError("%s: a pair map with a pending sigmoid can only leave through nhwc_to_nchw" % what)
+    _need_cuda(x.t)
+
+
+def pair_from_nchw(x: torch.Tensor, dtype: torch.dtype) -> PairMap:
+    """fp32 NCHW -> (hi | lo | hi) pair map."""
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, split_blocks(dtype) * cs8(c)), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().cgan_pair_from_nchw(_ptr(x), _ptr(y), _DT[dtype], n, c, h, w, _stream()), "cgan_pair_from_nchw")
+    return PairMap(y, c)
+
+
+def pair_to_nhwc(x: PairMap) -> NHWC:
+    """hi + lo rounded once to the 16-bit type: the ordinary map the event kernels and the Painter read."""
+    _plain_pair(x, "pair_to_nhwc")
+    y = torch.empty((x.n, x.h, x.w, x.cs), dtype=x.t.dtype, device=x.t.device)
+    _lib.check(_lib.load().cgan_pair_to_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n * x.h * x.w, x.c, _stream()),
+               "cgan_pair_to_nhwc")
+    return NHWC(y, x.c)
+
+
 # ------------------------------------------------------------------------------------------------ maps of 2 GiB and more
 def _cat_results(outs):
     """Concatenate per-chunk results along the batch: NHWC maps, [N, ...] tensors, tuples of those (None stays None)."""
@@ -142,6 +207,8 @@ def _cat_results(outs):
         return None
     if isinstance(first, NHWC):
         return NHWC(torch.cat([o.t for o in outs], 0), first.c)
+    if isinstance(first, PairMap):
+        return PairMap(torch.cat([o.t for o in outs], 0), first.c, first.sigmoid)
     if isinstance(first, torch.Tensor):
         return torch.cat(outs, 0)
     if isinstance(first, tuple):
@@ -165,12 +232,12 @@ def _batch_chunked(*split, out_bytes_per_sample=None):
         def wrapper(*args, **kwargs):
             big = 0
             for v in args:
-                if type(v) is NHWC:
+                if type(v) is NHWC or type(v) is PairMap:
                     big = max(big, v.t.nbytes)
                 elif type(v) is torch.Tensor:
                     big = max(big, v.nbytes)
             for v in kwargs.values():
-                if type(v) is NHWC:
+                if type(v) is NHWC or type(v) is PairMap:
                     big = max(big, v.t.nbytes)
                 elif type(v) is torch.Tensor:
                     big = max(big, v.nbytes)
@@ -186,7 +253,7 @@ def _batch_chunked(*split, out_bytes_per_sample=None):
                 v = args[i] if i < len(args) else kwargs.get(name)
                 if v is None:
                     continue
-                t = v.t if type(v) is NHWC else v
+                t = v.t if type(v) in (NHWC, PairMap) else v
                 n = t.shape[0]
                 per_sample = max(per_sample, t.nbytes // max(n, 1))
             if n is None:
@@ -206,7 +273,8 @@ def _batch_chunked(*split, out_bytes_per_sample=None):
                     v = a[i] if i < len(a) else kw.get(name)
                     if v is None:
                         continue
-                    piece = NHWC(v.t[lo:lo + k], v.c) if type(v) is NHWC else v[lo:lo + k]
+                    piece = (NHWC(v.t[lo:lo + k], v.c) if type(v) is NHWC else
+                             PairMap(v.t[lo:lo + k], v.c, v.sigmoid) if type(v) is PairMap else v[lo:lo + k])
                     if i < len(a):
                         a[i] = piece
                     else:
@@ -215,6 +283,11 @@ def _batch_chunked(*split, out_bytes_per_sample=None):
             return _cat_results(outs)
         return wrapper
     return deco
+
+
+def _nbf(x) -> int:
+    """channel blocks per pixel: 1 for an ordinary map, 3 / 6 for a split-precision one"""
+    return x.nb if isinstance(x, PairMap) else 1
 
 
 def _conv_out_hw(h, w, k, stride, pad, dil):
@@ -243,6 +316,14 @@ def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cs: Optional[int] = None,
 @_batch_chunked("y", "paste_x", "paste_m", out_bytes_per_sample=lambda g: g("y").h * g("y").w * g("y").c * 4)
 def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optional[torch.Tensor] = None):
     """16-bit NHWC -> fp32 NCHW; with paste: out = paste_x * (1 - m) + y * m (reference generator.py:295-296)."""
+    if isinstance(y, PairMap):
+        if paste_x is not None:
+            raise RuntimeError("nhwc_to_nchw: the paste is not available on a pair map")
+        _need_cuda(y.t)
+        out = torch.empty((y.n, y.c, y.h, y.w), dtype=torch.float32, device=y.t.device)
+        _lib.check(_lib.load().cgan_pair_to_nchw(_ptr(y.t), _ptr(out), y.dtype_id, y.n, y.c, y.h, y.w, int(y.sigmoid),
+                                                 _stream()), "cgan_pair_to_nchw")
+        return out
     _need_cuda(y.t, paste_x, paste_m)
     n, h, w, cs = y.t.shape
     out = torch.empty((n, y.c, h, w), dtype=torch.float32, device=y.t.device)
@@ -256,8 +337,15 @@ def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optio
     return out
 
 
-@_batch_chunked("x", out_bytes_per_sample=lambda g: g("size")[0] * g("size")[1] * (g("cs_out") or g("x").cs) * 2)
+@_batch_chunked("x", out_bytes_per_sample=lambda g: g("size")[0] * g("size")[1] * (g("cs_out") or g("x").cs) * 2 * _nbf(g("x")))
 def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None) -> NHWC:
+    if isinstance(x, PairMap):
+        _plain_pair(x, "resize_nearest")
+        y = torch.empty((x.n, size[0], size[1], x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        _lib.check(_lib.load().cgan_pair_resize_nearest(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, size[0], size[1],
+                                                        _stream()),
+                   "cgan_pair_resize_nearest")
+        return PairMap(y, x.c)
     _need_cuda(x.t)
     oh, ow = size
     cs_out = cs_out or x.cs
@@ -291,7 +379,14 @@ def avgpool3x3s2(x: NHWC) -> NHWC:
     return NHWC(y, x.c)
 
 
+@_batch_chunked("x")
 def maxpool3x3s2(x: NHWC) -> NHWC:
+    if isinstance(x, PairMap):
+        _plain_pair(x, "maxpool3x3s2")
+        y = torch.empty((x.n, (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        _lib.check(_lib.load().cgan_pair_maxpool3x3s2(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
+                   "cgan_pair_maxpool3x3s2")
+        return PairMap(y, x.c)
     _need_cuda(x.t)
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
     y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
@@ -301,7 +396,14 @@ def maxpool3x3s2(x: NHWC) -> NHWC:
     return NHWC(y, x.c)
 
 
+@_batch_chunked("x", out_bytes_per_sample=lambda g: g("size")[0] * g("size")[1] * g("x").cs * 2 * _nbf(g("x")))
 def resize_bilinear(x: NHWC, size: Tuple[int, int], align_corners: bool = False) -> NHWC:
+    if isinstance(x, PairMap):
+        _plain_pair(x, "resize_bilinear")
+        y = torch.empty((x.n, size[0], size[1], x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        _lib.check(_lib.load().cgan_pair_resize_bilinear(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, size[0], size[1],
+                                                         int(bool(align_corners)), _stream()), "cgan_pair_resize_bilinear")
+        return PairMap(y, x.c)
     _need_cuda(x.t)
     oh, ow = size
     if x.cs != cs8(x.c):
@@ -328,6 +430,17 @@ def concat_channels(xs) -> NHWC:
     """torch.cat(xs, dim=1) on NHWC tensors; every input but the last must have a multiple-of-8 channel count."""
     n, h, w = xs[0].n, xs[0].h, xs[0].w
     c_total = sum(x.c for x in xs)
+    if isinstance(xs[0], PairMap):
+        y = torch.zeros((n, h, w, xs[0].nb * cs8(c_total)), dtype=xs[0].t.dtype, device=xs[0].t.device)
+        off = 0
+        for x in xs:
+            if not isinstance(x, PairMap) or (x.n, x.h, x.w) != (n, h, w) or x.t.dtype != y.dtype:
+                raise RuntimeError("concat_channels: pair maps of one shape / dtype only")
+            _plain_pair(x, "concat_channels")
+            _lib.check(_lib.load().cgan_pair_copy_channels(_ptr(x.t), _ptr(y), x.dtype_id, n * h * w, x.c, c_total, off, _stream()),
+                       "cgan_pair_copy_channels")
+            off += x.c
+        return PairMap(y, c_total)
     y = torch.zeros((n, h, w, cs8(c_total)), dtype=xs[0].t.dtype, device=xs[0].t.device)
     lib = _lib.load()
     off = 0
@@ -345,6 +458,15 @@ def concat_channels(xs) -> NHWC:
 
 @_batch_chunked("a", "b")
 def eltwise_mul(a: NHWC, b: NHWC) -> NHWC:
+    if isinstance(a, PairMap):
+        if not isinstance(b, PairMap) or a.t.shape != b.t.shape or a.c != b.c:
+            raise RuntimeError("eltwise_mul: two pair maps of one shape expected")
+        _plain_pair(a, "eltwise_mul")
+        _plain_pair(b, "eltwise_mul")
+        y = torch.empty_like(a.t)
+        _lib.check(_lib.load().cgan_pair_mul(_ptr(a.t), _ptr(b.t), _ptr(y), a.dtype_id, a.n * a.h * a.w, a.c, _stream()),
+                   "cgan_pair_mul")
+        return PairMap(y, a.c)
     _need_cuda(a.t, b.t)
     if a.t.shape != b.t.shape or a.c != b.c:
         raise RuntimeError("eltwise_mul: shape mismatch")
@@ -357,6 +479,9 @@ def eltwise_mul(a: NHWC, b: NHWC) -> NHWC:
 
 def sigmoid(a: NHWC) -> NHWC:
     """Elementwise sigmoid (pad channels are re-zeroed by the caller if it matters: sigmoid(0) = 0.5)."""
+    if isinstance(a, PairMap):          # applied in fp32 when the map leaves as NCHW (cgan_pair_to_nchw)
+        _plain_pair(a, "sigmoid")
+        return PairMap(a.t, a.c, sigmoid=True)
     _need_cuda(a.t)
     y = torch.empty_like(a.t)
     lib = _lib.load()
@@ -565,6 +690,7 @@ class PackedConv:
     kw: int
     has_bias: bool
     dtype: torch.dtype
+    pair_c_in: int = 0   # > 0: a split-precision operator (pack_conv_weight(pair=True)) of this many logical input channels
 
 
 def _conv_desc(dtype_id, n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dil, pad_mode, in_upsample=False,
@@ -576,10 +702,19 @@ def _conv_desc(dtype_id, n, h_in, w_in, c_in, c_out, kh, kw, stride, pad, dil, p
 
 
 def pack_conv_weight(w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
-                     sigma: Optional[torch.Tensor] = None) -> PackedConv:
-    """fp32 OIHW (+ optional device scalar sigma: packed = w / sigma) -> MFMA fragment order."""
+                     sigma: Optional[torch.Tensor] = None, pair: bool = False) -> PackedConv:
+    """fp32 OIHW (+ optional device scalar sigma: packed = w / sigma) -> MFMA fragment order.  ``pair``: the operator of a
+    split-precision conv (PairMap input): (W_hi | W_hi | W_lo) along the 3 * round_up(c_in, 8) input channels."""
     _need_cuda(w, bias, sigma)
     w = w.detach().contiguous().float()
+    if pair:
+        c_out, c_in, kh, kw = w.shape
+        w3 = torch.empty((c_out, split_blocks(dtype) * cs8(c_in), kh, kw), dtype=torch.float32, device=w.device)
+        _lib.check(_lib.load().cgan_pair_expand_weight(_ptr(w), _ptr(sigma), _ptr(w3), _DT[dtype], c_out, c_in, kh, kw,
+                                                       _stream()), "cgan_pair_expand_weight")
+        pk = pack_conv_weight(w3, bias, dtype)
+        pk.pair_c_in = c_in
+        return pk
     c_out, c_in, kh, kw = w.shape
     d = _conv_desc(_DT[dtype], 1, max(kh, 1), max(kw, 1), c_in, c_out, kh, kw, 1, 0, 1, PAD_ZERO)
     lib = _lib.load()
@@ -642,12 +777,29 @@ def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
 _PACK_TABLES = []
 
 
-@_batch_chunked("x", "residual", out_bytes_per_sample=lambda g: (lambda hw: hw[0] * hw[1] * cs8(g("pw").c_out) * 2)(
+@_batch_chunked("x", "residual", out_bytes_per_sample=lambda g: (lambda hw: hw[0] * hw[1] * cs8(g("pw").c_out) * 2 * _nbf(g("x")))(
     _conv_out_hw(g("x").h * (2 if g("in_upsample") else 1), g("x").w * (2 if g("in_upsample") else 1), g("pw").kh, g("stride"),
                  g("pad"), g("dilation"))))
 def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2,
            residual: Optional[NHWC] = None, in_upsample=False, residual_upsample=False) -> NHWC:
     """y = act(conv(x) + bias + residual) on NHWC tensors; x may be read through a folded x2 nearest upsample."""
+    if isinstance(x, PairMap):
+        _plain_pair(x, "conv2d")
+        if pw.pair_c_in != x.c or x.t.dtype != pw.dtype:
+            raise RuntimeError("conv2d: a pair map of %d channels needs a pair-packed operator of the same type (got %d)"
+                               % (x.c, pw.pair_c_in))
+        if residual is not None and (not isinstance(residual, PairMap) or residual.c != pw.c_out):
+            raise RuntimeError("conv2d: the residual of a pair conv must be a pair map of the output's channels")
+        h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
+        d = _conv_desc(x.dtype_id, x.n, h_in, w_in, x.nb * x.cs, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode,
+                       in_upsample, act, slope, pw.has_bias, residual is not None, residual_upsample)
+        y = torch.empty((x.n, d.h_out, d.w_out, x.nb * cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
+        _lib.check(_lib.load().cgan_conv2d_nhwc_fwd_pair(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias),
+                                                         _ptr(residual.t if residual is not None else None), _ptr(y),
+                                                         C.byref(d), _stream()), "cgan_conv2d_nhwc_fwd_pair")
+        return PairMap(y, pw.c_out)
+    if pw.pair_c_in:
+        raise RuntimeError("conv2d: a pair-packed operator needs a pair map input")
     _need_cuda(x.t)
     _need_cs8("conv2d", x, residual)
     if x.c != pw.c_in:

@@ -833,9 +833,16 @@ class Trainer:
                 depth_nhwc, z_depth = self.G.decoders["d"].forward_nhwc(z)
             with timed("segmentation"):
                 seg_nhwc = self.G.decoders["s"].forward_nhwc(z, z_depth)
+            if isinstance(seg_nhwc, ops.PairMap):
+                # split-precision Masker (G.set_compute_dtype("pair16")): the mask decoder stays on the pair maps (the mask
+                # leaves as fp32); the conditioning map and the event kernels read the maps rounded once to 16 bit
+                depth_nhwc, seg_nhwc = ops.pair_to_nhwc(depth_nhwc), ops.pair_to_nhwc(seg_nhwc)
             with timed("mask"):
                 cond = self.G.make_m_cond(depth_nhwc, seg_nhwc, x) if self.opts.gen.m.use_spade else None   # :285
-                mask = self.G.mask(z=z, cond=cond, z_depth=z_depth).to(x.dtype)
+                if cond is not None and isinstance(z[0], ops.PairMap):
+                    raise NotImplementedError("pair16 inference with the SPADE mask decoder (gen.m.use_spade) is not built")
+                mask = self.G.mask(z=z, cond=cond, z_depth=z_depth)
+                mask = mask if isinstance(z[0], ops.PairMap) else mask.to(x.dtype)     # pair16: the fp32 mask is binarised
 
             wildfire = smog = flood = None
             # the flood painter is independent of the other two events: it runs on the side stream beside them (only when

@@ -599,6 +599,41 @@ int cgan_comm_init_rank(void** comm, int32_t nranks, const void* id128, int32_t 
 int cgan_comm_destroy(void* comm);
 int cgan_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* comm, void* stream);
 
+/* ---- split-precision ("pair16") inference path of the Masker (round 4) -------------------------------------------------
+ * The reference's default apply_events run is fp32 (apply_events.py:465-468: --half is opt-in) and binarises an fp32 mask
+ * (trainer.py:1866-1871); these entry points carry every activation of the eval-mode Masker (deeplab/resnet101_v3.py:176-187,
+ * deeplab_v3.py:244-266, depth.py:128-155, blocks.py:292-313) as SEVERAL 16-bit numbers whose sum is the value, so that the
+ * 16-bit MFMA kernels reproduce the fp32 arithmetic: dtype CGAN_F16 = pairs hi + lo (22 bits of mantissa where lo stays a
+ * normal number, an absolute floor of 2^-24 below |v| ~ 0.1), dtype CGAN_BF16 = triples hi + mid + lo (24 bits at any
+ * magnitude: what the module mirror's G.float() / G.set_compute_dtype("split24") selects; "pair16" = the fp16 pairs).
+ * A split map of C channels is an NHWC buffer of NB * cgan_cs(C) channels per pixel, NB = 3 blocks (hi | lo | hi) resp.
+ * NB = 6 blocks (hi | mid | lo | hi | mid | hi); conv weights are expanded to (W_hi | W_hi | W_lo) resp. (W_hi | W_hi | W_hi |
+ * W_mid | W_mid | W_lo) along the input channels (cgan_pair_expand_weight, then the ordinary cgan_conv2d_pack_weight with
+ * c_in = NB * cgan_cs(C_in)): every cross product above the type's precision floor accumulates in fp32 inside the existing
+ * conv kernel.
+ * cgan_conv2d_nhwc_fwd_pair: the conv of such a map (d->c_in = NB * cgan_cs(C_in), d->c_out = C_out; bias, optional split
+ * residual, activation in fp32) stored as a split map again (NB * cgan_cs(C_out) channels).  The rest are the Masker's glue
+ * ops between convs, each evaluated in fp32 on the sum of the components: layout edges (fp32 NCHW <-> split; _to_nchw with
+ * the sigmoid of generator.py:277; _to_nhwc = one ordinary 16-bit map for the event kernels), nn.MaxPool2d(3, 2, 1),
+ * F.interpolate bilinear (both align_corners) / legacy nearest, the DADA product (deeplab_v3.py:253-254), torch.cat on
+ * channels. */
+int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, const float* bias_padded, const void* residual3,
+                              void* y3, const CganConvDesc* d, void* stream);
+int cgan_pair_expand_weight(const float* w_oihw, const float* sigma, float* w3, int32_t dtype, int32_t c_out, int32_t c_in,
+                            int32_t kh, int32_t kw, void* stream);
+int cgan_pair_from_nchw(const float* x, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+int cgan_pair_to_nchw(const void* x3, float* y, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, int32_t sigmoid,
+                      void* stream);
+int cgan_pair_to_nhwc(const void* x3, void* y, int32_t dtype, int64_t npix, int32_t c, void* stream);
+int cgan_pair_maxpool3x3s2(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+int cgan_pair_resize_bilinear(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                              int32_t h_out, int32_t w_out, int32_t align_corners, void* stream);
+int cgan_pair_resize_nearest(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                             int32_t h_out, int32_t w_out, void* stream);
+int cgan_pair_mul(const void* a3, const void* b3, void* y3, int32_t dtype, int64_t npix, int32_t c, void* stream);
+int cgan_pair_copy_channels(const void* src3, void* dst3, int32_t dtype, int64_t npix, int32_t c, int32_t c_dst, int32_t c_off,
+                            void* stream);
+
 /* libcgan_hip.so exports exactly the entry points declared above: no development knob, no process-global mutable state
  * behind the ABI besides the thread-local error string and the lazily loaded RCCL handle.  The kernel-selection /
  * ablation / timestamp knobs (cgan_debug_set_*) that tools/ and the every-kernel-variant tests use exist only in the

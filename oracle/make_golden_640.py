@@ -281,6 +281,25 @@ def run_infer640(case):
     out["seg_argmax"] = seg.argmax(1).numpy().astype(np.uint8)
     out["seg_tie_band"] = np.packbits((top2[:, 0] - top2[:, 1]).numpy() < case["seg_band"])
     out["seg_tie_frac"] = np.array([((top2[:, 0] - top2[:, 1]).numpy() < case["seg_band"]).mean()], dtype=np.float32)
+    # What fp32 arithmetic itself can decide about the mask: the reference's mask logits once more in fp32 and in FLOAT64
+    # (its own modules, same weights, one power iteration of the mask decoder's spectral norms as in infer_all).  Their
+    # largest difference is the rounding noise of the fp32 run; a pixel whose float64 logit is inside 8x that noise of the
+    # threshold is one whose bit ANOTHER fp32 summation order (MKL-DNN here, MFMA tiles there) may decide the other way.
+    logits = {}
+    for dt in (torch.float32, torch.float64):
+        T.G.load_state_dict({k: t(v) for k, v in generator_fill(shapes, case).items()})
+        T.G.to(dt).eval()
+        with torch.no_grad():
+            z = T.G.encode(x.to(dt))
+            logits[dt] = T.G.mask(z=z, sigmoid=False).double().numpy()
+    T.G.float()
+    noise = float(np.abs(logits[torch.float32] - logits[torch.float64]).max())
+    assert np.array_equal(logits[torch.float32] > 0, res["mask"] > 0)         # the second fp32 pass is infer_all's mask
+    fp32_band = np.abs(logits[torch.float64]) < 8 * noise
+    out["m_fp32_noise"] = np.array([noise], dtype=np.float32)
+    out["m_fp32_band"] = np.packbits(fp32_band)
+    out["m_fp32_band_count"] = np.array([int(fp32_band.sum())], dtype=np.int64)
+    out["m_fp32_vs_fp64_flips"] = np.array([int(((logits[torch.float32] > 0) != (logits[torch.float64] > 0)).sum())], dtype=np.int64)
     for k in ("flood", "smog", "wildfire"):
         u8 = np.ascontiguousarray(res[k].transpose(0, 3, 1, 2))              # [B,3,H,W] uint8
         out.update({k + "_u8_" + a: b for a, b in summarize(u8.astype(np.float32)).items()})

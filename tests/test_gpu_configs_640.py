@@ -195,6 +195,66 @@ def test_masker_stages_640_vs_reference(infer_trainer):
     T.G.set_compute_dtype(torch.float16)
 
 
+@pytest.mark.parametrize("mode", ["split24", "pair16"])
+def test_split_precision_masker_reproduces_the_fp32_reference(infer_trainer, mode):
+    """``G.float()`` on the eval-mode generator = the split-precision Masker ("split24": every activation as three bf16
+    numbers hi + mid + lo; "pair16": two fp16 numbers; csrc/pair.hip) through the same MFMA kernels: the arithmetic of the
+    reference's DEFAULT apply_events run (fp32; --half is opt-in, apply_events.py:465-468).  Against the reference's own
+    fp32 ``infer_all`` at 640 x 640, bs 16:
+    * depth / segmentation / mask floats within 2e-5 of their scale (north_star asks 1e-3): 6e-6 / 4.5e-6 / 3.5e-5 measured,
+      which is what the reference's fp32 run itself is away from float64 on this fixture (2.6e-6 / 4.1e-6 / 2.9e-5,
+      tests/devtools/measure_ref_fp32_floor.py) -- the noise floor of ANY fp32 evaluation;
+    * the binarised flood mask ("bit-exact", trainer.py:1866-1871) equal to the reference's on every pixel fp32 arithmetic
+      can decide: the fixture stores the 69 pixels (of 819 200) whose FLOAT64 logit is inside 8 x the reference's own fp32
+      rounding noise (1.3e-4) of the threshold; outside them no bit may differ, inside at most 2 per image pair (measured:
+      1, at a logit of -2.7e-5, where MKL-DNN's and the MFMA tiles' fp32 summation orders disagree).  No fp16 band any more
+      (test_apply_events_bs16: 3.8 % of the pixels in fp16)."""
+    T, sd, case = infer_trainer
+    gold = load_golden("infer_640")
+    B, H, W = case["B"], case["H"], case["W"]
+    x2 = t(infer_inputs(case)["x"]).cuda()
+    _load(T.G, sd)
+    T.G.eval()
+    if mode == "split24":
+        assert T.G.float() is T.G and T.G.pair_precision and T.G.compute_dtype == torch.bfloat16
+    else:
+        T.G.set_compute_dtype("pair16")
+    try:
+        with torch.no_grad():
+            out = T.G.masker_forward(x2)
+        worst = {}
+        for k in ("d", "s", "m"):
+            y = out[k].float().cpu().numpy()
+            assert out[k].dtype == torch.float32
+            s = summarize(y)
+            scale = max(np.abs(gold[k + "_crop_c"]).max(), np.abs(gold[k + "_pooled8"]).max())
+            errs = np.concatenate([np.abs(s[c] - gold["%s_%s" % (k, c)]).ravel() for c in ("crop_tl", "crop_c", "crop_br")])
+            worst[k] = errs.max() / scale
+            print("%s masker 640 %s: max %.3g mean %.3g of scale %.3g (%.2g relative)" % (mode, k, errs.max(), errs.mean(), scale, worst[k]))
+            assert errs.max() <= 1e-3 * scale, (k, errs.max(), scale)          # north_star's 1e-3 ...
+            assert errs.max() <= (1e-4 if k == "m" else 2e-5) * scale, (k, errs.max(), scale)   # ... and what fp32-grade arithmetic gives
+            # (m: the fixture's output conv has gain 40, the sigmoid's slope is 1/4)
+        _load(T.G, sd)                                                        # (spectral-norm u / v back to the fixture's)
+        random.seed(case["rng_seed"])
+        res = T.infer_all(x2.repeat(8, 1, 1, 1), numpy=True, bin_value=case["bin_value"], half=False, return_masks=True)
+        ref_mask = np.unpackbits(gold["mask_bits"])[: B * H * W].reshape(B, 1, H, W).astype(bool)
+        got = res["mask"] > 0
+        diff = sum(int((got[i] != ref_mask[i % B]).sum()) for i in range(16))
+        print("%s flood mask vs the reference's fp32 mask: %d of %d bits differ" % (mode, diff, got.size))
+        band = np.unpackbits(gold["m_fp32_band"])[: B * H * W].reshape(B, 1, H, W).astype(bool)
+        assert int(gold["m_fp32_band_count"][0]) == band.sum() <= 100 and int(gold["m_fp32_vs_fp64_flips"][0]) <= 2
+        for i in range(16):
+            d = got[i] != ref_mask[i % B]
+            assert not d[~band[i % B]].any(), "sample %d: %d mask bits differ where fp32 decides" % (i, d[~band[i % B]].sum())
+            assert np.array_equal(got[i], got[i % B])                          # every repeat of an image: the same bits
+        assert diff // 8 <= 2, diff
+        for k in ("flood", "wildfire", "smog"):
+            assert res[k].shape == (16, H, W, 3) and res[k].dtype == np.uint8
+    finally:
+        T.G.set_compute_dtype(torch.float16)
+        _load(T.G, sd)
+
+
 # ------------------------------------------------------------------------------------------------ configs[2], [3]
 def _build_train(tasks, case, reps, dt=torch.bfloat16, merge=True, opt_overrides=None):
     from climategan_amd import fill

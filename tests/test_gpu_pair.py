@@ -1,0 +1,102 @@
+"""Split-precision maps (ops.PairMap, csrc/pair.hip, cgan_conv2d_nhwc_fwd_pair): every op of the inference-time Masker on
+fp16 pairs ("pair16") and bf16 triples ("split24") against torch's fp32 / float64 ops on the same fp32 inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DTS = [torch.bfloat16, torch.float16]
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(shape, device="cuda", generator=g) * scale
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layout_round_trip_and_precision(dt):
+    from climategan_amd import ops
+
+    x = _rand((2, 19, 24, 20), 1, 3.0)
+    p = ops.pair_from_nchw(x, dt)
+    assert tuple(p.t.shape) == (2, 24, 20, ops.split_blocks(dt) * 24) and p.c == 19
+    back = ops.nhwc_to_nchw(p)
+    rel = ((back - x).abs() / x.abs().clamp_min(0.25)).max().item()        # (fp16 pairs: an absolute floor below |v| ~ 0.1)
+    assert rel <= (2.0 ** -21 if dt == torch.float16 else 2.0 ** -23), rel
+    assert torch.equal(ops.nhwc_to_nchw(ops.sigmoid(p)), torch.sigmoid(back)) or \
+        (ops.nhwc_to_nchw(ops.sigmoid(p)) - torch.sigmoid(back.double()).float()).abs().max().item() <= 2e-7
+    r = ops.pair_to_nhwc(p)
+    assert isinstance(r, ops.NHWC) and torch.equal(r.t[..., :19], back.permute(0, 2, 3, 1).to(dt))
+    assert bool((r.t[..., 19:] == 0).all())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [
+    # (cin, cout, k, stride, pad, dil, reflect, in_upsample, residual, act)
+    (24, 40, 3, 1, 1, 1, False, False, True, "relu"),
+    (64, 32, 1, 1, 0, 1, False, False, False, "none"),
+    (16, 24, 3, 1, 2, 2, False, False, False, "lrelu"),
+    (32, 16, 3, 1, 1, 1, True, False, True, "lrelu"),
+    (16, 8, 3, 1, 1, 1, True, True, False, "none"),
+    (3, 64, 7, 2, 3, 1, False, False, False, "relu"),
+    (130, 20, 3, 2, 1, 1, False, False, False, "none"),
+])
+def test_split_conv_matches_float64(dt, case):
+    """hi W_hi + lo W_hi + hi W_lo (+ the bf16 triples' second-order terms) accumulated in fp32 by the MFMA kernel, against
+    the float64 convolution of the same fp32 operands: a few 1e-7 of the output's scale -- fp32-grade."""
+    from climategan_amd import ops
+
+    cin, cout, k, stride, pad, dil, reflect, ups, with_res, act = case
+    n, h, w = 2, 20, 28
+    x = _rand((n, cin, h, w), 3)
+    wt = _rand((cout, cin, k, k), 4, (2.0 / (cin * k * k)) ** 0.5)
+    b = _rand((cout,), 5)
+    p = ops.pair_from_nchw(x, dt)
+    pw = ops.pack_conv_weight(wt, b, dt, pair=True)
+    xr = F.interpolate(x.double(), scale_factor=2, mode="nearest") if ups else x.double()
+    xp = F.pad(xr, (pad,) * 4, mode="reflect") if reflect else xr
+    ref = F.conv2d(xp, wt.double(), b.double(), stride=stride, padding=0 if reflect else pad, dilation=dil)
+    res = None
+    if with_res:
+        rt = _rand(tuple(ref.shape), 6)
+        res = ops.pair_from_nchw(rt, dt)
+        ref = ref + ops.nhwc_to_nchw(res).double()                  # (the residual as the split map carries it)
+    ref = {"relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "none": lambda v: v}[act](ref)
+    y = ops.conv2d(p, pw, stride=stride, pad=pad, dilation=dil, pad_mode=ops.PAD_REFLECT if reflect else ops.PAD_ZERO,
+                   act={"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act], residual=res, in_upsample=ups)
+    assert isinstance(y, ops.PairMap) and y.c == cout
+    got = ops.nhwc_to_nchw(y).double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= (1.5e-6 if dt == torch.float16 else 1e-6), err
+    # the ordinary 16-bit conv on the same operands, for scale: three to four orders of magnitude further away
+    y16 = ops.nhwc_to_nchw(ops.conv2d(ops.nchw_to_nhwc(x, dt), ops.pack_conv_weight(wt, b, dt), stride=stride, pad=pad,
+                                      dilation=dil, pad_mode=ops.PAD_REFLECT if reflect else ops.PAD_ZERO, in_upsample=ups))
+    if not with_res and act == "none":
+        assert (y16.double() - ref).abs().max().item() / ref.abs().max().item() > 100 * err
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_glue_ops_match_torch_fp32(dt):
+    from climategan_amd import ops
+
+    x = _rand((2, 24, 21, 30), 7, 2.0)
+    p = ops.pair_from_nchw(x, dt)
+    xq = ops.nhwc_to_nchw(p)                                       # what the map carries (= x to fp32-grade precision)
+    tol = 3e-6 if dt == torch.float16 else 6e-7
+
+    def close(got, ref):
+        return (got - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+
+    assert torch.equal(ops.nhwc_to_nchw(ops.maxpool3x3s2(p)), F.max_pool2d(xq, 3, 2, 1))
+    for size, ac in (((40, 64), True), ((40, 64), False), ((11, 15), False), ((82, 82), True)):
+        assert close(ops.nhwc_to_nchw(ops.resize_bilinear(p, size, align_corners=ac)),
+                     F.interpolate(xq, size=size, mode="bilinear", align_corners=ac)), (size, ac)
+    assert torch.equal(ops.nhwc_to_nchw(ops.resize_nearest(p, (42, 60))), F.interpolate(xq, scale_factor=2, mode="nearest"))
+    assert torch.equal(ops.nhwc_to_nchw(ops.resize_nearest(p, (13, 17))), F.interpolate(xq, size=(13, 17), mode="nearest"))
+    q = ops.pair_from_nchw(_rand((2, 24, 21, 30), 8), dt)
+    assert close(ops.nhwc_to_nchw(ops.eltwise_mul(p, q)), xq * ops.nhwc_to_nchw(q))
+    r = ops.pair_from_nchw(_rand((2, 13, 21, 30), 9), dt)
+    cat = ops.concat_channels([p, q, r])
+    assert cat.c == 61 and torch.equal(ops.nhwc_to_nchw(cat), torch.cat([xq, ops.nhwc_to_nchw(q), ops.nhwc_to_nchw(r)], 1))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(p, ops.pack_conv_weight(_rand((8, 24, 1, 1), 10), None, dt))       # an ordinary operator on a split map
