@@ -497,6 +497,81 @@ class BceLogitsFn(torch.autograd.Function):
         return ops.scale_by_scalar(ops.NHWC(dx_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None
 
 
+class MseConstFn(torch.autograd.Function):
+    """weight * sum (x - target)^2 over the logical channels (GANLoss with use_lsgan=True, losses.py:50-52)."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, target, weight):
+        from . import _lib
+        ctx.c = c
+        acc = torch.zeros(1, dtype=torch.float32, device=x_t.device)
+        dx = torch.empty_like(x_t) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.load().cgan_mse_const_nhwc(ops._ptr(x_t), ops._DT[x_t.dtype], _npix(x_t), c, float(target),
+                                                   float(weight * GRAD_SCALE), ops._ptr(acc), ops._ptr(dx), ops._stream()),
+                   "cgan_mse_const_nhwc")
+        ctx.save_for_backward(dx)
+        return acc[0] / GRAD_SCALE if GRAD_SCALE != 1.0 else acc[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx_t,) = ctx.saved_tensors
+        if dx_t is None:
+            return None, None, None, None
+        return ops.scale_by_scalar(ops.NHWC(dx_t, ctx.c), g.reshape(1).float().contiguous()).t, None, None, None
+
+
+class PainterAuxFn(torch.autograd.Function):
+    """The Painter's optional image-space terms on the pasted image (trainer.py:1289-1315): returns (their sum, the three
+    weighted values tv / context / reconstruction as a detached [3] tensor); the gradient flows to ``fake`` only."""
+
+    @staticmethod
+    def forward(ctx, fake_t, x, m, lam_tv, lam_ctx, lam_rec):
+        from . import _lib
+        n, h, w = fake_t.shape[0], fake_t.shape[1], fake_t.shape[2]
+        x = x.contiguous().float()
+        m = m.contiguous().float()
+        cnt = float(n * 3 * h * w)
+        wh = GRAD_SCALE * lam_tv * 2.0 / (3 * (h - 1) * w) / n                 # TVLoss.forward, losses.py:157-166
+        ww = GRAD_SCALE * lam_tv * 2.0 / (3 * h * (w - 1)) / n
+        acc = torch.zeros(3, dtype=torch.float32, device=fake_t.device)
+        dfake = torch.empty_like(fake_t) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.load().cgan_painter_aux_losses(ops._ptr(fake_t), ops._ptr(x), ops._ptr(m), ops._DT[fake_t.dtype], n, h, w,
+                                                       wh, ww, GRAD_SCALE * lam_ctx / cnt, GRAD_SCALE * lam_rec / cnt,
+                                                       ops._ptr(acc), ops._ptr(dfake), ops._stream()), "cgan_painter_aux_losses")
+        ctx.save_for_backward(dfake)
+        if GRAD_SCALE != 1.0:
+            acc = acc / GRAD_SCALE
+        ctx.mark_non_differentiable(acc)
+        return acc.sum(), acc
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        (dfake,) = ctx.saved_tensors
+        if dfake is None:
+            return None, None, None, None, None, None
+        return ops.scale_by_scalar(ops.NHWC(dfake, 3), g.reshape(1).float().contiguous()).t, None, None, None, None, None
+
+
+class ResizeBicubicFn(torch.autograd.Function):
+    """F.interpolate(mode="bicubic", align_corners=False) with its adjoint (the DADA depth decoder's resize when the map's
+    width differs from the target size, depth.py:143-149)."""
+
+    @staticmethod
+    def forward(ctx, x_t, c, size):
+        ctx.cfg = (c, x_t.shape[1], x_t.shape[2], int(size[0]), int(size[1]))
+        return ops.resize_bicubic(ops.NHWC(x_t, c), size).t
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        c, h_in, w_in, h_out, w_out = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((dy.shape[0], h_in, w_in, dy.shape[3]), dtype=dy.dtype, device=dy.device)
+        _lib.check(_lib.load().cgan_resize_bicubic_bwd_nhwc(ops._ptr(dy), ops._ptr(dx), ops._DT[dy.dtype], dy.shape[0], c, h_in,
+                                                            w_in, h_out, w_out, ops._stream()), "cgan_resize_bicubic_bwd_nhwc")
+        return dx, None, None
+
+
 class HingeFn(torch.autograd.Function):
     """weight * sum of HingeLoss.loss's per-element terms (reference losses.py:565-579) -> fp32 device scalar."""
 

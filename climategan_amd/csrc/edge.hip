@@ -260,6 +260,72 @@ __global__ void resize_bicubic_kernel(const uint16_t* __restrict__ x, uint16_t* 
   }
 }
 
+// adjoint of resize_bicubic_kernel in gather form: every INPUT pixel sums w_y w_x dy over the output pixels whose 4 x 4
+// (border-clamped) taps touch it, re-evaluating the forward's index rule (the DADA depth decoder's 384^2 resize under
+// autograd, depth.py:143-149); candidates: output rows whose source position lies within 3 input rows of this one
+template <typename T>
+__global__ void resize_bicubic_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int h_in, int w_in,
+                                          int h_out, int w_out, int cs, float sy, float sx, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int ix = (int)(pix % w_in);
+    const long r = pix / w_in;
+    const int iy = (int)(r % h_in);
+    const long n = r / h_in;
+    int oy0 = (int)floorf((iy - 3 + 0.5f) / sy - 0.5f), oy1 = (int)ceilf((iy + 3 + 0.5f) / sy - 0.5f);
+    int ox0 = (int)floorf((ix - 3 + 0.5f) / sx - 0.5f), ox1 = (int)ceilf((ix + 3 + 0.5f) / sx - 0.5f);
+    // border pixels also receive the clamped taps of every output row / column beyond them
+    if (iy == 0) oy0 = 0;
+    if (iy == h_in - 1) oy1 = h_out - 1;
+    if (ix == 0) ox0 = 0;
+    if (ix == w_in - 1) ox1 = w_out - 1;
+    oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
+    oy1 = oy1 > h_out - 1 ? h_out - 1 : oy1; ox1 = ox1 > w_out - 1 ? w_out - 1 : ox1;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const float fy = (oy + 0.5f) * sy - 0.5f, fly = floorf(fy);
+      float wy[4];
+      cubic_coeffs(fy - fly, wy);
+      float cy = 0.f;
+      for (int i = 0; i < 4; ++i) {
+        int yy = (int)fly - 1 + i;
+        yy = yy < 0 ? 0 : (yy > h_in - 1 ? h_in - 1 : yy);
+        if (yy == iy) cy += wy[i];
+      }
+      if (cy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const float fx = (ox + 0.5f) * sx - 0.5f, flx = floorf(fx);
+        float wx[4];
+        cubic_coeffs(fx - flx, wx);
+        float cx = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          int xx = (int)flx - 1 + j;
+          xx = xx < 0 ? 0 : (xx > w_in - 1 ? w_in - 1 : xx);
+          if (xx == ix) cx += wx[j];
+        }
+        if (cx == 0.f) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dy + ((n * h_out + oy) * (long)w_out + ox) * cs + cg * 8);
+        const float wgt = cy * cx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          unpack2<T>(v[e], a, b);
+          acc[2 * e] += wgt * a;
+          acc[2 * e + 1] += wgt * b;
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(dx + pix * cs + cg * 8) = o;
+  }
+}
+
 // backward of the nearest x2 upsample (InterpolateNearest2d, blocks.py:28-43): y[n][oy][ox] = sum of the 2x2 block of x
 template <typename T>
 __global__ void sumpool2x2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_out, int w_out, int cs,
@@ -530,6 +596,25 @@ extern "C" int cgan_resize_bicubic_nhwc(const void* x, void* y, int32_t dtype, i
     hipLaunchKernelGGL(resize_bicubic_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)x,
                        (uint16_t*)y, h_in, w_in, h_out, w_out, cs, sy, sx, total);
   CGAN_CHECK_LAUNCH("resize_bicubic");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_resize_bicubic_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                            int32_t w_in, int32_t h_out, int32_t w_out, void* stream) {
+  CGAN_REQUIRE(dy && dx, "resize_bicubic_bwd: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "resize_bicubic_bwd: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "resize_bicubic_bwd: bad shape");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h_in * w_in * (cs / 8);
+  const float sy = (float)h_in / (float)h_out, sx = (float)w_in / (float)w_out;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CGAN_F16)
+    hipLaunchKernelGGL(resize_bicubic_bwd_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)dy,
+                       (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, sy, sx, total);
+  else
+    hipLaunchKernelGGL(resize_bicubic_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)dy,
+                       (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, sy, sx, total);
+  CGAN_CHECK_LAUNCH("resize_bicubic_bwd");
   return CGAN_OK;
 }
 

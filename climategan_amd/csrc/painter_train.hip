@@ -75,6 +75,70 @@ __global__ void painter_heads_bwd_kernel(const uint16_t* __restrict__ dd, const 
   }
 }
 
+// The Painter's optional image-space terms (get_painter_loss, climategan/trainer.py:1289-1315; lambdas 0 in defaults.yaml)
+// on the pasted image p = x (1 - m) + fake m, value and gradient w.r.t. ``fake`` in one pass:
+//   TVLoss(p m)               losses.py:142-169   wh sum (q[y+1] - q[y])^2 + ww sum (q[x+1] - q[x])^2,  q = p m
+//   ContextLoss(p, x, m)      losses.py:281-287   w_ctx sum |(p - x)(1 - m)|
+//   ReconstructionLoss(p,x,m) losses.py:290-296   w_rec sum |(p - x) m|
+// (the weights carry lambda and the means' 1 / count).  Gradient in gather form (every pixel adds its own five-point
+// stencil: no atomics): d/dfake = m dL/dp, dL/dp = m dTV/dq + sign((p - x)(1 - m)) (1 - m) w_ctx + sign((p - x) m) m w_rec.
+// loss[0..2] += the three values (tv, context, reconstruction).
+template <typename T>
+__global__ __launch_bounds__(256) void painter_aux_kernel(const uint16_t* __restrict__ fake, const float* __restrict__ x,
+                                                          const float* __restrict__ m, float wh, float ww, float w_ctx,
+                                                          float w_rec, float* __restrict__ loss, uint16_t* __restrict__ dfake,
+                                                          int h, int w, long total) {
+  const long hw = (long)h * w;
+  float a_tv = 0.f, a_ctx = 0.f, a_rec = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    const int py = (int)(p / w), px = (int)(p - (long)py * w);
+    const float mv = m[i];
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* xc = x + (n * 3 + c) * hw;
+      auto q_at = [&](long j) {                       // q = (x (1 - m) + fake m) m at pixel j of this image
+        const float mj = m[n * hw + j];
+        return (xc[j] * (1.f - mj) + f32_of_bits<T>(fake[(n * hw + j) * 8 + c]) * mj) * mj;
+      };
+      const float xv = xc[p], fv = f32_of_bits<T>(fake[i * 8 + c]);
+      const float pv = xv * (1.f - mv) + fv * mv;
+      const float q0 = pv * mv;
+      float dq = 0.f;
+      if (wh != 0.f || ww != 0.f) {
+        if (py + 1 < h) { const float d = q_at(p + w) - q0; a_tv += wh * d * d; dq -= 2.f * wh * d; }
+        if (py > 0) dq += 2.f * wh * (q0 - q_at(p - w));
+        if (px + 1 < w) { const float d = q_at(p + 1) - q0; a_tv += ww * d * d; dq -= 2.f * ww * d; }
+        if (px > 0) dq += 2.f * ww * (q0 - q_at(p - 1));
+      }
+      const float tc = (pv - xv) * (1.f - mv), tr = (pv - xv) * mv;
+      a_ctx += w_ctx * fabsf(tc);
+      a_rec += w_rec * fabsf(tr);
+      const float sc = tc > 0.f ? 1.f : (tc < 0.f ? -1.f : 0.f), sr = tr > 0.f ? 1.f : (tr < 0.f ? -1.f : 0.f);
+      g[c] = mv * (mv * dq + sc * (1.f - mv) * w_ctx + sr * mv * w_rec);
+    }
+    if (dfake) {
+      u32x4 o;
+      o[0] = pack2<T>(g[0], g[1]);
+      o[1] = pack2<T>(g[2], 0.f);
+      o[2] = 0u;
+      o[3] = 0u;
+      reinterpret_cast<u32x4*>(dfake)[i] = o;
+    }
+  }
+  // block sums -> one atomic per block and term (logged loss scalars only: the gradient above has no atomics)
+  __shared__ float part[3][4];
+  float v[3] = {a_tv, a_ctx, a_rec};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(loss + threadIdx.x, part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
+}
+
 // backward of nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False): every input pixel collects dy / count
 // from the (at most 4) windows that contain it
 template <typename T>
@@ -412,6 +476,19 @@ extern "C" int cgan_painter_heads_bwd(const void* d_d_in, const void* d_vgg_in, 
   DISPATCH_PT(dtype, painter_heads_bwd_kernel, dim3(grid_pt(total)), dim3(256), 0, (hipStream_t)stream,
               (const uint16_t*)d_d_in, (const uint16_t*)d_vgg_in, m_nchw, (uint16_t*)d_fake, total);
   CGAN_CHECK_LAUNCH("painter_heads_bwd");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_painter_aux_losses(const void* fake_nhwc, const float* x_nchw, const float* m_nchw, int32_t dtype, int32_t n,
+                                       int32_t h, int32_t w, float w_tv_h, float w_tv_w, float w_context,
+                                       float w_reconstruction, float* loss3, void* d_fake, void* stream) {
+  CGAN_REQUIRE(fake_nhwc && x_nchw && m_nchw && loss3, "painter_aux_losses: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "painter_aux_losses: bad dtype %d", dtype);
+  CGAN_REQUIRE(n > 0 && h > 1 && w > 1, "painter_aux_losses: bad shape");
+  const long total = (long)n * h * w;
+  DISPATCH_PT(dtype, painter_aux_kernel, dim3(grid_pt(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)fake_nhwc,
+              x_nchw, m_nchw, w_tv_h, w_tv_w, w_context, w_reconstruction, loss3, (uint16_t*)d_fake, h, w, total);
+  CGAN_CHECK_LAUNCH("painter_aux_losses");
   return CGAN_OK;
 }
 

@@ -511,6 +511,36 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const uint16_t* __restr
   block_atomic_add(acc * weight, loss);
 }
 
+// nn.MSELoss against a constant target (GANLoss with use_lsgan=True, climategan/losses.py:50-52) over the c logical channels:
+// loss += weight * sum (x - t)^2;  dx = weight * 2 (x - t) (pad channels 0)
+template <typename T>
+__global__ __launch_bounds__(256) void mse_const_kernel(const uint16_t* __restrict__ x, float target, float weight,
+                                                        float* __restrict__ loss, uint16_t* __restrict__ dx, int cs, int c,
+                                                        long groups) {
+  const int cg_total = cs / 8;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a[2], gr[2];
+      unpack2<T>(v[e], a[0], a[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool live = cg * 8 + 2 * e + h < c;
+        const float d = a[h] - target;
+        acc += live ? d * d : 0.f;
+        gr[h] = live ? weight * 2.f * d : 0.f;
+      }
+      r[e] = pack2<T>(gr[0], gr[1]);
+    }
+    if (dx) reinterpret_cast<u32x4*>(dx)[i] = r;
+  }
+  block_atomic_add(acc * weight, loss);
+}
+
 // HingeLoss (climategan/losses.py:550-593) over the c logical channels: discriminator side (hinged)
 // loss += weight * sum max(0, 1 - sgn x)   [= -mean(min(sgn x - 1, 0))],  dx = -sgn weight where 1 - sgn x > 0 (half of it
 // on an exact tie, torch.min's rule); generator side (not hinged) loss += weight * sum(-sgn x), dx = -sgn weight
@@ -784,6 +814,19 @@ extern "C" int cgan_bce_logits_nhwc(const void* x, int32_t dtype, int64_t npix, 
   DISPATCH_T(dtype, bce_logits_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
              target, weight, loss_accum, (uint16_t*)dx, cs, c, groups);
   CGAN_CHECK_LAUNCH("bce_logits");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_mse_const_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float target, float weight,
+                                   float* loss_accum, void* dx, void* stream) {
+  CGAN_REQUIRE(x && loss_accum, "mse_const: null pointer");
+  CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "mse_const: bad dtype %d", dtype);
+  CGAN_REQUIRE(npix > 0 && c > 0, "mse_const: bad shape");
+  const int cs = cgan_cs(c);
+  const long groups = npix * (cs / 8);
+  DISPATCH_T(dtype, mse_const_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+             target, weight, loss_accum, (uint16_t*)dx, cs, c, groups);
+  CGAN_CHECK_LAUNCH("mse_const");
   return CGAN_OK;
 }
 

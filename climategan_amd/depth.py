@@ -61,11 +61,8 @@ class DADADepthDecoder(nn.Module):
                 # the reference passes (ts, ts) to F.interpolate, which rejects a tuple of tuples (depth.py:151-153)
                 raise TypeError("DADADepthDecoder: target size %r is not an int (reference depth.py:151-153 fails "
                                 "the same way after set_target_size)" % (ts,))
-            if depth.t.requires_grad:
-                raise NotImplementedError("DADADepthDecoder: the bicubic / nearest resize to the target size has no HIP "
-                                          "backward; train at a size whose depth map already matches (x.w / 4 == target)")
-            depth = ops.resize_bicubic(depth, (384, 384))          # MiDaS inference size, depth.py:144-149
-            depth = ops.resize_nearest(depth, (ts, ts))            # depth.py:151-153
+            depth = Fn.resize_bicubic(depth, (384, 384))           # MiDaS inference size, depth.py:144-149
+            depth = Fn.resize_nearest(depth, (ts, ts))             # depth.py:151-153 (both with their HIP adjoints)
         return depth, z_depth
 
     def forward(self, z):

@@ -90,3 +90,10 @@ def sigmoid(x: ops.NHWC) -> ops.NHWC:
         from .autograd import SigmoidFn
         return ops.NHWC(SigmoidFn.apply(x.t, x.c), x.c)
     return ops.sigmoid(x)
+
+
+def resize_bicubic(x: ops.NHWC, size) -> ops.NHWC:
+    if _tracked(x):
+        from .autograd import ResizeBicubicFn
+        return ops.NHWC(ResizeBicubicFn.apply(x.t, x.c, tuple(int(s) for s in size)), x.c)
+    return ops.resize_bicubic(x, size)

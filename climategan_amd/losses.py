@@ -39,15 +39,13 @@ def _as_nhwc(t, what):
 
 
 class GANLoss(nn.Module):
-    """reference losses.py:13-83 (BCE-with-logits form, ``use_lsgan=False`` as built by ``get_losses``,
-    losses.py:384-388)."""
+    """reference losses.py:13-83: BCE-with-logits (``use_lsgan=False``, what ``get_losses`` builds, losses.py:384-388) or the
+    LSGAN form (nn.MSELoss, losses.py:50-52)."""
 
     def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, soft_shift=0.0, flip_prob=0.0,
                  verbose=0):
         super().__init__()
-        if use_lsgan:
-            raise NotImplementedError("GANLoss: the LSGAN (MSE) form has no HIP kernel (the reference's get_losses "
-                                      "builds use_lsgan=False, losses.py:384-388)")
+        self.use_lsgan = bool(use_lsgan)          # nn.MSELoss (losses.py:50-52) instead of nn.BCEWithLogitsLoss
         self.soft_shift = soft_shift
         self.verbose = verbose
         self.register_buffer("real_label", torch.tensor(target_real_label))
@@ -63,6 +61,9 @@ class GANLoss(nn.Module):
     def _one(self, pred, target_is_real):
         pred = _as_nhwc(pred, "GANLoss")
         n = pred.n * pred.h * pred.w * pred.c
+        if self.use_lsgan:
+            from .autograd import MseConstFn
+            return MseConstFn.apply(pred.t, pred.c, self.get_target_value(target_is_real), 1.0 / n)
         return BceLogitsFn.apply(pred.t, pred.c, self.get_target_value(target_is_real), 1.0 / n)
 
     def __call__(self, input, target_is_real, *args, **kwargs):

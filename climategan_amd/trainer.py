@@ -147,6 +147,7 @@ class Trainer:
         want_vgg = for_g and self.losses["G"]["p"]["vgg"] is not None
         if for_g:
             fake = self.G.paint_nhwc(m, x)
+            self._last_fake = fake                                     # (the optional image-space terms read it)
         else:
             with torch.no_grad():                                     # trainer.py:1076-1083
                 fake = self.G.paint_nhwc(m, x)
@@ -163,14 +164,20 @@ class Trainer:
         return real_d, fake_d, vgg
 
     def get_painter_loss(self, multi_domain_batch):
-        """reference trainer.py:1256-1387 (single-discriminator branch; TV / context / reconstruction lambdas are 0 in
-        defaults.yaml:293-300 and have no HIP kernel: non-zero values raise)."""
+        """reference trainer.py:1256-1387 (single-discriminator branch; the TV / context / reconstruction terms, lambdas 0
+        in defaults.yaml:293-300, come from one fused kernel on the pasted image, autograd.PainterAuxFn)."""
         lambdas = self.opts.train.lambdas
-        for k in ("tv", "context", "reconstruction"):
-            if lambdas.G.p[k] != 0:
-                raise NotImplementedError("painter loss '%s' has no HIP kernel (lambda must be 0)" % k)
         real_d, fake_d, vgg = self._painter_terms(multi_domain_batch["rf"], True)
         step_loss = 0
+        if any(lambdas.G.p[k] != 0 for k in ("tv", "context", "reconstruction")):      # trainer.py:1289-1315 (0 by default)
+            from .autograd import PainterAuxFn
+            data = multi_domain_batch["rf"]["data"]
+            loss, parts = PainterAuxFn.apply(self._last_fake.t, data["x"], data["m"], float(lambdas.G.p.tv),
+                                             float(lambdas.G.p.context), float(lambdas.G.p.reconstruction))
+            for i, k in enumerate(("tv", "context", "reconstruction")):
+                if lambdas.G.p[k] != 0:
+                    self.loss_log["G.p." + k] = parts[i]
+            step_loss = step_loss + loss
         if vgg is not None:
             loss = self.losses["G"]["p"]["vgg"](vgg[0], vgg[1]) * lambdas.G.p.vgg
             self.loss_log["G.p.vgg"] = loss.detach()

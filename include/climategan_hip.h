@@ -365,6 +365,22 @@ int cgan_bce_logits_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, 
  * be real, else negative rc like the reference's assert): *loss_accum += weight * sum(-x), dx = -weight. dx may be NULL. */
 int cgan_hinge_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, int32_t target_is_real,
                     int32_t for_discriminator, float weight, float* loss_accum, void* dx, void* stream);
+/* nn.MSELoss against a constant target over the c logical channels of x [npix][cgan_cs(c)]: the LSGAN form of GANLoss
+ * (use_lsgan=True, climategan/losses.py:50-52): *loss_accum += weight * sum (x - target)^2, dx = 2 weight (x - target). */
+int cgan_mse_const_nhwc(const void* x, int32_t dtype, int64_t npix, int32_t c, float target, float weight, float* loss_accum,
+                        void* dx, void* stream);
+/* The Painter's optional image-space terms of get_painter_loss (climategan/trainer.py:1289-1315; TVLoss losses.py:142-169,
+ * ContextLoss :281-287, ReconstructionLoss :290-296) on the pasted image p = x (1 - m) + fake m (fake NHWC 3 channels stored
+ * as 8; x [n,3,h,w], m [n,1,h,w] fp32): loss3[0] += w_tv_h sum_y (q[y+1] - q[y])^2 + w_tv_w sum_x (q[x+1] - q[x])^2 with
+ * q = p m; loss3[1] += w_context sum |(p - x)(1 - m)|; loss3[2] += w_reconstruction sum |(p - x) m|; d_fake (may be NULL) =
+ * the gradient of their sum w.r.t. fake (gather form: no atomics).  The weights carry lambda and the means' 1 / count. */
+int cgan_painter_aux_losses(const void* fake_nhwc, const float* x_nchw, const float* m_nchw, int32_t dtype, int32_t n,
+                            int32_t h, int32_t w, float w_tv_h, float w_tv_w, float w_context, float w_reconstruction,
+                            float* loss3, void* d_fake, void* stream);
+/* Adjoint of cgan_resize_bicubic_nhwc (the DADA depth decoder's 384^2 resize under autograd, climategan/depth.py:143-149):
+ * dx [n][h_in][w_in][cgan_cs(c)] from dy [n][h_out][w_out][cgan_cs(c)], gather form. */
+int cgan_resize_bicubic_bwd_nhwc(const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                                 int32_t h_out, int32_t w_out, void* stream);
 /* nn.L1Loss pieces (FeatMatchLoss, climategan/losses.py:86-103): *loss_accum += weight * sum|a - b|,
  * da = weight * sign(a - b); da may be NULL. */
 int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t numel, float weight, float* loss_accum, void* da,

@@ -42,6 +42,11 @@ def golden_cases():
         "mstep_spade": dict(kind="mstep", H=128, W=160, B=2, seed=67, gain=1.6, sub=512, use_spade=True),
         "dstep_p": dict(kind="dstep_p", ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=81),
         "gstep_p": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=91),
+        # the non-default branches of get_painter_loss (trainer.py:1289-1315: TV / context / reconstruction, lambdas 0 in
+        # defaults.yaml:293-300) and the LSGAN form of GANLoss (losses.py:50-52), on a SOFT mask (0.1 / 0.9: with a binary
+        # mask the context term (p - x)(1 - m) = m (1 - m)(fake - x) vanishes identically)
+        "gstep_p_aux": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=92,
+                            aux=dict(tv=2.0, context=3.0, reconstruction=5.0, lsgan=True, soft_mask=True)),
         # VGG term of get_painter_loss through the reference's own Vgg19 / VGGLoss / vgg_preprocess; VGG-19 weights from
         # the portable fill with a He-preserving bound (gain sqrt(6): activations keep the input's 0-255 scale)
         "vgg_small": dict(kind="vgg", H=64, W=96, B=2, seed=85, gain=2.449489742783178, lambda_vgg=10.0),
@@ -100,8 +105,10 @@ def case_inputs(name, case):
                     depth_pred=fill.uniform((B, 1, h, w), s * 100 + 8, -1.0, 2.0),
                     depth_target=fill.uniform((B, 1, h, w), s * 100 + 9, 0.35, 6.95))
     if k == "gstep_p":
-        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1),
-                    m=fill.rect_mask(B, case["H"], case["W"], s * 100 + 3))
+        m = fill.rect_mask(B, case["H"], case["W"], s * 100 + 3)
+        if case.get("aux", {}).get("soft_mask"):
+            m = (0.1 + 0.8 * m).astype(np.float32)
+        return dict(x=fill.uniform((B, 3, case["H"], case["W"]), s * 100 + 1), m=m)
     if k == "fire":
         H, W = case["H"], case["W"]
         seg = fill.uniform((B, 11, H // 4, W // 4), s * 100 + 2, -1, 1)
@@ -541,7 +548,8 @@ def run_reference_gstep(name, case):
     inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
     x, m = inp["x"], inp["m"]
     painter.set_latent_shape(tuple(x.shape), True)
-    gan, fm = losses.GANLoss(use_lsgan=False), losses.FeatMatchLoss()
+    aux = case.get("aux", {})
+    gan, fm = losses.GANLoss(use_lsgan=bool(aux.get("lsgan"))), losses.FeatMatchLoss()
     fake_flooded = G.paint(m, x)
     real_cat = torch.cat([m, x], axis=1)
     fake_cat = torch.cat([m, fake_flooded], axis=1)
@@ -550,9 +558,16 @@ def run_reference_gstep(name, case):
     l_gan = gan(fake_d, True, False)
     l_fm = fm(real_d, fake_d) * 10
     loss = l_gan + l_fm
+    extra = {}
+    if aux:                                                    # the reference's own classes, get_painter_loss's expressions
+        extra["tv"] = losses.TVLoss()(fake_flooded * m) * aux["tv"]                              # trainer.py:1289-1293
+        extra["context"] = losses.ContextLoss()(fake_flooded, x, m) * aux["context"]             # :1298-1302
+        extra["reconstruction"] = losses.ReconstructionLoss()(fake_flooded, x, m) * aux["reconstruction"]   # :1307-1311
+        loss = loss + sum(extra.values())
     loss.backward()
     out = {"loss": loss.detach().numpy().reshape(1), "gan": l_gan.detach().numpy().reshape(1),
            "featmatch": l_fm.detach().numpy().reshape(1), "fake": fake_flooded.detach().numpy()}
+    out.update({k2: v.detach().numpy().reshape(1) for k2, v in extra.items()})
     for key, p in painter.named_parameters():
         if p.requires_grad:
             out["grad." + key] = p.grad.numpy().copy()

@@ -858,3 +858,29 @@ def _bn_stats_from_epilogue(case, shifted):
         assert (u[:, :cout] - v[:, :cout]).abs().max().item() <= 1e-4 * max(v[:, :cout].abs().max().item(), 1.0)
     assert int(nbt_a) == int(nbt_b) == G
     assert (rm_a - rm_b).abs().max().item() <= 1e-4 * max(spread, 1.0) + 1e-6 and (rv_a / rv_b - 1).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("sizes", [((40, 40), (96, 96), 40), ((40, 52), (384, 384), 30), ((24, 24), (17, 31), 24)])
+def test_depth_decoder_resize_backward(dt, sizes):
+    """The DADA depth decoder's resize when the map's width differs from the target (depth.py:143-153): bicubic to the MiDaS
+    size then nearest to the target, under autograd -- Fn.resize_bicubic / Fn.resize_nearest against torch's own
+    F.interpolate pair (value and gradient)."""
+    import torch.nn.functional as F
+    from climategan_amd import functional as Fn, ops
+
+    (h, w), mid, ts = sizes
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(2, 1, h, w, device="cuda", generator=g).to(dt).float().requires_grad_(True)
+    up = torch.randn(2, 1, ts, ts, device="cuda", generator=g).to(dt).float()
+    ref = F.interpolate(F.interpolate(x, size=mid, mode="bicubic", align_corners=False), size=(ts, ts), mode="nearest")
+    ref.backward(up)
+    xh = ops.NHWC(ops.nchw_to_nhwc(x.detach(), dt).t.requires_grad_(True), 1)
+    y = Fn.resize_nearest(Fn.resize_bicubic(xh, mid), (ts, ts))
+    got = ops.nhwc_to_nchw(ops.NHWC(y.t.detach(), 1))
+    tol = 8e-3 if dt == torch.bfloat16 else 1e-3
+    assert (got - ref.detach()).abs().max().item() <= 2 * tol * ref.detach().abs().max().item()      # two 16-bit stores
+    y.t.backward(ops.nchw_to_nhwc(up, dt).t)
+    dx = ops.nhwc_to_nchw(ops.NHWC(xh.t.grad, 1))
+    assert (dx - x.grad).abs().max().item() <= 2 * tol * x.grad.abs().max().item()
+    assert bool((xh.t.grad[..., 1:] == 0).all())

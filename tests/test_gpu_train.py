@@ -196,6 +196,53 @@ def test_painter_g_step_matches_reference():
     assert checked == sum(1 for k in gold if k.startswith("grad."))
 
 
+def test_painter_g_step_optional_terms_and_lsgan_match_reference():
+    """The non-default branches of get_painter_loss (trainer.py:1289-1315): TVLoss(fake_flooded * m), ContextLoss,
+    ReconstructionLoss with non-zero lambdas, and the LSGAN form of GANLoss (losses.py:50-52), against the reference's own
+    classes on a soft mask (golden ``gstep_p_aux``): every term's value, and the gradient of every trainable Painter tensor
+    (the fused image-space kernel's gradient joins the heads' gradient in front of the Painter)."""
+    from climategan_amd.losses import GANLoss
+
+    name = "gstep_p_aux"
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    T = build_trainer(case, torch.float16)
+    lam = T.opts.train.lambdas.G.p
+    lam.tv, lam.context, lam.reconstruction = case["aux"]["tv"], case["aux"]["context"], case["aux"]["reconstruction"]
+    T.losses["G"]["p"]["gan"] = GANLoss(use_lsgan=True, soft_shift=0.0, flip_prob=0.0)
+    inp = {k: t(v).cuda() for k, v in case_inputs(name, case).items()}
+    batch = {"rf": {"data": {"x": inp["x"], "m": inp["m"]}}}
+    for p in T.D.parameters():
+        p.requires_grad_(False)
+    loss = T.get_painter_loss(batch)
+    loss.backward()
+    for key, log, tol in (("gan", "G.p.gan", 5e-3), ("featmatch", "G.p.featmatch", 1e-2), ("tv", "G.p.tv", 1e-2),
+                          ("context", "G.p.context", 5e-3), ("reconstruction", "G.p.reconstruction", 5e-3)):
+        ref, got = float(gold[key][0]), T.loss_log[log].item()
+        assert abs(got - ref) <= tol * abs(ref), (key, got, ref)
+    assert abs(loss.item() - float(gold["loss"][0])) <= 1e-2 * float(gold["loss"][0])
+    bad, checked = [], 0
+    for key, p in T.G.painter.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = gold["grad." + key].astype(np.float64)
+        got = p.grad.cpu().numpy().astype(np.float64)
+        base = key.rsplit(".", 1)[0]
+        wkey = "grad." + base + (".weight_bar" if "grad." + base + ".weight_bar" in gold else ".weight")
+        wscale = np.abs(gold[wkey]).max()
+        if key.endswith("bias") and np.abs(ref).max() < 1e-4 * wscale:
+            if np.abs(got).max() > 1e-2 * wscale:
+                bad.append((key, "zero-bias", np.abs(got).max() / wscale))
+        else:
+            l2 = np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum())
+            cos = (got * ref).sum() / np.sqrt((got ** 2).sum() * (ref ** 2).sum())
+            if not (l2 <= 0.15 and cos >= 0.99):
+                bad.append((key, l2, cos))
+        checked += 1
+    assert not bad, bad
+    assert checked == sum(1 for k in gold if k.startswith("grad."))
+
+
 def test_painter_train_steps_run_and_learn():
     """Trainer.train_step (G update, D update, ExtraAdam extrapolate / step) incl. the VGG term with its random-init
     feature extractor: finite losses, parameters move, spectral-norm vectors advance, D flags restored."""
