@@ -798,6 +798,11 @@ def main():
                  % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hook (tests/test_gpu_bench_two_ranks.py): every rank on device 0 over gloo -- RCCL refuses two ranks on one
+    # device, and a one-GPU box is all the tests have; the driver's runs never set these
+    backend = os.environ.get("CGAN_BENCH_BACKEND", "nccl")
+    if os.environ.get("CGAN_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -805,7 +810,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
 
     def barrier():

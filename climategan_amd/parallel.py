@@ -84,6 +84,8 @@ class GradBucketReducer:
             on_rccl = self.active and dist.get_backend() == "nccl"
             grad_dtype = torch.bfloat16 if (on_rccl and os.environ.get("CGAN_DDP_BF16_GRADS") == "1") else torch.float32
         self.grad_dtype = grad_dtype
+        if os.environ.get("CGAN_DDP_BUCKET_MB"):          # (bucket-size experiments and the stream-ordering tests)
+            bucket_mb = float(os.environ["CGAN_DDP_BUCKET_MB"])
         cap = int(bucket_mb * 2 ** 20)
         self.buckets: List[_Bucket] = []
         cur, cur_bytes = [], 0

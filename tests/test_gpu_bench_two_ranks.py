@@ -1,0 +1,40 @@
+"""``bench.py --gpus 2`` exactly as the driver launches it (``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+--master-addr 127.0.0.1 ...``), on ONE GPU: both ranks on device 0 over gloo (test hooks CGAN_BENCH_ONE_DEVICE /
+CGAN_BENCH_BACKEND; RCCL refuses two ranks per device).  Everything else is the N > 1 path of the bench: rendezvous from the
+environment, replicas broadcast in ``Trainer.setup``, per-rank shards, the bucketed reducer inside the timed train steps,
+barrier + synchronize on both sides, max over ranks, rank 0's single JSON line with the whole-job value."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_bench_gpus_2_code_path_on_one_device():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CGAN_BENCH_ONE_DEVICE="1", CGAN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    steps, warmup = 3, 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--sub-steps", "0"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line (rank 0): %r" % lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == steps and r["warmup"] == warmup and r["scaling"] == "weak"
+    assert r["config"]["rccl_ranks"] == 2 and r["config"]["backend"] == "gloo" and r["config"]["grad_wire_dtype"] == "float32"
+    assert r["config"]["global_batch"] == 8 and r["config"]["batch_per_domain_per_gpu"] == 4
+    assert "dp2" in r["config"]["parallelism"]
+    # whole-job value = N x 4 per-domain slots x steps / max-over-ranks time
+    assert abs(r["value"] - 2 * 4 / (r["ms_per_step"] * 1e-3)) <= 1e-2 * r["value"]
+    assert r["roofline"] is not None and 0.05 < r["roofline"]["frac"] < 1.0          # rank 0's launch brackets still there
+    assert r["cpu_baseline"] is None and all(v == v for v in r["losses_last_step"].values())

@@ -118,8 +118,15 @@ def _worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def test_two_ranks_on_one_gpu_train_in_lock_step():
+@pytest.mark.parametrize("env", [{}, {"CGAN_DDP_BUCKET_MB": "3", "CGAN_OVERLAP": "1"}, {"CGAN_OVERLAP": "0"}],
+                         ids=["default", "3MB-buckets-two-streams", "one-stream"])
+def test_two_ranks_on_one_gpu_train_in_lock_step(env, monkeypatch):
+    """``env``: the default configuration (25 MB buckets, two-stream overlap), many small buckets with the overlap on (140
+    exchanges per G update launched from hooks on both branches' streams: shakes out stream-ordering mistakes between the
+    gather, the collective and the optimizer before the first real 8-rank run), and the one-stream schedule."""
     import torch.multiprocessing as mp
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
