@@ -893,7 +893,7 @@ def main():
                             "cgan_conv2d_nhwc_fwd_stats", "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd")
             with open(args.call_log, "w") as f:
                 for _e0, _e1, _fl, nb, tg in all_timer.pairs[n0:]:
-                    f.write("mfma:%s\t%d\n" % (tg.split()[0], nb))
+                    f.write("mfma:%s\t%d\t%s\t%.1f\n" % (tg.split()[0], nb, " ".join(tg.split()), _e0.elapsed_time(_e1) * 1e3))
                 for entry, nb in log:
                     if entry not in mfma_entries:
                         f.write("%s\t%d\n" % (entry, nb))

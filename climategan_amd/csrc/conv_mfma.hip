@@ -144,12 +144,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   // operand fetch of one k-step (A: packed weights [ctile][ks][lane] x 16 B; B: 8 channels of the tap-shifted
   // input pixel), then advance this lane's K group by 4
   auto fetch = [&](int ks, u32x4 (&a)[CT], u32x4 (&b)[PT]) {
+    // (k-steps past the end -- the pipelined loop runs to a multiple of its depth -- fetch NOTHING new: the weight address is
+    // clamped and kvalid masks the activation loads, so the extra MFMAs multiply by zero activations)
     const bool kvalid = (ks * 4 + g) < kgroups;
+    const int ksc = ks < ksteps ? ks : ksteps - 1;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       int ct = ctile0 + c;
       a[c] = (u32x4){0u, 0u, 0u, 0u};
-      if (ct < p.ctiles) a[c] = wbase[((size_t)ct * ksteps + ks) * 64 + lane];
+      if (ct < p.ctiles) a[c] = wbase[((size_t)ct * ksteps + ksc) * 64 + lane];
     }
     const int dy = ky * p.dil, dx = kx * p.dil;
 #pragma unroll
@@ -191,19 +194,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   };
 
   if (PIPE) {
-    // software pipeline: the loads of k-step ks+1 are in flight while the MFMAs of k-step ks execute (operands
-    // come from L1/L2: ~500+ cycles, which a small grid cannot hide by occupancy alone; on large grids the extra
-    // registers cost more occupancy than the pipelining buys, so those use the plain loop)
-    u32x4 a0[CT], b0[PT], a1[CT], b1[PT];
-    if (ksteps > 0) fetch(0, a0, b0);
-    int ks = 0;
-    for (; ks + 2 <= ksteps; ks += 2) {
-      fetch(ks + 1, a1, b1);
-      mma(a0, b0);
-      if (ks + 2 < ksteps) fetch(ks + 2, a0, b0);
-      mma(a1, b1);
+    // software pipeline, 4 k-steps deep: the loads of k-steps ks+1 .. ks+3 are in flight while the MFMAs of k-step ks
+    // execute.  Operands come from L1/L2 (~1 us under load), and a small grid -- few output pixels, long K: the
+    // discriminators' 512 -> 512 4x4 layers at 19^2 / 9^2, the Painter's 640-channel blocks at 5^2 - 20^2 -- has nothing
+    // else to hide that latency with: with ONE k-step in flight (rounds 1-3) such a layer spent ~0.8 us per k-step, 100-200
+    // us for 2-10 us of work.  fetch() advances the lane's (tap, channel group) state, so it is called once per k-step, in
+    // order; the slots are compile-time indices after unrolling (registers: 3 (CT + PT) x 4 more than the plain loop, on
+    // grids that cannot fill the chip anyway).
+    constexpr int D = 4;
+    u32x4 ra[D][CT], rb[D][PT];
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) fetch(i, ra[i], rb[i]);
+    // branch-free body (a fetch under a run-time condition makes the compiler wait for ALL outstanding loads at the join)
+    for (int ks = 0; ks < ksteps; ks += D) {
+#pragma unroll
+      for (int jj = 0; jj < D; ++jj) {
+        fetch(ks + jj + D - 1, ra[(jj + D - 1) % D], rb[(jj + D - 1) % D]);
+        mma(ra[jj], rb[jj]);
+      }
     }
-    if (ks < ksteps) mma(a0, b0);
   } else {
     for (int ks = 0; ks < ksteps; ++ks) {
       u32x4 a[CT], b[PT];

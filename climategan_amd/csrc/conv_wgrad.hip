@@ -795,11 +795,13 @@ CGAN_KNOB(int, g_wgrad_coop_min_pix, 32768);
 CGAN_KNOB(int, g_wgrad_coop_chunk, 0);
 CGAN_KNOB(int, g_wgrad_slots, 512);
 CGAN_KNOB(int, g_wgrad_tile, 1);
+CGAN_KNOB(int, g_wgrad_ws_cost_pct, 100);   // dev: the planner's cost of a partial tile through the workspace, in % of the fitted value
 CGAN_KNOB(unsigned long long*, g_wgrad_ts, nullptr);
 }  // namespace
 
 #ifdef CGAN_DEV
 extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
+extern "C" void cgan_debug_set_wgrad_ws_cost(int pct) { g_wgrad_ws_cost_pct = pct > 0 ? pct : 100; }
 extern "C" void cgan_debug_set_wgrad_tile3x3(int v) { g_wgrad_tile = v; }   // 0: never the spatially tiled 3 x 3 kernel, 2: wherever it applies
 extern "C" void cgan_debug_set_wgrad_slots(int v) { g_wgrad_slots = v > 0 ? v : 512; }   // resident workgroups the planner assumes
 extern "C" void cgan_debug_set_wgrad_coop_chunk(int v) { g_wgrad_coop_chunk = (v == 32 || v == 64) ? v : 0; }   // 0: automatic
@@ -877,7 +879,7 @@ static WgradPlan wgrad_plan(const CganConvDesc* d, bool have_ws = true) {
     } else if (g_wgrad_target < 0) {
       sp_best = -g_wgrad_target;
     } else {
-      const double t_ws = pl.coop ? 0.024 : 0.008;
+      const double t_ws = (pl.coop ? 0.024 : 0.008) * (g_wgrad_ws_cost_pct / 100.0);
       double best = 1e30;
       for (int m = 0; m <= 8; ++m) {
         long sp = m == 0 ? 1 : (slots * m) / tiles;

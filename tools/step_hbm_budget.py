@@ -112,7 +112,7 @@ def main():
     alg_calls = collections.defaultdict(int)
     if calllog:
         for line in open(calllog):
-            entry, nb = line.rstrip("\n").split("\t")
+            entry, nb = line.rstrip("\n").split("\t")[:2]
             alg[call_family(entry)] += float(nb)
             alg_calls[call_family(entry)] += 1
     out = Path(__file__).resolve().parent.parent / "profiles" / outname
