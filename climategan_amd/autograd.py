@@ -320,10 +320,9 @@ class SpadeFn(torch.autograd.Function):
         dw_gb = db_gb = dw_sh = db_sh = None
         if want_gb:
             dw_gb, db_gb = ops.conv2d_bwd_weight(actv, dgb, tuple(w_gb.shape), pad=1)
-        d_actv = ops.conv2d_bwd_data(dgb, w_gb, (actv.n, h, w), pad=1)
-        del dgb
-        d_pre = ops.act_bwd(actv, d_actv, ops.ACT_RELU)
-        del d_actv, actv
+        # (the ReLU derivative of mlp_shared rides in the data-gradient kernel's epilogue: no pass over the 128-channel map)
+        d_pre = ops.conv2d_bwd_data(dgb, w_gb, (actv.n, h, w), pad=1, relu_out=actv)
+        del dgb, actv
         if want_sh:
             dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
         dcond_t = None

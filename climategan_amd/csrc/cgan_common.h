@@ -30,6 +30,14 @@ void cgan_set_error(const char* fmt, ...);
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
+// the conv epilogues' "residual" slot
+// ------------------------------------------------------------------------------------------------
+// has_res = 1: v += r (residual add; the second gradient contribution of a data-gradient conv).  has_res = 2: v = r > 0 ? v : 0
+// -- the ReLU derivative taken from the activation's OUTPUT r, for a data-gradient conv whose result is the gradient of a
+// ReLU's output (cgan_conv2d_nhwc_bwd_data_relu): the separate act_bwd pass (two reads + one write of the map) disappears.
+__device__ __forceinline__ float cgan_res_apply(float v, float r, int mode) { return mode == 2 ? (r > 0.f ? v : 0.f) : v + r; }
+
+// ------------------------------------------------------------------------------------------------
 // development knobs
 // ------------------------------------------------------------------------------------------------
 // Kernel-selection / ablation / in-kernel-timestamp knobs (cgan_debug_set_*) exist only in the CGAN_DEV build

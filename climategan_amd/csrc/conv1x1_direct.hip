@@ -156,8 +156,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
           for (int e = 0; e < 4; ++e) {
             float r0, r1;
             unpack2<T>(rv[e], r0, r1);
-            v[2 * e] += r0;
-            v[2 * e + 1] += r1;
+            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
+            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
           }
         }
         act_apply_n(v, p.act, p.slope);

@@ -77,7 +77,8 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
           float r0, r1, r2, r3;
           unpack2<T>(rv[0], r0, r1);
           unpack2<T>(rv[1], r2, r3);
-          v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+          v[0] = cgan_res_apply(v[0], r0, p.has_res); v[1] = cgan_res_apply(v[1], r1, p.has_res);
+          v[2] = cgan_res_apply(v[2], r2, p.has_res); v[3] = cgan_res_apply(v[3], r3, p.has_res);
         }
         act_apply_n(v, p.act, p.slope);
         if (pad_c) {

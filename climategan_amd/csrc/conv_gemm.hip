@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
           for (int e = 0; e < 4; ++e) {
             float r0, r1;
             unpack2<T>(rv[e], r0, r1);
-            v[2 * e] += r0;
-            v[2 * e + 1] += r1;
+            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
+            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
           }
         }
         act_apply_n(v, p.act, p.slope);
@@ -572,9 +572,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_k64_kernel(ConvGemmArgs p, i
           const uint2 rv = *reinterpret_cast<const uint2*>(p.res + rbase + ch);
           float r0, r1;
           unpack2<T>(rv.x, r0, r1);
-          v[0] += r0; v[1] += r1;
+          v[0] = cgan_res_apply(v[0], r0, p.has_res); v[1] = cgan_res_apply(v[1], r1, p.has_res);
           unpack2<T>(rv.y, r0, r1);
-          v[2] += r0; v[3] += r1;
+          v[2] = cgan_res_apply(v[2], r0, p.has_res); v[3] = cgan_res_apply(v[3], r1, p.has_res);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
           for (int e = 0; e < 4; ++e) {
             float r0, r1;
             unpack2<T>(rv[e], r0, r1);
-            v[2 * e] += r0;
-            v[2 * e + 1] += r1;
+            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
+            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
           }
         }
         act_apply_n(v, p.act, p.slope);

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         float r0, r1, r2, r3;
         unpack2<T>(rv[0], r0, r1);
         unpack2<T>(rv[1], r2, r3);
-        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+        v[0] = cgan_res_apply(v[0], r0, p.has_res); v[1] = cgan_res_apply(v[1], r1, p.has_res);
+        v[2] = cgan_res_apply(v[2], r2, p.has_res); v[3] = cgan_res_apply(v[3], r3, p.has_res);
       }
       act_apply_n(v, p.act, p.slope);
       if (pad_c) {
@@ -880,7 +881,7 @@ extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) 
 }
 
 static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx, const CganConvDesc* fwd,
-                         void* stream) {
+                         void* stream, int res_mode = 1) {
   ConvParams p;
   CganConvDesc t;
   int rc = dgrad_params(p, fwd, &t);
@@ -893,7 +894,7 @@ static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void*
   CGAN_REQUIRE(dx_add == nullptr || plain, "conv2d_nhwc_bwd_data_add: only for stride-1 'same' convolutions");
   if (dx_add) {             // the other gradient contribution of the same tensor rides in the epilogue's residual slot
     p.res = (const uint16_t*)dx_add;
-    p.has_res = 1;
+    p.has_res = res_mode;         // 1: add the other contribution; 2: the ReLU derivative from the activation's output
     p.res_ups = 0;
     t.has_residual = 1;
   }
@@ -910,6 +911,12 @@ static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void*
 extern "C" int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* dx, const CganConvDesc* fwd,
                                          void* stream) {
   return bwd_data_impl(dy, packed_w_dgrad, nullptr, dx, fwd, stream);
+}
+
+extern "C" int cgan_conv2d_nhwc_bwd_data_relu(const void* dy, const void* packed_w_dgrad, const void* relu_out, void* dx,
+                                              const CganConvDesc* fwd, void* stream) {
+  CGAN_REQUIRE(relu_out != nullptr, "conv2d_nhwc_bwd_data_relu: null pointer");
+  return bwd_data_impl(dy, packed_w_dgrad, relu_out, dx, fwd, stream, 2);
 }
 
 extern "C" int cgan_conv2d_nhwc_bwd_data_add(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx,

@@ -945,11 +945,19 @@ def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
 
 def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilation=1,
                     sigma: Optional[torch.Tensor] = None, pad_mode=PAD_ZERO, add: Optional[NHWC] = None,
-                    prepacked: Optional[DgradPack] = None) -> NHWC:
+                    prepacked: Optional[DgradPack] = None, relu_out: Optional[NHWC] = None) -> NHWC:
     """dx of y = conv(x, w / sigma): ``w`` fp32 OIHW, ``x_shape`` = (n, h_in, w_in) of the forward input.  Reflect
     padding: data gradient of the pad-0 conv over the padded extent, folded back by the reflection's adjoint.
     ``add``: another gradient contribution of the same input tensor, summed in the kernel's epilogue (stride-1 'same'
     convolutions with zero padding; otherwise by a separate pass)."""
+    if relu_out is not None:
+        # ``relu_out``: the forward INPUT map, itself the output of a ReLU -- the kernel's epilogue applies that ReLU's
+        # derivative (dx * [relu_out > 0]); where the fused form does not apply, the separate pass does
+        if add is not None:
+            raise RuntimeError("conv2d_bwd_data: add and relu_out cannot be combined")
+        if not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1) and w.shape[2] == w.shape[3]):
+            dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode, prepacked=prepacked)
+            return act_bwd(relu_out, dx, ACT_RELU)
     per_sample = max(dy.t.nbytes // max(dy.n, 1), (x_shape[1] + 2 * pad) * (x_shape[2] + 2 * pad) * cs8(w.shape[1]) * 2)
     if x_shape[0] * per_sample >= MAX_MAP_BYTES:                 # see _batch_chunked
         k = (MAX_MAP_BYTES - 1) // per_sample
@@ -957,7 +965,8 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
             raise RuntimeError("conv2d_bwd_data: ONE sample's map exceeds the 2 GiB a C-ABI call covers")
         return _cat_results([conv2d_bwd_data(NHWC(dy.t[lo:lo + k], dy.c), w, (min(k, x_shape[0] - lo), x_shape[1], x_shape[2]),
                                              stride, pad, dilation, sigma, pad_mode,
-                                             NHWC(add.t[lo:lo + k], add.c) if add is not None else None, prepacked)
+                                             NHWC(add.t[lo:lo + k], add.c) if add is not None else None, prepacked,
+                                             NHWC(relu_out.t[lo:lo + k], relu_out.c) if relu_out is not None else None)
                              for lo in range(0, x_shape[0], k)])
     if add is not None and not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1)
                                 and w.shape[2] == w.shape[3]):
@@ -988,6 +997,12 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
         _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
                    "cgan_conv2d_pack_weight_dgrad")
     dx = torch.empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
+    if relu_out is not None:
+        if relu_out.t.shape != dx.shape or relu_out.t.dtype != dx.dtype or not relu_out.t.is_contiguous():
+            raise RuntimeError("conv2d_bwd_data: ``relu_out`` %s does not match dx %s" % (tuple(relu_out.t.shape), tuple(dx.shape)))
+        _lib.check(lib.cgan_conv2d_nhwc_bwd_data_relu(_ptr(dy.t), _ptr(packed), _ptr(relu_out.t), _ptr(dx), C.byref(d), _stream()),
+                   "cgan_conv2d_nhwc_bwd_data_relu")
+        return NHWC(dx, c_in)
     if add is not None:
         if add.t.shape != dx.shape or add.t.dtype != dx.dtype or not add.t.is_contiguous():
             raise RuntimeError("conv2d_bwd_data: ``add`` %s does not match dx %s" % (tuple(add.t.shape), tuple(dx.shape)))

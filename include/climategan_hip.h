@@ -141,6 +141,12 @@ int cgan_conv2d_nhwc_bwd_data(const void* dy, const void* packed_w_dgrad, void* 
  * conv kernel's epilogue instead of by a separate element-wise pass (autograd's gradient accumulation). */
 int cgan_conv2d_nhwc_bwd_data_add(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx,
                                   const CganConvDesc* fwd, void* stream);
+/* dx = conv_transpose(dy, w) * [relu_out > 0]: the data gradient of a conv whose INPUT was the output of a ReLU (``relu_out``,
+ * the forward input map itself, [n][h_in][w_in][cgan_cs(c_in)]), with that ReLU's derivative applied in the kernel's epilogue
+ * -- the gradient w.r.t. the ReLU's input, without the separate activation-backward pass over the map (SPADE's mlp_shared
+ * ReLU, norms.py:163-166; the VGG-19 ReLUs, losses.py:304-334).  Stride-1 'same' convolutions, like _bwd_data_add. */
+int cgan_conv2d_nhwc_bwd_data_relu(const void* dy, const void* packed_w_dgrad, const void* relu_out, void* dx,
+                                   const CganConvDesc* fwd, void* stream);
 size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* fwd);
 int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias, const CganConvDesc* fwd,
                                 void* workspace, size_t workspace_bytes,

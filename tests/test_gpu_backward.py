@@ -653,6 +653,35 @@ def test_dgrad_with_added_gradient(dt, case):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(256, 64, 1, 0, 1, 1, 2, 24, 40), (128, 96, 3, 2, 2, 1, 1, 33, 21),
+                                  (40, 24, 3, 1, 1, 1, 2, 16, 16), (128, 256, 3, 1, 1, 1, 2, 40, 40),
+                                  (64, 64, 3, 1, 1, 1, 1, 48, 32), (128, 64, 3, 1, 1, 2, 1, 20, 20)])
+def test_dgrad_with_relu_derivative(dt, case):
+    """cgan_conv2d_nhwc_bwd_data_relu (ops.conv2d_bwd_data(relu_out=...)): dx = data gradient * [relu_out > 0], the mask
+    applied in the conv kernel's epilogue -- every kernel family.  The mask either keeps or zeroes the fp32 value before the
+    one 16-bit rounding, so the result is BIT-IDENTICAL to the two-pass form (gradient rounded, then masked).  The last case
+    (stride 2) is not a 'same' convolution: the wrapper falls back to the two passes."""
+    from climategan_amd import ops
+
+    cin, cout, k, pad, dil, stride, B, H, W = case
+    rng = np.random.RandomState(6)
+    w = torch.from_numpy(rng.randn(cout, cin, k, k).astype(np.float32) * 0.05).cuda()
+    ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    dy = to_nhwc(torch.from_numpy(rng.randn(B, cout, ho, wo).astype(np.float32)), dt)
+    x = to_nhwc(torch.relu(torch.from_numpy(rng.randn(B, cin, H, W).astype(np.float32))), dt)
+    dx = ops.conv2d_bwd_data(dy, w, (B, H, W), stride=stride, pad=pad, dilation=dil, relu_out=x)
+    two_pass = ops.act_bwd(x, ops.conv2d_bwd_data(dy, w, (B, H, W), stride=stride, pad=pad, dilation=dil), ops.ACT_RELU)
+    assert torch.equal(dx.t, two_pass.t)
+    assert 0.2 < (dx.t[..., :cin] == 0).float().mean().item() < 0.8       # the mask did something, and not everything
+    ref = F.conv_transpose2d(back(dy).float(), q(w.cpu().numpy(), dt), stride=stride, padding=pad, dilation=dil,
+                             output_padding=(H + 2 * pad - dil * (k - 1) - 1) % stride) * (back(x).float() > 0)
+    assert rel_err(back(dx).float(), ref) <= TOL[dt]
+    with pytest.raises(RuntimeError):
+        ops.conv2d_bwd_data(dy, w, (B, H, W), stride=stride, pad=pad, dilation=dil, relu_out=x, add=x)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_conv_pass_fn_matches_autograd_on_a_residual_block(dt):
     """autograd.ConvPassFn: y = act(bn(conv1(x))) ... + x with x handed through conv1's node.  Gradients of x, the conv
     weight and the tail must equal those of the plain graph (two consumers of x, autograd's own accumulation) up to the
