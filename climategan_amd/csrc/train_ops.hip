@@ -114,22 +114,47 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const uint16_t* __re
 // butterfly over the lanes
 __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums,
                                                               int n_total, int cs, int chunks) {
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (idx >= n_total * cs) return;
-  const int n = idx / cs, c = idx - n * cs;
+  // block = 8 channels x 32 chunk lanes of one sample (see instnorm_finalize_kernel, norm_stats.hip): 64-byte row segments,
+  // 8 loads in flight, fixed-order tree
+  __shared__ float red[4][8][2];
+  const int cl = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cblocks = cs >> 3;
+  const int n = blockIdx.x / cblocks, c = (blockIdx.x % cblocks) * 8 + cl;
+  const float* rows = partial + ((size_t)n * chunks * cs + c) * 2;
   float a = 0.f, b = 0.f;
-  for (int k = lane; k < chunks; k += 64) {
-    const float2 v = *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * cs + c) * 2);
-    a += v.x;
-    b += v.y;
+  for (int k0 = kl; k0 < chunks; k0 += 256) {
+    float2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 32 * j;
+      v[j] = k < chunks ? *reinterpret_cast<const float2*>(rows + (size_t)k * cs * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a += v[j].x;
+      b += v[j].y;
+    }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off, 64);
-    b += __shfl_xor(b, off, 64);
+  for (int off = 32; off >= 8; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
   }
-  if (lane == 0) *reinterpret_cast<float2*>(sums + (size_t)idx * 2) = make_float2(a, b);
+  if (lane < 8) {
+    red[wave][cl][0] = a;
+    red[wave][cl][1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    a = b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][cl][0];
+      b += red[w][cl][1];
+    }
+    *reinterpret_cast<float2*>(sums + ((size_t)n * cs + c) * 2) = make_float2(a, b);
+  }
 }
 
 template <typename T>
@@ -355,42 +380,54 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 // Stage 2: totals over the chunks, dgamma = sum dz xh, dbeta = sum dz (written, not accumulated), and the three per-channel
 // coefficients of
 //   dx = rstd gamma (dz - mean(dz) - xh mean(dz xh))  =  A dz + B x + C
-// block = 16 channels x 16 chunk lanes
+// block = 8 channels x 32 chunk lanes (a partial row's 8 pairs for the block = one 64-byte segment); a thread keeps 8 row
+// loads in flight and adds them in row order; chunk lanes are summed by a 3-step shuffle tree and a 4-entry LDS row, every
+// group's rows are read before the one barrier -- all in a fixed order
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, float inv_count,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int c, int cs, int groups) {
-  __shared__ float red[16][16][2];
-  const int chl = threadIdx.x & 15, kl = threadIdx.x >> 4;
-  const int ch = blockIdx.x * 16 + chl;
-  float dg_sum = 0.f, db_sum = 0.f;       // dgamma / dbeta: summed over the groups (one parameter, several forward calls)
+  __shared__ float red[16][4][8][2];
+  const int chl = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 8 + chl;          // < cs: cs is a multiple of 8
   for (int grp = 0; grp < groups; ++grp) {
-  float a = 0.f, b = 0.f;
-  if (ch < cs)
-    for (int k0 = kl; k0 < chunks; k0 += 64) {             // four rows in flight, summed in loop order
-      float2 v[4];
+    const float* rows = partial + ((size_t)grp * chunks * cs + ch) * 2;
+    float a = 0.f, b = 0.f;
+    for (int k0 = kl; k0 < chunks; k0 += 256) {
+      float2 v[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = k0 + 16 * j;
-        v[j] = k < chunks ? *reinterpret_cast<const float2*>(partial + ((size_t)k * cs + ch) * 2) : make_float2(0.f, 0.f);
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + 32 * j;
+        v[j] = k < chunks ? *reinterpret_cast<const float2*>(rows + (size_t)k * cs * 2) : make_float2(0.f, 0.f);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 8; ++j) {
         a += v[j].x;
         b += v[j].y;
       }
     }
-  red[kl][chl][0] = a;
-  red[kl][chl][1] = b;
+#pragma unroll
+    for (int off = 32; off >= 8; off >>= 1) {
+      a += __shfl_down(a, off, 64);
+      b += __shfl_down(b, off, 64);
+    }
+    if (lane < 8) {
+      red[grp][wave][chl][0] = a;
+      red[grp][wave][chl][1] = b;
+    }
+  }
   __syncthreads();
-  if (kl == 0 && ch < cs) {
+  if (threadIdx.x >= 8) return;
+  float dg_sum = 0.f, db_sum = 0.f;       // dgamma / dbeta: summed over the groups (one parameter, several forward calls)
+  for (int grp = 0; grp < groups; ++grp) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
-      s1 += red[l][chl][0];
-      s2 += red[l][chl][1];
+    for (int w = 0; w < 4; ++w) {
+      s1 += red[grp][w][chl][0];
+      s2 += red[grp][w][chl][1];
     }
     float A = 0.f, B = 0.f, C = 0.f;
     if (ch < c) {
@@ -405,11 +442,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[ch] = A;
     coef[cs + ch] = B;
     coef[2 * cs + ch] = C;
+    mean += cs; rstd += cs; coef += 3 * (size_t)cs;
   }
-  __syncthreads();
-  partial += (size_t)chunks * cs * 2; mean += cs; rstd += cs; coef += 3 * (size_t)cs;
-  }
-  if (kl == 0 && ch < c) {
+  if (ch < c) {
     if (dgamma) dgamma[ch] = dg_sum;
     if (dbeta) dbeta[ch] = db_sum;
   }
@@ -697,7 +732,7 @@ extern "C" int cgan_instnorm_act_bwd(const void* out, const void* dy, const floa
   const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
   DISPATCH_T(d->dtype, in_bwd_reduce_kernel, dim3(chunks, ceil_div(cg_total, cgb), d->n), dim3(256), smem, s,
              (const uint16_t*)out, (const uint16_t*)dy, partial, d->hw, cs, ppb, act, act_slope);
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(d->n * cs, 4)), dim3(256), 0, s, (const float*)partial, sums,
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->n * cs / 8), dim3(256), 0, s, (const float*)partial, sums,
                      d->n, cs, chunks);
   const long groups = (long)d->n * d->hw * cg_total;
   DISPATCH_T(d->dtype, in_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)out,
@@ -791,7 +826,7 @@ extern "C" int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, co
   DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, cgblocks, groups), dim3(256), smem, s,
              (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, partial,
              (long)npix, cs, (int)ppb, act, act_slope);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cs, 16)), dim3(256), 0, s, (const float*)partial, (int)chunks,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cs / 8), dim3(256), 0, s, (const float*)partial, (int)chunks,
                      batch_mean, batch_rstd, gamma, 1.f / (float)npix, coef, dgamma, dbeta, (int)c, cs, (int)groups);
   const int tpp = cg_total < 256 ? cg_total : 256;
   const int rows = 256 / tpp;
