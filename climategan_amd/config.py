@@ -65,6 +65,8 @@ def default_opts() -> Opts:
                 "latent_dim": 640, "no_z": True, "output_dim": 3, "paste_original_content": True, "pl4m_epoch": 49,
                 "spade_kernel_size": 3, "spade_n_up": 7, "spade_param_free_norm": "instance",
                 "spade_use_spectral_norm": True, "use_final_shortcut": False,
+                "diff_aug": {"use": False, "do_color_jittering": False, "do_cutout": False, "cutout_ratio": 0.5,
+                             "do_translation": False, "translation_ratio": 0.125},     # :158-164 (use: true raises)
             },
         },
         "dis": {

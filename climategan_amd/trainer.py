@@ -163,10 +163,49 @@ class Trainer:
         vgg = (ops.NHWC(vgg_fake_t, 6), vgg_real) if want_vgg else None
         return real_d, fake_d, vgg
 
-    def get_painter_loss(self, multi_domain_batch):
-        """reference trainer.py:1256-1387 (single-discriminator branch; the TV / context / reconstruction terms, lambdas 0
-        in defaults.yaml:293-300, come from one fused kernel on the pasted image, autograd.PainterAuxFn)."""
+    def _painter_loss_local_pair(self, batch):
+        """``dis.p.use_local_discriminator`` (off in defaults.yaml:227), G side: reference trainer.py:1323-1358.  D["p"] is
+        the pair {"global", "local"} of 3-channel discriminators (discriminator.py:246-252); the global one sees the
+        painted image, the local one ``fake * m``; both GAN terms are scaled by lambdas.G.p.gan (the single-discriminator
+        branch is not, :1369), feature matching on the global one only, and WITHOUT the featmatch != 0 test of the other
+        branch.  Written on the NCHW boundary (G.paint / D(x) / the loss classes carry their graphs): a non-default
+        branch, not a fused path."""
+        from .tutils import vgg_preprocess
+
         lambdas = self.opts.train.lambdas
+        x, m = batch["data"]["x"], batch["data"]["m"]
+        fake = self.G.paint(m, x)
+        step_loss = 0
+        if lambdas.G.p.vgg != 0 and self.losses["G"]["p"]["vgg"] is not None:                       # :1276-1287
+            loss = self.losses["G"]["p"]["vgg"](vgg_preprocess(fake * m), vgg_preprocess(x * m)) * lambdas.G.p.vgg
+            self.loss_log["G.p.vgg"] = loss.detach()
+            step_loss = step_loss + loss
+        if any(lambdas.G.p[k] != 0 for k in ("tv", "context", "reconstruction")):
+            raise NotImplementedError("painter TV / context / reconstruction terms together with the local / global "
+                                      "discriminator pair have no HIP path")
+        fake_d_global = self.D["p"]["global"](fake)
+        fake_d_local = self.D["p"]["local"](fake * m)
+        real_d_global = self.D["p"]["global"](x)
+        loss = self.losses["G"]["p"]["gan"](fake_d_global, True, False)
+        loss = loss + self.losses["G"]["p"]["gan"](fake_d_local, True, False)
+        loss = loss * lambdas.G["p"]["gan"]
+        self.loss_log["G.p.gan"] = loss.detach()
+        step_loss = step_loss + loss
+        if self.opts.dis.p.get_intermediate_features:
+            loss = self.losses["G"]["p"]["featmatch"](real_d_global, fake_d_global) * lambdas.G["p"]["featmatch"]
+            self.loss_log["G.p.featmatch"] = loss.detach() if torch.is_tensor(loss) else loss
+            step_loss = step_loss + loss
+        return step_loss
+
+    def get_painter_loss(self, multi_domain_batch):
+        """reference trainer.py:1256-1387 (the TV / context / reconstruction terms, lambdas 0 in defaults.yaml:293-300, come
+        from one fused kernel on the pasted image, autograd.PainterAuxFn)."""
+        lambdas = self.opts.train.lambdas
+        if self.opts.gen.p.get("diff_aug", {}).get("use", False):
+            raise NotImplementedError("gen.p.diff_aug (transforms.py:609 DiffTransforms: data augmentation, out of scope) "
+                                      "has no HIP path")
+        if self.opts.dis.p.use_local_discriminator:
+            return self._painter_loss_local_pair(multi_domain_batch["rf"])
         real_d, fake_d, vgg = self._painter_terms(multi_domain_batch["rf"], True)
         step_loss = 0
         if any(lambdas.G.p[k] != 0 for k in ("tv", "context", "reconstruction")):      # trainer.py:1289-1315 (0 by default)
@@ -193,6 +232,19 @@ class Trainer:
 
     def get_D_loss(self, multi_domain_batch):
         """reference trainer.py:1034-1160, Painter branch (1073-1107)."""
+        if self.opts.gen.p.get("diff_aug", {}).get("use", False):
+            raise NotImplementedError("gen.p.diff_aug has no HIP path")
+        if self.opts.dis.p.use_local_discriminator:                                   # :1085-1099
+            data = multi_domain_batch["rf"]["data"]
+            x, m = data["x"], data["m"]
+            with torch.no_grad():
+                fake = self.G.paint(m, x)
+            fake = fake.detach()
+            crit = self.losses["D"]["p"]
+            g_loss = crit(self.D["p"]["global"](fake), False, True) + crit(self.D["p"]["global"](x), True, True)
+            l_loss = crit(self.D["p"]["local"](fake * m), False, True) + crit(self.D["p"]["local"](x * m), True, True)
+            self.loss_log["D.p.global"], self.loss_log["D.p.local"] = g_loss.detach(), l_loss.detach()
+            return g_loss + l_loss
         real_d, fake_d, _ = self._painter_terms(multi_domain_batch["rf"], False)
         loss = self.losses["D"]["p"](fake_d, False, True)
         loss = loss + self.losses["D"]["p"](real_d, True, True)

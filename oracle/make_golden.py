@@ -47,6 +47,11 @@ def golden_cases():
         # mask the context term (p - x)(1 - m) = m (1 - m)(fake - x) vanishes identically)
         "gstep_p_aux": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=92,
                             aux=dict(tv=2.0, context=3.0, reconstruction=5.0, lsgan=True, soft_mask=True)),
+        # the local / global discriminator pair (dis.p.use_local_discriminator: trainer.py:1323-1358 on the G side,
+        # 1085-1099 on the D side; discriminator.py:242-324 builds the two 3-channel discriminators), lambdas.G.p.gan = 2
+        # so that the scaling of this branch (the single-discriminator branch does not scale) shows
+        "gstep_p_local": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=93,
+                              local=dict(lambda_gan=2.0)),
         # VGG term of get_painter_loss through the reference's own Vgg19 / VGGLoss / vgg_preprocess; VGG-19 weights from
         # the portable fill with a He-preserving bound (gain sqrt(6): activations keep the input's 0-255 scale)
         "vgg_small": dict(kind="vgg", H=64, W=96, B=2, seed=85, gain=2.449489742783178, lambda_vgg=10.0),
@@ -574,6 +579,76 @@ def run_reference_gstep(name, case):
     return out
 
 
+def run_reference_gstep_local(name, case):
+    """``dis.p.use_local_discriminator``: the reference's ``OmniDiscriminator`` builds D["p"] = {"global", "local"}, two
+    3-channel multiscale discriminators (discriminator.py:242-324).  G side = trainer.py:1323-1358 (GAN terms of both,
+    scaled by lambdas.G.p.gan; feature matching on the global one only), D side = trainer.py:1085-1099 on the detached fake
+    (real / fake in separate calls, the local one on ``* m``), each with its own ``backward()``."""
+    from oracle import ref_shim
+
+    gen = ref_shim.ref("generator")
+    disc = ref_shim.ref("discriminator")
+    losses = ref_shim.ref("losses")
+    painter, _ = build_reference_module(dict(case, kind="painter"))
+    painter.train()
+    G = gen.OmniGenerator.__new__(gen.OmniGenerator)
+    torch.nn.Module.__init__(G)
+    G.opts = _painter_opts(case)
+    G.painter = painter
+    opts = ref_shim.default_opts()
+    opts.tasks = ["p"]
+    opts.dis.p.use_local_discriminator = True
+    opts.dis.p.ndf, opts.dis.p.n_layers, opts.dis.p.num_D = case["ndf"], case["n_layers"], case["num_D"]
+    D = disc.OmniDiscriminator(opts)
+    assert set(D["p"].keys()) == {"global", "local"}
+    for i, which in enumerate(("global", "local")):
+        shapes = {key: tuple(v.shape) for key, v in D["p"][which].state_dict().items()}
+        D["p"][which].load_state_dict({key: t(v) for key, v in fill.fill_state_dict(shapes, case["seed"] + 1 + i).items()})
+    D.train()
+    inp = {k2: t(v) for k2, v in case_inputs(name, case).items()}
+    x, m = inp["x"], inp["m"]
+    painter.set_latent_shape(tuple(x.shape), True)
+    gan, fm = losses.GANLoss(use_lsgan=False, soft_shift=0.0, flip_prob=0.0), losses.FeatMatchLoss()   # get_losses, :384-388
+    lam = case["local"]["lambda_gan"]
+    out = {}
+    # ---- G side (D frozen, as update_G leaves it)
+    for p in D.parameters():
+        p.requires_grad = False
+    fake_flooded = G.paint(m, x)
+    fake_d_global = D["p"]["global"](fake_flooded)
+    fake_d_local = D["p"]["local"](fake_flooded * m)
+    real_d_global = D["p"]["global"](x)
+    l_gan = gan(fake_d_global, True, False)
+    l_gan = l_gan + gan(fake_d_local, True, False)
+    l_gan = l_gan * lam
+    l_fm = fm(real_d_global, fake_d_global) * 10
+    loss = l_gan + l_fm
+    loss.backward()
+    out.update({"loss": loss.detach().numpy().reshape(1), "gan": l_gan.detach().numpy().reshape(1),
+                "featmatch": l_fm.detach().numpy().reshape(1), "fake": fake_flooded.detach().numpy()})
+    for key, p in painter.named_parameters():
+        if p.requires_grad:
+            out["grad." + key] = p.grad.numpy().copy()
+    for key, v in D.state_dict().items():
+        if key.endswith("weight_u"):
+            out["post_g." + key] = v.numpy().copy()
+    # ---- D side, on the same (detached) fake, continuing from the state the G side left (u / v advanced)
+    for p in D.parameters():
+        p.requires_grad = True
+    fake = fake_flooded.detach()
+    gan_d = losses.GANLoss(use_lsgan=False, soft_shift=0.0, flip_prob=0.0)
+    g_loss = gan_d(D["p"]["global"](fake), False, True) + gan_d(D["p"]["global"](x), True, True)
+    l_loss = gan_d(D["p"]["local"](fake * m), False, True) + gan_d(D["p"]["local"](x * m), True, True)
+    (g_loss + l_loss).backward()
+    out["d.global"] = g_loss.detach().numpy().reshape(1)
+    out["d.local"] = l_loss.detach().numpy().reshape(1)
+    for which in ("global", "local"):
+        for key, p in D["p"][which].named_parameters():
+            if p.grad is not None and not key.endswith(("weight_u", "weight_v")):
+                out["dgrad.%s.%s" % (which, key)] = p.grad.numpy().copy()
+    return out
+
+
 def reference_vgg_loss(case):
     """The reference's ``VGGLoss`` (losses.py:337-350) around its own ``Vgg19`` (losses.py:304-334).  ``Vgg19`` asks
     torchvision for ``models.vgg19(pretrained=True).features``; torchvision is not installed, so the shim's dummy
@@ -742,6 +817,8 @@ def run_reference(name, case):
         return run_reference_mstep(name, case)
     if case["kind"] == "dstep_p":
         return run_reference_dstep(name, case)
+    if case["kind"] == "gstep_p" and case.get("local"):
+        return run_reference_gstep_local(name, case)
     if case["kind"] == "gstep_p":
         return run_reference_gstep(name, case)
     if case["kind"] == "vgg":

@@ -243,6 +243,97 @@ def test_painter_g_step_optional_terms_and_lsgan_match_reference():
     assert checked == sum(1 for k in gold if k.startswith("grad."))
 
 
+def test_painter_local_global_discriminator_pair_matches_reference():
+    """``dis.p.use_local_discriminator`` (reference trainer.py:1323-1358 on the G side, 1085-1099 on the D side; the pair is
+    built by OmniDiscriminator, discriminator.py:246-252) against the reference's own modules (golden ``gstep_p_local``,
+    lambdas.G.p.gan = 2 so that this branch's scaling shows): G-side terms and the gradient of every trainable Painter
+    tensor; then, continuing from the spectral-norm state the G side left (as update_D follows update_G), the two D losses
+    and the gradient of every trainable tensor of both discriminators."""
+    name = "gstep_p_local"
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+    from helpers import disc_p_shapes
+    from climategan_amd import fill
+
+    opts = default_opts()
+    opts.tasks = ["p"]
+    opts.gen.p.latent_dim, opts.gen.p.spade_n_up = case["latent_dim"], case["n_up"]
+    opts.dis.p.ndf, opts.dis.p.n_layers, opts.dis.p.num_D = case["ndf"], case["n_layers"], case["num_D"]
+    opts.dis.p.use_local_discriminator = True
+    opts.dis.soft_shift, opts.dis.flip_prob = 0.0, 0.0
+    opts.train.lambdas.G.p.vgg = 0
+    opts.train.lambdas.G.p.gan = case["local"]["lambda_gan"]
+    T = Trainer(opts, device="cuda").setup(inference=False)
+    assert set(T.D["p"].keys()) == {"global", "local"}
+    T.G.painter.load_state_dict(case_state_dict(case), strict=True)
+    shapes = disc_p_shapes(3, case["ndf"], case["n_layers"], case["num_D"])
+    for i, which in enumerate(("global", "local")):
+        T.D["p"][which].load_state_dict({k: t(v) for k, v in fill.fill_state_dict(shapes, case["seed"] + 1 + i).items()},
+                                        strict=True)
+    T.G.set_compute_dtype(torch.float16)
+    T.D.set_compute_dtype(torch.float16)
+    T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
+    inp = {k: t(v).cuda() for k, v in case_inputs(name, case).items()}
+    batch = {"rf": {"data": {"x": inp["x"], "m": inp["m"]}}}
+    # ---- G side
+    for p in T.D.parameters():
+        p.requires_grad_(False)
+    loss = T.get_painter_loss(batch)
+    loss.backward()
+    for key, log, tol in (("gan", "G.p.gan", 5e-3), ("featmatch", "G.p.featmatch", 1e-2)):
+        ref, got = float(gold[key][0]), float(T.loss_log[log])
+        assert abs(got - ref) <= tol * abs(ref), (key, got, ref)
+    assert abs(loss.item() - float(gold["loss"][0])) <= 1e-2 * float(gold["loss"][0])
+
+    def compare(named, prefix):
+        bad, checked = [], 0
+        for key, p in named:
+            if not p.requires_grad or key.endswith(("weight_u", "weight_v")):
+                continue
+            assert p.grad is not None, key
+            ref = gold[prefix + key].astype(np.float64)
+            got = p.grad.cpu().numpy().astype(np.float64)
+            base = key.rsplit(".", 1)[0]
+            wkey = prefix + base + (".weight_bar" if prefix + base + ".weight_bar" in gold else ".weight")
+            wscale = np.abs(gold[wkey]).max()
+            if key.endswith("bias") and np.abs(ref).max() < 1e-4 * wscale:
+                if np.abs(got).max() > 1e-2 * wscale:
+                    bad.append((key, "zero-bias", np.abs(got).max() / wscale))
+            else:
+                l2 = np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum())
+                cos = (got * ref).sum() / np.sqrt((got ** 2).sum() * (ref ** 2).sum())
+                if not (l2 <= 0.15 and cos >= 0.99):
+                    bad.append((key, l2, cos))
+            checked += 1
+        assert not bad, (prefix, len(bad), [(k, "%.3g" % a if not isinstance(a, str) else a, "%.4f" % b) for k, a, b in bad])
+        return checked
+
+    assert compare(T.G.painter.named_parameters(), "grad.") == sum(1 for k in gold if k.startswith("grad."))
+    # ---- D side
+    for key, p in T.D.named_parameters():
+        if not key.endswith(("weight_u", "weight_v")):
+            p.requires_grad_(True)
+    # (on the reference's own painted image, as the golden D-step ``dstep_p`` does: a discriminator's first-layer gradients
+    # are differences of nearly cancelling real / fake sums, and the 16-bit Painter's 0.5 % deviation of ``fake`` would be
+    # what the comparison measures)
+    gold_fake = t(gold["fake"]).cuda()
+    T.G.paint = lambda m, x, **kw: gold_fake
+    d_loss = T.get_D_loss(batch)
+    del T.G.paint
+    d_loss.backward()
+    for which in ("global", "local"):
+        ref, got = float(gold["d." + which][0]), float(T.loss_log["D.p." + which])
+        assert abs(got - ref) <= 5e-3 * abs(ref), (which, got, ref)
+        n = compare(T.D["p"][which].named_parameters(), "dgrad.%s." % which)
+        assert n == sum(1 for k in gold if k.startswith("dgrad.%s." % which))
+    # the other non-default switch of this range raises instead of being ignored
+    T.opts.gen.p.diff_aug.use = True
+    with pytest.raises(NotImplementedError):
+        T.get_painter_loss(batch)
+
+
 def test_painter_train_steps_run_and_learn():
     """Trainer.train_step (G update, D update, ExtraAdam extrapolate / step) incl. the VGG term with its random-init
     feature extractor: finite losses, parameters move, spectral-norm vectors advance, D flags restored."""
