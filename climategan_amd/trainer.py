@@ -366,21 +366,22 @@ class Trainer:
         return full_loss, prob
 
     def painter_loss_for_masker(self, x, m):
-        """reference trainer.py:1618-1651 (pl4m, single-discriminator branch): the GAN term of the Painter's discriminator
+        """reference trainer.py:1618-1651 (pl4m; both discriminator branches): the GAN term of the Painter's discriminator
         on ``paint(m, x)`` with the PREDICTED mask probability ``m`` -- the Painter (and D, frozen throughout the G update)
         is not updated; the gradient reaches the Masker through the paste, through the discriminator's mask channel and
         through the Painter's conditioning image x (1 - m) (``SpadeFn``'s cond branch).  ``m``: NHWC map or NCHW tensor."""
         from . import functional as Fn
         from .tutils import divide_pred
 
-        if self.opts.dis.p.use_local_discriminator:
-            raise NotImplementedError("pl4m with the local / global discriminator pair has no HIP path")
         frozen = [p for p in self.G.painter.parameters() if p.requires_grad]
         for p in frozen:
             p.requires_grad_(False)
         try:
             m = Fn.to_nchw(m) if isinstance(m, ops.NHWC) else m
             fake = self.G.paint(m, x)
+            if self.opts.dis.p.use_local_discriminator:                                   # trainer.py:1628-1636
+                gan = self.losses["G"]["p"]["gan"]
+                return gan(self.D["p"]["global"](fake), True, False) + gan(self.D["p"]["local"](fake * m), True, False)
             real_fake_cat = torch.cat([torch.cat([m, x], dim=1), torch.cat([m, fake], dim=1)], dim=0)
             _, fake_d = divide_pred(self.D["p"](real_fake_cat, nhwc=True))
             return self.losses["G"]["p"]["gan"](fake_d, True, False)

@@ -311,6 +311,22 @@ def test_painter_local_global_discriminator_pair_matches_reference():
         return checked
 
     assert compare(T.G.painter.named_parameters(), "grad.") == sum(1 for k in gold if k.startswith("grad."))
+    # ---- pl4m with the pair (trainer.py:1628-1636): from the same discriminator state, the un-scaled sum of the two GAN terms
+    # = the golden G-side GAN term / lambda; the mask (a prediction there) receives a gradient
+    def load_d():
+        for i, which in enumerate(("global", "local")):
+            T.D["p"][which].load_state_dict({k: t(v) for k, v in fill.fill_state_dict(shapes, case["seed"] + 1 + i).items()},
+                                            strict=True)
+    post = {k: v.clone() for k, v in T.D.state_dict().items()}
+    load_d()
+    m_pred = inp["m"].clone().requires_grad_(True)
+    pl4m = T.painter_loss_for_masker(inp["x"], m_pred)
+    ref = float(gold["gan"][0]) / case["local"]["lambda_gan"]
+    assert abs(pl4m.item() - ref) <= 1e-2 * ref, (pl4m.item(), ref)
+    pl4m.backward()
+    assert torch.isfinite(m_pred.grad).all() and m_pred.grad.abs().max() > 0
+    assert all(p.requires_grad for k, p in T.G.painter.named_parameters() if not k.endswith(("weight_u", "weight_v")))
+    T.D.load_state_dict(post)
     # ---- D side
     for key, p in T.D.named_parameters():
         if not key.endswith(("weight_u", "weight_v")):
