@@ -13,6 +13,7 @@
 // tiles are summed through LDS at the end and added to dW with fp32 atomics (grid = pixel splits x taps x channel
 // blocks, so several workgroups contribute to each weight).
 #include "cgan_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -23,6 +24,8 @@ struct WgradArgs {
   float* dw;
   unsigned x_bytes, dy_bytes;   // extents for the buffer descriptors (out-of-range DMA lanes read zeros)
   float* ws;   // non-null: partial tiles go to ws[split][tile][16 fragments][64 lanes] (f32x4) for wgrad_reduce_kernel
+  float* bpart;  // non-null: the bias gradient rides along -- the workgroups of N tile 0 multiply their dy fragments with a
+                 // constant-one B fragment as well (sum over pixels = one more GEMM column) and store bpart[split][cout_s]
   int n, h_in, w_in, cin, cin_s;
   int cout, cout_s;
   int kh, kw, stride, pad, dil;
@@ -67,6 +70,24 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* slab, int tile, in
   r[2] = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
   r[3] = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
   return r;
+}
+
+// the all-ones B fragment of the bias column (bf16 1.0 = 0x3f80, fp16 1.0 = 0x3c00)
+template <typename T>
+__device__ __forceinline__ u32x4 ones_frag() {
+  constexpr uint32_t one = std::is_same<T, BF16>::value ? 0x3f803f80u : 0x3c003c00u;
+  return (u32x4){one, one, one, one};
+}
+// accb[a]: rows = output channels co0 + 16 a + 4 g + r, every column the same sum: column 0's lanes store the row
+__device__ __forceinline__ void store_bias_row(float* __restrict__ row, const f32x4 (&accb)[4], int na, int co0, int cout_s,
+                                               int lane) {
+  if ((lane & 15) != 0) return;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int co = co0 + a * 16 + 4 * g;
+    if (a < na && co < cout_s) *reinterpret_cast<f32x4*>(row + co) = accb[a];
+  }
 }
 
 // Column `col` (0..63) of the N tile (tap slot `slot`, ci block `cib`) -> (tap, ci).  Normal layout: one tap per slot,
@@ -262,6 +283,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const bool do_bias = p.bpart != nullptr && slot == 0 && cib == 0;      // block-uniform
+  f32x4 accb[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int c = split, buf = 0;
   if (c < p.nchunks) issue(0);
   for (; c < p.nchunks; c += p.splits) {
@@ -284,8 +309,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb[b]), acc[a][b]);
+    if (do_bias) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) accb[a] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(ones_frag<T>()), accb[a]);
+    }
     buf ^= 1;
   }
+  // bias rows: one per (pixel split, wave) -- a wave covers its own 32 pixels of every chunk
+  if (do_bias) store_bias_row(p.bpart + ((size_t)split * 4 + wave) * p.cout_s, accb, 4, co0, p.cout_s, lane);
 
   // ---- sum the four waves' partial tiles through LDS, then fp32 atomics into dW (OIHW)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -337,7 +368,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 // CH = pixels per stage (64 or 32); a sub-slab is CH pixels x 64 channels x 2 B; a stage = dy half 0 | dy half 1 |
 // x tile 0 | x tile 1; two stages: 64 KiB (2 workgroups per CU) or 32 KiB (4 per CU) of LDS.
 
-template <typename T, int MODE, int CH = 64, bool TS = false>
+template <typename T, int MODE, int CH = 64, bool TS = false, bool BIAS = false>
 __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(WgradArgs p) {
   constexpr int CHUNK2 = CH, SUB2 = CH * 128, STAGE2 = 4 * SUB2;
   constexpr int PPS = CH / 8, PW = PPS / 2;      // pieces per sub-slab, pieces of each operand a wave stages
@@ -470,6 +501,12 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // (BIAS is a template parameter: the four extra accumulators do not fit the 128-register budget of the 32-pixel-stage
+  // variant, and a run-time flag would make every instance pay for them)
+  const bool do_bias = BIAS && p.bpart != nullptr && np == 0 && wn == 0;      // wave-uniform: the quadrants of N tile 0
+  f32x4 accb[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nchunks = (p.npix + CHUNK2 - 1) / CHUNK2;
   int c = split, buf = 0;
   unsigned long long t_a = 0, t_b = 0, ts_sum[4] = {0, 0, 0, 0}, t_start = 0;
@@ -504,10 +541,16 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(fb[b]), acc[a][b]);
+      if (BIAS && do_bias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) accb[a] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(ones_frag<T>()), accb[a]);
+      }
     }
     buf ^= 1;
     if (TS) { t_a = __builtin_readcyclecounter(); ts_sum[3] += t_a - t_b; }
   }
+  if (BIAS && do_bias && cop * 2 + wc < p.co_blocks)
+    store_bias_row(p.bpart + (size_t)split * p.cout_s, accb, 4, (cop * 2 + wc) * 64, p.cout_s, lane);
   if (TS && CGAN_WTS(p) && lane == 0) {
     unsigned long long* o = CGAN_WTS(p) + ((size_t)blockIdx.x * 4 + wave) * 8;
     o[0] = t_start;
@@ -577,7 +620,7 @@ __device__ __forceinline__ u32x4 tr_frag_at(const unsigned char* slab, int q0, i
   return r;
 }
 
-template <typename T, int NA = 4>      // NA: 16-row co tiles per block that exist (a 40-channel gradient: 3)
+template <typename T, int NA = 4, bool BIAS = false>   // NA: 16-row co tiles per block that exist (a 40-channel gradient: 3)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* xh = smem;
@@ -641,6 +684,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[a][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const bool do_bias = BIAS && p.bpart != nullptr && cib == 0 && wave == 0;   // (template parameter: NA = 4 has no registers left)
+  f32x4 accb[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int t = split; t < ntiles; t += p.splits) {
     __syncthreads();                                              // the previous tile's fragment reads are done
     stage(t);
@@ -651,6 +698,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
       u32x4 fa[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) fa[a] = tr_frag_at(dyt, ty * TL_W, a, lane);
+      if (BIAS && do_bias) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) accb[a] = mfma16(as_vec8<T>(fa[a]), as_vec8<T>(ones_frag<T>()), accb[a]);
+      }
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int jn = wave * 9 + i, tap = jn >> 2, grp = jn & 3;
@@ -662,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile3x3_kernel(WgradArgs p)
     }
   }
 
+  if (BIAS && do_bias) store_bias_row(p.bpart + (size_t)split * p.cout_s, accb, NA, cob * 64, p.cout_s, lane);
   // partial tiles to the workspace in the layout wgrad_reduce_kernel sums: [split][64 x 64 tile (tap, cib, cob)][a * 4 + b][lane]
   const int tiles_n = 9 * p.ci_blocks * p.co_blocks;
 #pragma unroll
@@ -795,12 +847,14 @@ CGAN_KNOB(int, g_wgrad_coop_min_pix, 32768);
 CGAN_KNOB(int, g_wgrad_coop_chunk, 0);
 CGAN_KNOB(int, g_wgrad_slots, 512);
 CGAN_KNOB(int, g_wgrad_tile, 1);
+CGAN_KNOB(int, g_wgrad_bias_fused, 1);      // dev: 0 = the separate channel-sum pass for every bias gradient
 CGAN_KNOB(int, g_wgrad_ws_cost_pct, 100);   // dev: the planner's cost of a partial tile through the workspace, in % of the fitted value
 CGAN_KNOB(unsigned long long*, g_wgrad_ts, nullptr);
 }  // namespace
 
 #ifdef CGAN_DEV
 extern "C" void cgan_debug_set_wgrad_tsbuf(void* p) { g_wgrad_ts = (unsigned long long*)p; }
+extern "C" void cgan_debug_set_wgrad_bias_fused(int v) { g_wgrad_bias_fused = v; }
 extern "C" void cgan_debug_set_wgrad_ws_cost(int pct) { g_wgrad_ws_cost_pct = pct > 0 ? pct : 100; }
 extern "C" void cgan_debug_set_wgrad_tile3x3(int v) { g_wgrad_tile = v; }   // 0: never the spatially tiled 3 x 3 kernel, 2: wherever it applies
 extern "C" void cgan_debug_set_wgrad_slots(int v) { g_wgrad_slots = v > 0 ? v : 512; }   // resident workgroups the planner assumes
@@ -814,7 +868,8 @@ extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
 }
 #endif
 
-constexpr int BIAS_MAX_BLOCKS = 512;
+constexpr int BIAS_MAX_BLOCKS = 512;      // rows of the separate channel-sum pass
+constexpr int BIAS_MAX_ROWS = 1024;       // rows of bias partials the workspace holds (fused: one per pixel split [x wave])
 
 // Tiling of one weight-gradient call: N tiles (tap slots x ci blocks), M tiles (co blocks), pixel splits.
 struct WgradPlan {
@@ -914,7 +969,7 @@ extern "C" size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* d) 
     return 0;
   const WgradPlan pl = wgrad_plan(d);
   // partial tiles | up to BIAS_MAX_BLOCKS rows of per-block channel sums (the bias gradient's deterministic reduction)
-  return (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64 * sizeof(float) + (size_t)BIAS_MAX_BLOCKS * cgan_cs(d->c_out) * sizeof(float);
+  return (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64 * sizeof(float) + (size_t)BIAS_MAX_ROWS * cgan_cs(d->c_out) * sizeof(float);
 }
 
 extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias,
@@ -957,10 +1012,23 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   CGAN_REQUIRE(items < (1L << 30), "conv2d_nhwc_bwd_weight: grid too large");
   const unsigned gx = (unsigned)a.per_xcd * 8;
   a.ws = nullptr;
+  a.bpart = nullptr;
+  int bias_rows = 0;
   if (workspace) {
     CGAN_REQUIRE(workspace_bytes >= cgan_conv2d_bwd_weight_workspace_bytes(d),
                  "conv2d_nhwc_bwd_weight: workspace too small (%zu bytes)", workspace_bytes);
     a.ws = (float*)workspace;
+    // the bias gradient inside the weight-gradient kernel (a constant-one GEMM column in the workgroups of N tile 0): one
+    // partial row per pixel split (x 4 waves in the single-wave-tile kernel), as long as the rows fit; otherwise, and
+    // without a workspace, the separate channel-sum pass below
+    const int rows = a.splits * ((pl.tile || pl.coop) ? 1 : 4);
+    // (not in the two variants without registers to spare: the cooperative kernel's 32-pixel stages, the tiled kernel with
+    // four co tiles)
+    const bool variant_ok = pl.tile ? (pl.co_blocks == 1 && ceil_div(cgan_cs(d->c_out), 16) < 4) : (!pl.coop || pl.chunk == 64);
+    if (dbias && rows <= BIAS_MAX_ROWS && variant_ok && g_wgrad_bias_fused && CGAN_WTS(a) == nullptr) {
+      a.bpart = a.ws + (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64;
+      bias_rows = rows;
+    }
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = 4 * WAVE_LDS;   // 64 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
@@ -986,18 +1054,21 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     const size_t smem3 = TL_XH_BYTES + TL_DY_BYTES;
     // a single co block of <= 48 channels: only the co tiles that exist (the 16-row tiles past cout_s would multiply zeros)
     const int na = pl.co_blocks == 1 ? ceil_div(a.cout_s, 16) : 4;
-#define TILE_LAUNCH(TT, NN) hipLaunchKernelGGL((conv_wgrad_tile3x3_kernel<TT, NN>), dim3(gx), dim3(256), smem3, s, a)
-#define TILE_NA(TT) do { if (na == 1) TILE_LAUNCH(TT, 1); else if (na == 2) TILE_LAUNCH(TT, 2); else if (na == 3) TILE_LAUNCH(TT, 3); else TILE_LAUNCH(TT, 4); } while (0)
+#define TILE_LAUNCH(TT, NN, BB) hipLaunchKernelGGL((conv_wgrad_tile3x3_kernel<TT, NN, BB>), dim3(gx), dim3(256), smem3, s, a)
+#define TILE_NB(TT, NN) do { if (a.bpart) TILE_LAUNCH(TT, NN, true); else TILE_LAUNCH(TT, NN, false); } while (0)
+#define TILE_NA(TT) do { if (na == 1) TILE_NB(TT, 1); else if (na == 2) TILE_NB(TT, 2); else if (na == 3) TILE_NB(TT, 3); else TILE_LAUNCH(TT, 4, false); } while (0)
     if (d->dtype == CGAN_F16) TILE_NA(F16); else TILE_NA(BF16);
 #undef TILE_NA
+#undef TILE_NB
 #undef TILE_LAUNCH
   } else if (pl.coop) {
     const size_t smem2 = (size_t)2 * 4 * pl.chunk * 128;
-#define COOP_LAUNCH(TT, MM, CC) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC>), dim3(gx), dim3(256), smem2, s, a)
+#define COOP_LAUNCH(TT, MM, CC, BB) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC, false, BB>), dim3(gx), dim3(256), smem2, s, a)
 #define COOP_MODE(TT)                                                                       \
   do {                                                                                      \
-    if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32); else if (mode == 2) COOP_LAUNCH(TT, 2, 32); else COOP_LAUNCH(TT, 0, 32); } \
-    else { if (mode == 1) COOP_LAUNCH(TT, 1, 64); else if (mode == 2) COOP_LAUNCH(TT, 2, 64); else COOP_LAUNCH(TT, 0, 64); }            \
+    if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32, false); else if (mode == 2) COOP_LAUNCH(TT, 2, 32, false); else COOP_LAUNCH(TT, 0, 32, false); } \
+    else if (a.bpart) { if (mode == 1) COOP_LAUNCH(TT, 1, 64, true); else if (mode == 2) COOP_LAUNCH(TT, 2, 64, true); else COOP_LAUNCH(TT, 0, 64, true); }            \
+    else { if (mode == 1) COOP_LAUNCH(TT, 1, 64, false); else if (mode == 2) COOP_LAUNCH(TT, 2, 64, false); else COOP_LAUNCH(TT, 0, 64, false); }            \
   } while (0)
 #ifdef CGAN_DEV
     if (CGAN_WTS(a) && d->dtype == CGAN_BF16 && mode == 0) {
@@ -1013,9 +1084,8 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #undef WGRAD_MODE
 #undef WGRAD_LAUNCH
   CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_weight");
-  float* bpart = nullptr;
-  int bias_rows = 0;
-  if (dbias) {
+  float* bpart = a.bpart;
+  if (dbias && !a.bpart) {
     const int cs = a.cout_s;
     const int threads = 256;
     const int ppb = threads / (cs / 8) > 0 ? threads / (cs / 8) : 1;

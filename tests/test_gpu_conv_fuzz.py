@@ -98,7 +98,13 @@ def test_conv_forward_dgrad_wgrad(dt, case):
                                            use_workspace=use_ws)
             assert rel_err(dw.cpu(), w.grad) <= 3e-4, "wgrad (%s)" % name
             assert rel_err(db.cpu(), b.grad) <= 3e-4, "bias grad (%s)" % name
+        # the bias gradient as a separate channel-sum pass (what the kernels above do with a constant-one GEMM column)
+        lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_bias_fused(ctypes.c_int(0))
+        dw, db = ops.conv2d_bwd_weight(xg, dyg, tuple(w.shape), stride=stride, pad=pad, dilation=dil)
+        assert rel_err(db.cpu(), b.grad) <= 3e-4, "bias grad (separate pass)"
     finally:
+        lib.cgan_debug_set_wgrad_bias_fused(ctypes.c_int(1))
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_chunk(ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
@@ -129,7 +135,8 @@ def test_spatially_tiled_3x3_wgrad(dt, case):
             dw, db = ops.conv2d_bwd_weight(xg, dyg, (cout, cin, 3, 3), pad=1)
             assert rel_err(dw.cpu(), w.grad) <= 3e-4, ("tiled", splits)
             assert rel_err(dw.cpu(), dw_old.cpu()) <= 1e-5, ("tiled vs per-tap", splits)
-            assert rel_err(db.cpu(), db_old.cpu()) <= 1e-5          # (the channel sum ends in atomics: order varies)
+            assert rel_err(db.cpu(), db_old.cpu()) <= 1e-5
+            assert rel_err(db.cpu(), dy.float().sum((0, 2, 3))) <= 3e-4, ("tiled: bias gradient", splits)
     finally:
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_tile3x3(ctypes.c_int(1))
