@@ -144,10 +144,10 @@ _SIGNATURES = {
     "cgan_conv2d_nhwc_fwd_stats": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.POINTER(ConvDesc), _P]),
     "cgan_bn_train_prepare": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "cgan_batchnorm_act_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
-    "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
-                                         C.c_float, _P, C.c_size_t, _P]),
-    "cgan_batchnorm_act_bwd_grouped": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32,
-                                                 C.c_int32, C.c_int32, C.c_float, _P, C.c_size_t, _P]),
+    "cgan_batchnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32,
+                                         C.c_int32, C.c_float, _P, C.c_size_t, _P]),
+    "cgan_batchnorm_act_bwd_grouped": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64,
+                                                 C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, C.c_size_t, _P]),
     "cgan_bce_logits_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, _P, _P, _P]),
     "cgan_hinge_nhwc": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "cgan_l1_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),

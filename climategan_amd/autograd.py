@@ -8,6 +8,8 @@ tensors, with the logical channel count passed alongside.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import ops
@@ -415,6 +417,9 @@ class MaxPool2x2Fn(torch.autograd.Function):
         return ops.maxpool2x2_bwd(ops.NHWC(x_t, ctx.c), ops.NHWC(dy_t.contiguous(), ctx.c)).t, None
 
 
+_BN_BWD_READS_OUT = os.environ.get("CGAN_BN_BWD_OUT") == "1"     # same-box A/B switch (tools/gpu_ab_env.sh): the old passes
+
+
 class BatchNormActFn(torch.autograd.Function):
     """out = act(batch_norm(x) [+ residual]) in TRAINING mode (batch statistics over n, h, w; running statistics
     updated in place, momentum / unbiased variance as nn.BatchNorm2d).  gamma / beta may be None (affine=False).
@@ -447,14 +452,18 @@ class BatchNormActFn(torch.autograd.Function):
         out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope, residual=res).t.view(n, h, w, cs)
         ctx.cfg = (c, act, slope, G)
         ctx.has_res = res_t is not None
-        ctx.save_for_backward(x_t, out, mean, rstd, gamma)
+        # without a fused residual the backward recomputes act'(.) from x with (mean', rstd') -- the apply kernel's own
+        # arithmetic -- and never reads `out`: one map less in each of its two passes
+        keep_out = res_t is not None or _BN_BWD_READS_OUT
+        ctx.save_for_backward(x_t, out if keep_out else None, mean, rstd, gamma,
+                              None if keep_out else mean_f, None if keep_out else rstd_f)
         return out
 
     @staticmethod
     def backward(ctx, dy_t):
         from . import _lib
         lib = _lib.load()
-        x_t, out, mean, rstd, gamma = ctx.saved_tensors
+        x_t, out, mean, rstd, gamma, mean_f, rstd_f = ctx.saved_tensors
         c, act, slope, G = ctx.cfg
         n, h, w, cs = x_t.shape
         nbytes = G * lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
@@ -471,7 +480,7 @@ class BatchNormActFn(torch.autograd.Function):
             dg, db = torch.empty((2, c), dtype=torch.float32, device=x_t.device).unbind(0)   # written by the kernel
         _lib.check(lib.cgan_batchnorm_act_bwd_grouped(
             ops._ptr(x_t), ops._ptr(out), ops._ptr(dy_t), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma),
-            ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._ptr(dres) if dres is not None and dres is not dy_t else None,
+            ops._ptr(mean_f), ops._ptr(rstd_f), ops._ptr(dx), ops._ptr(dg), ops._ptr(db), ops._ptr(dres) if dres is not None and dres is not dy_t else None,
             ops._DT[x_t.dtype], n * h * w, c, G, act, slope, ops._ptr(ws), nbytes, ops._stream()),
             "cgan_batchnorm_act_bwd_grouped")
         return dx, dg, db, None, None, None, None, None, None, None, None, dres, None

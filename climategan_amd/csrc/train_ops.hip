@@ -303,11 +303,25 @@ __global__ void bn_train_prepare_kernel(const float* __restrict__ mean, const fl
 // Stage 1: partial[chunk][cs][2] = (sum dz, sum dz xh) over the chunk's pixels (plain stores: fp32 atomics from 1000+
 // workgroups to the same 2*cs addresses cross the XCDs and were ~2/3 of this kernel's time).
 constexpr int BN_BWD_MAX_CHUNKS = 512;
-template <typename T>
+// MASK: where act'(.) comes from.  0 = no activation (nothing read), 1 = from `out` (a residual was fused into the
+// forward's apply, so out is not a function of x alone), 2 = recomputed from x: z = (x - m') r' exactly as the forward's
+// apply kernel formed it (fold_mean / fold_rstd = the m', r' rows cgan_bn_train_prepare wrote), so `out` is not read at all -- one 16-bit map less
+// per pass for every BatchNorm + ReLU that has no residual (two of a bottleneck's three)
+// gneg = act'(.) on the non-positive side (0 ReLU, the slope for LeakyReLU): one compare + select per element, no
+// per-element switch on the activation
+template <int MASK>
+__device__ __forceinline__ float bn_bwd_act_grad(float ov, float xv, float fm, float fr, float gneg) {
+  if (MASK == 0) return 1.f;
+  if (MASK == 1) return ov > 0.f ? 1.f : gneg;
+  return (xv - fm) * fr > 0.f ? 1.f : gneg;
+}
+
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
                                                             const uint16_t* __restrict__ dy, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ partial,
-                                                            long npix, int cs, int ppb, int act, float slope) {
+                                                            const float* __restrict__ rstd, const float* __restrict__ fmean,
+                                                            const float* __restrict__ frstd, float* __restrict__ partial,
+                                                            long npix, int cs, int ppb, float gneg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL][cgb*8][2]
   const int cg_total = cs / 8;
   const int cgb = cg_total < 256 ? cg_total : 256;
@@ -315,8 +329,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
   const int cg0 = blockIdx.y * cgb;
   // blockIdx.z = group (npix = pixels PER GROUP): its slice of the tensors, its statistics row, its partial rows
   const size_t gofs = (size_t)blockIdx.z * npix * cs;
-  x += gofs; out += gofs; dy += gofs;
+  x += gofs; dy += gofs;
+  if (MASK == 1) out += gofs;
   mean += (size_t)blockIdx.z * cs; rstd += (size_t)blockIdx.z * cs;
+  if (MASK == 2) { fmean += (size_t)blockIdx.z * cs; frstd += (size_t)blockIdx.z * cs; }
   partial += (size_t)blockIdx.z * gridDim.x * cs * 2;
   const long p0 = (long)blockIdx.x * ppb, p1 = min(npix, p0 + ppb);
   const int t = threadIdx.x, cgl = t % cgb, pl = t / cgb;
@@ -325,11 +341,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
   if (pl < PL && cg < cg_total) {
-    float mu[8], rs[8];
+    float mu[8], rs[8], fm[8], fr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       mu[e] = mean[cg * 8 + e];
       rs[e] = rstd[cg * 8 + e];
+      fm[e] = MASK == 2 ? fmean[cg * 8 + e] : 0.f;
+      fr[e] = MASK == 2 ? frstd[cg * 8 + e] : 0.f;
     }
     const uint16_t* xp = x + cg * 8;
     const uint16_t* op = out + cg * 8;
@@ -338,7 +356,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
     for (long p = p0 + pl; p < p1; p += PL) {
       const size_t off = (size_t)p * cs;
       const u32x4 vx = *reinterpret_cast<const u32x4*>(xp + off);
-      const u32x4 vo = *reinterpret_cast<const u32x4*>(op + off);
+      u32x4 vo = {0, 0, 0, 0};
+      if (MASK == 1) vo = *reinterpret_cast<const u32x4*>(op + off);
       const u32x4 vg = *reinterpret_cast<const u32x4*>(gp + off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
         unpack2<T>(vg[e], gv[0], gv[1]);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const float dz = gv[hh] * act_grad_from_out(ov[hh], act, slope);
+          const float dz = gv[hh] * bn_bwd_act_grad<MASK>(ov[hh], xv[hh], fm[2 * e + hh], fr[2 * e + hh], gneg);
           const float xh = (xv[hh] - mu[2 * e + hh]) * rs[2 * e + hh];
           s1[2 * e + hh] += dz;
           s2[2 * e + hh] += dz * xh;
@@ -452,11 +471,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // Stage 3: dx = A dz + B x + C.  A thread keeps its 8 channels (coefficients in registers) and walks pixels: no
 // per-element index division, no per-element coefficient loads.
-template <typename T>
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ out,
                                                            const uint16_t* __restrict__ dy, const float* __restrict__ coef,
+                                                           const float* __restrict__ fmean, const float* __restrict__ frstd,
                                                            uint16_t* __restrict__ dx, uint16_t* __restrict__ dz_out,
-                                                           long npix, int cs, int act, float slope) {
+                                                           long npix, int cs, float gneg) {
   const int cg_total = cs / 8;
   const int tpp = cg_total < 256 ? cg_total : 256;   // threads per pixel
   const int rows = 256 / tpp;
@@ -464,23 +484,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
   if (prow >= rows) return;
   {   // blockIdx.y = group (npix = pixels per group): its slice, its coefficient rows
     const size_t gofs = (size_t)blockIdx.y * npix * cs;
-    x += gofs; out += gofs; dy += gofs; dx += gofs;
+    x += gofs; dy += gofs; dx += gofs;
+    if (MASK == 1) out += gofs;
     if (dz_out) dz_out += gofs;
     coef += (size_t)blockIdx.y * 3 * cs;
+    if (MASK == 2) { fmean += (size_t)blockIdx.y * cs; frstd += (size_t)blockIdx.y * cs; }
   }
   for (int cg = cgl; cg < cg_total; cg += tpp) {
-    float A[8], B[8], Cc[8];
+    float A[8], B[8], Cc[8], fm[8], fr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       A[e] = coef[cg * 8 + e];
       B[e] = coef[cs + cg * 8 + e];
       Cc[e] = coef[2 * cs + cg * 8 + e];
+      fm[e] = MASK == 2 ? fmean[cg * 8 + e] : 0.f;
+      fr[e] = MASK == 2 ? frstd[cg * 8 + e] : 0.f;
     }
 #pragma unroll 2
     for (long p = (long)blockIdx.x * rows + prow; p < npix; p += (long)gridDim.x * rows) {
       const size_t off = (size_t)p * cs + cg * 8;
       const u32x4 vx = *reinterpret_cast<const u32x4*>(x + off);
-      const u32x4 vo = *reinterpret_cast<const u32x4*>(out + off);
+      u32x4 vo = {0, 0, 0, 0};
+      if (MASK == 1) vo = *reinterpret_cast<const u32x4*>(out + off);
       const u32x4 vg = *reinterpret_cast<const u32x4*>(dy + off);
       u32x4 r, z;
 #pragma unroll
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int k = 2 * e + hh;
-          dzv[hh] = gv[hh] * act_grad_from_out(ov[hh], act, slope);
+          dzv[hh] = gv[hh] * bn_bwd_act_grad<MASK>(ov[hh], xv[hh], fm[k], fr[k], gneg);
           res[hh] = A[k] * dzv[hh] + B[k] * xv[hh] + Cc[k];
         }
         r[e] = pack2<T>(res[0], res[1]);
@@ -680,6 +705,12 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(float* __restrict__ g
     else hipLaunchKernelGGL(KERNEL<BF16>, __VA_ARGS__);              \
   } while (0)
 
+#define DISPATCH_T2(dtype, KERNEL, M, ...)                                  \
+  do {                                                                      \
+    if ((dtype) == CGAN_F16) hipLaunchKernelGGL((KERNEL<F16, M>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<BF16, M>), __VA_ARGS__);                \
+  } while (0)
+
 extern "C" int cgan_act_bwd(const void* out, const void* dy, void* dx, int32_t dtype, int32_t act, float act_slope,
                             int64_t numel, void* stream) {
   CGAN_REQUIRE(out && dy && dx, "act_bwd: null pointer");
@@ -788,19 +819,24 @@ extern "C" size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c) {
 }
 
 extern "C" int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
-                                      const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                                      void* dz_out, int32_t dtype, int64_t npix, int32_t c, int32_t act,
-                                      float act_slope, void* workspace, size_t workspace_bytes, void* stream) {
-  return cgan_batchnorm_act_bwd_grouped(x, out, dy, batch_mean, batch_rstd, gamma, dx, dgamma, dbeta, dz_out, dtype, npix,
-                                        c, 1, act, act_slope, workspace, workspace_bytes, stream);
+                                      const float* batch_rstd, const float* gamma, const float* fold_mean,
+                                      const float* fold_rstd, void* dx, float* dgamma, float* dbeta, void* dz_out,
+                                      int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return cgan_batchnorm_act_bwd_grouped(x, out, dy, batch_mean, batch_rstd, gamma, fold_mean, fold_rstd, dx, dgamma, dbeta,
+                                        dz_out, dtype, npix, c, 1, act, act_slope, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, const void* dy, const float* batch_mean,
-                                              const float* batch_rstd, const float* gamma, void* dx, float* dgamma,
-                                              float* dbeta, void* dz_out, int32_t dtype, int64_t npix_total, int32_t c,
-                                              int32_t groups, int32_t act, float act_slope, void* workspace,
-                                              size_t workspace_bytes, void* stream) {
-  CGAN_REQUIRE(x && out && dy && batch_mean && batch_rstd && dx && workspace, "batchnorm_act_bwd: null pointer");
+                                              const float* batch_rstd, const float* gamma, const float* fold_mean,
+                                              const float* fold_rstd, void* dx, float* dgamma, float* dbeta,
+                                              void* dz_out, int32_t dtype, int64_t npix_total, int32_t c, int32_t groups,
+                                              int32_t act, float act_slope, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+  CGAN_REQUIRE(x && dy && batch_mean && batch_rstd && dx && workspace, "batchnorm_act_bwd: null pointer");
+  CGAN_REQUIRE(out || !dz_out, "batchnorm_act_bwd: a fused residual (dz_out) needs out");
+  CGAN_REQUIRE(out || act == CGAN_ACT_NONE || (fold_mean && fold_rstd),
+               "batchnorm_act_bwd: without out the activation mask needs fold_mean / fold_rstd");
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "batchnorm_act_bwd: bad dtype %d", dtype);
   CGAN_REQUIRE(groups >= 1 && groups <= 16 && npix_total > 0 && c > 0 && npix_total % groups == 0,
                "batchnorm_act_bwd: bad shape (the pixel count must divide into the groups)");
@@ -823,18 +859,27 @@ extern "C" int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, co
   if (ppb < 8 * PL) ppb = 8 * PL;
   chunks = (npix + ppb - 1) / ppb;
   const size_t smem = (size_t)PL * cgb * 8 * 2 * sizeof(float);
-  DISPATCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)chunks, cgblocks, groups), dim3(256), smem, s,
-             (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, partial,
-             (long)npix, cs, (int)ppb, act, act_slope);
+  // where act' comes from: nothing to mask / from out (given: a residual may have been fused) / recomputed from x
+  const int mask = act == CGAN_ACT_NONE ? 0 : (out ? 1 : 2);
+  const float gneg = act == CGAN_ACT_RELU ? 0.f : act_slope;
+#define BN_BWD_REDUCE(M)                                                                                              \
+  DISPATCH_T2(dtype, bn_bwd_reduce_kernel, M, dim3((unsigned)chunks, cgblocks, groups), dim3(256), smem, s,           \
+              (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, fold_mean,       \
+              fold_rstd, partial, (long)npix, cs, (int)ppb, gneg)
+  if (mask == 0) { BN_BWD_REDUCE(0); } else if (mask == 1) { BN_BWD_REDUCE(1); } else { BN_BWD_REDUCE(2); }
+#undef BN_BWD_REDUCE
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cs / 8), dim3(256), 0, s, (const float*)partial, (int)chunks,
                      batch_mean, batch_rstd, gamma, 1.f / (float)npix, coef, dgamma, dbeta, (int)c, cs, (int)groups);
   const int tpp = cg_total < 256 ? cg_total : 256;
   const int rows = 256 / tpp;
   long blocks = (npix + (long)rows * 4 - 1) / ((long)rows * 4);
   blocks = blocks < 1 ? 1 : (blocks > 4096 / groups ? 4096 / groups : blocks);
-  DISPATCH_T(dtype, bn_bwd_apply_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, s, (const uint16_t*)x,
-             (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, (uint16_t*)dx, (uint16_t*)dz_out, (long)npix,
-             cs, act, act_slope);
+#define BN_BWD_APPLY(M)                                                                                               \
+  DISPATCH_T2(dtype, bn_bwd_apply_kernel, M, dim3((unsigned)blocks, groups), dim3(256), 0, s, (const uint16_t*)x,     \
+              (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, fold_mean, fold_rstd, (uint16_t*)dx,     \
+              (uint16_t*)dz_out, (long)npix, cs, gneg)
+  if (mask == 0) { BN_BWD_APPLY(0); } else if (mask == 1) { BN_BWD_APPLY(1); } else { BN_BWD_APPLY(2); }
+#undef BN_BWD_APPLY
   CGAN_CHECK_LAUNCH("batchnorm_act_bwd");
   return CGAN_OK;
 }

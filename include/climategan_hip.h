@@ -328,6 +328,9 @@ int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const f
  *                     running statistics (momentum, unbiased variance) as nn.BatchNorm2d does; count = n*h*w;
  *                     num_batches_tracked (device int64 scalar, may be NULL) is incremented by one
  *  batchnorm_act_bwd  given x (the BN input), out = act(bn(x) [+ residual]) and dy: dx, and dgamma / dbeta
+ *                     (out may be NULL when no residual was fused: act'(.) is then recomputed from x with fold_mean /
+ *                     fold_rstd -- the mean_out / rstd_out rows the forward's statistics call wrote, i.e. the forward
+ *                     apply's own arithmetic -- and the kernels read one map less per pass; with out given both may be NULL)
  *                     WRITTEN (fp32 [c], no zero fill needed; either may be NULL); dz_out (may be NULL) receives dz = dy * act'(out), the gradient of the
  *                     residual fused by cgan_norm_add_act_apply; workspace cgan_batchnorm_act_bwd_workspace_bytes(c) */
 int cgan_bn_train_prepare(const float* batch_mean, const float* batch_rstd, const float* gamma, const float* beta,
@@ -348,18 +351,19 @@ int cgan_batchnorm_train_stats_from_partials(const float* partial, int32_t chunk
                                              float* mean_out, float* rstd_out, const CganNormStatsDesc* d, void* stream);
 size_t cgan_batchnorm_act_bwd_workspace_bytes(int32_t c);   /* per group */
 int cgan_batchnorm_act_bwd(const void* x, const void* out, const void* dy, const float* batch_mean,
-                           const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                           void* dz_out, int32_t dtype, int64_t npix, int32_t c, int32_t act, float act_slope,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           const float* batch_rstd, const float* gamma, const float* fold_mean, const float* fold_rstd,
+                           void* dx, float* dgamma, float* dbeta, void* dz_out, int32_t dtype, int64_t npix, int32_t c,
+                           int32_t act, float act_slope, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with the batch split into `groups` equal slices that are normalised independently (cgan_batchnorm_train_stats
  * with d->n = groups): what the reference does when it passes the real and the simulated domain batch through the
  * Masker in separate forward calls (trainer.py:1200-1254) -- here one launch sequence over the concatenated batch.
  * batch_mean / batch_rstd: [groups][cgan_cs(c)]; dgamma / dbeta: summed over the groups; npix_total = all pixels;
  * workspace: groups * cgan_batchnorm_act_bwd_workspace_bytes(c). */
 int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, const void* dy, const float* batch_mean,
-                                   const float* batch_rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                                   void* dz_out, int32_t dtype, int64_t npix_total, int32_t c, int32_t groups,
-                                   int32_t act, float act_slope, void* workspace, size_t workspace_bytes, void* stream);
+                                   const float* batch_rstd, const float* gamma, const float* fold_mean,
+                                   const float* fold_rstd, void* dx, float* dgamma, float* dbeta, void* dz_out,
+                                   int32_t dtype, int64_t npix_total, int32_t c, int32_t groups, int32_t act,
+                                   float act_slope, void* workspace, size_t workspace_bytes, void* stream);
 /* nn.BCEWithLogitsLoss(x, target) pieces against a constant target (GANLoss, climategan/losses.py:50-83; ADVENT
  * D-side BCE, losses.py:461-477) over the c logical channels of x [npix][cgan_cs(c)]:
  * *loss_accum += weight * sum(max(x,0) - x t + log1p(exp(-|x|))), dx = weight * (sigmoid(x) - t); dx may be NULL. */
