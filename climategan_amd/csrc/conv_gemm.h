@@ -36,3 +36,99 @@ int conv_gemm_big_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
 // conv1x1_xres.hip: short-K (cin <= 256) 1x1 layers, activation tile resident in LDS, all couts per workgroup
 bool conv1x1_xres_ok(const ConvGemmArgs& a);
 int conv1x1_xres_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
+
+#ifdef __HIPCC__
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four row rotations on the
+// VALU's data-parallel-primitive path (__shfl_xor compiles to ds_bpermute_b32: an LDS instruction per step and value)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
+// Training-mode BatchNorm statistics from a wave's accumulator tile acc[WC][WP] (lane (j, g) holds channels
+// ct*16 + 4g + {0..3} of pixel (tile, j)): one (mean, M2) pair per channel over the wave's WP x 16 pixels = statistics
+// chunk ``chunk``, written to p.stats [chunk][cout_s][2].  The bias, if any, is folded into the accumulators first (the
+// caller's store path must then skip it).  Shared by conv_gemm_kernel and conv_gemm_big_kernel.
+template <typename T, int WC, int WP>
+__device__ __forceinline__ void conv_gemm_stats_epilogue(f32x4 (&acc)[WC][WP], const ConvGemmArgs& p, int cout_base,
+                                                         int chunk, int j, int g) {
+  if (p.bias) {
+    // statistics are of the values AS STORED = round(acc + bias): fold the bias into the accumulators here and let the
+    // store path skip it (wave-uniform branch)
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+      const int chb = cout_base + c * 16 + 4 * g;
+      const f32x4 b = chb < p.cout_s ? *reinterpret_cast<const f32x4*>(p.bias + chb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < WP; ++t) acc[c][t] += b;
+    }
+  }
+  // training-mode BatchNorm statistics from the accumulators: (mean, M2) of this wave's WP x 16 pixels per channel --
+  // sum and sum of squares over the wave's pixel tiles, then over the 16 lanes (pixels) that share a channel quad; the
+  // finalize kernel of norm_stats.hip merges the chunks with Chan's formula.  Every chunk is full (the dispatcher
+  // checked npix against the chunk size), pixels past npix do not exist here.
+  constexpr float inv_cnt = 1.f / (float)(WP * 16);
+#pragma unroll
+  for (int c = 0; c < WC; ++c) {
+    // Statistics of the values AS STORED (rounded to the 16-bit type), not of the fp32 accumulators: a channel whose
+    // spread is below the rounding step of its mean (post-ReLU inputs make such channels) is pure rounding noise in y,
+    // and only the stored values' own variance normalises that noise to unit size -- with the accumulators' (true,
+    // much smaller) variance it was amplified (batch variances up to 30 % apart in layer3 / layer4, the encoder's
+    // gradient 2 % longer and 0.02 further from the reference's direction: tests/test_gpu_configs_640.py).
+    // Two passes, pairs of channels on the packed-fp32 VALU path: the chunk mean first, then M2 = sum (v - mean)^2
+    // (the one-pass form sum v^2 - (sum v)^2 / n cancels where the mean is large against the spread).
+    f32x2 vr[WP][2];
+#pragma unroll
+    for (int t = 0; t < WP; ++t) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float r0, r1;
+        unpack2<T>(pack2<T>(acc[c][t][2 * hh], acc[c][t][2 * hh + 1]), r0, r1);
+        vr[t][hh] = (f32x2){r0, r1};
+      }
+    }
+    f32x2 s0[2] = {vr[0][0], vr[0][1]};      // (no "0 + v": that is a packed add with an op_sel-modified constant)
+#pragma unroll
+    for (int t = 1; t < WP; ++t) {
+      s0[0] += vr[t][0];
+      s0[1] += vr[t][1];
+    }
+    float sm[4], sq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm[r] = row16_sum(s0[r >> 1][r & 1]) * inv_cnt;     // the chunk mean, in every lane of the row
+    const f32x2 m2[2] = {(f32x2){sm[0], sm[1]}, (f32x2){sm[2], sm[3]}};
+    f32x2 s1[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x2 dv = vr[0][hh] - m2[hh];
+      s1[hh] = dv * dv;
+    }
+#pragma unroll
+    for (int t = 1; t < WP; ++t)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x2 dv = vr[t][hh] - m2[hh];
+        s1[hh] += dv * dv;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sq[r] = row16_sum(s1[r >> 1][r & 1]);
+    const int ch = cout_base + c * 16 + 4 * g;
+    if (j == 0 && ch < p.cout_s) {
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[2 * r] = sm[r];
+        o[2 * r + 1] = sq[r];
+      }
+      float* dst = p.stats + ((size_t)chunk * p.cout_s + ch) * 2;
+      *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+#endif

@@ -27,24 +27,12 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_gemm_zeros[4];
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int NSTAGE = 3;
 // development knob (cgan_debug_set_gemm_ws): 0 = automatic, 1 = never a K = 64 kernel, 5 / 6 = force conv_gemm_k64_kernel,
 // 8 = force the 256 x 256 kernel of conv_gemm_big.hip, 10 = force the direct 1x1 kernel of conv1x1_direct.hip,
 // 9 = automatic without those two and without the x-resident 1x1 kernel, 11 = force conv1x1_xres.hip, 12 = automatic
 // without it
 CGAN_KNOB(int, g_gemm_ws, 0);
-
-// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), left in every lane of the row: four row rotations on the
-// VALU's data-parallel-primitive path (__shfl_xor compiles to ds_bpermute_b32: an LDS instruction per step and value)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
-  return v;
-}
 
 __device__ __forceinline__ int reflect_i(int i, int n) {
   if (i < 0) i = -i;
@@ -202,81 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   // A wave's statistics chunk is whole or absent: npix is a multiple of the chunk (the dispatcher checked), but not
   // necessarily of the workgroup's pixel count -- the trailing waves of the last block own no pixel and no partial row.
   if (p.stats && (pblk * PT_BLK + wp * WP) * 16 < p.npix) {
-    if (p.bias) {
-      // statistics are of the values AS STORED = round(acc + bias): fold the bias into the accumulators here and let the
-      // store path skip it (wave-uniform branch)
-#pragma unroll
-      for (int c = 0; c < WC; ++c) {
-        const int chb = cout_base + c * 16 + 4 * g;
-        const f32x4 b = chb < p.cout_s ? *reinterpret_cast<const f32x4*>(p.bias + chb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < WP; ++t) acc[c][t] += b;
-      }
-      bias_ep = nullptr;
-    }
-    // training-mode BatchNorm statistics from the accumulators: (mean, M2) of this wave's WP x 16 pixels per channel --
-    // sum and sum of squares over the wave's pixel tiles, then over the 16 lanes (pixels) that share a channel quad; the
-    // finalize kernel of norm_stats.hip merges the chunks with Chan's formula.  Every chunk is full (the dispatcher
-    // checked npix against the chunk size), pixels past npix do not exist here.
-    const int chunk = pblk * WAVES_P + wp;
-    constexpr float inv_cnt = 1.f / (float)(WP * 16);
-#pragma unroll
-    for (int c = 0; c < WC; ++c) {
-      // Statistics of the values AS STORED (rounded to the 16-bit type), not of the fp32 accumulators: a channel whose
-      // spread is below the rounding step of its mean (post-ReLU inputs make such channels) is pure rounding noise in y,
-      // and only the stored values' own variance normalises that noise to unit size -- with the accumulators' (true,
-      // much smaller) variance it was amplified (batch variances up to 30 % apart in layer3 / layer4, the encoder's
-      // gradient 2 % longer and 0.02 further from the reference's direction: tests/test_gpu_configs_640.py).
-      // Two passes, pairs of channels on the packed-fp32 VALU path: the chunk mean first, then M2 = sum (v - mean)^2
-      // (the one-pass form sum v^2 - (sum v)^2 / n cancels where the mean is large against the spread).
-      f32x2 vr[WP][2];
-#pragma unroll
-      for (int t = 0; t < WP; ++t) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          float r0, r1;
-          unpack2<T>(pack2<T>(acc[c][t][2 * hh], acc[c][t][2 * hh + 1]), r0, r1);
-          vr[t][hh] = (f32x2){r0, r1};
-        }
-      }
-      f32x2 s0[2] = {vr[0][0], vr[0][1]};      // (no "0 + v": that is a packed add with an op_sel-modified constant)
-#pragma unroll
-      for (int t = 1; t < WP; ++t) {
-        s0[0] += vr[t][0];
-        s0[1] += vr[t][1];
-      }
-      float sm[4], sq[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm[r] = row16_sum(s0[r >> 1][r & 1]) * inv_cnt;     // the chunk mean, in every lane of the row
-      const f32x2 m2[2] = {(f32x2){sm[0], sm[1]}, (f32x2){sm[2], sm[3]}};
-      f32x2 s1[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const f32x2 dv = vr[0][hh] - m2[hh];
-        s1[hh] = dv * dv;
-      }
-#pragma unroll
-      for (int t = 1; t < WP; ++t)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const f32x2 dv = vr[t][hh] - m2[hh];
-          s1[hh] += dv * dv;
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sq[r] = row16_sum(s1[r >> 1][r & 1]);
-      const int ch = cout_base + c * 16 + 4 * g;
-      if (j == 0 && ch < p.cout_s) {
-        float o[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[2 * r] = sm[r];
-          o[2 * r + 1] = sq[r];
-        }
-        float* dst = p.stats + ((size_t)chunk * p.cout_s + ch) * 2;
-        *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-      }
-    }
+    conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * WAVES_P + wp, j, g);
+    if (p.bias) bias_ep = nullptr;       // folded into the accumulators: the store path skips it (wave-uniform)
   }
   const bool plain = !bias_ep && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
 #pragma unroll
@@ -673,7 +588,7 @@ Choice choose(const ConvGemmArgs& a, bool bf16) {
   const int ptiles = ceil_div(a.npix, 16);
   const bool no_big = g_gemm_ws == 9;
   const bool no_xres = g_gemm_ws == 9 || g_gemm_ws == 12;
-  const int ws = (no_big || no_xres) ? 0 : g_gemm_ws;
+  const int ws = (no_big || no_xres || g_gemm_ws == 13 || g_gemm_ws == 14) ? 0 : g_gemm_ws;     // 13: automatic as before round 4's long-K 1x1 rule
   switch (ws) {
     case 5: if (k64_ok(a)) return {KIND_K64_256x128, 0}; break;         // K = 64 stages, 256 couts x 128 pixels
     case 6: if (k64_ok(a)) return {KIND_K64_128x256, 0}; break;         // K = 64 stages, 128 x 256
@@ -700,8 +615,15 @@ Choice choose(const ConvGemmArgs& a, bool bf16) {
   // win where K is long enough to amortise a prologue and an epilogue that nothing overlaps with one workgroup per CU
   // -- 512 -> 512 3x3 at 8 x 80^2 289 -> 256 us, at 4 x 80^2 163 -> 135 us, 2048 -> 512 1x1 181 -> 157 us -- and lose on the
   // short-K bottleneck layers (256 -> 1024 1x1: 68 -> 118 us, 256 -> 256 3x3: 72 -> 84 us at 200 tiles for 256 CUs)
-  if (automatic && !no_big && conv_gemm_big_ok(a) && a.npix >= 16384 && a.cin_s * a.kh * a.kw >= 4096 && a.cin_s >= 512 &&
-      !(a.kh * a.kw >= 9 && a.cin_s >= 2048))
+  // Round 4, cold operands (tools/micro/gemm_yardstick2.py, hipBLASLt beside it): the 1x1 layers with >= 1024 input
+  // channels too -- 2048 -> 512 182 -> 114 us (hipBLASLt 116), 1024 -> 256 42.8 -> 35.2 (37.3), 1024 -> 2048 304 -> 226
+  // (244), 1024 -> 512 91 -> 65 (58), and 512 -> 2048 178 -> 147 (178) -- now that the kernel writes the BatchNorm
+  // statistics from its epilogue as well
+  const bool long_1x1 = a.kh * a.kw == 1 && g_gemm_ws != 13 &&
+                        (g_gemm_ws == 14 ? (a.cin_s >= 2048 || (a.cin_s >= 512 && a.ctiles >= 128))
+                                         : (a.cin_s >= 1024 || (a.cin_s >= 512 && a.ctiles >= 128)));
+  if (automatic && !no_big && conv_gemm_big_ok(a) && a.npix >= 16384 &&
+      ((a.cin_s * a.kh * a.kw >= 4096 && a.cin_s >= 512 && !(a.kh * a.kw >= 9 && a.cin_s >= 2048)) || long_1x1))
     return {KIND_BIG, 0};
   // long-K 3x3 layers (>= 512 input channels: ASPP's 2048 -> 256): the K = 64 / whole-line producer / consumer kernel,
   // 14-16 % faster than the plain one there (rocprofv3, bs 8: 2048 -> 256 d6 538 -> 459 us); everywhere else it is slower
@@ -769,6 +691,7 @@ int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
 int conv_gemm_stats_chunk_pixels(const ConvGemmArgs& a, int dtype) {
   const Choice ch = choose(a, dtype == CGAN_BF16);
   if (ch.kind == KIND_XRES) return a.npix % 128 == 0 ? 128 : 0;   // a wave's 8 pixel tiles
+  if (ch.kind == KIND_BIG) return a.npix % 64 == 0 ? 64 : 0;      // eight waves of 128 couts x 64 pixels
   if (ch.kind != KIND_PLAIN) return 0;
   const int ppb = ch.cfg == 3 ? 128 : 64;        // WP x 16 pixels of a wave: <.,.,8> -> 128, <.,.,4> -> 64
   return a.npix % ppb == 0 ? ppb : 0;

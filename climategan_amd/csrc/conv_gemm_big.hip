@@ -247,7 +247,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   __builtin_amdgcn_s_barrier();                               // every wave is done with the operand rings
   unsigned char* stg = smem + wave * (PP * 16 * ROWB);
   const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
-  const bool plain = !p.bias && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
+  const float* bias_ep = p.bias;       // the bias the store path still has to add
+  // training-mode BatchNorm statistics of this wave's WP x 16 pixels (one chunk; whole or absent, as in conv_gemm_kernel)
+  if (p.stats && (pblk * PT_BLK + wp * WP) * 16 < p.npix) {
+    conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * (NW / 2) + wp, j16, g);
+    if (p.bias) bias_ep = nullptr;
+  }
+  const bool plain = !bias_ep && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
   auto epilogue_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
 #pragma unroll
@@ -268,8 +274,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (!plain) {     // wave-uniform: convs without bias / residual / activation / pad channels skip all of it
-        if (p.bias) {     // (padded to whole cout tiles: two 16-byte loads)
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch + 4);
+        if (bias_ep) {     // (padded to whole cout tiles: two 16-byte loads)
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] += b0[r];
