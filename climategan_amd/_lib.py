@@ -111,6 +111,7 @@ _SIGNATURES = {
     "cgan_spade_packed_weight_bytes": (C.c_size_t, [C.POINTER(SpadeDesc)]),
     "cgan_spade_pack_weights": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
     "cgan_spade_fused_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
+    "cgan_spade_fused_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
     "cgan_spectral_norm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cgan_spectral_norm_power_iter": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     "cgan_spectral_norm_power_iter_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -280,6 +280,9 @@ class InstNormActFn(torch.autograd.Function):
         return dx.t, None, None, None, None
 
 
+_SPADE_REMAT_GAMMA = os.environ.get("CGAN_SPADE_REMAT_GAMMA") == "1"
+
+
 class SpadeFn(torch.autograd.Function):
     """y = act(param_free_norm(up?(x)) * (1 + gamma(cond)) + beta(cond)) (reference norms.py:174-186 + the block's
     LeakyReLU); the norm is an instance norm (Painter) or, with cfg["batch_stats"], a training-mode batch norm whose
@@ -295,16 +298,24 @@ class SpadeFn(torch.autograd.Function):
     def forward(ctx, x_t, cond_t, mean, rstd, w_sh, b_sh, w_g, b_g, w_b, b_b, packed, cfg):
         x = ops.NHWC(x_t, cfg["c"])
         cond = ops.NHWC(cond_t, cfg["cond_c"])
-        y = ops.spade_fused(x, mean, rstd, cond, packed, act=cfg["act"], slope=cfg["slope"],
-                            x_upsample=cfg["x_upsample"])
+        # training: the kernel also writes gamma (2 bytes per element) -- the backward then does not re-run mlp_gamma's
+        # 128 -> C convolution over the re-materialised hidden map (CGAN_SPADE_REMAT_GAMMA=1: the old path, for A/B)
+        gamma_t = None
+        if _SPADE_REMAT_GAMMA or not any(ctx.needs_input_grad):
+            y = ops.spade_fused(x, mean, rstd, cond, packed, act=cfg["act"], slope=cfg["slope"],
+                                x_upsample=cfg["x_upsample"])
+        else:
+            y, gamma = ops.spade_fused(x, mean, rstd, cond, packed, act=cfg["act"], slope=cfg["slope"],
+                                       x_upsample=cfg["x_upsample"], want_gamma=True)
+            gamma_t = gamma.t
         ctx.cfg = cfg
-        ctx.save_for_backward(x_t, cond_t, mean, rstd, y.t, w_sh, b_sh, w_g, b_g, w_b, b_b)
+        ctx.save_for_backward(x_t, cond_t, mean, rstd, y.t, w_sh, b_sh, w_g, b_g, w_b, b_b, gamma_t)
         return y.t
 
     @staticmethod
     def backward(ctx, dy_t):
         cfg = ctx.cfg
-        x_t, cond_t, mean, rstd, y_t, w_sh, b_sh, w_g, b_g, w_b, b_b = ctx.saved_tensors
+        x_t, cond_t, mean, rstd, y_t, w_sh, b_sh, w_g, b_g, w_b, b_b, gamma_t = ctx.saved_tensors
         c, dt = cfg["c"], y_t.dtype
         x, y = ops.NHWC(x_t, c), ops.NHWC(y_t, c)
         dy = ops.NHWC(dy_t.contiguous(), c)
@@ -312,7 +323,7 @@ class SpadeFn(torch.autograd.Function):
         # re-materialise seg -> hidden -> gamma at full resolution
         seg = ops.resize_nearest(ops.NHWC(cond_t, cfg["cond_c"]), (h, w), cs_out=ops.cs8(cfg["cond_c"]))
         actv = ops.conv2d(seg, ops.pack_conv_weight(w_sh, b_sh, dt), pad=1, act=ops.ACT_RELU)
-        gamma = ops.conv2d(actv, ops.pack_conv_weight(w_g, b_g, dt), pad=1)
+        gamma = ops.NHWC(gamma_t, c) if gamma_t is not None else ops.conv2d(actv, ops.pack_conv_weight(w_g, b_g, dt), pad=1)
         dgb, xhat, dxhat = ops.spade_bwd_prepare(dy, y, x, mean, rstd, gamma, act=cfg["act"], slope=cfg["slope"],
                                                  x_upsample=cfg["x_upsample"])
         del gamma

@@ -61,6 +61,7 @@ struct SpadeParams {
   const u32x4* w_gb;    // [nt][36][64]
   const float* b_gb;    // [nt][16]  (gamma bias + 1 | beta bias), zero on pad channels
   uint16_t* y;
+  uint16_t* gamma;      // training: the modulation map gamma (bias included, without the +1) [n][h][w][cs] for the backward, or null
   int n, h, w, c, cs, nt;
   int hx, wx, x_ups;
   int cond_h, cond_w, cond_c, cond_cs, ksh;
@@ -127,7 +128,9 @@ __device__ __forceinline__ int actv_addr(int q, int slot) {
 //         hidden map: cond gather -> small MFMAs -> ReLU -> LDS).  All 8 waves fit the 128-VGPR budget of 4 waves per
 //         SIMD (NCT <= 4), so with two co-resident workgroups every SIMD has two MFMA streams and two producer streams to
 //         pick from: the MFMA stream of a workgroup no longer waits on the producer chains of its own wave.
-template <typename T, int NCT, bool C4, int NW>
+// GM: the training form that also writes gamma (p.gamma); a template parameter so that the inference kernels keep their
+// register allocation (as a run-time branch it cost the NCT = 4 / 5 consumers 2 / 8 more spilled registers).
+template <typename T, int NCT, bool C4, int NW, bool GM>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_fused_kernel(SpadeParams p) {   // 2nd arg: waves per SIMD
   constexpr int WAVES = NW;               // shadows the namespace constant inside this kernel
   constexpr bool SPEC = NW == 8;          // wave-specialised: consumers 0-3, producers 4-7
@@ -519,6 +522,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
     __builtin_amdgcn_s_setprio(2);
     const bool lrelu_max = p.slope >= 0.f && p.slope <= 1.f;
     unsigned char* xt = actv;   // [256 px][NCT * 16 B]
+    // training (p.gamma): gamma leaves through the OTHER hidden buffer in the same layout -- the backward reads it instead
+    // of re-running the 128 -> C convolution over a re-materialised hidden map.  That buffer is free once every wave has
+    // left the K loop: one more workgroup barrier (the producers meet it at the end of run_producer).
+    unsigned char* gt = actv + ACTV_Q_BYTES;
+    static_assert(MAX_NCT * 4096 <= ACTV_Q_BYTES, "a 256-pixel x NCT-tile staging block fits one hidden buffer");
+    if (GM) COUNTED_BARRIER(0);
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
       const int cg = C0 + c;      // channel tile within the workgroup's chunk
@@ -559,6 +568,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
           if (ch + 1 >= p.c) o1 = 0.f;
         }
         *slot = pack2<T>(o0, o1);   // each lane reads and rewrites only its own 4 bytes
+        if (GM) {
+          float g0 = gm0 - 1.f, g1 = gm1 - 1.f;      // the packed bias carries the "1 +"
+          if (tile_pad) {
+            if (ch >= p.c) g0 = 0.f;
+            if (ch + 1 >= p.c) g1 = 0.f;
+          }
+          *reinterpret_cast<uint32_t*>(gt + (pix * NCT + cg) * 16 + chan_in_tile * 2) = pack2<T>(g0, g1);
+        }
       }
     }
   };
@@ -618,6 +635,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
       }
     }
     TS(5);
+    if (GM) COUNTED_BARRIER(0);   // the consumers' "every wave has left the K loop" barrier (epilogue, training)
   };
   if (!SPEC || wave < 4) {
     run(std::integral_constant<int, 0>{}, std::integral_constant<int, NCT>{});
@@ -635,6 +653,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
       if (id < NCT * 256 && yy < p.h && xx < p.w && cc < nchunk)
         *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w + xx) * p.cs + (nt0 + cc) * 8) =
             *reinterpret_cast<const u32x4*>(xt + id * 16);
+    }
+    if (GM) {
+      const unsigned char* gts = actv + ACTV_Q_BYTES;
+#pragma unroll
+      for (int k = 0; k < (NCT * 256 + WAVES * 64 - 1) / (WAVES * 64); ++k) {
+        const int id = k * (WAVES * 64) + threadIdx.x;
+        const int pix = id / NCT, cc = id - pix * NCT;
+        const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
+        if (id < NCT * 256 && yy < p.h && xx < p.w && cc < nchunk)
+          *reinterpret_cast<u32x4*>(p.gamma + (((size_t)n * p.h + yy) * p.w + xx) * p.cs + (nt0 + cc) * 8) =
+              *reinterpret_cast<const u32x4*>(gts + id * 16);
+      }
     }
   }
   TS(6);
@@ -739,8 +769,8 @@ int check(const CganSpadeDesc* d) {
   return CGAN_OK;
 }
 
-template <typename T, int NCT, bool C4, int NW>
-int launch(const SpadeParams& p0, hipStream_t s) {
+template <typename T, int NCT, bool C4, int NW, bool GM>
+int launch_gm(const SpadeParams& p0, hipStream_t s) {
   SpadeParams p = p0;
   p.tiles_y = ceil_div(p.h, TH);
   p.tiles_x = ceil_div(p.w, TW);
@@ -749,7 +779,7 @@ int launch(const SpadeParams& p0, hipStream_t s) {
   size_t smem = (size_t)2 * ACTV_Q_BYTES + (size_t)NBUF * 3 * NCT * 1024 + (size_t)NCT * 32 * 4 + align16((size_t)CTH * CTW * p.cond_cs * 2) + (C4 ? 0 : (size_t)p.ksh * 32 * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_kernel<T, NCT, C4, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spade_fused_kernel<T, NCT, C4, NW, GM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("spade_fused_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -757,8 +787,13 @@ int launch(const SpadeParams& p0, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((spade_fused_kernel<T, NCT, C4, NW>), dim3(tiles, chunks), dim3(NW * 64), smem, s, p);
+  hipLaunchKernelGGL((spade_fused_kernel<T, NCT, C4, NW, GM>), dim3(tiles, chunks), dim3(NW * 64), smem, s, p);
   return CGAN_OK;
+}
+
+template <typename T, int NCT, bool C4, int NW>
+int launch(const SpadeParams& p, hipStream_t s) {
+  return p.gamma ? launch_gm<T, NCT, C4, NW, true>(p, s) : launch_gm<T, NCT, C4, NW, false>(p, s);
 }
 
 template <typename T, bool C4>
@@ -827,6 +862,12 @@ extern "C" int cgan_spade_pack_weights(const float* w_shared, const float* b_sha
 
 extern "C" int cgan_spade_fused_fwd(const void* x, const float* mean, const float* rstd, const void* cond,
                                     const void* packed, void* y, const CganSpadeDesc* d, void* stream) {
+  return cgan_spade_fused_fwd_train(x, mean, rstd, cond, packed, y, nullptr, d, stream);
+}
+
+extern "C" int cgan_spade_fused_fwd_train(const void* x, const float* mean, const float* rstd, const void* cond,
+                                          const void* packed, void* y, void* gamma_out, const CganSpadeDesc* d,
+                                          void* stream) {
   int rc = check(d);
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(x && mean && rstd && cond && packed && y, "spade_fused_fwd: null pointer");
@@ -837,7 +878,7 @@ extern "C" int cgan_spade_fused_fwd(const void* x, const float* mean, const floa
   p.x = (const uint16_t*)x; p.mean = mean; p.rstd = rstd; p.cond = (const uint16_t*)cond;
   p.w_sh = (const u32x4*)(base + L.w_sh);
   p.w_gb = (const u32x4*)(base + L.w_gb); p.b_gb = (const float*)(base + L.b_gb);
-  p.y = (uint16_t*)y;
+  p.y = (uint16_t*)y; p.gamma = (uint16_t*)gamma_out;
   p.n = d->n; p.h = d->h; p.w = d->w; p.c = d->c; p.cs = cs; p.nt = cs / 8;
   p.x_ups = d->x_upsample; p.hx = d->x_upsample ? d->h / 2 : d->h; p.wx = d->x_upsample ? d->w / 2 : d->w;
   p.cond_h = d->cond_h; p.cond_w = d->cond_w; p.cond_c = d->cond_c; p.cond_cs = cgan_cond_cs(d->cond_c);

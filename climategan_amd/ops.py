@@ -1244,8 +1244,10 @@ def pack_spade_weights(w_shared, b_shared, w_gamma, b_gamma, w_beta, b_beta, dty
 
 
 @_batch_chunked("x", "mean", "rstd", "cond", out_bytes_per_sample=lambda g: g("x").h * g("x").w * g("x").cs * 2 * (4 if g("x_upsample") else 1))
-def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, slope=0.2, x_upsample=False) -> NHWC:
-    """Fused SPADE: act((x-mean)*rstd*(1+gamma(cond))+beta(cond)); x optionally read through x2 nearest."""
+def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, slope=0.2, x_upsample=False,
+                want_gamma=False):
+    """Fused SPADE: act((x-mean)*rstd*(1+gamma(cond))+beta(cond)); x optionally read through x2 nearest.
+    ``want_gamma`` (training): returns (y, gamma) -- the kernel also writes the modulation map the backward needs."""
     _need_cuda(x.t, cond.t, mean, rstd)
     if x.c != pk.c or cond.c != pk.cond_c:
         raise RuntimeError("spade_fused: channel mismatch (x %d vs %d, cond %d vs %d)" % (x.c, pk.c, cond.c, pk.cond_c))
@@ -1257,6 +1259,11 @@ def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, 
     d = _spade_desc(x.dtype_id, x.n, h, w, x.c, x_upsample, cond.h, cond.w, cond.c, act, slope)
     y = torch.empty((x.n, h, w, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
+    if want_gamma:
+        gamma = torch.empty_like(y)
+        _lib.check(lib.cgan_spade_fused_fwd_train(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(cond.t), _ptr(pk.buf), _ptr(y),
+                                                  _ptr(gamma), C.byref(d), _stream()), "cgan_spade_fused_fwd_train")
+        return NHWC(y, x.c), NHWC(gamma, x.c)
     _lib.check(lib.cgan_spade_fused_fwd(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(cond.t), _ptr(pk.buf), _ptr(y),
                                         C.byref(d), _stream()), "cgan_spade_fused_fwd")
     return NHWC(y, x.c)

@@ -202,6 +202,12 @@ int cgan_spade_pack_weights(const float* w_shared, const float* b_shared, const 
                             void* stream);
 int cgan_spade_fused_fwd(const void* x, const float* mean, const float* rstd, const void* cond, const void* packed,
                          void* y, const CganSpadeDesc* d, void* stream);
+/* The same launch in training: gamma_out [n][h][w][cgan_cs(c)] (may be NULL = cgan_spade_fused_fwd) also receives the
+ * modulation map gamma = mlp_gamma(actv) (climategan/norms.py:181, bias included, without the "1 +" of norms.py:184), which
+ * the backward needs for d(normalized) = dout * (1 + gamma): 2 bytes per element written here instead of a 128 -> c
+ * convolution over a re-materialised hidden map there. */
+int cgan_spade_fused_fwd_train(const void* x, const float* mean, const float* rstd, const void* cond, const void* packed,
+                               void* y, void* gamma_out, const CganSpadeDesc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectral norm power iteration (climategan/norms.py:100-112), run on every forward:

@@ -226,6 +226,14 @@ def test_spade_fused(dt, case):
     assert_close(back(y), ref, dt, "spade %s" % (case,))
     if ops.cs8(C) != C:
         assert y.t[..., C:].abs().max().item() == 0
+    # the training form of the launch (cgan_spade_fused_fwd_train): the same y bit for bit, plus the modulation map gamma the
+    # backward consumes
+    y2, gam = ops.spade_fused(xn, mean, rstd, to_nhwc(seg, dt, cs=4), pk, act=ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE,
+                              x_upsample=ups, want_gamma=True)
+    assert torch.equal(y2.t, y.t)
+    assert_close(back(gam), gamma, dt, "spade gamma %s" % (case,))
+    if ops.cs8(C) != C:
+        assert gam.t[..., C:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("rows,cols", [(20, 360), (640, 5760), (1, 8192), (64, 64)])
