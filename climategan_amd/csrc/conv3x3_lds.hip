@@ -301,7 +301,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void conv3x3_lds_onechunk_kernel(Con
 //     tile, once per workgroup;
 //   * all couts (<= 8 tiles) in one workgroup, epilogue shared with the kernels above.
 template <typename T, int NCT>
-__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c4_kernel(Conv3x3LdsArgs p) {
+__global__ __launch_bounds__(WAVES * 64, NCT <= 2 ? 8 : (NCT <= 4 ? 4 : 2)) void conv3x3_c4_kernel(Conv3x3LdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -424,8 +424,14 @@ template <typename T>
 int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
   // folded taps for <= 4 input channels stored as 4 / 8 / ... channels per pixel (the packed weights keep one k-step per tap)
   if (g_c4_enabled && a.cin <= 4 && a.cin_p == 32 && a.ksteps == 9 && (a.cin_s & 3) == 0) {
-    if (a.ctiles <= 2) return launch_c4<T, 2>(a, s);
-    if (a.ctiles <= 4) return launch_c4<T, 4>(a, s);
+    // Channel tiles per workgroup.  The workgroup is a latency chain (halo load -> 2 MFMAs per tile -> staged stores); its
+    // epilogue staging (8 KiB per channel tile) decides how many share a CU.  4 x 640^2, 128 couts, same box
+    // (tools/bench_conv.py --c4): 8 tiles (2 per CU) 195 us, 4 tiles 135 us, 2 tiles 135 us; at 320^2 56 / 47 / 39 us --
+    // so 4 tiles (whole 128-byte lines per pixel) on large grids, 2 where the grid would otherwise leave CUs waiting.
+    // (g_c4_enabled 2 / 3: force 8 / 2 tiles -- development knob)
+    const long wg4 = (long)a.n * ((a.h + TH - 1) / TH) * ((a.w_ + TW - 1) / TW) * ceil_div(a.ctiles, 4);
+    if (a.ctiles <= 2 || g_c4_enabled == 3 || (g_c4_enabled == 1 && wg4 < 8192)) return launch_c4<T, 2>(a, s);
+    if (a.ctiles <= 4 || g_c4_enabled != 2) return launch_c4<T, 4>(a, s);
     return launch_c4<T, 8>(a, s);
   }
   // channel tiles per workgroup: the divisor of ctiles (<= 5) with the least padding

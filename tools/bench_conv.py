@@ -33,6 +33,8 @@ SHAPES = [
     ("vgg 3x3 64->128 @320", 64, 128, 3, 1, 1, 1, 320),
     ("vgg 3x3 128->128 @320", 128, 128, 3, 1, 1, 1, 320),
     ("vgg 3x3 128->256 @160", 128, 256, 3, 1, 1, 1, 160),
+    ("spade shared 3x3 3->128 @640", 3, 128, 3, 1, 1, 1, 640),
+    ("spade shared 3x3 3->128 @320", 3, 128, 3, 1, 1, 1, 320),
     ("spade gb 3x3 128->80 @640", 128, 80, 3, 1, 1, 1, 640),
     ("spade gb 3x3 128->160 @320", 128, 160, 3, 1, 1, 1, 320),
 ]
@@ -50,12 +52,14 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare with the plain kernel")
     ap.add_argument("--hw", type=int, default=0, help="override the input extent of every shape")
     ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
+    ap.add_argument("--c4", type=int, default=1, help="cgan_debug_set_conv3x3_c4: 0 no folded-tap kernel, 1 default, 2 all 128 couts per workgroup")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     lib = _lib.load_dev()
     lib.cgan_debug_set_conv_kernel(ctypes.c_int(args.force))
     lib.cgan_debug_set_gemm_cfg(ctypes.c_int(args.cfg))
     lib.cgan_debug_set_gemm_ws(ctypes.c_int(args.ws))
+    lib.cgan_debug_set_conv3x3_c4(ctypes.c_int(args.c4))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
         if args.only not in name:
             continue
