@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
                                                             const uint16_t* __restrict__ dy, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ fmean,
                                                             const float* __restrict__ frstd, float* __restrict__ partial,
-                                                            long npix, int cs, int ppb, float gneg) {
+                                                            uint16_t* __restrict__ dz_out, long npix, int cs, int ppb,
+                                                            float gneg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [PL][cgb*8][2]
   const int cg_total = cs / 8;
   const int cgb = cg_total < 256 ? cg_total : 256;
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
   const size_t gofs = (size_t)blockIdx.z * npix * cs;
   x += gofs; dy += gofs;
   if (MASK == 1) out += gofs;
+  if (dz_out) dz_out += gofs;
   mean += (size_t)blockIdx.z * cs; rstd += (size_t)blockIdx.z * cs;
   if (MASK == 2) { fmean += (size_t)blockIdx.z * cs; frstd += (size_t)blockIdx.z * cs; }
   partial += (size_t)blockIdx.z * gridDim.x * cs * 2;
@@ -359,9 +361,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
       u32x4 vo = {0, 0, 0, 0};
       if (MASK == 1) vo = *reinterpret_cast<const u32x4*>(op + off);
       const u32x4 vg = *reinterpret_cast<const u32x4*>(gp + off);
+      u32x4 z;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float xv[2], ov[2], gv[2];
+        float xv[2], ov[2], gv[2], dzv[2];
         unpack2<T>(vx[e], xv[0], xv[1]);
         unpack2<T>(vo[e], ov[0], ov[1]);
         unpack2<T>(vg[e], gv[0], gv[1]);
@@ -371,8 +374,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
           const float xh = (xv[hh] - mu[2 * e + hh]) * rs[2 * e + hh];
           s1[2 * e + hh] += dz;
           s2[2 * e + hh] += dz * xh;
+          dzv[hh] = dz;
         }
+        z[e] = pack2<T>(dzv[0], dzv[1]);
       }
+      // ReLU with a fused residual: dz = dy or 0 is exact in 16 bits -- written here (it is the residual branch's gradient),
+      // the apply pass then reads (x, dz) instead of (x, out, dy) and writes dx only
+      if (MASK == 1 && dz_out) *reinterpret_cast<u32x4*>(dz_out + cg * 8 + off) = z;
     }
   }
   if (pl < PL) {
@@ -862,10 +870,12 @@ extern "C" int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, co
   // where act' comes from: nothing to mask / from out (given: a residual may have been fused) / recomputed from x
   const int mask = act == CGAN_ACT_NONE ? 0 : (out ? 1 : 2);
   const float gneg = act == CGAN_ACT_RELU ? 0.f : act_slope;
+  // ReLU + fused residual: the reduce pass writes dz (exact in 16 bits), the apply pass runs on (x, dz) without a mask
+  uint16_t* dz_early = (mask == 1 && dz_out && act == CGAN_ACT_RELU) ? (uint16_t*)dz_out : nullptr;
 #define BN_BWD_REDUCE(M)                                                                                              \
   DISPATCH_T2(dtype, bn_bwd_reduce_kernel, M, dim3((unsigned)chunks, cgblocks, groups), dim3(256), smem, s,           \
               (const uint16_t*)x, (const uint16_t*)out, (const uint16_t*)dy, batch_mean, batch_rstd, fold_mean,       \
-              fold_rstd, partial, (long)npix, cs, (int)ppb, gneg)
+              fold_rstd, partial, dz_early, (long)npix, cs, (int)ppb, gneg)
   if (mask == 0) { BN_BWD_REDUCE(0); } else if (mask == 1) { BN_BWD_REDUCE(1); } else { BN_BWD_REDUCE(2); }
 #undef BN_BWD_REDUCE
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cs / 8), dim3(256), 0, s, (const float*)partial, (int)chunks,
@@ -878,7 +888,11 @@ extern "C" int cgan_batchnorm_act_bwd_grouped(const void* x, const void* out, co
   DISPATCH_T2(dtype, bn_bwd_apply_kernel, M, dim3((unsigned)blocks, groups), dim3(256), 0, s, (const uint16_t*)x,     \
               (const uint16_t*)out, (const uint16_t*)dy, (const float*)coef, fold_mean, fold_rstd, (uint16_t*)dx,     \
               (uint16_t*)dz_out, (long)npix, cs, gneg)
-  if (mask == 0) { BN_BWD_APPLY(0); } else if (mask == 1) { BN_BWD_APPLY(1); } else { BN_BWD_APPLY(2); }
+  if (dz_early) {
+    DISPATCH_T2(dtype, bn_bwd_apply_kernel, 0, dim3((unsigned)blocks, groups), dim3(256), 0, s, (const uint16_t*)x,
+                (const uint16_t*)nullptr, (const uint16_t*)dz_early, (const float*)coef, fold_mean, fold_rstd,
+                (uint16_t*)dx, (uint16_t*)nullptr, (long)npix, cs, gneg);
+  } else if (mask == 0) { BN_BWD_APPLY(0); } else if (mask == 1) { BN_BWD_APPLY(1); } else { BN_BWD_APPLY(2); }
 #undef BN_BWD_APPLY
   CGAN_CHECK_LAUNCH("batchnorm_act_bwd");
   return CGAN_OK;
