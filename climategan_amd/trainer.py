@@ -17,6 +17,7 @@ import time
 
 import torch
 
+from . import autograd as ag
 from . import ops
 from .generator import create_generator
 from .utils import find_target_size
@@ -79,6 +80,10 @@ class Trainer:
         import os
         self.overlap_branches = os.environ.get("CGAN_OVERLAP", "1") != "0"
         self._side = None
+        # a third stream for the weight-gradient kernels of the calling stream's branch (autograd.WGRAD_STREAM: they leave the
+        # data-gradient chain); CGAN_WGRAD_STREAM=0: on the chain as before (same-box A/B)
+        self._wstream = None
+        self.wgrad_stream = os.environ.get("CGAN_WGRAD_STREAM", "1") != "0"
         # development aid (tools/branch_times.py): [(fork event, end of the main-stream branch, end of the side-stream branch)]
         self.branch_events = [] if os.environ.get("CGAN_BRANCH_TIMES") == "1" else None
 
@@ -580,9 +585,12 @@ class Trainer:
         from .norms import _PackCache
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-            for red in (self.g_reducer, self.d_reducer):           # gradients now come from two streams
+            self._wstream = torch.cuda.Stream(device=self.device) if self.wgrad_stream else None
+            for red in (self.g_reducer, self.d_reducer):           # gradients now come from two (three) streams
                 if red is not None:
-                    red.streams = [torch.cuda.current_stream(self.device), self._side]
+                    red.streams = [torch.cuda.current_stream(self.device), self._side] + \
+                        ([self._wstream] if self._wstream is not None else [])
+        ag.reset_weight_uses()               # forwards of this update count their uses per weight (autograd._wgrad_call)
         _PackCache.repack_stale(dtype, self.device)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         if self.branch_events is not None:
@@ -611,13 +619,22 @@ class Trainer:
             ops.dgrad_prepack_run(side)      # every stride-1 data-gradient operator of this backward, one pack launch
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dev))        # the arena's zeros, the packed operators
-                torch.autograd.backward(list(loss))
+                prev_ws = (ag.WGRAD_STREAM, ag.WGRAD_FROM)
+                if self._wstream is not None:
+                    self._wstream.wait_stream(torch.cuda.current_stream(dev))
+                    ag.WGRAD_STREAM, ag.WGRAD_FROM = self._wstream, torch.cuda.current_stream(dev)
+                try:
+                    torch.autograd.backward(list(loss))
+                finally:
+                    ag.WGRAD_STREAM, ag.WGRAD_FROM = prev_ws
                 if self.branch_events is not None:
                     em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     em.record(torch.cuda.current_stream(dev))
                     es.record(side)
                     self.branch_events[-1][1:] = [em, es]
                 torch.cuda.current_stream(dev).wait_stream(side)        # the optimizer runs on the calling stream
+                if self._wstream is not None:
+                    torch.cuda.current_stream(dev).wait_stream(self._wstream)
             else:
                 loss.backward()
         finally:
