@@ -585,7 +585,11 @@ class Trainer:
         from .norms import _PackCache
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-            self._wstream = torch.cuda.Stream(device=self.device) if self.wgrad_stream else None
+            # (single-process runs only: under the bucket reducer every bucket launch makes the calling stream wait for the
+            # gradient streams, which puts the weight gradients back on the chain -- and with gloo on one device, the
+            # two-rank test configuration, the step doubled: tests/test_gpu_bench_two_ranks.py)
+            single = self.g_reducer is None and self.d_reducer is None
+            self._wstream = torch.cuda.Stream(device=self.device) if (self.wgrad_stream and single) else None
             for red in (self.g_reducer, self.d_reducer):           # gradients now come from two (three) streams
                 if red is not None:
                     red.streams = [torch.cuda.current_stream(self.device), self._side] + \
