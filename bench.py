@@ -315,7 +315,7 @@ def install_all_mfma_timer(timer):
 
     lib = _lib.load()
     names = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add", "cgan_conv2d_nhwc_fwd_stats",
-             "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd")
+             "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd", "cgan_spade_fused_fwd_train")
     orig = {n: getattr(lib, n) for n in names}
     kind = lib.cgan_conv2d_kernel_kind
     KIND = {0: "general", 1: "lds3x3", 2: "gemm"}
@@ -369,7 +369,14 @@ def install_all_mfma_timer(timer):
         return timer.bracket(lambda: orig[names[5]](x, cond, mean, rstd, packed, y, dref, stream), fl, int(nb),
                              "%-7s %-9s n%d %dx%d c%d%s" % ("spade", "fwd", d.n, d.h, d.w, d.c, " ups" if d.x_upsample else ""))
 
-    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade)):
+    def spade_train(x, cond, mean, rstd, packed, y, gamma, dref, stream):      # the training launch also writes gamma
+        d = dref._obj
+        fl = d.n * d.h * d.w * 2.0 * (d.cond_c * 9 * d.hidden + 2 * d.hidden * 9 * d.c)
+        nb = d.n * d.h * d.w * 2 * (cs8(d.c) * (2.25 if d.x_upsample else 3) + 4)
+        return timer.bracket(lambda: orig[names[6]](x, cond, mean, rstd, packed, y, gamma, dref, stream), fl, int(nb),
+                             "%-7s %-9s n%d %dx%d c%d%s" % ("spade", "fwd+gamma", d.n, d.h, d.w, d.c, " ups" if d.x_upsample else ""))
+
+    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train)):
         setattr(lib, n, f)
 
     def uninstall():
@@ -890,7 +897,8 @@ def main():
             # the MFMA families from their descriptors (the brackets above), everything else = the operands handed over
             log, _cl.CALL_LOG = _cl.CALL_LOG, None
             mfma_entries = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add",
-                            "cgan_conv2d_nhwc_fwd_stats", "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd")
+                            "cgan_conv2d_nhwc_fwd_stats", "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd",
+                            "cgan_spade_fused_fwd_train")
             with open(args.call_log, "w") as f:
                 for _e0, _e1, _fl, nb, tg in all_timer.pairs[n0:]:
                     f.write("mfma:%s\t%d\t%s\t%.1f\n" % (tg.split()[0], nb, " ".join(tg.split()), _e0.elapsed_time(_e1) * 1e3))
