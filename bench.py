@@ -287,6 +287,17 @@ def install_conv_gemm_timer(timer):
                                  tag(d, "bwd_data+"))
         return bwd_add(dy, w, dx_add, dx, dref, stream)
 
+    bwd_relu = lib.cgan_conv2d_nhwc_bwd_data_relu
+
+    def timed_bwd_relu(dy, w, relu_out, dx, dref, stream):      # data gradient masked by the ReLU output it flows back into
+        if timer.enabled and kind(dref, 1) == GEMM:
+            d = dref._obj
+            extra = 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)     # the activation's output is read once more
+            return timer.bracket(lambda: bwd_relu(dy, w, relu_out, dx, dref, stream),
+                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d) + extra,
+                                 tag(d, "bwd_data*"))
+        return bwd_relu(dy, w, relu_out, dx, dref, stream)
+
     fwd_stats = lib.cgan_conv2d_nhwc_fwd_stats
 
     def timed_fwd_stats(x, w, b, y, partial, nbytes, dref, stream):     # forward + BatchNorm statistics epilogue: GEMM kernel only
@@ -298,10 +309,12 @@ def install_conv_gemm_timer(timer):
 
     lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = timed_fwd, timed_bwd, timed_bwd_add
     lib.cgan_conv2d_nhwc_fwd_stats = timed_fwd_stats
+    lib.cgan_conv2d_nhwc_bwd_data_relu = timed_bwd_relu
 
     def uninstall():
         lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = fwd, bwd, bwd_add
         lib.cgan_conv2d_nhwc_fwd_stats = fwd_stats
+        lib.cgan_conv2d_nhwc_bwd_data_relu = bwd_relu
     return uninstall
 
 
@@ -315,7 +328,8 @@ def install_all_mfma_timer(timer):
 
     lib = _lib.load()
     names = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add", "cgan_conv2d_nhwc_fwd_stats",
-             "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd", "cgan_spade_fused_fwd_train")
+             "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd", "cgan_spade_fused_fwd_train",
+             "cgan_conv2d_nhwc_bwd_data_relu")
     orig = {n: getattr(lib, n) for n in names}
     kind = lib.cgan_conv2d_kernel_kind
     KIND = {0: "general", 1: "lds3x3", 2: "gemm"}
@@ -376,7 +390,12 @@ def install_all_mfma_timer(timer):
         return timer.bracket(lambda: orig[names[6]](x, cond, mean, rstd, packed, y, gamma, dref, stream), fl, int(nb),
                              "%-7s %-9s n%d %dx%d c%d%s" % ("spade", "fwd+gamma", d.n, d.h, d.w, d.c, " ups" if d.x_upsample else ""))
 
-    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train)):
+    def bwd_relu(dy, w, relu_out, dx, dref, stream):
+        d = dref._obj
+        return timer.bracket(lambda: orig[names[7]](dy, w, relu_out, dx, dref, stream), conv_flops(d),
+                             conv_bytes(d, 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1)], "bwd_data*"))
+
+    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train, bwd_relu)):
         setattr(lib, n, f)
 
     def uninstall():
@@ -898,7 +917,7 @@ def main():
             log, _cl.CALL_LOG = _cl.CALL_LOG, None
             mfma_entries = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add",
                             "cgan_conv2d_nhwc_fwd_stats", "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd",
-                            "cgan_spade_fused_fwd_train")
+                            "cgan_spade_fused_fwd_train", "cgan_conv2d_nhwc_bwd_data_relu")
             with open(args.call_log, "w") as f:
                 for _e0, _e1, _fl, nb, tg in all_timer.pairs[n0:]:
                     f.write("mfma:%s\t%d\t%s\t%.1f\n" % (tg.split()[0], nb, " ".join(tg.split()), _e0.elapsed_time(_e1) * 1e3))
