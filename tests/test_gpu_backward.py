@@ -775,12 +775,14 @@ def test_batched_dgrad_pack_equals_the_per_layer_pack():
     (1024, 256, 1, 0, 1, 8, 40, 40, 2), (256, 256, 3, 2, 2, 8, 40, 40, 2), (256, 128, 3, 1, 1, 4, 64, 64, 1),   # 128 x 128
     (256, 1024, 1, 0, 1, 4, 40, 40, 1), (128, 512, 1, 0, 1, 2, 96, 100, 2),   # 128 x 128, 2-stage ring (short-K 1x1)
     (256, 1024, 1, 0, 1, 8, 80, 80, 2), (128, 512, 1, 0, 1, 4, 64, 64, 1), (64, 256, 1, 0, 1, 2, 128, 128, 2),   # x-resident 1x1 kernel
+    (1024, 256, 1, 0, 1, 8, 80, 80, 2), (512, 2048, 1, 0, 1, 4, 80, 80, 1), (2048, 512, 1, 0, 1, 4, 64, 64, 2),   # 256 x 256 kernel (long-K 1x1)
 ])
 def test_batchnorm_statistics_from_the_conv_epilogue(case):
     _bn_stats_from_epilogue(case, shifted=False)
 
 
-@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 80, 80, 2), (256, 1024, 1, 0, 1, 8, 80, 80, 2), (1024, 256, 1, 0, 1, 8, 40, 40, 2)])
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 80, 80, 2), (256, 1024, 1, 0, 1, 8, 80, 80, 2), (1024, 256, 1, 0, 1, 8, 40, 40, 2),
+                                  (1024, 256, 1, 0, 1, 8, 80, 80, 2)])
 def test_batchnorm_statistics_from_the_conv_epilogue_with_large_channel_means(case):
     """Post-ReLU inputs and weights with a common sign give conv outputs whose channel mean is ten or more standard deviations
     away from zero: the epilogue's M2 must not be formed as sum v^2 - (sum v)^2 / n (round 3: that form cost the encoder 2 %
@@ -795,6 +797,7 @@ def test_batchnorm_statistics_from_the_conv_epilogue_with_large_channel_means(ca
     (256, 256, 3, 1, 1, 3, 40, 40, 1),       # 4800 px
     (128, 512, 1, 0, 1, 6, 56, 56, 1),       # 18816 px = 147 x 128: x-resident kernel, 256-pixel blocks
     (512, 128, 1, 0, 1, 5, 24, 24, 1),       # 2880 px = 45 x 64
+    (1024, 256, 1, 0, 1, 7, 56, 56, 1),      # 21952 px = 343 x 64: the 256 x 256 kernel's last block has three live waves of four
 ])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_conv_epilogue_statistics_stay_inside_their_buffer(case, with_bias):
