@@ -31,7 +31,8 @@ constexpr int NSTAGE = 3;
 // development knob (cgan_debug_set_gemm_ws): 0 = automatic, 1 = never a K = 64 kernel, 5 / 6 = force conv_gemm_k64_kernel,
 // 8 = force the 256 x 256 kernel of conv_gemm_big.hip, 10 = force the direct 1x1 kernel of conv1x1_direct.hip,
 // 9 = automatic without those two and without the x-resident 1x1 kernel, 11 = force conv1x1_xres.hip, 12 = automatic
-// without it
+// without it, 13 = automatic without round 4's long-K 1x1 rule (those layers on the plain tiles), 14 = that rule for layer4's
+// shapes only (same-box A/B of the rule: tools/gpu_ab_env.sh with CGAN_DEV_LIB=1 CGAN_DEBUG_GEMM_WS=13|14|0)
 CGAN_KNOB(int, g_gemm_ws, 0);
 
 __device__ __forceinline__ int reflect_i(int i, int n) {
