@@ -36,7 +36,10 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+# multi-process GPU work on these hosts needs dmabuf IPC (the image exports it; kept for launches from a bare environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
