@@ -54,6 +54,9 @@ __global__ __launch_bounds__(STATS_THREADS) void instnorm_partial_kernel(const u
   float cnt = 0.f;
   if (active) {
     const uint16_t* base = x + (size_t)n * hw * cs + cg * 8;
+    // (four loads in flight per lane: with one, 16 waves per CU kept 16 KB on their way and the pass ran at 1.7 TB/s; the
+    // sums are still formed pixel by pixel in the same order)
+#pragma unroll 4
     for (int p = p0 + pl; p < p1; p += PL) {
       u32x4 v = *reinterpret_cast<const u32x4*>(base + (size_t)p * cs);
 #pragma unroll

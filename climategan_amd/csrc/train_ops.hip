@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const uint16_t* __re
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
   if (pl < PL && cg < cg_total) {
     const size_t base = (size_t)n * hw * cs + cg * 8;
+#pragma unroll 4
     for (int p = p0 + pl; p < p1; p += PL) {
       const u32x4 o = *reinterpret_cast<const u32x4*>(out + base + (size_t)p * cs);
       const u32x4 g = *reinterpret_cast<const u32x4*>(dy + base + (size_t)p * cs);
@@ -157,38 +158,57 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __res
   }
 }
 
+// A thread keeps its 8 channels' per-(n, c) terms in registers and walks the pixels of ONE sample (blockIdx.y): no 64-bit
+// index divisions and no per-element statistic loads in the loop (the flat version spent more on those than on its three maps:
+// 2.2 TB/s).  Same expression, same operation order per element as before.
 template <typename T>
-__global__ void in_bwd_apply_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dy,
-                                    const float* __restrict__ rstd, const float* __restrict__ sums,
-                                    uint16_t* __restrict__ dx, int hw, int cs, int c, int act, float slope,
-                                    long groups) {
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dy,
+                                                           const float* __restrict__ rstd, const float* __restrict__ sums,
+                                                           uint16_t* __restrict__ dx, int hw, int cs, int c, int act,
+                                                           float slope) {
   const int cg_total = cs / 8;
+  const int tpp = cg_total < 256 ? cg_total : 256;   // threads per pixel
+  const int rows = 256 / tpp;
+  const int cgl = threadIdx.x % tpp, prow = threadIdx.x / tpp;
+  if (prow >= rows) return;
+  const int n = blockIdx.y;
   const float inv_hw = 1.f / (float)hw;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % cg_total);
-    const long pix = i / cg_total;
-    const int n = (int)(pix / hw);
-    const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
-    const u32x4 g = reinterpret_cast<const u32x4*>(dy)[i];
-    u32x4 r;
+  const size_t nofs = (size_t)n * hw * cs;
+  out += nofs; dy += nofs; dx += nofs;
+  for (int cg = cgl; cg < cg_total; cg += tpp) {
+    float rs[8], m1[8], m2[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float o0, o1, g0, g1;
-      unpack2<T>(o[e], o0, o1);
-      unpack2<T>(g[e], g0, g1);
-      float res[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ch = cg * 8 + 2 * e + h;
-        float dz, y;
-        in_bwd_terms(h ? o1 : o0, h ? g1 : g0, act, slope, dz, y);
-        const float* sp = sums + ((size_t)n * cs + ch) * 2;
-        const float v = rstd[(size_t)n * cs + ch] * (dz - sp[0] * inv_hw - y * sp[1] * inv_hw);
-        res[h] = ch < c ? v : 0.f;
-      }
-      r[e] = pack2<T>(res[0], res[1]);
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cg * 8 + e;
+      const float* sp = sums + ((size_t)n * cs + ch) * 2;
+      rs[e] = rstd[(size_t)n * cs + ch];
+      m1[e] = sp[0] * inv_hw;
+      m2[e] = sp[1] * inv_hw;
     }
-    reinterpret_cast<u32x4*>(dx)[i] = r;
+#pragma unroll 2
+    for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
+      const size_t off = (size_t)p * cs + cg * 8;
+      const u32x4 o = *reinterpret_cast<const u32x4*>(out + off);
+      const u32x4 g = *reinterpret_cast<const u32x4*>(dy + off);
+      u32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float o0, o1, g0, g1;
+        unpack2<T>(o[e], o0, o1);
+        unpack2<T>(g[e], g0, g1);
+        float res[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = 2 * e + h;
+          float dz, y;
+          in_bwd_terms(h ? o1 : o0, h ? g1 : g0, act, slope, dz, y);
+          const float v = rs[k] * (dz - m1[k] - y * m2[k]);
+          res[h] = cg * 8 + k < c ? v : 0.f;
+        }
+        r[e] = pack2<T>(res[0], res[1]);
+      }
+      *reinterpret_cast<u32x4*>(dx + off) = r;
+    }
   }
 }
 
@@ -203,15 +223,18 @@ __global__ void spade_bwd_prepare_kernel(const uint16_t* __restrict__ dy, const 
                                          uint16_t* __restrict__ dgb, uint16_t* __restrict__ xhat,
                                          uint16_t* __restrict__ dxhat, int h, int w, int c, int cs, int cs2, int x_ups,
                                          int act, float slope, long groups) {
-  const int cg_total = cs / 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % cg_total);
-    const long pix = i / cg_total;
-    const int ox = (int)(pix % w);
-    const long r = pix / w;
-    const int oy = (int)(r % h);
-    const int n = (int)(r / h);
-    const long xoff = x_ups ? (((long)n * (h >> 1) + (oy >> 1)) * (w >> 1) + (ox >> 1)) * cs + cg * 8 : i * 8;
+  const unsigned cg_total = cs / 8;
+  // (32-bit index arithmetic: a map handed to the C ABI is below 2 GiB, i.e. below 2^27 groups; the four 64-bit divisions per
+  // group of the first version cost more than the seven maps the kernel moves)
+  for (long il = (long)blockIdx.x * blockDim.x + threadIdx.x; il < groups; il += (long)gridDim.x * blockDim.x) {
+    const unsigned i = (unsigned)il;
+    const unsigned pix = i / cg_total;
+    const int cg = (int)(i - pix * cg_total);
+    const unsigned r = pix / (unsigned)w;
+    const int ox = (int)(pix - r * (unsigned)w);
+    const int n = (int)(r / (unsigned)h);
+    const int oy = (int)(r - (unsigned)n * (unsigned)h);
+    const long xoff = x_ups ? (((long)n * (h >> 1) + (oy >> 1)) * (w >> 1) + (ox >> 1)) * cs + cg * 8 : (long)i * 8;
     const u32x4 vdy = reinterpret_cast<const u32x4*>(dy)[i];
     const u32x4 vy = reinterpret_cast<const u32x4*>(y)[i];
     const u32x4 vg = reinterpret_cast<const u32x4*>(gamma)[i];
@@ -654,6 +677,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const uint16_t* __restrict__ a,
                                                  float weight, float* __restrict__ loss, uint16_t* __restrict__ da,
                                                  long groups) {
   float acc = 0.f;
+#pragma unroll 2
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
     const u32x4 va = reinterpret_cast<const u32x4*>(a)[i];
     const u32x4 vb = reinterpret_cast<const u32x4*>(b)[i];
@@ -773,9 +797,14 @@ extern "C" int cgan_instnorm_act_bwd(const void* out, const void* dy, const floa
              (const uint16_t*)out, (const uint16_t*)dy, partial, d->hw, cs, ppb, act, act_slope);
   hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->n * cs / 8), dim3(256), 0, s, (const float*)partial, sums,
                      d->n, cs, chunks);
-  const long groups = (long)d->n * d->hw * cg_total;
-  DISPATCH_T(d->dtype, in_bwd_apply_kernel, dim3(grid_for_n(groups)), dim3(256), 0, s, (const uint16_t*)out,
-             (const uint16_t*)dy, rstd, (const float*)workspace, (uint16_t*)dx, d->hw, cs, d->c, act, act_slope, groups);
+  {
+    const int tpp = cg_total < 256 ? cg_total : 256, rows = 256 / tpp;
+    long blocks = (d->hw + (long)rows * 4 - 1) / ((long)rows * 4);          // ~4 pixels per thread
+    const long cap = 8192 / d->n > 0 ? 8192 / d->n : 1;
+    blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+    DISPATCH_T(d->dtype, in_bwd_apply_kernel, dim3((unsigned)blocks, d->n), dim3(256), 0, s, (const uint16_t*)out,
+               (const uint16_t*)dy, rstd, (const float*)workspace, (uint16_t*)dx, d->hw, cs, d->c, act, act_slope);
+  }
   CGAN_CHECK_LAUNCH("instnorm_act_bwd");
   return CGAN_OK;
 }
@@ -944,7 +973,10 @@ extern "C" int cgan_l1_nhwc(const void* a, const void* b, int32_t dtype, int64_t
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "l1: bad dtype %d", dtype);
   CGAN_REQUIRE(numel > 0 && (numel % 8) == 0, "l1: numel must be a positive multiple of 8");
   const long groups = numel / 8;
-  DISPATCH_T(dtype, l1_kernel, dim3(grid_for_n(groups)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+  // at most 2048 blocks (one full round of the chip): every block ends in an atomic on the same address, and 8192 of them
+  // were most of this kernel's time on the large VGG / discriminator maps
+  const int l1_grid = grid_for_n(groups) < 2048 ? grid_for_n(groups) : 2048;
+  DISPATCH_T(dtype, l1_kernel, dim3(l1_grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
              (const uint16_t*)b, weight, loss_accum, (uint16_t*)da, groups);
   CGAN_CHECK_LAUNCH("l1");
   return CGAN_OK;
