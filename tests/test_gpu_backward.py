@@ -798,6 +798,9 @@ def test_batchnorm_statistics_from_the_conv_epilogue_with_large_channel_means(ca
     (128, 512, 1, 0, 1, 6, 56, 56, 1),       # 18816 px = 147 x 128: x-resident kernel, 256-pixel blocks
     (512, 128, 1, 0, 1, 5, 24, 24, 1),       # 2880 px = 45 x 64
     (1024, 256, 1, 0, 1, 7, 56, 56, 1),      # 21952 px = 343 x 64: the 256 x 256 kernel's last block has three live waves of four
+    # whole workgroup tiles (one statistics row per workgroup), every block tile, with and without a bias
+    (2048, 512, 1, 0, 1, 8, 80, 80, 1), (256, 256, 3, 1, 1, 8, 80, 80, 1), (512, 128, 1, 0, 1, 8, 80, 80, 1),
+    (256, 64, 3, 1, 1, 4, 64, 64, 1), (256, 512, 3, 1, 1, 4, 80, 80, 1), (128, 512, 1, 0, 1, 4, 64, 64, 1),
 ])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_conv_epilogue_statistics_stay_inside_their_buffer(case, with_bias):
