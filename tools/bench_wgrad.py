@@ -28,6 +28,8 @@ SHAPES = [
     ("painter 3x3 40->40 @640", 40, 40, 3, 1, 1, 1, 640),
     ("vgg 3x3 64->64 @640", 64, 64, 3, 1, 1, 1, 640),
     ("D 4x4s2 64->128 @320", 64, 128, 4, 2, 2, 1, 320),
+    ("spade sh 3->128 @640", 3, 128, 3, 1, 1, 1, 640),
+    ("spade gb 128->40 @640", 128, 40, 3, 1, 1, 1, 640),
     ("spade gb 128->80 @640", 128, 80, 3, 1, 1, 1, 640),
     ("spade gb 128->160 @320", 128, 160, 3, 1, 1, 1, 320),
     ("vgg 3x3 128->128 @320", 128, 128, 3, 1, 1, 1, 320),
@@ -44,6 +46,7 @@ def main():
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--coop-min", type=int, default=-1, help="cgan_debug_set_wgrad_coop_min_pixels")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--bias", action="store_true", help="with the bias gradient (rides in the weight-gradient kernels)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     lib = _lib.load_dev()
@@ -55,18 +58,19 @@ def main():
         if args.only not in name:
             continue
         bs = args.bs if H < 320 else max(args.bs // 3, 1)
-        x = ops.NHWC(torch.randn(bs, H, H, cin, device="cuda").to(dt), cin)
+        x = ops.NHWC(torch.randn(bs, H, H, ops.cs8(cin), device="cuda").to(dt), cin)       # storage channels: round_up(cin, 8)
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        dy = ops.NHWC(torch.randn(bs, Ho, Ho, cout, device="cuda").to(dt), cout)
+        dy = ops.NHWC(torch.randn(bs, Ho, Ho, ops.cs8(cout), device="cuda").to(dt), cout)
         dw = torch.zeros(cout, cin, k, k, device="cuda")
+        db = torch.zeros(cout, device="cuda")
         for _ in range(2):
-            ops.conv2d_bwd_weight(x, dy, (cout, cin, k, k), stride, pad, dil, want_bias=False, dw=dw, use_workspace=not args.atomic)
+            ops.conv2d_bwd_weight(x, dy, (cout, cin, k, k), stride, pad, dil, want_bias=args.bias, dw=dw, dbias=db if args.bias else None, use_workspace=not args.atomic)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         n = 10
         for _ in range(n):
-            ops.conv2d_bwd_weight(x, dy, (cout, cin, k, k), stride, pad, dil, want_bias=False, dw=dw, use_workspace=not args.atomic)
+            ops.conv2d_bwd_weight(x, dy, (cout, cin, k, k), stride, pad, dil, want_bias=args.bias, dw=dw, dbias=db if args.bias else None, use_workspace=not args.atomic)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
