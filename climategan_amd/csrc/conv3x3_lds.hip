@@ -22,6 +22,7 @@ constexpr int HPW = TW + 2, HPH = TH + 2, HP = HPH * HPW;   // 18 x 18 halo
 constexpr int XDMA = (HP * 4 + 63) / 64;                    // 21 wave-wide DMAs per input chunk
 constexpr int XBUF_BYTES = XDMA * 1024;                     // 21504 (324 px x 64 B + tail of the last DMA)
 constexpr int MAX_NCT = 5;
+CGAN_KNOB(int, g_lds_nct, 0);       // development knob (cgan_debug_set_conv3x3_nct): force the channel tiles per workgroup
 CGAN_KNOB(int, g_c4_enabled, 1);    // development knob (cgan_debug_set_conv3x3_c4): 0 = never the folded-tap kernel
 
 // [halo pixel q][4 slots of 16 B]: logical slot s of pixel q lives at slot position s ^ ((q >> 2) & 3)
@@ -435,6 +436,15 @@ int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
     return launch_c4<T, 8>(a, s);
   }
   // channel tiles per workgroup: the divisor of ctiles (<= 5) with the least padding
+  if (g_lds_nct >= 1 && g_lds_nct <= MAX_NCT) {          // development knob
+    switch (g_lds_nct) {
+      case 1: return launch<T, 1>(a, s);
+      case 2: return launch<T, 2>(a, s);
+      case 3: return launch<T, 3>(a, s);
+      case 4: return launch<T, 4>(a, s);
+      default: return launch<T, 5>(a, s);
+    }
+  }
   int nct = a.ctiles < MAX_NCT ? a.ctiles : MAX_NCT;
   if (a.ctiles > MAX_NCT) {
     int best = MAX_NCT, waste = ceil_div(a.ctiles, MAX_NCT) * MAX_NCT - a.ctiles;
@@ -456,6 +466,7 @@ int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
 }  // namespace
 
 CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv3x3_c4(int v) { g_c4_enabled = v; })
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv3x3_nct(int v) { g_lds_nct = v; })
 
 bool conv3x3_lds_applicable(const CganConvDesc* d) {
   return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && d->pad == 1 &&

@@ -35,6 +35,8 @@ SHAPES = [
     ("vgg 3x3 128->256 @160", 128, 256, 3, 1, 1, 1, 160),
     ("spade shared 3x3 3->128 @640", 3, 128, 3, 1, 1, 1, 640),
     ("spade shared 3x3 3->128 @320", 3, 128, 3, 1, 1, 1, 320),
+    ("spade dgrad 3x3 40->128 @640", 40, 128, 3, 1, 1, 1, 640),
+    ("spade dgrad 3x3 80->128 @640", 80, 128, 3, 1, 1, 1, 640),
     ("spade gb 3x3 128->80 @640", 128, 80, 3, 1, 1, 1, 640),
     ("spade gb 3x3 128->160 @320", 128, 160, 3, 1, 1, 1, 320),
 ]
@@ -52,6 +54,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare with the plain kernel")
     ap.add_argument("--hw", type=int, default=0, help="override the input extent of every shape")
     ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
+    ap.add_argument("--nct", type=int, default=0, help="cgan_debug_set_conv3x3_nct: channel tiles per workgroup of the 3x3 LDS kernel")
     ap.add_argument("--c4", type=int, default=1, help="cgan_debug_set_conv3x3_c4: 0 no folded-tap kernel, 1 default, 2 all 128 couts per workgroup")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -60,6 +63,7 @@ def main():
     lib.cgan_debug_set_gemm_cfg(ctypes.c_int(args.cfg))
     lib.cgan_debug_set_gemm_ws(ctypes.c_int(args.ws))
     lib.cgan_debug_set_conv3x3_c4(ctypes.c_int(args.c4))
+    lib.cgan_debug_set_conv3x3_nct(ctypes.c_int(args.nct))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
         if args.only not in name:
             continue
