@@ -372,7 +372,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const CganPackItem* __restrict__ items) {
   constexpr int CB = 32;                       // channels per unit
-  __shared__ float tile[16][CB * 16 + 1];      // [cout row][c * taps + tap], taps <= 16 staged per pass; +1: bank spread
+  __shared__ float tile[16][CB * 16 + 17];     // [cout row][c * 16 + tap] (tap passes) or the raw layouts below; + pad: bank spread
+  float* tile_flat = &tile[0][0];              // 16 x 529 floats >= 32 x 257 (the data-gradient operator's raw layout)
   const CganPackItem it = items[blockIdx.y];
   // rows / K channels of the packed operator: the forward weight's (c_out, c_in), or -- data-gradient operator -- swapped
   const int n_rows = it.transposed ? it.c_in : it.c_out, n_k = it.transposed ? it.c_out : it.c_in;
@@ -393,10 +394,87 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
     const int c0 = cc * CB, t0 = tp * 16;
     const int nt = min(16, taps - t0);         // taps staged in this pass
     __syncthreads();
-    // ---- load: rows of the OIHW tensor, contiguous in (c, tap).  (c, tap) of a thread's elements advance by constants
+    const bool plain = it.sigma == nullptr;
+    if (taps <= 16) {
+      // ---- RAW staging (all layers but the 7x7 stem): the unit's source floats are copied to LDS exactly as they lie in memory
+      // (16-byte loads where the rows are 16-byte aligned, no per-element (channel, tap) bookkeeping), and the store phase
+      // below picks element (row, channel, tap) out of the raw rows.  Forward operator: 16 rows (couts) of up to CB * taps
+      // contiguous floats, raw[row][c_local * taps + tap]; data-gradient operator: per K channel 16 * taps contiguous floats,
+      // raw[c_local][row * taps + forward tap].  (The first staged version walked (channel, tap) per element with carries
+      // and 4-byte loads: the full pack of the generator's 105 M weights took 340-450 us against 140 us of HBM time.)
+      const int nc = min(CB, n_k - c0);                       // K channels of this unit that exist
+      if (!it.transposed) {
+        constexpr int PITCH = CB * 16 + 1;
+        const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
+        const int co = ct * 16 + row;
+        const int len = nc * taps;
+        if (co < it.c_out && nc > 0) {
+          const float* src = it.w_oihw + ((size_t)co * it.c_in + c0) * taps;
+          float* dst = tile_flat + row * PITCH;
+          if (((((size_t)co * it.c_in + c0) * taps) & 3) == 0 && (reinterpret_cast<size_t>(it.w_oihw) & 15) == 0) {
+            const int len4 = len & ~3;
+            for (int k = l * 4; k < len4; k += 64) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + k);
+              dst[k] = v[0]; dst[k + 1] = v[1]; dst[k + 2] = v[2]; dst[k + 3] = v[3];
+            }
+            for (int k = len4 + l; k < len; k += 16) dst[k] = src[k];
+          } else {
+            for (int k = l; k < len; k += 16) dst[k] = src[k];
+          }
+        }
+      } else {
+        constexpr int PITCH = 16 * 16 + 1;
+        const int c = threadIdx.x >> 3, l = threadIdx.x & 7;          // 32 K channels x 8 lanes
+        const int k = c0 + c;
+        const int nr = min(16, n_rows - ct * 16);                     // rows of this tile that exist
+        const int len = nr * taps;
+        if (k < n_k && nr > 0) {
+          const float* src = it.w_oihw + ((size_t)k * n_rows + ct * 16) * taps;
+          float* dst = tile_flat + c * PITCH;
+          if (((((size_t)k * n_rows + ct * 16) * taps) & 3) == 0 && (reinterpret_cast<size_t>(it.w_oihw) & 15) == 0) {
+            const int len4 = len & ~3;
+            for (int q = l * 4; q < len4; q += 32) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + q);
+              dst[q] = v[0]; dst[q + 1] = v[1]; dst[q + 2] = v[2]; dst[q + 3] = v[3];
+            }
+            for (int q = len4 + l; q < len; q += 8) dst[q] = src[q];
+          } else {
+            for (int q = l; q < len; q += 8) dst[q] = src[q];
+          }
+        }
+      }
+      __syncthreads();
+      const int groups = min(CB, cin_p - c0) / 8;
+      for (int idx = threadIdx.x; idx < taps * groups * 16; idx += blockDim.x) {
+        const int row = idx & 15;
+        const int gq = (idx >> 4) % groups;
+        const int tap = (idx >> 4) / groups;
+        const int k = tap * cin_p + c0 + gq * 8;
+        const int ks = k >> 5, g = (k & 31) >> 3;
+        const bool row_ok = ct * 16 + row < n_rows;
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cl = gq * 8 + e;
+          float v = 0.f;
+          if (row_ok && c0 + cl < n_k) {
+            v = it.transposed ? tile_flat[cl * (16 * 16 + 1) + row * taps + (taps - 1 - tap)]
+                              : tile_flat[row * (CB * 16 + 1) + cl * taps + tap];
+            if (!plain) v = __fdiv_rn(v, sig);
+          }
+          o[e] = bits_of<T>(v);
+        }
+        u32x4 pk;
+        pk[0] = o[0] | ((uint32_t)o[1] << 16);
+        pk[1] = o[2] | ((uint32_t)o[3] << 16);
+        pk[2] = o[4] | ((uint32_t)o[5] << 16);
+        pk[3] = o[6] | ((uint32_t)o[7] << 16);
+        out[((size_t)ct * ksteps + ks) * 64 + g * 16 + row] = pk;
+      }
+    } else {
+    // ---- load (more than 16 taps, staged in passes of 16): rows of the OIHW tensor, contiguous in (c, tap).  (c, tap) of a thread's elements advance by constants
     // with a carry -- the first version divided twice per element and always divided by sigma: the pack of the
     // generator's 105 M weights ran at a quarter of the HBM rate on instruction count alone
-    const bool plain = it.sigma == nullptr;
     if (!it.transposed) {
       // thread = (row, 16 lanes along the row's CB * taps contiguous floats)
       const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
@@ -458,6 +536,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const Cga
       pk[2] = o[4] | ((uint32_t)o[5] << 16);
       pk[3] = o[6] | ((uint32_t)o[7] << 16);
       out[((size_t)ct * ksteps + ks) * 64 + g * 16 + row] = pk;
+    }
     }
     // ---- the K groups past taps * cin_p that pad the last k-step are zero
     if (cc == 0 && tp == 0) {
