@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void sn_wt_u_batched(const CganSnItem* __restr
   if (r0 >= it.rows || k >= it.cols) return;
   int r1 = min(it.rows, r0 + SN_ROWS_PER_CHUNK);
   float acc = 0.f;
+  // (eight rows in flight per thread; the products are still added row by row in order)
+#pragma unroll 8
   for (int o = r0; o < r1; ++o) acc += it.w_bar[(size_t)o * it.cols + k] * it.u[o];
   it.workspace[(size_t)blockIdx.y * it.cols + k] = acc;
 }
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void sn_w_t_batched(const CganSnItem* __restri
   float* r = it.workspace + (size_t)rchunks * it.cols + it.cols;
   const float* wr = it.w_bar + (size_t)o * it.cols;
   float acc = 0.f;
+#pragma unroll 8
   for (int k = lane; k < it.cols; k += 64) acc += wr[k] * t[k];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
