@@ -59,13 +59,15 @@ __global__ void resize_nearest_kernel(const uint16_t* __restrict__ x, uint16_t* 
                                       int w_in, int cs_in, int h_out, int w_out, int cs_out, float sy, float sx,
                                       long total) {
   const int g_out = cs_out / 4;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    int g = (int)(idx % g_out);
-    long pix = idx / g_out;
-    int ox = (int)(pix % w_out);
-    long r = pix / w_out;
-    int oy = (int)(r % h_out);
-    long n = r / h_out;
+  // (32-bit index arithmetic: a map below 2 GiB has fewer than 2^28 four-channel groups)
+  for (long idl = (long)blockIdx.x * blockDim.x + threadIdx.x; idl < total; idl += (long)gridDim.x * blockDim.x) {
+    const unsigned idx = (unsigned)idl;
+    const unsigned pix = idx / (unsigned)g_out;
+    int g = (int)(idx - pix * (unsigned)g_out);
+    const unsigned r = pix / (unsigned)w_out;
+    int ox = (int)(pix - r * (unsigned)w_out);
+    const long n = (long)(r / (unsigned)h_out);
+    int oy = (int)(r - (unsigned)n * (unsigned)h_out);
     int iy = nearest_src(oy, sy, h_in), ix = nearest_src(ox, sx, w_in);
     const uint16_t* src = x + ((n * h_in + iy) * (long)w_in + ix) * cs_in;
     uint16_t o[4];
@@ -77,7 +79,7 @@ __global__ void resize_nearest_kernel(const uint16_t* __restrict__ x, uint16_t* 
     u32x2 pk;
     pk[0] = o[0] | ((uint32_t)o[1] << 16);
     pk[1] = o[2] | ((uint32_t)o[3] << 16);
-    *reinterpret_cast<u32x2*>(y + pix * cs_out + g * 4) = pk;
+    *reinterpret_cast<u32x2*>(y + (size_t)pix * cs_out + g * 4) = pk;
   }
 }
 
