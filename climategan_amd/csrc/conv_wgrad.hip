@@ -818,6 +818,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const uint16_t* __rest
   const int gi = threadIdx.x % groups, pl = threadIdx.x / groups;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (pl < ppb) {
+#pragma unroll 4
     for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(x + pix * cs + gi * 8);
 #pragma unroll

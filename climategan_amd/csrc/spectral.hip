@@ -106,6 +106,7 @@ __global__ __launch_bounds__(1024) void sn_reduce_t_batched(const CganSnItem* __
   float sq = 0.f;
   for (int k = threadIdx.x; k < it.cols; k += blockDim.x) {
     float acc = 0.f;
+#pragma unroll 8
     for (int rc = 0; rc < rchunks; ++rc) acc += it.workspace[(size_t)rc * it.cols + k];
     t[k] = acc;
     sq += acc * acc;
