@@ -81,9 +81,12 @@ class Trainer:
         self.overlap_branches = os.environ.get("CGAN_OVERLAP", "1") != "0"
         self._side = None
         # a third stream for the weight-gradient kernels of the calling stream's branch (autograd.WGRAD_STREAM: they leave the
-        # data-gradient chain); CGAN_WGRAD_STREAM=0: on the chain as before (same-box A/B)
+        # data-gradient chain).  OPT-IN (CGAN_WGRAD_STREAM=1 or ``wgrad_stream = True`` before the first update): twelve
+        # alternating runs on one box gave 94.0-94.9 ms per step without it and 93.3 / 93.3 / 93.3 / 94.7 / 95.4 / 98.5 with it
+        # -- a millisecond in the good runs, several lost in the others (which hardware queue the third stream lands on is
+        # decided per process); a step time that repeats is worth more than its best case
         self._wstream = None
-        self.wgrad_stream = os.environ.get("CGAN_WGRAD_STREAM", "1") != "0"
+        self.wgrad_stream = os.environ.get("CGAN_WGRAD_STREAM", "0") == "1"
         # development aid (tools/branch_times.py): [(fork event, end of the main-stream branch, end of the side-stream branch)]
         self.branch_events = [] if os.environ.get("CGAN_BRANCH_TIMES") == "1" else None
 
