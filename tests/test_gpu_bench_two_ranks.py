@@ -36,5 +36,8 @@ def test_bench_gpus_2_code_path_on_one_device():
     assert "dp2" in r["config"]["parallelism"]
     # whole-job value = N x 4 per-domain slots x steps / max-over-ranks time
     assert abs(r["value"] - 2 * 4 / (r["ms_per_step"] * 1e-3)) <= 1e-2 * r["value"]
-    assert r["roofline"] is not None and 0.05 < r["roofline"]["frac"] < 1.0          # rank 0's launch brackets still there
+    # rank 0's launch brackets are still there.  (Their durations mean little here: two processes share ONE device in this
+    # test, so a bracket may span the other rank's kernels or a gloo host copy -- the fraction was 0.15 in most runs and
+    # below 0.05 in about one of three inside the full suite; what is checked is that every launch of the family was seen.)
+    assert r["roofline"] is not None and 0.0 < r["roofline"]["frac"] < 1.0 and r["roofline"]["launches_per_step"] >= 400
     assert r["cpu_baseline"] is None and all(v == v for v in r["losses_last_step"].values())
