@@ -129,6 +129,29 @@ def recorded_traffic(pattern):
     return int(float(m.group(1)) * 1e6) if m else None
 
 
+def recorded_mfma_util():
+    """Matrix-pipe busy fraction and wave-life split per kernel family from the newest committed SQ-counter summary
+    (profiles/*_mfma_util.csv: tools/gpu_pmc_step_sq.sh + tools/mfma_util.py, rocprofv3 --pmc passes of this command's
+    headline step); None if absent.  Counter passes wrap the process, so they are recorded, not taken inside the bench."""
+    import glob
+    files = sorted(glob.glob(str(ROOT / "profiles" / "*_mfma_util.csv")))
+    if not files:
+        return None
+    out, cols = {"source": "profiles/" + os.path.basename(files[-1])}, None
+    for line in open(files[-1]):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split(",")
+        if f[0] == "family":
+            cols = f
+            continue
+        if cols and f[0] in ("gemm 1x1", "gemm kxk", "gemm", "general", "lds3x3", "wgrad", "spade"):
+            row = dict(zip(cols, f))
+            out[f[0]] = {k: (float(row[k]) if row.get(k) else None)
+                         for k in ("mfma_busy", "waves_per_simd", "active", "parked", "issue_stall", "lds_issue", "lds_conflict")}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ timing helpers
 def timed_steps(step, steps, warmup, barrier):
     """W untimed warm-up steps, then exactly K timed steps bracketed by barrier() on both sides."""
@@ -963,6 +986,12 @@ def main():
                                    % (sampled, args.steps, EVENT_EVERY),
                 "share_of_step": round((ms / sampled) / (elapsed / args.steps * 1e3), 3),
                 "by_class": timer.classes()}
+            mu = recorded_mfma_util()
+            if mu:
+                gk = [mu[k] for k in ("gemm 1x1", "gemm kxk") if k in mu]
+                res["roofline"]["mfma_busy_frac"] = mu.get("gemm", {}).get("mfma_busy") if "gemm" in mu else (
+                    {k: mu[k]["mfma_busy"] for k in ("gemm 1x1", "gemm kxk") if k in mu} if gk else None)
+                res["mfma_util"] = mu
         else:
             res["roofline"] = None
         if all_timer is not None and all_timer.pairs:
