@@ -84,6 +84,7 @@ _SIGNATURES = {
     "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_bwd_data_relu": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_kernel_kind": (C.c_int, [C.POINTER(ConvDesc), C.c_int32]),
+    "cgan_conv2d_bind_workspace": (C.c_int, [_P, _P, C.c_size_t]),
     "cgan_rccl_load": (C.c_int, [C.c_char_p]),
     "cgan_rccl_loaded": (C.c_int, []),
     "cgan_comm_unique_id": (C.c_int, [_P]),

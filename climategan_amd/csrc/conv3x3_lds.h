@@ -8,14 +8,16 @@ struct Conv3x3LdsArgs {
   const float* bias;    // padded to ctiles*16, or null
   const uint16_t* res;  // residual or null
   uint16_t* y;
-  int n, h, w_;         // output extent (== logical input extent: stride 1, pad 1)
-  int hx, wx;           // stored input extent (h/2, w/2 when in_ups)
+  int n, h, w_;         // output extent
+  int hi, wi;           // logical input extent (h + 2 - 2 pad)
+  int pad, reflect;     // 0 / 1 / 2 zero padding ('valid' / 'same' / 'full'), or 1 with reflect = 1
+  int hx, wx;           // stored input extent (hi/2, wi/2 when in_ups)
   int cin;              // logical input channels (<= 4: the folded-tap kernel)
   int cin_s, cin_p, cout, cout_s, ctiles, ksteps;
   int in_ups, act, has_res, res_ups;
   float slope;
 };
 
-// true if this conv is a 3x3 / stride 1 / pad 1 (zero) / dilation 1 conv large enough for the tiled kernel
+// true if this conv is a 3x3 / stride 1 / dilation 1 conv (zero pad 0..2, or reflect pad 1) large enough for the tiled kernel
 bool conv3x3_lds_applicable(const CganConvDesc* d);
 int conv3x3_lds_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s);

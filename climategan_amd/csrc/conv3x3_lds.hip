@@ -31,6 +31,19 @@ __device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot
 // 16-byte-aligned zeros in device memory: the source of every out-of-image / pad-channel DMA lane
 __device__ __attribute__((aligned(16))) unsigned int g_zeros[64];
 
+// halo coordinate -> input coordinate: the conv's padding shifts the halo's origin (pad 1: the 'same' conv; 2: the 'full' conv
+// = the data gradient of a pad-0 layer; 0: 'valid'), reflect padding (nn.ReflectionPad2d(1) folded into the mask / depth
+// decoders' convs: reference blocks.py:21-78) mirrors the one ring it can reach.  Out-of-image positions stay out of range
+// (zero page); positions of a tile's overhang past the image only feed outputs that are never stored.
+__device__ __forceinline__ void halo_coord(const Conv3x3LdsArgs& p, int& yy, int& xx) {
+  if (p.reflect) {
+    yy = yy < 0 ? -yy : yy;
+    xx = xx < 0 ? -xx : xx;
+    yy = yy >= p.hi ? 2 * p.hi - 2 - yy : yy;
+    xx = xx >= p.wi ? 2 * p.wi - 2 - xx : xx;
+  }
+}
+
 #define STAGE_BARRIER()                                            \
   do {                                                             \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
@@ -140,10 +153,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_lds_kernel(Conv3x3LdsAr
       const int pix = idx >> 2, spos = idx & 3;
       const int slot = spos ^ ((pix >> 2) & 3);     // logical 8-channel group that belongs at this position
       const int py = pix / HPW, px = pix - py * HPW;
-      const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+      int yy = ty0 - p.pad + py, xx = tx0 - p.pad + px;
+      halo_coord(p, yy, xx);
       const int ch = q * 32 + slot * 8;
       const u32x4* src = zero_page;
-      if (pix < HP && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_ && ch < p.cin_s) {
+      if (pix < HP && yy >= 0 && yy < p.hi && xx >= 0 && xx < p.wi && ch < p.cin_s) {
         const int sy = p.in_ups ? (yy >> 1) : yy, sx = p.in_ups ? (xx >> 1) : xx;
         src = reinterpret_cast<const u32x4*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cin_s + ch);
       }
@@ -237,10 +251,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void conv3x3_lds_onechunk_kernel(Con
     const int pix = idx >> 2, spos = idx & 3;
     const int slot = spos ^ ((pix >> 2) & 3);
     const int py = pix / HPW, px = pix - py * HPW;
-    const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+    int yy = ty0 - p.pad + py, xx = tx0 - p.pad + px;
+    halo_coord(p, yy, xx);
     const int ch = slot * 8;
     const u32x4* src = zero_page;
-    if (pix < HP && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_ && ch < p.cin_s) {
+    if (pix < HP && yy >= 0 && yy < p.hi && xx >= 0 && xx < p.wi && ch < p.cin_s) {
       const int sy = p.in_ups ? (yy >> 1) : yy, sx = p.in_ups ? (xx >> 1) : xx;
       src = reinterpret_cast<const u32x4*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cin_s + ch);
     }
@@ -321,9 +336,10 @@ __global__ __launch_bounds__(WAVES * 64, NCT <= 2 ? 8 : (NCT <= 4 ? 4 : 2)) void
   u32x2* xh = reinterpret_cast<u32x2*>(smem);        // [18 * 18]
   for (int pix = threadIdx.x; pix < HP; pix += WAVES * 64) {
     const int py = pix / HPW, px = pix - py * HPW;
-    const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+    int yy = ty0 - p.pad + py, xx = tx0 - p.pad + px;
+    halo_coord(p, yy, xx);
     u32x2 v = {0u, 0u};
-    if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w_) {
+    if (yy >= 0 && yy < p.hi && xx >= 0 && xx < p.wi) {
       const int sy = p.in_ups ? (yy >> 1) : yy, sx = p.in_ups ? (xx >> 1) : xx;
       v = *reinterpret_cast<const u32x2*>(p.x + (((size_t)n * p.hx + sy) * p.wx + sx) * p.cin_s);
     }
@@ -469,8 +485,9 @@ CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv3x3_c4(int v) { g_c4_enabled = 
 CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv3x3_nct(int v) { g_lds_nct = v; })
 
 bool conv3x3_lds_applicable(const CganConvDesc* d) {
-  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && d->pad == 1 &&
-         d->pad_mode == CGAN_PAD_ZERO && (long)d->h_out * d->w_out >= 1024;
+  const bool pad_ok = d->pad_mode == CGAN_PAD_ZERO ? (d->pad >= 0 && d->pad <= 2)
+                                                   : (d->pad == 1 && d->h_in >= 2 && d->w_in >= 2 && !d->in_upsample);
+  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && pad_ok && (long)d->h_out * d->w_out >= 1024;
 }
 
 int conv3x3_lds_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s) {

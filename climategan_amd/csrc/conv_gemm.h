@@ -21,6 +21,26 @@ struct ConvGemmArgs {
   float* stats;
 };
 
+// conv_gemm_ext.hip: the same tiling for strided data gradients by output parity classes and for split-K launches
+struct ConvGemmCls {
+  int koff;        // k-step offset of the class's block inside the packed operator (pack_dgrad_classes_kernel)
+  int kh, kw;      // the class's taps per axis (0 x 0: the class only writes zeros)
+  int offy, offx;  // first dy row / column an output (i, j) of the class reads: i + offy, j + offx
+};
+struct ConvGemmExtArgs {
+  ConvGemmArgs a;
+  int cls_s;       // > 0: parity-class mode of a stride-cls_s data gradient, blockIdx.y = class (a.h_out x a.w_out = dx extent)
+  int ksplit;      // > 1: split-K, blockIdx.y = K slice of ks_per k-steps, fp32 partials to ws [slice][pixel][cout_s]
+  int ks_per;
+  float* ws;
+  ConvGemmCls cls[4];
+};
+bool conv_gemm_ext_shape_ok(const ConvGemmArgs& a);
+int conv_gemm_splitk_plan(const ConvGemmArgs& a);        // K slices for a grid that cannot fill the chip (1 = none)
+size_t conv_gemm_splitk_workspace_bytes(const ConvGemmArgs& a, int ksplit);
+int conv_gemm_splitk_launch(const ConvGemmArgs& a, int ksplit, float* ws, int dtype, hipStream_t s);
+int conv_gemm_cls_launch(const ConvGemmArgs& a, int cls_s, const ConvGemmCls* cls, int dtype, hipStream_t s);
+
 // true for convs whose channel counts make the 128x256 (cout x pixel) LDS tiling worthwhile
 bool conv_gemm_applicable(const CganConvDesc* d);
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);

@@ -676,8 +676,8 @@ void launch(const ConvParams& p, hipStream_t s) {
 }  // namespace
 
 // development knob: 1 = always use the general gather kernel, 2 = never use the wide-layer GEMM kernel, 3 = the GEMM
-// kernel also where the spatially tiled 3x3 kernel would be preferred
-// (A/B measurements, parity tests of every kernel)
+// kernel also where the spatially tiled 3x3 kernel would be preferred, 4 = automatic without round 5's parity-class /
+// split-K launches of the LDS-tiled GEMM (A/B measurements, parity tests of every kernel)
 CGAN_KNOB(int, g_conv_force, 0);
 CGAN_DEV_ONLY(extern "C" void cgan_debug_set_conv_kernel(int v) { g_conv_force = v; })
 // 1: strided data gradients read dy through zero insertion (the first implementation) instead of by parity classes
@@ -723,6 +723,76 @@ extern "C" int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device,
   return CGAN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-K workspaces (round 5): one caller-owned fp32 scratch buffer per stream, registered once
+// (cgan_conv2d_bind_workspace).  Launches on one stream are ordered, so consecutive convolutions share their stream's buffer;
+// two streams never share one.  Without a binding (or with one that is too small) the small-grid layers stay on the general
+// kernel -- slower, same results up to the fp32 summation order.
+// ------------------------------------------------------------------------------------------------
+#include <mutex>
+namespace {
+struct WsSlot { void* stream; void* ws; size_t bytes; };
+constexpr int WS_SLOTS = 16;
+WsSlot g_ws[WS_SLOTS];
+int g_ws_n = 0;
+std::mutex g_ws_mu;
+WsSlot ws_lookup(void* stream) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < g_ws_n; ++i)
+    if (g_ws[i].stream == stream) return g_ws[i];
+  return WsSlot{stream, nullptr, 0};
+}
+size_t ws_max_bytes() {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  size_t m = 0;
+  for (int i = 0; i < g_ws_n; ++i) m = g_ws[i].bytes > m ? g_ws[i].bytes : m;
+  return m;
+}
+}  // namespace
+
+extern "C" int cgan_conv2d_bind_workspace(void* stream, void* workspace, size_t bytes) {
+  CGAN_REQUIRE((workspace != nullptr) == (bytes > 0), "conv2d_bind_workspace: workspace and bytes must both be set or both be zero");
+  CGAN_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "conv2d_bind_workspace: workspace must be 16-byte aligned");
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < g_ws_n; ++i)
+    if (g_ws[i].stream == stream) {
+      g_ws[i].ws = workspace; g_ws[i].bytes = bytes;
+      return CGAN_OK;
+    }
+  CGAN_REQUIRE(g_ws_n < WS_SLOTS, "conv2d_bind_workspace: more than %d streams", WS_SLOTS);
+  g_ws[g_ws_n++] = WsSlot{stream, workspace, bytes};
+  return CGAN_OK;
+}
+
+static ConvGemmArgs gemm_args(const ConvParams& p) {
+  ConvGemmArgs a;
+  a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+  a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
+  a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+  a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
+  a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
+  a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
+  a.stats = p.stats;
+  return a;
+}
+
+// K slices if this launch (which the size thresholds keep off the plain wide-layer kernel) runs as a split-K launch of the
+// LDS-tiled GEMM with ``ws_bytes`` of workspace; 1 = it does not
+static int splitk_for(const ConvParams& p, size_t ws_bytes) {
+  if (g_conv_force != 0 || p.in_zs != 1 || p.in_ups || p.cls_s || p.pair || p.stats || p.pad < 0) return 1;
+  if (p.cin_p != p.cin_s) return 1;      // (3x3 layers whose per-tap channel extent is padded to 32: cin_s % 32 != 0 anyway)
+  const ConvGemmArgs a = gemm_args(p);
+  const int ks = conv_gemm_splitk_plan(a);
+  if (ks <= 1 || conv_gemm_splitk_workspace_bytes(a, ks) > ws_bytes) return 1;
+  return ks;
+}
+
+// launches the selection below leaves on the general kernel, or on the spatially tiled 3x3 kernel only because the wide-layer
+// kernel's size thresholds refused them (>= 256 input channels: the tiled kernel is not the preferred one there)
+static bool splitk_candidate(int kind, const ConvParams& p) {
+  return kind == CGAN_CONV_KERNEL_GENERAL || (kind == CGAN_CONV_KERNEL_LDS3X3 && p.cin_s >= 256);
+}
+
 // kernel selection shared by the forward and the stride-1 data-gradient entry points
 static int select_conv_kernel(const ConvParams& p, const CganConvDesc* d) {
   // narrow 3x3 / stride-1 layers (< 256 channels in) are faster in the spatially tiled 3x3 kernel (halo reuse in LDS)
@@ -735,23 +805,29 @@ static int select_conv_kernel(const ConvParams& p, const CganConvDesc* d) {
 static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, const char* what) {
   const int kind = select_conv_kernel(p, d);
   if (kind == CGAN_CONV_KERNEL_GEMM) {
-    ConvGemmArgs a;
-    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
-    a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
-    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
-    a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
-    a.h_out = p.h_out; a.w_out = p.w_out; a.npix = p.npix;
-    a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
-    a.stats = p.stats;
+    const ConvGemmArgs a = gemm_args(p);
     int rc2 = conv_gemm_launch(a, d->dtype, s);
     if (rc2 != CGAN_OK) return rc2;
     CGAN_CHECK_LAUNCH(what);
     return CGAN_OK;
   }
+  if (splitk_candidate(kind, p)) {
+    // few output pixels, long K: K slices of the LDS-tiled GEMM + an ordered reduce (conv_gemm_ext.hip)
+    const WsSlot slot = ws_lookup((void*)s);
+    const int ks = splitk_for(p, slot.bytes);
+    if (ks > 1) {
+      int rc2 = conv_gemm_splitk_launch(gemm_args(p), ks, (float*)slot.ws, d->dtype, s);
+      if (rc2 != CGAN_OK) return rc2;
+      CGAN_CHECK_LAUNCH(what);
+      return CGAN_OK;
+    }
+  }
   if (kind == CGAN_CONV_KERNEL_LDS3X3) {
     Conv3x3LdsArgs a;
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
-    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hx = p.hx; a.wx = p.wx; a.cin = d->c_in; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
+    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hi = p.h_in; a.wi = p.w_in; a.pad = p.pad;
+    a.reflect = p.pad_mode == CGAN_PAD_REFLECT;
+    a.hx = p.hx; a.wx = p.wx; a.cin = d->c_in; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
     a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
     a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
     int rc2 = conv3x3_lds_launch(a, d->dtype, s);
@@ -943,20 +1019,45 @@ extern "C" int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* s
   return CGAN_OK;
 }
 
+// parity-class data gradient on the LDS-tiled GEMM (conv_gemm_ext.hip): the class table, or false = stays on the general kernel
+static bool cls_on_gemm(const ConvParams& p, ConvGemmCls (&cls)[4]) {
+  if (!p.cls_s || p.cls_s > 2 || g_conv_force != 0 || p.cin_p != p.cin_s || p.pair) return false;
+  if (!conv_gemm_ext_shape_ok(gemm_args(p)) || p.cout_s < 64) return false;
+  int koff = 0;
+  for (int c = 0; c < p.cls_s * p.cls_s; ++c) {
+    const int ca = c / p.cls_s, cb = c % p.cls_s;
+    int ry, rx, nty, ntx;
+    cls_axis(p.cls_s, p.kh, p.cls_pad, ca, ry, nty);
+    cls_axis(p.cls_s, p.kw, p.cls_pad, cb, rx, ntx);
+    // (a - pad' + r) is a multiple of s by the choice of r: output row i s + a first reads dy row i + (a - pad' + r) / s
+    cls[c] = ConvGemmCls{koff, nty, ntx, (ca - p.cls_pad + ry) / p.cls_s, (cb - p.cls_pad + rx) / p.cls_s};
+    if (nty * ntx == 0) cls[c].kh = cls[c].kw = 0;
+    koff += cls_ksteps(p.cls_s, p.kh, p.kw, p.cls_pad, p.cg, c);
+  }
+  return true;
+}
+
 extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) {
   ConvParams p;
   if (!bwd_data) {
     int rc = fill_params(p, d);
-    return rc != CGAN_OK ? rc : select_conv_kernel(p, d);
+    if (rc != CGAN_OK) return rc;
+    const int kind = select_conv_kernel(p, d);
+    // (a split-K launch needs its stream's workspace: the query answers for the largest one bound)
+    return splitk_candidate(kind, p) && splitk_for(p, ws_max_bytes()) > 1 ? CGAN_CONV_KERNEL_GEMM : kind;
   }
   CganConvDesc t;
   int rc = dgrad_params(p, d, &t);
   if (rc != CGAN_OK) return rc;
   const bool plain = d->stride == 1 && p.pad >= 0 && t.h_in + 2 * p.pad - t.dilation * (t.kh - 1) == t.h_out &&
                      t.w_in + 2 * p.pad - t.dilation * (t.kw - 1) == t.w_out;
-  if (!plain) return CGAN_CONV_KERNEL_GENERAL;
+  if (!plain) {
+    ConvGemmCls cls[4];
+    return cls_on_gemm(p, cls) ? CGAN_CONV_KERNEL_GEMM : CGAN_CONV_KERNEL_GENERAL;
+  }
   t.pad = p.pad;
-  return select_conv_kernel(p, &t);
+  const int kind = select_conv_kernel(p, &t);
+  return splitk_candidate(kind, p) && splitk_for(p, ws_max_bytes()) > 1 ? CGAN_CONV_KERNEL_GEMM : kind;
 }
 
 static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx, const CganConvDesc* fwd,
@@ -980,6 +1081,13 @@ static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void*
   if (plain) {
     t.pad = p.pad;
     return dispatch_conv(p, &t, s, "conv2d_nhwc_bwd_data");
+  }
+  ConvGemmCls cls[4];
+  if (cls_on_gemm(p, cls)) {
+    int rc2 = conv_gemm_cls_launch(gemm_args(p), p.cls_s, cls, fwd->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_data");
+    return CGAN_OK;
   }
   if (fwd->dtype == CGAN_F16) launch<F16>(p, s);
   else launch<BF16>(p, s);

@@ -776,6 +776,24 @@ def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
 
 _PACK_TABLES = []
 
+CONV_WS_BYTES = 64 << 20
+_CONV_WS = {}
+
+
+def _conv_ws() -> None:
+    """Bind (once per library build and stream) the calling stream's split-K scratch buffer for the convolution entry points
+    (cgan_conv2d_bind_workspace): the small-grid / long-K layers then run as K slices of the LDS-tiled GEMM."""
+    lib = _lib.load()
+    st = _stream()
+    key = (id(lib), st.value, _GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device())
+    if key not in _CONV_WS:
+        buf = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device="cuda")
+        rc = lib.cgan_conv2d_bind_workspace(st, C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()))
+        if rc != 0:
+            msg = lib.cgan_last_error()
+            raise RuntimeError("cgan_conv2d_bind_workspace failed (status %d): %s" % (rc, msg.decode() if msg else "?"))
+        _CONV_WS[key] = buf
+
 
 @_batch_chunked("x", "residual", out_bytes_per_sample=lambda g: (lambda hw: hw[0] * hw[1] * cs8(g("pw").c_out) * 2 * _nbf(g("x")))(
     _conv_out_hw(g("x").h * (2 if g("in_upsample") else 1), g("x").w * (2 if g("in_upsample") else 1), g("pw").kh, g("stride"),
@@ -815,6 +833,7 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
             raise RuntimeError("conv2d: residual shape mismatch")
     y = torch.empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
+    _conv_ws()
     _lib.check(lib.cgan_conv2d_nhwc_fwd(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias), _ptr(residual.t if residual else None),
                                         _ptr(y), C.byref(d), _stream()), "cgan_conv2d_nhwc_fwd")
     return NHWC(y, pw.c_out)
@@ -997,6 +1016,7 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
         _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
                    "cgan_conv2d_pack_weight_dgrad")
     dx = torch.empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
+    _conv_ws()
     if relu_out is not None:
         if relu_out.t.shape != dx.shape or relu_out.t.dtype != dx.dtype or not relu_out.t.is_contiguous():
             raise RuntimeError("conv2d_bwd_data: ``relu_out`` %s does not match dx %s" % (tuple(relu_out.t.shape), tuple(dx.shape)))

@@ -325,3 +325,114 @@ def test_folded_tap_3x3_kernel_for_few_input_channels(case):
         d = (y.t.float() - y0.t.float()).abs()
         assert (d <= 2 * eps * y0.t.float().abs() + 1e-3).all(), (dt, d.max().item())
         assert y.t[..., cout:].abs().max().item() == 0 if y.t.shape[-1] > cout else True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: parity-class data gradients and split-K launches on the LDS-tiled GEMM (conv_gemm_ext.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+CLS_CASES = [
+    # (cin, cout, k, stride, pad, B, H, W): strided convs whose data gradient has >= 64 output and % 32 input channels
+    (64, 128, 4, 2, 1, 2, 32, 32),      # PatchGAN 64 -> 128 (discriminator.py:100-163)
+    (128, 256, 4, 2, 1, 1, 24, 40),
+    (256, 512, 4, 2, 1, 2, 10, 10),     # few pixels per class
+    (64, 64, 4, 2, 1, 1, 17, 23),       # odd extents: classes of different sizes, rows no window reaches
+    (128, 128, 3, 2, 1, 2, 33, 31),     # ResNet layer2 3x3 s2: 2 / 1 taps per axis by class
+    (256, 512, 1, 2, 0, 2, 16, 16),     # 1x1 s2 shortcut: three classes without taps write zeros
+    (72, 96, 4, 2, 1, 1, 12, 20),       # 72 dx channels (a padded cout tile)
+]
+
+
+def _kind(lib, dt, case, bwd):
+    from climategan_amd import ops
+    cin, cout, k, stride, pad, B, H, W = case
+    d = ops._conv_desc(ops._DT[dt], B, H, W, cin, cout, k, k, stride, pad, 1, ops.PAD_ZERO, has_bias=not bwd)
+    return lib.cgan_conv2d_kernel_kind(ctypes.byref(d), ctypes.c_int32(1 if bwd else 0))
+
+
+@pytest.mark.usefixtures("dev_lib")
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CLS_CASES)
+def test_strided_dgrad_by_parity_classes_on_the_tiled_gemm(dt, case):
+    from climategan_amd import _lib, ops
+    cin, cout, k, stride, pad, B, H, W = case
+    tol16 = 1e-3 if dt == torch.float16 else 8e-3
+    lib = _lib.load()
+    x = q(fill.uniform((B, cin, H, W), 2100 + cin + H), dt).requires_grad_(True)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = q(fill.uniform((cout, cin, k, k), 2200 + cout + k, -bound, bound), dt)
+    y = F.conv2d(x, w, None, stride=stride, padding=pad)
+    dy = q(fill.uniform(tuple(y.shape), 2300 + cout + W), dt)
+    y.backward(dy)
+    dyg = ops.nchw_to_nhwc(dy.cuda(), dt)
+    assert _kind(lib, dt, case, True) == 2, "this case must run on the tiled GEMM"
+    dx = ops.conv2d_bwd_data(dyg, w.cuda(), (B, H, W), stride=stride, pad=pad)
+    assert rel_err(ops.nhwc_to_nchw(dx).cpu(), x.grad) <= tol16
+    if ops.cs8(cin) != cin:
+        assert dx.t[..., cin:].abs().max().item() == 0
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(4))
+    try:
+        assert _kind(lib, dt, case, True) == 0
+        dx2 = ops.conv2d_bwd_data(dyg, w.cuda(), (B, H, W), stride=stride, pad=pad)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    # same products, another fp32 summation order: within one rounding step of the general kernel's result
+    assert rel_err(dx.t.float(), dx2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)
+
+
+SPLITK_CASES = [
+    # (cin, cout, k, stride, pad, B, H, W, residual, act)
+    (640, 640, 3, 1, 1, 2, 10, 10, True, "none"),     # Painter G_middle (painter.py:149-160)
+    (640, 640, 3, 1, 1, 1, 5, 5, False, "lrelu"),
+    (512, 512, 4, 1, 1, 2, 20, 20, False, "lrelu"),   # PatchGAN 512 -> 512 4x4 s1 (19 x 19 out)
+    (256, 512, 4, 2, 1, 2, 20, 20, False, "none"),    # strided, 10 x 10 out
+    (1280, 128, 3, 1, 1, 1, 10, 10, False, "relu"),   # long K, one cout block
+    (512, 72, 3, 1, 1, 2, 9, 11, True, "none"),       # pad tile, ragged
+    (512, 1, 4, 1, 1, 2, 19, 19, False, "none"),      # PatchGAN head (discriminator.py:163): one output channel
+    (512, 1, 4, 2, 1, 2, 20, 20, False, "none"),
+    (1280, 128, 3, 1, 1, 1, 40, 40, False, "none"),   # wide input on a map the tiled 3x3 kernel would otherwise take
+]
+
+
+@pytest.mark.usefixtures("dev_lib")
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_small_grids_run_as_k_slices_of_the_tiled_gemm(dt, case):
+    from climategan_amd import _lib, ops
+    cin, cout, k, stride, pad, B, H, W, with_res, act = case
+    tol16 = 1e-3 if dt == torch.float16 else 8e-3
+    lib = _lib.load()
+    x = q(fill.uniform((B, cin, H, W), 3100 + cin + H), dt).requires_grad_(True)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = q(fill.uniform((cout, cin, k, k), 3200 + cout + k, -bound, bound), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 3300 + cout, -bound, bound))
+    y0 = F.conv2d(x, w, b, stride=stride, padding=pad)
+    dy = q(fill.uniform(tuple(y0.shape), 3400 + cout + W), dt)
+    y0.backward(dy)
+    ref = y0.detach()
+    res = None
+    if with_res:
+        res = q(fill.uniform(tuple(ref.shape), 3500 + cout), dt)
+        ref = ref + res
+    ref = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2)}[act](ref)
+    xg = ops.nchw_to_nhwc(x.detach().cuda(), dt)
+    dyg = ops.nchw_to_nhwc(dy.cuda(), dt)
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    kw = dict(stride=stride, pad=pad, act={"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}[act],
+              residual=ops.nchw_to_nhwc(res.cuda(), dt) if res is not None else None)
+    yg = ops.conv2d(xg, pw, **kw)                    # binds this stream's workspace on first use
+    assert _kind(lib, dt, case[:8], False) == 2, "this case must run as K slices of the tiled GEMM"
+    assert rel_err(ops.nhwc_to_nchw(yg).cpu(), ref) <= tol16, "forward"
+    if ops.cs8(cout) != cout:
+        assert yg.t[..., cout:].abs().max().item() == 0
+    yg_again = ops.conv2d(xg, pw, **kw)
+    assert torch.equal(yg.t, yg_again.t), "the ordered reduce is deterministic"
+    if stride == 1:
+        dx = ops.conv2d_bwd_data(dyg, w.cuda(), (B, H, W), stride=stride, pad=pad)
+        assert rel_err(ops.nhwc_to_nchw(dx).cpu(), x.grad) <= tol16, "dgrad"
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(4))
+    try:
+        assert _kind(lib, dt, case[:8], False) != 2
+        y2 = ops.conv2d(xg, pw, **kw)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    assert rel_err(yg.t.float(), y2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)

@@ -349,6 +349,60 @@ def test_conv3x3_lds_tiled(dt, case):
     assert_close(back(y2), ref, dt, "conv3x3 gather %s" % (case,))
 
 
+LDS_PAD_CASES = [
+    # cin, cout, H, W, pad, reflect, act: the mask / depth decoders' reflect-padded 3x3 convs (reference blocks.py:21-78,
+    # masker.py:45-107) and the 'full' convs that are the data gradients of their pad-0 form
+    (16, 8, 48, 40, 1, True, "lrelu"),
+    (8, 1, 64, 33, 1, True, "none"),
+    (128, 32, 37, 45, 1, True, "lrelu"),
+    (64, 32, 32, 32, 1, True, "none"),
+    (8, 16, 34, 50, 2, False, "none"),            # 'full': 36 x 52 out
+    (32, 64, 40, 40, 2, False, "none"),
+    (24, 24, 40, 44, 0, False, "none"),           # 'valid': 38 x 42 out
+]
+
+
+@pytest.mark.usefixtures("dev_lib")
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", LDS_PAD_CASES)
+def test_conv3x3_lds_tiled_padding_modes(dt, case):
+    """Round 5: the tiled 3x3 kernel with reflect padding and with zero padding 0 / 2 (halo origin shifted, input and output
+    extents differ) against torch, against the general kernel, and that the dispatcher really takes it."""
+    import ctypes
+    from climategan_amd import _lib, ops
+    cin, cout, H, W, pad, reflect, act = case
+    B = 2
+    x = q(fill.uniform((B, cin, H, W), 510 + cin + H), dt).requires_grad_(True)
+    w = q(fill.uniform((cout, cin, 3, 3), 610 + cout, -0.2, 0.2), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 710 + cout))
+    xin = F.pad(x, (1,) * 4, mode="reflect") if reflect else x
+    ref0 = F.conv2d(xin, w, b, padding=0 if reflect else pad)
+    ref = F.leaky_relu(ref0, 0.2) if act == "lrelu" else ref0
+    lib = _lib.load()
+    pmode = ops.PAD_REFLECT if reflect else ops.PAD_ZERO
+    d = ops._conv_desc(ops._DT[dt], B, H, W, cin, cout, 3, 3, 1, pad, 1, pmode)
+    assert lib.cgan_conv2d_kernel_kind(ctypes.byref(d), ctypes.c_int32(0)) == 1, "must run on the tiled 3x3 kernel"
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    kw = dict(pad=pad, pad_mode=pmode, act=ops.ACT_LRELU if act == "lrelu" else ops.ACT_NONE)
+    xg = to_nhwc(x.detach(), dt)
+    y = ops.conv2d(xg, pw, **kw)
+    assert y.t.shape == (B, ref.shape[2], ref.shape[3], ops.cs8(cout))
+    assert_close(back(y), ref.detach(), dt, "conv3x3 LDS padding %s" % (case,))
+    if ops.cs8(cout) != cout:
+        assert y.t[..., cout:].abs().max().item() == 0
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(1))
+    try:
+        y2 = ops.conv2d(xg, pw, **kw)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    assert_close(back(y2), ref.detach(), dt, "conv3x3 gather padding %s" % (case,))
+    # the data gradient (reflect: pad-0 gradient over the padded extent = a 'full' conv on the tiled kernel, folded back)
+    dy = q(fill.uniform(tuple(ref0.shape), 810 + cout), dt)
+    ref0.backward(dy)
+    dx = ops.conv2d_bwd_data(to_nhwc(dy, dt), w.cuda(), (B, H, W), pad=pad, pad_mode=pmode)
+    assert_close(back(dx), x.grad, dt, "conv3x3 LDS padding, data gradient %s" % (case,))
+
+
 GEMM_CONV_CASES = [
     # cin, cout, k, stride, pad, dil, pad_mode, B, H, W, residual, act      (all hit conv_gemm.hip: cin % 32 == 0, cout >= 64)
     (256, 256, 1, 1, 0, 1, "zero", 2, 80, 80, False, "relu"),       # ResNet 1x1 (128x256 tile config)
@@ -401,4 +455,9 @@ def test_conv_gemm_wide_layers(dt, case):
         lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
     assert_close(back(y2), ref, dt, "conv gather %s" % (case,))
     if k == 1:   # same MFMA k-order in both kernels for 1x1 -> they agree to the last bit (k > 1: taps innermost here)
-        assert torch.equal(y.t, y2.t)
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(4))      # (without round 5's split-K launches: K slices sum in another order)
+        try:
+            y3 = ops.conv2d(xg, pw, **kw)
+        finally:
+            lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+        assert torch.equal(y3.t, y2.t)
