@@ -150,48 +150,6 @@ class ResizeNearestFn(torch.autograd.Function):
         return ops.resize_nearest_bwd(ops.NHWC(dy_t.contiguous(), c), (h, w), cs).t, None, None, None
 
 
-# ---- weight gradients off the data-gradient chain ------------------------------------------------------------------------
-# Nothing in a backward pass depends on a weight gradient except the optimizer step, while every data gradient is a link of
-# one long dependency chain (2 300 launches on the Masker's stream, tools/stream_chain.py).  With WGRAD_STREAM set (the
-# trainer's two-stream backward sets it), ConvFn / ConvPassFn issue their weight-gradient kernels (+ the spectral-norm
-# mapping of the result) on that stream: it waits for the chain's current point (dy is ready there), and the calling stream
-# never waits for it -- the trainer joins it before the optimizer step.  Returned through autograd as before, so the
-# reducer's hooks keep firing (GradBucketReducer.streams has the stream: a bucket's gather waits for it).  Safe only where
-# autograd's AccumulateGrad does no arithmetic on the calling stream, i.e. the parameter receives exactly ONE gradient in
-# this backward and has none yet: forwards count their uses per weight (reset_weight_uses() at the start of an update);
-# any weight used twice (a discriminator applied to two inputs) or never counted keeps its weight gradient on the chain.
-WGRAD_STREAM = None
-WGRAD_FROM = None       # only nodes running on THIS stream (the long chain: the Masker's) hand their weight gradients over
-_WEIGHT_USES = {}
-
-
-def reset_weight_uses():
-    _WEIGHT_USES.clear()
-
-
-def _count_use(weight):
-    k = weight.data_ptr()
-    _WEIGHT_USES[k] = _WEIGHT_USES.get(k, 0) + 1
-
-
-def _wgrad_call(weight, reads, fn):
-    """fn() -> (dw, db) on WGRAD_STREAM when that is safe (see above), else on the calling stream.  ``reads``: the tensors
-    the kernels read that the calling stream may free right after (their blocks must outlive the other stream's use)."""
-    ws = WGRAD_STREAM
-    if ws is None or not weight.is_cuda or _WEIGHT_USES.get(weight.data_ptr(), 0) != 1 or weight.grad is not None:
-        return fn()
-    cur = torch.cuda.current_stream(weight.device)
-    if cur != WGRAD_FROM:
-        return fn()
-    ws.wait_stream(cur)
-    with torch.cuda.stream(ws):
-        out = fn()
-    for t in reads:
-        if t is not None:
-            t.record_stream(ws)
-    return out
-
-
 class ConvFn(torch.autograd.Function):
     """y = act(conv(up?(x), w[/sigma]) + b + up?(res)).  ``weight`` is the fp32 OIHW parameter (``weight_bar`` under
     spectral norm, in which case sigma/u/v of THIS forward's power iteration are given and the weight gradient is mapped
@@ -216,7 +174,6 @@ class ConvFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
-        _count_use(weight)
         # (sigma, u, v) as used in this forward: private copies (the batched step hands them over already copied)
         ctx.sn = None if sn is None else (tuple(sn) if cfg.get("sn_owned") else tuple(t.clone() for t in sn))
         ctx.dgrad = None
@@ -259,7 +216,7 @@ class ConvFn(torch.autograd.Function):
                 if ctx.sn is not None:
                     dw = ops.spectral_norm_bwd(dw, weight.detach(), ctx.sn[1], ctx.sn[2], ctx.sn[0])
                 return dw, db
-            dw, db = _wgrad_call(weight, (x_t, dy.t, dy_t) + (tuple(ctx.sn) if ctx.sn is not None else ()), wgrad)
+            dw, db = wgrad()
         return dx_t, dw, db, dres_t, None, None, None
 
 
@@ -282,7 +239,6 @@ class ConvPassFn(torch.autograd.Function):
                            pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
-        _count_use(weight)
         ctx.dgrad = ops.dgrad_register(weight, None, x_t.dtype, cfg["stride"]) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x_t, weight)
         return y.t, x_t                   # (returned as-is: autograd makes it an output of this node)
@@ -301,9 +257,9 @@ class ConvPassFn(torch.autograd.Function):
                                        pad_mode=cfg.get("pad_mode", ops.PAD_ZERO), add=add, prepacked=ctx.dgrad).t
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = _wgrad_call(weight, (x_t, dy.t, dy_t), lambda: ops.conv2d_bwd_weight(
+            dw, db = ops.conv2d_bwd_weight(
                 ops.NHWC(x_t, cfg["c_in"]), dy, tuple(weight.shape), stride=cfg["stride"], pad=cfg["pad"],
-                dilation=cfg["dilation"], want_bias=ctx.has_bias, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO)))
+                dilation=cfg["dilation"], want_bias=ctx.has_bias, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
         return dx_t, dw, db, None, None
 
 

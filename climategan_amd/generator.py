@@ -123,6 +123,11 @@ class OmniGenerator(nn.Module):
         Painter and the event kernels keep running in 16 bit on the maps rounded once."""
         pair = dtype in ("pair16", "split24")
         if pair:
+            why = self._pair_unsupported()
+            if why:
+                raise NotImplementedError("split-precision inference (%s) is not built for this generator: %s" % (dtype, why))
+            if not self.pair_precision:
+                self._dtype_before_pair = self.compute_dtype      # train() / a later cast restores it
             dtype = torch.float16 if dtype == "pair16" else torch.bfloat16
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16, torch.bfloat16, \"split24\" or \"pair16\"")
@@ -135,6 +140,22 @@ class OmniGenerator(nn.Module):
         self.pair_precision = pair
         return self
 
+    def _pair_unsupported(self):
+        """Why this generator cannot run the split-precision Masker (None: it can).  Only the ResNet encoder, the DADA depth
+        decoder, the DeepLab segmentation decoder and the plain mask decoder carry pair maps."""
+        if self.encoder is None or not hasattr(self.encoder, "pair_precision"):
+            return "the encoder has no pair-map path"
+        if "m" in self.decoders and self.opts.gen.m.use_spade:
+            return "the SPADE mask decoder (gen.m.use_spade) has no pair-map path"
+        return None
+
+    def train(self, mode=True):
+        """nn.Module.train; the split-precision modes are INFERENCE modes: switching to training leaves them and restores the
+        16-bit type that was selected before (a training forward on pair maps is not built)."""
+        if mode and self.pair_precision:
+            self.set_compute_dtype(getattr(self, "_dtype_before_pair", None) or self.compute_dtype)
+        return super().train(mode)
+
     # nn.Module's dtype casts (reference apply_events.py:467-468 ``trainer.G.half()``; trainer.py's ``.to(device)``).  The
     # parameters of this package ARE the fp32 masters -- spectral norm power-iterates them, ExtraAdam steps them and the
     # kernels read 16-bit packs made from them -- so a cast selects the 16-bit type the kernels compute and store in and
@@ -146,10 +167,12 @@ class OmniGenerator(nn.Module):
         return self.set_compute_dtype(torch.bfloat16)
 
     def float(self):
-        """The reference's fp32 inference (apply_events without --half): in eval mode the split-precision mode of the
-        Masker ("split24", see set_compute_dtype); a generator in training mode keeps its 16-bit compute type (the reference
-        trains in fp32; this package trains in bf16 with fp32 masters)."""
-        if not self.training:
+        """The reference's fp32 inference (apply_events without --half).  On an eval-mode generator whose Masker can run on
+        pair maps this selects the split-precision mode ("split24", see set_compute_dtype; ``train()``, ``half()`` or
+        ``bfloat16()`` leave it again).  Anywhere else -- training mode, the SPADE mask decoder, another encoder -- it is a
+        no-op that keeps the 16-bit compute type, as before round 4 (the reference trains in fp32; this package trains in
+        bf16 with fp32 masters): nothing is half-switched and nothing that ran before starts to raise."""
+        if not self.training and self._pair_unsupported() is None:
             return self.set_compute_dtype("split24")
         return self
 

@@ -80,13 +80,6 @@ class Trainer:
         import os
         self.overlap_branches = os.environ.get("CGAN_OVERLAP", "1") != "0"
         self._side = None
-        # a third stream for the weight-gradient kernels of the calling stream's branch (autograd.WGRAD_STREAM: they leave the
-        # data-gradient chain).  OPT-IN (CGAN_WGRAD_STREAM=1 or ``wgrad_stream = True`` before the first update): twelve
-        # alternating runs on one box gave 94.0-94.9 ms per step without it and 93.3 / 93.3 / 93.3 / 94.7 / 95.4 / 98.5 with it
-        # -- a millisecond in the good runs, several lost in the others (which hardware queue the third stream lands on is
-        # decided per process); a step time that repeats is worth more than its best case
-        self._wstream = None
-        self.wgrad_stream = os.environ.get("CGAN_WGRAD_STREAM", "0") == "1"
         # development aid (tools/branch_times.py): [(fork event, end of the main-stream branch, end of the side-stream branch)]
         self.branch_events = [] if os.environ.get("CGAN_BRANCH_TIMES") == "1" else None
 
@@ -181,6 +174,22 @@ class Trainer:
         vgg = (ops.NHWC(vgg_fake_t, 6), vgg_real) if want_vgg else None
         return real_d, fake_d, vgg
 
+    def _painter_aux_terms(self, raw, x, m):
+        """TV(p m) / context / reconstruction terms of reference trainer.py:1289-1315 on the painted image p, from ONE fused
+        kernel (autograd.PainterAuxFn) that forms p = x (1 - m) + raw m itself: ``raw`` is the Painter's map before the paste.
+        The reference applies the terms to ``G.paint()``'s output, which is the un-pasted map when
+        ``gen.p.paste_original_content`` is off: that combination has no kernel and raises instead of computing another loss."""
+        from .autograd import PainterAuxFn
+        lam = self.opts.train.lambdas.G.p
+        if not self.opts.gen.p.paste_original_content or raw is None:
+            raise NotImplementedError("painter TV / context / reconstruction terms with gen.p.paste_original_content = False "
+                                      "have no HIP path (the fused kernel evaluates them on the pasted image)")
+        loss, parts = PainterAuxFn.apply(raw.t, x, m, float(lam.tv), float(lam.context), float(lam.reconstruction))
+        for i, k in enumerate(("tv", "context", "reconstruction")):
+            if lam[k] != 0:
+                self.loss_log["G.p." + k] = parts[i]
+        return loss
+
     def _painter_loss_local_pair(self, batch):
         """``dis.p.use_local_discriminator`` (off in defaults.yaml:227), G side: reference trainer.py:1323-1358.  D["p"] is
         the pair {"global", "local"} of 3-channel discriminators (discriminator.py:246-252); the global one sees the
@@ -192,15 +201,21 @@ class Trainer:
 
         lambdas = self.opts.train.lambdas
         x, m = batch["data"]["x"], batch["data"]["m"]
-        fake = self.G.paint(m, x)
+        aux = any(lambdas.G.p[k] != 0 for k in ("tv", "context", "reconstruction"))
+        if aux and self.opts.gen.p.paste_original_content:
+            # the Painter's raw map is needed as well (the fused image-space kernel pastes it itself): G.paint's two halves
+            from . import functional as Fn
+            raw = self.G.paint_nhwc(m, x)
+            fake = Fn.to_nchw(raw, paste_x=x, paste_m=m.to(x.dtype)).to(x.dtype)
+        else:
+            raw, fake = None, self.G.paint(m, x)
         step_loss = 0
         if lambdas.G.p.vgg != 0 and self.losses["G"]["p"]["vgg"] is not None:                       # :1276-1287
             loss = self.losses["G"]["p"]["vgg"](vgg_preprocess(fake * m), vgg_preprocess(x * m)) * lambdas.G.p.vgg
             self.loss_log["G.p.vgg"] = loss.detach()
             step_loss = step_loss + loss
-        if any(lambdas.G.p[k] != 0 for k in ("tv", "context", "reconstruction")):
-            raise NotImplementedError("painter TV / context / reconstruction terms together with the local / global "
-                                      "discriminator pair have no HIP path")
+        if aux:                                                                                       # :1289-1315
+            step_loss = step_loss + self._painter_aux_terms(raw, x, m)
         fake_d_global = self.D["p"]["global"](fake)
         fake_d_local = self.D["p"]["local"](fake * m)
         real_d_global = self.D["p"]["global"](x)
@@ -227,14 +242,8 @@ class Trainer:
         real_d, fake_d, vgg = self._painter_terms(multi_domain_batch["rf"], True)
         step_loss = 0
         if any(lambdas.G.p[k] != 0 for k in ("tv", "context", "reconstruction")):      # trainer.py:1289-1315 (0 by default)
-            from .autograd import PainterAuxFn
             data = multi_domain_batch["rf"]["data"]
-            loss, parts = PainterAuxFn.apply(self._last_fake.t, data["x"], data["m"], float(lambdas.G.p.tv),
-                                             float(lambdas.G.p.context), float(lambdas.G.p.reconstruction))
-            for i, k in enumerate(("tv", "context", "reconstruction")):
-                if lambdas.G.p[k] != 0:
-                    self.loss_log["G.p." + k] = parts[i]
-            step_loss = step_loss + loss
+            step_loss = step_loss + self._painter_aux_terms(self._last_fake, data["x"], data["m"])
         if vgg is not None:
             loss = self.losses["G"]["p"]["vgg"](vgg[0], vgg[1]) * lambdas.G.p.vgg
             self.loss_log["G.p.vgg"] = loss.detach()
@@ -598,16 +607,9 @@ class Trainer:
         from .norms import _PackCache
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-            # (single-process runs only: under the bucket reducer every bucket launch makes the calling stream wait for the
-            # gradient streams, which puts the weight gradients back on the chain -- and with gloo on one device, the
-            # two-rank test configuration, the step doubled: tests/test_gpu_bench_two_ranks.py)
-            single = self.g_reducer is None and self.d_reducer is None
-            self._wstream = torch.cuda.Stream(device=self.device) if (self.wgrad_stream and single) else None
-            for red in (self.g_reducer, self.d_reducer):           # gradients now come from two (three) streams
+            for red in (self.g_reducer, self.d_reducer):           # gradients now come from two streams
                 if red is not None:
-                    red.streams = [torch.cuda.current_stream(self.device), self._side] + \
-                        ([self._wstream] if self._wstream is not None else [])
-        ag.reset_weight_uses()               # forwards of this update count their uses per weight (autograd._wgrad_call)
+                    red.streams = [torch.cuda.current_stream(self.device), self._side]
         _PackCache.repack_stale(dtype, self.device)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         if self.branch_events is not None:
@@ -636,22 +638,13 @@ class Trainer:
             ops.dgrad_prepack_run(side)      # every stride-1 data-gradient operator of this backward, one pack launch
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dev))        # the arena's zeros, the packed operators
-                prev_ws = (ag.WGRAD_STREAM, ag.WGRAD_FROM)
-                if self._wstream is not None:
-                    self._wstream.wait_stream(torch.cuda.current_stream(dev))
-                    ag.WGRAD_STREAM, ag.WGRAD_FROM = self._wstream, torch.cuda.current_stream(dev)
-                try:
-                    torch.autograd.backward(list(loss))
-                finally:
-                    ag.WGRAD_STREAM, ag.WGRAD_FROM = prev_ws
+                torch.autograd.backward(list(loss))
                 if self.branch_events is not None:
                     em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     em.record(torch.cuda.current_stream(dev))
                     es.record(side)
                     self.branch_events[-1][1:] = [em, es]
                 torch.cuda.current_stream(dev).wait_stream(side)        # the optimizer runs on the calling stream
-                if self._wstream is not None:
-                    torch.cuda.current_stream(dev).wait_stream(self._wstream)
             else:
                 loss.backward()
         finally:

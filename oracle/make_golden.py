@@ -52,6 +52,10 @@ def golden_cases():
         # so that the scaling of this branch (the single-discriminator branch does not scale) shows
         "gstep_p_local": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=93,
                               local=dict(lambda_gan=2.0)),
+        # both non-default branches at once (round 5): the image-space terms of trainer.py:1289-1315 in front of the local /
+        # global pair of :1323-1358, on a soft mask (G side only: the D side is gstep_p_local's)
+        "gstep_p_local_aux": dict(kind="gstep_p", latent_dim=32, n_up=4, ndf=16, n_layers=3, num_D=3, H=96, W=128, B=2, seed=94,
+                                  local=dict(lambda_gan=2.0), aux=dict(tv=2.0, context=3.0, reconstruction=5.0, soft_mask=True)),
         # VGG term of get_painter_loss through the reference's own Vgg19 / VGGLoss / vgg_preprocess; VGG-19 weights from
         # the portable fill with a He-preserving bound (gain sqrt(6): activations keep the input's 0-255 scale)
         "vgg_small": dict(kind="vgg", H=64, W=96, B=2, seed=85, gain=2.449489742783178, lambda_vgg=10.0),
@@ -623,9 +627,16 @@ def run_reference_gstep_local(name, case):
     l_gan = l_gan * lam
     l_fm = fm(real_d_global, fake_d_global) * 10
     loss = l_gan + l_fm
+    aux, extra = case.get("aux", {}), {}
+    if aux:                                                    # trainer.py:1289-1315 come before the pair's terms
+        extra["tv"] = losses.TVLoss()(fake_flooded * m) * aux["tv"]
+        extra["context"] = losses.ContextLoss()(fake_flooded, x, m) * aux["context"]
+        extra["reconstruction"] = losses.ReconstructionLoss()(fake_flooded, x, m) * aux["reconstruction"]
+        loss = loss + sum(extra.values())
     loss.backward()
     out.update({"loss": loss.detach().numpy().reshape(1), "gan": l_gan.detach().numpy().reshape(1),
                 "featmatch": l_fm.detach().numpy().reshape(1), "fake": fake_flooded.detach().numpy()})
+    out.update({k2: v.detach().numpy().reshape(1) for k2, v in extra.items()})
     for key, p in painter.named_parameters():
         if p.requires_grad:
             out["grad." + key] = p.grad.numpy().copy()

@@ -243,6 +243,73 @@ def test_painter_g_step_optional_terms_and_lsgan_match_reference():
     assert checked == sum(1 for k in gold if k.startswith("grad."))
 
 
+def test_painter_local_pair_with_image_space_terms_matches_reference():
+    """Both non-default branches of get_painter_loss together (round 5; the combination used to raise): TV / context /
+    reconstruction (trainer.py:1289-1315) in front of the local / global pair (:1323-1358) on a soft mask, against the
+    reference's own classes (golden ``gstep_p_local_aux``): every term and the gradient of every trainable Painter tensor."""
+    name = "gstep_p_local_aux"
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+    from helpers import disc_p_shapes
+    from climategan_amd import fill
+
+    opts = default_opts()
+    opts.tasks = ["p"]
+    opts.gen.p.latent_dim, opts.gen.p.spade_n_up = case["latent_dim"], case["n_up"]
+    opts.dis.p.ndf, opts.dis.p.n_layers, opts.dis.p.num_D = case["ndf"], case["n_layers"], case["num_D"]
+    opts.dis.p.use_local_discriminator = True
+    opts.dis.soft_shift, opts.dis.flip_prob = 0.0, 0.0
+    lam = opts.train.lambdas.G.p
+    lam.vgg, lam.gan = 0, case["local"]["lambda_gan"]
+    lam.tv, lam.context, lam.reconstruction = case["aux"]["tv"], case["aux"]["context"], case["aux"]["reconstruction"]
+    T = Trainer(opts, device="cuda").setup(inference=False)
+    T.G.painter.load_state_dict(case_state_dict(case), strict=True)
+    shapes = disc_p_shapes(3, case["ndf"], case["n_layers"], case["num_D"])
+    for i, which in enumerate(("global", "local")):
+        T.D["p"][which].load_state_dict({k: t(v) for k, v in fill.fill_state_dict(shapes, case["seed"] + 1 + i).items()},
+                                        strict=True)
+    T.G.set_compute_dtype(torch.float16)
+    T.D.set_compute_dtype(torch.float16)
+    T.G.painter.set_latent_shape((case["B"], 3, case["H"], case["W"]), True)
+    inp = {k: t(v).cuda() for k, v in case_inputs(name, case).items()}
+    batch = {"rf": {"data": {"x": inp["x"], "m": inp["m"]}}}
+    for p in T.D.parameters():
+        p.requires_grad_(False)
+    loss = T.get_painter_loss(batch)
+    loss.backward()
+    for key, log, tol in (("gan", "G.p.gan", 5e-3), ("featmatch", "G.p.featmatch", 1e-2), ("tv", "G.p.tv", 1e-2),
+                          ("context", "G.p.context", 5e-3), ("reconstruction", "G.p.reconstruction", 5e-3)):
+        ref, got = float(gold[key][0]), float(T.loss_log[log])
+        assert abs(got - ref) <= tol * abs(ref), (key, got, ref)
+    assert abs(loss.item() - float(gold["loss"][0])) <= 1e-2 * float(gold["loss"][0])
+    bad, checked = [], 0
+    for key, p in T.G.painter.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = gold["grad." + key].astype(np.float64)
+        got = p.grad.cpu().numpy().astype(np.float64)
+        base = key.rsplit(".", 1)[0]
+        wkey = "grad." + base + (".weight_bar" if "grad." + base + ".weight_bar" in gold else ".weight")
+        wscale = np.abs(gold[wkey]).max()
+        if key.endswith("bias") and np.abs(ref).max() < 1e-4 * wscale:
+            if np.abs(got).max() > 1e-2 * wscale:
+                bad.append((key, "zero-bias", np.abs(got).max() / wscale))
+        else:
+            l2 = np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum())
+            cos = (got * ref).sum() / np.sqrt((got ** 2).sum() * (ref ** 2).sum())
+            if not (l2 <= 0.15 and cos >= 0.99):
+                bad.append((key, l2, cos))
+        checked += 1
+    assert not bad, bad
+    assert checked == sum(1 for k in gold if k.startswith("grad."))
+    # the un-pasted form of the terms has no kernel: loud, not another loss (advisor, round 4)
+    T.opts.gen.p.paste_original_content = False
+    with pytest.raises(NotImplementedError):
+        T.get_painter_loss(batch)
+
+
 def test_painter_local_global_discriminator_pair_matches_reference():
     """``dis.p.use_local_discriminator`` (reference trainer.py:1323-1358 on the G side, 1085-1099 on the D side; the pair is
     built by OmniDiscriminator, discriminator.py:246-252) against the reference's own modules (golden ``gstep_p_local``,

@@ -190,7 +190,11 @@ def test_product_library_exports_no_development_knob():
 
     def exported(path):
         out = subprocess.run(["nm", "-D", "--defined-only", str(path)], check=True, capture_output=True, text=True).stdout
-        return {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("cgan_")}
+        names = {line.split()[-1] for line in out.splitlines() if line.split()}
+        # the dynamic symbol table holds the C ABI only (csrc/exports.map): no C++-mangled internals of the kernels' launchers
+        foreign = sorted(n for n in names if not n.startswith("cgan_"))
+        assert not foreign, "%s exports symbols outside the C ABI: %s" % (path.name, foreign[:8])
+        return names
 
     prod, dev = exported(_lib.LIB_PATH), exported(_lib.DEV_LIB_PATH)
     assert prod == set(_lib.EXPORTED_SYMBOLS), sorted(prod ^ set(_lib.EXPORTED_SYMBOLS))
@@ -198,3 +202,34 @@ def test_product_library_exports_no_development_knob():
     knobs = dev - prod
     assert knobs and all(s.startswith("cgan_debug_") for s in knobs), sorted(knobs)
     assert prod <= dev
+
+
+def test_float_cast_is_guarded_and_reversible():
+    """``G.float()`` (the reference's fp32 apply_events run, apply_events.py:465-468) selects the split-precision Masker only
+    where every module can run it, never in training mode, and ``train()`` / a 16-bit cast leave the mode again (advisor,
+    round 4: the mode was sticky and half-switched generators it could not serve)."""
+    import pytest
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    G = create_generator(opts, no_init=True)
+    G.half()
+    assert G.train().float().pair_precision is False and G.compute_dtype == torch.float16      # training mode: no-op
+    G.eval().float()
+    assert G.pair_precision and G.encoder.pair_precision and G.compute_dtype == torch.bfloat16  # split24 = bf16 triples
+    G.train()
+    assert not G.pair_precision and not G.encoder.pair_precision and G.compute_dtype == torch.float16
+    G.eval().float().bfloat16()
+    assert not G.pair_precision and G.compute_dtype == torch.bfloat16
+
+    opts2 = default_opts()
+    opts2.tasks = ["d", "s", "m"]
+    opts2.gen.m.use_spade = True
+    G2 = create_generator(opts2, no_init=True)
+    before = G2.compute_dtype
+    G2.eval().float()
+    assert not G2.pair_precision and G2.compute_dtype == before                   # unsupported: keeps the 16-bit type
+    with pytest.raises(NotImplementedError):
+        G2.set_compute_dtype("split24")

@@ -10,7 +10,7 @@ CASES = golden_cases()
 TOL = 2e-5
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p", "gstep_p", "gstep_p_aux", "gstep_p_local", "cloudy_small", "maskspade_small", "masker_losses", "mstep", "mstep_spade", "vgg_small", "fire_small")])
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ("painter_640", "masker_small", "infer_small", "dstep_p", "gstep_p", "gstep_p_aux", "gstep_p_local", "gstep_p_local_aux", "cloudy_small", "maskspade_small", "masker_losses", "mstep", "mstep_spade", "vgg_small", "fire_small")])
 def test_oracle_matches_golden(name):
     gold = load_golden(name)
     got = run_oracle(name, CASES[name])
