@@ -479,7 +479,7 @@ def joint_batch(bs, rank, device, domains=("r", "s", "rf")):
     return {d: batch[d] for d in domains}
 
 
-def build_trainer(device, dtype, tasks=("d", "s", "m", "p")):
+def build_trainer(device, dtype, tasks=("d", "s", "m", "p"), freeze=False):
     """``Trainer.setup(inference=False)`` of the default config, every parameter overwritten by the portable fill."""
     from climategan_amd import fill
     from climategan_amd.config import default_opts
@@ -500,6 +500,11 @@ def build_trainer(device, dtype, tasks=("d", "s", "m", "p")):
     # (under torchrun the replicas were broadcast inside setup(); every rank then loads the same portable fill)
     T.G.set_compute_dtype(dtype)
     T.D.set_compute_dtype(dtype)
+    # ``freeze`` (bench.py's own runs): this process trains this one trainer at a time, its long-lived Python objects leave
+    # the garbage collector's generations (a full collection cost one 160-220 ms step in ~34); opt-in since
+    # round 5 because it is process-global; ``T.close()`` undoes it before the trainer is dropped
+    if freeze:
+        T.freeze_host_objects()
     return T
 
 
@@ -751,10 +756,11 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
 
 def masker_block(steps, warmup, rank, world, device, dtype, dist, barrier):
     """configs[2]: Masker train step (encoder + depth / seg / mask decoders + ADVENT discriminators), bs 8."""
-    T = build_trainer(device, dtype, tasks=("d", "s", "m"))
+    T = build_trainer(device, dtype, tasks=("d", "s", "m"), freeze=True)
     batch = joint_batch(MASKER_BS, rank, device, domains=("r", "s"))
     elapsed = max_over_ranks(timed_steps(lambda: T.train_step(batch), steps, warmup, barrier), dist, device)
     assert all(torch.isfinite(v) for v in T.loss_log.values())
+    T.close()
     return {"workload": "BASELINE configs[2]: Masker train step (Trainer.train_step, tasks d,s,m; domains r,s), 640x640, "
                         "bs 8 per domain per GPU, bf16",
             "images_per_s": round(world * MASKER_BS * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
@@ -770,7 +776,7 @@ def large_batch_block(steps, warmup, rank, device, dtype, barrier):
     for bs in (32, 16):
         T = batch = None
         try:
-            T = build_trainer(device, dtype)
+            T = build_trainer(device, dtype, freeze=True)
             batch = joint_batch(bs, rank, device)
             T.G.painter.set_latent_shape((bs, 3, H, W), True)
             torch.cuda.reset_peak_memory_stats()
@@ -785,6 +791,8 @@ def large_batch_block(steps, warmup, rank, device, dtype, barrier):
         except RuntimeError as e:
             tried[str(bs)] = str(e)[:240]
         finally:
+            if T is not None:
+                T.close()
             del T, batch
             torch.cuda.empty_cache()
     return {"error": "no large batch ran", "attempts": tried}
@@ -889,7 +897,7 @@ def main():
         return
 
     # ---------------------------------------------------------------- headline: the joint G+D training step
-    T = build_trainer(device, dtype)
+    T = build_trainer(device, dtype, freeze=True)
     batch = joint_batch(TRAIN_BS, rank, device)
     T.G.painter.set_latent_shape((TRAIN_BS, 3, H, W), True)
     timer = LaunchTimer()
@@ -1037,6 +1045,7 @@ def main():
             os._exit(0)
 
     threading.Thread(target=watchdog, daemon=True).start()
+    T.close()
     del T, batch
     torch.cuda.empty_cache()
     sub = {}

@@ -368,10 +368,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 // CH = pixels per stage (64 or 32); a sub-slab is CH pixels x 64 channels x 2 B; a stage = dy half 0 | dy half 1 |
 // x tile 0 | x tile 1; two stages: 64 KiB (2 workgroups per CU) or 32 KiB (4 per CU) of LDS.
 
-template <typename T, int MODE, int CH = 64, bool TS = false, bool BIAS = false>
-__global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(WgradArgs p) {
-  constexpr int CHUNK2 = CH, SUB2 = CH * 128, STAGE2 = 4 * SUB2;
-  constexpr int PPS = CH / 8, PW = PPS / 2;      // pieces per sub-slab, pieces of each operand a wave stages
+// G = 4 (round 5): the same kernel on a 4 x 4 grid of waves -- a 256 co x 256 column tile per workgroup, 16 waves (four per
+// SIMD, one workgroup per CU, 128 KiB of LDS for two 64-pixel stages): every staged sub-slab now feeds FOUR quadrants instead
+// of two, i.e. half the L2 -> LDS bytes and half the LDS-DMA pieces per MFMA (4 pieces per wave and chunk instead of 8: the
+// pieces' issue time was as long as the chunk's MFMAs, tools/ts_wgrad.py), and four waves per SIMD to cover one another's
+// piece issue and transposing reads.  Needs co and N block counts divisible by four (256-channel multiples on both sides:
+// ResNet layer3 / layer4, ASPP, the decoders' 512-channel convs).
+template <typename T, int MODE, int CH = 64, bool TS = false, bool BIAS = false, int G = 2>
+__global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void conv_wgrad_coop_kernel(WgradArgs p) {
+  constexpr int CHUNK2 = CH, SUB2 = CH * 128, STAGE2 = 2 * G * SUB2;
+  constexpr int PPS = CH / 8, PW = PPS / G;      // pieces per sub-slab, pieces of each operand a wave stages
+  static_assert(PW >= 1, "a wave stages at least one piece of each operand");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -382,12 +389,12 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
   item /= p.co_pairs;
   const int np = item % p.n_pairs;
   const int split = item / p.n_pairs;
-  const int cpairs = p.fold ? 1 : (p.ci_blocks + 1) / 2;        // N-tile pairs per tap slot (normal layout)
-  // N tile (slot, cib) of pair member m
+  const int cpairs = p.fold ? 1 : (p.ci_blocks + G - 1) / G;    // N-tile groups per tap slot (normal layout)
+  // N tile (slot, cib) of group member m
   auto n_tile = [&](int m, int& slot, int& cib) {
-    if (p.fold) { slot = np * 2 + m; cib = 0; return slot < p.tap_slots; }
+    if (p.fold) { slot = np * G + m; cib = 0; return slot < p.tap_slots; }
     slot = np / cpairs;
-    cib = (np - slot * cpairs) * 2 + m;
+    cib = (np - slot * cpairs) * G + m;
     return cib < p.ci_blocks;
   };
 
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
   // an x piece cost ~4x a dy piece in issue time -- ~28 scalar instructions of coordinate carries per piece -- and the dy
   // waves spent 40 % of their life at the barrier waiting for the x waves, tools/ts_wgrad.py.)
   const int prow = lane >> 3, qs = (lane & 7) ^ swz(prow), q8 = qs * 8;
-  const int mem = wave >> 1, half = wave & 1;
+  const int mem = wave / G, half = wave % G;     // sub-slab (co block of the group / N tile of the group), its part
   const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
   const int hx = MODE == 1 ? (p.h_in >> 1) : p.h_in, wx = MODE == 1 ? (p.w_in >> 1) : p.w_in;
   const unsigned row_b = (unsigned)wx * cin_b;
@@ -404,8 +411,8 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
   unsigned dy_c = 0x80000000u;                  // dy lane constant (or the always-out-of-range marker)
   {
-    const int co = (cop * 2 + mem) * 64 + q8;
-    if ((cop * 2 + mem) < p.co_blocks && co < p.cout_s) dy_c = (unsigned)prow * cout_b + (unsigned)co * 2u;
+    const int co = (cop * G + mem) * 64 + q8;
+    if ((cop * G + mem) < p.co_blocks && co < p.cout_s) dy_c = (unsigned)prow * cout_b + (unsigned)co * 2u;
   }
   int lx, ly;                                   // x: the lane's tap offset (lx far out of range for a dead lane)
   unsigned cch2, x_c;
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
     if (MODE == 1) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
     else if (MODE == 2) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + iy) * row_b + (unsigned)ix * cin_b + cch2;
     else off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + x_c;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + 2 * SUB2 + j * 1024), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + G * SUB2 + j * 1024), 16,
                                              xv ? off : 0xffffffffu, 0, 0, 0);
   };
   auto advance = [&]() {
@@ -493,8 +500,8 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
     v_sx = sx; v_sy = sy; v_nh = nh;
   };
 
-  // ---- compute role: quadrant (co half wc, N tile wn)
-  const int wc = wave & 1, wn = wave >> 1;
+  // ---- compute role: quadrant (co block wc of the group, N tile wn)
+  const int wc = wave % G, wn = wave / G;
   f32x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
     }
     if (TS) { t_b = __builtin_readcyclecounter(); ts_sum[2] += t_b - t_a; }
     const unsigned char* sdy = smem + buf * STAGE2 + wc * SUB2;
-    const unsigned char* sx = smem + buf * STAGE2 + (2 + wn) * SUB2;
+    const unsigned char* sx = smem + buf * STAGE2 + (G + wn) * SUB2;
 #pragma unroll
     for (int ks = 0; ks < CH / 32; ++ks) {
       u32x4 fa[4], fb[4];
@@ -549,10 +556,10 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
     buf ^= 1;
     if (TS) { t_a = __builtin_readcyclecounter(); ts_sum[3] += t_a - t_b; }
   }
-  if (BIAS && do_bias && cop * 2 + wc < p.co_blocks)
-    store_bias_row(p.bpart + (size_t)split * p.cout_s, accb, 4, (cop * 2 + wc) * 64, p.cout_s, lane);
+  if (BIAS && do_bias && cop * G + wc < p.co_blocks)
+    store_bias_row(p.bpart + (size_t)split * p.cout_s, accb, 4, (cop * G + wc) * 64, p.cout_s, lane);
   if (TS && CGAN_WTS(p) && lane == 0) {
-    unsigned long long* o = CGAN_WTS(p) + ((size_t)blockIdx.x * 4 + wave) * 8;
+    unsigned long long* o = CGAN_WTS(p) + ((size_t)blockIdx.x * (G * G) + wave) * 8;
     o[0] = t_start;
     o[1] = __builtin_readcyclecounter();
     for (int i = 0; i < 4; ++i) o[2 + i] = ts_sum[i];
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(256, CH == 64 ? 2 : 4) void conv_wgrad_coop_kernel(
   }
 
   // ---- the quadrant is a complete 64 x 64 tile of this pixel split
-  const int cob = cop * 2 + wc;
+  const int cob = cop * G + wc;
   int slot_c, cib_c;
   const bool nt_ok = n_tile(wn, slot_c, cib_c);
   if (cob >= p.co_blocks || !nt_ok) return;
@@ -848,6 +855,7 @@ CGAN_KNOB(int, g_wgrad_coop_min_pix, 32768);
 CGAN_KNOB(int, g_wgrad_coop_chunk, 0);
 CGAN_KNOB(int, g_wgrad_slots, 512);
 CGAN_KNOB(int, g_wgrad_tile, 1);
+CGAN_KNOB(int, g_wgrad_coop_g, 0);          // dev: 0 = automatic, 2 = never the 16-wave 256 x 256 tile, 4 = wherever it applies
 CGAN_KNOB(int, g_wgrad_bias_fused, 1);      // dev: 0 = the separate channel-sum pass for every bias gradient
 CGAN_KNOB(int, g_wgrad_ws_cost_pct, 100);   // dev: the planner's cost of a partial tile through the workspace, in % of the fitted value
 CGAN_KNOB(unsigned long long*, g_wgrad_ts, nullptr);
@@ -862,6 +870,7 @@ extern "C" void cgan_debug_set_wgrad_slots(int v) { g_wgrad_slots = v > 0 ? v : 
 extern "C" void cgan_debug_set_wgrad_coop_chunk(int v) { g_wgrad_coop_chunk = (v == 32 || v == 64) ? v : 0; }   // 0: automatic
 
 extern "C" void cgan_debug_set_wgrad_coop_min_pixels(int v) { g_wgrad_coop_min_pix = v; }
+extern "C" void cgan_debug_set_wgrad_coop_g(int v) { g_wgrad_coop_g = (v == 2 || v == 4) ? v : 0; }
 
 extern "C" void cgan_debug_set_wgrad(int target_workgroups, int dbg) {
   g_wgrad_target = target_workgroups;          // > 0: target number of workgroups; < 0: -target pixel splits, as given
@@ -876,6 +885,7 @@ constexpr int BIAS_MAX_ROWS = 1024;       // rows of bias partials the workspace
 struct WgradPlan {
   int fold, cpt, tpt, tap_slots, ci_blocks, co_blocks, splits;
   int coop, co_pairs, n_pairs, chunk;   // chunk: pixels per stage of the cooperative kernel (64 / 32)
+  int g;                                // wave grid of the cooperative kernel: 2 (128 x 128 tile) or 4 (256 x 256, 16 waves)
   int tile;                             // the spatially tiled 3 x 3 kernel (conv_wgrad_tile3x3_kernel)
   long tiles() const { return (long)tap_slots * ci_blocks * co_blocks; }
 };
@@ -894,6 +904,7 @@ static WgradPlan wgrad_plan(const CganConvDesc* d, bool have_ws = true) {
   const long npix = (long)d->n * d->h_out * d->w_out;
   // cooperative 128 x 128 kernel: needs 2 co blocks and 2 N tiles to pair, rows of whole 8-pixel pieces, and either so many pixels that 4x the splits still leaves long pixel ranges or so many tiles that the
   // splits stay few (the partial-tile workspace grows with the splits)
+  pl.g = 2;
   pl.co_pairs = (pl.co_blocks + 1) / 2;
   pl.n_pairs = pl.fold ? (pl.tap_slots + 1) / 2 : pl.tap_slots * ((pl.ci_blocks + 1) / 2);
   // (odd block counts would leave a quarter of the quadrants idle: 128 -> 160 at 4 x 320^2 is 6 % slower that way)
@@ -951,6 +962,25 @@ static WgradPlan wgrad_plan(const CganConvDesc* d, bool have_ws = true) {
   };
   int nchunks = 0;
   pl.chunk = pl.coop ? 64 : 128;
+  // 16-wave 256 x 256 tile (round 5): block counts divisible by four on both sides; one workgroup per CU, so the splits are
+  // sized to 256 slots; taken where every workgroup still walks a handful of chunks (its 256 KiB partial tile and its
+  // first fill are not amortised below that)
+  if (pl.coop && g_wgrad_coop_g != 2 && (pl.co_blocks % 4) == 0 && ((pl.fold ? pl.tap_slots : pl.ci_blocks) % 4) == 0 &&
+      g_wgrad_coop_chunk == 0) {
+    const long tiles4 = (long)(pl.co_blocks / 4) * (pl.fold ? pl.tap_slots / 4 : (long)pl.tap_slots * (pl.ci_blocks / 4));
+    const int nch = (int)((npix + 63) / 64);
+    long sp = g_wgrad_target < 0 ? -g_wgrad_target : (g_wgrad_slots / 2) / tiles4;
+    if (sp < 1) sp = 1;
+    if (sp > nch) sp = nch;
+    if (g_wgrad_coop_g == 4 || (tiles4 <= g_wgrad_slots / 2 && nch / sp >= 8)) {
+      pl.g = 4;
+      pl.co_pairs = pl.co_blocks / 4;
+      pl.n_pairs = pl.fold ? pl.tap_slots / 4 : pl.tap_slots * (pl.ci_blocks / 4);
+      pl.chunk = 64;
+      pl.splits = (int)sp;
+      return pl;
+    }
+  }
   long splits = plan_splits(pl.chunk, g_wgrad_slots, nchunks);
   // cooperative kernel with 32-pixel stages (32 KiB of LDS, 4 workgroups per CU = 1024 at a time): pays on long pixel
   // ranges (ASPP 3x3 2048 -> 256: 612 -> 583 us, SPADE gamma|beta 128 -> 80 at 4 x 640^2: 586 -> 550 us, layer4) and
@@ -1025,7 +1055,8 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     const int rows = a.splits * ((pl.tile || pl.coop) ? 1 : 4);
     // (not in the two variants without registers to spare: the cooperative kernel's 32-pixel stages, the tiled kernel with
     // four co tiles)
-    const bool variant_ok = pl.tile ? (pl.co_blocks == 1 && ceil_div(cgan_cs(d->c_out), 16) < 4) : (!pl.coop || pl.chunk == 64);
+    const bool variant_ok = pl.tile ? (pl.co_blocks == 1 && ceil_div(cgan_cs(d->c_out), 16) < 4)
+                                    : (!pl.coop || (pl.chunk == 64 && pl.g == 2));
     if (dbias && rows <= BIAS_MAX_ROWS && variant_ok && g_wgrad_bias_fused && CGAN_WTS(a) == nullptr) {
       a.bpart = a.ws + (size_t)pl.tiles() * (size_t)pl.splits * 64 * 64;
       bias_rows = rows;
@@ -1062,6 +1093,27 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #undef TILE_NA
 #undef TILE_NB
 #undef TILE_LAUNCH
+  } else if (pl.coop && pl.g == 4) {
+    const size_t smem4 = (size_t)2 * 8 * 64 * 128;      // two stages of 4 dy + 4 x sub-slabs: 128 KiB
+#define COOP4_LAUNCH(TT, MM)                                                                                           \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_coop_kernel<TT, MM, 64, false, false, 4>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+      if (e != hipSuccess) {                                                                                           \
+        cgan_set_error("conv2d_nhwc_bwd_weight: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                \
+        return CGAN_ERR_HIP;                                                                                           \
+      }                                                                                                                \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, 64, false, false, 4>), dim3(gx), dim3(1024), smem4, s, a);      \
+  } while (0)
+#define COOP4_MODE(TT) do { if (mode == 1) COOP4_LAUNCH(TT, 1); else if (mode == 2) COOP4_LAUNCH(TT, 2); else COOP4_LAUNCH(TT, 0); } while (0)
+    if (d->dtype == CGAN_F16) COOP4_MODE(F16);
+    else COOP4_MODE(BF16);
+#undef COOP4_MODE
+#undef COOP4_LAUNCH
   } else if (pl.coop) {
     const size_t smem2 = (size_t)2 * 4 * pl.chunk * 128;
 #define COOP_LAUNCH(TT, MM, CC, BB) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC, false, BB>), dim3(gx), dim3(256), smem2, s, a)

@@ -146,6 +146,7 @@ class GradBucketReducer:
             b.seen = set()
             b.stale = False
             b.work = None
+            b.sent = None
 
     def _views(self, b: _Bucket, grads):
         """The bucket's flat buffer and its per-parameter views (shaped like the gradients), allocated once."""

@@ -134,18 +134,31 @@ class Trainer:
             broadcast_parameters(self.D)
             self.g_reducer = GradBucketReducer(g_params)
             self.d_reducer = GradBucketReducer(d_params)
-        # Host side: everything built so far (modules, parameters, packed-weight caches, optimizer state: ~10^6 Python
-        # objects) lives for the whole run.  Left in the collector's generations, every full collection walks all of it:
-        # 110-125 ms of host time every ~34 train steps (tools/step_times.py), five times the lead the host has over the
-        # GPU -- one 210 ms step in 34, +5 ms on a 20-step average when it falls into the window.  Frozen, a full
-        # collection only looks at what a step creates.  (Reference counting still frees these objects when they die;
-        # CGAN_GC_FREEZE=0 keeps the interpreter's default.)
-        if os.environ.get("CGAN_GC_FREEZE", "1") != "0":
-            import gc
-            gc.collect()
-            gc.freeze()
+        if os.environ.get("CGAN_GC_FREEZE", "0") == "1":
+            self.freeze_host_objects()
         self.is_setup = True
         return self
+
+    def freeze_host_objects(self):
+        """Opt-in, for a process that trains ONE trainer for its whole life (bench.py, a training entry point; or
+        CGAN_GC_FREEZE=1): everything built so far -- modules, parameters, packed-weight caches, optimizer state, ~10^6
+        Python objects -- leaves the garbage collector's generations.  Left there, every full collection walks all of it:
+        110-125 ms of host time every ~34 train steps (tools/step_times.py), five times the lead the host has over the
+        GPU.  The side effect is process-global (``gc.freeze()`` moves EVERY live object, the caller's too, to the
+        permanent generation, where reference cycles are never reclaimed), which is why ``setup()`` does not do it on its
+        own (advisor, round 4); ``close()`` undoes it."""
+        import gc
+        gc.collect()
+        gc.freeze()
+        self._gc_frozen = True
+        return self
+
+    def close(self):
+        """Undo ``freeze_host_objects`` (the permanent generation returns to the collector)."""
+        if getattr(self, "_gc_frozen", False):
+            import gc
+            gc.unfreeze()
+            self._gc_frozen = False
 
     # ------------------------------------------------------------------------------------------ training
     def _painter_terms(self, batch, for_g):

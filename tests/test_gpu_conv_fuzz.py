@@ -436,3 +436,49 @@ def test_small_grids_run_as_k_slices_of_the_tiled_gemm(dt, case):
     finally:
         lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
     assert rel_err(yg.t.float(), y2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)
+
+
+@pytest.mark.usefixtures("dev_lib")
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (cin, cout, k, stride, pad, dil, B, H, W, reflect): block counts divisible by four on both sides, w_out % 8 == 0
+    (256, 256, 3, 1, 2, 2, 2, 24, 16, False),     # ResNet layer3 (resnet101_v3.py:30-50)
+    (256, 512, 1, 1, 0, 1, 2, 16, 24, False),
+    (512, 256, 1, 1, 0, 1, 1, 40, 40, False),
+    (256, 256, 3, 1, 1, 1, 1, 16, 16, True),      # reflect padding
+    (8, 256, 4, 2, 1, 1, 2, 32, 32, False),       # folded taps: 4 tap slots
+])
+def test_weight_gradient_on_the_16_wave_tile(dt, case):
+    """Round 5: conv_wgrad_coop_kernel on a 4 x 4 wave grid (256 x 256 tile, 16 waves, one workgroup per CU), forced through
+    the development knob on small shapes, with the default and with given pixel splits: against torch's fp32 gradient of the
+    16-bit-rounded operands and against the 2 x 2 grid it generalises (same products, same per-quadrant summation order for
+    equal splits: bit-identical)."""
+    from climategan_amd import _lib, ops
+    cin, cout, k, stride, pad, dil, B, H, W, reflect = case
+    lib = _lib.load()
+    x = q(fill.uniform((B, cin, H, W), 5100 + cin + H), dt)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = q(fill.uniform((cout, cin, k, k), 5200 + cout + k, -bound, bound), dt).requires_grad_(True)
+    b = torch.from_numpy(fill.uniform((cout,), 5300 + cout, -bound, bound)).requires_grad_(True)
+    xin = F.pad(x, (pad,) * 4, mode="reflect") if reflect else x
+    y = F.conv2d(xin, w, b, stride=stride, padding=0 if reflect else pad, dilation=dil)
+    dy = q(fill.uniform(tuple(y.shape), 5400 + cout + W), dt)
+    y.backward(dy)
+    xg, dyg = ops.nchw_to_nhwc(x.cuda(), dt), ops.nchw_to_nhwc(dy.cuda(), dt)
+    kw = dict(stride=stride, pad=pad, dilation=dil, pad_mode=ops.PAD_REFLECT if reflect else ops.PAD_ZERO)
+    try:
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(0))
+        for splits in (0, 1, 3):
+            lib.cgan_debug_set_wgrad(ctypes.c_int(-splits), ctypes.c_int(0))
+            lib.cgan_debug_set_wgrad_coop_g(ctypes.c_int(4))
+            dw4, db4 = ops.conv2d_bwd_weight(xg, dyg, tuple(w.shape), **kw)
+            assert rel_err(dw4.cpu(), w.grad) <= 3e-4, ("16-wave tile", splits)
+            assert rel_err(db4.cpu(), b.grad) <= 3e-4, ("16-wave tile, bias", splits)
+            if splits:
+                lib.cgan_debug_set_wgrad_coop_g(ctypes.c_int(2))
+                dw2, _ = ops.conv2d_bwd_weight(xg, dyg, tuple(w.shape), **kw)
+                assert torch.equal(dw4, dw2), ("4 x 4 vs 2 x 2 wave grid", splits)
+    finally:
+        lib.cgan_debug_set_wgrad_coop_g(ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
+        lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
