@@ -452,6 +452,33 @@ def all_mfma_summary(timer, steps):
     return out
 
 
+def mfma_roofline(run, steps=2, table_path=""):
+    """``roofline`` sub-object of a sub-block: ``steps`` extra runs of ``run`` (single-stream) with EVERY MFMA-kernel launch
+    bracketed by events (install_all_mfma_timer), per kernel family against both rooflines; the per-shape table goes to
+    ``table_path`` when given."""
+    t = LaunchTimer()
+    un = install_all_mfma_timer(t)
+    t.enabled = True
+    try:
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+    finally:
+        t.enabled = False
+        un()
+    if not t.pairs:
+        return None
+    fam = all_mfma_summary(t, steps)
+    if table_path:
+        with open(table_path, "w") as f:
+            f.write(t.table(steps) + "\n")
+    return {"bound": "mfma", "kernel": "every MFMA kernel of the workload (wide-layer GEMM family, 3x3 LDS-tiled, general, weight "
+                                       "gradients, fused SPADE): launch events on %d extra single-stream runs" % steps,
+            "achieved": fam["all"]["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fam["all"]["frac_mfma"],
+            "mfma_kernel_ms": fam["all"]["ms_per_step"], "algorithmic_flops": fam["all"]["algorithmic_flops_per_step"],
+            "by_family": {k: v for k, v in fam.items() if k != "all"}}
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def _dev(a, device):
     return torch.from_numpy(a).to(device)
@@ -754,17 +781,21 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
     return res
 
 
-def masker_block(steps, warmup, rank, world, device, dtype, dist, barrier):
+def masker_block(steps, warmup, rank, world, device, dtype, dist, barrier, table_path=""):
     """configs[2]: Masker train step (encoder + depth / seg / mask decoders + ADVENT discriminators), bs 8."""
     T = build_trainer(device, dtype, tasks=("d", "s", "m"), freeze=True)
     batch = joint_batch(MASKER_BS, rank, device, domains=("r", "s"))
     elapsed = max_over_ranks(timed_steps(lambda: T.train_step(batch), steps, warmup, barrier), dist, device)
     assert all(torch.isfinite(v) for v in T.loss_log.values())
+    roof = None
+    if world == 1:
+        T.overlap_branches = False
+        roof = mfma_roofline(lambda: T.train_step(batch), 2, table_path)
     T.close()
     return {"workload": "BASELINE configs[2]: Masker train step (Trainer.train_step, tasks d,s,m; domains r,s), 640x640, "
                         "bs 8 per domain per GPU, bf16",
             "images_per_s": round(world * MASKER_BS * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 2),
-            "steps": steps, "warmup": warmup}
+            "steps": steps, "warmup": warmup, "roofline": roof}
 
 
 def large_batch_block(steps, warmup, rank, device, dtype, barrier):
@@ -798,7 +829,7 @@ def large_batch_block(steps, warmup, rank, device, dtype, barrier):
     return {"error": "no large batch ran", "attempts": tried}
 
 
-def infer_block(steps, warmup, rank, world, device, dist, barrier):
+def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""):
     """configs[4]: the apply_events inference loop (Trainer.infer_all: Masker + flood painter + wildfire + smog, uint8
     results copied to the host), 640x640, 16 images per GPU, fp16."""
     from climategan_amd import fill
@@ -822,12 +853,34 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier):
     # the opt-in inference mode of SURVEY 8f N2: spectral-norm weights frozen (no power iteration / re-pack per call)
     T.G.freeze_spectral_norm(True)
     frozen = max_over_ranks(timed_steps(step, steps, 2, barrier), dist, device)
+    T.G.freeze_spectral_norm(False)
+    roof = None
+    if world == 1:
+        ov = T.overlap_branches
+        T.overlap_branches = False
+        roof = mfma_roofline(step, 2, table_path)
+        T.overlap_branches = ov
+    # the reference's DEFAULT apply_events run is fp32 (--half is opt-in, apply_events.py:465-468): G.float() = the
+    # split-precision Masker (bf16 triples through the same MFMA kernels, 6x the multiply work, fp32-grade flood mask);
+    # the Painter and the event kernels stay 16-bit
+    T.G.eval().float()
+    assert T.G.pair_precision
+
+    def step32():
+        out.update(T.infer_all(x, numpy=True, bin_value=0.5, half=False))
+
+    n32 = max(3, steps // 2)
+    fp32 = max_over_ranks(timed_steps(step32, n32, 2, barrier), dist, device)
+    T.G.set_compute_dtype(torch.float16)
     return {"workload": "BASELINE configs[4]: apply_events inference (Trainer.infer_all: flood + wildfire + smog, uint8 "
                         "results on the host), 640x640, 16 images per GPU, fp16",
             "images_per_s": round(world * INFER_BS * steps / elapsed, 2), "ms_per_batch": round(elapsed / steps * 1e3, 2),
             "images_per_s_frozen_spectral_norm": round(world * INFER_BS * steps / frozen, 2),
             "ms_per_batch_frozen_spectral_norm": round(frozen / steps * 1e3, 2),
-            "steps": steps, "warmup": warmup}
+            "images_per_s_fp32_grade": round(world * INFER_BS * n32 / fp32, 2),
+            "ms_per_batch_fp32_grade": round(fp32 / n32 * 1e3, 2),
+            "fp32_grade_mode": "G.float() = set_compute_dtype('split24'): split-precision Masker (DESIGN 4.8), %d timed batches" % n32,
+            "steps": steps, "warmup": warmup, "roofline": roof}
 
 
 SUB_BLOCK_TIMEOUT_S = 1200    # watchdog of the sub-blocks (the headline line is complete before they start)
@@ -846,10 +899,21 @@ def main():
     ap.add_argument("--mfma-table-steps", type=int, default=2,
                     help="extra single-stream steps after the timed region with EVERY MFMA-kernel launch bracketed (0 = skip)")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each sub-block (0 = skip the sub-blocks)")
+    ap.add_argument("--ddp-bucket-mb", type=float, default=0.0, help="N > 1: gradient bucket size of the reducer (default 25)")
+    ap.add_argument("--ddp-bf16-wire", action="store_true", help="N > 1: bf16 gradient buckets on the wire (default fp32)")
+    ap.add_argument("--nccl-max-nchannels", type=int, default=0,
+                    help="N > 1: NCCL_MAX_NCHANNELS for RCCL (fewer channels = fewer CUs taken from the backward pass)")
     ap.add_argument("--only", default="", help="run ONE workload as the only measurement (profiling aid): "
                                                "painter | masker | large | infer")
     args = ap.parse_args()
 
+    # multi-GPU knobs reach the reducer / RCCL through the environment (read at communicator / reducer construction)
+    if args.ddp_bucket_mb > 0:
+        os.environ["CGAN_DDP_BUCKET_MB"] = str(args.ddp_bucket_mb)
+    if args.ddp_bf16_wire:
+        os.environ["CGAN_DDP_BF16_GRADS"] = "1"
+    if args.nccl_max_nchannels > 0:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_max_nchannels)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -974,6 +1038,8 @@ def main():
             res["config"]["rccl_ranks"] = rccl_ranks
             res["config"]["backend"] = dist.get_backend()
             res["config"]["grad_wire_dtype"] = str(T.g_reducer.grad_dtype).split(".")[1] if T.g_reducer is not None else None
+            res["config"]["grad_bucket_mb"] = float(os.environ.get("CGAN_DDP_BUCKET_MB", "25"))
+            res["config"]["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS", "default")
         ms, n = timer.total_ms(), len(timer.pairs)
         if n:
             achieved = timer.total_flops() / (ms * 1e-3) / 1e12
@@ -1054,10 +1120,11 @@ def main():
     if args.sub_steps > 0 and world == 1:
         blocks = (("painter_forward", lambda: painter_block(args.sub_steps, 5, rank, world, device, dtype, dist, barrier,
                                                            world == 1 and not args.no_cpu_baseline)),
-                  ("masker_train", lambda: masker_block(args.sub_steps, 3, rank, world, device, dtype, dist, barrier)),
-                  ("train_global_batch_1gpu", lambda: large_batch_block(max(3, args.sub_steps // 4), 2, rank, device, dtype,
-                                                                         barrier)),
-                  ("apply_events", lambda: infer_block(args.sub_steps, 2, rank, world, device, dist, barrier)))
+                  ("masker_train", lambda: masker_block(args.sub_steps, 3, rank, world, device, dtype, dist, barrier,
+                                                        args.conv_table + ".masker" if args.conv_table else "")),
+                  ("train_global_batch_1gpu", lambda: large_batch_block(args.sub_steps, 2, rank, device, dtype, barrier)),
+                  ("apply_events", lambda: infer_block(args.sub_steps, 2, rank, world, device, dist, barrier,
+                                                       args.conv_table + ".infer" if args.conv_table else "")))
         for name, fn in blocks:
             try:
                 sub[name] = fn()

@@ -263,6 +263,12 @@ def load_dev():
         ws = os.environ.get("CGAN_DEBUG_GEMM_WS")
         if ws:
             _dev.cgan_debug_set_gemm_ws(C.c_int(int(ws)))
+        cg = os.environ.get("CGAN_DEBUG_WGRAD_COOP_G")          # 2: never the 16-wave weight-gradient tile, 4: wherever it applies
+        if cg:
+            _dev.cgan_debug_set_wgrad_coop_g(C.c_int(int(cg)))
+        ck = os.environ.get("CGAN_DEBUG_CONV_KERNEL")            # cgan_debug_set_conv_kernel (4: without round 5's GEMM launches)
+        if ck:
+            _dev.cgan_debug_set_conv_kernel(C.c_int(int(ck)))
     _lib = _dev
     return _dev
 
