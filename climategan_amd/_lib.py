@@ -138,6 +138,8 @@ _SIGNATURES = {
     "cgan_instnorm_act_bwd": (C.c_int, [_P, _P, _P, _P, C.POINTER(NormStatsDesc), C.c_int32, C.c_float, _P, C.c_size_t,
                                         _P]),
     "cgan_spade_bwd_prepare": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(SpadeDesc), _P]),
+    "cgan_spade_hidden_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpadeDesc)]),
+    "cgan_spade_hidden_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, C.POINTER(SpadeDesc), _P]),
     "cgan_batchnorm_train_stats": (C.c_int, [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, C.POINTER(NormStatsDesc), _P,
                                              C.c_size_t, _P]),
     "cgan_batchnorm_train_stats_from_partials": (C.c_int, [_P, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P,

@@ -286,6 +286,9 @@ class InstNormActFn(torch.autograd.Function):
 _SPADE_REMAT_GAMMA = os.environ.get("CGAN_SPADE_REMAT_GAMMA") == "1"
 
 
+_SPADE_FUSED_BWD = os.environ.get("CGAN_SPADE_FUSED_BWD", "1") != "0"     # same-box A/B switch (0: the unfused backward)
+
+
 class SpadeFn(torch.autograd.Function):
     """y = act(param_free_norm(up?(x)) * (1 + gamma(cond)) + beta(cond)) (reference norms.py:174-186 + the block's
     LeakyReLU); the norm is an instance norm (Painter) or, with cfg["batch_stats"], a training-mode batch norm whose
@@ -325,7 +328,8 @@ class SpadeFn(torch.autograd.Function):
         h, w = y.h, y.w
         # re-materialise seg -> hidden -> gamma at full resolution
         seg = ops.resize_nearest(ops.NHWC(cond_t, cfg["cond_c"]), (h, w), cs_out=ops.cs8(cfg["cond_c"]))
-        actv = ops.conv2d(seg, ops.pack_conv_weight(w_sh, b_sh, dt), pad=1, act=ops.ACT_RELU)
+        pw_sh = ops.pack_conv_weight(w_sh, b_sh, dt)
+        actv = ops.conv2d(seg, pw_sh, pad=1, act=ops.ACT_RELU)
         gamma = ops.NHWC(gamma_t, c) if gamma_t is not None else ops.conv2d(actv, ops.pack_conv_weight(w_g, b_g, dt), pad=1)
         dgb, xhat, dxhat = ops.spade_bwd_prepare(dy, y, x, mean, rstd, gamma, act=cfg["act"], slope=cfg["slope"],
                                                  x_upsample=cfg["x_upsample"])
@@ -336,10 +340,19 @@ class SpadeFn(torch.autograd.Function):
         dw_gb = db_gb = dw_sh = db_sh = None
         if want_gb:
             dw_gb, db_gb = ops.conv2d_bwd_weight(actv, dgb, tuple(w_gb.shape), pad=1)
-        # (the ReLU derivative of mlp_shared rides in the data-gradient kernel's epilogue: no pass over the 128-channel map)
-        d_pre = ops.conv2d_bwd_data(dgb, w_gb, (actv.n, h, w), pad=1, relu_out=actv)
+        # Fused form (round 5, cgan_spade_hidden_bwd): for a <= 4-channel conditioning image that wants no gradient of its
+        # own (the Painter) on maps of 80 x 80 and up, mlp_shared's gradient comes out of ONE kernel that re-computes the hidden
+        # tile and keeps its gradient on the chip -- no 128-channel gradient map, no separate weight-gradient launch.
+        fused = (_SPADE_FUSED_BWD and want_sh and not ctx.needs_input_grad[1] and cfg["cond_c"] <= 4 and h * w >= 6400
+                 and w_sh.shape[0] == 128)
+        d_pre = None
+        if fused:
+            dw_sh, db_sh = ops.spade_hidden_bwd(dgb, w_gb, seg, pw_sh, c)
+        elif want_sh or ctx.needs_input_grad[1]:
+            # (the ReLU derivative of mlp_shared rides in the data-gradient kernel's epilogue: no pass over the 128-channel map)
+            d_pre = ops.conv2d_bwd_data(dgb, w_gb, (actv.n, h, w), pad=1, relu_out=actv)
         del dgb, actv
-        if want_sh:
+        if want_sh and not fused:
             dw_sh, db_sh = ops.conv2d_bwd_weight(seg, d_pre, tuple(w_sh.shape), pad=1)
         dcond_t = None
         if ctx.needs_input_grad[1]:

@@ -1305,6 +1305,33 @@ def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=A
     return NHWC(dgb, 2 * c), NHWC(xhat, c), NHWC(dxhat, c)
 
 
+def spade_hidden_bwd(dgb: NHWC, w_gb: torch.Tensor, seg: NHWC, pw_shared: PackedConv, c: int, want_bias=True):
+    """(dw_shared, db_shared) of SPADE's mlp_shared from the gamma||beta gradient map ``dgb`` (spade_bwd_prepare), in ONE
+    kernel (cgan_spade_hidden_bwd): the hidden map is re-computed per tile from ``seg`` (the conditioning image at the map's
+    extent, <= 4 channels) and its gradient never leaves the chip.  ``w_gb`` = cat[w_gamma, w_beta] fp32 OIHW."""
+    _need_cuda(dgb.t, w_gb, seg.t)
+    n, h, w = dgb.n, dgb.h, dgb.w
+    hidden = w_gb.shape[1]
+    if seg.c > 4 or hidden != 128 or (seg.n, seg.h, seg.w) != (n, h, w) or dgb.c != 2 * c or w_gb.shape[0] != 2 * c:
+        raise RuntimeError("spade_hidden_bwd: needs a <= 4-channel conditioning image at the map's extent and hidden width 128")
+    lib = _lib.load()
+    w_gb = w_gb.detach().contiguous().float()
+    dconv = _conv_desc(dgb.dtype_id, n, h, w, hidden, 2 * c, 3, 3, 1, 1, 1, PAD_ZERO, has_bias=False)
+    nbytes = lib.cgan_conv2d_dgrad_packed_weight_bytes(C.byref(dconv))
+    if nbytes == 0:
+        _lib.check(-1, "cgan_conv2d_dgrad_packed_weight_bytes")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w_gb.device)
+    _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w_gb), _ptr(None), _ptr(packed), C.byref(dconv), _stream()),
+               "cgan_conv2d_pack_weight_dgrad")
+    d = _spade_desc(dgb.dtype_id, n, h, w, c, False, h, w, seg.c, ACT_NONE)
+    ws = torch.empty(lib.cgan_spade_hidden_bwd_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dgb.t.device)
+    dw = zeros_f32(hidden * seg.c * 9, dgb.t.device).view(hidden, seg.c, 3, 3)
+    db = zeros_f32(hidden, dgb.t.device) if want_bias else None
+    _lib.check(lib.cgan_spade_hidden_bwd(_ptr(dgb.t), _ptr(packed), _ptr(seg.t), _ptr(pw_shared.w), _ptr(pw_shared.bias), _ptr(dw),
+                                         _ptr(db), _ptr(ws), ws.numel(), C.byref(d), _stream()), "cgan_spade_hidden_bwd")
+    return dw, db
+
+
 @_batch_chunked("fake", "x", "m")
 def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype, want_d=True, want_vgg=False):
     """(d_in, vgg_in) of the pasted image p = x (1 - m) + fake m (or p = x when ``fake`` is None): the discriminator

@@ -336,6 +336,20 @@ int cgan_instnorm_act_bwd(const void* out, const void* dy, const float* rstd, vo
  * xhat / dxhat) are separate calls. */
 int cgan_spade_bwd_prepare(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
                            const void* gamma, void* dgb, void* xhat, void* dxhat, const CganSpadeDesc* d, void* stream);
+/* Fused backward of SPADE's hidden map (round 5; autograd of climategan/norms.py:163-172,181-183 below gamma / beta): from
+ * dgb (cgan_spade_bwd_prepare) the gradient of mlp_shared's weight [hidden][cond_c][3][3] and bias [hidden], ADDED to
+ * dw_shared / db_shared (db_shared may be NULL), in one kernel per layer: the data gradient of the gamma||beta convolution
+ * (packed_dgrad_gb = cgan_conv2d_pack_weight_dgrad of cat[w_gamma, w_beta] with the forward descriptor hidden -> 2c, 3x3,
+ * pad 1), the ReLU mask from a hidden tile RE-COMPUTED from the conditioning image (packed_w_shared / bias_shared_padded =
+ * cgan_conv2d_pack_weight of mlp_shared), and the contraction with the conditioning image's 3x3 neighbourhood -- neither the
+ * hidden map nor its gradient touches HBM.  cond_hw: the conditioning image at the map's (h, w) (cond_h = h, cond_w = w),
+ * NHWC with cgan_cs(cond_c) storage channels; cond_c <= 4 (the Painter's x (1 - m)); hidden = 128.  The conditioning image
+ * receives no gradient here (callers that need one keep cgan_conv2d_nhwc_bwd_data_relu + the separate weight gradient).
+ * workspace: cgan_spade_hidden_bwd_workspace_bytes(d) (per-workgroup partial blocks, summed in workgroup order). */
+size_t cgan_spade_hidden_bwd_workspace_bytes(const CganSpadeDesc* d);
+int cgan_spade_hidden_bwd(const void* dgb, const void* packed_dgrad_gb, const void* cond_hw, const void* packed_w_shared,
+                          const float* bias_shared_padded, float* dw_shared, float* db_shared, void* workspace,
+                          size_t workspace_bytes, const CganSpadeDesc* d, void* stream);
 /* Training-mode nn.BatchNorm2d (+ ReLU / LeakyReLU) (ResNet-101, ASPP, depth decoder: climategan/deeplab/
  * resnet101_v3.py:30-50, deeplab_v3.py:54-57, depth.py:56-114).  Batch statistics = cgan_instnorm_stats on the tensor
  * viewed as one image of n*h*w pixels; then

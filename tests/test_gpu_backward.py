@@ -233,7 +233,9 @@ def test_conv_fn_upsample_residual_autograd(dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C,H,W,ups,act", [(20, 12, 16, False, "lrelu"), (40, 8, 12, True, "none"), (16, 10, 10, True, "lrelu"),
-                                           (10, 8, 8, False, "lrelu"), (12, 8, 12, False, "none")])   # pad channels past 2C; a straddling group
+                                           (10, 8, 8, False, "lrelu"), (12, 8, 12, False, "none"),   # pad channels past 2C; a straddling group
+                                           # maps of 80 x 80 and up: the fused hidden-map backward (cgan_spade_hidden_bwd)
+                                           (20, 80, 96, False, "lrelu"), (12, 88, 84, True, "none")])
 def test_spade_fn_backward(dt, C, H, W, ups, act):
     """autograd.SpadeFn (fused forward, re-materialising backward) against torch autograd of the reference expression
     (norms.py:174-186): gradients of x and of the six mlp parameters."""
@@ -273,10 +275,56 @@ def test_spade_fn_backward(dt, C, H, W, ups, act):
     out.backward(to_nhwc(dy, dt).t)
     # 16-bit re-materialised hidden map / gamma / gradients: a few 16-bit roundings deep
     # (bf16: the instance-norm backward subtracts two means from 8-bit-mantissa values: up to 7 % on the 5x5 case)
-    assert rel_err(back(ops.NHWC(xt.grad, C)), x.grad) <= (4e-3 if dt == torch.float16 else 1e-1)
+    # (on the 80 x 80-and-up cases the fp16 bound is the instance-norm backward's, fused or not: CGAN_SPADE_FUSED_BWD=0 gives
+    # the same 2.9e-2 -- dx does not depend on the hidden map's gradient path)
+    if H * W < 6400:
+        assert rel_err(back(ops.NHWC(xt.grad, C)), x.grad) <= (4e-3 if dt == torch.float16 else 1e-1)
+    else:
+        # 3e5 elements: a handful sit within one 16-bit rounding step of the LeakyReLU kink, where the 16-bit y has the other
+        # sign than the fp32 one and the slope flips 1 <-> 0.2 (up to 0.6 of the largest gradient on ONE element, fused or not):
+        # bound the 99.9th percentile instead of the maximum
+        err = (back(ops.NHWC(xt.grad, C)) - x.grad).abs().flatten()
+        assert torch.quantile(err, 0.999).item() <= (4e-2 if dt == torch.float16 else 1e-1) * x.grad.abs().max().item()
     for k in names:
         e = rel_err(ps[k].grad.cpu(), sd[k].grad)
         assert e <= (5e-3 if dt == torch.float16 else 8e-2), "%s: rel err %.3g" % (k, e)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,H,W,B", [(20, 96, 80, 2), (40, 83, 101, 1), (160, 80, 80, 1), (5, 112, 96, 3)])
+def test_spade_hidden_backward_fused_equals_the_unfused_kernels(dt, C, H, W, B):
+    """cgan_spade_hidden_bwd (round 5: data gradient of the gamma||beta conv + ReLU mask from a re-computed hidden tile +
+    mlp_shared's weight / bias gradient in one kernel, reference norms.py:163-172 under autograd) against the three kernels it
+    replaces on the same operands -- hidden map re-materialised, masked data gradient written as a 16-bit map, weight
+    gradient over it: the same 16-bit roundings in the same places, so only the fp32 summation order differs -- and against
+    torch's fp32 autograd of the same expression.  Ragged extents (tiles past the image), 1 .. 10 channel chunks."""
+    from climategan_amd import ops
+    dgb_f = q(fill.uniform((B, 2 * C, H, W), 7100 + C, -1, 1), dt)
+    seg_f = q(fill.uniform((B, 3, H, W), 7101 + H), dt)
+    w_sh = q(fill.uniform((128, 3, 3, 3), 7102, -0.4, 0.4), dt).requires_grad_(True)
+    b_sh = torch.from_numpy(fill.uniform((128,), 7103, -0.2, 0.2)).requires_grad_(True)
+    w_gb = q(fill.uniform((2 * C, 128, 3, 3), 7104 + C, -0.05, 0.05), dt)
+    actv = F.relu(F.conv2d(seg_f, w_sh, b_sh, padding=1))
+    gb = F.conv2d(actv, w_gb, None, padding=1)
+    gb.backward(dgb_f)
+    dgb = to_nhwc(dgb_f, dt)
+    seg = to_nhwc(seg_f, dt)
+    pw_sh = ops.pack_conv_weight(w_sh.detach().cuda(), b_sh.detach().cuda(), dt)
+    dw, db = ops.spade_hidden_bwd(dgb, w_gb.cuda(), seg, pw_sh, C)
+    a = ops.conv2d(seg, pw_sh, pad=1, act=ops.ACT_RELU)
+    d_pre = ops.conv2d_bwd_data(dgb, w_gb.cuda(), (B, H, W), pad=1, relu_out=a)
+    dw_u, db_u = ops.conv2d_bwd_weight(seg, d_pre, (128, 3, 3, 3), pad=1)
+    errs = dict(fused_vs_unfused=(rel_err(dw.cpu(), dw_u.cpu()), rel_err(db.cpu(), db_u.cpu())),
+                fused_vs_torch=(rel_err(dw.cpu(), w_sh.grad), rel_err(db.cpu(), b_sh.grad)),
+                unfused_vs_torch=(rel_err(dw_u.cpu(), w_sh.grad), rel_err(db_u.cpu(), b_sh.grad)))
+    print("spade_hidden_bwd %s C=%d %dx%d: %s" % (dt, C, H, W, errs))
+    tol = 5e-3 if dt == torch.float16 else 4e-2
+    assert max(errs["fused_vs_torch"]) <= tol, errs
+    # same products, same 16-bit roundings, the same mask bit for bit (h is rounded to the 16-bit type before the sign test, as
+    # the stored map would hold it): only the fp32 summation order differs
+    assert max(errs["fused_vs_unfused"]) <= 2e-4, errs
+    dw2, db2 = ops.spade_hidden_bwd(dgb, w_gb.cuda(), seg, pw_sh, C)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "deterministic"
 
 
 @pytest.mark.parametrize("dt", DTYPES)
