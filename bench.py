@@ -355,7 +355,7 @@ def install_all_mfma_timer(timer):
     lib = _lib.load()
     names = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add", "cgan_conv2d_nhwc_fwd_stats",
              "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd", "cgan_spade_fused_fwd_train",
-             "cgan_conv2d_nhwc_bwd_data_relu")
+             "cgan_conv2d_nhwc_bwd_data_relu", "cgan_spade_hidden_bwd")
     orig = {n: getattr(lib, n) for n in names}
     kind = lib.cgan_conv2d_kernel_kind
     KIND = {0: "general", 1: "lds3x3", 2: "gemm"}
@@ -421,7 +421,17 @@ def install_all_mfma_timer(timer):
         return timer.bracket(lambda: orig[names[7]](dy, w, relu_out, dx, dref, stream), conv_flops(d),
                              conv_bytes(d, 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1)], "bwd_data*"))
 
-    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train, bwd_relu)):
+    def spade_hid_bwd(dgb, wdg, cond, wsh, bsh, dw, db, ws, ws_bytes, dref, stream):
+        # fused hidden-map backward: the data gradient of the gamma||beta conv (2c -> hidden, 3x3) + the hidden tile's
+        # re-computation and mlp_shared's weight gradient (cond_c x 9 x hidden, twice); reads dgb and the conditioning image
+        d = dref._obj
+        npix = d.n * d.h * d.w
+        fl = npix * 2.0 * (2 * d.c * 9 * d.hidden + 2 * d.cond_c * 9 * d.hidden)
+        nb = npix * 2 * (cs8(2 * d.c) + cs8(d.cond_c))
+        return timer.bracket(lambda: orig[names[8]](dgb, wdg, cond, wsh, bsh, dw, db, ws, ws_bytes, dref, stream), fl, int(nb),
+                             "%-7s %-9s n%d %dx%d c%d" % ("spadebw", "hidden", d.n, d.h, d.w, d.c))
+
+    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train, bwd_relu, spade_hid_bwd)):
         setattr(lib, n, f)
 
     def uninstall():
