@@ -283,29 +283,34 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
   }
 }
 
-// dW[hidden][c][ky][kx] += sum over workgroups of part[wg][half][hidden % 64][tap * 4 + c]; db[hidden] += ... [48]
+// dW[hidden][c][ky][kx] += sum over workgroups of part[wg][half][hidden % 64][tap * 4 + c]; db[hidden] += ... [48].
+// One block per hidden row: thread (column = t & 63, lane = t >> 6) adds the workgroups lane, lane + 4, ... (in that order), the
+// four lanes meet in LDS and are added in lane order: a fixed order whatever the launch looks like.  (The first version walked
+// all workgroups from one thread per element: 66 us of dependent strided loads per layer.)
 __global__ __launch_bounds__(256) void spade_hidden_bwd_reduce_kernel(const float* __restrict__ part, int wgs, int halves,
                                                                       float* __restrict__ dw, float* __restrict__ db, int hidden,
                                                                       int cond_c) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int cols = 9 * cond_c + 1;
-  if (idx >= hidden * cols) return;
-  const int hid = idx / cols, k = idx - hid * cols;
-  int col;
-  float* dst;
-  if (k == 9 * cond_c) {
-    col = 48;
-    dst = db ? db + hid : nullptr;
-  } else {
-    const int c = k / 9, tap = k - c * 9;
-    col = tap * 4 + c;
-    dst = dw + ((size_t)hid * cond_c + c) * 9 + tap;
-  }
-  if (!dst) return;
+  __shared__ float red[4][PART_COLS];
+  const int hid = blockIdx.x;
+  const int col = threadIdx.x & 63, ln = threadIdx.x >> 6;
   const int half = hid >> 6, row = hid & 63;
-  float s = 0.f;
-  for (int wgi = 0; wgi < wgs; ++wgi) s += part[(((size_t)wgi * halves + half) * 64 + row) * PART_COLS + col];
-  *dst += s;
+  float s0 = 0.f, s1 = 0.f;
+  int wgi = ln;
+  for (; wgi + 4 < wgs; wgi += 8) {        // two loads in flight, summed in workgroup order
+    s0 += part[(((size_t)wgi * halves + half) * 64 + row) * PART_COLS + col];
+    s1 += part[(((size_t)(wgi + 4) * halves + half) * 64 + row) * PART_COLS + col];
+  }
+  if (wgi < wgs) s0 += part[(((size_t)wgi * halves + half) * 64 + row) * PART_COLS + col];
+  red[ln][col] = s0 + s1;
+  __syncthreads();
+  if (ln != 0) return;
+  const float s = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+  if (col == 48) {
+    if (db) db[hid] += s;
+    return;
+  }
+  const int tap = col >> 2, c = col & 3;
+  if (tap < 9 && c < cond_c) dw[((size_t)hid * cond_c + c) * 9 + tap] += s;
 }
 
 int hid_bwd_workgroups(const CganSpadeDesc* d) {
@@ -365,8 +370,7 @@ extern "C" int cgan_spade_hidden_bwd(const void* dgb, const void* packed_dgrad_g
   else
     hipLaunchKernelGGL(spade_hidden_bwd_kernel<BF16>, dim3(wgs, 2), dim3(WAVES * 64), SMEM_BYTES, s, a);
   CGAN_CHECK_LAUNCH("spade_hidden_bwd");
-  const int total = d->hidden * (9 * d->cond_c + 1);
-  hipLaunchKernelGGL(spade_hidden_bwd_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)workspace, wgs, 2,
+  hipLaunchKernelGGL(spade_hidden_bwd_reduce_kernel, dim3(d->hidden), dim3(256), 0, s, (const float*)workspace, wgs, 2,
                      dw_shared, db_shared, d->hidden, d->cond_c);
   CGAN_CHECK_LAUNCH("spade_hidden_bwd(reduce)");
   return CGAN_OK;
