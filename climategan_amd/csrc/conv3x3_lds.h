@@ -16,6 +16,10 @@ struct Conv3x3LdsArgs {
   int cin_s, cin_p, cout, cout_s, ctiles, ksteps;
   int in_ups, act, has_res, res_ups;
   float slope;
+  int shuffle;          // > 0: depth-to-space epilogue of the sub-pixel data gradient (conv_mfma.hip): the 16 output "channels"
+                        // are (class a, class b, 4 channels); lane group g = 2 a + b stores its four values (+ four zero pad
+                        // channels) to pixel (2 y + a, 2 x + b) of an [n][shuffle_h][shuffle_w][8] map; = shuffle_h
+  int shuffle_w;
 };
 
 // true if this conv is a 3x3 / stride 1 / dilation 1 conv (zero pad 0..2, or reflect pad 1) large enough for the tiled kernel

@@ -57,6 +57,24 @@ template <typename T, int NCT>
 __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 (&acc)[NCT][PT], unsigned char* smem,
                                                  int n, int ty0, int tx0, int ct0, int wave, int j, int g) {
   // ---------------- epilogue: lane holds channels (ct0+c)*16 + 4g + {0..3} of pixel (row wave*PT+t, column j)
+  if (p.shuffle) {
+    // sub-pixel data gradient of a 4x4 / stride-2 / pad-1 convolution with <= 4 input channels (the discriminators' first
+    // layer): channel 4 g + r of this 3x3 convolution over dy = gradient channel r of pixel (2 y + (g >> 1), 2 x + (g & 1));
+    // one 16-byte store per lane (4 values + the 4 zero pad channels of the 8-channel storage), the lanes of g and g ^ 1
+    // fill 32 contiguous bytes, a 16-lane row 512
+    const int a = g >> 1, b = g & 1;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int yy = ty0 + wave * PT + t, xx = tx0 + j;
+      const int oy = 2 * yy + a, ox = 2 * xx + b;
+      if (yy < p.h && xx < p.w_ && oy < p.shuffle && ox < p.shuffle_w && ct0 == 0) {
+        const f32x4 v = acc[0][t];
+        const u32x4 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), 0u, 0u};
+        *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.shuffle + oy) * p.shuffle_w + ox) * 8) = o;
+      }
+    }
+    return;
+  }
   __syncthreads();                                   // everyone is done with xbuf / wbuf
   unsigned char* yt = smem;                          // [256 px][NCT * 32 B]
   // the bias quad of a cout tile is loaded once (not per pixel row); the pad-channel test only runs when there are any

@@ -827,6 +827,7 @@ static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, co
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
     a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hi = p.h_in; a.wi = p.w_in; a.pad = p.pad;
     a.reflect = p.pad_mode == CGAN_PAD_REFLECT;
+    a.shuffle = 0; a.shuffle_w = 0;
     a.hx = p.hx; a.wx = p.wx; a.cin = d->c_in; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
     a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
     a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
@@ -965,6 +966,53 @@ static int dgrad_params(ConvParams& p, const CganConvDesc* f, CganConvDesc* t) {
   return CGAN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sub-pixel form of the data gradient of a 4x4 / stride-2 / pad-1 convolution with <= 4 input channels (the first layer of
+// the PatchGAN / ADVENT discriminators, reference discriminator.py:100-120, whose input gradient the Painter's GAN and
+// feature-matching terms need; round 5).  dx[2i + a][2j + b][c] = sum over the 3x3 neighbourhood (ty, tx) of dy[i + ty - 1]
+// [j + tx - 1][co] * w[co][c][a + 3 - 2 ty][b + 3 - 2 tx] (taps outside 0..3 do not exist): ONE 3x3 / stride-1 / pad-1
+// convolution of dy with 16 output channels (a, b, c) -- a full MFMA row tile instead of the parity classes' 4 live rows of
+// 16 -- on the spatially tiled 3x3 kernel, whose epilogue scatters the channels back to pixels (depth to space).  The
+// general kernel took 259 us for the 8 x 640 x 640 gradient (HBM time of its 157 MB: ~35 us).
+// ------------------------------------------------------------------------------------------------
+static bool dgrad_subpixel(const CganConvDesc* f) {
+  return g_conv_force == 0 && f->kh == 4 && f->kw == 4 && f->stride == 2 && f->pad == 1 && f->dilation == 1 &&
+         f->pad_mode == CGAN_PAD_ZERO && f->c_in <= 4 && !f->in_upsample && (cgan_cs(f->c_out) % 32) == 0 &&
+         (f->h_in % 2) == 0 && (f->w_in % 2) == 0 && (long)f->h_out * f->w_out >= 1024;
+}
+
+// packed operator of that 3x3 convolution in the tiled kernel's layout [ctile 0][ks = tap * nq + q][lane][8]: row (a, b, c),
+// K = the forward conv's output channels; w = the forward OIHW weight [c_out][c_in][4][4] (/ sigma)
+template <typename T>
+__global__ void pack_dgrad_subpixel_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                           uint16_t* __restrict__ packed, int c_out, int c_in, int cin_p) {
+  const int nq = cin_p / 32, total = 9 * nq * 64;
+  const float sig = sigma ? sigma[0] : 1.f;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, ks = idx >> 6;
+    const int tap = ks / nq, q = ks - tap * nq;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    const int row = lane & 15, a = row >> 3, b = (row >> 2) & 1, c = row & 3;
+    const int ky = a + 3 - 2 * ty, kx = b + 3 - 2 * tx;
+    const int k0 = q * 32 + (lane >> 4) * 8;
+    uint16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int co = k0 + e;
+      float v = 0.f;
+      if (co < c_out && c < c_in && ky >= 0 && ky < 4 && kx >= 0 && kx < 4)
+        v = __fdiv_rn(w[(((size_t)co * c_in + c) * 4 + ky) * 4 + kx], sig);
+      o[e] = bits_of<T>(v);
+    }
+    u32x4 pk;
+    pk[0] = o[0] | ((uint32_t)o[1] << 16);
+    pk[1] = o[2] | ((uint32_t)o[3] << 16);
+    pk[2] = o[4] | ((uint32_t)o[5] << 16);
+    pk[3] = o[6] | ((uint32_t)o[7] << 16);
+    reinterpret_cast<u32x4*>(packed)[idx] = pk;
+  }
+}
+
 static size_t dgrad_packed_fragments(const ConvParams& p) {
   if (!p.cls_s) return (size_t)p.ctiles * p.ksteps * 64;
   size_t ks = 0;
@@ -976,6 +1024,7 @@ extern "C" size_t cgan_conv2d_dgrad_packed_weight_bytes(const CganConvDesc* fwd)
   ConvParams p;
   CganConvDesc t;
   if (dgrad_params(p, fwd, &t) != CGAN_OK) return 0;
+  if (dgrad_subpixel(fwd)) return (size_t)9 * (((cgan_cs(fwd->c_out) + 31) & ~31) / 32) * 64 * 16;
   const size_t fr = dgrad_packed_fragments(p);
   return (fr ? fr : 64) * 16;
 }
@@ -987,6 +1036,19 @@ extern "C" int cgan_conv2d_pack_weight_dgrad(const float* w_oihw, const float* s
   int rc = dgrad_params(p, fwd, &t);
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(w_oihw && packed, "conv2d_pack_weight_dgrad: null pointer");
+  if (dgrad_subpixel(fwd)) {
+    const int cin_p = (cgan_cs(fwd->c_out) + 31) & ~31;
+    const int tot = 9 * (cin_p / 32) * 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd->dtype == CGAN_F16)
+      hipLaunchKernelGGL(pack_dgrad_subpixel_kernel<F16>, dim3(ceil_div(tot, 256)), dim3(256), 0, st, w_oihw, sigma,
+                         (uint16_t*)packed, fwd->c_out, fwd->c_in, cin_p);
+    else
+      hipLaunchKernelGGL(pack_dgrad_subpixel_kernel<BF16>, dim3(ceil_div(tot, 256)), dim3(256), 0, st, w_oihw, sigma,
+                         (uint16_t*)packed, fwd->c_out, fwd->c_in, cin_p);
+    CGAN_CHECK_LAUNCH("conv2d_pack_weight_dgrad(sub-pixel)");
+    return CGAN_OK;
+  }
   if (p.cls_s) {
     int max_ks = 1;
     for (int c = 0; c < p.cls_s * p.cls_s; ++c) {
@@ -1052,6 +1114,7 @@ extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) 
   const bool plain = d->stride == 1 && p.pad >= 0 && t.h_in + 2 * p.pad - t.dilation * (t.kh - 1) == t.h_out &&
                      t.w_in + 2 * p.pad - t.dilation * (t.kw - 1) == t.w_out;
   if (!plain) {
+    if (dgrad_subpixel(d)) return CGAN_CONV_KERNEL_LDS3X3;
     ConvGemmCls cls[4];
     return cls_on_gemm(p, cls) ? CGAN_CONV_KERNEL_GEMM : CGAN_CONV_KERNEL_GENERAL;
   }
@@ -1081,6 +1144,20 @@ static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void*
   if (plain) {
     t.pad = p.pad;
     return dispatch_conv(p, &t, s, "conv2d_nhwc_bwd_data");
+  }
+  if (dgrad_subpixel(fwd)) {
+    Conv3x3LdsArgs a;
+    a.x = p.x; a.w = p.w; a.bias = nullptr; a.res = nullptr; a.y = p.y;
+    a.n = fwd->n; a.h = fwd->h_out; a.w_ = fwd->w_out; a.hi = fwd->h_out; a.wi = fwd->w_out; a.pad = 1; a.reflect = 0;
+    a.hx = fwd->h_out; a.wx = fwd->w_out;
+    a.cin = fwd->c_out; a.cin_s = cgan_cs(fwd->c_out); a.cin_p = (a.cin_s + 31) & ~31;
+    a.cout = 16; a.cout_s = 16; a.ctiles = 1; a.ksteps = 9 * (a.cin_p / 32);
+    a.in_ups = 0; a.act = CGAN_ACT_NONE; a.has_res = 0; a.res_ups = 0; a.slope = 0.f;
+    a.shuffle = fwd->h_in; a.shuffle_w = fwd->w_in;
+    int rc2 = conv3x3_lds_launch(a, fwd->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_data(sub-pixel)");
+    return CGAN_OK;
   }
   ConvGemmCls cls[4];
   if (cls_on_gemm(p, cls)) {

@@ -482,3 +482,33 @@ def test_weight_gradient_on_the_16_wave_tile(dt, case):
         lib.cgan_debug_set_wgrad_coop_g(ctypes.c_int(0))
         lib.cgan_debug_set_wgrad(ctypes.c_int(0), ctypes.c_int(0))
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(32768))
+
+
+@pytest.mark.usefixtures("dev_lib")
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(4, 64, 2, 64, 64), (3, 64, 1, 96, 80), (1, 32, 2, 64, 96), (4, 128, 1, 66, 70)])
+def test_first_layer_dgrad_as_a_subpixel_3x3_conv(dt, case):
+    """Round 5: the data gradient of a 4x4 / stride-2 / pad-1 convolution with <= 4 input channels (the discriminators' first
+    layer, reference discriminator.py:100-120) as ONE 3x3 convolution of dy with 16 (class, channel) outputs on the tiled 3x3
+    kernel + a depth-to-space epilogue: against torch and against the parity-class form on the general kernel."""
+    from climategan_amd import _lib, ops
+    cin, cout, B, H, W = case
+    lib = _lib.load()
+    x = q(fill.uniform((B, cin, H, W), 6100 + cin + H), dt).requires_grad_(True)
+    bound = 1.0 / np.sqrt(cin * 16)
+    w = q(fill.uniform((cout, cin, 4, 4), 6200 + cout, -bound, bound), dt)
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = q(fill.uniform(tuple(y.shape), 6300 + cout + W), dt)
+    y.backward(dy)
+    dyg = ops.nchw_to_nhwc(dy.cuda(), dt)
+    assert _kind(lib, dt, (cin, cout, 4, 2, 1, B, H, W), True) == 1, "this case must run on the tiled 3x3 kernel"
+    dx = ops.conv2d_bwd_data(dyg, w.cuda(), (B, H, W), stride=2, pad=1)
+    assert rel_err(ops.nhwc_to_nchw(dx).cpu(), x.grad) <= (1e-3 if dt == torch.float16 else 8e-3)
+    assert dx.t[..., cin:].abs().max().item() == 0
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(4))
+    try:
+        assert _kind(lib, dt, (cin, cout, 4, 2, 1, B, H, W), True) == 0
+        dx2 = ops.conv2d_bwd_data(dyg, w.cuda(), (B, H, W), stride=2, pad=1)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    assert rel_err(dx.t.float(), dx2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)
