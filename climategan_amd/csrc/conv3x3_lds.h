@@ -20,8 +20,13 @@ struct Conv3x3LdsArgs {
                         // are (class a, class b, 4 channels); lane group g = 2 a + b stores its four values (+ four zero pad
                         // channels) to pixel (2 y + a, 2 x + b) of an [n][shuffle_h][shuffle_w][8] map; = shuffle_h
   int shuffle_w;
+  int k, stride;        // conv_smallcin_kernel only: square kernel size (<= 7) and stride (1 / 2); 0 elsewhere
 };
 
 // true if this conv is a 3x3 / stride 1 / dilation 1 conv (zero pad 0..2, or reflect pad 1) large enough for the tiled kernel
 bool conv3x3_lds_applicable(const CganConvDesc* d);
 int conv3x3_lds_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s);
+// first-layer convolutions: 8 storage channels in, <= 64 out, k x k (k != 3) with stride 1 / 2, zero padding: input halo tile in
+// LDS, all output channels per workgroup (the PatchGAN 4x4 s2 input conv, the ResNet 7x7 s2 stem)
+bool conv_smallcin_applicable(const CganConvDesc* d);
+int conv_smallcin_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s);

@@ -399,6 +399,100 @@ __global__ __launch_bounds__(WAVES * 64, NCT <= 2 ? 8 : (NCT <= 4 ? 4 : 2)) void
   conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);
 }
 
+// First-layer convolutions (round 5): 8 storage channels per input pixel (<= 8 real: the image, the mask || image pair of the
+// PatchGAN), k x k taps with stride 1 / 2, <= 64 output channels -- discriminator.py:100-120 (4x4 s2), resnet101_v3.py:176
+// (7x7 s2 stem).  The general gather kernel read every tap of every pixel as its own 16-byte global load and stored 8 bytes per
+// lane: 95 / 142 us at 8 x 640 x 640 for the 20 us their 105 MB of output take.  Here the input halo of a 16 x 16 output tile
+// ((15 s + k)^2 pixels x 16 B <= 22 KiB) is staged once in LDS; a k-step = four taps (the standard dense pack: k = tap * 8 + c),
+// lane (j, g) reads tap 4 ks + g of its pixel as ONE ds_read_b128; A fragments straight from L2 (16 B per lane, prefetched
+// one k-step ahead); all output channels in one workgroup; epilogue shared with the 3x3 kernels (whole 16-byte chunks).
+template <typename T, int NCT>
+__global__ __launch_bounds__(WAVES * 64, 4) void conv_smallcin_kernel(Conv3x3LdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int g = lane >> 4;
+  const int tiles_x = (p.w_ + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
+  int tile = blockIdx.x;
+  const int txi = tile % tiles_x;
+  tile /= tiles_x;
+  const int tyi = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int hp = (TW - 1) * p.stride + p.k;          // halo extent (pixels) per axis
+  const int taps = p.k * p.k;
+
+  // ---- input halo -> LDS, 16 bytes (8 storage channels) per pixel, zeros outside the image
+  u32x4* xh = reinterpret_cast<u32x4*>(smem);
+  const int iy0 = ty0 * p.stride - p.pad, ix0 = tx0 * p.stride - p.pad;
+  for (int pix = threadIdx.x; pix < hp * hp; pix += WAVES * 64) {
+    const int py = pix / hp, px = pix - py * hp;
+    const int yy = iy0 + py, xx = ix0 + px;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (yy >= 0 && yy < p.hi && xx >= 0 && xx < p.wi)
+      v = *reinterpret_cast<const u32x4*>(p.x + (((size_t)n * p.hi + yy) * p.wi + xx) * 8);
+    xh[pix] = v;
+  }
+  f32x4 acc[NCT][PT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto load_a = [&](int ks, u32x4 (&a)[NCT]) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int ct = min(c, p.ctiles - 1);
+      a[c] = p.w[((size_t)ct * p.ksteps + ks) * 64 + lane];
+    }
+  };
+  u32x4 a_cur[NCT], a_nxt[NCT];
+  load_a(0, a_cur);
+  __syncthreads();
+  for (int ks = 0; ks < p.ksteps; ++ks) {
+    if (ks + 1 < p.ksteps) load_a(ks + 1, a_nxt);
+    const int tap = ks * 4 + g;
+    const bool tv = tap < taps;
+    const int tc = tv ? tap : 0;
+    const int ky = tc / p.k, kx = tc - ky * p.k;
+    u32x4 b[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int row = wave * PT + t;
+      b[t] = xh[(row * p.stride + ky) * hp + j * p.stride + kx];
+      if (!tv) b[t] = (u32x4){0u, 0u, 0u, 0u};     // a lane without a tap multiplies zeros (its packed weights are zero too)
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int t = 0; t < PT; ++t) acc[c][t] = mfma16(as_vec8<T>(a_cur[c]), as_vec8<T>(b[t]), acc[c][t]);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) a_cur[c] = a_nxt[c];
+  }
+  conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, 0, wave, j, g);
+}
+
+template <typename T, int NCT>
+int launch_smallcin(const Conv3x3LdsArgs& a, hipStream_t s) {
+  const int tiles = a.n * ((a.h + TH - 1) / TH) * ((a.w_ + TW - 1) / TW);
+  const int hp = (TW - 1) * a.stride + a.k;
+  size_t smem = (size_t)hp * hp * 16;
+  const size_t epi = (size_t)256 * NCT * 32;
+  if (epi > smem) smem = epi;
+  hipLaunchKernelGGL((conv_smallcin_kernel<T, NCT>), dim3(tiles), dim3(WAVES * 64), smem, s, a);
+  return CGAN_OK;
+}
+
+template <typename T>
+int launch_smallcin_any(const Conv3x3LdsArgs& a, hipStream_t s) {
+  switch (a.ctiles) {
+    case 1: return launch_smallcin<T, 1>(a, s);
+    case 2: return launch_smallcin<T, 2>(a, s);
+    case 3: return launch_smallcin<T, 3>(a, s);
+    default: return launch_smallcin<T, 4>(a, s);
+  }
+}
+
 template <typename T, int NCT>
 int launch_c4(const Conv3x3LdsArgs& a, hipStream_t s) {
   const int tiles = a.n * ((a.h + TH - 1) / TH) * ((a.w_ + TW - 1) / TW);
@@ -506,6 +600,18 @@ bool conv3x3_lds_applicable(const CganConvDesc* d) {
   const bool pad_ok = d->pad_mode == CGAN_PAD_ZERO ? (d->pad >= 0 && d->pad <= 2)
                                                    : (d->pad == 1 && d->h_in >= 2 && d->w_in >= 2 && !d->in_upsample);
   return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1 && pad_ok && (long)d->h_out * d->w_out >= 1024;
+}
+
+bool conv_smallcin_applicable(const CganConvDesc* d) {
+  const int cs = cgan_cs(d->c_in);
+  return cs == 8 && d->kh == d->kw && d->kh != 3 && d->kh >= 2 && d->kh <= 7 && (d->stride == 1 || d->stride == 2) &&
+         d->dilation == 1 && d->pad_mode == CGAN_PAD_ZERO && d->pad >= 0 && d->pad <= d->kh && !d->in_upsample &&
+         cgan_cs(d->c_out) <= 64 && !d->has_residual && (long)d->h_out * d->w_out >= 1024 &&
+         (double)d->n * d->h_in * d->w_in * 16.0 < 4294967295.0;
+}
+
+int conv_smallcin_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s) {
+  return dtype == CGAN_F16 ? launch_smallcin_any<F16>(a, s) : launch_smallcin_any<BF16>(a, s);
 }
 
 int conv3x3_lds_launch(const Conv3x3LdsArgs& a, int dtype, hipStream_t s) {

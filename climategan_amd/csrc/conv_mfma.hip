@@ -799,6 +799,8 @@ static int select_conv_kernel(const ConvParams& p, const CganConvDesc* d) {
   const bool prefer_3x3 = conv3x3_lds_applicable(d) && p.cin_s < 256 && g_conv_force != 3;
   if ((g_conv_force == 0 || g_conv_force == 3) && p.in_zs == 1 && !prefer_3x3 && conv_gemm_applicable(d)) return CGAN_CONV_KERNEL_GEMM;
   if (g_conv_force != 1 && p.in_zs == 1 && conv3x3_lds_applicable(d)) return CGAN_CONV_KERNEL_LDS3X3;
+  // first-layer convs (8 storage channels in, k != 3): the halo-tiled kernel of the same family (conv_smallcin_kernel)
+  if (g_conv_force == 0 && p.in_zs == 1 && !p.pair && conv_smallcin_applicable(d)) return CGAN_CONV_KERNEL_LDS3X3;
   return CGAN_CONV_KERNEL_GENERAL;
 }
 
@@ -822,12 +824,25 @@ static int dispatch_conv(ConvParams& p, const CganConvDesc* d, hipStream_t s, co
       return CGAN_OK;
     }
   }
+  if (kind == CGAN_CONV_KERNEL_LDS3X3 && !conv3x3_lds_applicable(d)) {        // the first-layer kernel
+    Conv3x3LdsArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+    a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hi = p.h_in; a.wi = p.w_in; a.pad = p.pad; a.reflect = 0;
+    a.shuffle = 0; a.shuffle_w = 0; a.k = p.kh; a.stride = p.stride;
+    a.hx = p.hx; a.wx = p.wx; a.cin = d->c_in; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
+    a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
+    a.in_ups = 0; a.act = p.act; a.has_res = 0; a.res_ups = 0; a.slope = p.slope;
+    int rc2 = conv_smallcin_launch(a, d->dtype, s);
+    if (rc2 != CGAN_OK) return rc2;
+    CGAN_CHECK_LAUNCH(what);
+    return CGAN_OK;
+  }
   if (kind == CGAN_CONV_KERNEL_LDS3X3) {
     Conv3x3LdsArgs a;
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
     a.n = p.n; a.h = p.h_out; a.w_ = p.w_out; a.hi = p.h_in; a.wi = p.w_in; a.pad = p.pad;
     a.reflect = p.pad_mode == CGAN_PAD_REFLECT;
-    a.shuffle = 0; a.shuffle_w = 0;
+    a.shuffle = 0; a.shuffle_w = 0; a.k = 0; a.stride = 0;
     a.hx = p.hx; a.wx = p.wx; a.cin = d->c_in; a.cin_s = p.cin_s; a.cin_p = p.cin_p;
     a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
     a.in_ups = p.in_ups; a.act = p.act; a.has_res = p.has_res; a.res_ups = p.res_ups; a.slope = p.slope;
@@ -1153,7 +1168,7 @@ static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void*
     a.cin = fwd->c_out; a.cin_s = cgan_cs(fwd->c_out); a.cin_p = (a.cin_s + 31) & ~31;
     a.cout = 16; a.cout_s = 16; a.ctiles = 1; a.ksteps = 9 * (a.cin_p / 32);
     a.in_ups = 0; a.act = CGAN_ACT_NONE; a.has_res = 0; a.res_ups = 0; a.slope = 0.f;
-    a.shuffle = fwd->h_in; a.shuffle_w = fwd->w_in;
+    a.shuffle = fwd->h_in; a.shuffle_w = fwd->w_in; a.k = 0; a.stride = 0;
     int rc2 = conv3x3_lds_launch(a, fwd->dtype, s);
     if (rc2 != CGAN_OK) return rc2;
     CGAN_CHECK_LAUNCH("conv2d_nhwc_bwd_data(sub-pixel)");

@@ -512,3 +512,44 @@ def test_first_layer_dgrad_as_a_subpixel_3x3_conv(dt, case):
     finally:
         lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
     assert rel_err(dx.t.float(), dx2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)
+
+
+@pytest.mark.usefixtures("dev_lib")
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (cin, cout, k, stride, pad, B, H, W, act)
+    (3, 64, 7, 2, 3, 2, 96, 80, "none"),       # ResNet stem (resnet101_v3.py:176)
+    (4, 64, 4, 2, 1, 2, 64, 64, "lrelu"),      # PatchGAN input conv (discriminator.py:100-120)
+    (4, 64, 4, 2, 1, 1, 65, 71, "lrelu"),      # odd extents: a row / column no window reaches, ragged tiles
+    (8, 40, 5, 1, 2, 2, 40, 48, "none"),       # stride 1, 40 outputs (a pad tile), all 8 channels live
+    (1, 16, 2, 1, 0, 1, 33, 40, "relu"),       # one k-step, a single channel tile
+    (6, 24, 6, 2, 2, 1, 70, 66, "none"),
+])
+def test_first_layer_convs_on_the_halo_tiled_kernel(dt, case):
+    """Round 5: convolutions with <= 8 input channels and k != 3 (conv_smallcin_kernel: the input halo of a 16 x 16 output
+    tile staged once in LDS, four taps per MFMA k-step) against torch, against the general gather kernel, and that the
+    dispatcher takes the tiled family for them."""
+    from climategan_amd import _lib, ops
+    cin, cout, k, stride, pad, B, H, W, act = case
+    lib = _lib.load()
+    x = q(fill.uniform((B, cin, H, W), 8100 + cin + H), dt)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    w = q(fill.uniform((cout, cin, k, k), 8200 + cout + k, -bound, bound), dt)
+    b = torch.from_numpy(fill.uniform((cout,), 8300 + cout, -bound, bound))
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    ref = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2)}[act](ref)
+    assert _kind(lib, dt, (cin, cout, k, stride, pad, B, H, W), False) == 1, "this case must run on the tiled family"
+    xg = ops.nchw_to_nhwc(x.cuda(), dt)
+    pw = ops.pack_conv_weight(w.cuda(), b.cuda(), dt)
+    kw = dict(stride=stride, pad=pad, act={"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}[act])
+    y = ops.conv2d(xg, pw, **kw)
+    assert y.t.shape == (B, ref.shape[2], ref.shape[3], ops.cs8(cout))
+    assert rel_err(ops.nhwc_to_nchw(y).cpu(), ref) <= (1e-3 if dt == torch.float16 else 8e-3)
+    if ops.cs8(cout) != cout:
+        assert y.t[..., cout:].abs().max().item() == 0
+    lib.cgan_debug_set_conv_kernel(ctypes.c_int(1))
+    try:
+        y2 = ops.conv2d(xg, pw, **kw)
+    finally:
+        lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
+    assert rel_err(y.t.float(), y2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)
