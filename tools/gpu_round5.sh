@@ -22,4 +22,25 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
      python bench.py --only painter --steps 1 --warmup 1 2>&1 | tail -1 | cut -c1-200) > gpurun_out/pmc_${TAG}p_$ctr.log 2>&1
   rm -f gpurun_out/pmc_${TAG}p_$ctr/*kernel_trace.csv
 done
-cat gpurun_out/smoke.log; cut -c1-600 gpurun_out/bench_$TAG.json; ls gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_serial gpurun_out/prof_${TAG}_painter gpurun_out/pmc_${TAG}p_FETCH_SIZE
+# ---- summaries on the box (the raw per-dispatch counter csv files are tens of MB each: gpurun_out/ only carries 64 MiB back)
+mkdir -p gpurun_out/profiles_$TAG
+LPS=$(python - <<PY
+import json
+r = json.loads(open("gpurun_out/bench_$TAG.json").read())
+print(r["roofline"]["launches_per_step"])
+PY
+)
+python tools/step_hbm_budget.py gpurun_out $TAG ${TAG}_step_hbm_budget.csv gpurun_out/calllog_$TAG.txt > /dev/null 2>&1
+python tools/pmc_by_class.py gpurun_out $TAG gpurun_out/conv_table_$TAG.txt.launches ${TAG}_conv_gemm_hbm_by_class.csv > /dev/null 2>&1
+python tools/summarize_pmc_kernel.py gpurun_out $TAG "conv_gemm|conv1x1_xres|conv1x1_allc" $LPS ${TAG}_conv_gemm_hbm_pmc.csv > /dev/null 2>&1
+python tools/summarize_pmc_kernel.py gpurun_out ${TAG}p "spade_fused" 23 ${TAG}p_spade_hbm_pmc.csv > /dev/null 2>&1
+python tools/mfma_util.py gpurun_out $TAG ${TAG}_mfma_util.csv gpurun_out/conv_table_${TAG}sq.txt.launches > /dev/null 2>&1
+cp profiles/${TAG}_step_hbm_budget.csv profiles/${TAG}_conv_gemm_hbm_by_class.csv profiles/${TAG}_conv_gemm_hbm_pmc.csv \
+   profiles/${TAG}p_spade_hbm_pmc.csv profiles/${TAG}_mfma_util.csv gpurun_out/profiles_$TAG/ 2>/dev/null
+cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_headline_kernel_stats.csv
+cp gpurun_out/prof_${TAG}_serial/${TAG}_serial_kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_headline_serial_kernel_stats.csv
+cp gpurun_out/prof_${TAG}_painter/${TAG}_painter_kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_painter_kernel_stats.csv
+cp gpurun_out/bench_$TAG.json gpurun_out/profiles_$TAG/${TAG}_bench.json
+cp gpurun_out/conv_table_$TAG.txt gpurun_out/profiles_$TAG/${TAG}_conv_table_all_mfma.txt
+rm -rf gpurun_out/pmc_${TAG}_* gpurun_out/pmc_${TAG}p_* gpurun_out/sq_${TAG}_a gpurun_out/sq_${TAG}_b gpurun_out/sq_${TAG}_c gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_serial gpurun_out/prof_${TAG}_painter
+cat gpurun_out/smoke.log; cut -c1-600 gpurun_out/bench_$TAG.json; ls -la gpurun_out/profiles_$TAG; du -sh gpurun_out

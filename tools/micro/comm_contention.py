@@ -1,8 +1,9 @@
 """What the joint train step loses while a communication kernel occupies part of the chip (the risk named for the
 8-GPU run, measured on one GPU).  A stand-in for RCCL's ring kernels (tools/micro/comm_standin.hip: W persistent workgroups
 streaming a[i] += b[i] over a 25 MB bucket on their own stream) runs beside the headline step, ONE launch spanning all timed
-steps; the steps are timed by events on the training stream only.  Two regimes per W: unthrottled (the workgroups move
-whatever HBM gives them: an upper bound of the harm) and throttled to a link-like rate (idle slots between 4 KiB pieces).
+steps; the steps are timed by events on the training stream only, and every configuration is bracketed by its own
+stand-in-free baseline (the box drifts by milliseconds over a minute).  Two regimes per W: unthrottled (the workgroups move
+whatever HBM gives them: an upper bound of the harm) and throttled to a link-like rate (idle slots between 16-byte pieces).
 usage (GPU box): python tools/micro/comm_contention.py [--steps 10]"""
 import argparse
 import ctypes
@@ -36,7 +37,7 @@ def main():
     a = torch.zeros(n, device=dev)
     b = torch.ones(n, device=dev)
     comm = torch.cuda.Stream(device=dev)
-    for _ in range(5):
+    for _ in range(8):
         T.train_step(batch)
     torch.cuda.synchronize()
 
@@ -49,14 +50,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
 
-    print("workgroups idle  ms_per_step  delta_ms  standin_GBps_alone  (bucket %.0f MB, %d steps)" % (args.bucket_mb, args.steps))
-    base = None
-    for wgs, idle in ((0, 0), (8, 0), (8, 4), (16, 0), (16, 4), (32, 0), (32, 4), (64, 4), (0, 0)):
-        passes, alone = 1, 0.0
-        if wgs:
-            per_pass = standin_ms(wgs, 2, idle) / 2
-            alone = 3 * n * 4 / (per_pass * 1e-3) / 1e9
-            passes = max(1, int(1.6 * args.steps * 95.0 / per_pass))       # outlasts the timed steps even when they slow down
+    def steps_ms(wgs, passes, idle):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if wgs:
@@ -67,12 +61,20 @@ def main():
             T.train_step(batch)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / args.steps
-        still = not comm.query()
+        still = (not comm.query()) if wgs else True
         torch.cuda.synchronize()
-        base = base or ms
-        print("%10d %4d  %11.2f  %+8.2f  %18.1f  %s" % (wgs, idle, ms, ms - base, alone,
-                                                       "" if (still or not wgs) else "(stand-in ended before the steps did)"))
+        return e0.elapsed_time(e1) / args.steps, still
+
+    print("workgroups idle  base_ms  with_ms  delta_ms  standin_GBps_alone  (bucket %.0f MB, %d steps per arm)" % (args.bucket_mb, args.steps))
+    for wgs, idle in ((8, 0), (8, 2), (16, 0), (16, 2), (32, 0), (32, 2), (64, 2), (16, 8)):
+        standin_ms(wgs, 1, idle)
+        per_pass = standin_ms(wgs, 2, idle) / 2
+        alone = 3 * n * 4 / (per_pass * 1e-3) / 1e9
+        passes = max(1, int(1.6 * args.steps * 95.0 / per_pass))       # outlasts the timed steps even when they slow down
+        base, _ = steps_ms(0, 0, 0)
+        ms, still = steps_ms(wgs, passes, idle)
+        print("%10d %4d  %7.2f  %7.2f  %+8.2f  %18.1f  %s" % (wgs, idle, base, ms, ms - base, alone,
+                                                              "" if still else "(stand-in ended before the steps did)"), flush=True)
     T.close()
 
 
