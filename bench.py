@@ -129,6 +129,51 @@ def recorded_traffic(pattern):
     return int(float(m.group(1)) * 1e6) if m else None
 
 
+def live_traffic(launches_per_step, timeout_s=150):
+    """HBM bytes per launch of the wide-layer GEMM family MEASURED NOW (round 5): two child runs of this script's headline step
+    under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` / ``WRITE_SIZE`` (separate passes: the two counters do not fit one),
+    the family's dispatches of the last step summed as tools/summarize_pmc_kernel.py does (FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md).  None when rocprofv3 is not on the box, a pass fails or takes too long, or
+    CGAN_BENCH_NO_LIVE_PMC=1 -- the caller then reports the newest committed summary and says so."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("CGAN_BENCH_NO_LIVE_PMC") == "1" or shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):      # this run is itself being profiled
+        return None
+    fam = ("conv_gemm", "conv1x1_xres", "conv1x1_allc")
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="cgan_pmc_")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "live", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--sub-steps", "0",
+                   "--no-launch-events", "--mfma-table-steps", "0"]
+            env = dict(os.environ, CGAN_BENCH_NO_LIVE_PMC="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, timeout=timeout_s)
+            f = None
+            for root, _d, files in os.walk(out):
+                for name in files:
+                    if name.endswith("counter_collection.csv"):
+                        f = os.path.join(root, name)
+            if r.returncode != 0 or f is None:
+                return None
+            rows = [x for x in csv.DictReader(open(f)) if x["Counter_Name"] == ctr and any(k in x["Kernel_Name"] for k in fam)]
+            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+            rows = rows[-launches_per_step:]
+            if len(rows) != launches_per_step:
+                return None
+            tot[ctr] = sum(float(x["Counter_Value"]) for x in rows) * 1024.0
+        return int((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches_per_step)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def recorded_mfma_util():
     """Matrix-pipe busy fraction and wave-life split per kernel family from the newest committed SQ-counter summary
     (profiles/*_mfma_util.csv: tools/gpu_pmc_step_sq.sh + tools/mfma_util.py, rocprofv3 --pmc passes of this command's
@@ -909,6 +954,8 @@ def main():
     ap.add_argument("--mfma-table-steps", type=int, default=2,
                     help="extra single-stream steps after the timed region with EVERY MFMA-kernel launch bracketed (0 = skip)")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each sub-block (0 = skip the sub-blocks)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic with two rocprofv3 --pmc child passes (report the committed summary)")
     ap.add_argument("--ddp-bucket-mb", type=float, default=0.0, help="N > 1: gradient bucket size of the reducer (default 25)")
     ap.add_argument("--ddp-bf16-wire", action="store_true", help="N > 1: bf16 gradient buckets on the wire (default fp32)")
     ap.add_argument("--nccl-max-nchannels", type=int, default=0,
@@ -1059,9 +1106,7 @@ def main():
                           "output channels of ResNet-101 / ASPP / decoders / VGG-19 / PatchGAN)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": recorded_traffic("*_conv_gemm_hbm_pmc.csv"),
-                "traffic_unit": "HBM bytes per launch (mean), from the newest profiles/*_conv_gemm_hbm_pmc.csv: separate "
-                                "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction",
+                "traffic": None, "traffic_unit": None,
                 "algorithmic_flops_per_step": timer.total_flops() / sampled,
                 "algorithmic_bytes_per_launch": int(timer.total_bytes() / n),
                 "launches_per_step": n // max(sampled, 1), "avg_launch_ms": round(ms / n, 5),
@@ -1070,6 +1115,14 @@ def main():
                                    % (sampled, args.steps, EVENT_EVERY),
                 "share_of_step": round((ms / sampled) / (elapsed / args.steps * 1e3), 3),
                 "by_class": timer.classes()}
+            lps = n // max(sampled, 1)
+            live = live_traffic(lps) if (world == 1 and not args.no_live_traffic) else None
+            res["roofline"]["traffic"] = live if live is not None else recorded_traffic("*_conv_gemm_hbm_pmc.csv")
+            res["roofline"]["traffic_unit"] = (
+                "HBM bytes per launch (mean over the family's %d launches of one step), %s: separate rocprofv3 --pmc FETCH_SIZE / "
+                "WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction"
+                % (lps, "MEASURED IN THIS RUN (two child passes of this command's headline step)" if live is not None
+                   else "from the newest committed profiles/*_conv_gemm_hbm_pmc.csv (rocprofv3 not usable in this run)"))
             mu = recorded_mfma_util()
             if mu:
                 gk = [mu[k] for k in ("gemm 1x1", "gemm kxk") if k in mu]
