@@ -29,7 +29,9 @@ constexpr int KLOOP_BYTES = 2 * XBUF_BYTES + 2 * STAGE_BYTES;
 constexpr int SEG_BYTES = ((HP * 8 + 1023) / 1024) * 1024;        // 18 x 18 x 8 B, rounded to 1 KiB
 constexpr int SLAB_BYTES = 256 * 128;                              // [256 pixels][64 x 2 B]
 constexpr int EPI_BYTES = SEG_BYTES + 2 * SLAB_BYTES;
-constexpr int SMEM_BYTES = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+constexpr int WORK_BYTES = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+constexpr int WSH_BYTES = NCT * 64 * 32 + NCT * 64 * 16;           // mlp_shared's folded A fragments (a0 | a1) + bias quads, per lane
+constexpr int SMEM_BYTES = WORK_BYTES + WSH_BYTES;
 constexpr int PART_COLS = 64;                                      // columns of a partial row: 36 (tap, c4) + bias at 48
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -42,6 +44,7 @@ struct SpadeHidBwdArgs {
   const float* b_sh;       // its bias, padded to whole cout tiles
   float* part;             // [workgroups.x][2][64 hidden][PART_COLS] fp32
   int n, h, w, gs, cin_p, ksteps_dg, ksteps_sh, seg_cs, ctiles_dg, ctiles_sh, ntiles;
+  int tail_r;              // 1 / 2: the last 32-channel chunk holds 8 / 16 live channels and runs as dense tail passes (0: off)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_sb_zeros[64];
@@ -98,9 +101,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
   const int g = lane >> 4;
   const int ct0 = blockIdx.y * NCT;                                // first hidden-channel tile of this workgroup
   const int nq = p.cin_p / 32;
-  const int nstages = nq * 3;
   const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
 
+  // mlp_shared's folded A fragments (conv3x3_c4_kernel: k-step 0 = taps 0..7 x 4 channels, k-step 1 = tap 8) and bias quads of this
+  // workgroup's four channel tiles, once per workgroup into LDS (per lane 32 + 16 bytes per tile): the epilogue of every tile reads
+  // them back instead of waiting on L2 (their registers would not survive the K loop: 48 of the 256)
+  unsigned char* wsh = smem + WORK_BYTES;
+  if (wave < NCT) {
+    const int c = wave;
+    const int ct = min(ct0 + c, p.ctiles_sh - 1);
+    const u32x2* wt = reinterpret_cast<const u32x2*>(p.w_sh + (size_t)ct * p.ksteps_sh * 64);
+    const u32x2 wlo = wt[((2 * g) * 64 + j) * 2], whi = wt[((2 * g + 1) * 64 + j) * 2];
+    const u32x2 wlast = wt[(8 * 64 + j) * 2];
+    *reinterpret_cast<u32x4*>(wsh + (c * 64 + lane) * 32) = (u32x4){wlo[0], wlo[1], whi[0], whi[1]};
+    *reinterpret_cast<u32x4*>(wsh + (c * 64 + lane) * 32 + 16) = g == 0 ? (u32x4){wlast[0], wlast[1], 0u, 0u} : (u32x4){0u, 0u, 0u, 0u};
+    *reinterpret_cast<f32x4*>(wsh + NCT * 64 * 32 + (c * 64 + lane) * 16) = *reinterpret_cast<const f32x4*>(p.b_sh + ct * 16 + g * 4);
+  }
   // this workgroup's share of mlp_shared's gradient: wave w owns hidden rows 16 w .. 16 w + 15 of the 64, columns = three
   // 16-wide tiles of (tap, c4) + the all-ones column of the bias
   f32x4 accs[3], accb;
@@ -132,9 +148,39 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
       }
     };
+    // Stages: every FULL 32-channel chunk q runs three dx stages (3 dy taps x NCT operator fragments each).  A last chunk that
+    // holds only 8 / 16 live channels (2C = 40 / 80: the Painter's 640 x 640 and 320 x 320 layers) would multiply 24 / 16 zero
+    // channels per tap -- it runs as DENSE TAIL passes instead: one k-step = 4 / 2 taps x the live 8-channel groups, lane group
+    // g takes tap tp * G + g / r (and channel group g % r): 3 / 5 passes instead of 9 (K = 12 / 23 k-steps instead of 18 / 27).
+    // Its operator fragments are gathered per lane from the standard pack by the same LDS-DMA (16 bytes per lane from the
+    // k-step of the lane's own tap), its B fragments are per-lane reads of the halo chunk at the lane's own tap shift.
+    const int tr = p.tail_r;
+    const int nqf = tr ? nq - 1 : nq;                   // full chunks
+    const int tgp = tr ? 4 / tr : 1;                    // taps per tail pass
+    const int ntp = tr ? (9 + tgp - 1) / tgp : 0;       // tail passes, three to a stage (12 operator pieces = a stage's 12 KiB)
+    const int nts = (ntp + 2) / 3;                      // tail stages
+    const int nst = 3 * nqf + nts;
+    const int t_cg = tr == 2 ? (g & 1) : 0;             // this lane's live channel group in a tail pass
+    const int t_tl = tr == 2 ? (g >> 1) : g;            // ... and its tap within the pass
     auto issue_w = [&](int s) {
-      const int q = s / 3, dx = s - q * 3;
       unsigned char* dst = wbuf + (s & 1) * STAGE_BYTES;
+      if (s >= 3 * nqf) {
+        const int tp0 = (s - 3 * nqf) * 3;
+#pragma unroll
+        for (int i0 = 0; i0 < 3 * NCT; i0 += WAVES) {
+          const int i = i0 + wave;
+          const int pl = i / NCT, c = i - pl * NCT;     // pass of the stage, operator tile
+          if (i < 3 * NCT && tp0 + pl < ntp) {
+            const int tap = (tp0 + pl) * tgp + t_tl;
+            const int ct = min(ct0 + c, p.ctiles_dg - 1);
+            const u32x4* src = tap < 9 ? p.w_dg + ((size_t)ct * p.ksteps_dg + tap * nq + (nq - 1)) * 64 + t_cg * 16 + j : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+          }
+        }
+        return;
+      }
+      const int q = s / 3, dx = s - q * 3;
 #pragma unroll
       for (int i0 = 0; i0 < 3 * NCT; i0 += WAVES) {
         const int i = i0 + wave;
@@ -151,6 +197,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
     SB_BARRIER();                    // the previous tile's epilogue is done with the shared memory
     issue_x(0);
     issue_w(0);
+    // the conditioning halo's two pixels of this thread, requested now and parked in registers until the epilogue stores them
+    u32x2 sv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pix = threadIdx.x + u * WAVES * 64;
+      const int py = pix / HPW, px = pix - py * HPW;
+      const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+      sv[u] = (u32x2){0u, 0u};
+      if (pix < HP && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
+        sv[u] = *reinterpret_cast<const u32x2*>(p.seg + (((size_t)n * p.h + yy) * p.w + xx) * p.seg_cs);
+    }
     f32x4 acc[NCT][PT];
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -158,13 +215,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
       for (int t = 0; t < PT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- dh (before the mask) = the 3x3 data gradient over the dgb halo: conv3x3_lds_kernel's loop
-    for (int q = 0; q < nq; ++q) {
+    for (int q = 0; q < nqf; ++q) {
       const unsigned char* xb = xbuf + (q & 1) * XBUF_BYTES;
       for (int dx = 0; dx < 3; ++dx) {
         const int s = q * 3 + dx;
         SB_BARRIER();
         if (dx == 0 && q + 1 < nq) issue_x(q + 1);
-        if (s + 1 < nstages) issue_w(s + 1);
+        if (s + 1 < nst) issue_w(s + 1);
         u32x4 bfr[PT + 2];
 #pragma unroll
         for (int r = 0; r < PT + 2; ++r) {
@@ -185,33 +242,55 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
         }
       }
     }
+    for (int ts = 0; ts < nts; ++ts) {                  // dense tail stages (three passes each) over chunk nq - 1
+      const unsigned char* xb = xbuf + ((nq - 1) & 1) * XBUF_BYTES;
+      const int s = 3 * nqf + ts;
+      SB_BARRIER();
+      if (s + 1 < nst) issue_w(s + 1);
+      const unsigned char* wb = wbuf + (s & 1) * STAGE_BYTES + lane * 16;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const int tp = ts * 3 + pl;
+        if (tp < ntp) {                                 // (wave-uniform)
+          const int tap = tp * tgp + t_tl;
+          const bool tv = tap < 9;
+          const int tc = tv ? tap : 0;
+          const int dy = tc / 3, dx = tc - dy * 3;
+          u32x4 bt[PT];
+#pragma unroll
+          for (int t = 0; t < PT; ++t) {
+            const int qq = (wave * PT + t + dy) * HPW + (j + dx);
+            bt[t] = *reinterpret_cast<const u32x4*>(xb + xq_addr(qq, t_cg));
+            if (!tv) bt[t] = (u32x4){0u, 0u, 0u, 0u};
+          }
+          u32x4 a[NCT];
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const u32x4*>(wb + (pl * NCT + c) * 1024);
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[c][t] = mfma16(as_vec8<T>(a[c]), as_vec8<T>(bt[t]), acc[c][t]);
+        }
+      }
+    }
 
     // ---- epilogue 1: conditioning halo -> LDS (8 bytes = channels 0..3 per pixel, zeros outside the image)
     SB_BARRIER();
-    for (int pix = threadIdx.x; pix < HP; pix += WAVES * 64) {
-      const int py = pix / HPW, px = pix - py * HPW;
-      const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
-      u32x2 v = {0u, 0u};
-      if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
-        v = *reinterpret_cast<const u32x2*>(p.seg + (((size_t)n * p.h + yy) * p.w + xx) * p.seg_cs);
-      segh[pix] = v;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pix = threadIdx.x + u * WAVES * 64;
+      if (pix < HP) segh[pix] = sv[u];
     }
     __syncthreads();
     // ---- epilogue 2: hidden tile re-computed (two folded MFMAs per 16 x 16 block), dh masked with h > 0 and staged 16-bit
     // as [pixel][hidden]; the conditioning neighbourhood of every pixel as [pixel][(tap, c4)] beside it
-    // (mlp_shared's folded A fragments -- conv3x3_c4_kernel: k-step 0 = taps 0..7 x 4 channels, k-step 1 = tap 8 -- and
-    // its bias are re-read per tile and channel tile: 12 registers live here instead of 48 across the K loop)
     const int tA = 2 * g, tB = 2 * g + 1;
     const int offA = (tA / 3) * HPW + tA % 3, offB = (tB / 3) * HPW + tB % 3;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-      const int ct = min(ct0 + c, p.ctiles_sh - 1);
-      const u32x2* wt = reinterpret_cast<const u32x2*>(p.w_sh + (size_t)ct * p.ksteps_sh * 64);
-      const u32x2 wlo = wt[((2 * g) * 64 + j) * 2], whi = wt[((2 * g + 1) * 64 + j) * 2];
-      const u32x2 wlast = wt[(8 * 64 + j) * 2];
-      const u32x4 a0 = {wlo[0], wlo[1], whi[0], whi[1]};
-      const u32x4 a1 = g == 0 ? (u32x4){wlast[0], wlast[1], 0u, 0u} : (u32x4){0u, 0u, 0u, 0u};
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(p.b_sh + ct * 16 + g * 4);
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(wsh + (c * 64 + lane) * 32);
+      const u32x4 a1 = *reinterpret_cast<const u32x4*>(wsh + (c * 64 + lane) * 32 + 16);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(wsh + NCT * 64 * 32 + (c * 64 + lane) * 16);
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
         const int row = wave * PT + t;
@@ -348,6 +427,10 @@ extern "C" int cgan_spade_hidden_bwd(const void* dgb, const void* packed_dgrad_g
   a.ksteps_sh = 9;                                    // cond_c <= 4 -> cin_s 8 -> cin_p 32: one k-step per tap
   a.seg_cs = cgan_cs(d->cond_c);
   a.ctiles_dg = 8; a.ctiles_sh = 8;                   // 128 hidden channels
+  {
+    const int live = (a.gs - 32 * (a.cin_p / 32 - 1)) / 8;       // live 8-channel groups of the last 32-channel chunk
+    a.tail_r = (live == 1 || live == 2) ? live : 0;
+  }
   CGAN_REQUIRE((double)d->n * d->h * d->w * a.gs * 2.0 < 4294967295.0, "spade_hidden_bwd: map of 4 GiB or more");
   a.ntiles = d->n * ((d->h + TH - 1) / TH) * ((d->w + TW - 1) / TW);
   const int wgs = hid_bwd_workgroups(d);
