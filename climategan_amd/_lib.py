@@ -71,6 +71,9 @@ _SIGNATURES = {
     "cgan_conv2d_nhwc_bwd_data": (C.c_int, [_P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_fwd_pair": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_pair_expand_weight": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_pair_instnorm_stats": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, _P]),
+    "cgan_pair_spade_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_float, _P]),
     "cgan_pair_from_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_pair_to_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_pair_to_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),

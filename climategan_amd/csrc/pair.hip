@@ -252,6 +252,97 @@ __global__ void pair_expand_weight_kernel(const float* __restrict__ w, const flo
   }
 }
 
+
+// Instance-norm statistics of a split map (round 5: the split-precision Painter): one workgroup per (image, 8-channel group),
+// two passes over the pixels in fp64 (mean, then the biased variance around it) -- the arithmetic of F.instance_norm in the
+// reference's fp32 run (norms.py:151,174) with room to spare; mean / rstd rows fp32 [n][cs]
+template <typename T>
+__global__ __launch_bounds__(256) void pair_instnorm_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ mean,
+                                                                  float* __restrict__ rstd, int hw, int cs, float eps) {
+  __shared__ double red[256][8];
+  const int cg = blockIdx.x, n = blockIdx.y;
+  const uint16_t* base = x + (size_t)n * hw * Split<T>::NB * cs;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    float v[8];
+    pair_load8<T>(base + (size_t)p * Split<T>::NB * cs, cs, cg, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += (double)v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + st][e];
+    __syncthreads();
+  }
+  double m[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = red[0][e] / (double)hw;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0;
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    float v[8];
+    pair_load8<T>(base + (size_t)p * Split<T>::NB * cs, cs, cg, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double d = (double)v[e] - m[e];
+      s[e] += d * d;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + st][e];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8) {
+    const int e = threadIdx.x;
+    mean[(size_t)n * cs + cg * 8 + e] = (float)m[e];
+    rstd[(size_t)n * cs + cg * 8 + e] = (float)(1.0 / sqrt(red[0][e] / (double)hw + (double)eps));
+  }
+}
+
+// SPADE's de-normalisation on split maps: y = act((x - mean) rstd (1 + gamma) + beta) in fp32 on the sums of the components
+// (norms.py:181-186 + the block's LeakyReLU); x optionally read through the folded x2 nearest upsample
+template <typename T>
+__global__ void pair_spade_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, const uint16_t* __restrict__ gamma,
+                                        const uint16_t* __restrict__ beta, uint16_t* __restrict__ y, int h, int w, int c, int cs,
+                                        int ups, int act, float slope, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int xx = (int)(pix % w);
+    const long r = pix / w;
+    const int yy = (int)(r % h);
+    const long n = r / h;
+    const long xpix = ups ? (n * (h >> 1) + (yy >> 1)) * (long)(w >> 1) + (xx >> 1) : pix;
+    float xv[8], gv[8], bv[8], o[8];
+    pair_load8<T>(x + xpix * Split<T>::NB * cs, cs, cg, xv);
+    pair_load8<T>(gamma + pix * Split<T>::NB * cs, cs, cg, gv);
+    pair_load8<T>(beta + pix * Split<T>::NB * cs, cs, cg, bv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cg * 8 + e;
+      float v = 0.f;
+      if (ch < c) {
+        const float xh = (xv[e] - mean[n * cs + ch]) * rstd[n * cs + ch];
+        v = act_apply(xh * (1.f + gv[e]) + bv[e], act, slope);
+      }
+      o[e] = v;
+    }
+    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, o);
+  }
+}
+
 }  // namespace
 
 #define PAIR_DISPATCH(dtype, KERNEL, ...)                                  \
@@ -373,5 +464,32 @@ extern "C" int cgan_pair_expand_weight(const float* w_oihw, const float* sigma, 
   PAIR_DISPATCH(dtype, pair_expand_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, sigma, w3,
                 c_in, cs_in, taps, total);
   CGAN_CHECK_LAUNCH("pair_expand_weight");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_instnorm_stats(const void* x3, float* mean, float* rstd, int32_t dtype, int32_t n, int32_t c, int64_t hw,
+                                        float eps, void* stream) {
+  CGAN_REQUIRE(x3 && mean && rstd && n > 0 && c > 0 && hw > 0 && hw < (1L << 31), "pair_instnorm_stats: bad arguments");
+  PAIR_CHECK_DT("pair_instnorm_stats");
+  const int cs = cgan_cs(c);
+  PAIR_DISPATCH(dtype, pair_instnorm_stats_kernel, dim3(cs / 8, n), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3, mean,
+                rstd, (int)hw, cs, eps);
+  CGAN_CHECK_LAUNCH("pair_instnorm_stats");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_spade_apply(const void* x3, const float* mean, const float* rstd, const void* gamma3, const void* beta3,
+                                     void* y3, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t x_upsample,
+                                     int32_t act, float act_slope, void* stream) {
+  CGAN_REQUIRE(x3 && mean && rstd && gamma3 && beta3 && y3 && n > 0 && h > 0 && w > 0 && c > 0, "pair_spade_apply: bad arguments");
+  PAIR_CHECK_DT("pair_spade_apply");
+  CGAN_REQUIRE(!x_upsample || ((h % 2) == 0 && (w % 2) == 0), "pair_spade_apply: x_upsample needs even h / w");
+  CGAN_REQUIRE(act == CGAN_ACT_NONE || act == CGAN_ACT_LRELU, "pair_spade_apply: activation none or LeakyReLU");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h * w * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_spade_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3, mean,
+                rstd, (const uint16_t*)gamma3, (const uint16_t*)beta3, (uint16_t*)y3, h, w, c, cs, x_upsample ? 1 : 0, act, act_slope,
+                total);
+  CGAN_CHECK_LAUNCH("pair_spade_apply");
   return CGAN_OK;
 }

@@ -143,7 +143,7 @@ class OmniGenerator(nn.Module):
     def _pair_unsupported(self):
         """Why this generator cannot run the split-precision Masker (None: it can).  Only the ResNet encoder, the DADA depth
         decoder, the DeepLab segmentation decoder and the plain mask decoder carry pair maps."""
-        if self.encoder is None or not hasattr(self.encoder, "pair_precision"):
+        if self.encoder is not None and not hasattr(self.encoder, "pair_precision"):
             return "the encoder has no pair-map path"
         if "m" in self.decoders and self.opts.gen.m.use_spade:
             return "the SPADE mask decoder (gen.m.use_spade) has no pair-map path"
@@ -340,6 +340,15 @@ class OmniGenerator(nn.Module):
         dt = p.compute_dtype
         z = self.sample_painter_z(x.shape[0], x.device)
         m = m.to(x.dtype)
+        if getattr(p, "pair_precision", False) and not (torch.is_grad_enabled() and any(q.requires_grad for q in p.parameters())):
+            # split-precision inference (round 5): the Painter on split maps -- every conv as a split-precision conv, SPADE
+            # unfused with its de-normalisation in fp32 (norms.SPADE._forward_pair): the arithmetic of the reference's fp32 run
+            xf, mf = x.float(), m.float()
+            cond = ops.pair_from_nchw(xf * (1.0 - mf), dt)
+            zz = ops.pair_from_nchw(z.float(), dt) if z is not None else None
+            fake = ops.nhwc_to_nchw(p.forward_nhwc(zz, cond))
+            paste = self.opts.gen.p.paste_original_content and not no_paste
+            return (xf * (1.0 - mf) + fake * mf).to(x.dtype) if paste else fake.to(x.dtype)
         zz = ops.nchw_to_nhwc(z, dt) if z is not None else None
         paste = self.opts.gen.p.paste_original_content and not no_paste
         if torch.is_grad_enabled() and (m.requires_grad or x.requires_grad):

@@ -375,6 +375,8 @@ class SPADE(nn.Module):
     def forward_nhwc(self, x: ops.NHWC, cond: ops.NHWC, stats=None, act=ops.ACT_NONE, x_upsample=False) -> ops.NHWC:
         if self.kernel_size != 3:
             raise NotImplementedError("SPADE: only kernel_size 3 is supported")
+        if isinstance(x, ops.PairMap):
+            return self._forward_pair(x, cond, stats, act, x_upsample)
         batch_stats = False
         if self.param_free_norm_type == "batch":
             # nn.BatchNorm2d(affine=False) (norms.py:152-153): eval mode normalises with the running statistics
@@ -416,6 +418,30 @@ class SPADE(nn.Module):
                                 self.packed(x.t.dtype), cfg)
             return ops.NHWC(y_t, x.c)
         return ops.spade_fused(x, stats[0], stats[1], cond, self.packed(x.t.dtype), act=act, x_upsample=x_upsample)
+
+    def _forward_pair(self, x: "ops.PairMap", cond: "ops.PairMap", stats, act, x_upsample) -> "ops.PairMap":
+        """Split-precision inference (round 5; ``G.float()`` / ``set_compute_dtype("split24")``: the reference's fp32 run):
+        the fused kernel multiplies a 16-bit hidden map, so here SPADE runs as the reference writes it (norms.py:174-186) --
+        nearest-resized conditioning map, mlp_shared (+ ReLU), mlp_gamma, mlp_beta as split-precision convolutions, the
+        de-normalisation in fp32 on the sums of the components (cgan_pair_spade_apply)."""
+        _grad_guard(self)
+        if self.param_free_norm_type != "instance" or not isinstance(cond, ops.PairMap):
+            raise NotImplementedError("SPADE on split maps: instance param-free norm and a split conditioning map only")
+        if stats is None:
+            stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
+        h, w = (x.h * 2, x.w * 2) if x_upsample else (x.h, x.w)
+        seg = cond if (cond.h, cond.w) == (h, w) else ops.resize_nearest(cond, (h, w))
+        dt = x.t.dtype
+
+        def pk(conv):
+            return self._cache.get((conv.weight, conv.bias, "pair"), dt,
+                                   lambda: ops.pack_conv_weight(conv.weight.data, conv.bias.data, dt, pair=True))
+
+        actv = ops.conv2d(seg, pk(self.mlp_shared[0]), pad=1, act=ops.ACT_RELU)
+        gamma = ops.conv2d(actv, pk(self.mlp_gamma), pad=1)
+        beta = ops.conv2d(actv, pk(self.mlp_beta), pad=1)
+        del actv
+        return ops.pair_spade_apply(x, stats[0], stats[1], gamma, beta, act=act, x_upsample=x_upsample)
 
     def forward(self, x, segmap, compute_dtype=None):
         """Reference signature: NCHW tensors in, NCHW fp32 out."""

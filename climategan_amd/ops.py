@@ -100,7 +100,7 @@ def _need_cuda(*ts):
 
 def detached(x: "NHWC") -> "NHWC":
     """The same map without its autograd graph (an explicit stop-gradient for the ops that need one)."""
-    return NHWC(x.t.detach(), x.c)
+    return x.detach() if isinstance(x, PairMap) else NHWC(x.t.detach(), x.c)
 
 
 @dataclass
@@ -1126,6 +1126,14 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
 @_batch_chunked("x")
 def instnorm_stats(x: NHWC, eps: float = 1e-5):
     """Per-(n,c) mean and 1/sqrt(var+eps) (biased var over H*W) -> two fp32 [N, Cs] tensors."""
+    if isinstance(x, PairMap):          # split-precision Painter: fp64 two-pass statistics of the summed components
+        _plain_pair(x, "instnorm_stats")
+        _need_cuda(x.t)
+        mean = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+        rstd = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+        _lib.check(_lib.load().cgan_pair_instnorm_stats(_ptr(x.t), _ptr(mean), _ptr(rstd), x.dtype_id, x.n, x.c, x.h * x.w,
+                                                        float(eps), _stream()), "cgan_pair_instnorm_stats")
+        return mean, rstd
     _need_cuda(x.t)
     d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, eps)
     lib = _lib.load()
@@ -1303,6 +1311,21 @@ def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=A
                                           _ptr(dgb), _ptr(xhat), _ptr(dxhat), C.byref(d), _stream()),
                "cgan_spade_bwd_prepare")
     return NHWC(dgb, 2 * c), NHWC(xhat, c), NHWC(dxhat, c)
+
+
+@_batch_chunked("x", "mean", "rstd", "gamma", "beta")
+def pair_spade_apply(x: "PairMap", mean, rstd, gamma: "PairMap", beta: "PairMap", act=ACT_NONE, slope=0.2,
+                     x_upsample=False) -> "PairMap":
+    """SPADE's de-normalisation on split maps (cgan_pair_spade_apply): y = act((x - mean) rstd (1 + gamma) + beta) in fp32."""
+    _need_cuda(x.t, mean, rstd, gamma.t, beta.t)
+    h, w = (x.h * 2, x.w * 2) if x_upsample else (x.h, x.w)
+    if (gamma.n, gamma.h, gamma.w, gamma.c) != (x.n, h, w, x.c) or gamma.t.shape != beta.t.shape or gamma.t.dtype != x.t.dtype:
+        raise RuntimeError("pair_spade_apply: gamma / beta must be pair maps of x's channels at the output extent")
+    y = torch.empty((x.n, h, w, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+    _lib.check(_lib.load().cgan_pair_spade_apply(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(gamma.t), _ptr(beta.t), _ptr(y), x.dtype_id,
+                                                 x.n, h, w, x.c, int(bool(x_upsample)), int(act), float(slope), _stream()),
+               "cgan_pair_spade_apply")
+    return PairMap(y, x.c)
 
 
 def spade_hidden_bwd(dgb: NHWC, w_gb: torch.Tensor, seg: NHWC, pw_shared: PackedConv, c: int, want_bias=True):

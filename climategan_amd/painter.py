@@ -57,6 +57,7 @@ class PainterSpadeDecoder(nn.Module):
                 m.trainable = True
         self._fc_cache = _PackCache()
         self._img_cache = _PackCache()
+        self.pair_precision = False      # OmniGenerator.set_compute_dtype("split24" | "pair16"): split-precision inference
 
     def set_latent_shape(self, shape, is_input=True):
         """reference painter.py:115-136"""
@@ -91,6 +92,12 @@ class PainterSpadeDecoder(nn.Module):
     def forward(self, z, cond):
         """Reference signature (painter.py:149): z None or [B,latent,z_h,z_w]; cond [B,3,H,W] NCHW."""
         dt = self.compute_dtype
+        if self.pair_precision and not (torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())):
+            # split-precision inference (round 5): conditioning map and latent as split maps, every conv a split-precision
+            # conv, SPADE unfused with its de-normalisation in fp32 (norms.SPADE._forward_pair)
+            c = ops.pair_from_nchw(cond.float(), dt)
+            zz = ops.pair_from_nchw(z.float(), dt) if z is not None else None
+            return ops.nhwc_to_nchw(self.forward_nhwc(zz, c)).to(cond.dtype)
         c = Fn.from_nchw(cond, dt, cs=4)
         zz = Fn.from_nchw(z, dt) if z is not None else None
         return Fn.to_nchw(self.forward_nhwc(zz, c)).to(cond.dtype)

@@ -676,6 +676,17 @@ int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, const float
                               void* y3, const CganConvDesc* d, void* stream);
 int cgan_pair_expand_weight(const float* w_oihw, const float* sigma, float* w3, int32_t dtype, int32_t c_out, int32_t c_in,
                             int32_t kh, int32_t kw, void* stream);
+/* Split-precision Painter (round 5; the reference's fp32 apply_events run, apply_events.py:465-468, through SPADE:
+ * climategan/norms.py:151,174-186 and painter.py:149-168).  The fused SPADE kernel multiplies a 16-bit hidden map; on split maps
+ * the three convolutions run as cgan_conv2d_nhwc_fwd_pair and these two kernels do the rest in fp32 on the sums of the components:
+ *  pair_instnorm_stats  mean / rstd [n][round_up(c,8)] fp32 of F.instance_norm (biased variance), two fp64 passes
+ *  pair_spade_apply     y = act((x - mean) rstd (1 + gamma) + beta), gamma / beta = the mlp_gamma / mlp_beta conv outputs (bias
+ *                       included), x optionally read through the folded x2 nearest upsample; act none or LeakyReLU */
+int cgan_pair_instnorm_stats(const void* x3, float* mean, float* rstd, int32_t dtype, int32_t n, int32_t c, int64_t hw, float eps,
+                             void* stream);
+int cgan_pair_spade_apply(const void* x3, const float* mean, const float* rstd, const void* gamma3, const void* beta3, void* y3,
+                          int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t x_upsample, int32_t act,
+                          float act_slope, void* stream);
 int cgan_pair_from_nchw(const float* x, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 int cgan_pair_to_nchw(const void* x3, float* y, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, int32_t sigmoid,
                       void* stream);
