@@ -263,7 +263,10 @@ def test_fc_discriminator_on_pair_matches_single_map():
         assert torch.equal(y1.t, y2.t)
         y1.t.float().sum().backward()
         y2.t.float().sum().backward()
-        assert torch.equal(single.t.grad[..., :3], pair_t.grad[..., :3])
+        # (round 5: the 3-channel input's data gradient runs as the sub-pixel 3x3 conv, the 6-channel pair's by parity classes:
+        # the same products in another fp32 summation order -- within one rounding step of the 16-bit gradient)
+        ga, gb = single.t.grad[..., :3].float(), pair_t.grad[..., :3].float()
+        assert (ga - gb).abs().max().item() <= 2 ** -9 * gb.abs().max().item()
         assert torch.equal(pair_t.grad[..., :3], pair_t.grad[..., 3:6])
         for (k, p1), (_, p2) in zip(D.named_parameters(), D2.named_parameters()):
             assert torch.equal(p1.data, p2.data), k                       # u, v advanced identically
