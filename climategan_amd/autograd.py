@@ -292,13 +292,15 @@ _SPADE_FUSED_BWD = os.environ.get("CGAN_SPADE_FUSED_BWD", "1") != "0"     # same
 class SpadeFn(torch.autograd.Function):
     """y = act(param_free_norm(up?(x)) * (1 + gamma(cond)) + beta(cond)) (reference norms.py:174-186 + the block's
     LeakyReLU); the norm is an instance norm (Painter) or, with cfg["batch_stats"], a training-mode batch norm whose
-    (mean, rstd) rows are the batch statistics repeated per sample (MaskSpadeDecoder).  Forward: the fused HIP kernel (the 128-channel hidden map never leaves LDS).  Backward: the hidden map
-    and gamma are RE-COMPUTED at full resolution (conv kernels), the elementwise stage splits dy into the gradients of
-    gamma / beta / the normalised input, and the conv backward kernels produce the gradients of mlp_gamma, mlp_beta,
-    mlp_shared and -- only when the conditioning map wants a gradient (the SPADE mask decoder conditioned on the
-    non-detached depth / segmentation predictions; for the Painter cond is data) -- of cond, through mlp_shared's data
-    gradient and the adjoint of the nearest resize.  The instance-norm backward then gives dx.
-    The re-materialised maps cost HBM traffic the fused forward avoids (a fused backward is future work)."""
+    (mean, rstd) rows are the batch statistics repeated per sample (MaskSpadeDecoder).  Forward: the fused HIP kernel (the
+    128-channel hidden map never leaves LDS; in training it also writes gamma).  Backward: an elementwise stage splits dy into
+    the gradients of gamma / beta / the normalised input; the hidden map is re-materialised once for the gamma||beta weight
+    gradient; below that, for the Painter's <= 4-channel conditioning image on maps of 80 x 80 and up, ONE fused kernel
+    (cgan_spade_hidden_bwd, round 5) turns dgb into mlp_shared's weight / bias gradient -- data gradient of the gamma||beta conv,
+    ReLU mask from a re-computed hidden tile, contraction with the conditioning neighbourhood -- without writing the hidden
+    gradient; elsewhere (small maps, the SPADE mask decoder's 15-channel conditioning map, a conditioning map that wants a
+    gradient itself) the data-gradient conv with the ReLU derivative in its epilogue and a separate weight gradient do the
+    same.  The instance-norm backward then gives dx."""
 
     @staticmethod
     def forward(ctx, x_t, cond_t, mean, rstd, w_sh, b_sh, w_g, b_g, w_b, b_b, packed, cfg):
