@@ -74,6 +74,9 @@ _SIGNATURES = {
     "cgan_pair_instnorm_stats": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float, _P]),
     "cgan_pair_spade_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_float, _P]),
+    "cgan_pair_make_m_cond_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "cgan_pair_make_m_cond": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        _P, C.c_size_t, _P]),
     "cgan_pair_from_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_pair_to_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_pair_to_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
@@ -82,6 +85,7 @@ _SIGNATURES = {
                                             C.c_int32, C.c_int32, _P]),
     "cgan_pair_resize_nearest": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            _P]),
+    "cgan_pair_resize_bicubic": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_pair_mul": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "cgan_pair_copy_channels": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),

@@ -153,8 +153,13 @@ __global__ void pair_resize_bilinear_kernel(const uint16_t* __restrict__ x, uint
     const long r = pix / w_out;
     const int oy = (int)(r % h_out);
     const long n = r / h_out;
-    const float fy = align ? oy * sy : fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
-    const float fx = align ? ox * sx : fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    // the products rounded before anything is subtracted from them, as torch's CPU kernels form the source index (a fused
+    // multiply-add here moves the interpolation weight by up to half an ulp of the INDEX: 6e-6 of the neighbours' difference
+    // at index 60 -- visible at the split maps' precision)
+    float py = (float)oy * sy, px = (float)ox * sx;
+    asm volatile("" : "+v"(py), "+v"(px));
+    const float fy = align ? py : fmaxf(fmaf((float)oy + 0.5f, sy, -0.5f), 0.f);
+    const float fx = align ? px : fmaxf(fmaf((float)ox + 0.5f, sx, -0.5f), 0.f);
     int y0 = (int)fy, x0 = (int)fx;
     y0 = y0 < h_in - 1 ? y0 : h_in - 1;
     x0 = x0 < w_in - 1 ? x0 : w_in - 1;
@@ -170,6 +175,58 @@ __global__ void pair_resize_bilinear_kernel(const uint16_t* __restrict__ x, uint
     for (int e = 0; e < 8; ++e)
       o[e] = (1.f - ly) * ((1.f - lx) * v00[e] + lx * v01[e]) + ly * ((1.f - lx) * v10[e] + lx * v11[e]);
     pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, o);
+  }
+}
+
+// F.interpolate(mode="bicubic", align_corners=False) in fp32 (climategan/depth.py:144-149; as resize_bicubic_kernel, edge.hip:
+// torch's cubic convolution with A = -0.75, source index (dst + 0.5) in/out - 0.5, taps clamped to the border)
+__device__ __forceinline__ void pair_cubic_coeffs(float t, float* w) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+template <typename T>
+__global__ void pair_resize_bicubic_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int h_in, int w_in,
+                                           int h_out, int w_out, int cs, float sy, float sx, long total) {
+  const int cg_total = cs / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cg_total);
+    const long pix = idx / cg_total;
+    const int ox = (int)(pix % w_out);
+    const long r = pix / w_out;
+    const int oy = (int)(r % h_out);
+    const long n = r / h_out;
+    const float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int iy = (int)fly, ix = (int)flx;
+    float wy[4], wx[4];
+    pair_cubic_coeffs(fy - fly, wy);
+    pair_cubic_coeffs(fx - flx, wx);
+    const uint16_t* base = x + n * (long)h_in * w_in * Split<T>::NB * cs;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      int yy = iy - 1 + i;
+      yy = yy < 0 ? 0 : (yy > h_in - 1 ? h_in - 1 : yy);
+      float row[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[e] = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        int xx = ix - 1 + j;
+        xx = xx < 0 ? 0 : (xx > w_in - 1 ? w_in - 1 : xx);
+        float v[8];
+        pair_load8<T>(base + ((long)yy * w_in + xx) * Split<T>::NB * cs, cs, cg, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) row[e] += wx[j] * v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wy[i] * row[e];
+    }
+    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, acc);
   }
 }
 
@@ -310,7 +367,8 @@ __global__ __launch_bounds__(256) void pair_instnorm_stats_kernel(const uint16_t
 }
 
 // SPADE's de-normalisation on split maps: y = act((x - mean) rstd (1 + gamma) + beta) in fp32 on the sums of the components
-// (norms.py:181-186 + the block's LeakyReLU); x optionally read through the folded x2 nearest upsample
+// (norms.py:181-186 + the block's LeakyReLU); x optionally read through the folded x2 nearest upsample.  gamma == beta ==
+// nullptr: y = act((x - mean) rstd), the eval-mode BatchNorm of the SPADE mask decoder's projection convs (masker.py:96-140)
 template <typename T>
 __global__ void pair_spade_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
                                         const float* __restrict__ rstd, const uint16_t* __restrict__ gamma,
@@ -327,8 +385,13 @@ __global__ void pair_spade_apply_kernel(const uint16_t* __restrict__ x, const fl
     const long xpix = ups ? (n * (h >> 1) + (yy >> 1)) * (long)(w >> 1) + (xx >> 1) : pix;
     float xv[8], gv[8], bv[8], o[8];
     pair_load8<T>(x + xpix * Split<T>::NB * cs, cs, cg, xv);
-    pair_load8<T>(gamma + pix * Split<T>::NB * cs, cs, cg, gv);
-    pair_load8<T>(beta + pix * Split<T>::NB * cs, cs, cg, bv);
+    if (gamma) {
+      pair_load8<T>(gamma + pix * Split<T>::NB * cs, cs, cg, gv);
+      pair_load8<T>(beta + pix * Split<T>::NB * cs, cs, cg, bv);
+    } else {                     // a plain normalisation (+ activation): eval-mode BatchNorm behind a split-precision conv
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = bv[e] = 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int ch = cg * 8 + e;
@@ -340,6 +403,99 @@ __global__ void pair_spade_apply_kernel(const uint16_t* __restrict__ x, const fl
       o[e] = v;
     }
     pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, o);
+  }
+}
+
+// Conditioning map of the SPADE mask decoder on split maps (OmniGenerator.make_m_cond, generator.py:196-230, in the
+// reference's fp32 arithmetic): per-image min / max of the depth map ...
+template <typename T>
+__global__ __launch_bounds__(256) void pair_minmax_c0_kernel(const uint16_t* __restrict__ d, float* __restrict__ mm, int hw) {
+  __shared__ float smin[256], smax[256];
+  const int n = blockIdx.x;
+  const uint16_t* base = d + (size_t)n * hw * Split<T>::NB * 8;
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    float v[8];
+    pair_load8<T>(base + (size_t)p * Split<T>::NB * 8, 8, 0, v);
+    lo = fminf(lo, v[0]);
+    hi = fmaxf(hi, v[0]);
+  }
+  smin[threadIdx.x] = lo;
+  smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + st]);
+      smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    mm[2 * n] = smin[0];
+    mm[2 * n + 1] = smax[0];
+  }
+}
+
+// ... then cat[normalize(d), softmax(s, dim = 1), bilinear(x -> (h, w), align_corners = True)] per pixel, every term in fp32
+constexpr int PAIR_COND_MAX_C = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void pair_make_m_cond_kernel(const uint16_t* __restrict__ d, const uint16_t* __restrict__ seg,
+                                                               const float* __restrict__ x, const float* __restrict__ mm,
+                                                               uint16_t* __restrict__ cond, int h, int w, int sc, int scs, int xh,
+                                                               int xw, int with_x, int ccs, float sy, float sx, long total) {
+  const long hw = (long)h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    float o[PAIR_COND_MAX_C];
+#pragma unroll
+    for (int c = 0; c < PAIR_COND_MAX_C; ++c) o[c] = 0.f;
+    float v[8];
+    pair_load8<T>(d + i * Split<T>::NB * 8, 8, 0, v);
+    const float dmin = mm[2 * n], dmax = mm[2 * n + 1];
+    o[0] = __fdiv_rn(v[0] - dmin, dmax - dmin);            // tutils.normalize: (t - min) / max(t - min)
+    float sv[PAIR_COND_MAX_C];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int g = 0; g < PAIR_COND_MAX_C / 8; ++g)
+      if (g * 8 < sc) {
+        pair_load8<T>(seg + i * Split<T>::NB * scs, scs, g, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sv[g * 8 + e] = v[e];
+          if (g * 8 + e < sc) mx = fmaxf(mx, v[e]);
+        }
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < PAIR_COND_MAX_C; ++c)
+      if (c < sc) {
+        sv[c] = expf(sv[c] - mx);
+        sum += sv[c];
+      }
+#pragma unroll
+    for (int c = 0; c < PAIR_COND_MAX_C - 1; ++c)
+      if (c < sc) o[1 + c] = __fdiv_rn(sv[c], sum);
+    if (with_x) {
+      const int oy = (int)(p / w), ox = (int)(p - (long)oy * w);
+      float fy = (float)oy * sy, fx = (float)ox * sx;
+      asm volatile("" : "+v"(fy), "+v"(fx));      // the rounded products, as torch forms them: no fma with the subtraction below
+      int y0 = (int)fy, x0 = (int)fx;
+      y0 = y0 < xh - 1 ? y0 : xh - 1;
+      x0 = x0 < xw - 1 ? x0 : xw - 1;
+      const int y1 = y0 < xh - 1 ? y0 + 1 : y0, x1 = x0 < xw - 1 ? x0 + 1 : x0;
+      const float ly = fy - y0, lx = fx - x0;
+      for (int c = 0; c < 3; ++c) {
+        const float* xb = x + (n * 3 + c) * (long)xh * xw;
+        const float val = (1.f - ly) * ((1.f - lx) * xb[(long)y0 * xw + x0] + lx * xb[(long)y0 * xw + x1]) +
+                          ly * ((1.f - lx) * xb[(long)y1 * xw + x0] + lx * xb[(long)y1 * xw + x1]);
+#pragma unroll
+        for (int k = 0; k < PAIR_COND_MAX_C; ++k)           // (a register array takes compile-time indices)
+          if (k == 1 + sc + c) o[k] = val;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < PAIR_COND_MAX_C / 8; ++g)
+      if (g * 8 < ccs) pair_store8<T>(cond + i * Split<T>::NB * ccs, ccs, g, o + g * 8);
   }
 }
 
@@ -481,15 +637,54 @@ extern "C" int cgan_pair_instnorm_stats(const void* x3, float* mean, float* rstd
 extern "C" int cgan_pair_spade_apply(const void* x3, const float* mean, const float* rstd, const void* gamma3, const void* beta3,
                                      void* y3, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t x_upsample,
                                      int32_t act, float act_slope, void* stream) {
-  CGAN_REQUIRE(x3 && mean && rstd && gamma3 && beta3 && y3 && n > 0 && h > 0 && w > 0 && c > 0, "pair_spade_apply: bad arguments");
+  CGAN_REQUIRE(x3 && mean && rstd && y3 && n > 0 && h > 0 && w > 0 && c > 0, "pair_spade_apply: bad arguments");
+  CGAN_REQUIRE((gamma3 == nullptr) == (beta3 == nullptr), "pair_spade_apply: gamma and beta go together");
   PAIR_CHECK_DT("pair_spade_apply");
   CGAN_REQUIRE(!x_upsample || ((h % 2) == 0 && (w % 2) == 0), "pair_spade_apply: x_upsample needs even h / w");
-  CGAN_REQUIRE(act == CGAN_ACT_NONE || act == CGAN_ACT_LRELU, "pair_spade_apply: activation none or LeakyReLU");
+  CGAN_REQUIRE(act == CGAN_ACT_NONE || act == CGAN_ACT_LRELU || act == CGAN_ACT_RELU,
+               "pair_spade_apply: activation none, ReLU or LeakyReLU");
   const int cs = cgan_cs(c);
   const long total = (long)n * h * w * (cs / 8);
   PAIR_DISPATCH(dtype, pair_spade_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3, mean,
                 rstd, (const uint16_t*)gamma3, (const uint16_t*)beta3, (uint16_t*)y3, h, w, c, cs, x_upsample ? 1 : 0, act, act_slope,
                 total);
   CGAN_CHECK_LAUNCH("pair_spade_apply");
+  return CGAN_OK;
+}
+
+extern "C" size_t cgan_pair_make_m_cond_workspace_bytes(int32_t n) { return n > 0 ? (size_t)n * 2 * sizeof(float) : 0; }
+
+extern "C" int cgan_pair_make_m_cond(const void* depth3, const void* seg3, const float* x_nchw, void* cond3, int32_t dtype,
+                                     int32_t n, int32_t h, int32_t w, int32_t seg_c, int32_t x_h, int32_t x_w, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  CGAN_REQUIRE(depth3 && seg3 && cond3 && workspace, "pair_make_m_cond: null pointer");
+  PAIR_CHECK_DT("pair_make_m_cond");
+  CGAN_REQUIRE(n > 0 && h > 0 && w > 0 && seg_c > 0, "pair_make_m_cond: bad shape");
+  CGAN_REQUIRE((long)h * w < (1l << 31), "pair_make_m_cond: map too large");
+  CGAN_REQUIRE(!x_nchw || (x_h > 0 && x_w > 0), "pair_make_m_cond: bad x shape");
+  const int cond_c = 1 + seg_c + (x_nchw ? 3 : 0);
+  CGAN_REQUIRE(cgan_cs(cond_c) <= PAIR_COND_MAX_C, "pair_make_m_cond: at most %d conditioning channels", PAIR_COND_MAX_C);
+  CGAN_REQUIRE(workspace_bytes >= cgan_pair_make_m_cond_workspace_bytes(n), "pair_make_m_cond: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const float sy = (x_nchw && h > 1) ? (float)(x_h - 1) / (float)(h - 1) : 0.f;
+  const float sx = (x_nchw && w > 1) ? (float)(x_w - 1) / (float)(w - 1) : 0.f;
+  const long total = (long)n * h * w;
+  PAIR_DISPATCH(dtype, pair_minmax_c0_kernel, dim3(n), dim3(256), 0, s, (const uint16_t*)depth3, (float*)workspace, h * w);
+  PAIR_DISPATCH(dtype, pair_make_m_cond_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t*)depth3,
+                (const uint16_t*)seg3, x_nchw, (const float*)workspace, (uint16_t*)cond3, h, w, seg_c, cgan_cs(seg_c), x_h, x_w,
+                x_nchw ? 1 : 0, cgan_cs(cond_c), sy, sx, total);
+  CGAN_CHECK_LAUNCH("pair_make_m_cond");
+  return CGAN_OK;
+}
+
+extern "C" int cgan_pair_resize_bicubic(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                                        int32_t h_out, int32_t w_out, void* stream) {
+  CGAN_REQUIRE(x3 && y3 && n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "pair_resize_bicubic: bad arguments");
+  PAIR_CHECK_DT("pair_resize_bicubic");
+  const int cs = cgan_cs(c);
+  const long total = (long)n * h_out * w_out * (cs / 8);
+  PAIR_DISPATCH(dtype, pair_resize_bicubic_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3,
+                (uint16_t*)y3, h_in, w_in, h_out, w_out, cs, (float)h_in / (float)h_out, (float)w_in / (float)w_out, total);
+  CGAN_CHECK_LAUNCH("pair_resize_bicubic");
   return CGAN_OK;
 }

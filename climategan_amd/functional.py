@@ -61,7 +61,7 @@ def to_nchw(y: ops.NHWC, paste_x=None, paste_m=None) -> torch.Tensor:
 def from_nchw(x, dtype, cs=None, mask=None) -> ops.NHWC:
     """16-bit NHWC map of an NCHW tensor (optionally times (1 - mask)); differentiable w.r.t. ``x``.  An ``ops.NHWC``
     argument is handed through."""
-    if isinstance(x, ops.NHWC):
+    if isinstance(x, (ops.NHWC, ops.PairMap)):
         return x
     if torch.is_grad_enabled() and x.requires_grad:
         from .autograd import FromNchwFn

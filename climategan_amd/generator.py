@@ -141,12 +141,10 @@ class OmniGenerator(nn.Module):
         return self
 
     def _pair_unsupported(self):
-        """Why this generator cannot run the split-precision Masker (None: it can).  Only the ResNet encoder, the DADA depth
-        decoder, the DeepLab segmentation decoder and the plain mask decoder carry pair maps."""
+        """Why this generator cannot run the split-precision Masker (None: it can).  The ResNet encoder, the DADA depth
+        decoder, the DeepLab segmentation decoder and both mask decoders (plain; SPADE since round 5) carry pair maps."""
         if self.encoder is not None and not hasattr(self.encoder, "pair_precision"):
             return "the encoder has no pair-map path"
-        if "m" in self.decoders and self.opts.gen.m.use_spade:
-            return "the SPADE mask decoder (gen.m.use_spade) has no pair-map path"
         return None
 
     def train(self, mode=True):
@@ -169,7 +167,7 @@ class OmniGenerator(nn.Module):
     def float(self):
         """The reference's fp32 inference (apply_events without --half).  On an eval-mode generator whose Masker can run on
         pair maps this selects the split-precision mode ("split24", see set_compute_dtype; ``train()``, ``half()`` or
-        ``bfloat16()`` leave it again).  Anywhere else -- training mode, the SPADE mask decoder, another encoder -- it is a
+        ``bfloat16()`` leave it again).  Anywhere else -- training mode, an encoder without a split-precision path -- it is a
         no-op that keeps the 16-bit compute type, as before round 4 (the reference trains in fp32; this package trains in
         bf16 with fp32 masters): nothing is half-switched and nothing that ran before starts to raise."""
         if not self.training and self._pair_unsupported() is None:

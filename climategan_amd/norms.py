@@ -425,9 +425,16 @@ class SPADE(nn.Module):
         nearest-resized conditioning map, mlp_shared (+ ReLU), mlp_gamma, mlp_beta as split-precision convolutions, the
         de-normalisation in fp32 on the sums of the components (cgan_pair_spade_apply)."""
         _grad_guard(self)
-        if self.param_free_norm_type != "instance" or not isinstance(cond, ops.PairMap):
-            raise NotImplementedError("SPADE on split maps: instance param-free norm and a split conditioning map only")
-        if stats is None:
+        if not isinstance(cond, ops.PairMap):
+            raise NotImplementedError("SPADE on split maps: the conditioning map must be a split map too")
+        if self.param_free_norm_type == "batch":
+            # nn.BatchNorm2d(affine=False) of the SPADE mask decoder (norms.py:152-153): split precision is an inference mode,
+            # eval normalises with the running statistics
+            if self.param_free_norm.training:
+                raise NotImplementedError("SPADE on split maps: a batch param-free norm in training mode (split precision is "
+                                          "an inference mode)")
+            stats = ops.bn_eval_stats(self.param_free_norm, x.n)
+        elif stats is None:
             stats = ops.instnorm_stats(x, eps=self.param_free_norm.eps)
         h, w = (x.h * 2, x.w * 2) if x_upsample else (x.h, x.w)
         seg = cond if (cond.h, cond.w) == (h, w) else ops.resize_nearest(cond, (h, w))

@@ -419,6 +419,12 @@ def resize_bicubic(x: NHWC, size: Tuple[int, int]) -> NHWC:
     """F.interpolate(mode="bicubic", align_corners=False) (reference depth.py:143-149)."""
     _need_cuda(x.t)
     h, w = int(size[0]), int(size[1])
+    if isinstance(x, PairMap):
+        _plain_pair(x, "resize_bicubic")
+        y = torch.empty((x.n, h, w, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        _lib.check(_lib.load().cgan_pair_resize_bicubic(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, h, w, _stream()),
+                   "cgan_pair_resize_bicubic")
+        return PairMap(y, x.c)
     y = torch.empty((x.n, h, w, cs8(x.c)), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_resize_bicubic_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, h, w, _stream()),
@@ -641,8 +647,26 @@ def make_m_cond_bwd(dcond: NHWC, d: NHWC, s: NHWC, with_x: bool):
 
 
 def make_m_cond(d: NHWC, s: NHWC, x: Optional[torch.Tensor]) -> NHWC:
-    """cat[normalize(d), softmax(s), bilinear(x)] (reference generator.py:196-230) as an NHWC conditioning map."""
+    """cat[normalize(d), softmax(s), bilinear(x)] (reference generator.py:196-230) as an NHWC conditioning map; split maps in,
+    split map out (every term in fp32: cgan_pair_make_m_cond)."""
     _need_cuda(d.t, s.t, x)
+    if isinstance(d, PairMap) or isinstance(s, PairMap):
+        if not (isinstance(d, PairMap) and isinstance(s, PairMap)) or d.t.dtype != s.t.dtype:
+            raise RuntimeError("make_m_cond: depth and segmentation must both be split maps of one type")
+        _plain_pair(d, "make_m_cond")
+        _plain_pair(s, "make_m_cond")
+        if (d.h, d.w, d.n) != (s.h, s.w, s.n) or d.c != 1:
+            raise RuntimeError("make_m_cond: d and s must share batch and spatial size, d with one channel")
+        cond_c = 1 + s.c + (3 if x is not None else 0)
+        xx = x.contiguous().float() if x is not None else None
+        lib = _lib.load()
+        nbytes = lib.cgan_pair_make_m_cond_workspace_bytes(d.n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=d.t.device)
+        cond = torch.empty((d.n, d.h, d.w, d.nb * cs8(cond_c)), dtype=d.t.dtype, device=d.t.device)
+        _lib.check(lib.cgan_pair_make_m_cond(_ptr(d.t), _ptr(s.t), _ptr(xx), _ptr(cond), d.dtype_id, d.n, d.h, d.w, s.c,
+                                             xx.shape[-2] if xx is not None else 0, xx.shape[-1] if xx is not None else 0,
+                                             _ptr(ws), nbytes, _stream()), "cgan_pair_make_m_cond")
+        return PairMap(cond, cond_c)
     if (d.h, d.w, d.n) != (s.h, s.w, s.n) or d.c != 1:
         raise RuntimeError("make_m_cond: d and s must share batch and spatial size, d with one channel")
     cond_c = 1 + s.c + (3 if x is not None else 0)
@@ -1149,6 +1173,15 @@ def instnorm_stats(x: NHWC, eps: float = 1e-5):
 @_batch_chunked("x", "mean", "rstd", "residual")
 def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2, residual: NHWC = None) -> NHWC:
     """y = act((x - mean) * rstd [+ residual])."""
+    if isinstance(x, PairMap):          # split-precision inference: fp32 on the sums of the components (cgan_pair_spade_apply)
+        if residual is not None:
+            raise RuntimeError("norm_act_apply: no residual on a split map")
+        _plain_pair(x, "norm_act_apply")
+        _need_cuda(mean, rstd)
+        y = torch.empty_like(x.t)
+        _lib.check(_lib.load().cgan_pair_spade_apply(_ptr(x.t), _ptr(mean), _ptr(rstd), None, None, _ptr(y), x.dtype_id, x.n, x.h,
+                                                     x.w, x.c, 0, int(act), float(slope), _stream()), "cgan_pair_spade_apply")
+        return PairMap(y, x.c)
     _need_cuda(x.t, mean, rstd)
     d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, 0.0)
     y = torch.empty_like(x.t)

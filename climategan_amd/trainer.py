@@ -933,14 +933,17 @@ class Trainer:
                 depth_nhwc, z_depth = self.G.decoders["d"].forward_nhwc(z)
             with timed("segmentation"):
                 seg_nhwc = self.G.decoders["s"].forward_nhwc(z, z_depth)
+            cond = None
             if isinstance(seg_nhwc, ops.PairMap):
-                # split-precision Masker (G.set_compute_dtype("pair16")): the mask decoder stays on the pair maps (the mask
-                # leaves as fp32); the conditioning map and the event kernels read the maps rounded once to 16 bit
+                # split-precision Masker (G.set_compute_dtype("split24" | "pair16")): the mask decoder stays on the split maps
+                # (the mask leaves as fp32), its conditioning map included (SPADE mask decoder: built from the split depth /
+                # segmentation maps in fp32); the event kernels read the maps rounded once to 16 bit
+                if self.opts.gen.m.use_spade:
+                    cond = self.G.make_m_cond(depth_nhwc, seg_nhwc, x)                                        # :285
                 depth_nhwc, seg_nhwc = ops.pair_to_nhwc(depth_nhwc), ops.pair_to_nhwc(seg_nhwc)
+            elif self.opts.gen.m.use_spade:
+                cond = self.G.make_m_cond(depth_nhwc, seg_nhwc, x)                                            # :285
             with timed("mask"):
-                cond = self.G.make_m_cond(depth_nhwc, seg_nhwc, x) if self.opts.gen.m.use_spade else None   # :285
-                if cond is not None and isinstance(z[0], ops.PairMap):
-                    raise NotImplementedError("pair16 inference with the SPADE mask decoder (gen.m.use_spade) is not built")
                 mask = self.G.mask(z=z, cond=cond, z_depth=z_depth)
                 mask = mask if isinstance(z[0], ops.PairMap) else mask.to(x.dtype)     # pair16: the fp32 mask is binarised
 

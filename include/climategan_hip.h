@@ -681,12 +681,22 @@ int cgan_pair_expand_weight(const float* w_oihw, const float* sigma, float* w3, 
  * the three convolutions run as cgan_conv2d_nhwc_fwd_pair and these two kernels do the rest in fp32 on the sums of the components:
  *  pair_instnorm_stats  mean / rstd [n][round_up(c,8)] fp32 of F.instance_norm (biased variance), two fp64 passes
  *  pair_spade_apply     y = act((x - mean) rstd (1 + gamma) + beta), gamma / beta = the mlp_gamma / mlp_beta conv outputs (bias
- *                       included), x optionally read through the folded x2 nearest upsample; act none or LeakyReLU */
+ *                       included), x optionally read through the folded x2 nearest upsample; act none, ReLU or LeakyReLU.
+ *                       gamma3 == beta3 == NULL: y = act((x - mean) rstd) -- the eval-mode BatchNorm + LeakyReLU behind the SPADE
+ *                       mask decoder's spectral-norm projection convs (climategan/masker.py:96-140, blocks.py:96-150)
+ *  pair_make_m_cond     the SPADE mask decoder's conditioning map (OmniGenerator.make_m_cond, climategan/generator.py:196-230;
+ *                       tutils.normalize :567-576) from the split depth / segmentation maps in the reference's fp32 arithmetic:
+ *                       cat[(d - min) / max(d - min) per image, softmax(s, dim 1), bilinear(x, align_corners = True)] as a split
+ *                       map of 1 + seg_c (+ 3 with x_nchw) channels; workspace = 2 floats per image */
 int cgan_pair_instnorm_stats(const void* x3, float* mean, float* rstd, int32_t dtype, int32_t n, int32_t c, int64_t hw, float eps,
                              void* stream);
 int cgan_pair_spade_apply(const void* x3, const float* mean, const float* rstd, const void* gamma3, const void* beta3, void* y3,
                           int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t x_upsample, int32_t act,
                           float act_slope, void* stream);
+size_t cgan_pair_make_m_cond_workspace_bytes(int32_t n);
+int cgan_pair_make_m_cond(const void* depth3, const void* seg3, const float* x_nchw, void* cond3, int32_t dtype, int32_t n,
+                          int32_t h, int32_t w, int32_t seg_c, int32_t x_h, int32_t x_w, void* workspace, size_t workspace_bytes,
+                          void* stream);
 int cgan_pair_from_nchw(const float* x, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 int cgan_pair_to_nchw(const void* x3, float* y, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, int32_t sigmoid,
                       void* stream);
@@ -695,6 +705,10 @@ int cgan_pair_maxpool3x3s2(const void* x3, void* y3, int32_t dtype, int32_t n, i
 int cgan_pair_resize_bilinear(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
                               int32_t h_out, int32_t w_out, int32_t align_corners, void* stream);
 int cgan_pair_resize_nearest(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
+                             int32_t h_out, int32_t w_out, void* stream);
+/* F.interpolate(mode="bicubic", align_corners=False) on a split map in fp32: the depth decoder's resize to the MiDaS size
+ * (climategan/depth.py:143-149) when the depth map feeds the SPADE mask decoder's conditioning in the split-precision mode */
+int cgan_pair_resize_bicubic(const void* x3, void* y3, int32_t dtype, int32_t n, int32_t c, int32_t h_in, int32_t w_in,
                              int32_t h_out, int32_t w_out, void* stream);
 int cgan_pair_mul(const void* a3, const void* b3, void* y3, int32_t dtype, int64_t npix, int32_t c, void* stream);
 int cgan_pair_copy_channels(const void* src3, void* dst3, int32_t dtype, int64_t npix, int32_t c, int32_t c_dst, int32_t c_off,

@@ -348,3 +348,36 @@ def test_wildfire_blur_short_kernels_match_the_one_output_per_thread_form(ks):
     finally:
         lib.cgan_debug_set_wf_blur(ctypes.c_int(0))
     assert torch.equal(out, ref)
+
+
+def test_infer_all_spade_mask_decoder_split_precision():
+    """gen.m.use_spade through Trainer.infer_all in the split-precision mode (round 5): the conditioning map is built from the
+    split depth / segmentation maps BEFORE they are rounded for the event kernels, the SPADE mask decoder runs on split maps; the
+    binary mask is the one ``masker_forward`` gives on the same input (spectral norm frozen so that two calls see one operator),
+    and it is the 16-bit run's mask away from the threshold."""
+    from climategan_amd.config import default_opts
+    from climategan_amd.trainer import Trainer
+
+    torch.manual_seed(5)
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m", "p"]
+    opts.gen.m.use_spade = True
+    opts.gen.p.latent_dim, opts.gen.p.spade_n_up = 32, 4
+    T = Trainer(opts, device="cuda").setup(inference=True)
+    T.G.eval()
+    T.G.freeze_spectral_norm()
+    x = (torch.rand(2, 3, 128, 160, device="cuda") * 2 - 1)
+    with torch.no_grad():
+        T.G.half()
+        T.G.masker_forward(x)                                  # the frozen operators are taken at this call
+        m16 = T.G.masker_forward(x)["m"]
+        T.G.float()
+        assert T.G.pair_precision
+        m32 = T.G.masker_forward(x)["m"]
+        out = T.infer_all(x, numpy=True, bin_value=0.5, ignore_event={"wildfire", "smog"}, return_masks=True)
+    assert m32.dtype == torch.float32 and np.abs((m32 - m16).cpu().numpy()).max() < 5e-2
+    want = (m32 > 0.5).squeeze(1).cpu().numpy()
+    got = out["mask"].reshape(want.shape) > 0
+    assert np.array_equal(got, want)
+    sure = (m32 - 0.5).abs().squeeze(1).cpu().numpy() > 2e-2
+    assert np.array_equal((m16 > 0.5).squeeze(1).cpu().numpy()[sure], want[sure])

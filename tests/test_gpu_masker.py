@@ -117,3 +117,45 @@ def test_mask_spade_decoder_matches_reference_golden():
         assert err.max() <= 3e-2 * scale and err.mean() <= 4e-3 * scale, (k, err.max(), err.mean(), scale)
     sure = np.abs(gold["m"] - 0.5) > 0.02
     assert sure.mean() > 0.3 and np.array_equal((got["m"] > 0.5)[sure], (gold["m"] > 0.5)[sure])
+
+
+@pytest.mark.parametrize("mode", ["split24", "pair16"])
+def test_mask_spade_decoder_split_precision_matches_reference_fp32(mode):
+    """Round 5: the SPADE mask decoder in the split-precision inference mode (``G.float()`` = "split24"): the conditioning map
+    built in fp32 from the split depth / segmentation maps (cgan_pair_make_m_cond), spectral_batch projections as
+    split-precision convs + eval BatchNorm in fp32, SPADE blocks unfused with the running statistics, against the reference's
+    fp32 outputs -- the 16-bit path above is held to 3e-2 of the logits' scale, this one to 1e-4."""
+    from climategan_amd import ops
+    from climategan_amd.config import default_opts
+    from climategan_amd.generator import create_generator
+    from helpers import maskspade_state_dict
+
+    name = "maskspade_small"
+    case = golden_cases()[name]
+    gold = load_golden(name)
+    opts = default_opts()
+    opts.tasks = ["d", "s", "m"]
+    opts.gen.m.use_spade = True
+    G = create_generator(opts, device="cuda")
+    G.load_state_dict(maskspade_state_dict(case), strict=True)
+    G.eval()
+    G.set_compute_dtype(mode)
+    x = t(case_inputs(name, case)["x"]).cuda()
+    with torch.no_grad():
+        z = G.encode(x)
+        d, z_depth = G.decoders["d"].forward_nhwc(z)
+        s = G.decoders["s"].forward_nhwc(z, z_depth)
+        cond = G.make_m_cond(d, s, x)
+        assert isinstance(cond, ops.PairMap)
+        m = G.mask(z=z, cond=cond, z_depth=z_depth)
+        logits2 = G.mask(z=z, cond=cond, z_depth=z_depth, sigmoid=False)
+    got = {"cond": ops.nhwc_to_nchw(cond).cpu().numpy(), "m": m.cpu().numpy(), "logits2": logits2.cpu().numpy()}
+    err_c = np.abs(got["cond"] - gold["cond"])
+    print("cond max err", err_c.max(), "depth channel", err_c[:, :1].max())
+    assert err_c[:, 1:].max() <= 5e-5 and err_c[:, :1].max() <= 2e-4      # normalize(d) divides by the map's narrow range
+    for k in ("m", "logits2"):
+        scale = max(np.abs(gold[k]).max(), 1e-6)
+        err = np.abs(got[k] - gold[k])
+        print(k, "max err", err.max(), "scale", scale)
+        assert err.max() <= 2e-5 * max(scale, 1.0), (k, err.max(), scale)      # measured 2.6e-6
+    assert np.array_equal(got["m"] > 0.5, gold["m"] > 0.5) or (np.abs(gold["m"] - 0.5)[(got["m"] > 0.5) != (gold["m"] > 0.5)] < 1e-5).all()

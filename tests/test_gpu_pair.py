@@ -100,3 +100,49 @@ def test_glue_ops_match_torch_fp32(dt):
     assert cat.c == 61 and torch.equal(ops.nhwc_to_nchw(cat), torch.cat([xq, ops.nhwc_to_nchw(q), ops.nhwc_to_nchw(r)], 1))
     with pytest.raises(RuntimeError):
         ops.conv2d(p, ops.pack_conv_weight(_rand((8, 24, 1, 1), 10), None, dt))       # an ordinary operator on a split map
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_mask_decoder_glue_on_split_maps(dt):
+    """Round 5, the SPADE mask decoder's glue in the split-precision mode against torch's fp32 ops on the same values: the
+    bicubic resize of the depth map (depth.py:144-149), make_m_cond (generator.py:196-230: normalize | softmax | bilinear x with
+    align_corners) and the plain normalise + LeakyReLU of an eval-mode BatchNorm (cgan_pair_spade_apply without gamma / beta)."""
+    from climategan_amd import ops
+
+    d = _rand((2, 1, 20, 24), 21, 2.0)
+    pd = ops.pair_from_nchw(d, dt)
+    d = ops.nhwc_to_nchw(pd)                               # the values the split map carries
+    up = ops.resize_bicubic(pd, (48, 40))
+    assert isinstance(up, ops.PairMap) and (up.h, up.w) == (48, 40)
+    ref = F.interpolate(d, size=(48, 40), mode="bicubic", align_corners=False)
+    assert (ops.nhwc_to_nchw(up) - ref).abs().max().item() <= 3e-6
+
+    s = _rand((2, 11, 20, 24), 22, 3.0)
+    ps = ops.pair_from_nchw(s, dt)
+    s = ops.nhwc_to_nchw(ps)
+    x = _rand((2, 3, 64, 80), 23).clamp(-1, 1)
+    for xx in (x, None):
+        cond = ops.make_m_cond(pd, ps, xx)
+        assert isinstance(cond, ops.PairMap) and cond.c == (15 if xx is not None else 12)
+        mn = d.reshape(2, -1).min(1)[0].reshape(2, 1, 1, 1)
+        t0 = d - mn
+        cats = [t0 / t0.reshape(2, -1).max(1)[0].reshape(2, 1, 1, 1), torch.softmax(s, dim=1)]
+        if xx is not None:
+            # (torch's CPU kernel: its HIP bilinear kernel rounds the source index differently, 6e-6 on these values; the
+            # reference's golden runs are CPU runs)
+            cats.append(F.interpolate(xx.cpu(), (20, 24), mode="bilinear", align_corners=True).cuda())
+        ref = torch.cat(cats, 1)
+        got = ops.nhwc_to_nchw(cond)
+        assert (got - ref).abs().max().item() <= 1e-6, (got - ref).abs().max().item()
+        assert bool((cond.t.view(2, 20, 24, cond.nb, -1)[..., cond.c:] == 0).all())     # pad channels stay zero
+    with pytest.raises(RuntimeError, match="both be split maps"):
+        ops.make_m_cond(ops.pair_to_nhwc(pd), ps, None)
+
+    y = _rand((2, 19, 12, 16), 24, 2.0)
+    py = ops.pair_from_nchw(y, dt)
+    y = ops.nhwc_to_nchw(py)
+    mean = _rand((2, 24), 25)
+    rstd = _rand((2, 24), 26).abs() + 0.5
+    out = ops.norm_act_apply(py, mean, rstd, act=ops.ACT_LRELU, slope=0.2)
+    ref = F.leaky_relu((y - mean[:, :19, None, None]) * rstd[:, :19, None, None], 0.2)
+    assert isinstance(out, ops.PairMap) and (ops.nhwc_to_nchw(out) - ref).abs().max().item() <= 2e-6

@@ -230,6 +230,10 @@ def test_float_cast_is_guarded_and_reversible():
     G2 = create_generator(opts2, no_init=True)
     before = G2.compute_dtype
     G2.eval().float()
+    assert G2.pair_precision                                  # round 5: the SPADE mask decoder runs on split maps too
+    G2.set_compute_dtype(before)
+    G2.encoder = torch.nn.Identity()                          # an encoder without a split-precision path
+    G2.eval().float()
     assert not G2.pair_precision and G2.compute_dtype == before                   # unsupported: keeps the 16-bit type
     with pytest.raises(NotImplementedError):
         G2.set_compute_dtype("split24")
