@@ -111,6 +111,7 @@ struct BnEpilogue {
   long long* num_batches_tracked;
   float momentum;
   int c;
+  CGAN_DEV_ONLY(int jitter_ppm; unsigned jitter_seed;)     // dev: the sensitivity experiment of DESIGN 4.13
 };
 
 // one wave per (n, c): lanes stride over the chunk partials, then a 6-step shuffle tree of Chan merges
@@ -162,7 +163,15 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     acc = chan_merge(acc, b);
   }
   if (lane == 0) {
-    const float mu = acc.mean, rs = rsqrtf(acc.m2 / (float)hw + eps);
+    const float mu = acc.mean;
+    float rs = rsqrtf(acc.m2 / (float)hw + eps);
+#ifdef CGAN_DEV
+    if (bn.mean_out && bn.jitter_ppm) {       // batch rstd times (1 + u ppm), u uniform in [-1, 1] per (layer call, group, channel)
+      unsigned hsh = (unsigned)idx * 2654435761u ^ bn.jitter_seed * 40503u ^ (unsigned)(size_t)bn.mean_out;
+      hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+      rs *= 1.f + (float)bn.jitter_ppm * 1e-6f * ((float)(hsh & 0xffff) / 32767.5f - 1.f);
+    }
+#endif
     mean[idx] = mu;
     rstd[idx] = rs;
     if (bn.mean_out) {
@@ -272,6 +281,14 @@ int check(const CganNormStatsDesc* d) {
 
 }  // namespace
 
+#ifdef CGAN_DEV
+// dev: perturb every training-mode BatchNorm's batch rstd by up to +-ppm (uniform, hashed per layer call / group / channel):
+// how far do the step's gradients move for an error of a given size in the statistics
+static int g_bn_jitter_ppm = 0;
+static unsigned g_bn_jitter_seed = 0;
+extern "C" void cgan_debug_set_bn_jitter(int ppm, int seed) { g_bn_jitter_ppm = ppm; g_bn_jitter_seed = (unsigned)seed; }
+#endif
+
 extern "C" size_t cgan_instnorm_stats_workspace_bytes(const CganNormStatsDesc* d) {
   if (check(d) != CGAN_OK) return 0;
   int chunks = ceil_div(d->hw, 64);  // worst case of pix_per_block()
@@ -330,6 +347,7 @@ extern "C" int cgan_batchnorm_train_stats(const void* x, const float* gamma, con
   CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_stats: running stats go together");
   BnEpilogue bn = {gamma, beta, running_mean, running_var, mean_out, rstd_out, (long long*)num_batches_tracked, momentum,
                    d->c};
+  CGAN_DEV_ONLY(bn.jitter_ppm = g_bn_jitter_ppm; bn.jitter_seed = g_bn_jitter_seed;)
   return stats_impl(x, batch_mean, batch_rstd, d, workspace, workspace_bytes, stream, bn);
 }
 
@@ -350,6 +368,7 @@ extern "C" int cgan_batchnorm_train_stats_from_partials(const float* partial, in
   CGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_stats_from_partials: running stats go together");
   const int cs = cgan_cs(d->c);
   BnEpilogue bn = {gamma, beta, running_mean, running_var, mean_out, rstd_out, (long long*)num_batches_tracked, momentum, d->c};
+  CGAN_DEV_ONLY(bn.jitter_ppm = g_bn_jitter_ppm; bn.jitter_seed = g_bn_jitter_seed;)
   const int total = d->n > 1 ? cs : d->n * cs;
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, (hipStream_t)stream, partial,
                      batch_mean, batch_rstd, d->n, d->hw, cs, d->hw / chunk_pixels, chunk_pixels, d->eps, bn);
