@@ -934,7 +934,7 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
             "ms_per_batch_frozen_spectral_norm": round(frozen / steps * 1e3, 2),
             "images_per_s_fp32_grade": round(world * INFER_BS * n32 / fp32, 2),
             "ms_per_batch_fp32_grade": round(fp32 / n32 * 1e3, 2),
-            "fp32_grade_mode": "G.float() = set_compute_dtype('split24'): split-precision Masker (DESIGN 4.8), %d timed batches" % n32,
+            "fp32_grade_mode": "G.float() = set_compute_dtype('split24'): split-precision Masker AND Painter (DESIGN 4.8, 0 item 8), %d timed batches" % n32,
             "steps": steps, "warmup": warmup, "roofline": roof}
 
 

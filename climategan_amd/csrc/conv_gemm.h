@@ -33,6 +33,7 @@ struct ConvGemmExtArgs {
   int ksplit;      // > 1: split-K, blockIdx.y = K slice of ks_per k-steps, fp32 partials to ws [slice][pixel][cout_s]
   int ks_per;
   float* ws;
+  int pair;        // 1: split-precision output (cgan_conv2d_nhwc_fwd_pair): y / the residual are split maps of Split<T>::NB blocks
   ConvGemmCls cls[4];
 };
 bool conv_gemm_ext_shape_ok(const ConvGemmArgs& a);
@@ -40,6 +41,8 @@ int conv_gemm_splitk_plan(const ConvGemmArgs& a);        // K slices for a grid 
 size_t conv_gemm_splitk_workspace_bytes(const ConvGemmArgs& a, int ksplit);
 int conv_gemm_splitk_launch(const ConvGemmArgs& a, int ksplit, float* ws, int dtype, hipStream_t s);
 int conv_gemm_cls_launch(const ConvGemmArgs& a, int cls_s, const ConvGemmCls* cls, int dtype, hipStream_t s);
+// a plain (one class, one K range) launch whose epilogue stores the fp32 result as its 16-bit components (split-precision maps)
+int conv_gemm_pair_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
 
 // true for convs whose channel counts make the 128x256 (cout x pixel) LDS tiling worthwhile
 bool conv_gemm_applicable(const CganConvDesc* d);

@@ -213,6 +213,58 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
           v[4 + r] += b1[r];
         }
       }
+      if (q.pair) {
+        // split-precision epilogue (as conv_mfma_kernel's): residual = the sum of its components, activation in fp32, then
+        // v -> c0 = round16(v), c1 = round16(v - c0), ... stored as the channel blocks the next conv multiplies (Split<T>)
+        constexpr int NB = Split<T>::NB, NC = Split<T>::NC;
+        if (p.has_res) {
+          size_t rbase = (size_t)pix;
+          if (p.res_ups) {
+            const int ox = pix % p.w_out;
+            const int r = pix / p.w_out;
+            const int oy = r % p.h_out;
+            const int nn = r / p.h_out;
+            rbase = ((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1);
+          }
+          const uint16_t* rp = p.res + rbase * p.cout_s * NB + ch;
+          float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = NC - 1; k >= 0; --k) {         // smallest component first
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(rp + k * p.cout_s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float r0, r1;
+              unpack2<T>(rv[e], r0, r1);
+              rs[2 * e] += r0;
+              rs[2 * e + 1] += r1;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += rs[r];
+        }
+        act_apply_n(v, p.act, p.slope);
+        if (p.cout < p.cout_s) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (ch + r >= p.cout) v[r] = 0.f;
+        }
+        u32x4 comp[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            comp[k][e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            float q0, q1;
+            unpack2<T>(comp[k][e], q0, q1);
+            v[2 * e] -= q0;
+            v[2 * e + 1] -= q1;
+          }
+        }
+        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NB + ch;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) *reinterpret_cast<u32x4*>(yp + b * p.cout_s) = comp[Split<T>::xcomp(b)];
+        continue;
+      }
       act_apply_n(v, p.act, p.slope);
       if (p.cout < p.cout_s) {
 #pragma unroll
@@ -368,6 +420,7 @@ int conv_gemm_splitk_launch(const ConvGemmArgs& a, int ksplit, float* ws, int dt
   q.ksplit = ksplit;
   q.ks_per = ceil_div(a.ksteps, ksplit);
   q.ws = ws;
+  q.pair = 0;
   for (int c = 0; c < 4; ++c) q.cls[c] = ConvGemmCls{0, 0, 0, 0, 0};
   int rc = dtype == CGAN_F16 ? launch_any<F16>(q, a.npix, ksplit, s) : launch_any<BF16>(q, a.npix, ksplit, s);
   if (rc != CGAN_OK) return rc;
@@ -389,7 +442,23 @@ int conv_gemm_cls_launch(const ConvGemmArgs& a, int cls_s, const ConvGemmCls* cl
   q.ksplit = 1;
   q.ks_per = 0;
   q.ws = nullptr;
+  q.pair = 0;
   for (int c = 0; c < 4; ++c) q.cls[c] = c < cls_s * cls_s ? cls[c] : ConvGemmCls{0, 0, 0, 0, 0};
   const int grid_pixels = a.n * ceil_div(a.h_out, cls_s) * ceil_div(a.w_out, cls_s);     // the largest class
   return dtype == CGAN_F16 ? launch_any<F16>(q, grid_pixels, cls_s * cls_s, s) : launch_any<BF16>(q, grid_pixels, cls_s * cls_s, s);
+}
+
+// Split-precision forward (cgan_conv2d_nhwc_fwd_pair) on this tiling: ``a`` describes the conv over the NB * round_up(C, 8)
+// storage channels of the split input map; the epilogue takes bias / split residual / activation in fp32 and stores the
+// components.  (Round 4 ran every split conv on the gather kernel: 20 images/s of apply_events in the fp32-grade mode.)
+int conv_gemm_pair_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
+  ConvGemmExtArgs q;
+  q.a = a;
+  q.cls_s = 0;
+  q.ksplit = 1;
+  q.ks_per = 0;
+  q.ws = nullptr;
+  q.pair = 1;
+  for (int c = 0; c < 4; ++c) q.cls[c] = ConvGemmCls{0, 0, 0, 0, 0};
+  return dtype == CGAN_F16 ? launch_any<F16>(q, a.npix, 1, s) : launch_any<BF16>(q, a.npix, 1, s);
 }

@@ -870,7 +870,7 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
   return dispatch_conv(p, d, (hipStream_t)stream, "conv2d_nhwc_fwd");
 }
 
-// Split-precision forward (round 4): see the header.  Always the general gather kernel: one epilogue variant, opt-in mode.
+// Split-precision forward (round 4): see the header.  The general gather kernel, or (round 5) the LDS-tiled GEMM for wide layers.
 extern "C" int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, const float* bias_padded,
                                          const void* residual3, void* y3, const CganConvDesc* d, void* stream) {
   ConvParams p;
@@ -886,6 +886,17 @@ extern "C" int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, 
   p.res = (const uint16_t*)residual3; p.y = (uint16_t*)y3;
   p.pair = 1;
   hipStream_t s = (hipStream_t)stream;
+  // wide layers on the LDS-tiled GEMM (round 5): whole 32-channel k-steps per tap, zero padding, no folded upsample, enough
+  // pixels for its 128 / 256-pixel block tiles; everything else stays on the gather kernel
+  if (g_conv_force == 0 && p.in_zs == 1 && !p.in_ups && p.cin_p == p.cin_s && p.pad >= 0 && p.npix >= 1024 && p.ksteps >= 4) {
+    const ConvGemmArgs a = gemm_args(p);
+    if (conv_gemm_ext_shape_ok(a) && (double)p.npix * p.cout_s * nb < 2147483647.0) {
+      rc = conv_gemm_pair_launch(a, d->dtype, s);
+      if (rc != CGAN_OK) return rc;
+      CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd_pair(gemm)");
+      return CGAN_OK;
+    }
+  }
   if (d->dtype == CGAN_F16) launch<F16>(p, s);
   else launch<BF16>(p, s);
   CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd_pair");

@@ -146,3 +146,56 @@ def test_mask_decoder_glue_on_split_maps(dt):
     out = ops.norm_act_apply(py, mean, rstd, act=ops.ACT_LRELU, slope=0.2)
     ref = F.leaky_relu((y - mean[:, :19, None, None]) * rstd[:, :19, None, None], 0.2)
     assert isinstance(out, ops.PairMap) and (ops.nhwc_to_nchw(out) - ref).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, stride, pad, dil, residual ("same" | "up" | None), act)
+    (2, 24, 28, 64, 64, 3, 1, 1, 1, "same", "relu"),        # a ResNet 3x3
+    (2, 24, 28, 128, 256, 1, 1, 0, 1, "same", "none"),      # bottleneck expansion with the shortcut in the epilogue
+    (2, 24, 28, 64, 32, 3, 1, 2, 2, None, "lrelu"),         # dilated, <= 64 output channels (the 64-cout block tile)
+    (3, 48, 40, 64, 96, 3, 2, 1, 1, None, "none"),          # stride 2
+    (2, 32, 32, 128, 40, 3, 1, 1, 1, "up", "lrelu"),        # pad channels + the residual read through the folded x2 upsample
+    (1, 40, 40, 320, 160, 3, 1, 1, 1, None, "none"),        # a Painter main conv
+])
+def test_split_conv_on_the_gemm_tiling(dt, case):
+    """Round 5: split-precision convs whose storage channel count is a whole number of 32-channel k-steps (and >= 1024 output
+    pixels) run on the LDS-tiled GEMM with the split epilogue (conv_gemm_pair_launch) instead of the gather kernel: same
+    float64 yardstick as above, and agreement with the gather kernel (dev knob) to the same few 1e-7."""
+    from climategan_amd import _lib, ops
+
+    n, h, w, cin, cout, k, stride, pad, dil, res_kind, act = case
+    x = _rand((n, cin, h, w), 13)
+    wt = _rand((cout, cin, k, k), 14, (2.0 / (cin * k * k)) ** 0.5)
+    b = _rand((cout,), 15)
+    p = ops.pair_from_nchw(x, dt)
+    pw = ops.pack_conv_weight(wt, b, dt, pair=True)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    res = None
+    if res_kind:
+        shp = tuple(ref.shape) if res_kind == "same" else (n, cout, ref.shape[2] // 2, ref.shape[3] // 2)
+        res = ops.pair_from_nchw(_rand(shp, 16), dt)
+        r64 = ops.nhwc_to_nchw(res).double()
+        ref = ref + (r64 if res_kind == "same" else F.interpolate(r64, scale_factor=2, mode="nearest"))
+    ref = {"relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "none": lambda v: v}[act](ref)
+    kw = dict(stride=stride, pad=pad, dilation=dil, act={"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act],
+              residual=res, residual_upsample=res_kind == "up")
+    y = ops.conv2d(p, pw, **kw)
+    assert isinstance(y, ops.PairMap) and y.c == cout
+    got = ops.nhwc_to_nchw(y).double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    # (K up to 2880 here: the fp32 accumulation's own rounding, ~ sqrt(K) 6e-8 of the terms' scale, is what is left --
+    # torch's fp32 conv2d of the same operands is as far from float64)
+    f32 = F.conv2d(x, wt, b, stride=stride, padding=pad, dilation=dil).double()
+    f64 = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    floor = (f32 - f64).abs().max().item() / f64.abs().max().item()
+    assert err <= max(4e-6, 3 * floor), (err, floor)
+    assert bool((y.t.view(n, y.h, y.w, y.nb, -1)[..., cout:] == 0).all())          # pad channels of every block stay zero
+    dev = _lib.load_dev()
+    try:
+        dev.cgan_debug_set_conv_kernel(1)                                            # the gather kernel
+        yg = ops.nhwc_to_nchw(ops.conv2d(p, pw, **kw)).double()
+    finally:
+        dev.cgan_debug_set_conv_kernel(0)
+        _lib.use_product()
+    assert (got - yg).abs().max().item() / ref.abs().max().item() <= max(4e-6, 3 * floor)     # (another summation order)
