@@ -916,8 +916,8 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
         roof = mfma_roofline(step, 2, table_path)
         T.overlap_branches = ov
     # the reference's DEFAULT apply_events run is fp32 (--half is opt-in, apply_events.py:465-468): G.float() = the
-    # split-precision Masker (bf16 triples through the same MFMA kernels, 6x the multiply work, fp32-grade flood mask);
-    # the Painter and the event kernels stay 16-bit
+    # split-precision Masker and Painter (bf16 triples through the same MFMA kernels, 6x the multiply work, fp32-grade flood
+    # mask and flood image); the event kernels read the maps rounded once to 16 bit
     T.G.eval().float()
     assert T.G.pair_precision
 
