@@ -46,11 +46,14 @@ def main():
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--coop-min", type=int, default=-1, help="cgan_debug_set_wgrad_coop_min_pixels")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--tile", type=int, default=-1, help="cgan_debug_set_wgrad_tile3x3 (0 never, 1 default, 2 wherever it applies)")
     ap.add_argument("--bias", action="store_true", help="with the bias gradient (rides in the weight-gradient kernels)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     lib = _lib.load_dev()
     lib.cgan_debug_set_wgrad(ctypes.c_int(args.target), ctypes.c_int(args.dbg))
+    if args.tile >= 0:
+        lib.cgan_debug_set_wgrad_tile3x3(ctypes.c_int(args.tile))
     if args.coop_min >= 0:
         lib.cgan_debug_set_wgrad_coop_min_pixels(ctypes.c_int(args.coop_min))
     print("target %d dbg %d bs %d" % (args.target, args.dbg, args.bs))
