@@ -215,7 +215,13 @@ class GradBucketReducer:
 
     def finish(self):
         """Wait for every bucket (launching the ones whose parameters received no gradient this step as zeros would be
-        wrong: parameters without a gradient are skipped on every rank alike) and write the averages back."""
+        wrong: parameters without a gradient are skipped on every rank alike) and write the averages back.
+
+        Contract (advisor, round 4): between ``backward()`` and this call the gradients must not be touched in place (clipping,
+        unscaling: do them AFTER ``finish()``).  A bucket whose gradients changed after its hook sent them (``sent`` records
+        their data pointers and versions) is exchanged again here; that decision is taken from rank-local state and is the
+        same on every rank only because every rank runs the same step code -- a rank-conditional edit of a gradient before
+        ``finish()`` would make the ranks issue different numbers of collectives and hang."""
         if not self.active:
             self.reset()
             return
