@@ -1,19 +1,22 @@
 """bench.py -- throughput of the ClimateGAN hot path on MI355X.
 
-Headline (BASELINE.json ``metric``: "640x640 images/sec (G+D step) at 1/2/4/8 MI355X"; BASELINE configs[3], per-GPU slice):
+Headline (BASELINE.json ``metric``: "640x640 images/sec (G+D step) at 1/2/4/8 MI355X"; BASELINE configs[3] at its GLOBAL
+batch of 32 per domain -- SURVEY 8d M1: "at 1/2/4/8 GPUs, global bs 32 (4/GPU at 8 GPUs)", reference trainer.py:633,935-939):
   one step = ``Trainer.train_step`` = ``update_G`` + ``update_D`` of the reference's default task set [d, s, m, p]
   (reference trainer.py:989-1032) on one multi-domain batch -- domains r and s through the Masker (ResNet-101 encoder
   with batch-statistics BatchNorm, depth / segmentation / mask decoders, 10 loss terms, ADVENT discriminators), domain rf
-  through the Painter (GAN + feature-matching + VGG losses, 3-scale PatchGAN) -- 640x640, **4 samples per domain per
-  GPU** (global batch 32 per domain on 8 GPUs), bf16 activations / fp32 accumulation and parameters, ExtraAdam
-  extrapolation / step.  ``value`` = per-domain sample slots per second over all ranks (a step consumes
-  ``bs`` samples from each of the three domains; the raw-image figure is 3x and reported next to it).
+  through the Painter (GAN + feature-matching + VGG losses, 3-scale PatchGAN) -- 640x640, **32 samples per domain per
+  step over the whole job: 32 / N per rank** (N = 1: all 32 on the one GPU, 137 GB of the 288; N = 8: 4 per GPU), bf16
+  activations / fp32 accumulation and parameters, ExtraAdam extrapolation / step.  ``value`` = per-domain sample slots per
+  second over all ranks (a step consumes ``bs`` samples from each of the three domains; the raw-image
+  figure is 3x and reported next to it); ``scaling`` is "strong": the job's work per step does not change with N.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-N > 1: data parallel, one process per GPU, identical replicas, per-rank batches (weak scaling), the G and the D gradients
+N > 1: data parallel, one process per GPU, identical replicas, rank r takes samples [r * 32/N, (r+1) * 32/N) of the global
+batch (``climategan_amd.parallel.shard_range``: strong scaling), the G and the D gradients
 averaged by the bucketed RCCL all-reduce of ``climategan_amd/parallel.py`` launched from gradient hooks during the
 backward; timing is barrier + synchronize on both sides of the K timed steps, max over ranks.
 
@@ -27,7 +30,8 @@ The JSON line also carries
                 on a bounded sample -- one step at 1 sample per domain, 640x640 -- on the host cores (rank 0, N = 1);
   sub_blocks    the other BASELINE configurations on the same box, each with >= 20 timed steps: configs[1] Painter
                 forward bs 8 bf16 (with the fused-SPADE kernel's MFMA roofline, the kernel north_star names),
-                configs[2] Masker train step bs 8, configs[4] apply_events inference bs 16 fp16.
+                configs[2] Masker train step bs 8, configs[4] apply_events inference bs 16 fp16; and ``per_gpu_slice``,
+                the headline step at 4 per domain = one rank's share of an 8-GPU job (the rounds 1-5 headline).
 """
 import argparse
 import json
@@ -46,7 +50,8 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 BATCH_PER_GPU = 8      # configs[1]: Painter forward
-TRAIN_BS = 4           # configs[3]: per domain per GPU (global batch 32 per domain over 8 GPUs)
+GLOBAL_BS = 32         # configs[3]: samples per domain per step over the WHOLE job (32 / N per rank)
+SLICE_BS = 4           # one rank's share at N = 8 (sub_blocks.per_gpu_slice; the kernel-tuning proxy for the 8-GPU point)
 MASKER_BS = 8          # configs[2]
 INFER_BS = 16          # configs[4]
 H = W = 640
@@ -129,7 +134,7 @@ def recorded_traffic(pattern):
     return int(float(m.group(1)) * 1e6) if m else None
 
 
-def live_traffic(launches_per_step, timeout_s=150):
+def live_traffic(launches_per_step, global_batch=32, timeout_s=300):
     """HBM bytes per launch of the wide-layer GEMM family MEASURED NOW (round 5): two child runs of this script's headline step
     under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` / ``WRITE_SIZE`` (separate passes: the two counters do not fit one),
     the family's dispatches of the last step summed as tools/summarize_pmc_kernel.py does (FETCH_SIZE doubled per the gfx950
@@ -151,7 +156,7 @@ def live_traffic(launches_per_step, timeout_s=150):
             out = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "live", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--sub-steps", "0",
-                   "--no-launch-events", "--mfma-table-steps", "0"]
+                   "--no-launch-events", "--mfma-table-steps", "0", "--global-batch", str(global_batch)]
             env = dict(os.environ, CGAN_BENCH_NO_LIVE_PMC="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, timeout=timeout_s)
             f = None
@@ -219,29 +224,32 @@ def max_over_ranks(elapsed, dist, device):
     return el.item()
 
 
-def result_line(world, steps, warmup, elapsed, dtype_name):
+def result_line(world, steps, warmup, elapsed, dtype_name, per_rank, gbs=None):
+    gbs = GLOBAL_BS if gbs is None else gbs
     return {
         "metric": "640x640 images/sec (G+D step): per-domain sample slots per second of the joint Masker+Painter "
-                  "training step (update_G + update_D), 4 per domain per GPU",
-        "value": round(world * TRAIN_BS * steps / elapsed, 3),
+                  "training step (update_G + update_D), global batch %d per domain" % gbs,
+        "value": round(gbs * steps / elapsed, 3),
         "unit": "images/s",
         "n_gpus": world,
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": dtype_name,
         "data": "synthetic (counter-hash fill: U(-1,1) images, 3-rectangle masks ~35%, uniform depth / class targets; "
                 "untrained weights from the portable fill, VGG-19 random He-scale weights)",
-        "raw_images_per_s": round(3 * world * TRAIN_BS * steps / elapsed, 3),
-        "config": {"workload": "BASELINE configs[3] per-GPU slice: full Masker+Painter joint G/D train step "
-                               "(Trainer.train_step; tasks d,s,m,p; domains r,s,rf; all default loss terms incl. VGG; "
-                               "ExtraAdam), 640x640, 4 samples per domain per GPU",
-                   "batch_per_domain_per_gpu": TRAIN_BS, "global_batch": TRAIN_BS * world,
-                   "global_raw_images_per_step": 3 * TRAIN_BS * world, "latent_dim": LATENT, "spade_n_up": N_UP,
-                   "parallelism": "dp%d: replicas + bucketed RCCL all-reduce of G and D gradients from backward hooks" % world
+        "raw_images_per_s": round(3 * gbs * steps / elapsed, 3),
+        "config": {"workload": "BASELINE configs[3]: full Masker+Painter joint G/D train step (Trainer.train_step; tasks "
+                               "d,s,m,p; domains r,s,rf; all default loss terms incl. VGG; ExtraAdam), 640x640, GLOBAL batch "
+                               "%d samples per domain per step (%d raw images), %d per domain per GPU on %d GPU%s"
+                               % (gbs, 3 * gbs, per_rank, world, "s" if world > 1 else ""),
+                   "global_batch": gbs, "batch_per_domain_per_gpu": per_rank,
+                   "global_raw_images_per_step": 3 * gbs, "latent_dim": LATENT, "spade_n_up": N_UP,
+                   "parallelism": "dp%d: replicas, each rank takes %d of the %d samples per domain, bucketed RCCL all-reduce "
+                                  "of G and D gradients from backward hooks" % (world, per_rank, gbs)
                                   if world > 1 else "single GPU"},
     }
 
@@ -539,25 +547,37 @@ def _dev(a, device):
     return torch.from_numpy(a).to(device)
 
 
-def joint_batch(bs, rank, device, domains=("r", "s", "rf")):
-    """SURVEY 8d synthetic inputs: x ~ U(-1, 1); 3-rectangle masks; depth ~ U(0.35, 6.95); classes uniform in 0..10."""
+def joint_batch(bs, rank, device, domains=("r", "s", "rf"), first=None):
+    """SURVEY 8d synthetic inputs: x ~ U(-1, 1); 3-rectangle masks; depth ~ U(0.35, 6.95); classes uniform in 0..10.
+    ``first`` (the headline): the batch is samples [first, first + bs) of the job's GLOBAL batch -- sample j is drawn from
+    its own seed, so the union over the ranks of an N-GPU job is the same 32 samples per domain whatever N is."""
     import numpy as np
 
     from climategan_amd import fill
 
     hs = H // 4
+
+    def draw(fn, shape_tail, seed, *a):
+        if first is None:
+            return fn((bs,) + shape_tail, seed + (1000 * rank if seed >= 300 else rank), *a)
+        return np.concatenate([fn((1,) + shape_tail, seed + 7919 * (first + j), *a) for j in range(bs)])
+
+    def masks(seed):
+        if first is None:
+            return fill.rect_mask(bs, H, W, seed + (1000 * rank if seed >= 300 else rank))
+        return np.concatenate([fill.rect_mask(1, H, W, seed + 7919 * (first + j)) for j in range(bs)])
+
     batch = {}
     if "rf" in domains:
-        batch["rf"] = {"data": {"x": _dev(fill.uniform((bs, 3, H, W), 100 + rank), device),
-                                "m": _dev(fill.rect_mask(bs, H, W, 200 + rank), device)}}
+        batch["rf"] = {"data": {"x": _dev(draw(fill.uniform, (3, H, W), 100), device), "m": _dev(masks(200), device)}}
     for i, dom in enumerate(("r", "s")):
         if dom not in domains:
             continue
-        sd = 300 + 10 * i + 1000 * rank
-        batch[dom] = {"data": {"x": _dev(fill.uniform((bs, 3, H, W), sd), device),
-                               "d": _dev(fill.uniform((bs, 1, hs, hs), sd + 1, 0.35, 6.95), device),
-                               "s": _dev((fill.uniform01((bs, 1, hs, hs), sd + 2) * 11).astype(np.int64).clip(0, 10), device),
-                               "m": _dev(fill.rect_mask(bs, H, W, sd + 3), device)}}
+        sd = 300 + 10 * i
+        batch[dom] = {"data": {"x": _dev(draw(fill.uniform, (3, H, W), sd), device),
+                               "d": _dev(draw(fill.uniform, (1, hs, hs), sd + 1, 0.35, 6.95), device),
+                               "s": _dev((draw(fill.uniform01, (1, hs, hs), sd + 2) * 11).astype(np.int64).clip(0, 10), device),
+                               "m": _dev(masks(sd + 3), device)}}
     return {d: batch[d] for d in domains}
 
 
@@ -853,35 +873,25 @@ def masker_block(steps, warmup, rank, world, device, dtype, dist, barrier, table
             "steps": steps, "warmup": warmup, "roofline": roof}
 
 
-def large_batch_block(steps, warmup, rank, device, dtype, barrier):
-    """The headline step at the GLOBAL batch of BASELINE configs[3] -- 32 samples per domain -- on ONE GPU (SURVEY 8d M1:
-    the strong-scaling anchor an 8-GPU number at 4 per GPU can be read against; 288 GB hold it).  Activation maps of 2 GiB
-    or more are refused by the boundary (32-bit offsets in several kernels, ops.NHWC): if 32 per domain trips that
-    guard the block falls back to 16 and says so."""
-    tried = {}
-    for bs in (32, 16):
-        T = batch = None
-        try:
-            T = build_trainer(device, dtype, freeze=True)
-            batch = joint_batch(bs, rank, device)
-            T.G.painter.set_latent_shape((bs, 3, H, W), True)
-            torch.cuda.reset_peak_memory_stats()
-            elapsed = timed_steps(lambda: T.train_step(batch), steps, warmup, barrier)
-            assert all(torch.isfinite(v) for v in T.loss_log.values())
-            return {"workload": "BASELINE configs[3] at its GLOBAL batch on one GPU: joint G+D train step, 640x640, %d samples "
-                                "per domain (%d images per step), bf16" % (bs, 3 * bs),
-                    "batch_per_domain": bs, "images_per_s": round(bs * steps / elapsed, 3),
-                    "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup,
-                    "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                    "larger_batches_refused": tried or None}
-        except RuntimeError as e:
-            tried[str(bs)] = str(e)[:240]
-        finally:
-            if T is not None:
-                T.close()
-            del T, batch
-            torch.cuda.empty_cache()
-    return {"error": "no large batch ran", "attempts": tried}
+def slice_block(steps, warmup, rank, device, dtype, barrier):
+    """The headline step at ONE RANK'S SHARE of an 8-GPU job: 4 samples per domain (the rounds 1-5 headline).  What a rank
+    of the N = 8 point computes between two gradient exchanges; ``GLOBAL_BS / ms`` of this block x 8 against the
+    headline's value is the strong-scaling ceiling before any communication."""
+    T = build_trainer(device, dtype, freeze=True)
+    batch = joint_batch(SLICE_BS, rank, device)
+    T.G.painter.set_latent_shape((SLICE_BS, 3, H, W), True)
+    torch.cuda.reset_peak_memory_stats()
+    elapsed = timed_steps(lambda: T.train_step(batch), steps, warmup, barrier)
+    assert all(torch.isfinite(v) for v in T.loss_log.values())
+    roof = None
+    T.overlap_branches = False
+    roof = mfma_roofline(lambda: T.train_step(batch), 2, "")
+    T.close()
+    return {"workload": "BASELINE configs[3], one rank's share at N = 8: joint G+D train step, 640x640, %d samples per domain "
+                        "(%d images per step), bf16" % (SLICE_BS, 3 * SLICE_BS),
+            "batch_per_domain": SLICE_BS, "images_per_s": round(SLICE_BS * steps / elapsed, 3),
+            "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup,
+            "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "roofline": roof}
 
 
 def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""):
@@ -960,8 +970,11 @@ def main():
     ap.add_argument("--ddp-bf16-wire", action="store_true", help="N > 1: bf16 gradient buckets on the wire (default fp32)")
     ap.add_argument("--nccl-max-nchannels", type=int, default=0,
                     help="N > 1: NCCL_MAX_NCHANNELS for RCCL (fewer channels = fewer CUs taken from the backward pass)")
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BS,
+                    help="samples per domain per step over the whole job (BASELINE configs[3]: 32); anything else is a "
+                         "development run and the line says so")
     ap.add_argument("--only", default="", help="run ONE workload as the only measurement (profiling aid): "
-                                               "painter | masker | large | infer")
+                                               "painter | masker | slice | infer")
     args = ap.parse_args()
 
     # multi-GPU knobs reach the reducer / RCCL through the environment (read at communicator / reducer construction)
@@ -1007,8 +1020,8 @@ def main():
             r = painter_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier, False)
         elif args.only == "masker":
             r = masker_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier)
-        elif args.only == "large":
-            r = large_batch_block(args.steps, args.warmup, rank, device, dtype, barrier)
+        elif args.only == "slice":
+            r = slice_block(args.steps, args.warmup, rank, device, dtype, barrier)
         else:
             r = infer_block(args.steps, args.warmup, rank, world, device, dist, barrier)
         if rank == 0:
@@ -1018,9 +1031,12 @@ def main():
         return
 
     # ---------------------------------------------------------------- headline: the joint G+D training step
+    # strong scaling: the job's 32 samples per domain are split over the ranks; N = 1 takes them all
+    from climategan_amd.parallel import shard_range
+    first, per_rank = shard_range(args.global_batch, world, rank)
     T = build_trainer(device, dtype, freeze=True)
-    batch = joint_batch(TRAIN_BS, rank, device)
-    T.G.painter.set_latent_shape((TRAIN_BS, 3, H, W), True)
+    batch = joint_batch(per_rank, rank, device, first=first)
+    T.G.painter.set_latent_shape((per_rank, 3, H, W), True)
     timer = LaunchTimer()
     uninstall = (lambda: None) if args.no_launch_events else install_conv_gemm_timer(timer)
 
@@ -1084,13 +1100,17 @@ def main():
         one = torch.ones(1, device=device)
         dist.all_reduce(one)
         rccl_ranks = int(one.item())
+        if rccl_ranks != world:               # a job whose collective does not span its ranks measures N independent replicas
+            sys.exit("bench.py: an all-reduce over the job's process group summed %d ranks, launched with %d" % (rccl_ranks, world))
     losses = {k: float(v) for k, v in T.loss_log.items()}
     assert all(v == v and abs(v) != float("inf") for v in losses.values()), losses
     mem_gb = torch.cuda.max_memory_allocated() / 2 ** 30
 
     res = None
     if rank == 0:
-        res = result_line(world, args.steps, args.warmup, elapsed, args.dtype)
+        res = result_line(world, args.steps, args.warmup, elapsed, args.dtype, per_rank, args.global_batch)
+        if args.global_batch != GLOBAL_BS:
+            res["config"]["development_run"] = "global batch %d is not BASELINE configs[3]'s %d" % (args.global_batch, GLOBAL_BS)
         if dist is not None:
             res["config"]["rccl_ranks"] = rccl_ranks
             res["config"]["backend"] = dist.get_backend()
@@ -1116,7 +1136,7 @@ def main():
                 "share_of_step": round((ms / sampled) / (elapsed / args.steps * 1e3), 3),
                 "by_class": timer.classes()}
             lps = n // max(sampled, 1)
-            live = live_traffic(lps) if (world == 1 and not args.no_live_traffic) else None
+            live = live_traffic(lps, args.global_batch) if (world == 1 and not args.no_live_traffic) else None
             res["roofline"]["traffic"] = live if live is not None else recorded_traffic("*_conv_gemm_hbm_pmc.csv")
             res["roofline"]["traffic_unit"] = (
                 "HBM bytes per launch (mean over the family's %d launches of one step), %s: separate rocprofv3 --pmc FETCH_SIZE / "
@@ -1185,7 +1205,7 @@ def main():
                                                            world == 1 and not args.no_cpu_baseline)),
                   ("masker_train", lambda: masker_block(args.sub_steps, 3, rank, world, device, dtype, dist, barrier,
                                                         args.conv_table + ".masker" if args.conv_table else "")),
-                  ("train_global_batch_1gpu", lambda: large_batch_block(args.sub_steps, 2, rank, device, dtype, barrier)),
+                  ("per_gpu_slice", lambda: slice_block(args.sub_steps, 5, rank, device, dtype, barrier)),
                   ("apply_events", lambda: infer_block(args.sub_steps, 2, rank, world, device, dist, barrier,
                                                        args.conv_table + ".infer" if args.conv_table else "")))
         for name, fn in blocks:

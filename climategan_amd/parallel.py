@@ -44,6 +44,21 @@ def is_distributed() -> bool:
     return dist.get_world_size() > 1 or os.environ.get("CGAN_DDP_SINGLE_RANK_TEST") == "1"
 
 
+def shard_range(global_batch: int, world: int, rank: int):
+    """(first sample, count) of rank ``rank``'s share of a step's ``global_batch`` samples per domain: contiguous, equal
+    shares (global batch 32 per domain -> 4 per GPU per domain on 8 GPUs; the reference's one process takes
+    ``bs`` samples per domain per step, trainer.py:633,935-939).  Equal shares are REQUIRED, not a convenience: the
+    gradient exchange averages the ranks' batch-mean gradients with equal weights, which is the global batch mean only
+    then -- a batch the world size does not divide is refused."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("shard_range: rank %d outside a world of %d" % (rank, world))
+    if global_batch < world or global_batch % world:
+        raise ValueError("shard_range: a global batch of %d per domain cannot be split evenly over %d ranks (the all-reduce "
+                         "average weighs the ranks equally)" % (global_batch, world))
+    per = global_batch // world
+    return rank * per, per
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """Rank ``src``'s parameters and buffers to every rank (C3)."""
     if not is_distributed():

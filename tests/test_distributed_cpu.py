@@ -1,6 +1,7 @@
 """N > 1 path of bench.py on CPU: world_size 2, gloo.  The launch contract: every rank runs K timed steps between
 barriers, rank-specific synthetic shards differ, the whole-job time is the MAX over ranks and the JSON line aggregates
-all ranks (per-domain sample slots of the joint train step: 4 per GPU).  The data-path collective of the training step
+all ranks (per-domain sample slots of the joint train step: GLOBAL batch 32 per domain, 32 / N per rank -- strong scaling,
+SURVEY 8d M1).  The data-path collective of the training step
 (bucketed gradient all-reduce) is covered by the reducer tests below."""
 import json
 import os
@@ -37,9 +38,17 @@ def _worker(rank, world, port, q):
 
     elapsed = bench.timed_steps(step, steps=5, warmup=2, barrier=dist.barrier)
     total = bench.max_over_ranks(elapsed, dist, torch.device("cpu"))
-    shard = fill.uniform((2, 3, 8, 8), seed=1000 + rank)  # same seeding rule as bench.synthetic_batch
-    line = bench.result_line(world, 5, 2, total, "bf16") if rank == 0 else None
-    q.put((rank, calls["n"], elapsed, total, float(shard.sum()), json.dumps(line) if line else None))
+    # the headline's shard: samples [first, first + per) of the job's 32 per domain, each drawn from its own seed
+    from climategan_amd.parallel import shard_range
+    bench.H = bench.W = 16
+    first, per = shard_range(bench.GLOBAL_BS, world, rank)
+    shard = bench.joint_batch(per, rank, torch.device("cpu"), first=first)
+    whole = bench.joint_batch(bench.GLOBAL_BS, 0, torch.device("cpu"), first=0)      # what a 1-GPU job trains on
+    same = all(torch.equal(shard[d]["data"][k], whole[d]["data"][k][first:first + per])
+               for d in shard for k in shard[d]["data"])
+    line = bench.result_line(world, 5, 2, total, "bf16", per) if rank == 0 else None
+    q.put((rank, calls["n"], elapsed, total, (first, per, same, float(shard["r"]["data"]["x"].sum())),
+           json.dumps(line) if line else None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,13 +68,32 @@ def test_two_rank_timing_and_aggregation():
     assert (n0, n1) == (7, 7)                      # 2 warm-up + 5 timed on every rank
     assert abs(t0 - t1) < 1e-9 and t0 >= max(e0, e1) - 1e-9   # whole-job time = slowest rank, same on all ranks
     assert e1 >= 5 * 0.02 * 0.9                    # the slow rank really ran its 5 timed steps
-    assert s0 != s1                                # ranks get different synthetic shards
+    # strong scaling: the two ranks hold the two halves of the SAME 32 samples per domain a one-GPU job trains on
+    assert s0[:3] == (0, 16, True) and s1[:3] == (16, 16, True) and s0[3] != s1[3]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
-    assert abs(d["value"] - 2 * 4 * 5 / t0) < 1e-2 and abs(d["raw_images_per_s"] - 3 * d["value"]) < 1e-2
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 32
+    assert d["config"]["batch_per_domain_per_gpu"] == 16
+    assert abs(d["value"] - 32 * 5 / t0) < 1e-2 and abs(d["raw_images_per_s"] - 3 * d["value"]) < 1e-2
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config"):
         assert key in d
+
+
+def test_shard_range_is_the_32_over_n_split():
+    """bench.py's N = 1 / 2 / 4 / 8 points: contiguous equal shares that tile the global batch; anything the all-reduce
+    average would weigh wrongly is refused."""
+    import pytest
+
+    sys.path.insert(0, str(ROOT))
+    from climategan_amd.parallel import shard_range
+    for world in (1, 2, 4, 8, 16, 32):
+        parts = [shard_range(32, world, r) for r in range(world)]
+        assert all(n == 32 // world for _f, n in parts)
+        assert [f for f, _n in parts] == list(range(0, 32, 32 // world))
+    assert shard_range(32, 8, 7) == (28, 4)
+    for bad in ((32, 3, 0), (32, 64, 0), (32, 8, 8), (32, 8, -1), (32, 0, 0)):
+        with pytest.raises(ValueError):
+            shard_range(*bad)
 
 
 def _reducer_worker(rank, world, port, q):

@@ -383,8 +383,8 @@ def _check_terms(T, gold, mapping, rel, what):
         assert abs(got - ref) <= rel * max(abs(ref), 1e-3), (what, hk, got, ref)
 
 
-@pytest.mark.parametrize("config", ["configs2_masker_bs8", "configs3_joint_4_per_domain", "small_joint_merged",
-                                    "small_joint_per_domain"])
+@pytest.mark.parametrize("config", ["configs2_masker_bs8", "configs3_joint_4_per_domain", "configs3_joint_32_per_domain",
+                                    "small_joint_merged", "small_joint_per_domain"])
 def test_train_step_640_matches_reference_update(config):
     """One ``Trainer.train_step`` (update_G + update_D) at the benchmark batch size, bf16, vs the reference's own
     ``update_G`` / ``update_D`` at 640 x 640 (golden ``jstep_640``): logged loss terms, per-tensor gradient norms and
@@ -400,6 +400,12 @@ def test_train_step_640_matches_reference_update(config):
         tasks, reps, domains = ("d", "s", "m"), 4, ("r", "s")
     elif config == "configs3_joint_4_per_domain":
         tasks, reps, domains = ("d", "s", "m", "p"), 2, ("r", "s", "rf")
+    elif config == "configs3_joint_32_per_domain":
+        # BASELINE configs[3] at its GLOBAL batch on one GPU (bench.py's N = 1 headline): the golden pair repeated 16 x;
+        # every loss term is a batch mean (SIGMLoss rescaled in _build_train), BatchNorm statistics of a repeated batch are
+        # those of one copy, so the reference's step on the pair is the reference's step on the 32.  Maps of 2 GiB and
+        # more go through the batch-chunked path of ops.py here and nowhere else in the suite
+        tasks, reps, domains = ("d", "s", "m", "p"), 16, ("r", "s", "rf")
     else:
         tasks, reps, domains = ("d", "s", "m", "p"), 1, ("r", "s", "rf")
     T = _build_train(tasks, case, reps, merge=merge)

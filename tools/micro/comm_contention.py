@@ -31,8 +31,8 @@ def main():
                                    ctypes.c_void_p]
     dev = torch.device("cuda:0")
     T = bench.build_trainer(dev, torch.bfloat16, freeze=True)
-    batch = bench.joint_batch(bench.TRAIN_BS, 0, dev)
-    T.G.painter.set_latent_shape((bench.TRAIN_BS, 3, bench.H, bench.W), True)
+    batch = bench.joint_batch(bench.SLICE_BS, 0, dev)
+    T.G.painter.set_latent_shape((bench.SLICE_BS, 3, bench.H, bench.W), True)
     n = int(args.bucket_mb * 2 ** 20) // 4 // 4 * 4
     a = torch.zeros(n, device=dev)
     b = torch.ones(n, device=dev)

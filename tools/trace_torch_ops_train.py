@@ -13,8 +13,8 @@ import bench  # noqa: E402
 
 device = torch.device("cuda", 0)
 T = bench.build_trainer(device, torch.bfloat16)
-batch = bench.joint_batch(bench.TRAIN_BS, 0, device)
-T.G.painter.set_latent_shape((bench.TRAIN_BS, 3, bench.H, bench.W), True)
+batch = bench.joint_batch(bench.SLICE_BS, 0, device)
+T.G.painter.set_latent_shape((bench.SLICE_BS, 3, bench.H, bench.W), True)
 counts, nbytes = collections.Counter(), collections.Counter()
 SKIP = ("view", "_unsafe_view", "detach", "alias", "slice", "select", "expand", "as_strided", "unsqueeze", "squeeze", "t",
         "transpose", "permute", "reshape", "empty", "empty_like", "empty_strided", "unbind", "split", "_local_scalar_dense",
