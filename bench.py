@@ -326,7 +326,7 @@ def install_conv_gemm_timer(timer):
     from climategan_amd import _lib
 
     lib = _lib.load()
-    fwd, bwd, kind = lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_kernel_kind
+    fwd, bwd, kind = lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_kernel_kind_on
     GEMM = 2
 
     def cs8(c):
@@ -342,14 +342,14 @@ def install_conv_gemm_timer(timer):
                                                             d.kh, d.stride, d.dilation, " +res" if d.has_residual else "")
 
     def timed_fwd(x, w, b, r, y, dref, stream):
-        if timer.enabled and kind(dref, 0) == GEMM:
+        if timer.enabled and kind(dref, 0, stream) == GEMM:
             d = dref._obj
             return timer.bracket(lambda: fwd(x, w, b, r, y, dref, stream),
                                  2.0 * d.n * d.h_out * d.w_out * d.c_out * d.c_in * d.kh * d.kw, alg_bytes(d), tag(d, "fwd"))
         return fwd(x, w, b, r, y, dref, stream)
 
     def timed_bwd(dy, w, dx, dref, stream):
-        if timer.enabled and kind(dref, 1) == GEMM:
+        if timer.enabled and kind(dref, 1, stream) == GEMM:
             d = dref._obj
             return timer.bracket(lambda: bwd(dy, w, dx, dref, stream),
                                  2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d), tag(d, "bwd_data"))
@@ -358,7 +358,7 @@ def install_conv_gemm_timer(timer):
     bwd_add = lib.cgan_conv2d_nhwc_bwd_data_add
 
     def timed_bwd_add(dy, w, dx_add, dx, dref, stream):        # data gradient + the other contribution of the same tensor
-        if timer.enabled and kind(dref, 1) == GEMM:
+        if timer.enabled and kind(dref, 1, stream) == GEMM:
             d = dref._obj
             extra = 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)     # the added tensor is read once more
             return timer.bracket(lambda: bwd_add(dy, w, dx_add, dx, dref, stream),
@@ -369,7 +369,7 @@ def install_conv_gemm_timer(timer):
     bwd_relu = lib.cgan_conv2d_nhwc_bwd_data_relu
 
     def timed_bwd_relu(dy, w, relu_out, dx, dref, stream):      # data gradient masked by the ReLU output it flows back into
-        if timer.enabled and kind(dref, 1) == GEMM:
+        if timer.enabled and kind(dref, 1, stream) == GEMM:
             d = dref._obj
             extra = 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)     # the activation's output is read once more
             return timer.bracket(lambda: bwd_relu(dy, w, relu_out, dx, dref, stream),
@@ -410,7 +410,7 @@ def install_all_mfma_timer(timer):
              "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd", "cgan_spade_fused_fwd_train",
              "cgan_conv2d_nhwc_bwd_data_relu", "cgan_spade_hidden_bwd")
     orig = {n: getattr(lib, n) for n in names}
-    kind = lib.cgan_conv2d_kernel_kind
+    kind = lib.cgan_conv2d_kernel_kind_on
     KIND = {0: "general", 1: "lds3x3", 2: "gemm"}
 
     def cs8(c):
@@ -431,17 +431,17 @@ def install_all_mfma_timer(timer):
     def fwd(x, w, b, r, y, dref, stream):
         d = dref._obj
         return timer.bracket(lambda: orig[names[0]](x, w, b, r, y, dref, stream), conv_flops(d), conv_bytes(d),
-                             tag(d, KIND[kind(dref, 0)], "fwd"))
+                             tag(d, KIND[kind(dref, 0, stream)], "fwd"))
 
     def bwd(dy, w, dx, dref, stream):
         d = dref._obj      # the FORWARD descriptor: dx has its input shape
         return timer.bracket(lambda: orig[names[1]](dy, w, dx, dref, stream), conv_flops(d), conv_bytes(d),
-                             tag(d, KIND[kind(dref, 1)], "bwd_data"))
+                             tag(d, KIND[kind(dref, 1, stream)], "bwd_data"))
 
     def bwd_add(dy, w, dx_add, dx, dref, stream):
         d = dref._obj
         return timer.bracket(lambda: orig[names[2]](dy, w, dx_add, dx, dref, stream), conv_flops(d),
-                             conv_bytes(d, 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1)], "bwd_data+"))
+                             conv_bytes(d, 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1, stream)], "bwd_data+"))
 
     def fwd_stats(x, w, b, y, partial, nbytes, dref, stream):
         d = dref._obj
@@ -472,7 +472,7 @@ def install_all_mfma_timer(timer):
     def bwd_relu(dy, w, relu_out, dx, dref, stream):
         d = dref._obj
         return timer.bracket(lambda: orig[names[7]](dy, w, relu_out, dx, dref, stream), conv_flops(d),
-                             conv_bytes(d, 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1)], "bwd_data*"))
+                             conv_bytes(d, 2 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1, stream)], "bwd_data*"))
 
     def spade_hid_bwd(dgb, wdg, cond, wsh, bsh, dw, db, ws, ws_bytes, dref, stream):
         # fused hidden-map backward: the data gradient of the gamma||beta conv (2c -> hidden, 3x3) + the hidden tile's

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_bwd_data_relu": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_kernel_kind": (C.c_int, [C.POINTER(ConvDesc), C.c_int32]),
+    "cgan_conv2d_kernel_kind_on": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, _P]),
     "cgan_conv2d_bind_workspace": (C.c_int, [_P, _P, C.c_size_t]),
     "cgan_rccl_load": (C.c_int, [C.c_char_p]),
     "cgan_rccl_loaded": (C.c_int, []),
@@ -258,7 +259,8 @@ def load():
 
 _product = None
 _dev = None
-DEV_LIB_PATH = _HERE / "libcgan_hip_dev.so"
+# CGAN_LIB_DEV: another build of the development library (same-box A/B of a kernel change with tools/bench_*.py)
+DEV_LIB_PATH = Path(os.environ["CGAN_LIB_DEV"]).resolve() if os.environ.get("CGAN_LIB_DEV") else _HERE / "libcgan_hip_dev.so"
 
 
 def load_dev():

@@ -731,36 +731,60 @@ extern "C" int cgan_conv2d_pack_weight_batched(const CganPackItem* items_device,
 // ------------------------------------------------------------------------------------------------
 #include <mutex>
 namespace {
-struct WsSlot { void* stream; void* ws; size_t bytes; };
-constexpr int WS_SLOTS = 16;
+// keyed by (device, stream): the NULL stream has the same handle on every device of a process
+struct WsSlot { int device; void* stream; void* ws; size_t bytes; };
+constexpr int WS_SLOTS = 64;
 WsSlot g_ws[WS_SLOTS];
 int g_ws_n = 0;
+int g_ws_next = 0;      // replacement cursor once the table is full (oldest binding first)
 std::mutex g_ws_mu;
+int ws_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return dev;
+}
 WsSlot ws_lookup(void* stream) {
+  const int dev = ws_device();
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (int i = 0; i < g_ws_n; ++i)
-    if (g_ws[i].stream == stream) return g_ws[i];
-  return WsSlot{stream, nullptr, 0};
+    if (g_ws[i].stream == stream && g_ws[i].device == dev) return g_ws[i];
+  return WsSlot{dev, stream, nullptr, 0};
 }
-size_t ws_max_bytes() {
+size_t ws_max_bytes() {       // the largest workspace bound on the current device
+  const int dev = ws_device();
   std::lock_guard<std::mutex> lk(g_ws_mu);
   size_t m = 0;
-  for (int i = 0; i < g_ws_n; ++i) m = g_ws[i].bytes > m ? g_ws[i].bytes : m;
+  for (int i = 0; i < g_ws_n; ++i)
+    if (g_ws[i].device == dev && g_ws[i].bytes > m) m = g_ws[i].bytes;
   return m;
 }
 }  // namespace
 
+// workspace == NULL, bytes == 0 removes the binding of (current device, stream).  A full table replaces its OLDEST binding
+// (the caller that bound it loses split-K on that stream -- the general kernel runs instead -- nothing fails).
 extern "C" int cgan_conv2d_bind_workspace(void* stream, void* workspace, size_t bytes) {
   CGAN_REQUIRE((workspace != nullptr) == (bytes > 0), "conv2d_bind_workspace: workspace and bytes must both be set or both be zero");
   CGAN_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "conv2d_bind_workspace: workspace must be 16-byte aligned");
+  const int dev = ws_device();
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (int i = 0; i < g_ws_n; ++i)
-    if (g_ws[i].stream == stream) {
-      g_ws[i].ws = workspace; g_ws[i].bytes = bytes;
+    if (g_ws[i].stream == stream && g_ws[i].device == dev) {
+      if (workspace == nullptr) {               // unbind: close the gap
+        g_ws[i] = g_ws[g_ws_n - 1];
+        --g_ws_n;
+        if (g_ws_next >= g_ws_n) g_ws_next = 0;
+      } else {
+        g_ws[i].ws = workspace; g_ws[i].bytes = bytes;
+      }
       return CGAN_OK;
     }
-  CGAN_REQUIRE(g_ws_n < WS_SLOTS, "conv2d_bind_workspace: more than %d streams", WS_SLOTS);
-  g_ws[g_ws_n++] = WsSlot{stream, workspace, bytes};
+  if (workspace == nullptr) return CGAN_OK;     // nothing bound: nothing to remove
+  if (g_ws_n < WS_SLOTS) {
+    g_ws[g_ws_n++] = WsSlot{dev, stream, workspace, bytes};
+  } else {
+    g_ws[g_ws_next] = WsSlot{dev, stream, workspace, bytes};
+    g_ws_next = (g_ws_next + 1) % WS_SLOTS;
+  }
   return CGAN_OK;
 }
 
@@ -1125,14 +1149,14 @@ static bool cls_on_gemm(const ConvParams& p, ConvGemmCls (&cls)[4]) {
   return true;
 }
 
-extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) {
+// ws_bytes: the split-K workspace the launch in question would find (a split-K launch needs its stream's binding)
+static int kernel_kind_impl(const CganConvDesc* d, int32_t bwd_data, size_t ws_bytes) {
   ConvParams p;
   if (!bwd_data) {
     int rc = fill_params(p, d);
     if (rc != CGAN_OK) return rc;
     const int kind = select_conv_kernel(p, d);
-    // (a split-K launch needs its stream's workspace: the query answers for the largest one bound)
-    return splitk_candidate(kind, p) && splitk_for(p, ws_max_bytes()) > 1 ? CGAN_CONV_KERNEL_GEMM : kind;
+    return splitk_candidate(kind, p) && splitk_for(p, ws_bytes) > 1 ? CGAN_CONV_KERNEL_GEMM : kind;
   }
   CganConvDesc t;
   int rc = dgrad_params(p, d, &t);
@@ -1146,7 +1170,16 @@ extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) 
   }
   t.pad = p.pad;
   const int kind = select_conv_kernel(p, &t);
-  return splitk_candidate(kind, p) && splitk_for(p, ws_max_bytes()) > 1 ? CGAN_CONV_KERNEL_GEMM : kind;
+  return splitk_candidate(kind, p) && splitk_for(p, ws_bytes) > 1 ? CGAN_CONV_KERNEL_GEMM : kind;
+}
+
+// the kernel a launch of this descriptor on ``stream`` (of the current device) runs: that stream's workspace decides split-K
+extern "C" int cgan_conv2d_kernel_kind_on(const CganConvDesc* d, int32_t bwd_data, void* stream) {
+  return kernel_kind_impl(d, bwd_data, ws_lookup(stream).bytes);
+}
+// (kept for callers without a stream at hand: answers for the largest workspace bound on the current device)
+extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) {
+  return kernel_kind_impl(d, bwd_data, ws_max_bytes());
 }
 
 static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx, const CganConvDesc* fwd,

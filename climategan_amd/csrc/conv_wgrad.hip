@@ -46,7 +46,13 @@ struct WgradArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SLAB_BYTES = 32 * 128;        // 32 pixels x 64 channels x 2 B
+// An 8-pixel DMA piece (8 rows x 128 B) sits on a pitch of 1024 + 128 B (round 6): the two 16-lane groups a transposing read
+// services together read rows k and 8 + k of the slab -- 1024 B apart they start on the SAME banks whatever the slot
+// swizzle does (the swizzle depends on the row within a piece only), a 2-way conflict on every fragment read (SQ counters,
+// round 5: bank-conflict cycles = 0.49 of the LDS-active cycles).  One row of padding per piece rotates the odd pieces by
+// 32 banks: rows k and 8 + k then use complementary halves of the 64 banks for every slot pair.
+constexpr int PIECE = 1024 + 128;
+constexpr int SLAB_BYTES = 4 * PIECE;       // 32 pixels x 64 channels x 2 B, in four padded pieces
 constexpr int WAVE_LDS = 4 * SLAB_BYTES;    // {dy, x} x double buffer
 
 // LDS slabs are [pixel row][8 slots of 16 B]; row r keeps channel chunk c in slot c ^ swz(r): un-swizzled, the 16 rows a
@@ -60,8 +66,8 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* slab, int tile, in
   const int i = lane & 15, g = lane >> 4;
   const int k = i >> 2;                                   // row within the 4-row block
   const int chunk = tile * 2 + ((i & 3) >> 1);
-  const unsigned char* a0 = slab + (8 * g + k) * 128 + ((chunk ^ (k << 1)) << 4) + (i & 1) * 8;          // rows 8g + k
-  const unsigned char* a1 = slab + (8 * g + 4 + k) * 128 + ((chunk ^ ((k << 1) | 1)) << 4) + (i & 1) * 8;   // rows 8g + 4 + k
+  const unsigned char* a0 = slab + g * PIECE + k * 128 + ((chunk ^ (k << 1)) << 4) + (i & 1) * 8;          // rows 8g + k
+  const unsigned char* a1 = slab + g * PIECE + (4 + k) * 128 + ((chunk ^ ((k << 1) | 1)) << 4) + (i & 1) * 8;   // rows 8g + 4 + k
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
   u32x4 r;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         // pixels past the end: the dy offset is out of range by itself (zeros), which also neutralises whatever x holds
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * PIECE), 16,
                                                  u_dy0 + (unsigned)(i * 8) * cout_b + lane_dyc, 0, 0, 0);
         int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
         if (MODE == 2) {      // nn.ReflectionPad2d: mirror without repeating the border (a dead lane stays out of range)
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         } else {
           off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + lane_xc;   // piece part + lane constant
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * PIECE), 16,
                                                  xv ? off : 0xffffffffu, 0, 0, 0);
       }
       u_dy0 += step_dy;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool pv = c_pix[i] < p.npix;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * PIECE), 16,
                                                (pv && co_ok) ? c_dy[i] : 0xffffffffu, 0, 0, 0);
       int iy = c_sy[i] + tap_y, ix = c_sx[i] + tap_x;
       if (MODE == 2) {
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       const unsigned row = (unsigned)(c_nh[i] + (MODE == 1 ? (iy >> 1) : iy));
       const unsigned col = (unsigned)(MODE == 1 ? (ix >> 1) : ix);
       const unsigned off = row * row_b + col * cin_b + cch2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * PIECE), 16,
                                                xv ? off : 0xffffffffu, 0, 0, 0);
       // advance to the following chunk
       c_pix[i] += step;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 // ResNet layer3 / layer4, ASPP, the decoders' 512-channel convs).
 template <typename T, int MODE, int CH = 64, bool TS = false, bool BIAS = false, int G = 2>
 __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void conv_wgrad_coop_kernel(WgradArgs p) {
-  constexpr int CHUNK2 = CH, SUB2 = CH * 128, STAGE2 = 2 * G * SUB2;
+  constexpr int CHUNK2 = CH, SUB2 = (CH / 8) * PIECE, STAGE2 = 2 * G * SUB2;
   constexpr int PPS = CH / 8, PW = PPS / G;      // pieces per sub-slab, pieces of each operand a wave stages
   static_assert(PW >= 1, "a wave stages at least one piece of each operand");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -466,10 +472,10 @@ __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void c
   // (the MFMAs queue behind a piece's issue stall either way, and the pieces land later: l3 3x3 115 -> 125 us).
   unsigned v_off = 0;
   auto issue_piece = [&](int b, int k) {
-    unsigned char* dst = smem + b * STAGE2 + mem * SUB2 + half * (PW * 1024);
+    unsigned char* dst = smem + b * STAGE2 + mem * SUB2 + half * (PW * PIECE);
     if (k < PW) {
       const unsigned off = u_dy + (unsigned)((half * PW + k) * 8) * cout_b + dy_c;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst + k * PIECE), 16,
                                                off, 0, 0, 0);
       return;
     }
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void c
     if (MODE == 1) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
     else if (MODE == 2) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + iy) * row_b + (unsigned)ix * cin_b + cch2;
     else off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + x_c;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + G * SUB2 + j * 1024), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + G * SUB2 + j * PIECE), 16,
                                              xv ? off : 0xffffffffu, 0, 0, 0);
   };
   auto advance = [&]() {
@@ -541,9 +547,9 @@ __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void c
     for (int ks = 0; ks < CH / 32; ++ks) {
       u32x4 fa[4], fb[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) fa[a] = tr_frag(sdy + ks * 32 * 128, a, lane);
+      for (int a = 0; a < 4; ++a) fa[a] = tr_frag(sdy + ks * 4 * PIECE, a, lane);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) fb[b] = tr_frag(sx + ks * 32 * 128, b, lane);
+      for (int b = 0; b < 4; ++b) fb[b] = tr_frag(sx + ks * 4 * PIECE, b, lane);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1063,7 +1069,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     }
   }
   hipStream_t s = (hipStream_t)stream;
-  const size_t smem = 4 * WAVE_LDS;   // 64 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
+  const size_t smem = 4 * WAVE_LDS;   // 72 KiB: also holds the 4 x 16 KiB partial tiles of the final reduction
   // 32-bit byte offsets inside the kernel
   CGAN_REQUIRE((double)d->n * (a.x_ups ? d->h_in / 2 : d->h_in) * (a.x_ups ? d->w_in / 2 : d->w_in) * a.cin_s * 2.0 < 4294967295.0 &&
                    (double)a.npix * a.cout_s * 2.0 < 4294967295.0,
@@ -1075,7 +1081,23 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
   // the dy offsets (one chunk stride past the end included) below 2^31
   const bool uni = (d->w_out % 8) == 0 && g_wgrad_dbg != 16 &&
                    ((double)a.npix + (double)a.splits * 128.0 + 128.0) * a.cout_s * 2.0 < 2147483648.0;
-#define WGRAD_LAUNCH(TT, MM, UU) hipLaunchKernelGGL((conv_wgrad_kernel<TT, MM, UU>), dim3(gx), dim3(256), smem, s, a)
+// more than 64 KiB of dynamic LDS needs the function attribute, once per kernel instance and device
+#define CGAN_BIG_LDS(KERNEL)                                                                                           \
+  do {                                                                                                                 \
+    static unsigned long long done_mask = 0;                                                                           \
+    int dev_ = 0;                                                                                                      \
+    (void)hipGetDevice(&dev_);                                                                                         \
+    if (!((done_mask >> (dev_ & 63)) & 1ull)) {                                                                        \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+      if (e_ != hipSuccess) {                                                                                          \
+        cgan_set_error("conv2d_nhwc_bwd_weight: hipFuncSetAttribute failed: %s", hipGetErrorString(e_));               \
+        return CGAN_ERR_HIP;                                                                                           \
+      }                                                                                                                \
+      done_mask |= 1ull << (dev_ & 63);                                                                                \
+    }                                                                                                                  \
+  } while (0)
+#define WGRAD_LAUNCH(TT, MM, UU) do { CGAN_BIG_LDS((conv_wgrad_kernel<TT, MM, UU>)); hipLaunchKernelGGL((conv_wgrad_kernel<TT, MM, UU>), dim3(gx), dim3(256), smem, s, a); } while (0)
 #define WGRAD_MODE(TT)                                                          \
   do {                                                                          \
     if (mode == 2) { if (uni) WGRAD_LAUNCH(TT, 2, true); else WGRAD_LAUNCH(TT, 2, false); }     \
@@ -1094,19 +1116,10 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #undef TILE_NB
 #undef TILE_LAUNCH
   } else if (pl.coop && pl.g == 4) {
-    const size_t smem4 = (size_t)2 * 8 * 64 * 128;      // two stages of 4 dy + 4 x sub-slabs: 128 KiB
+    const size_t smem4 = (size_t)2 * 8 * 8 * PIECE;      // two stages of 4 dy + 4 x sub-slabs of 8 padded pieces: 144 KiB
 #define COOP4_LAUNCH(TT, MM)                                                                                           \
   do {                                                                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_coop_kernel<TT, MM, 64, false, false, 4>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
-      if (e != hipSuccess) {                                                                                           \
-        cgan_set_error("conv2d_nhwc_bwd_weight: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                \
-        return CGAN_ERR_HIP;                                                                                           \
-      }                                                                                                                \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
+    CGAN_BIG_LDS((conv_wgrad_coop_kernel<TT, MM, 64, false, false, 4>));                                               \
     hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, 64, false, false, 4>), dim3(gx), dim3(1024), smem4, s, a);      \
   } while (0)
 #define COOP4_MODE(TT) do { if (mode == 1) COOP4_LAUNCH(TT, 1); else if (mode == 2) COOP4_LAUNCH(TT, 2); else COOP4_LAUNCH(TT, 0); } while (0)
@@ -1115,8 +1128,8 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #undef COOP4_MODE
 #undef COOP4_LAUNCH
   } else if (pl.coop) {
-    const size_t smem2 = (size_t)2 * 4 * pl.chunk * 128;
-#define COOP_LAUNCH(TT, MM, CC, BB) hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC, false, BB>), dim3(gx), dim3(256), smem2, s, a)
+    const size_t smem2 = (size_t)2 * 4 * (pl.chunk / 8) * PIECE;      // 72 KiB (64-pixel stages) / 36 KiB (32-pixel)
+#define COOP_LAUNCH(TT, MM, CC, BB) do { CGAN_BIG_LDS((conv_wgrad_coop_kernel<TT, MM, CC, false, BB>)); hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, CC, false, BB>), dim3(gx), dim3(256), smem2, s, a); } while (0)
 #define COOP_MODE(TT)                                                                       \
   do {                                                                                      \
     if (pl.chunk == 32) { if (mode == 1) COOP_LAUNCH(TT, 1, 32, false); else if (mode == 2) COOP_LAUNCH(TT, 2, 32, false); else COOP_LAUNCH(TT, 0, 32, false); } \
@@ -1126,7 +1139,7 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
 #ifdef CGAN_DEV
     if (CGAN_WTS(a) && d->dtype == CGAN_BF16 && mode == 0) {
       if (pl.chunk == 32) hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 32, true>), dim3(gx), dim3(256), smem2, s, a);
-      else hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 64, true>), dim3(gx), dim3(256), smem2, s, a);
+      else { CGAN_BIG_LDS((conv_wgrad_coop_kernel<BF16, 0, 64, true>)); hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 64, true>), dim3(gx), dim3(256), smem2, s, a); }
     } else
 #endif
     if (d->dtype == CGAN_F16) COOP_MODE(F16);

@@ -185,7 +185,7 @@ def pair_from_nchw(x: torch.Tensor, dtype: torch.dtype) -> PairMap:
     _need_cuda(x)
     x = x.contiguous().float()
     n, c, h, w = x.shape
-    y = torch.empty((n, h, w, split_blocks(dtype) * cs8(c)), dtype=dtype, device=x.device)
+    y = _empty((n, h, w, split_blocks(dtype) * cs8(c)), dtype=dtype, device=x.device)
     _lib.check(_lib.load().cgan_pair_from_nchw(_ptr(x), _ptr(y), _DT[dtype], n, c, h, w, _stream()), "cgan_pair_from_nchw")
     return PairMap(y, c)
 
@@ -193,34 +193,111 @@ def pair_from_nchw(x: torch.Tensor, dtype: torch.dtype) -> PairMap:
 def pair_to_nhwc(x: PairMap) -> NHWC:
     """hi + lo rounded once to the 16-bit type: the ordinary map the event kernels and the Painter read."""
     _plain_pair(x, "pair_to_nhwc")
-    y = torch.empty((x.n, x.h, x.w, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, x.h, x.w, x.cs), dtype=x.t.dtype, device=x.t.device)
     _lib.check(_lib.load().cgan_pair_to_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n * x.h * x.w, x.c, _stream()),
                "cgan_pair_to_nhwc")
     return NHWC(y, x.c)
 
 
 # ------------------------------------------------------------------------------------------------ maps of 2 GiB and more
-def _cat_results(outs):
-    """Concatenate per-chunk results along the batch: NHWC maps, [N, ...] tensors, tuples of those (None stays None)."""
+class _ChunkArena:
+    """Result buffers of an op that runs on batch slices (round 6).  NHWC keeps a sample contiguous, so the slices' results
+    are consecutive ranges of ONE full-batch tensor: while an arena is active, ``_empty`` serves every [count, ...] map the
+    op allocates (4-D maps and [N, Cs] statistics, in allocation order) as the slice's range of a full-batch buffer
+    allocated on the first slice, and ``_join`` hands that buffer out as the result -- no concatenation pass (rounds 4-5
+    joined the slices with ``torch.cat``: 14 extra passes over 2-3.4 GB maps per train step at 32 samples per domain,
+    17.9 ms of a 634 ms step)."""
+
+    def __init__(self, n: int):
+        self.n, self.full, self.j, self.lo, self.cnt = n, [], 0, 0, 0
+
+    def begin(self, lo: int, cnt: int) -> None:
+        self.lo, self.cnt, self.j = lo, cnt, 0
+
+    def take(self, shape, dtype, device):
+        if len(shape) not in (2, 4) or shape[0] != self.cnt:
+            return None
+        j = self.j
+        if j == len(self.full):
+            if self.lo != 0:          # a later slice allocates a map the first one did not: plain allocation (joined by cat)
+                return None
+            self.full.append(torch.empty((self.n,) + tuple(shape[1:]), dtype=dtype, device=device))
+        f = self.full[j]
+        if tuple(f.shape[1:]) != tuple(shape[1:]) or f.dtype != dtype:
+            return None               # (the slices' allocation sequences differ: plain allocation, joined by cat)
+        self.j = j + 1
+        return f[self.lo:self.lo + self.cnt]
+
+    def whole(self, pieces, spans):
+        """The full-batch buffer whose ranges ``pieces`` (one tensor per slice) are, or None."""
+        t0 = pieces[0]
+        for f in self.full:
+            if f.data_ptr() == t0.data_ptr() and f.dtype == t0.dtype and tuple(f.shape[1:]) == tuple(t0.shape[1:]):
+                if all(t.is_contiguous() and t.shape[0] == cnt and t.data_ptr() == f[lo:lo + cnt].data_ptr()
+                       for t, (lo, cnt) in zip(pieces, spans)):
+                    return f
+        return None
+
+
+_ARENA = None
+
+
+def _empty(shape, dtype=None, device=None):
+    if _ARENA is not None and not isinstance(shape, int):
+        t = _ARENA.take(tuple(shape), dtype if dtype is not None else torch.get_default_dtype(), device)
+        if t is not None:
+            return t
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _empty_like(t: torch.Tensor):
+    if _ARENA is not None and t.is_contiguous():
+        r = _ARENA.take(tuple(t.shape), t.dtype, t.device)
+        if r is not None:
+            return r
+    return torch.empty_like(t)
+
+
+def _join(outs, spans, arena):
+    """Per-slice results -> the full-batch result: the arena's buffer where the slices wrote into one, else a concatenation
+    along the batch.  NHWC maps, [N, ...] tensors, tuples of those (None stays None)."""
     first = outs[0]
     if first is None:
         return None
-    if isinstance(first, NHWC):
-        return NHWC(torch.cat([o.t for o in outs], 0), first.c)
-    if isinstance(first, PairMap):
-        return PairMap(torch.cat([o.t for o in outs], 0), first.c, first.sigmoid)
-    if isinstance(first, torch.Tensor):
-        return torch.cat(outs, 0)
     if isinstance(first, tuple):
-        return tuple(_cat_results([o[i] for o in outs]) for i in range(len(first)))
+        return tuple(_join([o[i] for o in outs], spans, arena) for i in range(len(first)))
+    if isinstance(first, (NHWC, PairMap)):
+        f = arena.whole([o.t for o in outs], spans)
+        t = f if f is not None else torch.cat([o.t for o in outs], 0)
+        return NHWC(t, first.c) if isinstance(first, NHWC) else PairMap(t, first.c, first.sigmoid)
+    if isinstance(first, torch.Tensor):
+        f = arena.whole(outs, spans)
+        return f if f is not None else torch.cat(outs, 0)
     raise TypeError("cannot join chunk results of type %s" % type(first))
+
+
+def _run_chunks(n: int, k: int, call):
+    """``call(lo, count)`` over the batch in slices of ``k`` samples, results joined (see _ChunkArena)."""
+    global _ARENA
+    prev, arena = _ARENA, _ChunkArena(n)
+    outs, spans = [], []
+    try:
+        _ARENA = arena
+        for lo in range(0, n, k):
+            cnt = min(k, n - lo)
+            arena.begin(lo, cnt)
+            outs.append(call(lo, cnt))
+            spans.append((lo, cnt))
+    finally:
+        _ARENA = prev
+    return _join(outs, spans, arena)
 
 
 def _batch_chunked(*split, out_bytes_per_sample=None):
     """For ops whose samples are independent (NHWC keeps a sample contiguous: a batch slice is a view).  One C-ABI call
     covers maps below MAX_MAP_BYTES (32-bit offsets in the kernels); when an operand named in ``split`` (NHWC maps or
     [N, ...] tensors) or the result (``out_bytes_per_sample(get)`` with ``get(name)`` -> the call's argument) would reach
-    that, the op runs on batch slices and the results are concatenated (one extra pass over the result, only in that
+    that, the op runs on batch slices that write consecutive ranges of one full-batch result (_ChunkArena; only in that
     regime): configs[3]'s global batch of 32 per domain on ONE GPU has 3.4 GB maps (the SPADE hidden map, VGG's first
     block).  Below 1/256 of the limit nothing is examined (no op grows a map 256-fold)."""
     def deco(fn):
@@ -266,21 +343,21 @@ def _batch_chunked(*split, out_bytes_per_sample=None):
             if k < 1:
                 raise RuntimeError("%s: ONE sample's map (%.2f GiB) exceeds the 2 GiB a C-ABI call covers"
                                    % (fn.__name__, per_sample / 2 ** 30))
-            outs = []
-            for lo in range(0, n, k):
+
+            def call(lo, cnt):
                 a, kw = list(args), dict(kwargs)
                 for i, name in idx:
                     v = a[i] if i < len(a) else kw.get(name)
                     if v is None:
                         continue
-                    piece = (NHWC(v.t[lo:lo + k], v.c) if type(v) is NHWC else
-                             PairMap(v.t[lo:lo + k], v.c, v.sigmoid) if type(v) is PairMap else v[lo:lo + k])
+                    piece = (NHWC(v.t[lo:lo + cnt], v.c) if type(v) is NHWC else
+                             PairMap(v.t[lo:lo + cnt], v.c, v.sigmoid) if type(v) is PairMap else v[lo:lo + cnt])
                     if i < len(a):
                         a[i] = piece
                     else:
                         kw[name] = piece
-                outs.append(fn(*a, **kw))
-            return _cat_results(outs)
+                return fn(*a, **kw)
+            return _run_chunks(n, k, call)
         return wrapper
     return deco
 
@@ -306,7 +383,7 @@ def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cs: Optional[int] = None,
     if mask is not None:
         mask = mask.contiguous().float()
         assert mask.shape == (n, 1, h, w), mask.shape
-    y = torch.empty((n, h, w, cs), dtype=dtype, device=x.device)
+    y = _empty((n, h, w, cs), dtype=dtype, device=x.device)
     lib = _lib.load()
     _lib.check(lib.cgan_nchw_to_nhwc(_ptr(x), _ptr(mask), _ptr(y), _DT[dtype], n, c, h, w, cs, _stream()),
                "cgan_nchw_to_nhwc")
@@ -320,13 +397,13 @@ def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optio
         if paste_x is not None:
             raise RuntimeError("nhwc_to_nchw: the paste is not available on a pair map")
         _need_cuda(y.t)
-        out = torch.empty((y.n, y.c, y.h, y.w), dtype=torch.float32, device=y.t.device)
+        out = _empty((y.n, y.c, y.h, y.w), dtype=torch.float32, device=y.t.device)
         _lib.check(_lib.load().cgan_pair_to_nchw(_ptr(y.t), _ptr(out), y.dtype_id, y.n, y.c, y.h, y.w, int(y.sigmoid),
                                                  _stream()), "cgan_pair_to_nchw")
         return out
     _need_cuda(y.t, paste_x, paste_m)
     n, h, w, cs = y.t.shape
-    out = torch.empty((n, y.c, h, w), dtype=torch.float32, device=y.t.device)
+    out = _empty((n, y.c, h, w), dtype=torch.float32, device=y.t.device)
     if paste_x is not None:
         paste_x = paste_x.contiguous().float()
         paste_m = paste_m.contiguous().float()
@@ -341,7 +418,7 @@ def nhwc_to_nchw(y: NHWC, paste_x: Optional[torch.Tensor] = None, paste_m: Optio
 def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None) -> NHWC:
     if isinstance(x, PairMap):
         _plain_pair(x, "resize_nearest")
-        y = torch.empty((x.n, size[0], size[1], x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        y = _empty((x.n, size[0], size[1], x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
         _lib.check(_lib.load().cgan_pair_resize_nearest(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, size[0], size[1],
                                                         _stream()),
                    "cgan_pair_resize_nearest")
@@ -349,7 +426,7 @@ def resize_nearest(x: NHWC, size: Tuple[int, int], cs_out: Optional[int] = None)
     _need_cuda(x.t)
     oh, ow = size
     cs_out = cs_out or x.cs
-    y = torch.empty((x.n, oh, ow, cs_out), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, oh, ow, cs_out), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_resize_nearest_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, x.cs, oh, ow, cs_out,
                                             _stream()), "cgan_resize_nearest_nhwc")
@@ -361,7 +438,7 @@ def resize_nearest_bwd(dy: NHWC, size_in: Tuple[int, int], cs_in: int) -> NHWC:
     """Adjoint of ``resize_nearest``: the gradient of the (h_in, w_in) source map with ``cs_in`` storage channels."""
     _need_cuda(dy.t)
     hi, wi = size_in
-    dx = torch.empty((dy.n, hi, wi, cs_in), dtype=dy.t.dtype, device=dy.t.device)
+    dx = _empty((dy.n, hi, wi, cs_in), dtype=dy.t.dtype, device=dy.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_resize_nearest_bwd_nhwc(_ptr(dy.t), _ptr(dx), dy.dtype_id, dy.n, dy.c, hi, wi, cs_in, dy.h, dy.w,
                                                 dy.cs, _stream()), "cgan_resize_nearest_bwd_nhwc")
@@ -372,7 +449,7 @@ def resize_nearest_bwd(dy: NHWC, size_in: Tuple[int, int], cs_in: int) -> NHWC:
 def avgpool3x3s2(x: NHWC) -> NHWC:
     _need_cuda(x.t)
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
-    y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_avgpool3x3s2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
                "cgan_avgpool3x3s2_nhwc")
@@ -383,13 +460,13 @@ def avgpool3x3s2(x: NHWC) -> NHWC:
 def maxpool3x3s2(x: NHWC) -> NHWC:
     if isinstance(x, PairMap):
         _plain_pair(x, "maxpool3x3s2")
-        y = torch.empty((x.n, (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        y = _empty((x.n, (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
         _lib.check(_lib.load().cgan_pair_maxpool3x3s2(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
                    "cgan_pair_maxpool3x3s2")
         return PairMap(y, x.c)
     _need_cuda(x.t)
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
-    y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_maxpool3x3s2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
                "cgan_maxpool3x3s2_nhwc")
@@ -400,7 +477,7 @@ def maxpool3x3s2(x: NHWC) -> NHWC:
 def resize_bilinear(x: NHWC, size: Tuple[int, int], align_corners: bool = False) -> NHWC:
     if isinstance(x, PairMap):
         _plain_pair(x, "resize_bilinear")
-        y = torch.empty((x.n, size[0], size[1], x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        y = _empty((x.n, size[0], size[1], x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
         _lib.check(_lib.load().cgan_pair_resize_bilinear(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, size[0], size[1],
                                                          int(bool(align_corners)), _stream()), "cgan_pair_resize_bilinear")
         return PairMap(y, x.c)
@@ -408,7 +485,7 @@ def resize_bilinear(x: NHWC, size: Tuple[int, int], align_corners: bool = False)
     oh, ow = size
     if x.cs != cs8(x.c):
         raise RuntimeError("resize_bilinear: input must be stored with round_up(c, 8) channels")
-    y = torch.empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, oh, ow, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_resize_bilinear_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, oh, ow,
                                              int(bool(align_corners)), _stream()), "cgan_resize_bilinear_nhwc")
@@ -421,11 +498,11 @@ def resize_bicubic(x: NHWC, size: Tuple[int, int]) -> NHWC:
     h, w = int(size[0]), int(size[1])
     if isinstance(x, PairMap):
         _plain_pair(x, "resize_bicubic")
-        y = torch.empty((x.n, h, w, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+        y = _empty((x.n, h, w, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
         _lib.check(_lib.load().cgan_pair_resize_bicubic(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, h, w, _stream()),
                    "cgan_pair_resize_bicubic")
         return PairMap(y, x.c)
-    y = torch.empty((x.n, h, w, cs8(x.c)), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, h, w, cs8(x.c)), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_resize_bicubic_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, h, w, _stream()),
                "cgan_resize_bicubic_nhwc")
@@ -469,14 +546,14 @@ def eltwise_mul(a: NHWC, b: NHWC) -> NHWC:
             raise RuntimeError("eltwise_mul: two pair maps of one shape expected")
         _plain_pair(a, "eltwise_mul")
         _plain_pair(b, "eltwise_mul")
-        y = torch.empty_like(a.t)
+        y = _empty_like(a.t)
         _lib.check(_lib.load().cgan_pair_mul(_ptr(a.t), _ptr(b.t), _ptr(y), a.dtype_id, a.n * a.h * a.w, a.c, _stream()),
                    "cgan_pair_mul")
         return PairMap(y, a.c)
     _need_cuda(a.t, b.t)
     if a.t.shape != b.t.shape or a.c != b.c:
         raise RuntimeError("eltwise_mul: shape mismatch")
-    y = torch.empty_like(a.t)
+    y = _empty_like(a.t)
     lib = _lib.load()
     _lib.check(lib.cgan_eltwise_nhwc(_ptr(a.t), _ptr(b.t), _ptr(y), a.dtype_id, 0, a.t.numel(), _stream()),
                "cgan_eltwise_nhwc")
@@ -489,7 +566,7 @@ def sigmoid(a: NHWC) -> NHWC:
         _plain_pair(a, "sigmoid")
         return PairMap(a.t, a.c, sigmoid=True)
     _need_cuda(a.t)
-    y = torch.empty_like(a.t)
+    y = _empty_like(a.t)
     lib = _lib.load()
     _lib.check(lib.cgan_eltwise_nhwc(_ptr(a.t), _ptr(None), _ptr(y), a.dtype_id, 1, a.t.numel(), _stream()),
                "cgan_eltwise_nhwc")
@@ -501,7 +578,7 @@ def scale_by_scalar(a: NHWC, s: torch.Tensor) -> NHWC:
     _need_cuda(a.t, s)
     if s.dtype != torch.float32 or s.numel() != 1:
         raise RuntimeError("scale_by_scalar: one fp32 device scalar expected")
-    y = torch.empty_like(a.t)
+    y = _empty_like(a.t)
     lib = _lib.load()
     _lib.check(lib.cgan_eltwise_nhwc(_ptr(a.t), _ptr(s), _ptr(y), a.dtype_id, 2, a.t.numel(), _stream()),
                "cgan_eltwise_nhwc")
@@ -513,8 +590,8 @@ def fold_bn(w: torch.Tensor, bias, bn_weight, bn_bias, running_mean, running_var
     _need_cuda(w, bias, bn_weight, bn_bias, running_mean, running_var)
     w = w.detach().contiguous().float()
     c_out = w.shape[0]
-    w_out = torch.empty_like(w)
-    b_out = torch.empty(c_out, dtype=torch.float32, device=w.device)
+    w_out = _empty_like(w)
+    b_out = _empty(c_out, dtype=torch.float32, device=w.device)
     ts = [t.detach().contiguous().float() if t is not None else None
           for t in (bias, bn_weight, bn_bias, running_mean, running_var)]
     lib = _lib.load()
@@ -534,8 +611,8 @@ def normalize_to_uint8(x: torch.Tensor) -> torch.Tensor:
     n, c, h, w = x.shape
     lib = _lib.load()
     nbytes = lib.cgan_normalize_u8_workspace_bytes(n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    ws = _empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = _empty((n, h, w, c), dtype=torch.uint8, device=x.device)
     _lib.check(lib.cgan_normalize_u8_nhwc(_ptr(x), int(x.dtype == torch.float16), _ptr(out), n, c, h, w, _ptr(ws),
                                           nbytes, _stream()), "cgan_normalize_u8_nhwc")
     return out
@@ -547,8 +624,8 @@ def binarize(x: torch.Tensor, threshold: float, want_float: bool = True, want_ui
     if x.dtype not in (torch.float32, torch.float16):
         raise RuntimeError("binarize: fp32 or fp16 input expected, got %s" % x.dtype)
     x = x.contiguous()
-    y = torch.empty_like(x) if want_float else None
-    y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_uint8 else None
+    y = _empty_like(x) if want_float else None
+    y8 = _empty(x.shape, dtype=torch.uint8, device=x.device) if want_uint8 else None
     lib = _lib.load()
     _lib.check(lib.cgan_binarize(_ptr(x), int(x.dtype == torch.float16), _ptr(y), _ptr(y8), float(threshold),
                                  x.numel(), _stream()), "cgan_binarize")
@@ -569,8 +646,8 @@ def smog(x: torch.Tensor, depth: NHWC, airlight: float, beta: float, alpha: floa
         raise RuntimeError("smog: x must be [n,3,h,w] with the depth map's batch size")
     lib = _lib.load()
     nbytes = lib.cgan_smog_workspace_bytes(n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    out = torch.empty_like(x)
+    ws = _empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = _empty_like(x)
     yel = (C.c_float * 3)(*[float(v) for v in yellow_rgb01])
     _lib.check(lib.cgan_smog_nchw(_ptr(x), _ptr(depth.t), depth.dtype_id, _ptr(out), n, h, w, depth.h, depth.w,
                                   float(airlight), float(beta), float(alpha), yel, _ptr(ws), nbytes, _stream()),
@@ -589,8 +666,8 @@ def cloudy_cond(x: torch.Tensor, m: torch.Tensor, seg: NHWC, angles: torch.Tenso
     ry, rx = angles.shape[0] - 1, angles.shape[1] - 1
     lib = _lib.load()
     nbytes = lib.cgan_cloudy_cond_workspace_bytes(h, w)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    cond = torch.empty((n, h, w, 4), dtype=seg.t.dtype, device=x.device)
+    ws = _empty(nbytes, dtype=torch.uint8, device=x.device)
+    cond = _empty((n, h, w, 4), dtype=seg.t.dtype, device=x.device)
     _lib.check(lib.cgan_cloudy_cond_nhwc(_ptr(x), _ptr(m), _ptr(seg.t), _ptr(angles), _ptr(cond), seg.dtype_id, n, h, w,
                                          seg.h, seg.w, seg.c, int(sky_idx), ry, rx, float(weight), _ptr(ws), nbytes,
                                          _stream()), "cgan_cloudy_cond_nhwc")
@@ -609,8 +686,8 @@ def batchnorm_train_stats(x: NHWC, gamma, beta, running_mean, running_var, num_b
     cs = x.t.shape[-1]
     d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, float(eps))
     ws_bytes = lib.cgan_instnorm_stats_workspace_bytes(C.byref(d))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.t.device)
-    stats = torch.empty((4, x.n, cs), dtype=torch.float32, device=x.t.device)
+    ws = _empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.t.device)
+    stats = _empty((4, x.n, cs), dtype=torch.float32, device=x.t.device)
     _lib.check(lib.cgan_batchnorm_train_stats(
         _ptr(x.t), _ptr(gamma), _ptr(beta), float(momentum), _ptr(running_mean), _ptr(running_var),
         _ptr(num_batches_tracked), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), C.byref(d), _ptr(ws),
@@ -626,8 +703,8 @@ def bn_eval_stats(bn, n: int):
     c = rm.numel()
     g = bn.weight.detach().float().contiguous() if getattr(bn, "affine", False) and bn.weight is not None else None
     b = bn.bias.detach().float().contiguous() if getattr(bn, "affine", False) and bn.bias is not None else None
-    mean = torch.empty((n, cs8(c)), dtype=torch.float32, device=rm.device)
-    rstd = torch.empty_like(mean)
+    mean = _empty((n, cs8(c)), dtype=torch.float32, device=rm.device)
+    rstd = _empty_like(mean)
     lib = _lib.load()
     _lib.check(lib.cgan_bn_eval_stats(_ptr(g), _ptr(b), _ptr(rm.float().contiguous()), _ptr(rv.float().contiguous()),
                                       float(bn.eps), _ptr(mean), _ptr(rstd), n, c, _stream()), "cgan_bn_eval_stats")
@@ -639,7 +716,7 @@ def make_m_cond_bwd(dcond: NHWC, d: NHWC, s: NHWC, with_x: bool):
     _need_cuda(dcond.t, d.t, s.t)
     if dcond.c != 1 + s.c + (3 if with_x else 0) or (dcond.n, dcond.h, dcond.w) != (s.n, s.h, s.w):
         raise RuntimeError("make_m_cond_bwd: the conditioning gradient does not match d / s")
-    dd, ds = torch.empty_like(d.t), torch.empty_like(s.t)
+    dd, ds = _empty_like(d.t), _empty_like(s.t)
     lib = _lib.load()
     _lib.check(lib.cgan_make_m_cond_bwd_nhwc(_ptr(dcond.t), _ptr(d.t), _ptr(s.t), _ptr(dd), _ptr(ds), d.dtype_id, d.n, d.h,
                                              d.w, s.c, int(bool(with_x)), _stream()), "cgan_make_m_cond_bwd_nhwc")
@@ -661,8 +738,8 @@ def make_m_cond(d: NHWC, s: NHWC, x: Optional[torch.Tensor]) -> NHWC:
         xx = x.contiguous().float() if x is not None else None
         lib = _lib.load()
         nbytes = lib.cgan_pair_make_m_cond_workspace_bytes(d.n)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=d.t.device)
-        cond = torch.empty((d.n, d.h, d.w, d.nb * cs8(cond_c)), dtype=d.t.dtype, device=d.t.device)
+        ws = _empty(nbytes, dtype=torch.uint8, device=d.t.device)
+        cond = _empty((d.n, d.h, d.w, d.nb * cs8(cond_c)), dtype=d.t.dtype, device=d.t.device)
         _lib.check(lib.cgan_pair_make_m_cond(_ptr(d.t), _ptr(s.t), _ptr(xx), _ptr(cond), d.dtype_id, d.n, d.h, d.w, s.c,
                                              xx.shape[-2] if xx is not None else 0, xx.shape[-1] if xx is not None else 0,
                                              _ptr(ws), nbytes, _stream()), "cgan_pair_make_m_cond")
@@ -673,8 +750,8 @@ def make_m_cond(d: NHWC, s: NHWC, x: Optional[torch.Tensor]) -> NHWC:
     xx = x.contiguous().float() if x is not None else None
     lib = _lib.load()
     nbytes = lib.cgan_make_m_cond_workspace_bytes(d.n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=d.t.device)
-    cond = torch.empty((d.n, d.h, d.w, cs4(cond_c)), dtype=d.t.dtype, device=d.t.device)
+    ws = _empty(nbytes, dtype=torch.uint8, device=d.t.device)
+    cond = _empty((d.n, d.h, d.w, cs4(cond_c)), dtype=d.t.dtype, device=d.t.device)
     _lib.check(lib.cgan_make_m_cond_nhwc(_ptr(d.t), _ptr(s.t), _ptr(xx), _ptr(cond), d.dtype_id, d.n, d.h, d.w, s.c,
                                          xx.shape[-2] if xx is not None else 0, xx.shape[-1] if xx is not None else 0,
                                          _ptr(ws), nbytes, _stream()), "cgan_make_m_cond_nhwc")
@@ -694,8 +771,8 @@ def wildfire(x: torch.Tensor, seg: NHWC, filter_green: float, kernel_size=281, k
     nbytes = lib.cgan_wildfire_workspace_bytes(n, h, w, seg.h, seg.w, int(kernel_size))
     if nbytes == 0:
         _lib.check(-1, "cgan_wildfire_workspace_bytes")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    out = torch.empty_like(x)
+    ws = _empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = _empty_like(x)
     _lib.check(lib.cgan_wildfire_nchw(_ptr(x), _ptr(seg.t), seg.dtype_id, _ptr(out), n, h, w, seg.h, seg.w, seg.c,
                                       int(sky_idx), int(kernel_size), float(kernel_sigma), float(transparency),
                                       int(bool(crop_bottom)), float(filter_green), _ptr(ws), nbytes, _stream()),
@@ -733,7 +810,7 @@ def pack_conv_weight(w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch
     w = w.detach().contiguous().float()
     if pair:
         c_out, c_in, kh, kw = w.shape
-        w3 = torch.empty((c_out, split_blocks(dtype) * cs8(c_in), kh, kw), dtype=torch.float32, device=w.device)
+        w3 = _empty((c_out, split_blocks(dtype) * cs8(c_in), kh, kw), dtype=torch.float32, device=w.device)
         _lib.check(_lib.load().cgan_pair_expand_weight(_ptr(w), _ptr(sigma), _ptr(w3), _DT[dtype], c_out, c_in, kh, kw,
                                                        _stream()), "cgan_pair_expand_weight")
         pk = pack_conv_weight(w3, bias, dtype)
@@ -745,8 +822,8 @@ def pack_conv_weight(w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch
     nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
     if nbytes == 0:
         _lib.check(-1, "cgan_conv2d_packed_weight_bytes")
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    bias_out = torch.empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=w.device)
+    packed = _empty(nbytes, dtype=torch.uint8, device=w.device)
+    bias_out = _empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=w.device)
     b = bias.detach().contiguous().float() if bias is not None else None
     _lib.check(lib.cgan_conv2d_pack_weight(_ptr(w), _ptr(b), _ptr(sigma), _ptr(packed), _ptr(bias_out), C.byref(d),
                                            _stream()), "cgan_conv2d_pack_weight")
@@ -780,8 +857,8 @@ def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
         pk = reuse[i] if reuse is not None else None
         if pk is None or pk.w.numel() != nbytes or pk.dtype != dtype or (pk.c_out, pk.c_in, pk.kh, pk.kw) != (c_out, c_in, kh, kw) \
                 or pk.has_bias != (b is not None) or pk.w.device != dev:
-            pk = PackedConv(torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                            torch.empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=dev),
+            pk = PackedConv(_empty(nbytes, dtype=torch.uint8, device=dev),
+                            _empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=dev),
                             c_in, c_out, kh, kw, b is not None, dtype)
         out.append(pk)
         max_frag = max(max_frag, nbytes // 16)
@@ -801,22 +878,32 @@ def pack_conv_weights_batched(params, dtype: torch.dtype, reuse=None):
 _PACK_TABLES = []
 
 CONV_WS_BYTES = 64 << 20
-_CONV_WS = {}
+CONV_WS_KEEP = 8          # (library, device, stream) bindings kept alive; the least recently bound one is released beyond that
+_CONV_WS = {}             # key -> buffer, or None when the library refused the binding (split-K off for that stream)
 
 
 def _conv_ws() -> None:
-    """Bind (once per library build and stream) the calling stream's split-K scratch buffer for the convolution entry points
-    (cgan_conv2d_bind_workspace): the small-grid / long-K layers then run as K slices of the LDS-tiled GEMM."""
+    """Bind (once per library build, device and stream) the calling stream's split-K scratch buffer for the convolution entry
+    points (cgan_conv2d_bind_workspace): the small-grid / long-K layers then run as K slices of the LDS-tiled GEMM.  A refused
+    binding is not an error -- those layers run on the general kernel, as include/climategan_hip.h documents.  At most
+    CONV_WS_KEEP buffers stay allocated: a process that walks through many streams (every Trainer takes a side stream from
+    torch's pool of 32 per device) unbinds and frees the oldest instead of pinning 64 MiB per stream for ever."""
     lib = _lib.load()
     st = _stream()
-    key = (id(lib), st.value, _GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device())
-    if key not in _CONV_WS:
-        buf = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device="cuda")
-        rc = lib.cgan_conv2d_bind_workspace(st, C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()))
-        if rc != 0:
-            msg = lib.cgan_last_error()
-            raise RuntimeError("cgan_conv2d_bind_workspace failed (status %d): %s" % (rc, msg.decode() if msg else "?"))
-        _CONV_WS[key] = buf
+    dev = _GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device()
+    key = (id(lib), st.value, dev)
+    if key in _CONV_WS:
+        return
+    while len(_CONV_WS) >= CONV_WS_KEEP:
+        (olib, ostream, odev), obuf = next(iter(_CONV_WS.items()))
+        if obuf is not None:
+            # the buffer goes back to the allocator of the stream it was taken on: reuse is ordered after that stream's launches
+            with torch.cuda.device(odev):
+                lib.cgan_conv2d_bind_workspace(C.c_void_p(ostream), C.c_void_p(0), C.c_size_t(0))
+        del _CONV_WS[(olib, ostream, odev)]
+    buf = _empty(CONV_WS_BYTES, dtype=torch.uint8, device="cuda")
+    rc = lib.cgan_conv2d_bind_workspace(st, C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()))
+    _CONV_WS[key] = buf if rc == 0 else None
 
 
 @_batch_chunked("x", "residual", out_bytes_per_sample=lambda g: (lambda hw: hw[0] * hw[1] * cs8(g("pw").c_out) * 2 * _nbf(g("x")))(
@@ -835,7 +922,7 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
         h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
         d = _conv_desc(x.dtype_id, x.n, h_in, w_in, x.nb * x.cs, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode,
                        in_upsample, act, slope, pw.has_bias, residual is not None, residual_upsample)
-        y = torch.empty((x.n, d.h_out, d.w_out, x.nb * cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
+        y = _empty((x.n, d.h_out, d.w_out, x.nb * cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
         _lib.check(_lib.load().cgan_conv2d_nhwc_fwd_pair(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias),
                                                          _ptr(residual.t if residual is not None else None), _ptr(y),
                                                          C.byref(d), _stream()), "cgan_conv2d_nhwc_fwd_pair")
@@ -855,7 +942,7 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
         rh, rw = (residual.h * 2, residual.w * 2) if residual_upsample else (residual.h, residual.w)
         if (rh, rw) != (d.h_out, d.w_out) or residual.c != pw.c_out or residual.n != x.n:
             raise RuntimeError("conv2d: residual shape mismatch")
-    y = torch.empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _conv_ws()
     _lib.check(lib.cgan_conv2d_nhwc_fwd(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias), _ptr(residual.t if residual else None),
@@ -908,7 +995,7 @@ def dgrad_prepack_run(also_used_on=None) -> int:
             nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
             if nbytes == 0:
                 _lib.check(-1, "cgan_conv2d_packed_weight_bytes")
-            h.packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            h.packed = _empty(nbytes, dtype=torch.uint8, device=dev)
             max_frag = max(max_frag, nbytes // 16)
             items[i] = PackItem(h.w.data_ptr(), 0, h.sigma.data_ptr() if h.sigma is not None else 0, h.packed.data_ptr(), 0,
                                 c_out, c_in, kh, kw, 1)
@@ -951,8 +1038,8 @@ def conv2d_with_stats(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_
     npix = x.n * d.h_out * d.w_out
     if ppb <= 0 or x.n % groups or (npix // groups) % ppb:
         return conv2d(x, pw, stride=stride, pad=pad, dilation=dilation, pad_mode=pad_mode), None
-    y = torch.empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
-    partial = torch.empty((npix // ppb, cs8(pw.c_out), 2), dtype=torch.float32, device=x.t.device)
+    y = _empty((x.n, d.h_out, d.w_out, cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
+    partial = _empty((npix // ppb, cs8(pw.c_out), 2), dtype=torch.float32, device=x.t.device)
     _lib.check(lib.cgan_conv2d_nhwc_fwd_stats(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias), _ptr(y), _ptr(partial),
                                               partial.numel() * 4, C.byref(d), _stream()), "cgan_conv2d_nhwc_fwd_stats")
     return NHWC(y, pw.c_out), ConvStats(partial, ppb)
@@ -965,7 +1052,7 @@ def batchnorm_train_stats_from_partials(st: ConvStats, groups: int, pix_per_grou
     lib = _lib.load()
     cs = st.partial.shape[1]
     d = NormStatsDesc(CGAN_BF16, groups, pix_per_group, c, float(eps))
-    stats = torch.empty((4, groups, cs), dtype=torch.float32, device=st.partial.device)
+    stats = _empty((4, groups, cs), dtype=torch.float32, device=st.partial.device)
     _lib.check(lib.cgan_batchnorm_train_stats_from_partials(
         _ptr(st.partial), int(st.chunk_pixels), _ptr(gamma), _ptr(beta), float(momentum), _ptr(running_mean),
         _ptr(running_var), _ptr(num_batches_tracked), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]),
@@ -979,7 +1066,7 @@ def reflect_pad_bwd(dxp: NHWC, pad: int) -> NHWC:
     """Backward of nn.ReflectionPad2d(pad): folds the gradient of the padded tensor onto the unpadded extent."""
     _need_cuda(dxp.t)
     h, w = dxp.h - 2 * pad, dxp.w - 2 * pad
-    dx = torch.empty((dxp.n, h, w, dxp.cs), dtype=dxp.t.dtype, device=dxp.t.device)
+    dx = _empty((dxp.n, h, w, dxp.cs), dtype=dxp.t.dtype, device=dxp.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_reflect_pad_bwd_nhwc(_ptr(dxp.t), _ptr(dx), dxp.dtype_id, dxp.n, dxp.c, h, w, int(pad), _stream()),
                "cgan_reflect_pad_bwd_nhwc")
@@ -1006,11 +1093,10 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
         k = (MAX_MAP_BYTES - 1) // per_sample
         if k < 1:
             raise RuntimeError("conv2d_bwd_data: ONE sample's map exceeds the 2 GiB a C-ABI call covers")
-        return _cat_results([conv2d_bwd_data(NHWC(dy.t[lo:lo + k], dy.c), w, (min(k, x_shape[0] - lo), x_shape[1], x_shape[2]),
-                                             stride, pad, dilation, sigma, pad_mode,
-                                             NHWC(add.t[lo:lo + k], add.c) if add is not None else None, prepacked,
-                                             NHWC(relu_out.t[lo:lo + k], relu_out.c) if relu_out is not None else None)
-                             for lo in range(0, x_shape[0], k)])
+        return _run_chunks(x_shape[0], k, lambda lo, cnt: conv2d_bwd_data(
+            NHWC(dy.t[lo:lo + cnt], dy.c), w, (cnt, x_shape[1], x_shape[2]), stride, pad, dilation, sigma, pad_mode,
+            NHWC(add.t[lo:lo + cnt], add.c) if add is not None else None, prepacked,
+            NHWC(relu_out.t[lo:lo + cnt], relu_out.c) if relu_out is not None else None))
     if add is not None and not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1)
                                 and w.shape[2] == w.shape[3]):
         dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode, prepacked=prepacked)
@@ -1036,10 +1122,10 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
             and prepacked.packed.numel() == nbytes and tuple(prepacked.w.shape) == tuple(w.shape)):
         packed = prepacked.packed                            # packed with the whole backward's operators in one launch
     else:
-        packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        packed = _empty(nbytes, dtype=torch.uint8, device=w.device)
         _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w), _ptr(sigma), _ptr(packed), C.byref(d), _stream()),
                    "cgan_conv2d_pack_weight_dgrad")
-    dx = torch.empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
+    dx = _empty((n, h_in, w_in, cs8(c_in)), dtype=dy.t.dtype, device=dy.t.device)
     _conv_ws()
     if relu_out is not None:
         if relu_out.t.shape != dx.shape or relu_out.t.dtype != dx.dtype or not relu_out.t.is_contiguous():
@@ -1064,7 +1150,7 @@ def sumpool2x2(x: NHWC) -> NHWC:
     _need_cuda(x.t)
     if x.h % 2 or x.w % 2 or x.cs != cs8(x.c):
         raise RuntimeError("sumpool2x2: even extent and round_up(c, 8) storage expected")
-    y = torch.empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_sumpool2x2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h // 2, x.w // 2, _stream()),
                "cgan_sumpool2x2_nhwc")
@@ -1139,7 +1225,7 @@ def conv2d_bwd_weight(x: NHWC, dy: NHWC, w_shape, stride=1, pad=0, dilation=1, w
         dbias = zeros_f32(c_out, x.t.device)
     lib = _lib.load()
     ws_bytes = lib.cgan_conv2d_bwd_weight_workspace_bytes(C.byref(d)) if use_workspace else 0
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.t.device) if ws_bytes else None
+    ws = _empty(ws_bytes, dtype=torch.uint8, device=x.t.device) if ws_bytes else None
     _lib.check(lib.cgan_conv2d_nhwc_bwd_weight(_ptr(x.t), _ptr(dy.t), _ptr(dw), _ptr(dbias if want_bias else None),
                                                C.byref(d), _ptr(ws), ws_bytes, _stream()),
                "cgan_conv2d_nhwc_bwd_weight")
@@ -1153,8 +1239,8 @@ def instnorm_stats(x: NHWC, eps: float = 1e-5):
     if isinstance(x, PairMap):          # split-precision Painter: fp64 two-pass statistics of the summed components
         _plain_pair(x, "instnorm_stats")
         _need_cuda(x.t)
-        mean = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
-        rstd = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+        mean = _empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+        rstd = _empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
         _lib.check(_lib.load().cgan_pair_instnorm_stats(_ptr(x.t), _ptr(mean), _ptr(rstd), x.dtype_id, x.n, x.c, x.h * x.w,
                                                         float(eps), _stream()), "cgan_pair_instnorm_stats")
         return mean, rstd
@@ -1162,9 +1248,9 @@ def instnorm_stats(x: NHWC, eps: float = 1e-5):
     d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, eps)
     lib = _lib.load()
     ws_bytes = lib.cgan_instnorm_stats_workspace_bytes(C.byref(d))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.t.device)
-    mean = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
-    rstd = torch.empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+    ws = _empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.t.device)
+    mean = _empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
+    rstd = _empty((x.n, x.cs), dtype=torch.float32, device=x.t.device)
     _lib.check(lib.cgan_instnorm_stats(_ptr(x.t), _ptr(mean), _ptr(rstd), C.byref(d), _ptr(ws), ws_bytes, _stream()),
                "cgan_instnorm_stats")
     return mean, rstd
@@ -1178,13 +1264,13 @@ def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2, residual: NHWC 
             raise RuntimeError("norm_act_apply: no residual on a split map")
         _plain_pair(x, "norm_act_apply")
         _need_cuda(mean, rstd)
-        y = torch.empty_like(x.t)
+        y = _empty_like(x.t)
         _lib.check(_lib.load().cgan_pair_spade_apply(_ptr(x.t), _ptr(mean), _ptr(rstd), None, None, _ptr(y), x.dtype_id, x.n, x.h,
                                                      x.w, x.c, 0, int(act), float(slope), _stream()), "cgan_pair_spade_apply")
         return PairMap(y, x.c)
     _need_cuda(x.t, mean, rstd)
     d = NormStatsDesc(x.dtype_id, x.n, x.h * x.w, x.c, 0.0)
-    y = torch.empty_like(x.t)
+    y = _empty_like(x.t)
     lib = _lib.load()
     if residual is not None:
         _need_cuda(residual.t)
@@ -1202,7 +1288,7 @@ def norm_act_apply(x: NHWC, mean, rstd, act=ACT_NONE, slope=0.2, residual: NHWC 
 def act_bwd(out: NHWC, dy: NHWC, act, slope=0.2) -> NHWC:
     """dx = dy * act'(.) with the derivative taken from the activation's output."""
     _need_cuda(out.t, dy.t)
-    dx = torch.empty_like(out.t)
+    dx = _empty_like(out.t)
     lib = _lib.load()
     _lib.check(lib.cgan_act_bwd(_ptr(out.t), _ptr(dy.t), _ptr(dx), out.dtype_id, act, slope, out.t.numel(), _stream()),
                "cgan_act_bwd")
@@ -1216,8 +1302,8 @@ def instnorm_act_bwd(out: NHWC, dy: NHWC, rstd: torch.Tensor, act=ACT_NONE, slop
     d = NormStatsDesc(out.dtype_id, out.n, out.h * out.w, out.c, 0.0)
     lib = _lib.load()
     nbytes = lib.cgan_instnorm_act_bwd_workspace_bytes(C.byref(d))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=out.t.device)
-    dx = torch.empty_like(out.t)
+    ws = _empty(nbytes, dtype=torch.uint8, device=out.t.device)
+    dx = _empty_like(out.t)
     _lib.check(lib.cgan_instnorm_act_bwd(_ptr(out.t), _ptr(dy.t), _ptr(rstd), _ptr(dx), C.byref(d), act, slope,
                                          _ptr(ws), nbytes, _stream()), "cgan_instnorm_act_bwd")
     return NHWC(dx, out.c)
@@ -1227,7 +1313,7 @@ def instnorm_act_bwd(out: NHWC, dy: NHWC, rstd: torch.Tensor, act=ACT_NONE, slop
 def bce_logits(x: NHWC, target: float, weight: float, loss_accum: torch.Tensor, want_grad=True):
     """loss_accum += weight * sum BCEWithLogits(x, target) over x's logical channels; returns d(loss)/dx or None."""
     _need_cuda(x.t, loss_accum)
-    dx = torch.empty_like(x.t) if want_grad else None
+    dx = _empty_like(x.t) if want_grad else None
     lib = _lib.load()
     _lib.check(lib.cgan_bce_logits_nhwc(_ptr(x.t), x.dtype_id, x.n * x.h * x.w, x.c, float(target), float(weight),
                                         _ptr(loss_accum), _ptr(dx), _stream()), "cgan_bce_logits_nhwc")
@@ -1240,7 +1326,7 @@ def hinge_loss(x: NHWC, target_is_real: bool, for_discriminator: bool, weight: f
     """loss_accum += weight * sum HingeLoss.loss terms of x's logical channels (reference losses.py:565-579); returns
     d(loss)/dx or None."""
     _need_cuda(x.t, loss_accum)
-    dx = torch.empty_like(x.t) if want_grad else None
+    dx = _empty_like(x.t) if want_grad else None
     lib = _lib.load()
     _lib.check(lib.cgan_hinge_nhwc(_ptr(x.t), x.dtype_id, x.n * x.h * x.w, x.c, int(bool(target_is_real)),
                                    int(bool(for_discriminator)), float(weight), _ptr(loss_accum), _ptr(dx), _stream()),
@@ -1254,7 +1340,7 @@ def l1_loss(a: NHWC, b: NHWC, weight: float, loss_accum: torch.Tensor, want_grad
     _need_cuda(a.t, b.t, loss_accum)
     if a.t.shape != b.t.shape:
         raise RuntimeError("l1_loss: shape mismatch")
-    da = torch.empty_like(a.t) if want_grad else None
+    da = _empty_like(a.t) if want_grad else None
     lib = _lib.load()
     _lib.check(lib.cgan_l1_nhwc(_ptr(a.t), _ptr(b.t), a.dtype_id, a.t.numel(), float(weight), _ptr(loss_accum),
                                 _ptr(da), _stream()), "cgan_l1_nhwc")
@@ -1267,7 +1353,7 @@ def spectral_norm_bwd(grad_w: torch.Tensor, w_bar: torch.Tensor, u: torch.Tensor
     _need_cuda(grad_w, w_bar, u, v, sigma)
     rows = w_bar.shape[0]
     cols = w_bar.numel() // rows
-    scratch = torch.empty(1024, dtype=torch.float32, device=grad_w.device)      # CGAN_SN_BWD_WORKSPACE_FLOATS
+    scratch = _empty(1024, dtype=torch.float32, device=grad_w.device)      # CGAN_SN_BWD_WORKSPACE_FLOATS
     lib = _lib.load()
     _lib.check(lib.cgan_spectral_norm_bwd(_ptr(grad_w), _ptr(w_bar), _ptr(u), _ptr(v), _ptr(sigma), rows, cols,
                                           _ptr(scratch), _stream()), "cgan_spectral_norm_bwd")
@@ -1297,7 +1383,7 @@ def pack_spade_weights(w_shared, b_shared, w_gamma, b_gamma, w_beta, b_beta, dty
     nbytes = lib.cgan_spade_packed_weight_bytes(C.byref(d))
     if nbytes == 0:
         _lib.check(-1, "cgan_spade_packed_weight_bytes")
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w_gamma.device)
+    buf = _empty(nbytes, dtype=torch.uint8, device=w_gamma.device)
     ts = [t.detach().contiguous().float() for t in (w_shared, b_shared, w_gamma, b_gamma, w_beta, b_beta)]
     _lib.check(lib.cgan_spade_pack_weights(*[_ptr(t) for t in ts], _ptr(buf), C.byref(d), _stream()),
                "cgan_spade_pack_weights")
@@ -1318,10 +1404,10 @@ def spade_fused(x: NHWC, mean, rstd, cond: NHWC, pk: PackedSpade, act=ACT_NONE, 
         raise RuntimeError("spade_fused: dtype mismatch")
     h, w = (x.h * 2, x.w * 2) if x_upsample else (x.h, x.w)
     d = _spade_desc(x.dtype_id, x.n, h, w, x.c, x_upsample, cond.h, cond.w, cond.c, act, slope)
-    y = torch.empty((x.n, h, w, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, h, w, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     if want_gamma:
-        gamma = torch.empty_like(y)
+        gamma = _empty_like(y)
         _lib.check(lib.cgan_spade_fused_fwd_train(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(cond.t), _ptr(pk.buf), _ptr(y),
                                                   _ptr(gamma), C.byref(d), _stream()), "cgan_spade_fused_fwd_train")
         return NHWC(y, x.c), NHWC(gamma, x.c)
@@ -1336,9 +1422,9 @@ def spade_bwd_prepare(dy: NHWC, y: NHWC, x: NHWC, mean, rstd, gamma: NHWC, act=A
     _need_cuda(dy.t, y.t, x.t, mean, rstd, gamma.t)
     c = y.c
     d = _spade_desc(y.dtype_id, y.n, y.h, y.w, c, x_upsample, y.h, y.w, 3, act, slope)
-    dgb = torch.empty((y.n, y.h, y.w, cs8(2 * c)), dtype=y.t.dtype, device=y.t.device)
-    xhat = torch.empty_like(y.t)
-    dxhat = torch.empty_like(y.t)
+    dgb = _empty((y.n, y.h, y.w, cs8(2 * c)), dtype=y.t.dtype, device=y.t.device)
+    xhat = _empty_like(y.t)
+    dxhat = _empty_like(y.t)
     lib = _lib.load()
     _lib.check(lib.cgan_spade_bwd_prepare(_ptr(dy.t), _ptr(y.t), _ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(gamma.t),
                                           _ptr(dgb), _ptr(xhat), _ptr(dxhat), C.byref(d), _stream()),
@@ -1354,7 +1440,7 @@ def pair_spade_apply(x: "PairMap", mean, rstd, gamma: "PairMap", beta: "PairMap"
     h, w = (x.h * 2, x.w * 2) if x_upsample else (x.h, x.w)
     if (gamma.n, gamma.h, gamma.w, gamma.c) != (x.n, h, w, x.c) or gamma.t.shape != beta.t.shape or gamma.t.dtype != x.t.dtype:
         raise RuntimeError("pair_spade_apply: gamma / beta must be pair maps of x's channels at the output extent")
-    y = torch.empty((x.n, h, w, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, h, w, x.nb * x.cs), dtype=x.t.dtype, device=x.t.device)
     _lib.check(_lib.load().cgan_pair_spade_apply(_ptr(x.t), _ptr(mean), _ptr(rstd), _ptr(gamma.t), _ptr(beta.t), _ptr(y), x.dtype_id,
                                                  x.n, h, w, x.c, int(bool(x_upsample)), int(act), float(slope), _stream()),
                "cgan_pair_spade_apply")
@@ -1376,11 +1462,11 @@ def spade_hidden_bwd(dgb: NHWC, w_gb: torch.Tensor, seg: NHWC, pw_shared: Packed
     nbytes = lib.cgan_conv2d_dgrad_packed_weight_bytes(C.byref(dconv))
     if nbytes == 0:
         _lib.check(-1, "cgan_conv2d_dgrad_packed_weight_bytes")
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=w_gb.device)
+    packed = _empty(nbytes, dtype=torch.uint8, device=w_gb.device)
     _lib.check(lib.cgan_conv2d_pack_weight_dgrad(_ptr(w_gb), _ptr(None), _ptr(packed), C.byref(dconv), _stream()),
                "cgan_conv2d_pack_weight_dgrad")
     d = _spade_desc(dgb.dtype_id, n, h, w, c, False, h, w, seg.c, ACT_NONE)
-    ws = torch.empty(lib.cgan_spade_hidden_bwd_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dgb.t.device)
+    ws = _empty(lib.cgan_spade_hidden_bwd_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dgb.t.device)
     dw = zeros_f32(hidden * seg.c * 9, dgb.t.device).view(hidden, seg.c, 3, 3)
     db = zeros_f32(hidden, dgb.t.device) if want_bias else None
     _lib.check(lib.cgan_spade_hidden_bwd(_ptr(dgb.t), _ptr(packed), _ptr(seg.t), _ptr(pw_shared.w), _ptr(pw_shared.bias), _ptr(dw),
@@ -1398,8 +1484,8 @@ def painter_heads(fake: Optional[NHWC], x: torch.Tensor, m: torch.Tensor, dtype,
     x = x.contiguous().float()
     m = m.contiguous().float()
     n, _, h, w = x.shape
-    d_in = torch.empty((n, h, w, 8), dtype=dtype, device=x.device) if want_d else None
-    v_in = torch.empty((n, h, w, 8), dtype=dtype, device=x.device) if want_vgg else None
+    d_in = _empty((n, h, w, 8), dtype=dtype, device=x.device) if want_d else None
+    v_in = _empty((n, h, w, 8), dtype=dtype, device=x.device) if want_vgg else None
     lib = _lib.load()
     _lib.check(lib.cgan_painter_heads_fwd(_ptr(fake.t if fake is not None else None), _ptr(x), _ptr(m), _ptr(d_in),
                                           _ptr(v_in), _DT[dtype], n, h, w, _stream()), "cgan_painter_heads_fwd")
@@ -1412,7 +1498,7 @@ def painter_heads_bwd(d_d_in: Optional[NHWC], d_vgg_in: Optional[NHWC], m: torch
     _need_cuda(ref.t, m)
     m = m.contiguous().float()
     n, h, w = ref.n, ref.h, ref.w
-    dfake = torch.empty((n, h, w, 8), dtype=ref.t.dtype, device=ref.t.device)
+    dfake = _empty((n, h, w, 8), dtype=ref.t.dtype, device=ref.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_painter_heads_bwd(_ptr(d_d_in.t if d_d_in is not None else None),
                                           _ptr(d_vgg_in.t if d_vgg_in is not None else None), _ptr(m), _ptr(dfake),
@@ -1424,7 +1510,7 @@ def painter_heads_bwd(d_d_in: Optional[NHWC], d_vgg_in: Optional[NHWC], m: torch
 def avgpool3x3s2_bwd(dy: NHWC, in_hw) -> NHWC:
     _need_cuda(dy.t)
     h, w = in_hw
-    dx = torch.empty((dy.n, h, w, dy.cs), dtype=dy.t.dtype, device=dy.t.device)
+    dx = _empty((dy.n, h, w, dy.cs), dtype=dy.t.dtype, device=dy.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_avgpool3x3s2_bwd_nhwc(_ptr(dy.t), _ptr(dx), dy.dtype_id, dy.n, dy.c, h, w, _stream()),
                "cgan_avgpool3x3s2_bwd_nhwc")
@@ -1434,7 +1520,7 @@ def avgpool3x3s2_bwd(dy: NHWC, in_hw) -> NHWC:
 @_batch_chunked("x")
 def maxpool2x2(x: NHWC) -> NHWC:
     _need_cuda(x.t)
-    y = torch.empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
+    y = _empty((x.n, x.h // 2, x.w // 2, x.cs), dtype=x.t.dtype, device=x.t.device)
     lib = _lib.load()
     _lib.check(lib.cgan_maxpool2x2_nhwc(_ptr(x.t), _ptr(y), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
                "cgan_maxpool2x2_nhwc")
@@ -1444,7 +1530,7 @@ def maxpool2x2(x: NHWC) -> NHWC:
 @_batch_chunked("x", "dy")
 def maxpool2x2_bwd(x: NHWC, dy: NHWC) -> NHWC:
     _need_cuda(x.t, dy.t)
-    dx = torch.empty_like(x.t)
+    dx = _empty_like(x.t)
     lib = _lib.load()
     _lib.check(lib.cgan_maxpool2x2_bwd_nhwc(_ptr(x.t), _ptr(dy.t), _ptr(dx), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
                "cgan_maxpool2x2_bwd_nhwc")
@@ -1464,8 +1550,8 @@ def spectral_norm_power_iter(w_bar: torch.Tensor, u: torch.Tensor, v: torch.Tens
     assert u.numel() == rows and v.numel() == cols
     lib = _lib.load()
     ws_bytes = lib.cgan_spectral_norm_workspace_bytes(rows, cols)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=w_bar.device)
-    sigma = torch.empty(1, dtype=torch.float32, device=w_bar.device)
+    ws = _empty(ws_bytes, dtype=torch.uint8, device=w_bar.device)
+    sigma = _empty(1, dtype=torch.float32, device=w_bar.device)
     _lib.check(lib.cgan_spectral_norm_power_iter(_ptr(w_bar), _ptr(u), _ptr(v), _ptr(sigma), rows, cols, _ptr(ws),
                                                  ws_bytes, _stream()), "cgan_spectral_norm_power_iter")
     return sigma
@@ -1488,7 +1574,7 @@ class SpectralNormGroup:
         dev = params[0][0].device
         n = len(params)
         self.n = n
-        self.sigma = torch.empty(n, dtype=torch.float32, device=dev)
+        self.sigma = _empty(n, dtype=torch.float32, device=dev)
         ws_sizes = []
         self.packed = []
         self.max_rows = self.max_cols = self.max_frag = 0
@@ -1505,13 +1591,13 @@ class SpectralNormGroup:
             d = _conv_desc(_DT[dtype], 1, kh, kw, c_in, c_out, kh, kw, 1, 0, 1, PAD_ZERO)
             nbytes = lib.cgan_conv2d_packed_weight_bytes(C.byref(d))
             self.max_frag = max(self.max_frag, nbytes // 16)
-            pw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            bo = torch.empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=dev)
+            pw = _empty(nbytes, dtype=torch.uint8, device=dev)
+            bo = _empty(((c_out + 7) // 8 * 8 + 15) // 16 * 16, dtype=torch.float32, device=dev)
             self.packed.append(PackedConv(pw, bo, c_in, c_out, kh, kw, bias is not None, dtype))
         offs = [0]
         for sz in ws_sizes:
             offs.append(offs[-1] + (sz + 255) // 256 * 256)
-        self.ws = torch.empty(offs[-1], dtype=torch.uint8, device=dev)
+        self.ws = _empty(offs[-1], dtype=torch.uint8, device=dev)
         sn_items = (SnItem * n)()
         pk_items = (PackItem * n)()
         for i, (w_bar, u, v, bias) in enumerate(params):
@@ -1583,12 +1669,12 @@ def resize_and_crop_u8(img: torch.Tensor, to: int = 640, out: Optional[torch.Ten
         radius, wts = _gaussian_taps(max(0.0, (scale - 1.0) / 2.0))
         taps.append((radius, None if wts is None else torch.from_numpy(wts).to(img.device)))
     if out is None:
-        out = torch.empty((c, to, to), dtype=torch.float32, device=img.device)
+        out = _empty((c, to, to), dtype=torch.float32, device=img.device)
     elif out.shape != (c, to, to) or out.dtype != torch.float32 or not out.is_contiguous():
         raise RuntimeError("resize_and_crop_u8: out must be a contiguous fp32 [%d, %d, %d] tensor" % (c, to, to))
     lib = _lib.load()
     ws_bytes = lib.cgan_resize_crop_u8_workspace_bytes(h, w, c)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+    ws = _empty(ws_bytes, dtype=torch.uint8, device=img.device)
     _lib.check(lib.cgan_resize_crop_u8(_ptr(img), h, w, c, to, _ptr(taps[0][1]), taps[0][0], _ptr(taps[1][1]),
                                        taps[1][0], _ptr(out), _ptr(ws), ws_bytes, _stream()), "cgan_resize_crop_u8")
     return out
@@ -1609,10 +1695,10 @@ def resize_u8(img: torch.Tensor, size) -> torch.Tensor:
     for scale in (h / rows, w / cols):
         radius, wts = _gaussian_taps(max(0.0, (scale - 1.0) / 2.0))
         taps.append((radius, None if wts is None else torch.from_numpy(wts).to(img.device)))
-    out = torch.empty((c, rows, cols), dtype=torch.float32, device=img.device)
+    out = _empty((c, rows, cols), dtype=torch.float32, device=img.device)
     lib = _lib.load()
     ws_bytes = lib.cgan_resize_crop_u8_workspace_bytes(h, w, c)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+    ws = _empty(ws_bytes, dtype=torch.uint8, device=img.device)
     _lib.check(lib.cgan_resize_u8(_ptr(img), h, w, c, rows, cols, _ptr(taps[0][1]), taps[0][0], _ptr(taps[1][1]), taps[1][0],
                                   _ptr(out), _ptr(ws), ws_bytes, _stream()), "cgan_resize_u8")
     return out

@@ -114,18 +114,26 @@ int cgan_conv2d_nhwc_fwd_stats(const void* x, const void* packed_w, const float*
 /* Which kernel the forward (bwd_data = 0) or the data-gradient (bwd_data = 1) entry point runs for a descriptor --
  * the selection is a pure function of the descriptor: CGAN_CONV_KERNEL_GENERAL (gather implicit GEMM, conv_mfma.hip),
  * _LDS3X3 (spatially tiled 3x3, conv3x3_lds.hip) or _GEMM (wide-layer implicit GEMM, conv_gemm.hip); negative = the
- * descriptor is invalid.  Measurement aid: bench.py brackets the launches of one kernel family with events. */
+ * descriptor is invalid.  Measurement aid: bench.py brackets the launches of one kernel family with events.
+ * One run-time input besides the descriptor: the small-grid / long-K layers run as split-K launches of the GEMM kernel only
+ * when the launch stream has a workspace bound that holds their partial tiles (cgan_conv2d_bind_workspace, below) -- so the
+ * kernel, and with it the fp32 summation order, of such a layer can change with the batch size (partials outgrow the
+ * workspace) and between callers that bind a workspace and callers that do not.  Results are bit-identical from run to run
+ * for a fixed (descriptor, binding); cgan_conv2d_kernel_kind_on answers for the binding of one stream of the current
+ * device, cgan_conv2d_kernel_kind for the largest workspace bound on the current device. */
 enum { CGAN_CONV_KERNEL_GENERAL = 0, CGAN_CONV_KERNEL_LDS3X3 = 1, CGAN_CONV_KERNEL_GEMM = 2 };
 /* Split-K scratch for the convolution entry points (round 5).  Layers with few output pixels and a long K -- the Painter's
  * 640-channel 3x3 convs at 5x5 .. 20x20 (climategan/painter.py:149-160), the discriminators' 512-channel 4x4 convs at
  * 20x20 / 10x10 (climategan/discriminator.py:130-163) -- cannot fill 256 CUs with (c_out block x pixel block) tiles; with a
  * workspace bound to the launch stream they run as K slices of the LDS-tiled GEMM whose fp32 partial tiles
  * ([slice][pixel][round_up(c_out,8)]) are summed in slice order by a second kernel (deterministic).  One buffer per stream
- * (launches of a stream are ordered; two streams must not share one), caller-owned, 16-byte aligned, registered once;
- * workspace = NULL, bytes = 0 unbinds.  Without a binding those layers run on the general kernel: same results up to the fp32
+ * (launches of a stream are ordered; two streams must not share one), caller-owned, 16-byte aligned, registered once per
+ * (current device, stream) -- the NULL stream of two devices are two bindings; workspace = NULL, bytes = 0 unbinds.  The
+ * table holds 64 bindings; one more replaces the oldest (whose stream falls back to the general kernel: never an error).  Without a binding those layers run on the general kernel: same results up to the fp32
  * summation order, slower.  64 MiB covers every layer of the reference's default model at the benchmark batch sizes. */
 int cgan_conv2d_bind_workspace(void* stream, void* workspace, size_t bytes);
 int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data);
+int cgan_conv2d_kernel_kind_on(const CganConvDesc* d, int32_t bwd_data, void* stream);
 /* Backward of the convolution above (autograd of nn.Conv2d, reached from g_loss.backward() / d_loss.backward(),
  * climategan/trainer.py:1011,1028).  All take the FORWARD descriptor; act / bias / residual fields are ignored (their
  * backward is elementwise and lives in the callers).  bwd_data takes zero padding only: for a reflect-padded conv call it

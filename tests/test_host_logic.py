@@ -237,3 +237,51 @@ def test_float_cast_is_guarded_and_reversible():
     assert not G2.pair_precision and G2.compute_dtype == before                   # unsupported: keeps the 16-bit type
     with pytest.raises(NotImplementedError):
         G2.set_compute_dtype("split24")
+
+
+def test_chunk_arena_joins_batch_slices_without_a_copy():
+    """ops._run_chunks: the slices of a batch-chunked op write consecutive ranges of ONE full-batch buffer (no torch.cat);
+    anything the arena cannot serve falls back to a concatenation with the same values."""
+    import torch
+
+    from climategan_amd import ops
+
+    x = torch.arange(7 * 2 * 3 * 8, dtype=torch.float32).reshape(7, 2, 3, 8)
+
+    def op(lo, cnt):                      # an op with a 4-D map, [N, Cs] statistics, a scratch buffer and a non-arena result
+        xs = x[lo:lo + cnt]
+        scratch = ops._empty(64, dtype=torch.uint8, device="cpu")        # 1-D: never from the arena
+        y = ops._empty((cnt, 2, 3, 8), dtype=torch.float32, device="cpu")
+        y.copy_(xs * 2)
+        mean = ops._empty((cnt, 8), dtype=torch.float32, device="cpu")
+        mean.copy_(xs.mean((1, 2)))
+        z = ops._empty_like(y)
+        z.copy_(xs + 1)
+        assert scratch.numel() == 64
+        return ops.NHWC(y, 8), (mean, z.clone())                         # the clone is NOT an arena range -> joined by cat
+
+    out, (mean, z) = ops._run_chunks(7, 3, op)                           # slices of 3, 3, 1
+    assert ops._ARENA is None
+    assert torch.equal(out.t, x * 2) and torch.equal(mean, x.mean((1, 2))) and torch.equal(z, x + 1)
+    assert out.t.shape[0] == 7 and out.t.is_contiguous()
+    # the map and the statistics came out of the arena's full-batch buffers: nothing was concatenated
+    arena_ptrs = set()
+
+    def op2(lo, cnt):
+        y = ops._empty((cnt, 2, 3, 8), dtype=torch.float32, device="cpu")
+        arena_ptrs.add(ops._ARENA.full[0].data_ptr())
+        y.fill_(float(lo))
+        return y
+
+    y = ops._run_chunks(7, 3, op2)
+    assert y.data_ptr() in arena_ptrs and y[:, 0, 0, 0].tolist() == [0, 0, 0, 3, 3, 3, 6]
+    # an allocation sequence that differs between slices falls back to cat instead of handing out a wrong buffer
+    def op3(lo, cnt):
+        if lo == 0:
+            ops._empty((cnt, 1, 1, 8), dtype=torch.float32, device="cpu")
+        y = ops._empty((cnt, 2, 3, 8), dtype=torch.float32, device="cpu")
+        y.fill_(float(lo))
+        return y
+
+    y = ops._run_chunks(7, 3, op3)
+    assert y[:, 0, 0, 0].tolist() == [0, 0, 0, 3, 3, 3, 6]
