@@ -894,7 +894,7 @@ def slice_block(steps, warmup, rank, device, dtype, barrier):
             "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "roofline": roof}
 
 
-def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""):
+def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path="", only_fp32=False):
     """configs[4]: the apply_events inference loop (Trainer.infer_all: Masker + flood painter + wildfire + smog, uint8
     results copied to the host), 640x640, 16 images per GPU, fp16."""
     from climategan_amd import fill
@@ -913,6 +913,17 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
     def step():
         out.update(T.infer_all(x, numpy=True, bin_value=0.5, half=True))
 
+    if only_fp32:                       # development aid (--only infer32): the fp32-grade modes alone, one after the other
+        res = {"workload": "apply_events, fp32-grade modes only"}
+        mode = os.environ.get("CGAN_FP32_MODE", "")
+        for name in ([mode] if mode else ["split24", "pair16", "split24+fp16painter", "pair16+fp16painter"]):
+            T.G.eval()
+            T.G.set_compute_dtype(name.split("+")[0])
+            if "+" in name:
+                T.G.set_painter_compute_dtype(torch.float16)
+            dt = timed_steps(lambda: out.update(T.infer_all(x, numpy=True, bin_value=0.5, half=False)), steps, warmup, barrier)
+            res[name] = {"images_per_s": round(INFER_BS * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 2)}
+        return res
     elapsed = max_over_ranks(timed_steps(step, steps, warmup, barrier), dist, device)
     assert set(out) >= {"flood", "wildfire", "smog"} and out["flood"].shape == (INFER_BS, H, W, 3)
     # the opt-in inference mode of SURVEY 8f N2: spectral-norm weights frozen (no power iteration / re-pack per call)
@@ -974,7 +985,7 @@ def main():
                     help="samples per domain per step over the whole job (BASELINE configs[3]: 32); anything else is a "
                          "development run and the line says so")
     ap.add_argument("--only", default="", help="run ONE workload as the only measurement (profiling aid): "
-                                               "painter | masker | slice | infer")
+                                               "painter | masker | slice | infer | infer32")
     args = ap.parse_args()
 
     # multi-GPU knobs reach the reducer / RCCL through the environment (read at communicator / reducer construction)
@@ -1022,6 +1033,8 @@ def main():
             r = masker_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier)
         elif args.only == "slice":
             r = slice_block(args.steps, args.warmup, rank, device, dtype, barrier)
+        elif args.only == "infer32":
+            r = infer_block(args.steps, args.warmup, rank, world, device, dist, barrier, only_fp32=True)
         else:
             r = infer_block(args.steps, args.warmup, rank, world, device, dist, barrier)
         if rank == 0:

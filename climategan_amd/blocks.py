@@ -279,8 +279,23 @@ class SPADEResnetBlock(nn.Module):
         cond = Fn.from_nchw(seg, dt, cs=ops.cs4(seg.shape[1]))
         return Fn.to_nchw(self.forward_nhwc(xs, cond)).to(x.dtype)
 
-    def shortcut(self, x, seg):
-        raise NotImplementedError("SPADEResnetBlock.shortcut is fused into forward() in this build")
+    def shortcut_nhwc(self, x: ops.NHWC, cond: ops.NHWC, x_upsample=False) -> ops.NHWC:
+        """The block's skip path on its own: conv_s(SPADE_s(x, seg)) when fin != fout, else x (at the conditioning map's
+        resolution: a stored pre-upsample x is expanded)."""
+        if not self.learned_shortcut:
+            return Fn.resize_nearest(x, (cond.h, cond.w)) if x_upsample else x
+        stats = (None if self.param_free_norm == "batch" else
+                 ops.instnorm_stats(ops.detached(x), eps=self.norm_s.param_free_norm.eps))
+        s = self.norm_s.forward_nhwc(x, cond, stats, act=ops.ACT_NONE, x_upsample=x_upsample)
+        return conv_forward(self.conv_s, self._caches["conv_s"], s, **self._tr(self.conv_s))
+
+    def shortcut(self, x, seg, compute_dtype=None):
+        """Reference signature (climategan/blocks.py:387-392): NCHW tensors in, NCHW out.  ``forward`` does not call it (the
+        skip path rides in conv_1's residual epilogue there); it is the same fused-SPADE + 1x1 kernels run on their own."""
+        dt = compute_dtype or DEFAULT_COMPUTE_DTYPE
+        xs = Fn.from_nchw(x, dt)
+        cond = Fn.from_nchw(seg, dt, cs=ops.cs4(seg.shape[1]))
+        return Fn.to_nchw(self.shortcut_nhwc(xs, cond)).to(x.dtype)
 
     def activation(self, x):
         return torch.nn.functional.leaky_relu(x, 2e-1)

@@ -8,6 +8,11 @@
 #include "cgan_common.h"
 #include <type_traits>
 
+// Pre-merge of long partial lists (round 6): stats_premerge.hip (its own translation unit: it is compiled without the
+// vectorisers, see the Makefile's NOVEC note -- the SLP vectoriser turns chan_merge's pairs into op_sel-modified packed-fp32
+// instructions, which tests/test_build_isa.py refuses).
+int stats_premerge_launch(float* partial, int hw, int cs, int chunks, int ppb, int len, int groups, hipStream_t s);
+
 namespace {
 
 constexpr int STATS_THREADS = 256;
@@ -114,11 +119,15 @@ struct BnEpilogue {
   CGAN_DEV_ONLY(int jitter_ppm; unsigned jitter_seed;)     // dev: the sensitivity experiment of DESIGN 4.13
 };
 
+constexpr int PREMERGE_MIN_CHUNKS = 512;   // shorter lists go straight to the finalize kernel
+constexpr int PREMERGE_ROWS = 256;         // rows a block merges (8 per thread)
+
 // one wave per (n, c): lanes stride over the chunk partials, then a 6-step shuffle tree of Chan merges
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ partial,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
                                                                 int n_total, int hw, int cs, int chunks, int ppb,
-                                                                float eps, BnEpilogue bn) {
+                                                                float eps, BnEpilogue bn, int rows_per_group,
+                                                                int row_stride) {
   const int idx0 = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // instance norm: one wave per (n, c).  Batch norm with several GROUPS (n_total > 1: the batch is a concatenation of
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
       if (k < chunks) {
         const int p0 = k * ppb;
         cnt[j] = min(hw, p0 + ppb) - p0;
-        v[j] = *reinterpret_cast<const float2*>(partial + (((size_t)n * chunks + k) * cs + c) * 2);
+        v[j] = *reinterpret_cast<const float2*>(partial + (((size_t)n * rows_per_group + (size_t)k * row_stride) * cs + c) * 2);
       }
     }
 #pragma unroll
@@ -323,7 +332,7 @@ static int stats_impl(const void* x, float* mean, float* rstd, const CganNormSta
   CGAN_CHECK_LAUNCH("instnorm_stats(partial)");
   int total = (bn.mean_out != nullptr && d->n > 1) ? cs : d->n * cs;      // grouped batch norm: one wave per channel
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, s, (const float*)workspace,
-                     mean, rstd, d->n, d->hw, cs, chunks, ppb, d->eps, bn);
+                     mean, rstd, d->n, d->hw, cs, chunks, ppb, d->eps, bn, chunks, 1);
   CGAN_CHECK_LAUNCH("instnorm_stats(finalize)");
   return CGAN_OK;
 }
@@ -351,14 +360,14 @@ extern "C" int cgan_batchnorm_train_stats(const void* x, const float* gamma, con
   return stats_impl(x, batch_mean, batch_rstd, d, workspace, workspace_bytes, stream, bn);
 }
 
-extern "C" int cgan_batchnorm_train_stats_from_partials(const float* partial, int32_t chunk_pixels, const float* gamma,
+extern "C" int cgan_batchnorm_train_stats_from_partials(float* partial, int32_t chunk_pixels, const float* gamma,
                                                         const float* beta, float momentum, float* running_mean,
                                                         float* running_var, int64_t* num_batches_tracked,
                                                         float* batch_mean, float* batch_rstd, float* mean_out,
                                                         float* rstd_out, const CganNormStatsDesc* d, void* stream) {
   // the finalize half of cgan_batchnorm_train_stats on per-chunk (mean, M2) rows that a convolution's epilogue produced
   // (cgan_conv2d_nhwc_fwd_stats): [group][chunk][cs][2], chunk = chunk_pixels consecutive pixels, d->hw (pixels per group)
-  // a whole number of chunks
+  // a whole number of chunks.  The rows are CONSUMED: long lists are shortened in place first (stats_premerge_kernel)
   int rc = check(d);
   if (rc != CGAN_OK) return rc;
   CGAN_REQUIRE(partial && batch_mean && batch_rstd && mean_out && rstd_out, "batchnorm_train_stats_from_partials: null pointer");
@@ -370,8 +379,17 @@ extern "C" int cgan_batchnorm_train_stats_from_partials(const float* partial, in
   BnEpilogue bn = {gamma, beta, running_mean, running_var, mean_out, rstd_out, (long long*)num_batches_tracked, momentum, d->c};
   CGAN_DEV_ONLY(bn.jitter_ppm = g_bn_jitter_ppm; bn.jitter_seed = g_bn_jitter_seed;)
   const int total = d->n > 1 ? cs : d->n * cs;
+  const int rows = d->hw / chunk_pixels;          // per group
+  int chunks = rows, ppb = chunk_pixels, stride = 1;
+  if (rows >= PREMERGE_MIN_CHUNKS) {
+    const int len = PREMERGE_ROWS;
+    const int merged = ceil_div(rows, len);
+    rc = stats_premerge_launch(partial, d->hw, cs, rows, chunk_pixels, len, d->n, (hipStream_t)stream);
+    if (rc != CGAN_OK) return rc;
+    chunks = merged; ppb = chunk_pixels * len; stride = len;
+  }
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, (hipStream_t)stream, partial,
-                     batch_mean, batch_rstd, d->n, d->hw, cs, d->hw / chunk_pixels, chunk_pixels, d->eps, bn);
+                     batch_mean, batch_rstd, d->n, d->hw, cs, chunks, ppb, d->eps, bn, rows, stride);
   CGAN_CHECK_LAUNCH("batchnorm_train_stats_from_partials");
   return CGAN_OK;
 }

@@ -140,6 +140,22 @@ class OmniGenerator(nn.Module):
         self.pair_precision = pair
         return self
 
+    def set_painter_compute_dtype(self, dtype):
+        """HYBRID inference (round 6): the Painter alone on a 16-bit type (torch.float16 / torch.bfloat16) while the Masker
+        stays in the split-precision mode ``G.float()`` / ``set_compute_dtype("split24" | "pair16")`` selected -- the flood
+        MASK is the fp32-grade one (it is the Masker's output alone: the bit-exact half of north_star's parity statement),
+        the painted image carries the 16-bit Painter's tolerance, and the Painter's share of the work drops 6-fold (3-fold
+        against "pair16").  Call it after ``set_compute_dtype``; the next ``set_compute_dtype`` / ``float()`` / ``half()``
+        overrides it."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("set_painter_compute_dtype: torch.float16 or torch.bfloat16")
+        for m in self.painter.modules():
+            if hasattr(m, "compute_dtype"):
+                m.compute_dtype = dtype
+            if hasattr(m, "pair_precision"):
+                m.pair_precision = False
+        return self
+
     def _pair_unsupported(self):
         """Why this generator cannot run the split-precision Masker (None: it can).  The ResNet encoder, the DADA depth
         decoder, the DeepLab segmentation decoder and both mask decoders (plain; SPADE since round 5) carry pair maps."""

@@ -746,6 +746,127 @@ class Trainer:
         self.epoch += 1
         return last
 
+    # ------------------------------------------------------------------------------------------ validation
+    def eval_mode(self):
+        """reference trainer.py:581-589"""
+        if self.G is not None:
+            self.G.eval()
+        if self.D is not None:
+            self.D.eval()
+        self.current_mode = "eval"
+
+    def train_mode(self):
+        """reference trainer.py:591-600"""
+        if self.G is not None:
+            self.G.train()
+        if self.D is not None:
+            self.D.train()
+        self.current_mode = "train"
+
+    def get_G_loss(self, multi_domain_batch):
+        """reference trainer.py:1162-1182: the Masker's and the Painter's generator-side terms of one multi-domain batch,
+        no backward, no optimizer (``update_G`` = this + backward + the ExtraAdam half-step, on two streams); the logged
+        terms land in ``loss_log``."""
+        self._check_batch(multi_domain_batch)
+        g_loss = 0
+        if self.has_masker and any(d != "rf" for d in multi_domain_batch):
+            g_loss = g_loss + self.get_masker_loss(multi_domain_batch)
+        if self.has_painter and "rf" in multi_domain_batch:
+            g_loss = g_loss + self.get_painter_loss(multi_domain_batch)
+        return g_loss
+
+    @torch.no_grad()
+    def run_evaluation(self, val_batches, display_images=None):
+        """reference trainer.py:1653-1704 over an iterable of multi-domain validation batches (the zipped loaders are the
+        caller's): eval mode, ``get_G_loss`` per batch with the logged generator terms AVERAGED over the batches
+        (sum_dict / div_dict, trainer.py:1674-1679), then ``eval_images("val", d)`` for d in r, s when the Masker has an
+        m or s task, train mode again.  Comet image panels and the validation FID (logger.py, fid.py) are outside this
+        path.  Returns {"losses": averaged terms, "metrics": {domain: eval_images' table}}."""
+        self.eval_mode()
+        sums, n = {}, 0
+        for multi_domain_batch in val_batches:
+            self.loss_log = {}
+            self.get_G_loss(multi_domain_batch)
+            for k, v in self.loss_log.items():
+                if k.startswith("G."):
+                    sums[k] = sums.get(k, 0.0) + float(v)
+            n += 1
+        losses = {k: v / max(n, 1) for k, v in sums.items()}
+        metrics = {}
+        if display_images is not None:
+            self.display_images = display_images
+        if ("m" in self.opts.tasks or "s" in self.opts.tasks) and getattr(self, "display_images", None):
+            for d in ("r", "s"):
+                self.eval_images("val", d)
+                if ("val", d) in self.last_metrics:
+                    metrics[d] = self.last_metrics[("val", d)]
+        self.train_mode()
+        return {"losses": losses, "metrics": metrics}
+
+    @torch.no_grad()
+    def eval_images(self, mode, domain):
+        """reference trainer.py:1706-1799: accuracy and mIOU of the Masker's predictions over the display images
+        ``self.display_images[mode][domain]`` (a list of ``{"data": {"x", "s", "m"[, "d"]}}`` samples, one image at a time
+        as the reference does), per task m (binarised mask at 0.5; the 1-channel accuracy quirk of eval_metrics.py:67-76
+        kept) and s (segmentation logits); the counts behind both metrics come from one HIP pass over the device tensors
+        (``cgan_seg_counts``), nothing is moved to the host.  The averaged table is printed (the reference logs it to comet
+        when an experiment exists), kept in ``self.last_metrics[(mode, domain)]``; returns 0 like the reference."""
+        import numpy as np
+
+        from . import functional as Fn
+        from .eval_metrics import accuracy, mIOU
+        from .utils import flatten_opts
+
+        if domain == "s" and getattr(self, "kitti_pretrain", False):
+            domain = "kitti"
+        images = getattr(self, "display_images", None) or {}
+        if domain == "rf" or domain not in images.get(mode, {}):
+            return
+        if not hasattr(self, "last_metrics"):
+            self.last_metrics = {}
+        metric_funcs = {"accuracy": accuracy, "mIOU": mIOU}
+        scores = {"m": {}}
+        if "s" in self.opts.tasks:
+            scores["s"] = {}
+        if "d" in self.opts.tasks and domain == "s" and self.opts.gen.d.classify.enable:
+            raise NotImplementedError("eval_images: the depth CLASSIFICATION head (gen.d.classify.enable) is outside this build "
+                                      "(SURVEY 2: depth regression only)")
+        for task in scores:
+            for key in metric_funcs:
+                scores[task][key] = []
+        for im_set in images[mode][domain]:
+            data = im_set["data"]
+            x = data["x"].unsqueeze(0).to(self.device)
+            z = self.G.encode(x)
+            z_depth = None
+            if "s" in scores:
+                if self.opts.gen.s.use_dada and "d" in self.opts.tasks:
+                    _, z_depth = self.G.decoders["d"].forward_nhwc(z)
+                s_pred = Fn.to_nchw(self.G.decoders["s"].forward_nhwc(z, z_depth))
+                s = data["s"].unsqueeze(0).to(self.device)
+                for name, fn in metric_funcs.items():
+                    scores["s"][name].append(fn(s_pred, s))
+            if "m" in self.opts.tasks:
+                if z_depth is None and self.opts.gen.m.use_dada and "d" in self.opts.tasks:
+                    _, z_depth = self.G.decoders["d"].forward_nhwc(z)
+                # (cond stays None as in the reference, whose d_pred exists only with the classification head: G.mask builds
+                # the SPADE conditioning itself when the mask decoder uses one, generator.py:257-262)
+                pred_mask = (self.G.mask(x=x, z=z, cond=None, z_depth=z_depth) > 0.5).to(torch.float32)
+                pred_prob = torch.cat([1 - pred_mask, pred_mask], dim=1)
+                m = data["m"].unsqueeze(0).to(self.device)
+                scores["m"]["accuracy"].append(accuracy(pred_mask, m))
+                scores["m"]["mIOU"].append(mIOU(pred_prob, m))
+        table = {}
+        for task, met in scores.items():
+            table[task] = {}
+            for name, values in met.items():
+                v = float(np.mean(values)) if values else float("nan")
+                table[task][name] = v if not np.isnan(v) else -1
+        self.last_metrics[(mode, domain)] = table
+        print(f"metrics_{mode}_{domain}")
+        print(flatten_opts(table))
+        return 0
+
     # ------------------------------------------------------------------------------------------ checkpoints
     def update_learning_rates(self):
         """reference trainer.py:696-700 (called once per epoch by run_epoch, and epoch+1 times by resume)."""

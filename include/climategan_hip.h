@@ -381,8 +381,9 @@ int cgan_batchnorm_train_stats(const void* x, const float* gamma, const float* b
                                size_t workspace_bytes, void* stream);
 /* The finalize half of cgan_batchnorm_train_stats on the per-chunk (mean, M2) rows a convolution's epilogue wrote
  * (cgan_conv2d_nhwc_fwd_stats): d->n = groups, d->hw = pixels per group (a whole number of chunk_pixels), same outputs,
- * running-statistics updates and step counter as cgan_batchnorm_train_stats. */
-int cgan_batchnorm_train_stats_from_partials(const float* partial, int32_t chunk_pixels, const float* gamma,
+ * running-statistics updates and step counter as cgan_batchnorm_train_stats.  The partial rows are CONSUMED: lists of 512
+ * rows and more per group are shortened in place (256 rows -> 1, fixed merge order) before the per-channel walk. */
+int cgan_batchnorm_train_stats_from_partials(float* partial, int32_t chunk_pixels, const float* gamma,
                                              const float* beta, float momentum, float* running_mean, float* running_var,
                                              int64_t* num_batches_tracked, float* batch_mean, float* batch_rstd,
                                              float* mean_out, float* rstd_out, const CganNormStatsDesc* d, void* stream);

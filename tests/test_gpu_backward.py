@@ -824,13 +824,16 @@ def test_batched_dgrad_pack_equals_the_per_layer_pack():
     (256, 1024, 1, 0, 1, 4, 40, 40, 1), (128, 512, 1, 0, 1, 2, 96, 100, 2),   # 128 x 128, 2-stage ring (short-K 1x1)
     (256, 1024, 1, 0, 1, 8, 80, 80, 2), (128, 512, 1, 0, 1, 4, 64, 64, 1), (64, 256, 1, 0, 1, 2, 128, 128, 2),   # x-resident 1x1 kernel
     (1024, 256, 1, 0, 1, 8, 80, 80, 2), (512, 2048, 1, 0, 1, 4, 80, 80, 1), (2048, 512, 1, 0, 1, 4, 64, 64, 2),   # 256 x 256 kernel (long-K 1x1)
+    # 512 and more partial rows per group: the in-place pre-merge (round 6) in front of the per-channel walk -- 3 200 rows per
+    # group (a last block of 128 of the 256), 1 600 / 800 rows in one group, 1 000 rows (a last block of 232)
+    (64, 256, 1, 0, 1, 16, 160, 160, 2), (256, 256, 3, 1, 1, 16, 80, 80, 1), (256, 1024, 1, 0, 1, 20, 80, 80, 2),
 ])
 def test_batchnorm_statistics_from_the_conv_epilogue(case):
     _bn_stats_from_epilogue(case, shifted=False)
 
 
 @pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 8, 80, 80, 2), (256, 1024, 1, 0, 1, 8, 80, 80, 2), (1024, 256, 1, 0, 1, 8, 40, 40, 2),
-                                  (1024, 256, 1, 0, 1, 8, 80, 80, 2)])
+                                  (1024, 256, 1, 0, 1, 8, 80, 80, 2), (64, 256, 1, 0, 1, 16, 160, 160, 2)])
 def test_batchnorm_statistics_from_the_conv_epilogue_with_large_channel_means(case):
     """Post-ReLU inputs and weights with a common sign give conv outputs whose channel mean is ten or more standard deviations
     away from zero: the epilogue's M2 must not be formed as sum v^2 - (sum v)^2 / n (round 3: that form cost the encoder 2 %

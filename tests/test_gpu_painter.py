@@ -231,6 +231,31 @@ def test_spade_resnet_block_matches_reference_golden(name, dt, rel):
             assert np.abs(sd[k[5:]].cpu().numpy() - v).max() <= 2e-5, k
 
 
+@pytest.mark.parametrize("name", ["resblk_16_8", "resblk_8_8"])
+def test_spade_resnet_block_shortcut_is_callable(name):
+    """``SPADEResnetBlock.shortcut(x, seg)`` on its own (reference blocks.py:387-392: conv_s(norm_s(x, seg)) with a learned
+    shortcut, x itself otherwise) against the oracle's restatement of the same two lines on the golden case's weights."""
+    from climategan_amd.blocks import SPADEResnetBlock
+    from oracle import cpu_ref
+
+    case = CASES[name]
+    mod = SPADEResnetBlock(case["fin"], case["fout"], 3, True, "instance", 3).cuda()
+    sd = case_state_dict(case)
+    mod.load_state_dict(sd)
+    inp = {k: t(v) for k, v in case_inputs(name, case).items()}
+    with torch.no_grad():
+        got = mod.shortcut(inp["x"].cuda(), inp["seg"].cuda(), compute_dtype=torch.float16).float().cpu()
+        if case["fin"] != case["fout"]:
+            sdc = {k: v.clone() for k, v in sd.items()}
+            ref = cpu_ref.sn_conv2d(cpu_ref.spade(inp["x"], inp["seg"], sdc, "norm_s"), sdc, "conv_s", padding=0, update=True)
+        else:
+            ref = inp["x"]
+    assert got.shape == ref.shape
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+    print("\n%s shortcut: max err %.3g of scale %.3g" % (name, err, scale))
+    assert err <= 4e-3 * scale                      # two 16-bit stores (SPADE output, conv output)
+
+
 def test_frozen_spectral_norm_inference_mode():
     """``freeze_spectral_norm`` (opt-in): the first frozen forward is the reference-exact forward from the same
     state (it runs the one power iteration that forward would have run), every later call reproduces it bit for bit and

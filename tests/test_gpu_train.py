@@ -842,3 +842,69 @@ def test_fp16_loss_scale_is_divided_out():
         a, b = g1[k].float(), g64[k].float()
         # same magnitude (not 64x), up to 16-bit rounding; biases in front of an instance norm hold pure rounding noise
         assert (a - b).abs().max().item() <= 0.1 * a.abs().max().item() + 3e-4 * gmax, k
+
+
+def test_run_evaluation_and_eval_images():
+    """``Trainer.run_evaluation`` / ``eval_images`` (reference trainer.py:1653-1799): eval mode and no_grad around
+    ``get_G_loss`` per validation batch with the logged terms averaged, then accuracy / mIOU of the Masker's predictions over
+    the display images -- one image at a time, the table the reference prints; nothing trains, the trainer is back in train
+    mode afterwards.  The metric values are checked against the same metrics computed here from ``G.masker_forward`` (the
+    metric kernel itself is pinned by tests/test_gpu_metrics.py against the reference's eval_metrics.py)."""
+    from climategan_amd import eval_metrics
+
+    case = golden_cases()[MNAME]
+    T = build_masker_trainer(case, dt=torch.float16)
+    batch = masker_batch(case)
+    n = batch["r"]["data"]["x"].shape[0]
+    hs, ws = case["H"] // 4, case["W"] // 4
+    images = {"val": {dom: [{"data": {"x": batch[dom]["data"]["x"][i].float(),
+                                       "s": batch[dom]["data"]["s"][i].reshape(1, hs, ws),
+                                       "m": (batch[dom]["data"]["m"][i].reshape(1, case["H"], case["W"]) > 0.5).long()}}
+                             for i in range(n)] for dom in ("r", "s")}}
+    before = {k: v.clone() for k, v in T.G.state_dict().items()}
+    half = {dom: {"data": {k: v[: max(n // 2, 1)] for k, v in batch[dom]["data"].items()}} for dom in batch}
+    out = T.run_evaluation([batch, half], display_images=images)
+    assert T.current_mode == "train" and T.G.training
+    # validation does not train: parameters untouched (eval-mode BatchNorm: running statistics too), no gradients left behind
+    after = T.G.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k]) and not k.endswith(("weight_u", "weight_v"))]
+    assert not moved, moved[:5]
+    assert all(p.grad is None for p in T.G.parameters())
+    # averaged generator terms: the mean over the two batches of what get_G_loss logs for each
+    T.eval_mode()
+    terms = []
+    with torch.no_grad():
+        for b in (batch, half):
+            T.loss_log = {}
+            assert torch.isfinite(T.get_G_loss(b))
+            terms.append({k: float(v) for k, v in T.loss_log.items() if k.startswith("G.")})
+    assert set(out["losses"]) == set(terms[0]) and len(terms[0]) >= 8
+    for k, v in out["losses"].items():
+        ref = 0.5 * (terms[0][k] + terms[1][k])
+        assert abs(v - ref) <= 2e-3 * max(abs(ref), 1e-3), (k, v, ref)      # (spectral-norm power iterations between the passes)
+    # the metric table: tasks m and s, accuracy and mIOU, per domain
+    assert set(out["metrics"]) == {"r", "s"}
+    for dom in ("r", "s"):
+        tab = out["metrics"][dom]
+        assert set(tab) == {"m", "s"} and all(set(v) == {"accuracy", "mIOU"} for v in tab.values())
+        acc_s, iou_s, acc_m, iou_m = [], [], [], []
+        with torch.no_grad():
+            for im in images["val"][dom]:
+                x = im["data"]["x"].unsqueeze(0).cuda()
+                pred = T.G.masker_forward(x)
+                s, m = im["data"]["s"].unsqueeze(0).cuda(), im["data"]["m"].unsqueeze(0).cuda()
+                acc_s.append(eval_metrics.accuracy(pred["s"].float(), s))
+                iou_s.append(eval_metrics.mIOU(pred["s"].float(), s))
+                pm = (pred["m"] > 0.5).float()
+                acc_m.append(eval_metrics.accuracy(pm, m))
+                iou_m.append(eval_metrics.mIOU(torch.cat([1 - pm, pm], 1), m))
+        def mean(v):
+            v = float(np.mean(v))
+            return -1 if np.isnan(v) else v
+        # (the mask decoder's spectral-norm vectors advance with every forward: a handful of pixels at the 0.5 threshold may flip)
+        assert abs(tab["s"]["accuracy"] - mean(acc_s)) <= 2e-3 and abs(tab["s"]["mIOU"] - mean(iou_s)) <= 5e-3
+        assert abs(tab["m"]["accuracy"] - mean(acc_m)) <= 2e-3 and abs(tab["m"]["mIOU"] - mean(iou_m)) <= 2e-2
+        assert 0.0 <= tab["s"]["accuracy"] <= 1.0
+    T.train_mode()
+    # domains without display images, and the rf domain, are skipped like in the reference
+    assert T.eval_images("val", "rf") is None and T.eval_images("train", "r") is None

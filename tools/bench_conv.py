@@ -71,14 +71,18 @@ def main():
         x = ops.NHWC(torch.randn(args.bs, H, H, ops.cs8(cin), device="cuda").to(dt), cin)   # storage channels: round_up(cin, 8)
         w = torch.randn(cout, cin, k, k, device="cuda") * 0.02
         pw = ops.pack_conv_weight(w, None, dt)
+        res = None
+        if args.res:
+            Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            res = ops.NHWC(torch.randn(args.bs, Ho, Ho, ops.cs8(cout), device="cuda").to(dt), cout)
         for _ in range(3):
-            y = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_RELU)
+            y = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_NONE if args.res else ops.ACT_RELU, residual=res)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         n = 10
         for _ in range(n):
-            y = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_RELU)
+            y = ops.conv2d(x, pw, stride=stride, pad=pad, dilation=dil, act=ops.ACT_NONE if args.res else ops.ACT_RELU, residual=res)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
