@@ -17,8 +17,16 @@ reducer works on the parameter list:
 * a bucket's all-reduce is issued (``async_op=True``, on RCCL's own stream) as soon as its last gradient has been
   accumulated; xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link bound: few
   large messages, not one per tensor (105 M G parameters = 17 buckets);
-* ``finish()`` waits for the outstanding buckets, and copies the averaged values back into ``param.grad``.  ExtraAdam
-  needs it before both ``extrapolation()`` and ``step()`` (reference trainer.py:678-683).
+* ``finish()`` waits for the outstanding buckets and hands the averaged values over as ``param.grad`` -- with the fp32 wire
+  the gradients BECOME views of the bucket's flat buffer (no copy back) and the average is the collective's own (``AVG`` on
+  RCCL; one in-place scale of the flat buffer elsewhere): one pass over the gradients per exchange (the gather) instead of
+  three (round 5: gather, copy back, scale).  ExtraAdam needs it before both ``extrapolation()`` and ``step()`` (reference
+  trainer.py:678-683);
+* whether a bucket has to be exchanged AGAIN (a second ``backward()`` touched it after its hook sent it) is decided from
+  rank-local observations, so ``finish()`` first agrees on it: the per-bucket flags go through one MAX all-reduce of a
+  few bytes over a host-side (gloo) group -- no device synchronisation -- and every rank then issues the same collectives
+  even if only one of them saw a reason (round 5 trusted every rank to see the same; a rank-conditional edit of a gradient
+  would have left the ranks waiting on different collectives).
 
 ``CGAN_DDP_DIRECT_RCCL=1`` (RCCL backend only) takes torch out of the collective: the reducer creates its OWN communicator
 through the C ABI (``cgan_rccl_load`` / ``cgan_comm_unique_id`` / ``cgan_comm_init_rank``: the unique id travels over the
@@ -130,6 +138,10 @@ class GradBucketReducer:
         # First step: a hook on EVERY parameter counts the bucket down and remembers which parameter completed it.
         # Afterwards only those trigger parameters keep a hook (the backward graph is the same every step): ~1500 calls
         # from the autograd engine into Python per step cost more (~15 ms of a 160 ms step) than the overlap buys.
+        # host-side group for finish()'s per-bucket agreement (every rank constructs its reducers in the same order)
+        self._flag_group = None
+        if self.active and self.world > 1 and os.environ.get("CGAN_DDP_NO_FLAG_SYNC") != "1":
+            self._flag_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
         self._learning = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.reset()
@@ -162,6 +174,7 @@ class GradBucketReducer:
             b.stale = False
             b.work = None
             b.sent = None
+            b.averaged = False
 
     def _views(self, b: _Bucket, grads):
         """The bucket's flat buffer and its per-parameter views (shaped like the gradients), allocated once."""
@@ -186,6 +199,7 @@ class GradBucketReducer:
         # WITHOUT reaching its trigger parameter -- another sub-graph, e.g. a masker-only pass after a joint one -- fires
         # no hook once only the triggers keep theirs)
         b.sent = [(g.data_ptr(), g._version) for g in grads]
+        b.averaged = False
         if self.direct:
             from . import _lib
             gathered = torch.cuda.Event()
@@ -197,7 +211,9 @@ class GradBucketReducer:
             done.record(self._comm_stream)
             b.work = _EventWork(done)
             return
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+        # the mean over the ranks: RCCL averages inside the collective; gloo (and the direct path above) sum, finish() scales
+        b.averaged = dist.get_backend() == "nccl" and self.grad_dtype == torch.float32
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if b.averaged else dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
         if not self.active:
@@ -234,29 +250,55 @@ class GradBucketReducer:
 
         Contract (advisor, round 4): between ``backward()`` and this call the gradients must not be touched in place (clipping,
         unscaling: do them AFTER ``finish()``).  A bucket whose gradients changed after its hook sent them (``sent`` records
-        their data pointers and versions) is exchanged again here; that decision is taken from rank-local state and is the
-        same on every rank only because every rank runs the same step code -- a rank-conditional edit of a gradient before
-        ``finish()`` would make the ranks issue different numbers of collectives and hang."""
+        their data pointers and versions) is exchanged again here -- on EVERY rank as soon as one rank saw it (the flags'
+        MAX all-reduce below), so the ranks always issue the same collectives.  After this call ``param.grad`` may be a view
+        of the reducer's flat buffer (fp32 wire): valid until the next exchange of that bucket, i.e. through the optimizer
+        step and ``zero_grad``."""
         if not self.active:
             self.reset()
             return
+        # ---- what this rank would do per bucket: 0 nothing (no gradients at all), 1 wait for the exchange its hook started,
+        # 2 exchange now (the hook never fired, or what it sent is stale) -- then the ranks agree on the maximum
+        todo = []
         for b in self.buckets:
             if b.pending != 0:
                 if all(p.grad is None for p in b.params):
+                    todo.append(0)
                     continue
                 missing = [p for p in b.params if p.grad is None]
                 if missing:
                     raise RuntimeError("GradBucketReducer: %d parameters of a bucket got no gradient while others did; "
                                        "replicas would diverge" % len(missing))
-                self._launch(b)
-            b.work.wait()
-            grads = [p.grad for p in b.params]
-            if b.stale or b.sent != [(g.data_ptr(), g._version) for g in grads]:      # see _on_grad / _launch
+                todo.append(2)
+            else:
+                grads = [p.grad for p in b.params]
+                changed = b.stale or b.sent != [(g.data_ptr(), g._version) for g in grads]      # see _on_grad / _launch
+                todo.append(2 if changed else 1)
+        if self._flag_group is not None:
+            flags = torch.tensor(todo, dtype=torch.uint8)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._flag_group)
+            agreed = flags.tolist()
+            for b, mine, theirs in zip(self.buckets, todo, agreed):
+                if mine == 0 and theirs != 0:
+                    raise RuntimeError("GradBucketReducer: another rank has gradients for a bucket this rank has none for; "
+                                       "replicas would diverge")
+            todo = agreed
+        for b, what in zip(self.buckets, todo):
+            if what == 0:
+                continue
+            if b.work is not None:
+                b.work.wait()                     # (an exchange in flight is always completed before its buffer is reused)
+            if what == 2:
                 self._launch(b)
                 b.work.wait()
-            torch._foreach_copy_(grads, b.views)                      # back to the gradients' own dtype (fp32)
-            if self.world > 1:
-                torch._foreach_mul_(grads, 1.0 / self.world)          # the average, applied in fp32
+            grads = [p.grad for p in b.params]
+            if self.world > 1 and not b.averaged:
+                b.flat.mul_(1.0 / self.world)                          # the average, one pass over the flat buffer
+            if b.flat.dtype == grads[0].dtype:
+                for p, v in zip(b.params, b.views):                     # the gradients ARE the bucket's views from here on
+                    p.grad = v
+            else:
+                torch._foreach_copy_(grads, b.views)                   # 16-bit wire: back to the gradients' own dtype (fp32)
         if self._learning and any(getattr(b, "trigger", None) is not None for b in self.buckets):
             self._keep_trigger_hooks_only()
         self.reset()

@@ -384,3 +384,68 @@ def test_reducer_second_backward_over_another_subgraph_gloo():
         for rank in range(2):
             for got, w in zip(res[rank][1][step], want):
                 np.testing.assert_allclose(got, w.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _one_rank_edit_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climategan_amd.parallel import GradBucketReducer, broadcast_parameters
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.Tanh(), torch.nn.Linear(6, 3))
+        broadcast_parameters(net)
+        red = GradBucketReducer(net.parameters(), bucket_mb=0.0001)
+        outs = []
+        for step in range(3):
+            net.zero_grad(set_to_none=True)
+            net(torch.full((2, 4), 0.3 * (rank + 1) + step)).sum().backward()
+            if rank == 1 and step >= 1:
+                # against the contract, and on ONE rank only: an in-place edit of an exchanged gradient before finish()
+                net[2].weight.grad.mul_(2.0)
+            red.finish()                     # must not hang: both ranks re-exchange that bucket, because one of them has to
+            outs.append(([p.grad.clone().numpy() for p in net.parameters()],
+                         [p.grad.data_ptr() == v.data_ptr() for b in red.buckets for p, v in zip(b.params, b.views)]))
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_agrees_on_re_exchanges_across_ranks_gloo():
+    """Round 6: ``finish()`` decides per bucket whether it must be exchanged again from what THIS rank saw; the flags go through
+    a MAX all-reduce first, so a reason only one rank has (here: rank 1 scales one gradient in place after its hook sent it)
+    makes every rank issue the same collectives -- no hang -- and the result is the mean of what the ranks hold at
+    ``finish()``.  Also: with the fp32 wire the gradients come back AS views of the buckets' flat buffers (no copy back)."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_rank_edit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.Tanh(), torch.nn.Linear(6, 3))
+    for step in range(3):
+        acc = None
+        for rank in range(2):
+            net.zero_grad(set_to_none=True)
+            net(torch.full((2, 4), 0.3 * (rank + 1) + step)).sum().backward()
+            if rank == 1 and step >= 1:
+                net[2].weight.grad.mul_(2.0)
+            g = [p.grad.clone() for p in net.parameters()]
+            acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        for rank in range(2):
+            grads, are_views = res[rank][1][step]
+            assert all(are_views)
+            for got, e in zip(grads, acc):
+                assert np.allclose(got, (e / 2).numpy(), rtol=1e-6, atol=1e-7), (rank, step)
+        for a, b in zip(res[0][1][step][0], res[1][1][step][0]):
+            assert np.array_equal(a, b)
