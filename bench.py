@@ -947,6 +947,17 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
 
     n32 = max(3, steps // 2)
     fp32 = max_over_ranks(timed_steps(step32, n32, 2, barrier), dist, device)
+    # round 6: the other fp32-grade configurations.  HYBRID = the split-precision Masker (the flood MASK is the fp32-grade one:
+    # the bit-exact half of north_star's parity statement) with the Painter back on 16 bit (the painted image then carries the
+    # 16-bit Painter's tolerance); "pair16" = fp16 pairs instead of bf16 triples (half the multiplies, fp16's range)
+    modes = {}
+    for name in ("split24+fp16painter", "pair16", "pair16+fp16painter"):
+        T.G.eval()
+        T.G.set_compute_dtype(name.split("+")[0])
+        if "+" in name:
+            T.G.set_painter_compute_dtype(torch.float16)
+        dtm = max_over_ranks(timed_steps(step32, n32, 2, barrier), dist, device)
+        modes[name] = {"images_per_s": round(world * INFER_BS * n32 / dtm, 2), "ms_per_batch": round(dtm / n32 * 1e3, 2)}
     T.G.set_compute_dtype(torch.float16)
     return {"workload": "BASELINE configs[4]: apply_events inference (Trainer.infer_all: flood + wildfire + smog, uint8 "
                         "results on the host), 640x640, 16 images per GPU, fp16",
@@ -956,6 +967,10 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
             "images_per_s_fp32_grade": round(world * INFER_BS * n32 / fp32, 2),
             "ms_per_batch_fp32_grade": round(fp32 / n32 * 1e3, 2),
             "fp32_grade_mode": "G.float() = set_compute_dtype('split24'): split-precision Masker AND Painter (DESIGN 4.8, 0 item 8), %d timed batches" % n32,
+            "images_per_s_fp32_grade_mask_16bit_painter": modes["split24+fp16painter"]["images_per_s"],
+            "fp32_grade_other_modes": dict(modes, note="hybrid = split-precision Masker (fp32-grade flood mask, tests/test_gpu_configs_640.py::"
+                                           "test_hybrid_inference_keeps_the_fp32_grade_mask) + 16-bit Painter (G.set_painter_compute_dtype); pair16 = "
+                                           "fp16 pairs, half the multiplies of split24, fp16's range; %d timed batches each" % n32),
             "steps": steps, "warmup": warmup, "roofline": roof}
 
 

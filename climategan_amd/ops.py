@@ -879,7 +879,7 @@ _PACK_TABLES = []
 
 CONV_WS_BYTES = 64 << 20
 CONV_WS_KEEP = 8          # (library, device, stream) bindings kept alive; the least recently bound one is released beyond that
-_CONV_WS = {}             # key -> buffer, or None when the library refused the binding (split-K off for that stream)
+_CONV_WS = {}             # key -> (library, buffer or None when the library refused the binding: split-K off for that stream)
 
 
 def _conv_ws() -> None:
@@ -893,17 +893,20 @@ def _conv_ws() -> None:
     dev = _GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device()
     key = (id(lib), st.value, dev)
     if key in _CONV_WS:
+        if len(_CONV_WS) >= CONV_WS_KEEP:
+            _CONV_WS[key] = _CONV_WS.pop(key)      # most recently used last: the streams in use are never the ones released
         return
     while len(_CONV_WS) >= CONV_WS_KEEP:
-        (olib, ostream, odev), obuf = next(iter(_CONV_WS.items()))
+        okey, (olib, obuf) = next(iter(_CONV_WS.items()))
         if obuf is not None:
-            # the buffer goes back to the allocator of the stream it was taken on: reuse is ordered after that stream's launches
-            with torch.cuda.device(odev):
-                lib.cgan_conv2d_bind_workspace(C.c_void_p(ostream), C.c_void_p(0), C.c_size_t(0))
-        del _CONV_WS[(olib, ostream, odev)]
+            # unbind in the library that holds the binding (the product and the development build keep separate tables); the
+            # buffer goes back to the allocator of the stream it was taken on: reuse is ordered after that stream's launches
+            with torch.cuda.device(okey[2]):
+                olib.cgan_conv2d_bind_workspace(C.c_void_p(okey[1]), C.c_void_p(0), C.c_size_t(0))
+        del _CONV_WS[okey]
     buf = _empty(CONV_WS_BYTES, dtype=torch.uint8, device="cuda")
     rc = lib.cgan_conv2d_bind_workspace(st, C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()))
-    _CONV_WS[key] = buf if rc == 0 else None
+    _CONV_WS[key] = (lib, buf if rc == 0 else None)
 
 
 @_batch_chunked("x", "residual", out_bytes_per_sample=lambda g: (lambda hw: hw[0] * hw[1] * cs8(g("pw").c_out) * 2 * _nbf(g("x")))(

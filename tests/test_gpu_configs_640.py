@@ -271,6 +271,56 @@ def test_split_precision_masker_reproduces_the_fp32_reference(infer_trainer, mod
         _load(T.G, sd)
 
 
+@pytest.mark.parametrize("mode", ["split24", "pair16"])
+def test_hybrid_inference_keeps_the_fp32_grade_mask(infer_trainer, mode):
+    """Round 6, ``G.set_painter_compute_dtype``: the split-precision Masker with the Painter back on 16 bit.  The flood mask --
+    the output north_star wants bit-exact -- is the Masker's alone: it must be the reference's fp32 mask on every pixel fp32
+    arithmetic can decide, exactly like the full split-precision run (same fixture, same band as
+    test_split_precision_masker_reproduces_the_fp32_reference), and identical to that run's mask bit for bit; the flood IMAGE
+    then carries the 16-bit Painter's tolerance (channel means within 0.75 of a uint8 level, the bound of the fp16 run)."""
+    T, sd, case = infer_trainer
+    gold = load_golden("infer_640")
+    B, H, W = case["B"], case["H"], case["W"]
+    x2 = t(infer_inputs(case)["x"]).cuda()
+    try:
+        masks, floods = {}, {}
+        for hybrid in (False, True):
+            _load(T.G, sd)
+            T.G.eval()
+            T.G.set_compute_dtype(mode)
+            if hybrid:
+                assert T.G.set_painter_compute_dtype(torch.float16) is T.G
+                assert T.G.pair_precision and T.G.encoder.pair_precision and not T.G.painter.pair_precision
+                assert T.G.painter.compute_dtype == torch.float16
+            random.seed(case["rng_seed"])
+            res = T.infer_all(x2.repeat(8, 1, 1, 1), numpy=True, bin_value=case["bin_value"], half=False, return_masks=True)
+            masks[hybrid], floods[hybrid] = res["mask"] > 0, res["flood"]
+            for k in ("flood", "wildfire", "smog"):
+                assert res[k].shape == (16, H, W, 3) and res[k].dtype == np.uint8
+        assert np.array_equal(masks[True], masks[False])                  # the Masker does not know what the Painter runs in
+        ref_mask = np.unpackbits(gold["mask_bits"])[: B * H * W].reshape(B, 1, H, W).astype(bool)
+        band = np.unpackbits(gold["m_fp32_band"])[: B * H * W].reshape(B, 1, H, W).astype(bool)
+        diff = 0
+        for i in range(16):
+            d = masks[True][i] != ref_mask[i % B]
+            assert not d[~band[i % B]].any(), "sample %d: %d mask bits differ where fp32 decides" % (i, d[~band[i % B]].sum())
+            diff += int(d.sum())
+        assert diff // 8 <= 2, diff
+        # the painted image: the 16-bit Painter against the reference's fp32 run (uint8 levels)
+        u8 = np.ascontiguousarray(floods[True][:B].transpose(0, 3, 1, 2)).astype(np.float32)
+        sf = summarize(u8)
+        crops = np.concatenate([np.abs(sf[c] - gold["flood_u8_%s" % c]).ravel() for c in ("crop_tl", "crop_c", "crop_br")])
+        print("hybrid %s flood u8 vs the reference's fp32 run: crops max %g mean %.3g; channel mean %.3g"
+              % (mode, crops.max(), crops.mean(), np.abs(sf["mean"] - gold["flood_u8_mean"]).max()))
+        assert np.abs(sf["mean"] - gold["flood_u8_mean"]).max() <= 0.75 and crops.mean() <= 1.0
+        # outside the mask the paste keeps the original pixels: identical bytes in both runs
+        keep = ~masks[True].repeat(3, axis=1).transpose(0, 2, 3, 1)
+        assert np.array_equal(floods[True][keep], floods[False][keep])
+    finally:
+        T.G.set_compute_dtype(torch.float16)
+        _load(T.G, sd)
+
+
 # ------------------------------------------------------------------------------------------------ configs[2], [3]
 def _build_train(tasks, case, reps, dt=torch.bfloat16, merge=True, opt_overrides=None):
     from climategan_amd import fill

@@ -461,3 +461,40 @@ def test_conv_gemm_wide_layers(dt, case):
         finally:
             lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
         assert torch.equal(y3.t, y2.t)
+
+
+def test_conv_workspace_bindings_are_bounded_and_survive_many_streams():
+    """ops._conv_ws (advisor, round 5): a process that walks through many streams must neither fail ("more than 16 streams")
+    nor pin 64 MiB per stream for ever, and releasing a binding must happen in the LIBRARY that holds it -- the product and the
+    development build keep separate tables: an unbind sent to the wrong one silently moves a layer from the split-K GEMM to
+    the general kernel (another fp32 summation order; round 6 saw exactly that as a one-level difference in a smog image,
+    inside the full suite only).  A split-K layer (640 -> 640 3x3 at 10 x 10, painter.py:149-160) on 12 streams, on the
+    development library in between, and on the first stream again: the same bits every time."""
+    from climategan_amd import _lib, ops
+
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = ops.NHWC(torch.randn(2, 10, 10, 640, device="cuda", generator=g).to(dt), 640)
+    w = torch.randn(640, 640, 3, 3, device="cuda", generator=g) * 0.02
+    pw = ops.pack_conv_weight(w, None, dt)
+    y0 = ops.conv2d(x, pw, pad=1).t.clone()
+    torch.cuda.synchronize()
+    for i in range(12):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            y = ops.conv2d(x, pw, pad=1).t
+        st.synchronize()
+        assert torch.equal(y, y0), "stream %d" % i
+        if i == 5:
+            try:
+                _lib.load_dev()                                       # its own workspace table: its own bindings
+                pw_dev = ops.pack_conv_weight(w, None, dt)
+                yd = ops.conv2d(x, pw_dev, pad=1).t
+                torch.cuda.synchronize()
+                assert torch.equal(yd, y0)
+            finally:
+                _lib.use_product()
+    assert torch.equal(ops.conv2d(x, pw, pad=1).t, y0)                # the calling stream's binding is still the product's
+    assert len(ops._CONV_WS) <= ops.CONV_WS_KEEP
+    held = sum(b.numel() for _l, b in ops._CONV_WS.values() if b is not None)
+    assert held <= ops.CONV_WS_KEEP * ops.CONV_WS_BYTES

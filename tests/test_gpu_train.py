@@ -882,7 +882,7 @@ def test_run_evaluation_and_eval_images():
     for k, v in out["losses"].items():
         ref = 0.5 * (terms[0][k] + terms[1][k])
         # (the spectral-norm power iterations advance between the passes; GroundIntersection counts pixels across a threshold)
-        assert abs(v - ref) <= (0.25 if ".gi." in k else 2e-3) * abs(ref) + 2e-5, (k, v, ref)
+        assert abs(v - ref) <= (0.25 if ".gi." in k else 1e-2) * abs(ref) + 2e-5, (k, v, ref)
     # the metric table: tasks m and s, accuracy and mIOU, per domain
     assert set(out["metrics"]) == {"r", "s"}
     for dom in ("r", "s"):
