@@ -603,7 +603,7 @@ def build_trainer(device, dtype, tasks=("d", "s", "m", "p"), freeze=False):
     T.G.set_compute_dtype(dtype)
     T.D.set_compute_dtype(dtype)
     # ``freeze`` (bench.py's own runs): this process trains this one trainer at a time, its long-lived Python objects leave
-    # the garbage collector's generations (a full collection cost one 160-220 ms step in ~34); opt-in since
+    # the garbage collector's generations (a full collection cost one 160-220 ms step in ~34, R5 DESIGN 4.11); opt-in since
     # round 5 because it is process-global; ``T.close()`` undoes it before the trainer is dropped
     if freeze:
         T.freeze_host_objects()
@@ -966,7 +966,7 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
             "ms_per_batch_frozen_spectral_norm": round(frozen / steps * 1e3, 2),
             "images_per_s_fp32_grade": round(world * INFER_BS * n32 / fp32, 2),
             "ms_per_batch_fp32_grade": round(fp32 / n32 * 1e3, 2),
-            "fp32_grade_mode": "G.float() = set_compute_dtype('split24'): split-precision Masker AND Painter (DESIGN 4.8, 0 item 8), %d timed batches" % n32,
+            "fp32_grade_mode": "G.float() = set_compute_dtype('split24'): split-precision Masker AND Painter (DESIGN 4.7), %d timed batches" % n32,
             "images_per_s_fp32_grade_mask_16bit_painter": modes["split24+fp16painter"]["images_per_s"],
             "fp32_grade_other_modes": dict(modes, note="hybrid = split-precision Masker (fp32-grade flood mask, tests/test_gpu_configs_640.py::"
                                            "test_hybrid_inference_keeps_the_fp32_grade_mask) + 16-bit Painter (G.set_painter_compute_dtype); pair16 = "

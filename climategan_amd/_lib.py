@@ -277,7 +277,7 @@ def load_dev():
         cg = os.environ.get("CGAN_DEBUG_WGRAD_COOP_G")          # 2: never the 16-wave weight-gradient tile, 4: wherever it applies
         if cg:
             _dev.cgan_debug_set_wgrad_coop_g(C.c_int(int(cg)))
-        bj = os.environ.get("CGAN_DEBUG_BN_JITTER")              # "<ppm>,<seed>": cgan_debug_set_bn_jitter
+        bj = os.environ.get("CGAN_DEBUG_BN_JITTER")              # "<ppm>,<seed>": cgan_debug_set_bn_jitter (R5 DESIGN 4.13)
         if bj:
             _dev.cgan_debug_set_bn_jitter(C.c_int(int(bj.split(",")[0])), C.c_int(int(bj.split(",")[1]) if "," in bj else 0))
         ck = os.environ.get("CGAN_DEBUG_CONV_KERNEL")            # cgan_debug_set_conv_kernel (4: without round 5's GEMM launches)

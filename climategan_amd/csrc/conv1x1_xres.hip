@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
             vr[t][hh] = (f32x2){r0, r1};
           }
         }
-        f32x2 s0[2] = {vr[0][0], vr[0][1]};      // (no "0 + v": that is a packed add with an op_sel-modified constant)
+        f32x2 s0[2] = {vr[0][0], vr[0][1]};      // (no "0 + v": that is a packed add with an op_sel-modified constant, R5 DESIGN 4.6)
 #pragma unroll
         for (int t = 1; t < WP; ++t) {
           s0[0] += vr[t][0];

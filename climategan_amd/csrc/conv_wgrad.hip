@@ -50,7 +50,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // services together read rows k and 8 + k of the slab -- 1024 B apart they start on the SAME banks whatever the slot
 // swizzle does (the swizzle depends on the row within a piece only), a 2-way conflict on every fragment read (SQ counters,
 // round 5: bank-conflict cycles = 0.49 of the LDS-active cycles).  One row of padding per piece rotates the odd pieces by
-// 32 banks: rows k and 8 + k then use complementary halves of the 64 banks for every slot pair (DESIGN 7).
+// 32 banks: rows k and 8 + k then use complementary halves of the 64 banks for every slot pair (DESIGN 4.3).
 constexpr int PIECE = 1024 + 128;
 constexpr int SLAB_BYTES = 4 * PIECE;       // 32 pixels x 64 channels x 2 B, in four padded pieces
 constexpr int WAVE_LDS = 4 * SLAB_BYTES;    // {dy, x} x double buffer

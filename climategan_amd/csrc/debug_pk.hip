@@ -1,7 +1,7 @@
 // Development aid (tools/check_pk_opsel_concurrent.py): a kernel made of the packed-fp32 instruction pair the vectoriser
 // formed in the first version of the wildfire blur -- v_pk_mul_f32 with one half of source 0 broadcast (op_sel_hi:[0,1]) and
 // v_pk_add_f32 with crossed halves -- on register pairs whose other half holds junk, repeated `iters` times, so that its
-// result can be compared alone and next to another stream's MFMA / LDS-DMA kernels.
+// result can be compared alone and next to another stream's MFMA / LDS-DMA kernels (R5 DESIGN 4.6).
 #include "cgan_common.h"
 
 #ifdef CGAN_DEV      // dev build only (libcgan_hip_dev.so): the product library has no development entry point

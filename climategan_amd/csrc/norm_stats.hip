@@ -292,7 +292,7 @@ int check(const CganNormStatsDesc* d) {
 
 #ifdef CGAN_DEV
 // dev: perturb every training-mode BatchNorm's batch rstd by up to +-ppm (uniform, hashed per layer call / group / channel):
-// how far do the step's gradients move for an error of a given size in the statistics
+// how far do the step's gradients move for an error of a given size in the statistics (R5 DESIGN 4.13)
 static int g_bn_jitter_ppm = 0;
 static unsigned g_bn_jitter_seed = 0;
 extern "C" void cgan_debug_set_bn_jitter(int ppm, int seed) { g_bn_jitter_ppm = ppm; g_bn_jitter_seed = (unsigned)seed; }

@@ -1,7 +1,7 @@
 // In-place pre-merge of a convolution epilogue's per-chunk BatchNorm statistics rows (cgan_batchnorm_train_stats_from_partials,
 // norm_stats.hip).  Own translation unit, listed in the Makefile's NOVEC: the SLP vectoriser forms op_sel-modified packed-fp32
 // instructions from chan_merge's pairs, whose results change on gfx950 while another stream runs MFMA / LDS-DMA kernels
-//  -- the two-stream train step stopped being bit-reproducible with them (tests/test_gpu_determinism.py).
+// (R5 DESIGN 4.6) -- the two-stream train step stopped being bit-reproducible with them (tests/test_gpu_determinism.py).
 #include "cgan_common.h"
 
 namespace {

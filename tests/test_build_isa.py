@@ -1,7 +1,7 @@
 """The built library's device code, disassembled: no op_sel-modified packed-fp32 instruction outside the development kernel
 that exists to demonstrate them.
 
-Round 3: on gfx950 ``v_pk_mul_f32`` / ``v_pk_add_f32`` with op_sel modifiers (one half of a source broadcast,
+Round 3 (R5 DESIGN 4.6): on gfx950 ``v_pk_mul_f32`` / ``v_pk_add_f32`` with op_sel modifiers (one half of a source broadcast,
 halves crossed) changed their results whenever another stream ran MFMA / LDS-DMA kernels on the same chip
 (tools/check_pk_opsel_concurrent.py); plain packed operations on fully defined register pairs and scalar operations did not.
 The compiler forms such instructions on its own (SLP / loop vectoriser), so the build switches both vectorisers off and this

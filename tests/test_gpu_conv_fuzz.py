@@ -212,7 +212,7 @@ WS_CASES = [
 @pytest.mark.parametrize("case", WS_CASES)
 def test_k64_specialised_gemm_matches_the_plain_kernel(case):
     """The persistent producer / consumer variant of the wide-layer GEMM with K = 64 stages (automatic for long-K 3x3 layers
-    in bf16, forced here through cgan_debug_set_gemm_ws) sums K in another order than the plain kernel: same
+    in bf16, forced here through cgan_debug_set_gemm_ws; R5 DESIGN 4.2) sums K in another order than the plain kernel: same
     products, results within a bf16 rounding step -- ragged pixel counts, partial cout blocks, dilation, stride, residual +
     activation, several tiles per workgroup.  Layers it does not take (reflect padding, channel counts that are not whole
     64-chunks) fall through to the plain kernel."""

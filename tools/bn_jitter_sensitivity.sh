@@ -1,6 +1,6 @@
 #!/bin/bash
 # How far does the joint train step's gradient move for an error of a given size in the training-mode BatchNorm statistics?
-# (the "one statistics row per workgroup" experiment of round 4 changed the batch rstd rows by up to 6e-4 and the
+# (R5 DESIGN 4.13: the "one statistics row per workgroup" experiment of round 4 changed the batch rstd rows by up to 6e-4 and the
 # encoder's gradient by 2.4 % / 0.015 of cosine.)  Dev build, every batch rstd times (1 + u * ppm * 1e-6), u uniform in [-1, 1]
 # per (layer call, group, channel); the metric lines are those of tests/test_gpu_configs_640.py (vs the reference's fp32 step).
 out=${1:-gpurun_out/bn_jitter.txt}

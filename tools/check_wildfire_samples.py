@@ -1,7 +1,7 @@
 """GPU box: the wildfire event on a batch of repeats next to kernels of a second stream -- per stage of the kernel chain, how
 many values of a repeat differ from its original (must be 0), for the 8-outputs-per-thread blur (0) and the reference blur
 (1); and sentinels that show whether the side-stream kernels write outside their own tensors.  This is the harness that
-found the round-3 packed-fp32 problem."""
+found the round-3 packed-fp32 problem (R5 DESIGN 4.6)."""
 import ctypes as C
 import sys
 from pathlib import Path

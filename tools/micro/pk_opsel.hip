@@ -1,6 +1,6 @@
 // Micro-test (GPU box): does v_pk_mul_f32 / v_pk_add_f32 with op_sel broadcasting ONE half of a source pair give a result
 // that is independent of the other half's content on gfx950?  (Round 3: compiler-formed packed operations on pairs with an
-// undefined half made the wildfire blur depend on other kernels' register leftovers)
+// undefined half made the wildfire blur depend on other kernels' register leftovers, R5 DESIGN 4.6.)
 //   build: hipcc --offload-arch=gfx950 -O2 tools/micro/pk_opsel.hip -o gpurun_out/pk_opsel   run: gpurun_out/pk_opsel
 #include <hip/hip_runtime.h>
 #include <cstdio>
