@@ -1164,13 +1164,13 @@ def main():
                 "share_of_step": round((ms / sampled) / (elapsed / args.steps * 1e3), 3),
                 "by_class": timer.classes()}
             lps = n // max(sampled, 1)
-            live = live_traffic(lps, args.global_batch) if (world == 1 and not args.no_live_traffic) else None
-            res["roofline"]["traffic"] = live if live is not None else recorded_traffic("*_conv_gemm_hbm_pmc.csv")
+            # (re-measured live further down, once this process has released the trainer's memory: the two child passes need the
+            # same 137 GB; until then the newest committed summary stands in)
+            res["roofline"]["traffic"] = recorded_traffic("*_conv_gemm_hbm_pmc.csv")
             res["roofline"]["traffic_unit"] = (
-                "HBM bytes per launch (mean over the family's %d launches of one step), %s: separate rocprofv3 --pmc FETCH_SIZE / "
-                "WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction"
-                % (lps, "MEASURED IN THIS RUN (two child passes of this command's headline step)" if live is not None
-                   else "from the newest committed profiles/*_conv_gemm_hbm_pmc.csv (rocprofv3 not usable in this run)"))
+                "HBM bytes per launch (mean over the family's %d launches of one step), from the newest committed "
+                "profiles/*_conv_gemm_hbm_pmc.csv (rocprofv3 not usable in this run): separate rocprofv3 --pmc FETCH_SIZE / "
+                "WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction" % lps)
             mu = recorded_mfma_util()
             if mu:
                 gk = [mu[k] for k in ("gemm 1x1", "gemm kxk") if k in mu]
@@ -1225,6 +1225,15 @@ def main():
     T.close()
     del T, batch
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_live_traffic and res.get("roofline"):
+        lps = res["roofline"]["launches_per_step"]
+        live = live_traffic(lps, args.global_batch)
+        if live is not None:
+            res["roofline"]["traffic"] = live
+            res["roofline"]["traffic_unit"] = (
+                "HBM bytes per launch (mean over the family's %d launches of one step), MEASURED IN THIS RUN (two child passes "
+                "of this command's headline step): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled "
+                "per the gfx950 correction" % lps)
     sub = {}
     # the sub-blocks are single-GPU measurements (BASELINE configs[1], [2], [4]); under torchrun only the headline runs: one
     # collective-bearing path less that could leave ranks waiting on each other after the line is out

@@ -110,7 +110,7 @@ def main():
 
     out = Path(__file__).resolve().parent.parent / "profiles" / outname
     with open(out, "w") as fo:
-        fo.write("# one joint train step (update_G + update_D, 4 per domain, bf16, single-stream), rocprofv3 --pmc SQ passes "
+        fo.write("# one joint train step (update_G + update_D, bench.py headline batch: 32 per domain since round 6, bf16, single-stream), rocprofv3 --pmc SQ passes "
                  "(tools/gpu_pmc_step_sq.sh), per kernel family; definitions in tools/mfma_util.py\n")
         fo.write("family," + ",".join(cols) + "\n")
         for k, a in agg.items():

@@ -118,7 +118,7 @@ def main():
     out = Path(__file__).resolve().parent.parent / "profiles" / outname
     tot = [0, 0.0, 0.0, 0.0, 0.0]
     with open(out, "w") as fo:
-        fo.write("# one joint train step (update_G + update_D, 4 per domain, bf16), every dispatch between two optimizer launches; HBM "
+        fo.write("# one joint train step (update_G + update_D, bench.py headline batch: 32 per domain since round 6, bf16), every dispatch between two optimizer launches; HBM "
                  "bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled per the gfx950 correction); "
                  "ms = the dispatches' own durations in the FETCH_SIZE pass (streams serialised by the tool); algorithmic_MB = operand "
                  "bytes each C-ABI call must touch once (bench.py --call-log), blank where no call log was given / torch-side\n")
