@@ -140,8 +140,15 @@ class GradBucketReducer:
         # from the autograd engine into Python per step cost more (~15 ms of a 160 ms step) than the overlap buys.
         # host-side group for finish()'s per-bucket agreement (every rank constructs its reducers in the same order)
         self._flag_group = None
-        if self.active and self.world > 1 and os.environ.get("CGAN_DDP_NO_FLAG_SYNC") != "1":
-            self._flag_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        if self.active and os.environ.get("CGAN_DDP_NO_FLAG_SYNC") != "1":
+            # (also on the one-rank RCCL group of tests/test_gpu_train.py: the only place a single-GPU box can run a gloo group
+            # beside an RCCL default group)
+            try:
+                self._flag_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+            except Exception as e:       # no gloo in this build, a refused rendezvous ...: rank-local decisions, as in round 5
+                if dist.get_rank() == 0:
+                    print("GradBucketReducer: no host-side group for the re-exchange flags (%s: %s); every rank decides for "
+                          "itself" % (type(e).__name__, e), flush=True)
         self._learning = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.reset()
