@@ -79,26 +79,29 @@ struct BF16 {
 // ------------------------------------------------------------------------------------------------
 // split-precision maps (csrc/pair.hip, cgan_conv2d_nhwc_fwd_pair)
 // ------------------------------------------------------------------------------------------------
-// A value is carried as NC 16-bit components (v = c0 + c1 [+ c2], each the rounding of what the previous ones left) and a
-// map stores NB channel blocks per pixel, block b holding component xcomp(b); the matching weights hold component wcomp(b)
-// along their input channels, so that ONE ordinary K loop accumulates every product of (sum x_i)(sum w_j) down to the
-// type's precision floor:
+// A value is carried as NC 16-bit components (v = c0 + c1 [+ c2], each the rounding of what the previous ones left).  A conv
+// multiplies NB K-blocks per pixel, K-block b being component xcomp(b) of the input against component wcomp(b) of the weights
+// along their input channels, so that ONE ordinary K loop accumulates every product of (sum x_i)(sum w_j) down to the type's
+// precision floor.  A map STORES each component once: NS = NC channel blocks per pixel (round 6; rounds 4-5 stored all NB
+// K-blocks, i.e. every component up to three times: twice the bytes per activation) -- the conv kernels read K-block b from
+// storage block xcomp(b):
 //   fp16 (11-bit mantissa, narrow exponent): NC = 2, blocks (c0 | c1 | c0) x (w0 | w0 | w1): 22 bits where the low part
 //        stays a normal number (|v| >~ 0.1), an absolute floor of 2^-24 below;
 //   bf16 (8-bit mantissa, fp32's exponent):  NC = 3, blocks (c0 | c1 | c2 | c0 | c1 | c0) x (w0 | w0 | w0 | w1 | w1 | w2):
 //        every product down to 2^-16 of the leading one, 24 bits at any magnitude = the fp32 reference's arithmetic.
 template <typename T> struct Split;
 template <> struct Split<F16> {
-  static constexpr int NC = 2, NB = 3;
+  static constexpr int NC = 2, NB = 3, NS = 2;
   __host__ __device__ static constexpr int xcomp(int b) { return b == 1 ? 1 : 0; }
   __host__ __device__ static constexpr int wcomp(int b) { return b == 2 ? 1 : 0; }
 };
 template <> struct Split<BF16> {
-  static constexpr int NC = 3, NB = 6;
+  static constexpr int NC = 3, NB = 6, NS = 3;
   __host__ __device__ static constexpr int xcomp(int b) { return b == 1 || b == 4 ? 1 : (b == 2 ? 2 : 0); }
   __host__ __device__ static constexpr int wcomp(int b) { return b < 3 ? 0 : (b < 5 ? 1 : 2); }
 };
-static inline int cgan_split_blocks(int dtype) { return dtype == CGAN_BF16 ? 6 : 3; }
+static inline int cgan_split_blocks(int dtype) { return dtype == CGAN_BF16 ? 6 : 3; }      // K blocks a conv multiplies
+static inline int cgan_split_store_blocks(int dtype) { return dtype == CGAN_BF16 ? 3 : 2; }  // blocks a map STORES (round 6)
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);

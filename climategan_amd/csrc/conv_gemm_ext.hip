@@ -72,6 +72,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
   const int pblk = xcd * ((npb + 7) >> 3) + slot / ncb;
   if (pblk >= npb || pblk * PT_BLK * 16 >= npix) return;
 
+  // split maps (q.pair): the map stores each component once (Split<T>::NS blocks of csb channels per pixel); K-block b of the
+  // conv's NB * csb input channels is storage block xcomp(b): the pixel stride is the stored one and a lane's 8-channel group
+  // is looked up per stage (pair_coff)
+  const int csb = q.pair ? p.cin_s / Split<T>::NB : p.cin_s;
+  const int xstride = q.pair ? Split<T>::NS * csb : p.cin_s;
+  const float inv_csb = 1.0f / (float)csb;
+  auto pair_coff = [&](int c) {       // channel c of the K extent -> channel of the stored pixel (c, csb multiples of 8)
+    const int b = (int)(((float)c + 0.5f) * inv_csb);
+    return Split<T>::xcomp(b) * csb + (c - b * csb);
+  };
   int pbase[P_PER_WAVE], py0[P_PER_WAVE], px0[P_PER_WAVE];
 #pragma unroll
   for (int m = 0; m < P_PER_WAVE; ++m) {
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
     int r = pc / wcls;
     int oy = r % hc;
     int nn = r / hc;
-    pbase[m] = nn * p.h_in * p.w_in * p.cin_s + g * 8;
+    pbase[m] = nn * p.h_in * p.w_in * xstride + (q.pair ? 0 : g * 8);
     py0[m] = v ? oy * stride + offy : -(1 << 28);
     px0[m] = ox * stride + offx;
   }
@@ -107,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
       const int i = wave + 4 * m;
       const int iy = py0[m] + i_ky * p.dil, ix = px0[m] + i_kx * p.dil;
       const bool ok = (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
-      const long off = ok ? (long)(pbase[m] + (iy * p.w_in + ix) * p.cin_s + i_cc * 32) * 2 : zero_off;
+      const int coff = q.pair ? pair_coff(i_cc * 32 + g * 8) : i_cc * 32;
+      const long off = ok ? (long)(pbase[m] + (iy * p.w_in + ix) * xstride + coff) * 2 : zero_off;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + off;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(buf + (CT_BLK + i) * 1024), 16, 0, 0);
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
       if (q.pair) {
         // split-precision epilogue (as conv_mfma_kernel's): residual = the sum of its components, activation in fp32, then
         // v -> c0 = round16(v), c1 = round16(v - c0), ... stored as the channel blocks the next conv multiplies (Split<T>)
-        constexpr int NB = Split<T>::NB, NC = Split<T>::NC;
+        constexpr int NS = Split<T>::NS, NC = Split<T>::NC;
         if (p.has_res) {
           size_t rbase = (size_t)pix;
           if (p.res_ups) {
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
             const int nn = r / p.h_out;
             rbase = ((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1);
           }
-          const uint16_t* rp = p.res + rbase * p.cout_s * NB + ch;
+          const uint16_t* rp = p.res + rbase * p.cout_s * NS + ch;
           float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int k = NC - 1; k >= 0; --k) {         // smallest component first
@@ -260,9 +271,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
             v[2 * e + 1] -= q1;
           }
         }
-        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NB + ch;
+        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NS + ch;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) *reinterpret_cast<u32x4*>(yp + b * p.cout_s) = comp[Split<T>::xcomp(b)];
+        for (int b = 0; b < NS; ++b) *reinterpret_cast<u32x4*>(yp + b * p.cout_s) = comp[b];
         continue;
       }
       act_apply_n(v, p.act, p.slope);

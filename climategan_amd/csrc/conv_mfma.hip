@@ -37,8 +37,9 @@ struct ConvParams {
   int cls_pad; // pad' = k - 1 - pad of that data gradient
   float slope;
   float* stats; // optional per-chunk (mean, M2) output of the wide-layer GEMM kernel (cgan_conv2d_nhwc_fwd_stats)
-  int pair;     // 1: split-precision output (cgan_conv2d_nhwc_fwd_pair): y and the residual are split maps of Split<T>::NB
-                // blocks of cout_s channels per pixel (the fp32 result carried in two / three 16-bit numbers)
+  int pair;     // 1: split-precision conv (cgan_conv2d_nhwc_fwd_pair): x, y and the residual are split maps of Split<T>::NS
+                // blocks per pixel (a value carried in two / three 16-bit numbers); the K extent cin_s = NB * csb
+  int xs, csb;  // pixel stride of x in elements (cin_s; split maps: NS * csb) and channels per block of a split map
 };
 
 // Parity-class decomposition of the data gradient of a stride-s convolution (dilation 1).  dx[y] = sum over the
@@ -155,6 +156,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       if (ct < p.ctiles) a[c] = wbase[((size_t)ct * ksteps + ksc) * 64 + lane];
     }
     const int dy = ky * p.dil, dx = kx * p.dil;
+    unsigned coff = (unsigned)(c8 * 8);
+    if (p.pair) {      // K-block b of a split map's NB * csb input channels = storage block xcomp(b) (cgan_common.h, Split<T>)
+      const int b = (int)(((float)(c8 * 8) + 0.5f) * (1.0f / (float)p.csb));
+      coff = (unsigned)(Split<T>::xcomp(b < Split<T>::NB ? b : 0) * p.csb + (c8 * 8 - b * p.csb));
+    }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       int iy = py0[t] + dy, ix = px0[t] + dx;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         if (p.in_ups) { iy >>= 1; ix >>= 1; }
         // 32-bit element offset (fill_params checks the tensor has < 2^32 elements): a 64-bit multiply chain here
         // costs more issue slots than the MFMAs it feeds
-        const unsigned off = ((unsigned)(pn[t] * p.hx + iy) * (unsigned)p.wx + (unsigned)ix) * (unsigned)p.cin_s + (unsigned)(c8 * 8);
+        const unsigned off = ((unsigned)(pn[t] * p.hx + iy) * (unsigned)p.wx + (unsigned)ix) * (unsigned)p.xs + coff;
         b[t] = *reinterpret_cast<const u32x4*>(p.x + off);
       }
     }
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       // split-precision epilogue: bias / residual / activation in fp32, then v -> its 16-bit components (c0 = round16(v),
       // c1 = round16(v - c0), ...), stored as the channel blocks the next conv multiplies by the matching weight blocks
       // (cgan_common.h, Split<T>)
-      constexpr int NB = Split<T>::NB, NC = Split<T>::NC;
+      constexpr int NS = Split<T>::NS, NC = Split<T>::NC;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int ch = (ctile0 + c) * 16 + g * 4;
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[c][t][r] + bias_q[c][r];
         if (p.has_res) {
-          const uint16_t* rp = p.res + rbase * NB + ch;
+          const uint16_t* rp = p.res + rbase * NS + ch;
           float rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int k = NC - 1; k >= 0; --k) {
@@ -288,9 +294,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
           unpack2<T>(comp[k][1], q2, q3);
           v[0] -= q0; v[1] -= q1; v[2] -= q2; v[3] -= q3;
         }
-        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NB + ch;
+        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NS + ch;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) *reinterpret_cast<u32x2*>(yp + b * p.cout_s) = comp[Split<T>::xcomp(b)];
+        for (int b = 0; b < NS; ++b) *reinterpret_cast<u32x2*>(yp + b * p.cout_s) = comp[b];
       }
       continue;
     }
@@ -615,6 +621,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   p.hx = d->in_upsample ? d->h_in / 2 : d->h_in;
   p.wx = d->in_upsample ? d->w_in / 2 : d->w_in;
   p.cin_s = cgan_cs(d->c_in); p.cin_p = conv_cin_p(p.cin_s, d->kh, d->kw); p.cg = p.cin_p / 8;
+  p.xs = p.cin_s; p.csb = p.cin_s;
   p.cout = d->c_out; p.cout_s = cgan_cs(d->c_out); p.ctiles = ceil_div(p.cout_s, 16);
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dilation; p.pad_mode = d->pad_mode;
   p.h_out = d->h_out; p.w_out = d->w_out;
@@ -905,16 +912,18 @@ extern "C" int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, 
   CGAN_REQUIRE(!d->has_residual || residual3, "conv2d_nhwc_fwd_pair: has_residual but residual is null");
   const int nb = cgan_split_blocks(d->dtype);
   CGAN_REQUIRE((d->c_in % (8 * nb)) == 0, "conv2d_nhwc_fwd_pair: c_in must be the %d * round_up(C, 8) storage channels of a split map", nb);
-  CGAN_REQUIRE((double)p.npix * p.cout_s * nb * 2.0 < 4294967295.0, "conv2d_nhwc_fwd_pair: output map of 4 GiB or more");
+  CGAN_REQUIRE((double)p.npix * p.cout_s * cgan_split_store_blocks(d->dtype) * 2.0 < 4294967295.0, "conv2d_nhwc_fwd_pair: output map of 4 GiB or more");
   p.x = (const uint16_t*)x3; p.w = (const u32x4*)packed_w3; p.bias = d->has_bias ? bias_padded : nullptr;
   p.res = (const uint16_t*)residual3; p.y = (uint16_t*)y3;
   p.pair = 1;
+  p.csb = p.cin_s / nb;                                   // the input map stores each component once: NS blocks of csb
+  p.xs = cgan_split_store_blocks(d->dtype) * p.csb;
   hipStream_t s = (hipStream_t)stream;
   // wide layers on the LDS-tiled GEMM (round 5): whole 32-channel k-steps per tap, zero padding, no folded upsample, enough
   // pixels for its 128 / 256-pixel block tiles; everything else stays on the gather kernel
   if (g_conv_force == 0 && p.in_zs == 1 && !p.in_ups && p.cin_p == p.cin_s && p.pad >= 0 && p.npix >= 1024 && p.ksteps >= 4) {
     const ConvGemmArgs a = gemm_args(p);
-    if (conv_gemm_ext_shape_ok(a) && (double)p.npix * p.cout_s * nb < 2147483647.0) {
+    if (conv_gemm_ext_shape_ok(a) && (double)p.npix * p.cout_s * cgan_split_store_blocks(d->dtype) < 2147483647.0) {
       rc = conv_gemm_pair_launch(a, d->dtype, s);
       if (rc != CGAN_OK) return rc;
       CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd_pair(gemm)");

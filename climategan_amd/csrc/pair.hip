@@ -3,8 +3,8 @@
 // The reference's default apply_events run and its binarised flood mask are fp32 (apply_events.py:465-468,
 // trainer.py:1866-1871); every conv kernel of this library multiplies 16-bit operands on the MFMA units.  A value v is
 // therefore carried as several 16-bit numbers (cgan_common.h, Split<T>: fp16 pairs hi + lo, bf16 triples hi + mid + lo) and
-// a map is stored per pixel as NB channel blocks of round_up(C, 8) channels each -- (hi | lo | hi) resp.
-// (hi | mid | lo | hi | mid | hi) -- multiplied by packed weights (W_hi | W_hi | W_lo) resp. (W_hi | W_hi | W_hi | W_mid |
+// a map is stored per pixel as NS = NC channel blocks of round_up(C, 8) channels each -- (hi | lo) resp. (hi | mid | lo); a conv
+// reads them as the NB K-blocks (hi | lo | hi) resp. (hi | mid | lo | hi | mid | hi) -- multiplied by packed weights (W_hi | W_hi | W_lo) resp. (W_hi | W_hi | W_hi | W_mid |
 // W_mid | W_lo) along K: an existing conv kernel then accumulates every cross product above the type's precision floor in
 // fp32.  cgan_conv2d_nhwc_fwd_pair (conv_mfma.hip) stores its fp32 result as such a map again; the few glue ops of the Masker
 // between convs (max-pool, bilinear / nearest resize, channel concatenation, the DADA product, sigmoid, the layout edges) are
@@ -54,7 +54,7 @@ __device__ __forceinline__ void pair_store8(uint16_t* __restrict__ px, int cs, i
     }
   }
 #pragma unroll
-  for (int b = 0; b < Split<T>::NB; ++b) *reinterpret_cast<u32x4*>(px + b * cs + cg * 8) = comp[Split<T>::xcomp(b)];
+  for (int b = 0; b < Split<T>::NS; ++b) *reinterpret_cast<u32x4*>(px + b * cs + cg * 8) = comp[b];
 }
 
 // fp32 NCHW -> pair NHWC (pad channels zero)
@@ -71,7 +71,7 @@ __global__ void pair_from_nchw_kernel(const float* __restrict__ x, uint16_t* __r
       const int ch = cg * 8 + e;
       v[e] = ch < c ? x[(n * c + ch) * (long)hw + p] : 0.f;
     }
-    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, v);
+    pair_store8<T>(y + pix * Split<T>::NS * cs, cs, cg, v);
   }
 }
 
@@ -85,7 +85,7 @@ __global__ void pair_to_nchw_kernel(const uint16_t* __restrict__ x, float* __res
     const long pix = idx / cg_total;
     const long n = pix / hw, p = pix % hw;
     float v[8];
-    pair_load8<T>(x + pix * Split<T>::NB * cs, cs, cg, v);
+    pair_load8<T>(x + pix * Split<T>::NS * cs, cs, cg, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int ch = cg * 8 + e;
@@ -102,7 +102,7 @@ __global__ void pair_to_nhwc_kernel(const uint16_t* __restrict__ x, uint16_t* __
     const int cg = (int)(idx % cg_total);
     const long pix = idx / cg_total;
     float v[8];
-    pair_load8<T>(x + pix * Split<T>::NB * cs, cs, cg, v);
+    pair_load8<T>(x + pix * Split<T>::NS * cs, cs, cg, v);
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
@@ -132,12 +132,12 @@ __global__ void pair_maxpool3x3s2_kernel(const uint16_t* __restrict__ x, uint16_
         const int ix = 2 * ox - 1 + dx;
         if (ix < 0 || ix >= w) continue;
         float v[8];
-        pair_load8<T>(x + ((n * h + iy) * (long)w + ix) * Split<T>::NB * cs, cs, cg, v);
+        pair_load8<T>(x + ((n * h + iy) * (long)w + ix) * Split<T>::NS * cs, cs, cg, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
       }
     }
-    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, m);
+    pair_store8<T>(y + pix * Split<T>::NS * cs, cs, cg, m);
   }
 }
 
@@ -165,16 +165,16 @@ __global__ void pair_resize_bilinear_kernel(const uint16_t* __restrict__ x, uint
     x0 = x0 < w_in - 1 ? x0 : w_in - 1;
     const int y1 = y0 < h_in - 1 ? y0 + 1 : y0, x1 = x0 < w_in - 1 ? x0 + 1 : x0;
     const float ly = fy - y0, lx = fx - x0;
-    const uint16_t* base = x + n * (long)h_in * w_in * Split<T>::NB * cs;
+    const uint16_t* base = x + n * (long)h_in * w_in * Split<T>::NS * cs;
     float v00[8], v01[8], v10[8], v11[8], o[8];
-    pair_load8<T>(base + ((long)y0 * w_in + x0) * Split<T>::NB * cs, cs, cg, v00);
-    pair_load8<T>(base + ((long)y0 * w_in + x1) * Split<T>::NB * cs, cs, cg, v01);
-    pair_load8<T>(base + ((long)y1 * w_in + x0) * Split<T>::NB * cs, cs, cg, v10);
-    pair_load8<T>(base + ((long)y1 * w_in + x1) * Split<T>::NB * cs, cs, cg, v11);
+    pair_load8<T>(base + ((long)y0 * w_in + x0) * Split<T>::NS * cs, cs, cg, v00);
+    pair_load8<T>(base + ((long)y0 * w_in + x1) * Split<T>::NS * cs, cs, cg, v01);
+    pair_load8<T>(base + ((long)y1 * w_in + x0) * Split<T>::NS * cs, cs, cg, v10);
+    pair_load8<T>(base + ((long)y1 * w_in + x1) * Split<T>::NS * cs, cs, cg, v11);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       o[e] = (1.f - ly) * ((1.f - lx) * v00[e] + lx * v01[e]) + ly * ((1.f - lx) * v10[e] + lx * v11[e]);
-    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, o);
+    pair_store8<T>(y + pix * Split<T>::NS * cs, cs, cg, o);
   }
 }
 
@@ -205,7 +205,7 @@ __global__ void pair_resize_bicubic_kernel(const uint16_t* __restrict__ x, uint1
     float wy[4], wx[4];
     pair_cubic_coeffs(fy - fly, wy);
     pair_cubic_coeffs(fx - flx, wx);
-    const uint16_t* base = x + n * (long)h_in * w_in * Split<T>::NB * cs;
+    const uint16_t* base = x + n * (long)h_in * w_in * Split<T>::NS * cs;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -219,14 +219,14 @@ __global__ void pair_resize_bicubic_kernel(const uint16_t* __restrict__ x, uint1
         int xx = ix - 1 + j;
         xx = xx < 0 ? 0 : (xx > w_in - 1 ? w_in - 1 : xx);
         float v[8];
-        pair_load8<T>(base + ((long)yy * w_in + xx) * Split<T>::NB * cs, cs, cg, v);
+        pair_load8<T>(base + ((long)yy * w_in + xx) * Split<T>::NS * cs, cs, cg, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) row[e] += wx[j] * v[e];
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += wy[i] * row[e];
     }
-    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, acc);
+    pair_store8<T>(y + pix * Split<T>::NS * cs, cs, cg, acc);
   }
 }
 
@@ -258,11 +258,11 @@ __global__ void pair_mul_kernel(const uint16_t* __restrict__ a, const uint16_t* 
     const int cg = (int)(idx % cg_total);
     const long pix = idx / cg_total;
     float va[8], vb[8];
-    pair_load8<T>(a + pix * Split<T>::NB * cs, cs, cg, va);
-    pair_load8<T>(b + pix * Split<T>::NB * cs, cs, cg, vb);
+    pair_load8<T>(a + pix * Split<T>::NS * cs, cs, cg, va);
+    pair_load8<T>(b + pix * Split<T>::NS * cs, cs, cg, vb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) va[e] *= vb[e];
-    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, va);
+    pair_store8<T>(y + pix * Split<T>::NS * cs, cs, cg, va);
   }
 }
 
@@ -318,11 +318,11 @@ __global__ __launch_bounds__(256) void pair_instnorm_stats_kernel(const uint16_t
                                                                   float* __restrict__ rstd, int hw, int cs, float eps) {
   __shared__ double red[256][8];
   const int cg = blockIdx.x, n = blockIdx.y;
-  const uint16_t* base = x + (size_t)n * hw * Split<T>::NB * cs;
+  const uint16_t* base = x + (size_t)n * hw * Split<T>::NS * cs;
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int p = threadIdx.x; p < hw; p += 256) {
     float v[8];
-    pair_load8<T>(base + (size_t)p * Split<T>::NB * cs, cs, cg, v);
+    pair_load8<T>(base + (size_t)p * Split<T>::NS * cs, cs, cg, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] += (double)v[e];
   }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void pair_instnorm_stats_kernel(const uint16_t
   for (int e = 0; e < 8; ++e) s[e] = 0;
   for (int p = threadIdx.x; p < hw; p += 256) {
     float v[8];
-    pair_load8<T>(base + (size_t)p * Split<T>::NB * cs, cs, cg, v);
+    pair_load8<T>(base + (size_t)p * Split<T>::NS * cs, cs, cg, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const double d = (double)v[e] - m[e];
@@ -384,10 +384,10 @@ __global__ void pair_spade_apply_kernel(const uint16_t* __restrict__ x, const fl
     const long n = r / h;
     const long xpix = ups ? (n * (h >> 1) + (yy >> 1)) * (long)(w >> 1) + (xx >> 1) : pix;
     float xv[8], gv[8], bv[8], o[8];
-    pair_load8<T>(x + xpix * Split<T>::NB * cs, cs, cg, xv);
+    pair_load8<T>(x + xpix * Split<T>::NS * cs, cs, cg, xv);
     if (gamma) {
-      pair_load8<T>(gamma + pix * Split<T>::NB * cs, cs, cg, gv);
-      pair_load8<T>(beta + pix * Split<T>::NB * cs, cs, cg, bv);
+      pair_load8<T>(gamma + pix * Split<T>::NS * cs, cs, cg, gv);
+      pair_load8<T>(beta + pix * Split<T>::NS * cs, cs, cg, bv);
     } else {                     // a plain normalisation (+ activation): eval-mode BatchNorm behind a split-precision conv
 #pragma unroll
       for (int e = 0; e < 8; ++e) gv[e] = bv[e] = 0.f;
@@ -402,7 +402,7 @@ __global__ void pair_spade_apply_kernel(const uint16_t* __restrict__ x, const fl
       }
       o[e] = v;
     }
-    pair_store8<T>(y + pix * Split<T>::NB * cs, cs, cg, o);
+    pair_store8<T>(y + pix * Split<T>::NS * cs, cs, cg, o);
   }
 }
 
@@ -412,11 +412,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void pair_minmax_c0_kernel(const uint16_t* __restrict__ d, float* __restrict__ mm, int hw) {
   __shared__ float smin[256], smax[256];
   const int n = blockIdx.x;
-  const uint16_t* base = d + (size_t)n * hw * Split<T>::NB * 8;
+  const uint16_t* base = d + (size_t)n * hw * Split<T>::NS * 8;
   float lo = __builtin_inff(), hi = -__builtin_inff();
   for (int p = threadIdx.x; p < hw; p += 256) {
     float v[8];
-    pair_load8<T>(base + (size_t)p * Split<T>::NB * 8, 8, 0, v);
+    pair_load8<T>(base + (size_t)p * Split<T>::NS * 8, 8, 0, v);
     lo = fminf(lo, v[0]);
     hi = fmaxf(hi, v[0]);
   }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void pair_make_m_cond_kernel(const uint16_t* _
 #pragma unroll
     for (int c = 0; c < PAIR_COND_MAX_C; ++c) o[c] = 0.f;
     float v[8];
-    pair_load8<T>(d + i * Split<T>::NB * 8, 8, 0, v);
+    pair_load8<T>(d + i * Split<T>::NS * 8, 8, 0, v);
     const float dmin = mm[2 * n], dmax = mm[2 * n + 1];
     o[0] = __fdiv_rn(v[0] - dmin, dmax - dmin);            // tutils.normalize: (t - min) / max(t - min)
     float sv[PAIR_COND_MAX_C];
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void pair_make_m_cond_kernel(const uint16_t* _
 #pragma unroll
     for (int g = 0; g < PAIR_COND_MAX_C / 8; ++g)
       if (g * 8 < sc) {
-        pair_load8<T>(seg + i * Split<T>::NB * scs, scs, g, v);
+        pair_load8<T>(seg + i * Split<T>::NS * scs, scs, g, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           sv[g * 8 + e] = v[e];
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void pair_make_m_cond_kernel(const uint16_t* _
     }
 #pragma unroll
     for (int g = 0; g < PAIR_COND_MAX_C / 8; ++g)
-      if (g * 8 < ccs) pair_store8<T>(cond + i * Split<T>::NB * ccs, ccs, g, o + g * 8);
+      if (g * 8 < ccs) pair_store8<T>(cond + i * Split<T>::NS * ccs, ccs, g, o + g * 8);
   }
 }
 
@@ -579,7 +579,7 @@ extern "C" int cgan_pair_resize_nearest(const void* x3, void* y3, int32_t dtype,
                                         int32_t w_in, int32_t h_out, int32_t w_out, void* stream) {
   CGAN_REQUIRE(x3 && y3 && n > 0 && c > 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0, "pair_resize_nearest: bad arguments");
   PAIR_CHECK_DT("pair_resize_nearest");
-  const int cs3 = cgan_split_blocks(dtype) * cgan_cs(c);
+  const int cs3 = cgan_split_store_blocks(dtype) * cgan_cs(c);
   const long total = (long)n * h_out * w_out * (cs3 / 8);
   hipLaunchKernelGGL(pair_resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x3,
                      (uint16_t*)y3, h_in, w_in, h_out, w_out, cs3, (float)h_in / (float)h_out, (float)w_in / (float)w_out, total);
@@ -603,7 +603,7 @@ extern "C" int cgan_pair_copy_channels(const void* src3, void* dst3, int32_t dty
   CGAN_REQUIRE(src3 && dst3 && npix > 0 && c > 0 && c_dst > 0, "pair_copy_channels: bad arguments");
   PAIR_CHECK_DT("pair_copy_channels");
   CGAN_REQUIRE((c_off % 8) == 0 && c_off + cgan_cs(c) <= cgan_cs(c_dst), "pair_copy_channels: bad channel offset %d", c_off);
-  const int nb = cgan_split_blocks(dtype);
+  const int nb = cgan_split_store_blocks(dtype);
   const long total = (long)npix * nb * (cgan_cs(c) / 8);
   hipLaunchKernelGGL(pair_copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src3,
                      (uint16_t*)dst3, cgan_cs(c), cgan_cs(c_dst), c_off, nb, total);

@@ -135,9 +135,15 @@ class NHWC:
 
 
 def split_blocks(dtype) -> int:
-    """Channel blocks per pixel of a split-precision map (csrc/cgan_common.h, Split<T>): fp16 pairs (hi | lo | hi) = 3,
-    bf16 triples (hi | mid | lo | hi | mid | hi) = 6."""
+    """K blocks a split-precision conv multiplies per pixel (csrc/cgan_common.h, Split<T>::NB): fp16 pairs (hi | lo | hi) = 3,
+    bf16 triples (hi | mid | lo | hi | mid | hi) = 6 -- the input-channel extent of the expanded weights."""
     return 6 if dtype == torch.bfloat16 else 3
+
+
+def store_blocks(dtype) -> int:
+    """Channel blocks per pixel a split-precision map STORES (Split<T>::NS, round 6): every component once -- fp16 (hi | lo) =
+    2, bf16 (hi | mid | lo) = 3; the conv kernels read K block b from storage block xcomp(b)."""
+    return 3 if dtype == torch.bfloat16 else 2
 
 
 @dataclass
@@ -150,9 +156,9 @@ class PairMap:
     sigmoid: bool = False
 
     def __post_init__(self):
-        if self.t.dim() != 4 or self.t.shape[3] != split_blocks(self.t.dtype) * cs8(self.c):
+        if self.t.dim() != 4 or self.t.shape[3] != store_blocks(self.t.dtype) * cs8(self.c):
             raise RuntimeError("PairMap: a [N,H,W,%d*%d] tensor is needed for %d logical channels, got shape %s"
-                               % (split_blocks(self.t.dtype), cs8(self.c), self.c, tuple(self.t.shape)))
+                               % (store_blocks(self.t.dtype), cs8(self.c), self.c, tuple(self.t.shape)))
 
     @property
     def n(self): return self.t.shape[0]
@@ -161,9 +167,11 @@ class PairMap:
     @property
     def w(self): return self.t.shape[2]
     @property
-    def cs(self): return self.t.shape[3] // split_blocks(self.t.dtype)
+    def cs(self): return self.t.shape[3] // store_blocks(self.t.dtype)
     @property
-    def nb(self): return split_blocks(self.t.dtype)
+    def nb(self): return store_blocks(self.t.dtype)          # stored blocks per pixel
+    @property
+    def kb(self): return split_blocks(self.t.dtype)          # K blocks a conv multiplies
     @property
     def dtype_id(self): return _DT[self.t.dtype]
     @property
@@ -185,7 +193,7 @@ def pair_from_nchw(x: torch.Tensor, dtype: torch.dtype) -> PairMap:
     _need_cuda(x)
     x = x.contiguous().float()
     n, c, h, w = x.shape
-    y = _empty((n, h, w, split_blocks(dtype) * cs8(c)), dtype=dtype, device=x.device)
+    y = _empty((n, h, w, store_blocks(dtype) * cs8(c)), dtype=dtype, device=x.device)
     _lib.check(_lib.load().cgan_pair_from_nchw(_ptr(x), _ptr(y), _DT[dtype], n, c, h, w, _stream()), "cgan_pair_from_nchw")
     return PairMap(y, c)
 
@@ -923,7 +931,7 @@ def conv2d(x: NHWC, pw: PackedConv, stride=1, pad=0, dilation=1, pad_mode=PAD_ZE
         if residual is not None and (not isinstance(residual, PairMap) or residual.c != pw.c_out):
             raise RuntimeError("conv2d: the residual of a pair conv must be a pair map of the output's channels")
         h_in, w_in = (x.h * 2, x.w * 2) if in_upsample else (x.h, x.w)
-        d = _conv_desc(x.dtype_id, x.n, h_in, w_in, x.nb * x.cs, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode,
+        d = _conv_desc(x.dtype_id, x.n, h_in, w_in, x.kb * x.cs, pw.c_out, pw.kh, pw.kw, stride, pad, dilation, pad_mode,
                        in_upsample, act, slope, pw.has_bias, residual is not None, residual_upsample)
         y = _empty((x.n, d.h_out, d.w_out, x.nb * cs8(pw.c_out)), dtype=x.t.dtype, device=x.t.device)
         _lib.check(_lib.load().cgan_conv2d_nhwc_fwd_pair(_ptr(x.t), _ptr(pw.w), _ptr(pw.bias),

@@ -670,13 +670,16 @@ int cgan_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* comm, v
  * 16-bit MFMA kernels reproduce the fp32 arithmetic: dtype CGAN_F16 = pairs hi + lo (22 bits of mantissa where lo stays a
  * normal number, an absolute floor of 2^-24 below |v| ~ 0.1), dtype CGAN_BF16 = triples hi + mid + lo (24 bits at any
  * magnitude: what the module mirror's G.float() / G.set_compute_dtype("split24") selects; "pair16" = the fp16 pairs).
- * A split map of C channels is an NHWC buffer of NB * cgan_cs(C) channels per pixel, NB = 3 blocks (hi | lo | hi) resp.
- * NB = 6 blocks (hi | mid | lo | hi | mid | hi); conv weights are expanded to (W_hi | W_hi | W_lo) resp. (W_hi | W_hi | W_hi |
- * W_mid | W_mid | W_lo) along the input channels (cgan_pair_expand_weight, then the ordinary cgan_conv2d_pack_weight with
- * c_in = NB * cgan_cs(C_in)): every cross product above the type's precision floor accumulates in fp32 inside the existing
- * conv kernel.
- * cgan_conv2d_nhwc_fwd_pair: the conv of such a map (d->c_in = NB * cgan_cs(C_in), d->c_out = C_out; bias, optional split
- * residual, activation in fp32) stored as a split map again (NB * cgan_cs(C_out) channels).  The rest are the Masker's glue
+ * A split map of C channels is an NHWC buffer of NS * cgan_cs(C) channels per pixel that stores every component ONCE: NS = 2
+ * blocks (hi | lo) resp. NS = 3 blocks (hi | mid | lo) (round 6; rounds 4-5 stored the NB K-blocks below, i.e. twice the
+ * bytes).  A conv multiplies NB = 3 K-blocks (hi | lo | hi) resp. NB = 6 (hi | mid | lo | hi | mid | hi) -- its kernels read
+ * K-block b from the storage block holding that component -- against weights expanded to (W_hi | W_hi | W_lo) resp. (W_hi |
+ * W_hi | W_hi | W_mid | W_mid | W_lo) along the input channels (cgan_pair_expand_weight, then the ordinary
+ * cgan_conv2d_pack_weight with c_in = NB * cgan_cs(C_in)): every cross product above the type's precision floor accumulates
+ * in fp32 inside the existing conv kernel.
+ * cgan_conv2d_nhwc_fwd_pair: the conv of such a map (d->c_in = NB * cgan_cs(C_in) = the K extent, x3 holds NS * cgan_cs(C_in)
+ * channels per pixel; d->c_out = C_out; bias, optional split residual, activation in fp32) stored as a split map again
+ * (NS * cgan_cs(C_out) channels).  The rest are the Masker's glue
  * ops between convs, each evaluated in fp32 on the sum of the components: layout edges (fp32 NCHW <-> split; _to_nchw with
  * the sigmoid of generator.py:277; _to_nhwc = one ordinary 16-bit map for the event kernels), nn.MaxPool2d(3, 2, 1),
  * F.interpolate bilinear (both align_corners) / legacy nearest, the DADA product (deeplab_v3.py:253-254), torch.cat on

@@ -19,7 +19,7 @@ def test_layout_round_trip_and_precision(dt):
 
     x = _rand((2, 19, 24, 20), 1, 3.0)
     p = ops.pair_from_nchw(x, dt)
-    assert tuple(p.t.shape) == (2, 24, 20, ops.split_blocks(dt) * 24) and p.c == 19
+    assert tuple(p.t.shape) == (2, 24, 20, ops.store_blocks(dt) * 24) and p.c == 19
     back = ops.nhwc_to_nchw(p)
     rel = ((back - x).abs() / x.abs().clamp_min(0.25)).max().item()        # (fp16 pairs: an absolute floor below |v| ~ 0.1)
     assert rel <= (2.0 ** -21 if dt == torch.float16 else 2.0 ** -23), rel
