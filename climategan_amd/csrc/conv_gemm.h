@@ -56,6 +56,8 @@ bool conv_gemm_big_ok(const ConvGemmArgs& a);
 bool conv1x1_allc_ok(const ConvGemmArgs& a);
 int conv1x1_allc_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
 int conv_gemm_big_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
+bool conv_gemm_big_pair_ok(const ConvGemmArgs& a, int dtype);     // split-precision forward on the 256 x 256 tile (round 6)
+int conv_gemm_big_pair_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
 // conv1x1_xres.hip: short-K (cin <= 256) 1x1 layers, activation tile resident in LDS, all couts per workgroup
 bool conv1x1_xres_ok(const ConvGemmArgs& a);
 int conv1x1_xres_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);

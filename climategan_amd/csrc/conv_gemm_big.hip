@@ -35,7 +35,11 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_big_zeros[4];   // what the lanes of a padded tap fetch
 
-template <typename T, int NW>
+// PAIR (round 6): the split-precision forward (cgan_conv2d_nhwc_fwd_pair) on this tile.  x is a split map that stores every
+// component once (Split<T>::NS blocks of csb channels per pixel); the K extent p.cin_s = NB * csb, K-block b = storage block
+// xcomp(b) -- a lane's 8-channel group of a stage is looked up when the stage is issued; the epilogue takes bias / split
+// residual / activation in fp32 and stores the components (as conv_gemm_ext_kernel's pair epilogue does).
+template <typename T, int NW, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemmArgs p, int npb, int ncb) {
   constexpr int WC = 8;                       // cout tiles per wave (128 couts)
   constexpr int WP = NW == 4 ? 8 : 4;         // pixel tiles per wave (128 / 64 pixels)
@@ -67,9 +71,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   const u32x4* wsrc[NPC];
   int poff[NPC];
   unsigned vmask[NPC];
+  const int csb = PAIR ? p.cin_s / Split<T>::NB : p.cin_s;         // channels per block of a split map
+  const int xs = PAIR ? Split<T>::NS * csb : p.cin_s;              // stored channels per pixel of x
+  const float inv_csb = 1.0f / (float)csb;
+  const int kchunk = (lane & 7) ^ (4 * half + (((lane >> 3) >> 1) & 3));
   {
     const int q = lane >> 3;
-    const int kchunk = (lane & 7) ^ (4 * half + ((q >> 1) & 3));
 #pragma unroll
     for (int m = 0; m < NPC; ++m) {
       const int t = (wave >> 1) + (NW / 2) * m;                      // cout tile / pixel tile of the block
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
       const int oy = r % p.h_out;
       const int nn = r / p.h_out;
       const int py0 = oy * p.stride - p.pad, px0 = ox * p.stride - p.pad;
-      poff[m] = ((nn * p.h_in * p.w_in + py0 * p.w_in + px0) * p.cin_s + kchunk * 8) * 2;
+      poff[m] = ((nn * p.h_in * p.w_in + py0 * p.w_in + px0) * xs + (PAIR ? 0 : kchunk * 8)) * 2;
       unsigned mk = 0;
       for (int ky = 0; ky < p.kh; ++ky)
         for (int kx = 0; kx < p.kw; ++kx) {
@@ -116,7 +123,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   };
   auto issue_x_piece = [&](int m) {
     const int tap = cx.ky * p.kw + cx.kx;
-    const int tap_off = ((cx.ky * p.w_in + cx.kx) * p.dil * p.cin_s + cx.cc2 * 64) * 2;
+    int coff = cx.cc2 * 64;
+    if (PAIR) {                               // K channel -> channel of the stored pixel (this lane's 8-channel group)
+      const int c = cx.cc2 * 64 + kchunk * 8;
+      const int b = (int)(((float)c + 0.5f) * inv_csb);
+      coff = Split<T>::xcomp(b) * csb + (c - b * csb);
+    }
+    const int tap_off = ((cx.ky * p.w_in + cx.kx) * p.dil * xs + coff) * 2;
     const long off = ((vmask[m] >> tap) & 1u) ? (long)(poff[m] + tap_off) : zero_off;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + off;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -273,6 +286,63 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (PAIR) {
+        constexpr int NS = Split<T>::NS, NC = Split<T>::NC;
+        if (bias_ep) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] += b0[r];
+            v[4 + r] += b1[r];
+          }
+        }
+        if (p.has_res) {
+          size_t rpix = (size_t)pix;
+          if (p.res_ups) {
+            const int ox = pix % p.w_out;
+            const int r = pix / p.w_out;
+            const int oy = r % p.h_out;
+            const int nn = r / p.h_out;
+            rpix = ((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1);
+          }
+          const uint16_t* rp = p.res + rpix * p.cout_s * NS + ch;
+          float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = NC - 1; k >= 0; --k) {         // smallest component first
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(rp + k * p.cout_s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float r0, r1;
+              unpack2<T>(rv[e], r0, r1);
+              rs[2 * e] += r0;
+              rs[2 * e + 1] += r1;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += rs[r];
+        }
+        act_apply_n(v, p.act, p.slope);
+        if (p.cout < p.cout_s) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (ch + r >= p.cout) v[r] = 0.f;
+        }
+        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NS + ch;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {                // component k = round16 of what the previous ones left
+          u32x4 comp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            comp[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            float q0, q1;
+            unpack2<T>(comp[e], q0, q1);
+            v[2 * e] -= q0;
+            v[2 * e + 1] -= q1;
+          }
+          *reinterpret_cast<u32x4*>(yp + k * p.cout_s) = comp;
+        }
+        continue;
+      }
       if (!plain) {     // wave-uniform: convs without bias / residual / activation / pad channels skip all of it
         if (bias_ep) {     // (padded to whole cout tiles: two 16-byte loads)
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
@@ -321,12 +391,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   epilogue_pass(std::integral_constant<int, 1>{});
 }
 
-template <typename T, int NW>
+template <typename T, int NW, bool PAIR = false>
 int launch_big(const ConvGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = 160 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_big_kernel<T, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_big_kernel<T, NW, PAIR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("conv_gemm_big: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -337,7 +407,7 @@ int launch_big(const ConvGemmArgs& a, hipStream_t s) {
   const int npb = ceil_div(ceil_div(a.npix, 16), 16);
   const int ncb = ceil_div(a.ctiles, 16);
   const int grid = ceil_div(npb, 8) * 8 * ncb;
-  hipLaunchKernelGGL((conv_gemm_big_kernel<T, NW>), dim3(grid), dim3(NW * 64), smem, s, a, npb, ncb);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<T, NW, PAIR>), dim3(grid), dim3(NW * 64), smem, s, a, npb, ncb);
   return CGAN_OK;
 }
 
@@ -356,4 +426,17 @@ bool conv_gemm_big_ok(const ConvGemmArgs& a) {
 // through a[0:3] with v_accvgpr_write / _read pairs around every MFMA (445 of them for 256 MFMAs in the loop body).
 int conv_gemm_big_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch_big<F16, 8>(a, s) : launch_big<BF16, 8>(a, s);
+}
+
+// split-precision forward on the 256 x 256 tile: ``a`` describes the conv over the K extent NB * csb; what is addressed with
+// 32-bit byte offsets is the STORED map (NS * csb channels per pixel)
+bool conv_gemm_big_pair_ok(const ConvGemmArgs& a, int dtype) {
+  const int nb = cgan_split_blocks(dtype), ns = cgan_split_store_blocks(dtype);
+  return (a.cin_s & 63) == 0 && (a.cin_s % nb) == 0 && a.pad_mode != CGAN_PAD_REFLECT && a.kh * a.kw <= 32 && a.ctiles >= 12 &&
+         a.npix >= 16384 && a.stats == nullptr &&
+         (long)a.n * a.h_in * a.w_in * (a.cin_s / nb) * ns < (1L << 30) - (1L << 20) &&
+         (long)a.npix * a.cout_s * ns < (1L << 31);
+}
+int conv_gemm_big_pair_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
+  return dtype == CGAN_F16 ? launch_big<F16, 8, true>(a, s) : launch_big<BF16, 8, true>(a, s);
 }

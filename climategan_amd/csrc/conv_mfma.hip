@@ -902,6 +902,8 @@ extern "C" int cgan_conv2d_nhwc_fwd(const void* x, const void* packed_w, const f
 }
 
 // Split-precision forward (round 4): see the header.  The general gather kernel, or (round 5) the LDS-tiled GEMM for wide layers.
+CGAN_KNOB(int, g_pair_big, 1);      // dev: 0 = never the 256 x 256 tile for split convs (same-box A/B, kernel-variant tests)
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_pair_big(int v) { g_pair_big = v; })
 extern "C" int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, const float* bias_padded,
                                          const void* residual3, void* y3, const CganConvDesc* d, void* stream) {
   ConvParams p;
@@ -923,6 +925,14 @@ extern "C" int cgan_conv2d_nhwc_fwd_pair(const void* x3, const void* packed_w3, 
   // pixels for its 128 / 256-pixel block tiles; everything else stays on the gather kernel
   if (g_conv_force == 0 && p.in_zs == 1 && !p.in_ups && p.cin_p == p.cin_s && p.pad >= 0 && p.npix >= 1024 && p.ksteps >= 4) {
     const ConvGemmArgs a = gemm_args(p);
+    // >= 192 couts and whole 64-channel K stages: the 256 x 256 / eight-wave tile (round 6: 0.30 -> 0.4+ of MFMA on the
+    // ResNet layer3 / layer4 / ASPP convs, which are most of a split-precision Masker)
+    if (g_pair_big && conv_gemm_big_pair_ok(a, d->dtype)) {
+      rc = conv_gemm_big_pair_launch(a, d->dtype, s);
+      if (rc != CGAN_OK) return rc;
+      CGAN_CHECK_LAUNCH("conv2d_nhwc_fwd_pair(gemm 256)");
+      return CGAN_OK;
+    }
     if (conv_gemm_ext_shape_ok(a) && (double)p.npix * p.cout_s * cgan_split_store_blocks(d->dtype) < 2147483647.0) {
       rc = conv_gemm_pair_launch(a, d->dtype, s);
       if (rc != CGAN_OK) return rc;

@@ -199,3 +199,53 @@ def test_split_conv_on_the_gemm_tiling(dt, case):
         dev.cgan_debug_set_conv_kernel(0)
         _lib.use_product()
     assert (got - yg).abs().max().item() / ref.abs().max().item() <= max(4e-6, 3 * floor)     # (another summation order)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, pad, dil, residual ("same" | None), act): >= 192 couts, whole 64-channel K stages, >= 16384 pixels
+    (4, 80, 80, 256, 256, 3, 2, 2, None, "relu"),           # ResNet layer3's dilated 3x3
+    (4, 80, 80, 256, 1024, 1, 0, 1, "same", "relu"),        # bottleneck expansion with the shortcut in the epilogue
+    (3, 80, 80, 1024, 256, 1, 0, 1, None, "none"),          # reduce (K = 6 x 1024 in bf16)
+    (3, 80, 96, 512, 200, 3, 4, 4, None, "lrelu"),          # pad channels (200 of 208 couts live), a last pixel block in part
+])
+def test_split_conv_on_the_256_tile(dt, case):
+    """Round 6: split-precision convs with >= 192 output channels and whole 64-channel K stages run on the 256 x 256 / eight-wave
+    tile (conv_gemm_big_kernel<.., PAIR>: x read from the stored components through the K-block -> storage-block map, split
+    epilogue): float64 yardstick as for the other tilings, and agreement with the 128-pixel tiling (dev knob pair_big = 0)."""
+    from climategan_amd import _lib, ops
+
+    n, h, w, cin, cout, k, pad, dil, res_kind, act = case
+    x = _rand((n, cin, h, w), 33)
+    wt = _rand((cout, cin, k, k), 34, (2.0 / (cin * k * k)) ** 0.5)
+    b = _rand((cout,), 35)
+    p = ops.pair_from_nchw(x, dt)
+    pw = ops.pack_conv_weight(wt, b, dt, pair=True)
+    f64 = F.conv2d(x.double(), wt.double(), b.double(), padding=pad, dilation=dil)
+    ref = f64
+    res = None
+    if res_kind:
+        res = ops.pair_from_nchw(_rand(tuple(ref.shape), 36), dt)
+        ref = ref + ops.nhwc_to_nchw(res).double()
+    ref = {"relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.2), "none": lambda v: v}[act](ref)
+    kw = dict(pad=pad, dilation=dil, act={"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act], residual=res)
+    y = ops.conv2d(p, pw, **kw)
+    assert isinstance(y, ops.PairMap) and y.c == cout and y.t.shape[3] == ops.store_blocks(dt) * ops.cs8(cout)
+    got = ops.nhwc_to_nchw(y).double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    f32 = F.conv2d(x, wt, b, padding=pad, dilation=dil).double()
+    floor = (f32 - f64).abs().max().item() / f64.abs().max().item()
+    assert err <= max(4e-6, 3 * floor), (err, floor)
+    assert bool((y.t.view(n, y.h, y.w, y.nb, -1)[..., cout:] == 0).all())          # pad channels of every block stay zero
+    dev = _lib.load_dev()
+    try:
+        dev.cgan_debug_set_pair_big(0)                                               # the 128-pixel tiling of round 5
+        pw_dev = ops.pack_conv_weight(wt, b, dt, pair=True)
+        ye = ops.nhwc_to_nchw(ops.conv2d(p, pw_dev, **kw)).double()
+        dev.cgan_debug_set_pair_big(1)
+        yb = ops.nhwc_to_nchw(ops.conv2d(p, pw_dev, **kw)).double()
+    finally:
+        dev.cgan_debug_set_pair_big(1)
+        _lib.use_product()
+    assert torch.equal(yb, got)                                                      # the development build runs the same kernel
+    assert (got - ye).abs().max().item() / ref.abs().max().item() <= max(4e-6, 3 * floor)     # (another summation order)
