@@ -345,8 +345,10 @@ class SpadeFn(torch.autograd.Function):
         # Fused form (round 5, cgan_spade_hidden_bwd): for a <= 4-channel conditioning image that wants no gradient of its
         # own (the Painter) on maps of 80 x 80 and up, mlp_shared's gradient comes out of ONE kernel that re-computes the hidden
         # tile and keeps its gradient on the chip -- no 128-channel gradient map, no separate weight-gradient launch.
+        # (the fused kernel is not batch-sliced and addresses dgb with 32-bit byte offsets: larger maps keep the unfused path,
+        # whose ops slice the batch -- advisor, round 5)
         fused = (_SPADE_FUSED_BWD and want_sh and not ctx.needs_input_grad[1] and cfg["cond_c"] <= 4 and h * w >= 6400
-                 and w_sh.shape[0] == 128)
+                 and w_sh.shape[0] == 128 and dgb.t.nbytes < ops.ABI_MAX_BYTES and seg.t.nbytes < ops.ABI_MAX_BYTES)
         d_pre = None
         if fused:
             dw_sh, db_sh = ops.spade_hidden_bwd(dgb, w_gb, seg, pw_sh, c)

@@ -161,6 +161,9 @@ class OmniGenerator(nn.Module):
         decoder, the DeepLab segmentation decoder and both mask decoders (plain; SPADE since round 5) carry pair maps."""
         if self.encoder is not None and not hasattr(self.encoder, "pair_precision"):
             return "the encoder has no pair-map path"
+        # (the depth / segmentation / mask decoders dispatch on the map type they are handed: nothing to check there)
+        if sum(q.numel() for q in self.painter.parameters()) > 0 and not hasattr(self.painter, "pair_precision"):
+            return "the painter has no pair-map path"
         return None
 
     def train(self, mode=True):
@@ -354,7 +357,15 @@ class OmniGenerator(nn.Module):
         dt = p.compute_dtype
         z = self.sample_painter_z(x.shape[0], x.device)
         m = m.to(x.dtype)
-        if getattr(p, "pair_precision", False) and not (torch.is_grad_enabled() and any(q.requires_grad for q in p.parameters())):
+        pair_ok = not (torch.is_grad_enabled() and any(q.requires_grad for q in p.parameters()))
+        if getattr(p, "pair_precision", False) and not pair_ok and not getattr(self, "_warned_pair_grad", False):
+            # (advisor, round 5: this used to switch to the 16-bit Painter without a word)
+            import warnings
+            warnings.warn("OmniGenerator.paint: the split-precision mode (G.float() / set_compute_dtype('split24' | 'pair16')) is an "
+                          "inference mode; with autograd enabled and a trainable Painter this call runs the 16-bit Painter. Wrap "
+                          "the call in torch.no_grad() for the fp32-grade result.")
+            self._warned_pair_grad = True
+        if getattr(p, "pair_precision", False) and pair_ok:
             # split-precision inference (round 5): the Painter on split maps -- every conv as a split-precision conv, SPADE
             # unfused with its de-normalisation in fp32 (norms.SPADE._forward_pair): the arithmetic of the reference's fp32 run
             xf, mf = x.float(), m.float()

@@ -553,3 +553,35 @@ def test_first_layer_convs_on_the_halo_tiled_kernel(dt, case):
     finally:
         lib.cgan_debug_set_conv_kernel(ctypes.c_int(0))
     assert rel_err(y.t.float(), y2.t.float()) <= (2 ** -10 if dt == torch.float16 else 2 ** -7)
+
+
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, stride, pad): the data-gradient launches that do not run the plain kernels
+    (4, 160, 160, 4, 64, 4, 2, 1),        # sub-pixel form (first PatchGAN / ADVENT layer)
+    (4, 80, 80, 64, 128, 4, 2, 1),        # parity classes on the tiled GEMM
+    (4, 40, 40, 256, 512, 3, 2, 1),       # parity classes, 3x3 s2
+    (2, 10, 10, 640, 640, 3, 1, 1),       # split-K (small grid, long K)
+    (4, 20, 20, 512, 512, 4, 1, 1),       # split-K, 4x4 s1 (PatchGAN tail)
+])
+def test_data_gradient_launch_kinds_are_bitwise_reproducible(case):
+    """Advisor (round 5): the sub-pixel, parity-class and split-K data-gradient launches are ordered reductions (no atomics):
+    the same call twice -- and once more on another stream -- gives the same bits."""
+    from climategan_amd import ops
+
+    n, h, w, cin, cout, k, stride, pad = case
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(41)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = ops.NHWC(torch.randn(n, ho, wo, ops.cs8(cout), device="cuda", generator=g).to(dt), cout)
+    if ops.cs8(cout) != cout:
+        dy.t[..., cout:] = 0
+    wt = torch.randn(cout, cin, k, k, device="cuda", generator=g) * 0.05
+    a = ops.conv2d_bwd_data(dy, wt, (n, h, w), stride=stride, pad=pad).t.clone()
+    b = ops.conv2d_bwd_data(dy, wt, (n, h, w), stride=stride, pad=pad).t.clone()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        c = ops.conv2d_bwd_data(dy, wt, (n, h, w), stride=stride, pad=pad).t.clone()
+    st.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert float(a.float().abs().max()) > 0
