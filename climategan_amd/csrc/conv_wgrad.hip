@@ -45,6 +45,27 @@ struct WgradArgs {
 #endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+// LDS-DMA of 16 bytes per lane through a buffer descriptor, HIDDEN from the compiler (round 6).  hipcc (ROCm 7.2) treats
+// __builtin_amdgcn_raw_ptr_buffer_load_lds as a store to LDS that any later ds_read may alias and puts ``s_waitcnt vmcnt(0)``
+// in front of the first fragment read after it -- i.e. behind the pieces of the NEXT chunk that were issued a moment before:
+// every chunk waited for its successor's L2 / HBM round trip before multiplying (the disassembly showed the wait in all
+// three kernels of this file; the SQ counters showed the waves parked 0.52-0.54 of their life).  As an asm statement the
+// load is outside the compiler's counters: the kernels' own counted waits (already there) are the only ones.  M0 (the LDS
+// destination) is saved and restored around the load; the s_nop covers the M0 write -> LDS-DMA hazard.
+typedef unsigned wg_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg_rsrc_t wg_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  return (wg_rsrc_t){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void wg_dma16(wg_rsrc_t rs, const unsigned char* lds_dst, unsigned voff) {
+  const unsigned lds = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const unsigned char*)lds_dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds), "s"(rs)
+               : "memory");
+}
+
 
 // An 8-pixel DMA piece (8 rows x 128 B) sits on a pitch of 1024 + 128 B (round 6): the two 16-lane groups a transposing read
 // services together read rows k and 8 + k of the slab -- 1024 B apart they start on the SAME banks whatever the slot
@@ -163,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   // DMA *and its address math* it ran twice as fast).  Byte offsets fit 32 bits (host check: tensors < 4 GiB).
   // Buffer descriptors: a lane whose pixel / tap / channel chunk does not exist sends an out-of-range offset and the
   // hardware writes zeros to its LDS slot -- no zero page, no 64-bit pointer selects.
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+  const wg_rsrc_t rs_dy = wg_make_rsrc(p.dy, p.dy_bytes);
+  const wg_rsrc_t rs_x = wg_make_rsrc(p.x, p.x_bytes);
   const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
   const unsigned cch2 = (unsigned)cch * 2u;
   const int tap_y = ky * p.dil - p.pad, tap_x = kx * p.dil - p.pad;
@@ -223,8 +244,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         // pixels past the end: the dy offset is out of range by itself (zeros), which also neutralises whatever x holds
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * PIECE), 16,
-                                                 u_dy0 + (unsigned)(i * 8) * cout_b + lane_dyc, 0, 0, 0);
+        wg_dma16(rs_dy, dst_dy + i * PIECE, u_dy0 + (unsigned)(i * 8) * cout_b + lane_dyc);
         int iy = __builtin_amdgcn_readlane(v_sy, i) + ly, ix = __builtin_amdgcn_readlane(v_sx, i) + lx;
         if (MODE == 2) {      // nn.ReflectionPad2d: mirror without repeating the border (a dead lane stays out of range)
           iy = iy < 0 ? -iy : (iy >= p.h_in ? 2 * p.h_in - 2 - iy : iy);
@@ -239,8 +259,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         } else {
           off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + lane_xc;   // piece part + lane constant
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * PIECE), 16,
-                                                 xv ? off : 0xffffffffu, 0, 0, 0);
+        wg_dma16(rs_x, dst_x + i * PIECE, xv ? off : 0xffffffffu);
       }
       u_dy0 += step_dy;
       int sx = v_sx + step_sx, sy = v_sy + step_sy, nh = v_nh + step_nh;
@@ -256,8 +275,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool pv = c_pix[i] < p.npix;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst_dy + i * PIECE), 16,
-                                               (pv && co_ok) ? c_dy[i] : 0xffffffffu, 0, 0, 0);
+      wg_dma16(rs_dy, dst_dy + i * PIECE, (pv && co_ok) ? c_dy[i] : 0xffffffffu);
       int iy = c_sy[i] + tap_y, ix = c_sx[i] + tap_x;
       if (MODE == 2) {
         iy = iy < 0 ? -iy : (iy >= p.h_in ? 2 * p.h_in - 2 - iy : iy);
@@ -267,8 +285,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       const unsigned row = (unsigned)(c_nh[i] + (MODE == 1 ? (iy >> 1) : iy));
       const unsigned col = (unsigned)(MODE == 1 ? (ix >> 1) : ix);
       const unsigned off = row * row_b + col * cin_b + cch2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_x + i * PIECE), 16,
-                                               xv ? off : 0xffffffffu, 0, 0, 0);
+      wg_dma16(rs_x, dst_x + i * PIECE, xv ? off : 0xffffffffu);
       // advance to the following chunk
       c_pix[i] += step;
       c_dy[i] += step_dy;
@@ -413,8 +430,8 @@ __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void c
   const unsigned cin_b = (unsigned)p.cin_s * 2u, cout_b = (unsigned)p.cout_s * 2u;
   const int hx = MODE == 1 ? (p.h_in >> 1) : p.h_in, wx = MODE == 1 ? (p.w_in >> 1) : p.w_in;
   const unsigned row_b = (unsigned)wx * cin_b;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const wg_rsrc_t rs_x = wg_make_rsrc(p.x, p.x_bytes);
+  const wg_rsrc_t rs_dy = wg_make_rsrc(p.dy, p.dy_bytes);
   unsigned dy_c = 0x80000000u;                  // dy lane constant (or the always-out-of-range marker)
   {
     const int co = (cop * G + mem) * 64 + q8;
@@ -475,8 +492,7 @@ __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void c
     unsigned char* dst = smem + b * STAGE2 + mem * SUB2 + half * (PW * PIECE);
     if (k < PW) {
       const unsigned off = u_dy + (unsigned)((half * PW + k) * 8) * cout_b + dy_c;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(dst + k * PIECE), 16,
-                                               off, 0, 0, 0);
+      wg_dma16(rs_dy, dst + k * PIECE, off);
       return;
     }
     const int j = k - PW, i = half * PW + j;
@@ -491,8 +507,7 @@ __global__ __launch_bounds__(64 * G * G, G == 4 ? 1 : (CH == 64 ? 2 : 4)) void c
     if (MODE == 1) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + (iy >> 1)) * row_b + (unsigned)(ix >> 1) * cin_b + cch2;
     else if (MODE == 2) off = (unsigned)(__builtin_amdgcn_readlane(v_nh, i) + iy) * row_b + (unsigned)ix * cin_b + cch2;
     else off = (unsigned)__builtin_amdgcn_readlane((int)v_off, i) + x_c;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + G * SUB2 + j * PIECE), 16,
-                                             xv ? off : 0xffffffffu, 0, 0, 0);
+    wg_dma16(rs_x, dst + G * SUB2 + j * PIECE, xv ? off : 0xffffffffu);
   };
   auto advance = [&]() {
     u_dy += step_dy;
