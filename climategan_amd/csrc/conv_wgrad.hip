@@ -1138,6 +1138,12 @@ extern "C" int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float*
     hipLaunchKernelGGL((conv_wgrad_coop_kernel<TT, MM, 64, false, false, 4>), dim3(gx), dim3(1024), smem4, s, a);      \
   } while (0)
 #define COOP4_MODE(TT) do { if (mode == 1) COOP4_LAUNCH(TT, 1); else if (mode == 2) COOP4_LAUNCH(TT, 2); else COOP4_LAUNCH(TT, 0); } while (0)
+#ifdef CGAN_DEV
+    if (CGAN_WTS(a) && d->dtype == CGAN_BF16 && mode == 0) {        // tools/ts_wgrad.py: the phase stamps of the 16-wave tile
+      CGAN_BIG_LDS((conv_wgrad_coop_kernel<BF16, 0, 64, true, false, 4>));
+      hipLaunchKernelGGL((conv_wgrad_coop_kernel<BF16, 0, 64, true, false, 4>), dim3(gx), dim3(1024), smem4, s, a);
+    } else
+#endif
     if (d->dtype == CGAN_F16) COOP4_MODE(F16);
     else COOP4_MODE(BF16);
 #undef COOP4_MODE
