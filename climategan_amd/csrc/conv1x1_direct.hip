@@ -111,69 +111,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_allc_kernel(ConvGemmArgs p) {
 
   // ---- epilogue: one pixel tile at a time through LDS (fp32 rows of CT*16 couts + 16 B pad), 16-byte stores
   constexpr int ROWB = CTW * 64 + 16;
-  constexpr int CH = CTW * 2;
   unsigned char* stg = smem + wave * (16 * ROWB);
   const int cout_base = wc * CTW * 16;
-  const bool plain = !p.bias && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
-#pragma unroll
-  for (int t = 0; t < WP; ++t) {
-#pragma unroll
-    for (int c = 0; c < CTW; ++c) *reinterpret_cast<f32x4*>(stg + j16 * ROWB + c * 64 + g * 16) = acc[c][t];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int pix_base = pix0 + t * 16;
-#pragma unroll
-    for (int it = 0; it < 16 * CH / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int pl = idx / CH, qc = idx % CH;
-      const int pix = pix_base + pl;
-      const int ch = cout_base + qc * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
-      if (pix >= p.npix || ch >= p.cout_s) continue;
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (!plain) {     // wave-uniform: convs without bias / residual / activation / pad channels skip all of it
-        if (p.bias) {     // (padded to whole cout tiles: two 16-byte loads)
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch + 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] += b0[r];
-            v[4 + r] += b1[r];
-          }
-        }
-        if (p.has_res) {
-          size_t rbase;
-          if (p.res_ups) {
-            int ox = pix % p.w_out;
-            int r = pix / p.w_out;
-            int oy = r % p.h_out;
-            int nn = r / p.h_out;
-            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
-          } else {
-            rbase = (size_t)pix * p.cout_s;
-          }
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float r0, r1;
-            unpack2<T>(rv[e], r0, r1);
-            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
-            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
-          }
-        }
-        act_apply_n(v, p.act, p.slope);
-        if (p.cout < p.cout_s) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
-        }
-      }
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  // (the store path shared with conv_gemm_kernel, one pixel tile per pass: conv_gemm.h)
+  conv_gemm_staged_store<T, CTW, WP, 1>(acc, p, stg, pix0, cout_base, p.bias, lane, j16, g);
 }
 
 template <typename T, int CTW, int WAVES_C, int WP>

@@ -156,4 +156,112 @@ __device__ __forceinline__ void conv_gemm_stats_epilogue(f32x4 (&acc)[WC][WP], c
     }
   }
 }
+
+// Store path of the LDS-staged GEMM kernels (conv_gemm_kernel, conv_gemm_big_kernel): the wave's accumulator tile
+// acc[WC][WP] (lane (j, g) holds channels ct*16 + 4g + {0..3} of pixel (tile, j)) goes through ``stg`` in fp32 (row = one
+// pixel x the wave's WC*16 couts, + 16 B pad) PP pixel tiles at a time and leaves as 16-byte chunks with bias / residual /
+// activation applied in fp32.  ``pix0``: first pixel of the wave's WP tiles; ``bias_ep``: the bias still to add (null if
+// the statistics epilogue folded it into the accumulators).
+//
+// Round 6: every global READ of the store path is issued before the first store.  The per-chunk form (load the residual
+// chunk, use it, store) compiled to ``global_load_dwordx4; s_waitcnt vmcnt(0)`` in front of every store -- vmcnt counts
+// the stores too, so a wave went through WP*WC/2 fully serialized HBM round trips (16 for the 256 x 256 tile, one
+// workgroup per CU: ~46 us of a 90-us workgroup on the bottleneck's 1x1 data gradients with the skip gradient added in
+// the epilogue, 600 us where the same GEMM without the residual takes 310).  A lane's 8-channel chunk is the same in
+// every iteration (64 % CH == 0): the bias is loaded once; the residual chunks of ALL passes (2*WC*WP registers, half the
+// accumulators' count, free once the K loop's fragments are dead) are in flight together, then the stores stream out.
+template <typename T, int WC, int WP, int PP>
+__device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP], const ConvGemmArgs& p,
+                                                       unsigned char* stg, int pix0, int cout_base, const float* bias_ep,
+                                                       int lane, int j, int g) {
+  constexpr int ROWB = WC * 64 + 16;
+  constexpr int CH = WC * 2;                                  // 8-channel chunks per staged row
+  constexpr int NIT = PP * 16 * CH / 64;                      // chunks per lane and pass
+  constexpr int NPASS = WP / PP;
+  constexpr int PSTEP = 64 / CH;                              // pixels between a lane's consecutive chunks
+  static_assert(64 % CH == 0 && WP % PP == 0, "a lane keeps its channel chunk over the iterations");
+  const int qc = lane % CH, pl0 = lane / CH;
+  const int ch = cout_base + qc * 8;
+  const bool ch_ok = ch < p.cout_s;
+  const bool plain = !bias_ep && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
+  f32x4 bb0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bb1 = bb0;
+  if (bias_ep && ch_ok) {                                     // (padded to whole cout tiles: two 16-byte loads)
+    bb0 = *reinterpret_cast<const f32x4*>(bias_ep + ch);
+    bb1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
+  }
+  u32x4 rv[NPASS][NIT];
+  if (p.has_res) {                                            // wave-uniform
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int pix = pix0 + pass * PP * 16 + it * PSTEP + pl0;
+        rv[pass][it] = (u32x4){0u, 0u, 0u, 0u};
+        if (pix < p.npix && ch_ok) {
+          size_t rbase;
+          if (p.res_ups) {
+            const int ox = pix % p.w_out;
+            const int r = pix / p.w_out;
+            const int oy = r % p.h_out;
+            const int nn = r / p.h_out;
+            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+          } else {
+            rbase = (size_t)pix * p.cout_s;
+          }
+          rv[pass][it] = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);                        // the loads stay in front of the staging and the stores
+  }
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int tt = 0; tt < PP; ++tt)
+#pragma unroll
+      for (int c = 0; c < WC; ++c)
+        *reinterpret_cast<f32x4*>(stg + (tt * 16 + j) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ONE wait for the bias / residual loads, as a builtin the compiler's wait-count pass sees, on every path: left to
+    // itself it puts s_waitcnt vmcnt(0) in front of each chunk's first use of a prefetched register (the uses sit behind
+    // wave-uniform branches, the merged scoreboard state is "maybe pending") -- and that waits for the previous STORE
+    if (pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = it * PSTEP + pl0;
+      const int pix = pix0 + pass * PP * 16 + pl;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (!plain) {     // wave-uniform: the BatchNorm-followed convs (no bias / residual / activation / pad channels) skip all of it
+        if (bias_ep) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] += bb0[r];
+            v[4 + r] += bb1[r];
+          }
+        }
+        if (p.has_res) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r0, r1;
+            unpack2<T>(rv[pass][it][e], r0, r1);
+            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
+            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
+          }
+        }
+        act_apply_n(v, p.act, p.slope);
+        if (p.cout < p.cout_s) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
+        }
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+      if (pix < p.npix && ch_ok) *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged rows are consumed before the next pass overwrites
+  }
+}
 #endif

@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
   constexpr int ROWB = WC * 64 + 16;
   constexpr int PP = (4 * 4 * 16 * ROWB <= NS * STAGE_BYTES && WP % 4 == 0) ? 4
                      : (4 * 2 * 16 * ROWB <= NS * STAGE_BYTES ? 2 : 1);                // pixel tiles per pass
-  constexpr int CH = WC * 2;                                  // 8-channel chunks per staged row
   static_assert(4 * PP * 16 * ROWB <= NS * STAGE_BYTES, "epilogue staging does not fit");
   static_assert(WP % PP == 0, "WP must be a multiple of PP");
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -194,69 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
     conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * WAVES_P + wp, j, g);
     if (p.bias) bias_ep = nullptr;       // folded into the accumulators: the store path skips it (wave-uniform)
   }
-  const bool plain = !bias_ep && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
-#pragma unroll
-  for (int pass = 0; pass < WP / PP; ++pass) {
-#pragma unroll
-    for (int tt = 0; tt < PP; ++tt)
-#pragma unroll
-      for (int c = 0; c < WC; ++c)
-        *reinterpret_cast<f32x4*>(stg + (tt * 16 + j) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int pix_base = (pblk * PT_BLK + wp * WP + pass * PP) * 16;
-#pragma unroll
-    for (int it = 0; it < PP * 16 * CH / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int pl = idx / CH, qc = idx % CH;
-      const int pix = pix_base + pl;
-      const int ch = cout_base + qc * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
-      if (pix >= p.npix || ch >= p.cout_s) continue;
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (!plain) {     // wave-uniform: the BatchNorm-followed convs (no bias / residual / activation / pad channels) skip all of it
-        if (bias_ep) {     // (padded to whole cout tiles: two 16-byte loads)
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] += b0[r];
-            v[4 + r] += b1[r];
-          }
-        }
-        if (p.has_res) {
-          size_t rbase;
-          if (p.res_ups) {
-            int ox = pix % p.w_out;
-            int r = pix / p.w_out;
-            int oy = r % p.h_out;
-            int nn = r / p.h_out;
-            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
-          } else {
-            rbase = (size_t)pix * p.cout_s;
-          }
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float r0, r1;
-            unpack2<T>(rv[e], r0, r1);
-            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
-            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
-          }
-        }
-        act_apply_n(v, p.act, p.slope);
-        if (p.cout < p.cout_s) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
-        }
-      }
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged rows are consumed before the next pass overwrites
-  }
+  conv_gemm_staged_store<T, WC, WP, PP>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -461,6 +398,35 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_k64_kernel(ConvGemmArgs p, i
     const int gt = first + ti * nslot;
     const int pblk = gt / ncb;
     const int cblk = gt - pblk * ncb;
+    // round 6: the residual chunks of the whole tile are requested before the first store (a load in front of every
+    // store compiled to s_waitcnt vmcnt(0) per chunk -- WC * WP serialized round trips, the stores' acknowledgements included)
+    uint2 rv[WP][WC];
+    if (p.has_res) {                                          // wave-uniform
+#pragma unroll
+      for (int t = 0; t < WP; ++t) {
+        const int pix = (pblk * PT_BLK + wp * WP + t) * 16 + j16;
+        size_t rbase = 0;
+        if (pix < p.npix) {
+          if (p.res_ups) {
+            int ox = pix % p.w_out;
+            int r = pix / p.w_out;
+            int oy = r % p.h_out;
+            int nn = r / p.h_out;
+            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
+          } else {
+            rbase = (size_t)pix * p.cout_s;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < WC; ++c) {
+          const int ch = (cblk * CT_BLK + wc * WC + c) * 16 + 4 * g;
+          rv[t][c] = make_uint2(0u, 0u);
+          if (pix < p.npix && ch < p.cout_s) rv[t][c] = *reinterpret_cast<const uint2*>(p.res + rbase + ch);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) once, visible to the wait-count pass (conv_gemm.h)
+    }
 #pragma unroll
     for (int t = 0; t < WP; ++t) {
       const int pix = (pblk * PT_BLK + wp * WP + t) * 16 + j16;
@@ -475,21 +441,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_k64_kernel(ConvGemmArgs p, i
           for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
         }
         if (p.has_res) {
-          size_t rbase;
-          if (p.res_ups) {
-            int ox = pix % p.w_out;
-            int r = pix / p.w_out;
-            int oy = r % p.h_out;
-            int nn = r / p.h_out;
-            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
-          } else {
-            rbase = (size_t)pix * p.cout_s;
-          }
-          const uint2 rv = *reinterpret_cast<const uint2*>(p.res + rbase + ch);
           float r0, r1;
-          unpack2<T>(rv.x, r0, r1);
+          unpack2<T>(rv[t][c].x, r0, r1);
           v[0] = cgan_res_apply(v[0], r0, p.has_res); v[1] = cgan_res_apply(v[1], r1, p.has_res);
-          unpack2<T>(rv.y, r0, r1);
+          unpack2<T>(rv[t][c].y, r0, r1);
           v[2] = cgan_res_apply(v[2], r0, p.has_res); v[3] = cgan_res_apply(v[3], r1, p.has_res);
         }
 #pragma unroll

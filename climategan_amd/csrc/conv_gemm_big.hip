@@ -266,7 +266,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
     conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * (NW / 2) + wp, j16, g);
     if (p.bias) bias_ep = nullptr;
   }
-  const bool plain = !bias_ep && !p.has_res && p.act == CGAN_ACT_NONE && p.cout == p.cout_s;
+  if constexpr (!PAIR) {     // the store path shared with conv_gemm_kernel: every global read in front of the first store
+    conv_gemm_staged_store<T, WC, WP, PP>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j16, g);
+    return;
+  }
   auto epilogue_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
 #pragma unroll
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
       if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (PAIR) {
+      {
         constexpr int NS = Split<T>::NS, NC = Split<T>::NC;
         if (bias_ep) {
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
@@ -341,48 +344,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
           }
           *reinterpret_cast<u32x4*>(yp + k * p.cout_s) = comp;
         }
-        continue;
       }
-      if (!plain) {     // wave-uniform: convs without bias / residual / activation / pad channels skip all of it
-        if (bias_ep) {     // (padded to whole cout tiles: two 16-byte loads)
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] += b0[r];
-            v[4 + r] += b1[r];
-          }
-        }
-        if (p.has_res) {
-          size_t rbase;
-          if (p.res_ups) {
-            int ox = pix % p.w_out;
-            int r = pix / p.w_out;
-            int oy = r % p.h_out;
-            int nn = r / p.h_out;
-            rbase = (((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1)) * p.cout_s;
-          } else {
-            rbase = (size_t)pix * p.cout_s;
-          }
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float r0, r1;
-            unpack2<T>(rv[e], r0, r1);
-            v[2 * e] = cgan_res_apply(v[2 * e], r0, p.has_res);
-            v[2 * e + 1] = cgan_res_apply(v[2 * e + 1], r1, p.has_res);
-          }
-        }
-        act_apply_n(v, p.act, p.slope);
-        if (p.cout < p.cout_s) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            if (ch + r >= p.cout) v[r] = 0.f;   // keep pad channels zero
-        }
-      }
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged rows are consumed before the next pass overwrites
   };
