@@ -90,6 +90,7 @@ _SIGNATURES = {
     "cgan_pair_copy_channels": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_conv2d_nhwc_bwd_data_add": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_nhwc_bwd_data_relu": (C.c_int, [_P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "cgan_conv2d_nhwc_bwd_data_add_relu": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "cgan_conv2d_kernel_kind": (C.c_int, [C.POINTER(ConvDesc), C.c_int32]),
     "cgan_conv2d_kernel_kind_on": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, _P]),
     "cgan_conv2d_bind_workspace": (C.c_int, [_P, _P, C.c_size_t]),

@@ -252,9 +252,14 @@ class ConvPassFn(torch.autograd.Function):
         dx_t = None
         if ctx.needs_input_grad[0]:
             add = ops.NHWC(dpass_t.contiguous(), cfg["c_in"]) if dpass_t is not None else None
+            # ``mask_input`` (claim_relu_mask): x is the output of a BatchNormActFn ReLU whose ONLY consumer is this node -- the
+            # ReLU's derivative is applied to the summed gradient here, in the data-gradient kernel's epilogue, and that
+            # node's backward skips its own mask (one read of `out` and one write of the masked gradient less)
+            relu_out = ops.NHWC(x_t, cfg["c_in"]) if cfg.get("mask_input") else None
             dx_t = ops.conv2d_bwd_data(dy, weight, (x_t.shape[0], x_t.shape[1], x_t.shape[2]), stride=cfg["stride"],
                                        pad=cfg["pad"], dilation=cfg["dilation"],
-                                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO), add=add, prepacked=ctx.dgrad).t
+                                       pad_mode=cfg.get("pad_mode", ops.PAD_ZERO), add=add, prepacked=ctx.dgrad,
+                                       relu_out=relu_out).t
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.conv2d_bwd_weight(
@@ -483,6 +488,7 @@ class BatchNormActFn(torch.autograd.Function):
         out = ops.norm_act_apply(flat, mean_f, rstd_f, act=act, slope=slope, residual=res).t.view(n, h, w, cs)
         ctx.cfg = (c, act, slope, G)
         ctx.has_res = res_t is not None
+        ctx.premasked = False            # see claim_relu_mask
         # without a fused residual the backward recomputes act'(.) from x with (mean', rstd') -- the apply kernel's own
         # arithmetic -- and never reads `out`: one map less in each of its two passes
         keep_out = res_t is not None or _BN_BWD_READS_OUT
@@ -496,6 +502,8 @@ class BatchNormActFn(torch.autograd.Function):
         lib = _lib.load()
         x_t, out, mean, rstd, gamma, mean_f, rstd_f = ctx.saved_tensors
         c, act, slope, G = ctx.cfg
+        if ctx.premasked:
+            act = ops.ACT_NONE           # dy arrives as dy * relu'(out): plain BatchNorm backward, the residual's gradient is dy
         n, h, w, cs = x_t.shape
         nbytes = G * lib.cgan_batchnorm_act_bwd_workspace_bytes(c)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
@@ -515,6 +523,21 @@ class BatchNormActFn(torch.autograd.Function):
             ops._DT[x_t.dtype], n * h * w, c, G, act, slope, ops._ptr(ws), nbytes, ops._stream()),
             "cgan_batchnorm_act_bwd_grouped")
         return dx, dg, db, None, None, None, None, None, None, None, None, dres, None
+
+
+def claim_relu_mask(out_t: torch.Tensor) -> bool:
+    """Called by the ONE consumer of ``out_t`` (a bottleneck's first conv, which also hands the tensor through to its block's
+    skip branch: ConvPassFn) before the backward pass: if ``out_t`` is the output of a training-mode BatchNorm + residual +
+    ReLU node, that node will receive its gradient with the ReLU's derivative already applied (the consumer's data-gradient
+    kernel takes it in its epilogue, ``cfg["mask_input"]``) and skips its own mask.  Returns whether the claim holds; the
+    caller vouches that nothing else reads ``out_t`` in the graph -- a second consumer's gradient would arrive unmasked."""
+    fn = out_t.grad_fn
+    if fn is None or not isinstance(fn, BatchNormActFn._backward_cls):
+        return False
+    if not fn.has_res or fn.cfg[1] != ops.ACT_RELU:
+        return False
+    fn.premasked = True
+    return True
 
 
 class BceLogitsFn(torch.autograd.Function):

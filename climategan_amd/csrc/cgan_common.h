@@ -36,6 +36,11 @@ void cgan_set_error(const char* fmt, ...);
 // -- the ReLU derivative taken from the activation's OUTPUT r, for a data-gradient conv whose result is the gradient of a
 // ReLU's output (cgan_conv2d_nhwc_bwd_data_relu): the separate act_bwd pass (two reads + one write of the map) disappears.
 __device__ __forceinline__ float cgan_res_apply(float v, float r, int mode) { return mode == 2 ? (r > 0.f ? v : 0.f) : v + r; }
+// has_res = 3 (round 6): both at once, from two tensors -- v = m > 0 ? v + r : 0 (cgan_conv2d_nhwc_bwd_data_add_relu: the
+// data gradient of a bottleneck's first conv + the skip branch's gradient, times the derivative of the ReLU whose output the
+// conv read: what BatchNorm's backward of the previous block would otherwise form in a pass of its own).  Only the kernels
+// with the shared store path of conv_gemm.h take it (conv_gemm_res2_ok); ``res2`` carries m.
+__device__ __forceinline__ float cgan_res_apply3(float v, float r, float m) { return m > 0.f ? v + r : 0.f; }
 
 // ------------------------------------------------------------------------------------------------
 // development knobs

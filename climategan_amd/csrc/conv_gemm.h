@@ -8,6 +8,7 @@ struct ConvGemmArgs {
   const u32x4* w;       // packed [ctile][ks = tap * (cin_s/32) + cc][lane]
   const float* bias;    // padded to ctiles*16, or null
   const uint16_t* res;  // residual or null
+  const uint16_t* res2; // has_res == 3 only: the ReLU output whose sign masks the result (cgan_res_apply3), else unused
   uint16_t* y;
   int n, h_in, w_in, cin_s;
   int cout, cout_s, ctiles, ksteps;
@@ -47,6 +48,8 @@ int conv_gemm_pair_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
 // true for convs whose channel counts make the 128x256 (cout x pixel) LDS tiling worthwhile
 bool conv_gemm_applicable(const CganConvDesc* d);
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s);
+// true if the kernel conv_gemm_launch picks for ``a`` takes has_res == 3 (the shared store path: conv_gemm_staged_store)
+bool conv_gemm_res2_ok(const ConvGemmArgs& a, int dtype);
 // pixels per statistics chunk of the kernel conv_gemm_launch would run for ``a`` (0: that kernel writes no statistics,
 // or npix is not a whole number of chunks)
 int conv_gemm_stats_chunk_pixels(const ConvGemmArgs& a, int dtype);
@@ -170,7 +173,7 @@ __device__ __forceinline__ void conv_gemm_stats_epilogue(f32x4 (&acc)[WC][WP], c
 // the epilogue, 600 us where the same GEMM without the residual takes 310).  A lane's 8-channel chunk is the same in
 // every iteration (64 % CH == 0): the bias is loaded once; the residual chunks of ALL passes (2*WC*WP registers, half the
 // accumulators' count, free once the K loop's fragments are dead) are in flight together, then the stores stream out.
-template <typename T, int WC, int WP, int PP>
+template <typename T, int WC, int WP, int PP, bool RES2 = false>
 __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP], const ConvGemmArgs& p,
                                                        unsigned char* stg, int pix0, int cout_base, const float* bias_ep,
                                                        int lane, int j, int g) {
@@ -190,6 +193,18 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
     bb1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
   }
   u32x4 rv[NPASS][NIT];
+  // has_res == 3 (RES2 instantiations only: the registers are not the common path's to spend): a second map (the mask's
+  // source) per chunk.  Pass k + 1's chunks are requested once pass k's accumulators are staged (dead): everything is
+  // still in flight before the one wait, except from the third pass on (tiles with one staging pass per pixel tile)
+  u32x4 rm[RES2 ? (NPASS > 1 ? 2 : 1) : 1][RES2 ? NIT : 1];
+  auto load_rm = [&](int pass, u32x4 (&dst)[RES2 ? NIT : 1]) {
+#pragma unroll
+    for (int it = 0; it < (RES2 ? NIT : 0); ++it) {
+      const int pix = pix0 + pass * PP * 16 + it * PSTEP + pl0;
+      dst[it] = (u32x4){0u, 0u, 0u, 0u};
+      if (pix < p.npix && ch_ok) dst[it] = *reinterpret_cast<const u32x4*>(p.res2 + (size_t)pix * p.cout_s + ch);
+    }
+  };
   if (p.has_res) {                                            // wave-uniform
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass)
@@ -211,6 +226,7 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
           rv[pass][it] = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
         }
       }
+    if (RES2 && p.has_res == 3) load_rm(0, rm[0]);
     __builtin_amdgcn_sched_barrier(0);                        // the loads stay in front of the staging and the stores
   }
 #pragma unroll
@@ -221,10 +237,15 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
       for (int c = 0; c < WC; ++c)
         *reinterpret_cast<f32x4*>(stg + (tt * 16 + j) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (RES2 && NPASS > 1 && p.has_res == 3 && pass + 1 < NPASS) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_rm(pass + 1, rm[(pass + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ONE wait for the bias / residual loads, as a builtin the compiler's wait-count pass sees, on every path: left to
     // itself it puts s_waitcnt vmcnt(0) in front of each chunk's first use of a prefetched register (the uses sit behind
     // wave-uniform branches, the merged scoreboard state is "maybe pending") -- and that waits for the previous STORE
-    if (pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
+    if (pass == 0 || (RES2 && p.has_res == 3 && pass >= 2)) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pl = it * PSTEP + pl0;
@@ -240,7 +261,16 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
             v[4 + r] += bb1[r];
           }
         }
-        if (p.has_res) {
+        if (RES2 && p.has_res == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r0, r1, m0, m1;
+            unpack2<T>(rv[pass][it][e], r0, r1);
+            unpack2<T>(rm[RES2 && NPASS > 1 ? (pass & 1) : 0][RES2 ? it : 0][e], m0, m1);
+            v[2 * e] = cgan_res_apply3(v[2 * e], r0, m0);
+            v[2 * e + 1] = cgan_res_apply3(v[2 * e + 1], r1, m1);
+          }
+        } else if (p.has_res) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float r0, r1;

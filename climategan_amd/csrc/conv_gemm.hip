@@ -41,7 +41,8 @@ __device__ __forceinline__ int reflect_i(int i, int n) {
   return i;
 }
 
-template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE>
+// RES2: the instantiation that takes has_res == 3 (a second epilogue map, conv_gemm_staged_store) -- the 2-stage 128 x 128 tile only
+template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE, bool RES2 = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int npb, int ncb) {
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int CT_BLK = WAVES_C * WC;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p, int n
     conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * WAVES_P + wp, j, g);
     if (p.bias) bias_ep = nullptr;       // folded into the accumulators: the store path skips it (wave-uniform)
   }
-  conv_gemm_staged_store<T, WC, WP, PP>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j, g);
+  conv_gemm_staged_store<T, WC, WP, PP, RES2>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -502,14 +503,14 @@ bool k64_ok(const ConvGemmArgs& a) {
 }
 
 
-template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE>
+template <typename T, int WAVES_C, int WC, int WP, bool REFLECT, int NS = NSTAGE, bool RES2 = false>
 int launch_cfg2(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int WAVES_P = 4 / WAVES_C;
   constexpr int CT_BLK = WAVES_C * WC, PT_BLK = WAVES_P * WP;
   constexpr size_t smem = (size_t)NS * (CT_BLK + PT_BLK) * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT, NS, RES2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -520,7 +521,7 @@ int launch_cfg2(const ConvGemmArgs& a, hipStream_t s) {
   const int npb = ceil_div(ceil_div(a.npix, 16), PT_BLK);
   const int ncb = ceil_div(a.ctiles, CT_BLK);
   const int grid = ceil_div(npb, 8) * 8 * ncb;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT, NS>), dim3(grid), dim3(256), smem, s, a, npb, ncb);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, WAVES_C, WC, WP, REFLECT, NS, RES2>), dim3(grid), dim3(256), smem, s, a, npb, ncb);
   return CGAN_OK;
 }
 
@@ -622,7 +623,9 @@ int launch(const ConvGemmArgs& a, hipStream_t s) {
     case 1: return launch_cfg<T, 1, 4, 4>(a, s);
     case 2: return launch_cfg<T, 2, 8, 4>(a, s);
     case 3: return launch_cfg<T, 2, 4, 8>(a, s);
-    case 5: return launch_cfg<T, 2, 4, 4, 2>(a, s);
+    case 5:
+      if (a.has_res == 3) return launch_cfg2<T, 2, 4, 4, false, 2, true>(a, s);      // (conv_gemm_res2_ok: zero padding)
+      return launch_cfg<T, 2, 4, 4, 2>(a, s);
     default: return launch_cfg<T, 2, 4, 4>(a, s);
   }
 }
@@ -642,6 +645,11 @@ CGAN_DEV_ONLY(extern "C" void cgan_debug_set_gemm_ws(int v) { g_gemm_ws = v; })
 
 int conv_gemm_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
   return dtype == CGAN_F16 ? launch<F16>(a, s) : launch<BF16>(a, s);
+}
+
+bool conv_gemm_res2_ok(const ConvGemmArgs& a, int dtype) {
+  const Choice ch = choose(a, dtype == CGAN_BF16);
+  return (ch.kind == KIND_PLAIN && ch.cfg == 5 && a.pad_mode != CGAN_PAD_REFLECT) || ch.kind == KIND_BIG;
 }
 
 int conv_gemm_stats_chunk_pixels(const ConvGemmArgs& a, int dtype) {

@@ -39,7 +39,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_big_zeros[4];   // what t
 // component once (Split<T>::NS blocks of csb channels per pixel); the K extent p.cin_s = NB * csb, K-block b = storage block
 // xcomp(b) -- a lane's 8-channel group of a stage is looked up when the stage is issued; the epilogue takes bias / split
 // residual / activation in fp32 and stores the components (as conv_gemm_ext_kernel's pair epilogue does).
-template <typename T, int NW, bool PAIR = false>
+template <typename T, int NW, bool PAIR = false, bool RES2 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemmArgs p, int npb, int ncb) {
   constexpr int WC = 8;                       // cout tiles per wave (128 couts)
   constexpr int WP = NW == 4 ? 8 : 4;         // pixel tiles per wave (128 / 64 pixels)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
     if (p.bias) bias_ep = nullptr;
   }
   if constexpr (!PAIR) {     // the store path shared with conv_gemm_kernel: every global read in front of the first store
-    conv_gemm_staged_store<T, WC, WP, PP>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j16, g);
+    conv_gemm_staged_store<T, WC, WP, PP, RES2>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j16, g);
     return;
   }
   auto epilogue_pass = [&](auto pass_tag) {
@@ -353,12 +353,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   epilogue_pass(std::integral_constant<int, 1>{});
 }
 
-template <typename T, int NW, bool PAIR = false>
+template <typename T, int NW, bool PAIR = false, bool RES2 = false>
 int launch_big(const ConvGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = 160 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_big_kernel<T, NW, PAIR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_big_kernel<T, NW, PAIR, RES2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       cgan_set_error("conv_gemm_big: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -369,7 +369,7 @@ int launch_big(const ConvGemmArgs& a, hipStream_t s) {
   const int npb = ceil_div(ceil_div(a.npix, 16), 16);
   const int ncb = ceil_div(a.ctiles, 16);
   const int grid = ceil_div(npb, 8) * 8 * ncb;
-  hipLaunchKernelGGL((conv_gemm_big_kernel<T, NW, PAIR>), dim3(grid), dim3(NW * 64), smem, s, a, npb, ncb);
+  hipLaunchKernelGGL((conv_gemm_big_kernel<T, NW, PAIR, RES2>), dim3(grid), dim3(NW * 64), smem, s, a, npb, ncb);
   return CGAN_OK;
 }
 
@@ -387,6 +387,8 @@ bool conv_gemm_big_ok(const ConvGemmArgs& a) {
 // template but not instantiated: hipcc (ROCm 7.2) cannot keep a 256-register accumulator in place -- it rotates tiles
 // through a[0:3] with v_accvgpr_write / _read pairs around every MFMA (445 of them for 256 MFMAs in the loop body).
 int conv_gemm_big_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
+  if (a.has_res == 3)      // the instantiation with the second epilogue map (two launches per train step: layer4's bottlenecks)
+    return dtype == CGAN_F16 ? launch_big<F16, 8, false, true>(a, s) : launch_big<BF16, 8, false, true>(a, s);
   return dtype == CGAN_F16 ? launch_big<F16, 8>(a, s) : launch_big<BF16, 8>(a, s);
 }
 

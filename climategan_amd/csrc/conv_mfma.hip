@@ -25,6 +25,7 @@ struct ConvParams {
   const u32x4* w;
   const float* bias;
   const uint16_t* res;
+  const uint16_t* res2;   // has_res == 3 only (cgan_res_apply3): the ReLU output that masks the result
   uint16_t* y;
   int n, h_in, w_in, hx, wx, cin_s, cin_p, cg;   // cin_p: per-tap K extent (cin_s, or padded to 32 for 3x3)
   int cout, cout_s, ctiles;
@@ -633,6 +634,7 @@ int fill_params(ConvParams& p, const CganConvDesc* d) {
   p.in_ups = d->in_upsample; p.act = d->act; p.slope = d->act_slope; p.in_zs = 1; p.cls_s = 0; p.cls_pad = 0;
   p.has_res = d->has_residual; p.res_ups = d->residual_upsample;
   p.stats = nullptr;
+  p.res2 = nullptr;
   p.pair = 0;
   return CGAN_OK;
 }
@@ -797,7 +799,7 @@ extern "C" int cgan_conv2d_bind_workspace(void* stream, void* workspace, size_t 
 
 static ConvGemmArgs gemm_args(const ConvParams& p) {
   ConvGemmArgs a;
-  a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
+  a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.res2 = p.res2; a.y = p.y;
   a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
   a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
   a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
@@ -953,7 +955,7 @@ static int stats_chunk_pixels(ConvParams& p, const CganConvDesc* d) {
   if (select_conv_kernel(p, d) != CGAN_CONV_KERNEL_GEMM) return 0;
   ConvGemmArgs a;
   a.x = nullptr; a.w = nullptr; a.bias = d->has_bias ? &k_bias_sentinel : nullptr;   // choose() keys on it: the query must pick what the launch picks
-  a.res = nullptr; a.y = nullptr; a.stats = nullptr;
+  a.res = nullptr; a.res2 = nullptr; a.y = nullptr; a.stats = nullptr;
   a.n = p.n; a.h_in = p.h_in; a.w_in = p.w_in; a.cin_s = p.cin_s;
   a.cout = p.cout; a.cout_s = p.cout_s; a.ctiles = p.ctiles; a.ksteps = p.ksteps;
   a.kh = p.kh; a.kw = p.kw; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil; a.pad_mode = p.pad_mode;
@@ -1202,7 +1204,7 @@ extern "C" int cgan_conv2d_kernel_kind(const CganConvDesc* d, int32_t bwd_data) 
 }
 
 static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx, const CganConvDesc* fwd,
-                         void* stream, int res_mode = 1) {
+                         void* stream, int res_mode = 1, const void* relu_out2 = nullptr) {
   ConvParams p;
   CganConvDesc t;
   int rc = dgrad_params(p, fwd, &t);
@@ -1215,7 +1217,8 @@ static int bwd_data_impl(const void* dy, const void* packed_w_dgrad, const void*
   CGAN_REQUIRE(dx_add == nullptr || plain, "conv2d_nhwc_bwd_data_add: only for stride-1 'same' convolutions");
   if (dx_add) {             // the other gradient contribution of the same tensor rides in the epilogue's residual slot
     p.res = (const uint16_t*)dx_add;
-    p.has_res = res_mode;         // 1: add the other contribution; 2: the ReLU derivative from the activation's output
+    p.has_res = res_mode;         // 1: add the other contribution; 2: the ReLU derivative from the activation's output;
+    p.res2 = (const uint16_t*)relu_out2;   // 3: both (the caller checked conv_gemm_res2_ok)
     p.res_ups = 0;
     t.has_residual = 1;
   }
@@ -1259,6 +1262,29 @@ extern "C" int cgan_conv2d_nhwc_bwd_data_relu(const void* dy, const void* packed
                                               const CganConvDesc* fwd, void* stream) {
   CGAN_REQUIRE(relu_out != nullptr, "conv2d_nhwc_bwd_data_relu: null pointer");
   return bwd_data_impl(dy, packed_w_dgrad, relu_out, dx, fwd, stream, 2);
+}
+
+// dx = [relu_out > 0] * (data gradient + dx_add).  Fused (one launch, has_res = 3) where the dispatcher's kernel for this
+// descriptor has the shared store path; elsewhere the add rides in the epilogue and the ReLU derivative is a pass of its own
+// over dx (cgan_act_bwd, in place: element i is read and written by the same thread) -- same values either way.
+extern "C" int cgan_conv2d_nhwc_bwd_data_add_relu(const void* dy, const void* packed_w_dgrad, const void* dx_add,
+                                                  const void* relu_out, void* dx, const CganConvDesc* fwd, void* stream) {
+  CGAN_REQUIRE(dx_add != nullptr && relu_out != nullptr, "conv2d_nhwc_bwd_data_add_relu: null pointer");
+  ConvParams p;
+  CganConvDesc t;
+  int rc = dgrad_params(p, fwd, &t);
+  if (rc != CGAN_OK) return rc;
+  const bool plain = fwd->stride == 1 && p.pad >= 0 && t.h_in + 2 * p.pad - t.dilation * (t.kh - 1) == t.h_out &&
+                     t.w_in + 2 * p.pad - t.dilation * (t.kw - 1) == t.w_out;
+  CGAN_REQUIRE(plain, "conv2d_nhwc_bwd_data_add_relu: only for stride-1 'same' convolutions");
+  p.res = (const uint16_t*)dx_add; p.has_res = 1; p.res_ups = 0;
+  t.has_residual = 1; t.pad = p.pad;
+  if (select_conv_kernel(p, &t) == CGAN_CONV_KERNEL_GEMM && conv_gemm_res2_ok(gemm_args(p), fwd->dtype))
+    return bwd_data_impl(dy, packed_w_dgrad, dx_add, dx, fwd, stream, 3, relu_out);
+  rc = bwd_data_impl(dy, packed_w_dgrad, dx_add, dx, fwd, stream);
+  if (rc != CGAN_OK) return rc;
+  return cgan_act_bwd(relu_out, dx, dx, fwd->dtype, CGAN_ACT_RELU, 0.f,
+                      (int64_t)fwd->n * fwd->h_in * fwd->w_in * cgan_cs(fwd->c_in), stream);
 }
 
 extern "C" int cgan_conv2d_nhwc_bwd_data_add(const void* dy, const void* packed_w_dgrad, const void* dx_add, void* dx,

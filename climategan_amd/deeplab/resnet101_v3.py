@@ -32,13 +32,16 @@ class Bottleneck(nn.Module):
         self.dilation = dilation
         self._c = [_PackCache() for _ in range(4)]
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, sole_consumer=False):
+        """``sole_consumer``: the caller vouches that nothing but this block reads ``x`` (the previous block's output) -- the
+        derivative of the ReLU that produced it then rides in conv1's data-gradient kernel (norms.conv_bn_forward)."""
         residual = x
         if FUSE_RESIDUAL_GRADIENT and self.bn1.training and needs_grad(self, x.t):
             # training: conv1 hands x through to the residual branch (the identity, or the downsample conv), so that x has
             # ONE consumer in the autograd graph and the two gradient contributions are summed inside conv1's
             # data-gradient kernel (autograd.ConvPassFn)
-            out, residual = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU, passthrough=True)
+            out, residual = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU, passthrough=True,
+                                            sole_consumer=sole_consumer)
             x = residual
         else:
             out = conv_bn_forward(self.conv1, self.bn1, self._c[0], x, act=ops.ACT_RELU)
@@ -98,12 +101,18 @@ class ResNet(nn.Module):
     def forward_nhwc(self, x: ops.NHWC):
         x = conv_bn_forward(self.conv1, self.bn1, self._stem, x, act=ops.ACT_RELU)
         x = Fn.maxpool3x3s2(x)
+        # a block's output is read by the next block only -- except the max-pool's (no bottleneck behind it), layer1's last
+        # (``low`` also feeds the decoders) and the encoder's result
+        sole = False
         for b in self.layer1:
-            x = b.forward_nhwc(x)
+            x = b.forward_nhwc(x, sole_consumer=sole)
+            sole = True
         low = x
+        sole = False
         for layer in (self.layer2, self.layer3, self.layer4):
             for b in layer:
-                x = b.forward_nhwc(x)
+                x = b.forward_nhwc(x, sole_consumer=sole)
+                sole = True
         return x, low
 
     def forward(self, input):

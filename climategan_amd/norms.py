@@ -263,6 +263,9 @@ FUSE_BN_RESIDUAL = True      # relu(bn3(.) + residual) in one apply pass (and on
 # separate statistics pass (same-box A/B)
 import os as _os
 FUSE_BN_STATS = _os.environ.get("CGAN_FUSE_BN_STATS", "1") != "0"
+# relu(bn3(.) + skip)'s derivative in the NEXT bottleneck's first data-gradient conv instead of in bn3's backward (round 6;
+# autograd.claim_relu_mask); CGAN_FUSE_RELU_MASK=0: the mask in BatchNorm's backward (same-box A/B, bit-identity test)
+FUSE_RELU_MASK = _os.environ.get("CGAN_FUSE_RELU_MASK", "1") != "0"
 
 
 def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mode=ops.PAD_ZERO, pad=None, **kw) -> ops.NHWC:
@@ -302,6 +305,7 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
     from .autograd import BatchNormActFn
 
     act, slope, residual = kw.pop("act", ops.ACT_NONE), kw.pop("slope", 0.2), kw.pop("residual", None)
+    sole_consumer = kw.pop("sole_consumer", False)
     if kw.get("in_upsample") or kw.get("residual_upsample"):
         raise NotImplementedError("conv_bn_forward: folded upsamples are not used on the training path")
     pw = cache.get_plain(conv.weight, conv.bias, x.t.dtype)
@@ -312,6 +316,10 @@ def conv_bn_forward(conv: nn.Conv2d, bn, cache: _PackCache, x: ops.NHWC, pad_mod
 
         assert bn is not None and residual is None
         pcfg = dict(c_in=x.c, stride=conv.stride[0], pad=p, dilation=conv.dilation[0], pad_mode=pad_mode, want_stats=FUSE_BN_STATS)
+        if sole_consumer and FUSE_RELU_MASK:
+            # x has no other reader: the derivative of the ReLU that produced it moves into this conv's data gradient
+            from .autograd import claim_relu_mask
+            pcfg["mask_input"] = claim_relu_mask(x.t)
         y_t, pass_t = ConvPassFn.apply(x.t, conv.weight, conv.bias, pw, pcfg)
         y, passthrough = ops.NHWC(y_t, conv.weight.shape[0]), ops.NHWC(pass_t, x.c)
         conv_stats = pcfg.get("stats_out")

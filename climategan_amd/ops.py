@@ -1094,10 +1094,9 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     if relu_out is not None:
         # ``relu_out``: the forward INPUT map, itself the output of a ReLU -- the kernel's epilogue applies that ReLU's
         # derivative (dx * [relu_out > 0]); where the fused form does not apply, the separate pass does
-        if add is not None:
-            raise RuntimeError("conv2d_bwd_data: add and relu_out cannot be combined")
+        # (with ``add``: dx = [relu_out > 0] * (data gradient + add), cgan_conv2d_nhwc_bwd_data_add_relu)
         if not (stride == 1 and pad_mode == PAD_ZERO and 2 * pad == dilation * (w.shape[2] - 1) and w.shape[2] == w.shape[3]):
-            dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode, prepacked=prepacked)
+            dx = conv2d_bwd_data(dy, w, x_shape, stride, pad, dilation, sigma, pad_mode, add=add, prepacked=prepacked)
             return act_bwd(relu_out, dx, ACT_RELU)
     per_sample = max(dy.t.nbytes // max(dy.n, 1), (x_shape[1] + 2 * pad) * (x_shape[2] + 2 * pad) * cs8(w.shape[1]) * 2)
     if x_shape[0] * per_sample >= MAX_MAP_BYTES:                 # see _batch_chunked
@@ -1141,6 +1140,12 @@ def conv2d_bwd_data(dy: NHWC, w: torch.Tensor, x_shape, stride=1, pad=0, dilatio
     if relu_out is not None:
         if relu_out.t.shape != dx.shape or relu_out.t.dtype != dx.dtype or not relu_out.t.is_contiguous():
             raise RuntimeError("conv2d_bwd_data: ``relu_out`` %s does not match dx %s" % (tuple(relu_out.t.shape), tuple(dx.shape)))
+        if add is not None:
+            if add.t.shape != dx.shape or add.t.dtype != dx.dtype or not add.t.is_contiguous():
+                raise RuntimeError("conv2d_bwd_data: ``add`` %s does not match dx %s" % (tuple(add.t.shape), tuple(dx.shape)))
+            _lib.check(lib.cgan_conv2d_nhwc_bwd_data_add_relu(_ptr(dy.t), _ptr(packed), _ptr(add.t), _ptr(relu_out.t), _ptr(dx),
+                                                              C.byref(d), _stream()), "cgan_conv2d_nhwc_bwd_data_add_relu")
+            return NHWC(dx, c_in)
         _lib.check(lib.cgan_conv2d_nhwc_bwd_data_relu(_ptr(dy.t), _ptr(packed), _ptr(relu_out.t), _ptr(dx), C.byref(d), _stream()),
                    "cgan_conv2d_nhwc_bwd_data_relu")
         return NHWC(dx, c_in)

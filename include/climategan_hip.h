@@ -164,6 +164,14 @@ int cgan_conv2d_nhwc_bwd_data_add(const void* dy, const void* packed_w_dgrad, co
  * ReLU, norms.py:163-166; the VGG-19 ReLUs, losses.py:304-334).  Stride-1 'same' convolutions, like _bwd_data_add. */
 int cgan_conv2d_nhwc_bwd_data_relu(const void* dy, const void* packed_w_dgrad, const void* relu_out, void* dx,
                                    const CganConvDesc* fwd, void* stream);
+/* dx = [relu_out > 0] * (conv_transpose(dy, w) + dx_add): _bwd_data_add and _bwd_data_relu at once (round 6).  The first conv
+ * of a ResNet bottleneck reads the previous block's output relu(bn3(.) + skip) (resnet101_v3.py:30-50) and hands it on to its
+ * own block's skip branch: everything that flows back into that tensor passes through this call, so the ReLU's derivative is
+ * taken here and the previous block's BatchNorm backward receives its gradient already masked (cgan_batchnorm_act_bwd_grouped
+ * with act = none: one read of `out` and one write of the masked gradient less per bottleneck).  Same values as _bwd_data_add
+ * followed by cgan_act_bwd(relu_out, dx, dx) -- which is what runs where the selected kernel has no fused form. */
+int cgan_conv2d_nhwc_bwd_data_add_relu(const void* dy, const void* packed_w_dgrad, const void* dx_add, const void* relu_out,
+                                       void* dx, const CganConvDesc* fwd, void* stream);
 size_t cgan_conv2d_bwd_weight_workspace_bytes(const CganConvDesc* fwd);
 int cgan_conv2d_nhwc_bwd_weight(const void* x, const void* dy, float* dw_oihw, float* dbias, const CganConvDesc* fwd,
                                 void* workspace, size_t workspace_bytes,

@@ -725,8 +725,75 @@ def test_dgrad_with_relu_derivative(dt, case):
     ref = F.conv_transpose2d(back(dy).float(), q(w.cpu().numpy(), dt), stride=stride, padding=pad, dilation=dil,
                              output_padding=(H + 2 * pad - dil * (k - 1) - 1) % stride) * (back(x).float() > 0)
     assert rel_err(back(dx).float(), ref) <= TOL[dt]
-    with pytest.raises(RuntimeError):
-        ops.conv2d_bwd_data(dy, w, (B, H, W), stride=stride, pad=pad, dilation=dil, relu_out=x, add=x)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(256, 64, 1, 0, 1, 1, 2, 48, 64),       # 2-stage 128 x 128 GEMM tile: fused (has_res = 3)
+                                  (1024, 256, 1, 0, 1, 1, 1, 70, 61),     # the same with pixel tails
+                                  (2048, 512, 1, 0, 1, 1, 1, 128, 130),   # 256 x 256 tile: fused
+                                  (128, 96, 3, 2, 2, 1, 1, 33, 21),       # 3x3: add in the epilogue + the mask as a pass
+                                  (40, 24, 3, 1, 1, 1, 2, 16, 16),        # general kernel: likewise
+                                  (128, 64, 3, 1, 1, 2, 1, 20, 20)])      # stride 2: the wrapper's own fallback
+def test_dgrad_with_added_gradient_and_relu_derivative(dt, case):
+    """cgan_conv2d_nhwc_bwd_data_add_relu (ops.conv2d_bwd_data(add=..., relu_out=...)): dx = [relu_out > 0] * (data gradient
+    + add) -- what a bottleneck's first conv hands back to the previous block's relu(bn3(.) + skip).  BIT-IDENTICAL to the
+    add-in-the-epilogue call followed by the activation-backward pass, whichever kernel the descriptor selects."""
+    from climategan_amd import ops
+
+    cin, cout, k, pad, dil, stride, B, H, W = case
+    rng = np.random.RandomState(7)
+    w = torch.from_numpy(rng.randn(cout, cin, k, k).astype(np.float32) * 0.05).cuda()
+    ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    dy = to_nhwc(torch.from_numpy(rng.randn(B, cout, ho, wo).astype(np.float32)), dt)
+    add = to_nhwc(torch.from_numpy(rng.randn(B, cin, H, W).astype(np.float32)), dt)
+    x = to_nhwc(torch.relu(torch.from_numpy(rng.randn(B, cin, H, W).astype(np.float32))), dt)
+    dx = ops.conv2d_bwd_data(dy, w, (B, H, W), stride=stride, pad=pad, dilation=dil, add=add, relu_out=x)
+    two_pass = ops.act_bwd(x, ops.conv2d_bwd_data(dy, w, (B, H, W), stride=stride, pad=pad, dilation=dil, add=add), ops.ACT_RELU)
+    assert torch.equal(dx.t, two_pass.t)
+    assert 0.2 < (dx.t[..., :cin] == 0).float().mean().item() < 0.8
+    ref = (F.conv_transpose2d(back(dy).float(), q(w.cpu().numpy(), dt), stride=stride, padding=pad, dilation=dil,
+                              output_padding=(H + 2 * pad - dil * (k - 1) - 1) % stride) + back(add).float()) * (back(x).float() > 0)
+    assert rel_err(back(dx).float(), ref) <= TOL[dt]
+    assert (dx.t[..., cin:] == 0).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_relu_mask_in_the_next_blocks_data_gradient_is_bitwise_the_batchnorm_mask(dt):
+    """norms.FUSE_RELU_MASK: three bottlenecks in a row, the derivative of relu(bn3(.) + skip) taken by the NEXT block's first
+    data-gradient conv (autograd.claim_relu_mask) or by bn3's own backward -- every gradient bit for bit the same; the last
+    block's output has another reader (the loss), so its mask stays where it was."""
+    from climategan_amd import autograd, norms, ops
+    from climategan_amd.deeplab import resnet101_v3 as R
+
+    torch.manual_seed(4)
+    # (256 -> 64 -> 256 at 4 x 48 x 48: the first convs' data gradients run on the wide-layer GEMM, i.e. the fused epilogue)
+    blocks = [R.Bottleneck(256, 64, 1, 1, torch.nn.Sequential(torch.nn.Conv2d(256, 256, 1, bias=False), torch.nn.BatchNorm2d(256)),
+                           torch.nn.BatchNorm2d),
+              R.Bottleneck(256, 64, 1, 2, None, torch.nn.BatchNorm2d), R.Bottleneck(256, 64, 1, 1, None, torch.nn.BatchNorm2d)]
+    blocks = [b.cuda().train() for b in blocks]
+    x0 = torch.randn(4, 256, 48, 48, device="cuda")
+    grads, claimed = {}, {}
+    for fuse in (True, False):
+        norms.FUSE_RELU_MASK = fuse
+        try:
+            for b in blocks:
+                for p in b.parameters():
+                    p.grad = None
+            x = ops.nchw_to_nhwc(x0, dt)
+            x.t.requires_grad_(True)
+            y, nodes = x, []
+            for i, b in enumerate(blocks):
+                y = b.forward_nhwc(y, sole_consumer=i > 0)
+                nodes.append(y.t.grad_fn)
+            claimed[fuse] = [bool(n.premasked) for n in nodes]
+            (y.t.float() * torch.linspace(-1, 1, y.t.numel(), device="cuda").view_as(y.t)).sum().backward()
+            grads[fuse] = [x.t.grad.clone()] + [p.grad.clone() for b in blocks for p in b.parameters()]
+        finally:
+            norms.FUSE_RELU_MASK = True
+    assert claimed[True] == [True, True, False] and claimed[False] == [False, False, False]
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
