@@ -53,7 +53,8 @@ __device__ __forceinline__ void halo_coord(const Conv3x3LdsArgs& p, int& yy, int
 
 // Epilogue shared by both kernels: bias + residual (optionally through the folded upsample) + activation, staged
 // through LDS so that the tile leaves as whole 16-byte channel chunks.
-template <typename T, int NCT>
+// RES: whether the kernel takes a residual at all (the first-layer kernels never do: no registers for its prefetch there)
+template <typename T, int NCT, bool RES = true>
 __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 (&acc)[NCT][PT], unsigned char* smem,
                                                  int n, int ty0, int tx0, int ct0, int wave, int j, int g) {
   // ---------------- epilogue: lane holds channels (ct0+c)*16 + 4g + {0..3} of pixel (row wave*PT+t, column j)
@@ -85,16 +86,34 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
     const int ch = (ct0 + c) * 16 + g * 4;           // (the bias vector is padded to whole cout tiles)
     bias_q[c] = (p.bias && ch < p.cout_s) ? *reinterpret_cast<const f32x4*>(p.bias + ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // the residual quads of the whole tile are requested together (round 6): a load next to its use compiled to
+  // global_load; s_waitcnt vmcnt(0) per (row, cout tile) -- PT * NCT serialized round trips per wave
+  u32x2 rq[RES ? PT : 1][RES ? NCT : 1];
+  if (RES && p.has_res) {                            // wave-uniform
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int yy = ty0 + wave * PT + t, xx = tx0 + j;
+      const bool pin = yy < p.h && xx < p.w_;
+      size_t rbase = 0;
+      if (pin) {
+        if (p.res_ups) rbase = (((size_t)n * (p.h >> 1) + (yy >> 1)) * (p.w_ >> 1) + (xx >> 1)) * p.cout_s;
+        else rbase = (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s;
+      }
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int ch = (ct0 + c) * 16 + g * 4;
+        rq[t][c] = (u32x2){0u, 0u};
+        if (pin && ch < p.cout_s) rq[t][c] = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), once, as a builtin the wait-count pass sees (conv_gemm.h)
+  }
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
     const int row = wave * PT + t;
     const int yy = ty0 + row, xx = tx0 + j;
     const bool pin = yy < p.h && xx < p.w_;
-    size_t rbase = 0;
-    if (p.has_res && pin) {
-      if (p.res_ups) rbase = (((size_t)n * (p.h >> 1) + (yy >> 1)) * (p.w_ >> 1) + (xx >> 1)) * p.cout_s;
-      else rbase = (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s;
-    }
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
       const int ch = (ct0 + c) * 16 + g * 4;
@@ -104,8 +123,8 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
       if (ch < p.cout_s) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bias_q[c][r];
-        if (p.has_res && pin) {
-          const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + rbase + ch);
+        if (RES && p.has_res && pin) {
+          const u32x2 rv = rq[RES ? t : 0][RES ? c : 0];
           float r0, r1, r2, r3;
           unpack2<T>(rv[0], r0, r1);
           unpack2<T>(rv[1], r2, r3);
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, NCT <= 2 ? 8 : (NCT <= 4 ? 4 : 2)) void
       acc[c][t] = mfma16(as_vec8<T>(a1[c]), as_vec8<T>(b1), acc[c][t]);
     }
   }
-  conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);
+  conv3x3_epilogue<T, NCT, false>(p, acc, smem, n, ty0, tx0, ct0, wave, j, g);       // (launch_nct: never with a residual)
 }
 
 // First-layer convolutions (round 5): 8 storage channels per input pixel (<= 8 real: the image, the mask || image pair of the
@@ -469,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void conv_smallcin_kernel(Conv3x3Lds
 #pragma unroll
     for (int c = 0; c < NCT; ++c) a_cur[c] = a_nxt[c];
   }
-  conv3x3_epilogue<T, NCT>(p, acc, smem, n, ty0, tx0, 0, wave, j, g);
+  conv3x3_epilogue<T, NCT, false>(p, acc, smem, n, ty0, tx0, 0, wave, j, g);          // (has_res = 0 by construction)
 }
 
 template <typename T, int NCT>
@@ -552,7 +571,7 @@ int launch(const Conv3x3LdsArgs& a, hipStream_t s) {
 template <typename T>
 int launch_nct(const Conv3x3LdsArgs& a, hipStream_t s) {
   // folded taps for <= 4 input channels stored as 4 / 8 / ... channels per pixel (the packed weights keep one k-step per tap)
-  if (g_c4_enabled && a.cin <= 4 && a.cin_p == 32 && a.ksteps == 9 && (a.cin_s & 3) == 0) {
+  if (g_c4_enabled && a.cin <= 4 && a.cin_p == 32 && a.ksteps == 9 && (a.cin_s & 3) == 0 && !a.has_res) {
     // Channel tiles per workgroup.  The workgroup is a latency chain (halo load -> 2 MFMAs per tile -> staged stores); its
     // epilogue staging (8 KiB per channel tile) decides how many share a CU.  4 x 640^2, 128 couts, same box
     // (tools/bench_conv.py --c4): 8 tiles (2 per CU) 195 us, 4 tiles 135 us, 2 tiles 135 us; at 320^2 56 / 47 / 39 us --
