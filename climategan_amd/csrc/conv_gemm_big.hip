@@ -270,6 +270,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
     conv_gemm_staged_store<T, WC, WP, PP, RES2>(acc, p, stg, (pblk * PT_BLK + wp * WP) * 16, cout_base, bias_ep, lane, j16, g);
     return;
   }
+  // (round 6: as conv_gemm_staged_store -- the bias once, a pass's residual components requested together after the pass is
+  // staged (its accumulators are dead by then: 8 chunks x NC components fit), one wait per pass instead of one per load)
+  constexpr int NIT = PP * 16 * CH / 64;
+  constexpr int NSB = Split<T>::NS, NCC = Split<T>::NC;
+  const int qc = lane % CH, pl0 = lane / CH;
+  const int ch = cout_base + qc * 8;
+  const bool ch_ok = ch < p.cout_s;
+  f32x4 bb0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bb1 = bb0;
+  if (bias_ep && ch_ok) {
+    bb0 = *reinterpret_cast<const f32x4*>(bias_ep + ch);
+    bb1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
+  }
   auto epilogue_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
 #pragma unroll
@@ -279,71 +291,78 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
         *reinterpret_cast<f32x4*>(stg + (tt * 16 + j16) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int pix_base = (pblk * PT_BLK + wp * WP + pass * PP) * 16;
+    u32x4 rs[NIT][NCC];
+    if (p.has_res) {                                          // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < PP * 16 * CH / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int pl = idx / CH, qc = idx % CH;
+      for (int it = 0; it < NIT; ++it) {
+        const int pix = pix_base + it * (64 / CH) + pl0;
+        size_t rpix = (size_t)(pix < p.npix ? pix : 0);
+        if (p.res_ups && pix < p.npix) {
+          const int ox = pix % p.w_out;
+          const int r = pix / p.w_out;
+          const int oy = r % p.h_out;
+          const int nn = r / p.h_out;
+          rpix = ((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1);
+        }
+        const uint16_t* rp = p.res + rpix * p.cout_s * NSB + ch;
+#pragma unroll
+        for (int k = 0; k < NCC; ++k) {
+          rs[it][k] = (u32x4){0u, 0u, 0u, 0u};
+          if (pix < p.npix && ch_ok) rs[it][k] = *reinterpret_cast<const u32x4*>(rp + k * p.cout_s);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): bias and this pass's residual, once (conv_gemm.h)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = it * (64 / CH) + pl0;
       const int pix = pix_base + pl;
-      const int ch = cout_base + qc * 8;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
-      if (pix >= p.npix || ch >= p.cout_s) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      {
-        constexpr int NS = Split<T>::NS, NC = Split<T>::NC;
-        if (bias_ep) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_ep + ch), b1 = *reinterpret_cast<const f32x4*>(bias_ep + ch + 4);
+      if (bias_ep) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] += b0[r];
-            v[4 + r] += b1[r];
-          }
+        for (int r = 0; r < 4; ++r) {
+          v[r] += bb0[r];
+          v[4 + r] += bb1[r];
         }
-        if (p.has_res) {
-          size_t rpix = (size_t)pix;
-          if (p.res_ups) {
-            const int ox = pix % p.w_out;
-            const int r = pix / p.w_out;
-            const int oy = r % p.h_out;
-            const int nn = r / p.h_out;
-            rpix = ((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1);
-          }
-          const uint16_t* rp = p.res + rpix * p.cout_s * NS + ch;
-          float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      }
+      if (p.has_res) {
+        float rsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int k = NC - 1; k >= 0; --k) {         // smallest component first
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(rp + k * p.cout_s);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float r0, r1;
-              unpack2<T>(rv[e], r0, r1);
-              rs[2 * e] += r0;
-              rs[2 * e + 1] += r1;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += rs[r];
-        }
-        act_apply_n(v, p.act, p.slope);
-        if (p.cout < p.cout_s) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            if (ch + r >= p.cout) v[r] = 0.f;
-        }
-        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NS + ch;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {                // component k = round16 of what the previous ones left
-          u32x4 comp;
+        for (int k = NCC - 1; k >= 0; --k) {          // smallest component first
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            comp[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-            float q0, q1;
-            unpack2<T>(comp[e], q0, q1);
-            v[2 * e] -= q0;
-            v[2 * e + 1] -= q1;
+            float r0, r1;
+            unpack2<T>(rs[it][k][e], r0, r1);
+            rsum[2 * e] += r0;
+            rsum[2 * e + 1] += r1;
           }
-          *reinterpret_cast<u32x4*>(yp + k * p.cout_s) = comp;
         }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rsum[r];
+      }
+      act_apply_n(v, p.act, p.slope);
+      if (p.cout < p.cout_s) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (ch + r >= p.cout) v[r] = 0.f;
+      }
+      uint16_t* yp = p.y + (size_t)pix * p.cout_s * NSB + ch;
+#pragma unroll
+      for (int k = 0; k < NCC; ++k) {                 // component k = round16 of what the previous ones left
+        u32x4 comp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          comp[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+          float q0, q1;
+          unpack2<T>(comp[e], q0, q1);
+          v[2 * e] -= q0;
+          v[2 * e + 1] -= q1;
+        }
+        if (pix < p.npix && ch_ok) *reinterpret_cast<u32x4*>(yp + k * p.cout_s) = comp;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged rows are consumed before the next pass overwrites

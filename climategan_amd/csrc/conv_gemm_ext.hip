@@ -23,6 +23,14 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_ext_zeros[4];
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void ext_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ext_static_for<I + 1, N>(f);
+  }
+}
+
 template <typename T, int WAVES_C, int WC, int WP>
 __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q, int npb, int ncb) {
   constexpr int NS = 3;
@@ -191,8 +199,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
   unsigned char* stg = smem + wave * (PP * 16 * ROWB);
   const int cout_base = (cblk * CT_BLK + wc * WC) * 16;
   const bool split = q.ksplit > 1;
-#pragma unroll
-  for (int pass = 0; pass < WP / PP; ++pass) {
+  // (round 6, as conv_gemm_staged_store: a lane's 8-channel chunk is the same in every iteration -- the bias is loaded once;
+  // a pass's residual components (split-precision launches) are requested together once the pass is staged; one wait per
+  // pass instead of one in front of every store)
+  constexpr int NIT = PP * 16 * CH / 64;
+  constexpr int PSTEP = 64 / CH;
+  constexpr int NSB = Split<T>::NS, NCC = Split<T>::NC;
+  static_assert(64 % CH == 0, "a lane keeps its channel chunk over the iterations");
+  const int qc = lane % CH, pl0 = lane / CH;
+  const int ch = cout_base + qc * 8;
+  const bool ch_ok = ch < p.cout_s;
+  f32x4 bb0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bb1 = bb0;
+  if (p.bias && !split && ch_ok) {
+    bb0 = *reinterpret_cast<const f32x4*>(p.bias + ch);
+    bb1 = *reinterpret_cast<const f32x4*>(p.bias + ch + 4);
+  }
+  // (a lambda per pass with a compile-time pass index: written as a loop with ``continue`` the compiler did not unroll it for
+  // the 128 x 256 tile and kept the accumulators -- indexed by the pass -- in scratch: 528 bytes per lane)
+  auto do_pass = [&](auto pass_tag) {
+    constexpr int pass = decltype(pass_tag)::value;
 #pragma unroll
     for (int tt = 0; tt < PP; ++tt)
 #pragma unroll
@@ -200,58 +225,77 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
         *reinterpret_cast<f32x4*>(stg + (tt * 16 + j) * ROWB + c * 64 + g * 16) = acc[c][pass * PP + tt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int pix_base = (pblk * PT_BLK + wp * WP + pass * PP) * 16;
+    if (split) {
 #pragma unroll
-    for (int it = 0; it < PP * 16 * CH / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int pl = idx / CH, qc = idx % CH;
-      const int pix = pix_base + pl;
-      const int ch = cout_base + qc * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
-      if (pix >= npix || ch >= p.cout_s) continue;
-      if (split) {
+      for (int it = 0; it < NIT; ++it) {
+        const int pl = it * PSTEP + pl0;
+        const int pix = pix_base + pl;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
+        if (pix >= npix || !ch_ok) continue;
         float* dst = q.ws + ((size_t)yi * p.npix + pix) * p.cout_s + ch;
         *reinterpret_cast<f32x4*>(dst) = v0;
         *reinterpret_cast<f32x4*>(dst + 4) = v1;
-        continue;
       }
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (p.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch + 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      return;
+    }
+    if (q.pair) {
+      // split-precision epilogue (as conv_mfma_kernel's): residual = the sum of its components, activation in fp32, then
+      // v -> c0 = round16(v), c1 = round16(v - c0), ... stored as the channel blocks the next conv multiplies (Split<T>)
+      u32x4 rs[NIT][NCC];
+      if (p.has_res) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] += b0[r];
-          v[4 + r] += b1[r];
-        }
-      }
-      if (q.pair) {
-        // split-precision epilogue (as conv_mfma_kernel's): residual = the sum of its components, activation in fp32, then
-        // v -> c0 = round16(v), c1 = round16(v - c0), ... stored as the channel blocks the next conv multiplies (Split<T>)
-        constexpr int NS = Split<T>::NS, NC = Split<T>::NC;
-        if (p.has_res) {
-          size_t rbase = (size_t)pix;
-          if (p.res_ups) {
+        for (int it = 0; it < NIT; ++it) {
+          const int pix = pix_base + it * PSTEP + pl0;
+          const bool ok = pix < npix && ch_ok;
+          size_t rbase = (size_t)(ok ? pix : 0);
+          if (p.res_ups && ok) {
             const int ox = pix % p.w_out;
             const int r = pix / p.w_out;
             const int oy = r % p.h_out;
             const int nn = r / p.h_out;
             rbase = ((size_t)nn * (p.h_out >> 1) + (oy >> 1)) * (p.w_out >> 1) + (ox >> 1);
           }
-          const uint16_t* rp = p.res + rbase * p.cout_s * NS + ch;
-          float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          const uint16_t* rp = p.res + rbase * p.cout_s * NSB + ch;
 #pragma unroll
-          for (int k = NC - 1; k >= 0; --k) {         // smallest component first
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(rp + k * p.cout_s);
+          for (int k = 0; k < NCC; ++k) {
+            rs[it][k] = (u32x4){0u, 0u, 0u, 0u};
+            if (ok) rs[it][k] = *reinterpret_cast<const u32x4*>(rp + k * p.cout_s);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): the bias and this pass's residual, once (conv_gemm.h)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int pl = it * PSTEP + pl0;
+        const int pix = pix_base + pl;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] += bb0[r];
+            v[4 + r] += bb1[r];
+          }
+        }
+        if (p.has_res) {
+          float rsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = NCC - 1; k >= 0; --k) {         // smallest component first
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float r0, r1;
-              unpack2<T>(rv[e], r0, r1);
-              rs[2 * e] += r0;
-              rs[2 * e + 1] += r1;
+              unpack2<T>(rs[it][k][e], r0, r1);
+              rsum[2 * e] += r0;
+              rsum[2 * e + 1] += r1;
             }
           }
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += rs[r];
+          for (int r = 0; r < 8; ++r) v[r] += rsum[r];
         }
         act_apply_n(v, p.act, p.slope);
         if (p.cout < p.cout_s) {
@@ -259,22 +303,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
           for (int r = 0; r < 8; ++r)
             if (ch + r >= p.cout) v[r] = 0.f;
         }
-        u32x4 comp[NC];
+        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NSB + ch;
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
+        for (int k = 0; k < NCC; ++k) {
+          u32x4 comp;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            comp[k][e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+            comp[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
             float q0, q1;
-            unpack2<T>(comp[k][e], q0, q1);
+            unpack2<T>(comp[e], q0, q1);
             v[2 * e] -= q0;
             v[2 * e + 1] -= q1;
           }
+          if (pix < npix && ch_ok) *reinterpret_cast<u32x4*>(yp + k * p.cout_s) = comp;
         }
-        uint16_t* yp = p.y + (size_t)pix * p.cout_s * NS + ch;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      return;
+    }
+    if (pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);        // the bias
 #pragma unroll
-        for (int b = 0; b < NS; ++b) *reinterpret_cast<u32x4*>(yp + b * p.cout_s) = comp[b];
-        continue;
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = it * PSTEP + pl0;
+      const int pix = pix_base + pl;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + pl * ROWB + qc * 32 + 16);
+      if (pix >= npix || !ch_ok) continue;
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] += bb0[r];
+          v[4 + r] += bb1[r];
+        }
       }
       act_apply_n(v, p.act, p.slope);
       if (p.cout < p.cout_s) {
@@ -296,7 +357,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
       *reinterpret_cast<u32x4*>(p.y + opix * p.cout_s + ch) = o;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  };
+  ext_static_for<0, WP / PP>(do_pass);
 }
 
 // sum of the K slices (in slice order: deterministic) + the plain kernel's epilogue, one thread per (pixel, 8-channel chunk)
