@@ -25,8 +25,12 @@ constexpr int MAX_NCT = 5;
 CGAN_KNOB(int, g_lds_nct, 0);       // development knob (cgan_debug_set_conv3x3_nct): force the channel tiles per workgroup
 CGAN_KNOB(int, g_c4_enabled, 1);    // development knob (cgan_debug_set_conv3x3_c4): 0 = never the folded-tap kernel
 
-// [halo pixel q][4 slots of 16 B]: logical slot s of pixel q lives at slot position s ^ ((q >> 2) & 3)
-__device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 2) & 3)) << 4); }
+// [halo pixel q][4 slots of 16 B]: logical slot s of pixel q lives at slot position s ^ ((q >> 1) & 3).  A B-fragment
+// ds_read_b128 -- lane (j, g) reads slot g of pixel base + j -- is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11,
+// 16-19, 28-31} (+ 32): with bits 1..2 of q every group covers the 64 banks once, for every base (round 6; rounds 1-5 used
+// bits 2..3, conflict-free only for 16 CONSECUTIVE lanes: 8 LDS cycles per read instead of 4 for 14 of 16 bases, the
+// family's SQ_LDS_BANK_CONFLICT at 0.66 of its LDS-active cycles)
+__device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 1) & 3)) << 4); }
 
 // 16-byte-aligned zeros in device memory: the source of every out-of-image / pad-channel DMA lane
 __device__ __attribute__((aligned(16))) unsigned int g_zeros[64];
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_lds_kernel(Conv3x3LdsAr
     for (int i = wave; i < XDMA; i += WAVES) {
       const int idx = i * 64 + lane;                // LDS position: pixel idx/4, slot position idx%4
       const int pix = idx >> 2, spos = idx & 3;
-      const int slot = spos ^ ((pix >> 2) & 3);     // logical 8-channel group that belongs at this position
+      const int slot = spos ^ ((pix >> 1) & 3);     // logical 8-channel group that belongs at this position
       const int py = pix / HPW, px = pix - py * HPW;
       int yy = ty0 - p.pad + py, xx = tx0 - p.pad + px;
       halo_coord(p, yy, xx);
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void conv3x3_lds_onechunk_kernel(Con
   for (int i = wave; i < XDMA; i += WAVES) {
     const int idx = i * 64 + lane;
     const int pix = idx >> 2, spos = idx & 3;
-    const int slot = spos ^ ((pix >> 2) & 3);
+    const int slot = spos ^ ((pix >> 1) & 3);
     const int py = pix / HPW, px = pix - py * HPW;
     int yy = ty0 - p.pad + py, xx = tx0 - p.pad + px;
     halo_coord(p, yy, xx);

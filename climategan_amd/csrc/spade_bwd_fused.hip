@@ -49,7 +49,7 @@ struct SpadeHidBwdArgs {
 
 __device__ __attribute__((aligned(16))) unsigned int g_sb_zeros[64];
 
-__device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 2) & 3)) << 4); }
+__device__ __forceinline__ int xq_addr(int q, int slot) { return q * 64 + ((slot ^ ((q >> 1) & 3)) << 4); }   // (bits 1..2: conv3x3_lds.hip)
 __device__ __forceinline__ int swz(int r) { return ((r & 3) << 1) | ((r >> 2) & 1); }
 
 // the 32 pixel rows q0 .. q0+31 of 16-channel tile `tile` of a [pixel][64 ch] slab (row q keeps 16-byte chunk c in slot
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void spade_hidden_bwd_kernel(SpadeHi
       for (int i = wave; i < XDMA; i += WAVES) {
         const int idx = i * 64 + lane;
         const int pix = idx >> 2, spos = idx & 3;
-        const int slot = spos ^ ((pix >> 2) & 3);
+        const int slot = spos ^ ((pix >> 1) & 3);
         const int py = pix / HPW, px = pix - py * HPW;
         const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
         const int ch = q * 32 + slot * 8;

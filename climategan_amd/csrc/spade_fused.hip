@@ -96,14 +96,15 @@ __host__ inline PackedLayout packed_layout(int cs, int cond_c) {
 }
 
 // hidden map in LDS: [buffer][halo pixel q][4 slots of 16 B = 32 channels]; the slot is XOR-swizzled with bits
-// 2..3 of q (four pixels share a 256-B bank row)
+// 1..2 of q (round 6: conflict-free for ds_read_b128's lane groups at every base, see conv3x3_lds.hip's xq_addr; bits 2..3
+// were a 2-way conflict on most reads)
 // SWZ = false (the wave-specialised kernel): plain [pixel][slot] order.  A B-fragment address is then one per-lane
 // constant plus compile-time / wave-uniform offsets -- the swizzled form needs a separate address register per (row, dx),
 // which the compiler hoists out of the K loop: 18+ long-lived VGPRs that the 128-register consumers do not have.  Cost: a
 // 2-way bank conflict on every B-fragment read (6 of the 21 reads of a stage; measured irrelevant next to 60 MFMAs).
 template <bool SWZ>
 __device__ __forceinline__ int actv_addr(int q, int slot) {
-  return q * (QC * 2) + ((SWZ ? (slot ^ ((q >> 2) & 3)) : slot) << 4);
+  return q * (QC * 2) + ((SWZ ? (slot ^ ((q >> 1) & 3)) : slot) << 4);
 }
 
 #define TS(i)                                                                                          \
