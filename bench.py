@@ -377,6 +377,17 @@ def install_conv_gemm_timer(timer):
                                  tag(d, "bwd_data*"))
         return bwd_relu(dy, w, relu_out, dx, dref, stream)
 
+    bwd_add_relu = lib.cgan_conv2d_nhwc_bwd_data_add_relu
+
+    def timed_bwd_add_relu(dy, w, dx_add, relu_out, dx, dref, stream):   # both: the added tensor AND the activation's output
+        if timer.enabled and kind(dref, 1, stream) == GEMM:
+            d = dref._obj
+            extra = 4 * d.n * d.h_in * d.w_in * cs8(d.c_in)
+            return timer.bracket(lambda: bwd_add_relu(dy, w, dx_add, relu_out, dx, dref, stream),
+                                 2.0 * d.n * d.h_in * d.w_in * d.c_in * d.c_out * d.kh * d.kw, alg_bytes(d) + extra,
+                                 tag(d, "bwd_data+*"))
+        return bwd_add_relu(dy, w, dx_add, relu_out, dx, dref, stream)
+
     fwd_stats = lib.cgan_conv2d_nhwc_fwd_stats
 
     def timed_fwd_stats(x, w, b, y, partial, nbytes, dref, stream):     # forward + BatchNorm statistics epilogue: GEMM kernel only
@@ -389,11 +400,13 @@ def install_conv_gemm_timer(timer):
     lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = timed_fwd, timed_bwd, timed_bwd_add
     lib.cgan_conv2d_nhwc_fwd_stats = timed_fwd_stats
     lib.cgan_conv2d_nhwc_bwd_data_relu = timed_bwd_relu
+    lib.cgan_conv2d_nhwc_bwd_data_add_relu = timed_bwd_add_relu
 
     def uninstall():
         lib.cgan_conv2d_nhwc_fwd, lib.cgan_conv2d_nhwc_bwd_data, lib.cgan_conv2d_nhwc_bwd_data_add = fwd, bwd, bwd_add
         lib.cgan_conv2d_nhwc_fwd_stats = fwd_stats
         lib.cgan_conv2d_nhwc_bwd_data_relu = bwd_relu
+        lib.cgan_conv2d_nhwc_bwd_data_add_relu = bwd_add_relu
     return uninstall
 
 
@@ -408,7 +421,7 @@ def install_all_mfma_timer(timer):
     lib = _lib.load()
     names = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add", "cgan_conv2d_nhwc_fwd_stats",
              "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd", "cgan_spade_fused_fwd_train",
-             "cgan_conv2d_nhwc_bwd_data_relu", "cgan_spade_hidden_bwd")
+             "cgan_conv2d_nhwc_bwd_data_relu", "cgan_spade_hidden_bwd", "cgan_conv2d_nhwc_bwd_data_add_relu")
     orig = {n: getattr(lib, n) for n in names}
     kind = lib.cgan_conv2d_kernel_kind_on
     KIND = {0: "general", 1: "lds3x3", 2: "gemm"}
@@ -484,7 +497,12 @@ def install_all_mfma_timer(timer):
         return timer.bracket(lambda: orig[names[8]](dgb, wdg, cond, wsh, bsh, dw, db, ws, ws_bytes, dref, stream), fl, int(nb),
                              "%-7s %-9s n%d %dx%d c%d" % ("spadebw", "hidden", d.n, d.h, d.w, d.c))
 
-    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train, bwd_relu, spade_hid_bwd)):
+    def bwd_add_relu(dy, w, dx_add, relu_out, dx, dref, stream):
+        d = dref._obj
+        return timer.bracket(lambda: orig[names[9]](dy, w, dx_add, relu_out, dx, dref, stream), conv_flops(d),
+                             conv_bytes(d, 4 * d.n * d.h_in * d.w_in * cs8(d.c_in)), tag(d, KIND[kind(dref, 1, stream)], "bwd_data+*"))
+
+    for n, f in zip(names, (fwd, bwd, bwd_add, fwd_stats, wgrad, spade, spade_train, bwd_relu, spade_hid_bwd, bwd_add_relu)):
         setattr(lib, n, f)
 
     def uninstall():
@@ -1116,7 +1134,7 @@ def main():
             log, _cl.CALL_LOG = _cl.CALL_LOG, None
             mfma_entries = ("cgan_conv2d_nhwc_fwd", "cgan_conv2d_nhwc_bwd_data", "cgan_conv2d_nhwc_bwd_data_add",
                             "cgan_conv2d_nhwc_fwd_stats", "cgan_conv2d_nhwc_bwd_weight", "cgan_spade_fused_fwd",
-                            "cgan_spade_fused_fwd_train", "cgan_conv2d_nhwc_bwd_data_relu")
+                            "cgan_spade_fused_fwd_train", "cgan_conv2d_nhwc_bwd_data_relu", "cgan_conv2d_nhwc_bwd_data_add_relu")
             with open(args.call_log, "w") as f:
                 for _e0, _e1, _fl, nb, tg in all_timer.pairs[n0:]:
                     f.write("mfma:%s\t%d\t%s\t%.1f\n" % (tg.split()[0], nb, " ".join(tg.split()), _e0.elapsed_time(_e1) * 1e3))

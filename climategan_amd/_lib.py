@@ -175,6 +175,7 @@ _SIGNATURES = {
     "cgan_avgpool3x3s2_bwd_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_maxpool2x2_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_maxpool2x2_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cgan_maxpool2x2_relu_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cgan_softmax_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "cgan_softmax_bwd_nhwc": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P]),
     "cgan_sigmoid_pair_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),

@@ -160,6 +160,8 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x_t, weight, bias, res_t, packed, cfg, sn):
         x = ops.NHWC(x_t, cfg["c_in"])
         res = ops.NHWC(res_t, weight.shape[0]) if res_t is not None else None
+        if cfg.get("mask_input") and (cfg.get("in_upsample", False) or cfg.get("pair_in", False)):
+            raise NotImplementedError("ConvFn: mask_input with a folded upsample / a pair map")
         if cfg.get("want_stats") and res is None and cfg["act"] == ops.ACT_NONE and not cfg.get("in_upsample", False):
             # a BatchNorm follows: its statistics come out of this kernel's epilogue (handed over through cfg: the
             # partials are no tensor of the graph)
@@ -174,6 +176,7 @@ class ConvFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = res_t is not None
+        ctx.premasked = False            # see claim_relu_mask: dy arrives with this conv's ReLU derivative applied
         # (sigma, u, v) as used in this forward: private copies (the batched step hands them over already copied)
         ctx.sn = None if sn is None else (tuple(sn) if cfg.get("sn_owned") else tuple(t.clone() for t in sn))
         ctx.dgrad = None
@@ -191,7 +194,7 @@ class ConvFn(torch.autograd.Function):
         c_out = weight.shape[0]
         ups = cfg.get("in_upsample", False)
         dy = ops.NHWC(dy_t.contiguous(), c_out)
-        if y_t is not None:
+        if y_t is not None and not ctx.premasked:
             dy = ops.act_bwd(ops.NHWC(y_t, c_out), dy, cfg["act"], cfg["slope"])
         sigma = ctx.sn[0] if ctx.sn is not None else None
         dx_t = dres_t = None
@@ -199,9 +202,11 @@ class ConvFn(torch.autograd.Function):
         w_eff = torch.cat([weight.detach(), weight.detach()], 1) if pair else weight
         if ctx.needs_input_grad[0]:
             h_in, w_in = (x_t.shape[1] * 2, x_t.shape[2] * 2) if ups else (x_t.shape[1], x_t.shape[2])
+            # ``mask_input`` (claim_relu_mask): x is a ReLU's output read by nothing else -- its derivative rides in the epilogue
+            relu_out = ops.NHWC(x_t, cfg["c_in"]) if cfg.get("mask_input") else None
             dx = ops.conv2d_bwd_data(dy, w_eff, (x_t.shape[0], h_in, w_in), stride=cfg["stride"], pad=cfg["pad"],
                                      dilation=cfg["dilation"], sigma=sigma, pad_mode=cfg.get("pad_mode", ops.PAD_ZERO),
-                                     prepacked=ctx.dgrad)
+                                     prepacked=ctx.dgrad, relu_out=relu_out)
             dx_t = (ops.sumpool2x2(dx) if ups else dx).t
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres_t = (ops.sumpool2x2(dy) if cfg.get("residual_upsample", False) else dy).t
@@ -441,16 +446,19 @@ class AvgPool3x3s2Fn(torch.autograd.Function):
 
 
 class MaxPool2x2Fn(torch.autograd.Function):
+    """``mask_input`` (claim_relu_mask): x is a ReLU's output read by nothing else; the backward also takes that ReLU's derivative."""
+
     @staticmethod
-    def forward(ctx, x_t, c):
+    def forward(ctx, x_t, c, mask_input=False):
         ctx.c = c
+        ctx.mask_input = bool(mask_input)
         ctx.save_for_backward(x_t)
         return ops.maxpool2x2(ops.NHWC(x_t, c)).t
 
     @staticmethod
     def backward(ctx, dy_t):
         (x_t,) = ctx.saved_tensors
-        return ops.maxpool2x2_bwd(ops.NHWC(x_t, ctx.c), ops.NHWC(dy_t.contiguous(), ctx.c)).t, None
+        return ops.maxpool2x2_bwd(ops.NHWC(x_t, ctx.c), ops.NHWC(dy_t.contiguous(), ctx.c), relu_input=ctx.mask_input).t, None, None
 
 
 _BN_BWD_READS_OUT = os.environ.get("CGAN_BN_BWD_OUT") == "1"     # same-box A/B switch (tools/gpu_ab_env.sh): the old passes
@@ -527,14 +535,20 @@ class BatchNormActFn(torch.autograd.Function):
 
 def claim_relu_mask(out_t: torch.Tensor) -> bool:
     """Called by the ONE consumer of ``out_t`` (a bottleneck's first conv, which also hands the tensor through to its block's
-    skip branch: ConvPassFn) before the backward pass: if ``out_t`` is the output of a training-mode BatchNorm + residual +
-    ReLU node, that node will receive its gradient with the ReLU's derivative already applied (the consumer's data-gradient
+    skip branch: ConvPassFn; the next conv or max-pool of the VGG-19 chain) before the backward pass: if ``out_t`` is the output
+    of a training-mode BatchNorm + residual + ReLU node, or of a conv with a fused ReLU, that node will receive its gradient with the ReLU's derivative already applied (the consumer's data-gradient
     kernel takes it in its epilogue, ``cfg["mask_input"]``) and skips its own mask.  Returns whether the claim holds; the
     caller vouches that nothing else reads ``out_t`` in the graph -- a second consumer's gradient would arrive unmasked."""
     fn = out_t.grad_fn
-    if fn is None or not isinstance(fn, BatchNormActFn._backward_cls):
+    if fn is None:
         return False
-    if not fn.has_res or fn.cfg[1] != ops.ACT_RELU:
+    if isinstance(fn, BatchNormActFn._backward_cls):
+        if not fn.has_res or fn.cfg[1] != ops.ACT_RELU:
+            return False
+    elif isinstance(fn, ConvFn._backward_cls):          # conv + bias + ReLU in one kernel (VGG-19: losses.Vgg19)
+        if fn.cfg["act"] != ops.ACT_RELU:
+            return False
+    else:
         return False
     fn.premasked = True
     return True

@@ -216,7 +216,9 @@ __global__ void maxpool2x2_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* 
   }
 }
 
-template <typename T>
+// RELU: x is itself the output of a ReLU whose derivative is taken here as well (cgan_maxpool2x2_relu_bwd_nhwc): the routed
+// gradient survives only where the window's maximum is positive -- what a separate activation-backward pass over dx would leave
+template <typename T, bool RELU>
 __global__ void maxpool2x2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                       uint16_t* __restrict__ dx, int h_in, int w_in, int h_out, int w_out, int cs,
                                       long total) {
@@ -248,7 +250,7 @@ __global__ void maxpool2x2_bwd_kernel(const uint16_t* __restrict__ x, const uint
 #pragma unroll
       for (int k = 1; k < 4; ++k)
         if (v[k][e] > best) { best = v[k][e]; a = k; }
-      arg[e] = a;
+      arg[e] = (RELU && !(best > 0.f)) ? -1 : a;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -519,8 +521,8 @@ extern "C" int cgan_maxpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32
   return CGAN_OK;
 }
 
-extern "C" int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c,
-                                        int32_t h_in, int32_t w_in, void* stream) {
+static int maxpool2x2_bwd_impl(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                               int32_t w_in, void* stream, bool relu) {
   CGAN_REQUIRE(x && dy && dx, "maxpool2x2_bwd: null pointer");
   CGAN_REQUIRE(dtype == CGAN_F16 || dtype == CGAN_BF16, "maxpool2x2_bwd: bad dtype %d", dtype);
   CGAN_REQUIRE(n > 0 && c > 0 && h_in > 1 && w_in > 1, "maxpool2x2_bwd: bad shape");
@@ -534,10 +536,24 @@ extern "C" int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx,
     }
   }
   const long total = (long)n * h_out * w_out * (cs / 8);
-  DISPATCH_PT(dtype, maxpool2x2_bwd_kernel, dim3(grid_pt(total)), dim3(256), 0, s, (const uint16_t*)x,
-              (const uint16_t*)dy, (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, total);
+#define MP_BWD(TT, RR)                                                                                                     \
+  hipLaunchKernelGGL((maxpool2x2_bwd_kernel<TT, RR>), dim3(grid_pt(total)), dim3(256), 0, s, (const uint16_t*)x,         \
+                     (const uint16_t*)dy, (uint16_t*)dx, h_in, w_in, h_out, w_out, cs, total)
+  if (dtype == CGAN_F16) { if (relu) MP_BWD(F16, true); else MP_BWD(F16, false); }
+  else { if (relu) MP_BWD(BF16, true); else MP_BWD(BF16, false); }
+#undef MP_BWD
   CGAN_CHECK_LAUNCH("maxpool2x2_bwd");
   return CGAN_OK;
+}
+
+extern "C" int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c,
+                                        int32_t h_in, int32_t w_in, void* stream) {
+  return maxpool2x2_bwd_impl(x, dy, dx, dtype, n, c, h_in, w_in, stream, false);
+}
+
+extern "C" int cgan_maxpool2x2_relu_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c,
+                                             int32_t h_in, int32_t w_in, void* stream) {
+  return maxpool2x2_bwd_impl(x, dy, dx, dtype, n, c, h_in, w_in, stream, true);
 }
 
 extern "C" size_t cgan_resize_bilinear_bwd_workspace_bytes(int32_t n, int32_t c, int32_t h_in, int32_t w_in) {

@@ -12,6 +12,7 @@ import torch.nn as nn
 from . import ops
 from . import autograd as ag
 from .autograd import BceLogitsFn, ConvFn, HingeFn, L1Fn, MaxPool2x2Fn
+from . import norms as _norms
 from .norms import _PackCache
 
 
@@ -124,6 +125,9 @@ class FeatMatchLoss(nn.Module):
         return total
 
 
+_VGG_MASK = __import__("os").environ.get("CGAN_FUSE_VGG_MASK", "1") != "0"     # same-box A/B of the VGG chain's part of norms.FUSE_RELU_MASK
+
+
 class Vgg19(nn.Module):
     """reference losses.py:304-334: torchvision VGG19 ``features[0:30]`` in five slices ending at relu1_1 ... relu5_1,
     same child names (``slice1.0``, ``slice2.2``, ``slice2.5`` ...) so a torchvision state dict maps onto it.  The
@@ -158,12 +162,18 @@ class Vgg19(nn.Module):
         returns [relu1_1, relu2_1, relu3_1, relu4_1, relu5_1]."""
         outs = []
         y = X
+        tapped = True        # y is also read by someone else (the input; a slice's result = a tap of the loss)
         for k in range(5):
             seq = getattr(self, "slice%d" % (k + 1))
             mods = list(seq.named_children())
             j = 0
             while j < len(mods):
                 name, mod = mods[j]
+                # y = relu(conv(.)) read by THIS layer only: the ReLU's derivative moves into this layer's backward
+                # (autograd.claim_relu_mask; norms.FUSE_RELU_MASK = False: the separate pass)
+                claim = ((not tapped) and _norms.FUSE_RELU_MASK and _VGG_MASK and torch.is_grad_enabled() and y.t.requires_grad
+                         and ag.claim_relu_mask(y.t))
+                tapped = False
                 if isinstance(mod, nn.Conv2d):                      # conv + the ReLU that follows it, fused
                     cache = self._caches.setdefault(name, _PackCache())
                     weight = mod.weight
@@ -180,18 +190,19 @@ class Vgg19(nn.Module):
                                    lambda weight=weight, mod=mod: ops.pack_conv_weight(weight.data, mod.bias.data,
                                                                                        y.t.dtype))
                     if torch.is_grad_enabled() and (y.t.requires_grad or mod.weight.requires_grad):
-                        cfg = dict(c_in=y.c, stride=1, pad=1, dilation=1, act=ops.ACT_RELU, slope=0.0)
+                        cfg = dict(c_in=y.c, stride=1, pad=1, dilation=1, act=ops.ACT_RELU, slope=0.0, mask_input=claim)
                         y = ops.NHWC(ConvFn.apply(y.t, weight, mod.bias, None, pw, cfg, None), mod.out_channels)
                     else:
                         y = ops.conv2d(y, pw, pad=1, act=ops.ACT_RELU)
                     j += 2
                 else:                                                # max pool
                     if torch.is_grad_enabled() and y.t.requires_grad:
-                        y = ops.NHWC(MaxPool2x2Fn.apply(y.t, y.c), y.c)
+                        y = ops.NHWC(MaxPool2x2Fn.apply(y.t, y.c, claim), y.c)
                     else:
                         y = ops.maxpool2x2(y)
                     j += 1
             outs.append(y)
+            tapped = True
         return outs
 
 

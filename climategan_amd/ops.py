@@ -1544,12 +1544,17 @@ def maxpool2x2(x: NHWC) -> NHWC:
 
 
 @_batch_chunked("x", "dy")
-def maxpool2x2_bwd(x: NHWC, dy: NHWC) -> NHWC:
+def maxpool2x2_bwd(x: NHWC, dy: NHWC, relu_input=False) -> NHWC:
+    """``relu_input``: x is a ReLU's output whose derivative is taken here too (dx * [x > 0], cgan_maxpool2x2_relu_bwd_nhwc)."""
     _need_cuda(x.t, dy.t)
     dx = _empty_like(x.t)
     lib = _lib.load()
-    _lib.check(lib.cgan_maxpool2x2_bwd_nhwc(_ptr(x.t), _ptr(dy.t), _ptr(dx), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
-               "cgan_maxpool2x2_bwd_nhwc")
+    if relu_input:
+        _lib.check(lib.cgan_maxpool2x2_relu_bwd_nhwc(_ptr(x.t), _ptr(dy.t), _ptr(dx), x.dtype_id, x.n, x.c, x.h, x.w,
+                                                     _stream()), "cgan_maxpool2x2_relu_bwd_nhwc")
+    else:
+        _lib.check(lib.cgan_maxpool2x2_bwd_nhwc(_ptr(x.t), _ptr(dy.t), _ptr(dx), x.dtype_id, x.n, x.c, x.h, x.w, _stream()),
+                   "cgan_maxpool2x2_bwd_nhwc")
     return NHWC(dx, x.c)
 
 

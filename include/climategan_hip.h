@@ -468,6 +468,10 @@ int cgan_maxpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t n, int32
                          void* stream);
 int cgan_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
                              int32_t w_in, void* stream);
+/* the same times [x > 0]: x is the output of a ReLU (VGG-19's conv + ReLU in front of every pool, losses.py:304-334) whose
+ * derivative is taken here instead of by cgan_act_bwd over dx -- bit-identical to the two calls (round 6) */
+int cgan_maxpool2x2_relu_bwd_nhwc(const void* x, const void* dy, void* dx, int32_t dtype, int32_t n, int32_t c, int32_t h_in,
+                                  int32_t w_in, void* stream);
 
 /* Masker-side losses (climategan/losses.py:106-196, 444-524) on the decoders' NHWC maps; same accumulate-into-a-
  * device-scalar convention as above (weight carries 1/N and the lambdas).

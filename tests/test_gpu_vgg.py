@@ -88,3 +88,23 @@ def test_vgg_input_pair_is_exact():
         # lo is itself rounded to 16 bit: 2^-8 (bf16) of a remainder that is at most 2^-8 of 151
         assert (got - ref).abs().max().item() <= 151 * (2.0 ** -16 if dt == torch.bfloat16 else 2.0 ** -21) + 2e-5
         assert (v.t[..., 6:] == 0).all()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_relu_derivatives_in_the_consumers_backward_are_bitwise_the_separate_pass(dt):
+    """norms.FUSE_RELU_MASK in the VGG chain: the derivative of a conv's fused ReLU is taken by the ONE layer that reads its
+    output -- the next conv's data-gradient epilogue or the max-pool's backward (cgan_maxpool2x2_relu_bwd_nhwc) -- instead of
+    by an activation-backward pass; the five taps (read by the loss as well) keep theirs.  Same gradient, bit for bit."""
+    from climategan_amd import norms
+
+    _run(dt)     # (settles the stream's split-K workspace binding: a first call after other tests may run a small conv on another kernel)
+    res = {}
+    for fuse in (True, False):
+        norms.FUSE_RELU_MASK = fuse
+        try:
+            res[fuse] = _run(dt)
+        finally:
+            norms.FUSE_RELU_MASK = True
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])     # (the loss scalar's own reduction: atomics, last-bit noise)
+    assert torch.equal(res[True][1], res[False][1])
+    assert res[True][1].abs().max().item() > 0
