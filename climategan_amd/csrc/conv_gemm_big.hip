@@ -41,7 +41,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_big_zeros[4];   // what t
 // residual / activation in fp32 and stores the components (as conv_gemm_ext_kernel's pair epilogue does).
 template <typename T, int NW, bool PAIR = false, bool RES2 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemmArgs p, int npb, int ncb) {
-  constexpr int WC = 8;                       // cout tiles per wave (128 couts)
+  constexpr int WC = NW == 16 ? 4 : 8;        // cout tiles per wave (128 couts; sixteen waves: 64)
   constexpr int WP = NW == 4 ? 8 : 4;         // pixel tiles per wave (128 / 64 pixels)
   constexpr bool DOUBLE = NW == 4;            // second fragment register set (512 registers per lane with one wave per SIMD)
   constexpr int CT_BLK = 16, PT_BLK = 16;     // 256 x 256
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   };
 
   // ------------------------------------------------------------------------------------------------ consumer side
-  const int wc = wave & 1, wp = wave >> 1;
+  constexpr int NWC = CT_BLK / WC;            // wave grid: NWC cout groups x NW / NWC pixel groups
+  const int wc = wave % NWC, wp = wave / NWC;
   const int j16 = lane & 15, g = lane >> 4;
   f32x4 acc[WC][WP];
 #pragma unroll
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_gemm_big_kernel(ConvGemm
   const float* bias_ep = p.bias;       // the bias the store path still has to add
   // training-mode BatchNorm statistics of this wave's WP x 16 pixels (one chunk; whole or absent, as in conv_gemm_kernel)
   if (p.stats && (pblk * PT_BLK + wp * WP) * 16 < p.npix) {
-    conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * (NW / 2) + wp, j16, g);
+    conv_gemm_stats_epilogue<T, WC, WP>(acc, p, cout_base, pblk * (PT_BLK / WP) + wp, j16, g);
     if (p.bias) bias_ep = nullptr;
   }
   if constexpr (!PAIR) {     // the store path shared with conv_gemm_kernel: every global read in front of the first store
@@ -405,7 +406,14 @@ bool conv_gemm_big_ok(const ConvGemmArgs& a) {
 // four-wave form (one per SIMD, 128 x 128 per wave: 256 accumulator registers + a second fragment set) is kept in the
 // template but not instantiated: hipcc (ROCm 7.2) cannot keep a 256-register accumulator in place -- it rotates tiles
 // through a[0:3] with v_accvgpr_write / _read pairs around every MFMA (445 of them for 256 MFMAs in the loop body).
+// development knob (cgan_debug_set_big_waves): 16 = the sixteen-wave form (4 x 4 waves of 64 couts x 64 pixels, four per SIMD at
+// <= 128 registers: twice the waves to cover a wave's fragment reads and DMA issue, twice the fragment reads per MFMA)
+CGAN_KNOB(int, g_big_waves, 8);
+CGAN_DEV_ONLY(extern "C" void cgan_debug_set_big_waves(int v) { g_big_waves = v; })
+
 int conv_gemm_big_launch(const ConvGemmArgs& a, int dtype, hipStream_t s) {
+  if (g_big_waves == 16 && a.has_res != 3)
+    return dtype == CGAN_F16 ? launch_big<F16, 16>(a, s) : launch_big<BF16, 16>(a, s);
   if (a.has_res == 3)      // the instantiation with the second epilogue map (two launches per train step: layer4's bottlenecks)
     return dtype == CGAN_F16 ? launch_big<F16, 8, false, true>(a, s) : launch_big<BF16, 8, false, true>(a, s);
   return dtype == CGAN_F16 ? launch_big<F16, 8>(a, s) : launch_big<BF16, 8>(a, s);

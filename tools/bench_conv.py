@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--hw", type=int, default=0, help="override the input extent of every shape")
     ap.add_argument("--res", action="store_true", help="add a residual input (bottleneck expand)")
     ap.add_argument("--nct", type=int, default=0, help="cgan_debug_set_conv3x3_nct: channel tiles per workgroup of the 3x3 LDS kernel")
+    ap.add_argument("--bigw", type=int, default=8, help="cgan_debug_set_big_waves: 16 = the sixteen-wave form of the 256 x 256 kernel")
     ap.add_argument("--c4", type=int, default=1, help="cgan_debug_set_conv3x3_c4: 0 no folded-tap kernel, 1 default, 2 all 128 couts per workgroup")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -64,6 +65,8 @@ def main():
     lib.cgan_debug_set_gemm_ws(ctypes.c_int(args.ws))
     lib.cgan_debug_set_conv3x3_c4(ctypes.c_int(args.c4))
     lib.cgan_debug_set_conv3x3_nct(ctypes.c_int(args.nct))
+    if hasattr(lib, "cgan_debug_set_big_waves"):
+        lib.cgan_debug_set_big_waves(ctypes.c_int(args.bigw))
     for name, cin, cout, k, stride, pad, dil, H in SHAPES:
         if args.only not in name:
             continue
