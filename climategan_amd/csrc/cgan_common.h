@@ -62,6 +62,20 @@ __device__ __forceinline__ float cgan_res_apply3(float v, float r, float m) { re
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// streaming accesses
+// ------------------------------------------------------------------------------------------------
+// The element-wise / normalisation passes touch every byte of a map once per launch and the maps of the train step are far
+// larger than L2 and the memory-side cache: their loads and stores carry the non-temporal hint (global_load / _store ... nt),
+// round 6, last session.  CGAN_NO_NT (build flag): plain accesses (same-box A/B).
+#ifndef CGAN_NO_NT
+#define CGAN_LD_STREAM(p) __builtin_nontemporal_load(p)
+#define CGAN_ST_STREAM(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define CGAN_LD_STREAM(p) (*(p))
+#define CGAN_ST_STREAM(v, p) (*(p) = (v))
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // 16-bit element types and MFMA wrappers
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

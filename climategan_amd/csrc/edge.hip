@@ -423,8 +423,8 @@ template <typename T>
 __global__ void eltwise_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
                                int op, long total_groups) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_groups; idx += (long)gridDim.x * blockDim.x) {
-    u32x4 va = reinterpret_cast<const u32x4*>(a)[idx];
-    u32x4 vb = op == 0 ? reinterpret_cast<const u32x4*>(b)[idx] : va;
+    u32x4 va = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(a) + idx);
+    u32x4 vb = op == 0 ? CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(b) + idx) : va;
     const float sc = op == 2 ? reinterpret_cast<const float*>(b)[0] : 1.f;   // op 2: b is a device fp32 scalar
     u32x4 o;
 #pragma unroll
@@ -436,7 +436,7 @@ __global__ void eltwise_kernel(const uint16_t* __restrict__ a, const uint16_t* _
       float r1 = op == 0 ? a1 * b1 : (op == 2 ? a1 * sc : 1.f / (1.f + __expf(-a1)));
       o[e] = pack2<T>(r0, r1);
     }
-    reinterpret_cast<u32x4*>(y)[idx] = o;
+    CGAN_ST_STREAM(o, reinterpret_cast<u32x4*>(y) + idx);
   }
 }
 

@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __r
 #pragma unroll 2
       for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
         const size_t off = (size_t)p * cs + cg * 8;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(xn + off);
+        const u32x4 v = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(xn + off));
         u32x4 rv = {0u, 0u, 0u, 0u};
-        if (RES) rv = *reinterpret_cast<const u32x4*>(rn + off);
+        if (RES) rv = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(rn + off));
         float f[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(const uint16_t* __r
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack2<T>(f[2 * e], f[2 * e + 1]);
-        *reinterpret_cast<u32x4*>(yn + off) = o;
+        CGAN_ST_STREAM(o, reinterpret_cast<u32x4*>(yn + off));
       }
     };
     if (rn) body(std::true_type{});

@@ -25,8 +25,8 @@ template <typename T>
 __global__ void act_bwd_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dy,
                                uint16_t* __restrict__ dx, int act, float slope, long groups) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
-    const u32x4 g = reinterpret_cast<const u32x4*>(dy)[i];
+    const u32x4 o = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(out) + i);
+    const u32x4 g = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(dy) + i);
     u32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -35,7 +35,7 @@ __global__ void act_bwd_kernel(const uint16_t* __restrict__ out, const uint16_t*
       unpack2<T>(g[e], g0, g1);
       r[e] = pack2<T>(g0 * act_grad_from_out(o0, act, slope), g1 * act_grad_from_out(o1, act, slope));
     }
-    reinterpret_cast<u32x4*>(dx)[i] = r;
+    CGAN_ST_STREAM(r, reinterpret_cast<u32x4*>(dx) + i);
   }
 }
 
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const uint16_t* __re
     const size_t base = (size_t)n * hw * cs + cg * 8;
 #pragma unroll 4
     for (int p = p0 + pl; p < p1; p += PL) {
-      const u32x4 o = *reinterpret_cast<const u32x4*>(out + base + (size_t)p * cs);
-      const u32x4 g = *reinterpret_cast<const u32x4*>(dy + base + (size_t)p * cs);
+      const u32x4 o = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(out + base + (size_t)p * cs));
+      const u32x4 g = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(dy + base + (size_t)p * cs));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float o0, o1, g0, g1, dz, y;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const uint16_t* __res
 #pragma unroll 2
     for (int p = blockIdx.x * rows + prow; p < hw; p += gridDim.x * rows) {
       const size_t off = (size_t)p * cs + cg * 8;
-      const u32x4 o = *reinterpret_cast<const u32x4*>(out + off);
-      const u32x4 g = *reinterpret_cast<const u32x4*>(dy + off);
+      const u32x4 o = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(out + off));
+      const u32x4 g = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(dy + off));
       u32x4 r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const uint16_t* __res
         }
         r[e] = pack2<T>(res[0], res[1]);
       }
-      *reinterpret_cast<u32x4*>(dx + off) = r;
+      CGAN_ST_STREAM(r, reinterpret_cast<u32x4*>(dx + off));
     }
   }
 }
@@ -235,9 +235,9 @@ __global__ void spade_bwd_prepare_kernel(const uint16_t* __restrict__ dy, const 
     const int n = (int)(r / (unsigned)h);
     const int oy = (int)(r - (unsigned)n * (unsigned)h);
     const long xoff = x_ups ? (((long)n * (h >> 1) + (oy >> 1)) * (w >> 1) + (ox >> 1)) * cs + cg * 8 : (long)i * 8;
-    const u32x4 vdy = reinterpret_cast<const u32x4*>(dy)[i];
-    const u32x4 vy = reinterpret_cast<const u32x4*>(y)[i];
-    const u32x4 vg = reinterpret_cast<const u32x4*>(gamma)[i];
+    const u32x4 vdy = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(dy) + i);
+    const u32x4 vy = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(y) + i);
+    const u32x4 vg = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(gamma) + i);
     const u32x4 vx = *reinterpret_cast<const u32x4*>(x + xoff);
     u32x4 oxh, odx, odg;
     float dbeta[8];
@@ -263,8 +263,8 @@ __global__ void spade_bwd_prepare_kernel(const uint16_t* __restrict__ dy, const 
       odx[e] = pack2<T>(rdx[0], rdx[1]);
       odg[e] = pack2<T>(rdg[0], rdg[1]);
     }
-    reinterpret_cast<u32x4*>(xhat)[i] = oxh;
-    reinterpret_cast<u32x4*>(dxhat)[i] = odx;
+    CGAN_ST_STREAM(oxh, reinterpret_cast<u32x4*>(xhat) + i);
+    CGAN_ST_STREAM(odx, reinterpret_cast<u32x4*>(dxhat) + i);
     uint16_t* row = dgb + pix * cs2;
     // d_gamma: channels cg*8 .. (8-aligned: one vector unless it would spill into the d_beta range)
     if (cg * 8 + 8 <= c) {
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
 #pragma unroll 2
     for (long p = p0 + pl; p < p1; p += PL) {
       const size_t off = (size_t)p * cs;
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(xp + off);
+      const u32x4 vx = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(xp + off));
       u32x4 vo = {0, 0, 0, 0};
-      if (MASK == 1) vo = *reinterpret_cast<const u32x4*>(op + off);
-      const u32x4 vg = *reinterpret_cast<const u32x4*>(gp + off);
+      if (MASK == 1) vo = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(op + off));
+      const u32x4 vg = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(gp + off));
       u32x4 z;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t* __re
       }
       // ReLU with a fused residual: dz = dy or 0 is exact in 16 bits -- written here (it is the residual branch's gradient),
       // the apply pass then reads (x, dz) instead of (x, out, dy) and writes dx only
-      if (MASK == 1 && dz_out) *reinterpret_cast<u32x4*>(dz_out + cg * 8 + off) = z;
+      if (MASK == 1 && dz_out) CGAN_ST_STREAM(z, reinterpret_cast<u32x4*>(dz_out + cg * 8 + off));
     }
   }
   if (pl < PL) {
@@ -534,10 +534,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
 #pragma unroll 2
     for (long p = (long)blockIdx.x * rows + prow; p < npix; p += (long)gridDim.x * rows) {
       const size_t off = (size_t)p * cs + cg * 8;
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(x + off);
+      const u32x4 vx = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(x + off));
       u32x4 vo = {0, 0, 0, 0};
-      if (MASK == 1) vo = *reinterpret_cast<const u32x4*>(out + off);
-      const u32x4 vg = *reinterpret_cast<const u32x4*>(dy + off);
+      if (MASK == 1) vo = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(out + off));
+      const u32x4 vg = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(dy + off));
       u32x4 r, z;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -554,8 +554,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t* __res
         r[e] = pack2<T>(res[0], res[1]);
         z[e] = pack2<T>(dzv[0], dzv[1]);
       }
-      *reinterpret_cast<u32x4*>(dx + off) = r;
-      if (dz_out) *reinterpret_cast<u32x4*>(dz_out + off) = z;   // the fused residual branch's gradient
+      CGAN_ST_STREAM(r, reinterpret_cast<u32x4*>(dx + off));
+      if (dz_out) CGAN_ST_STREAM(z, reinterpret_cast<u32x4*>(dz_out + off));   // the fused residual branch's gradient
     }
   }
 }
