@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_xres_kernel(ConvGemmArgs p, in
           const u32x4 o = *reinterpret_cast<const u32x4*>(stg + st_rd + it * 8 * ROWB);
           const int pix0 = pix_wave + t * 16 + it * 8;                   // wave-uniform: the store's SGPR offset
           if (FULL || (pix0 + (lane >> 3) < p.npix && cout_base + (lane & 7) * 8 < p.cout_s))
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, st_voff, (pix0 * p.cout_s + cout_base) * 2, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, st_voff, (pix0 * p.cout_s + cout_base) * 2, 2);   // aux 2 = nt (streamed: cgan_common.h)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staged rows are read before the next tile overwrites
         if (t == WP / 2 - 1 && cb + 1 < ncb) {

@@ -202,7 +202,7 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
     for (int it = 0; it < (RES2 ? NIT : 0); ++it) {
       const int pix = pix0 + pass * PP * 16 + it * PSTEP + pl0;
       dst[it] = (u32x4){0u, 0u, 0u, 0u};
-      if (pix < p.npix && ch_ok) dst[it] = *reinterpret_cast<const u32x4*>(p.res2 + (size_t)pix * p.cout_s + ch);
+      if (pix < p.npix && ch_ok) dst[it] = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(p.res2 + (size_t)pix * p.cout_s + ch));
     }
   };
   if (p.has_res) {                                            // wave-uniform
@@ -223,7 +223,7 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
           } else {
             rbase = (size_t)pix * p.cout_s;
           }
-          rv[pass][it] = *reinterpret_cast<const u32x4*>(p.res + rbase + ch);
+          rv[pass][it] = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(p.res + rbase + ch));
         }
       }
     if (RES2 && p.has_res == 3) load_rm(0, rm[0]);
@@ -289,7 +289,7 @@ __device__ __forceinline__ void conv_gemm_staged_store(const f32x4 (&acc)[WC][WP
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-      if (pix < p.npix && ch_ok) *reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch) = o;
+      if (pix < p.npix && ch_ok) CGAN_ST_STREAM(o, reinterpret_cast<u32x4*>(p.y + (size_t)pix * p.cout_s + ch));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // staged rows are consumed before the next pass overwrites
   }
