@@ -157,8 +157,8 @@ __device__ __forceinline__ void conv3x3_epilogue(const Conv3x3LdsArgs& p, f32x4 
     const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
     const int ch = ct0 * 16 + cc * 8;
     if (yy < p.h && xx < p.w_ && ch < p.cout_s)
-      *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s + ch) =
-          *reinterpret_cast<const u32x4*>(yt + id * 16);
+      CGAN_ST_STREAM(*reinterpret_cast<const u32x4*>(yt + id * 16),
+                     reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w_ + xx) * p.cout_s + ch));
   }
 }
 

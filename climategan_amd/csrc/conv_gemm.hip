@@ -453,10 +453,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_k64_kernel(ConvGemmArgs p, i
           v[r] = act_apply(v[r], p.act, p.slope);
           if (ch + r >= p.cout) v[r] = 0.f;
         }
-        uint2 o;
+        u32x2 o;
         o.x = pack2<T>(v[0], v[1]);
         o.y = pack2<T>(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p.y + (size_t)pix * p.cout_s + ch) = o;
+        CGAN_ST_STREAM(o, reinterpret_cast<u32x2*>(p.y + (size_t)pix * p.cout_s + ch));
       }
     }
   };

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_ext_kernel(ConvGemmExtArgs q
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-      *reinterpret_cast<u32x4*>(p.y + opix * p.cout_s + ch) = o;
+      CGAN_ST_STREAM(o, reinterpret_cast<u32x4*>(p.y + opix * p.cout_s + ch));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };

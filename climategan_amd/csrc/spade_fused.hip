@@ -652,8 +652,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? CGAN_SPADE_WPE : 2) void spade_f
       const int pix = id / NCT, cc = id - pix * NCT;
       const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
       if (id < NCT * 256 && yy < p.h && xx < p.w && cc < nchunk)
-        *reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w + xx) * p.cs + (nt0 + cc) * 8) =
-            *reinterpret_cast<const u32x4*>(xt + id * 16);
+        CGAN_ST_STREAM(*reinterpret_cast<const u32x4*>(xt + id * 16),
+                       reinterpret_cast<u32x4*>(p.y + (((size_t)n * p.h + yy) * p.w + xx) * p.cs + (nt0 + cc) * 8));
     }
     if (GM) {
       const unsigned char* gts = actv + ACTV_Q_BYTES;

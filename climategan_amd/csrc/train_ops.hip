@@ -679,8 +679,8 @@ __global__ __launch_bounds__(256) void l1_kernel(const uint16_t* __restrict__ a,
   float acc = 0.f;
 #pragma unroll 2
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const u32x4 va = reinterpret_cast<const u32x4*>(a)[i];
-    const u32x4 vb = reinterpret_cast<const u32x4*>(b)[i];
+    const u32x4 va = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(a) + i);
+    const u32x4 vb = CGAN_LD_STREAM(reinterpret_cast<const u32x4*>(b) + i);
     u32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const uint16_t* __restrict__ a,
       acc += fabsf(d0) + fabsf(d1);
       r[e] = pack2<T>(d0 > 0.f ? weight : (d0 < 0.f ? -weight : 0.f), d1 > 0.f ? weight : (d1 < 0.f ? -weight : 0.f));
     }
-    if (da) reinterpret_cast<u32x4*>(da)[i] = r;
+    if (da) CGAN_ST_STREAM(r, reinterpret_cast<u32x4*>(da) + i);
   }
   block_atomic_add(acc * weight, loss);
 }
