@@ -1106,7 +1106,15 @@ def main():
         step()
     count["i"] = 0
     timer.armed = not args.no_launch_events
+    ms0 = torch.cuda.memory_stats(device)
     elapsed = timed_steps(step, args.steps, 0, barrier)
+    ms1 = torch.cuda.memory_stats(device)
+    # what torch's caching allocator did INSIDE the timed region: a device malloc / free there is a synchronizing driver call
+    alloc_stats = {"device_mallocs_in_timed_steps": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                   "device_frees_in_timed_steps": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+                   "alloc_retries_in_timed_steps": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
+                   "reserved_GB": round(ms1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 1),
+                   "allocator_conf": os.environ.get("PYTORCH_HIP_ALLOC_CONF", os.environ.get("PYTORCH_CUDA_ALLOC_CONF", ""))}
     timer.armed = timer.enabled = False
     uninstall()
     elapsed = max_over_ranks(elapsed, dist, device)
@@ -1220,6 +1228,7 @@ def main():
         res["config"]["two_stream_overlap"] = bool(overlap_default)
         res["losses_last_step"] = {k: round(v, 4) for k, v in losses.items()}
         res["max_mem_GB"] = round(mem_gb, 1)
+        res["allocator"] = alloc_stats
         res["cpu_baseline"] = None
 
     # ---- the line is complete (minus cpu_baseline / sub-blocks) before anything else runs: a watchdog prints it and

@@ -226,11 +226,12 @@ class ConvFn(torch.autograd.Function):
 
 
 class ConvPassFn(torch.autograd.Function):
-    """(y, x) = (conv(x, w) + b, x): a plain conv (no activation, no residual) that also hands its input through.  A
-    consumer of the second output (the residual add at the end of a ResNet bottleneck) sends its gradient back through
+    """(y, x) = (act(conv(x, w) + b), x): a conv without a residual that also hands its input through.  A
+    consumer of the second output (the residual add at the end of a ResNet bottleneck; the L1 term of the VGG loss on a
+    tapped feature map, losses.Vgg19) sends its gradient back through
     THIS node, and the backward adds it in the data-gradient kernel's epilogue (``conv2d_bwd_data(add=...)``) -- instead
     of x collecting two gradients that the autograd engine sums with an element-wise pass of its own (33 such adds of
-    50-200 MB per train step)."""
+    50-200 MB per train step).  ``cfg["act"]`` (optional): the fused activation of the VGG chain's conv + ReLU pairs."""
 
     @staticmethod
     def forward(ctx, x_t, weight, bias, packed, cfg):
@@ -241,19 +242,25 @@ class ConvPassFn(torch.autograd.Function):
                                                         groups=BN_GROUPS)
         else:
             y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"],
+                           act=cfg.get("act", ops.ACT_NONE), slope=cfg.get("slope", 0.0),
                            pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
+        if cfg.get("want_stats") and cfg.get("act", ops.ACT_NONE) != ops.ACT_NONE:
+            raise NotImplementedError("ConvPassFn: the statistics epilogue belongs to a conv without an activation")
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.premasked = False            # see claim_relu_mask: dy arrives with this conv's ReLU derivative applied
         ctx.dgrad = ops.dgrad_register(weight, None, x_t.dtype, cfg["stride"]) if ctx.needs_input_grad[0] else None
-        ctx.save_for_backward(x_t, weight)
+        ctx.save_for_backward(x_t, weight, y.t if cfg.get("act", ops.ACT_NONE) != ops.ACT_NONE else None)
         return y.t, x_t                   # (returned as-is: autograd makes it an output of this node)
 
     @staticmethod
     def backward(ctx, dy_t, dpass_t):
         cfg = ctx.cfg
-        x_t, weight = ctx.saved_tensors
+        x_t, weight, y_t = ctx.saved_tensors
         c_out = weight.shape[0]
         dy = ops.NHWC(dy_t.contiguous(), c_out)
+        if y_t is not None and not ctx.premasked:
+            dy = ops.act_bwd(ops.NHWC(y_t, c_out), dy, cfg["act"], cfg.get("slope", 0.0))
         dx_t = None
         if ctx.needs_input_grad[0]:
             add = ops.NHWC(dpass_t.contiguous(), cfg["c_in"]) if dpass_t is not None else None
@@ -545,8 +552,8 @@ def claim_relu_mask(out_t: torch.Tensor) -> bool:
     if isinstance(fn, BatchNormActFn._backward_cls):
         if not fn.has_res or fn.cfg[1] != ops.ACT_RELU:
             return False
-    elif isinstance(fn, ConvFn._backward_cls):          # conv + bias + ReLU in one kernel (VGG-19: losses.Vgg19)
-        if fn.cfg["act"] != ops.ACT_RELU:
+    elif isinstance(fn, (ConvFn._backward_cls, ConvPassFn._backward_cls)):   # conv + bias + ReLU in one kernel (VGG-19: losses.Vgg19)
+        if fn.cfg.get("act", ops.ACT_NONE) != ops.ACT_RELU:
             return False
     else:
         return False

@@ -87,9 +87,18 @@ class Conv2dBlock(nn.Module):
                                   bias=self.use_bias if norm != "batch" else False)
         self._cache = _PackCache()
 
-    def forward_nhwc(self, x: ops.NHWC, residual=None) -> ops.NHWC:
+    def forward_nhwc(self, x: ops.NHWC, residual=None, passthrough=False) -> ops.NHWC:
+        """``passthrough`` (training, plain conv + BatchNorm blocks only): also return x as an output of this conv's autograd
+        node, for the next consumer of the same tensor (norms.conv_bn_forward / autograd.ConvPassFn)."""
         if self.pad_type == "replicate":
             raise NotImplementedError("Conv2dBlock: replicate padding has no HIP path")
+        if passthrough:
+            if (isinstance(self.conv, SpectralNorm) or not isinstance(self.norm, nn.BatchNorm2d) or residual is not None
+                    or not self.norm.training):
+                raise NotImplementedError("Conv2dBlock: passthrough is for a plain conv + training-mode BatchNorm block")
+            pad_mode = ops.PAD_REFLECT if (self.pad_type == "reflect" and self.padding > 0) else ops.PAD_ZERO
+            return conv_bn_forward(self.conv, self.norm, self._cache, x, pad_mode=pad_mode, pad=self.padding,
+                                   act=_ACTS[self.activation_name], slope=0.2, passthrough=True)
         pad_mode = ops.PAD_REFLECT if (self.pad_type == "reflect" and self.padding > 0) else ops.PAD_ZERO
         act = _ACTS[self.activation_name]
         sn = isinstance(self.conv, SpectralNorm)

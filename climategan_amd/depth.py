@@ -44,10 +44,19 @@ class DADADepthDecoder(nn.Module):
     def set_target_size(self, size):
         self._target_size = size[:2] if isinstance(size, (list, tuple)) else (size, size)
 
-    def forward_nhwc(self, z):
+    def forward_nhwc(self, z, passthrough=False):
+        """``passthrough`` (the trainer's merged trunk, training mode): a third result, the latent handed through enc4_1's
+        autograd node -- the latent's other readers (segmentation / mask decoders) take THAT tensor, so their gradients
+        reach the encoder through enc4_1's data-gradient kernel (summed in its epilogue, autograd.ConvPassFn) instead of
+        an element-wise sum of 2048-channel maps by the autograd engine."""
         if isinstance(z, (list, tuple)):
             z = z[0]
-        z4 = self.enc4_3.forward_nhwc(self.enc4_2.forward_nhwc(self.enc4_1.forward_nhwc(z)))
+        z_pass = None
+        if passthrough:
+            z1, z_pass = self.enc4_1.forward_nhwc(z, passthrough=True)
+        else:
+            z1 = self.enc4_1.forward_nhwc(z)
+        z4 = self.enc4_3.forward_nhwc(self.enc4_2.forward_nhwc(z1))
         z_depth = self.dec4.forward_nhwc(z4) if self.do_feat_fusion else None
         if self.upsample is None:
             raise NotImplementedError("DADADepthDecoder: upsample_featuremaps=False (channel mean over 128 maps) "
@@ -63,6 +72,8 @@ class DADADepthDecoder(nn.Module):
                                 "the same way after set_target_size)" % (ts,))
             depth = Fn.resize_bicubic(depth, (384, 384))           # MiDaS inference size, depth.py:144-149
             depth = Fn.resize_nearest(depth, (ts, ts))             # depth.py:151-153 (both with their HIP adjoints)
+        if passthrough:
+            return depth, z_depth, z_pass
         return depth, z_depth
 
     def forward(self, z):

@@ -125,6 +125,7 @@ class FeatMatchLoss(nn.Module):
         return total
 
 
+_VGG_TAP_PASS = __import__("os").environ.get("CGAN_VGG_TAP_PASS", "1") != "0"   # same-box A/B: the taps' gradients summed by the engine
 _VGG_MASK = __import__("os").environ.get("CGAN_FUSE_VGG_MASK", "1") != "0"     # same-box A/B of the VGG chain's part of norms.FUSE_RELU_MASK
 
 
@@ -169,10 +170,15 @@ class Vgg19(nn.Module):
             j = 0
             while j < len(mods):
                 name, mod = mods[j]
+                fusable = _norms.FUSE_RELU_MASK and _VGG_MASK and torch.is_grad_enabled() and y.t.requires_grad
+                # a tapped map (relu1_1 ... relu4_1: read by the loss AND by this conv) is handed THROUGH this conv's node
+                # (autograd.ConvPassFn): the loss reads the second output, its gradient comes back through this node and is
+                # summed in the data-gradient kernel's epilogue -- no element-wise sum by the autograd engine, and the tap's
+                # ReLU derivative can move into this layer's backward like everywhere else in the chain
+                hand_through = fusable and _VGG_TAP_PASS and tapped and k > 0 and isinstance(mod, nn.Conv2d)
                 # y = relu(conv(.)) read by THIS layer only: the ReLU's derivative moves into this layer's backward
                 # (autograd.claim_relu_mask; norms.FUSE_RELU_MASK = False: the separate pass)
-                claim = ((not tapped) and _norms.FUSE_RELU_MASK and _VGG_MASK and torch.is_grad_enabled() and y.t.requires_grad
-                         and ag.claim_relu_mask(y.t))
+                claim = ((hand_through or not tapped) and fusable and ag.claim_relu_mask(y.t))
                 tapped = False
                 if isinstance(mod, nn.Conv2d):                      # conv + the ReLU that follows it, fused
                     cache = self._caches.setdefault(name, _PackCache())
@@ -189,7 +195,12 @@ class Vgg19(nn.Module):
                     pw = cache.get((weight, mod.bias), y.t.dtype,
                                    lambda weight=weight, mod=mod: ops.pack_conv_weight(weight.data, mod.bias.data,
                                                                                        y.t.dtype))
-                    if torch.is_grad_enabled() and (y.t.requires_grad or mod.weight.requires_grad):
+                    if hand_through:
+                        cfg = dict(c_in=y.c, stride=1, pad=1, dilation=1, act=ops.ACT_RELU, slope=0.0, mask_input=claim)
+                        y_t, pass_t = ag.ConvPassFn.apply(y.t, weight, mod.bias, pw, cfg)
+                        outs[-1] = ops.NHWC(pass_t, y.c)         # the loss reads the tap through this node
+                        y = ops.NHWC(y_t, mod.out_channels)
+                    elif torch.is_grad_enabled() and (y.t.requires_grad or mod.weight.requires_grad):
                         cfg = dict(c_in=y.c, stride=1, pad=1, dilation=1, act=ops.ACT_RELU, slope=0.0, mask_input=claim)
                         y = ops.NHWC(ConvFn.apply(y.t, weight, mod.bias, None, pw, cfg, None), mod.out_channels)
                     else:

@@ -22,6 +22,8 @@ from . import ops
 from .generator import create_generator
 from .utils import find_target_size
 
+_Z_PASS = os.environ.get("CGAN_Z_PASS", "1") != "0"     # same-box A/B: the latent's fan-in summed by the autograd engine
+
 
 class Timer:
     """reference utils.py:899-960: context manager appending elapsed seconds to ``store`` (device-synchronised)."""
@@ -452,7 +454,12 @@ class Trainer:
             z = self.G.encode(x)
             d_pred = z_depth = s_pred = None
             if "d" in self.opts.tasks:
-                d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
+                if _Z_PASS and torch.is_grad_enabled() and z[0].t.requires_grad and self.G.decoders["d"].enc4_1.norm.training:
+                    # the latent's other readers take it from the depth decoder's first conv node (depth.py forward_nhwc)
+                    d_pred, z_depth, z_pass = self.G.decoders["d"].forward_nhwc(z, passthrough=True)
+                    z = (z_pass,) + tuple(z[1:])
+                else:
+                    d_pred, z_depth = self.G.decoders["d"].forward_nhwc(z)
             if want_s and "s" in self.opts.tasks:
                 s_pred = self.G.decoders["s"].forward_nhwc(z, z_depth)
 

@@ -95,19 +95,53 @@ def test_relu_derivatives_in_the_consumers_backward_are_bitwise_the_separate_pas
     """norms.FUSE_RELU_MASK in the VGG chain: the derivative of a conv's fused ReLU is taken by the ONE layer that reads its
     output -- the next conv's data-gradient epilogue or the max-pool's backward (cgan_maxpool2x2_relu_bwd_nhwc) -- instead of
     by an activation-backward pass; the five taps (read by the loss as well) keep theirs.  Same gradient, bit for bit."""
-    from climategan_amd import norms
+    from climategan_amd import losses, norms
 
     _run(dt)     # (settles the stream's split-K workspace binding: a first call after other tests may run a small conv on another kernel)
     res = {}
-    for fuse in (True, False):
-        norms.FUSE_RELU_MASK = fuse
-        try:
-            res[fuse] = _run(dt)
-        finally:
-            norms.FUSE_RELU_MASK = True
+    losses._VGG_TAP_PASS = False      # (the taps' pass-through nodes sum two gradients in fp32 before ONE rounding: next test)
+    try:
+        for fuse in (True, False):
+            norms.FUSE_RELU_MASK = fuse
+            try:
+                res[fuse] = _run(dt)
+            finally:
+                norms.FUSE_RELU_MASK = True
+    finally:
+        losses._VGG_TAP_PASS = True
     assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])     # (the loss scalar's own reduction: atomics, last-bit noise)
     assert torch.equal(res[True][1], res[False][1])
     assert res[True][1].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_tapped_features_handed_through_the_next_conv_node(dt):
+    """losses.Vgg19 with ``_VGG_TAP_PASS``: relu1_1 ... relu4_1 reach the loss through the NEXT conv's autograd node
+    (autograd.ConvPassFn with the fused ReLU), so the loss term's gradient is summed with that conv's data gradient in the
+    kernel's epilogue (fp32, one rounding) and the tap's ReLU derivative rides there too -- instead of an element-wise sum by
+    the autograd engine (two 16-bit roundings) and an activation-backward pass.  Same loss; the gradient within a few 16-bit roundings
+    of the engine's form, and no further from the reference's than the engine's form is."""
+    from climategan_amd import losses
+
+    gold = load_golden(NAME)
+    gr = t(gold["dfake"])
+    _run(dt)
+    res = {}
+    for on in (True, False):
+        losses._VGG_TAP_PASS = on
+        try:
+            res[on] = _run(dt)
+        finally:
+            losses._VGG_TAP_PASS = True
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    a, b = res[True][1], res[False][1]
+    assert a.abs().max().item() > 0
+    rel = ((a - b).norm() / b.norm()).item()
+    # (measured 1.0e-3 in fp16: one 2^-11 rounding per tap, carried through up to 12 layers of data gradients)
+    assert rel <= (2e-2 if dt == torch.bfloat16 else 2.5e-3), rel
+    la, lb = ((a - gr).norm() / gr.norm()).item(), ((b - gr).norm() / gr.norm()).item()
+    print("\nvgg taps %s: pass-through vs engine sum rel L2 %.3g; vs reference %.3g (engine form %.3g)" % (dt, rel, la, lb))
+    assert la <= 1.05 * lb + 1e-4, (la, lb)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

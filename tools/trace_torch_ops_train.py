@@ -28,6 +28,8 @@ class Mode(TorchDispatchMode):
         if name not in SKIP:
             st = [f for f in traceback.extract_stack()[:-1] if "climategan_amd" in f.filename]
             site = "%s:%d" % (st[-1].filename.split("/")[-1], st[-1].lineno) if st else "autograd engine"
+            if name == "add" and args and isinstance(args[0], torch.Tensor) and args[0].dim() == 4:   # the engine's fan-in sums
+                site = "%s fan-in %s %s" % (site, tuple(args[0].shape), str(args[0].dtype).replace("torch.", ""))
             if site == "autograd engine" and args and isinstance(args[0], torch.Tensor):
                 site = "autograd engine %s %s" % (tuple(args[0].shape), str(args[0].dtype).replace("torch.", ""))
             counts[(func.__name__, site)] += 1
@@ -46,4 +48,4 @@ with torch.autograd.set_multithreading_enabled(False), Mode():
 torch.cuda.synchronize()
 print("torch-side ops of one joint train step:", sum(counts.values()))
 for (name, site), n in counts.most_common(90):
-    print("%5d  %-32s %-28s %9.3f MB" % (n, name, site, nbytes[(name, site)] / 1e6))
+    print("%5d  %-32s %-60s %9.3f MB" % (n, name, site, nbytes[(name, site)] / 1e6))
