@@ -236,6 +236,8 @@ class ConvPassFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_t, weight, bias, packed, cfg):
         x = ops.NHWC(x_t, cfg["c_in"])
+        if cfg.get("want_stats") and cfg.get("act", ops.ACT_NONE) != ops.ACT_NONE:
+            raise NotImplementedError("ConvPassFn: the statistics epilogue belongs to a conv without an activation")
         if cfg.get("want_stats"):
             y, cfg["stats_out"] = ops.conv2d_with_stats(x, packed, stride=cfg["stride"], pad=cfg["pad"],
                                                         dilation=cfg["dilation"], pad_mode=cfg.get("pad_mode", ops.PAD_ZERO),
@@ -244,8 +246,6 @@ class ConvPassFn(torch.autograd.Function):
             y = ops.conv2d(x, packed, stride=cfg["stride"], pad=cfg["pad"], dilation=cfg["dilation"],
                            act=cfg.get("act", ops.ACT_NONE), slope=cfg.get("slope", 0.0),
                            pad_mode=cfg.get("pad_mode", ops.PAD_ZERO))
-        if cfg.get("want_stats") and cfg.get("act", ops.ACT_NONE) != ops.ACT_NONE:
-            raise NotImplementedError("ConvPassFn: the statistics epilogue belongs to a conv without an activation")
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.premasked = False            # see claim_relu_mask: dy arrives with this conv's ReLU derivative applied
