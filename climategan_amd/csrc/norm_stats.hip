@@ -137,14 +137,9 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
   if (idx0 >= (grouped_bn ? cs : n_total * cs)) return;
   const int n_first = grouped_bn ? 0 : idx0 / cs, n_last = grouped_bn ? n_total : n_first + 1;
   const int c = grouped_bn ? idx0 : idx0 - n_first * cs;
-  for (int n = n_first; n < n_last; ++n) {
-  const int idx = n * cs + c;
-  MeanM2 acc = {0.f, 0.f, 0.f};
   // four partial rows in flight per lane (the rows of one lane are cs * 8 bytes apart: every load is its own cache
   // line, so the latency has to be overlapped); merged in the same order as a plain loop
-  for (int k0 = lane; k0 < chunks; k0 += 256) {
-    float2 v[4];
-    int cnt[4];
+  auto load_rows = [&](int n, int k0, float2 (&v)[4], int (&cnt)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + 64 * j;
@@ -155,6 +150,36 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
         cnt[j] = min(hw, p0 + ppb) - p0;
         v[j] = *reinterpret_cast<const float2*>(partial + (((size_t)n * rows_per_group + (size_t)k * row_stride) * cs + c) * 2);
       }
+    }
+  };
+  // The kernel is a chain of memory round trips (per group: the rows, then the epilogue's operands), 292 launches per joint
+  // train step whatever the batch: everything that does not depend on a result is requested up front -- the first rows of
+  // group n + 1 before group n is merged, and the epilogue's per-channel operands (the running statistics travel through
+  // registers from group to group: same arithmetic, same order) before the first row arrives.
+  float2 vn[4];
+  int cn[4];
+  load_rows(n_first, lane, vn, cn);
+  float bn_g = 1.f, bn_b = 0.f, run_m = 0.f, run_v = 0.f;
+  if (bn.mean_out && c < bn.c) {
+    if (bn.gamma) bn_g = bn.gamma[c];
+    if (bn.beta) bn_b = bn.beta[c];
+    if (bn.running_mean) {
+      run_m = bn.running_mean[c];
+      run_v = bn.running_var[c];
+    }
+  }
+  for (int n = n_first; n < n_last; ++n) {
+  const int idx = n * cs + c;
+  MeanM2 acc = {0.f, 0.f, 0.f};
+  for (int k0 = lane; k0 < chunks; k0 += 256) {
+    float2 v[4];
+    int cnt[4];
+    if (k0 == lane) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = vn[j]; cnt[j] = cn[j]; }
+      if (n + 1 < n_last) load_rows(n + 1, lane, vn, cn);
+    } else {
+      load_rows(n, k0, v, cnt);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -187,14 +212,16 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
       if (c == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;     // once per group = per reference forward
       float m = 0.f, r = 0.f;
       if (c < bn.c) {
-        r = rs * (bn.gamma ? bn.gamma[c] : 1.f);
-        m = mu - ((bn.beta && r != 0.f) ? bn.beta[c] / r : 0.f);
+        r = rs * bn_g;
+        m = mu - ((bn.beta && r != 0.f) ? bn_b / r : 0.f);
         if (bn.running_mean) {
           const float count = (float)hw;
           const float var_b = 1.f / (rs * rs) - eps;
           const float var_u = count > 1.f ? var_b * count / (count - 1.f) : var_b;
-          bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * mu;
-          bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * var_u;
+          run_m = (1.f - bn.momentum) * run_m + bn.momentum * mu;
+          run_v = (1.f - bn.momentum) * run_v + bn.momentum * var_u;
+          bn.running_mean[c] = run_m;
+          bn.running_var[c] = run_v;
         }
       }
       bn.mean_out[idx] = m;

@@ -2,6 +2,7 @@
 global batch: torch.profiler with Python stacks; every aten op that launched a device kernel is keyed by (op, enclosing
 autograd node or op, first climategan_amd frame).  usage (GPU box): python tools/trace_small_launches.py [per_domain]"""
 import collections
+import re
 import sys
 from pathlib import Path
 
@@ -23,6 +24,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     T.train_step(batch)
     torch.cuda.synchronize()
 
+def short(n):
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "").replace("at::native::", "")
+    return re.sub(r"\(.*", "", n)[:70]
+
+
+copies = collections.Counter()
 ev = prof.events()
 by_kernel = collections.Counter()
 sites = collections.Counter()
@@ -31,7 +38,6 @@ for e in ev:
     if str(e.device_type).endswith("CPU") and e.kernels:            # a host op that launched device work itself
         if e.cpu_children and any(c.kernels for c in e.cpu_children):
             continue                                                 # count the innermost launching op only
-        names = ",".join(sorted({k.name.split("<")[0].split("(")[0][-40:] for k in e.kernels}))
         if "cgan" in e.name:
             continue
         frame = next((s for s in (e.stack or []) if "climategan_amd" in s or "bench.py" in s), "")
@@ -45,11 +51,16 @@ for e in ev:
         sites[key] += len(e.kernels)
         dur[key] += sum(k.duration for k in e.kernels)
         for k in e.kernels:
-            by_kernel[k.name.split("(")[0][:90]] += 1
+            by_kernel[short(k.name)] += 1
+            if "copyBuffer" in k.name or "Memcpy" in k.name or "FillFunctor<float>" in k.name:
+                copies[(short(k.name)[:40],) + key] += 1
 print("device launches of torch ops in one step at %d per domain: %d" % (bs, sum(sites.values())))
 for k, n in by_kernel.most_common(12):
     print("  %5d  %s" % (n, k))
 print("by site (launches, device us, op, enclosing, frame):")
 for key, n in sites.most_common(45):
     print("  %4d %8.1f  %-28s | %-70s | %s" % (n, dur[key], key[0], key[1], key[2]))
+print("copies and fp32 fills by site:")
+for key, n in copies.most_common(25):
+    print("  %4d  %-40s %-24s | %-60s | %s" % ((n,) + key))
 T.close()
