@@ -203,10 +203,26 @@ def recorded_mfma_util():
 
 
 # ------------------------------------------------------------------------------------------------ timing helpers
-def timed_steps(step, steps, warmup, barrier):
-    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier() on both sides."""
+# Sub-blocks with millisecond steps (Painter forward: 6 ms, apply_events: 34 ms) start after seconds of host-only work (model
+# construction, weight fill) during which the GPU has dropped to its idle clocks; five warm-up steps = 30 ms do not bring them
+# back on every box (one evidence box of round 6 read the Painter block 20 % low and the SAME kernels at their usual time under
+# rocprofv3 minutes later).  Their warm-up therefore also lasts at least SUB_WARM_SECONDS[0] of device time; the headline's
+# W = 5 steps are 2.8 s by themselves.  (--only runs: 0 unless --sub-warm-seconds is given, so profiles keep their launch counts.)
+SUB_WARM_SECONDS = [0.0]
+
+
+def timed_steps(step, steps, warmup, barrier, min_warm_s=0.0):
+    """W untimed warm-up steps (and as many more as ``min_warm_s`` seconds take), then exactly K timed steps bracketed by
+    barrier() on both sides."""
+    t_w = time.perf_counter()
     for _ in range(warmup):
         step()
+    if min_warm_s > 0:
+        torch.cuda.synchronize()
+        while time.perf_counter() - t_w < min_warm_s:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -823,8 +839,7 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
 
     try:
         with torch.no_grad():
-            for _ in range(warmup):
-                step()
+            timed_steps(step, 0, warmup, barrier, SUB_WARM_SECONDS[0])          # warm-up only
             count["i"] = 0
             timer.armed = True
             elapsed = max_over_ranks(timed_steps(step, steps, 0, barrier), dist, device)
@@ -852,7 +867,7 @@ def painter_block(steps, warmup, rank, world, device, dtype, dist, barrier, with
     res = {"workload": "BASELINE configs[1]: Painter-only SPADE generator fwd 640x640 bs=8 (OmniGenerator.paint incl. mask, "
                        "spectral-norm power iterations, paste), %s" % str(dtype).split(".")[1],
            "images_per_s": round(world * BATCH_PER_GPU * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
-           "steps": steps, "warmup": warmup,
+           "steps": steps, "warmup": warmup, "warmup_seconds_min": SUB_WARM_SECONDS[0],
            "roofline": {"bound": "mfma", "kernel": "spade_fused_kernel (23 launches/step: all SPADE layers of the Painter)",
                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
@@ -942,7 +957,7 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
             dt = timed_steps(lambda: out.update(T.infer_all(x, numpy=True, bin_value=0.5, half=False)), steps, warmup, barrier)
             res[name] = {"images_per_s": round(INFER_BS * steps / dt, 2), "ms_per_batch": round(dt / steps * 1e3, 2)}
         return res
-    elapsed = max_over_ranks(timed_steps(step, steps, warmup, barrier), dist, device)
+    elapsed = max_over_ranks(timed_steps(step, steps, warmup, barrier, SUB_WARM_SECONDS[0]), dist, device)
     assert set(out) >= {"flood", "wildfire", "smog"} and out["flood"].shape == (INFER_BS, H, W, 3)
     # the opt-in inference mode of SURVEY 8f N2: spectral-norm weights frozen (no power iteration / re-pack per call)
     T.G.freeze_spectral_norm(True)
@@ -989,7 +1004,7 @@ def infer_block(steps, warmup, rank, world, device, dist, barrier, table_path=""
             "fp32_grade_other_modes": dict(modes, note="hybrid = split-precision Masker (fp32-grade flood mask, tests/test_gpu_configs_640.py::"
                                            "test_hybrid_inference_keeps_the_fp32_grade_mask) + 16-bit Painter (G.set_painter_compute_dtype); pair16 = "
                                            "fp16 pairs, half the multiplies of split24, fp16's range; %d timed batches each" % n32),
-            "steps": steps, "warmup": warmup, "roofline": roof}
+            "steps": steps, "warmup": warmup, "warmup_seconds_min": SUB_WARM_SECONDS[0], "roofline": roof}
 
 
 SUB_BLOCK_TIMEOUT_S = 1200    # watchdog of the sub-blocks (the headline line is complete before they start)
@@ -1008,6 +1023,9 @@ def main():
     ap.add_argument("--mfma-table-steps", type=int, default=2,
                     help="extra single-stream steps after the timed region with EVERY MFMA-kernel launch bracketed (0 = skip)")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each sub-block (0 = skip the sub-blocks)")
+    ap.add_argument("--sub-warm-seconds", type=float, default=-1.0,
+                    help="minimum warm-up time of the millisecond-step blocks (Painter forward, apply_events): default 1 s in "
+                         "the default run, 0 with --only")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-measure roofline.traffic with two rocprofv3 --pmc child passes (report the committed summary)")
     ap.add_argument("--ddp-bucket-mb", type=float, default=0.0, help="N > 1: gradient bucket size of the reducer (default 25)")
@@ -1059,6 +1077,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    SUB_WARM_SECONDS[0] = args.sub_warm_seconds if args.sub_warm_seconds >= 0 else (0.0 if args.only else 1.0)
     if args.only:
         if args.only == "painter":
             r = painter_block(args.steps, args.warmup, rank, world, device, dtype, dist, barrier, False)
