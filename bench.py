@@ -1216,6 +1216,9 @@ def main():
                 "share_of_step": round((ms / sampled) / (elapsed / args.steps * 1e3), 3),
                 "by_class": timer.classes()}
             lps = n // max(sampled, 1)
+            if sampled and n == lps * sampled:      # the family's time in each bracketed step: how far one step's reading is from the next's
+                res["roofline"]["family_ms_per_bracketed_step"] = [
+                    round(sum(p[0].elapsed_time(p[1]) for p in timer.pairs[i * lps:(i + 1) * lps]), 2) for i in range(sampled)]
             # (re-measured live further down, once this process has released the trainer's memory: the two child passes need the
             # same 137 GB; until then the newest committed summary stands in)
             res["roofline"]["traffic"] = recorded_traffic("*_conv_gemm_hbm_pmc.csv")
